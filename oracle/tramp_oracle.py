@@ -1,0 +1,907 @@
+"""CPU oracle for the Tree-AMP message-passing hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a NumPy/SciPy restatement of the
+reference algorithm (sphinxteam/tramp) for the hot path of SURVEY.md section 8.
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it, and only as the checker / the timed CPU baseline.
+The product path (``tramp_amd``) never imports it and has no CPU fallback.
+
+Parity pinning: every function below is checked in ``tests/test_oracle_golden.py``
+against golden vectors captured by importing the reference in the build
+container (``tools/make_golden.py`` -> ``tests/golden/*.npz``), including the
+known-answer values listed in SURVEY.md section 8(c).  The reference's own tests hold
+no fixture files for this path; LinearChannel has no reference test at all, so
+for it the oracle is additionally pinned on the algebraic identity
+``rz = (az I + ax W^T W)^-1 (bz + W^T bx)``.
+
+Third-party arithmetic not vendored in the reference:
+``scipy.special.{erfcx, erf, expit, softmax}``, ``numpy.logaddexp``,
+``numpy.linalg.svd``, ``scipy.integrate.{quad, dblquad}`` (numpy 2.2.6 /
+scipy 1.15.3 in the build image).
+
+All ``file:line`` citations are relative to the reference repository root.
+"""
+import numpy as np
+from scipy.special import erfcx, erf, expit
+from scipy.integrate import quad, dblquad
+
+AMIN = 1e-11   # tramp/base.py:238-239
+AMAX = 1e+11
+
+SQRT2 = np.sqrt(2)
+
+
+# --------------------------------------------------------------------------
+# A1  node protocol arithmetic                      tramp/base.py:44-46,245-255
+# --------------------------------------------------------------------------
+def inv(v):
+    "Safe inverse, floor 1e-20 (tramp/base.py:44-46)."
+    return 1 / np.maximum(v, 1e-20)
+
+
+def a_new(v, a):
+    "tramp/base.py:245-248"
+    return np.clip(inv(v) - a, AMIN, AMAX)
+
+
+def ab_new(r, v, a, b):
+    "tramp/base.py:250-255"
+    an = np.clip(inv(v) - a, AMIN, AMAX)
+    bn = r * (a + an) - b
+    return an, bn
+
+
+# --------------------------------------------------------------------------
+# A2  Gauss-Bernoulli prior      tramp/priors/gauss_bernoulli_prior.py:26-83
+#                                tramp/beliefs/sparse.py:5-27, normal.py:3-4
+# --------------------------------------------------------------------------
+def normal_A(a, b):
+    "tramp/beliefs/normal.py:3-4"
+    return 0.5 * (b**2 / a + np.log(2 * np.pi / a))
+
+
+def gb_params(rho, mean, var):
+    "Natural parameters and eta of the prior (gauss_bernoulli_prior.py:32-36)."
+    a0 = 1 / var
+    b0 = mean / var
+    eta = normal_A(a0, b0) - np.log(rho / (1 - rho))
+    return a0, b0, eta
+
+
+def gb_prior_posterior(ax, bx, rho=0.5, mean=0, var=1, isotropic=True):
+    """(rx, vx) of the Gauss-Bernoulli denoiser.
+
+    gauss_bernoulli_prior.py:70-77 with sparse.p/r/v (beliefs/sparse.py:9-22).
+    """
+    a0, b0, eta = gb_params(rho, mean, var)
+    a = ax + a0
+    b = bx + b0
+    s = expit(normal_A(a, b) - eta)
+    rx = s * (b / a)
+    vx = s / a + s * (1 - s) * (b / a)**2
+    if isotropic:
+        vx = vx.mean()
+    return rx, vx
+
+
+def gb_prior_message(ax, bx, rho=0.5, mean=0, var=1, isotropic=True):
+    "Prior.compute_forward_message (tramp/priors/base_prior.py:13-16)."
+    rx, vx = gb_prior_posterior(ax, bx, rho, mean, var, isotropic)
+    return ab_new(rx, vx, ax, bx)
+
+
+def gb_prior_log_partition(ax, bx, rho=0.5, mean=0, var=1):
+    "gauss_bernoulli_prior.py:79-83 (per-element, before the mean)."
+    a0, b0, eta = gb_params(rho, mean, var)
+    a = ax + a0
+    b = bx + b0
+    return (np.logaddexp(eta, normal_A(a, b))
+            - np.logaddexp(eta, normal_A(a0, b0)))
+
+
+# --------------------------------------------------------------------------
+# A3  MAP L1 prior (soft threshold)   tramp/priors/map_L1_norm_prior.py:11-71
+# --------------------------------------------------------------------------
+def l1_support_mask(bx, gamma):
+    "v_soft_threshold (map_L1_norm_prior.py:16-17): boolean, bit-exact row."
+    return np.abs(bx) > gamma
+
+
+def l1_prior_posterior(ax, bx, gamma=1, isotropic=True):
+    "map_L1_norm_prior.py:66-71"
+    with np.errstate(divide="ignore", invalid="ignore"):
+        shrink = np.maximum(0, 1 - gamma / np.abs(bx)) * bx
+    rx = (1 / ax) * shrink
+    vx = (1 / ax) * l1_support_mask(bx, gamma)
+    if isotropic:
+        vx = vx.mean()
+    return rx, vx
+
+
+def l1_prior_message(ax, bx, gamma=1, isotropic=True):
+    rx, vx = l1_prior_posterior(ax, bx, gamma, isotropic)
+    return ab_new(rx, vx, ax, bx)
+
+
+# --------------------------------------------------------------------------
+# A4 / A5  Gaussian prior and Gaussian likelihood: constant messages
+#   tramp/priors/gaussian_prior.py:63-68,76-79,86-93
+#   tramp/likelihoods/gaussian_likelihood.py:43-49,58-61,68-75
+# --------------------------------------------------------------------------
+def gauss_prior_posterior(ax, bx, mean=0, var=1):
+    a = ax + 1 / var
+    b = bx + mean / var
+    return b / a, 1 / a
+
+
+def gauss_prior_message(ax, bx, mean=0, var=1):
+    "Bypasses ab_new entirely (gaussian_prior.py:86-89)."
+    return (1 / var) * np.ones_like(ax), (mean / var) * np.ones_like(bx)
+
+
+def gauss_prior_error(ax, var=1):
+    return 1 / (ax + 1 / var)
+
+
+def gauss_lik_posterior(az, bz, y, var=1):
+    a = az + 1 / var
+    b = bz + (1 / var) * y
+    return b / a, 1 / a
+
+
+def gauss_lik_message(az, bz, y, var=1):
+    "Constant (1/var, y/var) (gaussian_likelihood.py:68-71, :17)."
+    return 1 / var, y / var
+
+
+def gauss_lik_error(az, tau_z, var=1):
+    return 1 / (az + 1 / var)
+
+
+# --------------------------------------------------------------------------
+# Half-line truncated normal    tramp/utils/truncated_normal.py:21-29,92-94,
+#                               147-149,218-298
+# side=+1 : z in [0, +inf)   side=-1 : z in (-inf, 0]
+# --------------------------------------------------------------------------
+def log_Phi(x):
+    "log Phi(x) with the reference's x<30 mask (truncated_normal.py:21-29)."
+    x = np.asarray(x, dtype=float)
+    y = np.zeros_like(x)
+    m = x < 30
+    xm = x[m]
+    y[m] = np.log(0.5 * erfcx(-xm / SQRT2)) - 0.5 * xm**2
+    return y
+
+
+def halfline_moments(r0, v0, side):
+    """Mean, variance and log-probability of N(r0, v0) restricted to a half line.
+
+    truncated_normal_mean/_var/_log_proba (truncated_normal.py:234-281) through
+    the ``_inf`` branches G0_inf/G1_inf/G2_inf (:218-231), F1_inf/F2_inf
+    (:92-94, :147-149).  For both sides the standardised bound is
+    y0 = (0 - r0)/s0 and the reference evaluates the functions with s = side.
+    """
+    s0 = np.sqrt(v0)
+    y0 = (0 - r0) / s0
+    x = y0 / SQRT2
+    e = erfcx(side * x)
+    g1 = np.sqrt(2 / np.pi) * (side / e)
+    g2 = (2 / np.sqrt(np.pi)) * (side * x / e)
+    mean = r0 + s0 * g1
+    var = v0 * (1. + g2 - g1**2)
+    logp = log_Phi(-side * y0)
+    return mean, var, logp
+
+
+def halfline_logZ(r0, v0, side):
+    "truncated_normal_logZ (truncated_normal.py:294-298)."
+    _, _, g0 = halfline_moments(r0, v0, side)
+    return 0.5 * np.log(2 * np.pi * v0) + 0.5 * r0**2 / v0 + g0
+
+
+def norm_cdf(x):
+    "tramp/utils/misc.py:50-52"
+    return 0.5 * (1 + erf(x / SQRT2))
+
+
+def norm_pdf(x):
+    "tramp/utils/misc.py:55-57"
+    return np.exp(-0.5 * x**2) / np.sqrt(2 * np.pi)
+
+
+def halfline_proba(r0, v0, side):
+    "truncated_normal_proba (truncated_normal.py:284-291)."
+    s0 = np.sqrt(v0)
+    y0 = (0 - r0) / s0
+    if side > 0:
+        return norm_cdf(np.inf) - norm_cdf(y0)
+    return norm_cdf(y0) - norm_cdf(-np.inf)
+
+
+# --------------------------------------------------------------------------
+# A6  Sgn likelihood     tramp/likelihoods/sgn_likelihood.py:23-41
+#                        tramp/beliefs/positive.py:8-26
+# --------------------------------------------------------------------------
+def sgn_lik_posterior(az, bz, y, isotropic=True):
+    b = bz * y
+    m, v, _ = halfline_moments(b / az, 1 / az, +1)
+    rz = y * m
+    vz = v
+    if isotropic:
+        vz = vz.mean()
+    return rz, vz
+
+
+def sgn_lik_message(az, bz, y, isotropic=True):
+    "Likelihood.compute_backward_message (base_likelihood.py:25-28)."
+    rz, vz = sgn_lik_posterior(az, bz, y, isotropic)
+    return ab_new(rz, vz, az, bz)
+
+
+# --------------------------------------------------------------------------
+# A7  Abs likelihood     tramp/likelihoods/abs_likelihood.py:22-40
+#                        tramp/beliefs/binary.py:4-17
+# --------------------------------------------------------------------------
+def abs_lik_posterior(az, bz, y, isotropic=True):
+    t = np.tanh(bz * y)
+    rz = y * t
+    vz = (y**2) * (1 - t**2)
+    if isotropic:
+        vz = vz.mean()
+    return rz, vz
+
+
+def abs_lik_message(az, bz, y, isotropic=True):
+    rz, vz = abs_lik_posterior(az, bz, y, isotropic)
+    return ab_new(rz, vz, az, bz)
+
+
+# --------------------------------------------------------------------------
+# A8  Piecewise-linear channels (Sgn / Abs / Relu)
+#   tramp/channels/activation/piecewise_linear_channel.py:27-53,80-106
+#   tramp/utils/linear_region.py:32-64
+# Region order is [pos, neg] as in the reference constructors.
+# --------------------------------------------------------------------------
+PWL_REGIONS = {
+    # kind: [(side, slope, x0) for pos, (side, slope, x0) for neg]
+    "sgn":  [(+1, 0., +1.), (-1, 0., -1.)],    # piecewise_linear_channel.py:80-84
+    "abs":  [(+1, +1., 0.), (-1, -1., 0.)],    # :87-91
+    "relu": [(+1, 1., 0.), (-1, 0., 0.)],      # :102-106
+}
+
+
+def pwl_region_terms(side, slope, x0, az, bz, ax, bx):
+    "Per-region (rz, vz, logZ): linear_region.py:32-64."
+    a = az + slope**2 * ax
+    b = bz + slope * (bx - ax * x0)
+    r0 = b / a
+    v0 = 1 / a
+    rz, vz, g0 = halfline_moments(r0, v0, side)
+    logZ = (0.5 * np.log(2 * np.pi * v0) + 0.5 * r0**2 / v0 + g0
+            - 0.5 * ax * x0**2 + bx * x0)
+    return rz, vz, logZ
+
+
+def pwl_channel_posterior(kind, direction, az, bz, ax, bx, isotropic=True):
+    """(r, v) for direction 'fwd' (x side) or 'bwd' (z side).
+
+    merge_estimates (piecewise_linear_channel.py:27-37) with scipy softmax over
+    the two regions; the reference always takes v.mean().
+    """
+    bz = np.asarray(bz, dtype=float)
+    bx = np.asarray(bx, dtype=float)
+    rs, vs, As = [], [], []
+    for side, slope, x0 in PWL_REGIONS[kind]:
+        rz, vz, A = pwl_region_terms(side, slope, x0, az, bz, ax, bx)
+        if direction == "fwd":
+            rs.append(slope * rz + x0)
+            vs.append(slope**2 * vz)
+        else:
+            rs.append(rz)
+            vs.append(vz)
+        As.append(A)
+    A = np.stack(As)
+    e = np.exp(A - A.max(axis=0, keepdims=True))      # scipy.special.softmax
+    ps = e / e.sum(axis=0, keepdims=True)
+    r = ps[0] * rs[0] + ps[1] * rs[1]
+    v = ps[0] * vs[0] + ps[1] * vs[1] + ps[0] * ps[1] * (rs[0] - rs[1])**2
+    if isotropic:
+        v = v.mean()
+    return r, v
+
+
+def pwl_channel_message(kind, direction, az, bz, ax, bx):
+    "Channel.compute_forward/backward_message (channels/base_channel.py:9-17)."
+    r, v = pwl_channel_posterior(kind, direction, az, bz, ax, bx)
+    if direction == "fwd":
+        return ab_new(r, v, ax, bx)
+    return ab_new(r, v, az, bz)
+
+
+def pwl_proba_ab(side, slope, x0, az, bz, ax, bx):
+    "LinearRegion.proba_ab (linear_region.py:78-81)."
+    a = az + slope**2 * ax
+    b = bz + slope * (bx - ax * x0)
+    return halfline_proba(b / a, 1 / a, side)
+
+
+# --------------------------------------------------------------------------
+# A9 / A10  Dense linear channel
+#   tramp/channels/linear/linear_channel.py:8-15,30-46,55-125
+# --------------------------------------------------------------------------
+class LinearOracle:
+    """x = W z with the reference's full-SVD formulation."""
+
+    def __init__(self, W):
+        W = np.asarray(W, dtype=float)
+        self.W = W
+        self.Nx, self.Nz = W.shape
+        self.rank = np.linalg.matrix_rank(W)                     # :37
+        self.alpha = self.Nx / self.Nz                           # :38
+        U, s, VT = np.linalg.svd(W, full_matrices=True)          # :8-15
+        S = np.zeros((U.shape[0], VT.shape[0]))
+        S[:len(s), :len(s)] = np.diag(s)
+        self.U, self.S, self.V = U, S, VT.T
+        spectrum = np.zeros(self.Nz)                             # diag(S^T S), :41
+        spectrum[:len(s)] = s**2
+        self.spectrum = spectrum
+        self.singular = spectrum[:self.rank]                     # :46
+
+    def second_moment(self, tau_z):
+        return tau_z * self.spectrum.sum() / self.Nx             # :55-56
+
+    def n_eff(self, az, ax):
+        ":58-67"
+        if ax == 0:
+            return 0.
+        if az / ax == 0:
+            return self.rank / self.Nz
+        return np.sum(self.singular / (az / ax + self.singular)) / self.Nz
+
+    def backward_mean(self, az, bz, ax, bx):
+        ":69-78 (precompute_svd=True branch)"
+        bx_svd = self.U.T @ bx
+        bz_svd = self.V.T @ bz
+        resolvent = 1 / (az + ax * self.spectrum)
+        if bz.ndim > 1:
+            resolvent = resolvent[:, np.newaxis]
+        return self.V @ (resolvent * (bz_svd + self.S.T @ bx_svd))
+
+    def backward_mean_solve(self, az, bz, ax, bx):
+        ":79-82 (precompute_svd=False branch) - the algebraic identity."
+        A = az * np.identity(self.Nz) + ax * (self.W.T @ self.W)
+        return np.linalg.solve(A, bz + self.W.T @ bx)
+
+    def forward_mean(self, az, bz, ax, bx):
+        ":85-89"
+        return self.W @ self.backward_mean(az, bz, ax, bx)
+
+    def backward_variance(self, az, ax):
+        ":91-97"
+        az = np.maximum(1e-11, az)
+        return (1 - self.n_eff(az, ax)) / az
+
+    def forward_variance(self, az, ax):
+        ":99-105"
+        if ax == 0:
+            return np.mean(self.singular) * self.rank / (self.Nx * az)
+        return self.n_eff(az, ax) / (self.alpha * ax)
+
+    def forward_message(self, az, bz, ax, bx):
+        rx = self.forward_mean(az, bz, ax, bx)
+        vx = self.forward_variance(az, ax)
+        return ab_new(rx, vx, ax, bx)
+
+    def backward_message(self, az, bz, ax, bx):
+        rz = self.backward_mean(az, bz, ax, bx)
+        vz = self.backward_variance(az, ax)
+        return ab_new(rz, vz, az, bz)
+
+
+class LinearThinOracle(LinearOracle):
+    """Same results from the thin factorisation the HIP path stores.
+
+    Only ``V_M`` (first ``M = Nx`` right singular vectors), ``U`` and the
+    singular values enter.  With t = V_M^T bz and u = U^T bx,
+    D = az + ax sigma^2:
+
+      rz = bz/az + V_M [ (1/D - 1/az) t + sigma u / D ]      (Nx <  Nz)
+      rz =         V   [ (t + sigma u) / D ]                  (Nx >= Nz)
+      rx = U [ sigma (t + sigma u) / D ]
+
+    This is what tramp_amd computes; the class exists so that tests can check
+    that the re-association is numerically equivalent to the reference form.
+    """
+
+    def __init__(self, W):
+        super().__init__(W)
+        k = min(self.Nx, self.Nz)
+        self.sigma = np.sqrt(self.spectrum[:k])
+        self.Vk = self.V[:, :k]
+        self.Uk = self.U[:, :k]
+
+    def backward_mean(self, az, bz, ax, bx):
+        t = self.Vk.T @ bz
+        u = self.Uk.T @ bx
+        sg = self.sigma if bz.ndim == 1 else self.sigma[:, None]
+        D = az + ax * sg**2
+        if self.Vk.shape[1] == self.Nz:     # Nx >= Nz: V_k spans everything
+            return self.Vk @ ((t + sg * u) / D)
+        return bz / az + self.Vk @ ((1 / D - 1 / az) * t + sg * u / D)
+
+    def forward_mean(self, az, bz, ax, bx):
+        t = self.Vk.T @ bz
+        u = self.Uk.T @ bx
+        sg = self.sigma if bz.ndim == 1 else self.sigma[:, None]
+        D = az + ax * sg**2
+        return self.Uk @ (sg * (t + sg * u) / D)
+
+
+# --------------------------------------------------------------------------
+# A14  Marchenko-Pastur closed-form linear channel (SE only)
+#   tramp/channels/linear/analytical_linear_channel.py:23-53
+#   tramp/ensembles/marchenko_pastur_ensemble.py:7-45
+# --------------------------------------------------------------------------
+class MarchenkoPasturOracle:
+    def __init__(self, alpha):
+        self.alpha = alpha
+        self.z_max = (1 + np.sqrt(alpha))**2
+        self.z_min = (1 - np.sqrt(alpha))**2
+
+        def dens(z):
+            return z * (np.sqrt((z - self.z_min) * (self.z_max - z)) / (2 * np.pi * z))
+        # measure(lambda z: z): atomic part contributes f(0) = 0
+        self.mean_spectrum = quad(dens, self.z_min, self.z_max)[0]
+
+    def second_moment(self, tau_z):
+        return tau_z * (self.mean_spectrum / self.alpha)
+
+    def eta_transform(self, gamma):
+        F = (np.sqrt(gamma * self.z_max + 1) - np.sqrt(gamma * self.z_min + 1))**2
+        return 1 - F / (4 * gamma)
+
+    def n_eff(self, az, ax):
+        if ax == 0:
+            return 0.
+        if az / ax == 0:
+            return min(1, self.alpha)
+        return 1 - self.eta_transform(ax / az)
+
+    def backward_error(self, az, ax, tau_z=None):
+        az = np.maximum(1e-11, az)
+        return (1 - self.n_eff(az, ax)) / az
+
+    def forward_error(self, az, ax, tau_z=None):
+        if ax == 0:
+            return self.mean_spectrum / (self.alpha * az)
+        return self.n_eff(az, ax) / (self.alpha * ax)
+
+
+# --------------------------------------------------------------------------
+# A11-A13  State-evolution errors (Gaussian quadrature of posterior variances)
+#   tramp/utils/integration.py:13-73
+# method="quadpack": the reference's adaptive QUADPACK calls (slow, faithful)
+# method="gl": fixed Gauss-Legendre panels on [-10,10] (fast; what the HIP
+#              kernels implement); agrees with quadpack to ~1e-9.
+# --------------------------------------------------------------------------
+def _gl_nodes(n_panels=40, order=16, lo=-10., hi=10.):
+    x, w = np.polynomial.legendre.leggauss(order)
+    edges = np.linspace(lo, hi, n_panels + 1)
+    h = 0.5 * (edges[1:] - edges[:-1])
+    c = 0.5 * (edges[1:] + edges[:-1])
+    X = (c[:, None] + h[:, None] * x[None, :]).ravel()
+    Wt = (h[:, None] * w[None, :]).ravel()
+    return X, Wt
+
+
+def gaussian_measure(m, s, f, method="quadpack"):
+    "integration.py:13-28"
+    if method == "quadpack":
+        return quad(lambda x: norm_pdf(x) * f(m + s * x), -10, 10)[0]
+    X, Wt = _gl_nodes()
+    return np.sum(Wt * norm_pdf(X) * f(m + s * X))
+
+
+def gaussian_measure_2d(m1, s1, m2, s2, f, method="quadpack"):
+    "integration.py:31-47"
+    if method == "quadpack":
+        def integrand(x2, x1):
+            return norm_pdf(x1) * norm_pdf(x2) * f(m1 + s1 * x1, m2 + s2 * x2)
+        return dblquad(integrand, -10, 10, -10, 10)[0]
+    X, Wt = _gl_nodes()
+    X1, X2 = np.meshgrid(X, X, indexing="ij")
+    W2 = (Wt * norm_pdf(X))[:, None] * (Wt * norm_pdf(X))[None, :]
+    return np.sum(W2 * f(m1 + s1 * X1, m2 + s2 * X2))
+
+
+def gaussian_measure_2d_full(mean, cov, f, method="quadpack"):
+    "integration.py:50-73 (Cholesky-correlated)."
+    L = np.linalg.cholesky(cov)
+    if method == "quadpack":
+        def integrand(x2, x1):
+            y1, y2 = L @ [x1, x2] + mean
+            return norm_pdf(x1) * norm_pdf(x2) * f(y1, y2)
+        return dblquad(integrand, -10, 10, -10, 10)[0]
+    X, Wt = _gl_nodes()
+    X1, X2 = np.meshgrid(X, X, indexing="ij")
+    W2 = (Wt * norm_pdf(X))[:, None] * (Wt * norm_pdf(X))[None, :]
+    Y1 = L[0, 0] * X1 + L[0, 1] * X2 + mean[0]
+    Y2 = L[1, 0] * X1 + L[1, 1] * X2 + mean[1]
+    return np.sum(W2 * f(Y1, Y2))
+
+
+def se_gb_prior_error(ax, rho=0.5, mean=0, var=1, method="quadpack"):
+    """Prior.compute_forward_error (priors/base_prior.py:66-69) with
+    GaussBernoulliPrior.beliefs_measure (gauss_bernoulli_prior.py:116-122)."""
+    def v_func(bx):
+        _, v = gb_prior_posterior(ax, np.asarray(bx, dtype=float),
+                                  rho, mean, var, isotropic=False)
+        return v
+    mu0 = gaussian_measure(0, np.sqrt(ax), v_func, method)
+    mu1 = gaussian_measure(ax * mean, np.sqrt(ax + (ax**2) * var), v_func, method)
+    return (1 - rho) * mu0 + rho * mu1
+
+
+def se_sgn_lik_error(az, tau_z, method="quadpack"):
+    """Likelihood.compute_backward_error (base_likelihood.py:78-81) with
+    SgnLikelihood.beliefs_measure (sgn_likelihood.py:79-92)."""
+    mz_hat = az - 1 / tau_z
+    assert mz_hat > 0, "az must be greater than 1/ tau_z"
+    sz_eff = np.sqrt(mz_hat + (mz_hat**2) * tau_z)
+
+    def branch(y):
+        def g(bz):
+            bz = np.asarray(bz, dtype=float)
+            p = halfline_proba((y * bz) / az, 1 / az, +1)
+            _, v, _ = halfline_moments((bz * y) / az, 1 / az, +1)
+            return p * v
+        return g
+    return (gaussian_measure(0, sz_eff, branch(+1), method)
+            + gaussian_measure(0, sz_eff, branch(-1), method))
+
+
+def se_abs_lik_error(az, tau_z, method="quadpack"):
+    "AbsLikelihood.beliefs_measure (abs_likelihood.py:60-69)."
+    mz_hat = az - 1 / tau_z
+    assert mz_hat > 0, "az must be greater than 1/tau_z"
+
+    def integrand(z, xi_b):
+        bz = mz_hat * z + np.sqrt(mz_hat) * xi_b
+        y = np.abs(z)
+        return (y**2) * (1 - np.tanh(bz * y)**2)
+    return gaussian_measure_2d(0, np.sqrt(tau_z), 0, 1, integrand, method)
+
+
+def se_pwl_channel_error(kind, direction, az, ax, tau_z, method="quadpack"):
+    """Channel.compute_forward/backward_error (channels/base_channel.py:29-41)
+    with PiecewiseLinearChannel.beliefs_measure (piecewise_linear_channel.py:60-64)
+    and LinearRegion.beliefs_measure (linear_region.py:83-101)."""
+    def variance(bz, bx):
+        _, v = pwl_channel_posterior(kind, direction, az, bz, ax, bx,
+                                     isotropic=False)
+        return v
+    u_eff = np.maximum(0, az * tau_z - 1)
+    total = 0.
+    for side, slope, x0 in PWL_REGIONS[kind]:
+        mean_x = ax * x0
+
+        def integrand(bz, bx, side=side, slope=slope, x0=x0):
+            return pwl_proba_ab(side, slope, x0, az, bz, ax, bx) * variance(bz, bx)
+        sx2 = ax * (slope**2 * ax * tau_z + 1)
+        if ax == 0 or u_eff == 0 or slope == 0:
+            total += gaussian_measure_2d(0, np.sqrt(az * u_eff), mean_x,
+                                         np.sqrt(sx2), integrand, method)
+        else:
+            cov = np.array([[az * u_eff, slope * ax * u_eff],
+                            [slope * ax * u_eff, sx2]])
+            total += gaussian_measure_2d_full(np.array([0, mean_x]), cov,
+                                              integrand, method)
+    return total
+
+
+def pwl_second_moment(kind, tau_z):
+    "PiecewiseLinearChannel.second_moment (piecewise_linear_channel.py:21-25)."
+    tot = 0.
+    for side, slope, x0 in PWL_REGIONS[kind]:
+        rz, vz, _ = halfline_moments(np.float64(0), np.float64(tau_z), side)
+        rx = slope * rz + x0
+        vx = slope**2 * vz
+        p = halfline_proba(np.float64(0), np.float64(tau_z), side)
+        tot += p * (rx**2 + vx)
+    return tot
+
+
+# --------------------------------------------------------------------------
+# Row H  caller harness: chain-model EP / SE sweeps
+#   tramp/algos/message_passing.py:108-127,187-269,330-357
+#   tramp/base.py:152-170,329-413; tramp/variables/sub_variables.py:21-43
+#   tramp/algos/callbacks.py:195-286; tramp/algos/initial_conditions.py:13-24
+# --------------------------------------------------------------------------
+class OracleFactor:
+    """A factor of a chain model: callables working on (a, b) messages."""
+    kind = "channel"       # 'prior' | 'channel' | 'likelihood'
+
+    def forward(self, az, bz, ax, bx):
+        raise NotImplementedError
+
+    def backward(self, az, bz, ax, bx):
+        raise NotImplementedError
+
+
+class GBPriorFactor(OracleFactor):
+    kind = "prior"
+
+    def __init__(self, size, rho=0.5, mean=0, var=1):
+        self.size, self.rho, self.mean, self.var = size, rho, mean, var
+
+    def forward(self, az, bz, ax, bx):
+        return gb_prior_message(ax, bx, self.rho, self.mean, self.var)
+
+    def forward_se(self, az, ax, tau_z, method="quadpack"):
+        v = se_gb_prior_error(ax, self.rho, self.mean, self.var, method)
+        return a_new(v, ax)
+
+    def second_moment(self):
+        return self.rho * (self.mean**2 + self.var)
+
+
+class GaussPriorFactor(OracleFactor):
+    kind = "prior"
+
+    def __init__(self, size, mean=0, var=1):
+        self.size, self.mean, self.var = size, mean, var
+
+    def forward(self, az, bz, ax, bx):
+        return gauss_prior_message(ax, bx, self.mean, self.var)
+
+    def forward_se(self, az, ax, tau_z, method="quadpack"):
+        return 1 / self.var
+
+    def second_moment(self):
+        return self.mean**2 + self.var
+
+
+class LinearFactor(OracleFactor):
+    def __init__(self, W, thin=False):
+        self.lin = (LinearThinOracle if thin else LinearOracle)(W)
+
+    def forward(self, az, bz, ax, bx):
+        return self.lin.forward_message(az, bz, ax, bx)
+
+    def backward(self, az, bz, ax, bx):
+        return self.lin.backward_message(az, bz, ax, bx)
+
+    def forward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(self.lin.forward_variance(az, ax), ax)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(self.lin.backward_variance(az, ax), az)
+
+    def second_moment(self, tau_z):
+        return self.lin.second_moment(tau_z)
+
+
+class MPFactor(OracleFactor):
+    def __init__(self, alpha):
+        self.mp = MarchenkoPasturOracle(alpha)
+
+    def forward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(self.mp.forward_error(az, ax), ax)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(self.mp.backward_error(az, ax), az)
+
+    def second_moment(self, tau_z):
+        return self.mp.second_moment(tau_z)
+
+
+class PWLFactor(OracleFactor):
+    def __init__(self, kind):
+        self.kind_pwl = kind
+
+    def forward(self, az, bz, ax, bx):
+        return pwl_channel_message(self.kind_pwl, "fwd", az, bz, ax, bx)
+
+    def backward(self, az, bz, ax, bx):
+        return pwl_channel_message(self.kind_pwl, "bwd", az, bz, ax, bx)
+
+    def forward_se(self, az, ax, tau_z, method="quadpack"):
+        v = se_pwl_channel_error(self.kind_pwl, "fwd", az, ax, tau_z, method)
+        return a_new(v, ax)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        v = se_pwl_channel_error(self.kind_pwl, "bwd", az, ax, tau_z, method)
+        return a_new(v, az)
+
+    def second_moment(self, tau_z):
+        return pwl_second_moment(self.kind_pwl, tau_z)
+
+
+class GaussLikFactor(OracleFactor):
+    kind = "likelihood"
+
+    def __init__(self, y, var=1):
+        self.y, self.var = y, var
+
+    def backward(self, az, bz, ax, bx):
+        return gauss_lik_message(az, bz, self.y, self.var)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        return 1 / self.var
+
+
+class SgnLikFactor(OracleFactor):
+    kind = "likelihood"
+
+    def __init__(self, y):
+        self.y = y
+
+    def backward(self, az, bz, ax, bx):
+        return sgn_lik_message(az, bz, self.y)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(se_sgn_lik_error(az, tau_z, method), az)
+
+
+class AbsLikFactor(OracleFactor):
+    kind = "likelihood"
+
+    def __init__(self, y):
+        self.y = y
+
+    def backward(self, az, bz, ax, bx):
+        return abs_lik_message(az, bz, self.y)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(se_abs_lik_error(az, tau_z, method), az)
+
+
+def _rms(x):
+    return np.sqrt(np.mean(x**2))       # callbacks.py:246-247
+
+
+def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
+             wait_increase=5, max_increase=0.2, record=None):
+    """Expectation propagation on the chain  f0 - x0 - f1 - x1 - ... - fL.
+
+    factors[0] is a prior, factors[-1] a likelihood, the others channels;
+    variable i sits between factors[i] and factors[i+1]; ``shapes[i]`` is its
+    shape.  Mirrors MessagePassing.iterate (message_passing.py:330-357) for a
+    chain: ConstantInit(a=0, b=0) (initial_conditions.py:13-24); forward sweep
+    in topological order, backward sweep in reverse, SISO variables copy
+    messages through (sub_variables.py:21-33); constant damping only on
+    factor->variable edges, on both a and b (message_passing.py:70-127);
+    variable posterior r = sum b / sum a, v = 1 / sum a (base.py:152-161);
+    EarlyStoppingEP (callbacks.py:250-286).
+
+    ``record(it, fwd, bwd, rs, vs)`` is called after every iteration with the
+    factor->variable messages and posteriors.  Returns dict with the final
+    state and n_iter.
+    """
+    L = len(factors) - 1            # number of variables
+    # fwd[i] = message factor i -> variable i ; bwd[i] = factor i+1 -> variable i
+    fwd = [(0, np.zeros(shapes[i])) for i in range(L)]
+    bwd = [(0, np.zeros(shapes[i])) for i in range(L)]
+    d = damping if damping else 0.
+    old_rs = None
+    n_iter = 0
+    rs = vs = None
+
+    def check(a, b, where):
+        if np.isnan(a):
+            raise ValueError(f"{where} a is nan")    # message_passing.py:187-209
+        if np.isnan(b).any():
+            raise ValueError(f"{where} b is nan")
+
+    def damp(old, new):
+        if not d:
+            return new
+        return (d * old[0] + (1 - d) * new[0], d * old[1] + (1 - d) * new[1])
+
+    for it in range(max_iter):
+        # forward sweep
+        for i in range(L):
+            f = factors[i]
+            if f.kind == "prior":
+                new = f.forward(None, None, bwd[i][0], bwd[i][1])
+            else:
+                new = f.forward(fwd[i - 1][0], fwd[i - 1][1], bwd[i][0], bwd[i][1])
+            check(new[0], new[1], f"f_{i}->x_{i}")
+            fwd[i] = damp(fwd[i], new)
+        # backward sweep
+        for i in reversed(range(L)):
+            f = factors[i + 1]
+            if f.kind == "likelihood":
+                new = f.backward(fwd[i][0], fwd[i][1], None, None)
+            else:
+                new = f.backward(fwd[i][0], fwd[i][1], bwd[i + 1][0], bwd[i + 1][1])
+            check(new[0], new[1], f"f_{i+1}->x_{i}")
+            bwd[i] = damp(bwd[i], new)
+        # variable posteriors
+        rs, vs = [], []
+        for i in range(L):
+            a_hat = fwd[i][0] + bwd[i][0]
+            b_hat = fwd[i][1] + bwd[i][1]
+            rs.append(b_hat / a_hat)
+            vs.append(1. / a_hat)
+        n_iter += 1
+        if record is not None:
+            record(it, fwd, bwd, rs, vs)
+        if it == 0:
+            old_rs = None
+        if old_rs is not None:
+            tols = [_rms(n - o) / _rms(n) for o, n in zip(old_rs, rs)]
+            if max(tols) < tol:
+                break
+            if it > wait_increase and max(tols) > max_increase:
+                break
+        old_rs = rs
+    return dict(fwd=fwd, bwd=bwd, r=rs, v=vs, n_iter=n_iter)
+
+
+def se_chain(factors, max_iter=200, damping=None, tol=1e-6, a0=0.,
+             method="quadpack", record=None):
+    """State evolution on the same chain, messages are scalars ``a``.
+
+    StateEvolution (algos/state_evolution.py:5-27); second moments propagated
+    as Model.init_second_moments (models/base_model.py:111-124); stopping rule
+    EarlyStopping on v (callbacks.py:195-243).
+    """
+    L = len(factors) - 1
+    taus = []
+    for i in range(L):
+        f = factors[i]
+        taus.append(f.second_moment() if f.kind == "prior"
+                    else f.second_moment(taus[i - 1]))
+    fwd = [a0] * L
+    bwd = [a0] * L
+    d = damping if damping else 0.
+    old_vs = None
+    n_iter = 0
+    vs = None
+    for it in range(max_iter):
+        for i in range(L):
+            f = factors[i]
+            if f.kind == "prior":
+                new = f.forward_se(None, bwd[i], None, method)
+            else:
+                new = f.forward_se(fwd[i - 1], bwd[i], taus[i - 1], method)
+            if np.isnan(new):
+                raise ValueError(f"f_{i}->x_{i} a is nan")
+            fwd[i] = d * fwd[i] + (1 - d) * new if d else new
+        for i in reversed(range(L)):
+            f = factors[i + 1]
+            if f.kind == "likelihood":
+                new = f.backward_se(fwd[i], None, taus[i], method)
+            else:
+                new = f.backward_se(fwd[i], bwd[i + 1], taus[i], method)
+            if np.isnan(new):
+                raise ValueError(f"f_{i+1}->x_{i} a is nan")
+            bwd[i] = d * bwd[i] + (1 - d) * new if d else new
+        vs = [1. / (fwd[i] + bwd[i]) for i in range(L)]
+        n_iter += 1
+        if record is not None:
+            record(it, list(fwd), list(bwd), vs)
+        if it == 0:
+            old_vs = None
+        if old_vs is not None:
+            if max(abs(o - n) for o, n in zip(old_vs, vs)) < tol:
+                break
+            if it > 5 and max(n - o for o, n in zip(old_vs, vs)) > 0.2:
+                break
+        old_vs = vs
+    return dict(fwd=fwd, bwd=bwd, v=vs, tau=taus, n_iter=n_iter)
+
+
+# --------------------------------------------------------------------------
+# Synthetic teacher data (legacy RandomState is version-stable)
+#   tramp/ensembles/gaussian_ensemble.py:11-21
+#   tramp/priors/gauss_bernoulli_prior.py:38-42
+# --------------------------------------------------------------------------
+def gaussian_ensemble(rs, M, N):
+    return rs.randn(M, N) / np.sqrt(N)
+
+
+def gb_sample(rs, N, rho, mean=0., var=1.):
+    g = mean + np.sqrt(var) * rs.standard_normal(N)
+    return g * rs.binomial(n=1, size=N, p=rho)

@@ -1,0 +1,62 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN, name + ".npz")
+    with np.load(path, allow_pickle=True) as f:
+        return f["data"].item() if f["data"].shape == () else list(f["data"])
+
+
+@pytest.fixture(scope="session")
+def golden_factors():
+    return load_golden("factors")
+
+
+@pytest.fixture(scope="session")
+def golden_linear():
+    return load_golden("linear")
+
+
+@pytest.fixture(scope="session")
+def golden_ep():
+    return load_golden("ep_traj")
+
+
+@pytest.fixture(scope="session")
+def golden_se():
+    return load_golden("se")
+
+
+def _gpu_available():
+    try:
+        from tramp_amd import _lib
+        return _lib.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    "A device context on GPU 0; GPU tests fail loudly when the HIP library is missing."
+    from tramp_amd import device
+    return device.default_context()
+
+
+def regen_W(seed, M, N):
+    rs = np.random.RandomState(seed)
+    return rs.randn(M, N) / np.sqrt(N)

@@ -1,0 +1,492 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the reference (sphinxteam/tramp).
+
+Runs ONLY in the build container (needs /root/reference); its outputs, small
+``.npz`` files of inputs and expected outputs, are committed under
+``tests/golden/``.  Nothing here travels to the GPU box except those data files.
+
+The reference's graph layer needs networkx 1.x; a test-time shim
+below restores the list-returning API before ``tramp`` is imported.
+
+    python tools/make_golden.py [--skip-slow]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+REF = os.environ.get("TRAMP_REFERENCE", "/root/reference")
+
+
+def install_networkx1_shim():
+    import networkx as nx
+
+    class DiGraph1(nx.DiGraph):
+        @property
+        def node(self):
+            return self._node
+
+        def predecessors(self, n):
+            return list(super().predecessors(n))
+
+        def successors(self, n):
+            return list(super().successors(n))
+
+        def in_edges(self, *a, **k):
+            return list(super().in_edges(*a, **k))
+
+        def edges(self, *a, **k):
+            return list(super().edges(*a, **k))
+
+        def nodes(self, *a, **k):
+            return list(super().nodes(*a, **k))
+
+    _topo = nx.topological_sort
+    nx.DiGraph = DiGraph1
+    nx.topological_sort = lambda g: list(_topo(g))
+
+
+install_networkx1_shim()
+sys.path.insert(0, REF)
+
+from tramp.priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior  # noqa: E402
+from tramp.likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood  # noqa: E402
+from tramp.channels import (  # noqa: E402
+    LinearChannel, SgnChannel, AbsChannel, ReluChannel, MarchenkoPasturChannel
+)
+from tramp.variables import SISOVariable as V  # noqa: E402
+from tramp.algos import ExpectationPropagation, StateEvolution, EarlyStoppingEP  # noqa: E402
+from tramp.algos import EarlyStopping, ConstantInit  # noqa: E402
+from tramp.base import Variable  # noqa: E402
+from tramp.utils.truncated_normal import log_Phi  # noqa: E402
+from tramp.priors.map_L1_norm_prior import v_soft_threshold  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ---------------------------------------------------------------- factors
+def message_law(rs, a, x):
+    "Bayes-optimal message b = a x + sqrt(a) xi (checks/check_high_dim.py:11-13)."
+    return a * x + np.sqrt(a) * rs.standard_normal(x.shape)
+
+
+def factor_goldens():
+    rs = np.random.RandomState(20260101)
+    N = 257                       # ragged: not a multiple of 64 / 256
+    out = {}
+
+    # SURVEY section 8c known-answer inputs
+    kat_b = np.array([-3, -.5, 0, .25, 2, 6.])
+    kat_bx = np.array([.5, -1, 2, 0, -.3, 1.5])
+    kat_y = np.array([1, -1, 1, 1, -1, 1.])
+    out["kat_b"], out["kat_bx"], out["kat_y"] = kat_b, kat_bx, kat_y
+
+    # --- Gauss-Bernoulli prior
+    gb_cases = []
+    x = rs.standard_normal(N) * rs.binomial(1, 0.1, N)
+    b_rand = message_law(rs, 1.3, x)
+    b_edge = np.array([0., 1e-300, -1e-300, 50., -50., 700., -700., 1e-8, 3.5, -3.5])
+    for (rho, mean, var, ax, b) in [
+        (0.1, 0., 1., 1.3, kat_b),
+        (0.1, 0., 1., 1.3, b_rand),
+        (0.05, 0., 1., 0., b_rand),           # first iteration: ax = 0
+        (0.05, 0., 1., 0, np.zeros(16)),      # python int 0, b = 0
+        (0.5, 0.3, 2.0, 0.7, b_rand),
+        (0.01, -1.0, 0.25, 25.0, b_rand * 10),
+        (0.1, 0., 1., 1.3, b_edge),
+        (0.3, 0.1, 1.5, 1e-11, b_rand),
+        (0.3, 0.1, 1.5, 1e+11, b_rand * 1e11),
+    ]:
+        p = GaussBernoulliPrior(size=b.shape[0], rho=rho, mean=mean, var=var)
+        r, v = p.compute_forward_posterior(ax, b)
+        an, bn = p.compute_forward_message(ax, b)
+        pd_ = GaussBernoulliPrior(size=b.shape[0], rho=rho, mean=mean, var=var,
+                                  isotropic=False)
+        rd, vd = pd_.compute_forward_posterior(ax, b)
+        gb_cases.append(dict(rho=rho, mean=mean, var=var, ax=float(ax), b=b, r=r,
+                             v=v, a_new=an, b_new=bn, v_diag=vd, eta=p.eta))
+    # diagonal beliefs with array ax (reference tests/test_priors.py:17-24)
+    axd = np.linspace(1, 2, 100)
+    bxd = np.linspace(-2, 2, 100)
+    pd_ = GaussBernoulliPrior(size=100, rho=0.5, isotropic=False)
+    rd, vd = pd_.compute_forward_posterior(axd, bxd)
+    and_, bnd = pd_.compute_forward_message(axd, bxd)
+    out["gb_diag"] = dict(ax=axd, bx=bxd, r=rd, v=vd, a_new=and_, b_new=bnd)
+    out["gb"] = gb_cases
+
+    # --- MAP L1 prior
+    l1_cases = []
+    gam = 1.0
+    b_l1_edge = np.array([gam, -gam, np.nextafter(gam, 2), np.nextafter(gam, 0),
+                          -np.nextafter(gam, 2), 0., -0., 1e-310, 5., -5., 1e300])
+    for (gamma, ax, b) in [(1.0, 1.3, kat_b), (1.0, 1.3, b_rand), (0.37, 2.5, b_rand),
+                           (1.0, 0.9, b_l1_edge), (2.0, 1e-3, b_rand)]:
+        p = MAP_L1NormPrior(size=b.shape[0], gamma=gamma)
+        with np.errstate(all="ignore"):
+            r, v = p.compute_forward_posterior(ax, b)
+            an, bn = p.compute_forward_message(ax, b)
+        l1_cases.append(dict(gamma=gamma, ax=ax, b=b, r=r, v=v, a_new=an, b_new=bn,
+                             mask=v_soft_threshold(b, gamma)))
+    out["l1"] = l1_cases
+
+    # --- Gaussian prior / likelihood
+    p = GaussianPrior(size=N, mean=0.3, var=2.0)
+    an, bn = p.compute_forward_message(1.3, b_rand)
+    r, v = p.compute_forward_posterior(1.3, b_rand)
+    out["gauss_prior"] = dict(mean=0.3, var=2.0, ax=1.3, b=b_rand, a_new=an, b_new=bn,
+                              r=r, v=v, se_a=p.compute_forward_state_evolution(1.3),
+                              err=p.compute_forward_error(1.3))
+    yv = rs.standard_normal(N)
+    lk = GaussianLikelihood(y=yv, var=0.01)
+    an, bn = lk.compute_backward_message(1.3, b_rand)
+    r, v = lk.compute_backward_posterior(1.3, b_rand, yv)
+    out["gauss_lik"] = dict(var=0.01, az=1.3, b=b_rand, y=yv, a_new=an, b_new=bn,
+                            r=r, v=v, err=lk.compute_backward_error(1.3, 1.0))
+
+    # --- Sgn / Abs likelihoods
+    z = rs.standard_normal(N)
+    bz_rand = message_law(rs, 1.3, z)
+    sgn_cases = []
+    y_sgn = np.sign(z)
+    bz_edge = np.array([0., 40., -40., 1e-9, 5., -5., 12., -12., 100., -100.])
+    y_edge = np.array([1., 1., 1., -1., -1., 1., -1., 1., -1., -1.])
+    for (az, bz, y) in [(1.3, kat_b, kat_y), (1.3, bz_rand, y_sgn), (0.02, bz_rand * 0.1, y_sgn),
+                        (45.0, bz_rand * 30, y_sgn), (1.3, bz_edge, y_edge),
+                        (1e-11, bz_rand * 1e-6, y_sgn)]:
+        lk = SgnLikelihood(y=y)
+        with np.errstate(all="ignore"):
+            r, v = lk.compute_backward_posterior(az, bz, y)
+            an, bn = lk.compute_backward_message(az, bz)
+            _, vd = SgnLikelihood(y=y, isotropic=False).compute_backward_posterior(az, bz, y)
+        sgn_cases.append(dict(az=az, bz=bz, y=y, r=r, v=v, a_new=an, b_new=bn, v_diag=vd))
+    out["sgn_lik"] = sgn_cases
+    abs_cases = []
+    y_abs = np.abs(z)
+    for (az, bz, y) in [(1.3, kat_b, np.abs(kat_y) * np.array([.5, 1, 2, 0, .1, 3.])),
+                        (1.3, bz_rand, y_abs), (30.0, bz_rand * 20, y_abs),
+                        (1.3, bz_edge, np.abs(bz_edge) * .1)]:
+        lk = AbsLikelihood(y=y)
+        r, v = lk.compute_backward_posterior(az, bz, y)
+        an, bn = lk.compute_backward_message(az, bz)
+        _, vd = AbsLikelihood(y=y, isotropic=False).compute_backward_posterior(az, bz, y)
+        abs_cases.append(dict(az=az, bz=bz, y=y, r=r, v=v, a_new=an, b_new=bn, v_diag=vd))
+    out["abs_lik"] = abs_cases
+
+    # --- piecewise-linear channels
+    pwl_cases = []
+    chans = dict(sgn=SgnChannel, abs=AbsChannel, relu=ReluChannel)
+    bx_rand = {}
+    for kind, cls in chans.items():
+        ch = cls()
+        xk = ch.sample(z)
+        bx_rand[kind] = message_law(rs, 0.7, xk)
+    bz_pe = np.array([0., 30., -30., 1e-9, 5., -5., 60., -60., 0.3, -0.3, 45., -45.])
+    bx_pe = np.array([0., 5., 5., -1e-9, -40., 40., 0., 0., 0., 0., 45., 45.])
+    # reference tests/test_channels.py:55-59 records
+    recs = [dict(az=2.1, bz=2.0, ax=2.0, bx=2.0), dict(az=2.0, bz=+1.6, ax=1.5, bx=1.3),
+            dict(az=2.0, bz=-1.6, ax=1.5, bx=1.3)]
+    rec_bz = np.array([r_["bz"] for r_ in recs])
+    rec_bx = np.array([r_["bx"] for r_ in recs])
+    for kind, cls in chans.items():
+        ch = cls()
+        for (az, bz, ax, bx) in [
+            (1.3, kat_b, 0.7, kat_bx),
+            (1.3, bz_rand, 0.7, bx_rand[kind]),
+            (1.3, bz_rand, 0., np.zeros(N)),              # first iteration: ax=0, bx=0
+            (1.3, bz_rand, 0, np.zeros(N)),
+            (0.05, bz_rand * .05, 12.0, bx_rand[kind] * 15),
+            (2.0, bz_pe, 1.5, bx_pe),
+            (2.0, rec_bz, 1.5, rec_bx),
+            (1e-11, bz_rand * 1e-8, 3.0, bx_rand[kind] * 3),
+            (25., bz_rand * 20, 1e-11, bx_rand[kind] * 1e-9),
+        ]:
+            with np.errstate(all="ignore"):
+                rf, vf = ch.compute_forward_posterior(az, bz, ax, bx)
+                af, bf = ch.compute_forward_message(az, bz, ax, bx)
+                rb, vb = ch.compute_backward_posterior(az, bz, ax, bx)
+                ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+            pwl_cases.append(dict(kind=kind, az=float(az), bz=bz, ax=float(ax), bx=bx,
+                                  r_fwd=rf, v_fwd=vf, a_fwd=af, b_fwd=bf,
+                                  r_bwd=rb, v_bwd=vb, a_bwd=ab, b_bwd=bb))
+    out["pwl"] = pwl_cases
+
+    # --- log_Phi mask
+    xs = np.array([-1e3, -40., -5., -1., 0., 1., 5., 10., 29.9, np.nextafter(30, 0), 30.,
+                   np.nextafter(30, 31), 31., 100., 1e4])
+    out["log_Phi"] = dict(x=xs, y=log_Phi(xs), mask=(xs < 30))
+    save("factors", data=np.array(out, dtype=object))
+
+
+# ---------------------------------------------------------------- linear
+def linear_goldens():
+    out = []
+    for (M, N, seed) in [(12, 24, 1), (32, 64, 2), (40, 40, 3), (48, 32, 4), (100, 200, 5)]:
+        rs = np.random.RandomState(seed)
+        W = rs.randn(M, N) / np.sqrt(N)
+        ch = LinearChannel(W)
+        bz = rs.standard_normal(N) * 2
+        bx = rs.standard_normal(M) * 3
+        bzK = rs.standard_normal((N, 3))
+        bxK = rs.standard_normal((M, 3))
+        cases = []
+        for (az, ax) in [(1.3, 0.7), (2.0, 0.), (2.0, 0), (1e-11, 5.0), (1e11, 1e-11),
+                         (100.0, 100.0), (0.37, 1e4)]:
+            rz = ch.compute_backward_mean(az, bz, ax, bx)
+            rx = ch.compute_forward_mean(az, bz, ax, bx)
+            rzK = ch.compute_backward_mean(az, bzK, ax, bxK)
+            vz = ch.compute_backward_variance(az, ax)
+            vx = ch.compute_forward_variance(az, ax)
+            af, bf = ch.compute_forward_message(az, bz, ax, bx)
+            ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+            cases.append(dict(az=float(az), ax=float(ax), rz=rz, rx=rx, rzK=rzK, vz=vz, vx=vx,
+                              a_fwd=af, b_fwd=bf, a_bwd=ab, b_bwd=bb,
+                              n_eff=ch.compute_n_eff(az, ax)))
+        # az = 0 only enters the variance path (linear_channel.py:92-94)
+        vz0 = ch.compute_backward_variance(0., 0.7)
+        out.append(dict(M=M, N=N, seed=seed, W_sum=W.sum(), W_abs_sum=np.abs(W).sum(),
+                        bz=bz, bx=bx, bzK=bzK, bxK=bxK, cases=cases, vz_az0=vz0,
+                        rank=ch.rank, spectrum=ch.spectrum,
+                        second_moment=ch.second_moment(1.7)))
+    # rank-deficient W (rank < min(M, N)): singular = spectrum[:rank]
+    rs = np.random.RandomState(6)
+    W = rs.randn(20, 6) @ rs.randn(6, 30) / 30
+    ch = LinearChannel(W)
+    bz = rs.standard_normal(30)
+    bx = rs.standard_normal(20)
+    out.append(dict(M=20, N=30, seed=6, lowrank=6, W=W, bz=bz, bx=bx, rank=ch.rank,
+                    spectrum=ch.spectrum,
+                    cases=[dict(az=1.3, ax=0.7, rz=ch.compute_backward_mean(1.3, bz, 0.7, bx),
+                                rx=ch.compute_forward_mean(1.3, bz, 0.7, bx),
+                                vz=ch.compute_backward_variance(1.3, 0.7),
+                                vx=ch.compute_forward_variance(1.3, 0.7),
+                                n_eff=ch.compute_n_eff(1.3, 0.7))]))
+    save("linear", data=np.array(out, dtype=object))
+
+
+# ---------------------------------------------------------------- EP trajectories
+class Recorder:
+    "Callback capturing every edge's (a, b) and every variable's (r, v)."
+
+    def __init__(self, stopper):
+        self.stopper = stopper
+        self.iters = []
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.iters = []
+        rec = {}
+        for source, target, data in algo.message_dag.edges(data=True):
+            if isinstance(target, Variable):          # factor -> variable edges
+                key = f"{data['direction']}:{target.id}"
+                rec[key + ":a"] = float(data["a"])
+                if "b" in data:
+                    rec[key + ":b"] = np.array(data["b"], dtype=float)
+        for vid, d in algo.get_variables_data().items():
+            if "r" in d:
+                rec[f"r:{vid}"] = np.array(d["r"], dtype=float)
+            rec[f"v:{vid}"] = float(d["v"])
+        self.iters.append(rec)
+        return self.stopper(algo, i, max_iter)
+
+
+def pack_traj(iters):
+    keys = iters[0].keys()
+    return {k: np.stack([np.asarray(it[k]) for it in iters]) for k in keys}
+
+
+def teacher_glm(seed, N, alpha, rho, output, noise_var):
+    rs = np.random.RandomState(seed)
+    M = int(alpha * N)
+    W = rs.randn(M, N) / np.sqrt(N)
+    x = rs.standard_normal(N) * rs.binomial(n=1, size=N, p=rho)
+    z = W @ x
+    if output == "gaussian":
+        y = z + np.sqrt(noise_var) * rs.standard_normal(M)
+    elif output == "sgn":
+        y = np.sign(z)
+    elif output == "abs":
+        y = np.abs(z)
+    return W, x, y
+
+
+def ep_goldens():
+    trajs = []
+    for output, alpha in [("gaussian", 0.5), ("sgn", 0.7), ("abs", 1.5)]:
+        for N in (64, 256):
+            for seed in (1, 2, 3):
+                for damping in (None, 0.1):
+                    if damping and seed != 1:
+                        continue
+                    rho, nv = (0.05, 1e-2) if output == "gaussian" else (0.25, None)
+                    if N == 64:
+                        rho = 0.25
+                    W, x, y = teacher_glm(seed, N, alpha, rho, output, nv)
+                    prior = GaussBernoulliPrior(size=N, rho=rho)
+                    lin = LinearChannel(W)
+                    if output == "gaussian":
+                        lik = GaussianLikelihood(y=y, var=nv)
+                    elif output == "sgn":
+                        lik = SgnLikelihood(y=y)
+                    else:
+                        lik = AbsLikelihood(y=y)
+                    model = (prior @ V(id="x") @ lin @ V(id="z") @ lik).to_model()
+                    ep = ExpectationPropagation(model)
+                    rec = Recorder(EarlyStoppingEP())
+                    err = None
+                    try:
+                        with np.errstate(all="ignore"):
+                            ep.iterate(max_iter=30, callback=rec, damping=damping)
+                    except Exception as e:    # noqa: BLE001
+                        err = repr(e)
+                    t = pack_traj(rec.iters[:12])
+                    trajs.append(dict(kind="glm", output=output, N=N, alpha=alpha, seed=seed,
+                                      rho=rho, noise_var=nv, damping=damping, y=y, x=x,
+                                      W_sum=W.sum(), n_iter=ep.n_iter, error=err,
+                                      n_recorded=len(rec.iters), traj=t))
+                    print("glm", output, N, seed, damping, "n_iter", ep.n_iter, err)
+    # two-layer:  Gaussian prior -> Linear(W1) -> Relu -> Linear(W2) -> Gaussian likelihood
+    for N in (64, 200):
+        for seed in (1, 2):
+            rs = np.random.RandomState(seed)
+            M1, M2 = N // 2 * 2, N // 2
+            if N == 64:
+                M1 = 128       # expanding first layer, as the reference's alpha=2 example
+            W1 = rs.randn(M1, N) / np.sqrt(N)
+            W2 = rs.randn(M2, M1) / np.sqrt(M1)
+            x = rs.standard_normal(N)
+            h = np.maximum(0, W1 @ x)
+            nv = 1e-2
+            y = W2 @ h + np.sqrt(nv) * rs.standard_normal(M2)
+            model = (GaussianPrior(size=N) @ V(id="x") @ LinearChannel(W1) @ V(id="z1")
+                     @ ReluChannel() @ V(id="a1") @ LinearChannel(W2) @ V(id="z2")
+                     @ GaussianLikelihood(y=y, var=nv)).to_model()
+            ep = ExpectationPropagation(model)
+            rec = Recorder(EarlyStoppingEP())
+            err = None
+            try:
+                with np.errstate(all="ignore"):
+                    ep.iterate(max_iter=30, callback=rec, damping=None)
+            except Exception as e:    # noqa: BLE001
+                err = repr(e)
+            t = pack_traj(rec.iters[:12])
+            trajs.append(dict(kind="two_layer", N=N, M1=M1, M2=M2, seed=seed, noise_var=nv,
+                              y=y, x=x, W1_sum=W1.sum(), W2_sum=W2.sum(), n_iter=ep.n_iter,
+                              error=err, n_recorded=len(rec.iters), traj=t))
+            print("two_layer", N, seed, "n_iter", ep.n_iter, err)
+    save("ep_traj", data=np.array(trajs, dtype=object))
+
+
+# ---------------------------------------------------------------- SE
+def se_goldens(skip_slow):
+    out = {}
+    # 1-D quadrature rows (fast)
+    gb = []
+    for rho in (0.05, 0.1, 0.5):
+        for (mean, var) in ((0., 1.), (0.3, 2.0)):
+            p = GaussBernoulliPrior(size=None, rho=rho, mean=mean, var=var)
+            for ax in (1e-3, 0.05, 0.5, 1.3, 10., 200.):
+                gb.append(dict(rho=rho, mean=mean, var=var, ax=ax,
+                               v=p.compute_forward_error(ax),
+                               a_new=p.compute_forward_state_evolution(ax)))
+    out["gb_prior"] = gb
+    sg = []
+    lk = SgnLikelihood(y=None)
+    for (az, tau_z) in ((1.3, 1.0), (1.01, 1.0), (3.0, 0.5), (25., 2.0), (0.6, 2.0)):
+        sg.append(dict(az=az, tau_z=tau_z, v=lk.compute_backward_error(az, tau_z),
+                       a_new=lk.compute_backward_state_evolution(az, tau_z)))
+    out["sgn_lik"] = sg
+    mp = []
+    for alpha in (0.5, 0.7, 2.0):
+        ch = MarchenkoPasturChannel(alpha=alpha)
+        for (az, ax) in ((1.3, 0.7), (2.0, 0.), (1e-11, 5.0), (0., 5.0), (100., 100.), (0.3, 40.)):
+            mp.append(dict(alpha=alpha, az=az, ax=ax,
+                           vz=ch.compute_backward_error(az, ax, 1.0),
+                           vx=ch.compute_forward_error(az, ax, 1.0),
+                           tau_x=ch.second_moment(1.7),
+                           mean_spectrum=ch.ensemble.mean_spectrum))
+    out["mp"] = mp
+    # SE trajectory: sparse GLM (GB prior + MP + Gaussian likelihood); fast
+    traj = []
+    for (alpha, rho, nv) in ((0.5, 0.05, 1e-2), (0.5, 0.25, 1e-2), (0.3, 0.25, 1e-8)):
+        model = (GaussBernoulliPrior(size=None, rho=rho) @ V(id="x")
+                 @ MarchenkoPasturChannel(alpha=alpha) @ V(id="z")
+                 @ GaussianLikelihood(y=None, var=nv)).to_model()
+        se = StateEvolution(model)
+        rec = Recorder(EarlyStopping())
+        se.iterate(max_iter=200, callback=rec)
+        traj.append(dict(kind="glm_gauss", alpha=alpha, rho=rho, noise_var=nv, a0=0.,
+                         n_iter=se.n_iter, traj=pack_traj(rec.iters)))
+        print("se glm", alpha, rho, nv, se.n_iter)
+    for (alpha, rho) in ((0.7, 0.25), (2.0, 0.5)):
+        model = (GaussBernoulliPrior(size=None, rho=rho) @ V(id="x")
+                 @ MarchenkoPasturChannel(alpha=alpha) @ V(id="z")
+                 @ SgnLikelihood(y=None)).to_model()
+        se = StateEvolution(model)
+        rec = Recorder(EarlyStopping())
+        a0 = 10.
+        se.iterate(max_iter=200, callback=rec, initializer=ConstantInit(a=a0))
+        traj.append(dict(kind="glm_sgn", alpha=alpha, rho=rho, a0=a0,
+                         n_iter=se.n_iter, traj=pack_traj(rec.iters)))
+        print("se sgn", alpha, rho, se.n_iter)
+    out["traj"] = traj
+    if not skip_slow:
+        t0 = time.time()
+        # 2-D quadrature rows (seconds each)
+        ab = []
+        lk = AbsLikelihood(y=None)
+        for (az, tau_z) in ((1.3, 1.0), (3.0, 0.5)):
+            ab.append(dict(az=az, tau_z=tau_z, v=lk.compute_backward_error(az, tau_z)))
+        out["abs_lik"] = ab
+        pw = []
+        chans = dict(sgn=SgnChannel, abs=AbsChannel, relu=ReluChannel)
+        recs = [(2.0, 1.5, 1.0), (2.1, 2.0, 2.0), (2.0, 1.5, 1.5), (1.3, 0., 1.0), (0.8, 2.5, 1.0),
+                (1.0, 0.6, 1.0)]
+        for kind, cls in chans.items():
+            ch = cls()
+            for (az, ax, tau_z) in recs:
+                with np.errstate(all="ignore"):
+                    vf = ch.compute_forward_error(az, ax, tau_z)
+                    vb = ch.compute_backward_error(az, ax, tau_z)
+                pw.append(dict(kind=kind, az=az, ax=ax, tau_z=tau_z, v_fwd=vf, v_bwd=vb,
+                               tau_x=ch.second_moment(tau_z)))
+                print("se pwl", kind, az, ax, tau_z, vf, vb, f"{time.time()-t0:.0f}s")
+        out["pwl"] = pw
+        # two-layer relu SE, a few iterations (13 s / iteration in the reference)
+        model = (GaussianPrior(size=None) @ V(id="x") @ MarchenkoPasturChannel(alpha=2.0)
+                 @ V(id="z1") @ ReluChannel() @ V(id="a1")
+                 @ MarchenkoPasturChannel(alpha=0.5) @ V(id="z2")
+                 @ GaussianLikelihood(y=None, var=1e-2)).to_model()
+        se = StateEvolution(model)
+        rec = Recorder(EarlyStopping())
+        with np.errstate(all="ignore"):
+            se.iterate(max_iter=6, callback=rec)
+        out["traj_two_layer"] = dict(alpha1=2.0, alpha2=0.5, noise_var=1e-2, a0=0.,
+                                     n_iter=se.n_iter, traj=pack_traj(rec.iters),
+                                     tau=model.get_second_moments())
+        print("se two-layer", se.n_iter, f"{time.time()-t0:.0f}s")
+    save("se", data=np.array(out, dtype=object))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-slow", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    only = set(args.only.split(",")) if args.only else None
+    if not only or "factors" in only:
+        factor_goldens()
+    if not only or "linear" in only:
+        linear_goldens()
+    if not only or "ep" in only:
+        ep_goldens()
+    if not only or "se" in only:
+        se_goldens(args.skip_slow)
