@@ -1,0 +1,277 @@
+/* tramp_hip.h - C ABI of the MI355X (gfx950) message-passing hot path of Tree-AMP.
+ *
+ * Drop-in boundary.  The reference, sphinxteam/tramp, is pure
+ * Python: its "plugin interface" for this path is the factor-module protocol
+ * (compute_forward_message / compute_backward_message / compute_*_posterior /
+ * compute_*_error).  Each entry point below replaces the NumPy body of one such
+ * method; the reference file:line it stands for is cited on every declaration
+ * (paths relative to the reference repository root).  The Python mirror of the
+ * protocol lives in tramp_amd/ and binds these symbols with ctypes
+ * (INTEGRATION.md shows the stub a tramp maintainer would add).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++ / torch types.
+ *  - every function returns a tramp_status; the message is retrievable with
+ *    tramp_last_error(ctx).  Nothing aborts.
+ *  - dtype selects the element type of the N-vectors ("b", "r", "y"): f32 or
+ *    f64.  Scalar precisions "a" and variances "v" are ALWAYS double.
+ *  - ensemble axis: every vector argument is a [batch, n] row-major array of
+ *    independent problem instances; every scalar argument is a double[batch]
+ *    array IN DEVICE MEMORY (instances never interact).  batch = 1 is the
+ *    reference's single-instance call.
+ *  - all pointers named *_d / documented "device" are device pointers obtained
+ *    from tramp_buf_alloc (or any hipMalloc'd memory); kernels never allocate;
+ *    inputs are const; launches are asynchronous on the context's stream, in
+ *    program order.  tramp_sync / tramp_d2h synchronise.
+ *  - message update (tramp/base.py:250-255, fused into every kernel):
+ *        a_new = clip(1/max(v,1e-20) - a, 1e-11, 1e11);  b_new = r (a + a_new) - b
+ *    optional constant damping (tramp/algos/message_passing.py:119-127):
+ *        out = d * old + (1 - d) * new   on both a and b,
+ *    selected by passing damping != 0 together with a_old / b_old (which may
+ *    alias the outputs for an in-place update).
+ *  - a non-finite posterior mean poisons the reduced variance (NaN), so the
+ *    reference's NaN guard (message_passing.py:187-209) only needs a_new.
+ */
+#ifndef TRAMP_HIP_H
+#define TRAMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tramp_ctx tramp_ctx;
+typedef struct tramp_linear tramp_linear;
+typedef struct tramp_event tramp_event;
+
+typedef enum {
+    TRAMP_OK = 0,
+    TRAMP_EINVAL = 1,   /* bad argument (null pointer, negative size, unknown enum) */
+    TRAMP_EHIP = 2,     /* a HIP runtime call failed; see tramp_last_error */
+    TRAMP_ENOMEM = 3,
+    TRAMP_ENOTSUP = 4,  /* valid request this build does not implement */
+    TRAMP_ENODEV = 5    /* no usable gfx950 device */
+} tramp_status;
+
+typedef enum { TRAMP_F32 = 0, TRAMP_F64 = 1 } tramp_dtype;
+typedef enum { TRAMP_SGN = 0, TRAMP_ABS = 1, TRAMP_RELU = 2 } tramp_pwl_kind;
+typedef enum { TRAMP_FWD = 0, TRAMP_BWD = 1 } tramp_dir;
+
+/* ---- library / context ------------------------------------------------- */
+const char* tramp_version(void);
+/* Number of visible HIP devices (0 without a GPU; never fails hard). */
+int tramp_device_count(int* n);
+/* One context per GPU per host thread: owns a HIP stream and a reduction
+ * workspace; holds no globals, re-entrant across contexts. */
+int tramp_ctx_create(int device, tramp_ctx** ctx);
+int tramp_ctx_destroy(tramp_ctx* ctx);
+const char* tramp_last_error(const tramp_ctx* ctx);
+int tramp_sync(tramp_ctx* ctx);
+/* Raw hipStream_t of the context (for interop with other HIP users). */
+int tramp_ctx_stream(tramp_ctx* ctx, void** stream);
+int tramp_device_name(tramp_ctx* ctx, char* out, size_t cap);
+int tramp_mem_info(tramp_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+
+/* ---- device memory ------------------------------------------------------ */
+int tramp_buf_alloc(tramp_ctx* ctx, size_t bytes, void** dptr);
+int tramp_buf_free(tramp_ctx* ctx, void* dptr);
+int tramp_h2d(tramp_ctx* ctx, void* dst_d, const void* src_h, size_t bytes);
+int tramp_d2h(tramp_ctx* ctx, void* dst_h, const void* src_d, size_t bytes); /* synchronises */
+int tramp_d2d(tramp_ctx* ctx, void* dst_d, const void* src_d, size_t bytes);
+int tramp_memset(tramp_ctx* ctx, void* dst_d, int value, size_t bytes);
+/* out[i] = value for a typed vector / a double scalar array. */
+int tramp_fill(tramp_ctx* ctx, int dtype, void* dst_d, size_t count, double value);
+int tramp_fill_f64(tramp_ctx* ctx, double* dst_d, size_t count, double value);
+/* dtype conversion of a vector (f64 <-> f32), count elements. */
+int tramp_convert(tramp_ctx* ctx, int dst_dtype, void* dst_d, int src_dtype,
+                  const void* src_d, size_t count);
+
+/* ---- timing (HIP events on the context's stream; bench.py roofline) ------ */
+int tramp_event_create(tramp_ctx* ctx, tramp_event** ev);
+int tramp_event_destroy(tramp_ctx* ctx, tramp_event* ev);
+int tramp_event_record(tramp_ctx* ctx, tramp_event* ev);
+/* Synchronises on `stop`; milliseconds between the two recorded events. */
+int tramp_event_elapsed_ms(tramp_ctx* ctx, tramp_event* start, tramp_event* stop, float* ms);
+
+/* ---- priors (root factors) ---------------------------------------------- */
+/* K1. GaussBernoulliPrior.compute_forward_posterior + Prior.compute_forward_message
+ *     tramp/priors/gauss_bernoulli_prior.py:70-77, tramp/priors/base_prior.py:13-16,
+ *     tramp/beliefs/sparse.py:9-22, tramp/beliefs/normal.py:3-4.
+ * in : ax_d[batch], bx_d[batch,n]; prior (rho, mean, var)
+ * out: a_new_d[batch], b_new_d[batch,n]; optional r_d[batch,n], v_d[batch] (posterior). */
+int tramp_gb_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                       const double* ax_d, const void* bx_d,
+                       double rho, double mean, double var,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
+/* K2. MAP_L1NormPrior.compute_forward_posterior (soft threshold)
+ *     tramp/priors/map_L1_norm_prior.py:11-17,66-71.
+ * count_d[batch] (optional) receives the exact support size #{|bx| > gamma};
+ * mask_d[batch,n] (optional, uint8) the support mask itself. */
+int tramp_l1_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                       const double* ax_d, const void* bx_d, double gamma,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d,
+                       unsigned long long* count_d, uint8_t* mask_d);
+
+/* K3. GaussianPrior.compute_forward_message: constant message, bypasses ab_new
+ *     tramp/priors/gaussian_prior.py:86-89 (posterior :63-68). */
+int tramp_gauss_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                          double mean, double var, double* a_new_d, void* b_new_d);
+
+/* ---- likelihoods (leaf factors, y observed) ------------------------------- */
+/* K6. GaussianLikelihood.compute_backward_message: constant (1/var, y/var)
+ *     tramp/likelihoods/gaussian_likelihood.py:68-71,:17. */
+int tramp_gauss_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                        const void* y_d, double var, double* a_new_d, void* b_new_d);
+
+/* K4. SgnLikelihood.compute_backward_posterior + Likelihood.compute_backward_message
+ *     tramp/likelihoods/sgn_likelihood.py:32-37, tramp/likelihoods/base_likelihood.py:25-28,
+ *     tramp/beliefs/positive.py:12-17, tramp/utils/truncated_normal.py:92-94,147-149,224-266.
+ * y_d[batch,n] in {-1,+1}. */
+int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                      const double* az_d, const void* bz_d, const void* y_d,
+                      double damping, const double* a_old_d, const void* b_old_d,
+                      double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
+/* K5. AbsLikelihood.compute_backward_posterior  (y >= 0)
+ *     tramp/likelihoods/abs_likelihood.py:31-36, tramp/beliefs/binary.py:8-13. */
+int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                      const double* az_d, const void* bz_d, const void* y_d,
+                      double damping, const double* a_old_d, const void* b_old_d,
+                      double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
+/* ---- componentwise channels ---------------------------------------------- */
+/* K7. PiecewiseLinearChannel.compute_forward/backward_posterior + Channel message
+ *     tramp/channels/activation/piecewise_linear_channel.py:27-53 (regions :80-106),
+ *     tramp/utils/linear_region.py:32-64, tramp/utils/truncated_normal.py:21-29,218-298,
+ *     tramp/channels/base_channel.py:9-17.
+ * kind: SGN/ABS/RELU; dir: FWD updates the x-side message (a = ax, b = bx), BWD
+ * the z-side.  mask_d[batch,n] (optional, uint8): bit0/bit1 = the log_Phi
+ * "x < 30" branch mask (truncated_normal.py:27) of the pos/neg region. */
+int tramp_pwl_channel(tramp_ctx* ctx, int dtype, int kind, int dir, size_t n, size_t batch,
+                      const double* az_d, const void* bz_d,
+                      const double* ax_d, const void* bx_d,
+                      double damping, const double* a_old_d, const void* b_old_d,
+                      double* a_new_d, void* b_new_d, void* r_d, double* v_d,
+                      uint8_t* mask_d);
+
+/* ---- diagonal-belief variants (isotropic=False): a is an n-vector too ------
+ * Same files as above with the `.mean()` line skipped
+ * (gauss_bernoulli_prior.py:75-76, sgn_likelihood.py:35-36, map_L1_norm_prior.py:69-70)
+ * and compute_ab_new clipping element-wise (tramp/base.py:252).  `count` flat
+ * elements; a vectors have the same dtype as b.  which: 0 = GaussBernoulli
+ * (p0=rho,p1=mean,p2=var), 1 = L1 (p0=gamma), 2 = SgnLikelihood, 3 = AbsLikelihood
+ * (in2_d = y). Outputs r, v are the posterior, a_new/b_new the message. */
+int tramp_diag_factor(tramp_ctx* ctx, int dtype, int which, size_t count,
+                      const void* a_d, const void* b_d, const void* in2_d,
+                      double p0, double p1, double p2,
+                      void* a_new_d, void* b_new_d, void* r_d, void* v_d);
+
+/* ---- dense linear channel x = W z --------------------------------------- */
+/* LinearChannel.__init__ (tramp/channels/linear/linear_channel.py:30-46): the
+ * factorisation is supplied by the caller (host LAPACK or tramp_linear_factorize)
+ * in THIN form, k = min(M, N):
+ *    Uk_d  [M, k] row-major  left singular vectors
+ *    Vt_d  [k, N] row-major  right singular vectors (rows)
+ *    sing_d[k]     singular values (descending), always double
+ * The handle keeps the pointers (no copy); the caller owns the buffers. */
+int tramp_linear_create(tramp_ctx* ctx, int dtype, size_t M, size_t N, size_t rank,
+                        const void* Uk_d, const void* Vt_d, const double* sing_d,
+                        tramp_linear** lin);
+int tramp_linear_destroy(tramp_ctx* ctx, tramp_linear* lin);
+
+/* Device factorisation (setup path): Gram matrix on the
+ * smaller side (rocBLAS), symmetric eigensolve (rocSOLVER), thin factors.
+ * W_d [M,N] row-major of `dtype`; outputs as tramp_linear_create expects
+ * (caller-allocated).  Computation is always carried out in f64. */
+int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_t N, const void* W_d,
+                           void* Uk_d, void* Vt_d, double* sing_d, size_t* rank);
+
+/* K9. LinearChannel.compute_n_eff / compute_forward_variance / compute_backward_variance
+ *     tramp/channels/linear/linear_channel.py:58-67,91-105 (same scalars serve SE:
+ *     compute_forward_error / compute_backward_error :119-125) + compute_a_new
+ *     (tramp/base.py:245-248).  dir FWD: v = vx, a_new from ax; BWD: v = vz, from az. */
+int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, int dir, size_t batch,
+                          const double* az_d, const double* ax_d,
+                          double* v_d, double* a_new_d, double* n_eff_d);
+
+/* K8. LinearChannel.compute_forward_message / compute_backward_message
+ *     tramp/channels/linear/linear_channel.py:69-117 + tramp/channels/base_channel.py:9-17.
+ * With t = Vt bz, u = Uk^T bx, D = az + ax sing^2:
+ *    FWD  rx = Uk [ sing (t + sing u) / D ]
+ *    BWD  rz = bz/az + Vt^T [ (1/D - 1/az) t + sing u / D ]     (k < N)
+ *         rz =         Vt^T [ (t + sing u) / D ]                 (k = N)
+ * then the fused message update.  bz_d [batch,N], bx_d [batch,M].
+ * B = 1..TRAMP_GEMV_MAX_BATCH uses HBM-streaming GEMV kernels, larger batches
+ * the MFMA kernels.  r_d optional (posterior mean), v_d optional. */
+int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batch,
+                         const double* az_d, const void* bz_d,
+                         const double* ax_d, const void* bx_d,
+                         double damping, const double* a_old_d, const void* b_old_d,
+                         double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
+/* Building blocks of K8, exported for tests, profiling and the roofline bench:
+ *   NT: out[b, r] = sum_c mat[r, c] * x[b, c]     mat [R, C] row-major
+ *   NN: out[b, c] = sum_r mat[r, c] * x[b, r]
+ * algo: 0 = auto, 1 = VALU GEMV, 2 = MFMA. */
+int tramp_matvec_nt(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
+                    const void* mat_d, const void* x_d, void* out_d);
+int tramp_matvec_nn(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
+                    const void* mat_d, const void* x_d, void* out_d);
+
+/* ---- variable nodes / scheduler helpers ------------------------------------ */
+/* K11. Variable.posterior_rv (tramp/base.py:157-161) for a SISO variable:
+ *      r = (b1 + b2) / (a1 + a2), v = 1 / (a1 + a2), plus the two sums the
+ *      EarlyStoppingEP rule needs (tramp/algos/callbacks.py:246-247,265-268):
+ *      sq_diff[b] = sum (r - r_old)^2, sq_norm[b] = sum r^2.
+ *      r_old_d may be NULL (first iteration; sq_diff = sq_norm). r_d may alias r_old_d. */
+int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                             const double* a1_d, const void* b1_d,
+                             const double* a2_d, const void* b2_d,
+                             const void* r_old_d, void* r_d, double* v_d,
+                             double* sq_diff_d, double* sq_norm_d);
+
+/* K12. constant damping of an (a, b) message in place
+ *      (tramp/algos/message_passing.py:119-127): x = d*old + (1-d)*x. */
+int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
+               const double* a_old_d, const void* b_old_d, double* a_d, void* b_d);
+
+/* sum_d[batch] = sum_i (x[b,i] - y[b,i])^2  (y may be NULL): mse / norms for callbacks
+ * (tramp/algos/metrics.py:5-8). */
+int tramp_sq_dist(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                  const void* x_d, const void* y_d, double* sum_d);
+
+/* ---- state evolution (scalar recursions; host scalars in, host scalars out) --
+ * Each call evaluates `count` independent parameter points in one launch.
+ * K13. Prior.compute_forward_error for the Gauss-Bernoulli prior
+ *      tramp/priors/base_prior.py:66-69, gauss_bernoulli_prior.py:59-62,116-122,
+ *      tramp/utils/integration.py:13-28.  All arrays are HOST arrays[count]. */
+int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
+                      const double* rho, const double* mean, const double* var, double* v);
+/* K13. Likelihood.compute_backward_error for SgnLikelihood (1-D) and AbsLikelihood (2-D)
+ *      tramp/likelihoods/base_likelihood.py:78-81, sgn_likelihood.py:79-92,
+ *      abs_likelihood.py:60-69.  Requires az > 1/tau_z (TRAMP_EINVAL otherwise,
+ *      mirroring the reference's AssertionError). */
+int tramp_se_sgn_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
+int tramp_se_abs_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
+/* K14. Channel.compute_forward_error / compute_backward_error for Sgn/Abs/Relu channels
+ *      tramp/channels/base_channel.py:29-41, piecewise_linear_channel.py:60-64,
+ *      tramp/utils/linear_region.py:78-101, tramp/utils/integration.py:31-73. */
+int tramp_se_pwl_channel(tramp_ctx* ctx, int kind, int dir, size_t count,
+                         const double* az, const double* ax, const double* tau_z, double* v);
+
+/* ---- synthetic data (bench / tests; counter-based, reproducible per seed) --- */
+/* out[i] = scale * N(0,1), Philox-4x32 + Box-Muller, element i from counter i. */
+int tramp_randn(tramp_ctx* ctx, int dtype, void* out_d, size_t count,
+                unsigned long long seed, double scale);
+
+#define TRAMP_GEMV_MAX_BATCH 8
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAMP_HIP_H */

@@ -498,7 +498,7 @@ def gaussian_measure(m, s, f, method="quadpack"):
     "integration.py:13-28"
     if method == "quadpack":
         return quad(lambda x: norm_pdf(x) * f(m + s * x), -10, 10)[0]
-    X, Wt = _gl_nodes()
+    X, Wt = _gl_nodes(n_panels=1024, order=8)   # sharp features at large a need fine panels
     return np.sum(Wt * norm_pdf(X) * f(m + s * X))
 
 

@@ -1,0 +1,141 @@
+"""GPU parity of the whole EP iteration: the device-resident scheduler
+against per-iteration trajectories captured from the reference's iterate()."""
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol, scale=None):
+    b = np.asarray(b, dtype=float)
+    sc = np.abs(b).max() if scale is None else scale
+    np.testing.assert_allclose(np.asarray(a, dtype=float), b, rtol=rtol, atol=rtol * max(sc, 1e-300))
+
+
+class Recorder:
+    def __init__(self, stopper):
+        self.stopper = stopper
+        self.iters = []
+
+    def __call__(self, algo, i, max_iter):
+        rec = dict(edges=algo.get_edges_data(), vars=algo.get_variables_data())
+        rec["b"] = {(v.id, d): algo.get_message(v.id, d)[1] for v in algo.variables for d in ("fwd", "bwd")}
+        self.iters.append(rec)
+        return self.stopper(algo, i, max_iter)
+
+
+def build_glm(T, ctx, c, dtype=np.float64):
+    N, M = c["N"], int(c["alpha"] * c["N"])
+    rs = np.random.RandomState(c["seed"])
+    W = rs.randn(M, N) / np.sqrt(N)
+    assert W.sum() == c["W_sum"]
+    prior = T.GaussBernoulliPrior(size=N, rho=c["rho"], dtype=dtype, ctx=ctx)
+    lin = T.LinearChannel(W, dtype=dtype, ctx=ctx, svd="host")
+    if c["output"] == "gaussian":
+        lik = T.GaussianLikelihood(y=c["y"], var=c["noise_var"], dtype=dtype, ctx=ctx)
+    elif c["output"] == "sgn":
+        lik = T.SgnLikelihood(y=c["y"], dtype=dtype, ctx=ctx)
+    else:
+        lik = T.AbsLikelihood(y=c["y"], dtype=dtype, ctx=ctx)
+    model = (prior @ T.SISOVariable(id="x") @ lin @ T.SISOVariable(id="z") @ lik).to_model()
+    return model, ["x", "z"]
+
+
+def build_two_layer(T, ctx, c, dtype=np.float64):
+    N, M1, M2 = c["N"], c["M1"], c["M2"]
+    rs = np.random.RandomState(c["seed"])
+    W1 = rs.randn(M1, N) / np.sqrt(N)
+    W2 = rs.randn(M2, M1) / np.sqrt(M1)
+    assert W1.sum() == c["W1_sum"] and W2.sum() == c["W2_sum"]
+    model = T.MultiLayerModel([
+        T.GaussianPrior(size=N, dtype=dtype, ctx=ctx),
+        T.LinearChannel(W1, dtype=dtype, ctx=ctx, svd="host"),
+        T.ReluChannel(dtype=dtype, ctx=ctx),
+        T.LinearChannel(W2, dtype=dtype, ctx=ctx, svd="host"),
+        T.GaussianLikelihood(y=c["y"], var=c["noise_var"], dtype=dtype, ctx=ctx),
+    ], ids=["x", "z1", "a1", "z2", "y"])
+    return model, ["x", "z1", "a1", "z2"]
+
+
+def test_ep_trajectories_fp64(ctx, golden_ep):
+    import tramp_amd as T
+    for c in golden_ep:
+        model, ids = build_glm(T, ctx, c) if c["kind"] == "glm" else build_two_layer(T, ctx, c)
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        rec = Recorder(T.EarlyStoppingEP())
+        ep.iterate(max_iter=30, callback=rec, damping=c.get("damping"))
+        assert ep.n_iter == c["n_iter"], (c["kind"], c.get("output"), c["N"], c["seed"], c.get("damping"))
+        t = c["traj"]
+        n = min(t[f"v:{ids[0]}"].shape[0], len(rec.iters))
+        for it in range(n):
+            rt = 1e-7 if it < 6 else 1e-5            # round-off amplifies along the trajectory
+            for vid in ids:
+                e = rec.iters[it]["edges"]
+                close(e[(vid, "fwd")][0], t[f"fwd:{vid}:a"][it], rt)
+                close(e[(vid, "bwd")][0], t[f"bwd:{vid}:a"][it], rt)
+                close(rec.iters[it]["b"][(vid, "fwd")], t[f"fwd:{vid}:b"][it], rt)
+                close(rec.iters[it]["b"][(vid, "bwd")], t[f"bwd:{vid}:b"][it], rt)
+                close(rec.iters[it]["vars"][vid]["r"], t[f"r:{vid}"][it], rt)
+                close(rec.iters[it]["vars"][vid]["v"], t[f"v:{vid}"][it], rt)
+
+
+def test_ep_trajectory_fp32(ctx, golden_ep):
+    """fp32 vectors (scalars stay f64): 1e-3 on posterior means for the first iterations."""
+    import tramp_amd as T
+    for c in [c for c in golden_ep if c["kind"] == "glm" and c["N"] == 256 and not c.get("damping")][:4]:
+        model, ids = build_glm(T, ctx, c, np.float32)
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        rec = Recorder(T.PassCallback())
+        ep.iterate(max_iter=5, callback=rec)
+        t = c["traj"]
+        for it in range(5):
+            for vid in ids:
+                close(rec.iters[it]["vars"][vid]["r"], t[f"r:{vid}"][it], 2e-3)
+                close(rec.iters[it]["vars"][vid]["v"], t[f"v:{vid}"][it], 2e-3)
+
+
+@pytest.mark.parametrize("batch", [2, 5, 16])
+def test_ep_ensemble_matches_oracle_per_instance(ctx, batch):
+    """Config-4 shape in miniature: B instances share W; instance b == oracle EP on (x_b, y_b)."""
+    import tramp_amd as T
+    N, M, rho, nv = 128, 64, 0.1, 1e-2
+    rs = np.random.RandomState(11)
+    W = rs.randn(M, N) / np.sqrt(N)
+    X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(batch)])
+    Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((batch, M))
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    assert ep.batch == batch
+    ep.iterate(max_iter=8, callback=T.PassCallback(), damping=0.1)
+    r = ep.get_variables_data()["x"]["r"].reshape(batch, N)
+    v = np.atleast_1d(ep.get_variables_data()["x"]["v"])
+    lin = orc.LinearFactor(W, thin=True)
+    for b in range(batch):
+        fs = [orc.GBPriorFactor(N, rho=rho), lin, orc.GaussLikFactor(Y[b], nv)]
+        res = orc.ep_chain(fs, [N, M], max_iter=8, damping=0.1, tol=0.0)
+        close(r[b], res["r"][0], 1e-6)
+        close(v[b], res["v"][0], 1e-6)
+        mse = np.mean((res["r"][0] - X[b])**2)
+        close(np.atleast_1d(ep.mse("x", X))[b], mse, 1e-5)
+
+
+def test_model_api_to_observed_and_sample(ctx):
+    """glm_generative -> sample -> to_observed -> EP, as tramp.experiments' teacher-student flow."""
+    import tramp_amd as T
+    np.random.seed(0)
+    model = T.glm_generative(N=200, alpha=0.6, ensemble_type="gaussian", prior_type="gauss_bernoulli",
+                             output_type="gaussian", prior_rho=0.1, output_var=1e-3, ctx=ctx)
+    sample = model.sample(seed=3)
+    assert sample["x"].shape == (200,) and sample["y"].shape == (120,)
+    student = model.to_observed({"y": sample["y"]})
+    assert [type(f).__name__ for f in student.factors] == ["GaussBernoulliPrior", "LinearChannel",
+                                                           "GaussianLikelihood"]
+    ep = T.ExpectationPropagation(student, ctx=ctx)
+    ep.iterate(max_iter=100)
+    x_hat = ep.get_variable_data("x")["r"]
+    assert np.mean((x_hat - sample["x"])**2) < 5e-3
+    assert ep.n_iter < 100

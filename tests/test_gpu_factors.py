@@ -1,0 +1,302 @@
+"""GPU parity: HIP factor kernels (through the C ABI) vs the CPU oracle and the
+golden vectors captured from the reference.
+
+fp64: 1e-9 relative (the north-star bar is 1e-6), fp32: 1e-3; masks/counts bit-exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+F64 = dict(rtol=1e-9, atol_scale=1e-10)
+F32 = dict(rtol=2e-3, atol_scale=2e-4)
+
+
+def tol(dtype):
+    return F64 if dtype == np.float64 else F32
+
+
+def close(a, b, dtype=np.float64, scale=None):
+    t = tol(dtype)
+    b = np.asarray(b, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    sc = np.nanmax(np.abs(b)) if scale is None and b.size else (scale or 0.0)
+    np.testing.assert_allclose(a, b, rtol=t["rtol"], atol=t["atol_scale"] * max(sc, 1e-300), equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tramp_amd
+    return tramp_amd
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gb_prior_golden(T, ctx, golden_factors, dtype):
+    for c in golden_factors["gb"]:
+        if dtype == np.float32 and (np.abs(c["b"]).max() > 1e4 or c["ax"] > 1e6 or c["ax"] < 1e-6):
+            continue     # outside f32 range by construction
+        p = T.GaussBernoulliPrior(size=c["b"].shape[0], rho=c["rho"], mean=c["mean"], var=c["var"],
+                                  dtype=dtype, ctx=ctx)
+        r, v = p.compute_forward_posterior(c["ax"], c["b"])
+        close(r, c["r"], dtype)
+        close(v, c["v"], dtype)
+        a_new, b_new = p.compute_forward_message(c["ax"], c["b"])
+        close(a_new, c["a_new"], dtype)
+        close(b_new, c["b_new"], dtype, scale=np.abs(c["b"]).max() + np.abs(c["b_new"]).max())
+        assert isinstance(a_new, float) and b_new.shape == c["b"].shape
+    d = golden_factors["gb_diag"]
+    p = T.GaussBernoulliPrior(size=100, rho=0.5, isotropic=False, dtype=dtype, ctx=ctx)
+    r, v = p.compute_forward_posterior(d["ax"], d["bx"])
+    close(r, d["r"], dtype); close(v, d["v"], dtype)
+    a_new, b_new = p.compute_forward_message(d["ax"], d["bx"])
+    close(a_new, d["a_new"], dtype); close(b_new, d["b_new"], dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_l1_prior_and_mask(T, ctx, golden_factors, dtype):
+    for c in golden_factors["l1"]:
+        b = c["b"]
+        if dtype == np.float32:
+            b32 = b.astype(np.float32)
+            if not np.all(np.isfinite(b32)):
+                continue
+            ref_mask = orc.l1_support_mask(b32, np.float32(c["gamma"]))
+        else:
+            ref_mask = c["mask"]
+        p = T.MAP_L1NormPrior(size=b.shape[0], gamma=c["gamma"], dtype=dtype, ctx=ctx)
+        mask, count = p.support(c["ax"], b)
+        assert np.array_equal(mask, ref_mask)              # bit-exact row
+        assert int(count[0]) == int(ref_mask.sum())
+        if dtype == np.float64:
+            r, v = p.compute_forward_posterior(c["ax"], b)
+            close(r, c["r"], dtype); close(v, c["v"], dtype)
+            a_new, b_new = p.compute_forward_message(c["ax"], b)
+            close(a_new, c["a_new"], dtype)
+            close(b_new, c["b_new"], dtype, scale=np.abs(b).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gaussian_prior_likelihood(T, ctx, golden_factors, dtype):
+    c = golden_factors["gauss_prior"]
+    p = T.GaussianPrior(size=c["b"].shape[0], mean=c["mean"], var=c["var"], dtype=dtype, ctx=ctx)
+    a_new, b_new = p.compute_forward_message(c["ax"], c["b"])
+    close(a_new, c["a_new"], dtype); close(b_new, c["b_new"], dtype)
+    close(p.compute_forward_error(c["ax"]), c["err"])
+    c = golden_factors["gauss_lik"]
+    lk = T.GaussianLikelihood(y=c["y"], var=c["var"], dtype=dtype, ctx=ctx)
+    a_new, b_new = lk.compute_backward_message(c["az"], c["b"])
+    close(a_new, c["a_new"], dtype); close(b_new, c["b_new"], dtype)
+    close(lk.compute_backward_error(c["az"], 1.0), c["err"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sgn_abs_likelihood(T, ctx, golden_factors, dtype):
+    for c in golden_factors["sgn_lik"]:
+        if dtype == np.float32 and c["az"] < 1e-6:
+            continue
+        lk = T.SgnLikelihood(y=c["y"], dtype=dtype, ctx=ctx)
+        r, v = lk.compute_backward_posterior(c["az"], c["bz"], c["y"])
+        sc = np.abs(c["r"]).max()
+        close(r, c["r"], dtype, scale=sc); close(v, c["v"], dtype)
+        a_new, b_new = lk.compute_backward_message(c["az"], c["bz"])
+        close(a_new, c["a_new"], dtype)
+        close(b_new, c["b_new"], dtype, scale=np.abs(c["bz"]).max() + np.abs(c["b_new"]).max())
+        if dtype == np.float64:
+            _, vd = T.SgnLikelihood(y=c["y"], isotropic=False, ctx=ctx).compute_backward_posterior(
+                c["az"], c["bz"], c["y"])
+            close(vd, c["v_diag"], dtype)
+    for c in golden_factors["abs_lik"]:
+        lk = T.AbsLikelihood(y=c["y"], dtype=dtype, ctx=ctx)
+        r, v = lk.compute_backward_posterior(c["az"], c["bz"], c["y"])
+        close(r, c["r"], dtype); close(v, c["v"], dtype)
+        a_new, b_new = lk.compute_backward_message(c["az"], c["bz"])
+        close(a_new, c["a_new"], dtype)
+        close(b_new, c["b_new"], dtype, scale=np.abs(c["bz"]).max() + np.abs(c["b_new"]).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pwl_channels(T, ctx, golden_factors, dtype):
+    cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)
+    for c in golden_factors["pwl"]:
+        if dtype == np.float32 and (c["az"] < 1e-6 or c["ax"] != 0 and c["ax"] < 1e-6):
+            continue
+        if np.isnan(c["v_fwd"]) or np.isnan(c["v_bwd"]):
+            continue           # reference itself overflows on this row
+        ch = cls[c["kind"]](dtype=dtype, ctx=ctx)
+        for d, post, msg in (("fwd", ch.compute_forward_posterior, ch.compute_forward_message),
+                             ("bwd", ch.compute_backward_posterior, ch.compute_backward_message)):
+            r, v = post(c["az"], c["bz"], c["ax"], c["bx"])
+            close(r, c["r_" + d], dtype, scale=max(1.0, np.abs(c["r_" + d]).max()))
+            close(v, c["v_" + d], dtype)
+            a_new, b_new = msg(c["az"], c["bz"], c["ax"], c["bx"])
+            close(a_new, c["a_" + d], dtype)
+            tgt = c["bx"] if d == "fwd" else c["bz"]
+            close(b_new, c["b_" + d], dtype, scale=np.abs(tgt).max() + np.abs(c["b_" + d]).max())
+
+
+def test_pwl_branch_masks_bit_exact(T, ctx, golden_factors):
+    """log_Phi 'x < 30' masks: same comparison on the same f64 operands as the reference."""
+    cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)
+    for c in golden_factors["pwl"]:
+        ch = cls[c["kind"]](ctx=ctx)
+        with np.errstate(all="ignore"):
+            m_pos, m_neg = ch.branch_masks(c["az"], c["bz"], c["ax"], c["bx"])
+            exp = []
+            for side, slope, x0 in orc.PWL_REGIONS[c["kind"]]:
+                a = c["az"] + slope**2 * c["ax"]
+                b = c["bz"] + slope * (c["bx"] - c["ax"] * x0)
+                r0, v0 = b / a, 1 / a
+                y0 = (0 - r0) / np.sqrt(v0)
+                exp.append((-side * y0) < 30)
+        assert np.array_equal(m_pos, exp[0])
+        assert np.array_equal(m_neg, exp[1])
+
+
+def _W(case):
+    if "W" in case:
+        return case["W"]
+    rs = np.random.RandomState(case["seed"])
+    return rs.randn(case["M"], case["N"]) / np.sqrt(case["N"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_linear_channel_golden(T, ctx, golden_linear, dtype):
+    for case in golden_linear:
+        W = _W(case)
+        ch = T.LinearChannel(W, dtype=dtype, ctx=ctx, svd="host")
+        assert ch.rank == case["rank"]
+        bz, bx = case["bz"], case["bx"]
+        for c in case["cases"]:
+            az, ax = c["az"], c["ax"]
+            if dtype == np.float32 and (az < 1e-3 or az > 1e6):
+                continue
+            cancel = 4e-16 * np.abs(bz).max() / max(az, 1e-11) * case["N"]
+            rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+            rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+            close(rz, c["rz"], dtype, scale=np.abs(c["rz"]).max() * 10)
+            close(rx, c["rx"], dtype, scale=np.abs(c["rx"]).max() * 10 + cancel / tol(dtype)["atol_scale"])
+            close(vz, c["vz"]); close(vx, c["vx"])
+            v, a_new, n_eff = ch.device_variance(T._lib.FWD, az, ax)
+            close(n_eff, c["n_eff"]); close(v, c["vx"])
+            if "a_fwd" in c:
+                a, b = ch.compute_forward_message(az, bz, ax, bx)
+                close(a, c["a_fwd"])
+                close(b, c["b_fwd"], dtype,
+                      scale=(np.abs(c["b_fwd"]).max() + np.abs(bx).max()) * 10
+                      + cancel * (ax + c["a_fwd"]) / tol(dtype)["atol_scale"])
+                a, b = ch.compute_backward_message(az, bz, ax, bx)
+                close(a, c["a_bwd"])
+                close(b, c["b_bwd"], dtype, scale=(np.abs(c["b_bwd"]).max() + np.abs(bz).max()) * 10)
+        if "vz_az0" in case:
+            v, _, _ = ch.device_variance(T._lib.BWD, 0.0, 0.7)
+            close(v, case["vz_az0"])
+
+
+@pytest.mark.parametrize("batch", [1, 3, 8, 11])
+def test_batch_matches_per_instance_oracle(T, ctx, batch):
+    """Ensemble axis: instance b of a batched call == the single-instance oracle on row b."""
+    rs = np.random.RandomState(7)
+    N, M = 96, 40
+    W = rs.randn(M, N) / np.sqrt(N)
+    lin = orc.LinearThinOracle(W)
+    ch = T.LinearChannel(W, ctx=ctx, svd="host")
+    az = rs.uniform(0.5, 3, batch); ax = rs.uniform(0.2, 5, batch)
+    bz = rs.standard_normal((batch, N)); bx = rs.standard_normal((batch, M))
+    af, bf = ch.compute_forward_message(az, bz, ax, bx)
+    ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+    prior = T.GaussBernoulliPrior(size=N, rho=0.2, ctx=ctx)
+    ap, bp = prior.compute_forward_message(az, bz)
+    relu = T.ReluChannel(ctx=ctx)
+    bx2 = rs.standard_normal((batch, N))
+    ar, br = relu.compute_backward_message(az, bz, ax, bx2)
+    for b in range(batch):
+        a, bb_ = lin.forward_message(az[b], bz[b], ax[b], bx[b])
+        close(af[b], a); close(bf[b], bb_, scale=10 * np.abs(bb_).max())
+        a, bb_ = lin.backward_message(az[b], bz[b], ax[b], bx[b])
+        close(ab[b], a); close(bb[b], bb_, scale=10 * np.abs(bb_).max())
+        a, bb_ = orc.gb_prior_message(az[b], bz[b], rho=0.2)
+        close(ap[b], a); close(bp[b], bb_, scale=10 * np.abs(bb_).max())
+        a, bb_ = orc.pwl_channel_message("relu", "bwd", az[b], bz[b], ax[b], bx2[b])
+        close(ar[b], a); close(br[b], bb_, scale=10 * np.abs(bb_).max())
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 4099])
+def test_ragged_and_empty_sizes(T, ctx, n):
+    rs = np.random.RandomState(n)
+    b = rs.standard_normal(n) * 2
+    p = T.GaussBernoulliPrior(size=n, rho=0.3, ctx=ctx)
+    if n == 0:
+        a_new, b_new = p.compute_forward_message(1.1, b.reshape(1, 0))
+        assert b_new.shape == (1, 0)
+        return
+    a_new, b_new = p.compute_forward_message(1.1, b)
+    a_ref, b_ref = orc.gb_prior_message(1.1, b, rho=0.3)
+    close(a_new, a_ref); close(b_new, b_ref, scale=10 * np.abs(b_ref).max())
+    y = np.sign(rs.standard_normal(n))
+    lk = T.SgnLikelihood(y=y, ctx=ctx)
+    a_new, b_new = lk.compute_backward_message(0.9, b)
+    a_ref, b_ref = orc.sgn_lik_message(0.9, b, y)
+    close(a_new, a_ref); close(b_new, b_ref, scale=10 * np.abs(b_ref).max())
+
+
+def test_damping_fused(T, ctx):
+    rs = np.random.RandomState(3)
+    n, d = 1000, 0.3
+    b = rs.standard_normal(n)
+    old_b = rs.standard_normal(n); old_a = 0.7
+    p = T.GaussBernoulliPrior(size=n, rho=0.3, ctx=ctx)
+    oa = ctx.scalars(old_a); ob = ctx.array(old_b.reshape(1, n))
+    p.compute_forward_message(ctx.scalars(1.4), ctx.array(b.reshape(1, n)), out_a=oa, out_b=ob,
+                              damping=d, old_a=oa, old_b=ob)
+    a_ref, b_ref = orc.gb_prior_message(1.4, b, rho=0.3)
+    close(oa.get()[0], d * old_a + (1 - d) * a_ref)
+    close(ob.get()[0], d * old_b + (1 - d) * b_ref, scale=10)
+
+
+def test_nan_poisons_precision(T, ctx):
+    b = np.array([1.0, np.nan, 2.0, 0.5])
+    p = T.GaussBernoulliPrior(size=4, rho=0.3, ctx=ctx)
+    a_new, _ = p.compute_forward_message(1.0, b)
+    assert np.isnan(a_new)
+
+
+def test_error_conventions(T, ctx):
+    p = T.GaussBernoulliPrior(size=4, rho=0.3, ctx=ctx)
+    with pytest.raises(ValueError):
+        p.compute_forward_message(1.0, np.zeros((2, 2, 2)))
+    with pytest.raises(T._lib.TrampHipError):
+        T.GaussBernoulliPrior(size=4, rho=1.5, ctx=ctx).compute_forward_message(1.0, np.zeros(4))
+    ch = T.LinearChannel(np.eye(4), ctx=ctx, svd="host")
+    with pytest.raises(ValueError):
+        ch.compute_forward_message(1.0, np.zeros(5), 1.0, np.zeros(4))
+    with pytest.raises(AssertionError):
+        T.SgnLikelihood(y=None, ctx=ctx).compute_backward_error(0.5, 1.0)   # az <= 1/tau_z
+
+
+def test_large_properties_full_size(T, ctx):
+    """BASELINE sizes (N = 1e6): size-independent properties instead of a CPU loop."""
+    N = 1_000_000
+    for dtype in (np.float64, np.float32):
+        bx = ctx.randn((1, N), dtype, seed=5, scale=1.5)
+        ax = ctx.scalars(1.3)
+        p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=dtype, ctx=ctx)
+        a1, b1 = p.compute_forward_message(ax, bx)
+        a2, b2 = p.compute_forward_message(ax, bx)
+        assert np.array_equal(a1.get(), a2.get()) and np.array_equal(b1.get(), b2.get())   # deterministic
+        # consistency with the oracle on the SAME device-generated data
+        bh = bx.get()[0].astype(np.float64)
+        a_ref, b_ref = orc.gb_prior_message(1.3, bh, rho=0.05)
+        close(a1.get()[0], a_ref, dtype)
+        close(b1.get()[0], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+        # symmetry: flipping the sign of b flips r (zero-mean prior) and keeps v
+        neg = ctx.array(-bx.get(), dtype)
+        a3, b3 = p.compute_forward_message(ax, neg)
+        close(a3.get(), a1.get(), dtype)
+        close(b3.get(), -b1.get(), dtype, scale=10 * np.abs(b_ref).max())
+        # L1: count equals the number of |b| > gamma exactly
+        l1 = T.MAP_L1NormPrior(size=N, gamma=1.0, dtype=dtype, ctx=ctx)
+        mask, count = l1.support(ax, bx)
+        hb = bx.get()[0]
+        assert int(count[0]) == int((np.abs(hb) > hb.dtype.type(1.0)).sum()) == int(mask.sum())

@@ -1,0 +1,22 @@
+"""tramp_amd - MI355X-native message-passing hot path of Tree-AMP (sphinxteam/tramp).
+
+The per-iteration factor updates of Expectation Propagation and the State
+Evolution recursions run as hand-written HIP kernels for gfx950 behind a C ABI
+(include/tramp_hip.h, tramp_amd/libtramp_hip.so); this package is the host-side
+mirror of the reference's factor-module API (tramp.priors / tramp.channels /
+tramp.likelihoods) plus a minimal scheduler (tramp.algos counterpart).
+
+There is no CPU fallback: without the built HIP library the compute methods raise.
+"""
+from . import _lib
+from .device import Context, DeviceArray, default_context
+from .priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior, get_prior
+from .likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood, get_likelihood
+from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
+                       MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
+from .variables import SISOVariable, SILeafVariable
+from .models import Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution
+from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, EarlyStopping,
+                    ConstantInit, CustomInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors)
+
+__version__ = "0.1.0"

@@ -1,0 +1,122 @@
+"""ctypes binding of libtramp_hip.so (the C ABI declared in include/tramp_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, the
+caller gets an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtramp_hip.so")
+
+OK, EINVAL, EHIP, ENOMEM, ENOTSUP, ENODEV = range(6)
+F32, F64 = 0, 1
+SGN, ABS, RELU = 0, 1, 2
+FWD, BWD = 0, 1
+GEMV_MAX_BATCH = 8
+
+_STATUS = {EINVAL: "invalid argument", EHIP: "HIP runtime error", ENOMEM: "out of device memory",
+           ENOTSUP: "not supported", ENODEV: "no MI355X / HIP device"}
+
+
+class TrampHipError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {_STATUS.get(code, code)} {detail}".strip())
+
+
+_lib = None
+
+vp, sz, dbl, i32 = C.c_void_p, C.c_size_t, C.c_double, C.c_int
+u64 = C.c_ulonglong
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "tramp_device_count": [C.POINTER(i32)],
+    "tramp_ctx_create": [i32, C.POINTER(vp)],
+    "tramp_ctx_destroy": [vp],
+    "tramp_sync": [vp],
+    "tramp_ctx_stream": [vp, C.POINTER(vp)],
+    "tramp_device_name": [vp, C.c_char_p, sz],
+    "tramp_mem_info": [vp, C.POINTER(sz), C.POINTER(sz)],
+    "tramp_buf_alloc": [vp, sz, C.POINTER(vp)],
+    "tramp_buf_free": [vp, vp],
+    "tramp_h2d": [vp, vp, vp, sz],
+    "tramp_d2h": [vp, vp, vp, sz],
+    "tramp_d2d": [vp, vp, vp, sz],
+    "tramp_memset": [vp, vp, i32, sz],
+    "tramp_fill": [vp, i32, vp, sz, dbl],
+    "tramp_fill_f64": [vp, vp, sz, dbl],
+    "tramp_convert": [vp, i32, vp, i32, vp, sz],
+    "tramp_event_create": [vp, C.POINTER(vp)],
+    "tramp_event_destroy": [vp, vp],
+    "tramp_event_record": [vp, vp],
+    "tramp_event_elapsed_ms": [vp, vp, vp, C.POINTER(C.c_float)],
+    "tramp_gb_prior_fwd": [vp, i32, sz, sz, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_l1_prior_fwd": [vp, i32, sz, sz, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp],
+    "tramp_gauss_prior_fwd": [vp, i32, sz, sz, dbl, dbl, vp, vp],
+    "tramp_gauss_lik_bwd": [vp, i32, sz, sz, vp, dbl, vp, vp],
+    "tramp_sgn_lik_bwd": [vp, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_abs_lik_bwd": [vp, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_pwl_channel": [vp, i32, i32, i32, sz, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, vp],
+    "tramp_diag_factor": [vp, i32, i32, sz, vp, vp, vp, dbl, dbl, dbl, vp, vp, vp, vp],
+    "tramp_linear_create": [vp, i32, sz, sz, sz, vp, vp, vp, C.POINTER(vp)],
+    "tramp_linear_destroy": [vp, vp],
+    "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],
+    "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
+    "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
+    "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
+    "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "tramp_damp": [vp, i32, sz, sz, dbl, vp, vp, vp, vp],
+    "tramp_sq_dist": [vp, i32, sz, sz, vp, vp, vp],
+    "tramp_se_gb_prior": [vp, sz, vp, vp, vp, vp, vp],
+    "tramp_se_sgn_lik": [vp, sz, vp, vp, vp],
+    "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
+    "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],
+    "tramp_randn": [vp, i32, vp, sz, u64, dbl],
+}
+_RESTYPES = {"tramp_version": C.c_char_p, "tramp_last_error": C.c_char_p}
+EXPORTS = sorted(list(_SIGNATURES) + list(_RESTYPES))
+
+
+def load():
+    """Load libtramp_hip.so once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C tramp_amd/csrc). "
+            "tramp_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.tramp_version.argtypes = []
+    lib.tramp_version.restype = C.c_char_p
+    lib.tramp_last_error.argtypes = [vp]
+    lib.tramp_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(code, where, ctx=None):
+    if code == OK:
+        return
+    detail = ""
+    if ctx:
+        detail = load().tramp_last_error(ctx).decode(errors="replace")
+    raise TrampHipError(code, where, detail)
+
+
+def device_count():
+    n = i32(0)
+    load().tramp_device_count(C.byref(n))
+    return n.value
+
+
+def version():
+    return load().tramp_version().decode()

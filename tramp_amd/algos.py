@@ -1,0 +1,456 @@
+"""Message-passing schedulers (host Python, CPU) driving the HIP factor kernels.
+
+Counterpart of tramp/algos/{message_passing,expectation_propagation,state_evolution,
+callbacks,initial_conditions}.py for SISO chains:
+
+  iterate():  forward sweep in topological order, backward sweep in reverse order,
+              variable posteriors, callback   (message_passing.py:330-357)
+  init:       ConstantInit(a=0, b=0)           (initial_conditions.py:13-24)
+  damping:    constant, on factor->variable edges, both a and b (message_passing.py:70-127)
+  NaN guard:  ValueError when a message precision is NaN (message_passing.py:187-209)
+  stopping:   EarlyStoppingEP on ||r_new - r_old|| / ||r_new|| (callbacks.py:250-286),
+              EarlyStopping on |v_new - v_old| for SE (callbacks.py:195-243)
+
+All messages stay resident in HBM: per variable two (a[batch], b[batch, n]) pairs,
+updated in place by the factor kernels (damping fused).  One device->host read of
+the scalar table per iteration feeds the NaN guard and the stopping rule.
+"""
+import logging
+
+import numpy as np
+
+from . import _lib
+from .base import Factor, Variable
+from .device import default_context, dtype_code
+from .priors import GaussianPrior
+from .likelihoods import GaussianLikelihood
+
+logger = logging.getLogger(__name__)
+
+
+# ------------------------------------------------------------------ initial conditions
+class ConstantInit:
+    "tramp/algos/initial_conditions.py:13-24"
+
+    def __init__(self, a=0, b=0):
+        self.a = a
+        self.b = b
+
+    def init_a(self, shape, id, direction):
+        return self.a
+
+    def init_b(self, shape, id, direction):
+        return self.b
+
+
+class CustomInit(ConstantInit):
+    "Per-(variable id, direction) constants (initial_conditions.py:45-85), scalar b only."
+
+    def __init__(self, a_init=None, b_init=None, a=0, b=0):
+        super().__init__(a, b)
+        self.a_init = {(i, d): v for i, d, v in (a_init or [])}
+        self.b_init = {(i, d): v for i, d, v in (b_init or [])}
+
+    def init_a(self, shape, id, direction):
+        return self.a_init.get((id, direction), self.a)
+
+    def init_b(self, shape, id, direction):
+        return self.b_init.get((id, direction), self.b)
+
+
+# ------------------------------------------------------------------ callbacks
+class PassCallback:
+    def __call__(self, algo, i, max_iter):
+        return False
+
+
+class JoinCallback:
+    "tramp/algos/callbacks.py:22-32"
+
+    def __init__(self, callbacks):
+        self.callbacks = callbacks
+
+    def __call__(self, algo, i, max_iter):
+        return any([cb(algo, i, max_iter) for cb in self.callbacks])
+
+
+class EarlyStoppingEP:
+    """tramp/algos/callbacks.py:250-286; with an ensemble every instance must be
+    below ``tol`` (``algo.n_iter_instance`` records when each one first was)."""
+
+    def __init__(self, ids="all", tol=1e-6, wait_increase=5, max_increase=0.2):
+        self.ids = ids
+        self.tol = tol
+        self.wait_increase = wait_increase
+        self.max_increase = max_increase
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            return False                      # old_rs = None on the first iteration
+        tols = algo.relative_change(self.ids)          # [n_vars, batch]
+        worst = tols.max(axis=0)
+        algo.mark_converged(worst < self.tol)
+        if np.all(worst < self.tol):
+            logger.info("early stopping all tolerances (on r) are below tol=%.2e", self.tol)
+            return True
+        if i > self.wait_increase and np.any(worst > self.max_increase):
+            logger.info("increase=%s above max_increase=%.2e", worst.max(), self.max_increase)
+            return True
+        return False
+
+
+class EarlyStopping:
+    "tramp/algos/callbacks.py:195-243 (state evolution: change of v)"
+
+    def __init__(self, ids="all", tol=1e-6, min_variance=-1, wait_increase=5, max_increase=0.2):
+        self.ids, self.tol, self.min_variance = ids, tol, min_variance
+        self.wait_increase, self.max_increase = wait_increase, max_increase
+        self.old_vs = None
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.old_vs = None
+        data = algo.get_variables_data(self.ids)
+        new_vs = [np.asarray(d["v"], dtype=float) for d in data.values()]
+        if any(np.any(v < self.min_variance) for v in new_vs):
+            return True
+        if any(np.any(np.isnan(v)) for v in new_vs):
+            logger.warning("early stopping nan values")
+            return True
+        if self.old_vs is not None:
+            tols = [np.abs(o - n) for o, n in zip(self.old_vs, new_vs)]
+            if max(np.max(t) for t in tols) < self.tol:
+                return True
+            inc = [n - o for o, n in zip(self.old_vs, new_vs)]
+            if i > self.wait_increase and max(np.max(t) for t in inc) > self.max_increase:
+                return True
+        self.old_vs = new_vs
+        return False
+
+
+class TrackEvolution:
+    "tramp/algos/callbacks.py:88-108"
+
+    def __init__(self, ids="all", every=1):
+        self.ids, self.every, self.records = ids, every, []
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.records = []
+        if i % self.every == 0:
+            for vid, d in algo.get_variables_data(self.ids, want_r=False).items():
+                self.records.append(dict(id=vid, v=d["v"], iter=i))
+        return False
+
+
+class TrackErrors:
+    "tramp/algos/callbacks.py:131-162 (mse against the true signal, computed on the device)"
+
+    def __init__(self, true_values, every=1):
+        self.true_values, self.every, self.records = true_values, every, []
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.records = []
+        if i % self.every == 0:
+            for vid, x in self.true_values.items():
+                self.records.append(dict(id=vid, mse=algo.mse(vid, x), iter=i))
+        return False
+
+
+# ------------------------------------------------------------------ EP
+class ExpectationPropagation:
+    """Gaussian EP on a chain model (tramp/algos/expectation_propagation.py:5-32).
+
+    ``batch`` independent instances share the model structure (and the linear
+    channels' matrices); it is inferred from the observations' leading axis.
+    """
+
+    def __init__(self, model, batch=None, ctx=None):
+        self.model = model
+        self.shapes = model.init_shapes()
+        self.variables = model.variables
+        self.factors = model.factors
+        for v in self.variables:
+            if v.n_next != 1 or v.n_prev != 1:
+                raise ValueError(f"variable {v.id}: EP runs on observed models (every variable between "
+                                 "two factors); call model.to_observed(...) first")
+        dev_factors = [f for f in self.factors if hasattr(f, "_dt")]
+        dts = {f.dtype for f in dev_factors}
+        if len(dts) != 1:
+            raise ValueError(f"all factors must compute in the same dtype, got {dts}")
+        self.dtype = dts.pop()
+        self.ctx = ctx or next((f._ctx for f in dev_factors if f._ctx is not None), None) or default_context()
+        for f in dev_factors:
+            f._ctx = self.ctx
+        if batch is None:
+            batch = 1
+            for f in self.factors:
+                yd = getattr(f, "_y_dev", None)
+                if yd is not None:
+                    batch = yd.shape[0]
+        self.batch = int(batch)
+        self.n_iter = 0
+        self.n_iter_instance = np.zeros(self.batch, dtype=int)
+        self._allocated = False
+        self.default_stopping = EarlyStoppingEP()
+
+    # -- storage
+    def _allocate(self):
+        ctx, B, L = self.ctx, self.batch, len(self.variables)
+        self.A = ctx.zeros((2 * L, B), np.float64)           # a of every factor->variable edge
+        self.S = ctx.zeros((3 * L, B), np.float64)           # per variable: v, sum (r-r_old)^2, sum r^2
+        self.a_fwd = [self.A.row(2 * i) for i in range(L)]
+        self.a_bwd = [self.A.row(2 * i + 1) for i in range(L)]
+        self.b_fwd, self.b_bwd, self.r = [], [], []
+        for v in self.variables:
+            n = int(np.prod(self.shapes[v.id]))
+            self.b_fwd.append(ctx.zeros((B, n), self.dtype))
+            self.b_bwd.append(ctx.zeros((B, n), self.dtype))
+            self.r.append(ctx.zeros((B, n), self.dtype))
+        self._scratch = {}
+        self._allocated = True
+
+    def _scratch_for(self, i):
+        if i not in self._scratch:
+            n = self.b_fwd[i].shape[1]
+            self._scratch[i] = (self.ctx.empty((self.batch,), np.float64),
+                                self.ctx.empty((self.batch, n), self.dtype))
+        return self._scratch[i]
+
+    def init_message_dag(self, initializer):
+        "message_passing.py:211-232"
+        if not self._allocated:
+            self._allocate()
+        for i, v in enumerate(self.variables):
+            shape = self.shapes[v.id]
+            self.a_fwd[i].fill(initializer.init_a(shape, v.id, "fwd"))
+            self.a_bwd[i].fill(initializer.init_a(shape, v.id, "bwd"))
+            self.b_fwd[i].fill(initializer.init_b(shape, v.id, "fwd"))
+            self.b_bwd[i].fill(initializer.init_b(shape, v.id, "bwd"))
+            self.r[i].fill(0.0)
+        self._first_update = True
+
+    # -- one factor update, in place, damping fused where the kernel supports it
+    def _update(self, factor, direction, i_in, i_out):
+        d = self.damping
+        out_a = self.a_fwd[i_out] if direction == "fwd" else self.a_bwd[i_out]
+        out_b = self.b_fwd[i_out] if direction == "fwd" else self.b_bwd[i_out]
+        const = isinstance(factor, (GaussianPrior, GaussianLikelihood))
+        kw = dict(out_a=out_a, out_b=out_b)
+        if d and not const:
+            kw.update(damping=d, old_a=out_a, old_b=out_b)
+        if d and const:
+            sa, sb = self._scratch_for(i_out)
+            kw = dict(out_a=sa, out_b=sb)
+        if factor.n_prev == 0:
+            factor.compute_forward_message(self.a_bwd[i_out], self.b_bwd[i_out], **kw)
+        elif factor.n_next == 0:
+            factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out], **kw)
+        elif direction == "fwd":
+            factor.compute_forward_message(self.a_fwd[i_in], self.b_fwd[i_in],
+                                           self.a_bwd[i_out], self.b_bwd[i_out], **kw)
+        else:
+            factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out],
+                                            self.a_bwd[i_in], self.b_bwd[i_in], **kw)
+        if d and const:
+            # msg = d * msg + (1 - d) * const    (K12)
+            n = out_b.shape[1]
+            self.ctx._call("tramp_damp", dtype_code(self.dtype), n, self.batch, float(d), out_a.ptr,
+                           out_b.ptr, sa.ptr, sb.ptr)
+            out_a.copy_from(sa)
+            out_b.copy_from(sb)
+
+    def forward_message(self):
+        "message_passing.py:249-255"
+        for i, v in enumerate(self.variables):
+            self._update(self.model.prev_factor(v), "fwd", i - 1, i)
+
+    def backward_message(self):
+        "message_passing.py:257-263"
+        for i in reversed(range(len(self.variables))):
+            self._update(self.model.next_factor(self.variables[i]), "bwd", i + 1, i)
+
+    def update_variables(self):
+        "message_passing.py:265-269 -> Variable.posterior_rv (base.py:157-161), kernel K11"
+        dt = dtype_code(self.dtype)
+        for i in range(len(self.variables)):
+            n = self.r[i].shape[1]
+            self.ctx._call("tramp_variable_posterior", dt, n, self.batch, self.a_fwd[i].ptr,
+                           self.b_fwd[i].ptr, self.a_bwd[i].ptr, self.b_bwd[i].ptr, self.r[i].ptr,
+                           self.r[i].ptr, self.S.row(3 * i).ptr, self.S.row(3 * i + 1).ptr,
+                           self.S.row(3 * i + 2).ptr)
+
+    def _read_scalars(self):
+        self.A_host = self.A.get()
+        self.S_host = self.S.get()
+
+    def check_message(self):
+        "message_passing.py:187-209 (a non-finite mean poisons the reduced variance, so a suffices)"
+        bad = np.isnan(self.A_host)
+        if bad.any():
+            e, b = np.argwhere(bad)[0]
+            v = self.variables[e // 2]
+            d = "fwd" if e % 2 == 0 else "bwd"
+            raise ValueError(f"{d} message into {v.id} (instance {b}): a is nan")
+        if (self.A_host < 0).any():
+            logger.warning("negative a in messages")
+
+    # -- results
+    def relative_change(self, ids="all"):
+        rows = [i for i, v in enumerate(self.variables) if ids == "all" or v.id in ids]
+        sd = np.stack([self.S_host[3 * i + 1] for i in rows])
+        sn = np.stack([self.S_host[3 * i + 2] for i in rows])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.sqrt(sd) / np.sqrt(sn)
+
+    def mark_converged(self, mask):
+        newly = mask & (self.n_iter_instance == 0)
+        self.n_iter_instance[newly] = self.n_iter
+
+    def get_variables_data(self, ids="all", want_r=True):
+        out = {}
+        for i, v in enumerate(self.variables):
+            if ids == "all" or v.id in ids:
+                vv = self.S_host[3 * i]
+                d = dict(v=float(vv[0]) if self.batch == 1 else vv.copy())
+                if want_r:
+                    r = self.r[i].get()
+                    d["r"] = r[0] if self.batch == 1 else r
+                out[v.id] = d
+        return out
+
+    def get_variable_data(self, id):
+        return self.get_variables_data([id])[id]
+
+    def get_edges_data(self):
+        "a of every factor->variable edge, as {(variable id, direction): array[batch]}"
+        out = {}
+        for i, v in enumerate(self.variables):
+            out[(v.id, "fwd")] = self.A_host[2 * i].copy()
+            out[(v.id, "bwd")] = self.A_host[2 * i + 1].copy()
+        return out
+
+    def get_message(self, id, direction):
+        i = self.variable_index(id)
+        a = (self.a_fwd if direction == "fwd" else self.a_bwd)[i].get()
+        b = (self.b_fwd if direction == "fwd" else self.b_bwd)[i].get()
+        return (float(a[0]), b[0]) if self.batch == 1 else (a, b)
+
+    def variable_index(self, id):
+        return [v.id for v in self.variables].index(id)
+
+    def mse(self, id, x_true):
+        i = self.variable_index(id)
+        xt = self.ctx.array(np.atleast_2d(np.asarray(x_true, dtype=self.dtype)), self.dtype)
+        out = self.ctx.empty((self.batch,), np.float64)
+        n = self.r[i].shape[1]
+        self.ctx._call("tramp_sq_dist", dtype_code(self.dtype), n, self.batch, self.r[i].ptr, xt.ptr, out.ptr)
+        m = out.get() / n
+        return float(m[0]) if self.batch == 1 else m
+
+    # -- main loop
+    def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False,
+                check_every=1):
+        """message_passing.py:330-357.  ``check_every`` > 1 reads the scalar table (NaN guard,
+        stopping rule) only every k-th iteration - the sweeps themselves never wait on the host."""
+        initializer = initializer or ConstantInit(a=0, b=0)
+        callback = callback or self.default_stopping
+        if damping is not None and damping is not False and not isinstance(damping, float):
+            raise ValueError("damping must be None or a float (constant damping)")
+        self.damping = float(damping) if damping else 0.0
+        if warm_start:
+            if not self._allocated:
+                raise ValueError("message dag was never initialized")
+        else:
+            self.init_message_dag(initializer)
+            self.n_iter = 0
+            self.n_iter_instance[:] = 0
+        for i in range(max_iter):
+            self.forward_message()
+            self.backward_message()
+            self.update_variables()
+            self.n_iter += 1
+            if (i + 1) % check_every == 0 or i == max_iter - 1:
+                self._read_scalars()
+                self.check_message()
+                if callback(self, i, max_iter):
+                    logger.info("terminated after n_iter=%d iterations", self.n_iter)
+                    break
+        self.n_iter_instance[self.n_iter_instance == 0] = self.n_iter
+        return self
+
+
+# ------------------------------------------------------------------ SE
+class StateEvolution:
+    """Scalar state evolution on the same chain (tramp/algos/state_evolution.py:5-27).
+
+    Messages are host scalars ``a``; the factor errors are closed forms or the
+    device quadratures K13/K14 (factor.compute_*_state_evolution)."""
+
+    def __init__(self, model):
+        self.model = model
+        model.init_second_moments()
+        self.variables = model.variables
+        self.taus = model.get_second_moments()
+        self.n_iter = 0
+        self.default_stopping = EarlyStopping()
+
+    def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False):
+        initializer = initializer or ConstantInit(a=0, b=0)
+        callback = callback or self.default_stopping
+        d = float(damping) if damping else 0.0
+        L = len(self.variables)
+        if not warm_start:
+            self.a_fwd = [initializer.init_a(None, v.id, "fwd") for v in self.variables]
+            self.a_bwd = [initializer.init_a(None, v.id, "bwd") for v in self.variables]
+            self.n_iter = 0
+        m = self.model
+        for it in range(max_iter):
+            for i, v in enumerate(self.variables):
+                f = m.prev_factor(v)
+                if f.n_prev == 0:
+                    new = f.compute_forward_state_evolution(self.a_bwd[i])
+                else:
+                    tau = self.taus[self.variables[i - 1].id]
+                    new = f.compute_forward_state_evolution(self.a_fwd[i - 1], self.a_bwd[i], tau)
+                self._check(new, f"{f.id}->{v.id}")
+                self.a_fwd[i] = d * self.a_fwd[i] + (1 - d) * new if d else new
+            for i in reversed(range(L)):
+                v = self.variables[i]
+                f = m.next_factor(v)
+                if f is None:
+                    continue
+                tau = self.taus[v.id]
+                if f.n_next == 0:
+                    new = f.compute_backward_state_evolution(self.a_fwd[i], tau)
+                else:
+                    new = f.compute_backward_state_evolution(self.a_fwd[i], self.a_bwd[i + 1], tau)
+                self._check(new, f"{f.id}->{v.id}")
+                self.a_bwd[i] = d * self.a_bwd[i] + (1 - d) * new if d else new
+            self.v = [1. / (self.a_fwd[i] + self.a_bwd[i]) for i in range(L)]     # base.py:167-170
+            self.n_iter += 1
+            if callback(self, it, max_iter):
+                break
+        return self
+
+    @staticmethod
+    def _check(a, where):
+        if np.any(np.isnan(a)):
+            raise ValueError(f"{where} a is nan")
+
+    def get_variables_data(self, ids="all", want_r=False):
+        return {v.id: dict(v=self.v[i]) for i, v in enumerate(self.variables)
+                if ids == "all" or v.id in ids}
+
+    def get_edges_data(self):
+        out = {}
+        for i, v in enumerate(self.variables):
+            out[(v.id, "fwd")] = self.a_fwd[i]
+            out[(v.id, "bwd")] = self.a_bwd[i]
+        return out
+
+
+__all__ = ["ExpectationPropagation", "StateEvolution", "EarlyStoppingEP", "EarlyStopping", "ConstantInit",
+           "CustomInit", "JoinCallback", "PassCallback", "TrackEvolution", "TrackErrors", "Factor", "Variable",
+           "_lib"]

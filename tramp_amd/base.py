@@ -1,0 +1,203 @@
+"""Node protocol of the factor graph (host side).
+
+Mirror of tramp/base.py: ``Variable`` / ``Factor`` with the message parse/emit
+methods the scheduler calls (``forward_message`` / ``backward_message`` /
+``forward_state_evolution`` / ``backward_state_evolution``, tramp/base.py:329-413)
+and the scalar message update (``compute_a_new`` :245-248).  The N-dimensional
+part of every update runs in HIP kernels behind the C ABI; this module only moves
+handles around.
+
+Messages are ``(source, target, data)`` triples like the reference's, with
+``data = dict(a=..., b=..., direction="fwd"|"bwd")``.  ``a`` is a ``DeviceArray``
+of ``batch`` doubles and ``b`` a ``DeviceArray`` [batch, n] in resident mode, or
+Python/NumPy values in strict (NumPy in, NumPy out) mode.
+"""
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, default_context, dtype_code
+
+AMIN = 1e-11   # tramp/base.py:238-239
+AMAX = 1e+11
+
+
+def inv(v):
+    "tramp/base.py:44-46"
+    return 1 / np.maximum(v, 1e-20)
+
+
+def filter_message(message, direction):
+    return [(s, t, d) for s, t, d in message if d["direction"] == direction]
+
+
+class ReprMixin:
+    def repr_init(self):
+        self._repr_kwargs = {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
+
+    def __repr__(self):
+        kw = getattr(self, "_repr_kwargs", {})
+        args = ",".join(f"{k}={v if np.isscalar(v) or v is None else type(v).__name__}"
+                        for k, v in kw.items())
+        return f"{self.__class__.__name__}({args})"
+
+
+class VecArg:
+    """Normalised view of a ``b``-type argument: device buffer [batch, n]."""
+
+    def __init__(self, ctx, b, dtype):
+        self.was_host = not isinstance(b, DeviceArray)
+        if self.was_host:
+            h = np.asarray(b, dtype=dtype)
+            if h.ndim == 0 or h.ndim > 2:
+                raise ValueError(f"b must be a vector [n] or an ensemble [batch, n], got shape {h.shape}")
+            self.host_shape = h.shape
+            self.dev = ctx.array(np.atleast_2d(h), dtype)
+        else:
+            if b.dtype != np.dtype(dtype):
+                raise TypeError(f"device vector has dtype {b.dtype}, factor computes in {np.dtype(dtype)}")
+            self.host_shape = b.shape
+            self.dev = b if b.ndim == 2 else b.reshape(1, b.shape[0])
+        self.batch, self.n = self.dev.shape
+
+
+class ScalArg:
+    """Normalised view of an ``a``-type argument: double[batch] on the device."""
+
+    def __init__(self, ctx, a, batch):
+        self.was_host = not isinstance(a, DeviceArray)
+        if self.was_host:
+            self.scalar_like = np.ndim(a) == 0
+            self.dev = ctx.scalars(a, batch)
+        else:
+            self.scalar_like = False
+            if a.size != batch or a.dtype != np.float64:
+                raise ValueError(f"a must hold {batch} doubles, got {a.shape} {a.dtype}")
+            self.dev = a
+
+
+def out_vec(ctx, like: VecArg, dtype):
+    return ctx.empty((like.batch, like.n), dtype)
+
+
+def ret_vec(dev, like: VecArg):
+    "Device result -> what the caller handed in (NumPy array or DeviceArray)."
+    if like.was_host:
+        return dev.get().reshape(like.host_shape)
+    return dev if len(like.host_shape) == 2 else dev.reshape(like.host_shape)
+
+
+def ret_scal(dev, like: ScalArg, vec_like: VecArg):
+    if like.was_host and vec_like.was_host:
+        h = dev.get()
+        if like.scalar_like and len(vec_like.host_shape) == 1:
+            return float(h[0])
+        return h
+    return dev
+
+
+class Variable(ReprMixin):
+    def __init__(self, id, n_prev, n_next):
+        self.id = id
+        self.n_prev = n_prev
+        self.n_next = n_next
+        self.repr_init()
+
+    def __matmul__(self, other):
+        from .models import DAG
+        return DAG(self) @ other
+
+
+class Factor(ReprMixin):
+    """Base of priors / channels / likelihoods (tramp/base.py:236-464)."""
+    AMAX = AMAX
+    AMIN = AMIN
+    dtype = np.float64
+    id = None
+
+    def _init_device(self, dtype=np.float64, ctx=None):
+        self.dtype = np.dtype(dtype)
+        self._dt = dtype_code(dtype)
+        self._ctx = ctx
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    def compute_a_new(self, v, a):
+        "tramp/base.py:245-248"
+        return np.clip(inv(v) - a, self.AMIN, self.AMAX)
+
+    def __matmul__(self, other):
+        from .models import DAG
+        return DAG(self) @ other
+
+    # -- message parse / emit (tramp/base.py:275-365)
+    def _parse_message_ab(self, message):
+        z = filter_message(message, "fwd")
+        x = filter_message(message, "bwd")
+        assert len(z) == self.n_prev and len(x) == self.n_next
+        az = bz = z_source = ax = bx = x_source = None
+        if self.n_prev == 1:
+            z_source, _, d = z[0]
+            az, bz = d["a"], d["b"]
+        if self.n_next == 1:
+            x_source, _, d = x[0]
+            ax, bx = d["a"], d["b"]
+        return z_source, x_source, az, bz, ax, bx
+
+    def _parse_message_a(self, message):
+        z = filter_message(message, "fwd")
+        x = filter_message(message, "bwd")
+        az = tau_z = z_source = ax = x_source = None
+        if self.n_prev == 1:
+            z_source, _, d = z[0]
+            az, tau_z = d["a"], d.get("tau")
+        if self.n_next == 1:
+            x_source, _, d = x[0]
+            ax = d["a"]
+        return z_source, x_source, az, ax, tau_z
+
+    def forward_message(self, message):
+        if self.n_next == 0:
+            return []
+        z_source, x_source, az, bz, ax, bx = self._parse_message_ab(message)
+        if self.n_prev == 0:
+            ax_new, bx_new = self.compute_forward_message(ax, bx)
+        else:
+            ax_new, bx_new = self.compute_forward_message(az, bz, ax, bx)
+        return [(self, x_source, dict(a=ax_new, b=bx_new, direction="fwd"))]
+
+    def backward_message(self, message):
+        if self.n_prev == 0:
+            return []
+        z_source, x_source, az, bz, ax, bx = self._parse_message_ab(message)
+        if self.n_next == 0:
+            az_new, bz_new = self.compute_backward_message(az, bz)
+        else:
+            az_new, bz_new = self.compute_backward_message(az, bz, ax, bx)
+        return [(self, z_source, dict(a=az_new, b=bz_new, direction="bwd"))]
+
+    def forward_state_evolution(self, message):
+        if self.n_next == 0:
+            return []
+        z_source, x_source, az, ax, tau_z = self._parse_message_a(message)
+        if self.n_prev == 0:
+            ax_new = self.compute_forward_state_evolution(ax)
+        else:
+            ax_new = self.compute_forward_state_evolution(az, ax, tau_z)
+        return [(self, x_source, dict(a=ax_new, direction="fwd"))]
+
+    def backward_state_evolution(self, message):
+        if self.n_prev == 0:
+            return []
+        z_source, x_source, az, ax, tau_z = self._parse_message_a(message)
+        if self.n_next == 0:
+            az_new = self.compute_backward_state_evolution(az, tau_z)
+        else:
+            az_new = self.compute_backward_state_evolution(az, ax, tau_z)
+        return [(self, z_source, dict(a=az_new, direction="bwd"))]
+
+
+__all__ = ["Variable", "Factor", "VecArg", "ScalArg", "filter_message", "inv", "AMIN", "AMAX", "_lib"]

@@ -1,0 +1,387 @@
+"""Channels (1-in / 1-out factors): host mirror of tramp.channels for the hot path.
+
+tramp/channels/base_channel.py, channels/linear/linear_channel.py,
+channels/linear/analytical_linear_channel.py,
+channels/activation/piecewise_linear_channel.py, channels/noise/gaussian_channel.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .base import Factor, VecArg, ScalArg, ret_vec, ret_scal
+from .device import DeviceArray
+from .ensembles import MarchenkoPasturEnsemble
+
+
+class Channel(Factor):
+    "tramp/channels/base_channel.py:5-97"
+    n_next = 1
+    n_prev = 1
+
+    def compute_forward_state_evolution(self, az, ax, tau_z):
+        return self.compute_a_new(self.compute_forward_error(az, ax, tau_z), ax)      # :19-22
+
+    def compute_backward_state_evolution(self, az, ax, tau_z):
+        return self.compute_a_new(self.compute_backward_error(az, ax, tau_z), az)     # :24-27
+
+    def compute_forward_overlap(self, az, ax, tau_z):
+        return self.second_moment(tau_z) - self.compute_forward_error(az, ax, tau_z)
+
+    def compute_backward_overlap(self, az, ax, tau_z):
+        return tau_z - self.compute_backward_error(az, ax, tau_z)
+
+
+class GaussianChannel(Channel):
+    """Additive Gaussian noise channel (tramp/channels/noise/gaussian_channel.py).
+
+    Only the closed-form scalar gains are needed on the hot path: once its output is
+    observed the model builder turns it into a GaussianLikelihood
+    (tramp/models/dag_algebra.py:22-23).
+    """
+
+    def __init__(self, var=1):
+        self.var = var
+        self.repr_init()
+        self.sigma = np.sqrt(var)
+        self.a = 1 / var
+
+    def sample(self, Z):
+        return Z + self.sigma * np.random.standard_normal(Z.shape)
+
+    def second_moment(self, tau_z):
+        return tau_z + self.var
+
+    def compute_forward_state_evolution(self, az, ax, tau_z):
+        return self.a / (self.a + az) * az                     # gaussian_channel.py:35-38
+
+    def compute_backward_state_evolution(self, az, ax, tau_z):
+        return self.a / (self.a + ax) * ax                     # :40-43
+
+
+# ------------------------------------------------------------------ componentwise
+class PiecewiseLinearChannel(Channel):
+    """x = f(z), f piecewise linear with two half-line regions (kernel K7).
+
+    tramp/channels/activation/piecewise_linear_channel.py:7-69; region tables of
+    SgnChannel :80-84, AbsChannel :87-91, ReluChannel :102-106.
+    """
+    _kind = None
+    _f = None
+
+    def __init__(self, dtype=np.float64, ctx=None):
+        self.name = {_lib.SGN: "sgn", _lib.ABS: "abs", _lib.RELU: "relu"}[self._kind]
+        self.repr_init()
+        self._init_device(dtype, ctx)
+
+    def sample(self, Z):
+        return type(self)._f(Z)
+
+    def second_moment(self, tau_z):
+        "piecewise_linear_channel.py:21-25 with the half-line moments of N(0, tau_z)"
+        # both regions have probability 1/2; |z| has mean sqrt(2 tau/pi), E z^2 = tau
+        if self._kind == _lib.SGN:
+            return 1.0
+        if self._kind == _lib.ABS:
+            return tau_z
+        return 0.5 * tau_z
+
+    def _run(self, direction, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+             old_b=None, want_posterior=False, want_mask=False):
+        ctx = self.ctx
+        z = VecArg(ctx, bz, self.dtype)
+        x = VecArg(ctx, bx, self.dtype)
+        if (z.batch, z.n) != (x.batch, x.n):
+            raise ValueError(f"bz {z.dev.shape} and bx {x.dev.shape} must have the same shape")
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((z.batch, z.n), self.dtype)
+        r = ctx.empty((z.batch, z.n), self.dtype) if want_posterior else None
+        v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        mask = ctx.empty((z.batch, z.n), np.uint8) if want_mask else None
+        ctx._call("tramp_pwl_channel", self._dt, self._kind, direction, z.n, z.batch,
+                  a_z.dev.ptr, z.dev.ptr, a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
+                  old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
+                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
+                  v.ptr if v is not None else None, mask.ptr if mask is not None else None)
+        tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
+        return tgt, a_t, a_new, b_new, r, v, mask
+
+    def compute_forward_posterior(self, az, bz, ax, bx):
+        t, a, _, _, r, v, _ = self._run(_lib.FWD, az, bz, ax, bx, want_posterior=True)
+        return ret_vec(r, t), ret_scal(v, a, t)
+
+    def compute_backward_posterior(self, az, bz, ax, bx):
+        t, a, _, _, r, v, _ = self._run(_lib.BWD, az, bz, ax, bx, want_posterior=True)
+        return ret_vec(r, t), ret_scal(v, a, t)
+
+    def compute_forward_message(self, az, bz, ax, bx, **kw):
+        t, a, a_new, b_new, _, _, _ = self._run(_lib.FWD, az, bz, ax, bx, **kw)
+        return ret_scal(a_new, a, t), ret_vec(b_new, t)
+
+    def compute_backward_message(self, az, bz, ax, bx, **kw):
+        t, a, a_new, b_new, _, _, _ = self._run(_lib.BWD, az, bz, ax, bx, **kw)
+        return ret_scal(a_new, a, t), ret_vec(b_new, t)
+
+    def branch_masks(self, az, bz, ax, bx):
+        """log_Phi 'x < 30' masks of the (pos, neg) regions as two boolean arrays
+        (tramp/utils/truncated_normal.py:27) - the index masks pinned bit-exact."""
+        t, _, _, _, _, _, mask = self._run(_lib.BWD, az, bz, ax, bx, want_mask=True)
+        m = mask.get().reshape(t.host_shape)
+        return (m & 1).astype(bool), ((m >> 1) & 1).astype(bool)
+
+    def _se(self, direction, az, ax, tau_z):
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        ax_h = np.broadcast_to(np.asarray(ax, dtype=np.float64), az_h.shape).copy()
+        tz_h = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_pwl_channel", self._kind, direction, az_h.shape[0], az_h.ctypes.data,
+                       ax_h.ctypes.data, tz_h.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+    def compute_forward_error(self, az, ax, tau_z):
+        "channels/base_channel.py:29-34 with LinearRegion.beliefs_measure (K14)"
+        return self._se(_lib.FWD, az, ax, tau_z)
+
+    def compute_backward_error(self, az, ax, tau_z):
+        "channels/base_channel.py:36-41 (K14)"
+        return self._se(_lib.BWD, az, ax, tau_z)
+
+
+class SgnChannel(PiecewiseLinearChannel):
+    _kind = _lib.SGN
+    _f = staticmethod(np.sign)
+
+
+class AbsChannel(PiecewiseLinearChannel):
+    _kind = _lib.ABS
+    _f = staticmethod(np.abs)
+
+
+class ReluChannel(PiecewiseLinearChannel):
+    _kind = _lib.RELU
+    _f = staticmethod(lambda z: np.maximum(0, z))
+
+
+# ------------------------------------------------------------------ dense linear
+def thin_svd_host(W):
+    """Thin SVD on the host (LAPACK), the factorisation LinearChannel.__init__ computes
+    (tramp/channels/linear/linear_channel.py:8-15,37-41) minus the parts that only
+    multiply zeros.  Returns Uk [M,k], sing [k], Vt [k,N], rank."""
+    W = np.asarray(W, dtype=np.float64)
+    U, s, Vt = np.linalg.svd(W, full_matrices=False)
+    tol = s.max() * max(W.shape) * np.finfo(np.float64).eps     # np.linalg.matrix_rank
+    rank = int(np.sum(s > tol))
+    return np.ascontiguousarray(U), s, np.ascontiguousarray(Vt), rank
+
+
+class LinearChannel(Channel):
+    """Linear channel x = W z (kernels K8, K9).
+
+    tramp/channels/linear/linear_channel.py:18-143.  ``W`` may be a NumPy array
+    (uploaded) or a DeviceArray [M, N].  ``svd``: "host" (LAPACK), "device"
+    (tramp_linear_factorize: rocBLAS Gram + rocSOLVER eigensolve) or "auto"
+    (host below 2048 on the smaller side).  Pre-computed thin factors can be
+    passed as ``factors=(Uk, sing, Vt, rank)``.  W itself is not kept on the
+    device: only Uk [M,k], Vt [k,N], sing enter the posterior (see csrc/linear.hip).
+    """
+
+    def __init__(self, W, precompute_svd=True, name="W", dtype=np.float64, ctx=None, svd="auto",
+                 factors=None, keep_W=False):
+        self.name = name
+        self.Nx, self.Nz = (int(s) for s in W.shape)
+        self.precompute_svd = precompute_svd
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        if not precompute_svd:
+            raise NotImplementedError("the per-call np.linalg.solve branch (linear_channel.py:79-82) "
+                                      "is not part of the HIP path; use precompute_svd=True")
+        self.alpha = self.Nx / self.Nz
+        ctx = self.ctx
+        k = min(self.Nx, self.Nz)
+        if factors is None:
+            on_dev = isinstance(W, DeviceArray)
+            if svd == "auto":
+                svd = "device" if (on_dev or k > 2048) else "host"
+            if svd == "host":
+                Wh = W.get() if on_dev else W
+                factors = thin_svd_host(Wh)
+            else:
+                Wd = W if on_dev else ctx.array(np.asarray(W, dtype=self.dtype), self.dtype)
+                if Wd.dtype != self.dtype:
+                    Wd = Wd.astype(self.dtype)
+                Uk = ctx.empty((self.Nx, k), self.dtype)
+                Vt = ctx.empty((k, self.Nz), self.dtype)
+                sing = ctx.empty((k,), np.float64)
+                rank = C.c_size_t()
+                ctx._call("tramp_linear_factorize", self._dt, self.Nx, self.Nz, Wd.ptr, Uk.ptr, Vt.ptr,
+                          sing.ptr, C.byref(rank))
+                factors = (Uk, sing, Vt, rank.value)
+        Uk, sing, Vt, rank = factors
+        self._Uk = Uk if isinstance(Uk, DeviceArray) else ctx.array(Uk, self.dtype)
+        self._Vt = Vt if isinstance(Vt, DeviceArray) else ctx.array(Vt, self.dtype)
+        self._sing = sing if isinstance(sing, DeviceArray) else ctx.array(sing, np.float64)
+        self.rank = int(rank)
+        sing_h = self._sing.get()
+        self.spectrum = np.zeros(self.Nz)                       # diag(S^T S), linear_channel.py:41
+        self.spectrum[:k] = sing_h**2
+        self.singular = self.spectrum[:self.rank]
+        self.W = W if keep_W else None
+        h = C.c_void_p()
+        ctx._call("tramp_linear_create", self._dt, self.Nx, self.Nz, self.rank, self._Uk.ptr,
+                  self._Vt.ptr, self._sing.ptr, C.byref(h))
+        self._handle = h
+
+    def __del__(self):
+        try:
+            if self._handle and self.ctx.handle:
+                self.ctx.lib.tramp_linear_destroy(self.ctx.handle, self._handle)
+        except Exception:
+            pass
+        self._handle = None
+
+    def sample(self, Z):
+        if self.W is None:
+            raise RuntimeError("LinearChannel was built with keep_W=False")
+        W = self.W.get() if isinstance(self.W, DeviceArray) else self.W
+        return W @ Z
+
+    def second_moment(self, tau_z):
+        return tau_z * self.spectrum.sum() / self.Nx            # linear_channel.py:55-56
+
+    # -- scalars (K9); host closed forms for host scalars, kernel for device scalars
+    def compute_n_eff(self, az, ax):
+        "linear_channel.py:58-67"
+        if ax == 0:
+            return 0.
+        if az / ax == 0:
+            return self.rank / self.Nz
+        return np.sum(self.singular / (az / ax + self.singular)) / self.Nz
+
+    def compute_backward_variance(self, az, ax):
+        "linear_channel.py:91-97"
+        az = np.maximum(1e-11, az)
+        return (1 - self.compute_n_eff(az, ax)) / az
+
+    def compute_forward_variance(self, az, ax):
+        "linear_channel.py:99-105"
+        if ax == 0:
+            return np.mean(self.singular) * self.rank / (self.Nx * az)
+        return self.compute_n_eff(az, ax) / (self.alpha * ax)
+
+    def compute_backward_error(self, az, ax, tau_z):
+        return self.compute_backward_variance(az, ax)           # :119-121
+
+    def compute_forward_error(self, az, ax, tau_z):
+        return self.compute_forward_variance(az, ax)            # :123-125
+
+    def device_variance(self, direction, az, ax):
+        "K9 on the device for a batch of (az, ax); returns (v, a_new, n_eff) as NumPy arrays."
+        ctx = self.ctx
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        a_z = ctx.scalars(az_h)
+        a_x = ctx.scalars(ax, az_h.shape[0])
+        outs = [ctx.empty((az_h.shape[0],), np.float64) for _ in range(3)]
+        ctx._call("tramp_linear_variance", self._handle, direction, az_h.shape[0], a_z.ptr, a_x.ptr,
+                  *[o.ptr for o in outs])
+        return [o.get() for o in outs]
+
+    # -- means + message (K8)
+    def _run(self, direction, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+             old_b=None, want_posterior=False):
+        ctx = self.ctx
+        z = VecArg(ctx, bz, self.dtype)
+        x = VecArg(ctx, bx, self.dtype)
+        if z.n != self.Nz or x.n != self.Nx or z.batch != x.batch:
+            raise ValueError(f"expected bz [batch,{self.Nz}] and bx [batch,{self.Nx}], "
+                             f"got {z.dev.shape} and {x.dev.shape}")
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
+        a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((tgt.batch, tgt.n), self.dtype)
+        r = ctx.empty((tgt.batch, tgt.n), self.dtype) if want_posterior else None
+        v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        ctx._call("tramp_linear_message", self._handle, direction, z.batch, a_z.dev.ptr, z.dev.ptr,
+                  a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
+                  old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
+                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
+                  v.ptr if v is not None else None)
+        return tgt, a_t, a_new, b_new, r, v
+
+    def compute_backward_mean(self, az, bz, ax, bx):
+        "linear_channel.py:69-83"
+        return self.compute_backward_posterior(az, bz, ax, bx)[0]
+
+    def compute_forward_mean(self, az, bz, ax, bx):
+        "linear_channel.py:85-89"
+        return self.compute_forward_posterior(az, bz, ax, bx)[0]
+
+    def compute_backward_posterior(self, az, bz, ax, bx):
+        t, a, _, _, r, v = self._run(_lib.BWD, az, bz, ax, bx, want_posterior=True)
+        return ret_vec(r, t), ret_scal(v, a, t)
+
+    def compute_forward_posterior(self, az, bz, ax, bx):
+        t, a, _, _, r, v = self._run(_lib.FWD, az, bz, ax, bx, want_posterior=True)
+        return ret_vec(r, t), ret_scal(v, a, t)
+
+    def compute_forward_message(self, az, bz, ax, bx, **kw):
+        t, a, a_new, b_new, _, _ = self._run(_lib.FWD, az, bz, ax, bx, **kw)
+        return ret_scal(a_new, a, t), ret_vec(b_new, t)
+
+    def compute_backward_message(self, az, bz, ax, bx, **kw):
+        t, a, a_new, b_new, _, _ = self._run(_lib.BWD, az, bz, ax, bx, **kw)
+        return ret_scal(a_new, a, t), ret_vec(b_new, t)
+
+
+class AnalyticalLinearChannel(Channel):
+    "SE-only linear channel with closed-form spectrum transforms (analytical_linear_channel.py:8-62)"
+
+    def __init__(self, ensemble, name="W"):
+        self.name = name
+        self.alpha = ensemble.alpha
+        self.repr_init()
+        self.ensemble = ensemble
+
+    def second_moment(self, tau_z):
+        return tau_z * (self.ensemble.mean_spectrum / self.alpha)
+
+    def compute_n_eff(self, az, ax):
+        if ax == 0:
+            return 0.
+        if az / ax == 0:
+            return min(1, self.alpha)
+        return 1 - self.ensemble.eta_transform(ax / az)
+
+    def compute_backward_error(self, az, ax, tau_z):
+        az = np.maximum(1e-11, az)
+        return (1 - self.compute_n_eff(az, ax)) / az
+
+    def compute_forward_error(self, az, ax, tau_z):
+        if ax == 0:
+            return self.ensemble.mean_spectrum / (self.alpha * az)
+        return self.compute_n_eff(az, ax) / (self.alpha * ax)
+
+
+class MarchenkoPasturChannel(AnalyticalLinearChannel):
+    "analytical_linear_channel.py:65-90"
+
+    def __init__(self, alpha, name="W"):
+        super().__init__(ensemble=MarchenkoPasturEnsemble(alpha=alpha), name=name)
+
+
+CHANNEL_CLASSES = {
+    "gaussian": GaussianChannel,
+    "linear": LinearChannel,
+    "analytical": AnalyticalLinearChannel,
+    "marchenko": MarchenkoPasturChannel,
+    "sgn": SgnChannel,
+    "abs": AbsChannel,
+    "relu": ReluChannel,
+}
+
+
+def get_channel(channel_type, **kwargs):
+    "tramp/channels/__init__.py:68-70"
+    return CHANNEL_CLASSES[channel_type](**kwargs)

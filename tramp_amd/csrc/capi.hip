@@ -1,0 +1,199 @@
+// capi.hip - context, device memory and timing entry points of the C ABI.
+#include "common.h"
+
+extern "C" const char* tramp_version(void) { return "tramp_hip 0.1 (gfx950)"; }
+
+extern "C" int tramp_device_count(int* n) {
+    if (!n) return TRAMP_EINVAL;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_ctx_create(int device, tramp_ctx** out) {
+    if (!out) return TRAMP_EINVAL;
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) {
+        (void)hipGetLastError();
+        return TRAMP_ENODEV;
+    }
+    if (device < 0 || device >= c) return TRAMP_EINVAL;
+    tramp_ctx* ctx = new (std::nothrow) tramp_ctx();
+    if (!ctx) return TRAMP_ENOMEM;
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return TRAMP_EHIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    ctx->ws_bytes = 4u << 20;
+    if (hipMalloc((void**)&ctx->ws, ctx->ws_bytes) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return TRAMP_ENOMEM;
+    }
+    ctx->hscratch_bytes = 1u << 20;
+    if (hipHostMalloc((void**)&ctx->hscratch, ctx->hscratch_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(ctx->ws);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return TRAMP_ENOMEM;
+    }
+    *out = ctx;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
+    if (!ctx) return TRAMP_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->hscratch) (void)hipHostFree(ctx->hscratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TRAMP_OK;
+}
+
+extern "C" const char* tramp_last_error(const tramp_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int tramp_ws_reserve(tramp_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return TRAMP_OK;
+    size_t nb = ctx->ws_bytes;
+    while (nb < bytes) nb *= 2;
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    if (hipMalloc((void**)&ctx->ws, nb) != hipSuccess) {
+        (void)hipGetLastError();
+        return tramp_fail(ctx, TRAMP_ENOMEM, "workspace", "hipMalloc failed");
+    }
+    ctx->ws_bytes = nb;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_sync(tramp_ctx* ctx) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_ctx_stream(tramp_ctx* ctx, void** stream) {
+    if (!ctx || !stream) return TRAMP_EINVAL;
+    *stream = (void*)ctx->stream;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_device_name(tramp_ctx* ctx, char* out, size_t cap) {
+    if (!ctx || !out || !cap) return TRAMP_EINVAL;
+    hipDeviceProp_t prop;
+    TRAMP_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(out, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_mem_info(tramp_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return TRAMP_EINVAL;
+    TRAMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    TRAMP_HIP_CHECK(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_buf_alloc(tramp_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return TRAMP_EINVAL;
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    TRAMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return tramp_fail(ctx, e == hipErrorOutOfMemory ? TRAMP_ENOMEM : TRAMP_EHIP, "hipMalloc",
+                          hipGetErrorString(e));
+    }
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_buf_free(tramp_ctx* ctx, void* dptr) {
+    if (!ctx) return TRAMP_EINVAL;
+    if (!dptr) return TRAMP_OK;
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipFree(dptr));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_h2d(tramp_ctx* ctx, void* dst_d, const void* src_h, size_t bytes) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, (dst_d && src_h) || bytes == 0);
+    if (!bytes) return TRAMP_OK;
+    // pageable source: the call returns once the staging copy is done
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_d2h(tramp_ctx* ctx, void* dst_h, const void* src_d, size_t bytes) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, (dst_h && src_d) || bytes == 0);
+    if (!bytes) return TRAMP_OK;
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_d2d(tramp_ctx* ctx, void* dst_d, const void* src_d, size_t bytes) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, (dst_d && src_d) || bytes == 0);
+    if (!bytes) return TRAMP_OK;
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(dst_d, src_d, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_memset(tramp_ctx* ctx, void* dst_d, int value, size_t bytes) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, dst_d || bytes == 0);
+    if (!bytes) return TRAMP_OK;
+    TRAMP_HIP_CHECK(ctx, hipMemsetAsync(dst_d, value, bytes, ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_event_create(tramp_ctx* ctx, tramp_event** ev) {
+    if (!ctx || !ev) return TRAMP_EINVAL;
+    tramp_event* e = new (std::nothrow) tramp_event();
+    if (!e) return TRAMP_ENOMEM;
+    hipError_t rc = hipEventCreate(&e->ev);
+    if (rc != hipSuccess) {
+        delete e;
+        return tramp_fail(ctx, TRAMP_EHIP, "hipEventCreate", hipGetErrorString(rc));
+    }
+    *ev = e;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_event_destroy(tramp_ctx* ctx, tramp_event* ev) {
+    if (!ctx || !ev) return TRAMP_EINVAL;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_event_record(tramp_ctx* ctx, tramp_event* ev) {
+    if (!ctx || !ev) return TRAMP_EINVAL;
+    TRAMP_HIP_CHECK(ctx, hipEventRecord(ev->ev, ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_event_elapsed_ms(tramp_ctx* ctx, tramp_event* start, tramp_event* stop, float* ms) {
+    if (!ctx || !start || !stop || !ms) return TRAMP_EINVAL;
+    TRAMP_HIP_CHECK(ctx, hipEventSynchronize(stop->ev));
+    TRAMP_HIP_CHECK(ctx, hipEventElapsedTime(ms, start->ev, stop->ev));
+    return TRAMP_OK;
+}

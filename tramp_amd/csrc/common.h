@@ -1,0 +1,125 @@
+// common.h - context, error handling and wave/block reduction helpers (gfx950).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tramp_hip.h"
+
+struct tramp_ctx {
+    int device;
+    hipStream_t stream;
+    double* ws;          // reduction workspace (device)
+    size_t ws_bytes;
+    double* hscratch;    // pinned host scratch for SE scalar round trips
+    size_t hscratch_bytes;
+    int num_cu;
+    char err[512];
+};
+
+struct tramp_event {
+    hipEvent_t ev;
+};
+
+static inline int tramp_fail(tramp_ctx* ctx, int code, const char* what, const char* detail) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, detail ? detail : "");
+    return code;
+}
+
+#define TRAMP_HIP_CHECK(ctx, call)                                                   \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) return tramp_fail(ctx, TRAMP_EHIP, #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define TRAMP_REQUIRE(ctx, cond)                                                     \
+    do {                                                                             \
+        if (!(cond)) return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", #cond); \
+    } while (0)
+
+#define TRAMP_LAUNCH_CHECK(ctx)                                                      \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) return tramp_fail(ctx, TRAMP_EHIP, "kernel launch", hipGetErrorString(e_)); \
+    } while (0)
+
+// Grow the context's reduction workspace to at least `bytes` (synchronises when it grows).
+int tramp_ws_reserve(tramp_ctx* ctx, size_t bytes);
+
+constexpr int kBlock = 256;           // 4 wavefronts of 64
+constexpr int kWave = 64;
+constexpr int kMaxBlocksPerInst = 1024;
+
+// ---- wave64 / block reductions (deterministic: fixed tree) ------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread block; result valid in every thread. `smem` >= 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double* smem) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();                 // protect smem reuse between calls
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    double t = smem[0];
+#pragma unroll
+    for (int i = 1; i < kBlock / kWave; ++i) t += smem[i];
+    return t;
+}
+
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v,
+                                                            unsigned long long* smem) {
+    v = wave_sum_u64(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    unsigned long long t = smem[0];
+#pragma unroll
+    for (int i = 1; i < kBlock / kWave; ++i) t += smem[i];
+    return t;
+}
+
+// 16-byte vector views of the element type.
+template <typename T> struct Vec;
+template <> struct Vec<double> {
+    using type = double2;
+    static constexpr int N = 2;
+};
+template <> struct Vec<float> {
+    using type = float4;
+    static constexpr int N = 4;
+};
+
+template <typename T> __device__ __forceinline__ T vget(const typename Vec<T>::type& v, int i);
+template <> __device__ __forceinline__ double vget<double>(const double2& v, int i) { return i ? v.y : v.x; }
+template <> __device__ __forceinline__ float vget<float>(const float4& v, int i) {
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+template <typename T> __device__ __forceinline__ void vset(typename Vec<T>::type& v, int i, T x);
+template <> __device__ __forceinline__ void vset<double>(double2& v, int i, double x) { if (i) v.y = x; else v.x = x; }
+template <> __device__ __forceinline__ void vset<float>(float4& v, int i, float x) {
+    if (i == 0) v.x = x; else if (i == 1) v.y = x; else if (i == 2) v.z = x; else v.w = x;
+}
+
+static inline size_t dtype_size(int dtype) { return dtype == TRAMP_F64 ? 8 : 4; }
+
+// blocks per instance for an n-element streaming pass (>= 4 vectors of work per thread)
+static inline int blocks_for(size_t n, int vecN) {
+    size_t per_block = (size_t)kBlock * vecN * 4;
+    size_t nb = (n + per_block - 1) / per_block;
+    if (nb < 1) nb = 1;
+    if (nb > kMaxBlocksPerInst) nb = kMaxBlocksPerInst;
+    return (int)nb;
+}

@@ -1,0 +1,746 @@
+// ew_kernels.hip - componentwise factor updates (K1-K7, K10-K12) for gfx950.
+//
+// Every isotropic factor update is "posterior moments (r_i, v_i) per component,
+// v = mean_i v_i, then the message update with the scalar a_new(v)"
+// (tramp/base.py:250-255).  b_new depends on the global mean, so each update is
+// two streaming passes over the instance:
+//   pass 1  read inputs, reduce sum(v_i) per block        -> partials[batch, nblk]
+//   pass 2  every block folds the partials (fixed order, deterministic), forms
+//           a_new, recomputes r_i and writes b_new (+ optional damping, r, masks)
+// r is recomputed rather than round-tripped through HBM.  Algorithmic traffic is
+// 2T (priors) / 3T (likelihoods, channels) bytes per component; the two-pass form
+// moves one extra read of the inputs, which stays in L2 / Infinity Cache for
+// single instances.  HBM-bound: 16-byte vector loads/stores, 64-wide shuffles,
+// one LDS hop per block.  No atomics, results are run-to-run reproducible.
+//
+// Built with -ffp-contract=off so that f64 branch masks see the same operands as
+// the NumPy reference (no FMA contraction).
+#include "common.h"
+#include "tramp_math.h"
+
+using tmath::RV;
+
+// ---------------------------------------------------------------- functors
+// Each Op: setup(b) loads the per-instance scalars; eval(in0, in1) -> (r, v, mask);
+// a_msg / TARGET select the message being updated.
+template <typename T> struct EwOut { T r, v; unsigned mask; };
+
+template <typename T> struct GbOp {       // K1; in0 = bx
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    double a0, b0, eta;
+    T a, lg, b0T, etaT;
+    double a_msg;
+    __device__ void setup(size_t b) {
+        a_msg = ax[b];
+        double ad = a_msg + a0;
+        a = T(ad);
+        lg = T(log(2 * tmath::kPi / ad));
+        b0T = T(b0);
+        etaT = T(eta);
+    }
+    __device__ EwOut<T> eval(T x0, T) const {
+        RV<T> o = tmath::gb_posterior<T>(x0, a, lg, b0T, etaT);
+        return {o.r, o.v, 0u};
+    }
+};
+
+template <typename T> struct L1Op {       // K2; in0 = bx
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    double gamma;
+    T inv_ax, gT;
+    double a_msg;
+    __device__ void setup(size_t b) {
+        a_msg = ax[b];
+        inv_ax = T(1.0 / a_msg);
+        gT = T(gamma);
+    }
+    __device__ EwOut<T> eval(T x0, T) const {
+        RV<T> o = tmath::l1_posterior<T>(x0, inv_ax, gT);
+        return {o.r, o.v, tmath::l1_support<T>(x0, gT) ? 1u : 0u};
+    }
+};
+
+template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    T a, v0;
+    double a_msg;
+    __device__ void setup(size_t b) {
+        a_msg = az[b];
+        a = T(a_msg);
+        v0 = T(1.0 / a_msg);
+    }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        RV<T> o = tmath::sgn_lik_posterior<T>(x0, x1, a, v0);
+        return {o.r, o.v, 0u};
+    }
+};
+
+template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    double a_msg;
+    __device__ void setup(size_t b) { a_msg = az[b]; }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        RV<T> o = tmath::abs_lik_posterior<T>(x0, x1);
+        return {o.r, o.v, 0u};
+    }
+};
+
+template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 = bx
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = FWD ? 1 : 0;
+    const double* az;
+    const double* ax;
+    T azT, axT;
+    double a_msg;
+    __device__ void setup(size_t b) {
+        double z = az[b], x = ax[b];
+        azT = T(z);
+        axT = T(x);
+        a_msg = FWD ? x : z;
+    }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        tmath::PwlOut<T> o = tmath::pwl_posterior<T, KIND, FWD>(x0, x1, azT, axT);
+        return {o.r, o.v, o.mask};
+    }
+};
+
+// ---------------------------------------------------------------- pass 1
+template <typename T> __device__ __forceinline__ bool not_finite(T x) { return (x - x) != T(0); }
+
+template <typename T, typename Op, bool VEC>
+__global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, const T* __restrict__ in0,
+                                                   const T* __restrict__ in1,
+                                                   double* __restrict__ partials,
+                                                   unsigned long long* __restrict__ pcount) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    __shared__ double smem[kBlock / kWave];
+    __shared__ unsigned long long smem_u[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    op.setup(b);
+    const T* p0 = in0 + b * n;
+    const T* p1 = (Op::NIN > 1) ? in1 + b * n : nullptr;
+    double acc = 0.0;
+    unsigned long long cnt = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    if (VEC) {
+        const size_t nv = n / VN;
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) {
+            V v0 = reinterpret_cast<const V*>(p0)[i];
+            V v1 = v0;
+            if (Op::NIN > 1) v1 = reinterpret_cast<const V*>(p1)[i];
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                EwOut<T> o = op.eval(vget<T>(v0, j), vget<T>(v1, j));
+                acc += (double)o.v;
+                if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
+                cnt += o.mask & 1u;
+            }
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            T x0 = p0[i];
+            T x1 = (Op::NIN > 1) ? p1[i] : x0;
+            EwOut<T> o = op.eval(x0, x1);
+            acc += (double)o.v;
+            if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
+            cnt += o.mask & 1u;
+        }
+    }
+    acc = block_sum(acc, smem);
+    if (pcount) cnt = block_sum_u64(cnt, smem_u);
+    if (threadIdx.x == 0) {
+        partials[b * gridDim.x + blockIdx.x] = acc;
+        if (pcount) pcount[b * gridDim.x + blockIdx.x] = cnt;
+    }
+}
+
+// ---------------------------------------------------------------- pass 2
+struct MsgOut {
+    double damping;
+    const double* a_old;
+    const void* b_old;
+    double* a_new;
+    void* b_new;
+    void* r;
+    double* v;
+    unsigned long long* count;
+    uint8_t* mask;
+};
+
+template <typename T, typename Op, bool VEC>
+__global__ __launch_bounds__(kBlock) void ew_pass2(Op op, size_t n, const T* __restrict__ in0,
+                                                   const T* __restrict__ in1,
+                                                   const double* __restrict__ partials,
+                                                   const unsigned long long* __restrict__ pcount,
+                                                   int nblk1, MsgOut out) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    __shared__ double smem[kBlock / kWave];
+    __shared__ unsigned long long smem_u[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    op.setup(b);
+    // fold the pass-1 partials of this instance: same order in every block
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk1; i += kBlock) s += partials[b * nblk1 + i];
+    s = block_sum(s, smem);
+    const double v = s / (double)n;
+    const double a_in = op.a_msg;
+    const double a_new = tmath::a_new_of(v, a_in);
+    const double d = out.damping;
+    if (blockIdx.x == 0) {
+        if (out.count) {
+            unsigned long long c = 0;
+            for (int i = threadIdx.x; i < nblk1; i += kBlock) c += pcount[b * nblk1 + i];
+            c = block_sum_u64(c, smem_u);
+            if (threadIdx.x == 0) out.count[b] = c;
+        }
+        if (threadIdx.x == 0) {
+            double a_out = a_new;
+            if (d != 0.0) a_out = d * out.a_old[b] + (1.0 - d) * a_new;
+            out.a_new[b] = a_out;
+            if (out.v) out.v[b] = v;
+        }
+    }
+    const T vinv = T(a_in + a_new);
+    const T dT = T(d), omd = T(1.0 - d);
+    const T* p0 = in0 + b * n;
+    const T* p1 = (Op::NIN > 1) ? in1 + b * n : nullptr;
+    const T* ptgt = (Op::TARGET == 0) ? p0 : p1;
+    T* bo = reinterpret_cast<T*>(out.b_new) + b * n;
+    const T* bold = out.b_old ? reinterpret_cast<const T*>(out.b_old) + b * n : nullptr;
+    T* ro = out.r ? reinterpret_cast<T*>(out.r) + b * n : nullptr;
+    uint8_t* mo = out.mask ? out.mask + b * n : nullptr;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    if (VEC) {
+        const size_t nv = n / VN;
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) {
+            V v0 = reinterpret_cast<const V*>(p0)[i];
+            V v1 = v0;
+            if (Op::NIN > 1) v1 = reinterpret_cast<const V*>(p1)[i];
+            V vo, vr, vold;
+            if (bold) vold = reinterpret_cast<const V*>(bold)[i];
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                T x0 = vget<T>(v0, j), x1 = vget<T>(v1, j);
+                EwOut<T> o = op.eval(x0, x1);
+                T bt = (Op::TARGET == 0) ? x0 : x1;
+                T bn = o.r * vinv - bt;
+                if (bold) bn = dT * vget<T>(vold, j) + omd * bn;
+                vset<T>(vo, j, bn);
+                vset<T>(vr, j, o.r);
+                if (mo) mo[i * VN + j] = (uint8_t)o.mask;
+            }
+            reinterpret_cast<V*>(bo)[i] = vo;
+            if (ro) reinterpret_cast<V*>(ro)[i] = vr;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            T x0 = p0[i];
+            T x1 = (Op::NIN > 1) ? p1[i] : x0;
+            EwOut<T> o = op.eval(x0, x1);
+            T bn = o.r * vinv - ptgt[i];
+            if (bold) bn = dT * bold[i] + omd * bn;
+            bo[i] = bn;
+            if (ro) ro[i] = o.r;
+            if (mo) mo[i] = (uint8_t)o.mask;
+        }
+    }
+}
+
+template <typename T, typename Op>
+static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0,
+                        const void* in1, const MsgOut& out) {
+    TRAMP_REQUIRE(ctx, in0 && out.a_new && out.b_new);
+    TRAMP_REQUIRE(ctx, Op::NIN == 1 || in1);
+    if (n == 0 || batch == 0) return TRAMP_OK;
+    TRAMP_REQUIRE(ctx, batch <= 65535);
+    TRAMP_REQUIRE(ctx, out.damping == 0.0 || (out.a_old && out.b_old));
+    constexpr int VN = Vec<T>::N;
+    const bool vec = (n % VN) == 0;
+    const int nblk = blocks_for(n, VN);
+    const size_t need = batch * (size_t)nblk * (sizeof(double) + sizeof(unsigned long long));
+    int rc = tramp_ws_reserve(ctx, need);
+    if (rc) return rc;
+    double* partials = ctx->ws;
+    unsigned long long* pcount =
+        out.count ? reinterpret_cast<unsigned long long*>(ctx->ws + batch * (size_t)nblk) : nullptr;
+    dim3 grid(nblk, (unsigned)batch), block(kBlock);
+    MsgOut o = out;
+    if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
+    const T* p0 = reinterpret_cast<const T*>(in0);
+    const T* p1 = reinterpret_cast<const T*>(in1);
+    if (vec) {
+        hipLaunchKernelGGL((ew_pass1<T, Op, true>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount);
+        hipLaunchKernelGGL((ew_pass2<T, Op, true>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount, nblk, o);
+    } else {
+        hipLaunchKernelGGL((ew_pass1<T, Op, false>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount);
+        hipLaunchKernelGGL((ew_pass2<T, Op, false>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount, nblk, o);
+    }
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+#define DISPATCH_DTYPE(ctx, dtype, CALL_F32, CALL_F64)                    \
+    do {                                                                  \
+        if ((dtype) == TRAMP_F32) return CALL_F32;                        \
+        if ((dtype) == TRAMP_F64) return CALL_F64;                        \
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype"); \
+    } while (0)
+
+// ---------------------------------------------------------------- C ABI: K1, K2, K4, K5, K7
+extern "C" int tramp_gb_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                  const double* ax_d, const void* bx_d, double rho, double mean,
+                                  double var, double damping, const double* a_old_d,
+                                  const void* b_old_d, double* a_new_d, void* b_new_d, void* r_d,
+                                  double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax_d && rho > 0.0 && rho < 1.0 && var > 0.0);
+    // natural parameters of the prior (gauss_bernoulli_prior.py:32-36)
+    const double a0 = 1.0 / var, b0 = mean / var;
+    const double eta = 0.5 * (b0 * b0 / a0 + log(2 * tmath::kPi / a0)) - log(rho / (1 - rho));
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    GbOp<float> of{ax_d, a0, b0, eta};
+    GbOp<double> od{ax_d, a0, b0, eta};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, out)));
+}
+
+extern "C" int tramp_l1_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                  const double* ax_d, const void* bx_d, double gamma,
+                                  double damping, const double* a_old_d, const void* b_old_d,
+                                  double* a_new_d, void* b_new_d, void* r_d, double* v_d,
+                                  unsigned long long* count_d, uint8_t* mask_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax_d && gamma >= 0.0);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, count_d, mask_d};
+    L1Op<float> of{ax_d, gamma};
+    L1Op<double> od{ax_d, gamma};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, out)));
+}
+
+extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                 const double* az_d, const void* bz_d, const void* y_d,
+                                 double damping, const double* a_old_d, const void* b_old_d,
+                                 double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    SgnLikOp<float> of{az_d};
+    SgnLikOp<double> od{az_d};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, out)));
+}
+
+extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                 const double* az_d, const void* bz_d, const void* y_d,
+                                 double damping, const double* a_old_d, const void* b_old_d,
+                                 double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    AbsLikOp<float> of{az_d};
+    AbsLikOp<double> od{az_d};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, out)));
+}
+
+template <typename T, int KIND>
+static int pwl_dir(tramp_ctx* ctx, int dir, size_t n, size_t batch, const double* az_d,
+                   const void* bz_d, const double* ax_d, const void* bx_d, const MsgOut& out) {
+    if (dir == TRAMP_FWD) {
+        PwlOp<T, KIND, true> op{az_d, ax_d};
+        return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, out);
+    }
+    PwlOp<T, KIND, false> op{az_d, ax_d};
+    return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, out);
+}
+
+template <typename T>
+static int pwl_kind(tramp_ctx* ctx, int kind, int dir, size_t n, size_t batch, const double* az_d,
+                    const void* bz_d, const double* ax_d, const void* bx_d, const MsgOut& out) {
+    switch (kind) {
+        case TRAMP_SGN: return pwl_dir<T, 0>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out);
+        case TRAMP_ABS: return pwl_dir<T, 1>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out);
+        case TRAMP_RELU: return pwl_dir<T, 2>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out);
+    }
+    return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "kind");
+}
+
+extern "C" int tramp_pwl_channel(tramp_ctx* ctx, int dtype, int kind, int dir, size_t n,
+                                 size_t batch, const double* az_d, const void* bz_d,
+                                 const double* ax_d, const void* bx_d, double damping,
+                                 const double* a_old_d, const void* b_old_d, double* a_new_d,
+                                 void* b_new_d, void* r_d, double* v_d, uint8_t* mask_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && ax_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, mask_d};
+    DISPATCH_DTYPE(ctx, dtype,
+                   (pwl_kind<float>(ctx, kind, dir, n, batch, az_d, bz_d, ax_d, bx_d, out)),
+                   (pwl_kind<double>(ctx, kind, dir, n, batch, az_d, bz_d, ax_d, bx_d, out)));
+}
+
+// ---------------------------------------------------------------- K3 / K6 constant messages
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_fill_kernel(size_t count, const T* __restrict__ y,
+                                                            T scale, T value, T* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock)
+        out[i] = y ? y[i] / scale : value;     // y / var as the reference (gaussian_likelihood.py:17)
+}
+
+__global__ void fill_f64_kernel(size_t count, double value, double* out) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock)
+        out[i] = value;
+}
+
+static inline int grid_for(size_t count) {
+    size_t g = (count + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int tramp_fill_f64(tramp_ctx* ctx, double* dst_d, size_t count, double value) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, dst_d || count == 0);
+    if (!count) return TRAMP_OK;
+    hipLaunchKernelGGL(fill_f64_kernel, dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, count, value, dst_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_fill(tramp_ctx* ctx, int dtype, void* dst_d, size_t count, double value) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, dst_d || count == 0);
+    if (!count) return TRAMP_OK;
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((scale_fill_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream,
+                           count, (const double*)nullptr, 1.0, value, (double*)dst_d);
+    else if (dtype == TRAMP_F32)
+        hipLaunchKernelGGL((scale_fill_kernel<float>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream,
+                           count, (const float*)nullptr, 1.0f, (float)value, (float*)dst_d);
+    else
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_gauss_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double mean,
+                                     double var, double* a_new_d, void* b_new_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, var > 0.0 && a_new_d && b_new_d);
+    int rc = tramp_fill_f64(ctx, a_new_d, batch, 1.0 / var);
+    if (rc) return rc;
+    return tramp_fill(ctx, dtype, b_new_d, n * batch, mean / var);
+}
+
+extern "C" int tramp_gauss_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                   const void* y_d, double var, double* a_new_d, void* b_new_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, var > 0.0 && a_new_d && b_new_d && y_d);
+    int rc = tramp_fill_f64(ctx, a_new_d, batch, 1.0 / var);
+    if (rc) return rc;
+    const size_t count = n * batch;
+    if (!count) return TRAMP_OK;
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((scale_fill_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream,
+                           count, (const double*)y_d, var, 0.0, (double*)b_new_d);
+    else if (dtype == TRAMP_F32)
+        hipLaunchKernelGGL((scale_fill_kernel<float>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream,
+                           count, (const float*)y_d, (float)var, 0.0f, (float*)b_new_d);
+    else
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// ---------------------------------------------------------------- diagonal beliefs (K1d..K5d)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, const T* __restrict__ a,
+                                                      const T* __restrict__ b, const T* __restrict__ in2,
+                                                      double p0, double p1, double p2,
+                                                      T* __restrict__ a_new, T* __restrict__ b_new,
+                                                      T* __restrict__ r_out, T* __restrict__ v_out) {
+    double a0 = 0, b0 = 0, eta = 0;
+    if (which == 0) {
+        a0 = 1.0 / p2;
+        b0 = p1 / p2;
+        eta = 0.5 * (b0 * b0 / a0 + log(2 * tmath::kPi / a0)) - log(p0 / (1 - p0));
+    }
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) {
+        T ai = a[i], bi = b[i];
+        RV<T> o;
+        if (which == 0) {
+            T at = ai + T(a0);
+            o = tmath::gb_posterior<T>(bi, at, tmath::log_(T(2 * tmath::kPi) / at), T(b0), T(eta));
+        } else if (which == 1) {
+            o = tmath::l1_posterior<T>(bi, T(1) / ai, T(p0));
+        } else if (which == 2) {
+            o = tmath::sgn_lik_posterior<T>(bi, in2[i], ai, T(1) / ai);
+        } else {
+            o = tmath::abs_lik_posterior<T>(bi, in2[i]);
+        }
+        // element-wise compute_ab_new (tramp/base.py:250-255)
+        double an = tmath::a_new_of((double)o.v, (double)ai);
+        T vinv = ai + T(an);
+        if (a_new) a_new[i] = T(an);
+        if (b_new) b_new[i] = o.r * vinv - bi;
+        if (r_out) r_out[i] = o.r;
+        if (v_out) v_out[i] = o.v;
+    }
+}
+
+extern "C" int tramp_diag_factor(tramp_ctx* ctx, int dtype, int which, size_t count, const void* a_d,
+                                 const void* b_d, const void* in2_d, double p0, double p1, double p2,
+                                 void* a_new_d, void* b_new_d, void* r_d, void* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, which >= 0 && which <= 3 && a_d && b_d);
+    TRAMP_REQUIRE(ctx, which < 2 || in2_d);
+    if (!count) return TRAMP_OK;
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((diag_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, which,
+                           count, (const double*)a_d, (const double*)b_d, (const double*)in2_d, p0, p1, p2,
+                           (double*)a_new_d, (double*)b_new_d, (double*)r_d, (double*)v_d);
+    else if (dtype == TRAMP_F32)
+        hipLaunchKernelGGL((diag_kernel<float>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, which,
+                           count, (const float*)a_d, (const float*)b_d, (const float*)in2_d, p0, p1, p2,
+                           (float*)a_new_d, (float*)b_new_d, (float*)r_d, (float*)v_d);
+    else
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// ---------------------------------------------------------------- K11 variable posterior + norms
+// One streaming pass (no global dependency): r, and per-block partial sums folded
+// by a second tiny kernel.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void var_post_kernel(size_t n, const double* __restrict__ a1,
+                                                          const T* __restrict__ b1,
+                                                          const double* __restrict__ a2,
+                                                          const T* __restrict__ b2,
+                                                          const T* __restrict__ r_old, T* __restrict__ r,
+                                                          double* __restrict__ v,
+                                                          double* __restrict__ partials) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    // Variable.posterior_ab: python sum() starts from 0 (tramp/base.py:152-155)
+    const double a_hat = 0.0 + a1[b] + a2[b];
+    const T ah = T(a_hat);
+    const T* p1 = b1 + b * n;
+    const T* p2 = b2 + b * n;
+    const T* po = r_old ? r_old + b * n : nullptr;
+    T* pr = r + b * n;
+    double sd = 0.0, sn = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        T ri = (p1[i] + p2[i]) / ah;
+        T old = po ? po[i] : T(0);
+        double dd = (double)ri - (double)old;
+        sd += dd * dd;
+        sn += (double)ri * (double)ri;
+        pr[i] = ri;
+    }
+    sd = block_sum(sd, smem);
+    sn = block_sum(sn, smem);
+    if (threadIdx.x == 0) {
+        partials[(b * gridDim.x + blockIdx.x) * 2 + 0] = sd;
+        partials[(b * gridDim.x + blockIdx.x) * 2 + 1] = sn;
+        if (blockIdx.x == 0 && v) v[b] = 1.0 / a_hat;
+    }
+}
+
+// out_q[b] = sum_k partials[(b*nblk + k)*nq + q]; one block per instance.
+__global__ __launch_bounds__(kBlock) void fold_partials_kernel(const double* __restrict__ partials, int nblk,
+                                                               int nq, double* out0, double* out1) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.x;
+    for (int q = 0; q < nq; ++q) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += kBlock) s += partials[(b * nblk + i) * nq + q];
+        s = block_sum(s, smem);
+        double* o = q == 0 ? out0 : out1;
+        if (threadIdx.x == 0 && o) o[b] = s;
+    }
+}
+
+extern "C" int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                        const double* a1_d, const void* b1_d, const double* a2_d,
+                                        const void* b2_d, const void* r_old_d, void* r_d, double* v_d,
+                                        double* sq_diff_d, double* sq_norm_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, a1_d && b1_d && a2_d && b2_d && r_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    if (!n || !batch) return TRAMP_OK;
+    TRAMP_REQUIRE(ctx, batch <= 65535);
+    const int nblk = blocks_for(n, 1);
+    int rc = tramp_ws_reserve(ctx, batch * (size_t)nblk * 2 * sizeof(double));
+    if (rc) return rc;
+    dim3 grid(nblk, (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((var_post_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, a1_d,
+                           (const double*)b1_d, a2_d, (const double*)b2_d, (const double*)r_old_d,
+                           (double*)r_d, v_d, ctx->ws);
+    else
+        hipLaunchKernelGGL((var_post_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, a1_d,
+                           (const float*)b1_d, a2_d, (const float*)b2_d, (const float*)r_old_d,
+                           (float*)r_d, v_d, ctx->ws);
+    if (sq_diff_d || sq_norm_d)
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, ctx->ws,
+                           nblk, 2, sq_diff_d, sq_norm_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// ---------------------------------------------------------------- K12 damping, distances
+template <typename T>
+__global__ __launch_bounds__(kBlock) void damp_kernel(size_t n, double d, const double* __restrict__ a_old,
+                                                      const T* __restrict__ b_old, double* __restrict__ a,
+                                                      T* __restrict__ bb) {
+    const size_t b = blockIdx.y;
+    const T dT = T(d), omd = T(1.0 - d);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        bb[b * n + i] = dT * b_old[b * n + i] + omd * bb[b * n + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a[b] = d * a_old[b] + (1.0 - d) * a[b];
+}
+
+extern "C" int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
+                          const double* a_old_d, const void* b_old_d, double* a_d, void* b_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, a_old_d && b_old_d && a_d && b_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    if (!n || !batch || damping == 0.0) return TRAMP_OK;
+    dim3 grid(blocks_for(n, 1), (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((damp_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, damping, a_old_d,
+                           (const double*)b_old_d, a_d, (double*)b_d);
+    else
+        hipLaunchKernelGGL((damp_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, damping, a_old_d,
+                           (const float*)b_old_d, a_d, (float*)b_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sq_dist_kernel(size_t n, const T* __restrict__ x,
+                                                         const T* __restrict__ y, double* __restrict__ partials) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        double d = (double)x[b * n + i] - (y ? (double)y[b * n + i] : 0.0);
+        s += d * d;
+    }
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) partials[b * gridDim.x + blockIdx.x] = s;
+}
+
+extern "C" int tramp_sq_dist(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const void* x_d,
+                             const void* y_d, double* sum_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, x_d && sum_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    if (!batch) return TRAMP_OK;
+    if (!n) return tramp_fill_f64(ctx, sum_d, batch, 0.0);
+    const int nblk = blocks_for(n, 1);
+    int rc = tramp_ws_reserve(ctx, batch * (size_t)nblk * sizeof(double));
+    if (rc) return rc;
+    dim3 grid(nblk, (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((sq_dist_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, (const double*)x_d,
+                           (const double*)y_d, ctx->ws);
+    else
+        hipLaunchKernelGGL((sq_dist_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, (const float*)x_d,
+                           (const float*)y_d, ctx->ws);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, ctx->ws, nblk, 1,
+                       sum_d, (double*)nullptr);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// ---------------------------------------------------------------- convert, randn
+template <typename D, typename S>
+__global__ __launch_bounds__(kBlock) void convert_kernel(size_t count, const S* __restrict__ src, D* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock)
+        dst[i] = (D)src[i];
+}
+
+extern "C" int tramp_convert(tramp_ctx* ctx, int dst_dtype, void* dst_d, int src_dtype, const void* src_d,
+                             size_t count) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, (dst_d && src_d) || count == 0);
+    if (!count) return TRAMP_OK;
+    dim3 g(grid_for(count)), b(kBlock);
+    if (dst_dtype == TRAMP_F64 && src_dtype == TRAMP_F32)
+        hipLaunchKernelGGL((convert_kernel<double, float>), g, b, 0, ctx->stream, count, (const float*)src_d, (double*)dst_d);
+    else if (dst_dtype == TRAMP_F32 && src_dtype == TRAMP_F64)
+        hipLaunchKernelGGL((convert_kernel<float, double>), g, b, 0, ctx->stream, count, (const double*)src_d, (float*)dst_d);
+    else if (dst_dtype == src_dtype && (dst_dtype == TRAMP_F32 || dst_dtype == TRAMP_F64))
+        TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(dst_d, src_d, count * dtype_size(dst_dtype), hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// Philox-4x32-10 (Salmon et al. 2011), counter = element pair index, key = seed.
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void randn_kernel(size_t count, unsigned long long seed, double scale,
+                                                       T* __restrict__ out) {
+    // each counter yields 128 bits -> two 53-bit uniforms -> one Box-Muller pair
+    const size_t npair = (count + 1) / 2;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npair; p += (size_t)gridDim.x * kBlock) {
+        uint32_t c[4] = {(uint32_t)p, (uint32_t)(p >> 32), 0u, 0u};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        uint64_t u0 = ((uint64_t)c[0] << 32 | c[1]) >> 11;
+        uint64_t u1 = ((uint64_t)c[2] << 32 | c[3]) >> 11;
+        double x0 = ((double)u0 + 0.5) * (1.0 / 9007199254740992.0);   // (0,1)
+        double x1 = ((double)u1 + 0.5) * (1.0 / 9007199254740992.0);
+        double rad = sqrt(-2.0 * log(x0)) * scale;
+        double s, cth;
+        sincospi(2.0 * x1, &s, &cth);
+        out[2 * p] = (T)(rad * cth);
+        if (2 * p + 1 < count) out[2 * p + 1] = (T)(rad * s);
+    }
+}
+
+extern "C" int tramp_randn(tramp_ctx* ctx, int dtype, void* out_d, size_t count, unsigned long long seed,
+                           double scale) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, out_d || count == 0);
+    if (!count) return TRAMP_OK;
+    size_t g = ((count + 1) / 2 + kBlock - 1) / kBlock;
+    if (g > 16384) g = 16384;
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((randn_kernel<double>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, count, seed, scale, (double*)out_d);
+    else if (dtype == TRAMP_F32)
+        hipLaunchKernelGGL((randn_kernel<float>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, count, seed, scale, (float*)out_d);
+    else
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}

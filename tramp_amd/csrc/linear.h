@@ -1,0 +1,40 @@
+// linear.h - internal types shared by linear.hip and gemm_mfma.hip.
+#pragma once
+#include "common.h"
+
+struct tramp_linear {
+    int dtype;
+    size_t M, N, k, rank;
+    const void* Uk;      // [M, k]
+    const void* Vt;      // [k, N]
+    const double* sing;  // [k]
+    double* s2;          // [k] spectrum = sing^2 (owned)
+    void* work;          // owned: t, u, w [batch, k] + a_raw[batch]
+    size_t work_batch;
+    void* t;
+    void* u;
+    void* w;
+    double* a_raw;
+};
+
+// Epilogue applied to every output element acc = (mat x)[b, idx]:
+//   mode 0: out = acc
+//   mode 1: r = acc (+ b_in/a_in); out = r (a_in + a_new_raw) - b_in, optionally damped
+struct LinEpi {
+    int mode;
+    int add_b_over_a;
+    const double* a_in;       // [batch]
+    const double* a_new_raw;  // [batch]
+    const void* b_in;         // [batch, len]
+    double damping;
+    const void* b_old;        // [batch, len] or null
+    void* out;                // [batch, len]
+    void* r_out;              // [batch, len] or null
+};
+
+int lin_square(tramp_ctx* ctx, const double* in, double* out, size_t n);
+
+// MFMA GEMM path (gemm_mfma.hip)
+bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch);
+int gemm_mfma(tramp_ctx* ctx, int dtype, bool nt, size_t R, size_t C, size_t batch, const void* mat_d,
+              const void* x_d, const LinEpi& epi);

@@ -1,0 +1,502 @@
+// linear.hip - dense linear channel x = W z (K8, K9) for gfx950.
+//
+// Reference: tramp/channels/linear/linear_channel.py:58-117.  The reference keeps
+// the FULL SVD (U [M,M], zero-padded S [M,N], V [N,N]) and W, 3.75 N^2 elements at
+// alpha = 0.5, and forms rz = V diag(1/(az+ax s^2)) (V^T bz + S^T U^T bx), rx = W rz.
+// Here only the thin factors are resident, k = min(M,N):
+//     Uk [M,k], Vt [k,N] (rows = right singular vectors), sing[k]
+// and with t = Vt bz, u = Uk^T bx, D = az + ax sing^2 the same posterior means are
+//     rx = Uk [ sing (t + sing u) / D ]                                   (FWD)
+//     rz = bz/az + Vt^T [ -ax sing^2 t / (D az) + sing u / D ]   (k <  N)   (BWD)
+//     rz =         Vt^T [ (t + sing u) / D ]                     (k == N)
+// (W V = U S, so rx never needs W or rz).  0.75 N^2 elements at alpha = 0.5 and
+// 2MN + 4M^2 (FWD) / 4MN + 2M^2 (BWD) flops per instance instead of 8MN + ...
+//
+// Two streaming primitives over a row-major matrix mat [R, C]:
+//     NT: out[b, r] = sum_c mat[r, c] x[b, c]    (row dot products)
+//     NN: out[b, c] = sum_r mat[r, c] x[b, r]    (column accumulation)
+// Small ensembles (batch <= 8) are HBM-bound: VALU kernels stream mat exactly once
+// with 16-byte loads (this file).  Larger ensembles use the MFMA kernels of
+// gemm_mfma.hip.  Both accept the fused message-update epilogue.
+#include "common.h"
+#include "linear.h"
+#include "tramp_math.h"
+
+// ---------------------------------------------------------------- K9 variances
+// LinearChannel.compute_n_eff / compute_forward_variance / compute_backward_variance
+// (linear_channel.py:58-67, 91-105) + compute_a_new (tramp/base.py:245-248).
+__global__ __launch_bounds__(kBlock) void lin_variance_kernel(const double* __restrict__ s2, int k, int rank,
+                                                              double Nx, double Nz, int dir,
+                                                              const double* __restrict__ az_d,
+                                                              const double* __restrict__ ax_d, double damping,
+                                                              const double* __restrict__ a_old,
+                                                              double* __restrict__ v_out,
+                                                              double* __restrict__ a_new_out,
+                                                              double* __restrict__ a_new_raw,
+                                                              double* __restrict__ n_eff_out) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.x;
+    const double az = az_d[b], ax = ax_d[b];
+    const double azc = (dir == TRAMP_BWD) ? fmax(1e-11, az) : az;     // :92-94
+    double n_eff;
+    double ssum = 0.0;
+    if (ax == 0.0) {
+        n_eff = 0.0;                                                  // :60-62
+        for (int i = threadIdx.x; i < rank; i += kBlock) ssum += s2[i];
+        ssum = block_sum(ssum, smem);
+    } else if (azc / ax == 0.0) {
+        n_eff = (double)rank / Nz;                                    // :63-65
+    } else {
+        const double q = azc / ax;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < rank; i += kBlock) s += s2[i] / (q + s2[i]);
+        s = block_sum(s, smem);
+        n_eff = s / Nz;                                               // :66-67
+    }
+    if (threadIdx.x != 0) return;
+    double v, a_in;
+    if (dir == TRAMP_FWD) {
+        if (ax == 0.0) {
+            double s_mean = ssum / (double)rank;                      // :100-102
+            v = s_mean * (double)rank / (Nx * az);
+        } else {
+            v = n_eff / ((Nx / Nz) * ax);                             // :103-105
+        }
+        a_in = ax;
+    } else {
+        v = (1.0 - n_eff) / azc;                                      // :95-97
+        a_in = az;
+    }
+    const double an = tmath::a_new_of(v, a_in);
+    if (a_new_raw) a_new_raw[b] = an;
+    if (a_new_out) a_new_out[b] = (damping != 0.0) ? damping * a_old[b] + (1.0 - damping) * an : an;
+    if (v_out) v_out[b] = v;
+    if (n_eff_out) n_eff_out[b] = n_eff;
+}
+
+// ---------------------------------------------------------------- fused epilogue
+template <typename T>
+__device__ __forceinline__ void lin_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
+    if (e.mode == 0) {
+        reinterpret_cast<T*>(e.out)[b * len + idx] = T(acc);
+        return;
+    }
+    const T bin = reinterpret_cast<const T*>(e.b_in)[b * len + idx];
+    const double a_in = e.a_in[b];
+    double r = acc;
+    if (e.add_b_over_a) r += (double)bin / a_in;
+    const double an = e.a_new_raw[b];
+    // b_new = r (a + a_new) - b  (tramp/base.py:253-254)
+    T bn = T(r) * T(a_in + an) - bin;
+    if (e.damping != 0.0) {
+        const T bo = reinterpret_cast<const T*>(e.b_old)[b * len + idx];
+        bn = T(e.damping) * bo + T(1.0 - e.damping) * bn;
+    }
+    reinterpret_cast<T*>(e.out)[b * len + idx] = bn;
+    if (e.r_out) reinterpret_cast<T*>(e.r_out)[b * len + idx] = T(r);
+}
+
+// ---------------------------------------------------------------- NT: row dot products
+// One wave owns ROWS rows; lanes stride over the columns with 16-byte loads, the
+// batch of x vectors comes from L1/L2 (x is tiny next to mat).  f32 accumulates in
+// f32, f64 in f64; 64-wide shuffle reduction at the end.
+template <typename T, int NB, int ROWS, bool VEC>
+__global__ __launch_bounds__(kBlock) void gemv_nt_kernel(size_t R, size_t C, int nb, const T* __restrict__ mat,
+                                                         const T* __restrict__ x, size_t b0, LinEpi epi) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const size_t r0 = wave * ROWS;
+    if (r0 >= R) return;
+    T acc[ROWS][NB];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[i][b] = T(0);
+    const T* rowp[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) rowp[i] = mat + (r0 + i < R ? r0 + i : R - 1) * C;
+    if (VEC) {
+        const size_t nv = C / VN;
+        for (size_t j = lane; j < nv; j += 64) {
+            V m[ROWS];
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) m[i] = reinterpret_cast<const V*>(rowp[i])[j];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b < nb) {
+                    V xv = reinterpret_cast<const V*>(x + (b0 + b) * C)[j];
+#pragma unroll
+                    for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+                        for (int q = 0; q < VN; ++q) acc[i][b] += vget<T>(m[i], q) * vget<T>(xv, q);
+                }
+            }
+        }
+    } else {
+        for (size_t j = lane; j < C; j += 64) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b < nb) {
+                    T xv = x[(b0 + b) * C + j];
+#pragma unroll
+                    for (int i = 0; i < ROWS; ++i) acc[i][b] += rowp[i][j] * xv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double s = wave_sum((double)acc[i][b]);
+            if (lane == 0 && b < nb && r0 + i < R) lin_epilogue<T>(epi, b0 + b, r0 + i, R, s);
+        }
+}
+
+// ---------------------------------------------------------------- NN: column accumulation
+// A thread owns VN adjacent columns; blockIdx.y splits the rows into chunks whose
+// partial sums go to the workspace and are folded (fixed order) by nn_fold_kernel,
+// which also applies the epilogue.  x[b, r] is wave-uniform (scalar loads).
+template <typename T, int NB, bool VEC>
+__global__ __launch_bounds__(kBlock) void gemv_nn_kernel(size_t R, size_t C, int nb, size_t rows_per_chunk,
+                                                         const T* __restrict__ mat, const T* __restrict__ x,
+                                                         size_t b0, double* __restrict__ partials) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = VEC ? Vec<T>::N : 1;
+    const size_t cv = (size_t)blockIdx.x * kBlock + threadIdx.x;      // vector-column index
+    const size_t c0 = cv * VN;
+    if (c0 >= C) return;
+    const size_t rbeg = (size_t)blockIdx.y * rows_per_chunk;
+    size_t rend = rbeg + rows_per_chunk;
+    if (rend > R) rend = R;
+    T acc[NB][VN];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < VN; ++q) acc[b][q] = T(0);
+    constexpr int UNR = 4;
+    size_t r = rbeg;
+    for (; r + UNR <= rend; r += UNR) {
+        T m[UNR][VN];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (VEC) {
+                V mv = reinterpret_cast<const V*>(mat + (r + u) * C)[cv];
+#pragma unroll
+                for (int q = 0; q < VN; ++q) m[u][q] = vget<T>(mv, q);
+            } else {
+                m[u][0] = mat[(r + u) * C + c0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b < nb) {
+                    const T xv = x[(b0 + b) * R + r + u];
+#pragma unroll
+                    for (int q = 0; q < VN; ++q) acc[b][q] += m[u][q] * xv;
+                }
+            }
+    }
+    for (; r < rend; ++r) {
+#pragma unroll
+        for (int q = 0; q < VN; ++q) {
+            const T mv = mat[r * C + c0 + q];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (b < nb) acc[b][q] += mv * x[(b0 + b) * R + r];
+        }
+    }
+    // partials[chunk][b][c]
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b < nb)
+#pragma unroll
+            for (int q = 0; q < VN; ++q)
+                partials[((size_t)blockIdx.y * nb + b) * C + c0 + q] = (double)acc[b][q];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nn_fold_kernel(size_t C, int nb, int nchunk,
+                                                         const double* __restrict__ partials, size_t b0,
+                                                         LinEpi epi) {
+    const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += partials[((size_t)k * nb + b) * C + c];
+    lin_epilogue<T>(epi, b0 + b, c, C, s);
+}
+
+// ---------------------------------------------------------------- launchers (VALU path)
+template <typename T, int NB>
+static void launch_nt(tramp_ctx* ctx, size_t R, size_t C, int nb, const T* mat, const T* x, size_t b0,
+                      const LinEpi& epi) {
+    constexpr int ROWS = (NB >= 8) ? 2 : 4;
+    const size_t waves = (R + ROWS - 1) / ROWS;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(kBlock);
+    if (C % Vec<T>::N == 0)
+        hipLaunchKernelGGL((gemv_nt_kernel<T, NB, ROWS, true>), grid, block, 0, ctx->stream, R, C, nb, mat, x, b0, epi);
+    else
+        hipLaunchKernelGGL((gemv_nt_kernel<T, NB, ROWS, false>), grid, block, 0, ctx->stream, R, C, nb, mat, x, b0, epi);
+}
+
+template <typename T, int NB>
+static int launch_nn(tramp_ctx* ctx, size_t R, size_t C, int nb, const T* mat, const T* x, size_t b0,
+                     const LinEpi& epi) {
+    const bool vec = (C % Vec<T>::N == 0);
+    const int VN = vec ? Vec<T>::N : 1;
+    const size_t colthreads = (C + VN - 1) / VN;
+    const size_t colwaves = (colthreads + 63) / 64;
+    size_t nchunk = (4096 + colwaves - 1) / colwaves;
+    if (nchunk > R / 16) nchunk = R / 16;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 256) nchunk = 256;
+    const size_t rpc = (R + nchunk - 1) / nchunk;
+    nchunk = (R + rpc - 1) / rpc;
+    int rc = tramp_ws_reserve(ctx, nchunk * (size_t)nb * C * sizeof(double));
+    if (rc) return rc;
+    dim3 grid((unsigned)((colthreads + kBlock - 1) / kBlock), (unsigned)nchunk), block(kBlock);
+    if (vec)
+        hipLaunchKernelGGL((gemv_nn_kernel<T, NB, true>), grid, block, 0, ctx->stream, R, C, nb, rpc, mat, x, b0, ctx->ws);
+    else
+        hipLaunchKernelGGL((gemv_nn_kernel<T, NB, false>), grid, block, 0, ctx->stream, R, C, nb, rpc, mat, x, b0, ctx->ws);
+    dim3 g2((unsigned)((C + kBlock - 1) / kBlock), (unsigned)nb);
+    hipLaunchKernelGGL((nn_fold_kernel<T>), g2, block, 0, ctx->stream, C, nb, (int)nchunk, ctx->ws, b0, epi);
+    return TRAMP_OK;
+}
+
+template <typename T>
+int matvec_valu(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch, const void* mat_d, const void* x_d,
+                const LinEpi& epi) {
+    const T* mat = reinterpret_cast<const T*>(mat_d);
+    const T* x = reinterpret_cast<const T*>(x_d);
+    for (size_t b0 = 0; b0 < batch; b0 += TRAMP_GEMV_MAX_BATCH) {
+        const int nb = (int)((batch - b0 < TRAMP_GEMV_MAX_BATCH) ? batch - b0 : TRAMP_GEMV_MAX_BATCH);
+        int rc = TRAMP_OK;
+        if (nt) {
+            if (nb == 1) launch_nt<T, 1>(ctx, R, C, nb, mat, x, b0, epi);
+            else if (nb == 2) launch_nt<T, 2>(ctx, R, C, nb, mat, x, b0, epi);
+            else if (nb <= 4) launch_nt<T, 4>(ctx, R, C, nb, mat, x, b0, epi);
+            else launch_nt<T, 8>(ctx, R, C, nb, mat, x, b0, epi);
+        } else {
+            if (nb == 1) rc = launch_nn<T, 1>(ctx, R, C, nb, mat, x, b0, epi);
+            else if (nb == 2) rc = launch_nn<T, 2>(ctx, R, C, nb, mat, x, b0, epi);
+            else if (nb <= 4) rc = launch_nn<T, 4>(ctx, R, C, nb, mat, x, b0, epi);
+            else rc = launch_nn<T, 8>(ctx, R, C, nb, mat, x, b0, epi);
+        }
+        if (rc) return rc;
+    }
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+template int matvec_valu<float>(tramp_ctx*, bool, size_t, size_t, size_t, const void*, const void*, const LinEpi&);
+template int matvec_valu<double>(tramp_ctx*, bool, size_t, size_t, size_t, const void*, const void*, const LinEpi&);
+
+static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t R, size_t C, size_t batch,
+                           const void* mat_d, const void* x_d, const LinEpi& epi) {
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, mat_d && x_d && epi.out);
+    if (!R || !C || !batch) return TRAMP_OK;
+    bool mfma = (algo == 2) || (algo == 0 && batch > TRAMP_GEMV_MAX_BATCH);
+    if (mfma && !gemm_mfma_supported(dtype, nt, R, C, batch)) {
+        if (algo == 2) return tramp_fail(ctx, TRAMP_ENOTSUP, "mfma path", "shape/dtype not supported");
+        mfma = false;
+    }
+    if (mfma) return gemm_mfma(ctx, dtype, nt, R, C, batch, mat_d, x_d, epi);
+    if (dtype == TRAMP_F64) return matvec_valu<double>(ctx, nt, R, C, batch, mat_d, x_d, epi);
+    return matvec_valu<float>(ctx, nt, R, C, batch, mat_d, x_d, epi);
+}
+
+extern "C" int tramp_matvec_nt(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
+                               const void* mat_d, const void* x_d, void* out_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    LinEpi epi{};
+    epi.mode = 0;
+    epi.out = out_d;
+    return matvec_dispatch(ctx, dtype, algo, true, R, C, batch, mat_d, x_d, epi);
+}
+
+extern "C" int tramp_matvec_nn(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
+                               const void* mat_d, const void* x_d, void* out_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    LinEpi epi{};
+    epi.mode = 0;
+    epi.out = out_d;
+    return matvec_dispatch(ctx, dtype, algo, false, R, C, batch, mat_d, x_d, epi);
+}
+
+// ---------------------------------------------------------------- spectral coefficients
+// w = f(t, u) on [batch, k]; tiny next to the matrix passes.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lin_mid_kernel(int k, int mode, const double* __restrict__ sing,
+                                                         const double* __restrict__ az_d,
+                                                         const double* __restrict__ ax_d, const T* __restrict__ t,
+                                                         const T* __restrict__ u, T* __restrict__ w) {
+    const size_t b = blockIdx.y;
+    const double az = az_d[b], ax = ax_d[b];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < k; i += gridDim.x * kBlock) {
+        const double s = sing[i];
+        const double D = az + ax * (s * s);
+        const double ti = (double)t[b * k + i], ui = (double)u[b * k + i];
+        double o;
+        if (mode == 0) o = s * (ti + s * ui) / D;                               // FWD
+        else if (mode == 1) o = (-(ax * (s * s)) * ti / az + s * ui) / D;       // BWD, k < N
+        else o = (ti + s * ui) / D;                                             // BWD, k == N
+        w[b * k + i] = T(o);
+    }
+}
+
+// ---------------------------------------------------------------- handle + message
+extern "C" int tramp_linear_create(tramp_ctx* ctx, int dtype, size_t M, size_t N, size_t rank, const void* Uk_d,
+                                   const void* Vt_d, const double* sing_d, tramp_linear** out) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, out && Uk_d && Vt_d && sing_d && M > 0 && N > 0);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    const size_t k = M < N ? M : N;
+    TRAMP_REQUIRE(ctx, rank <= k);
+    tramp_linear* lin = new (std::nothrow) tramp_linear();
+    if (!lin) return TRAMP_ENOMEM;
+    memset(lin, 0, sizeof(*lin));
+    lin->dtype = dtype;
+    lin->M = M;
+    lin->N = N;
+    lin->k = k;
+    lin->rank = rank;
+    lin->Uk = Uk_d;
+    lin->Vt = Vt_d;
+    lin->sing = sing_d;
+    if (hipMalloc((void**)&lin->s2, k * sizeof(double)) != hipSuccess) {
+        delete lin;
+        return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_linear_create", "hipMalloc");
+    }
+    // spectrum = sing^2  (diag(S^T S), linear_channel.py:41)
+    int rc = lin_square(ctx, sing_d, lin->s2, k);
+    if (rc) {
+        (void)hipFree(lin->s2);
+        delete lin;
+        return rc;
+    }
+    *out = lin;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_linear_destroy(tramp_ctx* ctx, tramp_linear* lin) {
+    if (!ctx || !lin) return TRAMP_EINVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (lin->s2) (void)(void)hipFree(lin->s2);
+    if (lin->work) (void)hipFree(lin->work);
+    delete lin;
+    return TRAMP_OK;
+}
+
+__global__ void square_kernel(const double* in, double* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[i] * in[i];
+}
+
+int lin_square(tramp_ctx* ctx, const double* in, double* out, size_t n) {
+    hipLaunchKernelGGL(square_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, in, out, n);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+static int lin_reserve(tramp_ctx* ctx, tramp_linear* lin, size_t batch) {
+    if (batch <= lin->work_batch) return TRAMP_OK;
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (lin->work) TRAMP_HIP_CHECK(ctx, hipFree(lin->work));
+    lin->work = nullptr;
+    lin->work_batch = 0;
+    const size_t es = dtype_size(lin->dtype);
+    const size_t vec = ((batch * lin->k * es + 255) / 256) * 256;
+    const size_t sc = ((batch * sizeof(double) + 255) / 256) * 256;
+    if (hipMalloc(&lin->work, 3 * vec + sc) != hipSuccess) {
+        (void)hipGetLastError();
+        return tramp_fail(ctx, TRAMP_ENOMEM, "linear workspace", "hipMalloc");
+    }
+    char* p = (char*)lin->work;
+    lin->t = p;
+    lin->u = p + vec;
+    lin->w = p + 2 * vec;
+    lin->a_raw = (double*)(p + 3 * vec);
+    lin->work_batch = batch;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, int dir, size_t batch,
+                                     const double* az_d, const double* ax_d, double* v_d, double* a_new_d,
+                                     double* n_eff_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, lin && az_d && ax_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    if (!batch) return TRAMP_OK;
+    hipLaunchKernelGGL(lin_variance_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, lin->s2, (int)lin->k,
+                       (int)lin->rank, (double)lin->M, (double)lin->N, dir, az_d, ax_d, 0.0, (const double*)nullptr,
+                       v_d, a_new_d, (double*)nullptr, n_eff_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batch, const double* az_d,
+                                    const void* bz_d, const double* ax_d, const void* bx_d, double damping,
+                                    const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d,
+                                    void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, lin && az_d && bz_d && ax_d && bx_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!batch) return TRAMP_OK;
+    int rc = lin_reserve(ctx, lin, batch);
+    if (rc) return rc;
+    const int dtype = lin->dtype;
+    const size_t M = lin->M, N = lin->N, k = lin->k;
+    // 1. scalars: v, a_new (K9)
+    hipLaunchKernelGGL(lin_variance_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, lin->s2, (int)k,
+                       (int)lin->rank, (double)M, (double)N, dir, az_d, ax_d, damping, a_old_d, v_d, a_new_d,
+                       lin->a_raw, (double*)nullptr);
+    // 2. t = Vt bz  [batch, k]
+    LinEpi plain{};
+    plain.mode = 0;
+    plain.out = lin->t;
+    rc = matvec_dispatch(ctx, dtype, 0, true, k, N, batch, lin->Vt, bz_d, plain);
+    if (rc) return rc;
+    // 3. u = Uk^T bx  [batch, k]
+    plain.out = lin->u;
+    rc = matvec_dispatch(ctx, dtype, 0, false, M, k, batch, lin->Uk, bx_d, plain);
+    if (rc) return rc;
+    // 4. spectral coefficients
+    const int mode = (dir == TRAMP_FWD) ? 0 : (k < N ? 1 : 2);
+    dim3 gm((unsigned)((k + kBlock - 1) / kBlock > 1024 ? 1024 : (k + kBlock - 1) / kBlock), (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((lin_mid_kernel<double>), gm, dim3(kBlock), 0, ctx->stream, (int)k, mode, lin->sing, az_d,
+                           ax_d, (const double*)lin->t, (const double*)lin->u, (double*)lin->w);
+    else
+        hipLaunchKernelGGL((lin_mid_kernel<float>), gm, dim3(kBlock), 0, ctx->stream, (int)k, mode, lin->sing, az_d,
+                           ax_d, (const float*)lin->t, (const float*)lin->u, (float*)lin->w);
+    // 5. back-projection with the fused message update
+    LinEpi epi{};
+    epi.mode = 1;
+    epi.a_new_raw = lin->a_raw;
+    epi.damping = damping;
+    epi.b_old = (damping != 0.0) ? b_old_d : nullptr;
+    epi.out = b_new_d;
+    epi.r_out = r_d;
+    if (dir == TRAMP_FWD) {
+        epi.a_in = ax_d;
+        epi.b_in = bx_d;
+        epi.add_b_over_a = 0;
+        rc = matvec_dispatch(ctx, dtype, 0, true, M, k, batch, lin->Uk, lin->w, epi);      // rx = Uk w
+    } else {
+        epi.a_in = az_d;
+        epi.b_in = bz_d;
+        epi.add_b_over_a = (k < N) ? 1 : 0;
+        rc = matvec_dispatch(ctx, dtype, 0, false, k, N, batch, lin->Vt, lin->w, epi);     // rz = Vt^T w
+    }
+    if (rc) return rc;
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}

@@ -1,0 +1,210 @@
+// tramp_math.h - per-component belief arithmetic of the Tree-AMP hot path.
+//
+// Scalar building blocks shared by every elementwise HIP kernel; templated on
+// the vector element type T (float / double).  Each function names the
+// reference lines it restates (paths relative to sphinxteam/tramp).  The same
+// header is compiled for the host by tests/host_math (a unit-test harness for
+// the arithmetic, never a product path) - hence the TM_HD macro.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TM_HD __host__ __device__ __forceinline__
+#else
+#define TM_HD inline
+#endif
+
+namespace tmath {
+
+constexpr double kAMin = 1e-11;   // tramp/base.py:238-239
+constexpr double kAMax = 1e+11;
+constexpr double kVFloor = 1e-20; // tramp/base.py:44-46
+constexpr double kPi = 3.141592653589793238462643383279502884;
+constexpr double kSqrt2 = 1.4142135623730951;          // np.sqrt(2)
+constexpr double kSqrt2OverPi = 0.7978845608028654;    // np.sqrt(2/np.pi)
+constexpr double kTwoOverSqrtPi = 1.1283791670955126;  // 2/np.sqrt(np.pi)
+
+template <typename T> struct RV { T r, v; };
+
+// ---- special functions -------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+TM_HD double erfcx_(double x) { return ::erfcx(x); }
+TM_HD float erfcx_(float x) { return ::erfcxf(x); }
+#else
+// Host stand-in used only by the unit-test harness (glibc has no erfcx).
+inline double erfcx_(double x) {
+    if (x < 25.0) return ::exp(x * x) * ::erfc(x);
+    double y = 1.0 / (2.0 * x * x);   // asymptotic series, rel. error < 1e-16 for x >= 25
+    return (1.0 / (x * 1.772453850905516)) * (1.0 - y * (1.0 - 3.0 * y * (1.0 - 5.0 * y * (1.0 - 7.0 * y))));
+}
+inline float erfcx_(float x) { return (float)erfcx_((double)x); }
+#endif
+
+TM_HD double exp_(double x) { return ::exp(x); }
+TM_HD float exp_(float x) { return ::expf(x); }
+TM_HD double log_(double x) { return ::log(x); }
+TM_HD float log_(float x) { return ::logf(x); }
+TM_HD double sqrt_(double x) { return ::sqrt(x); }
+TM_HD float sqrt_(float x) { return ::sqrtf(x); }
+TM_HD double tanh_(double x) { return ::tanh(x); }
+TM_HD float tanh_(float x) { return ::tanhf(x); }
+TM_HD double fabs_(double x) { return ::fabs(x); }
+TM_HD float fabs_(float x) { return ::fabsf(x); }
+TM_HD double fmax_(double a, double b) { return ::fmax(a, b); }
+TM_HD float fmax_(float a, float b) { return ::fmaxf(a, b); }
+
+// scipy.special.expit: two-branch logistic (no overflow on either side).
+template <typename T> TM_HD T expit(T x) {
+    if (x < T(0)) {
+        T e = exp_(x);
+        return e / (T(1) + e);
+    }
+    return T(1) / (T(1) + exp_(-x));
+}
+
+// ---- A1: message update, scalars always double (tramp/base.py:245-255) ----
+TM_HD double a_new_of(double v, double a) {
+    double inv = 1.0 / fmax(v, kVFloor);
+    double an = inv - a;
+    // np.clip propagates NaN; fmin/fmax would swallow it
+    if (an < kAMin) an = kAMin;
+    if (an > kAMax) an = kAMax;
+    return an;
+}
+
+// ---- A2: Gauss-Bernoulli denoiser ------------------------------------------
+// tramp/priors/gauss_bernoulli_prior.py:70-77, tramp/beliefs/sparse.py:9-22,
+// tramp/beliefs/normal.py:3-4.  a = ax + 1/var (per instance), lg = log(2 pi / a).
+template <typename T> TM_HD RV<T> gb_posterior(T bx, T a, T lg, T b0, T eta) {
+    T b = bx + b0;
+    T xi = T(0.5) * (b * b / a + lg) - eta;
+    T s = expit(xi);
+    T ba = b / a;
+    RV<T> o;
+    o.r = s * ba;
+    o.v = s / a + s * (T(1) - s) * (ba * ba);
+    return o;
+}
+
+// ---- A3: soft threshold (tramp/priors/map_L1_norm_prior.py:11-17,66-71) -----
+// The support test is |b| > gamma on the same operands as the reference.
+template <typename T> TM_HD bool l1_support(T bx, T gamma) { return fabs_(bx) > gamma; }
+
+template <typename T> TM_HD RV<T> l1_posterior(T bx, T inv_ax, T gamma) {
+    T shrink = fmax_(T(0), T(1) - gamma / fabs_(bx)) * bx;   // gamma/0 = inf -> 0
+    RV<T> o;
+    o.r = inv_ax * shrink;
+    o.v = l1_support(bx, gamma) ? inv_ax : T(0);
+    return o;
+}
+
+// ---- half-line truncated normal ------------------------------------------------
+// tramp/utils/truncated_normal.py: truncated_normal_mean/_var/_log_proba (:234-281)
+// through G0_inf/G1_inf/G2_inf (:218-231), F1_inf/F2_inf (:92-94,147-149), log_Phi
+// (:21-29).  side = +1: z in [0,inf), side = -1: z in (-inf,0].
+// One erfcx per region: log_Phi(-side*y0) = log(0.5*erfcx(side*y0/sqrt2)) - y0^2/2
+// shares its erfcx with G1/G2.
+template <typename T> struct LogPhiCut;
+template <> struct LogPhiCut<double> { static constexpr double value = 30.0; }; // reference mask x < 30
+// f32: erfcxf overflows below -9.2; log Phi(8) = -6e-16 is far under f32 resolution.
+template <> struct LogPhiCut<float> { static constexpr float value = 8.0f; };
+
+template <typename T> struct HalfLine { T mean, var, logp; bool mask; };
+
+template <typename T> TM_HD HalfLine<T> halfline(T r0, T v0, int side) {
+    T s0 = sqrt_(v0);
+    T y0 = (T(0) - r0) / s0;
+    T x = y0 / T(kSqrt2);
+    T sd = T(side);
+    T e = erfcx_(sd * x);
+    T g1 = T(kSqrt2OverPi) * (sd / e);
+    T g2 = T(kTwoOverSqrtPi) * (sd * x / e);
+    HalfLine<T> h;
+    h.mean = r0 + s0 * g1;
+    h.var = v0 * (T(1) + g2 - g1 * g1);
+    T u = -sd * y0;                         // argument of log_Phi
+    h.mask = u < LogPhiCut<T>::value;
+    h.logp = h.mask ? (log_(T(0.5) * e) - T(0.5) * (u * u)) : T(0);
+    return h;
+}
+
+// ---- A6: sign likelihood (tramp/likelihoods/sgn_likelihood.py:32-37,
+//          tramp/beliefs/positive.py:12-17) -----------------------------------------
+template <typename T> TM_HD RV<T> sgn_lik_posterior(T bz, T y, T az, T v0 /* 1/az */) {
+    T b = bz * y;
+    HalfLine<T> h = halfline<T>(b / az, v0, +1);
+    RV<T> o;
+    o.r = y * h.mean;
+    o.v = h.var;
+    return o;
+}
+
+// ---- A7: abs likelihood (tramp/likelihoods/abs_likelihood.py:31-36,
+//          tramp/beliefs/binary.py:8-13) ------------------------------------------
+template <typename T> TM_HD RV<T> abs_lik_posterior(T bz, T y) {
+    T t = tanh_(bz * y);
+    RV<T> o;
+    o.r = y * t;
+    o.v = (y * y) * (T(1) - t * t);
+    return o;
+}
+
+// ---- A8: piecewise-linear channels ---------------------------------------------
+// tramp/channels/activation/piecewise_linear_channel.py:27-53, region tables :80-106
+// (order [pos, neg]); tramp/utils/linear_region.py:32-64.
+// kind: 0 = sgn, 1 = abs, 2 = relu;  k: 0 = pos region, 1 = neg region.
+TM_HD constexpr double pwl_slope(int kind, int k) {
+    return kind == 0 ? 0.0 : (kind == 1 ? (k == 0 ? 1.0 : -1.0) : (k == 0 ? 1.0 : 0.0));
+}
+TM_HD constexpr double pwl_x0(int kind, int k) {
+    return kind == 0 ? (k == 0 ? 1.0 : -1.0) : 0.0;
+}
+
+template <typename T> struct PwlOut { T r, v; unsigned mask; };
+
+// FWD: posterior of x = f(z) (a = ax side); BWD: posterior of z.
+template <typename T, int KIND, bool FWD>
+TM_HD PwlOut<T> pwl_posterior(T bz, T bx, T az, T ax) {
+    T rs[2], vs[2], As[2];
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const T slope = T(pwl_slope(KIND, k));
+        const T x0 = T(pwl_x0(KIND, k));
+        const int side = (k == 0) ? +1 : -1;
+        T a = az + slope * slope * ax;
+        T b = bz + slope * (bx - ax * x0);
+        T r0 = b / a;
+        T v0 = T(1) / a;
+        HalfLine<T> h = halfline<T>(r0, v0, side);
+        As[k] = T(0.5) * log_(T(2 * kPi) * v0) + T(0.5) * (r0 * r0) / v0 + h.logp
+                - T(0.5) * ax * (x0 * x0) + bx * x0;
+        if (FWD) {
+            rs[k] = slope * h.mean + x0;
+            vs[k] = slope * slope * h.var;
+        } else {
+            rs[k] = h.mean;
+            vs[k] = h.var;
+        }
+        mask |= (h.mask ? 1u : 0u) << k;
+    }
+    // scipy.special.softmax over the two regions
+    T m = fmax_(As[0], As[1]);
+    T e0 = exp_(As[0] - m), e1 = exp_(As[1] - m);
+    T se = e0 + e1;
+    T p0 = e0 / se, p1 = e1 / se;
+    PwlOut<T> o;
+    o.r = p0 * rs[0] + p1 * rs[1];
+    T d = rs[0] - rs[1];
+    o.v = p0 * vs[0] + p1 * vs[1] + p0 * p1 * (d * d);
+    o.mask = mask;
+    return o;
+}
+
+// Gaussian CDF / PDF (tramp/utils/misc.py:50-57) for the SE quadratures.
+TM_HD double norm_cdf(double x) { return 0.5 * (1.0 + ::erf(x / kSqrt2)); }
+TM_HD double norm_pdf(double x) { return ::exp(-0.5 * x * x) / 2.5066282746310002; }
+
+}  // namespace tmath

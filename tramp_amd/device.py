@@ -1,0 +1,223 @@
+"""Device context and device-resident arrays (thin wrappers over the C ABI).
+
+Ownership: the Python wrapper owns device buffers through
+``DeviceArray`` objects whose ``__del__`` returns the memory; kernels never
+allocate; outputs go to caller-provided buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import F32, F64
+
+_DT = {np.dtype(np.float32): F32, np.dtype(np.float64): F64}
+
+
+def dtype_code(dtype):
+    try:
+        return _DT[np.dtype(dtype)]
+    except KeyError:
+        raise ValueError(f"dtype must be float32 or float64, got {dtype}") from None
+
+
+class Event:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._call("tramp_event_create", C.byref(h))
+        self.handle = h
+
+    def record(self):
+        self.ctx._call("tramp_event_record", self.handle)
+        return self
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        self.ctx._call("tramp_event_elapsed_ms", self.handle, stop.handle, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx.lib.tramp_event_destroy(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+class Context:
+    """One per GPU: a HIP stream plus the reduction workspace (tramp_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.tramp_ctx_create(int(device), C.byref(h))
+        if rc != _lib.OK:
+            raise _lib.TrampHipError(rc, f"tramp_ctx_create(device={device})")
+        self.handle = h
+        self.device = int(device)
+
+    # -- plumbing
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self.handle, *args)
+        if rc != _lib.OK:
+            _lib.check(rc, name, self.handle)
+
+    def sync(self):
+        self._call("tramp_sync")
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._call("tramp_device_name", buf, 256)
+        return buf.value.decode()
+
+    def mem_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        self._call("tramp_mem_info", C.byref(f), C.byref(t))
+        return f.value, t.value
+
+    def stream(self):
+        s = C.c_void_p()
+        self._call("tramp_ctx_stream", C.byref(s))
+        return s.value
+
+    def event(self):
+        return Event(self)
+
+    def close(self):
+        if self.handle:
+            self.lib.tramp_ctx_destroy(self.handle)
+            self.handle = None
+
+    # -- arrays
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float64):
+        a = DeviceArray(self, shape, dtype)
+        self._call("tramp_memset", a.ptr, 0, a.nbytes)
+        return a
+
+    def full(self, shape, value, dtype=np.float64):
+        a = DeviceArray(self, shape, dtype)
+        self._call("tramp_fill", dtype_code(dtype), a.ptr, a.size, float(value))
+        return a
+
+    def array(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype if dtype is not None else None)
+        if host.dtype not in _DT and host.dtype != np.uint8:
+            host = host.astype(np.float64)
+        a = DeviceArray(self, host.shape, host.dtype)
+        a.set(host)
+        return a
+
+    def scalars(self, values, batch=None):
+        "double[batch] device array of message precisions / variances."
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        if batch is not None and v.shape[0] != batch:
+            if v.shape[0] != 1:
+                raise ValueError(f"expected {batch} scalars, got {v.shape[0]}")
+            v = np.repeat(v, batch)
+        return self.array(v, np.float64)
+
+    def randn(self, shape, dtype=np.float64, seed=0, scale=1.0):
+        a = DeviceArray(self, shape, dtype)
+        self._call("tramp_randn", dtype_code(dtype), a.ptr, a.size, int(seed), float(scale))
+        return a
+
+
+class DeviceArray:
+    """A contiguous row-major array in HBM.  Vectors are [batch, n] (or [n])."""
+
+    def __init__(self, ctx, shape, dtype=np.float64, ptr=None, owner=True):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owner = owner and ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            ctx._call("tramp_buf_alloc", self.nbytes, C.byref(p))
+            ptr = p.value
+        self.ptr = ptr
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError(f"size mismatch: device {self.shape} vs host {host.shape}")
+        self.ctx._call("tramp_h2d", self.ptr, host.ctypes.data, self.nbytes)
+        return self
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx._call("tramp_d2h", out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a.astype(dtype) if dtype is not None else a
+
+    def copy_from(self, other):
+        if other.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        self.ctx._call("tramp_d2d", self.ptr, other.ptr, self.nbytes)
+        return self
+
+    def copy(self):
+        return DeviceArray(self.ctx, self.shape, self.dtype).copy_from(self)
+
+    def fill(self, value):
+        if self.dtype == np.uint8:
+            self.ctx._call("tramp_memset", self.ptr, int(value), self.nbytes)
+        else:
+            self.ctx._call("tramp_fill", dtype_code(self.dtype), self.ptr, self.size, float(value))
+        return self
+
+    def astype(self, dtype):
+        out = DeviceArray(self.ctx, self.shape, dtype)
+        self.ctx._call("tramp_convert", dtype_code(dtype), out.ptr, dtype_code(self.dtype), self.ptr,
+                       self.size)
+        return out
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        v = DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr, owner=False)
+        if v.size != self.size:
+            raise ValueError("cannot reshape")
+        v._base = self      # keep the owner alive
+        return v
+
+    def row(self, b):
+        "View of instance b of a [batch, n] array."
+        n = self.shape[-1]
+        v = DeviceArray(self.ctx, (n,), self.dtype, ptr=self.ptr + b * n * self.dtype.itemsize,
+                        owner=False)
+        v._base = self
+        return v
+
+    def __del__(self):
+        try:
+            if self._owner and self.ptr and self.ctx.handle:
+                self.ctx.lib.tramp_buf_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.ctx.device})"
+
+
+_default = {}
+
+
+def default_context(device=0):
+    """Process-wide context for `device` (created on first use)."""
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]

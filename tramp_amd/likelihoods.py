@@ -1,0 +1,201 @@
+"""Likelihoods (leaf factors, y observed): host mirror of tramp.likelihoods.
+
+tramp/likelihoods/{base_likelihood,gaussian_likelihood,sgn_likelihood,abs_likelihood}.py.
+``y`` is uploaded once at construction and stays resident.
+"""
+import numpy as np
+
+from .base import Factor, VecArg, ScalArg, out_vec, ret_vec, ret_scal
+from .device import DeviceArray
+
+
+class Likelihood(Factor):
+    "tramp/likelihoods/base_likelihood.py:6-118"
+    n_next = 0
+    n_prev = 1
+    _which_diag = None
+
+    def get_size(self, y):
+        if y is None:
+            return None
+        return y.shape[0] if len(y.shape) == 1 else y.shape
+
+    def _set_y(self, y):
+        self.y = y
+        self._y_dev = None
+        if y is None:
+            return
+        if isinstance(y, DeviceArray):
+            self._y_dev = y if y.ndim == 2 else y.reshape(1, y.shape[0])
+        else:
+            self._y_dev = self.ctx.array(np.atleast_2d(np.asarray(y, dtype=self.dtype)), self.dtype)
+
+    def _y_for(self, b: VecArg, y=None):
+        yd = self._y_dev
+        if y is not None and y is not self.y:
+            yd = VecArg(self.ctx, y, self.dtype).dev
+        if yd is None:
+            raise ValueError("likelihood has no observation y")
+        if yd.shape != (b.batch, b.n):
+            raise ValueError(f"y has shape {yd.shape}, message has {(b.batch, b.n)}")
+        return yd
+
+    def _message(self, az, bz, y=None, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None,
+                 want_posterior=False):
+        ctx = self.ctx
+        b = VecArg(ctx, bz, self.dtype)
+        a = ScalArg(ctx, az, b.batch)
+        yd = self._y_for(b, y)
+        a_new = out_a if out_a is not None else ctx.empty((b.batch,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, b, self.dtype)
+        r = out_vec(ctx, b, self.dtype) if want_posterior else None
+        v = ctx.empty((b.batch,), np.float64) if want_posterior else None
+        ctx._call(self._kernel_name, self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr, yd.ptr,
+                  float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr,
+                  r.ptr if r is not None else None, v.ptr if v is not None else None)
+        return a, b, a_new, b_new, r, v
+
+    def _diag(self, az, bz, y):
+        ctx = self.ctx
+        b = ctx.array(np.asarray(bz, dtype=self.dtype))
+        a = ctx.array(np.broadcast_to(np.asarray(az, dtype=self.dtype), b.shape).copy())
+        yd = ctx.array(np.asarray(y, dtype=self.dtype))
+        outs = [ctx.empty(b.shape, self.dtype) for _ in range(4)]
+        ctx._call("tramp_diag_factor", self._dt, self._which_diag, b.size, a.ptr, b.ptr, yd.ptr, 0.0, 0.0, 0.0,
+                  *[o.ptr for o in outs])
+        return [o.get() for o in outs]
+
+    def compute_backward_message(self, az, bz, **kw):
+        "Likelihood.compute_backward_message (base_likelihood.py:25-28)"
+        if not self.isotropic:
+            a_new, b_new, _, _ = self._diag(az, bz, self.y)
+            return a_new, b_new
+        a, b, a_new, b_new, _, _ = self._message(az, bz, **kw)
+        return ret_scal(a_new, a, b), ret_vec(b_new, b)
+
+    def compute_backward_posterior(self, az, bz, y):
+        if not self.isotropic:
+            _, _, r, v = self._diag(az, bz, y)
+            return r, v
+        a, b, _, _, r, v = self._message(az, bz, y=y, want_posterior=True)
+        return ret_vec(r, b), ret_scal(v, a, b)
+
+    def compute_backward_state_evolution(self, az, tau_z):
+        "base_likelihood.py:73-76"
+        vz = self.compute_backward_error(az, tau_z)
+        return self.compute_a_new(vz, az)
+
+    def compute_backward_overlap(self, az, tau_z):
+        return tau_z - self.compute_backward_error(az, tau_z)
+
+
+class GaussianLikelihood(Likelihood):
+    "tramp/likelihoods/gaussian_likelihood.py:7-132 (K6: constant message)"
+
+    def __init__(self, y, var=1, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        self.y_name = y_name
+        self.size = self.get_size(y)
+        self.var = var
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.sigma = np.sqrt(var)
+        self.a = 1 / var
+        self._set_y(y)
+        self._b_dev = None      # y / var, formed once on the device (gaussian_likelihood.py:17)
+
+    def sample(self, X):
+        return X + self.sigma * np.random.standard_normal(X.shape)
+
+    def compute_backward_posterior(self, az, bz, y):
+        "gaussian_likelihood.py:43-49 (host arithmetic; not on the EP path)"
+        bz = bz.get() if isinstance(bz, DeviceArray) else np.asarray(bz)
+        y = y.get() if isinstance(y, DeviceArray) else np.asarray(y)
+        a = az + self.a
+        return (bz + self.a * y) / a, 1 / a
+
+    def compute_backward_message(self, az, bz, out_a=None, out_b=None, **_):
+        "gaussian_likelihood.py:68-71"
+        ctx = self.ctx
+        b = VecArg(ctx, bz, self.dtype)
+        a = ScalArg(ctx, az, b.batch)
+        yd = self._y_for(b)
+        a_new = out_a if out_a is not None else ctx.empty((b.batch,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, b, self.dtype)
+        ctx._call("tramp_gauss_lik_bwd", self._dt, b.n, b.batch, yd.ptr, float(self.var), a_new.ptr, b_new.ptr)
+        return ret_scal(a_new, a, b), ret_vec(b_new, b)
+
+    def compute_backward_error(self, az, tau_z):
+        "gaussian_likelihood.py:58-61"
+        return 1 / (az + self.a)
+
+    def compute_backward_state_evolution(self, az, tau_z):
+        "gaussian_likelihood.py:73-75"
+        return self.a
+
+
+class SgnLikelihood(Likelihood):
+    "tramp/likelihoods/sgn_likelihood.py:9-98 (K4)"
+    _kernel_name = "tramp_sgn_lik_bwd"
+    _which_diag = 2
+
+    def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        self.y_name = y_name
+        self.size = self.get_size(y)
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self._set_y(y)
+
+    def sample(self, X):
+        return np.sign(X)
+
+    def compute_backward_error(self, az, tau_z):
+        "base_likelihood.py:78-81 with beliefs_measure sgn_likelihood.py:79-92 (K13)"
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        tz = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        if np.any(az_h - 1 / tz <= 0):
+            raise AssertionError("az must be greater than 1/ tau_z")     # sgn_likelihood.py:80-81
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_sgn_lik", az_h.shape[0], az_h.ctypes.data, tz.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+
+class AbsLikelihood(Likelihood):
+    "tramp/likelihoods/abs_likelihood.py:8-72 (K5)"
+    _kernel_name = "tramp_abs_lik_bwd"
+    _which_diag = 3
+
+    def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        self.y_name = y_name
+        self.size = self.get_size(y)
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self._set_y(y)
+
+    def sample(self, X):
+        return np.abs(X)
+
+    def compute_backward_error(self, az, tau_z):
+        "beliefs_measure abs_likelihood.py:60-69 (2-D quadrature, K14 family)"
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        tz = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        if np.any(az_h - 1 / tz <= 0):
+            raise AssertionError("az must be greater than 1/tau_z")
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_abs_lik", az_h.shape[0], az_h.ctypes.data, tz.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+
+LIKELIHOOD_CLASSES = {
+    "gaussian": GaussianLikelihood,
+    "abs": AbsLikelihood,
+    "sgn": SgnLikelihood,
+}
+
+
+def get_likelihood(y, likelihood_type, **kwargs):
+    "tramp/likelihoods/__init__.py:25-27"
+    return LIKELIHOOD_CLASSES[likelihood_type](y=y, **kwargs)

@@ -1,0 +1,245 @@
+"""Priors (root factors): host mirror of tramp.priors for the hot-path classes.
+
+Same class names, constructor arguments and method signatures as
+tramp/priors/{base_prior,gauss_bernoulli_prior,map_L1_norm_prior,gaussian_prior}.py;
+the method bodies launch HIP kernels through the C ABI.  Extra keyword-only
+arguments (``out_a``, ``out_b``, ``damping``, ``old_a``, ``old_b``) serve the
+device-resident scheduler and have no counterpart in the reference.
+"""
+import numpy as np
+
+from .base import Factor, VecArg, ScalArg, out_vec, ret_vec, ret_scal
+from .device import DeviceArray
+
+
+class Prior(Factor):
+    "tramp/priors/base_prior.py:6-107"
+    n_next = 1
+    n_prev = 0
+
+    def _message(self, kernel, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None,
+                 want_posterior=False):
+        ctx = self.ctx
+        b = VecArg(ctx, bx, self.dtype)
+        a = ScalArg(ctx, ax, b.batch)
+        a_new = out_a if out_a is not None else ctx.empty((b.batch,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, b, self.dtype)
+        r = out_vec(ctx, b, self.dtype) if want_posterior else None
+        v = ctx.empty((b.batch,), np.float64) if want_posterior else None
+        kernel(b, a, float(damping or 0.0),
+               old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
+               a_new, b_new, r, v)
+        return a, b, a_new, b_new, r, v
+
+    def compute_forward_message(self, ax, bx, **kw):
+        "Prior.compute_forward_message (base_prior.py:13-16)"
+        a, b, a_new, b_new, _, _ = self._message(self._kernel, ax, bx, **kw)
+        return ret_scal(a_new, a, b), ret_vec(b_new, b)
+
+    def compute_forward_posterior(self, ax, bx):
+        a, b, _, _, r, v = self._message(self._kernel, ax, bx, want_posterior=True)
+        return ret_vec(r, b), ret_scal(v, a, b)
+
+    def compute_forward_state_evolution(self, ax):
+        "base_prior.py:61-64"
+        vx = self.compute_forward_error(ax)
+        return self.compute_a_new(vx, ax)
+
+    def compute_forward_overlap(self, ax):
+        return self.second_moment() - self.compute_forward_error(ax)
+
+
+class GaussBernoulliPrior(Prior):
+    r"""Gauss-Bernoulli prior p(x) = (1-rho) delta(x) + rho N(x | mean, var).
+
+    tramp/priors/gauss_bernoulli_prior.py:8-126 (kernel K1).
+    """
+
+    def __init__(self, size, rho=0.5, mean=0, var=1, isotropic=True, dtype=np.float64, ctx=None):
+        self.size = size
+        self.rho = rho
+        self.mean = mean
+        self.var = var
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.sigma = np.sqrt(var)
+        self.a = 1 / var
+        self.b = mean / var
+        # normal.A(a, b) - log(rho / (1 - rho))   (gauss_bernoulli_prior.py:36)
+        self.eta = 0.5 * (self.b**2 / self.a + np.log(2 * np.pi / self.a)) - np.log(rho / (1 - rho))
+
+    def sample(self):
+        "gauss_bernoulli_prior.py:38-42"
+        X_gauss = self.mean + self.sigma * np.random.standard_normal(self.size)
+        X_bernoulli = np.random.binomial(n=1, size=self.size, p=self.rho)
+        return X_gauss * X_bernoulli
+
+    def second_moment(self):
+        return self.rho * (self.mean**2 + self.var)
+
+    def _kernel(self, b, a, damping, old_a, old_b, a_new, b_new, r, v):
+        self.ctx._call("tramp_gb_prior_fwd", self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr,
+                       float(self.rho), float(self.mean), float(self.var), damping, old_a, old_b,
+                       a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
+                       v.ptr if v is not None else None)
+
+    def _diag(self, ax, bx):
+        ctx = self.ctx
+        b = ctx.array(np.asarray(bx, dtype=self.dtype))
+        a = ctx.array(np.broadcast_to(np.asarray(ax, dtype=self.dtype), b.shape).copy())
+        outs = [ctx.empty(b.shape, self.dtype) for _ in range(4)]
+        ctx._call("tramp_diag_factor", self._dt, 0, b.size, a.ptr, b.ptr, None, float(self.rho),
+                  float(self.mean), float(self.var), *[o.ptr for o in outs])
+        return [o.get() for o in outs]      # a_new, b_new, r, v
+
+    def compute_forward_posterior(self, ax, bx):
+        if not self.isotropic:
+            _, _, r, v = self._diag(ax, bx)
+            return r, v
+        return super().compute_forward_posterior(ax, bx)
+
+    def compute_forward_message(self, ax, bx, **kw):
+        if not self.isotropic:
+            a_new, b_new, _, _ = self._diag(ax, bx)
+            return a_new, b_new
+        return super().compute_forward_message(ax, bx, **kw)
+
+    def compute_forward_error(self, ax):
+        """SE error E_b[v(ax, b)] (base_prior.py:66-69, beliefs_measure
+        gauss_bernoulli_prior.py:116-122): quadrature kernel K13."""
+        ax_h = np.atleast_1d(np.asarray(ax, dtype=np.float64))
+        n = ax_h.shape[0]
+        par = [np.full(n, float(p)) for p in (self.rho, self.mean, self.var)]
+        v = np.empty(n)
+        self.ctx._call("tramp_se_gb_prior", n, ax_h.ctypes.data, par[0].ctypes.data, par[1].ctypes.data,
+                       par[2].ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(ax) == 0 else v
+
+
+class MAP_L1NormPrior(Prior):
+    r"""MAP prior of the penalty gamma ||x||_1: soft-threshold denoiser.
+
+    tramp/priors/map_L1_norm_prior.py:20-88 (kernel K2).
+    """
+
+    def __init__(self, size, gamma=1, isotropic=True, dtype=np.float64, ctx=None):
+        self.size = size
+        self.gamma = gamma
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+
+    def sample(self):
+        return np.random.laplace(size=self.size, scale=1 / self.gamma)
+
+    def second_moment(self):
+        raise NotImplementedError
+
+    def _kernel(self, b, a, damping, old_a, old_b, a_new, b_new, r, v, count=None, mask=None):
+        self.ctx._call("tramp_l1_prior_fwd", self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr,
+                       float(self.gamma), damping, old_a, old_b, a_new.ptr, b_new.ptr,
+                       r.ptr if r is not None else None, v.ptr if v is not None else None,
+                       count.ptr if count is not None else None, mask.ptr if mask is not None else None)
+
+    def support(self, ax, bx):
+        "Exact support mask |bx| > gamma and its count (v_soft_threshold, map_L1_norm_prior.py:16-17)."
+        ctx = self.ctx
+        b = VecArg(ctx, bx, self.dtype)
+        a = ScalArg(ctx, ax, b.batch)
+        count = ctx.empty((b.batch,), np.uint64)
+        mask = ctx.empty((b.batch, b.n), np.uint8)
+        self._kernel(b, a, 0.0, None, None, ctx.empty((b.batch,), np.float64),
+                     out_vec(ctx, b, self.dtype), None, None, count, mask)
+        return mask.get().reshape(b.host_shape).astype(bool), count.get()
+
+    def _diag(self, ax, bx):
+        ctx = self.ctx
+        b = ctx.array(np.asarray(bx, dtype=self.dtype))
+        a = ctx.array(np.broadcast_to(np.asarray(ax, dtype=self.dtype), b.shape).copy())
+        outs = [ctx.empty(b.shape, self.dtype) for _ in range(4)]
+        ctx._call("tramp_diag_factor", self._dt, 1, b.size, a.ptr, b.ptr, None, float(self.gamma), 0.0, 0.0,
+                  *[o.ptr for o in outs])
+        return [o.get() for o in outs]
+
+    def compute_forward_posterior(self, ax, bx):
+        if not self.isotropic:
+            _, _, r, v = self._diag(ax, bx)
+            return r, v
+        return super().compute_forward_posterior(ax, bx)
+
+    def compute_forward_message(self, ax, bx, **kw):
+        if not self.isotropic:
+            a_new, b_new, _, _ = self._diag(ax, bx)
+            return a_new, b_new
+        return super().compute_forward_message(ax, bx, **kw)
+
+    def compute_forward_error(self, ax):
+        raise NotImplementedError      # as the reference (map_L1_norm_prior.py:84-85)
+
+
+class GaussianPrior(Prior):
+    r"""Gaussian prior N(x | mean, var): constant message, closed-form errors.
+
+    tramp/priors/gaussian_prior.py:8-143 (kernel K3).
+    """
+
+    def __init__(self, size, mean=0, var=1, isotropic=True, dtype=np.float64, ctx=None):
+        self.size = size
+        self.mean = mean
+        self.var = var
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.sigma = np.sqrt(var)
+        self.a = 1 / var
+        self.b = mean / var
+
+    def sample(self):
+        return self.mean + self.sigma * np.random.standard_normal(self.size)
+
+    def second_moment(self):
+        return self.mean**2 + self.var
+
+    def compute_forward_posterior(self, ax, bx):
+        "gaussian_prior.py:63-68 (host arithmetic on the caller's arrays; not on the EP path)"
+        if isinstance(bx, DeviceArray):
+            bx = bx.get()
+        if isinstance(ax, DeviceArray):
+            ax = ax.get()
+        a = np.asarray(ax) + self.a
+        b = np.asarray(bx) + self.b
+        if np.ndim(a) == 1 and np.ndim(b) == 2:
+            a = a[:, None]
+        return b / a, 1 / (np.asarray(ax) + self.a)
+
+    def compute_forward_message(self, ax, bx, out_a=None, out_b=None, **_):
+        "gaussian_prior.py:86-89: bypasses compute_ab_new (and damping sees a constant)"
+        ctx = self.ctx
+        b = VecArg(ctx, bx, self.dtype)
+        a = ScalArg(ctx, ax, b.batch)
+        a_new = out_a if out_a is not None else ctx.empty((b.batch,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, b, self.dtype)
+        ctx._call("tramp_gauss_prior_fwd", self._dt, b.n, b.batch, float(self.mean), float(self.var),
+                  a_new.ptr, b_new.ptr)
+        return ret_scal(a_new, a, b), ret_vec(b_new, b)
+
+    def compute_forward_error(self, ax):
+        "gaussian_prior.py:76-79"
+        return 1 / (ax + self.a)
+
+    def compute_forward_state_evolution(self, ax):
+        "gaussian_prior.py:91-93"
+        return self.a
+
+
+PRIOR_CLASSES = {
+    "gauss_bernoulli": GaussBernoulliPrior,
+    "gaussian": GaussianPrior,
+    "L1_norm": MAP_L1NormPrior,
+}
+
+
+def get_prior(size, prior_type, **kwargs):
+    "tramp/priors/__init__.py:25-27"
+    return PRIOR_CLASSES[prior_type](size=size, **kwargs)
