@@ -73,8 +73,11 @@ def test_ep_trajectories_fp64(ctx, golden_ep):
             rt = 1e-7 if it < 6 else 1e-5            # round-off amplifies along the trajectory
             for vid in ids:
                 e = rec.iters[it]["edges"]
-                close(e[(vid, "fwd")][0], t[f"fwd:{vid}:a"][it], rt)
-                close(e[(vid, "bwd")][0], t[f"bwd:{vid}:a"][it], rt)
+                # a_new = 1/v - a cancels when the posterior precision is dominated by the
+                # other direction: compare on the scale of 1/v = a_fwd + a_bwd
+                a_tot = t[f"fwd:{vid}:a"][it] + t[f"bwd:{vid}:a"][it]
+                close(e[(vid, "fwd")][0], t[f"fwd:{vid}:a"][it], rt, scale=a_tot)
+                close(e[(vid, "bwd")][0], t[f"bwd:{vid}:a"][it], rt, scale=a_tot)
                 close(rec.iters[it]["b"][(vid, "fwd")], t[f"fwd:{vid}:b"][it], rt)
                 close(rec.iters[it]["b"][(vid, "bwd")], t[f"bwd:{vid}:b"][it], rt)
                 close(rec.iters[it]["vars"][vid]["r"], t[f"r:{vid}"][it], rt)

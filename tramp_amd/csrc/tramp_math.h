@@ -66,7 +66,7 @@ template <typename T> TM_HD T expit(T x) {
 
 // ---- A1: message update, scalars always double (tramp/base.py:245-255) ----
 TM_HD double a_new_of(double v, double a) {
-    double inv = 1.0 / fmax(v, kVFloor);
+    double inv = 1.0 / (v < kVFloor ? kVFloor : v);   // np.maximum propagates NaN, fmax would not
     double an = inv - a;
     // np.clip propagates NaN; fmin/fmax would swallow it
     if (an < kAMin) an = kAMin;
