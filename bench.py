@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EP iterations/s x N x instances (msg-components/s) for the sparse GLM
+(GaussBernoulli prior + dense LinearChannel + Gaussian likelihood, Gaussian ensemble,
+alpha = 0.5, fp64) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full EP iteration (forward sweep, backward sweep, variable posteriors) over
+the rank's batch of independent problem instances that share the sensing matrix W (the
+ensemble axis of BASELINE.json configs[3]).  Instances are sharded across ranks with no
+data-path collective: rank 0 draws W and broadcasts it once over RCCL (setup, untimed), every
+rank factorises it and runs its own instances ("weak" scaling: per-GPU work fixed).
+Setup (W generation, broadcast, factorisation, teacher data) is reported separately, as the
+reference reports svd_time separately (examples/figures/compute_benchmark.py:21-27).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # fp64: AMD datasheet (matrix = vector rate); fp32: guide
+
+TAGS = ["ew_factor_update", "matvec_nt", "matvec_nn", "linear_scalars", "variable_posterior", "other"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 16384)))
+    ap.add_argument("--alpha", type=float, default=0.5)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TRAMP_BENCH_BATCH", 64)),
+                    help="instances per GPU")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--rho", type=float, default=0.05)
+    ap.add_argument("--noise-var", type=float, default=1e-2)
+    ap.add_argument("--damping", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-denoiser", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=2000)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (NumPy restatement of the reference's path, reference formulation with the
+    full SVD) timed on the host cores, on a bounded sample of the same workload."""
+    from oracle import tramp_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    N = args.cpu_n
+    M = int(args.alpha * N)
+    rs = np.random.RandomState(1)
+    W = orc.gaussian_ensemble(rs, M, N)
+    x = orc.gb_sample(rs, N, args.rho)
+    y = W @ x + np.sqrt(args.noise_var) * rs.standard_normal(M)
+    t0 = time.perf_counter()
+    lin = orc.LinearFactor(W)
+    setup_s = time.perf_counter() - t0
+    fs = [orc.GBPriorFactor(N, rho=args.rho), lin, orc.GaussLikFactor(y, args.noise_var)]
+    iters = 40
+    orc.ep_chain(fs, [N, M], max_iter=2, damping=args.damping, tol=0.0)       # warm-up
+    t0 = time.perf_counter()
+    res = orc.ep_chain(fs, [N, M], max_iter=iters, damping=args.damping, tol=0.0, max_increase=np.inf)
+    dt = time.perf_counter() - t0
+    return {"value": N * res["n_iter"] / dt, "unit": "msg-components/s", "cores": int(threads), "kind": "port",
+            "sample": f"oracle EP (reference formulation: full SVD, 4 dense mat-vecs per solve), 1 instance, "
+                      f"N={N}, alpha={args.alpha}, {res['n_iter']} iterations in {dt:.2f} s "
+                      f"(+{setup_s:.1f} s SVD setup, untimed), NumPy/OpenBLAS {threads} threads, "
+                      f"{os.cpu_count()} host cores"}
+
+
+def denoiser_roofline(T, ctx, dtype):
+    """Gauss-Bernoulli denoiser (K1) at the BASELINE vector size N = 1e6: single instance
+    (latency regime, data stays in cache) and a 64-instance ensemble (512 MB per array, past
+    the 256 MB Infinity Cache).  Algorithmic traffic 2T bytes per component."""
+    out = {}
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    for B in (1, 64):
+        N = 1_000_000
+        bx = ctx.randn((B, N), np_dt, seed=3, scale=1.5)
+        ax = ctx.scalars(1.3, B)
+        p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
+        a_new = ctx.empty((B,), np.float64)
+        b_new = ctx.empty((B, N), np_dt)
+        for _ in range(3):
+            p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)
+        reps = 50 if B == 1 else 10
+        e0, e1 = ctx.event(), ctx.event()
+        e0.record()
+        for _ in range(reps):
+            p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)
+        e1.record()
+        ms = e0.elapsed_ms(e1) / reps
+        alg = 2 * np.dtype(np_dt).itemsize * N * B
+        out[f"B{B}"] = {"n": N, "batch": B, "us_per_update": ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
+                        "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
+                        "components_per_sec": N * B / (ms * 1e-3)}
+        del bx, b_new
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks",
+                  file=sys.stderr)
+            sys.exit(2)
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import tramp_amd as T
+    ctx = T.Context(local_rank)
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    N, B = args.n, args.batch
+    M = int(args.alpha * N)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    # ---------------- setup (untimed, reported)
+    t_setup = time.perf_counter()
+    if dist is None:
+        W = ctx.randn((M, N), np_dt, seed=1234, scale=1.0 / np.sqrt(N))
+    else:
+        # shared sensing matrix: rank 0 draws it, RCCL broadcast over xGMI to the other ranks
+        Wt = torch.empty((M, N), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device="cuda")
+        W = T.DeviceArray(ctx, (M, N), np_dt, ptr=Wt.data_ptr(), owner=False)
+        if rank == 0:
+            ctx._call("tramp_randn", T.device.dtype_code(np_dt), W.ptr, W.size, 1234, 1.0 / np.sqrt(N))
+            ctx.sync()
+        tb = time.perf_counter()
+        dist.broadcast(Wt, src=0)
+        torch.cuda.synchronize()
+        bcast_s = time.perf_counter() - tb
+    # teacher data of this rank's instances (per-rank seeds)
+    rs = np.random.RandomState(1000 + rank)
+    X = (rs.standard_normal((B, N)) * rs.binomial(1, args.rho, (B, N))).astype(np_dt)
+    Xd = ctx.array(X, np_dt)
+    Zd = ctx.empty((B, M), np_dt)
+    ctx._call("tramp_matvec_nt", T.device.dtype_code(np_dt), 0, M, N, B, W.ptr, Xd.ptr, Zd.ptr)
+    Y = Zd.get() + np.sqrt(args.noise_var) * rs.standard_normal((B, M))
+    tf = time.perf_counter()
+    lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device")
+    ctx.sync()
+    factorize_s = time.perf_counter() - tf
+    del W
+    if dist is not None:
+        del Wt
+        torch.cuda.empty_cache()
+    model = (T.GaussBernoulliPrior(size=N, rho=args.rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x")
+             @ lin @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=Y.astype(np_dt), var=args.noise_var, dtype=np_dt, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    setup_s = time.perf_counter() - t_setup
+
+    # ---------------- warm-up, then EXACTLY K timed steps
+    never = 1 << 30
+    ep.iterate(max_iter=max(args.warmup, 1), callback=T.PassCallback(), damping=args.damping, check_every=never)
+    ctx._call("tramp_profile_enable", 1)
+    barrier()
+    t0 = time.perf_counter()
+    ep.iterate(max_iter=args.steps, callback=T.PassCallback(), damping=args.damping, warm_start=True,
+               check_every=never)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes as C
+    cnt = (C.c_int * 6)()
+    ms = (C.c_double * 6)()
+    by = (C.c_double * 6)()
+    fl = (C.c_double * 6)()
+    ctx._call("tramp_profile_report", cnt, ms, by, fl)
+    ctx._call("tramp_profile_enable", 0)
+    mse = float(np.mean(ep.mse("x", X)))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_units = float(N) * B * world * args.steps
+        kern = {TAGS[i]: {"launches": cnt[i], "ms": ms[i], "bytes": by[i], "flops": fl[i]} for i in range(6)
+                if cnt[i]}
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        d = kern[dom]
+        use_mfma = B > T._lib.GEMV_MAX_BATCH and dom.startswith("matvec")
+        if use_mfma:
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": None,
+                    "avg_launch_ms": d["ms"] / d["launches"], "launches": d["launches"],
+                    "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
+        else:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": d["ms"] / d["launches"],
+                    "launches": d["launches"]}
+        out = {
+            "metric": "EP iterations/sec x N x instances (msg-components/sec), sparse GLM, alpha=0.5",
+            "value": total_units / elapsed, "unit": "msg-components/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "sparse-GLM EP ensemble: GaussBernoulliPrior(rho=%g) + dense LinearChannel "
+                                   "(Gaussian ensemble W shared by the instances) + GaussianLikelihood(var=%g), "
+                                   "damping %g; dense W at N=1e6 (4 TB) cannot exist, this is BASELINE "
+                                   "configs[3]'s per-GPU shard shape" % (args.rho, args.noise_var, args.damping),
+                       "N": N, "M": M, "alpha": args.alpha, "instances_per_gpu": B,
+                       "instances_total": B * world, "parallelism": f"ensemble-shard x{world}"},
+            "roofline": roof,
+            "kernels": kern,
+            "setup": {"total_s": setup_s, "factorize_s": factorize_s,
+                      "broadcast_W_s": (bcast_s if dist is not None else None)},
+            "mse_after_run": mse,
+            "device": ctx.device_name(),
+        }
+        if world == 1 and not args.no_denoiser:
+            out["denoiser_n1e6"] = denoiser_roofline(T, ctx, args.dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

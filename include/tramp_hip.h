@@ -95,6 +95,22 @@ int tramp_event_record(tramp_ctx* ctx, tramp_event* ev);
 /* Synchronises on `stop`; milliseconds between the two recorded events. */
 int tramp_event_elapsed_ms(tramp_ctx* ctx, tramp_event* start, tramp_event* stop, float* ms);
 
+/* Per-kernel timing for the roofline report: while enabled, every launch group is
+ * bracketed by HIP events on the context's stream.  tramp_profile_report synchronises
+ * and returns, per tag (TRAMP_PROF_*), the number of launch groups, their summed
+ * duration in ms and the summed ALGORITHMIC bytes / flops the library attributed to
+ * them (matrix passes: R*C*sizeof(T) bytes, 2*R*C*batch flops; elementwise updates:
+ * 2T or 3T bytes per component).  Arrays hold TRAMP_PROF_NTAGS entries. */
+#define TRAMP_PROF_EW 0
+#define TRAMP_PROF_MATVEC_NT 1
+#define TRAMP_PROF_MATVEC_NN 2
+#define TRAMP_PROF_LIN_SCALARS 3
+#define TRAMP_PROF_VAR_POST 4
+#define TRAMP_PROF_OTHER 5
+#define TRAMP_PROF_NTAGS 6
+int tramp_profile_enable(tramp_ctx* ctx, int on);
+int tramp_profile_report(tramp_ctx* ctx, int* count, double* ms, double* bytes, double* flops);
+
 /* ---- priors (root factors) ---------------------------------------------- */
 /* K1. GaussBernoulliPrior.compute_forward_posterior + Prior.compute_forward_message
  *     tramp/priors/gauss_bernoulli_prior.py:70-77, tramp/priors/base_prior.py:13-16,

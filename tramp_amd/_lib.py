@@ -75,6 +75,8 @@ _SIGNATURES = {
     "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
     "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],
     "tramp_randn": [vp, i32, vp, sz, u64, dbl],
+    "tramp_profile_enable": [vp, i32],
+    "tramp_profile_report": [vp, vp, vp, vp, vp],
 }
 _RESTYPES = {"tramp_version": C.c_char_p, "tramp_last_error": C.c_char_p}
 EXPORTS = sorted(list(_SIGNATURES) + list(_RESTYPES))

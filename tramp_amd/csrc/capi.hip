@@ -58,8 +58,51 @@ extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->hscratch) (void)hipHostFree(ctx->hscratch);
+    if (ctx->prof) {
+        for (int i = 0; i < ctx->prof_cap; ++i) {
+            (void)hipEventDestroy(ctx->prof[i].start);
+            (void)hipEventDestroy(ctx->prof[i].stop);
+        }
+        delete[] ctx->prof;
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_profile_enable(tramp_ctx* ctx, int on) {
+    if (!ctx) return TRAMP_EINVAL;
+    if (on && !ctx->prof) {
+        ctx->prof_cap = 8192;
+        ctx->prof = new (std::nothrow) TrampProfRec[ctx->prof_cap];
+        if (!ctx->prof) return TRAMP_ENOMEM;
+        for (int i = 0; i < ctx->prof_cap; ++i) {
+            TRAMP_HIP_CHECK(ctx, hipEventCreate(&ctx->prof[i].start));
+            TRAMP_HIP_CHECK(ctx, hipEventCreate(&ctx->prof[i].stop));
+        }
+    }
+    ctx->prof_on = on != 0;
+    ctx->prof_n = 0;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_profile_report(tramp_ctx* ctx, int* count, double* ms, double* bytes, double* flops) {
+    if (!ctx || !count || !ms || !bytes || !flops) return TRAMP_EINVAL;
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < PROF_NTAGS; ++t) {
+        count[t] = 0;
+        ms[t] = bytes[t] = flops[t] = 0.0;
+    }
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        const TrampProfRec& r = ctx->prof[i];
+        float e = 0.f;
+        TRAMP_HIP_CHECK(ctx, hipEventElapsedTime(&e, r.start, r.stop));
+        count[r.tag] += 1;
+        ms[r.tag] += e;
+        bytes[r.tag] += r.bytes;
+        flops[r.tag] += r.flops;
+    }
+    ctx->prof_n = 0;
     return TRAMP_OK;
 }
 

@@ -8,6 +8,23 @@
 
 #include "../../include/tramp_hip.h"
 
+// ---- optional per-kernel timing (bench.py roofline): HIP events around tagged launches
+enum TrampProfTag {
+    PROF_EW = 0,        // elementwise factor update (both passes)
+    PROF_MATVEC_NT,     // row-dot matrix pass (GEMV or MFMA)
+    PROF_MATVEC_NN,     // column-accumulate matrix pass (+ fold)
+    PROF_LIN_SCALARS,   // K9 + spectral coefficients
+    PROF_VAR_POST,      // K11
+    PROF_OTHER,
+    PROF_NTAGS
+};
+
+struct TrampProfRec {
+    hipEvent_t start, stop;
+    int tag;
+    double bytes, flops;
+};
+
 struct tramp_ctx {
     int device;
     hipStream_t stream;
@@ -17,6 +34,27 @@ struct tramp_ctx {
     size_t hscratch_bytes;
     int num_cu;
     char err[512];
+    // profiling
+    bool prof_on;
+    TrampProfRec* prof;
+    int prof_cap, prof_n;
+};
+
+// RAII scope: records start/stop events on the context's stream when profiling is on.
+struct ProfScope {
+    tramp_ctx* ctx;
+    TrampProfRec* rec;
+    ProfScope(tramp_ctx* c, int tag, double bytes, double flops) : ctx(c), rec(nullptr) {
+        if (!c->prof_on || c->prof_n >= c->prof_cap) return;
+        rec = &c->prof[c->prof_n++];
+        rec->tag = tag;
+        rec->bytes = bytes;
+        rec->flops = flops;
+        (void)hipEventRecord(rec->start, c->stream);
+    }
+    ~ProfScope() {
+        if (rec) (void)hipEventRecord(rec->stop, ctx->stream);
+    }
 };
 
 struct tramp_event {

@@ -278,6 +278,8 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
     if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
     const T* p0 = reinterpret_cast<const T*>(in0);
     const T* p1 = reinterpret_cast<const T*>(in1);
+    // algorithmic traffic: read every input once, write b_new once
+    ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
     if (vec) {
         hipLaunchKernelGGL((ew_pass1<T, Op, true>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount);
         hipLaunchKernelGGL((ew_pass2<T, Op, true>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount, nblk, o);
@@ -586,6 +588,7 @@ extern "C" int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, siz
     int rc = tramp_ws_reserve(ctx, batch * (size_t)nblk * 2 * sizeof(double));
     if (rc) return rc;
     dim3 grid(nblk, (unsigned)batch);
+    ProfScope prof(ctx, PROF_VAR_POST, 3.0 * dtype_size(dtype) * (double)n * (double)batch, 0.0);
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((var_post_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, a1_d,
                            (const double*)b1_d, a2_d, (const double*)b2_d, (const double*)r_old_d,

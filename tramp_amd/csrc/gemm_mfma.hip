@@ -1,10 +1,322 @@
-// gemm_mfma.hip - MFMA (matrix-core) kernels of the dense linear channel for
-// ensembles of instances (batch > 8).  Placeholder until the tiled kernels land:
-// reports "unsupported" so that the dispatcher streams with the VALU kernels.
+// gemm_mfma.hip - matrix-core kernels of the dense linear channel for ensembles (batch > 8).
+//
+// Both primitives stream a large row-major matrix mat [R, C] exactly once from HBM and
+// contract it against a small batch of vectors (<= 64 per pass) on v_mfma_f64_16x16x4_f64
+// (f32: v_mfma_f32_16x16x4_f32, same fragment shape):
+//     NT: out[b, r] = sum_c mat[r, c] x[b, c]        NN: out[b, c] = sum_r mat[r, c] x[b, r]
+// At batch 64 / f64 the contraction is balanced between HBM (R*C*8 bytes) and the matrix
+// pipe (2*R*C*64 flops), so the design keeps both busy:
+//   * mat goes global -> registers directly in MFMA operand layout (no reuse across
+//     workgroups exists, LDS would only add a hop).  The MFMA k index is free to permute
+//     as long as A and B agree, which lets every lane fetch 16-byte pieces:
+//       NT  lane (j = l&15, q = l>>4) loads mat[r0+j][k0 + 8p + 2q + e]  (p,e in {0,1})
+//           -> 4 MFMAs per 16-column step; a row contributes 64 contiguous bytes per load
+//       NN  lane (j, q) loads mat[k0 + 4q + s][c0 + 2j + {0,1}], s = 0..3
+//           -> even / odd output columns are two MFMA n-tiles; 256 contiguous bytes per row
+//   * x (shared by all waves of a workgroup, re-read by every row block) is staged through
+//     LDS in fragment order (lane l owns bytes [16 l, 16 l + 16) of a 1 KiB fragment):
+//     linear ds_write_b128 / ds_read_b128, no bank conflicts; double-buffered, one barrier
+//     per 16-deep k step (32 MFMAs = 2048 matrix-pipe cycles per wave between barriers).
+//   * split-K: blockIdx = row_block * S + split with S = 8, so split index == XCD under the
+//     round-robin dispatch (speed only): each XCD's L2 holds only its eighth of x.
+//     Partial tiles go to a workspace and are folded in fixed order by a second kernel that
+//     also applies the fused message-update epilogue -> deterministic results.
+// One wave: RT x 16 mat rows (NT) or 32 columns (NN) times up to 64 instances:
+// 8 accumulator tiles = 64 VGPRs.
 #include "linear.h"
 
-bool gemm_mfma_supported(int, bool, size_t, size_t, size_t) { return false; }
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
-int gemm_mfma(tramp_ctx* ctx, int, bool, size_t, size_t, size_t, const void*, const void*, const LinEpi&) {
-    return tramp_fail(ctx, TRAMP_ENOTSUP, "gemm_mfma", "not built");
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+    using acc_t = d4;
+    static __device__ __forceinline__ d4 run(double a, double b, d4 c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<float> {
+    using acc_t = f4;
+    static __device__ __forceinline__ f4 run(float a, float b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+constexpr int kSplit = 8;     // == number of XCDs
+constexpr int kKStep = 16;    // k depth of one pipeline step (f64: 2 x 16-byte pieces per lane)
+
+// ------------------------------------------------------------------------------ NT, f64
+// Workgroup: 4 waves x (RT*16) rows; grid.x = row_blocks * kSplit; grid.y = batch chunks of 64.
+template <int BT, int RT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_nt_f64_kernel(size_t R, size_t C, size_t B,
+                                                                const double* __restrict__ mat,
+                                                                const double* __restrict__ x,
+                                                                size_t steps_per_split,
+                                                                double* __restrict__ partials) {
+    __shared__ double2 xs[2][BT][2][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const size_t rb = blockIdx.x / kSplit, split = blockIdx.x % kSplit;
+    const size_t bchunk = (size_t)blockIdx.y * 64;
+    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;          // instances in this chunk
+    const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
+    const size_t nsteps_total = C / kKStep;
+    const size_t sbeg = split * steps_per_split;
+    size_t send = sbeg + steps_per_split;
+    if (send > nsteps_total) send = nsteps_total;
+    // lane's mat rows (clamped: out-of-range rows are computed on valid memory and never stored)
+    const double* mp[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        size_t r = row0 + rt * 16 + j;
+        if (r >= R) r = R - 1;
+        mp[rt] = mat + r * C + 2 * q;
+    }
+    // x loader: wave w stages batch tile w
+    size_t xb = bchunk + (size_t)wave * 16 + j;
+    if (xb >= B) xb = B - 1;
+    const double* xp = x + xb * C + 2 * q;
+    const bool loads_x = wave < BT;
+
+    d4 acc[RT][BT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = d4{0, 0, 0, 0};
+
+    double2 m[RT][2], mn[RT][2], xg[2];
+    if (sbeg < send) {
+        const size_t k0 = sbeg * kKStep;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            m[rt][0] = *reinterpret_cast<const double2*>(mp[rt] + k0);
+            m[rt][1] = *reinterpret_cast<const double2*>(mp[rt] + k0 + 8);
+        }
+        if (loads_x) {
+            xg[0] = *reinterpret_cast<const double2*>(xp + k0);
+            xg[1] = *reinterpret_cast<const double2*>(xp + k0 + 8);
+        }
+    }
+    for (size_t s = sbeg; s < send; ++s) {
+        const int st = (int)((s - sbeg) & 1);
+        if (loads_x) {
+            xs[st][wave][0][lane] = xg[0];
+            xs[st][wave][1][lane] = xg[1];
+        }
+        if (s + 1 < send) {
+            const size_t k1 = (s + 1) * kKStep;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                mn[rt][0] = *reinterpret_cast<const double2*>(mp[rt] + k1);
+                mn[rt][1] = *reinterpret_cast<const double2*>(mp[rt] + k1 + 8);
+            }
+            if (loads_x) {
+                xg[0] = *reinterpret_cast<const double2*>(xp + k1);
+                xg[1] = *reinterpret_cast<const double2*>(xp + k1 + 8);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                const double2 a = xs[st][bt][p][lane];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][bt] = Mfma<double>::run(a.x, m[rt][p].x, acc[rt][bt]);
+                    acc[rt][bt] = Mfma<double>::run(a.y, m[rt][p].y, acc[rt][bt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            m[rt][0] = mn[rt][0];
+            m[rt][1] = mn[rt][1];
+        }
+    }
+    // D[row = (l>>4) + 4 reg][col = l&15]: row -> instance, col -> mat row
+    double* pout = partials + (split * B) * R;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const size_t r = row0 + rt * 16 + j;
+        if (r < R) {
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const size_t b = bt * 16 + q + 4 * g;
+                    if (b < nb) pout[(bchunk + b) * R + r] = acc[rt][bt][g];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ NN, f64
+// Workgroup: 4 waves x 32 columns; rows (the contraction) split kSplit ways.
+template <int BT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_nn_f64_kernel(size_t R, size_t C, size_t B,
+                                                                const double* __restrict__ mat,
+                                                                const double* __restrict__ x,
+                                                                size_t steps_per_split,
+                                                                double* __restrict__ partials) {
+    __shared__ double2 xs[2][BT][2][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const size_t cb = blockIdx.x / kSplit, split = blockIdx.x % kSplit;
+    const size_t bchunk = (size_t)blockIdx.y * 64;
+    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
+    const size_t col0 = cb * 128 + (size_t)wave * 32;
+    const size_t nsteps_total = R / kKStep;
+    const size_t sbeg = split * steps_per_split;
+    size_t send = sbeg + steps_per_split;
+    if (send > nsteps_total) send = nsteps_total;
+    size_t cl = col0 + 2 * j;                   // lane's column pair (clamped, C is even)
+    if (cl + 1 >= C) cl = C - 2;
+    const double* mp = mat + cl + (size_t)(4 * q) * C;
+    size_t xb = bchunk + (size_t)wave * 16 + j;
+    if (xb >= B) xb = B - 1;
+    const double* xp = x + xb * R + 4 * q;
+    const bool loads_x = wave < BT;
+
+    d4 acc[2][BT];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) acc[nt][bt] = d4{0, 0, 0, 0};
+
+    double2 m[4], mn[4], xg[2];
+    if (sbeg < send) {
+        const size_t k0 = sbeg * kKStep;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) m[s4] = *reinterpret_cast<const double2*>(mp + (k0 + s4) * C);
+        if (loads_x) {
+            xg[0] = *reinterpret_cast<const double2*>(xp + k0);
+            xg[1] = *reinterpret_cast<const double2*>(xp + k0 + 2);
+        }
+    }
+    for (size_t s = sbeg; s < send; ++s) {
+        const int st = (int)((s - sbeg) & 1);
+        if (loads_x) {
+            xs[st][wave][0][lane] = xg[0];
+            xs[st][wave][1][lane] = xg[1];
+        }
+        if (s + 1 < send) {
+            const size_t k1 = (s + 1) * kKStep;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) mn[s4] = *reinterpret_cast<const double2*>(mp + (k1 + s4) * C);
+            if (loads_x) {
+                xg[0] = *reinterpret_cast<const double2*>(xp + k1);
+                xg[1] = *reinterpret_cast<const double2*>(xp + k1 + 2);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                const double2 a = xs[st][bt][p][lane];
+                acc[0][bt] = Mfma<double>::run(a.x, m[2 * p].x, acc[0][bt]);
+                acc[1][bt] = Mfma<double>::run(a.x, m[2 * p].y, acc[1][bt]);
+                acc[0][bt] = Mfma<double>::run(a.y, m[2 * p + 1].x, acc[0][bt]);
+                acc[1][bt] = Mfma<double>::run(a.y, m[2 * p + 1].y, acc[1][bt]);
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) m[s4] = mn[s4];
+    }
+    double* pout = partials + (split * B) * C;
+    const size_t c = col0 + 2 * j;
+    if (c + 1 < C) {
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const size_t b = bt * 16 + q + 4 * g;
+                if (b < nb)
+                    *reinterpret_cast<double2*>(pout + (bchunk + b) * C + c) =
+                        double2{acc[0][bt][g], acc[1][bt][g]};
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------ fold + epilogue
+template <typename T>
+__device__ __forceinline__ void mfma_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
+    if (e.mode == 0) {
+        reinterpret_cast<T*>(e.out)[b * len + idx] = T(acc);
+        return;
+    }
+    const T bin = reinterpret_cast<const T*>(e.b_in)[b * len + idx];
+    const double a_in = e.a_in[b];
+    double r = acc;
+    if (e.add_b_over_a) r += (double)bin / a_in;
+    const double an = e.a_new_raw[b];
+    T bn = T(r) * T(a_in + an) - bin;          // b_new = r (a + a_new) - b  (tramp/base.py:253-254)
+    if (e.damping != 0.0) {
+        const T bo = reinterpret_cast<const T*>(e.b_old)[b * len + idx];
+        bn = T(e.damping) * bo + T(1.0 - e.damping) * bn;
+    }
+    reinterpret_cast<T*>(e.out)[b * len + idx] = bn;
+    if (e.r_out) reinterpret_cast<T*>(e.r_out)[b * len + idx] = T(r);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mfma_fold_kernel(size_t len, size_t B, int nsplit,
+                                                           const double* __restrict__ partials, LinEpi epi) {
+    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (idx >= len) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += partials[((size_t)k * B + b) * len + idx];
+    mfma_epilogue<T>(epi, b, idx, len, s);
+}
+
+// ------------------------------------------------------------------------------ host side
+bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch) {
+    if (dtype != TRAMP_F64) return false;
+    if (batch == 0 || batch > 65535 * 64ull) return false;
+    if (nt) return (C % kKStep) == 0 && C >= kKStep && R >= 1;
+    return (R % kKStep) == 0 && R >= kKStep && (C % 2) == 0 && C >= 2;
+}
+
+int gemm_mfma(tramp_ctx* ctx, int dtype, bool nt, size_t R, size_t C, size_t batch, const void* mat_d,
+              const void* x_d, const LinEpi& epi) {
+    if (!gemm_mfma_supported(dtype, nt, R, C, batch)) return tramp_fail(ctx, TRAMP_ENOTSUP, "gemm_mfma", "shape");
+    const size_t len = nt ? R : C;                  // output length per instance
+    const size_t kdim = nt ? C : R;
+    const size_t nsteps = kdim / kKStep;
+    const size_t sps = (nsteps + kSplit - 1) / kSplit;
+    int rc = tramp_ws_reserve(ctx, (size_t)kSplit * batch * len * sizeof(double));
+    if (rc) return rc;
+    const double* mat = reinterpret_cast<const double*>(mat_d);
+    const double* x = reinterpret_cast<const double*>(x_d);
+    const unsigned nchunk = (unsigned)((batch + 63) / 64);
+    const size_t btail = batch - (size_t)(nchunk - 1) * 64;
+    // BT is a compile-time tile count; a ragged last chunk simply masks its stores
+    const int bt = (nchunk > 1) ? 4 : (int)((btail + 15) / 16);
+    dim3 block(kBlock);
+    if (nt) {
+        constexpr int RT = 2;
+        const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
+        dim3 grid((unsigned)(nrb * kSplit), nchunk);
+        switch (bt) {
+            case 1: hipLaunchKernelGGL((gemm_nt_f64_kernel<1, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_f64_kernel<2, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 3: hipLaunchKernelGGL((gemm_nt_f64_kernel<3, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            default: hipLaunchKernelGGL((gemm_nt_f64_kernel<4, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+        }
+    } else {
+        const size_t ncb = (C + 127) / 128;
+        dim3 grid((unsigned)(ncb * kSplit), nchunk);
+        switch (bt) {
+            case 1: hipLaunchKernelGGL((gemm_nn_f64_kernel<1>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 2: hipLaunchKernelGGL((gemm_nn_f64_kernel<2>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 3: hipLaunchKernelGGL((gemm_nn_f64_kernel<3>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            default: hipLaunchKernelGGL((gemm_nn_f64_kernel<4>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+        }
+    }
+    dim3 g2((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
+    hipLaunchKernelGGL((mfma_fold_kernel<double>), g2, block, 0, ctx->stream, len, batch, kSplit, ctx->ws, epi);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
 }

@@ -307,6 +307,8 @@ static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t 
         if (algo == 2) return tramp_fail(ctx, TRAMP_ENOTSUP, "mfma path", "shape/dtype not supported");
         mfma = false;
     }
+    ProfScope prof(ctx, nt ? PROF_MATVEC_NT : PROF_MATVEC_NN, (double)R * (double)C * dtype_size(dtype),
+                   2.0 * (double)R * (double)C * (double)batch);
     if (mfma) return gemm_mfma(ctx, dtype, nt, R, C, batch, mat_d, x_d, epi);
     if (dtype == TRAMP_F64) return matvec_valu<double>(ctx, nt, R, C, batch, mat_d, x_d, epi);
     return matvec_valu<float>(ctx, nt, R, C, batch, mat_d, x_d, epi);
