@@ -1,0 +1,101 @@
+"""GPU parity of the state-evolution quadrature kernels (K13, K14) and of the SE recursion
+against values captured from the reference (adaptive QUADPACK).  Budget: 1e-6 on v
+(fixed panels reproduce quad/dblquad to ~1e-8, not bit-wise)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-6, atol=1e-9):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_se_gb_prior(ctx, golden_se):
+    import tramp_amd as T
+    for c in golden_se["gb_prior"]:
+        p = T.GaussBernoulliPrior(size=None, rho=c["rho"], mean=c["mean"], var=c["var"], ctx=ctx)
+        close(p.compute_forward_error(c["ax"]), c["v"])
+        close(p.compute_forward_state_evolution(c["ax"]), c["a_new"], rtol=1e-5)
+    # batched parameter points in one launch
+    cs = [c for c in golden_se["gb_prior"] if c["rho"] == 0.1 and c["mean"] == 0.0]
+    p = T.GaussBernoulliPrior(size=None, rho=0.1, ctx=ctx)
+    close(p.compute_forward_error(np.array([c["ax"] for c in cs])), [c["v"] for c in cs])
+
+
+def test_se_sgn_abs_likelihood(ctx, golden_se):
+    import tramp_amd as T
+    lk = T.SgnLikelihood(y=None, ctx=ctx)
+    for c in golden_se["sgn_lik"]:
+        close(lk.compute_backward_error(c["az"], c["tau_z"]), c["v"])
+        close(lk.compute_backward_state_evolution(c["az"], c["tau_z"]), c["a_new"], rtol=1e-5)
+    lk = T.AbsLikelihood(y=None, ctx=ctx)
+    for c in golden_se["abs_lik"]:
+        close(lk.compute_backward_error(c["az"], c["tau_z"]), c["v"])
+
+
+def test_se_pwl_channels(ctx, golden_se):
+    import tramp_amd as T
+    cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)
+    for c in golden_se["pwl"]:
+        ch = cls[c["kind"]](ctx=ctx)
+        close(ch.compute_forward_error(c["az"], c["ax"], c["tau_z"]), c["v_fwd"])
+        close(ch.compute_backward_error(c["az"], c["ax"], c["tau_z"]), c["v_bwd"])
+        close(ch.second_moment(c["tau_z"]), c["tau_x"], rtol=1e-12)
+
+
+def test_se_mp_channel(golden_se):
+    import tramp_amd as T
+    for c in golden_se["mp"]:
+        ch = T.MarchenkoPasturChannel(alpha=c["alpha"])
+        close(ch.compute_backward_error(c["az"], c["ax"], 1.0), c["vz"], rtol=1e-12)
+        close(ch.compute_forward_error(c["az"], c["ax"], 1.0), c["vx"], rtol=1e-12)
+        close(ch.second_moment(1.7), c["tau_x"], rtol=1e-12)
+
+
+def test_se_trajectories(ctx, golden_se):
+    import tramp_amd as T
+    for c in golden_se["traj"]:
+        if c["kind"] == "glm_gauss":
+            lik = T.GaussianLikelihood(y=None, var=c["noise_var"], ctx=ctx)
+        else:
+            lik = T.SgnLikelihood(y=None, ctx=ctx)
+        model = (T.GaussBernoulliPrior(size=None, rho=c["rho"], ctx=ctx) @ T.SISOVariable(id="x")
+                 @ T.MarchenkoPasturChannel(alpha=c["alpha"]) @ T.SISOVariable(id="z") @ lik).to_model()
+        se = T.StateEvolution(model)
+        recs = []
+
+        def cb(algo, i, max_iter, stop=T.EarlyStopping()):
+            recs.append((algo.get_edges_data(), algo.get_variables_data()))
+            return stop(algo, i, max_iter)
+        se.iterate(max_iter=200, callback=cb, initializer=T.ConstantInit(a=c["a0"]))
+        t = c["traj"]
+        assert abs(se.n_iter - c["n_iter"]) <= 1
+        for it in range(min(len(recs), t["v:x"].shape[0])):
+            rt = 1e-5 if it < 8 else 1e-3           # quadrature differences compound over the recursion
+            for vid in ("x", "z"):
+                close(recs[it][0][(vid, "fwd")], t[f"fwd:{vid}:a"][it], rtol=rt)
+                close(recs[it][0][(vid, "bwd")], t[f"bwd:{vid}:a"][it], rtol=rt)
+                close(recs[it][1][vid]["v"], t[f"v:{vid}"][it], rtol=rt)
+
+
+def test_se_two_layer_relu(ctx, golden_se):
+    """BASELINE configs[4]: Gaussian prior -> MP(alpha=2) -> Relu -> MP(alpha=.5) -> Gaussian likelihood."""
+    import tramp_amd as T
+    c = golden_se["traj_two_layer"]
+    model = T.MultiLayerModel([
+        T.GaussianPrior(size=None, ctx=ctx), T.MarchenkoPasturChannel(alpha=c["alpha1"]),
+        T.ReluChannel(ctx=ctx), T.MarchenkoPasturChannel(alpha=c["alpha2"]),
+        T.GaussianLikelihood(y=None, var=c["noise_var"], ctx=ctx)], ids=["x", "z1", "a1", "z2", "y"])
+    se = T.StateEvolution(model)
+    recs = []
+    se.iterate(max_iter=c["n_iter"], callback=lambda a, i, m: recs.append((a.get_edges_data(),
+                                                                            a.get_variables_data())) and False)
+    for vid, tau in c["tau"].items():
+        close(se.taus[vid], tau, rtol=1e-10)
+    t = c["traj"]
+    for it in range(len(recs)):
+        for vid in ("x", "z1", "a1", "z2"):
+            close(recs[it][0][(vid, "fwd")], t[f"fwd:{vid}:a"][it], rtol=1e-5)
+            close(recs[it][0][(vid, "bwd")], t[f"bwd:{vid}:a"][it], rtol=1e-5)
+            close(recs[it][1][vid]["v"], t[f"v:{vid}"][it], rtol=1e-5)

@@ -1,18 +1,320 @@
-// se_kernels.hip - state-evolution quadratures (K13, K14).  Filled in below.
+// se_kernels.hip - state-evolution errors (K13, K14): Gaussian averages of the factor
+// posterior variances, evaluated by brute-force composite Gauss-Legendre quadrature.
+//
+// The reference integrates with adaptive QUADPACK through Python callbacks
+// (tramp/utils/integration.py:13-73: quad / dblquad on [-10, 10] resp. [-10, 10]^2,
+// ~4e4 scalar posterior evaluations and 4-7 s per 2-D call).  On the GPU the same
+// integrals are embarrassingly parallel over nodes:
+//   1-D: 2048 panels x 8-point GL, panels graded cubically towards the point where the
+//        integrand's argument b crosses 0 (the denoisers change regime on a width
+//        ~ 1/sqrt(SNR) around it; a uniform mesh under-resolves that at large a).
+//   2-D: tensor grid of 8-point GL panels (default 768 panels = 6144 nodes per axis,
+//        3.8e7 evaluations per call), one block per strip of x1 nodes.
+// VALU / transcendental bound, no meaningful memory traffic: report evaluations/s.
+// Inputs and outputs are HOST arrays of `count` independent parameter points; partial
+// sums are folded in a fixed order (deterministic).
 #include "common.h"
 #include "tramp_math.h"
 
-extern "C" int tramp_se_gb_prior(tramp_ctx* ctx, size_t, const double*, const double*, const double*,
-                                 const double*, double*) {
-    return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_se_gb_prior", "not built");
+using tmath::norm_cdf;
+using tmath::norm_pdf;
+
+__constant__ double kGLx[8] = {-0.9602898564975363, -0.7966664774136267, -0.5255324099163290,
+                               -0.1834346424956498, 0.1834346424956498,  0.5255324099163290,
+                               0.7966664774136267,  0.9602898564975363};
+__constant__ double kGLw[8] = {0.1012285362903763, 0.2223810344533745, 0.3137066458778873,
+                               0.3626837833783620, 0.3626837833783620, 0.3137066458778873,
+                               0.2223810344533745, 0.1012285362903763};
+
+constexpr int kPanels1D = 2048;
+static int g_panels2d = 768;      // per axis; tunable through TRAMP_SE_PANELS2D
+
+// Node `idx` (0 .. 8*P-1) of a mesh on [-10, 10] with P/2 panels on each side of xc, graded
+// as xc + L t^3, t uniform in [0,1]; returns x and the weight dx (Jacobian included).
+__device__ __forceinline__ void graded_node(int idx, int P, double xc, double& x, double& w) {
+    const int half = P / 2;
+    const int panel = idx >> 3, g = idx & 7;
+    const bool right = panel >= half;
+    const int pi = right ? panel - half : panel;
+    const double L = right ? (10.0 - xc) : (xc + 10.0);
+    const double h = 0.5 / half;
+    const double t = (pi + 0.5) * (1.0 / half) + h * kGLx[g];
+    const double t2 = t * t;
+    x = right ? xc + L * t2 * t : xc - L * t2 * t;
+    w = L * 3.0 * t2 * h * kGLw[g];
 }
-extern "C" int tramp_se_sgn_lik(tramp_ctx* ctx, size_t, const double*, const double*, double*) {
-    return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_se_sgn_lik", "not built");
+
+// ---------------------------------------------------------------- K13: GB prior, sgn likelihood
+// mode 0: Gauss-Bernoulli prior  (gauss_bernoulli_prior.py:59-62,116-122; base_prior.py:66-69)
+//         v = (1-rho) E_{N(0, ax)}[f] + rho E_{N(ax mean, ax + ax^2 var)}[f],  f(b) = v(ax, b)
+// mode 1: sign likelihood        (sgn_likelihood.py:26-27,79-92; base_likelihood.py:78-81)
+//         v = sum_{y=+-1} E_{N(0, mz + mz^2 tau)}[ p(az, y b) v(az, y b) ]
+struct Se1dParams {
+    const double* p0;   // ax | az
+    const double* p1;   // rho | tau_z
+    const double* p2;   // mean
+    const double* p3;   // var
+};
+
+__global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, double* __restrict__ out) {
+    __shared__ double smem[kBlock / kWave];
+    const int pt = blockIdx.x;
+    double total = 0.0;
+    if (mode == 0) {
+        const double ax = P.p0[pt], rho = P.p1[pt], mean = P.p2[pt], var = P.p3[pt];
+        const double a0 = 1.0 / var, b0 = mean / var;
+        const double eta = 0.5 * (b0 * b0 / a0 + log(2 * tmath::kPi / a0)) - log(rho / (1 - rho));
+        const double a = ax + a0, lg = log(2 * tmath::kPi / a);
+        for (int br = 0; br < 2; ++br) {
+            const double m = br ? ax * mean : 0.0;
+            const double s = br ? sqrt(ax + ax * ax * var) : sqrt(ax);
+            const double wt = br ? rho : 1.0 - rho;
+            // the denoiser switches regime where b = bx + b0 crosses 0
+            double xc = (s > 0) ? (-b0 - m) / s : 0.0;
+            xc = fmin(fmax(xc, -10.0), 10.0);
+            double acc = 0.0;
+            for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
+                double x, w;
+                graded_node(i, kPanels1D, xc, x, w);
+                tmath::RV<double> o = tmath::gb_posterior<double>(m + s * x, a, lg, b0, eta);
+                acc += w * norm_pdf(x) * o.v;
+            }
+            total += wt * acc;
+        }
+    } else {
+        const double az = P.p0[pt], tau = P.p1[pt];
+        const double mz = az - 1.0 / tau;
+        const double s = sqrt(mz + mz * mz * tau);
+        const double v0 = 1.0 / az;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
+            double x, w;
+            graded_node(i, kPanels1D, 0.0, x, w);
+            const double bz = s * x;
+            double f = 0.0;
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                const double y = yy ? -1.0 : 1.0;
+                const double r0 = (y * bz) / az;
+                tmath::HalfLine<double> h = tmath::halfline<double>(r0, v0, +1);
+                // positive.p: P[N(r0, v0) > 0] = norm_cdf(inf) - norm_cdf(-r0/s0)
+                const double p = 1.0 - norm_cdf((0 - r0) / sqrt(v0));
+                f += p * h.var;
+            }
+            acc += w * norm_pdf(x) * f;
+        }
+        total = acc;
+    }
+    total = block_sum(total, smem);
+    if (threadIdx.x == 0) out[pt] = total;
 }
-extern "C" int tramp_se_abs_lik(tramp_ctx* ctx, size_t, const double*, const double*, double*) {
-    return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_se_abs_lik", "not built");
+
+// ---------------------------------------------------------------- K14: 2-D averages
+// kind 0/1/2: Sgn/Abs/Relu channel, dir 0 fwd / 1 bwd
+//   (channels/base_channel.py:29-41, piecewise_linear_channel.py:60-64, linear_region.py:78-101)
+// kind 3: abs likelihood (abs_likelihood.py:25-26,60-69)
+struct Se2dParams {
+    const double* az;
+    const double* ax;
+    const double* tau;
+};
+
+template <int KIND, bool FWD>
+__device__ __forceinline__ double pwl_integrand(double x1, double x2, double az, double ax, double tau) {
+    const double u_eff = fmax(0.0, az * tau - 1.0);
+    double total = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double slope = tmath::pwl_slope(KIND, k), x0 = tmath::pwl_x0(KIND, k);
+        const int side = k == 0 ? +1 : -1;
+        const double mean_x = ax * x0;
+        const double sx2 = ax * (slope * slope * ax * tau + 1.0);
+        double bz, bx;
+        if (ax == 0.0 || u_eff == 0.0 || slope == 0.0) {
+            bz = sqrt(az * u_eff) * x1;                          // gaussian_measure_2d
+            bx = mean_x + sqrt(sx2) * x2;
+        } else {
+            const double c00 = az * u_eff, c01 = slope * ax * u_eff;   // gaussian_measure_2d_full
+            const double l00 = sqrt(c00), l10 = c01 / l00, l11 = sqrt(sx2 - l10 * l10);
+            bz = l00 * x1;
+            bx = l10 * x1 + l11 * x2 + mean_x;
+        }
+        // LinearRegion.proba_ab (linear_region.py:78-81)
+        const double a = az + slope * slope * ax;
+        const double b = bz + slope * (bx - ax * x0);
+        const double y0 = (0 - b / a) / sqrt(1.0 / a);
+        const double p = side > 0 ? 1.0 - norm_cdf(y0) : norm_cdf(y0);
+        tmath::PwlOut<double> o = tmath::pwl_posterior<double, KIND, FWD>(bz, bx, az, ax);
+        total += p * o.v;
+    }
+    return total;
 }
-extern "C" int tramp_se_pwl_channel(tramp_ctx* ctx, int, int, size_t, const double*, const double*,
-                                    const double*, double*) {
-    return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_se_pwl_channel", "not built");
+
+__device__ __forceinline__ double abs_lik_integrand(double x1, double x2, double az, double tau) {
+    const double mz = az - 1.0 / tau;
+    const double z = sqrt(tau) * x1;
+    const double bz = mz * z + sqrt(mz) * x2;
+    const double y = fabs(z);
+    const double t = tanh(bz * y);
+    return (y * y) * (1.0 - t * t);
+}
+
+// grid: (strips, count); each block integrates a strip of x1 nodes against ALL x2 nodes.
+// nodes: [2][n] = x, w*pdf(x) for the uniform mesh (precomputed by se_nodes_kernel).
+template <int KIND, bool FWD>
+__global__ __launch_bounds__(kBlock) void se_2d_kernel(Se2dParams P, const double* __restrict__ nodes, int n,
+                                                       int strip, double* __restrict__ partials) {
+    __shared__ double smem[kBlock / kWave];
+    const int pt = blockIdx.y;
+    const double az = P.az[pt], ax = (KIND == 3) ? 0.0 : P.ax[pt], tau = P.tau[pt];
+    const double* xs = nodes;
+    const double* ws = nodes + n;
+    const int i0 = blockIdx.x * strip;
+    const int i1 = min(n, i0 + strip);
+    double acc = 0.0;
+    for (int i = i0; i < i1; ++i) {
+        const double x1 = xs[i], w1 = ws[i];
+        double row = 0.0;
+        for (int j = threadIdx.x; j < n; j += kBlock) {
+            const double x2 = xs[j];
+            double f;
+            if (KIND == 3) f = abs_lik_integrand(x1, x2, az, tau);
+            else f = pwl_integrand<(KIND == 3 ? 0 : KIND), FWD>(x1, x2, az, ax, tau);
+            row += ws[j] * f;
+        }
+        acc += w1 * row;
+    }
+    acc = block_sum(acc, smem);
+    if (threadIdx.x == 0) partials[(size_t)pt * gridDim.x + blockIdx.x] = acc;
+}
+
+__global__ void se_nodes_kernel(int panels, double* __restrict__ nodes) {
+    const int n = panels * 8;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double h = 10.0 / panels;                 // half panel width
+    const double c = -10.0 + (2 * (i >> 3) + 1) * h;
+    const double x = c + h * kGLx[i & 7];
+    nodes[i] = x;
+    nodes[n + i] = h * kGLw[i & 7] * norm_pdf(x);
+}
+
+__global__ __launch_bounds__(kBlock) void se_fold_kernel(const double* __restrict__ partials, int nblk,
+                                                         double* __restrict__ out) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t pt = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += kBlock) s += partials[pt * nblk + i];
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) out[pt] = s;
+}
+
+// ---------------------------------------------------------------- host wrappers
+// Device scratch layout inside ctx->ws: [params 4 x count][out count][nodes 2n][partials]
+static int se_stage(tramp_ctx* ctx, size_t count, const double* const* host_in, int nin, double** dev_in,
+                    double** dev_out, size_t extra_doubles, double** extra) {
+    const size_t need = ((size_t)(nin + 1) * count + extra_doubles) * sizeof(double);
+    int rc = tramp_ws_reserve(ctx, need);
+    if (rc) return rc;
+    double* p = ctx->ws;
+    for (int i = 0; i < nin; ++i) {
+        dev_in[i] = p;
+        TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(p, host_in[i], count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        p += count;
+    }
+    *dev_out = p;
+    p += count;
+    if (extra) *extra = p;
+    return TRAMP_OK;
+}
+
+static int se_finish(tramp_ctx* ctx, size_t count, const double* dev_out, double* host_out) {
+    TRAMP_LAUNCH_CHECK(ctx);
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(host_out, dev_out, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax, const double* rho,
+                                 const double* mean, const double* var, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax && rho && mean && var && v);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i)
+        TRAMP_REQUIRE(ctx, ax[i] >= 0.0 && rho[i] > 0.0 && rho[i] < 1.0 && var[i] > 0.0);
+    const double* hin[4] = {ax, rho, mean, var};
+    double *din[4], *dout;
+    int rc = se_stage(ctx, count, hin, 4, din, &dout, 0, nullptr);
+    if (rc) return rc;
+    Se1dParams P{din[0], din[1], din[2], din[3]};
+    hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 0, P, dout);
+    return se_finish(ctx, count, dout, v);
+}
+
+extern "C" int tramp_se_sgn_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && tau_z && v);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] - 1.0 / tau_z[i] > 0.0);   // sgn_likelihood.py:80-81
+    const double* hin[2] = {az, tau_z};
+    double *din[2], *dout;
+    int rc = se_stage(ctx, count, hin, 2, din, &dout, 0, nullptr);
+    if (rc) return rc;
+    Se1dParams P{din[0], din[1], nullptr, nullptr};
+    hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 1, P, dout);
+    return se_finish(ctx, count, dout, v);
+}
+
+static int panels2d() {
+    const char* e = getenv("TRAMP_SE_PANELS2D");
+    if (e) {
+        int p = atoi(e);
+        if (p >= 8 && p <= 4096) return p;
+    }
+    return g_panels2d;
+}
+
+template <int KIND, bool FWD>
+static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const double* ax, const double* tau,
+                     double* v) {
+    const int panels = panels2d();
+    const int n = panels * 8;
+    const int strip = 8;
+    const int nstrips = (n + strip - 1) / strip;
+    const double* hin[3] = {az, ax ? ax : az, tau};
+    double *din[3], *dout, *extra;
+    int rc = se_stage(ctx, count, hin, 3, din, &dout, 2 * (size_t)n + count * (size_t)nstrips, &extra);
+    if (rc) return rc;
+    double* nodes = extra;
+    double* partials = extra + 2 * (size_t)n;
+    hipLaunchKernelGGL(se_nodes_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, panels, nodes);
+    Se2dParams P{din[0], din[1], din[2]};
+    hipLaunchKernelGGL((se_2d_kernel<KIND, FWD>), dim3(nstrips, (unsigned)count), dim3(kBlock), 0, ctx->stream, P, nodes,
+                       n, strip, partials);
+    hipLaunchKernelGGL(se_fold_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, partials, nstrips, dout);
+    return se_finish(ctx, count, dout, v);
+}
+
+extern "C" int tramp_se_abs_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && tau_z && v);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] - 1.0 / tau_z[i] > 0.0);   // abs_likelihood.py:61-62
+    return se_2d_run<3, false>(ctx, count, az, nullptr, tau_z, v);
+}
+
+extern "C" int tramp_se_pwl_channel(tramp_ctx* ctx, int kind, int dir, size_t count, const double* az,
+                                    const double* ax, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && ax && tau_z && v);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] > 0.0 && ax[i] >= 0.0 && tau_z[i] > 0.0);
+    const bool f = dir == TRAMP_FWD;
+    switch (kind) {
+        case TRAMP_SGN: return f ? se_2d_run<0, true>(ctx, count, az, ax, tau_z, v) : se_2d_run<0, false>(ctx, count, az, ax, tau_z, v);
+        case TRAMP_ABS: return f ? se_2d_run<1, true>(ctx, count, az, ax, tau_z, v) : se_2d_run<1, false>(ctx, count, az, ax, tau_z, v);
+        case TRAMP_RELU: return f ? se_2d_run<2, true>(ctx, count, az, ax, tau_z, v) : se_2d_run<2, false>(ctx, count, az, ax, tau_z, v);
+    }
+    return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "kind");
 }
