@@ -1,0 +1,116 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol declared in
+include/tramp_hip.h; host-side logic (model algebra, argument validation, error
+conventions) behaves as the reference's; the product path refuses to run without a GPU
+instead of falling back to CPU arithmetic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tramp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tramp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tramp_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the Python binding knows each of them
+    assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
+    assert "gfx950" in _lib.version()
+
+
+def test_null_context_is_rejected_not_crashed():
+    from tramp_amd import _lib
+    lib = _lib.load()
+    assert lib.tramp_sync(None) == _lib.EINVAL
+    assert lib.tramp_gb_prior_fwd(None, 1, 4, 1, None, None, 0.5, 0.0, 1.0, 0.0, None, None, None, None,
+                                  None, None) == _lib.EINVAL
+    n = ctypes.c_int(-1)
+    assert lib.tramp_device_count(ctypes.byref(n)) == _lib.OK and n.value >= 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    import tramp_amd as T
+    if T._lib.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(T._lib.TrampHipError):
+        T.GaussBernoulliPrior(size=4, rho=0.5).compute_forward_message(1.0, np.zeros(4))
+
+
+def test_product_path_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tramp_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, f"{f} mentions the oracle"
+
+
+def test_model_algebra_and_observation():
+    import tramp_amd as T
+    W = np.random.RandomState(0).randn(6, 12)
+
+    class FakeLinear(T.channels.Channel):      # geometry only: no device needed
+        Nx, Nz = 6, 12
+
+        def sample(self, Z):
+            return W @ Z
+
+        def second_moment(self, tau_z):
+            return 2 * tau_z
+
+    prior = T.GaussBernoulliPrior(size=12, rho=0.3)
+    model = (prior @ T.SISOVariable(id="x") @ FakeLinear() @ T.SISOVariable(id="z")
+             @ T.GaussianChannel(var=0.1) @ T.SILeafVariable(id="y")).to_model()
+    assert model.variable_ids == ["x", "z", "y"]
+    assert [f.id for f in model.factors] == ["f_0", "f_1", "f_2"]
+    s = model.sample(seed=5)
+    assert s["x"].shape == (12,) and s["y"].shape == (6,)
+    np.testing.assert_allclose(s["z"], W @ s["x"])
+    model.init_second_moments()
+    tau = model.get_second_moments()
+    assert tau["x"] == pytest.approx(0.3) and tau["z"] == pytest.approx(0.6) and tau["y"] == pytest.approx(0.7)
+    with pytest.raises(ValueError):
+        T.Model(T.DAG([prior, T.GaussianChannel()]))            # factor-factor edge
+    with pytest.raises(ValueError):
+        (prior @ T.SISOVariable(id="x") @ T.GaussianChannel() @ T.SISOVariable(id="x")
+         @ T.GaussianChannel() @ T.SILeafVariable(id="y")).to_model()     # duplicate ids
+    with pytest.raises(NotImplementedError):
+        T.models.channel2likelihood(FakeLinear(), None, "y")
+
+
+def test_scheduler_argument_validation():
+    import tramp_amd as T
+    prior = T.GaussBernoulliPrior(size=4, rho=0.3)
+    model = (prior @ T.SISOVariable(id="x") @ T.GaussianChannel(var=0.1) @ T.SILeafVariable(id="y")).to_model()
+    with pytest.raises(ValueError):
+        T.ExpectationPropagation(model)      # unobserved leaf: must call to_observed first
+    assert T.EarlyStoppingEP().tol == 1e-6 and T.EarlyStopping().tol == 1e-6
+    ci = T.CustomInit(a_init=[("x", "bwd", 3.0)], a=1.0)
+    assert ci.init_a(None, "x", "bwd") == 3.0 and ci.init_a(None, "x", "fwd") == 1.0
+
+
+def test_host_closed_forms_match_oracle():
+    """Scalar closed forms that stay on the host (Gaussian prior/likelihood, MP channel)."""
+    import tramp_amd as T
+    from oracle import tramp_oracle as orc
+    mp, mo = T.MarchenkoPasturChannel(alpha=0.5), orc.MarchenkoPasturOracle(0.5)
+    for az, ax in [(1.3, 0.7), (2.0, 0.0), (0.0, 5.0), (1e-11, 5.0)]:
+        assert mp.compute_backward_error(az, ax, 1.0) == pytest.approx(mo.backward_error(az, ax), rel=1e-13)
+        if az > 0:
+            assert mp.compute_forward_error(az, ax, 1.0) == pytest.approx(mo.forward_error(az, ax), rel=1e-13)
+    assert T.GaussianPrior(size=None, var=2.0).compute_forward_error(1.3) == orc.gauss_prior_error(1.3, 2.0)
+    assert T.GaussianLikelihood(y=None, var=0.5).compute_backward_error(1.3, 1.0) == orc.gauss_lik_error(1.3, 1.0, 0.5)
+    f = T.GaussBernoulliPrior(size=4, rho=0.3)
+    assert f.compute_a_new(0.5, 1.0) == orc.a_new(0.5, 1.0)
+    assert f.compute_a_new(1e-30, 0.0) == 1e11 and f.compute_a_new(10.0, 5.0) == 1e-11

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py.
+# Usage: tools/profile_bench.sh <N> <steps> <tag>
+set -u
+N=${1:-32768}; STEPS=${2:-10}; TAG=${3:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="bench.py --n $N --steps $STEPS --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
+# counter passes: own runs, kernel-trace only, on the kernels alone (rocSOLVER crashes under --pmc)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_kernels.py $N 64 > $OUT/fetch.out 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/pmc_kernels.py $N 64 > $OUT/write.out 2> $OUT/write.err
+find $OUT -name "*.csv" | head -20
+python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
+# keep only the small files
+find $OUT -name "*kernel_trace.csv" -size +4M -delete
+find $OUT -name "*counter_collection.csv" -size +4M -delete
+du -sh $OUT
