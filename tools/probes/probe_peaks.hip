@@ -1,0 +1,82 @@
+// Measures on the box: (1) v_mfma_f64_16x16x4_f64 and v_mfma_f32_16x16x4_f32 issue rate,
+// (2) HBM streaming read bandwidth (double2 loads), (3) copy bandwidth.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mfma64(double* out, int iters, double a, double b) {
+    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+__global__ __launch_bounds__(256) void mfma32(float* out, int iters, float a, float b) {
+    f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c3, 0, 0, 0);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+__global__ __launch_bounds__(256) void fma64(double* out, int iters, double a, double b) {
+    double c0 = 0, c1 = 1, c2 = 2, c3 = 3, c4 = 4, c5 = 5, c6 = 6, c7 = 7;
+    for (int i = 0; i < iters; ++i) {
+        c0 = fma(a, b, c0); c1 = fma(a, b, c1); c2 = fma(a, b, c2); c3 = fma(a, b, c3);
+        c4 = fma(a, b, c4); c5 = fma(a, b, c5); c6 = fma(a, b, c6); c7 = fma(a, b, c7);
+        a += 1e-9;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+}
+__global__ __launch_bounds__(256) void stream_read(const double2* __restrict__ in, size_t n, double* out) {
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double2 v = in[i];
+        acc += v.x + v.y;
+    }
+    if (acc == 1.2345) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void stream_copy(const double2* __restrict__ in, double2* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = in[i];
+}
+template <typename F> float timeit(F f, int reps) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a); for (int i = 0; i < reps; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+int main() {
+    double* out; hipMalloc(&out, 1 << 24);
+    const int iters = 20000;
+    for (int wpc : {4, 8, 16}) {       // waves per CU
+        int blocks = 256 * wpc / 4;
+        float ms = timeit([&] { hipLaunchKernelGGL(mfma64, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0, 2.0); }, 3);
+        double fl = (double)blocks * 4 * iters * 4 * 2048.0;
+        printf("mfma_f64_16x16x4 waves/CU=%d: %.1f TFLOP/s\n", wpc, fl / ms / 1e9);
+        ms = timeit([&] { hipLaunchKernelGGL(mfma32, dim3(blocks), dim3(256), 0, 0, (float*)out, iters, 1.0f, 2.0f); }, 3);
+        printf("mfma_f32_16x16x4 waves/CU=%d: %.1f TFLOP/s\n", wpc, fl / ms / 1e9);
+    }
+    {
+        int blocks = 256 * 8;
+        float ms = timeit([&] { hipLaunchKernelGGL(fma64, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0, 2.0); }, 3);
+        printf("v_fma_f64: %.1f TFLOP/s\n", (double)blocks * 256 * iters * 8 * 2.0 / ms / 1e9);
+    }
+    size_t bytes = 8ull << 30;
+    double2 *a, *b; hipMalloc(&a, bytes); hipMalloc(&b, bytes);
+    hipMemset(a, 1, bytes); hipMemset(b, 0, bytes);
+    size_t n = bytes / 16;
+    for (int blocks : {2048, 4096, 8192, 16384}) {
+        float ms = timeit([&] { hipLaunchKernelGGL(stream_read, dim3(blocks), dim3(256), 0, 0, a, n, out); }, 5);
+        printf("stream read  %5d blocks: %.0f GB/s\n", blocks, bytes / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL(stream_copy, dim3(blocks), dim3(256), 0, 0, a, b, n); }, 5);
+        printf("stream copy  %5d blocks: %.0f GB/s (read+write)\n", blocks, 2.0 * bytes / ms / 1e6);
+    }
+    return 0;
+}
