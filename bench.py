@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # fp64: AMD datasheet (matrix = vector rate); fp32: guide
+# measured on the box by tools/probes/probe_peaks.hip (back-to-back independent MFMAs, 16 waves/CU)
+MFMA_MEASURED_TFLOPS = {"f64": 47.5, "f32": 146.3}
 
 TAGS = ["ew_factor_update", "matvec_nt", "matvec_nn", "linear_scalars", "variable_posterior", "other"]
 
@@ -48,7 +50,7 @@ def parse():
     ap.add_argument("--damping", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denoiser", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=2000)
+    ap.add_argument("--cpu-n", type=int, default=4000)
     return ap.parse_args()
 
 
@@ -71,7 +73,7 @@ def cpu_baseline(args):
     lin = orc.LinearFactor(W)
     setup_s = time.perf_counter() - t0
     fs = [orc.GBPriorFactor(N, rho=args.rho), lin, orc.GaussLikFactor(y, args.noise_var)]
-    iters = 40
+    iters = 300
     orc.ep_chain(fs, [N, M], max_iter=2, damping=args.damping, tol=0.0)       # warm-up
     t0 = time.perf_counter()
     res = orc.ep_chain(fs, [N, M], max_iter=iters, damping=args.damping, tol=0.0, max_increase=np.inf)
@@ -132,6 +134,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import tramp_amd as T
+    from tramp_amd import ensemble
     ctx = T.Context(local_rank)
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     N, B = args.n, args.batch
@@ -154,12 +157,10 @@ def main():
         if rank == 0:
             ctx._call("tramp_randn", T.device.dtype_code(np_dt), W.ptr, W.size, 1234, 1.0 / np.sqrt(N))
             ctx.sync()
-        tb = time.perf_counter()
-        dist.broadcast(Wt, src=0)
-        torch.cuda.synchronize()
-        bcast_s = time.perf_counter() - tb
-    # teacher data of this rank's instances (per-rank seeds)
-    rs = np.random.RandomState(1000 + rank)
+        bcast_s = ensemble.broadcast_tensor(Wt, src=0)
+    # teacher data of this rank's instances: block [start, stop) of the B*world ensemble
+    start, stop = ensemble.shard_range(B * world, rank, world)
+    rs = np.random.RandomState(ensemble.instance_seeds(1000, start, stop)[0] % (2**31))
     X = (rs.standard_normal((B, N)) * rs.binomial(1, args.rho, (B, N))).astype(np_dt)
     Xd = ctx.array(X, np_dt)
     Zd = ctx.empty((B, M), np_dt)
@@ -198,9 +199,7 @@ def main():
     ctx._call("tramp_profile_enable", 0)
     mse = float(np.mean(ep.mse("x", X)))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = ensemble.max_over_ranks(elapsed, device="cuda")
 
     if rank == 0:
         total_units = float(N) * B * world * args.steps
@@ -208,11 +207,12 @@ def main():
                 if cnt[i]}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
-        use_mfma = B > T._lib.GEMV_MAX_BATCH and dom.startswith("matvec")
+        use_mfma = B > 16 and dom.startswith("matvec")     # batch <= 16 streams at the HBM rate
         if use_mfma:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": None,
+                    "peak_measured_issue_rate": MFMA_MEASURED_TFLOPS[args.dtype],
                     "avg_launch_ms": d["ms"] / d["launches"], "launches": d["launches"],
                     "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
         else:

@@ -228,7 +228,13 @@ int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batc
                          const double* az_d, const void* bz_d,
                          const double* ax_d, const void* bx_d,
                          double damping, const double* a_old_d, const void* b_old_d,
-                         double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+                         double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse);
+/* `reuse` (bit mask): the handle keeps the projections t = Vt bz and u = Uk^T bx of its
+ * previous call.  TRAMP_REUSE_T / TRAMP_REUSE_U tell this call that bz / bx are unchanged
+ * since then (the forward and the backward update of one EP iteration share bz), so the
+ * corresponding matrix pass is skipped.  The caller is responsible for the claim. */
+#define TRAMP_REUSE_T 1
+#define TRAMP_REUSE_U 2
 
 /* Building blocks of K8, exported for tests, profiling and the roofline bench:
  *   NT: out[b, r] = sum_c mat[r, c] * x[b, c]     mat [R, C] row-major

@@ -28,19 +28,22 @@ def test_gemv_valu(ctx, kind, shape, B, dtype):
     np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("kind", ["nt", "nn"])
-@pytest.mark.parametrize("shape", [(16, 16), (128, 256), (130, 272), (272, 130), (1000, 512), (48, 4096),
-                                   (4096, 48), (50, 1600)])
+@pytest.mark.parametrize("shape", [(16, 16), (32, 32), (128, 256), (130, 288), (288, 130), (1000, 512), (64, 4096),
+                                   (4096, 64), (50, 1600)])
 @pytest.mark.parametrize("B", [1, 9, 16, 17, 33, 64, 65, 130])
-def test_gemm_mfma_f64(ctx, kind, shape, B):
+def test_gemm_mfma(ctx, kind, shape, B, dtype):
     import tramp_amd as T
     R, C = shape
-    if kind == "nt" and C % 16 or kind == "nn" and (R % 16 or C % 2):
+    ks, e = (16, 2) if dtype == np.float64 else (32, 4)
+    if kind == "nt" and C % ks or kind == "nn" and (R % ks or C % e):
         with pytest.raises(T._lib.TrampHipError):
-            run(ctx, T, kind, 2, R, C, B, np.float64)      # algo=2 forces MFMA: unsupported shape
+            run(ctx, T, kind, 2, R, C, B, dtype)      # algo=2 forces MFMA: unsupported shape
         return
-    out, ref = run(ctx, T, kind, 2, R, C, B, np.float64)
-    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    out, ref = run(ctx, T, kind, 2, R, C, B, dtype)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.abs(ref).max())
 
 
 def test_mfma_deterministic(ctx):

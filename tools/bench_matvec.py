@@ -5,6 +5,7 @@ sys.path.insert(0, '.')
 import tramp_amd as T
 N = int(sys.argv[1]); B = int(sys.argv[2]); M = N // 2
 np_dt = np.float32 if len(sys.argv) > 3 and sys.argv[3] == "f32" else np.float64
+ALGO = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = T.default_context()
 dt = T.device.dtype_code(np_dt)
 es = np.dtype(np_dt).itemsize
@@ -19,8 +20,8 @@ def timeit(name, fn, R, C, reps=5):
     for _ in range(reps): fn()
     e1.record()
     ms = e0.elapsed_ms(e1) / reps
-    print(f"{name:10s} R={R} C={C} B={B}: {ms:8.3f} ms  {2.0*R*C*B/ms/1e9:7.2f} TFLOP/s  {R*C*es/ms/1e6:7.0f} GB/s(mat)", flush=True)
-timeit("NT(Vt)", lambda: ctx._call("tramp_matvec_nt", dt, 0, M, N, B, Vt.ptr, x.ptr, t.ptr), M, N)
-timeit("NN(Vt)", lambda: ctx._call("tramp_matvec_nn", dt, 0, M, N, B, Vt.ptr, y.ptr, r.ptr), M, N)
-timeit("NT(U)", lambda: ctx._call("tramp_matvec_nt", dt, 0, M, M, B, U.ptr, y.ptr, t.ptr), M, M)
-timeit("NN(U)", lambda: ctx._call("tramp_matvec_nn", dt, 0, M, M, B, U.ptr, y.ptr, t.ptr), M, M)
+    print(f"{name:10s} algo={ALGO} {np_dt.__name__} R={R} C={C} B={B}: {ms:8.3f} ms  {2.0*R*C*B/ms/1e9:7.2f} TFLOP/s  {R*C*es/ms/1e6:7.0f} GB/s(mat)", flush=True)
+timeit("NT(Vt)", lambda: ctx._call("tramp_matvec_nt", dt, ALGO, M, N, B, Vt.ptr, x.ptr, t.ptr), M, N)
+timeit("NN(Vt)", lambda: ctx._call("tramp_matvec_nn", dt, ALGO, M, N, B, Vt.ptr, y.ptr, r.ptr), M, N)
+timeit("NT(U)", lambda: ctx._call("tramp_matvec_nt", dt, ALGO, M, M, B, U.ptr, y.ptr, t.ptr), M, M)
+timeit("NN(U)", lambda: ctx._call("tramp_matvec_nn", dt, ALGO, M, M, B, U.ptr, y.ptr, t.ptr), M, M)

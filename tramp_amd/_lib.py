@@ -14,6 +14,7 @@ F32, F64 = 0, 1
 SGN, ABS, RELU = 0, 1, 2
 FWD, BWD = 0, 1
 GEMV_MAX_BATCH = 8
+REUSE_T, REUSE_U = 1, 2
 
 _STATUS = {EINVAL: "invalid argument", EHIP: "HIP runtime error", ENOMEM: "out of device memory",
            ENOTSUP: "not supported", ENODEV: "no MI355X / HIP device"}
@@ -64,7 +65,7 @@ _SIGNATURES = {
     "tramp_linear_destroy": [vp, vp],
     "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
-    "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -208,7 +208,10 @@ class ExpectationPropagation:
             self.b_fwd.append(ctx.zeros((B, n), self.dtype))
             self.b_bwd.append(ctx.zeros((B, n), self.dtype))
             self.r.append(ctx.zeros((B, n), self.dtype))
+        for buf in self.b_fwd + self.b_bwd:
+            buf.version = 0
         self._scratch = {}
+        self._const_done = set()
         self._allocated = True
 
     def _scratch_for(self, i):
@@ -229,7 +232,9 @@ class ExpectationPropagation:
             self.b_fwd[i].fill(initializer.init_b(shape, v.id, "fwd"))
             self.b_bwd[i].fill(initializer.init_b(shape, v.id, "bwd"))
             self.r[i].fill(0.0)
-        self._first_update = True
+            self.b_fwd[i].version += 1
+            self.b_bwd[i].version += 1
+        self._const_done = set()
 
     # -- one factor update, in place, damping fused where the kernel supports it
     def _update(self, factor, direction, i_in, i_out):
@@ -237,6 +242,8 @@ class ExpectationPropagation:
         out_a = self.a_fwd[i_out] if direction == "fwd" else self.a_bwd[i_out]
         out_b = self.b_fwd[i_out] if direction == "fwd" else self.b_bwd[i_out]
         const = isinstance(factor, (GaussianPrior, GaussianLikelihood))
+        if const and not d and (factor, direction) in self._const_done:
+            return          # undamped constant message: already in place, bit-identical every iteration
         kw = dict(out_a=out_a, out_b=out_b)
         if d and not const:
             kw.update(damping=d, old_a=out_a, old_b=out_b)
@@ -260,6 +267,9 @@ class ExpectationPropagation:
                            out_b.ptr, sa.ptr, sb.ptr)
             out_a.copy_from(sa)
             out_b.copy_from(sb)
+        out_b.version += 1          # consumers (LinearChannel projection cache) see a new message
+        if const and not d:
+            self._const_done.add((factor, direction))
 
     def forward_message(self):
         "message_passing.py:249-255"

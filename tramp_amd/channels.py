@@ -232,6 +232,7 @@ class LinearChannel(Channel):
         ctx._call("tramp_linear_create", self._dt, self.Nx, self.Nz, self.rank, self._Uk.ptr,
                   self._Vt.ptr, self._sing.ptr, C.byref(h))
         self._handle = h
+        self._t_key = self._u_key = None
 
     def __del__(self):
         try:
@@ -303,12 +304,29 @@ class LinearChannel(Channel):
         b_new = out_b if out_b is not None else ctx.empty((tgt.batch, tgt.n), self.dtype)
         r = ctx.empty((tgt.batch, tgt.n), self.dtype) if want_posterior else None
         v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        # projection cache: t = Vt bz and u = Uk^T bx persist in the handle; a device-resident
+        # message that has not been rewritten since (same buffer, same version) needs no new pass
+        reuse = 0
+        kz, kx = self._proj_key(bz, z), self._proj_key(bx, x)
+        if kz is not None and kz == self._t_key:
+            reuse |= _lib.REUSE_T
+        if kx is not None and kx == self._u_key:
+            reuse |= _lib.REUSE_U
+        self._t_key, self._u_key = kz, kx
         ctx._call("tramp_linear_message", self._handle, direction, z.batch, a_z.dev.ptr, z.dev.ptr,
                   a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
                   old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
                   a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
-                  v.ptr if v is not None else None)
+                  v.ptr if v is not None else None, reuse)
         return tgt, a_t, a_new, b_new, r, v
+
+    @staticmethod
+    def _proj_key(arg, norm):
+        "Identity of a device-resident message for the projection cache (None: not cacheable)."
+        version = getattr(arg, "version", None)
+        if not isinstance(arg, DeviceArray) or version is None:
+            return None
+        return (arg.ptr, version, norm.batch)
 
     def compute_backward_mean(self, az, bz, ax, bx):
         "linear_channel.py:69-83"

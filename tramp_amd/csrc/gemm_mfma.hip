@@ -2,7 +2,7 @@
 //
 // Both primitives stream a large row-major matrix mat [R, C] exactly once from HBM and
 // contract it against a small batch of vectors (<= 64 per pass) on v_mfma_f64_16x16x4_f64
-// (f32: v_mfma_f32_16x16x4_f32, same fragment shape):
+// (f32: v_mfma_f32_16x16x4_f32, same fragment shape; one template, 16-byte pieces of E = 2 / 4 elements):
 //     NT: out[b, r] = sum_c mat[r, c] x[b, c]        NN: out[b, c] = sum_r mat[r, c] x[b, r]
 // At batch 64 / f64 the contraction is balanced between HBM (R*C*8 bytes) and the matrix
 // pipe (2*R*C*64 flops), so the design keeps both busy:
@@ -27,114 +27,120 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
-template <typename T> struct Mfma;
-template <> struct Mfma<double> {
+// Per element type: 16-byte piece type, elements per piece E, accumulator tile, MFMA.
+template <typename T> struct Mx;
+template <> struct Mx<double> {
+    using piece = v2d;
     using acc_t = d4;
-    static __device__ __forceinline__ d4 run(double a, double b, d4 c) {
+    static constexpr int E = 2;
+    // C/D fragment: col = lane&15; f64: row = (lane>>4) + 4*reg
+    static __device__ __forceinline__ int drow(int q, int g) { return q + 4 * g; }
+    static __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
 };
-template <> struct Mfma<float> {
+template <> struct Mx<float> {
+    using piece = f4;
     using acc_t = f4;
-    static __device__ __forceinline__ f4 run(float a, float b, f4 c) {
+    static constexpr int E = 4;
+    // f32 16x16 tiles: row = 4*(lane>>4) + reg
+    static __device__ __forceinline__ int drow(int q, int g) { return 4 * q + g; }
+    static __device__ __forceinline__ f4 mfma(float a, float b, f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
 };
 
 constexpr int kSplit = 8;     // == number of XCDs
-constexpr int kKStep = 16;    // k depth of one pipeline step (f64: 2 x 16-byte pieces per lane)
+constexpr int kPieces = 2;    // 16-byte pieces per lane per row (NT) / per x fragment, per step
+template <typename T> constexpr int kstep_of() { return 4 * kPieces * Mx<T>::E; }   // f64: 16, f32: 32
 
-// ------------------------------------------------------------------------------ NT, f64
+// ------------------------------------------------------------------------------ NT
 // Workgroup: 4 waves x (RT*16) rows; grid.x = row_blocks * kSplit; grid.y = batch chunks of 64.
-template <int BT, int RT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_nt_f64_kernel(size_t R, size_t C, size_t B,
-                                                                const double* __restrict__ mat,
-                                                                const double* __restrict__ x,
-                                                                size_t steps_per_split,
-                                                                double* __restrict__ partials) {
-    __shared__ double2 xs[2][BT][2][64];
+// lane (j = l&15, q = l>>4), piece p, element e  <->  column k0 + p*4E + q*E + e.
+template <typename T, int BT, int RT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, const T* __restrict__ x,
+                    size_t steps_per_split, double* __restrict__ partials) {
+    using V = typename Mx<T>::piece;
+    using A = typename Mx<T>::acc_t;
+    constexpr int E = Mx<T>::E;
+    constexpr int KS = kstep_of<T>();
+    __shared__ V xs[2][BT][kPieces][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const size_t rb = blockIdx.x / kSplit, split = blockIdx.x % kSplit;
     const size_t bchunk = (size_t)blockIdx.y * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;          // instances in this chunk
     const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
-    const size_t nsteps_total = C / kKStep;
+    const size_t nsteps_total = C / KS;
     const size_t sbeg = split * steps_per_split;
     size_t send = sbeg + steps_per_split;
     if (send > nsteps_total) send = nsteps_total;
     // lane's mat rows (clamped: out-of-range rows are computed on valid memory and never stored)
-    const double* mp[RT];
+    const T* mp[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         size_t r = row0 + rt * 16 + j;
         if (r >= R) r = R - 1;
-        mp[rt] = mat + r * C + 2 * q;
+        mp[rt] = mat + r * C + q * E;
     }
     // x loader: wave w stages batch tile w
     size_t xb = bchunk + (size_t)wave * 16 + j;
     if (xb >= B) xb = B - 1;
-    const double* xp = x + xb * C + 2 * q;
+    const T* xp = x + xb * C + q * E;
     const bool loads_x = wave < BT;
 
-    d4 acc[RT][BT];
+    A acc[RT][BT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = d4{0, 0, 0, 0};
+        for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = A{0, 0, 0, 0};
 
-    double2 m[RT][2], mn[RT][2], xg[2];
+    V m[RT][kPieces], mn[RT][kPieces], xg[kPieces];
     if (sbeg < send) {
-        const size_t k0 = sbeg * kKStep;
+        const size_t k0 = sbeg * KS;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            m[rt][0] = *reinterpret_cast<const double2*>(mp[rt] + k0);
-            m[rt][1] = *reinterpret_cast<const double2*>(mp[rt] + k0 + 8);
-        }
-        if (loads_x) {
-            xg[0] = *reinterpret_cast<const double2*>(xp + k0);
-            xg[1] = *reinterpret_cast<const double2*>(xp + k0 + 8);
+        for (int p = 0; p < kPieces; ++p) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) m[rt][p] = *reinterpret_cast<const V*>(mp[rt] + k0 + p * 4 * E);
+            if (loads_x) xg[p] = *reinterpret_cast<const V*>(xp + k0 + p * 4 * E);
         }
     }
     for (size_t s = sbeg; s < send; ++s) {
         const int st = (int)((s - sbeg) & 1);
         if (loads_x) {
-            xs[st][wave][0][lane] = xg[0];
-            xs[st][wave][1][lane] = xg[1];
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) xs[st][wave][p][lane] = xg[p];
         }
         if (s + 1 < send) {
-            const size_t k1 = (s + 1) * kKStep;
+            const size_t k1 = (s + 1) * KS;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                mn[rt][0] = *reinterpret_cast<const double2*>(mp[rt] + k1);
-                mn[rt][1] = *reinterpret_cast<const double2*>(mp[rt] + k1 + 8);
-            }
-            if (loads_x) {
-                xg[0] = *reinterpret_cast<const double2*>(xp + k1);
-                xg[1] = *reinterpret_cast<const double2*>(xp + k1 + 8);
+            for (int p = 0; p < kPieces; ++p) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) mn[rt][p] = *reinterpret_cast<const V*>(mp[rt] + k1 + p * 4 * E);
+                if (loads_x) xg[p] = *reinterpret_cast<const V*>(xp + k1 + p * 4 * E);
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < kPieces; ++p) {
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) {
-                const double2 a = xs[st][bt][p][lane];
+                const V a = xs[st][bt][p][lane];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    acc[rt][bt] = Mfma<double>::run(a.x, m[rt][p].x, acc[rt][bt]);
-                    acc[rt][bt] = Mfma<double>::run(a.y, m[rt][p].y, acc[rt][bt]);
-                }
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][bt] = Mx<T>::mfma(a[e], m[rt][p][e], acc[rt][bt]);
             }
         }
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            m[rt][0] = mn[rt][0];
-            m[rt][1] = mn[rt][1];
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) m[rt][p] = mn[rt][p];
     }
-    // D[row = (l>>4) + 4 reg][col = l&15]: row -> instance, col -> mat row
+    // D[row = drow(l>>4, reg)][col = l&15]: row -> instance, col -> mat row
     double* pout = partials + (split * B) * R;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -144,97 +150,106 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3))) 
             for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const size_t b = bt * 16 + q + 4 * g;
-                    if (b < nb) pout[(bchunk + b) * R + r] = acc[rt][bt][g];
+                    const size_t b = bt * 16 + Mx<T>::drow(q, g);
+                    if (b < nb) pout[(bchunk + b) * R + r] = (double)acc[rt][bt][g];
                 }
         }
     }
 }
 
-// ------------------------------------------------------------------------------ NN, f64
-// Workgroup: 4 waves x 32 columns; rows (the contraction) split kSplit ways.
-template <int BT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_nn_f64_kernel(size_t R, size_t C, size_t B,
-                                                                const double* __restrict__ mat,
-                                                                const double* __restrict__ x,
-                                                                size_t steps_per_split,
-                                                                double* __restrict__ partials) {
-    __shared__ double2 xs[2][BT][2][64];
+// ------------------------------------------------------------------------------ NN
+// Workgroup: 4 waves x (16 E) columns; rows (the contraction) split kSplit ways.
+// lane (j, q), piece p, element e <-> row k0 + q*P*E + p*E + e; a 16-byte piece of that row
+// holds E adjacent output columns col0 + E j + (0..E-1) = E MFMA n-tiles.
+template <typename T, int BT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, const T* __restrict__ x,
+                    size_t steps_per_split, double* __restrict__ partials) {
+    using V = typename Mx<T>::piece;
+    using A = typename Mx<T>::acc_t;
+    constexpr int E = Mx<T>::E;
+    constexpr int KS = kstep_of<T>();
+    constexpr int S = kPieces * E;            // rows per lane per step
+    __shared__ V xs[2][BT][kPieces][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const size_t cb = blockIdx.x / kSplit, split = blockIdx.x % kSplit;
     const size_t bchunk = (size_t)blockIdx.y * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
-    const size_t col0 = cb * 128 + (size_t)wave * 32;
-    const size_t nsteps_total = R / kKStep;
+    const size_t col0 = cb * (64 * E) + (size_t)wave * (16 * E);
+    const size_t nsteps_total = R / KS;
     const size_t sbeg = split * steps_per_split;
     size_t send = sbeg + steps_per_split;
     if (send > nsteps_total) send = nsteps_total;
-    size_t cl = col0 + 2 * j;                   // lane's column pair (clamped, C is even)
-    if (cl + 1 >= C) cl = C - 2;
-    const double* mp = mat + cl + (size_t)(4 * q) * C;
+    size_t cl = col0 + E * j;                   // lane's column group (clamped, C % E == 0)
+    if (cl + E > C) cl = C - E;
+    const T* mp = mat + cl + (size_t)(S * q) * C;
     size_t xb = bchunk + (size_t)wave * 16 + j;
     if (xb >= B) xb = B - 1;
-    const double* xp = x + xb * R + 4 * q;
+    const T* xp = x + xb * R + S * q;
     const bool loads_x = wave < BT;
 
-    d4 acc[2][BT];
+    A acc[E][BT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < E; ++nt)
 #pragma unroll
-        for (int bt = 0; bt < BT; ++bt) acc[nt][bt] = d4{0, 0, 0, 0};
+        for (int bt = 0; bt < BT; ++bt) acc[nt][bt] = A{0, 0, 0, 0};
 
-    double2 m[4], mn[4], xg[2];
+    V m[S], mn[S], xg[kPieces];
     if (sbeg < send) {
-        const size_t k0 = sbeg * kKStep;
+        const size_t k0 = sbeg * KS;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) m[s4] = *reinterpret_cast<const double2*>(mp + (k0 + s4) * C);
+        for (int s4 = 0; s4 < S; ++s4) m[s4] = *reinterpret_cast<const V*>(mp + (k0 + s4) * C);
         if (loads_x) {
-            xg[0] = *reinterpret_cast<const double2*>(xp + k0);
-            xg[1] = *reinterpret_cast<const double2*>(xp + k0 + 2);
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) xg[p] = *reinterpret_cast<const V*>(xp + k0 + p * E);
         }
     }
     for (size_t s = sbeg; s < send; ++s) {
         const int st = (int)((s - sbeg) & 1);
         if (loads_x) {
-            xs[st][wave][0][lane] = xg[0];
-            xs[st][wave][1][lane] = xg[1];
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) xs[st][wave][p][lane] = xg[p];
         }
         if (s + 1 < send) {
-            const size_t k1 = (s + 1) * kKStep;
+            const size_t k1 = (s + 1) * KS;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) mn[s4] = *reinterpret_cast<const double2*>(mp + (k1 + s4) * C);
+            for (int s4 = 0; s4 < S; ++s4) mn[s4] = *reinterpret_cast<const V*>(mp + (k1 + s4) * C);
             if (loads_x) {
-                xg[0] = *reinterpret_cast<const double2*>(xp + k1);
-                xg[1] = *reinterpret_cast<const double2*>(xp + k1 + 2);
+#pragma unroll
+                for (int p = 0; p < kPieces; ++p) xg[p] = *reinterpret_cast<const V*>(xp + k1 + p * E);
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < kPieces; ++p) {
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) {
-                const double2 a = xs[st][bt][p][lane];
-                acc[0][bt] = Mfma<double>::run(a.x, m[2 * p].x, acc[0][bt]);
-                acc[1][bt] = Mfma<double>::run(a.x, m[2 * p].y, acc[1][bt]);
-                acc[0][bt] = Mfma<double>::run(a.y, m[2 * p + 1].x, acc[0][bt]);
-                acc[1][bt] = Mfma<double>::run(a.y, m[2 * p + 1].y, acc[1][bt]);
+                const V a = xs[st][bt][p][lane];
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < E; ++nt)
+                        acc[nt][bt] = Mx<T>::mfma(a[e], m[p * E + e][nt], acc[nt][bt]);
             }
         }
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) m[s4] = mn[s4];
+        for (int s4 = 0; s4 < S; ++s4) m[s4] = mn[s4];
     }
     double* pout = partials + (split * B) * C;
-    const size_t c = col0 + 2 * j;
-    if (c + 1 < C) {
+    const size_t c = col0 + E * j;
+    if (c + E <= C) {
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const size_t b = bt * 16 + q + 4 * g;
-                if (b < nb)
-                    *reinterpret_cast<double2*>(pout + (bchunk + b) * C + c) =
-                        double2{acc[0][bt][g], acc[1][bt][g]};
+                const size_t b = bt * 16 + Mx<T>::drow(q, g);
+                if (b < nb) {
+#pragma unroll
+                    for (int nt = 0; nt < E; nt += 2)
+                        *reinterpret_cast<double2*>(pout + (bchunk + b) * C + c + nt) =
+                            double2{(double)acc[nt][bt][g], (double)acc[nt + 1][bt][g]};
+                }
             }
     }
 }
@@ -273,23 +288,24 @@ __global__ __launch_bounds__(kBlock) void mfma_fold_kernel(size_t len, size_t B,
 
 // ------------------------------------------------------------------------------ host side
 bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch) {
-    if (dtype != TRAMP_F64) return false;
+    if (dtype != TRAMP_F64 && dtype != TRAMP_F32) return false;
     if (batch == 0 || batch > 65535 * 64ull) return false;
-    if (nt) return (C % kKStep) == 0 && C >= kKStep && R >= 1;
-    return (R % kKStep) == 0 && R >= kKStep && (C % 2) == 0 && C >= 2;
+    const size_t ks = dtype == TRAMP_F64 ? kstep_of<double>() : kstep_of<float>();
+    const size_t e = dtype == TRAMP_F64 ? 2 : 4;
+    if (nt) return (C % ks) == 0 && C >= ks && R >= 1;
+    return (R % ks) == 0 && R >= ks && (C % e) == 0 && C >= e;
 }
 
-int gemm_mfma(tramp_ctx* ctx, int dtype, bool nt, size_t R, size_t C, size_t batch, const void* mat_d,
-              const void* x_d, const LinEpi& epi) {
-    if (!gemm_mfma_supported(dtype, nt, R, C, batch)) return tramp_fail(ctx, TRAMP_ENOTSUP, "gemm_mfma", "shape");
+template <typename T>
+static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch, const T* mat, const T* x,
+                       const LinEpi& epi) {
+    constexpr int E = Mx<T>::E;
     const size_t len = nt ? R : C;                  // output length per instance
     const size_t kdim = nt ? C : R;
-    const size_t nsteps = kdim / kKStep;
+    const size_t nsteps = kdim / kstep_of<T>();
     const size_t sps = (nsteps + kSplit - 1) / kSplit;
     int rc = tramp_ws_reserve(ctx, (size_t)kSplit * batch * len * sizeof(double));
     if (rc) return rc;
-    const double* mat = reinterpret_cast<const double*>(mat_d);
-    const double* x = reinterpret_cast<const double*>(x_d);
     const unsigned nchunk = (unsigned)((batch + 63) / 64);
     const size_t btail = batch - (size_t)(nchunk - 1) * 64;
     // BT is a compile-time tile count; a ragged last chunk simply masks its stores
@@ -300,23 +316,31 @@ int gemm_mfma(tramp_ctx* ctx, int dtype, bool nt, size_t R, size_t C, size_t bat
         const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
         dim3 grid((unsigned)(nrb * kSplit), nchunk);
         switch (bt) {
-            case 1: hipLaunchKernelGGL((gemm_nt_f64_kernel<1, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 2: hipLaunchKernelGGL((gemm_nt_f64_kernel<2, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 3: hipLaunchKernelGGL((gemm_nt_f64_kernel<3, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            default: hipLaunchKernelGGL((gemm_nt_f64_kernel<4, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 1: hipLaunchKernelGGL((gemm_nt_kernel<T, 1, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_kernel<T, 2, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 3: hipLaunchKernelGGL((gemm_nt_kernel<T, 3, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            default: hipLaunchKernelGGL((gemm_nt_kernel<T, 4, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
         }
     } else {
-        const size_t ncb = (C + 127) / 128;
+        const size_t ncb = (C + 64 * E - 1) / (64 * E);
         dim3 grid((unsigned)(ncb * kSplit), nchunk);
         switch (bt) {
-            case 1: hipLaunchKernelGGL((gemm_nn_f64_kernel<1>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 2: hipLaunchKernelGGL((gemm_nn_f64_kernel<2>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 3: hipLaunchKernelGGL((gemm_nn_f64_kernel<3>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            default: hipLaunchKernelGGL((gemm_nn_f64_kernel<4>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 1: hipLaunchKernelGGL((gemm_nn_kernel<T, 1>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 2: hipLaunchKernelGGL((gemm_nn_kernel<T, 2>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            case 3: hipLaunchKernelGGL((gemm_nn_kernel<T, 3>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
+            default: hipLaunchKernelGGL((gemm_nn_kernel<T, 4>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
         }
     }
     dim3 g2((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
-    hipLaunchKernelGGL((mfma_fold_kernel<double>), g2, block, 0, ctx->stream, len, batch, kSplit, ctx->ws, epi);
+    hipLaunchKernelGGL((mfma_fold_kernel<T>), g2, block, 0, ctx->stream, len, batch, kSplit, ctx->ws, epi);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
+}
+
+int gemm_mfma(tramp_ctx* ctx, int dtype, bool nt, size_t R, size_t C, size_t batch, const void* mat_d,
+              const void* x_d, const LinEpi& epi) {
+    if (!gemm_mfma_supported(dtype, nt, R, C, batch)) return tramp_fail(ctx, TRAMP_ENOTSUP, "gemm_mfma", "shape");
+    if (dtype == TRAMP_F64)
+        return gemm_mfma_t<double>(ctx, nt, R, C, batch, (const double*)mat_d, (const double*)x_d, epi);
+    return gemm_mfma_t<float>(ctx, nt, R, C, batch, (const float*)mat_d, (const float*)x_d, epi);
 }

@@ -11,6 +11,7 @@ struct tramp_linear {
     double* s2;          // [k] spectrum = sing^2 (owned)
     void* work;          // owned: t, u, w [batch, k] + a_raw[batch]
     size_t work_batch;
+    size_t proj_batch;   // batch of the projections currently held in t / u
     void* t;
     void* u;
     void* w;

@@ -302,7 +302,8 @@ static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t 
     TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
     TRAMP_REQUIRE(ctx, mat_d && x_d && epi.out);
     if (!R || !C || !batch) return TRAMP_OK;
-    bool mfma = (algo == 2) || (algo == 0 && batch > TRAMP_GEMV_MAX_BATCH);
+    // measured on MI355X: the VALU GEMV wins up to 2 instances (6.1 vs 5.7 TB/s), MFMA from 3 on
+    bool mfma = (algo == 2) || (algo == 0 && batch > 2);
     if (mfma && !gemm_mfma_supported(dtype, nt, R, C, batch)) {
         if (algo == 2) return tramp_fail(ctx, TRAMP_ENOTSUP, "mfma path", "shape/dtype not supported");
         mfma = false;
@@ -446,14 +447,17 @@ extern "C" int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, in
 extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batch, const double* az_d,
                                     const void* bz_d, const double* ax_d, const void* bx_d, double damping,
                                     const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d,
-                                    void* r_d, double* v_d) {
+                                    void* r_d, double* v_d, int reuse) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, lin && az_d && bz_d && ax_d && bx_d && a_new_d && b_new_d);
     TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
     TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
     if (!batch) return TRAMP_OK;
+    const void* work_before = lin->work;
     int rc = lin_reserve(ctx, lin, batch);
     if (rc) return rc;
+    if (lin->work != work_before || lin->proj_batch != batch) reuse = 0;   // projections are gone
+    lin->proj_batch = batch;
     const int dtype = lin->dtype;
     const size_t M = lin->M, N = lin->N, k = lin->k;
     // 1. scalars: v, a_new (K9)
@@ -464,12 +468,16 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
     LinEpi plain{};
     plain.mode = 0;
     plain.out = lin->t;
-    rc = matvec_dispatch(ctx, dtype, 0, true, k, N, batch, lin->Vt, bz_d, plain);
-    if (rc) return rc;
+    if (!(reuse & TRAMP_REUSE_T)) {
+        rc = matvec_dispatch(ctx, dtype, 0, true, k, N, batch, lin->Vt, bz_d, plain);
+        if (rc) return rc;
+    }
     // 3. u = Uk^T bx  [batch, k]
     plain.out = lin->u;
-    rc = matvec_dispatch(ctx, dtype, 0, false, M, k, batch, lin->Uk, bx_d, plain);
-    if (rc) return rc;
+    if (!(reuse & TRAMP_REUSE_U)) {
+        rc = matvec_dispatch(ctx, dtype, 0, false, M, k, batch, lin->Uk, bx_d, plain);
+        if (rc) return rc;
+    }
     // 4. spectral coefficients
     const int mode = (dir == TRAMP_FWD) ? 0 : (k < N ? 1 : 2);
     dim3 gm((unsigned)((k + kBlock - 1) / kBlock > 1024 ? 1024 : (k + kBlock - 1) / kBlock), (unsigned)batch);
