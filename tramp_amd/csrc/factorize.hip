@@ -71,6 +71,12 @@ extern "C" int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_
     TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
     TRAMP_REQUIRE(ctx, M < (1u << 30) && N < (1u << 30));
     const size_t k = M < N ? M : N;
+    // rocSOLVER 7.2 has no 64-bit syevd: its kernels index the k x k matrix with 32-bit ints
+    // (observed: GPU memory fault at k = 50000).  Refuse instead of faulting.
+    if (k * k >= (1ull << 31))
+        return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_linear_factorize",
+                          "min(M,N) > 46340 exceeds rocSOLVER's 32-bit indexing; factorise on the host "
+                          "or pass precomputed factors");
     TRAMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     rocblas_handle h = nullptr;
     RB_CHECK(ctx, rocblas_create_handle(&h));
