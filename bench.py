@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 16384)))
+    ap.add_argument("--n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 65536)))
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TRAMP_BENCH_BATCH", 64)),
                     help="instances per GPU")
@@ -207,18 +207,30 @@ def main():
                 if cnt[i]}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
+        # measured HBM traffic of the dominant kernel at this shape, if a PMC profile of it is committed.
+        # the dominant tag mixes the Vt pass (k x N) and the Uk pass (M x k); the profile covers the Vt shape.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))["entries"]
+            key = f"{dom}:{args.dtype}:R{M}:C{N}:B{B}"
+            if key in tj:
+                traffic = {"hbm_bytes_per_launch": tj[key]["hbm_bytes_per_launch"],
+                           "algorithmic_bytes_per_launch": tj[key]["algorithmic_bytes"],
+                           "shape": f"{M}x{N} pass", "source": "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"}
+        except Exception:
+            traffic = None
         use_mfma = B > 16 and dom.startswith("matvec")     # batch <= 16 streams at the HBM rate
         if use_mfma:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
-                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": traffic,
                     "peak_measured_issue_rate": MFMA_MEASURED_TFLOPS[args.dtype],
                     "avg_launch_ms": d["ms"] / d["launches"], "launches": d["launches"],
                     "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": d["ms"] / d["launches"],
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": d["ms"] / d["launches"],
                     "launches": d["launches"]}
         out = {
             "metric": "EP iterations/sec x N x instances (msg-components/sec), sparse GLM, alpha=0.5",

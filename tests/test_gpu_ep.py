@@ -142,3 +142,49 @@ def test_model_api_to_observed_and_sample(ctx):
     x_hat = ep.get_variable_data("x")["r"]
     assert np.mean((x_hat - sample["x"])**2) < 5e-3
     assert ep.n_iter < 100
+
+
+def test_config0_sparse_glm_n1000_matches_oracle(ctx):
+    """BASELINE configs[0]: sparse linear regression N=1000, alpha=0.5, the reference benchmark's
+    parameters (rho=0.05, noise 1e-2, damping 0.1, EarlyStoppingEP tol 1e-6): same n_iter,
+    same estimate as the oracle's EP."""
+    import tramp_amd as T
+    N, M, rho, nv = 1000, 500, 0.05, 1e-2
+    rs = np.random.RandomState(1)
+    W = orc.gaussian_ensemble(rs, M, N)
+    x = orc.gb_sample(rs, N, rho)
+    y = W @ x + np.sqrt(nv) * rs.standard_normal(M)
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, ctx=ctx, svd="device") @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=y, var=nv, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=1000, damping=0.1)
+    res = orc.ep_chain([orc.GBPriorFactor(N, rho=rho), orc.LinearFactor(W), orc.GaussLikFactor(y, nv)],
+                       [N, M], max_iter=1000, damping=0.1)
+    assert ep.n_iter == res["n_iter"] and ep.n_iter < 100
+    d = ep.get_variables_data()
+    close(d["x"]["r"], res["r"][0], 1e-6)
+    close(d["x"]["v"], res["v"][0], 1e-6)
+    assert np.mean((d["x"]["r"] - x)**2) < 1e-2
+
+
+def test_config2_one_bit_cs_fp32(ctx):
+    """BASELINE configs[2] in miniature: 1-bit compressed sensing (sign output), alpha=0.7, fp32
+    vectors: posterior means within 1e-3 of the f64 oracle over the first iterations."""
+    import tramp_amd as T
+    N, M, rho = 2048, 1434, 0.25
+    rs = np.random.RandomState(4)
+    W = orc.gaussian_ensemble(rs, M, N)
+    x = orc.gb_sample(rs, N, rho)
+    y = np.sign(W @ x)
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, dtype=np.float32, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, dtype=np.float32, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+             @ T.SgnLikelihood(y=y, dtype=np.float32, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=6, callback=T.PassCallback())
+    res = orc.ep_chain([orc.GBPriorFactor(N, rho=rho), orc.LinearFactor(W), orc.SgnLikFactor(y)], [N, M],
+                       max_iter=6, tol=0.0)
+    d = ep.get_variables_data()
+    close(d["x"]["r"], res["r"][0], 1e-3)
+    close(d["z"]["r"], res["r"][1], 1e-3)
+    close(d["x"]["v"], res["v"][0], 1e-3)

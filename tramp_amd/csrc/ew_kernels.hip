@@ -4,14 +4,21 @@
 // v = mean_i v_i, then the message update with the scalar a_new(v)"
 // (tramp/base.py:250-255).  b_new depends on the global mean, so each update is
 // two streaming passes over the instance:
-//   pass 1  read inputs, reduce sum(v_i) per block        -> partials[batch, nblk]
-//   pass 2  every block folds the partials (fixed order, deterministic), forms
-//           a_new, recomputes r_i and writes b_new (+ optional damping, r, masks)
-// r is recomputed rather than round-tripped through HBM.  Algorithmic traffic is
-// 2T (priors) / 3T (likelihoods, channels) bytes per component; the two-pass form
-// moves one extra read of the inputs, which stays in L2 / Infinity Cache for
-// single instances.  HBM-bound: 16-byte vector loads/stores, 64-wide shuffles,
-// one LDS hop per block.  No atomics, results are run-to-run reproducible.
+//   pass 1  read inputs, evaluate (r_i, v_i) ONCE, park r_i in a chunk scratch, reduce
+//           sum(v_i) per block                            -> partials[chunk, nblk]
+//   pass 2  (one generic kernel for all factors) folds the partials in fixed order,
+//           forms a_new and writes b_new = r (a + a_new) - b (+ damping, optional r)
+// Two realisations of pass 2, chosen per factor (measured on MI355X, 64 x 1e6 f64):
+//   light denoisers (GaussBernoulli, L1): pass 2 RECOMPUTES r_i from the inputs - 3T bytes
+//     moved for 2T algorithmic; the L1 update then runs at the box's read+write stream
+//     limit (~5 TB/s actual), GaussBernoulli ~25 % above it (two exp per component);
+//   heavy factors (erfcx / log / tanh: Sgn/Abs likelihoods, Sgn/Abs/Relu channels): pass 1
+//     parks r_i in a scratch and pass 2 (one generic kernel) reads it back - the
+//     transcendental math runs once; these are f64-VALU-bound, not HBM-bound.
+// Chunking instances so that the re-reads hit the 256 MiB Infinity Cache was measured and
+// did NOT pay (TRAMP_EW_CHUNK_MB keeps the knob; default off).
+// 16-byte vector loads/stores, 64-wide shuffles, one LDS hop per block; no atomics:
+// results are run-to-run reproducible.
 //
 // Built with -ffp-contract=off so that f64 branch masks see the same operands as
 // the NumPy reference (no FMA contraction).
@@ -26,27 +33,30 @@ using tmath::RV;
 template <typename T> struct EwOut { T r, v; unsigned mask; };
 
 template <typename T> struct GbOp {       // K1; in0 = bx
+    static constexpr bool HEAVY = false;
     static constexpr int NIN = 1;
     static constexpr int TARGET = 0;
     const double* ax;
     double a0, b0, eta;
-    T a, lg, b0T, etaT;
+    tmath::GbConst<T> k;
     double a_msg;
     __device__ void setup(size_t b) {
         a_msg = ax[b];
-        double ad = a_msg + a0;
-        a = T(ad);
-        lg = T(log(2 * tmath::kPi / ad));
-        b0T = T(b0);
-        etaT = T(eta);
+        const double ad = a_msg + a0;
+        const double inv = 1.0 / ad;
+        k.inv_a = T(inv);
+        k.c1 = T(0.5 * inv);
+        k.c0 = T(0.5 * log(2 * tmath::kPi / ad) - eta);
+        k.b0 = T(b0);
     }
     __device__ EwOut<T> eval(T x0, T) const {
-        RV<T> o = tmath::gb_posterior<T>(x0, a, lg, b0T, etaT);
+        RV<T> o = tmath::gb_posterior_fast<T>(x0, k);
         return {o.r, o.v, 0u};
     }
 };
 
 template <typename T> struct L1Op {       // K2; in0 = bx
+    static constexpr bool HEAVY = false;
     static constexpr int NIN = 1;
     static constexpr int TARGET = 0;
     const double* ax;
@@ -65,23 +75,24 @@ template <typename T> struct L1Op {       // K2; in0 = bx
 };
 
 template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
+    static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
     static constexpr int TARGET = 0;
     const double* az;
-    T a, v0;
+    tmath::RegionConst<T> c;
     double a_msg;
     __device__ void setup(size_t b) {
         a_msg = az[b];
-        a = T(a_msg);
-        v0 = T(1.0 / a_msg);
+        c = tmath::region_const<T>(a_msg);
     }
     __device__ EwOut<T> eval(T x0, T x1) const {
-        RV<T> o = tmath::sgn_lik_posterior<T>(x0, x1, a, v0);
+        RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, x1, c);
         return {o.r, o.v, 0u};
     }
 };
 
 template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
+    static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
     static constexpr int TARGET = 0;
     const double* az;
@@ -94,40 +105,45 @@ template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
 };
 
 template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 = bx
+    static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
     static constexpr int TARGET = FWD ? 1 : 0;
     const double* az;
     const double* ax;
-    T azT, axT;
+    tmath::PwlConst<T> c;
     double a_msg;
     __device__ void setup(size_t b) {
-        double z = az[b], x = ax[b];
-        azT = T(z);
-        axT = T(x);
+        const double z = az[b], x = ax[b];
+        c = tmath::pwl_const<T, KIND>(z, x);
         a_msg = FWD ? x : z;
     }
     __device__ EwOut<T> eval(T x0, T x1) const {
-        tmath::PwlOut<T> o = tmath::pwl_posterior<T, KIND, FWD>(x0, x1, azT, axT);
+        tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD>(x0, x1, c);
         return {o.r, o.v, o.mask};
     }
 };
 
-// ---------------------------------------------------------------- pass 1
+// ---------------------------------------------------------------- pass 1: moments
 template <typename T> __device__ __forceinline__ bool not_finite(T x) { return (x - x) != T(0); }
 
+// Reads the inputs once, evaluates (r_i, v_i), stores r_i to the chunk scratch and reduces
+// sum(v_i) per block.  `inst0` is the first instance of the chunk (blockIdx.y is relative).
 template <typename T, typename Op, bool VEC>
-__global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, const T* __restrict__ in0,
-                                                   const T* __restrict__ in1,
+__global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, size_t inst0, const T* __restrict__ in0,
+                                                   const T* __restrict__ in1, T* __restrict__ rbuf,
                                                    double* __restrict__ partials,
-                                                   unsigned long long* __restrict__ pcount) {
+                                                   unsigned long long* __restrict__ pcount,
+                                                   uint8_t* __restrict__ mask_out) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     __shared__ double smem[kBlock / kWave];
     __shared__ unsigned long long smem_u[kBlock / kWave];
-    const size_t b = blockIdx.y;
+    const size_t b = inst0 + blockIdx.y;
     op.setup(b);
     const T* p0 = in0 + b * n;
     const T* p1 = (Op::NIN > 1) ? in1 + b * n : nullptr;
+    T* pr = rbuf ? rbuf + (size_t)blockIdx.y * n : nullptr;
+    uint8_t* mo = mask_out ? mask_out + b * n : nullptr;
     double acc = 0.0;
     unsigned long long cnt = 0;
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -137,13 +153,17 @@ __global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, const T* __r
             V v0 = reinterpret_cast<const V*>(p0)[i];
             V v1 = v0;
             if (Op::NIN > 1) v1 = reinterpret_cast<const V*>(p1)[i];
+            V vr;
 #pragma unroll
             for (int j = 0; j < VN; ++j) {
                 EwOut<T> o = op.eval(vget<T>(v0, j), vget<T>(v1, j));
                 acc += (double)o.v;
                 if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
                 cnt += o.mask & 1u;
+                vset<T>(vr, j, o.r);
+                if (mo) mo[i * VN + j] = (uint8_t)o.mask;
             }
+            if (pr) reinterpret_cast<V*>(pr)[i] = vr;
         }
     } else {
         for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -153,17 +173,19 @@ __global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, const T* __r
             acc += (double)o.v;
             if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
             cnt += o.mask & 1u;
+            if (pr) pr[i] = o.r;
+            if (mo) mo[i] = (uint8_t)o.mask;
         }
     }
     acc = block_sum(acc, smem);
     if (pcount) cnt = block_sum_u64(cnt, smem_u);
     if (threadIdx.x == 0) {
-        partials[b * gridDim.x + blockIdx.x] = acc;
-        if (pcount) pcount[b * gridDim.x + blockIdx.x] = cnt;
+        partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+        if (pcount) pcount[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = cnt;
     }
 }
 
-// ---------------------------------------------------------------- pass 2
+// ---------------------------------------------------------------- pass 2: message update
 struct MsgOut {
     double damping;
     const double* a_old;
@@ -176,21 +198,92 @@ struct MsgOut {
     uint8_t* mask;
 };
 
-template <typename T, typename Op, bool VEC>
-__global__ __launch_bounds__(kBlock) void ew_pass2(Op op, size_t n, const T* __restrict__ in0,
-                                                   const T* __restrict__ in1,
+// Generic for every factor: folds the partials (same order in every block), forms
+// a_new = clip(1/v - a) and writes b_new = r (a + a_new) - b (tramp/base.py:250-255) with the
+// optional damping; r comes from the chunk scratch (cache resident), b from the input message.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void ew_pass2(size_t n, size_t inst0, const double* __restrict__ a_in_d,
+                                                   const T* __restrict__ b_in, const T* __restrict__ rbuf,
                                                    const double* __restrict__ partials,
-                                                   const unsigned long long* __restrict__ pcount,
-                                                   int nblk1, MsgOut out) {
+                                                   const unsigned long long* __restrict__ pcount, int nblk1,
+                                                   MsgOut out) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     __shared__ double smem[kBlock / kWave];
     __shared__ unsigned long long smem_u[kBlock / kWave];
-    const size_t b = blockIdx.y;
-    op.setup(b);
-    // fold the pass-1 partials of this instance: same order in every block
+    const size_t bl = blockIdx.y, b = inst0 + bl;
     double s = 0.0;
-    for (int i = threadIdx.x; i < nblk1; i += kBlock) s += partials[b * nblk1 + i];
+    for (int i = threadIdx.x; i < nblk1; i += kBlock) s += partials[bl * nblk1 + i];
+    s = block_sum(s, smem);
+    const double v = s / (double)n;
+    const double a_in = a_in_d[b];
+    const double a_new = tmath::a_new_of(v, a_in);
+    const double d = out.damping;
+    if (blockIdx.x == 0) {
+        if (out.count) {
+            unsigned long long c = 0;
+            for (int i = threadIdx.x; i < nblk1; i += kBlock) c += pcount[bl * nblk1 + i];
+            c = block_sum_u64(c, smem_u);
+            if (threadIdx.x == 0) out.count[b] = c;
+        }
+        if (threadIdx.x == 0) {
+            double a_out = a_new;
+            if (d != 0.0) a_out = d * out.a_old[b] + (1.0 - d) * a_new;
+            out.a_new[b] = a_out;
+            if (out.v) out.v[b] = v;
+        }
+    }
+    const T vinv = T(a_in + a_new);
+    const T dT = T(d), omd = T(1.0 - d);
+    const T* pb = b_in + b * n;
+    const T* pr = rbuf + bl * n;
+    T* bo = reinterpret_cast<T*>(out.b_new) + b * n;
+    const T* bold = out.b_old ? reinterpret_cast<const T*>(out.b_old) + b * n : nullptr;
+    T* ro = out.r ? reinterpret_cast<T*>(out.r) + b * n : nullptr;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    if (VEC) {
+        const size_t nv = n / VN;
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) {
+            const V vb = reinterpret_cast<const V*>(pb)[i];
+            const V vr = reinterpret_cast<const V*>(pr)[i];
+            V vo, vold;
+            if (bold) vold = reinterpret_cast<const V*>(bold)[i];
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                T bn = vget<T>(vr, j) * vinv - vget<T>(vb, j);
+                if (bold) bn = dT * vget<T>(vold, j) + omd * bn;
+                vset<T>(vo, j, bn);
+            }
+            reinterpret_cast<V*>(bo)[i] = vo;
+            if (ro) reinterpret_cast<V*>(ro)[i] = vr;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            const T ri = pr[i];
+            T bn = ri * vinv - pb[i];
+            if (bold) bn = dT * bold[i] + omd * bn;
+            bo[i] = bn;
+            if (ro) ro[i] = ri;
+        }
+    }
+}
+
+// Variant of pass 2 that recomputes r_i from the inputs instead of reading the scratch
+// (cheaper for the light denoisers, whose arithmetic hides under the stream).
+template <typename T, typename Op, bool VEC>
+__global__ __launch_bounds__(kBlock) void ew_pass2_recompute(Op op, size_t n, size_t inst0,
+                                                             const T* __restrict__ in0, const T* __restrict__ in1,
+                                                             const double* __restrict__ partials,
+                                                             const unsigned long long* __restrict__ pcount,
+                                                             int nblk1, MsgOut out) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    __shared__ double smem[kBlock / kWave];
+    __shared__ unsigned long long smem_u[kBlock / kWave];
+    const size_t bl = blockIdx.y, b = inst0 + bl;
+    op.setup(b);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk1; i += kBlock) s += partials[bl * nblk1 + i];
     s = block_sum(s, smem);
     const double v = s / (double)n;
     const double a_in = op.a_msg;
@@ -199,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void ew_pass2(Op op, size_t n, const T* __r
     if (blockIdx.x == 0) {
         if (out.count) {
             unsigned long long c = 0;
-            for (int i = threadIdx.x; i < nblk1; i += kBlock) c += pcount[b * nblk1 + i];
+            for (int i = threadIdx.x; i < nblk1; i += kBlock) c += pcount[bl * nblk1 + i];
             c = block_sum_u64(c, smem_u);
             if (threadIdx.x == 0) out.count[b] = c;
         }
@@ -214,11 +307,9 @@ __global__ __launch_bounds__(kBlock) void ew_pass2(Op op, size_t n, const T* __r
     const T dT = T(d), omd = T(1.0 - d);
     const T* p0 = in0 + b * n;
     const T* p1 = (Op::NIN > 1) ? in1 + b * n : nullptr;
-    const T* ptgt = (Op::TARGET == 0) ? p0 : p1;
     T* bo = reinterpret_cast<T*>(out.b_new) + b * n;
     const T* bold = out.b_old ? reinterpret_cast<const T*>(out.b_old) + b * n : nullptr;
     T* ro = out.r ? reinterpret_cast<T*>(out.r) + b * n : nullptr;
-    uint8_t* mo = out.mask ? out.mask + b * n : nullptr;
     const size_t stride = (size_t)gridDim.x * kBlock;
     if (VEC) {
         const size_t nv = n / VN;
@@ -232,12 +323,10 @@ __global__ __launch_bounds__(kBlock) void ew_pass2(Op op, size_t n, const T* __r
             for (int j = 0; j < VN; ++j) {
                 T x0 = vget<T>(v0, j), x1 = vget<T>(v1, j);
                 EwOut<T> o = op.eval(x0, x1);
-                T bt = (Op::TARGET == 0) ? x0 : x1;
-                T bn = o.r * vinv - bt;
+                T bn = o.r * vinv - ((Op::TARGET == 0) ? x0 : x1);
                 if (bold) bn = dT * vget<T>(vold, j) + omd * bn;
                 vset<T>(vo, j, bn);
                 vset<T>(vr, j, o.r);
-                if (mo) mo[i * VN + j] = (uint8_t)o.mask;
             }
             reinterpret_cast<V*>(bo)[i] = vo;
             if (ro) reinterpret_cast<V*>(ro)[i] = vr;
@@ -247,45 +336,82 @@ __global__ __launch_bounds__(kBlock) void ew_pass2(Op op, size_t n, const T* __r
             T x0 = p0[i];
             T x1 = (Op::NIN > 1) ? p1[i] : x0;
             EwOut<T> o = op.eval(x0, x1);
-            T bn = o.r * vinv - ptgt[i];
+            T bn = o.r * vinv - ((Op::TARGET == 0) ? x0 : x1);
             if (bold) bn = dT * bold[i] + omd * bn;
             bo[i] = bn;
             if (ro) ro[i] = o.r;
-            if (mo) mo[i] = (uint8_t)o.mask;
         }
     }
 }
 
+// Instances are processed in chunks small enough that pass 2 finds r and b in the
+// 256 MiB Infinity Cache: HBM then sees each input once and b_new once (2T / 3T per
+// component, the algorithmic minimum) although the update is two launches.
+static size_t env_size(const char* name, size_t dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    long v = atol(e);
+    return v >= 0 ? (size_t)v : dflt;
+}
+
 template <typename T, typename Op>
 static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0,
-                        const void* in1, const MsgOut& out) {
-    TRAMP_REQUIRE(ctx, in0 && out.a_new && out.b_new);
+                        const void* in1, const double* a_in_d, const MsgOut& out) {
+    TRAMP_REQUIRE(ctx, in0 && out.a_new && out.b_new && a_in_d);
     TRAMP_REQUIRE(ctx, Op::NIN == 1 || in1);
     if (n == 0 || batch == 0) return TRAMP_OK;
-    TRAMP_REQUIRE(ctx, batch <= 65535);
     TRAMP_REQUIRE(ctx, out.damping == 0.0 || (out.a_old && out.b_old));
     constexpr int VN = Vec<T>::N;
     const bool vec = (n % VN) == 0;
     const int nblk = blocks_for(n, VN);
-    const size_t need = batch * (size_t)nblk * (sizeof(double) + sizeof(unsigned long long));
+    // heavy factors (erfcx / log / tanh per component) park r in a scratch; light ones recompute
+    static const size_t mode_env = env_size("TRAMP_EW_MODE", 2);           // 0 store, 1 recompute, 2 auto
+    static const size_t chunk_mb = env_size("TRAMP_EW_CHUNK_MB", 0);        // 0: whole batch per launch
+    const bool store_r = mode_env == 0 || (mode_env == 2 && Op::HEAVY);
+    // chunk: inputs (+ r scratch) of `cb` instances within the cache budget
+    size_t cb = (chunk_mb << 20) / (n * sizeof(T) * (Op::NIN + (store_r ? 1 : 0)));
+    if (cb < 1) cb = 1;
+    if (cb > batch || chunk_mb == 0) cb = batch;
+    if (cb > 65535) cb = 65535;
+    const size_t r_bytes = store_r ? ((cb * n * sizeof(T) + 255) / 256) * 256 : 0;
+    const size_t need = r_bytes + cb * (size_t)nblk * (sizeof(double) + sizeof(unsigned long long));
     int rc = tramp_ws_reserve(ctx, need);
     if (rc) return rc;
-    double* partials = ctx->ws;
+    T* rbuf = store_r ? reinterpret_cast<T*>(ctx->ws) : nullptr;
+    double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ws) + r_bytes);
     unsigned long long* pcount =
-        out.count ? reinterpret_cast<unsigned long long*>(ctx->ws + batch * (size_t)nblk) : nullptr;
-    dim3 grid(nblk, (unsigned)batch), block(kBlock);
+        out.count ? reinterpret_cast<unsigned long long*>(partials + cb * (size_t)nblk) : nullptr;
     MsgOut o = out;
     if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
     const T* p0 = reinterpret_cast<const T*>(in0);
     const T* p1 = reinterpret_cast<const T*>(in1);
+    const T* ptgt = (Op::TARGET == 0) ? p0 : p1;
     // algorithmic traffic: read every input once, write b_new once
     ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
-    if (vec) {
-        hipLaunchKernelGGL((ew_pass1<T, Op, true>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount);
-        hipLaunchKernelGGL((ew_pass2<T, Op, true>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount, nblk, o);
-    } else {
-        hipLaunchKernelGGL((ew_pass1<T, Op, false>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount);
-        hipLaunchKernelGGL((ew_pass2<T, Op, false>), grid, block, 0, ctx->stream, op, n, p0, p1, partials, pcount, nblk, o);
+    for (size_t inst0 = 0; inst0 < batch; inst0 += cb) {
+        const size_t nb = (batch - inst0 < cb) ? batch - inst0 : cb;
+        dim3 grid(nblk, (unsigned)nb), block(kBlock);
+        if (vec)
+            hipLaunchKernelGGL((ew_pass1<T, Op, true>), grid, block, 0, ctx->stream, op, n, inst0, p0, p1, rbuf,
+                               partials, pcount, out.mask);
+        else
+            hipLaunchKernelGGL((ew_pass1<T, Op, false>), grid, block, 0, ctx->stream, op, n, inst0, p0, p1, rbuf,
+                               partials, pcount, out.mask);
+        if (store_r) {
+            if (vec)
+                hipLaunchKernelGGL((ew_pass2<T, true>), grid, block, 0, ctx->stream, n, inst0, a_in_d, ptgt, rbuf,
+                                   partials, pcount, nblk, o);
+            else
+                hipLaunchKernelGGL((ew_pass2<T, false>), grid, block, 0, ctx->stream, n, inst0, a_in_d, ptgt, rbuf,
+                                   partials, pcount, nblk, o);
+        } else {
+            if (vec)
+                hipLaunchKernelGGL((ew_pass2_recompute<T, Op, true>), grid, block, 0, ctx->stream, op, n, inst0, p0,
+                                   p1, partials, pcount, nblk, o);
+            else
+                hipLaunchKernelGGL((ew_pass2_recompute<T, Op, false>), grid, block, 0, ctx->stream, op, n, inst0, p0,
+                                   p1, partials, pcount, nblk, o);
+        }
     }
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
@@ -312,8 +438,8 @@ extern "C" int tramp_gb_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     GbOp<float> of{ax_d, a0, b0, eta};
     GbOp<double> od{ax_d, a0, b0, eta};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
 }
 
 extern "C" int tramp_l1_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
@@ -326,8 +452,8 @@ extern "C" int tramp_l1_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, count_d, mask_d};
     L1Op<float> of{ax_d, gamma};
     L1Op<double> od{ax_d, gamma};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
 }
 
 extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
@@ -339,8 +465,8 @@ extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     SgnLikOp<float> of{az_d};
     SgnLikOp<double> od{az_d};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
 }
 
 extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
@@ -352,8 +478,8 @@ extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     AbsLikOp<float> of{az_d};
     AbsLikOp<double> od{az_d};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
 }
 
 template <typename T, int KIND>
@@ -361,10 +487,10 @@ static int pwl_dir(tramp_ctx* ctx, int dir, size_t n, size_t batch, const double
                    const void* bz_d, const double* ax_d, const void* bx_d, const MsgOut& out) {
     if (dir == TRAMP_FWD) {
         PwlOp<T, KIND, true> op{az_d, ax_d};
-        return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, out);
+        return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, ax_d, out);
     }
     PwlOp<T, KIND, false> op{az_d, ax_d};
-    return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, out);
+    return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, az_d, out);
 }
 
 template <typename T>

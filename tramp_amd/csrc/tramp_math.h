@@ -54,14 +54,31 @@ TM_HD double fabs_(double x) { return ::fabs(x); }
 TM_HD float fabs_(float x) { return ::fabsf(x); }
 TM_HD double fmax_(double a, double b) { return ::fmax(a, b); }
 TM_HD float fmax_(float a, float b) { return ::fmaxf(a, b); }
+TM_HD double fma_(double a, double b, double c) { return ::fma(a, b, c); }
+TM_HD float fma_(float a, float b, float c) { return ::fmaf(a, b, c); }
 
-// scipy.special.expit: two-branch logistic (no overflow on either side).
+// Reciprocal without the IEEE division fix-up sequence (about 5 instead of ~25 instructions in
+// f64): hardware estimate + two Newton steps, within 1 ulp for normal operands; 0 -> inf,
+// inf -> 0 as 1/x.  Used only where no branch mask depends on the quotient.
+#if defined(__HIP_DEVICE_COMPILE__)
+TM_HD double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = (e == e && fabs(e) < 1.0) ? fma(r, e, r) : r;      // skip the refinement for 0 / inf / nan
+    e = fma(-x, r, 1.0);
+    return (e == e && fabs(e) < 1.0) ? fma(r, e, r) : r;
+}
+TM_HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+inline double fast_rcp(double x) { return 1.0 / x; }
+inline float fast_rcp(float x) { return 1.0f / x; }
+#endif
+
+// scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal.
 template <typename T> TM_HD T expit(T x) {
-    if (x < T(0)) {
-        T e = exp_(x);
-        return e / (T(1) + e);
-    }
-    return T(1) / (T(1) + exp_(-x));
+    T e = exp_(-fabs_(x));
+    T r = fast_rcp(T(1) + e);
+    return x < T(0) ? e * r : r;
 }
 
 // ---- A1: message update, scalars always double (tramp/base.py:245-255) ----
@@ -85,6 +102,21 @@ template <typename T> TM_HD RV<T> gb_posterior(T bx, T a, T lg, T b0, T eta) {
     RV<T> o;
     o.r = s * ba;
     o.v = s / a + s * (T(1) - s) * (ba * ba);
+    return o;
+}
+
+// Same denoiser with the per-instance scalars hoisted: inv_a = 1/a, c1 = 0.5/a,
+// c0 = 0.5 log(2 pi / a) - eta.  No division left in the element loop.
+template <typename T> struct GbConst { T inv_a, c1, c0, b0; };
+
+template <typename T> TM_HD RV<T> gb_posterior_fast(T bx, const GbConst<T>& k) {
+    T b = bx + k.b0;
+    T xi = fma_(b * b, k.c1, k.c0);
+    T s = expit(xi);
+    T ba = b * k.inv_a;
+    RV<T> o;
+    o.r = s * ba;
+    o.v = s * fma_(T(1) - s, ba * ba, k.inv_a);      // s/a + s (1-s) (b/a)^2
     return o;
 }
 
@@ -130,11 +162,57 @@ template <typename T> TM_HD HalfLine<T> halfline(T r0, T v0, int side) {
     return h;
 }
 
+// Per-region scalars of one instance: a = az + slope^2 ax, v0 = 1/a, s0 = sqrt(v0) are formed
+// once with the reference's (IEEE) operations, so that y0 = (0 - b/a)/s0 - the operand of the
+// log_Phi branch mask - is bit-identical to NumPy's.  Everything downstream of y0 uses
+// reciprocals (no mask depends on it).
+template <typename T> struct RegionConst { T a, v0, s0, half_log2piv0; };
+
+template <typename T> TM_HD RegionConst<T> region_const(double a) {
+    RegionConst<T> c;
+    c.a = T(a);
+    c.v0 = T(1) / c.a;
+    c.s0 = sqrt_(c.v0);
+    c.half_log2piv0 = T(0.5) * log_(T(2 * kPi) * c.v0);
+    return c;
+}
+
+template <typename T, bool LOGP> TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0) {
+    r0 = b / c.a;                              // exact: mask operand
+    T y0 = (T(0) - r0) / c.s0;                 // exact: mask operand
+    T sd = T(side);
+    T x = sd * (y0 * T(0.70710678118654752440));
+    T e = erfcx_(x);
+    T ie = fast_rcp(e);
+    T g1 = T(kSqrt2OverPi) * (sd * ie);
+    T g2 = T(kTwoOverSqrtPi) * (x * ie);
+    HalfLine<T> h;
+    h.mean = r0 + c.s0 * g1;
+    h.var = c.v0 * (T(1) + g2 - g1 * g1);
+    h.mask = true;
+    h.logp = T(0);
+    if (LOGP) {
+        T u = -sd * y0;
+        h.mask = u < LogPhiCut<T>::value;
+        h.logp = h.mask ? (log_(T(0.5) * e) - T(0.5) * (u * u)) : T(0);
+    }
+    return h;
+}
+
 // ---- A6: sign likelihood (tramp/likelihoods/sgn_likelihood.py:32-37,
 //          tramp/beliefs/positive.py:12-17) -----------------------------------------
 template <typename T> TM_HD RV<T> sgn_lik_posterior(T bz, T y, T az, T v0 /* 1/az */) {
     T b = bz * y;
     HalfLine<T> h = halfline<T>(b / az, v0, +1);
+    RV<T> o;
+    o.r = y * h.mean;
+    o.v = h.var;
+    return o;
+}
+
+template <typename T> TM_HD RV<T> sgn_lik_posterior_fast(T bz, T y, const RegionConst<T>& c) {
+    T r0;
+    HalfLine<T> h = halfline_fast<T, false>(bz * y, c, +1, r0);
     RV<T> o;
     o.r = y * h.mean;
     o.v = h.var;
@@ -195,6 +273,62 @@ TM_HD PwlOut<T> pwl_posterior(T bz, T bx, T az, T ax) {
     T e0 = exp_(As[0] - m), e1 = exp_(As[1] - m);
     T se = e0 + e1;
     T p0 = e0 / se, p1 = e1 / se;
+    PwlOut<T> o;
+    o.r = p0 * rs[0] + p1 * rs[1];
+    T d = rs[0] - rs[1];
+    o.v = p0 * vs[0] + p1 * vs[1] + p0 * p1 * (d * d);
+    o.mask = mask;
+    return o;
+}
+
+// Hoisted form used by the streaming kernels: RegionConst per region (a, 1/a, sqrt(1/a),
+// 0.5 log(2 pi v0)) computed once per instance.
+template <typename T> struct PwlConst { RegionConst<T> reg[2]; T az, ax; };
+
+template <typename T, int KIND> TM_HD PwlConst<T> pwl_const(double az, double ax) {
+    PwlConst<T> c;
+    c.az = T(az);
+    c.ax = T(ax);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const T slope = T(pwl_slope(KIND, k));
+        c.reg[k] = region_const<T>((double)(c.az + slope * slope * c.ax));
+    }
+    return c;
+}
+
+template <typename T, int KIND, bool FWD>
+TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
+    T rs[2], vs[2], As[2];
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const T slope = T(pwl_slope(KIND, k));
+        const T x0 = T(pwl_x0(KIND, k));
+        const int side = (k == 0) ? +1 : -1;
+        T b = bz + slope * (bx - c.ax * x0);
+        T r0;
+        HalfLine<T> h = halfline_fast<T, true>(b, c.reg[k], side, r0);
+        // 0.5 r0^2 / v0 = 0.5 r0^2 a
+        As[k] = c.reg[k].half_log2piv0 + T(0.5) * (r0 * r0) * c.reg[k].a + h.logp
+                - T(0.5) * c.ax * (x0 * x0) + bx * x0;
+        if (FWD) {
+            rs[k] = slope * h.mean + x0;
+            vs[k] = slope * slope * h.var;
+        } else {
+            rs[k] = h.mean;
+            vs[k] = h.var;
+        }
+        mask |= (h.mask ? 1u : 0u) << k;
+    }
+    // softmax over two regions = logistic of the difference: one exp, one reciprocal; the
+    // small probability is formed directly (e * r), never as 1 - big
+    const T dA = As[0] - As[1];
+    const T ee = exp_(-fabs_(dA));
+    const T rr = fast_rcp(T(1) + ee);
+    const T big = rr, small = ee * rr;
+    const T p0 = dA < T(0) ? small : big;
+    const T p1 = dA < T(0) ? big : small;
     PwlOut<T> o;
     o.r = p0 * rs[0] + p1 * rs[1];
     T d = rs[0] - rs[1];
