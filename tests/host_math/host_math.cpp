@@ -1,0 +1,73 @@
+// Host build of tramp_amd/csrc/tramp_math.h: a UNIT-TEST HARNESS for the per-component
+// arithmetic (tests/test_host_math.py compares it with the oracle on the CPU).  It is test
+// infrastructure only - nothing in tramp_amd/ loads it, and it is not a CPU fallback.
+// erfcx on the host is a stand-in (exp(x^2) erfc(x)), so agreement is ~1e-12, not bitwise.
+#include <cstddef>
+#include <cstdint>
+
+#include "../../tramp_amd/csrc/tramp_math.h"
+
+using namespace tmath;
+
+template <typename T>
+static void gb(size_t n, const T* bx, double ax, double rho, double mean, double var, T* r, T* v, int fast) {
+    const double a0 = 1.0 / var, b0 = mean / var;
+    const double eta = 0.5 * (b0 * b0 / a0 + log(2 * kPi / a0)) - log(rho / (1 - rho));
+    const double ad = ax + a0;
+    GbConst<T> k{T(1.0 / ad), T(0.5 / ad), T(0.5 * log(2 * kPi / ad) - eta), T(b0)};
+    for (size_t i = 0; i < n; ++i) {
+        RV<T> o = fast ? gb_posterior_fast<T>(bx[i], k)
+                       : gb_posterior<T>(bx[i], T(ad), T(log(2 * kPi / ad)), T(b0), T(eta));
+        r[i] = o.r;
+        v[i] = o.v;
+    }
+}
+
+template <typename T, int KIND, bool FWD>
+static void pwl(size_t n, const T* bz, const T* bx, double az, double ax, T* r, T* v, uint8_t* mask, int fast) {
+    PwlConst<T> c = pwl_const<T, KIND>(az, ax);
+    for (size_t i = 0; i < n; ++i) {
+        PwlOut<T> o = fast ? pwl_posterior_fast<T, KIND, FWD>(bz[i], bx[i], c)
+                           : pwl_posterior<T, KIND, FWD>(bz[i], bx[i], T(az), T(ax));
+        r[i] = o.r;
+        v[i] = o.v;
+        mask[i] = (uint8_t)o.mask;
+    }
+}
+
+extern "C" {
+void hm_gb_f64(size_t n, const double* bx, double ax, double rho, double mean, double var, double* r, double* v, int fast) { gb<double>(n, bx, ax, rho, mean, var, r, v, fast); }
+void hm_gb_f32(size_t n, const float* bx, double ax, double rho, double mean, double var, float* r, float* v, int fast) { gb<float>(n, bx, ax, rho, mean, var, r, v, fast); }
+
+void hm_l1_f64(size_t n, const double* bx, double ax, double gamma, double* r, double* v, uint8_t* mask) {
+    for (size_t i = 0; i < n; ++i) {
+        RV<double> o = l1_posterior<double>(bx[i], 1.0 / ax, gamma);
+        r[i] = o.r; v[i] = o.v; mask[i] = l1_support<double>(bx[i], gamma);
+    }
+}
+void hm_sgn_lik_f64(size_t n, const double* bz, const double* y, double az, double* r, double* v, int fast) {
+    RegionConst<double> c = region_const<double>(az);
+    for (size_t i = 0; i < n; ++i) {
+        RV<double> o = fast ? sgn_lik_posterior_fast<double>(bz[i], y[i], c)
+                            : sgn_lik_posterior<double>(bz[i], y[i], az, 1.0 / az);
+        r[i] = o.r; v[i] = o.v;
+    }
+}
+void hm_abs_lik_f64(size_t n, const double* bz, const double* y, double* r, double* v) {
+    for (size_t i = 0; i < n; ++i) {
+        RV<double> o = abs_lik_posterior<double>(bz[i], y[i]);
+        r[i] = o.r; v[i] = o.v;
+    }
+}
+void hm_pwl_f64(int kind, int fwd, size_t n, const double* bz, const double* bx, double az, double ax, double* r, double* v, uint8_t* mask, int fast) {
+    switch (kind * 2 + (fwd ? 1 : 0)) {
+        case 0: pwl<double, 0, false>(n, bz, bx, az, ax, r, v, mask, fast); break;
+        case 1: pwl<double, 0, true>(n, bz, bx, az, ax, r, v, mask, fast); break;
+        case 2: pwl<double, 1, false>(n, bz, bx, az, ax, r, v, mask, fast); break;
+        case 3: pwl<double, 1, true>(n, bz, bx, az, ax, r, v, mask, fast); break;
+        case 4: pwl<double, 2, false>(n, bz, bx, az, ax, r, v, mask, fast); break;
+        case 5: pwl<double, 2, true>(n, bz, bx, az, ax, r, v, mask, fast); break;
+    }
+}
+double hm_a_new(double v, double a) { return a_new_of(v, a); }
+}

@@ -35,6 +35,31 @@ __global__ __launch_bounds__(256) void fma64(double* out, int iters, double a, d
     }
     out[blockIdx.x * 256 + threadIdx.x] = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
 }
+// co-issue test: waves 0,1 of each block run the MFMA loop, waves 2,3 the v_fma_f64 loop
+// (mode 0: all MFMA, 1: all FMA, 2: half/half)
+__global__ __launch_bounds__(256) void mixed64(double* out, int iters, double a, double b, int mode) {
+    const int wave = threadIdx.x >> 6;
+    const bool do_mfma = mode == 0 || (mode == 2 && wave < 2);
+    double res = 0;
+    if (do_mfma) {
+        d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+        for (int i = 0; i < iters; ++i) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+        }
+        res = c0[0] + c1[1] + c2[2] + c3[3];
+    } else {
+        double c0 = 0, c1 = 1, c2 = 2, c3 = 3, c4 = 4, c5 = 5, c6 = 6, c7 = 7;
+        for (int i = 0; i < iters * 16; ++i) {       // 16*8*64*2 = 16384 flop per iteration per wave = 8 MFMAs worth
+            c0 = fma(a, b, c0); c1 = fma(a, b, c1); c2 = fma(a, b, c2); c3 = fma(a, b, c3);
+            c4 = fma(a, b, c4); c5 = fma(a, b, c5); c6 = fma(a, b, c6); c7 = fma(a, b, c7);
+        }
+        res = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = res;
+}
 __global__ __launch_bounds__(256) void stream_read(const double2* __restrict__ in, size_t n, double* out) {
     double acc = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -67,6 +92,14 @@ int main() {
         int blocks = 256 * 8;
         float ms = timeit([&] { hipLaunchKernelGGL(fma64, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0, 2.0); }, 3);
         printf("v_fma_f64: %.1f TFLOP/s\n", (double)blocks * 256 * iters * 8 * 2.0 / ms / 1e9);
+    }
+    for (int mode : {0, 1, 2}) {
+        int blocks = 256 * 4;     // 16 waves per CU
+        int it = 5000;
+        float ms = timeit([&] { hipLaunchKernelGGL(mixed64, dim3(blocks), dim3(256), 0, 0, out, it, 1.0, 2.0, mode); }, 3);
+        double wm = (mode == 0 ? 4 : mode == 2 ? 2 : 0), wf = 4 - wm;
+        double fl = (double)blocks * it * (wm * 4 * 2048.0 + wf * 16 * 8 * 64 * 2.0);
+        printf("mixed f64 mode=%d (0 mfma,1 fma,2 half/half): %.3f ms  %.1f TFLOP/s total\n", mode, ms, fl / ms / 1e9);
     }
     size_t bytes = 8ull << 30;
     double2 *a, *b; hipMalloc(&a, bytes); hipMalloc(&b, bytes);
