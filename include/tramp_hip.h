@@ -95,6 +95,18 @@ int tramp_event_record(tramp_ctx* ctx, tramp_event* ev);
 /* Synchronises on `stop`; milliseconds between the two recorded events. */
 int tramp_event_elapsed_ms(tramp_ctx* ctx, tramp_event* start, tramp_event* stop, float* ms);
 
+/* ---- hipGraph capture of a launch sequence (launch-bound inner loops) --------
+ * Between tramp_graph_begin and tramp_graph_end every launch on the context's stream is
+ * recorded instead of executed; the resulting executable graph replays the whole sequence
+ * (e.g. one EP iteration: all factor updates + variable posteriors) with one host call.
+ * Everything the sequence needs must have been allocated by an eager run before (capture
+ * forbids allocation and synchronisation); buffers and scalar arguments are baked in. */
+typedef struct tramp_graph tramp_graph;
+int tramp_graph_begin(tramp_ctx* ctx);
+int tramp_graph_end(tramp_ctx* ctx, tramp_graph** graph);
+int tramp_graph_launch(tramp_ctx* ctx, tramp_graph* graph);
+int tramp_graph_destroy(tramp_ctx* ctx, tramp_graph* graph);
+
 /* Per-kernel timing for the roofline report: while enabled, every launch group is
  * bracketed by HIP events on the context's stream.  tramp_profile_report synchronises
  * and returns, per tag (TRAMP_PROF_*), the number of launch groups, their summed

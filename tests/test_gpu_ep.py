@@ -188,3 +188,27 @@ def test_config2_one_bit_cs_fp32(ctx):
     close(d["x"]["r"], res["r"][0], 1e-3)
     close(d["z"]["r"], res["r"][1], 1e-3)
     close(d["x"]["v"], res["v"][0], 1e-3)
+
+
+@pytest.mark.parametrize("damping", [None, 0.1])
+def test_graph_replay_identical_to_eager(ctx, damping):
+    """hipGraph replay of the iteration == the eager loop, bit for bit."""
+    import tramp_amd as T
+    N, M, B, rho, nv = 512, 256, 3, 0.1, 1e-2
+    rs = np.random.RandomState(21)
+    W = orc.gaussian_ensemble(rs, M, N)
+    X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(B)])
+    Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
+    out = []
+    for use_graph in (False, True):
+        model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+                 @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+                 @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        ep.iterate(max_iter=40, damping=damping, graph=use_graph)
+        d = ep.get_variables_data()
+        out.append((ep.n_iter, d["x"]["r"].copy(), np.copy(d["x"]["v"]), ep.get_edges_data()))
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    for k in out[0][3]:
+        assert np.array_equal(out[0][3][k], out[1][3][k])

@@ -31,13 +31,13 @@ def test_gemv_valu(ctx, kind, shape, B, dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("kind", ["nt", "nn"])
 @pytest.mark.parametrize("shape", [(16, 16), (32, 32), (128, 256), (130, 288), (288, 130), (1000, 512), (64, 4096),
-                                   (4096, 64), (50, 1600)])
+                                   (4096, 64), (50, 1600), (500, 1000), (1000, 500), (37, 102), (102, 38), (5, 7)])
 @pytest.mark.parametrize("B", [1, 9, 16, 17, 33, 64, 65, 130])
 def test_gemm_mfma(ctx, kind, shape, B, dtype):
     import tramp_amd as T
     R, C = shape
-    ks, e = (16, 2) if dtype == np.float64 else (32, 4)
-    if kind == "nt" and C % ks or kind == "nn" and (R % ks or C % e):
+    e = 2 if dtype == np.float64 else 4
+    if kind == "nt" and C % e or kind == "nn" and (R % e or C % e):
         with pytest.raises(T._lib.TrampHipError):
             run(ctx, T, kind, 2, R, C, B, dtype)      # algo=2 forces MFMA: unsupported shape
         return

@@ -76,6 +76,10 @@ _SIGNATURES = {
     "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
     "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],
     "tramp_randn": [vp, i32, vp, sz, u64, dbl],
+    "tramp_graph_begin": [vp],
+    "tramp_graph_end": [vp, C.POINTER(vp)],
+    "tramp_graph_launch": [vp, vp],
+    "tramp_graph_destroy": [vp, vp],
     "tramp_profile_enable": [vp, i32],
     "tramp_profile_report": [vp, vp, vp, vp, vp],
 }

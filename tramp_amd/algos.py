@@ -360,10 +360,25 @@ class ExpectationPropagation:
         return float(m[0]) if self.batch == 1 else m
 
     # -- main loop
+    def _capture_iteration(self):
+        "Record one steady-state iteration (all launches of the three sweeps) into a hipGraph."
+        import ctypes as C
+        self.ctx._call("tramp_graph_begin")
+        try:
+            self.forward_message()
+            self.backward_message()
+            self.update_variables()
+        finally:
+            g = C.c_void_p()
+            self.ctx._call("tramp_graph_end", C.byref(g))
+        return g
+
     def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False,
-                check_every=1):
+                check_every=1, graph=False):
         """message_passing.py:330-357.  ``check_every`` > 1 reads the scalar table (NaN guard,
-        stopping rule) only every k-th iteration - the sweeps themselves never wait on the host."""
+        stopping rule) only every k-th iteration - the sweeps themselves never wait on the host.
+        ``graph=True`` captures the third iteration's launch sequence in a hipGraph and replays
+        it afterwards (launch-bound small problems); results are identical to the eager loop."""
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
         if damping is not None and damping is not False and not isinstance(damping, float):
@@ -376,17 +391,29 @@ class ExpectationPropagation:
             self.init_message_dag(initializer)
             self.n_iter = 0
             self.n_iter_instance[:] = 0
-        for i in range(max_iter):
-            self.forward_message()
-            self.backward_message()
-            self.update_variables()
-            self.n_iter += 1
-            if (i + 1) % check_every == 0 or i == max_iter - 1:
-                self._read_scalars()
-                self.check_message()
-                if callback(self, i, max_iter):
-                    logger.info("terminated after n_iter=%d iterations", self.n_iter)
-                    break
+        g = None
+        try:
+            for i in range(max_iter):
+                if g is not None:
+                    self.ctx._call("tramp_graph_launch", g)
+                elif graph and i == 2:
+                    # iterations 0 and 1 ran eagerly: buffers exist, caches are in steady state
+                    g = self._capture_iteration()
+                    self.ctx._call("tramp_graph_launch", g)
+                else:
+                    self.forward_message()
+                    self.backward_message()
+                    self.update_variables()
+                self.n_iter += 1
+                if (i + 1) % check_every == 0 or i == max_iter - 1:
+                    self._read_scalars()
+                    self.check_message()
+                    if callback(self, i, max_iter):
+                        logger.info("terminated after n_iter=%d iterations", self.n_iter)
+                        break
+        finally:
+            if g is not None:
+                self.ctx._call("tramp_graph_destroy", g)
         self.n_iter_instance[self.n_iter_instance == 0] = self.n_iter
         return self
 

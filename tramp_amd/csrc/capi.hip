@@ -70,6 +70,66 @@ extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
     return TRAMP_OK;
 }
 
+struct tramp_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+extern "C" int tramp_graph_begin(tramp_ctx* ctx) {
+    if (!ctx) return TRAMP_EINVAL;
+    if (ctx->prof_on) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_graph_begin", "disable profiling before capture");
+    ctx->capturing = true;
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        ctx->capturing = false;
+        return tramp_fail(ctx, TRAMP_EHIP, "hipStreamBeginCapture", hipGetErrorString(e));
+    }
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_graph_end(tramp_ctx* ctx, tramp_graph** out) {
+    if (!ctx || !out) return TRAMP_EINVAL;
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    ctx->capturing = false;
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        return tramp_fail(ctx, TRAMP_EHIP, "hipStreamEndCapture", hipGetErrorString(e));
+    }
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return tramp_fail(ctx, TRAMP_EHIP, "hipGraphInstantiate", hipGetErrorString(e));
+    }
+    tramp_graph* tg = new (std::nothrow) tramp_graph();
+    if (!tg) {
+        (void)hipGraphExecDestroy(ex);
+        (void)hipGraphDestroy(g);
+        return TRAMP_ENOMEM;
+    }
+    tg->graph = g;
+    tg->exec = ex;
+    *out = tg;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_graph_launch(tramp_ctx* ctx, tramp_graph* graph) {
+    if (!ctx || !graph) return TRAMP_EINVAL;
+    TRAMP_HIP_CHECK(ctx, hipGraphLaunch(graph->exec, ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_graph_destroy(tramp_ctx* ctx, tramp_graph* graph) {
+    if (!ctx || !graph) return TRAMP_EINVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGraphExecDestroy(graph->exec);
+    (void)hipGraphDestroy(graph->graph);
+    delete graph;
+    return TRAMP_OK;
+}
+
 extern "C" int tramp_profile_enable(tramp_ctx* ctx, int on) {
     if (!ctx) return TRAMP_EINVAL;
     if (on && !ctx->prof) {
@@ -110,6 +170,9 @@ extern "C" const char* tramp_last_error(const tramp_ctx* ctx) { return ctx ? ctx
 
 int tramp_ws_reserve(tramp_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return TRAMP_OK;
+    if (ctx->capturing)
+        return tramp_fail(ctx, TRAMP_EINVAL, "workspace", "would have to grow during graph capture; run the "
+                          "sequence eagerly once first");
     size_t nb = ctx->ws_bytes;
     while (nb < bytes) nb *= 2;
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

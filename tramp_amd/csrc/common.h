@@ -36,6 +36,7 @@ struct tramp_ctx {
     char err[512];
     // profiling
     bool prof_on;
+    bool capturing;      // inside tramp_graph_begin/end
     TrampProfRec* prof;
     int prof_cap, prof_n;
 };

@@ -59,7 +59,8 @@ template <typename T> constexpr int kstep_of() { return 4 * kPieces * Mx<T>::E; 
 // ------------------------------------------------------------------------------ NT
 // Workgroup: 4 waves x (RT*16) rows; grid.x = row_blocks * kSplit; grid.y = batch chunks of 64.
 // lane (j = l&15, q = l>>4), piece p, element e  <->  column k0 + p*4E + q*E + e.
-template <typename T, int BT, int RT>
+// TAIL: the contraction length is not a multiple of the k step (guards only compiled in then).
+template <typename T, int BT, int RT, bool TAIL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
 void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, const T* __restrict__ x,
                     size_t steps_per_split, double* __restrict__ partials) {
@@ -74,10 +75,11 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     const size_t bchunk = (size_t)blockIdx.y * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;          // instances in this chunk
     const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
-    const size_t nsteps_total = C / KS;
+    const size_t nsteps_total = (C + KS - 1) / KS;      // a ragged k tail is zero-filled
     const size_t sbeg = split * steps_per_split;
     size_t send = sbeg + steps_per_split;
     if (send > nsteps_total) send = nsteps_total;
+    const V vzero = {};
     // lane's mat rows (clamped: out-of-range rows are computed on valid memory and never stored)
     const T* mp[RT];
 #pragma unroll
@@ -103,9 +105,11 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
         const size_t k0 = sbeg * KS;
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) {
+            const bool in = !TAIL || k0 + p * 4 * E + q * E < C;   // C % E == 0: pieces are all-in or all-out
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) m[rt][p] = *reinterpret_cast<const V*>(mp[rt] + k0 + p * 4 * E);
-            if (loads_x) xg[p] = *reinterpret_cast<const V*>(xp + k0 + p * 4 * E);
+            for (int rt = 0; rt < RT; ++rt)
+                m[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k0 + p * 4 * E) : vzero;
+            if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k0 + p * 4 * E) : vzero;
         }
     }
     for (size_t s = sbeg; s < send; ++s) {
@@ -118,9 +122,11 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
             const size_t k1 = (s + 1) * KS;
 #pragma unroll
             for (int p = 0; p < kPieces; ++p) {
+                const bool in = !TAIL || k1 + p * 4 * E + q * E < C;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) mn[rt][p] = *reinterpret_cast<const V*>(mp[rt] + k1 + p * 4 * E);
-                if (loads_x) xg[p] = *reinterpret_cast<const V*>(xp + k1 + p * 4 * E);
+                for (int rt = 0; rt < RT; ++rt)
+                    mn[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k1 + p * 4 * E) : vzero;
+                if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k1 + p * 4 * E) : vzero;
             }
         }
         __syncthreads();
@@ -161,7 +167,7 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
 // Workgroup: 4 waves x (16 E) columns; rows (the contraction) split kSplit ways.
 // lane (j, q), piece p, element e <-> row k0 + q*P*E + p*E + e; a 16-byte piece of that row
 // holds E adjacent output columns col0 + E j + (0..E-1) = E MFMA n-tiles.
-template <typename T, int BT>
+template <typename T, int BT, bool TAIL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
 void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, const T* __restrict__ x,
                     size_t steps_per_split, double* __restrict__ partials) {
@@ -177,10 +183,11 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     const size_t bchunk = (size_t)blockIdx.y * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
     const size_t col0 = cb * (64 * E) + (size_t)wave * (16 * E);
-    const size_t nsteps_total = R / KS;
+    const size_t nsteps_total = (R + KS - 1) / KS;      // a ragged k tail is zero-filled
     const size_t sbeg = split * steps_per_split;
     size_t send = sbeg + steps_per_split;
     if (send > nsteps_total) send = nsteps_total;
+    const V vzero = {};
     size_t cl = col0 + E * j;                   // lane's column group (clamped, C % E == 0)
     if (cl + E > C) cl = C - E;
     const T* mp = mat + cl + (size_t)(S * q) * C;
@@ -199,10 +206,12 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     if (sbeg < send) {
         const size_t k0 = sbeg * KS;
 #pragma unroll
-        for (int s4 = 0; s4 < S; ++s4) m[s4] = *reinterpret_cast<const V*>(mp + (k0 + s4) * C);
+        for (int s4 = 0; s4 < S; ++s4)
+            m[s4] = (!TAIL || k0 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k0 + s4) * C) : vzero;
         if (loads_x) {
 #pragma unroll
-            for (int p = 0; p < kPieces; ++p) xg[p] = *reinterpret_cast<const V*>(xp + k0 + p * E);
+            for (int p = 0; p < kPieces; ++p)
+                xg[p] = (!TAIL || k0 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k0 + p * E) : vzero;
         }
     }
     for (size_t s = sbeg; s < send; ++s) {
@@ -214,10 +223,12 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
         if (s + 1 < send) {
             const size_t k1 = (s + 1) * KS;
 #pragma unroll
-            for (int s4 = 0; s4 < S; ++s4) mn[s4] = *reinterpret_cast<const V*>(mp + (k1 + s4) * C);
+            for (int s4 = 0; s4 < S; ++s4)
+                mn[s4] = (!TAIL || k1 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k1 + s4) * C) : vzero;
             if (loads_x) {
 #pragma unroll
-                for (int p = 0; p < kPieces; ++p) xg[p] = *reinterpret_cast<const V*>(xp + k1 + p * E);
+                for (int p = 0; p < kPieces; ++p)
+                    xg[p] = (!TAIL || k1 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k1 + p * E) : vzero;
             }
         }
         __syncthreads();
@@ -290,10 +301,11 @@ __global__ __launch_bounds__(kBlock) void mfma_fold_kernel(size_t len, size_t B,
 bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch) {
     if (dtype != TRAMP_F64 && dtype != TRAMP_F32) return false;
     if (batch == 0 || batch > 65535 * 64ull) return false;
-    const size_t ks = dtype == TRAMP_F64 ? kstep_of<double>() : kstep_of<float>();
+    // 16-byte pieces must not straddle a row end: the contraction length (and, for NN, the row
+    // length) has to be a multiple of the piece width; ragged k tails are zero-filled in-kernel
     const size_t e = dtype == TRAMP_F64 ? 2 : 4;
-    if (nt) return (C % ks) == 0 && C >= ks && R >= 1;
-    return (R % ks) == 0 && R >= ks && (C % e) == 0 && C >= e;
+    if (nt) return (C % e) == 0 && C >= e && R >= 1;
+    return (R % e) == 0 && R >= e && (C % e) == 0 && C >= e;
 }
 
 template <typename T>
@@ -302,7 +314,7 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     constexpr int E = Mx<T>::E;
     const size_t len = nt ? R : C;                  // output length per instance
     const size_t kdim = nt ? C : R;
-    const size_t nsteps = kdim / kstep_of<T>();
+    const size_t nsteps = (kdim + kstep_of<T>() - 1) / kstep_of<T>();
     const size_t sps = (nsteps + kSplit - 1) / kSplit;
     int rc = tramp_ws_reserve(ctx, (size_t)kSplit * batch * len * sizeof(double));
     if (rc) return rc;
@@ -311,26 +323,29 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     // BT is a compile-time tile count; a ragged last chunk simply masks its stores
     const int bt = (nchunk > 1) ? 4 : (int)((btail + 15) / 16);
     dim3 block(kBlock);
+    const bool tail = (kdim % kstep_of<T>()) != 0;
+#define LAUNCH_NT(BTv, TAILv) hipLaunchKernelGGL((gemm_nt_kernel<T, BTv, RT, TAILv>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws)
+#define LAUNCH_NN(BTv, TAILv) hipLaunchKernelGGL((gemm_nn_kernel<T, BTv, TAILv>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws)
+#define BY_BT(M_, TAILv)                       \
+    switch (bt) {                              \
+        case 1: M_(1, TAILv); break;           \
+        case 2: M_(2, TAILv); break;           \
+        case 3: M_(3, TAILv); break;           \
+        default: M_(4, TAILv); break;          \
+    }
     if (nt) {
         constexpr int RT = 2;
         const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
         dim3 grid((unsigned)(nrb * kSplit), nchunk);
-        switch (bt) {
-            case 1: hipLaunchKernelGGL((gemm_nt_kernel<T, 1, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 2: hipLaunchKernelGGL((gemm_nt_kernel<T, 2, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 3: hipLaunchKernelGGL((gemm_nt_kernel<T, 3, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            default: hipLaunchKernelGGL((gemm_nt_kernel<T, 4, RT>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-        }
+        if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
     } else {
         const size_t ncb = (C + 64 * E - 1) / (64 * E);
         dim3 grid((unsigned)(ncb * kSplit), nchunk);
-        switch (bt) {
-            case 1: hipLaunchKernelGGL((gemm_nn_kernel<T, 1>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 2: hipLaunchKernelGGL((gemm_nn_kernel<T, 2>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            case 3: hipLaunchKernelGGL((gemm_nn_kernel<T, 3>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-            default: hipLaunchKernelGGL((gemm_nn_kernel<T, 4>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws); break;
-        }
+        if (tail) { BY_BT(LAUNCH_NN, true) } else { BY_BT(LAUNCH_NN, false) }
     }
+#undef BY_BT
+#undef LAUNCH_NT
+#undef LAUNCH_NN
     dim3 g2((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
     hipLaunchKernelGGL((mfma_fold_kernel<T>), g2, block, 0, ctx->stream, len, batch, kSplit, ctx->ws, epi);
     TRAMP_LAUNCH_CHECK(ctx);

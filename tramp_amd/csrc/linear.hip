@@ -410,6 +410,8 @@ int lin_square(tramp_ctx* ctx, const double* in, double* out, size_t n) {
 
 static int lin_reserve(tramp_ctx* ctx, tramp_linear* lin, size_t batch) {
     if (batch <= lin->work_batch) return TRAMP_OK;
+    if (ctx->capturing)
+        return tramp_fail(ctx, TRAMP_EINVAL, "linear workspace", "cannot allocate during graph capture");
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (lin->work) TRAMP_HIP_CHECK(ctx, hipFree(lin->work));
     lin->work = nullptr;
