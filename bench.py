@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 65536)))
+    ap.add_argument("--size", dest="n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 65536)),
+                    help="signal dimension N (not --n: torch.distributed.run would read it as its own option)")
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TRAMP_BENCH_BATCH", 64)),
                     help="instances per GPU")
@@ -127,7 +128,9 @@ def main():
             sys.exit(2)
     dist = None
     torch = None
-    if world > 1:
+    # TRAMP_BENCH_FORCE_DIST=1 takes the torch.distributed / RCCL path even with one rank
+    # (used to smoke-test the multi-GPU code on a 1-GPU box)
+    if world > 1 or os.environ.get("TRAMP_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
