@@ -212,3 +212,30 @@ def test_graph_replay_identical_to_eager(ctx, damping):
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     for k in out[0][3]:
         assert np.array_equal(out[0][3][k], out[1][3][k])
+
+
+def test_ensemble_per_instance_stopping(ctx):
+    """Instances converge at different iterations; the frozen result of instance b equals the
+    oracle's single-instance run stopped by its own EarlyStoppingEP (same n_iter, same estimate)."""
+    import tramp_amd as T
+    N, M, B, rho, nv = 256, 128, 6, 0.1, 1e-2
+    rs = np.random.RandomState(31)
+    W = orc.gaussian_ensemble(rs, M, N)
+    X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(B)])
+    Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=200, damping=0.1)
+    d = ep.get_variables_data(frozen=True)
+    lin = orc.LinearFactor(W)
+    n_iters = []
+    for b in range(B):
+        res = orc.ep_chain([orc.GBPriorFactor(N, rho=rho), lin, orc.GaussLikFactor(Y[b], nv)], [N, M],
+                           max_iter=200, damping=0.1)
+        n_iters.append(res["n_iter"])
+        assert ep.n_iter_instance[b] == res["n_iter"]
+        close(d["x"]["r"][b], res["r"][0], 1e-6)
+        close(d["x"]["v"][b], res["v"][0], 1e-6)
+    assert ep.n_iter == max(n_iters) and len(set(n_iters)) > 1

@@ -193,6 +193,7 @@ class ExpectationPropagation:
         self.n_iter = 0
         self.n_iter_instance = np.zeros(self.batch, dtype=int)
         self._allocated = False
+        self._frozen_r = None
         self.default_stopping = EarlyStoppingEP()
 
     # -- storage
@@ -315,17 +316,39 @@ class ExpectationPropagation:
             return np.sqrt(sd) / np.sqrt(sn)
 
     def mark_converged(self, mask):
+        """Record the instances that meet the stopping rule for the first time and freeze their
+        result: the reference would have stopped each instance's own run here, the ensemble keeps
+        iterating until all are done (instances never interact, so the others are unaffected)."""
         newly = mask & (self.n_iter_instance == 0)
+        if not newly.any():
+            return
         self.n_iter_instance[newly] = self.n_iter
+        if self.batch == 1:
+            return
+        if self._frozen_r is None:
+            self._frozen_r = [self.ctx.zeros(r.shape, self.dtype) for r in self.r]
+            self._frozen_v = np.zeros((len(self.variables), self.batch))
+        for b in np.flatnonzero(newly):
+            for i in range(len(self.variables)):
+                self._frozen_r[i].row(int(b)).copy_from(self.r[i].row(int(b)))
+                self._frozen_v[i, b] = self.S_host[3 * i, b]
 
-    def get_variables_data(self, ids="all", want_r=True):
+    def get_variables_data(self, ids="all", want_r=True, frozen=False):
+        """{id: dict(r=..., v=...)} of the current iteration; ``frozen=True`` returns, for
+        instances that already met the stopping rule, the estimate at THEIR stopping iteration."""
         out = {}
+        done = (self.n_iter_instance > 0) & (self.n_iter_instance < self.n_iter)
+        use_frozen = frozen and self._frozen_r is not None and done.any()
         for i, v in enumerate(self.variables):
             if ids == "all" or v.id in ids:
-                vv = self.S_host[3 * i]
-                d = dict(v=float(vv[0]) if self.batch == 1 else vv.copy())
+                vv = self.S_host[3 * i].copy()
+                if use_frozen:
+                    vv[done] = self._frozen_v[i, done]
+                d = dict(v=float(vv[0]) if self.batch == 1 else vv)
                 if want_r:
                     r = self.r[i].get()
+                    if use_frozen:
+                        r[done] = self._frozen_r[i].get()[done]
                     d["r"] = r[0] if self.batch == 1 else r
                 out[v.id] = d
         return out
@@ -391,6 +414,7 @@ class ExpectationPropagation:
             self.init_message_dag(initializer)
             self.n_iter = 0
             self.n_iter_instance[:] = 0
+            self._frozen_r = None
         g = None
         try:
             for i in range(max_iter):
