@@ -334,10 +334,23 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
         default: M_(4, TAILv); break;          \
     }
     if (nt) {
-        constexpr int RT = 2;
-        const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-        dim3 grid((unsigned)(nrb * kSplit), nchunk);
-        if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
+        static const int rt_env = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 4;   // measured: 54 (RT=4) vs 51 (RT=2) TFLOP/s in f64
+        if (rt_env == 4) {
+            constexpr int RT = 4;
+            const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
+            dim3 grid((unsigned)(nrb * kSplit), nchunk);
+            if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
+        } else if (rt_env == 1) {
+            constexpr int RT = 1;
+            const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
+            dim3 grid((unsigned)(nrb * kSplit), nchunk);
+            if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
+        } else {
+            constexpr int RT = 2;
+            const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
+            dim3 grid((unsigned)(nrb * kSplit), nchunk);
+            if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
+        }
     } else {
         const size_t ncb = (C + 64 * E - 1) / (64 * E);
         dim3 grid((unsigned)(ncb * kSplit), nchunk);
