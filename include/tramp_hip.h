@@ -187,6 +187,16 @@ int tramp_pwl_channel(tramp_ctx* ctx, int dtype, int kind, int dir, size_t n, si
                       double* a_new_d, void* b_new_d, void* r_d, double* v_d,
                       uint8_t* mask_d);
 
+/* K7, generic form: any channel made of the two half-line regions z in [zcut, inf) with
+ * x = x0_pos + slope_pos z and z in (-inf, zcut] with x = x0_neg + slope_neg z:
+ * LeakyReluChannel (slopes 1 / s; piecewise_linear_channel.py:72-77) and AsymmetricAbsChannel
+ * (slopes +1 / -1, zcut = shift; :94-99).  Same arguments otherwise as tramp_pwl_channel. */
+int tramp_pwl2_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batch,
+                       double slope_pos, double slope_neg, double x0_pos, double x0_neg, double zcut,
+                       const double* az_d, const void* bz_d, const double* ax_d, const void* bx_d,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d, uint8_t* mask_d);
+
 /* ---- diagonal-belief variants (isotropic=False): a is an n-vector too ------
  * Same files as above with the `.mean()` line skipped
  * (gauss_bernoulli_prior.py:75-76, sgn_likelihood.py:35-36, map_L1_norm_prior.py:69-70)
@@ -297,6 +307,10 @@ int tramp_se_abs_lik(tramp_ctx* ctx, size_t count, const double* az, const doubl
  *      tramp/utils/linear_region.py:78-101, tramp/utils/integration.py:31-73. */
 int tramp_se_pwl_channel(tramp_ctx* ctx, int kind, int dir, size_t count,
                          const double* az, const double* ax, const double* tau_z, double* v);
+
+int tramp_se_pwl2_channel(tramp_ctx* ctx, int dir, size_t count, double slope_pos, double slope_neg,
+                          double x0_pos, double x0_neg, double zcut,
+                          const double* az, const double* ax, const double* tau_z, double* v);
 
 /* ---- synthetic data (bench / tests; counter-based, reproducible per seed) --- */
 /* out[i] = scale * N(0,1), Philox-4x32 + Box-Muller, element i from counter i. */

@@ -173,8 +173,9 @@ def log_Phi(x):
     return y
 
 
-def halfline_moments(r0, v0, side):
-    """Mean, variance and log-probability of N(r0, v0) restricted to a half line.
+def halfline_moments(r0, v0, side, zb=0):
+    """Mean, variance and log-probability of N(r0, v0) restricted to a half line
+    [zb, inf) (side=+1) or (-inf, zb] (side=-1); zb = 0 for Sgn/Abs/Relu.
 
     truncated_normal_mean/_var/_log_proba (truncated_normal.py:234-281) through
     the ``_inf`` branches G0_inf/G1_inf/G2_inf (:218-231), F1_inf/F2_inf
@@ -182,7 +183,7 @@ def halfline_moments(r0, v0, side):
     y0 = (0 - r0)/s0 and the reference evaluates the functions with s = side.
     """
     s0 = np.sqrt(v0)
-    y0 = (0 - r0) / s0
+    y0 = (zb - r0) / s0
     x = y0 / SQRT2
     e = erfcx(side * x)
     g1 = np.sqrt(2 / np.pi) * (side / e)
@@ -209,10 +210,10 @@ def norm_pdf(x):
     return np.exp(-0.5 * x**2) / np.sqrt(2 * np.pi)
 
 
-def halfline_proba(r0, v0, side):
+def halfline_proba(r0, v0, side, zb=0):
     "truncated_normal_proba (truncated_normal.py:284-291)."
     s0 = np.sqrt(v0)
-    y0 = (0 - r0) / s0
+    y0 = (zb - r0) / s0
     if side > 0:
         return norm_cdf(np.inf) - norm_cdf(y0)
     return norm_cdf(y0) - norm_cdf(-np.inf)
@@ -270,19 +271,32 @@ PWL_REGIONS = {
 }
 
 
-def pwl_region_terms(side, slope, x0, az, bz, ax, bx):
+def pwl_regions(kind, param=None):
+    """Region table [(side, slope, x0, zb) for pos, neg].  Besides the three hot-path kinds:
+    'l-relu' (param = slope of the negative side; piecewise_linear_channel.py:72-77) and
+    'a-abs' (param = shift of the kink; :94-99)."""
+    if kind in PWL_REGIONS:
+        return [r + (0.,) for r in PWL_REGIONS[kind]]
+    if kind == "l-relu":
+        return [(+1, 1., 0., 0.), (-1, float(param), 0., 0.)]
+    if kind == "a-abs":
+        return [(+1, +1., 0., float(param)), (-1, -1., 0., float(param))]
+    raise KeyError(kind)
+
+
+def pwl_region_terms(side, slope, x0, az, bz, ax, bx, zb=0):
     "Per-region (rz, vz, logZ): linear_region.py:32-64."
     a = az + slope**2 * ax
     b = bz + slope * (bx - ax * x0)
     r0 = b / a
     v0 = 1 / a
-    rz, vz, g0 = halfline_moments(r0, v0, side)
+    rz, vz, g0 = halfline_moments(r0, v0, side, zb)
     logZ = (0.5 * np.log(2 * np.pi * v0) + 0.5 * r0**2 / v0 + g0
             - 0.5 * ax * x0**2 + bx * x0)
     return rz, vz, logZ
 
 
-def pwl_channel_posterior(kind, direction, az, bz, ax, bx, isotropic=True):
+def pwl_channel_posterior(kind, direction, az, bz, ax, bx, isotropic=True, param=None):
     """(r, v) for direction 'fwd' (x side) or 'bwd' (z side).
 
     merge_estimates (piecewise_linear_channel.py:27-37) with scipy softmax over
@@ -291,8 +305,8 @@ def pwl_channel_posterior(kind, direction, az, bz, ax, bx, isotropic=True):
     bz = np.asarray(bz, dtype=float)
     bx = np.asarray(bx, dtype=float)
     rs, vs, As = [], [], []
-    for side, slope, x0 in PWL_REGIONS[kind]:
-        rz, vz, A = pwl_region_terms(side, slope, x0, az, bz, ax, bx)
+    for side, slope, x0, zb in pwl_regions(kind, param):
+        rz, vz, A = pwl_region_terms(side, slope, x0, az, bz, ax, bx, zb)
         if direction == "fwd":
             rs.append(slope * rz + x0)
             vs.append(slope**2 * vz)
@@ -310,19 +324,19 @@ def pwl_channel_posterior(kind, direction, az, bz, ax, bx, isotropic=True):
     return r, v
 
 
-def pwl_channel_message(kind, direction, az, bz, ax, bx):
+def pwl_channel_message(kind, direction, az, bz, ax, bx, param=None):
     "Channel.compute_forward/backward_message (channels/base_channel.py:9-17)."
-    r, v = pwl_channel_posterior(kind, direction, az, bz, ax, bx)
+    r, v = pwl_channel_posterior(kind, direction, az, bz, ax, bx, param=param)
     if direction == "fwd":
         return ab_new(r, v, ax, bx)
     return ab_new(r, v, az, bz)
 
 
-def pwl_proba_ab(side, slope, x0, az, bz, ax, bx):
+def pwl_proba_ab(side, slope, x0, az, bz, ax, bx, zb=0):
     "LinearRegion.proba_ab (linear_region.py:78-81)."
     a = az + slope**2 * ax
     b = bz + slope * (bx - ax * x0)
-    return halfline_proba(b / a, 1 / a, side)
+    return halfline_proba(b / a, 1 / a, side, zb)
 
 
 # --------------------------------------------------------------------------
@@ -572,21 +586,21 @@ def se_abs_lik_error(az, tau_z, method="quadpack"):
     return gaussian_measure_2d(0, np.sqrt(tau_z), 0, 1, integrand, method)
 
 
-def se_pwl_channel_error(kind, direction, az, ax, tau_z, method="quadpack"):
+def se_pwl_channel_error(kind, direction, az, ax, tau_z, method="quadpack", param=None):
     """Channel.compute_forward/backward_error (channels/base_channel.py:29-41)
     with PiecewiseLinearChannel.beliefs_measure (piecewise_linear_channel.py:60-64)
     and LinearRegion.beliefs_measure (linear_region.py:83-101)."""
     def variance(bz, bx):
         _, v = pwl_channel_posterior(kind, direction, az, bz, ax, bx,
-                                     isotropic=False)
+                                     isotropic=False, param=param)
         return v
     u_eff = np.maximum(0, az * tau_z - 1)
     total = 0.
-    for side, slope, x0 in PWL_REGIONS[kind]:
+    for side, slope, x0, zb in pwl_regions(kind, param):
         mean_x = ax * x0
 
-        def integrand(bz, bx, side=side, slope=slope, x0=x0):
-            return pwl_proba_ab(side, slope, x0, az, bz, ax, bx) * variance(bz, bx)
+        def integrand(bz, bx, side=side, slope=slope, x0=x0, zb=zb):
+            return pwl_proba_ab(side, slope, x0, az, bz, ax, bx, zb) * variance(bz, bx)
         sx2 = ax * (slope**2 * ax * tau_z + 1)
         if ax == 0 or u_eff == 0 or slope == 0:
             total += gaussian_measure_2d(0, np.sqrt(az * u_eff), mean_x,
@@ -599,14 +613,14 @@ def se_pwl_channel_error(kind, direction, az, ax, tau_z, method="quadpack"):
     return total
 
 
-def pwl_second_moment(kind, tau_z):
+def pwl_second_moment(kind, tau_z, param=None):
     "PiecewiseLinearChannel.second_moment (piecewise_linear_channel.py:21-25)."
     tot = 0.
-    for side, slope, x0 in PWL_REGIONS[kind]:
-        rz, vz, _ = halfline_moments(np.float64(0), np.float64(tau_z), side)
+    for side, slope, x0, zb in pwl_regions(kind, param):
+        rz, vz, _ = halfline_moments(np.float64(0), np.float64(tau_z), side, zb)
         rx = slope * rz + x0
         vx = slope**2 * vz
-        p = halfline_proba(np.float64(0), np.float64(tau_z), side)
+        p = halfline_proba(np.float64(0), np.float64(tau_z), side, zb)
         tot += p * (rx**2 + vx)
     return tot
 
@@ -696,25 +710,26 @@ class MPFactor(OracleFactor):
 
 
 class PWLFactor(OracleFactor):
-    def __init__(self, kind):
+    def __init__(self, kind, param=None):
         self.kind_pwl = kind
+        self.param = param
 
     def forward(self, az, bz, ax, bx):
-        return pwl_channel_message(self.kind_pwl, "fwd", az, bz, ax, bx)
+        return pwl_channel_message(self.kind_pwl, "fwd", az, bz, ax, bx, self.param)
 
     def backward(self, az, bz, ax, bx):
-        return pwl_channel_message(self.kind_pwl, "bwd", az, bz, ax, bx)
+        return pwl_channel_message(self.kind_pwl, "bwd", az, bz, ax, bx, self.param)
 
     def forward_se(self, az, ax, tau_z, method="quadpack"):
-        v = se_pwl_channel_error(self.kind_pwl, "fwd", az, ax, tau_z, method)
+        v = se_pwl_channel_error(self.kind_pwl, "fwd", az, ax, tau_z, method, self.param)
         return a_new(v, ax)
 
     def backward_se(self, az, ax, tau_z, method="quadpack"):
-        v = se_pwl_channel_error(self.kind_pwl, "bwd", az, ax, tau_z, method)
+        v = se_pwl_channel_error(self.kind_pwl, "bwd", az, ax, tau_z, method, self.param)
         return a_new(v, az)
 
     def second_moment(self, tau_z):
-        return pwl_second_moment(self.kind_pwl, tau_z)
+        return pwl_second_moment(self.kind_pwl, tau_z, self.param)
 
 
 class GaussLikFactor(OracleFactor):

@@ -160,6 +160,31 @@ def test_pwl_channels(T, ctx, golden_factors, dtype):
             close_b(b_new, c["b_" + d], r_cond, a_in, c["a_" + d], tgt, dtype)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pwl2_channels(T, ctx, golden_factors, dtype):
+    "LeakyRelu / AsymmetricAbs through the generic K7 entry point (tramp_pwl2_channel)"
+    for c in golden_factors["pwl2"]:
+        if np.isnan(c["v_fwd"]) or np.isnan(c["v_bwd"]):
+            continue
+        ch = (T.LeakyReluChannel(slope=c["param"], dtype=dtype, ctx=ctx) if c["kind"] == "l-relu"
+              else T.AsymmetricAbsChannel(shift=c["param"], dtype=dtype, ctx=ctx))
+        close(ch.second_moment(1.7), c["tau_x"], atol=1e-12)
+        for d, post, msg in (("fwd", ch.compute_forward_posterior, ch.compute_forward_message),
+                             ("bwd", ch.compute_backward_posterior, ch.compute_backward_message)):
+            r, v = post(c["az"], c["bz"], c["ax"], c["bx"])
+            with np.errstate(all="ignore"):
+                rk = [orc.pwl_region_terms(sd, sl, x0, c["az"], c["bz"], c["ax"], c["bx"], zb)[0] * (sl if d == "fwd" else 1)
+                      + (x0 if d == "fwd" else 0) for sd, sl, x0, zb in orc.pwl_regions(c["kind"], c["param"])]
+            r_cond = np.maximum(np.abs(c["r_" + d]), np.minimum(np.abs(rk[0]), np.abs(rk[1])))
+            close(r, c["r_" + d], dtype, scale=max(1.0, np.nanmax(r_cond)))
+            close(v, c["v_" + d], dtype)
+            a_new, b_new = msg(c["az"], c["bz"], c["ax"], c["bx"])
+            tgt = c["bx"] if d == "fwd" else c["bz"]
+            a_in = c["ax"] if d == "fwd" else c["az"]
+            close_a(a_new, c["a_" + d], a_in, dtype)
+            close_b(b_new, c["b_" + d], r_cond, a_in, c["a_" + d], tgt, dtype)
+
+
 def test_pwl_branch_masks_bit_exact(T, ctx, golden_factors):
     """log_Phi 'x < 30' masks: same comparison on the same f64 operands as the reference."""
     cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)

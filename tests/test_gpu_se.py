@@ -99,3 +99,16 @@ def test_se_two_layer_relu(ctx, golden_se):
             close(recs[it][0][(vid, "fwd")], t[f"fwd:{vid}:a"][it], rtol=1e-5)
             close(recs[it][0][(vid, "bwd")], t[f"bwd:{vid}:a"][it], rtol=1e-5)
             close(recs[it][1][vid]["v"], t[f"v:{vid}"][it], rtol=1e-5)
+
+
+def test_se_pwl2_channels(ctx, golden_se):
+    "LeakyRelu / AsymmetricAbs SE errors (generic two-half-line quadrature)"
+    import tramp_amd as T
+    if "pwl2" not in golden_se:
+        pytest.skip("goldens not regenerated")
+    for c in golden_se["pwl2"]:
+        ch = (T.LeakyReluChannel(slope=c["param"], ctx=ctx) if c["kind"] == "l-relu"
+              else T.AsymmetricAbsChannel(shift=c["param"], ctx=ctx))
+        close(ch.compute_forward_error(c["az"], c["ax"], c["tau_z"]), c["v_fwd"])
+        close(ch.compute_backward_error(c["az"], c["ax"], c["tau_z"]), c["v_bwd"])
+        close(ch.second_moment(c["tau_z"]), c["tau_x"], rtol=1e-10)

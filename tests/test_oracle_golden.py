@@ -117,6 +117,20 @@ def test_pwl_channels(golden_factors):
                 np.testing.assert_allclose(b, c["b_" + d], rtol=RT, equal_nan=True)
 
 
+def test_pwl2_channels(golden_factors):
+    "LeakyRelu / AsymmetricAbs (generic two-half-line form)"
+    for c in golden_factors["pwl2"]:
+        with np.errstate(all="ignore"):
+            for d in ("fwd", "bwd"):
+                r, v = orc.pwl_channel_posterior(c["kind"], d, c["az"], c["bz"], c["ax"], c["bx"], param=c["param"])
+                a, b = orc.pwl_channel_message(c["kind"], d, c["az"], c["bz"], c["ax"], c["bx"], param=c["param"])
+                np.testing.assert_allclose(r, c["r_" + d], rtol=RT, equal_nan=True)
+                np.testing.assert_allclose(v, c["v_" + d], rtol=RT, equal_nan=True)
+                np.testing.assert_allclose(a, c["a_" + d], rtol=RT, equal_nan=True)
+                np.testing.assert_allclose(b, c["b_" + d], rtol=RT, equal_nan=True)
+        close(orc.pwl_second_moment(c["kind"], 1.7, c["param"]), c["tau_x"], rtol=1e-12)
+
+
 def test_log_Phi_mask(golden_factors):
     c = golden_factors["log_Phi"]
     close(orc.log_Phi(c["x"]), c["y"])
@@ -277,6 +291,13 @@ def test_se_2d_rows_gl(golden_se):
         close(orc.pwl_second_moment(c["kind"], c["tau_z"]), c["tau_x"], rtol=1e-12)
     for c in golden_se["abs_lik"]:
         close(orc.se_abs_lik_error(c["az"], c["tau_z"], "gl"), c["v"], rtol=1e-6)
+    for c in golden_se.get("pwl2", []):
+        with np.errstate(all="ignore"):
+            vf = orc.se_pwl_channel_error(c["kind"], "fwd", c["az"], c["ax"], c["tau_z"], "gl", c["param"])
+            vb = orc.se_pwl_channel_error(c["kind"], "bwd", c["az"], c["ax"], c["tau_z"], "gl", c["param"])
+        close(vf, c["v_fwd"], rtol=1e-6, atol=1e-8)
+        close(vb, c["v_bwd"], rtol=1e-6, atol=1e-8)
+        close(orc.pwl_second_moment(c["kind"], c["tau_z"], c["param"]), c["tau_x"], rtol=1e-12)
 
 
 @pytest.mark.slow

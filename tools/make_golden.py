@@ -56,7 +56,8 @@ sys.path.insert(0, REF)
 from tramp.priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior  # noqa: E402
 from tramp.likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood  # noqa: E402
 from tramp.channels import (  # noqa: E402
-    LinearChannel, SgnChannel, AbsChannel, ReluChannel, MarchenkoPasturChannel
+    LinearChannel, SgnChannel, AbsChannel, ReluChannel, MarchenkoPasturChannel,
+    LeakyReluChannel, AsymmetricAbsChannel
 )
 from tramp.variables import SISOVariable as V  # noqa: E402
 from tramp.algos import ExpectationPropagation, StateEvolution, EarlyStoppingEP  # noqa: E402
@@ -217,6 +218,31 @@ def factor_goldens():
                                   r_fwd=rf, v_fwd=vf, a_fwd=af, b_fwd=bf,
                                   r_bwd=rb, v_bwd=vb, a_bwd=ab, b_bwd=bb))
     out["pwl"] = pwl_cases
+
+    # --- section 8f rank 2: the other two-half-line channels (generic K7 form)
+    pwl2_cases = []
+    for kind, param, ch in [("l-relu", 0.1, LeakyReluChannel(slope=0.1)), ("l-relu", 0.5, LeakyReluChannel(slope=0.5)),
+                            ("a-abs", 1e-4, AsymmetricAbsChannel(shift=1e-4)),
+                            ("a-abs", 0.3, AsymmetricAbsChannel(shift=0.3))]:
+        xk = ch.sample(z)
+        bxk = message_law(rs, 0.7, xk)
+        for (az, bz, ax, bx) in [
+            (1.3, kat_b, 0.7, kat_bx),
+            (1.3, bz_rand, 0.7, bxk),
+            (1.3, bz_rand, 0., np.zeros(N)),
+            (0.05, bz_rand * .05, 12.0, bxk * 15),
+            (2.0, bz_pe, 1.5, bx_pe),
+            (2.0, rec_bz, 1.5, rec_bx),
+        ]:
+            with np.errstate(all="ignore"):
+                rf, vf = ch.compute_forward_posterior(az, bz, ax, bx)
+                af, bf = ch.compute_forward_message(az, bz, ax, bx)
+                rb, vb = ch.compute_backward_posterior(az, bz, ax, bx)
+                ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+            pwl2_cases.append(dict(kind=kind, param=param, az=float(az), bz=bz, ax=float(ax), bx=bx,
+                                   r_fwd=rf, v_fwd=vf, a_fwd=af, b_fwd=bf,
+                                   r_bwd=rb, v_bwd=vb, a_bwd=ab, b_bwd=bb, tau_x=ch.second_moment(1.7)))
+    out["pwl2"] = pwl2_cases
 
     # --- log_Phi mask
     xs = np.array([-1e3, -40., -5., -1., 0., 1., 5., 10., 29.9, np.nextafter(30, 0), 30.,
@@ -459,6 +485,17 @@ def se_goldens(skip_slow):
                                tau_x=ch.second_moment(tau_z)))
                 print("se pwl", kind, az, ax, tau_z, vf, vb, f"{time.time()-t0:.0f}s")
         out["pwl"] = pw
+        pw2 = []
+        for kind, param, ch in [("l-relu", 0.1, LeakyReluChannel(slope=0.1)),
+                                ("a-abs", 0.3, AsymmetricAbsChannel(shift=0.3))]:
+            for (az, ax, tau_z) in recs[:4]:
+                with np.errstate(all="ignore"):
+                    vf = ch.compute_forward_error(az, ax, tau_z)
+                    vb = ch.compute_backward_error(az, ax, tau_z)
+                pw2.append(dict(kind=kind, param=param, az=az, ax=ax, tau_z=tau_z, v_fwd=vf, v_bwd=vb,
+                                tau_x=ch.second_moment(tau_z)))
+                print("se pwl2", kind, az, ax, tau_z, vf, vb, f"{time.time()-t0:.0f}s")
+        out["pwl2"] = pw2
         # two-layer relu SE, a few iterations (13 s / iteration in the reference)
         model = (GaussianPrior(size=None) @ V(id="x") @ MarchenkoPasturChannel(alpha=2.0)
                  @ V(id="z1") @ ReluChannel() @ V(id="a1")

@@ -13,6 +13,7 @@ from .device import Context, DeviceArray, default_context
 from .priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior, get_prior
 from .likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood, get_likelihood
 from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
+                       LeakyReluChannel, AsymmetricAbsChannel,
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
 from .variables import SISOVariable, SILeafVariable
 from .models import Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution

@@ -164,6 +164,90 @@ class ReluChannel(PiecewiseLinearChannel):
     _f = staticmethod(lambda z: np.maximum(0, z))
 
 
+class TwoHalfLineChannel(PiecewiseLinearChannel):
+    """Generic K7: z in [zcut, inf) -> x0_pos + slope_pos z, z in (-inf, zcut] -> x0_neg + slope_neg z
+    (the remaining two-region members of the piecewise-linear family)."""
+    _spec = (1.0, 1.0, 0.0, 0.0, 0.0)     # slope_pos, slope_neg, x0_pos, x0_neg, zcut
+
+    def __init__(self, dtype=np.float64, ctx=None):
+        self.repr_init()
+        self._init_device(dtype, ctx)
+
+    def sample(self, Z):
+        sp, sn, xp, xn, zc = self._spec
+        return np.where(Z >= zc, xp + sp * Z, xn + sn * Z)
+
+    def second_moment(self, tau_z):
+        "piecewise_linear_channel.py:21-25: sum_k p_k (rx_k^2 + vx_k) for z ~ N(0, tau_z)"
+        from math import erfc, exp, pi, sqrt
+        sp, sn, xp, xn, zc = self._spec
+        s0 = sqrt(tau_z)
+        y = zc / s0
+        pdf = exp(-0.5 * y * y) / sqrt(2 * pi)
+        p_pos = 0.5 * erfc(y / sqrt(2))
+        p_neg = 1.0 - p_pos
+        tot = 0.0
+        for p, sgn, slope, x0 in ((p_pos, +1, sp, xp), (p_neg, -1, sn, xn)):
+            if p <= 0:
+                continue
+            lam = sgn * pdf / p                       # E[z]/s0 of the truncated standard normal
+            mean = s0 * lam
+            var = tau_z * (1 + y * lam - lam * lam)
+            tot += p * ((slope * mean + x0)**2 + slope * slope * var)
+        return tot
+
+    def _run(self, direction, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+             old_b=None, want_posterior=False, want_mask=False):
+        ctx = self.ctx
+        z = VecArg(ctx, bz, self.dtype)
+        x = VecArg(ctx, bx, self.dtype)
+        if (z.batch, z.n) != (x.batch, x.n):
+            raise ValueError(f"bz {z.dev.shape} and bx {x.dev.shape} must have the same shape")
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((z.batch, z.n), self.dtype)
+        r = ctx.empty((z.batch, z.n), self.dtype) if want_posterior else None
+        v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        mask = ctx.empty((z.batch, z.n), np.uint8) if want_mask else None
+        ctx._call("tramp_pwl2_channel", self._dt, direction, z.n, z.batch, *[float(p) for p in self._spec],
+                  a_z.dev.ptr, z.dev.ptr, a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
+                  old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
+                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
+                  v.ptr if v is not None else None, mask.ptr if mask is not None else None)
+        tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
+        return tgt, a_t, a_new, b_new, r, v, mask
+
+    def _se(self, direction, az, ax, tau_z):
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        ax_h = np.broadcast_to(np.asarray(ax, dtype=np.float64), az_h.shape).copy()
+        tz_h = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_pwl2_channel", direction, az_h.shape[0], *[float(p) for p in self._spec],
+                       az_h.ctypes.data, ax_h.ctypes.data, tz_h.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+
+class LeakyReluChannel(TwoHalfLineChannel):
+    "tramp/channels/activation/piecewise_linear_channel.py:72-77"
+
+    def __init__(self, slope, dtype=np.float64, ctx=None):
+        self.slope = slope
+        self.name = "l-relu"
+        self._spec = (1.0, float(slope), 0.0, 0.0, 0.0)
+        super().__init__(dtype, ctx)
+
+
+class AsymmetricAbsChannel(TwoHalfLineChannel):
+    "tramp/channels/activation/piecewise_linear_channel.py:94-99"
+
+    def __init__(self, shift=1e-4, dtype=np.float64, ctx=None):
+        self.shift = shift
+        self.name = "a-abs"
+        self._spec = (1.0, -1.0, 0.0, 0.0, float(shift))
+        super().__init__(dtype, ctx)
+
+
 # ------------------------------------------------------------------ dense linear
 def thin_svd_host(W):
     """Thin SVD on the host (LAPACK), the factorisation LinearChannel.__init__ computes
@@ -397,6 +481,8 @@ CHANNEL_CLASSES = {
     "sgn": SgnChannel,
     "abs": AbsChannel,
     "relu": ReluChannel,
+    "l-relu": LeakyReluChannel,
+    "a-abs": AsymmetricAbsChannel,
 }
 
 

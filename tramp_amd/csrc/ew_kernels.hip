@@ -110,11 +110,12 @@ template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 
     static constexpr int TARGET = FWD ? 1 : 0;
     const double* az;
     const double* ax;
+    tmath::PwlSpec spec;          // used by KIND 3 only
     tmath::PwlConst<T> c;
     double a_msg;
     __device__ void setup(size_t b) {
         const double z = az[b], x = ax[b];
-        c = tmath::pwl_const<T, KIND>(z, x);
+        c = tmath::pwl_const<T, KIND>(z, x, spec);
         a_msg = FWD ? x : z;
     }
     __device__ EwOut<T> eval(T x0, T x1) const {
@@ -484,12 +485,13 @@ extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
 
 template <typename T, int KIND>
 static int pwl_dir(tramp_ctx* ctx, int dir, size_t n, size_t batch, const double* az_d,
-                   const void* bz_d, const double* ax_d, const void* bx_d, const MsgOut& out) {
+                   const void* bz_d, const double* ax_d, const void* bx_d, const MsgOut& out,
+                   const tmath::PwlSpec& spec = tmath::PwlSpec{}) {
     if (dir == TRAMP_FWD) {
-        PwlOp<T, KIND, true> op{az_d, ax_d};
+        PwlOp<T, KIND, true> op{az_d, ax_d, spec};
         return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, ax_d, out);
     }
-    PwlOp<T, KIND, false> op{az_d, ax_d};
+    PwlOp<T, KIND, false> op{az_d, ax_d, spec};
     return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, az_d, out);
 }
 
@@ -516,6 +518,22 @@ extern "C" int tramp_pwl_channel(tramp_ctx* ctx, int dtype, int kind, int dir, s
     DISPATCH_DTYPE(ctx, dtype,
                    (pwl_kind<float>(ctx, kind, dir, n, batch, az_d, bz_d, ax_d, bx_d, out)),
                    (pwl_kind<double>(ctx, kind, dir, n, batch, az_d, bz_d, ax_d, bx_d, out)));
+}
+
+extern "C" int tramp_pwl2_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batch,
+                                  double slope_pos, double slope_neg, double x0_pos, double x0_neg,
+                                  double zcut, const double* az_d, const void* bz_d, const double* ax_d,
+                                  const void* bx_d, double damping, const double* a_old_d,
+                                  const void* b_old_d, double* a_new_d, void* b_new_d, void* r_d,
+                                  double* v_d, uint8_t* mask_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && ax_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, mask_d};
+    tmath::PwlSpec spec{{slope_pos, slope_neg}, {x0_pos, x0_neg}, zcut};
+    DISPATCH_DTYPE(ctx, dtype,
+                   (pwl_dir<float, 3>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)),
+                   (pwl_dir<double, 3>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)));
 }
 
 // ---------------------------------------------------------------- K3 / K6 constant messages

@@ -117,15 +117,18 @@ struct Se2dParams {
     const double* az;
     const double* ax;
     const double* tau;
+    tmath::PwlSpec spec;     // KIND 4 (generic two-half-line channel) only
 };
 
 template <int KIND, bool FWD>
-__device__ __forceinline__ double pwl_integrand(double x1, double x2, double az, double ax, double tau) {
+__device__ __forceinline__ double pwl_integrand(double x1, double x2, double az, double ax, double tau,
+                                                const tmath::PwlSpec& spec) {
     const double u_eff = fmax(0.0, az * tau - 1.0);
     double total = 0.0;
+    const tmath::PwlSpec sp = tmath::pwl_spec_of<(KIND == 4 ? 3 : KIND)>(spec);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const double slope = tmath::pwl_slope(KIND, k), x0 = tmath::pwl_x0(KIND, k);
+        const double slope = sp.slope[k], x0 = sp.x0[k];
         const int side = k == 0 ? +1 : -1;
         const double mean_x = ax * x0;
         const double sx2 = ax * (slope * slope * ax * tau + 1.0);
@@ -142,9 +145,9 @@ __device__ __forceinline__ double pwl_integrand(double x1, double x2, double az,
         // LinearRegion.proba_ab (linear_region.py:78-81)
         const double a = az + slope * slope * ax;
         const double b = bz + slope * (bx - ax * x0);
-        const double y0 = (0 - b / a) / sqrt(1.0 / a);
+        const double y0 = (sp.zb - b / a) / sqrt(1.0 / a);
         const double p = side > 0 ? 1.0 - norm_cdf(y0) : norm_cdf(y0);
-        tmath::PwlOut<double> o = tmath::pwl_posterior<double, KIND, FWD>(bz, bx, az, ax);
+        tmath::PwlOut<double> o = tmath::pwl_posterior_spec<double, FWD>(bz, bx, az, ax, sp);
         total += p * o.v;
     }
     return total;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void se_2d_kernel(Se2dParams P, const doubl
             const double x2 = xs[j];
             double f;
             if (KIND == 3) f = abs_lik_integrand(x1, x2, az, tau);
-            else f = pwl_integrand<(KIND == 3 ? 0 : KIND), FWD>(x1, x2, az, ax, tau);
+            else f = pwl_integrand<(KIND == 3 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
             row += ws[j] * f;
         }
         acc += w1 * row;
@@ -276,7 +279,7 @@ static int panels2d() {
 
 template <int KIND, bool FWD>
 static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const double* ax, const double* tau,
-                     double* v) {
+                     double* v, const tmath::PwlSpec& spec = tmath::PwlSpec{}) {
     const int panels = panels2d();
     const int n = panels * 8;
     const int strip = 8;
@@ -288,7 +291,7 @@ static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const doubl
     double* nodes = extra;
     double* partials = extra + 2 * (size_t)n;
     hipLaunchKernelGGL(se_nodes_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, panels, nodes);
-    Se2dParams P{din[0], din[1], din[2]};
+    Se2dParams P{din[0], din[1], din[2], spec};
     hipLaunchKernelGGL((se_2d_kernel<KIND, FWD>), dim3(nstrips, (unsigned)count), dim3(kBlock), 0, ctx->stream, P, nodes,
                        n, strip, partials);
     hipLaunchKernelGGL(se_fold_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, partials, nstrips, dout);
@@ -317,4 +320,17 @@ extern "C" int tramp_se_pwl_channel(tramp_ctx* ctx, int kind, int dir, size_t co
         case TRAMP_RELU: return f ? se_2d_run<2, true>(ctx, count, az, ax, tau_z, v) : se_2d_run<2, false>(ctx, count, az, ax, tau_z, v);
     }
     return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "kind");
+}
+
+extern "C" int tramp_se_pwl2_channel(tramp_ctx* ctx, int dir, size_t count, double slope_pos, double slope_neg,
+                                     double x0_pos, double x0_neg, double zcut, const double* az,
+                                     const double* ax, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && ax && tau_z && v);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] > 0.0 && ax[i] >= 0.0 && tau_z[i] > 0.0);
+    tmath::PwlSpec spec{{slope_pos, slope_neg}, {x0_pos, x0_neg}, zcut};
+    return dir == TRAMP_FWD ? se_2d_run<4, true>(ctx, count, az, ax, tau_z, v, spec)
+                            : se_2d_run<4, false>(ctx, count, az, ax, tau_z, v, spec);
 }

@@ -177,9 +177,10 @@ template <typename T> TM_HD RegionConst<T> region_const(double a) {
     return c;
 }
 
-template <typename T, bool LOGP> TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0) {
+template <typename T, bool LOGP>
+TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0, T zb = T(0)) {
     r0 = b / c.a;                              // exact: mask operand
-    T y0 = (T(0) - r0) / c.s0;                 // exact: mask operand
+    T y0 = (zb - r0) / c.s0;                   // exact: mask operand (zb = 0 for Sgn/Abs/Relu)
     T sd = T(side);
     T x = sd * (y0 * T(0.70710678118654752440));
     T e = erfcx_(x);
@@ -240,7 +241,59 @@ TM_HD constexpr double pwl_x0(int kind, int k) {
     return kind == 0 ? (k == 0 ? 1.0 : -1.0) : 0.0;
 }
 
+struct PwlSpec { double slope[2], x0[2], zb; };
+
 template <typename T> struct PwlOut { T r, v; unsigned mask; };
+
+// Half line with an arbitrary boundary zb (truncated_normal_mean/_var/_log_proba with
+// zmin = zb, zmax = inf resp. zmin = -inf, zmax = zb).
+template <typename T> TM_HD HalfLine<T> halfline_at(T r0, T v0, int side, T zb) {
+    T s0 = sqrt_(v0);
+    T y0 = (zb - r0) / s0;
+    T x = y0 / T(kSqrt2);
+    T sd = T(side);
+    T e = erfcx_(sd * x);
+    T g1 = T(kSqrt2OverPi) * (sd / e);
+    T g2 = T(kTwoOverSqrtPi) * (sd * x / e);
+    HalfLine<T> h;
+    h.mean = r0 + s0 * g1;
+    h.var = v0 * (T(1) + g2 - g1 * g1);
+    T u = -sd * y0;
+    h.mask = u < LogPhiCut<T>::value;
+    h.logp = h.mask ? (log_(T(0.5) * e) - T(0.5) * (u * u)) : T(0);
+    return h;
+}
+
+// Literal restatement for an arbitrary two-half-line spec (the SE quadratures use it).
+template <typename T, bool FWD>
+TM_HD PwlOut<T> pwl_posterior_spec(T bz, T bx, T az, T ax, const PwlSpec& sp) {
+    T rs[2], vs[2], As[2];
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const T slope = T(sp.slope[k]), x0 = T(sp.x0[k]);
+        const int side = (k == 0) ? +1 : -1;
+        T a = az + slope * slope * ax;
+        T b = bz + slope * (bx - ax * x0);
+        T r0 = b / a, v0 = T(1) / a;
+        HalfLine<T> h = halfline_at<T>(r0, v0, side, T(sp.zb));
+        As[k] = T(0.5) * log_(T(2 * kPi) * v0) + T(0.5) * (r0 * r0) / v0 + h.logp
+                - T(0.5) * ax * (x0 * x0) + bx * x0;
+        rs[k] = FWD ? slope * h.mean + x0 : h.mean;
+        vs[k] = FWD ? slope * slope * h.var : h.var;
+        mask |= (h.mask ? 1u : 0u) << k;
+    }
+    T m = fmax_(As[0], As[1]);
+    T e0 = exp_(As[0] - m), e1 = exp_(As[1] - m);
+    T se = e0 + e1;
+    T p0 = e0 / se, p1 = e1 / se;
+    PwlOut<T> o;
+    o.r = p0 * rs[0] + p1 * rs[1];
+    T d = rs[0] - rs[1];
+    o.v = p0 * vs[0] + p1 * vs[1] + p0 * p1 * (d * d);
+    o.mask = mask;
+    return o;
+}
 
 // FWD: posterior of x = f(z) (a = ax side); BWD: posterior of z.
 template <typename T, int KIND, bool FWD>
@@ -283,16 +336,31 @@ TM_HD PwlOut<T> pwl_posterior(T bz, T bx, T az, T ax) {
 
 // Hoisted form used by the streaming kernels: RegionConst per region (a, 1/a, sqrt(1/a),
 // 0.5 log(2 pi v0)) computed once per instance.
-template <typename T> struct PwlConst { RegionConst<T> reg[2]; T az, ax; };
+// KIND 3 = generic pair of half-line regions [zb, inf) and (-inf, zb] with run-time slopes and
+// offsets: LeakyReluChannel (slopes 1 / s, zb = 0; piecewise_linear_channel.py:72-77) and
+// AsymmetricAbsChannel (slopes +1 / -1, zb = shift; :94-99).
+template <typename T> struct PwlConst { RegionConst<T> reg[2]; T az, ax; T slope[2], x0[2], zb; };
 
-template <typename T, int KIND> TM_HD PwlConst<T> pwl_const(double az, double ax) {
+template <int KIND> TM_HD PwlSpec pwl_spec_of(const PwlSpec& rt) {
+    if (KIND == 3) return rt;
+    PwlSpec s;
+    s.slope[0] = pwl_slope(KIND, 0); s.slope[1] = pwl_slope(KIND, 1);
+    s.x0[0] = pwl_x0(KIND, 0); s.x0[1] = pwl_x0(KIND, 1);
+    s.zb = 0.0;
+    return s;
+}
+
+template <typename T, int KIND> TM_HD PwlConst<T> pwl_const(double az, double ax, const PwlSpec& rt = PwlSpec{}) {
     PwlConst<T> c;
     c.az = T(az);
     c.ax = T(ax);
+    const PwlSpec sp = pwl_spec_of<KIND>(rt);
+    c.zb = T(sp.zb);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const T slope = T(pwl_slope(KIND, k));
-        c.reg[k] = region_const<T>((double)(c.az + slope * slope * c.ax));
+        c.slope[k] = T(sp.slope[k]);
+        c.x0[k] = T(sp.x0[k]);
+        c.reg[k] = region_const<T>((double)(c.az + c.slope[k] * c.slope[k] * c.ax));
     }
     return c;
 }
@@ -303,12 +371,13 @@ TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
     unsigned mask = 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const T slope = T(pwl_slope(KIND, k));
-        const T x0 = T(pwl_x0(KIND, k));
+        // compile-time constants for Sgn/Abs/Relu (folds the 0 / 1 slopes away), run-time for KIND 3
+        const T slope = KIND < 3 ? T(pwl_slope(KIND < 3 ? KIND : 0, k)) : c.slope[k];
+        const T x0 = KIND < 3 ? T(pwl_x0(KIND < 3 ? KIND : 0, k)) : c.x0[k];
         const int side = (k == 0) ? +1 : -1;
         T b = bz + slope * (bx - c.ax * x0);
         T r0;
-        HalfLine<T> h = halfline_fast<T, true>(b, c.reg[k], side, r0);
+        HalfLine<T> h = halfline_fast<T, true>(b, c.reg[k], side, r0, KIND < 3 ? T(0) : c.zb);
         // 0.5 r0^2 / v0 = 0.5 r0^2 a
         As[k] = c.reg[k].half_log2piv0 + T(0.5) * (r0 * r0) * c.reg[k].a + h.logp
                 - T(0.5) * c.ax * (x0 * x0) + bx * x0;
