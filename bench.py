@@ -213,13 +213,16 @@ def main():
         # measured HBM traffic of the dominant kernel at this shape, if a PMC profile of it is committed.
         # the dominant tag mixes the Vt pass (k x N) and the Uk pass (M x k); the profile covers the Vt shape.
         traffic = None
+        traffic_detail = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))["entries"]
             key = f"{dom}:{args.dtype}:R{M}:C{N}:B{B}"
             if key in tj:
-                traffic = {"hbm_bytes_per_launch": tj[key]["hbm_bytes_per_launch"],
-                           "algorithmic_bytes_per_launch": tj[key]["algorithmic_bytes"],
-                           "shape": f"{M}x{N} pass", "source": "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"}
+                traffic = tj[key]["hbm_bytes_per_launch"]
+                traffic_detail = {"algorithmic_bytes_per_launch": tj[key]["algorithmic_bytes"],
+                                  "shape": f"{M}x{N} pass of the dominant kernel",
+                                  "source": "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                            "passes, FETCH_SIZE doubled per the gfx950 correction)"}
         except Exception:
             traffic = None
         use_mfma = B > 16 and dom.startswith("matvec")     # batch <= 16 streams at the HBM rate
@@ -227,13 +230,15 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": traffic,
+                    "traffic_detail": traffic_detail,
                     "peak_measured_issue_rate": MFMA_MEASURED_TFLOPS[args.dtype],
                     "avg_launch_ms": d["ms"] / d["launches"], "launches": d["launches"],
                     "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": d["ms"] / d["launches"],
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
+                    "avg_launch_ms": d["ms"] / d["launches"],
                     "launches": d["launches"]}
         out = {
             "metric": "EP iterations/sec x N x instances (msg-components/sec), sparse GLM, alpha=0.5",

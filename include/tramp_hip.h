@@ -172,6 +172,15 @@ int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
                       double damping, const double* a_old_d, const void* b_old_d,
                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
 
+/* ReluLikelihood (slope_neg = 0) / LeakyReluLikelihood (slope_neg = s > 0): SURVEY section 8f rank 2
+ *     tramp/likelihoods/piecewise_linear_likelihood.py:9-63,201-215,279-291.
+ * y > 0 pins z = y (variance 0); Relu with y == 0: truncated normal on (-inf, 0];
+ * Leaky with y < 0: z = y / s.  An observation no region contains yields NaN, as the reference. */
+int tramp_relu_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double slope_neg,
+                       const double* az_d, const void* bz_d, const void* y_d,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
 /* ---- componentwise channels ---------------------------------------------- */
 /* K7. PiecewiseLinearChannel.compute_forward/backward_posterior + Channel message
  *     tramp/channels/activation/piecewise_linear_channel.py:27-53 (regions :80-106),
@@ -302,6 +311,8 @@ int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
  *      mirroring the reference's AssertionError). */
 int tramp_se_sgn_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
 int tramp_se_abs_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
+/* ReluLikelihood SE error (only the flat region has a variance; 1-D quadrature). */
+int tramp_se_relu_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
 /* K14. Channel.compute_forward_error / compute_backward_error for Sgn/Abs/Relu channels
  *      tramp/channels/base_channel.py:29-41, piecewise_linear_channel.py:60-64,
  *      tramp/utils/linear_region.py:78-101, tramp/utils/integration.py:31-73. */

@@ -258,6 +258,61 @@ def abs_lik_message(az, bz, y, isotropic=True):
 
 
 # --------------------------------------------------------------------------
+# section 8f rank 2: (Leaky)Relu likelihood
+#   tramp/likelihoods/piecewise_linear_likelihood.py:9-63 (LinearRegionLikelihood),
+#   :201-215 (compute_backward_posterior), :279-291 (region tables)
+# --------------------------------------------------------------------------
+def relu_lik_posterior(az, bz, y, slope_neg=0., isotropic=True):
+    """Restates the reference region by region: a sloped region pins z = (y - x0)/slope when
+    that z is strictly inside it (log-partition -inf otherwise); the flat region of Relu holds
+    a truncated normal when y == x0 = 0; softmax of the log-partitions mixes them."""
+    bz = np.asarray(bz, dtype=float)
+    y = np.asarray(y, dtype=float)
+    rs, vs, As = [], [], []
+    for side, slope in ((+1, 1.), (-1, float(slope_neg))):
+        if slope == 0:
+            contains = (y == 0.)
+            m, v, logp = halfline_moments(bz / az, 1 / az, side)
+            r_k, v_k = m, v
+            A_k = 0.5 * np.log(2 * np.pi / az) + 0.5 * (bz / az)**2 * az + logp
+        else:
+            z = y / slope
+            contains = (z > 0) if side > 0 else (z < 0)
+            r_k, v_k = z, np.zeros_like(z)
+            A_k = -0.5 * az * (z**2) + bz * z - np.log(slope)
+        rs.append(np.where(contains, r_k, 0))
+        vs.append(np.where(contains, v_k, 0))
+        As.append(np.where(contains, A_k, -np.inf))
+    A = np.stack(As)
+    with np.errstate(invalid="ignore"):
+        e = np.exp(A - A.max(axis=0, keepdims=True))
+        ps = e / e.sum(axis=0, keepdims=True)
+    r = ps[0] * rs[0] + ps[1] * rs[1]
+    v = ps[0] * vs[0] + ps[1] * vs[1] + ps[0] * ps[1] * (rs[0] - rs[1])**2
+    if isotropic:
+        v = v.mean()
+    return r, v
+
+
+def relu_lik_message(az, bz, y, slope_neg=0.):
+    r, v = relu_lik_posterior(az, bz, y, slope_neg)
+    return ab_new(r, v, az, bz)
+
+
+def se_relu_lik_error(az, tau_z, method="quadpack"):
+    "piecewise_linear_likelihood.py:120-146 for Relu: the sloped region has zero variance"
+    mz_hat = az - 1 / tau_z
+    assert mz_hat > 0
+    sz_eff = np.sqrt(mz_hat + (mz_hat**2) * tau_z)
+
+    def g(bz):
+        bz = np.asarray(bz, dtype=float)
+        _, v, _ = halfline_moments(bz / az, 1 / az, -1)
+        return halfline_proba(bz / az, 1 / az, -1) * v
+    return gaussian_measure(0, sz_eff, g, method)
+
+
+# --------------------------------------------------------------------------
 # A8  Piecewise-linear channels (Sgn / Abs / Relu)
 #   tramp/channels/activation/piecewise_linear_channel.py:27-53,80-106
 #   tramp/utils/linear_region.py:32-64

@@ -239,3 +239,31 @@ def test_ensemble_per_instance_stopping(ctx):
         close(d["x"]["r"][b], res["r"][0], 1e-6)
         close(d["x"]["v"][b], res["v"][0], 1e-6)
     assert ep.n_iter == max(n_iters) and len(set(n_iters)) > 1
+
+
+def test_ep_agrees_with_state_evolution_at_large_n(ctx):
+    """Size-independent property at a size the CPU oracle cannot reach (reference:
+    tramp/checks/check_high_dim.py): for a Gaussian-ensemble sparse GLM, EP's posterior variance,
+    the empirical mse and the state-evolution fixed point coincide up to O(1/sqrt(N))."""
+    import tramp_amd as T
+    N, alpha, rho, nv, B = 16384, 0.5, 0.05, 1e-2, 8
+    M = int(alpha * N)
+    W = ctx.randn((M, N), np.float64, seed=77, scale=N ** -0.5)
+    rs = np.random.RandomState(5)
+    X = rs.standard_normal((B, N)) * rs.binomial(1, rho, (B, N))
+    Z = ctx.empty((B, M))
+    ctx._call("tramp_matvec_nt", T.device.dtype_code(np.float64), 0, M, N, B, W.ptr, ctx.array(X).ptr, Z.ptr)
+    Y = Z.get() + np.sqrt(nv) * rs.standard_normal((B, M))
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, ctx=ctx, svd="device") @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=200, damping=0.1)
+    assert ep.n_iter < 100
+    v_ep = np.asarray(ep.get_variables_data(want_r=False)["x"]["v"])
+    mse = np.asarray(ep.mse("x", X))
+    se_model = T.glm_state_evolution(alpha=alpha, prior_type="gauss_bernoulli", output_type="gaussian",
+                                     prior_rho=rho, output_var=nv)
+    se = T.StateEvolution(se_model).iterate(max_iter=200)
+    v_se = se.get_variables_data()["x"]["v"]
+    assert np.all(np.abs(v_ep - v_se) < 0.15 * v_se), (v_ep, v_se)
+    assert np.all(np.abs(mse - v_se) < 0.25 * v_se), (mse, v_se)

@@ -134,6 +134,21 @@ def test_sgn_abs_likelihood(T, ctx, golden_factors, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_relu_likelihoods(T, ctx, golden_factors, dtype):
+    for c in golden_factors["relu_lik"]:
+        lk = (T.ReluLikelihood(y=c["y"], dtype=dtype, ctx=ctx) if c["slope"] == 0
+              else T.LeakyReluLikelihood(slope=c["slope"], y=c["y"], dtype=dtype, ctx=ctx))
+        r, v = lk.compute_backward_posterior(c["az"], c["bz"], c["y"])
+        close(r, c["r"], dtype, scale=max(1.0, np.abs(c["r"]).max())); close(v, c["v"], dtype, atol=1e-300)
+        a_new, b_new = lk.compute_backward_message(c["az"], c["bz"])
+        close_a(a_new, c["a_new"], c["az"], dtype)
+        close_b(b_new, c["b_new"], c["r"], c["az"], c["a_new"], c["bz"], dtype)
+    # an observation no region contains poisons the message, as the reference (softmax of -inf, -inf)
+    a_new, _ = T.ReluLikelihood(y=np.array([1.0, -0.5, 0.0]), ctx=ctx).compute_backward_message(1.0, np.zeros(3))
+    assert np.isnan(a_new)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_pwl_channels(T, ctx, golden_factors, dtype):
     cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)
     for c in golden_factors["pwl"]:

@@ -112,3 +112,13 @@ def test_se_pwl2_channels(ctx, golden_se):
         close(ch.compute_forward_error(c["az"], c["ax"], c["tau_z"]), c["v_fwd"])
         close(ch.compute_backward_error(c["az"], c["ax"], c["tau_z"]), c["v_bwd"])
         close(ch.second_moment(c["tau_z"]), c["tau_x"], rtol=1e-10)
+
+
+def test_se_relu_likelihood(ctx, golden_se):
+    import tramp_amd as T
+    if "relu_lik" not in golden_se:
+        pytest.skip("goldens not regenerated")
+    lk = T.ReluLikelihood(y=None, ctx=ctx)
+    for c in golden_se["relu_lik"]:
+        close(lk.compute_backward_error(c["az"], c["tau_z"]), c["v"])
+    assert T.LeakyReluLikelihood(slope=0.2, y=None, ctx=ctx).compute_backward_error(2.0, 1.0) == 0.0

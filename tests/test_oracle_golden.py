@@ -131,6 +131,17 @@ def test_pwl2_channels(golden_factors):
         close(orc.pwl_second_moment(c["kind"], 1.7, c["param"]), c["tau_x"], rtol=1e-12)
 
 
+def test_relu_likelihoods(golden_factors):
+    for c in golden_factors["relu_lik"]:
+        with np.errstate(all="ignore"):
+            r, v = orc.relu_lik_posterior(c["az"], c["bz"], c["y"], c["slope"])
+            a, b = orc.relu_lik_message(c["az"], c["bz"], c["y"], c["slope"])
+        np.testing.assert_allclose(r, c["r"], rtol=RT, equal_nan=True)
+        np.testing.assert_allclose(v, c["v"], rtol=RT, equal_nan=True)
+        np.testing.assert_allclose(a, c["a_new"], rtol=RT, equal_nan=True)
+        np.testing.assert_allclose(b, c["b_new"], rtol=1e-10, equal_nan=True)
+
+
 def test_log_Phi_mask(golden_factors):
     c = golden_factors["log_Phi"]
     close(orc.log_Phi(c["x"]), c["y"])
@@ -249,6 +260,9 @@ def test_se_scalar_rows(golden_se):
     for c in golden_se["sgn_lik"]:
         close(orc.se_sgn_lik_error(c["az"], c["tau_z"]), c["v"], rtol=1e-9)
         close(orc.se_sgn_lik_error(c["az"], c["tau_z"], method="gl"), c["v"], rtol=2e-7)
+    for c in golden_se.get("relu_lik", []):
+        close(orc.se_relu_lik_error(c["az"], c["tau_z"]), c["v"], rtol=1e-9)
+        close(orc.se_relu_lik_error(c["az"], c["tau_z"], method="gl"), c["v"], rtol=2e-7)
     for c in golden_se["mp"]:
         mp = orc.MarchenkoPasturOracle(c["alpha"])
         close(mp.mean_spectrum, c["mean_spectrum"], rtol=1e-12)

@@ -55,6 +55,7 @@ sys.path.insert(0, REF)
 
 from tramp.priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior  # noqa: E402
 from tramp.likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood  # noqa: E402
+from tramp.likelihoods import ReluLikelihood, LeakyReluLikelihood  # noqa: E402
 from tramp.channels import (  # noqa: E402
     LinearChannel, SgnChannel, AbsChannel, ReluChannel, MarchenkoPasturChannel,
     LeakyReluChannel, AsymmetricAbsChannel
@@ -244,6 +245,22 @@ def factor_goldens():
                                    r_bwd=rb, v_bwd=vb, a_bwd=ab, b_bwd=bb, tau_x=ch.second_moment(1.7)))
     out["pwl2"] = pwl2_cases
 
+    # --- (Leaky)Relu likelihoods
+    relu_lik = []
+    for slope in (0.0, 0.2):
+        y_obs = np.where(z >= 0, z, slope * z)
+        y_kat = np.array([1.5, 0.7, 2., 0.3, 0.1, 3.]) if slope else np.array([1.5, 0., 2., 0., 0., 3.])
+        if slope:
+            y_kat = y_kat * np.array([1, -1, 1, -1, -1, 1.])
+        for (az, bz, y) in [(1.3, kat_b, y_kat), (1.3, bz_rand, y_obs), (0.05, bz_rand * .1, y_obs),
+                            (40., bz_rand * 30, y_obs)]:
+            lk = ReluLikelihood(y=y) if slope == 0 else LeakyReluLikelihood(slope=slope, y=y)
+            with np.errstate(all="ignore"):
+                r, v = lk.compute_backward_posterior(az, bz, y)
+                an, bn = lk.compute_backward_message(az, bz)
+            relu_lik.append(dict(slope=slope, az=az, bz=bz, y=y, r=r, v=v, a_new=an, b_new=bn))
+    out["relu_lik"] = relu_lik
+
     # --- log_Phi mask
     xs = np.array([-1e3, -40., -5., -1., 0., 1., 5., 10., 29.9, np.nextafter(30, 0), 30.,
                    np.nextafter(30, 31), 31., 100., 1e4])
@@ -429,6 +446,11 @@ def se_goldens(skip_slow):
         sg.append(dict(az=az, tau_z=tau_z, v=lk.compute_backward_error(az, tau_z),
                        a_new=lk.compute_backward_state_evolution(az, tau_z)))
     out["sgn_lik"] = sg
+    rl = []
+    lk = ReluLikelihood(y=None)
+    for (az, tau_z) in ((1.3, 1.0), (3.0, 0.5), (25., 2.0)):
+        rl.append(dict(az=az, tau_z=tau_z, v=lk.compute_backward_error(az, tau_z)))
+    out["relu_lik"] = rl
     mp = []
     for alpha in (0.5, 0.7, 2.0):
         ch = MarchenkoPasturChannel(alpha=alpha)

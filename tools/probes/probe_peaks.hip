@@ -71,6 +71,33 @@ __global__ __launch_bounds__(256) void stream_read(const double2* __restrict__ i
 __global__ __launch_bounds__(256) void stream_copy(const double2* __restrict__ in, double2* __restrict__ o, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = in[i];
 }
+// unrolled copy: each thread moves U independent 16-byte pieces per trip
+template <int U>
+__global__ __launch_bounds__(256) void stream_copy_u(const double2* __restrict__ in, double2* __restrict__ o, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        double2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) o[i + u * stride] = v[u];
+    }
+    for (; i < n; i += stride) o[i] = in[i];
+}
+// block-contiguous variant: a block owns a contiguous 16 KiB tile per trip
+template <int U>
+__global__ __launch_bounds__(256) void stream_copy_tile(const double2* __restrict__ in, double2* __restrict__ o, size_t n) {
+    const size_t tile = 256 * U;
+    for (size_t t = blockIdx.x; t * tile < n; t += gridDim.x) {
+        const size_t base = t * tile + threadIdx.x;
+        double2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (base + u * 256 < n) v[u] = in[base + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (base + u * 256 < n) o[base + u * 256] = v[u];
+    }
+}
 template <typename F> float timeit(F f, int reps) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -110,6 +137,20 @@ int main() {
         printf("stream read  %5d blocks: %.0f GB/s\n", blocks, bytes / ms / 1e6);
         ms = timeit([&] { hipLaunchKernelGGL(stream_copy, dim3(blocks), dim3(256), 0, 0, a, b, n); }, 5);
         printf("stream copy  %5d blocks: %.0f GB/s (read+write)\n", blocks, 2.0 * bytes / ms / 1e6);
+    }
+    for (int blocks : {1024, 2048, 4096, 8192}) {
+        float ms = timeit([&] { hipLaunchKernelGGL(stream_copy_u<4>, dim3(blocks), dim3(256), 0, 0, a, b, n); }, 5);
+        printf("copy unroll4 strided %5d blocks: %.0f GB/s\n", blocks, 2.0 * bytes / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL(stream_copy_u<8>, dim3(blocks), dim3(256), 0, 0, a, b, n); }, 5);
+        printf("copy unroll8 strided %5d blocks: %.0f GB/s\n", blocks, 2.0 * bytes / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL(stream_copy_tile<4>, dim3(blocks), dim3(256), 0, 0, a, b, n); }, 5);
+        printf("copy tile4          %5d blocks: %.0f GB/s\n", blocks, 2.0 * bytes / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL(stream_copy_tile<8>, dim3(blocks), dim3(256), 0, 0, a, b, n); }, 5);
+        printf("copy tile8          %5d blocks: %.0f GB/s\n", blocks, 2.0 * bytes / ms / 1e6);
+    }
+    {
+        float ms = timeit([&] { (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); }, 5);
+        printf("hipMemcpy D2D: %.0f GB/s (read+write)\n", 2.0 * bytes / ms / 1e6);
     }
     return 0;
 }

@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --size $N --steps $STEPS --warmup 2 --no-cpu-baseline"
+ARGS="bench.py --size $N --steps $STEPS --warmup 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
 # counter passes: own runs, kernel-trace only, on the kernels alone (rocSOLVER crashes under --pmc)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_kernels.py $N 64 > $OUT/fetch.out 2> $OUT/fetch.err

@@ -11,7 +11,8 @@ There is no CPU fallback: without the built HIP library the compute methods rais
 from . import _lib
 from .device import Context, DeviceArray, default_context
 from .priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior, get_prior
-from .likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood, get_likelihood
+from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
+                          LeakyReluLikelihood, get_likelihood)
 from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel,
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "tramp_gauss_lik_bwd": [vp, i32, sz, sz, vp, dbl, vp, vp],
     "tramp_sgn_lik_bwd": [vp, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_abs_lik_bwd": [vp, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_relu_lik_bwd": [vp, i32, sz, sz, dbl, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_se_relu_lik": [vp, sz, vp, vp, vp],
     "tramp_pwl_channel": [vp, i32, i32, i32, sz, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, vp],
     "tramp_pwl2_channel": [vp, i32, i32, sz, sz, dbl, dbl, dbl, dbl, dbl, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, vp],
     "tramp_se_pwl2_channel": [vp, i32, sz, dbl, dbl, dbl, dbl, dbl, vp, vp, vp, vp],

@@ -104,6 +104,26 @@ template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
     }
 };
 
+template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
+    static constexpr bool HEAVY = true;
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    double slope_neg;
+    tmath::RegionConst<T> c;
+    T sT;
+    double a_msg;
+    __device__ void setup(size_t b) {
+        a_msg = az[b];
+        c = tmath::region_const<T>(a_msg);
+        sT = T(slope_neg);
+    }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        RV<T> o = tmath::relu_lik_posterior<T>(x0, x1, sT, c);
+        return {o.r, o.v, 0u};
+    }
+};
+
 template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 = bx
     static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
@@ -479,6 +499,19 @@ extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     AbsLikOp<float> of{az_d};
     AbsLikOp<double> od{az_d};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
+}
+
+extern "C" int tramp_relu_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double slope_neg,
+                                  const double* az_d, const void* bz_d, const void* y_d, double damping,
+                                  const double* a_old_d, const void* b_old_d, double* a_new_d,
+                                  void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && slope_neg >= 0.0);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    ReluLikOp<float> of{az_d, slope_neg};
+    ReluLikOp<double> od{az_d, slope_neg};
     DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
                    (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
 }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
             }
             total += wt * acc;
         }
-    } else {
+    } else if (mode == 1) {
         const double az = P.p0[pt], tau = P.p1[pt];
         const double mz = az - 1.0 / tau;
         const double s = sqrt(mz + mz * mz * tau);
@@ -102,6 +102,24 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
                 f += p * h.var;
             }
             acc += w * norm_pdf(x) * f;
+        }
+        total = acc;
+    }
+    if (mode == 2) {
+        // ReluLikelihood: only the flat region has a non-zero variance
+        // (piecewise_linear_likelihood.py:124-131): E_{N(0, mz + mz^2 tau)}[ p(z <= 0) v_neg ]
+        const double az = P.p0[pt], tau = P.p1[pt];
+        const double mz = az - 1.0 / tau;
+        const double s = sqrt(mz + mz * mz * tau);
+        const double v0 = 1.0 / az;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
+            double x, w;
+            graded_node(i, kPanels1D, 0.0, x, w);
+            const double r0 = (s * x) / az;
+            tmath::HalfLine<double> h = tmath::halfline<double>(r0, v0, -1);
+            const double p = norm_cdf((0 - r0) / sqrt(v0));
+            acc += w * norm_pdf(x) * p * h.var;
         }
         total = acc;
     }
@@ -265,6 +283,20 @@ extern "C" int tramp_se_sgn_lik(tramp_ctx* ctx, size_t count, const double* az, 
     if (rc) return rc;
     Se1dParams P{din[0], din[1], nullptr, nullptr};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 1, P, dout);
+    return se_finish(ctx, count, dout, v);
+}
+
+extern "C" int tramp_se_relu_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && tau_z && v);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] - 1.0 / tau_z[i] > 0.0);   // piecewise_linear_likelihood.py:123-124
+    const double* hin[2] = {az, tau_z};
+    double *din[2], *dout;
+    int rc = se_stage(ctx, count, hin, 2, din, &dout, 0, nullptr);
+    if (rc) return rc;
+    Se1dParams P{din[0], din[1], nullptr, nullptr};
+    hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 2, P, dout);
     return se_finish(ctx, count, dout, v);
 }
 

@@ -220,6 +220,33 @@ template <typename T> TM_HD RV<T> sgn_lik_posterior_fast(T bz, T y, const Region
     return o;
 }
 
+// ---- (Leaky)Relu likelihood: y = max(z, 0) + slope_neg * min(z, 0) observed
+// tramp/likelihoods/piecewise_linear_likelihood.py:9-63,201-215,279-291.  Regions pos (slope 1) and
+// neg (slope s): a region with non-zero slope pins z = (y - x0)/slope exactly (v = 0) when that z
+// lies strictly inside it; the flat neg region of Relu (s = 0) contributes a half-line
+// truncated normal when y == 0.  No region contains y -> softmax of (-inf, -inf) = NaN, as the
+// reference.
+template <typename T> TM_HD RV<T> relu_lik_posterior(T bz, T y, T slope_neg, const RegionConst<T>& c) {
+    RV<T> o;
+    const T nan = T(__builtin_nan(""));
+    if (y > T(0)) {                       // pos region: z = y
+        o.r = y;
+        o.v = T(0);
+    } else if (slope_neg != T(0)) {       // leaky: neg region contains z = y/s iff z < 0
+        o.r = (y < T(0)) ? y / slope_neg : nan;
+        o.v = (y < T(0)) ? T(0) : nan;
+    } else if (y == T(0)) {               // relu: flat region, z in (-inf, 0]
+        T r0;
+        HalfLine<T> h = halfline_fast<T, false>(bz, c, -1, r0);
+        o.r = h.mean;
+        o.v = h.var;
+    } else {
+        o.r = nan;
+        o.v = nan;
+    }
+    return o;
+}
+
 // ---- A7: abs likelihood (tramp/likelihoods/abs_likelihood.py:31-36,
 //          tramp/beliefs/binary.py:8-13) ------------------------------------------
 template <typename T> TM_HD RV<T> abs_lik_posterior(T bz, T y) {

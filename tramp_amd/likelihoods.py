@@ -14,6 +14,7 @@ class Likelihood(Factor):
     n_next = 0
     n_prev = 1
     _which_diag = None
+    _kernel_extra = ()
 
     def get_size(self, y):
         if y is None:
@@ -50,7 +51,7 @@ class Likelihood(Factor):
         b_new = out_b if out_b is not None else out_vec(ctx, b, self.dtype)
         r = out_vec(ctx, b, self.dtype) if want_posterior else None
         v = ctx.empty((b.batch,), np.float64) if want_posterior else None
-        ctx._call(self._kernel_name, self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr, yd.ptr,
+        ctx._call(self._kernel_name, self._dt, b.n, b.batch, *self._kernel_extra, a.dev.ptr, b.dev.ptr, yd.ptr,
                   float(damping or 0.0), old_a.ptr if old_a is not None else None,
                   old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr,
                   r.ptr if r is not None else None, v.ptr if v is not None else None)
@@ -189,7 +190,51 @@ class AbsLikelihood(Likelihood):
         return float(v[0]) if np.ndim(az) == 0 else v
 
 
+class ReluLikelihood(Likelihood):
+    """y = relu(z) observed (tramp/likelihoods/piecewise_linear_likelihood.py:279-284): y > 0 pins
+    z = y, y == 0 leaves a truncated normal on (-inf, 0]."""
+    _kernel_name = "tramp_relu_lik_bwd"
+    _slope = 0.0
+
+    def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        if not isotropic:
+            raise NotImplementedError("diagonal beliefs are not built for the piecewise-linear likelihoods")
+        self.y_name = y_name
+        self.size = self.get_size(y)
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self._kernel_extra = (float(self._slope),)
+        self._set_y(y)
+
+    def sample(self, X):
+        return np.where(X >= 0, X, self._slope * X)
+
+    def compute_backward_error(self, az, tau_z):
+        "beliefs_measure (piecewise_linear_likelihood.py:120-146): only flat regions carry variance"
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        tz = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        if np.any(az_h - 1 / tz <= 0):
+            raise AssertionError("az must be greater than 1/ tau_z")
+        if self._slope != 0:
+            return 0.0 if np.ndim(az) == 0 else np.zeros_like(az_h)
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_relu_lik", az_h.shape[0], az_h.ctypes.data, tz.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+
+class LeakyReluLikelihood(ReluLikelihood):
+    "piecewise_linear_likelihood.py:286-291"
+
+    def __init__(self, slope, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        self.slope = slope
+        self._slope = float(slope)
+        super().__init__(y, y_name, isotropic, dtype, ctx)
+
+
 LIKELIHOOD_CLASSES = {
+    "relu": ReluLikelihood,
+    "l-relu": LeakyReluLikelihood,
     "gaussian": GaussianLikelihood,
     "abs": AbsLikelihood,
     "sgn": SgnLikelihood,

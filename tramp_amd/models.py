@@ -11,10 +11,11 @@ import networkx as nx
 import numpy as np
 
 from .base import Factor, Variable
-from .channels import (GaussianChannel, SgnChannel, AbsChannel, LinearChannel, PiecewiseLinearChannel,
-                       get_channel)
+from .channels import (GaussianChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
+                       PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
-from .likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood, Likelihood
+from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
+                          LeakyReluLikelihood, Likelihood)
 from .priors import Prior, get_prior
 from .variables import SISOVariable, SILeafVariable
 
@@ -28,6 +29,10 @@ def channel2likelihood(channel, y, y_name):
         return AbsLikelihood(y=y, y_name=y_name, **kw)
     if isinstance(channel, SgnChannel):
         return SgnLikelihood(y=y, y_name=y_name, **kw)
+    if isinstance(channel, ReluChannel):
+        return ReluLikelihood(y=y, y_name=y_name, **kw)
+    if isinstance(channel, LeakyReluChannel):
+        return LeakyReluLikelihood(slope=channel.slope, y=y, y_name=y_name, **kw)
     raise NotImplementedError(f"cannot convert {channel} to likelihood")
 
 
