@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denoiser", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=4000)
+    ap.add_argument("--save-factors", default=None, metavar="DIR",
+                    help="after the setup, dump the thin factors (Uk, Vt, sing) and the observations to DIR")
+    ap.add_argument("--load-factors", default=None, metavar="DIR",
+                    help="skip W generation / factorisation and load what --save-factors wrote (used to put the "
+                         "timed region under rocprofv3, which crashes inside rocSOLVER's syevd at k >= 24576)")
     return ap.parse_args()
 
 
@@ -116,6 +121,13 @@ def denoiser_roofline(T, ctx, dtype):
     return out
 
 
+class _Shape:
+    "Stand-in for W when the factors are supplied: LinearChannel only reads .shape then."
+
+    def __init__(self, m, n):
+        self.shape = (m, n)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -151,32 +163,54 @@ def main():
 
     # ---------------- setup (untimed, reported)
     t_setup = time.perf_counter()
-    if dist is None:
-        W = ctx.randn((M, N), np_dt, seed=1234, scale=1.0 / np.sqrt(N))
-    else:
-        # shared sensing matrix: rank 0 draws it, RCCL broadcast over xGMI to the other ranks
-        Wt = torch.empty((M, N), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device="cuda")
-        W = T.DeviceArray(ctx, (M, N), np_dt, ptr=Wt.data_ptr(), owner=False)
-        if rank == 0:
-            ctx._call("tramp_randn", T.device.dtype_code(np_dt), W.ptr, W.size, 1234, 1.0 / np.sqrt(N))
-            ctx.sync()
-        bcast_s = ensemble.broadcast_tensor(Wt, src=0)
-    # teacher data of this rank's instances: block [start, stop) of the B*world ensemble
+    bcast_s = None
     start, stop = ensemble.shard_range(B * world, rank, world)
-    rs = np.random.RandomState(ensemble.instance_seeds(1000, start, stop)[0] % (2**31))
-    X = (rs.standard_normal((B, N)) * rs.binomial(1, args.rho, (B, N))).astype(np_dt)
-    Xd = ctx.array(X, np_dt)
-    Zd = ctx.empty((B, M), np_dt)
-    ctx._call("tramp_matvec_nt", T.device.dtype_code(np_dt), 0, M, N, B, W.ptr, Xd.ptr, Zd.ptr)
-    Y = Zd.get() + np.sqrt(args.noise_var) * rs.standard_normal((B, M))
-    tf = time.perf_counter()
-    lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device")
-    ctx.sync()
-    factorize_s = time.perf_counter() - tf
-    del W
-    if dist is not None:
-        del Wt
-        torch.cuda.empty_cache()
+    if args.load_factors:
+        d = args.load_factors
+        k = min(M, N)
+        Uk = ctx.array(np.load(os.path.join(d, "Uk.npy"), mmap_mode="r"), np_dt)
+        Vt = ctx.array(np.load(os.path.join(d, "Vt.npy"), mmap_mode="r"), np_dt)
+        sing = np.load(os.path.join(d, "sing.npy"))
+        X = np.load(os.path.join(d, "X.npy"))
+        Y = np.load(os.path.join(d, "Y.npy"))
+        assert Uk.shape == (M, k) and Vt.shape == (k, N) and X.shape == (B, N), "factors do not match --size/--batch"
+        tf = time.perf_counter()
+        lin = T.LinearChannel(_Shape(M, N), dtype=np_dt, ctx=ctx,
+                              factors=(Uk, sing, Vt, int(np.sum(sing > 0))))
+        factorize_s = 0.0
+    else:
+        if dist is None:
+            W = ctx.randn((M, N), np_dt, seed=1234, scale=1.0 / np.sqrt(N))
+        else:
+            # shared sensing matrix: rank 0 draws it, RCCL broadcast over xGMI to the other ranks
+            Wt = torch.empty((M, N), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device="cuda")
+            W = T.DeviceArray(ctx, (M, N), np_dt, ptr=Wt.data_ptr(), owner=False)
+            if rank == 0:
+                ctx._call("tramp_randn", T.device.dtype_code(np_dt), W.ptr, W.size, 1234, 1.0 / np.sqrt(N))
+                ctx.sync()
+            bcast_s = ensemble.broadcast_tensor(Wt, src=0)
+        # teacher data of this rank's instances: block [start, stop) of the B*world ensemble
+        rs = np.random.RandomState(ensemble.instance_seeds(1000, start, stop)[0] % (2**31))
+        X = (rs.standard_normal((B, N)) * rs.binomial(1, args.rho, (B, N))).astype(np_dt)
+        Xd = ctx.array(X, np_dt)
+        Zd = ctx.empty((B, M), np_dt)
+        ctx._call("tramp_matvec_nt", T.device.dtype_code(np_dt), 0, M, N, B, W.ptr, Xd.ptr, Zd.ptr)
+        Y = Zd.get() + np.sqrt(args.noise_var) * rs.standard_normal((B, M))
+        tf = time.perf_counter()
+        lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device")
+        ctx.sync()
+        factorize_s = time.perf_counter() - tf
+        del W
+        if dist is not None:
+            del Wt
+            torch.cuda.empty_cache()
+        if args.save_factors and rank == 0:
+            os.makedirs(args.save_factors, exist_ok=True)
+            np.save(os.path.join(args.save_factors, "Uk.npy"), lin._Uk.get())
+            np.save(os.path.join(args.save_factors, "Vt.npy"), lin._Vt.get())
+            np.save(os.path.join(args.save_factors, "sing.npy"), lin._sing.get())
+            np.save(os.path.join(args.save_factors, "X.npy"), X)
+            np.save(os.path.join(args.save_factors, "Y.npy"), Y)
     model = (T.GaussBernoulliPrior(size=N, rho=args.rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x")
              @ lin @ T.SISOVariable(id="z")
              @ T.GaussianLikelihood(y=Y.astype(np_dt), var=args.noise_var, dtype=np_dt, ctx=ctx)).to_model()
@@ -254,7 +288,7 @@ def main():
             "roofline": roof,
             "kernels": kern,
             "setup": {"total_s": setup_s, "factorize_s": factorize_s,
-                      "broadcast_W_s": (bcast_s if dist is not None else None)},
+                      "broadcast_W_s": bcast_s, "factors_loaded_from": args.load_factors},
             "mse_after_run": mse,
             "device": ctx.device_name(),
         }
