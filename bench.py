@@ -128,8 +128,7 @@ class _Shape:
         self.shape = (m, n)
 
 
-def main():
-    args = parse()
+def run(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -300,6 +299,25 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    """Single-rank runs retry at half the size if the setup fails (e.g. the eigensolver or an
+    allocation): a smaller honest number beats no number; the size actually run is in `config`."""
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    while True:
+        try:
+            return run(args)
+        except Exception as e:      # noqa: BLE001
+            if world > 1 or args.n <= 8192 or args.load_factors:
+                raise
+            import gc
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            print(f"bench.py: run at N={args.n} failed ({e!r}); retrying at N={args.n // 2}", file=sys.stderr)
+            gc.collect()
+            args.n //= 2
 
 
 if __name__ == "__main__":
