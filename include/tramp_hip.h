@@ -206,6 +206,18 @@ int tramp_pwl2_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batc
                        double damping, const double* a_old_d, const void* b_old_d,
                        double* a_new_d, void* b_new_d, void* r_d, double* v_d, uint8_t* mask_d);
 
+/* K7, three regions [z_hi, inf), [z_lo, z_hi], (-inf, z_lo] (order pos, mid, neg in slopes3 / x03):
+ * HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel
+ * (tramp/channels/activation/piecewise_linear_channel.py:109-132); the mid region uses the
+ * finite-interval truncated normal with its close/neg/pos/other branches
+ * (tramp/utils/truncated_normal.py:32-200).  mask_d bits: 0/1 log_Phi mask of pos/neg,
+ * 2-3 branch taken by the mid region (0 close, 1 neg, 2 pos, 3 other). */
+int tramp_pwl3_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batch,
+                       double z_lo, double z_hi, const double* slopes3, const double* x03,
+                       const double* az_d, const void* bz_d, const double* ax_d, const void* bx_d,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d, uint8_t* mask_d);
+
 /* ---- diagonal-belief variants (isotropic=False): a is an n-vector too ------
  * Same files as above with the `.mean()` line skipped
  * (gauss_bernoulli_prior.py:75-76, sgn_likelihood.py:35-36, map_L1_norm_prior.py:69-70)
@@ -321,6 +333,10 @@ int tramp_se_pwl_channel(tramp_ctx* ctx, int kind, int dir, size_t count,
 
 int tramp_se_pwl2_channel(tramp_ctx* ctx, int dir, size_t count, double slope_pos, double slope_neg,
                           double x0_pos, double x0_neg, double zcut,
+                          const double* az, const double* ax, const double* tau_z, double* v);
+
+int tramp_se_pwl3_channel(tramp_ctx* ctx, int dir, size_t count, double z_lo, double z_hi,
+                          const double* slopes3, const double* x03,
                           const double* az, const double* ax, const double* tau_z, double* v);
 
 /* ---- synthetic data (bench / tests; counter-based, reproducible per seed) --- */

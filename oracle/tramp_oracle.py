@@ -220,6 +220,181 @@ def halfline_proba(r0, v0, side, zb=0):
 
 
 # --------------------------------------------------------------------------
+# Finite-interval truncated normal (three-region channels)
+#   tramp/utils/truncated_normal.py:13-16 (switch), :32-89 (F0), :97-144 (F1), :152-200 (F2),
+#   :203-215 (G0/G1/G2), :234-298.  The branch masks inf/close/neg/pos/other are index masks.
+# --------------------------------------------------------------------------
+def _switch(x, y):
+    "truncated_normal.py:13-18: order the pair so that |x| <= |y|"
+    sw = np.abs(x) > np.abs(y)
+    return np.where(sw, y, x), np.where(sw, x, y)
+
+
+def interval_branch_masks(x, y, thresh=1e-7):
+    """(close, neg, pos, other) of truncated_normal.py:68-82 for FINITE bounds, on the switched pair."""
+    x, y = _switch(np.asarray(x, dtype=float), np.asarray(y, dtype=float))
+    close = np.abs(x - y) <= thresh
+    neg = (x < 0) & (y < 0)
+    pos = (x > 0) & (y > 0)
+    other = ~(neg | pos)
+    return close, ~close & neg, ~close & pos, ~close & other
+
+
+def _F012(x, y, thresh=1e-7):
+    "F0, F1, F2 of truncated_normal.py for finite x, y (all three share the branch structure)."
+    x, y = _switch(np.asarray(x, dtype=float), np.asarray(y, dtype=float))
+    close, neg, pos, other = interval_branch_masks(x, y, thresh)
+    F0 = np.zeros_like(x); F1 = np.zeros_like(x); F2 = np.zeros_like(x)
+    with np.errstate(all="ignore"):
+        # close (Taylor, :38-46, :102-110, :157-166) - restated literally, quirks included
+        xc, yc = x[close], y[close]
+        e = yc - xc
+        F0[close] = (-xc * e + (1 / 6) * (xc**2 - 2) * e**2 - (1 / 180) * (xc**4 + 2 * xc**2 - 8)
+                     + np.log(2 * e / np.sqrt(np.pi))) - xc**2
+        F1[close] = np.sqrt(np.pi) * (xc + (1 / 2) * e - (1 / 6) * e**2 - (1 / 12) * e**3
+                                      + (1 / 90) * xc * (xc**2 + 1.) * e**4)
+        F2[close] = np.sqrt(np.pi) * (xc**2 - 1 / 2 + xc * e - (1 / 3) * (xc**2 - 1) * e**2
+                                      - (1 / 3) * xc * e**3 + (1 / 90) * (2 * xc**4 + 3 * xc**2 - 8) * e**4)
+        # neg (:49-54, :113-115, :169-171)
+        xn, yn = x[neg], y[neg]
+        D = np.exp(xn**2 - yn**2)
+        den = D * erfcx(-yn) - erfcx(-xn)
+        F0[neg] = np.log(np.abs(den)) - xn**2
+        F1[neg] = (1 - D) / den
+        F2[neg] = (xn - D * yn) / den
+        # pos (:57-62, :118-120, :174-176)
+        xp, yp = x[pos], y[pos]
+        D = np.exp(xp**2 - yp**2)
+        den = erfcx(xp) - D * erfcx(yp)
+        F0[pos] = np.log(np.abs(den)) - xp**2
+        F1[pos] = (1 - D) / den
+        F2[pos] = (xp - D * yp) / den
+        # other (:65-66, :123-125, :179-181)
+        xo, yo = x[other], y[other]
+        D = np.exp(xo**2 - yo**2)
+        den = erf(yo) - erf(xo)
+        F0[other] = np.log(np.abs(den))
+        F1[other] = np.exp(-xo**2) * (1 - D) / den
+        F2[other] = np.exp(-xo**2) * (xo - D * yo) / den
+    return F0, F1, F2
+
+
+def interval_moments(r0, v0, zmin, zmax):
+    "Mean, variance, log-probability of N(r0, v0) on a FINITE [zmin, zmax] (truncated_normal.py:234-281)."
+    r0 = np.asarray(r0, dtype=float)
+    s0 = np.sqrt(v0)
+    ymin = (zmin - r0) / s0
+    ymax = (zmax - r0) / s0
+    F0, F1, F2 = _F012(ymin / SQRT2, ymax / SQRT2)
+    g0 = np.log(0.5) + F0
+    g1 = np.sqrt(2 / np.pi) * F1
+    g2 = (2 / np.sqrt(np.pi)) * F2
+    return r0 + s0 * g1, v0 * (1. + g2 - g1**2), g0
+
+
+def interval_proba(r0, v0, zmin, zmax):
+    s0 = np.sqrt(v0)
+    return norm_cdf((zmax - r0) / s0) - norm_cdf((zmin - r0) / s0)
+
+
+# Three-region channels: [pos, mid, neg] as the reference constructors
+#   tramp/channels/activation/piecewise_linear_channel.py:109-132
+def pwl3_regions(kind, param=None):
+    "[(zmin, zmax, slope, x0)] for pos, mid, neg"
+    inf = np.inf
+    if kind == "h-tanh":
+        return [(1., inf, 0., 1.), (-1., 1., 1., 0.), (-inf, -1., 0., -1.)]
+    if kind == "h-sigm":
+        L = 2.5
+        return [(L, inf, 0., 1.), (-L, L, 1 / (2 * L), 0.5), (-inf, -L, 0., 0.)]
+    if kind == "door":
+        w = float(param)
+        return [(w, inf, 0., 1.), (-w, w, 0., -1.), (-inf, -w, 0., 1.)]
+    raise KeyError(kind)
+
+
+def _region_moments(zmin, zmax, r0, v0):
+    if np.isinf(zmax):
+        return halfline_moments(r0, v0, +1, zmin)
+    if np.isinf(zmin):
+        return halfline_moments(r0, v0, -1, zmax)
+    return interval_moments(r0, v0, zmin, zmax)
+
+
+def pwl3_channel_posterior(kind, direction, az, bz, ax, bx, isotropic=True, param=None):
+    "PiecewiseLinearChannel.compute_*_posterior with three regions (merge_estimates :27-37)."
+    bz = np.asarray(bz, dtype=float)
+    bx = np.asarray(bx, dtype=float)
+    rs, vs, As = [], [], []
+    for zmin, zmax, slope, x0 in pwl3_regions(kind, param):
+        a = az + slope**2 * ax
+        b = bz + slope * (bx - ax * x0)
+        r0, v0 = b / a, 1 / a
+        rz, vz, g0 = _region_moments(zmin, zmax, r0, v0)
+        A = 0.5 * np.log(2 * np.pi * v0) + 0.5 * r0**2 / v0 + g0 - 0.5 * ax * x0**2 + bx * x0
+        rs.append(slope * rz + x0 if direction == "fwd" else rz)
+        vs.append(slope**2 * vz if direction == "fwd" else vz)
+        As.append(A)
+    A = np.stack(As)
+    with np.errstate(invalid="ignore"):
+        e = np.exp(A - A.max(axis=0, keepdims=True))
+        ps = e / e.sum(axis=0, keepdims=True)
+    r = ps[0] * rs[0] + ps[1] * rs[1] + ps[2] * rs[2]
+    Dr = (ps[0] * ps[1] * (rs[0] - rs[1])**2 + ps[0] * ps[2] * (rs[0] - rs[2])**2
+          + ps[1] * ps[2] * (rs[1] - rs[2])**2)
+    v = ps[0] * vs[0] + ps[1] * vs[1] + ps[2] * vs[2] + Dr
+    if isotropic:
+        v = v.mean()
+    return r, v
+
+
+def pwl3_channel_message(kind, direction, az, bz, ax, bx, param=None):
+    r, v = pwl3_channel_posterior(kind, direction, az, bz, ax, bx, param=param)
+    return ab_new(r, v, ax, bx) if direction == "fwd" else ab_new(r, v, az, bz)
+
+
+def pwl3_mid_masks(kind, az, bz, ax, bx, param=None):
+    "Branch masks (close, neg, pos, other) of the finite mid region, as the reference forms them."
+    zmin, zmax, slope, x0 = pwl3_regions(kind, param)[1]
+    a = az + slope**2 * ax
+    b = np.asarray(bz, dtype=float) + slope * (np.asarray(bx, dtype=float) - ax * x0)
+    r0, v0 = b / a, 1 / a
+    s0 = np.sqrt(v0)
+    return interval_branch_masks((zmin - r0) / s0 / SQRT2, (zmax - r0) / s0 / SQRT2)
+
+
+def se_pwl3_channel_error(kind, direction, az, ax, tau_z, method="gl", param=None):
+    "beliefs_measure summed over the three regions (linear_region.py:83-101)."
+    def variance(bz, bx):
+        return pwl3_channel_posterior(kind, direction, az, bz, ax, bx, isotropic=False, param=param)[1]
+    u_eff = np.maximum(0, az * tau_z - 1)
+    total = 0.
+    for zmin, zmax, slope, x0 in pwl3_regions(kind, param):
+        mean_x = ax * x0
+
+        def integrand(bz, bx, zmin=zmin, zmax=zmax, slope=slope, x0=x0):
+            a = az + slope**2 * ax
+            b = bz + slope * (bx - ax * x0)
+            return interval_proba(b / a, 1 / a, zmin, zmax) * variance(bz, bx)
+        sx2 = ax * (slope**2 * ax * tau_z + 1)
+        if ax == 0 or u_eff == 0 or slope == 0:
+            total += gaussian_measure_2d(0, np.sqrt(az * u_eff), mean_x, np.sqrt(sx2), integrand, method)
+        else:
+            cov = np.array([[az * u_eff, slope * ax * u_eff], [slope * ax * u_eff, sx2]])
+            total += gaussian_measure_2d_full(np.array([0, mean_x]), cov, integrand, method)
+    return total
+
+
+def pwl3_second_moment(kind, tau_z, param=None):
+    tot = 0.
+    for zmin, zmax, slope, x0 in pwl3_regions(kind, param):
+        rz, vz, _ = _region_moments(zmin, zmax, np.float64(0), np.float64(tau_z))
+        p = interval_proba(np.float64(0), np.float64(tau_z), zmin, zmax)
+        tot += p * ((slope * rz + x0)**2 + slope**2 * vz)
+    return tot
+
+
+# --------------------------------------------------------------------------
 # A6  Sgn likelihood     tramp/likelihoods/sgn_likelihood.py:23-41
 #                        tramp/beliefs/positive.py:8-26
 # --------------------------------------------------------------------------

@@ -69,5 +69,31 @@ void hm_pwl_f64(int kind, int fwd, size_t n, const double* bz, const double* bx,
         case 5: pwl<double, 2, true>(n, bz, bx, az, ax, r, v, mask, fast); break;
     }
 }
+void hm_pwl3_f64(int fwd, size_t n, const double* bz, const double* bx, double az, double ax, double zlo, double zhi,
+                 const double* slopes3, const double* x03, double* r, double* v, uint8_t* mask) {
+    Pwl3Spec sp{zlo, zhi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}};
+    for (size_t i = 0; i < n; ++i) {
+        PwlOut<double> o = fwd ? pwl3_posterior<double, true>(bz[i], bx[i], az, ax, sp)
+                               : pwl3_posterior<double, false>(bz[i], bx[i], az, ax, sp);
+        r[i] = o.r; v[i] = o.v; mask[i] = (uint8_t)o.mask;
+    }
+}
+void hm_pwl2_f64(int fwd, size_t n, const double* bz, const double* bx, double az, double ax, double sp_, double sn,
+                 double xp, double xn, double zc, double* r, double* v) {
+    PwlSpec sp{{sp_, sn}, {xp, xn}, zc};
+    PwlConst<double> c = pwl_const<double, 3>(az, ax, sp);
+    for (size_t i = 0; i < n; ++i) {
+        PwlOut<double> o = fwd ? pwl_posterior_fast<double, 3, true>(bz[i], bx[i], c)
+                               : pwl_posterior_fast<double, 3, false>(bz[i], bx[i], c);
+        r[i] = o.r; v[i] = o.v;
+    }
+}
+void hm_relu_lik_f64(size_t n, const double* bz, const double* y, double az, double slope, double* r, double* v) {
+    RegionConst<double> c = region_const<double>(az);
+    for (size_t i = 0; i < n; ++i) {
+        RV<double> o = relu_lik_posterior<double>(bz[i], y[i], slope, c);
+        r[i] = o.r; v[i] = o.v;
+    }
+}
 double hm_a_new(double v, double a) { return a_new_of(v, a); }
 }

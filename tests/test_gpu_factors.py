@@ -200,6 +200,56 @@ def test_pwl2_channels(T, ctx, golden_factors, dtype):
             close_b(b_new, c["b_" + d], r_cond, a_in, c["a_" + d], tgt, dtype)
 
 
+def _pwl3(T, c, dtype, ctx):
+    if c["kind"] == "h-tanh":
+        return T.HardTanhChannel(dtype=dtype, ctx=ctx)
+    if c["kind"] == "h-sigm":
+        return T.HardSigmoidChannel(dtype=dtype, ctx=ctx)
+    return T.SymmetricDoorChannel(width=c["param"], dtype=dtype, ctx=ctx)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pwl3_channels(T, ctx, golden_factors, dtype):
+    "HardTanh / HardSigmoid / SymmetricDoor through tramp_pwl3_channel"
+    for c in golden_factors["pwl3"]:
+        if dtype == np.float32 and c["az"] >= 30:
+            continue          # the pos/neg erfcx differences of the mid interval cancel beyond f32 there
+        ch = _pwl3(T, c, dtype, ctx)
+        close(ch.second_moment(1.7), c["tau_x"], atol=1e-12)
+        for d, post, msg in (("fwd", ch.compute_forward_posterior, ch.compute_forward_message),
+                             ("bwd", ch.compute_backward_posterior, ch.compute_backward_message)):
+            r, v = post(c["az"], c["bz"], c["ax"], c["bx"])
+            with np.errstate(all="ignore"):
+                rk = []
+                for zmin, zmax, slope, x0 in orc.pwl3_regions(c["kind"], c["param"]):
+                    a = c["az"] + slope**2 * c["ax"]
+                    b = c["bz"] + slope * (c["bx"] - c["ax"] * x0)
+                    rz = orc._region_moments(zmin, zmax, b / a, 1 / a)[0]
+                    rk.append(np.abs(slope * rz + x0 if d == "fwd" else rz))
+            r_cond = np.maximum(np.abs(c["r_" + d]), np.sort(np.stack(rk), axis=0)[1])
+            close(r, c["r_" + d], dtype, scale=max(1.0, np.nanmax(r_cond)))
+            close(v, c["v_" + d], dtype, atol=(1e-9 if dtype == np.float64 else 3e-3) * c["v_" + d])
+            a_new, b_new = msg(c["az"], c["bz"], c["ax"], c["bx"])
+            tgt = c["bx"] if d == "fwd" else c["bz"]
+            a_in = c["ax"] if d == "fwd" else c["az"]
+            close_a(a_new, c["a_" + d], a_in, dtype)
+            close_b(b_new, c["b_" + d], r_cond, a_in, c["a_" + d], tgt, dtype)
+
+
+def test_pwl3_interval_branch_masks_bit_exact(T, ctx, golden_factors):
+    "close / neg / pos / other of the finite-interval truncated normal (truncated_normal.py:68-82)"
+    seen = np.zeros(4, dtype=int)
+    for c in golden_factors["pwl3"]:
+        ch = _pwl3(T, c, np.float64, ctx)
+        got = ch.branch_masks(c["az"], c["bz"], c["ax"], c["bx"])
+        with np.errstate(all="ignore"):
+            exp = orc.pwl3_mid_masks(c["kind"], c["az"], c["bz"], c["ax"], c["bx"], c["param"])
+        for k in range(4):
+            assert np.array_equal(got[k], exp[k]), (c["kind"], k)
+            seen[k] += int(exp[k].sum())
+    assert seen[1] and seen[2] and seen[3]
+
+
 def test_pwl_branch_masks_bit_exact(T, ctx, golden_factors):
     """log_Phi 'x < 30' masks: same comparison on the same f64 operands as the reference."""
     cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)

@@ -122,3 +122,15 @@ def test_se_relu_likelihood(ctx, golden_se):
     for c in golden_se["relu_lik"]:
         close(lk.compute_backward_error(c["az"], c["tau_z"]), c["v"])
     assert T.LeakyReluLikelihood(slope=0.2, y=None, ctx=ctx).compute_backward_error(2.0, 1.0) == 0.0
+
+
+def test_se_pwl3_channels(ctx, golden_se):
+    "HardTanh / SymmetricDoor SE errors (three-region quadrature)"
+    import tramp_amd as T
+    if "pwl3" not in golden_se:
+        pytest.skip("goldens not regenerated")
+    for c in golden_se["pwl3"]:
+        ch = T.HardTanhChannel(ctx=ctx) if c["kind"] == "h-tanh" else T.SymmetricDoorChannel(width=c["param"], ctx=ctx)
+        close(ch.compute_forward_error(c["az"], c["ax"], c["tau_z"]), c["v_fwd"])
+        close(ch.compute_backward_error(c["az"], c["ax"], c["tau_z"]), c["v_bwd"])
+        close(ch.second_moment(c["tau_z"]), c["tau_x"], rtol=1e-10)

@@ -105,6 +105,42 @@ def test_pwl_and_masks(hm, golden_factors, fast):
             assert np.array_equal(m, exp)
 
 
+def test_widened_factors(hm, golden_factors):
+    "SURVEY section 8f rank 2 factors: generic two-half-line, three-region channels, (Leaky)Relu likelihoods"
+    spec3 = {"h-tanh": ((-1., 1.), (0., 1., 0.), (1., 0., -1.)), "h-sigm": ((-2.5, 2.5), (0., .2, 0.), (1., .5, 0.))}
+    for c in golden_factors["pwl3"]:
+        (zlo, zhi), sl, x0 = spec3.get(c["kind"], ((-(c["param"] or 0), c["param"] or 0), (0., 0., 0.), (1., -1., 1.)))
+        bz, bx = np.ascontiguousarray(c["bz"], dtype=float), np.ascontiguousarray(c["bx"], dtype=float)
+        sl, x0 = np.array(sl), np.array(x0)
+        for d, fwd in (("fwd", 1), ("bwd", 0)):
+            r, v, m = np.empty_like(bz), np.empty_like(bz), np.empty(bz.size, dtype=np.uint8)
+            hm.hm_pwl3_f64(fwd, C.c_size_t(bz.size), ptr(bz), ptr(bx), C.c_double(c["az"]), C.c_double(c["ax"]),
+                           C.c_double(zlo), C.c_double(zhi), ptr(sl), ptr(x0), ptr(r), ptr(v), ptr(m))
+            with np.errstate(all="ignore"):
+                r_ref, v_ref = orc.pwl3_channel_posterior(c["kind"], d, c["az"], bz, c["ax"], bx, isotropic=False,
+                                                          param=c["param"])
+                exp = orc.pwl3_mid_masks(c["kind"], c["az"], bz, c["ax"], bx, c["param"])
+            close(v.mean(), c["v_" + d], rtol=1e-8)
+            close(r, r_ref, rtol=1e-8, scale=max(1.0, np.nanmax(np.abs(r_ref))))
+            code = (m >> 2) & 3
+            for k in range(4):
+                assert np.array_equal(code == k, exp[k])
+    for c in golden_factors["pwl2"]:
+        spec = (1., c["param"], 0., 0., 0.) if c["kind"] == "l-relu" else (1., -1., 0., 0., c["param"])
+        bz, bx = np.ascontiguousarray(c["bz"], dtype=float), np.ascontiguousarray(c["bx"], dtype=float)
+        for d, fwd in (("fwd", 1), ("bwd", 0)):
+            r, v = np.empty_like(bz), np.empty_like(bz)
+            hm.hm_pwl2_f64(fwd, C.c_size_t(bz.size), ptr(bz), ptr(bx), C.c_double(c["az"]), C.c_double(c["ax"]),
+                           *[C.c_double(x) for x in spec], ptr(r), ptr(v))
+            close(v.mean(), c["v_" + d], rtol=1e-8)
+    for c in golden_factors["relu_lik"]:
+        bz, y = np.ascontiguousarray(c["bz"], dtype=float), np.ascontiguousarray(c["y"], dtype=float)
+        r, v = np.empty_like(bz), np.empty_like(bz)
+        hm.hm_relu_lik_f64(C.c_size_t(bz.size), ptr(bz), ptr(y), C.c_double(c["az"]), C.c_double(c["slope"]), ptr(r), ptr(v))
+        close(r, c["r"], rtol=1e-9, scale=max(1.0, np.abs(c["r"]).max()))
+        close(v.mean(), c["v"], rtol=1e-7, scale=max(float(c["v"]), 1e-300))
+
+
 def test_a_new_clipping_and_nan(hm):
     assert hm.hm_a_new(0.5, 1.0) == orc.a_new(0.5, 1.0)
     assert hm.hm_a_new(1e-30, 0.0) == 1e11 and hm.hm_a_new(10.0, 5.0) == 1e-11

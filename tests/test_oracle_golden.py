@@ -131,6 +131,23 @@ def test_pwl2_channels(golden_factors):
         close(orc.pwl_second_moment(c["kind"], 1.7, c["param"]), c["tau_x"], rtol=1e-12)
 
 
+def test_pwl3_channels(golden_factors):
+    "HardTanh / HardSigmoid / SymmetricDoor: finite-interval truncated normal incl. branch coverage"
+    seen = np.zeros(4, dtype=int)
+    for c in golden_factors["pwl3"]:
+        with np.errstate(all="ignore"):
+            for d in ("fwd", "bwd"):
+                r, v = orc.pwl3_channel_posterior(c["kind"], d, c["az"], c["bz"], c["ax"], c["bx"], param=c["param"])
+                a, b = orc.pwl3_channel_message(c["kind"], d, c["az"], c["bz"], c["ax"], c["bx"], param=c["param"])
+                np.testing.assert_allclose(r, c["r_" + d], rtol=RT, equal_nan=True)
+                np.testing.assert_allclose(v, c["v_" + d], rtol=RT, equal_nan=True)
+                np.testing.assert_allclose(a, c["a_" + d], rtol=RT, equal_nan=True)
+                np.testing.assert_allclose(b, c["b_" + d], rtol=RT, equal_nan=True)
+            seen += [int(m.sum()) for m in orc.pwl3_mid_masks(c["kind"], c["az"], c["bz"], c["ax"], c["bx"], c["param"])]
+        close(orc.pwl3_second_moment(c["kind"], 1.7, c["param"]), c["tau_x"], rtol=1e-12)
+    assert seen[1] > 0 and seen[2] > 0 and seen[3] > 0      # neg, pos, other branches all exercised
+
+
 def test_relu_likelihoods(golden_factors):
     for c in golden_factors["relu_lik"]:
         with np.errstate(all="ignore"):
@@ -305,6 +322,13 @@ def test_se_2d_rows_gl(golden_se):
         close(orc.pwl_second_moment(c["kind"], c["tau_z"]), c["tau_x"], rtol=1e-12)
     for c in golden_se["abs_lik"]:
         close(orc.se_abs_lik_error(c["az"], c["tau_z"], "gl"), c["v"], rtol=1e-6)
+    for c in golden_se.get("pwl3", []):
+        with np.errstate(all="ignore"):
+            vf = orc.se_pwl3_channel_error(c["kind"], "fwd", c["az"], c["ax"], c["tau_z"], "gl", c["param"])
+            vb = orc.se_pwl3_channel_error(c["kind"], "bwd", c["az"], c["ax"], c["tau_z"], "gl", c["param"])
+        close(vf, c["v_fwd"], rtol=1e-6, atol=1e-8)
+        close(vb, c["v_bwd"], rtol=1e-6, atol=1e-8)
+        close(orc.pwl3_second_moment(c["kind"], c["tau_z"], c["param"]), c["tau_x"], rtol=1e-12)
     for c in golden_se.get("pwl2", []):
         with np.errstate(all="ignore"):
             vf = orc.se_pwl_channel_error(c["kind"], "fwd", c["az"], c["ax"], c["tau_z"], "gl", c["param"])

@@ -58,7 +58,7 @@ from tramp.likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood  
 from tramp.likelihoods import ReluLikelihood, LeakyReluLikelihood  # noqa: E402
 from tramp.channels import (  # noqa: E402
     LinearChannel, SgnChannel, AbsChannel, ReluChannel, MarchenkoPasturChannel,
-    LeakyReluChannel, AsymmetricAbsChannel
+    LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel
 )
 from tramp.variables import SISOVariable as V  # noqa: E402
 from tramp.algos import ExpectationPropagation, StateEvolution, EarlyStoppingEP  # noqa: E402
@@ -244,6 +244,31 @@ def factor_goldens():
                                    r_fwd=rf, v_fwd=vf, a_fwd=af, b_fwd=bf,
                                    r_bwd=rb, v_bwd=vb, a_bwd=ab, b_bwd=bb, tau_x=ch.second_moment(1.7)))
     out["pwl2"] = pwl2_cases
+
+    # --- three-region channels (finite-interval truncated normal)
+    pwl3_cases = []
+    for kind, param, ch in [("h-tanh", None, HardTanhChannel()), ("h-sigm", None, HardSigmoidChannel()),
+                            ("door", 0.8, SymmetricDoorChannel(width=0.8)), ("door", 0.2, SymmetricDoorChannel(width=0.2))]:
+        xk = ch.sample(z)
+        bxk = message_law(rs, 0.7, xk)
+        for (az, bz, ax, bx) in [
+            (1.3, kat_b, 0.7, kat_bx),
+            (1.3, bz_rand, 0.7, bxk),
+            (1.3, bz_rand, 0., np.zeros(N)),
+            (0.05, bz_rand * .05, 12.0, bxk * 15),
+            (2.0, bz_pe, 1.5, bx_pe),
+            (2.0, rec_bz, 1.5, rec_bx),
+            (30.0, bz_rand * 25, 0.7, bxk),
+        ]:
+            with np.errstate(all="ignore"):
+                rf, vf = ch.compute_forward_posterior(az, bz, ax, bx)
+                af, bf = ch.compute_forward_message(az, bz, ax, bx)
+                rb, vb = ch.compute_backward_posterior(az, bz, ax, bx)
+                ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+            pwl3_cases.append(dict(kind=kind, param=param, az=float(az), bz=bz, ax=float(ax), bx=bx,
+                                   r_fwd=rf, v_fwd=vf, a_fwd=af, b_fwd=bf,
+                                   r_bwd=rb, v_bwd=vb, a_bwd=ab, b_bwd=bb, tau_x=ch.second_moment(1.7)))
+    out["pwl3"] = pwl3_cases
 
     # --- (Leaky)Relu likelihoods
     relu_lik = []
@@ -518,6 +543,16 @@ def se_goldens(skip_slow):
                                 tau_x=ch.second_moment(tau_z)))
                 print("se pwl2", kind, az, ax, tau_z, vf, vb, f"{time.time()-t0:.0f}s")
         out["pwl2"] = pw2
+        pw3 = []
+        for kind, param, ch in [("h-tanh", None, HardTanhChannel()), ("door", 0.8, SymmetricDoorChannel(width=0.8))]:
+            for (az, ax, tau_z) in recs[:3]:
+                with np.errstate(all="ignore"):
+                    vf = ch.compute_forward_error(az, ax, tau_z)
+                    vb = ch.compute_backward_error(az, ax, tau_z)
+                pw3.append(dict(kind=kind, param=param, az=az, ax=ax, tau_z=tau_z, v_fwd=vf, v_bwd=vb,
+                                tau_x=ch.second_moment(tau_z)))
+                print("se pwl3", kind, az, ax, tau_z, vf, vb, f"{time.time()-t0:.0f}s", flush=True)
+        out["pwl3"] = pw3
         # two-layer relu SE, a few iterations (13 s / iteration in the reference)
         model = (GaussianPrior(size=None) @ V(id="x") @ MarchenkoPasturChannel(alpha=2.0)
                  @ V(id="z1") @ ReluChannel() @ V(id="a1")

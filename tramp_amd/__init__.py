@@ -14,7 +14,8 @@ from .priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior, get_pri
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, get_likelihood)
 from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
-                       LeakyReluChannel, AsymmetricAbsChannel,
+                       LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
+                       SymmetricDoorChannel,
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
 from .variables import SISOVariable, SILeafVariable
 from .models import Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution

@@ -248,6 +248,115 @@ class AsymmetricAbsChannel(TwoHalfLineChannel):
         super().__init__(dtype, ctx)
 
 
+class ThreeRegionChannel(PiecewiseLinearChannel):
+    """Generic three-region K7: pos [z_hi, inf), mid [z_lo, z_hi], neg (-inf, z_lo] (SURVEY section 8f
+    rank 2); the mid region is the finite-interval truncated normal of
+    tramp/utils/truncated_normal.py:32-200 with its close/neg/pos/other branch masks."""
+    _z = (-1.0, 1.0)
+    _slopes = (0.0, 1.0, 0.0)     # pos, mid, neg
+    _x0 = (1.0, 0.0, -1.0)
+
+    def __init__(self, dtype=np.float64, ctx=None):
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self._slopes_h = np.array(self._slopes, dtype=np.float64)
+        self._x0_h = np.array(self._x0, dtype=np.float64)
+
+    def sample(self, Z):
+        zlo, zhi = self._z
+        (sp, sm, sn), (xp, xm, xn) = self._slopes, self._x0
+        return np.where(Z >= zhi, xp + sp * Z, np.where(Z >= zlo, xm + sm * Z, xn + sn * Z))
+
+    def second_moment(self, tau_z):
+        "piecewise_linear_channel.py:21-25 with the truncated moments of N(0, tau_z) per region"
+        from math import erf, exp, pi, sqrt
+        s0 = sqrt(tau_z)
+        Phi = lambda t: 0.5 * (1 + erf(t / sqrt(2)))     # noqa: E731
+        phi = lambda t: exp(-0.5 * t * t) / sqrt(2 * pi)  # noqa: E731
+        zlo, zhi = self._z
+        tot = 0.0
+        for (lo, hi), slope, x0 in zip(((zhi, None), (zlo, zhi), (None, zlo)), self._slopes, self._x0):
+            a = -np.inf if lo is None else lo / s0
+            b = np.inf if hi is None else hi / s0
+            Pa, Pb = (0.0 if lo is None else Phi(a)), (1.0 if hi is None else Phi(b))
+            pa, pb = (0.0 if lo is None else phi(a)), (0.0 if hi is None else phi(b))
+            Z = Pb - Pa
+            if Z <= 0:
+                continue
+            lam = (pa - pb) / Z
+            apa = 0.0 if lo is None else a * pa
+            bpb = 0.0 if hi is None else b * pb
+            mean = s0 * lam
+            var = tau_z * (1 + (apa - bpb) / Z - lam * lam)
+            tot += Z * ((slope * mean + x0)**2 + slope * slope * var)
+        return tot
+
+    def _run(self, direction, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+             old_b=None, want_posterior=False, want_mask=False):
+        ctx = self.ctx
+        z = VecArg(ctx, bz, self.dtype)
+        x = VecArg(ctx, bx, self.dtype)
+        if (z.batch, z.n) != (x.batch, x.n):
+            raise ValueError(f"bz {z.dev.shape} and bx {x.dev.shape} must have the same shape")
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((z.batch, z.n), self.dtype)
+        r = ctx.empty((z.batch, z.n), self.dtype) if want_posterior else None
+        v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        mask = ctx.empty((z.batch, z.n), np.uint8) if want_mask else None
+        ctx._call("tramp_pwl3_channel", self._dt, direction, z.n, z.batch, float(self._z[0]), float(self._z[1]),
+                  self._slopes_h.ctypes.data, self._x0_h.ctypes.data,
+                  a_z.dev.ptr, z.dev.ptr, a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
+                  old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
+                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
+                  v.ptr if v is not None else None, mask.ptr if mask is not None else None)
+        tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
+        return tgt, a_t, a_new, b_new, r, v, mask
+
+    def branch_masks(self, az, bz, ax, bx):
+        """(close, neg, pos, other) boolean masks of the mid region's finite-interval branch
+        (tramp/utils/truncated_normal.py:68-82) - index masks, pinned bit-exact in f64."""
+        t, _, _, _, _, _, mask = self._run(_lib.BWD, az, bz, ax, bx, want_mask=True)
+        code = (mask.get().reshape(t.host_shape) >> 2) & 3
+        return tuple(code == k for k in range(4))
+
+    def _se(self, direction, az, ax, tau_z):
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        ax_h = np.broadcast_to(np.asarray(ax, dtype=np.float64), az_h.shape).copy()
+        tz_h = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_pwl3_channel", direction, az_h.shape[0], float(self._z[0]), float(self._z[1]),
+                       self._slopes_h.ctypes.data, self._x0_h.ctypes.data,
+                       az_h.ctypes.data, ax_h.ctypes.data, tz_h.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+
+class HardTanhChannel(ThreeRegionChannel):
+    "tramp/channels/activation/piecewise_linear_channel.py:109-114"
+    name = "h-tanh"
+
+
+class HardSigmoidChannel(ThreeRegionChannel):
+    "piecewise_linear_channel.py:117-123 (L = 2.5)"
+    name = "h-sigm"
+    _z = (-2.5, 2.5)
+    _slopes = (0.0, 1 / 5.0, 0.0)
+    _x0 = (1.0, 0.5, 0.0)
+
+
+class SymmetricDoorChannel(ThreeRegionChannel):
+    "piecewise_linear_channel.py:126-132"
+    name = "door"
+
+    def __init__(self, width, dtype=np.float64, ctx=None):
+        self.width = width
+        self._z = (-float(width), float(width))
+        self._slopes = (0.0, 0.0, 0.0)
+        self._x0 = (1.0, -1.0, 1.0)
+        super().__init__(dtype, ctx)
+
+
 # ------------------------------------------------------------------ dense linear
 def thin_svd_host(W):
     """Thin SVD on the host (LAPACK), the factorisation LinearChannel.__init__ computes
@@ -483,6 +592,9 @@ CHANNEL_CLASSES = {
     "relu": ReluChannel,
     "l-relu": LeakyReluChannel,
     "a-abs": AsymmetricAbsChannel,
+    "h-tanh": HardTanhChannel,
+    "h-sigm": HardSigmoidChannel,
+    "door": SymmetricDoorChannel,
 }
 
 

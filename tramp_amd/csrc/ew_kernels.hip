@@ -124,6 +124,27 @@ template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
     }
 };
 
+template <typename T, bool FWD> struct Pwl3Op {   // three-region channels; in0 = bz, in1 = bx
+    static constexpr bool HEAVY = true;
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = FWD ? 1 : 0;
+    const double* az;
+    const double* ax;
+    tmath::Pwl3Spec spec;
+    T azT, axT;
+    double a_msg;
+    __device__ void setup(size_t b) {
+        const double z = az[b], x = ax[b];
+        azT = T(z);
+        axT = T(x);
+        a_msg = FWD ? x : z;
+    }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        tmath::PwlOut<T> o = tmath::pwl3_posterior<T, FWD>(x0, x1, azT, axT, spec);
+        return {o.r, o.v, o.mask};
+    }
+};
+
 template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 = bx
     static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
@@ -567,6 +588,31 @@ extern "C" int tramp_pwl2_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, 
     DISPATCH_DTYPE(ctx, dtype,
                    (pwl_dir<float, 3>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)),
                    (pwl_dir<double, 3>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)));
+}
+
+template <typename T>
+static int pwl3_dir(tramp_ctx* ctx, int dir, size_t n, size_t batch, const double* az_d, const void* bz_d,
+                    const double* ax_d, const void* bx_d, const MsgOut& out, const tmath::Pwl3Spec& spec) {
+    if (dir == TRAMP_FWD) {
+        Pwl3Op<T, true> op{az_d, ax_d, spec};
+        return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, ax_d, out);
+    }
+    Pwl3Op<T, false> op{az_d, ax_d, spec};
+    return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, az_d, out);
+}
+
+extern "C" int tramp_pwl3_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batch, double z_lo,
+                                  double z_hi, const double* slopes3, const double* x03, const double* az_d,
+                                  const void* bz_d, const double* ax_d, const void* bx_d, double damping,
+                                  const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d,
+                                  void* r_d, double* v_d, uint8_t* mask_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && ax_d && slopes3 && x03 && z_lo < z_hi);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, mask_d};
+    tmath::Pwl3Spec spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}};
+    DISPATCH_DTYPE(ctx, dtype, (pwl3_dir<float>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)),
+                   (pwl3_dir<double>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)));
 }
 
 // ---------------------------------------------------------------- K3 / K6 constant messages

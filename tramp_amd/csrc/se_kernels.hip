@@ -136,6 +136,7 @@ struct Se2dParams {
     const double* ax;
     const double* tau;
     tmath::PwlSpec spec;     // KIND 4 (generic two-half-line channel) only
+    tmath::Pwl3Spec spec3;   // KIND 5 (three-region channel) only
 };
 
 template <int KIND, bool FWD>
@@ -171,6 +172,40 @@ __device__ __forceinline__ double pwl_integrand(double x1, double x2, double az,
     return total;
 }
 
+// Three-region channels: sum over [pos, mid, neg] of E[ p_k(bz, bx) v(bz, bx) ]
+template <bool FWD>
+__device__ __forceinline__ double pwl3_integrand(double x1, double x2, double az, double ax, double tau,
+                                                 const tmath::Pwl3Spec& sp) {
+    const double u_eff = fmax(0.0, az * tau - 1.0);
+    double total = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double slope = sp.slope[k], x0 = sp.x0[k];
+        const double mean_x = ax * x0;
+        const double sx2 = ax * (slope * slope * ax * tau + 1.0);
+        double bz, bx;
+        if (ax == 0.0 || u_eff == 0.0 || slope == 0.0) {
+            bz = sqrt(az * u_eff) * x1;
+            bx = mean_x + sqrt(sx2) * x2;
+        } else {
+            const double c00 = az * u_eff, c01 = slope * ax * u_eff;
+            const double l00 = sqrt(c00), l10 = c01 / l00, l11 = sqrt(sx2 - l10 * l10);
+            bz = l00 * x1;
+            bx = l10 * x1 + l11 * x2 + mean_x;
+        }
+        const double a = az + slope * slope * ax;
+        const double b = bz + slope * (bx - ax * x0);
+        const double r0 = b / a, s0 = sqrt(1.0 / a);
+        double p;                                              // truncated_normal_proba
+        if (k == 0) p = 1.0 - norm_cdf((sp.zhi - r0) / s0);
+        else if (k == 2) p = norm_cdf((sp.zlo - r0) / s0);
+        else p = norm_cdf((sp.zhi - r0) / s0) - norm_cdf((sp.zlo - r0) / s0);
+        tmath::PwlOut<double> o = tmath::pwl3_posterior<double, FWD>(bz, bx, az, ax, sp);
+        total += p * o.v;
+    }
+    return total;
+}
+
 __device__ __forceinline__ double abs_lik_integrand(double x1, double x2, double az, double tau) {
     const double mz = az - 1.0 / tau;
     const double z = sqrt(tau) * x1;
@@ -200,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void se_2d_kernel(Se2dParams P, const doubl
             const double x2 = xs[j];
             double f;
             if (KIND == 3) f = abs_lik_integrand(x1, x2, az, tau);
-            else f = pwl_integrand<(KIND == 3 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
+            else if (KIND == 5) f = pwl3_integrand<FWD>(x1, x2, az, ax, tau, P.spec3);
+            else f = pwl_integrand<(KIND == 3 || KIND == 5 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
             row += ws[j] * f;
         }
         acc += w1 * row;
@@ -311,7 +347,8 @@ static int panels2d() {
 
 template <int KIND, bool FWD>
 static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const double* ax, const double* tau,
-                     double* v, const tmath::PwlSpec& spec = tmath::PwlSpec{}) {
+                     double* v, const tmath::PwlSpec& spec = tmath::PwlSpec{},
+                     const tmath::Pwl3Spec& spec3 = tmath::Pwl3Spec{}) {
     const int panels = panels2d();
     const int n = panels * 8;
     const int strip = 8;
@@ -323,7 +360,7 @@ static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const doubl
     double* nodes = extra;
     double* partials = extra + 2 * (size_t)n;
     hipLaunchKernelGGL(se_nodes_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, panels, nodes);
-    Se2dParams P{din[0], din[1], din[2], spec};
+    Se2dParams P{din[0], din[1], din[2], spec, spec3};
     hipLaunchKernelGGL((se_2d_kernel<KIND, FWD>), dim3(nstrips, (unsigned)count), dim3(kBlock), 0, ctx->stream, P, nodes,
                        n, strip, partials);
     hipLaunchKernelGGL(se_fold_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, partials, nstrips, dout);
@@ -365,4 +402,17 @@ extern "C" int tramp_se_pwl2_channel(tramp_ctx* ctx, int dir, size_t count, doub
     tmath::PwlSpec spec{{slope_pos, slope_neg}, {x0_pos, x0_neg}, zcut};
     return dir == TRAMP_FWD ? se_2d_run<4, true>(ctx, count, az, ax, tau_z, v, spec)
                             : se_2d_run<4, false>(ctx, count, az, ax, tau_z, v, spec);
+}
+
+extern "C" int tramp_se_pwl3_channel(tramp_ctx* ctx, int dir, size_t count, double z_lo, double z_hi,
+                                     const double* slopes3, const double* x03, const double* az,
+                                     const double* ax, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && ax && tau_z && v && slopes3 && x03 && z_lo < z_hi);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] > 0.0 && ax[i] >= 0.0 && tau_z[i] > 0.0);
+    tmath::Pwl3Spec spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}};
+    return dir == TRAMP_FWD ? se_2d_run<5, true>(ctx, count, az, ax, tau_z, v, tmath::PwlSpec{}, spec)
+                            : se_2d_run<5, false>(ctx, count, az, ax, tau_z, v, tmath::PwlSpec{}, spec);
 }

@@ -54,6 +54,8 @@ TM_HD double fabs_(double x) { return ::fabs(x); }
 TM_HD float fabs_(float x) { return ::fabsf(x); }
 TM_HD double fmax_(double a, double b) { return ::fmax(a, b); }
 TM_HD float fmax_(float a, float b) { return ::fmaxf(a, b); }
+TM_HD double erf_(double x) { return ::erf(x); }
+TM_HD float erf_(float x) { return ::erff(x); }
 TM_HD double fma_(double a, double b, double c) { return ::fma(a, b, c); }
 TM_HD float fma_(float a, float b, float c) { return ::fmaf(a, b, c); }
 
@@ -429,6 +431,103 @@ TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
     o.r = p0 * rs[0] + p1 * rs[1];
     T d = rs[0] - rs[1];
     o.v = p0 * vs[0] + p1 * vs[1] + p0 * p1 * (d * d);
+    o.mask = mask;
+    return o;
+}
+
+// ---- finite-interval truncated normal + three-region channels ------
+// tramp/utils/truncated_normal.py:13-18 (switch), :32-89 (F0), :97-144 (F1), :152-200 (F2),
+// :203-215 (G0/G1/G2), :234-281.  Literal restatement, Taylor "close" branch and its quirks
+// included; `branch` reports which of close / neg / pos / other was taken (an index mask).
+template <typename T> struct IntervalOut { T mean, var, logp; unsigned branch; };
+
+template <typename T> TM_HD IntervalOut<T> interval_moments(T r0, T v0, T zmin, T zmax) {
+    const T s0 = sqrt_(v0);
+    const T ymin = (zmin - r0) / s0, ymax = (zmax - r0) / s0;
+    T x = ymin / T(kSqrt2), y = ymax / T(kSqrt2);
+    if (fabs_(x) > fabs_(y)) { T t = x; x = y; y = t; }           // switch: |x| <= |y|
+    const bool close = fabs_(x - y) <= T(1e-7);
+    const bool neg = (x < T(0)) && (y < T(0));
+    const bool pos = (x > T(0)) && (y > T(0));
+    T F0, F1, F2;
+    unsigned br;
+    const T sqrt_pi = T(1.7724538509055159);
+    if (close) {
+        br = 0;
+        const T e = y - x, x2 = x * x;
+        F0 = (-x * e + T(1.0 / 6) * (x2 - T(2)) * (e * e) - T(1.0 / 180) * (x2 * x2 + T(2) * x2 - T(8))
+              + log_(T(2) * e / sqrt_pi)) - x2;
+        F1 = sqrt_pi * (x + T(0.5) * e - T(1.0 / 6) * (e * e) - T(1.0 / 12) * (e * e * e)
+                        + T(1.0 / 90) * x * (x2 + T(1)) * (e * e * e * e));
+        F2 = sqrt_pi * (x2 - T(0.5) + x * e - T(1.0 / 3) * (x2 - T(1)) * (e * e) - T(1.0 / 3) * x * (e * e * e)
+                        + T(1.0 / 90) * (T(2) * x2 * x2 + T(3) * x2 - T(8)) * (e * e * e * e));
+    } else if (neg || pos) {
+        br = neg ? 1u : 2u;
+        const T D = exp_(x * x - y * y);
+        const T den = neg ? D * erfcx_(-y) - erfcx_(-x) : erfcx_(x) - D * erfcx_(y);
+        F0 = log_(fabs_(den)) - x * x;
+        F1 = (T(1) - D) / den;
+        F2 = (x - D * y) / den;
+    } else {
+        br = 3;
+        const T D = exp_(x * x - y * y);
+        const T den = erf_(y) - erf_(x);
+        const T ex = exp_(-(x * x));
+        F0 = log_(fabs_(den));
+        F1 = ex * (T(1) - D) / den;
+        F2 = ex * (x - D * y) / den;
+    }
+    const T g0 = T(-0.6931471805599453) + F0;                   // np.log(0.5) + F0
+    const T g1 = T(kSqrt2OverPi) * F1;
+    const T g2 = T(kTwoOverSqrtPi) * F2;
+    IntervalOut<T> o;
+    o.mean = r0 + s0 * g1;
+    o.var = v0 * (T(1) + g2 - g1 * g1);
+    o.logp = g0;
+    o.branch = br;
+    return o;
+}
+
+// Regions in the reference's order [pos, mid, neg]: pos = [zhi, inf), mid = [zlo, zhi],
+// neg = (-inf, zlo]  (HardTanh / HardSigmoid / SymmetricDoor,
+// tramp/channels/activation/piecewise_linear_channel.py:109-132).
+struct Pwl3Spec { double zlo, zhi, slope[3], x0[3]; };
+
+// mask: bit0 / bit1 = log_Phi branch of pos / neg, bits 2-3 = branch of the mid interval.
+template <typename T, bool FWD>
+TM_HD PwlOut<T> pwl3_posterior(T bz, T bx, T az, T ax, const Pwl3Spec& sp) {
+    T rs[3], vs[3], As[3];
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T slope = T(sp.slope[k]), x0 = T(sp.x0[k]);
+        const T a = az + slope * slope * ax;
+        const T b = bz + slope * (bx - ax * x0);
+        const T r0 = b / a, v0 = T(1) / a;
+        T rz, vz, g0;
+        if (k == 1) {
+            IntervalOut<T> m = interval_moments<T>(r0, v0, T(sp.zlo), T(sp.zhi));
+            rz = m.mean; vz = m.var; g0 = m.logp;
+            mask |= m.branch << 2;
+        } else {
+            HalfLine<T> h = halfline_at<T>(r0, v0, k == 0 ? +1 : -1, k == 0 ? T(sp.zhi) : T(sp.zlo));
+            rz = h.mean; vz = h.var; g0 = h.logp;
+            mask |= (h.mask ? 1u : 0u) << (k == 0 ? 0 : 1);
+        }
+        As[k] = T(0.5) * log_(T(2 * kPi) * v0) + T(0.5) * (r0 * r0) / v0 + g0
+                - T(0.5) * ax * (x0 * x0) + bx * x0;
+        rs[k] = FWD ? slope * rz + x0 : rz;
+        vs[k] = FWD ? slope * slope * vz : vz;
+    }
+    const T m = fmax_(As[0], fmax_(As[1], As[2]));
+    const T e0 = exp_(As[0] - m), e1 = exp_(As[1] - m), e2 = exp_(As[2] - m);
+    const T se = e0 + e1 + e2;
+    const T p0 = e0 / se, p1 = e1 / se, p2 = e2 / se;
+    PwlOut<T> o;
+    o.r = p0 * rs[0] + p1 * rs[1] + p2 * rs[2];
+    const T d01 = rs[0] - rs[1], d02 = rs[0] - rs[2], d12 = rs[1] - rs[2];
+    o.v = p0 * vs[0] + p1 * vs[1] + p2 * vs[2]
+          + (p0 * p1 * (d01 * d01) + p0 * p2 * (d02 * d02) + p1 * p2 * (d12 * d12));
     o.mask = mask;
     return o;
 }
