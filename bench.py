@@ -32,7 +32,7 @@ MFMA_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # fp64: AMD datasheet (matrix =
 # measured on the box by tools/probes/probe_peaks.hip (back-to-back independent MFMAs, 16 waves/CU)
 MFMA_MEASURED_TFLOPS = {"f64": 47.5, "f32": 146.3}
 
-TAGS = ["ew_factor_update", "matvec_nt", "matvec_nn", "linear_scalars", "variable_posterior", "other"]
+TAGS = ["ew_factor_update", "matvec_nt", "matvec_nn", "linear_scalars", "variable_posterior", "other", "fft"]
 
 
 def parse():
@@ -227,10 +227,11 @@ def run(args):
     barrier()
     elapsed = time.perf_counter() - t0
     import ctypes as C
-    cnt = (C.c_int * 6)()
-    ms = (C.c_double * 6)()
-    by = (C.c_double * 6)()
-    fl = (C.c_double * 6)()
+    NT = len(TAGS)
+    cnt = (C.c_int * NT)()
+    ms = (C.c_double * NT)()
+    by = (C.c_double * NT)()
+    fl = (C.c_double * NT)()
     ctx._call("tramp_profile_report", cnt, ms, by, fl)
     ctx._call("tramp_profile_enable", 0)
     mse = float(np.mean(ep.mse("x", X)))
@@ -239,7 +240,7 @@ def run(args):
 
     if rank == 0:
         total_units = float(N) * B * world * args.steps
-        kern = {TAGS[i]: {"launches": cnt[i], "ms": ms[i], "bytes": by[i], "flops": fl[i]} for i in range(6)
+        kern = {TAGS[i]: {"launches": cnt[i], "ms": ms[i], "bytes": by[i], "flops": fl[i]} for i in range(NT)
                 if cnt[i]}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]

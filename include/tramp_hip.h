@@ -119,7 +119,8 @@ int tramp_graph_destroy(tramp_ctx* ctx, tramp_graph* graph);
 #define TRAMP_PROF_LIN_SCALARS 3
 #define TRAMP_PROF_VAR_POST 4
 #define TRAMP_PROF_OTHER 5
-#define TRAMP_PROF_NTAGS 6
+#define TRAMP_PROF_FFT 6          /* rocFFT transforms of the convolution channel */
+#define TRAMP_PROF_NTAGS 7
 int tramp_profile_enable(tramp_ctx* ctx, int on);
 int tramp_profile_report(tramp_ctx* ctx, int* count, double* ms, double* bytes, double* flops);
 
@@ -265,8 +266,7 @@ int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, int dir, size
  *    BWD  rz = bz/az + Vt^T [ (1/D - 1/az) t + sing u / D ]     (k < N)
  *         rz =         Vt^T [ (t + sing u) / D ]                 (k = N)
  * then the fused message update.  bz_d [batch,N], bx_d [batch,M].
- * B = 1..TRAMP_GEMV_MAX_BATCH uses HBM-streaming GEMV kernels, larger batches
- * the MFMA kernels.  r_d optional (posterior mean), v_d optional. */
+ * Batches of 1-2 use HBM-streaming VALU GEMV kernels, larger batches the MFMA kernels.  r_d optional (posterior mean), v_d optional. */
 int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batch,
                          const double* az_d, const void* bz_d,
                          const double* ax_d, const void* bx_d,
@@ -287,6 +287,36 @@ int tramp_matvec_nt(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, siz
                     const void* mat_d, const void* x_d, void* out_d);
 int tramp_matvec_nn(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
                     const void* mat_d, const void* x_d, void* out_d);
+
+/* ---- convolution channel x = w * z ------------------ */
+/* ConvChannel (tramp/channels/linear/conv_channel.py:13-149), real signals of 1-3 axes
+ * with circular boundary: the operator is diagonal in the Fourier basis, so the update is
+ * O(n log n).  filter_d holds the FILTER f (always double, row-major `dims`); the conv
+ * weights are w[u] = f[-u], i.e. fft(w) = conj(fft(f)) (conv_channel.py:37-45).  The
+ * transforms run through rocFFT (batched real-to-complex plans on the context's stream),
+ * the spectral solve, scalar reductions and message update are this library's kernels. */
+typedef struct tramp_conv tramp_conv;
+int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filter_d,
+                      tramp_conv** conv);
+int tramp_conv_destroy(tramp_ctx* ctx, tramp_conv* conv);
+/* Half spectrum |fft(f)|^2 (last axis n_last/2+1 bins; *count entries, device copy optional)
+ * and the mean of the FULL spectrum (ConvChannel.second_moment, conv_channel.py:66-67). */
+int tramp_conv_spectrum(tramp_ctx* ctx, const tramp_conv* conv, double* s2_d, size_t* count, double* mean);
+/* ConvChannel.compute_n_eff / compute_backward_variance / compute_forward_variance
+ * (conv_channel.py:69-79,111-123) + compute_a_new; argument meaning as tramp_linear_variance. */
+int tramp_conv_variance(tramp_ctx* ctx, tramp_conv* conv, int dir, size_t batch,
+                        const double* az_d, const double* ax_d,
+                        double* v_d, double* a_new_d, double* n_eff_d);
+/* ConvChannel.convolve / sample (conv_channel.py:47-63): x = w * z for [batch, n] rows. */
+int tramp_conv_apply(tramp_ctx* ctx, tramp_conv* conv, size_t batch, const void* z_d, void* x_d);
+/* ConvChannel.compute_backward_mean / compute_forward_mean (conv_channel.py:81-109) with the
+ * fused message update; arguments and `reuse` exactly as tramp_linear_message (the cached
+ * projections are rfft(bz) and rfft(bx)).  bz_d, bx_d, b_new_d, r_d: [batch, n]. */
+int tramp_conv_message(tramp_ctx* ctx, tramp_conv* conv, int dir, size_t batch,
+                       const double* az_d, const void* bz_d,
+                       const double* ax_d, const void* bx_d,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse);
 
 /* ---- variable nodes / scheduler helpers ------------------------------------ */
 /* K11. Variable.posterior_rv (tramp/base.py:157-161) for a SISO variable:
@@ -344,6 +374,8 @@ int tramp_se_pwl3_channel(tramp_ctx* ctx, int dir, size_t count, double z_lo, do
 int tramp_randn(tramp_ctx* ctx, int dtype, void* out_d, size_t count,
                 unsigned long long seed, double scale);
 
+/* instances handled per launch of the VALU GEMV kernels (the dispatcher sends batches
+ * of 3 and more to the MFMA kernels, so only forced-VALU calls chunk by this) */
 #define TRAMP_GEMV_MAX_BATCH 8
 
 #ifdef __cplusplus

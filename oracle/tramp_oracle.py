@@ -682,6 +682,86 @@ class LinearThinOracle(LinearOracle):
 
 
 # --------------------------------------------------------------------------
+# Widening: circular convolution channel x = w * z, real signals
+#   tramp/channels/linear/conv_channel.py:13-149 (real=True)
+# --------------------------------------------------------------------------
+class ConvOracle:
+    def __init__(self, filt):
+        filt = np.asarray(filt, dtype=np.float64)
+        self.shape = filt.shape
+        self.w_fft_bar = np.fft.fftn(filt)                       # :42-45
+        self.w_fft = np.conjugate(self.w_fft_bar)
+        self.spectrum = np.absolute(self.w_fft)**2
+        self._axes = tuple(range(-filt.ndim, 0))                 # leading axes = ensemble
+
+    def _fft(self, a):
+        return np.fft.fftn(a, axes=self._axes)
+
+    def _ifft(self, a):
+        return np.real(np.fft.ifftn(a, axes=self._axes))
+
+    def convolve(self, z):
+        return self._ifft(self.w_fft * self._fft(z))             # :47-55
+
+    def second_moment(self, tau_z):
+        return tau_z * self.spectrum.mean()                      # :66-67
+
+    def n_eff(self, az, ax):
+        ":69-79"
+        if ax == 0:
+            return 0.
+        if az / ax == 0:
+            return 1.
+        return np.mean(self.spectrum / (az / ax + self.spectrum))
+
+    def backward_mean_fft(self, az, bz, ax, bx):
+        resolvent = 1 / (az + ax * self.spectrum)                # :92
+        return resolvent * (self._fft(bz) + self.w_fft_bar * self._fft(bx))
+
+    def backward_mean(self, az, bz, ax, bx):
+        return self._ifft(self.backward_mean_fft(az, bz, ax, bx))            # :81-103
+
+    def forward_mean(self, az, bz, ax, bx):
+        return self._ifft(self.w_fft * self.backward_mean_fft(az, bz, ax, bx))   # :105-109
+
+    def backward_variance(self, az, ax):
+        return (1 - self.n_eff(az, ax)) / az                     # :111-115
+
+    def forward_variance(self, az, ax):
+        if ax == 0:
+            return np.mean(self.spectrum) / az                   # :117-120
+        return self.n_eff(az, ax) / ax                           # :121-123
+
+    def forward_message(self, az, bz, ax, bx):
+        return ab_new(self.forward_mean(az, bz, ax, bx), self.forward_variance(az, ax), ax, bx)
+
+    def backward_message(self, az, bz, ax, bx):
+        return ab_new(self.backward_mean(az, bz, ax, bx), self.backward_variance(az, ax), az, bz)
+
+
+def gaussian_filter(sigma, N):
+    "tramp/utils/conv_filters.py:45-52"
+    freq = np.fft.fftfreq(N)
+    return np.real(np.fft.ifft(np.exp(-2 * (np.pi * sigma)**2 * freq**2)))
+
+
+def stencil_filter(shape, first=None, second=None):
+    """D1 . d/dx + D2 . d2/dx2 on a periodic grid (conv_filters.py:29-42,55-99):
+    forward difference (-1, +1) at offsets (0, 1); second difference (-2, 1, 1) at (0, 1, -1)."""
+    d = len(shape)
+    f = np.zeros(shape)
+    for ax in range(d):
+        for coef, taps in ((first, {0: -1., 1: 1.}), (second, {0: -2., 1: 1., -1: 1.})):
+            if coef is None or coef[ax] == 0:
+                continue
+            for off, w in taps.items():
+                idx = [0] * d
+                idx[ax] = off
+                f[tuple(idx)] += coef[ax] * w
+    return f
+
+
+# --------------------------------------------------------------------------
 # A14  Marchenko-Pastur closed-form linear channel (SE only)
 #   tramp/channels/linear/analytical_linear_channel.py:23-53
 #   tramp/ensembles/marchenko_pastur_ensemble.py:7-45
@@ -923,6 +1003,11 @@ class LinearFactor(OracleFactor):
 
     def second_moment(self, tau_z):
         return self.lin.second_moment(tau_z)
+
+
+class ConvFactor(LinearFactor):
+    def __init__(self, filt):
+        self.lin = ConvOracle(filt)
 
 
 class MPFactor(OracleFactor):

@@ -38,6 +38,13 @@ def golden_ep():
 
 
 @pytest.fixture(scope="session")
+def golden_conv():
+    path = os.path.join(GOLDEN, "conv.npz")
+    with np.load(path, allow_pickle=True) as f:
+        return dict(channels=list(f["data"]), ep=list(f["ep"]))
+
+
+@pytest.fixture(scope="session")
 def golden_se():
     return load_golden("se")
 

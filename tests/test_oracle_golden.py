@@ -346,3 +346,65 @@ def test_se_2d_rows_quadpack_one(golden_se):
     with np.errstate(all="ignore"):
         vf = orc.se_pwl_channel_error("relu", "fwd", c["az"], c["ax"], c["tau_z"])
     close(vf, c["v_fwd"], rtol=1e-9)
+
+
+# -- convolution channel family
+def conv_filter_of(c):
+    "Rebuild the filter from the constructor arguments (checks the filter builders too)."
+    kw = c["kwargs"]
+    if c["kind"] == "conv":
+        return np.asarray(kw["filter"])
+    if c["kind"] == "blur_1d":
+        return orc.gaussian_filter(kw["sigma"], kw["N"])
+    if c["kind"] == "blur_2d":
+        return np.outer(orc.gaussian_filter(kw["sigma"][0], kw["shape"][0]),
+                        orc.gaussian_filter(kw["sigma"][1], kw["shape"][1]))
+    if c["kind"] == "laplacian":
+        return orc.stencil_filter(tuple(kw["shape"]), None, [1.0] * len(kw["shape"]))
+    return orc.stencil_filter(tuple(kw["shape"]), kw["D1"], kw["D2"])
+
+
+def test_conv_channel_oracle_matches_reference(golden_conv):
+    for c in golden_conv["channels"]:
+        f = conv_filter_of(c)
+        close(f, c["filter"], rtol=1e-12, atol=1e-15)
+        o = orc.ConvOracle(c["filter"])
+        close(o.spectrum, c["spectrum"], rtol=1e-12, atol=1e-14)
+        close(o.second_moment(1.7), c["second_moment"])
+        close(o.convolve(c["z"]), c["x"], rtol=1e-12, atol=1e-13)
+        for k in c["cases"]:
+            az, ax = k["az"], k["ax"]
+            with np.errstate(all="ignore"):
+                sc = np.abs(k["rz"]).max()
+                close(o.backward_mean(az, c["bz"], ax, c["bx"]), k["rz"], rtol=1e-11, atol=1e-12 * sc)
+                close(o.forward_mean(az, c["bz"], ax, c["bx"]), k["rx"], rtol=1e-11,
+                      atol=1e-12 * np.abs(k["rx"]).max())
+                close(o.n_eff(az, ax), k["n_eff"])
+                close(o.backward_variance(az, ax), k["vz"])
+                close(o.forward_variance(az, ax), k["vx"])
+                a, b = o.forward_message(az, c["bz"], ax, c["bx"])
+                close(a, k["a_fwd"])
+                close(b, k["b_fwd"], rtol=1e-10, atol=1e-11 * np.abs(k["b_fwd"]).max())
+                a, b = o.backward_message(az, c["bz"], ax, c["bx"])
+                close(a, k["a_bwd"])
+                close(b, k["b_bwd"], rtol=1e-10, atol=1e-11 * np.abs(k["b_bwd"]).max())
+
+
+def test_conv_ep_oracle_matches_reference(golden_conv):
+    for c in golden_conv["ep"]:
+        shape = tuple(c["shape"])
+        fs = [orc.GBPriorFactor(shape, rho=c["rho"]), orc.ConvFactor(c["filter"]),
+              orc.GaussLikFactor(c["y"], c["noise_var"])]
+        iters = []
+        res = orc.ep_chain(fs, [shape, shape], max_iter=40, damping=c["damping"],
+                           record=lambda it, fwd, bwd, rs, vs: iters.append((list(fwd), list(bwd), rs, vs)))
+        assert res["n_iter"] == c["n_iter"], c["name"]
+        t = c["traj"]
+        for it in range(min(len(iters), t["v:x"].shape[0])):
+            fwd, bwd, rs, vs = iters[it]
+            for i, vid in enumerate(["x", "z"]):
+                close(fwd[i][0], t[f"fwd:{vid}:a"][it], rtol=1e-8)
+                close(bwd[i][0], t[f"bwd:{vid}:a"][it], rtol=1e-8)
+                close(rs[i], t[f"r:{vid}"][it], rtol=1e-7, atol=1e-9 * np.abs(t[f"r:{vid}"][it]).max())
+                close(vs[i], t[f"v:{vid}"][it], rtol=1e-8)
+        close(res["r"][0], c["final_r"], rtol=1e-6, atol=1e-7)

@@ -65,7 +65,7 @@ K = 20
 ep.iterate(max_iter=K, callback=T.PassCallback(), damping=0.1, warm_start=True, check_every=1 << 30)
 ctx.sync(); dt_s = time.perf_counter() - t0
 import ctypes as C
-cnt, ms, by, fl = (C.c_int * 6)(), (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)()
+cnt, ms, by, fl = (C.c_int * 8)(), (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
 ctx._call("tramp_profile_report", cnt, ms, by, fl)
 tags = ["ew", "matvec_nt", "matvec_nn", "lin_scalars", "var_post", "other"]
 print(f"{desc} {np_dt.__name__} B={B}: {dt_s/K*1e3:.3f} ms/iteration, {N*B*K/dt_s:.3e} msg-components/s, setup {setup:.1f} s, "

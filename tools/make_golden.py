@@ -60,6 +60,9 @@ from tramp.channels import (  # noqa: E402
     LinearChannel, SgnChannel, AbsChannel, ReluChannel, MarchenkoPasturChannel,
     LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel
 )
+from tramp.channels import (  # noqa: E402
+    ConvChannel, Blur1DChannel, Blur2DChannel, DifferentialChannel, LaplacianChannel
+)
 from tramp.variables import SISOVariable as V  # noqa: E402
 from tramp.algos import ExpectationPropagation, StateEvolution, EarlyStoppingEP  # noqa: E402
 from tramp.algos import EarlyStopping, ConstantInit  # noqa: E402
@@ -452,6 +455,73 @@ def ep_goldens():
     save("ep_traj", data=np.array(trajs, dtype=object))
 
 
+# ---------------------------------------------------------------- convolution channel
+def conv_goldens():
+    "ConvChannel family (real=True): posteriors, messages, scalars, samples, EP trajectories."
+    rs = np.random.RandomState(11)
+    chans = [
+        ("conv", dict(filter=rs.randn(16) / 4)),
+        ("conv", dict(filter=rs.randn(15) / 4)),
+        ("conv", dict(filter=rs.randn(6, 8) / 7)),
+        ("conv", dict(filter=rs.randn(3, 4, 5) / 8)),
+        ("blur_1d", dict(sigma=2.0, N=32)),
+        ("blur_2d", dict(sigma=[1.0, 2.0], shape=(8, 10))),
+        ("laplacian", dict(shape=(8, 8))),
+        ("diff", dict(D1=[1.0, -0.5, 0.25], D2=[0.3, 0.0, -0.2], shape=(3, 4, 5))),
+        ("diff", dict(D1=[1.0], D2=None, shape=(9,))),
+    ]
+    ctor = dict(conv=ConvChannel, blur_1d=Blur1DChannel, blur_2d=Blur2DChannel,
+                laplacian=LaplacianChannel, diff=DifferentialChannel)
+    out = []
+    for kind, kw in chans:
+        ch = ctor[kind](**kw)
+        shape = ch.shape
+        bz = rs.standard_normal(shape) * 2
+        bx = rs.standard_normal(shape) * 3
+        z = rs.standard_normal(shape)
+        cases = []
+        for (az, ax) in [(1.3, 0.7), (2.0, 0.), (1e-11, 5.0), (1e11, 1e-11), (100.0, 100.0),
+                         (0.37, 1e4), (1e-300, 3.0)]:
+            with np.errstate(all="ignore"):
+                rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+                rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+                af, bf = ch.compute_forward_message(az, bz, ax, bx)
+                ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+            cases.append(dict(az=float(az), ax=float(ax), rz=rz, rx=rx, vz=vz, vx=vx, a_fwd=af, b_fwd=bf,
+                              a_bwd=ab, b_bwd=bb, n_eff=ch.compute_n_eff(az, ax)))
+        out.append(dict(kind=kind, kwargs=kw, filter=np.array(ch.filter), bz=bz, bx=bx, z=z,
+                        x=ch.sample(z), spectrum=ch.spectrum, second_moment=ch.second_moment(1.7),
+                        cases=cases))
+    # EP: sparse deconvolution  GaussBernoulli -> Conv -> Gaussian likelihood
+    trajs = []
+    for name, shape, make, rho, damping in [
+            ("conv1d", (128,), lambda r: ConvChannel(filter=r.randn(128) / np.sqrt(128)), 0.1, None),
+            ("conv1d", (128,), lambda r: ConvChannel(filter=r.randn(128) / np.sqrt(128)), 0.1, 0.2),
+            ("conv1d_odd", (99,), lambda r: ConvChannel(filter=r.randn(99) / np.sqrt(99)), 0.2, None),
+            ("blur2d", (12, 16), lambda r: Blur2DChannel(sigma=[0.6, 0.8], shape=(12, 16)), 0.15, None)]:
+        r = np.random.RandomState(5)
+        ch = make(r)
+        x = r.standard_normal(shape) * r.binomial(n=1, size=shape, p=rho)
+        nv = 1e-3
+        y = ch.sample(x) + np.sqrt(nv) * r.standard_normal(shape)
+        model = (GaussBernoulliPrior(size=shape, rho=rho) @ V(id="x") @ ch @ V(id="z")
+                 @ GaussianLikelihood(y=y, var=nv)).to_model()
+        ep = ExpectationPropagation(model)
+        rec = Recorder(EarlyStoppingEP())
+        err = None
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=40, callback=rec, damping=damping)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        trajs.append(dict(name=name, shape=shape, rho=rho, noise_var=nv, damping=damping, x=x, y=y,
+                          filter=np.array(ch.filter), n_iter=ep.n_iter, error=err,
+                          n_recorded=len(rec.iters), traj=pack_traj(rec.iters[:12]),
+                          final_r=rec.iters[-1]["r:x"], mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2))))
+        print("conv ep", name, damping, "n_iter", ep.n_iter, err, "mse", trajs[-1]["mse"])
+    save("conv", data=np.array(out, dtype=object), ep=np.array(trajs, dtype=object))
+
+
 # ---------------------------------------------------------------- SE
 def se_goldens(skip_slow):
     out = {}
@@ -582,5 +652,7 @@ if __name__ == "__main__":
         linear_goldens()
     if not only or "ep" in only:
         ep_goldens()
+    if not only or "conv" in only:
+        conv_goldens()
     if not only or "se" in only:
         se_goldens(args.skip_slow)

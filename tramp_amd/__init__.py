@@ -15,7 +15,8 @@ from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, Relu
                           LeakyReluLikelihood, get_likelihood)
 from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
-                       SymmetricDoorChannel,
+                       SymmetricDoorChannel, ConvChannel, Blur1DChannel, Blur2DChannel,
+                       DifferentialChannel, LaplacianChannel,
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
 from .variables import SISOVariable, SILeafVariable
 from .models import Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution

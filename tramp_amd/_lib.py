@@ -72,6 +72,12 @@ _SIGNATURES = {
     "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
+    "tramp_conv_create": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],
+    "tramp_conv_destroy": [vp, vp],
+    "tramp_conv_spectrum": [vp, vp, vp, C.POINTER(sz), C.POINTER(dbl)],
+    "tramp_conv_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
+    "tramp_conv_apply": [vp, vp, sz, vp, vp],
+    "tramp_conv_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],

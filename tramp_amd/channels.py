@@ -546,6 +546,253 @@ class LinearChannel(Channel):
         return ret_scal(a_new, a, t), ret_vec(b_new, t)
 
 
+class ConvChannel(Channel):
+    """Circular convolution channel x = w * z for real signals (1-3 axes).
+
+    tramp/channels/linear/conv_channel.py:13-149 (``real=True``).  ``filter`` is the
+    filter f; the convolution weights are w[u] = f[-u] (fft(w) = conj(fft(f))).  All
+    O(n log n): batched rocFFT real transforms around hand-written spectral kernels
+    (csrc/conv.hip); no dense matrix exists at any point, so n = 10^6 and beyond fit.
+    Vectors are [batch, prod(shape)] on the device; host arrays of shape ``shape`` or
+    ``(batch,) + shape`` are accepted and returned in kind.
+    """
+
+    def __init__(self, filter, real=True, name="W", dtype=np.float64, ctx=None):
+        if not real:
+            raise NotImplementedError("complex ConvChannel (real=False) is outside the HIP path")
+        filter = np.asarray(filter, dtype=np.float64)
+        if not 1 <= filter.ndim <= 3:
+            raise ValueError("filter must have 1 to 3 axes")
+        self.shape = filter.shape
+        self.real = real
+        self.name = name
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.filter = filter
+        self.N = int(np.prod(self.shape))
+        self.Nx = self.Nz = self.N
+        ctx = self.ctx
+        fd = ctx.array(filter.reshape(-1), np.float64)
+        dims = (C.c_size_t * filter.ndim)(*self.shape)
+        h = C.c_void_p()
+        ctx._call("tramp_conv_create", self._dt, filter.ndim, dims, fd.ptr, C.byref(h))
+        self._handle = h
+        cnt, mean = C.c_size_t(), C.c_double()
+        ctx._call("tramp_conv_spectrum", h, None, C.byref(cnt), C.byref(mean))
+        self._n_half = cnt.value
+        self.spectrum_mean = mean.value
+        self._t_key = self._u_key = None
+
+    def __del__(self):
+        try:
+            if self._handle and self.ctx.handle:
+                self.ctx.lib.tramp_conv_destroy(self.ctx.handle, self._handle)
+        except Exception:
+            pass
+        self._handle = None
+
+    @property
+    def half_spectrum(self):
+        "|rfftn(filter)|^2 flattened (last axis n_last // 2 + 1 bins)."
+        out = self.ctx.empty((self._n_half,), np.float64)
+        self.ctx._call("tramp_conv_spectrum", self._handle, out.ptr, None, None)
+        return out.get()
+
+    # -- argument normalisation: flatten the signal axes
+    def _vec(self, b):
+        if isinstance(b, DeviceArray):
+            return VecArg(self.ctx, b, self.dtype)
+        h = np.asarray(b, dtype=self.dtype)
+        nd = len(self.shape)
+        if h.shape[-nd:] != tuple(self.shape) or h.ndim not in (nd, nd + 1):
+            raise ValueError(f"expected an array of shape {self.shape} or (batch,)+{self.shape}, got {h.shape}")
+        arg = VecArg(self.ctx, h.reshape(-1, self.N) if h.ndim == nd + 1 else h.reshape(self.N), self.dtype)
+        arg.host_shape = h.shape
+        arg._one = h.ndim == nd
+        return arg
+
+    @staticmethod
+    def _ret(dev, like):
+        if like.was_host:
+            return dev.get().reshape(like.host_shape)
+        return ret_vec(dev, like)
+
+    def convolve(self, z):
+        "conv_channel.py:47-55"
+        zz = self._vec(z)
+        x = self.ctx.empty((zz.batch, self.N), self.dtype)
+        self.ctx._call("tramp_conv_apply", self._handle, zz.batch, zz.dev.ptr, x.ptr)
+        self._t_key = self._u_key = None                       # the call reuses the projection buffers
+        return self._ret(x, zz)
+
+    def sample(self, Z):
+        return self.convolve(Z)                                # :57-63
+
+    def second_moment(self, tau_z):
+        return tau_z * self.spectrum_mean                      # :66-67
+
+    def device_variance(self, direction, az, ax):
+        "n_eff and the variances on the device for a batch of (az, ax): (v, a_new, n_eff)."
+        ctx = self.ctx
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        a_z = ctx.scalars(az_h)
+        a_x = ctx.scalars(ax, az_h.shape[0])
+        outs = [ctx.empty((az_h.shape[0],), np.float64) for _ in range(3)]
+        ctx._call("tramp_conv_variance", self._handle, direction, az_h.shape[0], a_z.ptr, a_x.ptr,
+                  *[o.ptr for o in outs])
+        return [o.get() for o in outs]
+
+    def compute_n_eff(self, az, ax):
+        return float(self.device_variance(_lib.BWD, az, ax)[2][0])     # :69-79
+
+    def compute_backward_variance(self, az, ax):
+        assert az > 0                                                  # :111-115
+        return float(self.device_variance(_lib.BWD, az, ax)[0][0])
+
+    def compute_forward_variance(self, az, ax):
+        return float(self.device_variance(_lib.FWD, az, ax)[0][0])     # :117-123
+
+    def compute_backward_error(self, az, ax, tau_z):
+        return self.compute_backward_variance(az, ax)                  # :137-139
+
+    def compute_forward_error(self, az, ax, tau_z):
+        return self.compute_forward_variance(az, ax)                   # :141-143
+
+    def _run(self, direction, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+             old_b=None, want_posterior=False):
+        ctx = self.ctx
+        z, x = self._vec(bz), self._vec(bx)
+        if z.n != self.N or x.n != self.N or z.batch != x.batch:
+            raise ValueError(f"expected bz and bx of [batch,{self.N}], got {z.dev.shape} and {x.dev.shape}")
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
+        a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((z.batch, self.N), self.dtype)
+        r = ctx.empty((z.batch, self.N), self.dtype) if want_posterior else None
+        v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        reuse = 0
+        kz, kx = LinearChannel._proj_key(bz, z), LinearChannel._proj_key(bx, x)
+        if kz is not None and kz == self._t_key:
+            reuse |= _lib.REUSE_T
+        if kx is not None and kx == self._u_key:
+            reuse |= _lib.REUSE_U
+        self._t_key, self._u_key = kz, kx
+        ctx._call("tramp_conv_message", self._handle, direction, z.batch, a_z.dev.ptr, z.dev.ptr,
+                  a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
+                  old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
+                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
+                  v.ptr if v is not None else None, reuse)
+        return tgt, a_t, a_new, b_new, r, v
+
+    def compute_backward_mean(self, az, bz, ax, bx):
+        return self.compute_backward_posterior(az, bz, ax, bx)[0]      # :81-103
+
+    def compute_forward_mean(self, az, bz, ax, bx):
+        return self.compute_forward_posterior(az, bz, ax, bx)[0]       # :105-109
+
+    def compute_backward_posterior(self, az, bz, ax, bx):
+        t, a, _, _, r, v = self._run(_lib.BWD, az, bz, ax, bx, want_posterior=True)
+        return self._ret(r, t), self._ret_scal(v, a, t)
+
+    def compute_forward_posterior(self, az, bz, ax, bx):
+        t, a, _, _, r, v = self._run(_lib.FWD, az, bz, ax, bx, want_posterior=True)
+        return self._ret(r, t), self._ret_scal(v, a, t)
+
+    def compute_forward_message(self, az, bz, ax, bx, **kw):
+        t, a, a_new, b_new, _, _ = self._run(_lib.FWD, az, bz, ax, bx, **kw)
+        return self._ret_scal(a_new, a, t), self._ret(b_new, t)
+
+    def compute_backward_message(self, az, bz, ax, bx, **kw):
+        t, a, a_new, b_new, _, _ = self._run(_lib.BWD, az, bz, ax, bx, **kw)
+        return self._ret_scal(a_new, a, t), self._ret(b_new, t)
+
+    @staticmethod
+    def _ret_scal(dev, like, vec_like):
+        if like.was_host and vec_like.was_host:
+            h = dev.get()
+            return float(h[0]) if (like.scalar_like and getattr(vec_like, "_one", False)) else h
+        return dev
+
+
+def _fd1(N):
+    "forward first-difference stencil (tramp/utils/conv_filters.py:29-34)"
+    f = np.zeros(N)
+    f[0], f[1] = -1, 1
+    return f
+
+
+def _fd2(N):
+    "second-difference stencil (conv_filters.py:37-42)"
+    f = np.zeros(N)
+    f[0] = -2
+    f[1] = f[-1] = 1
+    return f
+
+
+def _along_axis(stencil, axis, shape):
+    "place a 1-D stencil on `axis` at the origin of the other axes (conv_filters.py:55-78)"
+    f = np.zeros(shape)
+    idx = [0] * len(shape)
+    idx[axis] = slice(None)
+    f[tuple(idx)] = stencil(shape[axis])
+    return f
+
+
+def gaussian_filter(sigma, N):
+    "periodic Gaussian blur with unit DC gain (conv_filters.py:45-52)"
+    freq = np.fft.fftfreq(N)
+    return np.real(np.fft.ifft(np.exp(-2 * (np.pi * sigma)**2 * freq**2)))
+
+
+def differential_filter(shape, D1, D2=None):
+    "D = D1 . d/dx + D2 . d2/dx2 (conv_filters.py:81-90)"
+    d = len(shape)
+    D2 = D2 or np.zeros(d)
+    return sum(D1[ax] * _along_axis(_fd1, ax, shape) for ax in range(d)) + \
+        sum(D2[ax] * _along_axis(_fd2, ax, shape) for ax in range(d))
+
+
+def laplacian_filter(shape):
+    return sum(_along_axis(_fd2, ax, shape) for ax in range(len(shape)))     # conv_filters.py:93-99
+
+
+class DifferentialChannel(ConvChannel):
+    "conv_channel.py:166-176"
+
+    def __init__(self, D1, D2, shape, real=True, **kw):
+        super().__init__(filter=differential_filter(shape=tuple(shape), D1=D1, D2=D2), real=real, **kw)
+        self.D1, self.D2 = D1, D2
+
+
+class LaplacianChannel(ConvChannel):
+    "conv_channel.py:179-186"
+
+    def __init__(self, shape, real=True, **kw):
+        super().__init__(filter=laplacian_filter(tuple(shape)), real=real, **kw)
+
+
+class Blur1DChannel(ConvChannel):
+    "conv_channel.py:189-194"
+
+    def __init__(self, sigma, N, real=True, **kw):
+        super().__init__(filter=gaussian_filter(sigma=sigma, N=N), real=real, **kw)
+        self.sigma = sigma
+
+
+class Blur2DChannel(ConvChannel):
+    "conv_channel.py:197-208"
+
+    def __init__(self, sigma, shape, real=True, **kw):
+        if len(sigma) != 2:
+            raise ValueError("sigma must be a length 2 array")
+        if len(shape) != 2:
+            raise ValueError("shape must be a length 2 tuple")
+        f = np.outer(gaussian_filter(sigma=sigma[0], N=shape[0]), gaussian_filter(sigma=sigma[1], N=shape[1]))
+        super().__init__(filter=f, real=real, **kw)
+        self.sigma = sigma
+
+
 class AnalyticalLinearChannel(Channel):
     "SE-only linear channel with closed-form spectrum transforms (analytical_linear_channel.py:8-62)"
 
@@ -595,6 +842,11 @@ CHANNEL_CLASSES = {
     "h-tanh": HardTanhChannel,
     "h-sigm": HardSigmoidChannel,
     "door": SymmetricDoorChannel,
+    "conv": ConvChannel,
+    "blur_1d": Blur1DChannel,
+    "blur_2d": Blur2DChannel,
+    "diff": DifferentialChannel,
+    "laplacian": LaplacianChannel,
 }
 
 

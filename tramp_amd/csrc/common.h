@@ -16,6 +16,7 @@ enum TrampProfTag {
     PROF_LIN_SCALARS,   // K9 + spectral coefficients
     PROF_VAR_POST,      // K11
     PROF_OTHER,
+    PROF_FFT,           // rocFFT transforms (convolution channel)
     PROF_NTAGS
 };
 

@@ -1,0 +1,515 @@
+// conv.hip - circular-convolution linear channel x = w * z (real signals, 1-3 dimensions).
+//
+// tramp/channels/linear/conv_channel.py:13-149.  The operator is diagonal in the Fourier
+// basis, so the factor update is O(n log n) and never touches a dense matrix: with
+//     fz = rfft(bz), fx = rfft(bx), wbar = rfft(filter), s = |wbar|^2
+//     rz_fft = (fz + wbar fx) / (az + ax s)          (conv_channel.py:86-97)
+//     rx_fft = conj(wbar) rz_fft                     (conv_channel.py:105-109)
+// Real input => only the Hermitian half spectrum (last axis n_last/2+1) is stored and
+// streamed.  The transforms themselves are rocFFT plans (batched over the ensemble axis,
+// executing on the context's stream with a pre-reserved work buffer); everything between
+// them - the spectral solve, the message update epilogue, the scalar n_eff reduction - is
+// hand-written and HBM-streaming.  Like the dense channel, the handle keeps fz and fx so
+// the forward and backward update of one EP iteration share them (TRAMP_REUSE_T/U).
+#include <rocfft/rocfft.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "tramp_math.h"
+
+namespace {
+
+struct ConvPlans {
+    size_t batch;
+    rocfft_plan fwd, inv;
+    rocfft_execution_info info_fwd, info_inv;
+    void* work_fwd;
+    void* work_inv;
+};
+
+std::once_flag g_rocfft_once;
+
+template <typename T> struct Cx;
+template <> struct Cx<double> { using type = double2; };
+template <> struct Cx<float> { using type = float2; };
+
+}  // namespace
+
+struct tramp_conv {
+    int dtype;
+    int ndim;
+    size_t dims[3];
+    size_t n, nh, nlast, nhl;   // elements, half-spectrum elements, last axis, last axis half
+    void* wbar;                 // [nh] complex of dtype
+    double* s2;                 // [nh] spectrum (double)
+    double s_mean;              // mean of the full spectrum
+    std::vector<ConvPlans> plans;
+    void* work;                 // fz, fx, fo [batch, nh] complex + a_raw[batch] + partial sums
+    size_t work_batch, proj_batch;
+    void* fz;
+    void* fx;
+    void* fo;
+    void* fr;                   // [batch, n] real: the mean when b_new may alias b_old (damping)
+    double* a_raw;
+    double* partial;
+    int nblk;
+};
+
+namespace {
+
+int rocfft_fail(tramp_ctx* ctx, const char* what, rocfft_status st) {
+    char msg[64];
+    snprintf(msg, sizeof(msg), "rocfft status %d", (int)st);
+    return tramp_fail(ctx, TRAMP_EHIP, what, msg);
+}
+
+#define TRAMP_FFT_CHECK(ctx, call)                                   \
+    do {                                                             \
+        rocfft_status st_ = (call);                                  \
+        if (st_ != rocfft_status_success) return rocfft_fail(ctx, #call, st_); \
+    } while (0)
+
+int make_plan(tramp_ctx* ctx, const tramp_conv* cv, bool forward, bool f64, size_t batch, rocfft_plan* plan,
+              rocfft_execution_info* info, void** work) {
+    size_t lengths[3];
+    for (int d = 0; d < cv->ndim; ++d) lengths[d] = cv->dims[cv->ndim - 1 - d];   // rocFFT: fastest axis first
+    TRAMP_FFT_CHECK(ctx, rocfft_plan_create(plan, rocfft_placement_notinplace,
+                                            forward ? rocfft_transform_type_real_forward
+                                                    : rocfft_transform_type_real_inverse,
+                                            f64 ? rocfft_precision_double : rocfft_precision_single,
+                                            (size_t)cv->ndim, lengths, batch, nullptr));
+    size_t wsz = 0;
+    TRAMP_FFT_CHECK(ctx, rocfft_plan_get_work_buffer_size(*plan, &wsz));
+    TRAMP_FFT_CHECK(ctx, rocfft_execution_info_create(info));
+    *work = nullptr;
+    if (wsz) {
+        TRAMP_HIP_CHECK(ctx, hipMalloc(work, wsz));
+        TRAMP_FFT_CHECK(ctx, rocfft_execution_info_set_work_buffer(*info, *work, wsz));
+    }
+    TRAMP_FFT_CHECK(ctx, rocfft_execution_info_set_stream(*info, ctx->stream));
+    return TRAMP_OK;
+}
+
+int plans_for(tramp_ctx* ctx, tramp_conv* cv, size_t batch, ConvPlans** out) {
+    for (auto& p : cv->plans)
+        if (p.batch == batch) {
+            *out = &p;
+            return TRAMP_OK;
+        }
+    if (ctx->capturing) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_conv", "FFT plan creation inside graph capture");
+    ConvPlans p{};
+    p.batch = batch;
+    const bool f64 = cv->dtype == TRAMP_F64;
+    int rc = make_plan(ctx, cv, true, f64, batch, &p.fwd, &p.info_fwd, &p.work_fwd);
+    if (rc) return rc;
+    rc = make_plan(ctx, cv, false, f64, batch, &p.inv, &p.info_inv, &p.work_inv);
+    if (rc) return rc;
+    cv->plans.push_back(p);
+    *out = &cv->plans.back();
+    return TRAMP_OK;
+}
+
+int fft_exec(tramp_ctx* ctx, rocfft_plan plan, rocfft_execution_info info, const void* in, void* out) {
+    void* ib[1] = {const_cast<void*>(in)};
+    void* ob[1] = {out};
+    TRAMP_FFT_CHECK(ctx, rocfft_execute(plan, ib, ob, info));
+    return TRAMP_OK;
+}
+
+int conv_reserve(tramp_ctx* ctx, tramp_conv* cv, size_t batch) {
+    if (batch <= cv->work_batch) return TRAMP_OK;
+    if (ctx->capturing) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_conv", "workspace growth inside graph capture");
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (cv->work) (void)hipFree(cv->work);
+    cv->work = nullptr;
+    cv->work_batch = 0;
+    const size_t csz = 2 * dtype_size(cv->dtype);
+    const size_t per = ((batch * cv->nh * csz + 255) / 256) * 256;
+    const size_t scal = ((batch * sizeof(double) + 255) / 256) * 256;
+    const size_t part = ((batch * (size_t)cv->nblk * sizeof(double) + 255) / 256) * 256;
+    const size_t rper = ((batch * cv->n * dtype_size(cv->dtype) + 255) / 256) * 256;
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->work, 3 * per + rper + scal + part));
+    char* p = (char*)cv->work;
+    cv->fz = p;
+    cv->fx = p + per;
+    cv->fo = p + 2 * per;
+    cv->fr = p + 3 * per;
+    cv->a_raw = (double*)(p + 3 * per + rper);
+    cv->partial = (double*)(p + 3 * per + rper + scal);
+    cv->work_batch = batch;
+    cv->proj_batch = 0;
+    return TRAMP_OK;
+}
+
+// ---- setup: spectrum and filter transform in the working precision
+template <typename T>
+__global__ __launch_bounds__(kBlock) void conv_setup_kernel(const double2* __restrict__ w64, size_t nh,
+                                                            typename Cx<T>::type* __restrict__ wbar,
+                                                            double* __restrict__ s2) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nh) return;
+    const double2 w = w64[i];
+    typename Cx<T>::type o;
+    o.x = (T)w.x;
+    o.y = (T)w.y;
+    wbar[i] = o;
+    s2[i] = w.x * w.x + w.y * w.y;                                     // conv_channel.py:45
+}
+
+// Multiplicity of half-spectrum bin j of the last axis in the full spectrum.
+__device__ __forceinline__ double herm_weight(size_t j, size_t nlast) {
+    return (j == 0 || 2 * j == nlast) ? 1.0 : 2.0;
+}
+
+// ---- K9 for the convolution: n_eff = mean(s / (az/ax + s)) over the FULL spectrum
+// (conv_channel.py:69-79), two deterministic stages.
+__global__ __launch_bounds__(kBlock) void conv_neff_partial_kernel(const double* __restrict__ s2, size_t nh,
+                                                                   size_t nhl, size_t nlast,
+                                                                   const double* __restrict__ az_d,
+                                                                   const double* __restrict__ ax_d,
+                                                                   double* __restrict__ partial) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    const double az = az_d[b], ax = ax_d[b];
+    double s = 0.0;
+    if (ax != 0.0 && az / ax != 0.0) {
+        const double q = az / ax;
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nh; i += (size_t)gridDim.x * kBlock) {
+            const double sp = s2[i];
+            s += herm_weight(i % nhl, nlast) * (sp / (q + sp));
+        }
+    }
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void conv_variance_kernel(const double* __restrict__ partial, int nblk, double n, double s_mean, int dir,
+                                     const double* __restrict__ az_d, const double* __restrict__ ax_d,
+                                     double damping, const double* __restrict__ a_old, double* __restrict__ v_out,
+                                     double* __restrict__ a_new_out, double* __restrict__ a_new_raw,
+                                     double* __restrict__ n_eff_out, size_t batch) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double az = az_d[b], ax = ax_d[b];
+    double n_eff;
+    if (ax == 0.0) n_eff = 0.0;                                        // :71-73
+    else if (az / ax == 0.0) n_eff = 1.0;                              // :74-76
+    else {
+        double s = 0.0;
+        for (int j = 0; j < nblk; ++j) s += partial[b * nblk + j];
+        n_eff = s / n;                                                 // :77-78
+    }
+    double v, a_in;
+    if (dir == TRAMP_FWD) {
+        v = (ax == 0.0) ? s_mean / az : n_eff / ax;                    // :117-123
+        a_in = ax;
+    } else {
+        v = (1.0 - n_eff) / az;                                        // :111-115
+        a_in = az;
+    }
+    const double an = tmath::a_new_of(v, a_in);
+    if (a_new_raw) a_new_raw[b] = an;
+    if (a_new_out) a_new_out[b] = (damping != 0.0) ? damping * a_old[b] + (1.0 - damping) * an : an;
+    if (v_out) v_out[b] = v;
+    if (n_eff_out) n_eff_out[b] = n_eff;
+}
+
+// ---- spectral solve.  mode 0: out = conj(wbar) rz_fft / n (forward mean), 1: out = rz_fft / n
+// (backward mean), 2: out = conj(wbar) fz / n (plain convolution, sampling).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void conv_spectral_kernel(int mode, size_t nh, double inv_n,
+                                                               const typename Cx<T>::type* __restrict__ wbar,
+                                                               const double* __restrict__ s2,
+                                                               const double* __restrict__ az_d,
+                                                               const double* __restrict__ ax_d,
+                                                               const typename Cx<T>::type* __restrict__ fz,
+                                                               const typename Cx<T>::type* __restrict__ fx,
+                                                               typename Cx<T>::type* __restrict__ fo) {
+    using C = typename Cx<T>::type;
+    const size_t b = blockIdx.y;
+    const double az = (mode == 2) ? 0.0 : az_d[b];
+    const double ax = (mode == 2) ? 0.0 : ax_d[b];
+    const size_t base = b * nh;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nh; i += (size_t)gridDim.x * kBlock) {
+        const C w = wbar[i];
+        const C z = fz[base + i];
+        C o;
+        if (mode == 2) {
+            const T sc = (T)inv_n;
+            o.x = (w.x * z.x + w.y * z.y) * sc;                        // conj(w) z
+            o.y = (w.x * z.y - w.y * z.x) * sc;
+        } else {
+            const C x = fx[base + i];
+            const T res = (T)(inv_n / (az + ax * s2[i]));              // resolvent, :92
+            C rz;
+            rz.x = (z.x + (w.x * x.x - w.y * x.y)) * res;              // (fz + wbar fx) resolvent, :93
+            rz.y = (z.y + (w.x * x.y + w.y * x.x)) * res;
+            if (mode == 1) o = rz;
+            else {
+                o.x = w.x * rz.x + w.y * rz.y;                         // w_fft = conj(wbar), :107
+                o.y = w.x * rz.y - w.y * rz.x;
+            }
+        }
+        fo[base + i] = o;
+    }
+}
+
+// ---- message update on the inverse-transformed mean (tramp/channels/base_channel.py:9-17,
+// tramp/base.py:245-254), damping fused; r may be updated in place.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void conv_epilogue_kernel(size_t n, const double* __restrict__ a_in,
+                                                               const double* __restrict__ a_raw,
+                                                               const T* __restrict__ b_in, double damping,
+                                                               const T* b_old, const T* r, T* out, T* r_out) {
+    const size_t b = blockIdx.y;
+    const T asum = (T)(a_in[b] + a_raw[b]);
+    const T d = (T)damping, omd = (T)(1.0 - damping);
+    const size_t base = b * n;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const T rv = r[base + i];
+        T bn = rv * asum - b_in[base + i];
+        if (damping != 0.0) bn = d * b_old[base + i] + omd * bn;
+        out[base + i] = bn;
+        if (r_out) r_out[base + i] = rv;
+    }
+}
+
+unsigned grid_for(size_t n) {
+    size_t g = (n + (size_t)kBlock * 4 - 1) / ((size_t)kBlock * 4);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (unsigned)g;
+}
+
+int conv_scalars(tramp_ctx* ctx, const tramp_conv* cv, double* partial, int dir, size_t batch, const double* az_d,
+                 const double* ax_d, double damping, const double* a_old, double* v_d, double* a_new_d,
+                 double* a_raw, double* n_eff_d) {
+    hipLaunchKernelGGL(conv_neff_partial_kernel, dim3((unsigned)cv->nblk, (unsigned)batch), dim3(kBlock), 0,
+                       ctx->stream, cv->s2, cv->nh, cv->nhl, cv->nlast, az_d, ax_d, partial);
+    hipLaunchKernelGGL(conv_variance_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, partial,
+                       cv->nblk, (double)cv->n, cv->s_mean, dir, az_d, ax_d, damping, a_old, v_d, a_new_d, a_raw,
+                       n_eff_d, batch);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+}  // namespace
+
+extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filter_d,
+                                 tramp_conv** conv) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, conv && dims && filter_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F64 || dtype == TRAMP_F32);
+    TRAMP_REQUIRE(ctx, ndim >= 1 && ndim <= 3);
+    std::call_once(g_rocfft_once, [] { (void)rocfft_setup(); });
+    tramp_conv* cv = new tramp_conv();
+    cv->dtype = dtype;
+    cv->ndim = ndim;
+    cv->n = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (dims[d] == 0) {
+            delete cv;
+            return tramp_fail(ctx, TRAMP_EINVAL, "tramp_conv_create", "zero-length axis");
+        }
+        cv->dims[d] = dims[d];
+        cv->n *= dims[d];
+    }
+    cv->nlast = dims[ndim - 1];
+    cv->nhl = cv->nlast / 2 + 1;
+    cv->nh = cv->n / cv->nlast * cv->nhl;
+    cv->nblk = (int)((cv->nh + 4095) / 4096 > 256 ? 256 : (cv->nh + 4095) / 4096);
+    cv->work = nullptr;
+    cv->work_batch = cv->proj_batch = 0;
+    // filter transform in f64 regardless of the working precision (the scalars are f64)
+    rocfft_plan plan;
+    rocfft_execution_info info;
+    void* pwork = nullptr;
+    double2* w64 = nullptr;
+    int rc = make_plan(ctx, cv, true, true, 1, &plan, &info, &pwork);
+    if (rc) {
+        delete cv;
+        return rc;
+    }
+    const size_t csz = 2 * dtype_size(dtype);
+    hipError_t e = hipMalloc(&w64, cv->nh * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&cv->wbar, cv->nh * csz);
+    if (e == hipSuccess) e = hipMalloc(&cv->s2, cv->nh * sizeof(double));
+    if (e != hipSuccess) {
+        delete cv;
+        return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_conv_create", hipGetErrorString(e));
+    }
+    rc = fft_exec(ctx, plan, info, filter_d, w64);
+    if (rc) return rc;
+    const unsigned g = (unsigned)((cv->nh + kBlock - 1) / kBlock);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((conv_setup_kernel<double>), dim3(g), dim3(kBlock), 0, ctx->stream, w64, cv->nh,
+                           (double2*)cv->wbar, cv->s2);
+    else
+        hipLaunchKernelGGL((conv_setup_kernel<float>), dim3(g), dim3(kBlock), 0, ctx->stream, w64, cv->nh,
+                           (float2*)cv->wbar, cv->s2);
+    TRAMP_LAUNCH_CHECK(ctx);
+    // mean of the full spectrum (second_moment, ax = 0 branch): host fold, setup only
+    std::vector<double> s2h(cv->nh);
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(s2h.data(), cv->s2, cv->nh * sizeof(double), hipMemcpyDeviceToHost,
+                                        ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    long double acc = 0.0L;
+    for (size_t i = 0; i < cv->nh; ++i) {
+        const size_t j = i % cv->nhl;
+        acc += ((j == 0 || 2 * j == cv->nlast) ? 1.0L : 2.0L) * (long double)s2h[i];
+    }
+    cv->s_mean = (double)(acc / (long double)cv->n);
+    (void)hipFree(w64);
+    if (pwork) (void)hipFree(pwork);
+    (void)rocfft_execution_info_destroy(info);
+    (void)rocfft_plan_destroy(plan);
+    *conv = cv;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_conv_destroy(tramp_ctx* ctx, tramp_conv* cv) {
+    if (!cv) return TRAMP_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : cv->plans) {
+        (void)rocfft_execution_info_destroy(p.info_fwd);
+        (void)rocfft_execution_info_destroy(p.info_inv);
+        (void)rocfft_plan_destroy(p.fwd);
+        (void)rocfft_plan_destroy(p.inv);
+        if (p.work_fwd) (void)hipFree(p.work_fwd);
+        if (p.work_inv) (void)hipFree(p.work_inv);
+    }
+    if (cv->work) (void)hipFree(cv->work);
+    if (cv->wbar) (void)hipFree(cv->wbar);
+    if (cv->s2) (void)hipFree(cv->s2);
+    delete cv;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_conv_spectrum(tramp_ctx* ctx, const tramp_conv* cv, double* s2_d, size_t* count,
+                                   double* mean) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, cv);
+    if (count) *count = cv->nh;
+    if (mean) *mean = cv->s_mean;
+    if (s2_d)
+        TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(s2_d, cv->s2, cv->nh * sizeof(double), hipMemcpyDeviceToDevice,
+                                            ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_conv_variance(tramp_ctx* ctx, tramp_conv* cv, int dir, size_t batch, const double* az_d,
+                                   const double* ax_d, double* v_d, double* a_new_d, double* n_eff_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, cv && az_d && ax_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    if (!batch) return TRAMP_OK;
+    int rc = tramp_ws_reserve(ctx, batch * (size_t)cv->nblk * sizeof(double));
+    if (rc) return rc;
+    return conv_scalars(ctx, cv, ctx->ws, dir, batch, az_d, ax_d, 0.0, nullptr, v_d, a_new_d, nullptr, n_eff_d);
+}
+
+extern "C" int tramp_conv_apply(tramp_ctx* ctx, tramp_conv* cv, size_t batch, const void* z_d, void* x_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, cv && z_d && x_d);
+    if (!batch) return TRAMP_OK;
+    int rc = conv_reserve(ctx, cv, batch);
+    if (rc) return rc;
+    ConvPlans* p;
+    rc = plans_for(ctx, cv, batch, &p);
+    if (rc) return rc;
+    cv->proj_batch = 0;                                               // fz is overwritten below
+    rc = fft_exec(ctx, p->fwd, p->info_fwd, z_d, cv->fz);
+    if (rc) return rc;
+    dim3 g(grid_for(cv->nh), (unsigned)batch);
+    if (cv->dtype == TRAMP_F64)
+        hipLaunchKernelGGL((conv_spectral_kernel<double>), g, dim3(kBlock), 0, ctx->stream, 2, cv->nh, 1.0 / cv->n,
+                           (const double2*)cv->wbar, cv->s2, (const double*)nullptr, (const double*)nullptr,
+                           (const double2*)cv->fz, (const double2*)nullptr, (double2*)cv->fo);
+    else
+        hipLaunchKernelGGL((conv_spectral_kernel<float>), g, dim3(kBlock), 0, ctx->stream, 2, cv->nh, 1.0 / cv->n,
+                           (const float2*)cv->wbar, cv->s2, (const double*)nullptr, (const double*)nullptr,
+                           (const float2*)cv->fz, (const float2*)nullptr, (float2*)cv->fo);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return fft_exec(ctx, p->inv, p->info_inv, cv->fo, x_d);
+}
+
+extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_t batch, const double* az_d,
+                                  const void* bz_d, const double* ax_d, const void* bx_d, double damping,
+                                  const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d,
+                                  void* r_d, double* v_d, int reuse) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, cv && az_d && bz_d && ax_d && bx_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!batch) return TRAMP_OK;
+    const void* work_before = cv->work;
+    int rc = conv_reserve(ctx, cv, batch);
+    if (rc) return rc;
+    if (cv->work != work_before || cv->proj_batch != batch) reuse = 0;
+    cv->proj_batch = batch;
+    ConvPlans* p;
+    rc = plans_for(ctx, cv, batch, &p);
+    if (rc) return rc;
+    const size_t n = cv->n, nh = cv->nh;
+    const size_t esz = dtype_size(cv->dtype);
+    // 1. scalars
+    {
+        ProfScope ps(ctx, PROF_LIN_SCALARS, 0, 0);
+        rc = conv_scalars(ctx, cv, cv->partial, dir, batch, az_d, ax_d, damping, a_old_d, v_d, a_new_d, cv->a_raw,
+                          nullptr);
+        if (rc) return rc;
+    }
+    // 2. transforms of the incoming messages (shared by the two directions of one iteration)
+    if (!(reuse & TRAMP_REUSE_T)) {
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz + nh * 2 * esz), 0);
+        rc = fft_exec(ctx, p->fwd, p->info_fwd, bz_d, cv->fz);
+        if (rc) return rc;
+    }
+    if (!(reuse & TRAMP_REUSE_U)) {
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz + nh * 2 * esz), 0);
+        rc = fft_exec(ctx, p->fwd, p->info_fwd, bx_d, cv->fx);
+        if (rc) return rc;
+    }
+    // 3. spectral solve
+    {
+        ProfScope ps(ctx, PROF_LIN_SCALARS, (double)batch * nh * 6 * esz + nh * (2 * esz + 8.0), 0);
+        const int mode = (dir == TRAMP_FWD) ? 0 : 1;
+        dim3 g(grid_for(nh), (unsigned)batch);
+        if (cv->dtype == TRAMP_F64)
+            hipLaunchKernelGGL((conv_spectral_kernel<double>), g, dim3(kBlock), 0, ctx->stream, mode, nh, 1.0 / n,
+                               (const double2*)cv->wbar, cv->s2, az_d, ax_d, (const double2*)cv->fz,
+                               (const double2*)cv->fx, (double2*)cv->fo);
+        else
+            hipLaunchKernelGGL((conv_spectral_kernel<float>), g, dim3(kBlock), 0, ctx->stream, mode, nh, 1.0 / n,
+                               (const float2*)cv->wbar, cv->s2, az_d, ax_d, (const float2*)cv->fz,
+                               (const float2*)cv->fx, (float2*)cv->fo);
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    // 4. back to the signal domain; the mean lands in r_d when asked for, else in b_new_d
+    //    (scratch under damping: b_old usually IS b_new and must survive the transform)
+    void* mean = r_d ? r_d : (damping != 0.0 ? cv->fr : b_new_d);
+    {
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz + nh * 2 * esz), 0);
+        rc = fft_exec(ctx, p->inv, p->info_inv, cv->fo, mean);
+        if (rc) return rc;
+    }
+    // 5. message update (in place on the mean)
+    {
+        ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (damping != 0.0 ? 4 : 3), 0);
+        const double* a_in = (dir == TRAMP_FWD) ? ax_d : az_d;
+        const void* b_in = (dir == TRAMP_FWD) ? bx_d : bz_d;
+        dim3 g(grid_for(n), (unsigned)batch);
+        if (cv->dtype == TRAMP_F64)
+            hipLaunchKernelGGL((conv_epilogue_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n, a_in, cv->a_raw,
+                               (const double*)b_in, damping, (const double*)b_old_d, (const double*)mean,
+                               (double*)b_new_d, (double*)nullptr);
+        else
+            hipLaunchKernelGGL((conv_epilogue_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n, a_in, cv->a_raw,
+                               (const float*)b_in, damping, (const float*)b_old_d, (const float*)mean,
+                               (float*)b_new_d, (float*)nullptr);
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    return TRAMP_OK;
+}

@@ -11,7 +11,7 @@ import networkx as nx
 import numpy as np
 
 from .base import Factor, Variable
-from .channels import (GaussianChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
+from .channels import (ConvChannel, GaussianChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
                        PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
@@ -133,6 +133,8 @@ class Model:
                 shape = (node.size,) if np.isscalar(node.size) else tuple(node.size)
             elif isinstance(node, LinearChannel):
                 shape = (node.Nx,)
+            elif isinstance(node, ConvChannel):
+                shape = tuple(node.shape)
             if isinstance(node, Variable):
                 shapes[node.id] = shape
                 self.dag.nodes[node]["shape"] = shape
