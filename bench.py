@@ -94,11 +94,11 @@ def cpu_baseline(args):
 def denoiser_roofline(T, ctx, dtype):
     """Gauss-Bernoulli denoiser (K1) at the BASELINE vector size N = 1e6: single instance
     (latency regime, data stays in cache) and a 64-instance ensemble (512 MB per array, past
-    the 256 MB Infinity Cache).  Algorithmic traffic 2T bytes per component."""
+    the 256 MB Infinity Cache); plus 4096 instances of n = 4096, where an instance fits one
+    workgroup's registers and the update is a single pass.  Algorithmic traffic 2T bytes per component."""
     out = {}
     np_dt = np.float64 if dtype == "f64" else np.float32
-    for B in (1, 64):
-        N = 1_000_000
+    for B, N in ((1, 1_000_000), (64, 1_000_000), (4096, 4096)):
         bx = ctx.randn((B, N), np_dt, seed=3, scale=1.5)
         ax = ctx.scalars(1.3, B)
         p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
@@ -114,7 +114,7 @@ def denoiser_roofline(T, ctx, dtype):
         e1.record()
         ms = e0.elapsed_ms(e1) / reps
         alg = 2 * np.dtype(np_dt).itemsize * N * B
-        out[f"B{B}"] = {"n": N, "batch": B, "us_per_update": ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
+        out[f"B{B}" if N == 1_000_000 else f"B{B}_n{N}"] = {"n": N, "batch": B, "us_per_update": ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
                         "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
                         "components_per_sec": N * B / (ms * 1e-3)}
         del bx, b_new

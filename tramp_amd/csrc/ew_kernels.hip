@@ -386,6 +386,100 @@ __global__ __launch_bounds__(kBlock) void ew_pass2_recompute(Op op, size_t n, si
     }
 }
 
+// ---------------------------------------------------------------- single-launch form (small n)
+// An instance that fits one workgroup's registers (n <= 256 threads x 8 vectors: 4096 f64 /
+// 8192 f32 components) needs no second pass: load the tile, (r_i, v_i), block sum, a_new,
+// b_new from the registers, store - one launch, each byte moved once.  This is the latency
+// regime (BASELINE configs[0], N = 1000): one launch instead of two per factor update.
+// The same idea across SEVERAL workgroups (a team of P resident blocks per instance, partial
+// sums and arrive/leave counters as agent-scope atomics, tile kept in registers across the
+// team barrier) was built and measured on MI355X and does NOT pay: 64 x 10^6 f64 took
+// 1.3-1.8 ms against 0.30-0.38 ms for the two-pass kernels below.  A barrier round costs
+// ~15-20 us of pure latency (store ack -> atomic -> poll -> partial loads), the chip holds
+// only ~50 MB of tiles per round, and three waves per SIMD (147 VGPRs with the tile resident)
+// cannot overlap enough rounds; an agent-scope RELEASE on the arrival additionally writes
+// back the whole L2 (buffer_wbl2).  Two streaming passes with thousands of independent
+// workgroups win by 4x, so that is what large instances use.
+constexpr int kSingleVpt = 8;
+
+template <typename T, typename Op>
+__global__ __launch_bounds__(kBlock) void ew_single(Op op, size_t n, const T* __restrict__ in0,
+                                                    const T* __restrict__ in1, MsgOut out) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    constexpr int VPT = kSingleVpt;
+    __shared__ double smem[kBlock / kWave];
+    __shared__ unsigned long long smem_u[kBlock / kWave];
+    const size_t b = blockIdx.x;
+    const size_t nv = n / VN;
+    const double d = out.damping;
+    const T dT = T(d), omd = T(1.0 - d);
+    op.setup(b);
+    const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
+    const V* p1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
+    V tgt[VPT], oth[VPT], rr[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const size_t i = threadIdx.x + (size_t)k * kBlock;
+        if (i < nv) {
+            const V a0 = p0[i];
+            V a1 = a0;
+            if (Op::NIN > 1) a1 = p1[i];
+            tgt[k] = (Op::TARGET == 0) ? a0 : a1;
+            oth[k] = (Op::TARGET == 0) ? a1 : a0;
+        }
+    }
+    double acc = 0.0;
+    unsigned long long cnt = 0;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const size_t i = threadIdx.x + (size_t)k * kBlock;
+        if (i < nv) {
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                const T xt = vget<T>(tgt[k], j), xo = vget<T>(oth[k], j);
+                EwOut<T> o = op.eval((Op::TARGET == 0) ? xt : xo, (Op::TARGET == 0) ? xo : xt);
+                acc += (double)o.v;
+                if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
+                cnt += o.mask & 1u;
+                vset<T>(rr[k], j, o.r);
+            }
+        }
+    }
+    acc = block_sum(acc, smem);
+    if (out.count) cnt = block_sum_u64(cnt, smem_u);
+    const double v = acc / (double)n;
+    const double a_in = op.a_msg;
+    const double a_new = tmath::a_new_of(v, a_in);
+    if (threadIdx.x == 0) {
+        double a_out = a_new;
+        if (d != 0.0) a_out = d * out.a_old[b] + (1.0 - d) * a_new;
+        out.a_new[b] = a_out;
+        if (out.v) out.v[b] = v;
+        if (out.count) out.count[b] = cnt;
+    }
+    const T vinv = T(a_in + a_new);
+    V* bo = reinterpret_cast<V*>(reinterpret_cast<T*>(out.b_new) + b * n);
+    const V* bold = (d != 0.0) ? reinterpret_cast<const V*>(reinterpret_cast<const T*>(out.b_old) + b * n) : nullptr;
+    V* ro = out.r ? reinterpret_cast<V*>(reinterpret_cast<T*>(out.r) + b * n) : nullptr;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const size_t i = threadIdx.x + (size_t)k * kBlock;
+        if (i < nv) {
+            V vo, vold;
+            if (bold) vold = bold[i];
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                T bn = vget<T>(rr[k], j) * vinv - vget<T>(tgt[k], j);
+                if (bold) bn = dT * vget<T>(vold, j) + omd * bn;
+                vset<T>(vo, j, bn);
+            }
+            bo[i] = vo;
+            if (ro) ro[i] = rr[k];
+        }
+    }
+}
+
 // Instances are processed in chunks small enough that pass 2 finds r and b in the
 // 256 MiB Infinity Cache: HBM then sees each input once and b_new once (2T / 3T per
 // component, the algorithmic minimum) although the update is two launches.
@@ -410,6 +504,20 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
     static const size_t mode_env = env_size("TRAMP_EW_MODE", 2);           // 0 store, 1 recompute, 2 auto
     static const size_t chunk_mb = env_size("TRAMP_EW_CHUNK_MB", 0);        // 0: whole batch per launch
     const bool store_r = mode_env == 0 || (mode_env == 2 && Op::HEAVY);
+    static const size_t single_env = env_size("TRAMP_EW_SINGLE", 1);        // 0: always two-pass
+    // heavy factors hold 200+ VGPRs with the tile resident (1 wave/SIMD, 16 serial evaluations per
+    // thread): single launch only when each thread has <= 2 vectors or instances alone fill the chip
+    const size_t tile = (size_t)kBlock * kSingleVpt * VN;
+    const bool single_ok = n <= tile && (!Op::HEAVY || n <= tile / 4 || batch >= 1024);
+    if (single_env && vec && !out.mask && single_ok) {
+        MsgOut o = out;
+        if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
+        ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
+        hipLaunchKernelGGL((ew_single<T, Op>), dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, op, n,
+                           reinterpret_cast<const T*>(in0), reinterpret_cast<const T*>(in1), o);
+        TRAMP_LAUNCH_CHECK(ctx);
+        return TRAMP_OK;
+    }
     // chunk: inputs (+ r scratch) of `cb` instances within the cache budget
     size_t cb = (chunk_mb << 20) / (n * sizeof(T) * (Op::NIN + (store_r ? 1 : 0)));
     if (cb < 1) cb = 1;
