@@ -279,6 +279,17 @@ int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batc
 #define TRAMP_REUSE_T 1
 #define TRAMP_REUSE_U 2
 
+/* Constant damping of a CONSTANT factor's message (tramp/algos/message_passing.py:119-127
+ * applied to e.g. GaussianLikelihood's backward message) replaces the message on one side of
+ * the channel by  b <- damping * b + (1 - damping) * c  with the same c every iteration.  The
+ * projections are linear, so the cached one follows with O(k) work instead of a matrix pass:
+ *    p <- damping * p + (1 - damping) * P c ,   P c computed once (again when c_changed != 0).
+ * `which` is TRAMP_REUSE_T (the message is bz) or TRAMP_REUSE_U (bx); the handle must hold the
+ * projection of the message as it was BEFORE the update (TRAMP_EINVAL otherwise).  Afterwards
+ * the caller may claim the corresponding TRAMP_REUSE_* bit in the next tramp_linear_message. */
+int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, int which, size_t batch,
+                                const void* c_d, double damping, int c_changed);
+
 /* Building blocks of K8, exported for tests, profiling and the roofline bench:
  *   NT: out[b, r] = sum_c mat[r, c] * x[b, c]     mat [R, C] row-major
  *   NN: out[b, c] = sum_r mat[r, c] * x[b, r]
@@ -312,6 +323,9 @@ int tramp_conv_apply(tramp_ctx* ctx, tramp_conv* conv, size_t batch, const void*
 /* ConvChannel.compute_backward_mean / compute_forward_mean (conv_channel.py:81-109) with the
  * fused message update; arguments and `reuse` exactly as tramp_linear_message (the cached
  * projections are rfft(bz) and rfft(bx)).  bz_d, bx_d, b_new_d, r_d: [batch, n]. */
+/* As tramp_linear_project_affine, for the cached transforms rfft(bz) / rfft(bx). */
+int tramp_conv_project_affine(tramp_ctx* ctx, tramp_conv* conv, int which, size_t batch,
+                              const void* c_d, double damping, int c_changed);
 int tramp_conv_message(tramp_ctx* ctx, tramp_conv* conv, int dir, size_t batch,
                        const double* az_d, const void* bz_d,
                        const double* ax_d, const void* bx_d,

@@ -267,3 +267,39 @@ def test_ep_agrees_with_state_evolution_at_large_n(ctx):
     v_se = se.get_variables_data()["x"]["v"]
     assert np.all(np.abs(v_ep - v_se) < 0.15 * v_se), (v_ep, v_se)
     assert np.all(np.abs(mse - v_se) < 0.25 * v_se), (mse, v_se)
+
+
+def test_damped_constant_message_needs_no_matrix_pass(ctx):
+    """Constant damping of the Gaussian likelihood's (constant) message changes bx every iteration,
+    but affinely: the cached projection u = Uk^T bx follows by linearity (tramp_linear_project_affine),
+    so an iteration runs 3 matrix passes, not 4, and still matches the oracle's EP."""
+    import ctypes as C
+    import tramp_amd as T
+    N, M, rho, nv, B, d = 256, 128, 0.1, 1e-2, 3, 0.3
+    rs = np.random.RandomState(5)
+    W = rs.randn(M, N) / np.sqrt(N)
+    X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(B)])
+    Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=3, callback=T.PassCallback(), damping=d)
+    ctx._call("tramp_profile_enable", 1)
+    ep.iterate(max_iter=4, callback=T.PassCallback(), damping=d, warm_start=True)
+    cnt, ms, by, fl = (C.c_int * 8)(), (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+    ctx._call("tramp_profile_report", cnt, ms, by, fl)
+    ctx._call("tramp_profile_enable", 0)
+    assert cnt[1] + cnt[2] == 3 * 4, (cnt[1], cnt[2])          # matvec_nt + matvec_nn launches
+    r = ep.get_variables_data()["x"]["r"].reshape(B, N)
+    lin = orc.LinearFactor(W, thin=True)
+    for b in range(B):
+        fs = [orc.GBPriorFactor(N, rho=rho), lin, orc.GaussLikFactor(Y[b], nv)]
+        res = orc.ep_chain(fs, [N, M], max_iter=7, damping=d, tol=0.0)
+        close(r[b], res["r"][0], 1e-7)
+    # the raw entry point: p <- d p + (1-d) P c equals the projection of the damped message
+    lin_ch = model.factors[1]
+    with pytest.raises(T._lib.TrampHipError):
+        fresh = T.LinearChannel(W, ctx=ctx, svd="host")
+        ctx._call("tramp_linear_project_affine", fresh._handle, T._lib.REUSE_U, B, ctx.array(Y).ptr, 0.5, 1)
+    assert lin_ch._u_key is not None

@@ -212,8 +212,17 @@ class ExpectationPropagation:
         for buf in self.b_fwd + self.b_bwd:
             buf.version = 0
         self._scratch = {}
+        self._const_b = {}
         self._const_done = set()
         self._allocated = True
+
+    def _const_b_for(self, i, direction, sb):
+        "Keeps the constant part c of a damped constant message (sb is overwritten by the damped result)."
+        key = (i, direction)
+        if key not in self._const_b:
+            self._const_b[key] = self.ctx.empty(tuple(sb.shape), self.dtype)
+            self._const_b[key].copy_from(sb)
+        return self._const_b[key]
 
     def _scratch_for(self, i):
         if i not in self._scratch:
@@ -261,14 +270,23 @@ class ExpectationPropagation:
         else:
             factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out],
                                             self.a_bwd[i_in], self.b_bwd[i_in], **kw)
+        old_key = (out_b.ptr, out_b.version, self.batch)
         if d and const:
             # msg = d * msg + (1 - d) * const    (K12)
             n = out_b.shape[1]
+            const_b = self._const_b_for(i_out, direction, sb)       # before sb is damped in place
             self.ctx._call("tramp_damp", dtype_code(self.dtype), n, self.batch, float(d), out_a.ptr,
                            out_b.ptr, sa.ptr, sb.ptr)
             out_a.copy_from(sa)
             out_b.copy_from(sb)
         out_b.version += 1          # consumers (LinearChannel projection cache) see a new message
+        if d and const:
+            # the consumer's cached projection of this message follows by linearity (O(k), no matrix pass)
+            var = self.variables[i_out]
+            consumer = self.model.prev_factor(var) if direction == "bwd" else self.model.next_factor(var)
+            if hasattr(consumer, "affine_update"):
+                consumer.affine_update("x" if direction == "bwd" else "z", old_key, out_b, const_b, float(d),
+                                       token=(id(factor), direction))
         if const and not d:
             self._const_done.add((factor, direction))
 

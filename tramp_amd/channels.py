@@ -521,6 +521,24 @@ class LinearChannel(Channel):
             return None
         return (arg.ptr, version, norm.batch)
 
+    _affine_entry = "tramp_linear_project_affine"
+
+    def affine_update(self, side, old_key, msg, c, damping, token=None):
+        """``msg`` (the channel's bz for side "z", bx for "x") was just replaced in place by
+        damping * msg + (1 - damping) * c with a constant c (constant damping of a constant
+        factor's message).  If the cached projection belongs to the message as it was before
+        (``old_key``), it follows by linearity - O(k) instead of a matrix pass - and stays valid."""
+        attr = "_t_key" if side == "z" else "_u_key"
+        if old_key is None or getattr(self, attr) != old_key:
+            return False
+        tokens = self.__dict__.setdefault("_c_tokens", {})
+        changed = tokens.get(side) != token or token is None
+        self.ctx._call(self._affine_entry, self._handle, _lib.REUSE_T if side == "z" else _lib.REUSE_U,
+                       old_key[2], c.ptr, float(damping), int(changed))
+        tokens[side] = token
+        setattr(self, attr, (msg.ptr, msg.version, old_key[2]))
+        return True
+
     def compute_backward_mean(self, az, bz, ax, bx):
         "linear_channel.py:69-83"
         return self.compute_backward_posterior(az, bz, ax, bx)[0]
@@ -684,6 +702,9 @@ class ConvChannel(Channel):
                   a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
                   v.ptr if v is not None else None, reuse)
         return tgt, a_t, a_new, b_new, r, v
+
+    _affine_entry = "tramp_conv_project_affine"
+    affine_update = LinearChannel.affine_update
 
     def compute_backward_mean(self, az, bz, ax, bx):
         return self.compute_backward_posterior(az, bz, ax, bx)[0]      # :81-103

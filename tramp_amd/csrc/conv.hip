@@ -52,6 +52,9 @@ struct tramp_conv {
     void* fx;
     void* fo;
     void* fr;                   // [batch, n] real: the mean when b_new may alias b_old (damping)
+    void* fzc;                  // transforms of the constant part of a damped constant message
+    void* fxc;
+    bool fzc_valid, fxc_valid;
     double* a_raw;
     double* partial;
     int nblk;
@@ -130,14 +133,17 @@ int conv_reserve(tramp_ctx* ctx, tramp_conv* cv, size_t batch) {
     const size_t scal = ((batch * sizeof(double) + 255) / 256) * 256;
     const size_t part = ((batch * (size_t)cv->nblk * sizeof(double) + 255) / 256) * 256;
     const size_t rper = ((batch * cv->n * dtype_size(cv->dtype) + 255) / 256) * 256;
-    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->work, 3 * per + rper + scal + part));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->work, 5 * per + rper + scal + part));
     char* p = (char*)cv->work;
     cv->fz = p;
     cv->fx = p + per;
     cv->fo = p + 2 * per;
-    cv->fr = p + 3 * per;
-    cv->a_raw = (double*)(p + 3 * per + rper);
-    cv->partial = (double*)(p + 3 * per + rper + scal);
+    cv->fzc = p + 3 * per;
+    cv->fxc = p + 4 * per;
+    cv->fzc_valid = cv->fxc_valid = false;
+    cv->fr = p + 5 * per;
+    cv->a_raw = (double*)(p + 5 * per + rper);
+    cv->partial = (double*)(p + 5 * per + rper + scal);
     cv->work_batch = batch;
     cv->proj_batch = 0;
     return TRAMP_OK;
@@ -433,6 +439,48 @@ extern "C" int tramp_conv_apply(tramp_ctx* ctx, tramp_conv* cv, size_t batch, co
                            (const float2*)cv->fz, (const float2*)nullptr, (float2*)cv->fo);
     TRAMP_LAUNCH_CHECK(ctx);
     return fft_exec(ctx, p->inv, p->info_inv, cv->fo, x_d);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void conv_axpby_kernel(size_t count, T d, T omd, T* __restrict__ p,
+                                                            const T* __restrict__ pc) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock)
+        p[i] = d * p[i] + omd * pc[i];
+}
+
+extern "C" int tramp_conv_project_affine(tramp_ctx* ctx, tramp_conv* cv, int which, size_t batch, const void* c_d,
+                                         double damping, int c_changed) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, cv && c_d);
+    TRAMP_REQUIRE(ctx, which == TRAMP_REUSE_T || which == TRAMP_REUSE_U);
+    if (!batch) return TRAMP_OK;
+    if (!cv->work || cv->proj_batch != batch || batch > cv->work_batch)
+        return tramp_fail(ctx, TRAMP_EINVAL, "tramp_conv_project_affine",
+                          "the handle holds no transform of the message being updated");
+    const bool is_t = which == TRAMP_REUSE_T;
+    bool& valid = is_t ? cv->fzc_valid : cv->fxc_valid;
+    void* pc = is_t ? cv->fzc : cv->fxc;
+    void* p = is_t ? cv->fz : cv->fx;
+    const size_t esz = dtype_size(cv->dtype);
+    if (c_changed || !valid) {
+        ConvPlans* pl;
+        int rc = plans_for(ctx, cv, batch, &pl);
+        if (rc) return rc;
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (cv->n * esz + cv->nh * 2 * esz), 0);
+        rc = fft_exec(ctx, pl->fwd, pl->info_fwd, c_d, pc);
+        if (rc) return rc;
+        valid = true;
+    }
+    const size_t count = batch * cv->nh * 2;                           // real and imaginary parts alike
+    ProfScope ps(ctx, PROF_LIN_SCALARS, 3.0 * count * esz, 0);
+    if (cv->dtype == TRAMP_F64)
+        hipLaunchKernelGGL((conv_axpby_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, count,
+                           damping, 1.0 - damping, (double*)p, (const double*)pc);
+    else
+        hipLaunchKernelGGL((conv_axpby_kernel<float>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, count,
+                           (float)damping, (float)(1.0 - damping), (float*)p, (const float*)pc);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
 }
 
 extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_t batch, const double* az_d,

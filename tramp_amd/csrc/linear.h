@@ -15,6 +15,9 @@ struct tramp_linear {
     void* t;
     void* u;
     void* w;
+    void* tc;            // projections of the constant part of a damped constant message
+    void* uc;            //   (tramp_linear_project_affine)
+    bool tc_valid, uc_valid;
     double* a_raw;
 };
 

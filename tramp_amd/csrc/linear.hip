@@ -419,7 +419,7 @@ static int lin_reserve(tramp_ctx* ctx, tramp_linear* lin, size_t batch) {
     const size_t es = dtype_size(lin->dtype);
     const size_t vec = ((batch * lin->k * es + 255) / 256) * 256;
     const size_t sc = ((batch * sizeof(double) + 255) / 256) * 256;
-    if (hipMalloc(&lin->work, 3 * vec + sc) != hipSuccess) {
+    if (hipMalloc(&lin->work, 5 * vec + sc) != hipSuccess) {
         (void)hipGetLastError();
         return tramp_fail(ctx, TRAMP_ENOMEM, "linear workspace", "hipMalloc");
     }
@@ -427,7 +427,10 @@ static int lin_reserve(tramp_ctx* ctx, tramp_linear* lin, size_t batch) {
     lin->t = p;
     lin->u = p + vec;
     lin->w = p + 2 * vec;
-    lin->a_raw = (double*)(p + 3 * vec);
+    lin->tc = p + 3 * vec;
+    lin->uc = p + 4 * vec;
+    lin->tc_valid = lin->uc_valid = false;
+    lin->a_raw = (double*)(p + 5 * vec);
     lin->work_batch = batch;
     return TRAMP_OK;
 }
@@ -442,6 +445,50 @@ extern "C" int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, in
     hipLaunchKernelGGL(lin_variance_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, lin->s2, (int)lin->k,
                        (int)lin->rank, (double)lin->M, (double)lin->N, dir, az_d, ax_d, 0.0, (const double*)nullptr,
                        v_d, a_new_d, (double*)nullptr, n_eff_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// p <- d p + (1 - d) pc over [count] elements
+template <typename T>
+__global__ __launch_bounds__(kBlock) void axpby_kernel(size_t count, T d, T omd, T* __restrict__ p,
+                                                       const T* __restrict__ pc) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock)
+        p[i] = d * p[i] + omd * pc[i];
+}
+
+extern "C" int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, int which, size_t batch,
+                                           const void* c_d, double damping, int c_changed) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, lin && c_d);
+    TRAMP_REQUIRE(ctx, which == TRAMP_REUSE_T || which == TRAMP_REUSE_U);
+    if (!batch) return TRAMP_OK;
+    if (!lin->work || lin->proj_batch != batch || batch > lin->work_batch)
+        return tramp_fail(ctx, TRAMP_EINVAL, "tramp_linear_project_affine",
+                          "the handle holds no projection of the message being updated");
+    const bool is_t = which == TRAMP_REUSE_T;
+    bool& valid = is_t ? lin->tc_valid : lin->uc_valid;
+    void* pc = is_t ? lin->tc : lin->uc;
+    void* p = is_t ? lin->t : lin->u;
+    if (c_changed || !valid) {
+        LinEpi plain{};
+        plain.mode = 0;
+        plain.out = pc;
+        int rc = is_t ? matvec_dispatch(ctx, lin->dtype, 0, true, lin->k, lin->N, batch, lin->Vt, c_d, plain)
+                      : matvec_dispatch(ctx, lin->dtype, 0, false, lin->M, lin->k, batch, lin->Uk, c_d, plain);
+        if (rc) return rc;
+        valid = true;
+    }
+    const size_t count = batch * lin->k;
+    const unsigned g = (unsigned)((count + kBlock * 4 - 1) / (kBlock * 4) > 4096 ? 4096
+                                                                                : (count + kBlock * 4 - 1) / (kBlock * 4));
+    ProfScope ps(ctx, PROF_LIN_SCALARS, 3.0 * count * dtype_size(lin->dtype), 0);
+    if (lin->dtype == TRAMP_F64)
+        hipLaunchKernelGGL((axpby_kernel<double>), dim3(g), dim3(kBlock), 0, ctx->stream, count, damping,
+                           1.0 - damping, (double*)p, (const double*)pc);
+    else
+        hipLaunchKernelGGL((axpby_kernel<float>), dim3(g), dim3(kBlock), 0, ctx->stream, count, (float)damping,
+                           (float)(1.0 - damping), (float*)p, (const float*)pc);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
