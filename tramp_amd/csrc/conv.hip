@@ -328,14 +328,27 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
     cv->nblk = (int)((cv->nh + 4095) / 4096 > 256 ? 256 : (cv->nh + 4095) / 4096);
     cv->work = nullptr;
     cv->work_batch = cv->proj_batch = 0;
+    cv->wbar = nullptr;
+    cv->s2 = nullptr;
     // filter transform in f64 regardless of the working precision (the scalars are f64)
-    rocfft_plan plan;
-    rocfft_execution_info info;
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
     void* pwork = nullptr;
     double2* w64 = nullptr;
+    auto cleanup = [&](bool failed) {
+        if (w64) (void)hipFree(w64);
+        if (pwork) (void)hipFree(pwork);
+        if (info) (void)rocfft_execution_info_destroy(info);
+        if (plan) (void)rocfft_plan_destroy(plan);
+        if (failed) {
+            if (cv->wbar) (void)hipFree(cv->wbar);
+            if (cv->s2) (void)hipFree(cv->s2);
+            delete cv;
+        }
+    };
     int rc = make_plan(ctx, cv, true, true, 1, &plan, &info, &pwork);
     if (rc) {
-        delete cv;
+        cleanup(true);
         return rc;
     }
     const size_t csz = 2 * dtype_size(dtype);
@@ -343,11 +356,15 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
     if (e == hipSuccess) e = hipMalloc(&cv->wbar, cv->nh * csz);
     if (e == hipSuccess) e = hipMalloc(&cv->s2, cv->nh * sizeof(double));
     if (e != hipSuccess) {
-        delete cv;
+        (void)hipGetLastError();
+        cleanup(true);
         return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_conv_create", hipGetErrorString(e));
     }
     rc = fft_exec(ctx, plan, info, filter_d, w64);
-    if (rc) return rc;
+    if (rc) {
+        cleanup(true);
+        return rc;
+    }
     const unsigned g = (unsigned)((cv->nh + kBlock - 1) / kBlock);
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((conv_setup_kernel<double>), dim3(g), dim3(kBlock), 0, ctx->stream, w64, cv->nh,
@@ -355,22 +372,23 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
     else
         hipLaunchKernelGGL((conv_setup_kernel<float>), dim3(g), dim3(kBlock), 0, ctx->stream, w64, cv->nh,
                            (float2*)cv->wbar, cv->s2);
-    TRAMP_LAUNCH_CHECK(ctx);
     // mean of the full spectrum (second_moment, ax = 0 branch): host fold, setup only
     std::vector<double> s2h(cv->nh);
-    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(s2h.data(), cv->s2, cv->nh * sizeof(double), hipMemcpyDeviceToHost,
-                                        ctx->stream));
-    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(s2h.data(), cv->s2, cv->nh * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        cleanup(true);
+        return tramp_fail(ctx, TRAMP_EHIP, "tramp_conv_create", hipGetErrorString(e));
+    }
     long double acc = 0.0L;
     for (size_t i = 0; i < cv->nh; ++i) {
         const size_t j = i % cv->nhl;
         acc += ((j == 0 || 2 * j == cv->nlast) ? 1.0L : 2.0L) * (long double)s2h[i];
     }
     cv->s_mean = (double)(acc / (long double)cv->n);
-    (void)hipFree(w64);
-    if (pwork) (void)hipFree(pwork);
-    (void)rocfft_execution_info_destroy(info);
-    (void)rocfft_plan_destroy(plan);
+    cleanup(false);
     *conv = cv;
     return TRAMP_OK;
 }
