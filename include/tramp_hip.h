@@ -219,6 +219,16 @@ int tramp_pwl3_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batc
                        double damping, const double* a_old_d, const void* b_old_d,
                        double* a_new_d, void* b_new_d, void* r_d, double* v_d, uint8_t* mask_d);
 
+/* Three-region LIKELIHOODS with the same region table as tramp_pwl3_channel (y_d observed):
+ * HardTanhLikelihood, HardSigmoidLikelihood, SymmetricDoorLikelihood
+ * (tramp/likelihoods/piecewise_linear_likelihood.py:9-63,156-205,293-320): what
+ * Model.to_observed turns an observed three-region output channel into. */
+int tramp_pwl3_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                       double z_lo, double z_hi, const double* slopes3, const double* x03,
+                       const double* az_d, const void* bz_d, const void* y_d,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
 /* ---- diagonal-belief variants (isotropic=False): a is an n-vector too ------
  * Same files as above with the `.mean()` line skipped
  * (gauss_bernoulli_prior.py:75-76, sgn_likelihood.py:35-36, map_L1_norm_prior.py:69-70)
@@ -382,6 +392,11 @@ int tramp_se_pwl2_channel(tramp_ctx* ctx, int dir, size_t count, double slope_po
 int tramp_se_pwl3_channel(tramp_ctx* ctx, int dir, size_t count, double z_lo, double z_hi,
                           const double* slopes3, const double* x03,
                           const double* az, const double* ax, const double* tau_z, double* v);
+
+/* SE error of the three-region likelihoods (piecewise_linear_likelihood.py:120-146,210-214). */
+int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, double z_hi,
+                      const double* slopes3, const double* x03,
+                      const double* az, const double* tau_z, double* v);
 
 /* ---- synthetic data (bench / tests; counter-based, reproducible per seed) --- */
 /* out[i] = scale * N(0,1), Philox-4x32 + Box-Muller, element i from counter i. */

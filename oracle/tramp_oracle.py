@@ -487,6 +487,88 @@ def se_relu_lik_error(az, tau_z, method="quadpack"):
     return gaussian_measure(0, sz_eff, g, method)
 
 
+# Three-region likelihoods (what to_observed turns an observed HardTanh / HardSigmoid /
+# SymmetricDoor output into): tramp/likelihoods/piecewise_linear_likelihood.py:9-63 (regions),
+# :156-218 (merge), :293-320 (constructors; NB HardSigmoidLikelihood uses l = 3 where the
+# channel uses 2.5, restated as found).
+def pwl3_lik_regions(kind, param=None):
+    "[(zmin, zmax, slope, x0)] for pos, mid, neg"
+    inf = np.inf
+    if kind == "h-tanh":
+        return [(1., inf, 0., 1.), (-1., 1., 1., 0.), (-inf, -1., 0., -1.)]
+    if kind == "h-sigm":
+        L = 3.
+        return [(L, inf, 0., 1.), (-L, L, 1 / (2 * L), 0.5), (-inf, -L, 0., 0.)]
+    if kind == "door":
+        w = float(param)
+        return [(w, inf, 0., 1.), (-w, w, 0., -1.), (-inf, -w, 0., 1.)]
+    raise KeyError(kind)
+
+
+def _region_proba(zmin, zmax, r0, v0):
+    if np.isinf(zmax):
+        return halfline_proba(r0, v0, +1, zmin)
+    if np.isinf(zmin):
+        return halfline_proba(r0, v0, -1, zmax)
+    return interval_proba(r0, v0, zmin, zmax)
+
+
+def pwl3_lik_posterior(kind, az, bz, y, isotropic=True, param=None):
+    bz = np.asarray(bz, dtype=float)
+    y = np.asarray(y, dtype=float) + np.zeros_like(bz)
+    rs, vs, As = [], [], []
+    for (zmin, zmax, slope, x0) in pwl3_lik_regions(kind, param):
+        if slope == 0:
+            contains = (y == x0)
+            m, v, logp = _region_moments(zmin, zmax, bz / az, 1 / az)
+            r_k, v_k = m, v
+            A_k = 0.5 * np.log(2 * np.pi / az) + 0.5 * (bz / az)**2 * az + logp   # truncated_normal_logZ
+        else:
+            z = (y - x0) / slope
+            contains = (zmin < z) & (z < zmax)
+            r_k, v_k = z, np.zeros_like(z)
+            A_k = -0.5 * az * (z**2) + bz * z - np.log(slope)
+        rs.append(np.where(contains, r_k, 0))
+        vs.append(np.where(contains, v_k, 0))
+        As.append(np.where(contains, A_k, -np.inf))
+    A = np.stack(As)
+    with np.errstate(invalid="ignore"):
+        e = np.exp(A - A.max(axis=0, keepdims=True))
+        ps = e / e.sum(axis=0, keepdims=True)
+    r = sum(p_ * r_ for p_, r_ in zip(ps, rs))
+    v = sum(p_ * v_ for p_, v_ in zip(ps, vs))
+    for i in range(3):
+        for j in range(i + 1, 3):
+            v = v + ps[i] * ps[j] * (rs[i] - rs[j])**2
+    if isotropic:
+        v = v.mean()
+    return r, v
+
+
+def pwl3_lik_message(kind, az, bz, y, param=None):
+    r, v = pwl3_lik_posterior(kind, az, bz, y, param=param)
+    return ab_new(r, v, az, bz)
+
+
+def se_pwl3_lik_error(kind, az, tau_z, method="quadpack", param=None):
+    """piecewise_linear_likelihood.py:120-146, 210-214: sum over regions of E[1_R f]; a sloped
+    region pins z (variance 0), a flat one is a 1-D average over bz of p_R(bz) v(bz, y = x0)."""
+    mz_hat = az - 1 / tau_z
+    assert mz_hat > 0
+    sz_eff = np.sqrt(mz_hat + (mz_hat**2) * tau_z)
+    total = 0.
+    for (zmin, zmax, slope, x0) in pwl3_lik_regions(kind, param):
+        if slope != 0:
+            continue
+
+        def g(bz, zmin=zmin, zmax=zmax, x0=x0):
+            bz = np.asarray(bz, dtype=float)
+            _, v = pwl3_lik_posterior(kind, az, bz, x0, isotropic=False, param=param)
+            return _region_proba(zmin, zmax, bz / az, 1 / az) * v
+        total += gaussian_measure(0, sz_eff, g, method)
+    return total
+
+
 # --------------------------------------------------------------------------
 # A8  Piecewise-linear channels (Sgn / Abs / Relu)
 #   tramp/channels/activation/piecewise_linear_channel.py:27-53,80-106
@@ -1071,6 +1153,19 @@ class SgnLikFactor(OracleFactor):
 
     def backward_se(self, az, ax, tau_z, method="quadpack"):
         return a_new(se_sgn_lik_error(az, tau_z, method), az)
+
+
+class Pwl3LikFactor(OracleFactor):
+    kind = "likelihood"
+
+    def __init__(self, which, y, param=None):
+        self.which, self.y, self.param = which, y, param
+
+    def backward(self, az, bz, ax, bx):
+        return pwl3_lik_message(self.which, az, bz, self.y, self.param)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(se_pwl3_lik_error(self.which, az, tau_z, method, self.param), az)
 
 
 class AbsLikFactor(OracleFactor):

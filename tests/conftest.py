@@ -45,6 +45,13 @@ def golden_conv():
 
 
 @pytest.fixture(scope="session")
+def golden_pwl3_lik():
+    path = os.path.join(GOLDEN, "pwl3_lik.npz")
+    with np.load(path, allow_pickle=True) as f:
+        return dict(cases=list(f["data"]), se=list(f["se"]), ep=list(f["ep"]))
+
+
+@pytest.fixture(scope="session")
 def golden_se():
     return load_golden("se")
 

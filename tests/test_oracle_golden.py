@@ -408,3 +408,40 @@ def test_conv_ep_oracle_matches_reference(golden_conv):
                 close(rs[i], t[f"r:{vid}"][it], rtol=1e-7, atol=1e-9 * np.abs(t[f"r:{vid}"][it]).max())
                 close(vs[i], t[f"v:{vid}"][it], rtol=1e-8)
         close(res["r"][0], c["final_r"], rtol=1e-6, atol=1e-7)
+
+
+# -- three-region likelihoods (likelihood twins)
+def test_pwl3_lik_oracle_matches_reference(golden_pwl3_lik):
+    for c in golden_pwl3_lik["cases"]:
+        with np.errstate(all="ignore"):
+            r, v = orc.pwl3_lik_posterior(c["kind"], c["az"], c["bz"], c["y"], param=c["param"])
+            a, b = orc.pwl3_lik_message(c["kind"], c["az"], c["bz"], c["y"], param=c["param"])
+        close(r, c["r"], rtol=1e-10, atol=1e-12)
+        close(v, c["v"], rtol=1e-10)
+        close(a, c["a_new"], rtol=1e-9)
+        close(b, c["b_new"], rtol=1e-9, atol=1e-10 * np.abs(c["b_new"]).max())
+    for c in golden_pwl3_lik["se"]:
+        close(orc.se_pwl3_lik_error(c["kind"], c["az"], c["tau_z"], param=c["param"]), c["v"], rtol=1e-7)
+        close(orc.se_pwl3_lik_error(c["kind"], c["az"], c["tau_z"], method="gl", param=c["param"]), c["v"],
+              rtol=2e-6)
+
+
+def test_pwl3_lik_ep_oracle_matches_reference(golden_pwl3_lik):
+    for c in golden_pwl3_lik["ep"]:
+        N, M = c["N"], c["M"]
+        W = np.random.RandomState(c["seed"]).randn(M, N) / np.sqrt(N)
+        assert W.sum() == c["W_sum"]
+        fs = [orc.GaussPriorFactor(N), orc.LinearFactor(W), orc.Pwl3LikFactor(c["kind"], c["y"], c["param"])]
+        iters = []
+        with np.errstate(all="ignore"):
+            res = orc.ep_chain(fs, [N, M], max_iter=30, damping=c["damping"],
+                               record=lambda it, fwd, bwd, rs, vs: iters.append((list(fwd), list(bwd), rs, vs)))
+        assert res["n_iter"] == c["n_iter"]
+        t = c["traj"]
+        for it in range(min(len(iters), t["v:x"].shape[0])):
+            fwd, bwd, rs, vs = iters[it]
+            for i, vid in enumerate(["x", "z"]):
+                close(fwd[i][0], t[f"fwd:{vid}:a"][it], rtol=1e-7)
+                close(bwd[i][0], t[f"bwd:{vid}:a"][it], rtol=1e-7)
+                close(rs[i], t[f"r:{vid}"][it], rtol=1e-6, atol=1e-8 * np.abs(t[f"r:{vid}"][it]).max())
+                close(vs[i], t[f"v:{vid}"][it], rtol=1e-7)

@@ -56,6 +56,7 @@ sys.path.insert(0, REF)
 from tramp.priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior  # noqa: E402
 from tramp.likelihoods import GaussianLikelihood, SgnLikelihood, AbsLikelihood  # noqa: E402
 from tramp.likelihoods import ReluLikelihood, LeakyReluLikelihood  # noqa: E402
+from tramp.likelihoods import HardTanhLikelihood, HardSigmoidLikelihood, SymmetricDoorLikelihood  # noqa: E402
 from tramp.channels import (  # noqa: E402
     LinearChannel, SgnChannel, AbsChannel, ReluChannel, MarchenkoPasturChannel,
     LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel
@@ -455,6 +456,55 @@ def ep_goldens():
     save("ep_traj", data=np.array(trajs, dtype=object))
 
 
+# ---------------------------------------------------------------- three-region likelihoods
+def pwl3_lik_goldens():
+    "HardTanh / HardSigmoid / SymmetricDoor likelihoods: posteriors, messages, SE errors, EP runs."
+    rs = np.random.RandomState(21)
+    n = 96
+    mk = {"h-tanh": lambda y, p: HardTanhLikelihood(y=y), "h-sigm": lambda y, p: HardSigmoidLikelihood(y=y),
+          "door": lambda y, p: SymmetricDoorLikelihood(width=p, y=y)}
+    cases = []
+    for kind, param in (("h-tanh", None), ("h-sigm", None), ("door", 0.7), ("door", 1.5)):
+        z = rs.standard_normal(n) * 2.5
+        y = mk[kind](None, param).sample(z)
+        for (az, scale) in ((1.3, 1.0), (0.05, 0.1), (40., 30.), (3.0, 4.0)):
+            bz = az * z + np.sqrt(az) * rs.standard_normal(n) * scale / max(scale, 1.0)
+            lk = mk[kind](y, param)
+            with np.errstate(all="ignore"):
+                r, v = lk.compute_backward_posterior(az, bz, y)
+                an, bn = lk.compute_backward_message(az, bz)
+            cases.append(dict(kind=kind, param=param, az=az, bz=bz, y=y, r=r, v=v, a_new=an, b_new=bn))
+    se = []
+    for kind, param in (("h-tanh", None), ("h-sigm", None), ("door", 0.7)):
+        lk = mk[kind](None, param)
+        for (az, tau_z) in ((1.3, 1.0), (3.0, 0.5), (25., 2.0)):
+            t0 = time.time()
+            se.append(dict(kind=kind, param=param, az=az, tau_z=tau_z, v=lk.compute_backward_error(az, tau_z)))
+            print("se pwl3 lik", kind, az, tau_z, se[-1]["v"], f"{time.time()-t0:.1f}s")
+    trajs = []
+    for kind, param, alpha in (("door", 0.7, 2.0), ("h-tanh", None, 1.0)):
+        N = 128
+        M = int(alpha * N)
+        r = np.random.RandomState(3)
+        W = r.randn(M, N) / np.sqrt(N)
+        x = r.standard_normal(N)
+        y = mk[kind](None, param).sample(W @ x)
+        model = (GaussianPrior(size=N) @ V(id="x") @ LinearChannel(W) @ V(id="z") @ mk[kind](y, param)).to_model()
+        ep = ExpectationPropagation(model)
+        rec = Recorder(EarlyStoppingEP())
+        err = None
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=30, callback=rec, damping=0.2)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        trajs.append(dict(kind=kind, param=param, N=N, M=M, seed=3, damping=0.2, x=x, y=y, W_sum=W.sum(),
+                          n_iter=ep.n_iter, error=err, n_recorded=len(rec.iters), traj=pack_traj(rec.iters[:12])))
+        print("pwl3 lik ep", kind, "n_iter", ep.n_iter, err)
+    save("pwl3_lik", data=np.array(cases, dtype=object), se=np.array(se, dtype=object),
+         ep=np.array(trajs, dtype=object))
+
+
 # ---------------------------------------------------------------- convolution channel
 def conv_goldens():
     "ConvChannel family (real=True): posteriors, messages, scalars, samples, EP trajectories."
@@ -654,5 +704,7 @@ if __name__ == "__main__":
         ep_goldens()
     if not only or "conv" in only:
         conv_goldens()
+    if not only or "pwl3lik" in only:
+        pwl3_lik_goldens()
     if not only or "se" in only:
         se_goldens(args.skip_slow)

@@ -12,7 +12,8 @@ from . import _lib
 from .device import Context, DeviceArray, default_context
 from .priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior, get_prior
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
-                          LeakyReluLikelihood, get_likelihood)
+                          LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
+                          SymmetricDoorLikelihood, get_likelihood)
 from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
                        SymmetricDoorChannel, ConvChannel, Blur1DChannel, Blur2DChannel,

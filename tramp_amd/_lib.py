@@ -66,6 +66,8 @@ _SIGNATURES = {
     "tramp_se_pwl2_channel": [vp, i32, sz, dbl, dbl, dbl, dbl, dbl, vp, vp, vp, vp],
     "tramp_pwl3_channel": [vp, i32, i32, sz, sz, dbl, dbl, vp, vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, vp],
     "tramp_se_pwl3_channel": [vp, i32, sz, dbl, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_pwl3_lik_bwd": [vp, i32, sz, sz, dbl, dbl, vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_se_pwl3_lik": [vp, sz, dbl, dbl, vp, vp, vp, vp, vp],
     "tramp_diag_factor": [vp, i32, i32, sz, vp, vp, vp, dbl, dbl, dbl, vp, vp, vp, vp],
     "tramp_linear_create": [vp, i32, sz, sz, sz, vp, vp, vp, C.POINTER(vp)],
     "tramp_linear_destroy": [vp, vp],

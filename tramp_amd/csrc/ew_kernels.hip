@@ -124,6 +124,24 @@ template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
     }
 };
 
+template <typename T> struct Pwl3LikOp {  // three-region likelihoods; in0 = bz, in1 = y
+    static constexpr bool HEAVY = true;
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    tmath::Pwl3Spec spec;
+    T azT;
+    double a_msg;
+    __device__ void setup(size_t b) {
+        a_msg = az[b];
+        azT = T(a_msg);
+    }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        tmath::PwlOut<T> o = tmath::pwl3_lik_posterior<T>(x0, x1, azT, spec);
+        return {o.r, o.v, o.mask};
+    }
+};
+
 template <typename T, bool FWD> struct Pwl3Op {   // three-region channels; in0 = bz, in1 = bx
     static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
@@ -721,6 +739,21 @@ extern "C" int tramp_pwl3_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, 
     tmath::Pwl3Spec spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}};
     DISPATCH_DTYPE(ctx, dtype, (pwl3_dir<float>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)),
                    (pwl3_dir<double>(ctx, dir, n, batch, az_d, bz_d, ax_d, bx_d, out, spec)));
+}
+
+extern "C" int tramp_pwl3_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double z_lo, double z_hi,
+                                  const double* slopes3, const double* x03, const double* az_d, const void* bz_d,
+                                  const void* y_d, double damping, const double* a_old_d, const void* b_old_d,
+                                  double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && slopes3 && x03 && z_lo < z_hi);
+    TRAMP_REQUIRE(ctx, slopes3[0] >= 0.0 && slopes3[1] >= 0.0 && slopes3[2] >= 0.0);   // log(slope)
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    tmath::Pwl3Spec spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}};
+    Pwl3LikOp<float> of{az_d, spec};
+    Pwl3LikOp<double> od{az_d, spec};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
 }
 
 // ---------------------------------------------------------------- K3 / K6 constant messages

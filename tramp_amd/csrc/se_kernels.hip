@@ -54,6 +54,7 @@ struct Se1dParams {
     const double* p1;   // rho | tau_z
     const double* p2;   // mean
     const double* p3;   // var
+    tmath::Pwl3Spec spec3;   // mode 3 (three-region likelihood) only
 };
 
 __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, double* __restrict__ out) {
@@ -120,6 +121,34 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
             tmath::HalfLine<double> h = tmath::halfline<double>(r0, v0, -1);
             const double p = norm_cdf((0 - r0) / sqrt(v0));
             acc += w * norm_pdf(x) * p * h.var;
+        }
+        total = acc;
+    }
+    if (mode == 3) {
+        // three-region likelihood (piecewise_linear_likelihood.py:120-146, 210-214): a sloped region
+        // pins z (variance 0); each FLAT region R adds E_{bz ~ N(0, mz + mz^2 tau)}[ P_R(bz) v(bz, y = x0_R) ]
+        // with v the merged posterior variance at that observation.
+        const double az = P.p0[pt], tau = P.p1[pt];
+        const double mz = az - 1.0 / tau;
+        const double s = sqrt(mz + mz * mz * tau);
+        const double v0 = 1.0 / az, s0 = sqrt(v0);
+        const tmath::Pwl3Spec sp = P.spec3;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
+            double x, w;
+            graded_node(i, kPanels1D, 0.0, x, w);
+            const double bz = s * x, r0 = bz / az;
+            double f = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (sp.slope[k] != 0.0) continue;
+                const double lo = (k == 0) ? sp.zhi : (k == 1 ? sp.zlo : -INFINITY);
+                const double hi = (k == 0) ? INFINITY : (k == 1 ? sp.zhi : sp.zlo);
+                const double p = (k == 0 ? 1.0 : norm_cdf((hi - r0) / s0)) - (k == 2 ? 0.0 : norm_cdf((lo - r0) / s0));
+                tmath::PwlOut<double> o = tmath::pwl3_lik_posterior<double>(bz, sp.x0[k], az, sp);
+                f += p * o.v;
+            }
+            acc += w * norm_pdf(x) * f;
         }
         total = acc;
     }
@@ -303,7 +332,7 @@ extern "C" int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
     double *din[4], *dout;
     int rc = se_stage(ctx, count, hin, 4, din, &dout, 0, nullptr);
     if (rc) return rc;
-    Se1dParams P{din[0], din[1], din[2], din[3]};
+    Se1dParams P{din[0], din[1], din[2], din[3], tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 0, P, dout);
     return se_finish(ctx, count, dout, v);
 }
@@ -317,7 +346,7 @@ extern "C" int tramp_se_sgn_lik(tramp_ctx* ctx, size_t count, const double* az, 
     double *din[2], *dout;
     int rc = se_stage(ctx, count, hin, 2, din, &dout, 0, nullptr);
     if (rc) return rc;
-    Se1dParams P{din[0], din[1], nullptr, nullptr};
+    Se1dParams P{din[0], din[1], nullptr, nullptr, tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 1, P, dout);
     return se_finish(ctx, count, dout, v);
 }
@@ -331,8 +360,24 @@ extern "C" int tramp_se_relu_lik(tramp_ctx* ctx, size_t count, const double* az,
     double *din[2], *dout;
     int rc = se_stage(ctx, count, hin, 2, din, &dout, 0, nullptr);
     if (rc) return rc;
-    Se1dParams P{din[0], din[1], nullptr, nullptr};
+    Se1dParams P{din[0], din[1], nullptr, nullptr, tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 2, P, dout);
+    return se_finish(ctx, count, dout, v);
+}
+
+extern "C" int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, double z_hi, const double* slopes3,
+                                 const double* x03, const double* az, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && tau_z && v && slopes3 && x03 && z_lo < z_hi);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] - 1.0 / tau_z[i] > 0.0);   // :123-124
+    const double* hin[2] = {az, tau_z};
+    double *din[2], *dout;
+    int rc = se_stage(ctx, count, hin, 2, din, &dout, 0, nullptr);
+    if (rc) return rc;
+    Se1dParams P{din[0], din[1], nullptr, nullptr,
+                 tmath::Pwl3Spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}}};
+    hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 3, P, dout);
     return se_finish(ctx, count, dout, v);
 }
 

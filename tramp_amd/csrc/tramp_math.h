@@ -532,6 +532,58 @@ TM_HD PwlOut<T> pwl3_posterior(T bz, T bx, T az, T ax, const Pwl3Spec& sp) {
     return o;
 }
 
+// Three-region LIKELIHOODS (tramp/likelihoods/piecewise_linear_likelihood.py:9-63,156-205,
+// 293-320): the output y is observed.  A flat region (slope 0) is compatible with y == x0 and
+// then holds the truncated normal of N(bz/az, 1/az) on its interval; a sloped region pins
+// z = (y - x0)/slope when that lies strictly inside it (variance 0); incompatible regions get
+// log-partition -inf; softmax over the log-partitions merges (two flat regions of the door
+// share x0 = +1).  No compatible region -> NaN, as the reference's softmax of all -inf.
+template <typename T>
+TM_HD PwlOut<T> pwl3_lik_posterior(T bz, T y, T az, const Pwl3Spec& sp) {
+    T rs[3], vs[3], As[3];
+    unsigned mask = 0;
+    const T ninf = -T(INFINITY);
+    const T r0 = bz / az, v0 = T(1) / az;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T slope = T(sp.slope[k]), x0 = T(sp.x0[k]);
+        rs[k] = T(0); vs[k] = T(0); As[k] = ninf;
+        if (sp.slope[k] == 0.0) {
+            if (y == x0) {
+                T g0;
+                if (k == 1) {
+                    IntervalOut<T> m = interval_moments<T>(r0, v0, T(sp.zlo), T(sp.zhi));
+                    rs[k] = m.mean; vs[k] = m.var; g0 = m.logp;
+                    mask |= m.branch << 2;
+                } else {
+                    HalfLine<T> h = halfline_at<T>(r0, v0, k == 0 ? +1 : -1, k == 0 ? T(sp.zhi) : T(sp.zlo));
+                    rs[k] = h.mean; vs[k] = h.var; g0 = h.logp;
+                    mask |= (h.mask ? 1u : 0u) << (k == 0 ? 0 : 1);
+                }
+                As[k] = T(0.5) * log_(T(2 * kPi) * v0) + T(0.5) * (r0 * r0) / v0 + g0;
+            }
+        } else {
+            const T z = (y - x0) / slope;
+            const bool in = (k == 0) ? (z > T(sp.zhi)) : (k == 1 ? (z > T(sp.zlo) && z < T(sp.zhi)) : (z < T(sp.zlo)));
+            if (in) {
+                rs[k] = z;
+                As[k] = -T(0.5) * az * (z * z) + bz * z - log_(slope);
+            }
+        }
+    }
+    const T m = fmax_(As[0], fmax_(As[1], As[2]));
+    const T e0 = exp_(As[0] - m), e1 = exp_(As[1] - m), e2 = exp_(As[2] - m);   // m = -inf -> NaN
+    const T se = e0 + e1 + e2;
+    const T p0 = e0 / se, p1 = e1 / se, p2 = e2 / se;
+    PwlOut<T> o;
+    o.r = p0 * rs[0] + p1 * rs[1] + p2 * rs[2];
+    const T d01 = rs[0] - rs[1], d02 = rs[0] - rs[2], d12 = rs[1] - rs[2];
+    o.v = p0 * vs[0] + p1 * vs[1] + p2 * vs[2]
+          + (p0 * p1 * (d01 * d01) + p0 * p2 * (d02 * d02) + p1 * p2 * (d12 * d12));
+    o.mask = mask;
+    return o;
+}
+
 // Gaussian CDF / PDF (tramp/utils/misc.py:50-57) for the SE quadratures.
 TM_HD double norm_cdf(double x) { return 0.5 * (1.0 + ::erf(x / kSqrt2)); }
 TM_HD double norm_pdf(double x) { return ::exp(-0.5 * x * x) / 2.5066282746310002; }

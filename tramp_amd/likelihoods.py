@@ -232,12 +232,79 @@ class LeakyReluLikelihood(ReluLikelihood):
         super().__init__(y, y_name, isotropic, dtype, ctx)
 
 
+class ThreeRegionLikelihood(Likelihood):
+    """Observed three-region output (the likelihood twins of
+    HardTanh / HardSigmoid / SymmetricDoor): tramp/likelihoods/piecewise_linear_likelihood.py
+    :156-218 over the regions pos [z_hi, inf), mid [z_lo, z_hi], neg (-inf, z_lo]."""
+    _kernel_name = "tramp_pwl3_lik_bwd"
+    _z = (-1.0, 1.0)
+    _slopes = (0.0, 1.0, 0.0)     # pos, mid, neg
+    _x0 = (1.0, 0.0, -1.0)
+
+    def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        if not isotropic:
+            raise NotImplementedError("diagonal beliefs are not built for the piecewise-linear likelihoods")
+        self.y_name = y_name
+        self.size = self.get_size(y)
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self._slopes_h = np.array(self._slopes, dtype=np.float64)
+        self._x0_h = np.array(self._x0, dtype=np.float64)
+        self._kernel_extra = (float(self._z[0]), float(self._z[1]), self._slopes_h.ctypes.data,
+                              self._x0_h.ctypes.data)
+        self._set_y(y)
+
+    def sample(self, Z):
+        "sum of the regions' outputs: x0 + slope z on [zmin, zmax), zero elsewhere (:22-25, 168-170)"
+        zlo, zhi = self._z
+        (sp, sm, sn), (xp, xm, xn) = self._slopes, self._x0
+        return np.where(Z >= zhi, xp + sp * Z, np.where(Z >= zlo, xm + sm * Z, xn + sn * Z))
+
+    def compute_backward_error(self, az, tau_z):
+        "beliefs_measure summed over the regions (:120-146, 210-214); sloped regions carry no variance"
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        tz = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        if np.any(az_h - 1 / tz <= 0):
+            raise AssertionError("az must be greater than 1/ tau_z")
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_pwl3_lik", az_h.shape[0], float(self._z[0]), float(self._z[1]),
+                       self._slopes_h.ctypes.data, self._x0_h.ctypes.data, az_h.ctypes.data, tz.ctypes.data,
+                       v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+
+class HardTanhLikelihood(ThreeRegionLikelihood):
+    "piecewise_linear_likelihood.py:293-299"
+
+
+class HardSigmoidLikelihood(ThreeRegionLikelihood):
+    "piecewise_linear_likelihood.py:302-309 (l = 3 here; the channel of the same name uses 2.5)"
+    _z = (-3.0, 3.0)
+    _slopes = (0.0, 1.0 / 6.0, 0.0)
+    _x0 = (1.0, 0.5, 0.0)
+
+
+class SymmetricDoorLikelihood(ThreeRegionLikelihood):
+    "piecewise_linear_likelihood.py:312-320"
+
+    def __init__(self, width, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        self.width = width
+        self._z = (-float(width), float(width))
+        self._slopes = (0.0, 0.0, 0.0)
+        self._x0 = (1.0, -1.0, 1.0)
+        super().__init__(y, y_name, isotropic, dtype, ctx)
+
+
 LIKELIHOOD_CLASSES = {
     "relu": ReluLikelihood,
     "l-relu": LeakyReluLikelihood,
     "gaussian": GaussianLikelihood,
     "abs": AbsLikelihood,
     "sgn": SgnLikelihood,
+    "h-tanh": HardTanhLikelihood,
+    "h-sigm": HardSigmoidLikelihood,
+    "door": SymmetricDoorLikelihood,
 }
 
 

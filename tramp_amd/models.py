@@ -11,11 +11,12 @@ import networkx as nx
 import numpy as np
 
 from .base import Factor, Variable
-from .channels import (ConvChannel, GaussianChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
+from .channels import (ConvChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
                        PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
-                          LeakyReluLikelihood, Likelihood)
+                          LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
+                          SymmetricDoorLikelihood, Likelihood)
 from .priors import Prior, get_prior
 from .variables import SISOVariable, SILeafVariable
 
@@ -33,6 +34,12 @@ def channel2likelihood(channel, y, y_name):
         return ReluLikelihood(y=y, y_name=y_name, **kw)
     if isinstance(channel, LeakyReluChannel):
         return LeakyReluLikelihood(slope=channel.slope, y=y, y_name=y_name, **kw)
+    if isinstance(channel, HardTanhChannel):
+        return HardTanhLikelihood(y=y, y_name=y_name, **kw)
+    if isinstance(channel, HardSigmoidChannel):
+        return HardSigmoidLikelihood(y=y, y_name=y_name, **kw)
+    if isinstance(channel, SymmetricDoorChannel):
+        return SymmetricDoorLikelihood(width=channel.width, y=y, y_name=y_name, **kw)
     raise NotImplementedError(f"cannot convert {channel} to likelihood")
 
 
