@@ -342,6 +342,20 @@ int tramp_conv_message(tramp_ctx* ctx, tramp_conv* conv, int dir, size_t batch,
                        double damping, const double* a_old_d, const void* b_old_d,
                        double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse);
 
+/* ---- unitary channels: DFT and dense rotation ------------------------------- */
+/* DFTChannel (tramp/channels/linear/dft_channel.py:7-77, real=True): x = fftn(z, norm="ortho").
+ * The channel is unitary, so messages pass through: dir FWD  a_new = az, b_new = F bz as the
+ * planar array [batch, 2, n] (real parts, then imaginary parts); dir BWD  a_new = ax,
+ * b_new = Re F^-1 bx [batch, n] from the planar [batch, 2, n].  Constant damping fused.
+ * (RotationChannel, rotation_channel.py:15-44, is two calls of tramp_matvec_nt / _nn.) */
+typedef struct tramp_dft tramp_dft;
+int tramp_dft_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, tramp_dft** dft);
+int tramp_dft_destroy(tramp_ctx* ctx, tramp_dft* dft);
+int tramp_dft_message(tramp_ctx* ctx, tramp_dft* dft, int dir, size_t batch,
+                      const double* a_in_d, const void* b_in_d,
+                      double damping, const double* a_old_d, const void* b_old_d,
+                      double* a_new_d, void* b_new_d);
+
 /* ---- variable nodes / scheduler helpers ------------------------------------ */
 /* K11. Variable.posterior_rv (tramp/base.py:157-161) for a SISO variable:
  *      r = (b1 + b2) / (a1 + a2), v = 1 / (a1 + a2), plus the two sums the

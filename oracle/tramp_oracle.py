@@ -1092,6 +1092,31 @@ class ConvFactor(LinearFactor):
         self.lin = ConvOracle(filt)
 
 
+class DFTFactor(OracleFactor):
+    """tramp/channels/linear/dft_channel.py:46-64 (real z): messages pass through the unitary
+    transform; complex vectors are planar (2,) + shape arrays."""
+
+    def forward(self, az, bz, ax, bx):
+        f = np.fft.fftn(bz, norm="ortho")
+        return az, np.stack([f.real, f.imag])
+
+    def backward(self, az, bz, ax, bx):
+        return ax, np.real(np.fft.ifftn(bx[0] + 1j * bx[1], norm="ortho"))
+
+
+class RotationFactor(OracleFactor):
+    "tramp/channels/linear/rotation_channel.py:32-42"
+
+    def __init__(self, R):
+        self.R = np.asarray(R)
+
+    def forward(self, az, bz, ax, bx):
+        return az, self.R @ bz
+
+    def backward(self, az, bz, ax, bx):
+        return ax, self.R.T @ bx
+
+
 class MPFactor(OracleFactor):
     def __init__(self, alpha):
         self.mp = MarchenkoPasturOracle(alpha)

@@ -52,6 +52,13 @@ def golden_pwl3_lik():
 
 
 @pytest.fixture(scope="session")
+def golden_unitary():
+    path = os.path.join(GOLDEN, "unitary.npz")
+    with np.load(path, allow_pickle=True) as f:
+        return dict(msgs=list(f["data"]), ep=list(f["ep"]))
+
+
+@pytest.fixture(scope="session")
 def golden_se():
     return load_golden("se")
 

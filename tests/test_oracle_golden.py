@@ -445,3 +445,32 @@ def test_pwl3_lik_ep_oracle_matches_reference(golden_pwl3_lik):
                 close(bwd[i][0], t[f"bwd:{vid}:a"][it], rtol=1e-7)
                 close(rs[i], t[f"r:{vid}"][it], rtol=1e-6, atol=1e-8 * np.abs(t[f"r:{vid}"][it]).max())
                 close(vs[i], t[f"v:{vid}"][it], rtol=1e-7)
+
+
+# -- unitary channels (DFT, rotation)
+def _unitary_factor(c):
+    return orc.DFTFactor() if c["kind"] == "dft" else orc.RotationFactor(c["R"])
+
+
+def test_unitary_channels_oracle_matches_reference(golden_unitary):
+    for c in golden_unitary["msgs"]:
+        f = _unitary_factor(c)
+        a, b = f.forward(1.3, c["bz"], 0.7, c["bx"])
+        assert a == c["a_fwd"]
+        close(b, c["b_fwd"], rtol=1e-12, atol=1e-13)
+        a, b = f.backward(1.3, c["bz"], 0.7, c["bx"])
+        assert a == c["a_bwd"]
+        close(b, c["b_bwd"], rtol=1e-12, atol=1e-13)
+    for c in golden_unitary["ep"]:
+        N = c["N"]
+        zshape = (2, N) if c["kind"] == "dft" else (N,)
+        fs = [orc.GBPriorFactor(N, rho=c["rho"]), _unitary_factor(c), orc.GaussLikFactor(c["y"], c["noise_var"])]
+        iters = []
+        res = orc.ep_chain(fs, [(N,), zshape], max_iter=30, damping=c["damping"],
+                           record=lambda it, fwd, bwd, rs, vs: iters.append((rs, vs)))
+        assert res["n_iter"] == c["n_iter"]
+        t = c["traj"]
+        for it in range(min(len(iters), t["v:x"].shape[0])):
+            for i, vid in enumerate(["x", "z"]):
+                close(iters[it][0][i], t[f"r:{vid}"][it], rtol=1e-8, atol=1e-10)
+                close(iters[it][1][i], t[f"v:{vid}"][it], rtol=1e-9)

@@ -64,6 +64,7 @@ from tramp.channels import (  # noqa: E402
 from tramp.channels import (  # noqa: E402
     ConvChannel, Blur1DChannel, Blur2DChannel, DifferentialChannel, LaplacianChannel
 )
+from tramp.channels import DFTChannel, RotationChannel  # noqa: E402
 from tramp.variables import SISOVariable as V  # noqa: E402
 from tramp.algos import ExpectationPropagation, StateEvolution, EarlyStoppingEP  # noqa: E402
 from tramp.algos import EarlyStopping, ConstantInit  # noqa: E402
@@ -505,6 +506,53 @@ def pwl3_lik_goldens():
          ep=np.array(trajs, dtype=object))
 
 
+# ---------------------------------------------------------------- unitary channels (DFT, rotation)
+def unitary_goldens():
+    rs = np.random.RandomState(31)
+    msgs = []
+    for shape in ((16,), (15,), (6, 8)):
+        ch = DFTChannel(real=True)
+        bz = rs.standard_normal(shape)
+        bx = rs.standard_normal((2,) + shape)
+        af, bf = ch.compute_forward_message(1.3, bz, 0.7, bx)
+        ab, bb = ch.compute_backward_message(1.3, bz, 0.7, bx)
+        msgs.append(dict(kind="dft", shape=shape, bz=bz, bx=bx, a_fwd=af, b_fwd=bf, a_bwd=ab, b_bwd=bb,
+                         x=ch.sample(bz)))
+    for N in (12, 33):
+        Q, _ = np.linalg.qr(rs.randn(N, N))
+        ch = RotationChannel(Q)
+        bz, bx = rs.standard_normal(N), rs.standard_normal(N)
+        af, bf = ch.compute_forward_message(1.3, bz, 0.7, bx)
+        ab, bb = ch.compute_backward_message(1.3, bz, 0.7, bx)
+        msgs.append(dict(kind="rotation", R=Q, bz=bz, bx=bx, a_fwd=af, b_fwd=bf, a_bwd=ab, b_bwd=bb))
+    trajs = []
+    for kind, damping in (("dft", None), ("dft", 0.3), ("rotation", None), ("rotation", 0.3)):
+        r = np.random.RandomState(7)
+        N, rho, nv = 96, 0.15, 1e-2
+        x = r.standard_normal(N) * r.binomial(n=1, size=N, p=rho)
+        if kind == "dft":
+            ch, Q = DFTChannel(real=True), None
+        else:
+            Q, _ = np.linalg.qr(r.randn(N, N))
+            ch = RotationChannel(Q)
+        z = ch.sample(x)
+        y = z + np.sqrt(nv) * r.standard_normal(z.shape)
+        model = (GaussBernoulliPrior(size=N, rho=rho) @ V(id="x") @ ch @ V(id="z")
+                 @ GaussianLikelihood(y=y, var=nv)).to_model()
+        ep = ExpectationPropagation(model)
+        rec = Recorder(EarlyStoppingEP())
+        err = None
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=30, callback=rec, damping=damping)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        trajs.append(dict(kind=kind, N=N, rho=rho, noise_var=nv, damping=damping, x=x, y=y, R=Q, n_iter=ep.n_iter,
+                          error=err, n_recorded=len(rec.iters), traj=pack_traj(rec.iters[:12])))
+        print("unitary ep", kind, damping, "n_iter", ep.n_iter, err)
+    save("unitary", data=np.array(msgs, dtype=object), ep=np.array(trajs, dtype=object))
+
+
 # ---------------------------------------------------------------- convolution channel
 def conv_goldens():
     "ConvChannel family (real=True): posteriors, messages, scalars, samples, EP trajectories."
@@ -706,5 +754,7 @@ if __name__ == "__main__":
         conv_goldens()
     if not only or "pwl3lik" in only:
         pwl3_lik_goldens()
+    if not only or "unitary" in only:
+        unitary_goldens()
     if not only or "se" in only:
         se_goldens(args.skip_slow)

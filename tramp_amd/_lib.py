@@ -82,6 +82,9 @@ _SIGNATURES = {
     "tramp_conv_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_linear_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_conv_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
+    "tramp_dft_create": [vp, i32, i32, C.POINTER(sz), C.POINTER(vp)],
+    "tramp_dft_destroy": [vp, vp],
+    "tramp_dft_message": [vp, vp, i32, sz, vp, vp, dbl, vp, vp, vp, vp],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -814,6 +814,167 @@ class Blur2DChannel(ConvChannel):
         self.sigma = sigma
 
 
+class _UnitaryChannel(Channel):
+    """Shared message plumbing of the unitary channels (DFT, rotation): the posterior is not
+    needed - (a, b) travel through the change of basis (a unchanged, b transformed)."""
+
+    def second_moment(self, tau_z):
+        return tau_z
+
+    def compute_forward_state_evolution(self, az, ax, tau_z):
+        return az
+
+    def compute_backward_state_evolution(self, az, ax, tau_z):
+        return ax
+
+    def compute_forward_error(self, az, ax, tau_z):
+        return 1.0 / (az + ax)
+
+    def compute_backward_error(self, az, ax, tau_z):
+        return 1.0 / (az + ax)
+
+    def _finish(self, a_in, src, a_new, b_new, out_a, out_b):
+        if out_a is not None:
+            return out_a, out_b
+        if src.was_host:
+            a = a_new.get()
+            a = float(a[0]) if (a_in.was_host and a_in.scalar_like and len(src.host_shape) == 1) else a
+            return a, b_new.get().reshape(self._host_out_shape(src))
+        return a_new, b_new
+
+
+class DFTChannel(_UnitaryChannel):
+    """x = fftn(z, norm="ortho") for real z (tramp/channels/linear/dft_channel.py:7-77).
+
+    A complex vector is the planar real array [2, n] as in the reference; on the device
+    [batch, 2 n].  ``shape`` is only needed for transforms over more than one axis."""
+
+    def __init__(self, real=True, shape=None, dtype=np.float64, ctx=None):
+        if not real:
+            raise NotImplementedError("complex input (real=False) is outside the HIP path")
+        self.real = real
+        self.shape = None if shape is None else tuple(int(v) for v in np.atleast_1d(shape))
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self._handle = None
+        self._n = None
+
+    def _ensure(self, n):
+        if self._handle is not None and self._n == n:
+            return
+        dims = self.shape if self.shape is not None else (n,)
+        if int(np.prod(dims)) != n:
+            raise ValueError(f"message of {n} components does not match shape {dims}")
+        self.__del__()
+        arr = (C.c_size_t * len(dims))(*dims)
+        h = C.c_void_p()
+        self.ctx._call("tramp_dft_create", self._dt, len(dims), arr, C.byref(h))
+        self._handle, self._n = h, n
+
+    def __del__(self):
+        try:
+            if self._handle and self.ctx.handle:
+                self.ctx.lib.tramp_dft_destroy(self.ctx.handle, self._handle)
+        except Exception:
+            pass
+        self._handle = None
+
+    def _host_out_shape(self, src):
+        return self._out_shape
+
+    def _vec(self, b, planar):
+        if isinstance(b, DeviceArray):
+            return VecArg(self.ctx, b, self.dtype)
+        h = np.asarray(b, dtype=self.dtype)
+        core = h.shape[-(len(self.shape) if self.shape else 1):]
+        nd = len(core) + (1 if planar else 0)
+        if h.ndim not in (nd, nd + 1):
+            raise ValueError(f"unexpected message shape {h.shape}")
+        n_tot = int(np.prod(h.shape[-nd:]))
+        arg = VecArg(self.ctx, h.reshape(-1, n_tot) if h.ndim == nd + 1 else h.reshape(n_tot), self.dtype)
+        lead = h.shape[:-nd]
+        self._out_shape = lead + (core if planar else (2,) + core)
+        return arg
+
+    def _message(self, direction, a_in, b_in, out_a, out_b, damping, old_a, old_b):
+        ctx = self.ctx
+        src = self._vec(b_in, planar=(direction == _lib.BWD))
+        n = src.n if direction == _lib.FWD else src.n // 2
+        self._ensure(n)
+        a = ScalArg(ctx, a_in, src.batch)
+        a_new = out_a if out_a is not None else ctx.empty((src.batch,), np.float64)
+        n_out = 2 * n if direction == _lib.FWD else n
+        b_new = out_b if out_b is not None else ctx.empty((src.batch, n_out), self.dtype)
+        ctx._call("tramp_dft_message", self._handle, direction, src.batch, a.dev.ptr, src.dev.ptr,
+                  float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr)
+        return self._finish(a, src, a_new, b_new, out_a, out_b)
+
+    def sample(self, Z):
+        return self.compute_forward_message(1.0, Z, 0.0, None)[1]     # dft_channel.py:32-38
+
+    def compute_forward_message(self, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+                                old_b=None):
+        return self._message(_lib.FWD, az, bz, out_a, out_b, damping, old_a, old_b)      # :46-53
+
+    def compute_backward_message(self, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+                                 old_b=None):
+        return self._message(_lib.BWD, ax, bx, out_a, out_b, damping, old_a, old_b)      # :55-64
+
+
+class RotationChannel(_UnitaryChannel):
+    """x = R z with R orthogonal (tramp/channels/linear/rotation_channel.py:5-60): one pass of
+    the dense matrix kernels per message, b_new = R bz forward, R^T bx backward."""
+
+    def __init__(self, R, name="R", dtype=np.float64, ctx=None):
+        R = np.asarray(R)
+        if R.ndim != 2 or R.shape[0] != R.shape[1]:
+            raise ValueError(f"R.shape = {R.shape}")
+        if not np.allclose(R @ R.T, np.identity(R.shape[0])):
+            raise ValueError("R not a rotation")
+        self.name = name
+        self.N = R.shape[0]
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.R = R
+        self._R_dev = self.ctx.array(np.ascontiguousarray(R, dtype=self.dtype), self.dtype)
+
+    def _host_out_shape(self, src):
+        return src.host_shape
+
+    def sample(self, Z):
+        return self.R @ Z
+
+    def _message(self, direction, a_in, b_in, out_a, out_b, damping, old_a, old_b):
+        ctx = self.ctx
+        src = VecArg(ctx, b_in, self.dtype)
+        if src.n != self.N:
+            raise ValueError(f"expected messages of {self.N} components, got {src.n}")
+        a = ScalArg(ctx, a_in, src.batch)
+        d = float(damping or 0.0)
+        direct = out_b is not None and not d
+        b_tmp = out_b if direct else ctx.empty((src.batch, self.N), self.dtype)
+        ctx._call("tramp_matvec_nt" if direction == _lib.FWD else "tramp_matvec_nn", self._dt, 0, self.N, self.N,
+                  src.batch, self._R_dev.ptr, src.dev.ptr, b_tmp.ptr)
+        a_tmp = ctx.empty((src.batch,), np.float64)
+        a_tmp.copy_from(a.dev)
+        if d:
+            ctx._call("tramp_damp", self._dt, self.N, src.batch, d, old_a.ptr, old_b.ptr, a_tmp.ptr, b_tmp.ptr)
+        if out_a is not None:
+            out_a.copy_from(a_tmp)
+            if not direct:
+                out_b.copy_from(b_tmp)
+        return self._finish(a, src, a_tmp, b_tmp, out_a, out_b)
+
+    def compute_forward_message(self, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+                                old_b=None):
+        return self._message(_lib.FWD, az, bz, out_a, out_b, damping, old_a, old_b)      # :32-36
+
+    def compute_backward_message(self, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+                                 old_b=None):
+        return self._message(_lib.BWD, ax, bx, out_a, out_b, damping, old_a, old_b)      # :38-42
+
+
 class AnalyticalLinearChannel(Channel):
     "SE-only linear channel with closed-form spectrum transforms (analytical_linear_channel.py:8-62)"
 
@@ -868,6 +1029,8 @@ CHANNEL_CLASSES = {
     "blur_2d": Blur2DChannel,
     "diff": DifferentialChannel,
     "laplacian": LaplacianChannel,
+    "dft": DFTChannel,
+    "rotation": RotationChannel,
 }
 
 

@@ -74,15 +74,13 @@ int rocfft_fail(tramp_ctx* ctx, const char* what, rocfft_status st) {
         if (st_ != rocfft_status_success) return rocfft_fail(ctx, #call, st_); \
     } while (0)
 
-int make_plan(tramp_ctx* ctx, const tramp_conv* cv, bool forward, bool f64, size_t batch, rocfft_plan* plan,
-              rocfft_execution_info* info, void** work) {
+int make_plan_dims(tramp_ctx* ctx, int ndim, const size_t* dims, rocfft_transform_type type, bool f64, size_t batch,
+                   rocfft_plan* plan, rocfft_execution_info* info, void** work) {
     size_t lengths[3];
-    for (int d = 0; d < cv->ndim; ++d) lengths[d] = cv->dims[cv->ndim - 1 - d];   // rocFFT: fastest axis first
-    TRAMP_FFT_CHECK(ctx, rocfft_plan_create(plan, rocfft_placement_notinplace,
-                                            forward ? rocfft_transform_type_real_forward
-                                                    : rocfft_transform_type_real_inverse,
+    for (int d = 0; d < ndim; ++d) lengths[d] = dims[ndim - 1 - d];   // rocFFT: fastest axis first
+    TRAMP_FFT_CHECK(ctx, rocfft_plan_create(plan, rocfft_placement_notinplace, type,
                                             f64 ? rocfft_precision_double : rocfft_precision_single,
-                                            (size_t)cv->ndim, lengths, batch, nullptr));
+                                            (size_t)ndim, lengths, batch, nullptr));
     size_t wsz = 0;
     TRAMP_FFT_CHECK(ctx, rocfft_plan_get_work_buffer_size(*plan, &wsz));
     TRAMP_FFT_CHECK(ctx, rocfft_execution_info_create(info));
@@ -93,6 +91,13 @@ int make_plan(tramp_ctx* ctx, const tramp_conv* cv, bool forward, bool f64, size
     }
     TRAMP_FFT_CHECK(ctx, rocfft_execution_info_set_stream(*info, ctx->stream));
     return TRAMP_OK;
+}
+
+int make_plan(tramp_ctx* ctx, const tramp_conv* cv, bool forward, bool f64, size_t batch, rocfft_plan* plan,
+              rocfft_execution_info* info, void** work) {
+    return make_plan_dims(ctx, cv->ndim, cv->dims,
+                          forward ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse, f64,
+                          batch, plan, info, work);
 }
 
 int plans_for(tramp_ctx* ctx, tramp_conv* cv, size_t batch, ConvPlans** out) {
@@ -575,6 +580,216 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
             hipLaunchKernelGGL((conv_epilogue_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n, a_in, cv->a_raw,
                                (const float*)b_in, damping, (const float*)b_old_d, (const float*)mean,
                                (float*)b_new_d, (float*)nullptr);
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    return TRAMP_OK;
+}
+
+// ---------------------------------------------------------------- DFT channel x = F z / sqrt(n)
+// DFTChannel (tramp/channels/linear/dft_channel.py:7-77, real=True): a unitary change of basis,
+// so the messages just travel through it: forward (ax_new, bx_new) = (az, F bz), backward
+// (az_new, bz_new) = (ax, Re F^-1 bx), both with norm="ortho".  A complex vector is the planar
+// real array [2, n] (row 0 real parts, row 1 imaginary parts) as in the reference.
+struct DftPlans {
+    size_t batch;
+    rocfft_plan fwd, inv;
+    rocfft_execution_info info_fwd, info_inv;
+    void* work_fwd;
+    void* work_inv;
+};
+
+struct tramp_dft {
+    int dtype;
+    int ndim;
+    size_t dims[3];
+    size_t n;
+    std::vector<DftPlans> plans;
+    void* work;          // two interleaved complex buffers [batch, n]
+    size_t work_batch;
+    void* c0;
+    void* c1;
+};
+
+namespace {
+
+// real [batch, n] -> interleaved complex (imag 0)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dft_pack_real_kernel(size_t count, const T* __restrict__ in,
+                                                               typename Cx<T>::type* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) {
+        typename Cx<T>::type c;
+        c.x = in[i];
+        c.y = T(0);
+        out[i] = c;
+    }
+}
+
+// planar [batch, 2, n] -> interleaved [batch, n]
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dft_pack_planar_kernel(size_t n, const T* __restrict__ in,
+                                                                 typename Cx<T>::type* __restrict__ out) {
+    const size_t b = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        typename Cx<T>::type c;
+        c.x = in[b * 2 * n + i];
+        c.y = in[b * 2 * n + n + i];
+        out[b * n + i] = c;
+    }
+}
+
+// interleaved -> message: planar [batch, 2, n] (FWD) or real part [batch, n] (BWD), scaled by
+// 1/sqrt(n), constant damping fused
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dft_unpack_kernel(size_t n, int planar, T scale,
+                                                            const typename Cx<T>::type* __restrict__ in,
+                                                            double damping, const T* b_old, T* out) {
+    const size_t b = blockIdx.y;
+    const T d = T(damping), omd = T(1.0 - damping);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const typename Cx<T>::type c = in[b * n + i];
+        if (planar) {
+            T re = c.x * scale, im = c.y * scale;
+            const size_t o = b * 2 * n + i;
+            if (damping != 0.0) {
+                re = d * b_old[o] + omd * re;
+                im = d * b_old[o + n] + omd * im;
+            }
+            out[o] = re;
+            out[o + n] = im;
+        } else {
+            T re = c.x * scale;
+            if (damping != 0.0) re = d * b_old[b * n + i] + omd * re;
+            out[b * n + i] = re;
+        }
+    }
+}
+
+__global__ void dft_scalar_kernel(size_t batch, const double* __restrict__ a_in, double damping,
+                                  const double* __restrict__ a_old, double* __restrict__ a_new) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double a = a_in[b];
+    a_new[b] = (damping != 0.0) ? damping * a_old[b] + (1.0 - damping) * a : a;
+}
+
+}  // namespace
+
+extern "C" int tramp_dft_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, tramp_dft** dft) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, dft && dims);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F64 || dtype == TRAMP_F32);
+    TRAMP_REQUIRE(ctx, ndim >= 1 && ndim <= 3);
+    std::call_once(g_rocfft_once, [] { (void)rocfft_setup(); });
+    tramp_dft* h = new tramp_dft();
+    h->dtype = dtype;
+    h->ndim = ndim;
+    h->n = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (dims[d] == 0) {
+            delete h;
+            return tramp_fail(ctx, TRAMP_EINVAL, "tramp_dft_create", "zero-length axis");
+        }
+        h->dims[d] = dims[d];
+        h->n *= dims[d];
+    }
+    h->work = nullptr;
+    h->work_batch = 0;
+    *dft = h;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_dft_destroy(tramp_ctx* ctx, tramp_dft* h) {
+    if (!h) return TRAMP_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : h->plans) {
+        (void)rocfft_execution_info_destroy(p.info_fwd);
+        (void)rocfft_execution_info_destroy(p.info_inv);
+        (void)rocfft_plan_destroy(p.fwd);
+        (void)rocfft_plan_destroy(p.inv);
+        if (p.work_fwd) (void)hipFree(p.work_fwd);
+        if (p.work_inv) (void)hipFree(p.work_inv);
+    }
+    if (h->work) (void)hipFree(h->work);
+    delete h;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_dft_message(tramp_ctx* ctx, tramp_dft* h, int dir, size_t batch, const double* a_in_d,
+                                 const void* b_in_d, double damping, const double* a_old_d, const void* b_old_d,
+                                 double* a_new_d, void* b_new_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, h && a_in_d && b_in_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!batch) return TRAMP_OK;
+    const size_t n = h->n, esz = dtype_size(h->dtype);
+    if (batch > h->work_batch) {
+        if (ctx->capturing) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_dft", "workspace growth inside graph capture");
+        TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (h->work) (void)hipFree(h->work);
+        h->work = nullptr;
+        h->work_batch = 0;
+        const size_t per = ((batch * n * 2 * esz + 255) / 256) * 256;
+        TRAMP_HIP_CHECK(ctx, hipMalloc(&h->work, 2 * per));
+        h->c0 = h->work;
+        h->c1 = (char*)h->work + per;
+        h->work_batch = batch;
+    }
+    DftPlans* pl = nullptr;
+    for (auto& p : h->plans)
+        if (p.batch == batch) pl = &p;
+    if (!pl) {
+        if (ctx->capturing) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_dft", "FFT plan creation inside graph capture");
+        DftPlans p{};
+        p.batch = batch;
+        const bool f64 = h->dtype == TRAMP_F64;
+        int rc = make_plan_dims(ctx, h->ndim, h->dims, rocfft_transform_type_complex_forward, f64, batch, &p.fwd,
+                                &p.info_fwd, &p.work_fwd);
+        if (rc) return rc;
+        rc = make_plan_dims(ctx, h->ndim, h->dims, rocfft_transform_type_complex_inverse, f64, batch, &p.inv,
+                            &p.info_inv, &p.work_inv);
+        if (rc) return rc;
+        h->plans.push_back(p);
+        pl = &h->plans.back();
+    }
+    const bool fwd = dir == TRAMP_FWD;
+    const double scale = 1.0 / sqrt((double)n);
+    dim3 g(grid_for(n), (unsigned)batch);
+    hipLaunchKernelGGL(dft_scalar_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, batch, a_in_d,
+                       damping, a_old_d, a_new_d);
+    {
+        ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (fwd ? 3 : 4), 0);
+        if (h->dtype == TRAMP_F64) {
+            if (fwd)
+                hipLaunchKernelGGL((dft_pack_real_kernel<double>), dim3(grid_for(batch * n)), dim3(kBlock), 0,
+                                   ctx->stream, batch * n, (const double*)b_in_d, (double2*)h->c0);
+            else
+                hipLaunchKernelGGL((dft_pack_planar_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n,
+                                   (const double*)b_in_d, (double2*)h->c0);
+        } else {
+            if (fwd)
+                hipLaunchKernelGGL((dft_pack_real_kernel<float>), dim3(grid_for(batch * n)), dim3(kBlock), 0,
+                                   ctx->stream, batch * n, (const float*)b_in_d, (float2*)h->c0);
+            else
+                hipLaunchKernelGGL((dft_pack_planar_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n,
+                                   (const float*)b_in_d, (float2*)h->c0);
+        }
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(ctx, PROF_FFT, (double)batch * n * 4 * esz, 0);
+        int rc = fwd ? fft_exec(ctx, pl->fwd, pl->info_fwd, h->c0, h->c1)
+                     : fft_exec(ctx, pl->inv, pl->info_inv, h->c0, h->c1);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (fwd ? 4 : 3), 0);
+        if (h->dtype == TRAMP_F64)
+            hipLaunchKernelGGL((dft_unpack_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n, fwd ? 1 : 0, scale,
+                               (const double2*)h->c1, damping, (const double*)b_old_d, (double*)b_new_d);
+        else
+            hipLaunchKernelGGL((dft_unpack_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n, fwd ? 1 : 0,
+                               (float)scale, (const float2*)h->c1, damping, (const float*)b_old_d, (float*)b_new_d);
         TRAMP_LAUNCH_CHECK(ctx);
     }
     return TRAMP_OK;

@@ -11,7 +11,7 @@ import networkx as nx
 import numpy as np
 
 from .base import Factor, Variable
-from .channels import (ConvChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
+from .channels import (ConvChannel, DFTChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
                        PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
@@ -142,6 +142,8 @@ class Model:
                 shape = (node.Nx,)
             elif isinstance(node, ConvChannel):
                 shape = tuple(node.shape)
+            elif isinstance(node, DFTChannel):
+                shape = (2,) + tuple(shape)
             if isinstance(node, Variable):
                 shapes[node.id] = shape
                 self.dag.nodes[node]["shape"] = shape
