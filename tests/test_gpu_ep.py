@@ -252,7 +252,8 @@ def test_ep_agrees_with_state_evolution_at_large_n(ctx):
     rs = np.random.RandomState(5)
     X = rs.standard_normal((B, N)) * rs.binomial(1, rho, (B, N))
     Z = ctx.empty((B, M))
-    ctx._call("tramp_matvec_nt", T.device.dtype_code(np.float64), 0, M, N, B, W.ptr, ctx.array(X).ptr, Z.ptr)
+    Xd = ctx.array(X)                                   # named: the buffer must outlive the asynchronous launch
+    ctx._call("tramp_matvec_nt", T.device.dtype_code(np.float64), 0, M, N, B, W.ptr, Xd.ptr, Z.ptr)
     Y = Z.get() + np.sqrt(nv) * rs.standard_normal((B, M))
     model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
              @ T.LinearChannel(W, ctx=ctx, svd="device") @ T.SISOVariable(id="z")
@@ -301,5 +302,6 @@ def test_damped_constant_message_needs_no_matrix_pass(ctx):
     lin_ch = model.factors[1]
     with pytest.raises(T._lib.TrampHipError):
         fresh = T.LinearChannel(W, ctx=ctx, svd="host")
-        ctx._call("tramp_linear_project_affine", fresh._handle, T._lib.REUSE_U, B, ctx.array(Y).ptr, 0.5, 1)
+        Yd = ctx.array(Y)
+        ctx._call("tramp_linear_project_affine", fresh._handle, T._lib.REUSE_U, B, Yd.ptr, 0.5, 1)
     assert lin_ch._u_key is not None

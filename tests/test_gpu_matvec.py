@@ -51,3 +51,32 @@ def test_mfma_deterministic(ctx):
     a, _ = run(ctx, T, "nt", 2, 1000, 2048, 64, np.float64)
     b, _ = run(ctx, T, "nt", 2, 1000, 2048, 64, np.float64)
     assert np.array_equal(a, b)
+
+
+def test_f64_4x4x4_block_kernels_in_subprocess():
+    """The alternative f64 MFMA kernels (v_mfma_f64_4x4x4_4b, TRAMP_MFMA_F64_SHAPE=4; not the
+    default, see gemm_mfma.hip) give the same results: run a few shapes in a child process
+    because the choice is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, ".")
+import numpy as np, tramp_amd as T
+ctx = T.default_context(); dt = T.device.dtype_code(np.float64)
+rs = np.random.RandomState(0)
+for (R, C, B) in [(96, 160, 64), (130, 70, 37), (512, 1024, 64), (64, 30, 5), (34, 258, 130)]:
+    M = rs.randn(R, C); Xn = rs.randn(B, C); Xt = rs.randn(B, R)
+    o1 = ctx.empty((B, R)); o2 = ctx.empty((B, C))
+    Md, Xnd, Xtd = ctx.array(M), ctx.array(Xn), ctx.array(Xt)      # keep the buffers alive across the launches
+    ctx._call("tramp_matvec_nt", dt, 2, R, C, B, Md.ptr, Xnd.ptr, o1.ptr)
+    ctx._call("tramp_matvec_nn", dt, 2, R, C, B, Md.ptr, Xtd.ptr, o2.ptr)
+    assert np.abs(o1.get() - Xn @ M.T).max() < 1e-11 * C, (R, C, B, "nt")
+    assert np.abs(o2.get() - Xt @ M).max() < 1e-11 * R, (R, C, B, "nn")
+print("ok")
+'''
+    env = dict(os.environ, TRAMP_MFMA_F64_SHAPE="4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr

@@ -63,7 +63,7 @@ template <typename T> constexpr int kstep_of() { return 4 * kPieces * Mx<T>::E; 
 template <typename T, int BT, int RT, bool TAIL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
 void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, const T* __restrict__ x,
-                    size_t steps_per_split, double* __restrict__ partials) {
+                    size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
     using V = typename Mx<T>::piece;
     using A = typename Mx<T>::acc_t;
     constexpr int E = Mx<T>::E;
@@ -71,7 +71,7 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     __shared__ V xs[2][BT][kPieces][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
-    const size_t rb = blockIdx.x / kSplit, split = blockIdx.x % kSplit;
+    const size_t rb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
     const size_t bchunk = (size_t)blockIdx.y * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;          // instances in this chunk
     const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
@@ -170,7 +170,7 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
 template <typename T, int BT, bool TAIL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
 void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, const T* __restrict__ x,
-                    size_t steps_per_split, double* __restrict__ partials) {
+                    size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
     using V = typename Mx<T>::piece;
     using A = typename Mx<T>::acc_t;
     constexpr int E = Mx<T>::E;
@@ -179,7 +179,7 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     __shared__ V xs[2][BT][kPieces][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
-    const size_t cb = blockIdx.x / kSplit, split = blockIdx.x % kSplit;
+    const size_t cb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
     const size_t bchunk = (size_t)blockIdx.y * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
     const size_t col0 = cb * (64 * E) + (size_t)wave * (16 * E);
@@ -265,6 +265,258 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     }
 }
 
+// ------------------------------------------------------------------------------ f64 on 4x4x4 blocks
+// v_mfma_f64_4x4x4_4b_f64 (4 blocks of D[4x4] += A[4x4] B[4x4], 512 flop) issues every 16.5
+// cycles per SIMD on this part - 76 TFLOP/s chip-wide in a register-only loop - where
+// v_mfma_f64_16x16x4_f64 (2048 flop) needs ~105 cycles, 47 TFLOP/s (tools/probes/probe_mfma64.hip).
+// Lane layout (tools/probes/probe_mfma4_layout.hip): with k = lane >> 4, blk = (lane >> 2) & 3,
+//     A[blk][i][k] sits in lane 16 k + 4 blk + i,  B[blk][k][n] in lane 16 k + 4 blk + n,
+//     D[blk][i][n] in lane 16 i + 4 blk + n.
+// Taking A = matrix makes (4 blk + i) = lane & 15 the matrix row (NT) / column pair (NN) and
+// k = lane >> 4 the contraction slot: exactly the lane -> memory mapping of the 16x16x4
+// kernels above, so the global loads are unchanged.  B = x for a tile of 4 instances does
+// not depend on blk: the four blocks read the same 16 LDS entries (broadcast), which are laid
+// out contiguously per tile ([tile][k][n], 256 B) so the reads are bank-conflict free.
+// One MFMA = 16 rows x 4 instances x 4 k; 16 accumulator doubles per 16 rows x 64 instances.
+// STATUS (measured, N = 65536 x 64): 50-52 TFLOP/s against 54-55 for the 16x16x4 kernels, so
+// these are NOT the default (TRAMP_MFMA_F64_SHAPE=4 selects them; parity-tested).  The matrix
+// pipe is 65 % busy (SQ_VALU_MFMA_BUSY_CYCLES), the two resident waves per SIMD spend 67 % of
+// their cycles issue-stalled and 20 % in s_waitcnt / s_barrier; neither deeper LDS prefetch,
+// split-K, occupancy, nor dropping the workgroup barrier (one wave per workgroup) moved it.  The same instruction stream fed from registers reaches
+// 75 TFLOP/s with ONE wave per SIMD (tools/probes/probe_mfma4_ops.hip; 56-63 with LDS-fed
+// operands), so what is left is taking the per-step workgroup barrier and the global-load
+// waits off the MFMA waves (loader / consumer wave specialisation) - the next thing to try.
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int BT, int RT, bool TAIL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void gemm_nt4_kernel(size_t R, size_t C, size_t B, const double* __restrict__ mat, const double* __restrict__ x,
+                     size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
+    using V = v2d;
+    constexpr int E = 2;
+    constexpr int KS = 4 * kPieces * E;            // 16 columns per step
+    constexpr int NT4 = 4 * BT;                    // instance tiles of 4
+    __shared__ V xs[2][kPieces][BT * 64];          // [stage][piece][tile * 16 + k * 4 + n]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const size_t rb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    const size_t bchunk = (size_t)blockIdx.y * 64;
+    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
+    const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
+    const size_t nsteps_total = (C + KS - 1) / KS;
+    const size_t sbeg = split * steps_per_split;
+    size_t send = sbeg + steps_per_split;
+    if (send > nsteps_total) send = nsteps_total;
+    const V vzero = {};
+    const double* mp[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        size_t r = row0 + rt * 16 + j;
+        if (r >= R) r = R - 1;
+        mp[rt] = mat + r * C + q * E;
+    }
+    size_t xb = bchunk + (size_t)wave * 16 + j;
+    if (xb >= B) xb = B - 1;
+    const double* xp = x + xb * C + q * E;
+    const bool loads_x = wave < BT;
+    const int wr = 64 * wave + 16 * (j >> 2) + 4 * q + (j & 3);   // instance 16 w + j -> tile 4 w + j/4, n = j%4
+    const int rd = 4 * q + (lane & 3);
+
+    double acc[RT][NT4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT4; ++t) acc[rt][t] = 0.0;
+
+    V m[RT][kPieces], mn[RT][kPieces], xg[kPieces];
+    if (sbeg < send) {
+        const size_t k0 = sbeg * KS;
+#pragma unroll
+        for (int p = 0; p < kPieces; ++p) {
+            const bool in = !TAIL || k0 + p * 4 * E + q * E < C;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                m[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k0 + p * 4 * E) : vzero;
+            if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k0 + p * 4 * E) : vzero;
+        }
+    }
+    for (size_t s = sbeg; s < send; ++s) {
+        const int st = (int)((s - sbeg) & 1);
+        if (loads_x) {
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) xs[st][p][wr] = xg[p];
+        }
+        if (s + 1 < send) {
+            const size_t k1 = (s + 1) * KS;
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) {
+                const bool in = !TAIL || k1 + p * 4 * E + q * E < C;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    mn[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k1 + p * 4 * E) : vzero;
+                if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k1 + p * 4 * E) : vzero;
+            }
+        }
+        __syncthreads();
+        // software pipeline over the (piece, tile pair) stages: the x fragments of stage i+1 are
+        // read from LDS while the 4 RT MFMAs of stage i issue (one ds_read_b128 feeds 2 RT MFMAs)
+        constexpr int NST = kPieces * (NT4 / 2);
+        V xa = xs[st][0][rd], xc = xs[st][0][16 + rd];
+#pragma unroll
+        for (int sg = 0; sg < NST; ++sg) {
+            const int p = sg / (NT4 / 2), t = 2 * (sg % (NT4 / 2));
+            V na = xa, nc = xc;
+            if (sg + 1 < NST) {
+                const int p1 = (sg + 1) / (NT4 / 2), t1 = 2 * ((sg + 1) % (NT4 / 2));
+                na = xs[st][p1][t1 * 16 + rd];
+                nc = xs[st][p1][(t1 + 1) * 16 + rd];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][t] = mfma4(m[rt][p][e], xa[e], acc[rt][t]);
+                    acc[rt][t + 1] = mfma4(m[rt][p][e], xc[e], acc[rt][t + 1]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            xa = na;
+            xc = nc;
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) m[rt][p] = mn[rt][p];
+    }
+    // D[blk][i][n] in lane 16 i + 4 blk + n: mat row 4 blk + i, instance n of the tile
+    double* pout = partials + (split * B) * R;
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dn = lane & 3;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const size_t r = row0 + rt * 16 + drow;
+        if (r < R) {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) {
+                const size_t b = 4 * t + dn;
+                if (b < nb) pout[(bchunk + b) * R + r] = acc[rt][t];
+            }
+        }
+    }
+}
+
+template <int BT, bool TAIL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void gemm_nn4_kernel(size_t R, size_t C, size_t B, const double* __restrict__ mat, const double* __restrict__ x,
+                     size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
+    using V = v2d;
+    constexpr int E = 2;
+    constexpr int KS = 4 * kPieces * E;
+    constexpr int S = kPieces * E;                 // rows per lane per step
+    constexpr int NT4 = 4 * BT;
+    __shared__ V xs[2][kPieces][BT * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const size_t cb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    const size_t bchunk = (size_t)blockIdx.y * 64;
+    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
+    const size_t col0 = cb * (64 * E) + (size_t)wave * (16 * E);
+    const size_t nsteps_total = (R + KS - 1) / KS;
+    const size_t sbeg = split * steps_per_split;
+    size_t send = sbeg + steps_per_split;
+    if (send > nsteps_total) send = nsteps_total;
+    const V vzero = {};
+    size_t cl = col0 + E * j;
+    if (cl + E > C) cl = C - E;
+    const double* mp = mat + cl + (size_t)(S * q) * C;
+    size_t xb = bchunk + (size_t)wave * 16 + j;
+    if (xb >= B) xb = B - 1;
+    const double* xp = x + xb * R + S * q;
+    const bool loads_x = wave < BT;
+    const int wr = 64 * wave + 16 * (j >> 2) + 4 * q + (j & 3);
+    const int rd = 4 * q + (lane & 3);
+
+    double acc[E][NT4];
+#pragma unroll
+    for (int nt = 0; nt < E; ++nt)
+#pragma unroll
+        for (int t = 0; t < NT4; ++t) acc[nt][t] = 0.0;
+
+    V m[S], mn[S], xg[kPieces];
+    if (sbeg < send) {
+        const size_t k0 = sbeg * KS;
+#pragma unroll
+        for (int s4 = 0; s4 < S; ++s4)
+            m[s4] = (!TAIL || k0 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k0 + s4) * C) : vzero;
+        if (loads_x) {
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p)
+                xg[p] = (!TAIL || k0 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k0 + p * E) : vzero;
+        }
+    }
+    for (size_t s = sbeg; s < send; ++s) {
+        const int st = (int)((s - sbeg) & 1);
+        if (loads_x) {
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) xs[st][p][wr] = xg[p];
+        }
+        if (s + 1 < send) {
+            const size_t k1 = (s + 1) * KS;
+#pragma unroll
+            for (int s4 = 0; s4 < S; ++s4)
+                mn[s4] = (!TAIL || k1 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k1 + s4) * C) : vzero;
+            if (loads_x) {
+#pragma unroll
+                for (int p = 0; p < kPieces; ++p)
+                    xg[p] = (!TAIL || k1 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k1 + p * E) : vzero;
+            }
+        }
+        __syncthreads();
+        // stages of 4 instance tiles (16 MFMAs); the next stage's x fragments are read meanwhile
+        // (reading two stages ahead measured no faster)
+        constexpr int NST = kPieces * (NT4 / 4);
+        V xa[4], na[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) xa[tt] = xs[st][0][tt * 16 + rd];
+#pragma unroll
+        for (int sg = 0; sg < NST; ++sg) {
+            const int p = sg / (NT4 / 4), t0 = 4 * (sg % (NT4 / 4));
+            if (sg + 1 < NST) {
+                const int p1 = (sg + 1) / (NT4 / 4), t1 = 4 * ((sg + 1) % (NT4 / 4));
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) na[tt] = xs[st][p1][(t1 + tt) * 16 + rd];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int nt = 0; nt < E; ++nt)
+                        acc[nt][t0 + tt] = mfma4(m[p * E + e][nt], xa[tt][e], acc[nt][t0 + tt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sg + 1 < NST) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) xa[tt] = na[tt];
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < S; ++s4) m[s4] = mn[s4];
+    }
+    double* pout = partials + (split * B) * C;
+    const int dj = 4 * ((lane >> 2) & 3) + (lane >> 4), dn = lane & 3;
+    const size_t c = col0 + E * dj;
+    if (c + E <= C) {
+#pragma unroll
+        for (int t = 0; t < NT4; ++t) {
+            const size_t b = 4 * t + dn;
+            if (b < nb)
+                *reinterpret_cast<double2*>(pout + (bchunk + b) * C + c) = double2{acc[0][t], acc[1][t]};
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ fold + epilogue
 template <typename T>
 __device__ __forceinline__ void mfma_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
@@ -308,6 +560,13 @@ bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch) {
     return (R % e) == 0 && R >= e && (C % e) == 0 && C >= e;
 }
 
+// Split-K factor.  Default 8 (= XCDs: split index == XCD under the round-robin dispatch).
+static int pick_split(tramp_ctx* ctx, bool nt, size_t len, size_t nsteps, int forced) {
+    int s = forced > 0 ? forced : kSplit;
+    if ((size_t)s > nsteps) s = (int)(nsteps ? nsteps : 1);
+    return s;
+}
+
 template <typename T>
 static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch, const T* mat, const T* x,
                        const LinEpi& epi) {
@@ -315,8 +574,11 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     const size_t len = nt ? R : C;                  // output length per instance
     const size_t kdim = nt ? C : R;
     const size_t nsteps = (kdim + kstep_of<T>() - 1) / kstep_of<T>();
-    const size_t sps = (nsteps + kSplit - 1) / kSplit;
-    int rc = tramp_ws_reserve(ctx, (size_t)kSplit * batch * len * sizeof(double));
+    static const int split_env = getenv("TRAMP_MFMA_SPLIT") ? atoi(getenv("TRAMP_MFMA_SPLIT")) : 0;
+    static const int pad_env = getenv("TRAMP_MFMA_LDS_PAD") ? atoi(getenv("TRAMP_MFMA_LDS_PAD")) : 0;
+    const unsigned nsplit = (unsigned)pick_split(ctx, nt, len, nsteps, split_env);
+    const size_t sps = (nsteps + nsplit - 1) / nsplit;
+    int rc = tramp_ws_reserve(ctx, (size_t)nsplit * batch * len * sizeof(double));
     if (rc) return rc;
     const unsigned nchunk = (unsigned)((batch + 63) / 64);
     const size_t btail = batch - (size_t)(nchunk - 1) * 64;
@@ -324,8 +586,8 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     const int bt = (nchunk > 1) ? 4 : (int)((btail + 15) / 16);
     dim3 block(kBlock);
     const bool tail = (kdim % kstep_of<T>()) != 0;
-#define LAUNCH_NT(BTv, TAILv) hipLaunchKernelGGL((gemm_nt_kernel<T, BTv, RT, TAILv>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws)
-#define LAUNCH_NN(BTv, TAILv) hipLaunchKernelGGL((gemm_nn_kernel<T, BTv, TAILv>), grid, block, 0, ctx->stream, R, C, batch, mat, x, sps, ctx->ws)
+#define LAUNCH_NT(BTv, TAILv) hipLaunchKernelGGL((gemm_nt_kernel<T, BTv, RT, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
+#define LAUNCH_NN(BTv, TAILv) hipLaunchKernelGGL((gemm_nn_kernel<T, BTv, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
 #define BY_BT(M_, TAILv)                       \
     switch (bt) {                              \
         case 1: M_(1, TAILv); break;           \
@@ -333,34 +595,59 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
         case 3: M_(3, TAILv); break;           \
         default: M_(4, TAILv); break;          \
     }
+    // 16: v_mfma_f64_16x16x4 kernels (default, 54-55 TFLOP/s at batch 64); 4: the 4x4x4-block kernels
+    // (50-52 TFLOP/s today although the instruction itself issues 1.6x faster - see the note above them)
+    static const int shape_env = getenv("TRAMP_MFMA_F64_SHAPE") ? atoi(getenv("TRAMP_MFMA_F64_SHAPE")) : 16;
+    if constexpr (sizeof(T) == 8) {
+        if (shape_env == 4) {
+            constexpr int RT = 4;
+#define LAUNCH_NT4(BTv, TAILv) hipLaunchKernelGGL((gemm_nt4_kernel<BTv, RT, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
+#define LAUNCH_NN4(BTv, TAILv) hipLaunchKernelGGL((gemm_nn4_kernel<BTv, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
+            if (nt) {
+                const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
+                dim3 grid((unsigned)(nrb * nsplit), nchunk);
+                if (tail) { BY_BT(LAUNCH_NT4, true) } else { BY_BT(LAUNCH_NT4, false) }
+            } else {
+                const size_t ncb = (C + 64 * E - 1) / (64 * E);
+                dim3 grid((unsigned)(ncb * nsplit), nchunk);
+                if (tail) { BY_BT(LAUNCH_NN4, true) } else { BY_BT(LAUNCH_NN4, false) }
+            }
+#undef LAUNCH_NT4
+#undef LAUNCH_NN4
+            dim3 g4((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
+            hipLaunchKernelGGL((mfma_fold_kernel<T>), g4, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, epi);
+            TRAMP_LAUNCH_CHECK(ctx);
+            return TRAMP_OK;
+        }
+    }
     if (nt) {
         static const int rt_env = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 4;   // measured: 54 (RT=4) vs 51 (RT=2) TFLOP/s in f64
         if (rt_env == 4) {
             constexpr int RT = 4;
             const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid((unsigned)(nrb * kSplit), nchunk);
+            dim3 grid((unsigned)(nrb * nsplit), nchunk);
             if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
         } else if (rt_env == 1) {
             constexpr int RT = 1;
             const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid((unsigned)(nrb * kSplit), nchunk);
+            dim3 grid((unsigned)(nrb * nsplit), nchunk);
             if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
         } else {
             constexpr int RT = 2;
             const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid((unsigned)(nrb * kSplit), nchunk);
+            dim3 grid((unsigned)(nrb * nsplit), nchunk);
             if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
         }
     } else {
         const size_t ncb = (C + 64 * E - 1) / (64 * E);
-        dim3 grid((unsigned)(ncb * kSplit), nchunk);
+        dim3 grid((unsigned)(ncb * nsplit), nchunk);
         if (tail) { BY_BT(LAUNCH_NN, true) } else { BY_BT(LAUNCH_NN, false) }
     }
 #undef BY_BT
 #undef LAUNCH_NT
 #undef LAUNCH_NN
     dim3 g2((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
-    hipLaunchKernelGGL((mfma_fold_kernel<T>), g2, block, 0, ctx->stream, len, batch, kSplit, ctx->ws, epi);
+    hipLaunchKernelGGL((mfma_fold_kernel<T>), g2, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, epi);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
