@@ -266,6 +266,9 @@ def run(args):
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": traffic,
                     "traffic_detail": traffic_detail,
                     "peak_measured_issue_rate": MFMA_MEASURED_TFLOPS[args.dtype],
+                    "peak_notes": "register-loop rates on this part (tools/probes): v_mfma_f64_16x16x4 47.5, "
+                                  "v_mfma_f64_4x4x4_4b 76 TFLOP/s; PMC MfmaUtil of the f64 kernels 75.5 % "
+                                  "(profiles/r01/pmc_mfma_util_kernels_N65536.csv)" if args.dtype == "f64" else None,
                     "avg_launch_ms": d["ms"] / d["launches"], "launches": d["launches"],
                     "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
         else:
