@@ -76,7 +76,9 @@ for (R, C, B) in [(96, 160, 64), (130, 70, 37), (512, 1024, 64), (64, 30, 5), (3
     assert np.abs(o2.get() - Xt @ M).max() < 1e-11 * R, (R, C, B, "nn")
 print("ok")
 '''
-    env = dict(os.environ, TRAMP_MFMA_F64_SHAPE="4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+    for extra in ({}, {"TRAMP_MFMA_RING": "1"}):          # plain 4x4x4 kernels; loader/consumer ring variant (NT)
+        env = dict(os.environ, TRAMP_MFMA_F64_SHAPE="4", **extra)
+        res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True,
+                             timeout=300)
+        assert res.returncode == 0 and "ok" in res.stdout, str(extra) + res.stdout + res.stderr

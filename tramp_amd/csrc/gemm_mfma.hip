@@ -278,14 +278,14 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
 // not depend on blk: the four blocks read the same 16 LDS entries (broadcast), which are laid
 // out contiguously per tile ([tile][k][n], 256 B) so the reads are bank-conflict free.
 // One MFMA = 16 rows x 4 instances x 4 k; 16 accumulator doubles per 16 rows x 64 instances.
-// STATUS (measured, N = 65536 x 64): 50-52 TFLOP/s against 54-55 for the 16x16x4 kernels, so
-// these are NOT the default (TRAMP_MFMA_F64_SHAPE=4 selects them; parity-tested).  The matrix
-// pipe is 65 % busy (SQ_VALU_MFMA_BUSY_CYCLES), the two resident waves per SIMD spend 67 % of
-// their cycles issue-stalled and 20 % in s_waitcnt / s_barrier; neither deeper LDS prefetch,
-// split-K, occupancy, nor dropping the workgroup barrier (one wave per workgroup) moved it.  The same instruction stream fed from registers reaches
-// 75 TFLOP/s with ONE wave per SIMD (tools/probes/probe_mfma4_ops.hip; 56-63 with LDS-fed
-// operands), so what is left is taking the per-step workgroup barrier and the global-load
-// waits off the MFMA waves (loader / consumer wave specialisation) - the next thing to try.
+// STATUS (measured, N = 65536 x 64): 50-52 TFLOP/s against 54-57 for the 16x16x4 kernels, so
+// these are NOT the default (TRAMP_MFMA_F64_SHAPE=4 selects them; parity-tested).  The reason
+// turned out not to be the kernel structure but the package power limit: rocm-smi reads
+// 1340-1380 W (TBP 1400 W) with sclk throttled to 2250-2290 MHz for every variant at batch 64,
+// 1170 W at 70 TFLOP/s when the same MFMA stream runs without HBM traffic, 1325 W for the
+// HBM-bound batch 16 (tools/power_probe.sh).  P ~ 730 W + 6.3 W per TFLOP/s + 79 W per TB/s fits all
+// three and puts the wall of this contraction (16 flop per matrix byte) at 55 TFLOP/s - where
+// the 16x16x4 kernels already are; the 4x4x4 shape spends slightly more energy per flop.
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
@@ -517,6 +517,178 @@ void gemm_nn4_kernel(size_t R, size_t C, size_t B, const double* __restrict__ ma
     }
 }
 
+// ------------------------------------------------------------------------------ f64, specialised waves
+// 8 waves per workgroup, one workgroup per CU: waves 0-3 are CONSUMERS (one per SIMD; MFMA and
+// LDS reads only, never a global load), waves 4-7 are LOADERS (global -> registers -> LDS, two
+// k steps in flight).  A step's operands live in one of two LDS slots: the matrix tile of the
+// workgroup (256 rows x 16 columns) as 32 fragments in MFMA lane order and the x tile (64
+// instances x 16 columns) as [piece][tile][k][n]; one workgroup barrier per step hands slot
+// s+1 to the consumers while the loaders already have slots s+2 and s+3 in flight.
+// tools/probes/probe_mfma4_lds.hip: a wave fed this way from LDS sustains 70-76 TFLOP/s chip-wide,
+// and with the loads switched off (TRAMP_MFMA_RING_DBG=1) this kernel runs at 69-70 TFLOP/s;
+// with them it lands on the same power wall as every other variant (50 TFLOP/s at 1375 W).
+// Kept, off by default (TRAMP_MFMA_F64_SHAPE=4 TRAMP_MFMA_RING=1), as the evidence for that.
+constexpr int kRingRT = 4;                                   // 16-row tiles per consumer wave
+constexpr int kRingMatFrag = 4 * kRingRT * kPieces;          // 32 matrix fragments (1 KiB each) per slot
+// (padded to a multiple of 4 fragments so that every loader wave has the same, branch-free work)
+template <int BT> constexpr int ring_slot_v2d() { return ((kRingMatFrag + BT * kPieces + 3) / 4) * 4 * 64; }
+
+template <int BT, bool TAIL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_nt4_ring_kernel(size_t R, size_t C, size_t B, const double* __restrict__ mat, const double* __restrict__ x,
+                          size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
+    using V = v2d;
+    constexpr int E = 2, RT = kRingRT;
+    constexpr int KS = 4 * kPieces * E;
+    constexpr int NT4 = 4 * BT;
+    constexpr int NXF = BT * kPieces;                        // x fragments per slot
+    constexpr int NF = kRingMatFrag + NXF;                   // fragments per slot
+    constexpr int NFL = (NF + 3) / 4;                        // fragments per loader wave
+    constexpr int SLOT = ring_slot_v2d<BT>();
+    extern __shared__ V ring[];                              // [2][SLOT]
+    const unsigned dbg = nsplit >> 16;                       // experiment knob (0 in production)
+    nsplit &= 0xffffu;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const size_t rb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    const size_t bchunk = (size_t)blockIdx.y * 64;
+    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
+    const size_t nsteps_total = (C + KS - 1) / KS;
+    const size_t sbeg = split * steps_per_split;
+    size_t send = sbeg + steps_per_split;
+    if (send > nsteps_total) send = nsteps_total;
+    const size_t nst = send > sbeg ? send - sbeg : 0;
+    const V vzero = {};
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------ loader
+        const int lw = wave - 4;
+        const double* fp[NFL];                                // per-lane source of fragment i (column offset added per step)
+        int dst[NFL];                                         // per-lane destination inside a slot (V units)
+        int pofs[NFL];
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) {
+            const int f = lw + 4 * i;
+            if (f < kRingMatFrag) {
+                const int cw = f / (RT * kPieces), rt = (f / kPieces) % RT, p = f % kPieces;
+                size_t r = rb * (64 * RT) + (size_t)cw * (16 * RT) + rt * 16 + j;
+                if (r >= R) r = R - 1;
+                fp[i] = mat + r * C + q * E;
+                pofs[i] = p * 4 * E;
+                dst[i] = f * 64 + lane;
+            } else if (f < NF) {
+                const int g = (f - kRingMatFrag) / kPieces, p = (f - kRingMatFrag) % kPieces;
+                size_t xb = bchunk + (size_t)g * 16 + j;
+                if (xb >= B) xb = B - 1;
+                fp[i] = x + xb * C + q * E;
+                pofs[i] = p * 4 * E;
+                dst[i] = kRingMatFrag * 64 + p * (BT * 64) + 64 * g + 16 * (j >> 2) + 4 * q + (j & 3);
+            } else {                                          // padding fragment: harmless load, junk slot
+                fp[i] = mat + q * E;
+                pofs[i] = 0;
+                dst[i] = f * 64 + lane;
+            }
+        }
+        V buf[2][NFL];
+        auto issue = [&](size_t s, int set) {
+            const size_t k0 = (sbeg + s) * KS;
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) {
+                if (TAIL) {
+                    const bool in = k0 + pofs[i] + q * E < C;
+                    buf[set][i] = in ? *reinterpret_cast<const V*>(fp[i] + k0 + pofs[i]) : vzero;
+                } else {
+                    buf[set][i] = *reinterpret_cast<const V*>(fp[i] + k0 + pofs[i]);
+                }
+            }
+        };
+        auto store = [&](size_t s, int set) {
+            V* slot = ring + (s & 1) * SLOT;
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) slot[dst[i]] = buf[set][i];
+        };
+        // slots 0, 1, 2 in flight before the first barrier; slot 0 is stored right away
+        if (nst > 0) issue(0, 0);
+        if (nst > 1) issue(1, 1);
+        if (nst > 0) store(0, 0);
+        if (nst > 2) issue(2, 0);
+        __syncthreads();                                     // slot 0 visible
+        // consumers work on slot s; slot s+1 is handed over at the barrier that ends step s.
+        // Unrolled by two so that the register set of every load / store is a compile-time
+        // constant (a run-time set index makes the compiler wait for each load right away).
+        if (dbg == 1) {                                      // barriers only: consumer-side ceiling
+            for (size_t s = 0; s < nst; ++s) __syncthreads();
+            return;
+        }
+        for (size_t s = 0; s < nst; s += 2) {
+            if (s + 1 < nst) store(s + 1, 1);
+            if (s + 3 < nst) issue(s + 3, 1);
+            __syncthreads();
+            if (s + 1 < nst) {
+                if (s + 2 < nst) store(s + 2, 0);
+                if (s + 4 < nst) issue(s + 4, 0);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------- consumer
+    const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
+    const int rd = 4 * q + (lane & 3);
+    double acc[RT][NT4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT4; ++t) acc[rt][t] = 0.0;
+    __syncthreads();
+    for (size_t s = 0; s < nst; ++s) {
+        const V* slot = ring + (s & 1) * SLOT;
+        const V* xs = slot + kRingMatFrag * 64;
+        V m[RT][kPieces];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < kPieces; ++p) m[rt][p] = slot[((wave * RT + rt) * kPieces + p) * 64 + lane];
+        constexpr int NST = kPieces * (NT4 / 2);
+        V xa = xs[rd], xc = xs[16 + rd];
+#pragma unroll
+        for (int sg = 0; sg < NST; ++sg) {
+            const int p = sg / (NT4 / 2), t = 2 * (sg % (NT4 / 2));
+            V na = xa, nc = xc;
+            if (sg + 1 < NST) {
+                const int p1 = (sg + 1) / (NT4 / 2), t1 = 2 * ((sg + 1) % (NT4 / 2));
+                na = xs[p1 * (BT * 64) + t1 * 16 + rd];
+                nc = xs[p1 * (BT * 64) + (t1 + 1) * 16 + rd];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][t] = mfma4(m[rt][p][e], xa[e], acc[rt][t]);
+                    acc[rt][t + 1] = mfma4(m[rt][p][e], xc[e], acc[rt][t + 1]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            xa = na;
+            xc = nc;
+        }
+        __syncthreads();
+    }
+    double* pout = partials + (split * B) * R;
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dn = lane & 3;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const size_t r = row0 + rt * 16 + drow;
+        if (r < R) {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) {
+                const size_t b = 4 * t + dn;
+                if (b < nb) pout[(bchunk + b) * R + r] = acc[rt][t];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ fold + epilogue
 template <typename T>
 __device__ __forceinline__ void mfma_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
@@ -598,12 +770,31 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     // 16: v_mfma_f64_16x16x4 kernels (default, 54-55 TFLOP/s at batch 64); 4: the 4x4x4-block kernels
     // (50-52 TFLOP/s today although the instruction itself issues 1.6x faster - see the note above them)
     static const int shape_env = getenv("TRAMP_MFMA_F64_SHAPE") ? atoi(getenv("TRAMP_MFMA_F64_SHAPE")) : 16;
+    static const int ring_env = getenv("TRAMP_MFMA_RING") ? atoi(getenv("TRAMP_MFMA_RING")) : 0;
+    static const int ring_dbg = getenv("TRAMP_MFMA_RING_DBG") ? atoi(getenv("TRAMP_MFMA_RING_DBG")) : 0;
     if constexpr (sizeof(T) == 8) {
         if (shape_env == 4) {
             constexpr int RT = 4;
 #define LAUNCH_NT4(BTv, TAILv) hipLaunchKernelGGL((gemm_nt4_kernel<BTv, RT, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
 #define LAUNCH_NN4(BTv, TAILv) hipLaunchKernelGGL((gemm_nn4_kernel<BTv, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
-            if (nt) {
+            if (nt && ring_env) {
+                const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
+                dim3 grid((unsigned)(nrb * nsplit), nchunk);
+#define LAUNCH_NTR(BTv, TAILv)                                                                                         \
+    do {                                                                                                               \
+        const size_t lds = 2 * (size_t)ring_slot_v2d<BTv>() * sizeof(v2d);                                            \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_ring_kernel<BTv, TAILv>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_nt4_ring_kernel<BTv, TAILv>), grid, dim3(512), lds, ctx->stream, R, C, batch, mat, x, \
+                           sps, nsplit | ((unsigned)ring_dbg << 16), ctx->ws);                                                                    \
+    } while (0)
+                if (tail) { BY_BT(LAUNCH_NTR, true) } else { BY_BT(LAUNCH_NTR, false) }
+#undef LAUNCH_NTR
+            } else if (nt) {
                 const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
                 dim3 grid((unsigned)(nrb * nsplit), nchunk);
                 if (tail) { BY_BT(LAUNCH_NT4, true) } else { BY_BT(LAUNCH_NT4, false) }
