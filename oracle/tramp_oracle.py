@@ -1040,6 +1040,9 @@ class GBPriorFactor(OracleFactor):
     def __init__(self, size, rho=0.5, mean=0, var=1):
         self.size, self.rho, self.mean, self.var = size, rho, mean, var
 
+    def log_partition(self, az, bz, ax, bx):
+        return gb_prior_log_partition(ax, bx, self.rho, self.mean, self.var)
+
     def forward(self, az, bz, ax, bx):
         return gb_prior_message(ax, bx, self.rho, self.mean, self.var)
 
@@ -1060,6 +1063,9 @@ class GaussPriorFactor(OracleFactor):
     def forward(self, az, bz, ax, bx):
         return gauss_prior_message(ax, bx, self.mean, self.var)
 
+    def log_partition(self, az, bz, ax, bx):
+        return gauss_prior_log_partition(ax, bx, self.mean, self.var)
+
     def forward_se(self, az, ax, tau_z, method="quadpack"):
         return 1 / self.var
 
@@ -1076,6 +1082,9 @@ class LinearFactor(OracleFactor):
 
     def backward(self, az, bz, ax, bx):
         return self.lin.backward_message(az, bz, ax, bx)
+
+    def log_partition(self, az, bz, ax, bx):
+        return linear_log_partition(self.lin, az, bz, ax, bx)
 
     def forward_se(self, az, ax, tau_z, method="quadpack"):
         return a_new(self.lin.forward_variance(az, ax), ax)
@@ -1136,6 +1145,9 @@ class PWLFactor(OracleFactor):
         self.kind_pwl = kind
         self.param = param
 
+    def log_partition(self, az, bz, ax, bx):
+        return pwl_channel_log_partition(self.kind_pwl, az, bz, ax, bx, self.param)
+
     def forward(self, az, bz, ax, bx):
         return pwl_channel_message(self.kind_pwl, "fwd", az, bz, ax, bx, self.param)
 
@@ -1160,6 +1172,9 @@ class GaussLikFactor(OracleFactor):
     def __init__(self, y, var=1):
         self.y, self.var = y, var
 
+    def log_partition(self, az, bz, ax, bx):
+        return gauss_lik_log_partition(az, bz, self.y, self.var)
+
     def backward(self, az, bz, ax, bx):
         return gauss_lik_message(az, bz, self.y, self.var)
 
@@ -1172,6 +1187,9 @@ class SgnLikFactor(OracleFactor):
 
     def __init__(self, y):
         self.y = y
+
+    def log_partition(self, az, bz, ax, bx):
+        return sgn_lik_log_partition(az, bz, self.y)
 
     def backward(self, az, bz, ax, bx):
         return sgn_lik_message(az, bz, self.y)
@@ -1199,11 +1217,97 @@ class AbsLikFactor(OracleFactor):
     def __init__(self, y):
         self.y = y
 
+    def log_partition(self, az, bz, ax, bx):
+        return abs_lik_log_partition(az, bz, self.y)
+
     def backward(self, az, bz, ax, bx):
         return abs_lik_message(az, bz, self.y)
 
     def backward_se(self, az, ax, tau_z, method="quadpack"):
         return a_new(se_abs_lik_error(az, tau_z, method), az)
+
+
+# --------------------------------------------------------------------------
+# log-partitions and the EP log-evidence
+#   Factor.log_partition (tramp/base.py:367-375), Variable.compute_log_partition (:146-150),
+#   MessagePassing.update_objective (tramp/algos/message_passing.py:306-328),
+#   ExpectationPropagation.log_evidence (tramp/algos/expectation_propagation.py:21-27).
+# NB the reference mixes conventions (restated as found): priors and likelihoods return the
+# MEAN over components, channels and variables the SUM.
+# --------------------------------------------------------------------------
+def gb_prior_log_partition(ax, bx, rho=0.5, mean=0, var=1):
+    "gauss_bernoulli_prior.py:79-83 with sparse.A (beliefs/sparse.py:5-6)"
+    a0, b0, eta = gb_params(rho, mean, var)
+    A = np.logaddexp(eta, normal_A(ax + a0, bx + b0)) - np.logaddexp(eta, normal_A(a0, b0))
+    return A.mean()
+
+
+def gauss_prior_log_partition(ax, bx, mean=0, var=1):
+    "gaussian_prior.py:70-74"
+    a0, b0 = 1 / var, mean / var
+    return (normal_A(ax + a0, bx + b0) - normal_A(a0, b0)).mean()
+
+
+def l1_prior_log_partition(ax, bx, gamma=1):
+    "map_L1_norm_prior.py:73-76"
+    rx, _ = l1_prior_posterior(ax, bx, gamma, isotropic=False)
+    return (bx * rx - 0.5 * ax * rx**2 - gamma * np.abs(rx)).mean()
+
+
+def gauss_lik_log_partition(az, bz, y, var=1):
+    "gaussian_likelihood.py:51-56"
+    ay = 1 / var
+    by = ay * y
+    return (normal_A(az + ay, bz + by) - normal_A(ay, by)).mean()
+
+
+def sgn_lik_log_partition(az, bz, y):
+    "sgn_likelihood.py:39-41 with positive.A (beliefs/positive.py:8-9)"
+    b = bz * y
+    return halfline_logZ(b / az, 1 / az, +1).mean()
+
+
+def abs_lik_log_partition(az, bz, y):
+    "abs_likelihood.py:38-40 with binary.A (beliefs/binary.py:4-5)"
+    return (-0.5 * az * y**2 + np.logaddexp(bz * y, -bz * y)).mean()
+
+
+def pwl_channel_log_partition(kind, az, bz, ax, bx, param=None):
+    "piecewise_linear_channel.py:55-58: logsumexp of the regions' log-partitions, SUMMED"
+    As = [pwl_region_terms(side, slope, x0, az, np.asarray(bz, float), ax, np.asarray(bx, float), zb)[2]
+          for side, slope, x0, zb in pwl_regions(kind, param)]
+    return np.logaddexp(As[0], As[1]).sum()
+
+
+def variable_log_partition(a, b):
+    "tramp/base.py:146-150"
+    if a <= 0:
+        return np.inf
+    return 0.5 * np.sum(b**2 / a + np.log(2 * np.pi / a))
+
+
+def linear_log_partition(lin, az, bz, ax, bx):
+    "linear_channel.py:127-132 (lin: LinearOracle)"
+    rz = lin.backward_mean(az, bz, ax, bx)
+    b = bz + lin.W.T @ bx
+    a = az + ax * lin.spectrum
+    return 0.5 * np.sum(b * rz) + 0.5 * np.sum(np.log(2 * np.pi / a))
+
+
+def chain_log_evidence(factors, fwd, bwd):
+    """A_model of a chain f0 - x0 - f1 - ... (message_passing.py:306-328): sum of the node
+    log-partitions minus the fwd-edge ones.  A SISO variable forwards its messages, so both of
+    its edges carry the same (a, b) pair as the variable itself: nodes minus edges leaves
+    sum_factors A_f - sum_variables A_x."""
+    L = len(fwd)
+    A = 0.
+    for i, f in enumerate(factors):
+        az, bz = fwd[i - 1] if i > 0 else (None, None)
+        ax, bx = bwd[i] if i < L else (None, None)
+        A += f.log_partition(az, bz, ax, bx)
+    for i in range(L):
+        A -= variable_log_partition(fwd[i][0] + bwd[i][0], fwd[i][1] + bwd[i][1])
+    return A
 
 
 def _rms(x):

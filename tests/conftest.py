@@ -59,6 +59,13 @@ def golden_unitary():
 
 
 @pytest.fixture(scope="session")
+def golden_logz():
+    path = os.path.join(GOLDEN, "logz.npz")
+    with np.load(path, allow_pickle=True) as f:
+        return dict(cases=list(f["data"]), lin=list(f["lin"]), ep=list(f["ep"]))
+
+
+@pytest.fixture(scope="session")
 def golden_se():
     return load_golden("se")
 

@@ -474,3 +474,45 @@ def test_unitary_channels_oracle_matches_reference(golden_unitary):
             for i, vid in enumerate(["x", "z"]):
                 close(iters[it][0][i], t[f"r:{vid}"][it], rtol=1e-8, atol=1e-10)
                 close(iters[it][1][i], t[f"v:{vid}"][it], rtol=1e-9)
+
+
+# -- log-partitions and log-evidence
+def test_log_partitions_oracle_matches_reference(golden_logz):
+    for c in golden_logz["cases"]:
+        az, ax, bz, bx = c["az"], c["ax"], c["bz"], c["bx"]
+        close(orc.gb_prior_log_partition(ax, bx, 0.1, 0.3, 1.7), c["gb"])
+        close(orc.gauss_prior_log_partition(ax, bx, 0.3, 1.7), c["gauss_prior"])
+        close(orc.l1_prior_log_partition(ax, bx, 0.8), c["l1"])
+        close(orc.gauss_lik_log_partition(az, bz, c["y_g"], 0.4), c["gauss_lik"])
+        close(orc.sgn_lik_log_partition(az, bz, c["y_sgn"]), c["sgn_lik"])
+        close(orc.abs_lik_log_partition(az, bz, c["y_abs"]), c["abs_lik"])
+        for kind in ("sgn", "abs", "relu"):
+            close(orc.pwl_channel_log_partition(kind, az, bz, ax, bx), c["pwl_" + kind])
+        close(orc.variable_log_partition(az + ax, bz + bx), c["variable"])
+    for c in golden_logz["lin"]:
+        lin = orc.LinearOracle(c["W"])
+        for k in c["cases"]:
+            close(orc.linear_log_partition(lin, k["az"], c["bz"], k["ax"], c["bx"]), k["logZ"], rtol=1e-10)
+
+
+def _logz_chain(c):
+    if c["kind"] == "glm":
+        N, M = c["N"], int(c["alpha"] * c["N"])
+        W = np.random.RandomState(c["seed"]).randn(M, N) / np.sqrt(N)
+        assert W.sum() == c["W_sum"]
+        lik = {"gaussian": lambda: orc.GaussLikFactor(c["y"], c["noise_var"]), "sgn": lambda: orc.SgnLikFactor(c["y"]),
+               "abs": lambda: orc.AbsLikFactor(c["y"])}[c["output"]]()
+        return [orc.GBPriorFactor(N, rho=c["rho"]), orc.LinearFactor(W), lik], [N, M]
+    fs = [orc.GaussPriorFactor(c["N"]), orc.LinearFactor(c["W1"]), orc.PWLFactor("relu"), orc.LinearFactor(c["W2"]),
+          orc.GaussLikFactor(c["y"], c["noise_var"])]
+    return fs, [c["N"], c["M1"], c["M1"], c["M2"]]
+
+
+def test_ep_log_evidence_oracle_matches_reference(golden_logz):
+    for c in golden_logz["ep"]:
+        fs, shapes = _logz_chain(c)
+        As = []
+        with np.errstate(all="ignore"):
+            orc.ep_chain(fs, shapes, max_iter=len(c["A"]), damping=c["damping"], tol=0.0, max_increase=np.inf,
+                         record=lambda it, fwd, bwd, rs, vs: As.append(orc.chain_log_evidence(fs, fwd, bwd)))
+        close(As, c["A"], rtol=1e-7, atol=1e-8 * np.abs(c["A"]).max())

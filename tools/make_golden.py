@@ -553,6 +553,78 @@ def unitary_goldens():
     save("unitary", data=np.array(msgs, dtype=object), ep=np.array(trajs, dtype=object))
 
 
+# ---------------------------------------------------------------- log-partitions, log-evidence
+def logz_goldens():
+    "compute_log_partition of the hot-path factors and the EP log-evidence along a run."
+    rs = np.random.RandomState(41)
+    n = 80
+    bx = rs.standard_normal(n) * 2
+    bz = rs.standard_normal(n) * 1.5
+    y_sgn = np.sign(rs.standard_normal(n))
+    y_abs = np.abs(rs.standard_normal(n))
+    y_g = rs.standard_normal(n)
+    out = []
+    for (az, ax) in [(1.3, 0.7), (0.05, 4.0), (40., 0.2)]:
+        c = dict(az=az, ax=ax, bz=bz, bx=bx, y_sgn=y_sgn, y_abs=y_abs, y_g=y_g)
+        c["gb"] = GaussBernoulliPrior(size=n, rho=0.1, mean=0.3, var=1.7).compute_log_partition(ax, bx)
+        c["gauss_prior"] = GaussianPrior(size=n, mean=0.3, var=1.7).compute_log_partition(ax, bx)
+        c["l1"] = MAP_L1NormPrior(size=n, gamma=0.8).compute_log_partition(ax, bx)
+        c["gauss_lik"] = GaussianLikelihood(y=y_g, var=0.4).compute_log_partition(az, bz, y_g)
+        c["sgn_lik"] = SgnLikelihood(y=y_sgn).compute_log_partition(az, bz, y_sgn)
+        c["abs_lik"] = AbsLikelihood(y=y_abs).compute_log_partition(az, bz, y_abs)
+        for name, ch in (("sgn", SgnChannel()), ("abs", AbsChannel()), ("relu", ReluChannel())):
+            c["pwl_" + name] = ch.compute_log_partition(az, bz, ax, bx)
+        c["variable"] = V(id="v").compute_log_partition(az + ax, bz + bx)
+        out.append(c)
+    lin = []
+    for (M, N, seed) in [(12, 24, 1), (40, 40, 3), (48, 32, 4)]:
+        r = np.random.RandomState(seed)
+        W = r.randn(M, N) / np.sqrt(N)
+        ch = LinearChannel(W)
+        b_z, b_x = r.standard_normal(N) * 2, r.standard_normal(M) * 3
+        lin.append(dict(M=M, N=N, seed=seed, W=W, bz=b_z, bx=b_x,
+                        cases=[dict(az=az, ax=ax, logZ=ch.compute_log_partition(az, b_z, ax, b_x))
+                               for (az, ax) in [(1.3, 0.7), (0.2, 5.0), (30., 0.1)]]))
+    # log-evidence along EP runs
+    runs = []
+    for output, alpha in [("gaussian", 0.5), ("sgn", 0.7), ("abs", 1.5)]:
+        N, seed, damping = 64, 1, 0.1
+        rho, nv = 0.25, (1e-2 if output == "gaussian" else None)
+        W, x, y = teacher_glm(seed, N, alpha, rho, output, nv)
+        lik = (GaussianLikelihood(y=y, var=nv) if output == "gaussian"
+               else SgnLikelihood(y=y) if output == "sgn" else AbsLikelihood(y=y))
+        model = (GaussBernoulliPrior(size=N, rho=rho) @ V(id="x") @ LinearChannel(W) @ V(id="z") @ lik).to_model()
+        ep = ExpectationPropagation(model)
+        As = []
+
+        def cb(algo, i, max_iter, As=As):
+            As.append(float(algo.log_evidence()))
+        with np.errstate(all="ignore"):
+            ep.iterate(max_iter=10, callback=cb, damping=damping)
+        runs.append(dict(kind="glm", output=output, N=N, alpha=alpha, seed=seed, rho=rho, noise_var=nv,
+                         damping=damping, y=y, W_sum=W.sum(), A=np.array(As)))
+        print("logz glm", output, As[:3], As[-1])
+    rs2 = np.random.RandomState(2)
+    N, M1, M2 = 48, 64, 24
+    W1 = rs2.randn(M1, N) / np.sqrt(N)
+    W2 = rs2.randn(M2, M1) / np.sqrt(M1)
+    x = rs2.standard_normal(N)
+    y = W2 @ np.maximum(0, W1 @ x) + 0.1 * rs2.standard_normal(M2)
+    model = (GaussianPrior(size=N) @ V(id="x") @ LinearChannel(W1) @ V(id="z1") @ ReluChannel() @ V(id="a1")
+             @ LinearChannel(W2) @ V(id="z2") @ GaussianLikelihood(y=y, var=1e-2)).to_model()
+    ep = ExpectationPropagation(model)
+    As = []
+
+    def cb2(algo, i, max_iter):
+        As.append(float(algo.log_evidence()))
+    with np.errstate(all="ignore"):
+        ep.iterate(max_iter=8, callback=cb2, damping=0.1)
+    runs.append(dict(kind="two_layer", N=N, M1=M1, M2=M2, seed=2, noise_var=1e-2, damping=0.1, y=y,
+                     W1=W1, W2=W2, A=np.array(As)))
+    print("logz two_layer", As[:3], As[-1])
+    save("logz", data=np.array(out, dtype=object), lin=np.array(lin, dtype=object), ep=np.array(runs, dtype=object))
+
+
 # ---------------------------------------------------------------- convolution channel
 def conv_goldens():
     "ConvChannel family (real=True): posteriors, messages, scalars, samples, EP trajectories."
@@ -756,5 +828,7 @@ if __name__ == "__main__":
         pwl3_lik_goldens()
     if not only or "unitary" in only:
         unitary_goldens()
+    if not only or "logz" in only:
+        logz_goldens()
     if not only or "se" in only:
         se_goldens(args.skip_slow)
