@@ -412,6 +412,40 @@ int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, double z_hi,
                       const double* slopes3, const double* x03,
                       const double* az, const double* tau_z, double* v);
 
+/* ---- log-partitions -------------------------------- */
+/* Terms of the EP log-evidence (tramp/algos/message_passing.py:306-328): out_d[b] = SUM over the
+ * n components of the factor's / variable's log-partition, formed in double.  The caller divides
+ * by n where the reference takes the mean (priors, likelihoods: e.g. gauss_bernoulli_prior.py:79-83,
+ * sgn_likelihood.py:39-41) and keeps the sum for channels and variables
+ * (piecewise_linear_channel.py:55-58, tramp/base.py:146-150).
+ *   kind            a0_d, v0_d     a1_d, v1_d     p0, p1, p2
+ *   GB_PRIOR        ax, bx         -              rho, mean, var
+ *   GAUSS_PRIOR     ax, bx         -              mean, var
+ *   L1_PRIOR        ax, bx         -              gamma
+ *   GAUSS_LIK       az, bz         -, y           var
+ *   SGN_LIK/ABS_LIK az, bz         -, y
+ *   PWL_SGN/ABS/RELU az, bz        ax, bx
+ *   VARIABLE        a_fwd, b_fwd   a_bwd, b_bwd                                         */
+#define TRAMP_LOGZ_GB_PRIOR 0
+#define TRAMP_LOGZ_GAUSS_PRIOR 1
+#define TRAMP_LOGZ_L1_PRIOR 2
+#define TRAMP_LOGZ_GAUSS_LIK 3
+#define TRAMP_LOGZ_SGN_LIK 4
+#define TRAMP_LOGZ_ABS_LIK 5
+#define TRAMP_LOGZ_PWL_SGN 6
+#define TRAMP_LOGZ_PWL_ABS 7
+#define TRAMP_LOGZ_PWL_RELU 8
+#define TRAMP_LOGZ_VARIABLE 9
+int tramp_log_partition(tramp_ctx* ctx, int dtype, int kind, size_t n, size_t batch,
+                        double p0, double p1, double p2,
+                        const double* a0_d, const void* v0_d, const double* a1_d, const void* v1_d,
+                        double* out_d);
+/* LinearChannel.compute_log_partition (tramp/channels/linear/linear_channel.py:127-132) from the
+ * thin factors; `reuse` as in tramp_linear_message (the projections are shared with it). */
+int tramp_linear_log_partition(tramp_ctx* ctx, tramp_linear* lin, size_t batch,
+                               const double* az_d, const void* bz_d, const double* ax_d, const void* bx_d,
+                               int reuse, double* out_d);
+
 /* ---- synthetic data (bench / tests; counter-based, reproducible per seed) --- */
 /* out[i] = scale * N(0,1), Philox-4x32 + Box-Muller, element i from counter i. */
 int tramp_randn(tramp_ctx* ctx, int dtype, void* out_d, size_t count,

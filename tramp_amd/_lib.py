@@ -15,6 +15,8 @@ SGN, ABS, RELU = 0, 1, 2
 FWD, BWD = 0, 1
 GEMV_MAX_BATCH = 8
 REUSE_T, REUSE_U = 1, 2
+(LOGZ_GB_PRIOR, LOGZ_GAUSS_PRIOR, LOGZ_L1_PRIOR, LOGZ_GAUSS_LIK, LOGZ_SGN_LIK, LOGZ_ABS_LIK, LOGZ_PWL_SGN,
+ LOGZ_PWL_ABS, LOGZ_PWL_RELU, LOGZ_VARIABLE) = range(10)
 
 _STATUS = {EINVAL: "invalid argument", EHIP: "HIP runtime error", ENOMEM: "out of device memory",
            ENOTSUP: "not supported", ENODEV: "no MI355X / HIP device"}
@@ -85,6 +87,8 @@ _SIGNATURES = {
     "tramp_dft_create": [vp, i32, i32, C.POINTER(sz), C.POINTER(vp)],
     "tramp_dft_destroy": [vp, vp],
     "tramp_dft_message": [vp, vp, i32, sz, vp, vp, dbl, vp, vp, vp, vp],
+    "tramp_log_partition": [vp, i32, i32, sz, sz, dbl, dbl, dbl, vp, vp, vp, vp, vp],
+    "tramp_linear_log_partition": [vp, vp, sz, vp, vp, vp, vp, i32, vp],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],

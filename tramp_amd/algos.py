@@ -400,6 +400,34 @@ class ExpectationPropagation:
         m = out.get() / n
         return float(m[0]) if self.batch == 1 else m
 
+    def log_evidence(self):
+        """EP log-evidence A_model (tramp/algos/expectation_propagation.py:21-27,
+        tramp/algos/message_passing.py:306-328): node log-partitions minus the fwd-edge ones.  On a
+        chain of SISO variables both edges of a variable carry the variable's own (a, b) pair, so
+        this is sum_factors A_f - sum_variables A_x.  One value per instance."""
+        L = len(self.variables)
+        A = np.zeros(self.batch)
+        for i, v in enumerate(self.variables):
+            f = self.model.prev_factor(v)
+            if f.n_prev == 0:
+                A = A + np.atleast_1d(f.compute_log_partition(self.a_bwd[i], self.b_bwd[i]))
+            else:
+                A = A + np.atleast_1d(f.compute_log_partition(self.a_fwd[i - 1], self.b_fwd[i - 1],
+                                                              self.a_bwd[i], self.b_bwd[i]))
+        last = self.model.next_factor(self.variables[-1])
+        if last is not None:
+            A = A + np.atleast_1d(last.compute_log_partition(self.a_fwd[L - 1], self.b_fwd[L - 1]))
+        out = self.ctx.empty((self.batch,), np.float64)
+        for i in range(L):
+            n = self.b_fwd[i].shape[1]
+            self.ctx._call("tramp_log_partition", dtype_code(self.dtype), 9, n, self.batch, 0.0, 0.0, 0.0,
+                           self.a_fwd[i].ptr, self.b_fwd[i].ptr, self.a_bwd[i].ptr, self.b_bwd[i].ptr, out.ptr)
+            A = A - out.get()
+        return float(A[0]) if self.batch == 1 else A
+
+    def surprisal(self):
+        return -self.log_evidence()                        # expectation_propagation.py:29-32
+
     # -- main loop
     def _capture_iteration(self):
         "Record one steady-state iteration (all launches of the three sweeps) into a hipGraph."

@@ -129,6 +129,27 @@ class Factor(ReprMixin):
         "tramp/base.py:245-248"
         return np.clip(inv(v) - a, self.AMIN, self.AMAX)
 
+    def _logz(self, kind, a0, v0, a1=None, v1=None, params=(0.0, 0.0, 0.0), mean=True):
+        """Log-partition through tramp_log_partition: the kernel returns the sum
+        over the components; ``mean`` divides by n as the reference's priors / likelihoods do."""
+        ctx = self.ctx
+        v = VecArg(ctx, v0, self.dtype)
+        a = ScalArg(ctx, a0, v.batch)
+        w = VecArg(ctx, v1, self.dtype) if v1 is not None else None
+        aa = ScalArg(ctx, a1, v.batch) if a1 is not None else None
+        if w is not None and (w.batch, w.n) != (v.batch, v.n):
+            raise ValueError(f"shapes {v.dev.shape} and {w.dev.shape} differ")
+        out = ctx.empty((v.batch,), np.float64)
+        p = [float(x) for x in params] + [0.0] * (3 - len(params))
+        ctx._call("tramp_log_partition", self._dt, kind, v.n, v.batch, p[0], p[1], p[2], a.dev.ptr, v.dev.ptr,
+                  aa.dev.ptr if aa is not None else None, w.dev.ptr if w is not None else None, out.ptr)
+        res = out.get()
+        if mean:
+            res = res / v.n
+        if a.was_host and a.scalar_like and v.was_host and len(v.host_shape) == 1:
+            return float(res[0])
+        return res
+
     def __matmul__(self, other):
         from .models import DAG
         return DAG(self) @ other

@@ -108,6 +108,14 @@ class PiecewiseLinearChannel(Channel):
         tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
         return tgt, a_t, a_new, b_new, r, v, mask
 
+    def compute_log_partition(self, az, bz, ax, bx):
+        "logsumexp of the regions' log-partitions, summed (piecewise_linear_channel.py:55-58)"
+        kinds = {_lib.SGN: _lib.LOGZ_PWL_SGN, _lib.ABS: _lib.LOGZ_PWL_ABS, _lib.RELU: _lib.LOGZ_PWL_RELU}
+        kind = kinds.get(getattr(self, "_kind", None)) if type(self) in (SgnChannel, AbsChannel, ReluChannel) else None
+        if kind is None:
+            raise NotImplementedError(f"{type(self).__name__}.compute_log_partition is not on the HIP path")
+        return self._logz(kind, az, bz, a1=ax, v1=bx, mean=False)
+
     def compute_forward_posterior(self, az, bz, ax, bx):
         t, a, _, _, r, v, _ = self._run(_lib.FWD, az, bz, ax, bx, want_posterior=True)
         return ret_vec(r, t), ret_scal(v, a, t)
@@ -520,6 +528,26 @@ class LinearChannel(Channel):
         if not isinstance(arg, DeviceArray) or version is None:
             return None
         return (arg.ptr, version, norm.batch)
+
+    def compute_log_partition(self, az, bz, ax, bx):
+        "linear_channel.py:127-132, from the thin factors (the projections are shared with the messages)"
+        ctx = self.ctx
+        z = VecArg(ctx, bz, self.dtype)
+        x = VecArg(ctx, bx, self.dtype)
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        reuse = 0
+        kz, kx = self._proj_key(bz, z), self._proj_key(bx, x)
+        if kz is not None and kz == self._t_key:
+            reuse |= _lib.REUSE_T
+        if kx is not None and kx == self._u_key:
+            reuse |= _lib.REUSE_U
+        self._t_key, self._u_key = kz, kx
+        out = ctx.empty((z.batch,), np.float64)
+        ctx._call("tramp_linear_log_partition", self._handle, z.batch, a_z.dev.ptr, z.dev.ptr, a_x.dev.ptr,
+                  x.dev.ptr, reuse, out.ptr)
+        res = out.get()
+        return float(res[0]) if (a_z.was_host and a_z.scalar_like and z.was_host and len(z.host_shape) == 1) else res
 
     _affine_entry = "tramp_linear_project_affine"
 

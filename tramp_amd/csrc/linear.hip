@@ -449,6 +449,29 @@ extern "C" int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, in
     return TRAMP_OK;
 }
 
+// Brings the handle's projections t = Vt bz and u = Uk^T bx up to date (shared by the message
+// update and the log-partition); `reuse` as in tramp_linear_message.
+int lin_project(tramp_ctx* ctx, tramp_linear* lin, size_t batch, const void* bz_d, const void* bx_d, int reuse) {
+    const void* work_before = lin->work;
+    int rc = lin_reserve(ctx, lin, batch);
+    if (rc) return rc;
+    if (lin->work != work_before || lin->proj_batch != batch) reuse = 0;
+    lin->proj_batch = batch;
+    LinEpi plain{};
+    plain.mode = 0;
+    plain.out = lin->t;
+    if (!(reuse & TRAMP_REUSE_T)) {
+        rc = matvec_dispatch(ctx, lin->dtype, 0, true, lin->k, lin->N, batch, lin->Vt, bz_d, plain);
+        if (rc) return rc;
+    }
+    plain.out = lin->u;
+    if (!(reuse & TRAMP_REUSE_U)) {
+        rc = matvec_dispatch(ctx, lin->dtype, 0, false, lin->M, lin->k, batch, lin->Uk, bx_d, plain);
+        if (rc) return rc;
+    }
+    return TRAMP_OK;
+}
+
 // p <- d p + (1 - d) pc over [count] elements
 template <typename T>
 __global__ __launch_bounds__(kBlock) void axpby_kernel(size_t count, T d, T omd, T* __restrict__ p,

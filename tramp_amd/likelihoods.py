@@ -5,6 +5,7 @@ tramp/likelihoods/{base_likelihood,gaussian_likelihood,sgn_likelihood,abs_likeli
 """
 import numpy as np
 
+from . import _lib
 from .base import Factor, VecArg, ScalArg, out_vec, ret_vec, ret_scal
 from .device import DeviceArray
 
@@ -82,6 +83,17 @@ class Likelihood(Factor):
         a, b, _, _, r, v = self._message(az, bz, y=y, want_posterior=True)
         return ret_vec(r, b), ret_scal(v, a, b)
 
+    _logz_kind = None
+    _logz_params = ()
+
+    def compute_log_partition(self, az, bz, y=None):
+        "mean over the components of the likelihood's log-partition (e.g. sgn_likelihood.py:39-41)"
+        if self._logz_kind is None:
+            raise NotImplementedError(f"{type(self).__name__}.compute_log_partition is not on the HIP path")
+        b = VecArg(self.ctx, bz, self.dtype)
+        yd = self._y_for(b, y)
+        return self._logz(self._logz_kind, az, bz, v1=yd, params=self._logz_params)
+
     def compute_backward_state_evolution(self, az, tau_z):
         "base_likelihood.py:73-76"
         vz = self.compute_backward_error(az, tau_z)
@@ -92,12 +104,14 @@ class Likelihood(Factor):
 
 
 class GaussianLikelihood(Likelihood):
+    _logz_kind = _lib.LOGZ_GAUSS_LIK
     "tramp/likelihoods/gaussian_likelihood.py:7-132 (K6: constant message)"
 
     def __init__(self, y, var=1, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
         self.y_name = y_name
         self.size = self.get_size(y)
         self.var = var
+        self._logz_params = (float(var),)
         self.isotropic = isotropic
         self.repr_init()
         self._init_device(dtype, ctx)
@@ -137,6 +151,7 @@ class GaussianLikelihood(Likelihood):
 
 
 class SgnLikelihood(Likelihood):
+    _logz_kind = _lib.LOGZ_SGN_LIK
     "tramp/likelihoods/sgn_likelihood.py:9-98 (K4)"
     _kernel_name = "tramp_sgn_lik_bwd"
     _which_diag = 2
@@ -164,6 +179,7 @@ class SgnLikelihood(Likelihood):
 
 
 class AbsLikelihood(Likelihood):
+    _logz_kind = _lib.LOGZ_ABS_LIK
     "tramp/likelihoods/abs_likelihood.py:8-72 (K5)"
     _kernel_name = "tramp_abs_lik_bwd"
     _which_diag = 3

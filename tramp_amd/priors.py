@@ -8,6 +8,7 @@ device-resident scheduler and have no counterpart in the reference.
 """
 import numpy as np
 
+from . import _lib
 from .base import Factor, VecArg, ScalArg, out_vec, ret_vec, ret_scal
 from .device import DeviceArray
 
@@ -78,6 +79,10 @@ class GaussBernoulliPrior(Prior):
     def second_moment(self):
         return self.rho * (self.mean**2 + self.var)
 
+    def compute_log_partition(self, ax, bx):
+        "gauss_bernoulli_prior.py:79-83"
+        return self._logz(_lib.LOGZ_GB_PRIOR, ax, bx, params=(self.rho, self.mean, self.var))
+
     def _kernel(self, b, a, damping, old_a, old_b, a_new, b_new, r, v):
         self.ctx._call("tramp_gb_prior_fwd", self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr,
                        float(self.rho), float(self.mean), float(self.var), damping, old_a, old_b,
@@ -135,6 +140,10 @@ class MAP_L1NormPrior(Prior):
 
     def second_moment(self):
         raise NotImplementedError
+
+    def compute_log_partition(self, ax, bx):
+        "map_L1_norm_prior.py:73-76"
+        return self._logz(_lib.LOGZ_L1_PRIOR, ax, bx, params=(self.gamma,))
 
     def _kernel(self, b, a, damping, old_a, old_b, a_new, b_new, r, v, count=None, mask=None):
         self.ctx._call("tramp_l1_prior_fwd", self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr,
@@ -200,6 +209,10 @@ class GaussianPrior(Prior):
 
     def second_moment(self):
         return self.mean**2 + self.var
+
+    def compute_log_partition(self, ax, bx):
+        "gaussian_prior.py:70-74"
+        return self._logz(_lib.LOGZ_GAUSS_PRIOR, ax, bx, params=(self.mean, self.var))
 
     def compute_forward_posterior(self, ax, bx):
         "gaussian_prior.py:63-68 (host arithmetic on the caller's arrays; not on the EP path)"
