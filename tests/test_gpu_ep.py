@@ -305,3 +305,32 @@ def test_damped_constant_message_needs_no_matrix_pass(ctx):
         Yd = ctx.array(Y)
         ctx._call("tramp_linear_project_affine", fresh._handle, T._lib.REUSE_U, B, Yd.ptr, 0.5, 1)
     assert lin_ch._u_key is not None
+
+
+def test_tracking_callbacks(ctx):
+    """TrackEstimate / TrackMessages / TrackObjective / TrackOverlaps / LogProgress record what the
+    reference's callbacks of the same names record (tramp/algos/callbacks.py:33-191)."""
+    import tramp_amd as T
+    N, M, rho, nv = 96, 64, 0.2, 1e-2
+    rs = np.random.RandomState(2)
+    W = rs.randn(M, N) / np.sqrt(N)
+    x = orc.gb_sample(rs, N, rho)
+    y = W @ x + np.sqrt(nv) * rs.standard_normal(M)
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=y, var=nv, ctx=ctx)).to_model()
+    est, msg, obj, ovl = T.TrackEstimate(ids=["x"]), T.TrackMessages(), T.TrackObjective(), T.TrackOverlaps({"x": x})
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=6, callback=T.JoinCallback([est, msg, obj, ovl, T.LogProgress(every=2)]))
+    fs = [orc.GBPriorFactor(N, rho=rho), orc.LinearFactor(W), orc.GaussLikFactor(y, nv)]
+    ref = []
+    orc.ep_chain(fs, [N, M], max_iter=6, tol=0.0,
+                 record=lambda it, fwd, bwd, rs_, vs: ref.append((rs_[0].copy(), fwd[0][0], orc.chain_log_evidence(fs, fwd, bwd))))
+    assert len(est.records) == 6 and len(obj.model_records) == 6 and len(msg.records) == 6 * 4
+    for it in range(6):
+        close(est.records[it]["r"], ref[it][0], 1e-7)
+        close(obj.model_records[it]["A"], ref[it][2], 1e-6, scale=abs(ref[it][2]) + 1)
+        close(ovl.records[it]["m"], ref[it][0] @ x / N, 1e-7)
+        close(ovl.records[it]["Q"], x @ x / N, 1e-12)
+    fwd_x = [r for r in msg.records if r["id"] == "x" and r["direction"] == "fwd"]
+    close([r["a"] for r in fwd_x], [ref[it][1] for it in range(6)], 1e-7)

@@ -22,6 +22,7 @@ from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, Gauss
 from .variables import SISOVariable, SILeafVariable
 from .models import Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution
 from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, EarlyStopping,
-                    ConstantInit, CustomInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors)
+                    ConstantInit, CustomInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
+                    TrackEstimate, TrackMessages, TrackObjective, TrackOverlaps, LogProgress)
 
 __version__ = "0.1.0"

@@ -158,6 +158,86 @@ class TrackErrors:
         return False
 
 
+class TrackEstimate:
+    "tramp/algos/callbacks.py:111-128: the posterior means, every `every` iterations"
+
+    def __init__(self, ids="all", every=1):
+        self.ids, self.every, self.records = ids, every, []
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.records = []
+        if i % self.every == 0:
+            for vid, d in algo.get_variables_data(self.ids).items():
+                self.records.append(dict(id=vid, r=d["r"], iter=i))
+        return False
+
+
+class TrackMessages:
+    "tramp/algos/callbacks.py:49-62: the scalar part a of every factor->variable message"
+
+    def __init__(self, keys=("a", "n_iter", "direction")):
+        self.keys, self.records = tuple(keys), []
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.records = []
+        for (vid, direction), a in algo.get_edges_data().items():
+            rec = dict(a=float(a[0]) if a.size == 1 else a, n_iter=algo.n_iter, direction=direction, id=vid)
+            self.records.append({k: rec[k] for k in (*self.keys, "id") if k in rec})
+        return False
+
+
+class TrackObjective:
+    "tramp/algos/callbacks.py:65-85, model level: the EP log-evidence A_model per iteration"
+
+    def __init__(self):
+        self.model_records = []
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.model_records = []
+        self.model_records.append(dict(A=algo.log_evidence(), n_iter=algo.n_iter))
+        return False
+
+
+class TrackOverlaps:
+    "tramp/algos/callbacks.py:165-191: m = r.x/N, q = r.r/N, Q = x.x/N against the true signal"
+
+    def __init__(self, true_values, ids="all", every=1):
+        self.true_values, self.ids, self.every, self.records = true_values, ids, every, []
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.records = []
+        if i % self.every == 0:
+            for vid, d in algo.get_variables_data(self.ids).items():
+                if vid not in self.true_values:
+                    continue
+                x = np.asarray(self.true_values[vid], dtype=np.float64)
+                r = np.asarray(d["r"], dtype=np.float64).reshape(x.shape)
+                n = x.shape[-1]
+                self.records.append(dict(id=vid, m=np.sum(r * x, axis=-1) / n, q=np.sum(r * r, axis=-1) / n,
+                                         Q=np.sum(x * x, axis=-1) / n, iter=i))
+        return False
+
+
+class LogProgress:
+    "tramp/algos/callbacks.py:33-46"
+
+    def __init__(self, ids="all", every=1):
+        self.ids, self.every = ids, every
+
+    def __call__(self, algo, i, max_iter):
+        if i % self.every == 0:
+            import logging
+            log = logging.getLogger(__name__)
+            log.info(f"iteration={i+1}/{max_iter}")
+            for vid, d in algo.get_variables_data(self.ids, want_r=False).items():
+                log.info(f"id={vid} v={np.mean(d['v']):.3f}")
+        return False
+
+
 # ------------------------------------------------------------------ EP
 class ExpectationPropagation:
     """Gaussian EP on a chain model (tramp/algos/expectation_propagation.py:5-32).
