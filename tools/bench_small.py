@@ -3,13 +3,12 @@ import sys, time
 import numpy as np
 sys.path.insert(0, '.')
 import tramp_amd as T
-from oracle import tramp_oracle as orc
 ctx = T.default_context()
 for N, B in ((1000, 1), (1000, 64), (4000, 1)):
     M, rho, nv = N // 2, 0.05, 1e-2
     rs = np.random.RandomState(1)
-    W = orc.gaussian_ensemble(rs, M, N)
-    X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(B)])
+    W = rs.randn(M, N) / np.sqrt(N)
+    X = rs.standard_normal((B, N)) * rs.binomial(1, rho, (B, N))
     Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
     model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
              @ T.LinearChannel(W, ctx=ctx, svd="device") @ T.SISOVariable(id="z")
