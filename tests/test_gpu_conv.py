@@ -193,3 +193,45 @@ def test_conv_large_n_properties(ctx, dtype, n):
     close(az * vz + ax * vx, 1.0, 1e-12)                   # (1 - n_eff) + n_eff
     a_new, b_new = ch.compute_backward_message(az, bz, ax, bx)
     close(b_new, rz * (az + a_new) - bz, rt * 10)
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float64, 1 << 13), (np.float64, 1 << 16), (np.float32, 1 << 14)])
+def test_conv_own_fft_engine_matches_oracle(ctx, dtype, n):
+    """1-D power-of-two sizes run on the hand-written two-pass FFT (csrc/fft_pow2.hip) with the spectrum
+    kept in the transform's permuted order: posteriors, messages, samples and a damped EP run (which also
+    exercises the affine update of the cached transform) against the oracle."""
+    import tramp_amd as T
+    rs = np.random.RandomState(n % 1000)
+    f = np.zeros(n)
+    f[:48] = rs.randn(48) / 6
+    f[-5:] = rs.randn(5) / 6
+    ch = T.ConvChannel(f, dtype=dtype, ctx=ctx)
+    o = orc.ConvOracle(f)
+    rt = 1e-10 if dtype == np.float64 else 3e-4
+    B = 2
+    bz, bx = rs.standard_normal((B, n)), rs.standard_normal((B, n)) * 2
+    az, ax = np.array([1.7, 0.3]), np.array([3.1, 5.0])
+    rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+    rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+    for b in range(B):
+        close(rz[b], o.backward_mean(az[b], bz[b], ax[b], bx[b]), rt)
+        close(rx[b], o.forward_mean(az[b], bz[b], ax[b], bx[b]), rt)
+        close(vz[b], o.backward_variance(az[b], ax[b]), 1e-11)
+        close(vx[b], o.forward_variance(az[b], ax[b]), 1e-11)
+    close(ch.convolve(bz[0]), o.convolve(bz[0]), rt)
+    a_new, b_new = ch.compute_backward_message(az, bz, ax, bx)
+    for b in range(B):
+        a1, b1 = o.backward_message(az[b], bz[b], ax[b], bx[b])
+        close(a_new[b], a1, 1e-10, scale=az[b] + a1)
+        close(b_new[b], b1, rt * 10)
+    if dtype == np.float64:
+        rho, nv, d = 0.05, 1e-3, 0.2
+        x = orc.gb_sample(rs, n, rho)
+        y = o.convolve(x) + np.sqrt(nv) * rs.standard_normal(n)
+        model = (T.GaussBernoulliPrior(size=n, rho=rho, ctx=ctx) @ T.SISOVariable(id="x") @ ch @ T.SISOVariable(id="z")
+                 @ T.GaussianLikelihood(y=y, var=nv, ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        ep.iterate(max_iter=6, callback=T.PassCallback(), damping=d)
+        fs = [orc.GBPriorFactor(n, rho=rho), orc.ConvFactor(f), orc.GaussLikFactor(y, nv)]
+        ref = orc.ep_chain(fs, [n, n], max_iter=6, damping=d, tol=0.0)
+        close(np.asarray(ep.get_variables_data()["x"]["r"]).reshape(n), ref["r"][0], 1e-6)

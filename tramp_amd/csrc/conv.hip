@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.h"
+#include "fft_pow2.h"
 #include "tramp_math.h"
 
 namespace {
@@ -52,6 +53,18 @@ struct tramp_conv {
     void* fx;
     void* fo;
     void* fr;                   // [batch, n] real: the mean when b_new may alias b_old (damping)
+    // own two-pass FFT engine (1-D, n = 2^m, 2^13 <= n <= 2^22): half-length complex transforms
+    // of the packed signal, spectrum kept in the transform's permuted order (fft_pow2.hip)
+    Fft2Plan* fft2;             // null: rocFFT engine
+    size_t h;                   // n / 2
+    void* wbar_p;               // [h] filter bins in permuted order (bin kfreq(p) at position p)
+    double* s2_p;               // [h]
+    double wbar_nyq, s2_nyq;    // bin h (real)
+    int* partner;               // [h] position holding frequency h - k
+    int* leaders;               // [nlead] 128-byte lines of the spectrum that lead a (line, partner line) pair
+    size_t nlead;
+    bool lines_closed;
+    void* wk;                   // [h] unpack twiddle exp(-2 pi i kfreq(p) / n)
     void* fzc;                  // transforms of the constant part of a damped constant message
     void* fxc;
     bool fzc_valid, fxc_valid;
@@ -267,6 +280,105 @@ __global__ __launch_bounds__(kBlock) void conv_spectral_kernel(int mode, size_t 
     }
 }
 
+// ---- spectral solve on the PERMUTED half-length spectrum of the packed signal (own FFT engine).
+// z[j] = x[2j] + i x[2j+1] has the length-h transform Z; with E, O the transforms of the even and
+// odd samples, Z_k = E_k + i O_k and the real signal's bins are X_k = E_k + w^k O_k, w = exp(-2 pi i / n):
+//     X_k = ((Z_k + conj Z_{h-k}) - i w^k (Z_k - conj Z_{h-k})) / 2,   X_0 = Re Z_0 + Im Z_0,  X_h = Re Z_0 - Im Z_0
+// and back Z'_k = ((Y_k + conj Y_{h-k}) + i conj(w^k) (Y_k - conj Y_{h-k})) / 2.  A thread owns the pair
+// (k, h-k), k <= h/2, through the partner table; modes as conv_spectral_kernel.
+template <typename C> __device__ __forceinline__ C cx_mul(C a, C b) {
+    C r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+template <typename C> __device__ __forceinline__ C cx_conj(C a) { a.y = -a.y; return a; }
+
+template <typename T>
+__device__ __forceinline__ typename Cx<T>::type spectral_bin(int mode, typename Cx<T>::type xz,
+                                                            typename Cx<T>::type xx, typename Cx<T>::type w,
+                                                            double s, double az, double ax, double inv) {
+    using C = typename Cx<T>::type;
+    C o;
+    if (mode == 2) {
+        o = cx_mul(cx_conj(w), xz);
+        o.x *= (T)inv;
+        o.y *= (T)inv;
+        return o;
+    }
+    const T res = (T)(inv / (az + ax * s));
+    const C wx = cx_mul(w, xx);
+    C rz;
+    rz.x = (xz.x + wx.x) * res;
+    rz.y = (xz.y + wx.y) * res;
+    return mode == 1 ? rz : cx_mul(cx_conj(w), rz);
+}
+
+// Work is handed out by 128-byte LINES of the permuted spectrum: the frequencies of a line differ only in
+// their top bits, so all their partners h - k sit in ONE other line; a group of lanes takes a leading line
+// and its partner line whole (full-line loads and stores for both), instead of half lines twice.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void conv_spectral_perm_kernel(int mode, size_t h, double inv_h,
+                                                                    const typename Cx<T>::type* __restrict__ wbar_p,
+                                                                    const double* __restrict__ s2_p, double wbar_nyq,
+                                                                    double s2_nyq, const int* __restrict__ partner,
+                                                                    const int* __restrict__ leaders, size_t nlead,
+                                                                    int closed,
+                                                                    const typename Cx<T>::type* __restrict__ wk,
+                                                                    const double* __restrict__ az_d,
+                                                                    const double* __restrict__ ax_d,
+                                                                    const typename Cx<T>::type* __restrict__ fz,
+                                                                    const typename Cx<T>::type* __restrict__ fx,
+                                                                    typename Cx<T>::type* __restrict__ fo) {
+    using C = typename Cx<T>::type;
+    constexpr int LINE = 128 / (int)sizeof(C);
+    const size_t b = blockIdx.y;
+    const double az = (mode == 2) ? 0.0 : az_d[b];
+    const double ax = (mode == 2) ? 0.0 : ax_d[b];
+    const size_t base = b * h;
+    const C zero = {};
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < nlead * LINE; idx += (size_t)gridDim.x * kBlock) {
+        const size_t p = (size_t)leaders[idx / LINE] * LINE + (idx % LINE);
+        const int pp = partner[p];
+        // each pair once: inside a self-paired line (or when the lines do not close) by its lower position
+        if ((!closed || (size_t)pp / LINE == p / LINE) && (size_t)pp < p) continue;
+        const C zp = fz[base + p], xp = (mode == 2) ? zero : fx[base + p];
+        if (p == 0) {                                  // bins 0 and h, both real
+            C xz0 = {zp.x + zp.y, T(0)}, xzh = {zp.x - zp.y, T(0)};
+            C xx0 = {xp.x + xp.y, T(0)}, xxh = {xp.x - xp.y, T(0)};
+            C wn = {(T)wbar_nyq, T(0)};
+            const C y0 = spectral_bin<T>(mode, xz0, xx0, wbar_p[0], s2_p[0], az, ax, inv_h);
+            const C yh = spectral_bin<T>(mode, xzh, xxh, wn, s2_nyq, az, ax, inv_h);
+            C o = {T(0.5) * (y0.x + yh.x), T(0.5) * (y0.x - yh.x)};
+            fo[base] = o;
+            continue;
+        }
+        const C zq = fz[base + pp], xq = (mode == 2) ? zero : fx[base + pp];
+        const C w = wk[p];
+        const C wq = {-w.x, w.y};                     // w^(h-k) = -conj(w^k)
+        auto unpack = [](C a, C bq, C tw) {           // ((a + conj b) - i tw (a - conj b)) / 2
+            const C cb = cx_conj(bq);
+            C sum = {a.x + cb.x, a.y + cb.y}, dif = {a.x - cb.x, a.y - cb.y};
+            const C td = cx_mul(tw, dif);             // -i td = (td.y, -td.x)
+            C r = {T(0.5) * (sum.x + td.y), T(0.5) * (sum.y - td.x)};
+            return r;
+        };
+        auto repack = [](C y, C yq, C tw) {           // ((y + conj yq) + i conj(tw) (y - conj yq)) / 2
+            const C cb = cx_conj(yq);
+            C sum = {y.x + cb.x, y.y + cb.y}, dif = {y.x - cb.x, y.y - cb.y};
+            const C td = cx_mul(cx_conj(tw), dif);    // i td = (-td.y, td.x)
+            C r = {T(0.5) * (sum.x - td.y), T(0.5) * (sum.y + td.x)};
+            return r;
+        };
+        const C xzk = unpack(zp, zq, w), xzq = unpack(zq, zp, wq);
+        const C xxk = (mode == 2) ? zero : unpack(xp, xq, w), xxq = (mode == 2) ? zero : unpack(xq, xp, wq);
+        const C yk = spectral_bin<T>(mode, xzk, xxk, wbar_p[p], s2_p[p], az, ax, inv_h);
+        const C yq = spectral_bin<T>(mode, xzq, xxq, wbar_p[pp], s2_p[pp], az, ax, inv_h);
+        fo[base + p] = repack(yk, yq, w);
+        if ((size_t)pp != p) fo[base + pp] = repack(yq, yk, wq);
+    }
+}
+
 // ---- message update on the inverse-transformed mean (tramp/channels/base_channel.py:9-17,
 // tramp/base.py:245-254), damping fused; r may be updated in place.
 template <typename T>
@@ -306,6 +418,122 @@ int conv_scalars(tramp_ctx* ctx, const tramp_conv* cv, double* partial, int dir,
     return TRAMP_OK;
 }
 
+void conv_free_fft2(tramp_conv* cv) {
+    if (cv->fft2) fft2_plan_destroy(cv->fft2);
+    if (cv->wbar_p) (void)hipFree(cv->wbar_p);
+    if (cv->s2_p) (void)hipFree(cv->s2_p);
+    if (cv->partner) (void)hipFree(cv->partner);
+    if (cv->leaders) (void)hipFree(cv->leaders);
+    cv->leaders = nullptr;
+    if (cv->wk) (void)hipFree(cv->wk);
+    cv->fft2 = nullptr;
+    cv->wbar_p = cv->wk = nullptr;
+    cv->s2_p = nullptr;
+    cv->partner = nullptr;
+}
+
+// Tables of the own-FFT engine: the filter bins and the unpack twiddles in the transform's
+// permuted order, and the k <-> h-k partner positions.  w64: natural-order half spectrum (device),
+// s2h: its squared modulus (host).
+int conv_setup_fft2(tramp_ctx* ctx, tramp_conv* cv, const double2* w64, const std::vector<double>& s2h) {
+    const char* eng = getenv("TRAMP_CONV_FFT");
+    if (eng && strcmp(eng, "rocfft") == 0) return TRAMP_OK;
+    if (cv->ndim != 1 || cv->n < 2 || (cv->n & (cv->n - 1))) return TRAMP_OK;
+    int q = 0;
+    while (((size_t)1 << q) < cv->n / 2) ++q;
+    const int lb = fft2_lb_log(q);
+    if (lb < 0) return TRAMP_OK;
+    const size_t h = cv->n / 2;
+    std::vector<double2> wnat(cv->nh);
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(wnat.data(), w64, cv->nh * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<size_t> kf(h);
+    std::vector<int> pos(h), partner(h);
+    for (size_t p = 0; p < h; ++p) {
+        kf[p] = fft2_kfreq(q, lb, p);
+        pos[kf[p]] = (int)p;
+    }
+    const bool f64 = cv->dtype == TRAMP_F64;
+    std::vector<double> s2p(h);
+    std::vector<double2> wp64(h), wk64(h);
+    for (size_t p = 0; p < h; ++p) {
+        const size_t k = kf[p];
+        partner[p] = pos[(h - k) % h];
+        wp64[p] = wnat[k];
+        s2p[p] = s2h[k];
+        const double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)cv->n;
+        wk64[p] = double2{cos(ang), sin(ang)};
+    }
+    cv->wbar_nyq = wnat[h].x;
+    cv->s2_nyq = s2h[h];
+    // leading lines: line l pairs with the line of the partner of its second position (never frequency 0)
+    // (closed = every line's partners lie in exactly one line; otherwise every line leads and a pair is
+    //  taken by its lower position - correct for any digit order, only with half-used lines)
+    const size_t line = 128 / (2 * dtype_size(cv->dtype));
+    bool closed = true;
+    for (size_t l = 0; l < h / line && closed; ++l) {
+        const size_t lp = (size_t)partner[l * line + 1] / line;
+        for (size_t e = 0; e < line; ++e)
+            if ((size_t)partner[l * line + e] / line != lp && !(l == 0 && e == 0)) closed = false;
+    }
+    std::vector<int> leaders;
+    for (size_t l = 0; l < h / line; ++l)
+        if (!closed || l <= (size_t)partner[l * line + 1] / line) leaders.push_back((int)l);
+    cv->nlead = leaders.size();
+    cv->lines_closed = closed;
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->leaders, leaders.size() * sizeof(int)));
+    TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->leaders, leaders.data(), leaders.size() * sizeof(int), hipMemcpyHostToDevice));
+    const size_t csz = 2 * dtype_size(cv->dtype);
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->wbar_p, h * csz));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->wk, h * csz));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->s2_p, h * sizeof(double)));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->partner, h * sizeof(int)));
+    if (f64) {
+        TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->wbar_p, wp64.data(), h * csz, hipMemcpyHostToDevice));
+        TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->wk, wk64.data(), h * csz, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float2> a(h), b(h);
+        for (size_t p = 0; p < h; ++p) {
+            a[p] = float2{(float)wp64[p].x, (float)wp64[p].y};
+            b[p] = float2{(float)wk64[p].x, (float)wk64[p].y};
+        }
+        TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->wbar_p, a.data(), h * csz, hipMemcpyHostToDevice));
+        TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->wk, b.data(), h * csz, hipMemcpyHostToDevice));
+    }
+    TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->s2_p, s2p.data(), h * sizeof(double), hipMemcpyHostToDevice));
+    TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->partner, partner.data(), h * sizeof(int), hipMemcpyHostToDevice));
+    int rc = fft2_plan_create(ctx, cv->dtype, q, &cv->fft2);
+    if (rc) return rc;
+    cv->h = h;
+    return TRAMP_OK;
+}
+
+// forward transform of [batch, n] reals into the engine's spectrum buffer
+int conv_forward(tramp_ctx* ctx, tramp_conv* cv, ConvPlans* p, size_t batch, const void* in, void* spec) {
+    if (cv->fft2) return fft2_forward(ctx, cv->fft2, batch, in, spec);
+    return fft_exec(ctx, p->fwd, p->info_fwd, in, spec);
+}
+
+int conv_inverse(tramp_ctx* ctx, tramp_conv* cv, ConvPlans* p, size_t batch, void* spec, void* out) {
+    if (cv->fft2) return fft2_inverse(ctx, cv->fft2, batch, spec, out);
+    return fft_exec(ctx, p->inv, p->info_inv, spec, out);
+}
+
+template <typename T>
+void launch_spectral(tramp_ctx* ctx, tramp_conv* cv, int mode, size_t batch, const double* az_d, const double* ax_d) {
+    using C = typename Cx<T>::type;
+    if (cv->fft2) {
+        dim3 g(grid_for(cv->h / 2), (unsigned)batch);
+        hipLaunchKernelGGL((conv_spectral_perm_kernel<T>), g, dim3(kBlock), 0, ctx->stream, mode, cv->h, 1.0 / cv->h,
+                           (const C*)cv->wbar_p, cv->s2_p, cv->wbar_nyq, cv->s2_nyq, cv->partner, cv->leaders, cv->nlead,
+                           cv->lines_closed ? 1 : 0, (const C*)cv->wk, az_d, ax_d, (const C*)cv->fz, (const C*)cv->fx, (C*)cv->fo);
+    } else {
+        dim3 g(grid_for(cv->nh), (unsigned)batch);
+        hipLaunchKernelGGL((conv_spectral_kernel<T>), g, dim3(kBlock), 0, ctx->stream, mode, cv->nh, 1.0 / cv->n,
+                           (const C*)cv->wbar, cv->s2, az_d, ax_d, (const C*)cv->fz, (const C*)cv->fx, (C*)cv->fo);
+    }
+}
+
 }  // namespace
 
 extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filter_d,
@@ -335,6 +563,14 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
     cv->work_batch = cv->proj_batch = 0;
     cv->wbar = nullptr;
     cv->s2 = nullptr;
+    cv->fft2 = nullptr;
+    cv->h = 0;
+    cv->wbar_p = nullptr;
+    cv->s2_p = nullptr;
+    cv->partner = nullptr;
+    cv->leaders = nullptr;
+    cv->nlead = 0;
+    cv->wk = nullptr;
     // filter transform in f64 regardless of the working precision (the scalars are f64)
     rocfft_plan plan = nullptr;
     rocfft_execution_info info = nullptr;
@@ -348,6 +584,7 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
         if (failed) {
             if (cv->wbar) (void)hipFree(cv->wbar);
             if (cv->s2) (void)hipFree(cv->s2);
+            conv_free_fft2(cv);
             delete cv;
         }
     };
@@ -393,6 +630,12 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
         acc += ((j == 0 || 2 * j == cv->nlast) ? 1.0L : 2.0L) * (long double)s2h[i];
     }
     cv->s_mean = (double)(acc / (long double)cv->n);
+    // own FFT engine for 1-D power-of-two sizes (TRAMP_CONV_FFT=rocfft keeps the library transforms)
+    rc = conv_setup_fft2(ctx, cv, w64, s2h);
+    if (rc) {
+        cleanup(true);
+        return rc;
+    }
     cleanup(false);
     *conv = cv;
     return TRAMP_OK;
@@ -412,6 +655,7 @@ extern "C" int tramp_conv_destroy(tramp_ctx* ctx, tramp_conv* cv) {
     if (cv->work) (void)hipFree(cv->work);
     if (cv->wbar) (void)hipFree(cv->wbar);
     if (cv->s2) (void)hipFree(cv->s2);
+    conv_free_fft2(cv);
     delete cv;
     return TRAMP_OK;
 }
@@ -445,23 +689,18 @@ extern "C" int tramp_conv_apply(tramp_ctx* ctx, tramp_conv* cv, size_t batch, co
     if (!batch) return TRAMP_OK;
     int rc = conv_reserve(ctx, cv, batch);
     if (rc) return rc;
-    ConvPlans* p;
-    rc = plans_for(ctx, cv, batch, &p);
-    if (rc) return rc;
+    ConvPlans* p = nullptr;
+    if (!cv->fft2) {
+        rc = plans_for(ctx, cv, batch, &p);
+        if (rc) return rc;
+    }
     cv->proj_batch = 0;                                               // fz is overwritten below
-    rc = fft_exec(ctx, p->fwd, p->info_fwd, z_d, cv->fz);
+    rc = conv_forward(ctx, cv, p, batch, z_d, cv->fz);
     if (rc) return rc;
-    dim3 g(grid_for(cv->nh), (unsigned)batch);
-    if (cv->dtype == TRAMP_F64)
-        hipLaunchKernelGGL((conv_spectral_kernel<double>), g, dim3(kBlock), 0, ctx->stream, 2, cv->nh, 1.0 / cv->n,
-                           (const double2*)cv->wbar, cv->s2, (const double*)nullptr, (const double*)nullptr,
-                           (const double2*)cv->fz, (const double2*)nullptr, (double2*)cv->fo);
-    else
-        hipLaunchKernelGGL((conv_spectral_kernel<float>), g, dim3(kBlock), 0, ctx->stream, 2, cv->nh, 1.0 / cv->n,
-                           (const float2*)cv->wbar, cv->s2, (const double*)nullptr, (const double*)nullptr,
-                           (const float2*)cv->fz, (const float2*)nullptr, (float2*)cv->fo);
+    if (cv->dtype == TRAMP_F64) launch_spectral<double>(ctx, cv, 2, batch, nullptr, nullptr);
+    else launch_spectral<float>(ctx, cv, 2, batch, nullptr, nullptr);
     TRAMP_LAUNCH_CHECK(ctx);
-    return fft_exec(ctx, p->inv, p->info_inv, cv->fo, x_d);
+    return conv_inverse(ctx, cv, p, batch, cv->fo, x_d);
 }
 
 template <typename T>
@@ -486,15 +725,15 @@ extern "C" int tramp_conv_project_affine(tramp_ctx* ctx, tramp_conv* cv, int whi
     void* p = is_t ? cv->fz : cv->fx;
     const size_t esz = dtype_size(cv->dtype);
     if (c_changed || !valid) {
-        ConvPlans* pl;
-        int rc = plans_for(ctx, cv, batch, &pl);
+        ConvPlans* pl = nullptr;
+        int rc = cv->fft2 ? TRAMP_OK : plans_for(ctx, cv, batch, &pl);
         if (rc) return rc;
         ProfScope ps(ctx, PROF_FFT, (double)batch * (cv->n * esz + cv->nh * 2 * esz), 0);
-        rc = fft_exec(ctx, pl->fwd, pl->info_fwd, c_d, pc);
+        rc = conv_forward(ctx, cv, pl, batch, c_d, pc);
         if (rc) return rc;
         valid = true;
     }
-    const size_t count = batch * cv->nh * 2;                           // real and imaginary parts alike
+    const size_t count = batch * (cv->fft2 ? cv->h : cv->nh) * 2;      // real and imaginary parts alike
     ProfScope ps(ctx, PROF_LIN_SCALARS, 3.0 * count * esz, 0);
     if (cv->dtype == TRAMP_F64)
         hipLaunchKernelGGL((conv_axpby_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, count,
@@ -520,9 +759,11 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     if (rc) return rc;
     if (cv->work != work_before || cv->proj_batch != batch) reuse = 0;
     cv->proj_batch = batch;
-    ConvPlans* p;
-    rc = plans_for(ctx, cv, batch, &p);
-    if (rc) return rc;
+    ConvPlans* p = nullptr;
+    if (!cv->fft2) {
+        rc = plans_for(ctx, cv, batch, &p);
+        if (rc) return rc;
+    }
     const size_t n = cv->n, nh = cv->nh;
     const size_t esz = dtype_size(cv->dtype);
     // 1. scalars
@@ -535,27 +776,20 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     // 2. transforms of the incoming messages (shared by the two directions of one iteration)
     if (!(reuse & TRAMP_REUSE_T)) {
         ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz + nh * 2 * esz), 0);
-        rc = fft_exec(ctx, p->fwd, p->info_fwd, bz_d, cv->fz);
+        rc = conv_forward(ctx, cv, p, batch, bz_d, cv->fz);
         if (rc) return rc;
     }
     if (!(reuse & TRAMP_REUSE_U)) {
         ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz + nh * 2 * esz), 0);
-        rc = fft_exec(ctx, p->fwd, p->info_fwd, bx_d, cv->fx);
+        rc = conv_forward(ctx, cv, p, batch, bx_d, cv->fx);
         if (rc) return rc;
     }
     // 3. spectral solve
     {
         ProfScope ps(ctx, PROF_LIN_SCALARS, (double)batch * nh * 6 * esz + nh * (2 * esz + 8.0), 0);
         const int mode = (dir == TRAMP_FWD) ? 0 : 1;
-        dim3 g(grid_for(nh), (unsigned)batch);
-        if (cv->dtype == TRAMP_F64)
-            hipLaunchKernelGGL((conv_spectral_kernel<double>), g, dim3(kBlock), 0, ctx->stream, mode, nh, 1.0 / n,
-                               (const double2*)cv->wbar, cv->s2, az_d, ax_d, (const double2*)cv->fz,
-                               (const double2*)cv->fx, (double2*)cv->fo);
-        else
-            hipLaunchKernelGGL((conv_spectral_kernel<float>), g, dim3(kBlock), 0, ctx->stream, mode, nh, 1.0 / n,
-                               (const float2*)cv->wbar, cv->s2, az_d, ax_d, (const float2*)cv->fz,
-                               (const float2*)cv->fx, (float2*)cv->fo);
+        if (cv->dtype == TRAMP_F64) launch_spectral<double>(ctx, cv, mode, batch, az_d, ax_d);
+        else launch_spectral<float>(ctx, cv, mode, batch, az_d, ax_d);
         TRAMP_LAUNCH_CHECK(ctx);
     }
     // 4. back to the signal domain; the mean lands in r_d when asked for, else in b_new_d
@@ -563,7 +797,7 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     void* mean = r_d ? r_d : (damping != 0.0 ? cv->fr : b_new_d);
     {
         ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz + nh * 2 * esz), 0);
-        rc = fft_exec(ctx, p->inv, p->info_inv, cv->fo, mean);
+        rc = conv_inverse(ctx, cv, p, batch, cv->fo, mean);
         if (rc) return rc;
     }
     // 5. message update (in place on the mean)
