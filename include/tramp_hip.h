@@ -342,15 +342,15 @@ int tramp_conv_message(tramp_ctx* ctx, tramp_conv* conv, int dir, size_t batch,
                        double damping, const double* a_old_d, const void* b_old_d,
                        double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse);
 
-/* Two-pass complex FFT of length h = 2^log2h (12 <= log2h <= 21) used by the convolution channel
- * for 1-D power-of-two sizes (csrc/fft_pow2.hip).  Exported for tests: forward maps natural order
- * to the PERMUTED spectrum (position p holds frequency kfreq[p], tramp_fft_pow2_order), inverse maps
- * a permuted spectrum (overwritten) back to natural order, unnormalised.  Interleaved complex. */
-int tramp_fft_pow2(tramp_ctx* ctx, int dtype, int log2h, size_t batch, int inverse, void* in_d, void* out_d);
-int tramp_fft_pow2_order(tramp_ctx* ctx, int log2h, size_t count, unsigned long long* kfreq_host);
+/* Two-pass mixed-radix complex FFT of length h = 2^a 5^b (1024 <= h <= ~1.3 10^6) used by the convolution
+ * channel for 1-D sizes n = 2 h (csrc/fft_pow2.hip).  Exported for tests and tools: forward maps natural
+ * order to the PERMUTED spectrum (position p holds frequency kfreq[p], tramp_fft_order), inverse maps a
+ * permuted spectrum (overwritten) back to natural order, unnormalised.  Interleaved complex. */
+int tramp_fft_len(tramp_ctx* ctx, int dtype, size_t h, size_t batch, int inverse, void* in_d, void* out_d);
+int tramp_fft_order(tramp_ctx* ctx, size_t h, size_t count, unsigned long long* kfreq_host);
 /* average milliseconds of `reps` forward and `reps` inverse transforms (tools/bench_fft.py) */
-int tramp_fft_pow2_bench(tramp_ctx* ctx, int dtype, int log2h, size_t batch, int reps, void* in_d, void* out_d,
-                         double* ms_fwd, double* ms_inv);
+int tramp_fft_bench(tramp_ctx* ctx, int dtype, size_t h, size_t batch, int reps, void* in_d, void* out_d,
+                    double* ms_fwd, double* ms_inv);
 
 /* ---- unitary channels: DFT and dense rotation ------------------------------- */
 /* DFTChannel (tramp/channels/linear/dft_channel.py:7-77, real=True): x = fftn(z, norm="ortho").

@@ -195,9 +195,10 @@ def test_conv_large_n_properties(ctx, dtype, n):
     close(b_new, rz * (az + a_new) - bz, rt * 10)
 
 
-@pytest.mark.parametrize("dtype,n", [(np.float64, 1 << 13), (np.float64, 1 << 16), (np.float32, 1 << 14)])
+@pytest.mark.parametrize("dtype,n", [(np.float64, 1 << 13), (np.float64, 1 << 16), (np.float32, 1 << 14),
+                                     (np.float64, 20000), (np.float64, 100000), (np.float32, 25600)])
 def test_conv_own_fft_engine_matches_oracle(ctx, dtype, n):
-    """1-D power-of-two sizes run on the hand-written two-pass FFT (csrc/fft_pow2.hip) with the spectrum
+    """1-D sizes n = 2 h, h = 2^a 5^b, run on the hand-written two-pass FFT (csrc/fft_pow2.hip) with the spectrum
     kept in the transform's permuted order: posteriors, messages, samples and a damped EP run (which also
     exercises the affine update of the cached transform) against the oracle."""
     import tramp_amd as T

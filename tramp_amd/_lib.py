@@ -89,9 +89,9 @@ _SIGNATURES = {
     "tramp_dft_message": [vp, vp, i32, sz, vp, vp, dbl, vp, vp, vp, vp],
     "tramp_log_partition": [vp, i32, i32, sz, sz, dbl, dbl, dbl, vp, vp, vp, vp, vp],
     "tramp_linear_log_partition": [vp, vp, sz, vp, vp, vp, vp, i32, vp],
-    "tramp_fft_pow2": [vp, i32, i32, sz, i32, vp, vp],
-    "tramp_fft_pow2_order": [vp, i32, sz, vp],
-    "tramp_fft_pow2_bench": [vp, i32, i32, sz, i32, vp, vp, C.POINTER(dbl), C.POINTER(dbl)],
+    "tramp_fft_len": [vp, i32, sz, sz, i32, vp, vp],
+    "tramp_fft_order": [vp, sz, sz, vp],
+    "tramp_fft_bench": [vp, i32, sz, sz, i32, vp, vp, C.POINTER(dbl), C.POINTER(dbl)],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -53,7 +53,7 @@ struct tramp_conv {
     void* fx;
     void* fo;
     void* fr;                   // [batch, n] real: the mean when b_new may alias b_old (damping)
-    // own two-pass FFT engine (1-D, n = 2^m, 2^13 <= n <= 2^22): half-length complex transforms
+    // own two-pass FFT engine (1-D, n / 2 = 2^a 5^b up to ~1.3 10^6): half-length complex transforms
     // of the packed signal, spectrum kept in the transform's permuted order (fft_pow2.hip)
     Fft2Plan* fft2;             // null: rocFFT engine
     size_t h;                   // n / 2
@@ -438,19 +438,17 @@ void conv_free_fft2(tramp_conv* cv) {
 int conv_setup_fft2(tramp_ctx* ctx, tramp_conv* cv, const double2* w64, const std::vector<double>& s2h) {
     const char* eng = getenv("TRAMP_CONV_FFT");
     if (eng && strcmp(eng, "rocfft") == 0) return TRAMP_OK;
-    if (cv->ndim != 1 || cv->n < 2 || (cv->n & (cv->n - 1))) return TRAMP_OK;
-    int q = 0;
-    while (((size_t)1 << q) < cv->n / 2) ++q;
-    const int lb = fft2_lb_log(q);
-    if (lb < 0) return TRAMP_OK;
+    if (cv->ndim != 1 || cv->n < 2 || (cv->n & 1)) return TRAMP_OK;
     const size_t h = cv->n / 2;
+    Fft2Shape shp;
+    if (!fft2_shape(h, &shp)) return TRAMP_OK;           // not 2^a 5^b in the two-pass range: rocFFT
     std::vector<double2> wnat(cv->nh);
     TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(wnat.data(), w64, cv->nh * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<size_t> kf(h);
     std::vector<int> pos(h), partner(h);
     for (size_t p = 0; p < h; ++p) {
-        kf[p] = fft2_kfreq(q, lb, p);
+        kf[p] = fft2_kfreq(shp, p);
         pos[kf[p]] = (int)p;
     }
     const bool f64 = cv->dtype == TRAMP_F64;
@@ -502,7 +500,7 @@ int conv_setup_fft2(tramp_ctx* ctx, tramp_conv* cv, const double2* w64, const st
     }
     TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->s2_p, s2p.data(), h * sizeof(double), hipMemcpyHostToDevice));
     TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->partner, partner.data(), h * sizeof(int), hipMemcpyHostToDevice));
-    int rc = fft2_plan_create(ctx, cv->dtype, q, &cv->fft2);
+    int rc = fft2_plan_create(ctx, cv->dtype, h, &cv->fft2);
     if (rc) return rc;
     cv->h = h;
     return TRAMP_OK;

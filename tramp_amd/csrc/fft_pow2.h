@@ -1,20 +1,30 @@
-// fft_pow2.h - internal interface of the two-pass power-of-two complex FFT (fft_pow2.hip).
+// fft_pow2.h - internal interface of the two-pass mixed-radix (2^a 5^b) complex FFT (fft_pow2.hip).
 #pragma once
 #include "common.h"
 
+// h = G * LB; stage lists of the two passes (radices 5 / 4 / 2), with for every stage the stride
+// between a butterfly's legs (sub) and the factor that turns an offset into a w_h exponent (mul).
+struct Fft2Shape {
+    size_t h, LB;
+    int G;
+    int n1, r1[8], sub1[8];
+    size_t mul1[8];
+    int n2, r2[8], sub2[8];
+    size_t mul2[8];
+};
+
 struct Fft2Plan {
     int dtype;
-    int q;        // log2 of the transform length h
-    int lb_log;   // log2 of the block length handled by the second pass
+    Fft2Shape shape;
     void* tw_hi;  // w_h^(1024 i)
     void* tw_lo;  // w_h^i, i < 1024
 };
 
-// log2 of the block length for h = 2^q, or -1 when the length is not supported (q in 12..21)
-int fft2_lb_log(int q);
+// false when h is not 2^a 5^b or does not split into a [G <= 320] x [512 <= LB <= 4096] pair
+bool fft2_shape(size_t h, Fft2Shape* sh);
 // frequency held by position p of a forward-transformed array
-size_t fft2_kfreq(int q, int lb_log, size_t p);
-int fft2_plan_create(tramp_ctx* ctx, int dtype, int q, Fft2Plan** out);
+size_t fft2_kfreq(const Fft2Shape& sh, size_t p);
+int fft2_plan_create(tramp_ctx* ctx, int dtype, size_t h, Fft2Plan** out);
 void fft2_plan_destroy(Fft2Plan* pl);
 // natural order -> permuted spectrum (out of place; in and out may coincide)
 int fft2_forward(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, const void* in, void* out);

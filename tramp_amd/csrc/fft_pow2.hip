@@ -1,21 +1,21 @@
-// fft_pow2.hip - batched complex FFT of length h = 2^q in TWO passes over HBM (hand-written,
+// fft_pow2.hip - batched complex FFT of length h = 2^a 5^b in TWO passes over HBM (hand-written,
 // for the convolution channel: tramp/channels/linear/conv_channel.py:81-109 needs three
 // transforms per EP iteration and rocFFT spends ~5 passes on a 10^6-point real transform).
+// (The file keeps its first name; powers of two were the first lengths it handled.)
 //
-// Decimation in frequency, radix 4 (one closing radix-2 stage when the block length asks for
-// it), in place, NO reordering: position p of the result holds frequency kfreq(p), the
-// mixed-radix digit reversal of p.  Everything in the spectral domain of the convolution
-// channel is elementwise (up to the k <-> h-k pairing of a real signal, which a table
-// resolves), so the permuted order is simply kept, and the inverse - decimation in time, the
-// same stages backwards - consumes it and returns natural order.
-//   pass 1 (strided): the first S1 radix-4 stages couple positions that are multiples of the
-//          block length LB apart.  A workgroup takes C consecutive offsets c and all G = 4^S1
-//          rows g (position g LB + c): a [G][C] tile in LDS, S1 butterfly stages, twiddles
-//          w_L^(m j) from a two-level table of w_h (exponent e: hi[e >> 10] lo[e & 1023]).
+// Decimation in frequency, mixed radix 5 / 4 / 2, in place, NO reordering: position p of the
+// result holds frequency kfreq(p), the mixed-radix digit reversal of p.  Everything in the
+// spectral domain of the convolution channel is elementwise (up to the k <-> h-k pairing of a
+// real signal, which a table resolves), so the permuted order is simply kept, and the inverse
+// - decimation in time, the same stages backwards - consumes it and returns natural order.
+//   pass 1 (strided): the first stages couple positions that are multiples of the block length
+//          LB apart.  A workgroup takes C consecutive offsets c (one 128-byte line) and all
+//          G = h / LB rows g (position g LB + c): a [G][C] tile in LDS, twiddles w_L^(m j) from
+//          a two-level table of w_h (exponent e: hi[e >> 10] lo[e & 1023]).
 //   pass 2 (blocks):  the remaining stages stay inside contiguous blocks of LB points: one
 //          block per workgroup in LDS.
 // Each pass reads and writes every point once: 2 x (read + write) per transform.
-// The inverse runs pass 2 then pass 1 with conjugated twiddles and the transposed butterfly.
+// The inverse runs pass 2 then pass 1 with conjugated twiddles and the transposed butterflies.
 #include <algorithm>
 
 #include "common.h"
@@ -39,7 +39,8 @@ template <typename C> __device__ __forceinline__ C cconj(C a) {
 }
 template <typename C> __device__ __forceinline__ C cadd(C a, C b) { a.x += b.x; a.y += b.y; return a; }
 template <typename C> __device__ __forceinline__ C csub(C a, C b) { a.x -= b.x; a.y -= b.y; return a; }
-// multiplication by -i (forward) / +i (inverse)
+template <typename C, typename S> __device__ __forceinline__ C cscale(C a, S s) { a.x *= s; a.y *= s; return a; }
+// multiplication by -i / +i
 template <typename C> __device__ __forceinline__ C mul_mi(C a) { C r; r.x = a.y; r.y = -a.x; return r; }
 template <typename C> __device__ __forceinline__ C mul_pi(C a) { C r; r.x = -a.y; r.y = a.x; return r; }
 
@@ -49,8 +50,23 @@ __device__ __forceinline__ C twiddle(const C* __restrict__ hi, const C* __restri
     return cmul(hi[e >> 10], lo[e & 1023]);
 }
 
-// One radix-4 butterfly.  INV = false: decimation in frequency (forward, outputs multiplied by
-// w, w^2, w^3); INV = true: decimation in time with conjugated twiddles (inputs multiplied first).
+// Butterflies.  INV = false: decimation in frequency (forward DFT of the legs, outputs multiplied by
+// w^j); INV = true: the exact transpose for decimation in time (inputs multiplied by conj(w)^j, then
+// the conjugate DFT).  Unnormalised.
+template <typename C, bool INV>
+__device__ __forceinline__ void bfly2(C& a0, C& a1, C w1) {
+    if (!INV) {
+        const C s = cadd(a0, a1), d = csub(a0, a1);
+        a0 = s;
+        a1 = cmul(d, w1);
+    } else {
+        const C u1 = cmul(a1, cconj(w1));
+        const C s = cadd(a0, u1), d = csub(a0, u1);
+        a0 = s;
+        a1 = d;
+    }
+}
+
 template <typename C, bool INV>
 __device__ __forceinline__ void bfly4(C& a0, C& a1, C& a2, C& a3, C w1) {
     const C w2 = cmul(w1, w1), w3 = cmul(w2, w1);
@@ -70,22 +86,71 @@ __device__ __forceinline__ void bfly4(C& a0, C& a1, C& a2, C& a3, C w1) {
     }
 }
 
-// ---------------------------------------------------------------- pass 1: strided stages
-// tile [G][C] (+1 complex of padding per row), G = 4^S1 rows LB apart, C offsets = one 128-byte
-// line per row (8 f64 / 16 f32 complex): 35 KiB at G = 256, four workgroups per CU.
+template <typename C, bool INV>
+__device__ __forceinline__ void bfly5(C& a0, C& a1, C& a2, C& a3, C& a4, C w1) {
+    using S = decltype(a0.x);
+    const S c1 = S(0.30901699437494742410), c2 = S(-0.80901699437494742410);   // cos(2 pi/5), cos(4 pi/5)
+    const S s1 = S(0.95105651629515357212), s2 = S(0.58778525229247312917);    // sin(2 pi/5), sin(4 pi/5)
+    const C w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+    if (INV) {
+        a1 = cmul(a1, cconj(w1));
+        a2 = cmul(a2, cconj(w2));
+        a3 = cmul(a3, cconj(w3));
+        a4 = cmul(a4, cconj(w4));
+    }
+    const C t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+    const C y0 = cadd(a0, cadd(t1, t2));
+    const C m1 = cadd(a0, cadd(cscale(t1, c1), cscale(t2, c2)));
+    const C m2 = cadd(a0, cadd(cscale(t1, c2), cscale(t2, c1)));
+    const C n1 = cadd(cscale(t3, s1), cscale(t4, s2));
+    const C n2 = csub(cscale(t3, s2), cscale(t4, s1));
+    // forward: y1 = m1 - i n1, y4 = m1 + i n1, y2 = m2 - i n2, y3 = m2 + i n2; inverse: signs swapped
+    const C in1 = INV ? mul_pi(n1) : mul_mi(n1), in2 = INV ? mul_pi(n2) : mul_mi(n2);
+    C y1 = cadd(m1, in1), y4 = csub(m1, in1), y2 = cadd(m2, in2), y3 = csub(m2, in2);
+    if (!INV) {
+        y1 = cmul(y1, w1);
+        y2 = cmul(y2, w2);
+        y3 = cmul(y3, w3);
+        y4 = cmul(y4, w4);
+    }
+    a0 = y0; a1 = y1; a2 = y2; a3 = y3; a4 = y4;
+}
+
+// one butterfly of radix r on tile[i0 + j * stride], j < r
+template <typename C, bool INV>
+__device__ __forceinline__ void bfly_at(C* tile, int i0, int stride, int r, C w1) {
+    if (r == 4) {
+        C a0 = tile[i0], a1 = tile[i0 + stride], a2 = tile[i0 + 2 * stride], a3 = tile[i0 + 3 * stride];
+        bfly4<C, INV>(a0, a1, a2, a3, w1);
+        tile[i0] = a0; tile[i0 + stride] = a1; tile[i0 + 2 * stride] = a2; tile[i0 + 3 * stride] = a3;
+    } else if (r == 5) {
+        C a0 = tile[i0], a1 = tile[i0 + stride], a2 = tile[i0 + 2 * stride], a3 = tile[i0 + 3 * stride],
+          a4 = tile[i0 + 4 * stride];
+        bfly5<C, INV>(a0, a1, a2, a3, a4, w1);
+        tile[i0] = a0; tile[i0 + stride] = a1; tile[i0 + 2 * stride] = a2; tile[i0 + 3 * stride] = a3;
+        tile[i0 + 4 * stride] = a4;
+    } else {
+        C a0 = tile[i0], a1 = tile[i0 + stride];
+        bfly2<C, INV>(a0, a1, w1);
+        tile[i0] = a0; tile[i0 + stride] = a1;
+    }
+}
+
+// tile [G][C] (+1 complex of padding per row), G rows LB apart, C offsets = one 128-byte line per
+// row (8 f64 / 16 f32 complex)
 template <typename T> constexpr int c1_of() { return 128 / (2 * (int)sizeof(T)); }
 
+// ---------------------------------------------------------------- pass 1: strided stages
 template <typename T, bool INV>
-__global__ __launch_bounds__(256) void fft_strided_kernel(int q, int lb_log, const typename C2<T>::type* __restrict__ in,
+__global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const typename C2<T>::type* __restrict__ in,
                                                           typename C2<T>::type* __restrict__ out,
                                                           const typename C2<T>::type* __restrict__ tw_hi,
                                                           const typename C2<T>::type* __restrict__ tw_lo) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
-    const size_t h = (size_t)1 << q, LB = (size_t)1 << lb_log;
-    const int G = (int)(h >> lb_log);                 // 4^S1
-    const int S1 = (q - lb_log) / 2;
+    const size_t h = sh.h, LB = sh.LB;
+    const int G = sh.G;
     constexpr int kC1 = c1_of<T>();
     constexpr int P = kC1 + 1;                        // row pitch
     const size_t tiles_per_tf = LB / kC1;
@@ -93,27 +158,21 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(int q, int lb_log, con
     const size_t c0 = (blockIdx.x % tiles_per_tf) * kC1;
     const C* src = in + tf * h;
     C* dst = out + tf * h;
-    const int c = threadIdx.x % kC1, r0 = threadIdx.x / kC1;          // 16 row slots per sweep
+    const int c = threadIdx.x % kC1, r0 = threadIdx.x / kC1;
     for (int g = r0; g < G; g += 256 / kC1) tile[g * P + c] = src[(size_t)g * LB + c0 + c];
     __syncthreads();
-    const int nb = G / 4;                             // butterflies per column per stage
-    for (int st = 0; st < S1; ++st) {
-        const int s = INV ? S1 - 1 - st : st;         // DIT runs the stages backwards
-        const int sg = G >> (2 * (s + 1));            // stride between the 4 legs, in rows: 4^(S1-s-1)
-        const size_t mulh = (size_t)1 << (2 * s);     // w_L^m = w_h^(m 4^s), L = h / 4^s
+    for (int st = 0; st < sh.n1; ++st) {
+        const int s = INV ? sh.n1 - 1 - st : st;      // DIT runs the stages backwards
+        const int r = sh.r1[s];
+        const int sg = sh.sub1[s];                    // stride between the legs, in rows
+        const size_t mulh = sh.mul1[s];               // w_L^m = w_h^(m * prod of the earlier radices)
+        const int nb = G / r;                         // butterflies per column
         for (int b = r0; b < nb; b += 256 / kC1) {
-            // butterfly b: block index bh = b / sg, offset bl = b % sg  ->  first leg row = bh * 4 sg + bl
             const int bl = b % sg, bh = b / sg;
-            const int g0 = bh * 4 * sg + bl;
-            const size_t m = (size_t)bl * LB + c0 + c;                 // position inside the quarter
-            const C w1 = twiddle<C>(tw_hi, tw_lo, (m * mulh) & (h - 1));
-            C a0 = tile[g0 * P + c], a1 = tile[(g0 + sg) * P + c], a2 = tile[(g0 + 2 * sg) * P + c],
-              a3 = tile[(g0 + 3 * sg) * P + c];
-            bfly4<C, INV>(a0, a1, a2, a3, w1);
-            tile[g0 * P + c] = a0;
-            tile[(g0 + sg) * P + c] = a1;
-            tile[(g0 + 2 * sg) * P + c] = a2;
-            tile[(g0 + 3 * sg) * P + c] = a3;
+            const int g0 = bh * r * sg + bl;
+            const size_t m = (size_t)bl * LB + c0 + c;                 // position inside the sub-block
+            const C w1 = twiddle<C>(tw_hi, tw_lo, m * mulh);          // m < L / r, so the exponent stays below h
+            bfly_at<C, INV>(tile, g0 * P + c, sg * P, r, w1);
         }
         __syncthreads();
     }
@@ -122,41 +181,26 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(int q, int lb_log, con
 
 // ---------------------------------------------------------------- pass 2: inside blocks of LB
 template <typename T, bool INV>
-__global__ __launch_bounds__(256) void fft_block_kernel(int q, int lb_log, typename C2<T>::type* __restrict__ data,
+__global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C2<T>::type* __restrict__ data,
                                                         const typename C2<T>::type* __restrict__ tw_hi,
                                                         const typename C2<T>::type* __restrict__ tw_lo) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
-    const size_t h = (size_t)1 << q;
-    const int LB = 1 << lb_log;
+    const int LB = (int)sh.LB;
     C* blk = data + (size_t)blockIdx.x * LB;          // blocks of all transforms are contiguous
     for (int i = threadIdx.x; i < LB; i += 256) tile[i] = blk[i];
     __syncthreads();
-    const int n4 = lb_log / 2;                        // radix-4 stages
-    const bool has2 = lb_log & 1;                     // closing radix-2 stage (L = 2)
-    const int nst = n4 + (has2 ? 1 : 0);
-    for (int st = 0; st < nst; ++st) {
-        const int s = INV ? nst - 1 - st : st;
-        if (s < n4) {
-            const int L = LB >> (2 * s), qd = L / 4;  // sub-length and quarter
-            const size_t mulh = h / (size_t)L;        // w_L^m = w_h^(m h / L)
-            for (int b = threadIdx.x; b < LB / 4; b += 256) {
-                const int m = b % qd, base = (b / qd) * L + m;
-                const C w1 = twiddle<C>(tw_hi, tw_lo, (size_t)m * mulh);
-                C a0 = tile[base], a1 = tile[base + qd], a2 = tile[base + 2 * qd], a3 = tile[base + 3 * qd];
-                bfly4<C, INV>(a0, a1, a2, a3, w1);
-                tile[base] = a0;
-                tile[base + qd] = a1;
-                tile[base + 2 * qd] = a2;
-                tile[base + 3 * qd] = a3;
-            }
-        } else {
-            for (int b = threadIdx.x; b < LB / 2; b += 256) {
-                const C a0 = tile[2 * b], a1 = tile[2 * b + 1];
-                tile[2 * b] = cadd(a0, a1);
-                tile[2 * b + 1] = csub(a0, a1);
-            }
+    for (int st = 0; st < sh.n2; ++st) {
+        const int s = INV ? sh.n2 - 1 - st : st;
+        const int r = sh.r2[s];
+        const int sub = sh.sub2[s];                   // L / r, L the current sub-length
+        const size_t mulh = sh.mul2[s];               // h / L
+        const int L = sub * r;
+        for (int b = threadIdx.x; b < LB / r; b += 256) {
+            const int m = b % sub, base = (b / sub) * L + m;
+            const C w1 = twiddle<C>(tw_hi, tw_lo, (size_t)m * mulh);
+            bfly_at<C, INV>(tile, base, sub, r, w1);
         }
         __syncthreads();
     }
@@ -164,74 +208,114 @@ __global__ __launch_bounds__(256) void fft_block_kernel(int q, int lb_log, typen
 }
 
 template <typename T>
-__global__ void fft_tables_kernel(int q, typename C2<T>::type* hi, typename C2<T>::type* lo) {
+__global__ void fft_tables_kernel(size_t h, size_t nhi, typename C2<T>::type* hi, typename C2<T>::type* lo) {
     // w_h^e = exp(-2 pi i e / h) evaluated in double with sincospi
-    const size_t h = (size_t)1 << q;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nhi = h > 1024 ? h >> 10 : 1;
     if (i < nhi) {
         double s, c;
-        sincospi(-2.0 * (double)(i << 10) / (double)h, &s, &c);
+        sincospi(-2.0 * (double)((i << 10) % h) / (double)h, &s, &c);
         hi[i].x = (T)c;
         hi[i].y = (T)s;
     }
     if (i < 1024) {
         double s, c;
-        sincospi(-2.0 * (double)i / (double)h, &s, &c);
+        sincospi(-2.0 * (double)(i % h) / (double)h, &s, &c);
         lo[i].x = (T)c;
         lo[i].y = (T)s;
     }
 }
 
-}  // namespace
-
-// frequency held by position p after the forward transform
-size_t fft2_kfreq(int q, int lb_log, size_t p) {
-    size_t k = 0, weight = 1;
-    int bits = q;
-    const int n4 = (q - lb_log) / 2 + lb_log / 2;
-    for (int s = 0; s < n4; ++s) {                    // most significant base-4 digit of p first
-        bits -= 2;
-        k += ((p >> bits) & 3) * weight;
-        weight *= 4;
-    }
-    if (bits == 1) k += (p & 1) * weight;
-    return k;
+// radices of a 2^a 5^b number, fives first, then fours, then a closing two
+int radices_of(size_t v, int* r) {
+    int n = 0;
+    while (v % 5 == 0) { r[n++] = 5; v /= 5; }
+    while (v % 4 == 0) { r[n++] = 4; v /= 4; }
+    if (v % 2 == 0) { r[n++] = 2; v /= 2; }
+    return v == 1 ? n : -1;
 }
 
-int fft2_lb_log(int q) {
-    // block length 2^lb with h / LB = 4^S1, 4 <= 4^S1 <= 256 (the [G][16] tile of pass 1 must fit
-    // the LDS); 2^11 preferred (32 KiB f64 blocks: four workgroups per CU in pass 2)
-    if (q < 12 || q > 21) return -1;
-    const int order[4] = {11, 10, 12, 13};
-    for (int i = 0; i < 4; ++i) {
-        const int d = q - order[i];
-        if (d >= 2 && d <= 8 && d % 2 == 0) return order[i];
+}  // namespace
+
+// Split h = G * LB: LB (second pass, one block per workgroup) as close to 2048 as the factors
+// allow within [512, 4096], G (rows of the first pass's tile) within [2, 320].
+bool fft2_shape(size_t h, Fft2Shape* sh) {
+    size_t v = h;
+    int a = 0, b = 0;
+    while (v && v % 2 == 0) { v /= 2; ++a; }
+    while (v && v % 5 == 0) { v /= 5; ++b; }
+    if (v != 1 || h < 1024) return false;
+    size_t best = 0;
+    double best_cost = 1e300;
+    for (int a1 = 0; a1 <= a; ++a1) {
+        size_t lb = (size_t)1 << a1;
+        for (int b1 = 0; b1 <= b; ++b1, lb *= 5) {
+            if (lb < 512 || lb > 4096 || lb % 16) continue;
+            if (h % lb) continue;
+            const size_t g = h / lb;
+            if (g < 2 || g > 320) continue;
+            const double cost = fabs(log((double)lb / 2048.0));
+            if (cost < best_cost) { best_cost = cost; best = lb; }
+        }
     }
-    return -1;
+    if (!best) return false;
+    sh->h = h;
+    sh->LB = best;
+    sh->G = (int)(h / best);
+    sh->n1 = radices_of((size_t)sh->G, sh->r1);
+    sh->n2 = radices_of(best, sh->r2);
+    if (sh->n1 < 0 || sh->n2 < 0 || sh->n1 > 8 || sh->n2 > 8) return false;
+    size_t prod = 1;                                  // product of the radices of the earlier stages
+    int rows = sh->G;
+    for (int s = 0; s < sh->n1; ++s) {
+        rows /= sh->r1[s];
+        sh->sub1[s] = rows;
+        sh->mul1[s] = prod;
+        prod *= sh->r1[s];
+    }
+    size_t L = best;
+    for (int s = 0; s < sh->n2; ++s) {
+        sh->sub2[s] = (int)(L / sh->r2[s]);
+        sh->mul2[s] = h / L;
+        L /= sh->r2[s];
+    }
+    return true;
+}
+
+// frequency held by position p after the forward transform: mixed-radix digit reversal
+size_t fft2_kfreq(const Fft2Shape& sh, size_t p) {
+    size_t k = 0, weight = 1, len = sh.h;
+    for (int s = 0; s < sh.n1 + sh.n2; ++s) {
+        const int r = s < sh.n1 ? sh.r1[s] : sh.r2[s - sh.n1];
+        len /= r;
+        k += (p / len) * weight;                      // most significant remaining digit of p
+        p %= len;
+        weight *= r;
+    }
+    return k;
 }
 
 template <typename T>
 static int plan_create_t(tramp_ctx* ctx, Fft2Plan* pl) {
     using C = typename C2<T>::type;
-    const size_t h = (size_t)1 << pl->q;
-    const size_t nhi = h >> 10;
+    const size_t h = pl->shape.h;
+    const size_t nhi = (h + 1023) >> 10;
     TRAMP_HIP_CHECK(ctx, hipMalloc(&pl->tw_hi, nhi * sizeof(C)));
     TRAMP_HIP_CHECK(ctx, hipMalloc(&pl->tw_lo, 1024 * sizeof(C)));
     const unsigned nb = (unsigned)((std::max<size_t>(nhi, 1024) + 255) / 256);
-    hipLaunchKernelGGL((fft_tables_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, pl->q, (C*)pl->tw_hi, (C*)pl->tw_lo);
+    hipLaunchKernelGGL((fft_tables_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, h, nhi, (C*)pl->tw_hi,
+                       (C*)pl->tw_lo);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
 
-int fft2_plan_create(tramp_ctx* ctx, int dtype, int q, Fft2Plan** out) {
-    const int lb = fft2_lb_log(q);
-    if (lb < 0 || q > 30) return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2_plan_create", "length");
+int fft2_plan_create(tramp_ctx* ctx, int dtype, size_t h, Fft2Plan** out) {
     Fft2Plan* pl = new Fft2Plan();
     pl->dtype = dtype;
-    pl->q = q;
-    pl->lb_log = lb;
     pl->tw_hi = pl->tw_lo = nullptr;
+    if (!fft2_shape(h, &pl->shape)) {
+        delete pl;
+        return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2_plan_create", "length is not 2^a 5^b within the two-pass range");
+    }
     int rc = dtype == TRAMP_F64 ? plan_create_t<double>(ctx, pl) : plan_create_t<float>(ctx, pl);
     if (rc) {
         fft2_plan_destroy(pl);
@@ -251,12 +335,10 @@ void fft2_plan_destroy(Fft2Plan* pl) {
 template <typename T>
 static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inverse, const void* in, void* out) {
     using C = typename C2<T>::type;
-    const int q = pl->q, lb = pl->lb_log;
-    const size_t h = (size_t)1 << q, LB = (size_t)1 << lb;
-    const int G = (int)(h >> lb);
+    const Fft2Shape& sh = pl->shape;
     constexpr int kC1 = c1_of<T>();
-    const size_t lds1 = (size_t)G * (kC1 + 1) * sizeof(C), lds2 = LB * sizeof(C);
-    const unsigned g1 = (unsigned)(batch * (LB / kC1)), g2 = (unsigned)(batch * (h / LB));
+    const size_t lds1 = (size_t)sh.G * (kC1 + 1) * sizeof(C), lds2 = sh.LB * sizeof(C);
+    const unsigned g1 = (unsigned)(batch * (sh.LB / kC1)), g2 = (unsigned)(batch * (sh.h / sh.LB));
     static bool attr_done[4] = {false, false, false, false};
     const int slot = (sizeof(T) == 8 ? 0 : 2) + (inverse ? 1 : 0);
     if (!attr_done[slot]) {
@@ -271,16 +353,16 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024)
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "transform too long for the LDS tile");
     if (!inverse) {
-        hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(256), lds1, ctx->stream, q, lb,
-                           (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo);
-        hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(256), lds2, ctx->stream, q, lb, (C*)out,
+        hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
+                           (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo);
+        hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(256), lds2, ctx->stream, sh, (C*)out,
                            (const C*)pl->tw_hi, (const C*)pl->tw_lo);
     } else {
         // `in` (the permuted spectrum) is overwritten by the block pass
-        hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(256), lds2, ctx->stream, q, lb,
+        hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(256), lds2, ctx->stream, sh,
                            (C*)const_cast<void*>(in), (const C*)pl->tw_hi, (const C*)pl->tw_lo);
-        hipLaunchKernelGGL((fft_strided_kernel<T, true>), dim3(g1), dim3(256), lds1, ctx->stream, q, lb,
-                           (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo);
+        hipLaunchKernelGGL((fft_strided_kernel<T, true>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
+                           (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo);
     }
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
@@ -296,13 +378,13 @@ int fft2_inverse(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, void* spectru
                                   : fft2_run_t<float>(ctx, pl, batch, true, spectrum, out);
 }
 
-// ---------------------------------------------------------------- exported for tests
-extern "C" int tramp_fft_pow2(tramp_ctx* ctx, int dtype, int log2h, size_t batch, int inverse, void* in_d,
-                              void* out_d) {
+// ---------------------------------------------------------------- exported for tests / tools
+extern "C" int tramp_fft_len(tramp_ctx* ctx, int dtype, size_t h, size_t batch, int inverse, void* in_d,
+                             void* out_d) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, in_d && out_d && (dtype == TRAMP_F64 || dtype == TRAMP_F32));
     Fft2Plan* pl = nullptr;
-    int rc = fft2_plan_create(ctx, dtype, log2h, &pl);
+    int rc = fft2_plan_create(ctx, dtype, h, &pl);
     if (rc) return rc;
     rc = inverse ? fft2_inverse(ctx, pl, batch, in_d, out_d) : fft2_forward(ctx, pl, batch, in_d, out_d);
     (void)hipStreamSynchronize(ctx->stream);
@@ -310,22 +392,22 @@ extern "C" int tramp_fft_pow2(tramp_ctx* ctx, int dtype, int log2h, size_t batch
     return rc;
 }
 
-extern "C" int tramp_fft_pow2_order(tramp_ctx* ctx, int log2h, size_t count, unsigned long long* kfreq_h) {
+extern "C" int tramp_fft_order(tramp_ctx* ctx, size_t h, size_t count, unsigned long long* kfreq_h) {
     if (!ctx) return TRAMP_EINVAL;
-    const int lb = fft2_lb_log(log2h);
-    if (lb < 0) return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_fft_pow2_order", "length");
     TRAMP_REQUIRE(ctx, kfreq_h);
-    for (size_t p = 0; p < count; ++p) kfreq_h[p] = fft2_kfreq(log2h, lb, p);
+    Fft2Shape sh;
+    if (!fft2_shape(h, &sh)) return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_fft_order", "length");
+    for (size_t p = 0; p < count; ++p) kfreq_h[p] = fft2_kfreq(sh, p);
     return TRAMP_OK;
 }
 
 // Average time of `reps` forward and of `reps` inverse transforms (HIP events on the context's stream).
-extern "C" int tramp_fft_pow2_bench(tramp_ctx* ctx, int dtype, int log2h, size_t batch, int reps, void* in_d,
-                                    void* out_d, double* ms_fwd, double* ms_inv) {
+extern "C" int tramp_fft_bench(tramp_ctx* ctx, int dtype, size_t h, size_t batch, int reps, void* in_d, void* out_d,
+                               double* ms_fwd, double* ms_inv) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, in_d && out_d && ms_fwd && ms_inv && reps > 0);
     Fft2Plan* pl = nullptr;
-    int rc = fft2_plan_create(ctx, dtype, log2h, &pl);
+    int rc = fft2_plan_create(ctx, dtype, h, &pl);
     if (rc) return rc;
     hipEvent_t e0, e1, e2;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2);
