@@ -235,4 +235,9 @@ def test_conv_own_fft_engine_matches_oracle(ctx, dtype, n):
         ep.iterate(max_iter=6, callback=T.PassCallback(), damping=d)
         fs = [orc.GBPriorFactor(n, rho=rho), orc.ConvFactor(f), orc.GaussLikFactor(y, nv)]
         ref = orc.ep_chain(fs, [n, n], max_iter=6, damping=d, tol=0.0)
-        close(np.asarray(ep.get_variables_data()["x"]["r"]).reshape(n), ref["r"][0], 1e-6)
+        r_eager = np.asarray(ep.get_variables_data()["x"]["r"]).reshape(n)
+        close(r_eager, ref["r"][0], 1e-6)
+        # the own transforms capture into a hipGraph like any other launch: replay == eager, bit for bit
+        ep2 = T.ExpectationPropagation(model, ctx=ctx)
+        ep2.iterate(max_iter=6, callback=T.PassCallback(), damping=d, graph=True)
+        assert np.array_equal(np.asarray(ep2.get_variables_data()["x"]["r"]).reshape(n), r_eager)
