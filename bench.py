@@ -103,6 +103,62 @@ def cpu_baseline(args):
     return out
 
 
+def denoiser_roofline(T, ctx, dtype):
+    """Gauss-Bernoulli denoiser (K1) at the BASELINE vector size N = 1e6: single instance
+    (latency regime, data stays in cache) and a 64-instance ensemble (512 MB per array, past
+    the 256 MB Infinity Cache); plus 4096 instances of n = 4096, where an instance fits one
+    workgroup's registers and the update is a single pass.  Algorithmic traffic 2T bytes per component."""
+    out = {}
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    for B, N in ((1, 1_000_000), (64, 1_000_000), (4096, 4096)):
+        bx = ctx.randn((B, N), np_dt, seed=3, scale=1.5)
+        ax = ctx.scalars(1.3, B)
+        p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
+        a_new = ctx.empty((B,), np.float64)
+        b_new = ctx.empty((B, N), np_dt)
+        for _ in range(3):
+            p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)
+        reps = 50 if B == 1 else 10
+        e0, e1 = ctx.event(), ctx.event()
+        e0.record()
+        for _ in range(reps):
+            p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)
+        e1.record()
+        ms = e0.elapsed_ms(e1) / reps
+        alg = 2 * np.dtype(np_dt).itemsize * N * B
+        out[f"B{B}" if N == 1_000_000 else f"B{B}_n{N}"] = {"n": N, "batch": B, "us_per_update": ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
+                        "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
+                        "components_per_sec": N * B / (ms * 1e-3)}
+        del bx, b_new
+    return out
+
+
+def structured_n1e6(T, ctx, dtype):
+    """EP at BASELINE's literal vector size N = 10^6 with a matrix-free operator (dense W cannot exist
+    there): sparse deconvolution GaussBernoulli -> ConvChannel(dense random circulant filter) -> Gaussian
+    likelihood, 64 instances, on the hand-written two-pass FFT.  An auxiliary figure, never `value`."""
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    n, B, rho, nv = 1_000_000, 64, 0.05, 1e-3
+    rs = np.random.RandomState(3)
+    ch = T.ConvChannel(rs.randn(n) / np.sqrt(n), dtype=np_dt, ctx=ctx)
+    X = (rs.standard_normal((B, n)) * rs.binomial(1, rho, (B, n))).astype(np_dt)
+    Y = ch.convolve(ctx.array(X, np_dt)).get() + np.sqrt(nv) * rs.standard_normal((B, n)).astype(np_dt)
+    model = (T.GaussBernoulliPrior(size=n, rho=rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x") @ ch
+             @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=Y, var=nv, dtype=np_dt, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    never = 1 << 30
+    ep.iterate(max_iter=3, callback=T.PassCallback(), damping=0.1, check_every=never)
+    ctx.sync()
+    K = 20
+    t0 = time.perf_counter()
+    ep.iterate(max_iter=K, callback=T.PassCallback(), damping=0.1, warm_start=True, check_every=never)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    return {"workload": "sparse deconvolution EP, ConvChannel (circulant, matrix-free), damping 0.1", "n": n, "instances": B,
+            "ms_per_iteration": dt / K * 1e3, "msg_components_per_sec": n * B * K / dt,
+            "mse": float(np.mean(ep.mse("x", X)))}
+
+
 class _Shape:
     "Stand-in for W when the factors are supplied: LinearChannel only reads .shape then."
 
@@ -279,6 +335,10 @@ def run(args):
         }
         if world == 1 and not args.no_denoiser:
             out["denoiser_n1e6"] = denoiser_roofline(T, ctx, args.dtype)
+            try:
+                out["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
+            except Exception as e:                                            # noqa: BLE001
+                out["structured_n1e6"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
