@@ -159,7 +159,17 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
     const C* src = in + tf * h;
     C* dst = out + tf * h;
     const int c = threadIdx.x % kC1, r0 = threadIdx.x / kC1;
-    for (int g = r0; g < G; g += 256 / kC1) tile[g * P + c] = src[(size_t)g * LB + c0 + c];
+    if constexpr (sizeof(T) == 4) {
+        // f32: two complex (16 bytes) per lane on the global side, as in f64
+        const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
+        for (int g = q0; g < G; g += 512 / kC1) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)g * LB + c0 + 2 * c2);
+            tile[g * P + 2 * c2] = C{v.x, v.y};
+            tile[g * P + 2 * c2 + 1] = C{v.z, v.w};
+        }
+    } else {
+        for (int g = r0; g < G; g += 256 / kC1) tile[g * P + c] = src[(size_t)g * LB + c0 + c];
+    }
     __syncthreads();
     for (int st = 0; st < sh.n1; ++st) {
         const int s = INV ? sh.n1 - 1 - st : st;      // DIT runs the stages backwards
@@ -176,7 +186,15 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
         }
         __syncthreads();
     }
-    for (int g = r0; g < G; g += 256 / kC1) dst[(size_t)g * LB + c0 + c] = tile[g * P + c];
+    if constexpr (sizeof(T) == 4) {
+        const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
+        for (int g = q0; g < G; g += 512 / kC1) {
+            const C a = tile[g * P + 2 * c2], b = tile[g * P + 2 * c2 + 1];
+            *reinterpret_cast<float4*>(dst + (size_t)g * LB + c0 + 2 * c2) = float4{a.x, a.y, b.x, b.y};
+        }
+    } else {
+        for (int g = r0; g < G; g += 256 / kC1) dst[(size_t)g * LB + c0 + c] = tile[g * P + c];
+    }
 }
 
 // ---------------------------------------------------------------- pass 2: inside blocks of LB
@@ -189,7 +207,12 @@ __global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C
     C* tile = reinterpret_cast<C*>(smem_raw);
     const int LB = (int)sh.LB;
     C* blk = data + (size_t)blockIdx.x * LB;          // blocks of all transforms are contiguous
-    for (int i = threadIdx.x; i < LB; i += 256) tile[i] = blk[i];
+    if constexpr (sizeof(T) == 4) {
+        for (int i = threadIdx.x; i < LB / 2; i += 256)
+            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(blk)[i];
+    } else {
+        for (int i = threadIdx.x; i < LB; i += 256) tile[i] = blk[i];
+    }
     __syncthreads();
     for (int st = 0; st < sh.n2; ++st) {
         const int s = INV ? sh.n2 - 1 - st : st;
@@ -204,7 +227,12 @@ __global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < LB; i += 256) blk[i] = tile[i];
+    if constexpr (sizeof(T) == 4) {
+        for (int i = threadIdx.x; i < LB / 2; i += 256)
+            reinterpret_cast<float4*>(blk)[i] = reinterpret_cast<const float4*>(tile)[i];
+    } else {
+        for (int i = threadIdx.x; i < LB; i += 256) blk[i] = tile[i];
+    }
 }
 
 template <typename T>
