@@ -60,6 +60,16 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(args):
     """The oracle (NumPy restatement of the reference's path, reference formulation with the
     full SVD) timed on the host cores, on a bounded sample of the same workload."""
@@ -92,7 +102,7 @@ def cpu_baseline(args):
            "sample": f"oracle EP (reference formulation: full SVD, 4 dense mat-vecs per solve), 1 instance, "
                      f"N={N}, alpha={args.alpha}, median of 5 runs of {n_it} iterations ({dt:.2f} s each; "
                      f"+{setup_s:.1f} s SVD setup, untimed), NumPy/OpenBLAS {threads} threads, "
-                     f"{os.cpu_count()} host cores"}
+                     f"{os.cpu_count()} host cores ({_cpu_model()})"}
     try:
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):
