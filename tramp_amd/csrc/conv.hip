@@ -790,6 +790,16 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
         else launch_spectral<float>(ctx, cv, mode, batch, az_d, ax_d);
         TRAMP_LAUNCH_CHECK(ctx);
     }
+    const double* a_in = (dir == TRAMP_FWD) ? ax_d : az_d;
+    const void* b_in = (dir == TRAMP_FWD) ? bx_d : bz_d;
+    if (cv->fft2) {
+        // 4+5. own engine: the inverse transform's last pass applies the message update as it stores
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz * (damping != 0.0 ? 3 : 2) + nh * 2 * esz), 0);
+        Fft2Epi epi{a_in, cv->a_raw, b_in, damping, b_old_d, b_new_d, r_d};
+        rc = fft2_inverse(ctx, cv->fft2, batch, cv->fo, nullptr, &epi);
+        if (rc) return rc;
+        return TRAMP_OK;
+    }
     // 4. back to the signal domain; the mean lands in r_d when asked for, else in b_new_d
     //    (scratch under damping: b_old usually IS b_new and must survive the transform)
     void* mean = r_d ? r_d : (damping != 0.0 ? cv->fr : b_new_d);
@@ -801,8 +811,6 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     // 5. message update (in place on the mean)
     {
         ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (damping != 0.0 ? 4 : 3), 0);
-        const double* a_in = (dir == TRAMP_FWD) ? ax_d : az_d;
-        const void* b_in = (dir == TRAMP_FWD) ? bx_d : bz_d;
         dim3 g(grid_for(n), (unsigned)batch);
         if (cv->dtype == TRAMP_F64)
             hipLaunchKernelGGL((conv_epilogue_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n, a_in, cv->a_raw,

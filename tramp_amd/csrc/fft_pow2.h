@@ -20,6 +20,19 @@ struct Fft2Plan {
     void* tw_lo;  // w_h^i, i < 1024
 };
 
+// Optional message-update epilogue of the inverse transform (the convolution channel's
+//   b_new = r (a_in + a_raw) - b_in, constant damping against b_old, optional copy of r):
+// applied to the real pairs as the last pass stores them, instead of a separate streaming kernel.
+struct Fft2Epi {
+    const double* a_in;   // [batch]
+    const double* a_raw;  // [batch]
+    const void* b_in;     // [batch, 2 h] reals
+    double damping;
+    const void* b_old;    // may alias out
+    void* out;            // [batch, 2 h]; null: no epilogue (plain store)
+    void* r_out;          // optional
+};
+
 // false when h is not 2^a 5^b or does not split into a [G <= 320] x [512 <= LB <= 4096] pair
 bool fft2_shape(size_t h, Fft2Shape* sh);
 // frequency held by position p of a forward-transformed array
@@ -29,4 +42,5 @@ void fft2_plan_destroy(Fft2Plan* pl);
 // natural order -> permuted spectrum (out of place; in and out may coincide)
 int fft2_forward(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, const void* in, void* out);
 // permuted spectrum (overwritten) -> natural order, unnormalised (x h)
-int fft2_inverse(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, void* spectrum, void* out);
+int fft2_inverse(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, void* spectrum, void* out,
+                 const Fft2Epi* epi = nullptr);

@@ -141,11 +141,12 @@ __device__ __forceinline__ void bfly_at(C* tile, int i0, int stride, int r, C w1
 template <typename T> constexpr int c1_of() { return 128 / (2 * (int)sizeof(T)); }
 
 // ---------------------------------------------------------------- pass 1: strided stages
-template <typename T, bool INV>
+template <typename T, bool INV, bool EPI = false>
 __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const typename C2<T>::type* __restrict__ in,
                                                           typename C2<T>::type* __restrict__ out,
                                                           const typename C2<T>::type* __restrict__ tw_hi,
-                                                          const typename C2<T>::type* __restrict__ tw_lo) {
+                                                          const typename C2<T>::type* __restrict__ tw_lo,
+                                                          Fft2Epi epi = Fft2Epi{}) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
@@ -185,6 +186,28 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
             bfly_at<C, INV>(tile, g0 * P + c, sg * P, r, w1);
         }
         __syncthreads();
+    }
+    if constexpr (EPI) {
+        // message update on the way out: the complex value is the pair (r[2 i], r[2 i + 1]) of the mean
+        const T asum = (T)(epi.a_in[tf] + epi.a_raw[tf]);
+        const T d = (T)epi.damping, omd = (T)(1.0 - epi.damping);
+        const C* bin = reinterpret_cast<const C*>(epi.b_in) + tf * h;
+        const C* bold = epi.damping != 0.0 ? reinterpret_cast<const C*>(epi.b_old) + tf * h : nullptr;
+        C* bo = reinterpret_cast<C*>(epi.out) + tf * h;
+        C* ro = epi.r_out ? reinterpret_cast<C*>(epi.r_out) + tf * h : nullptr;
+        for (int g = r0; g < G; g += 256 / kC1) {
+            const size_t i = (size_t)g * LB + c0 + c;
+            const C r = tile[g * P + c], bi = bin[i];
+            C bn = {r.x * asum - bi.x, r.y * asum - bi.y};
+            if (bold) {
+                const C bp = bold[i];
+                bn.x = d * bp.x + omd * bn.x;
+                bn.y = d * bp.y + omd * bn.y;
+            }
+            bo[i] = bn;
+            if (ro) ro[i] = r;
+        }
+        return;
     }
     if constexpr (sizeof(T) == 4) {
         const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
@@ -361,7 +384,8 @@ void fft2_plan_destroy(Fft2Plan* pl) {
 }
 
 template <typename T>
-static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inverse, const void* in, void* out) {
+static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inverse, const void* in, void* out,
+                      const Fft2Epi* epi = nullptr) {
     using C = typename C2<T>::type;
     const Fft2Shape& sh = pl->shape;
     constexpr int kC1 = c1_of<T>();
@@ -374,6 +398,9 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
                                  : reinterpret_cast<const void*>(fft_strided_kernel<T, false>);
         const void* f2 = inverse ? reinterpret_cast<const void*>(fft_block_kernel<T, true>)
                                  : reinterpret_cast<const void*>(fft_block_kernel<T, false>);
+        if (inverse)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fft_strided_kernel<T, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done[slot] = true;
@@ -382,15 +409,19 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "transform too long for the LDS tile");
     if (!inverse) {
         hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
-                           (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo);
+                           (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, Fft2Epi{});
         hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(256), lds2, ctx->stream, sh, (C*)out,
                            (const C*)pl->tw_hi, (const C*)pl->tw_lo);
     } else {
         // `in` (the permuted spectrum) is overwritten by the block pass
         hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(256), lds2, ctx->stream, sh,
                            (C*)const_cast<void*>(in), (const C*)pl->tw_hi, (const C*)pl->tw_lo);
-        hipLaunchKernelGGL((fft_strided_kernel<T, true>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
-                           (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo);
+        if (epi && epi->out)
+            hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(256), lds1, ctx->stream, sh,
+                               (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, *epi);
+        else
+            hipLaunchKernelGGL((fft_strided_kernel<T, true>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
+                               (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, Fft2Epi{});
     }
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
@@ -401,9 +432,9 @@ int fft2_forward(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, const void* i
                                   : fft2_run_t<float>(ctx, pl, batch, false, in, out);
 }
 
-int fft2_inverse(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, void* spectrum, void* out) {
-    return pl->dtype == TRAMP_F64 ? fft2_run_t<double>(ctx, pl, batch, true, spectrum, out)
-                                  : fft2_run_t<float>(ctx, pl, batch, true, spectrum, out);
+int fft2_inverse(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, void* spectrum, void* out, const Fft2Epi* epi) {
+    return pl->dtype == TRAMP_F64 ? fft2_run_t<double>(ctx, pl, batch, true, spectrum, out, epi)
+                                  : fft2_run_t<float>(ctx, pl, batch, true, spectrum, out, epi);
 }
 
 // ---------------------------------------------------------------- exported for tests / tools
