@@ -11,6 +11,10 @@ struct Fft2Shape {
     size_t mul1[8];
     int n2, r2[8], sub2[8];
     size_t mul2[8];
+    // twiddles staged in LDS: per stage one entry per leg offset (pass 2: sub2[s] entries, the same for
+    // every block, kept as a table in global memory; pass 1: sub1[s] rows x one line of columns per tile)
+    int off1[8], ntw1;    // in rows (multiply by the columns per tile)
+    int off2[8], ntw2;
 };
 
 struct Fft2Plan {
@@ -18,6 +22,7 @@ struct Fft2Plan {
     Fft2Shape shape;
     void* tw_hi;  // w_h^(1024 i)
     void* tw_lo;  // w_h^i, i < 1024
+    void* tw_blk; // pass 2 stage twiddles w_h^(m mul2[s]) at off2[s] + m
 };
 
 // Optional message-update epilogue of the inverse transform (the convolution channel's

@@ -171,19 +171,27 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
     } else {
         for (int g = r0; g < G; g += 256 / kC1) tile[g * P + c] = src[(size_t)g * LB + c0 + c];
     }
+    // this tile's twiddles (one per stage, leg offset and column) go to LDS while the tile loads are in
+    // flight: the stage loops then never wait on global memory
+    C* twl = tile + (size_t)G * P;
+    for (int s = 0; s < sh.n1; ++s) {
+        const size_t mulh = sh.mul1[s];               // w_L^m = w_h^(m * prod of the earlier radices)
+        for (int bl = r0; bl < sh.sub1[s]; bl += 256 / kC1) {
+            const size_t m = (size_t)bl * LB + c0 + c;                 // position inside the sub-block; m mulh < h
+            twl[(sh.off1[s] + bl) * kC1 + c] = twiddle<C>(tw_hi, tw_lo, m * mulh);
+        }
+    }
     __syncthreads();
     for (int st = 0; st < sh.n1; ++st) {
         const int s = INV ? sh.n1 - 1 - st : st;      // DIT runs the stages backwards
         const int r = sh.r1[s];
         const int sg = sh.sub1[s];                    // stride between the legs, in rows
-        const size_t mulh = sh.mul1[s];               // w_L^m = w_h^(m * prod of the earlier radices)
         const int nb = G / r;                         // butterflies per column
+        const C* tws = twl + sh.off1[s] * kC1;
         for (int b = r0; b < nb; b += 256 / kC1) {
             const int bl = b % sg, bh = b / sg;
             const int g0 = bh * r * sg + bl;
-            const size_t m = (size_t)bl * LB + c0 + c;                 // position inside the sub-block
-            const C w1 = twiddle<C>(tw_hi, tw_lo, m * mulh);          // m < L / r, so the exponent stays below h
-            bfly_at<C, INV>(tile, g0 * P + c, sg * P, r, w1);
+            bfly_at<C, INV>(tile, g0 * P + c, sg * P, r, tws[bl * kC1 + c]);
         }
         __syncthreads();
     }
@@ -223,8 +231,7 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
 // ---------------------------------------------------------------- pass 2: inside blocks of LB
 template <typename T, bool INV>
 __global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C2<T>::type* __restrict__ data,
-                                                        const typename C2<T>::type* __restrict__ tw_hi,
-                                                        const typename C2<T>::type* __restrict__ tw_lo) {
+                                                        const typename C2<T>::type* __restrict__ tw_blk) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
@@ -236,17 +243,19 @@ __global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C
     } else {
         for (int i = threadIdx.x; i < LB; i += 256) tile[i] = blk[i];
     }
+    // the stage twiddles are the same for every block: a small table, copied to LDS beside the tile
+    C* twl = tile + LB;
+    for (int i = threadIdx.x; i < sh.ntw2; i += 256) twl[i] = tw_blk[i];
     __syncthreads();
     for (int st = 0; st < sh.n2; ++st) {
         const int s = INV ? sh.n2 - 1 - st : st;
         const int r = sh.r2[s];
         const int sub = sh.sub2[s];                   // L / r, L the current sub-length
-        const size_t mulh = sh.mul2[s];               // h / L
         const int L = sub * r;
+        const C* tws = twl + sh.off2[s];
         for (int b = threadIdx.x; b < LB / r; b += 256) {
             const int m = b % sub, base = (b / sub) * L + m;
-            const C w1 = twiddle<C>(tw_hi, tw_lo, (size_t)m * mulh);
-            bfly_at<C, INV>(tile, base, sub, r, w1);
+            bfly_at<C, INV>(tile, base, sub, r, tws[m]);
         }
         __syncthreads();
     }
@@ -256,6 +265,19 @@ __global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C
     } else {
         for (int i = threadIdx.x; i < LB; i += 256) blk[i] = tile[i];
     }
+}
+
+template <typename T>
+__global__ void fft_blk_table_kernel(Fft2Shape sh, typename C2<T>::type* tw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh.ntw2) return;
+    int s = 0;
+    while (s + 1 < sh.n2 && i >= sh.off2[s + 1]) ++s;
+    const size_t e = (size_t)(i - sh.off2[s]) * sh.mul2[s];
+    double sn, cs;
+    sincospi(-2.0 * (double)e / (double)sh.h, &sn, &cs);
+    tw[i].x = (T)cs;
+    tw[i].y = (T)sn;
 }
 
 template <typename T>
@@ -329,6 +351,9 @@ bool fft2_shape(size_t h, Fft2Shape* sh) {
         sh->mul2[s] = h / L;
         L /= sh->r2[s];
     }
+    sh->ntw1 = sh->ntw2 = 0;
+    for (int s = 0; s < sh->n1; ++s) { sh->off1[s] = sh->ntw1; sh->ntw1 += sh->sub1[s]; }
+    for (int s = 0; s < sh->n2; ++s) { sh->off2[s] = sh->ntw2; sh->ntw2 += sh->sub2[s]; }
     return true;
 }
 
@@ -355,6 +380,9 @@ static int plan_create_t(tramp_ctx* ctx, Fft2Plan* pl) {
     const unsigned nb = (unsigned)((std::max<size_t>(nhi, 1024) + 255) / 256);
     hipLaunchKernelGGL((fft_tables_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, h, nhi, (C*)pl->tw_hi,
                        (C*)pl->tw_lo);
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&pl->tw_blk, (size_t)pl->shape.ntw2 * sizeof(C)));
+    hipLaunchKernelGGL((fft_blk_table_kernel<T>), dim3((pl->shape.ntw2 + 255) / 256), dim3(256), 0, ctx->stream,
+                       pl->shape, (C*)pl->tw_blk);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
@@ -362,7 +390,7 @@ static int plan_create_t(tramp_ctx* ctx, Fft2Plan* pl) {
 int fft2_plan_create(tramp_ctx* ctx, int dtype, size_t h, Fft2Plan** out) {
     Fft2Plan* pl = new Fft2Plan();
     pl->dtype = dtype;
-    pl->tw_hi = pl->tw_lo = nullptr;
+    pl->tw_hi = pl->tw_lo = pl->tw_blk = nullptr;
     if (!fft2_shape(h, &pl->shape)) {
         delete pl;
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2_plan_create", "length is not 2^a 5^b within the two-pass range");
@@ -380,6 +408,7 @@ void fft2_plan_destroy(Fft2Plan* pl) {
     if (!pl) return;
     if (pl->tw_hi) (void)hipFree(pl->tw_hi);
     if (pl->tw_lo) (void)hipFree(pl->tw_lo);
+    if (pl->tw_blk) (void)hipFree(pl->tw_blk);
     delete pl;
 }
 
@@ -389,7 +418,8 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
     using C = typename C2<T>::type;
     const Fft2Shape& sh = pl->shape;
     constexpr int kC1 = c1_of<T>();
-    const size_t lds1 = (size_t)sh.G * (kC1 + 1) * sizeof(C), lds2 = sh.LB * sizeof(C);
+    const size_t lds1 = ((size_t)sh.G * (kC1 + 1) + (size_t)sh.ntw1 * kC1) * sizeof(C);
+    const size_t lds2 = (sh.LB + (size_t)sh.ntw2) * sizeof(C);
     const unsigned g1 = (unsigned)(batch * (sh.LB / kC1)), g2 = (unsigned)(batch * (sh.h / sh.LB));
     static bool attr_done[4] = {false, false, false, false};
     const int slot = (sizeof(T) == 8 ? 0 : 2) + (inverse ? 1 : 0);
@@ -411,11 +441,11 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
         hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
                            (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, Fft2Epi{});
         hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(256), lds2, ctx->stream, sh, (C*)out,
-                           (const C*)pl->tw_hi, (const C*)pl->tw_lo);
+                           (const C*)pl->tw_blk);
     } else {
         // `in` (the permuted spectrum) is overwritten by the block pass
         hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(256), lds2, ctx->stream, sh,
-                           (C*)const_cast<void*>(in), (const C*)pl->tw_hi, (const C*)pl->tw_lo);
+                           (C*)const_cast<void*>(in), (const C*)pl->tw_blk);
         if (epi && epi->out)
             hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(256), lds1, ctx->stream, sh,
                                (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, *epi);
