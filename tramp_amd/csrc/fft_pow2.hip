@@ -136,9 +136,12 @@ __device__ __forceinline__ void bfly_at(C* tile, int i0, int stride, int r, C w1
     }
 }
 
+#ifndef FFT_LINE
+#define FFT_LINE 128
+#endif
 // tile [G][C] (+1 complex of padding per row), G rows LB apart, C offsets = one 128-byte line per
 // row (8 f64 / 16 f32 complex)
-template <typename T> constexpr int c1_of() { return 128 / (2 * (int)sizeof(T)); }
+template <typename T> constexpr int c1_of() { return FFT_LINE / (2 * (int)sizeof(T)); }
 
 // ---------------------------------------------------------------- pass 1: strided stages
 template <typename T, bool INV, bool EPI = false>
