@@ -241,3 +241,25 @@ def test_conv_own_fft_engine_matches_oracle(ctx, dtype, n):
         ep2 = T.ExpectationPropagation(model, ctx=ctx)
         ep2.iterate(max_iter=6, callback=T.PassCallback(), damping=d, graph=True)
         assert np.array_equal(np.asarray(ep2.get_variables_data()["x"]["r"]).reshape(n), r_eager)
+
+
+def test_conv_state_evolution_matches_oracle(ctx):
+    """SE of the deconvolution model: the channel's errors are its posterior variances (conv_channel.py:137-143),
+    evaluated by the device n_eff reduction; the prior's by the device quadrature."""
+    import tramp_amd as T
+    rs = np.random.RandomState(4)
+    f = rs.randn(4096) / 64
+    rho, nv = 0.1, 1e-2
+    model = (T.GaussBernoulliPrior(size=None, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.ConvChannel(f, ctx=ctx) @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=None, var=nv, ctx=ctx)).to_model()
+    se = T.StateEvolution(model)
+    recs = []
+    se.iterate(max_iter=12, callback=lambda a, i, m: recs.append(a.get_variables_data()) and False)
+    fs = [orc.GBPriorFactor(None, rho=rho), orc.ConvFactor(f), orc.GaussLikFactor(None, nv)]
+    ref = []
+    orc.se_chain(fs, max_iter=12, tol=0.0, method="gl", record=lambda it, fwd, bwd, vs: ref.append(list(vs)))
+    assert len(recs) == len(ref) == 12
+    for it in range(12):
+        close(recs[it]["x"]["v"], ref[it][0], 1e-5)
+        close(recs[it]["z"]["v"], ref[it][1], 1e-5)
