@@ -209,22 +209,28 @@ __global__ __launch_bounds__(kBlock) void conv_neff_partial_kernel(const double*
     if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = s;
 }
 
-__global__ void conv_variance_kernel(const double* __restrict__ partial, int nblk, double n, double s_mean, int dir,
-                                     const double* __restrict__ az_d, const double* __restrict__ ax_d,
-                                     double damping, const double* __restrict__ a_old, double* __restrict__ v_out,
-                                     double* __restrict__ a_new_out, double* __restrict__ a_new_raw,
-                                     double* __restrict__ n_eff_out, size_t batch) {
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
+__global__ __launch_bounds__(kWave) void conv_variance_kernel(const double* __restrict__ partial, int nblk,
+                                                              double n, double s_mean, int dir,
+                                                              const double* __restrict__ az_d,
+                                                              const double* __restrict__ ax_d, double damping,
+                                                              const double* __restrict__ a_old,
+                                                              double* __restrict__ v_out, double* __restrict__ a_new_out,
+                                                              double* __restrict__ a_new_raw,
+                                                              double* __restrict__ n_eff_out, size_t batch) {
+    // one wave per instance: lanes fold the partial sums (fixed assignment and tree -> deterministic)
+    const size_t b = blockIdx.x;
     const double az = az_d[b], ax = ax_d[b];
     double n_eff;
     if (ax == 0.0) n_eff = 0.0;                                        // :71-73
     else if (az / ax == 0.0) n_eff = 1.0;                              // :74-76
     else {
         double s = 0.0;
-        for (int j = 0; j < nblk; ++j) s += partial[b * nblk + j];
+        for (int j = threadIdx.x; j < nblk; j += kWave) s += partial[b * nblk + j];
+        s = wave_sum(s);
+        s = __shfl(s, 0, kWave);
         n_eff = s / n;                                                 // :77-78
     }
+    if (threadIdx.x != 0) return;
     double v, a_in;
     if (dir == TRAMP_FWD) {
         v = (ax == 0.0) ? s_mean / az : n_eff / ax;                    // :117-123
@@ -411,7 +417,7 @@ int conv_scalars(tramp_ctx* ctx, const tramp_conv* cv, double* partial, int dir,
                  double* a_raw, double* n_eff_d) {
     hipLaunchKernelGGL(conv_neff_partial_kernel, dim3((unsigned)cv->nblk, (unsigned)batch), dim3(kBlock), 0,
                        ctx->stream, cv->s2, cv->nh, cv->nhl, cv->nlast, az_d, ax_d, partial);
-    hipLaunchKernelGGL(conv_variance_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, partial,
+    hipLaunchKernelGGL(conv_variance_kernel, dim3((unsigned)batch), dim3(kWave), 0, ctx->stream, partial,
                        cv->nblk, (double)cv->n, cv->s_mean, dir, az_d, ax_d, damping, a_old, v_d, a_new_d, a_raw,
                        n_eff_d, batch);
     TRAMP_LAUNCH_CHECK(ctx);
