@@ -148,3 +148,26 @@ def test_no_undefined_names_in_entry_points():
                 bound.update(node.names)
         missing = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)} - bound)
         assert not missing, f"{os.path.relpath(path, root)}: names read but never bound: {missing}"
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/tramp_hip.h is a C header (no C++, no torch types): a C99 program compiled with gcc
+    -pedantic links against the shared library and calls it."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "consumer.c"
+    src.write_text('#include "tramp_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { int n = -1; int rc = tramp_device_count(&n);\n'
+                   '  tramp_ctx* ctx = NULL; int rc2 = tramp_sync(ctx);\n'
+                   '  printf("%s|%d|%d|%d\\n", tramp_version(), rc, n >= 0, rc2 == TRAMP_EINVAL); return 0; }\n')
+    exe = tmp_path / "consumer"
+    libdir = os.path.join(root, "tramp_amd")
+    res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                          str(src), "-o", str(exe), "-L", libdir, "-ltramp_hip", f"-Wl,-rpath,{libdir}"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    version, rc, n_ok, einval = out.stdout.strip().split("|")
+    assert "gfx950" in version and rc == "0" and n_ok == "1" and einval == "1"
