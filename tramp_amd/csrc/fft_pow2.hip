@@ -145,7 +145,7 @@ template <typename T> constexpr int c1_of() { return FFT_LINE / (2 * (int)sizeof
 
 // ---------------------------------------------------------------- pass 1: strided stages
 template <typename T, bool INV, bool EPI = false>
-__global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const typename C2<T>::type* __restrict__ in,
+__global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const typename C2<T>::type* __restrict__ in,
                                                           typename C2<T>::type* __restrict__ out,
                                                           const typename C2<T>::type* __restrict__ tw_hi,
                                                           const typename C2<T>::type* __restrict__ tw_lo,
@@ -163,23 +163,24 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
     const C* src = in + tf * h;
     C* dst = out + tf * h;
     const int c = threadIdx.x % kC1, r0 = threadIdx.x / kC1;
+    const int rstep = blockDim.x / kC1;               // rows (or butterflies) per sweep of the workgroup
     if constexpr (sizeof(T) == 4) {
         // f32: two complex (16 bytes) per lane on the global side, as in f64
         const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
-        for (int g = q0; g < G; g += 512 / kC1) {
+        for (int g = q0; g < G; g += 2 * rstep) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)g * LB + c0 + 2 * c2);
             tile[g * P + 2 * c2] = C{v.x, v.y};
             tile[g * P + 2 * c2 + 1] = C{v.z, v.w};
         }
     } else {
-        for (int g = r0; g < G; g += 256 / kC1) tile[g * P + c] = src[(size_t)g * LB + c0 + c];
+        for (int g = r0; g < G; g += rstep) tile[g * P + c] = src[(size_t)g * LB + c0 + c];
     }
     // this tile's twiddles (one per stage, leg offset and column) go to LDS while the tile loads are in
     // flight: the stage loops then never wait on global memory
     C* twl = tile + (size_t)G * P;
     for (int s = 0; s < sh.n1; ++s) {
         const size_t mulh = sh.mul1[s];               // w_L^m = w_h^(m * prod of the earlier radices)
-        for (int bl = r0; bl < sh.sub1[s]; bl += 256 / kC1) {
+        for (int bl = r0; bl < sh.sub1[s]; bl += rstep) {
             const size_t m = (size_t)bl * LB + c0 + c;                 // position inside the sub-block; m mulh < h
             twl[(sh.off1[s] + bl) * kC1 + c] = twiddle<C>(tw_hi, tw_lo, m * mulh);
         }
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
         const int sg = sh.sub1[s];                    // stride between the legs, in rows
         const int nb = G / r;                         // butterflies per column
         const C* tws = twl + sh.off1[s] * kC1;
-        for (int b = r0; b < nb; b += 256 / kC1) {
+        for (int b = r0; b < nb; b += rstep) {
             const int bl = b % sg, bh = b / sg;
             const int g0 = bh * r * sg + bl;
             bfly_at<C, INV>(tile, g0 * P + c, sg * P, r, tws[bl * kC1 + c]);
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
         const C* bold = epi.damping != 0.0 ? reinterpret_cast<const C*>(epi.b_old) + tf * h : nullptr;
         C* bo = reinterpret_cast<C*>(epi.out) + tf * h;
         C* ro = epi.r_out ? reinterpret_cast<C*>(epi.r_out) + tf * h : nullptr;
-        for (int g = r0; g < G; g += 256 / kC1) {
+        for (int g = r0; g < G; g += rstep) {
             const size_t i = (size_t)g * LB + c0 + c;
             const C r = tile[g * P + c], bi = bin[i];
             C bn = {r.x * asum - bi.x, r.y * asum - bi.y};
@@ -222,33 +223,34 @@ __global__ __launch_bounds__(256) void fft_strided_kernel(Fft2Shape sh, const ty
     }
     if constexpr (sizeof(T) == 4) {
         const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
-        for (int g = q0; g < G; g += 512 / kC1) {
+        for (int g = q0; g < G; g += 2 * rstep) {
             const C a = tile[g * P + 2 * c2], b = tile[g * P + 2 * c2 + 1];
             *reinterpret_cast<float4*>(dst + (size_t)g * LB + c0 + 2 * c2) = float4{a.x, a.y, b.x, b.y};
         }
     } else {
-        for (int g = r0; g < G; g += 256 / kC1) dst[(size_t)g * LB + c0 + c] = tile[g * P + c];
+        for (int g = r0; g < G; g += rstep) dst[(size_t)g * LB + c0 + c] = tile[g * P + c];
     }
 }
 
 // ---------------------------------------------------------------- pass 2: inside blocks of LB
 template <typename T, bool INV>
-__global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C2<T>::type* __restrict__ data,
+__global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, typename C2<T>::type* __restrict__ data,
                                                         const typename C2<T>::type* __restrict__ tw_blk) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
     const int LB = (int)sh.LB;
+    const int nthr = blockDim.x;                      // 64 ... 256 threads per block (TRAMP_FFT_BLOCK_THREADS)
     C* blk = data + (size_t)blockIdx.x * LB;          // blocks of all transforms are contiguous
     if constexpr (sizeof(T) == 4) {
-        for (int i = threadIdx.x; i < LB / 2; i += 256)
+        for (int i = threadIdx.x; i < LB / 2; i += nthr)
             reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(blk)[i];
     } else {
-        for (int i = threadIdx.x; i < LB; i += 256) tile[i] = blk[i];
+        for (int i = threadIdx.x; i < LB; i += nthr) tile[i] = blk[i];
     }
     // the stage twiddles are the same for every block: a small table, copied to LDS beside the tile
     C* twl = tile + LB;
-    for (int i = threadIdx.x; i < sh.ntw2; i += 256) twl[i] = tw_blk[i];
+    for (int i = threadIdx.x; i < sh.ntw2; i += nthr) twl[i] = tw_blk[i];
     __syncthreads();
     for (int st = 0; st < sh.n2; ++st) {
         const int s = INV ? sh.n2 - 1 - st : st;
@@ -256,17 +258,17 @@ __global__ __launch_bounds__(256) void fft_block_kernel(Fft2Shape sh, typename C
         const int sub = sh.sub2[s];                   // L / r, L the current sub-length
         const int L = sub * r;
         const C* tws = twl + sh.off2[s];
-        for (int b = threadIdx.x; b < LB / r; b += 256) {
+        for (int b = threadIdx.x; b < LB / r; b += nthr) {
             const int m = b % sub, base = (b / sub) * L + m;
             bfly_at<C, INV>(tile, base, sub, r, tws[m]);
         }
         __syncthreads();
     }
     if constexpr (sizeof(T) == 4) {
-        for (int i = threadIdx.x; i < LB / 2; i += 256)
+        for (int i = threadIdx.x; i < LB / 2; i += nthr)
             reinterpret_cast<float4*>(blk)[i] = reinterpret_cast<const float4*>(tile)[i];
     } else {
-        for (int i = threadIdx.x; i < LB; i += 256) blk[i] = tile[i];
+        for (int i = threadIdx.x; i < LB; i += nthr) blk[i] = tile[i];
     }
 }
 
@@ -424,6 +426,12 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
     const size_t lds1 = ((size_t)sh.G * (kC1 + 1) + (size_t)sh.ntw1 * kC1) * sizeof(C);
     const size_t lds2 = (sh.LB + (size_t)sh.ntw2) * sizeof(C);
     const unsigned g1 = (unsigned)(batch * (sh.LB / kC1)), g2 = (unsigned)(batch * (sh.h / sh.LB));
+    // threads per workgroup, measured at 64 x 5 10^5: f64 0.56 ms with 512 / 512 against 0.63 with 256 / 256
+    // (more butterflies in flight per LDS tile); f32 is best at 256 / 256
+    static const int env_blk = getenv("TRAMP_FFT_BLOCK_THREADS") ? atoi(getenv("TRAMP_FFT_BLOCK_THREADS")) : 0;
+    static const int env_str = getenv("TRAMP_FFT_STRIDED_THREADS") ? atoi(getenv("TRAMP_FFT_STRIDED_THREADS")) : 0;
+    const int blk_threads = env_blk ? env_blk : (sizeof(T) == 8 ? 512 : 256);
+    const int str_threads = env_str ? env_str : (sizeof(T) == 8 ? 512 : 256);
     static bool attr_done[4] = {false, false, false, false};
     const int slot = (sizeof(T) == 8 ? 0 : 2) + (inverse ? 1 : 0);
     if (!attr_done[slot]) {
@@ -441,19 +449,19 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024)
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "transform too long for the LDS tile");
     if (!inverse) {
-        hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
+        hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh, (const C*)in,
                            (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, Fft2Epi{});
-        hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(256), lds2, ctx->stream, sh, (C*)out,
+        hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh, (C*)out,
                            (const C*)pl->tw_blk);
     } else {
         // `in` (the permuted spectrum) is overwritten by the block pass
-        hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(256), lds2, ctx->stream, sh,
+        hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh,
                            (C*)const_cast<void*>(in), (const C*)pl->tw_blk);
         if (epi && epi->out)
-            hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(256), lds1, ctx->stream, sh,
+            hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh,
                                (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, *epi);
         else
-            hipLaunchKernelGGL((fft_strided_kernel<T, true>), dim3(g1), dim3(256), lds1, ctx->stream, sh, (const C*)in,
+            hipLaunchKernelGGL((fft_strided_kernel<T, true>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh, (const C*)in,
                                (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, Fft2Epi{});
     }
     TRAMP_LAUNCH_CHECK(ctx);
