@@ -291,25 +291,9 @@ class ExpectationPropagation:
             self.r.append(ctx.zeros((B, n), self.dtype))
         for buf in self.b_fwd + self.b_bwd:
             buf.version = 0
-        self._scratch = {}
-        self._const_b = {}
+        self._const_msg = {}
         self._const_done = set()
         self._allocated = True
-
-    def _const_b_for(self, i, direction, sb):
-        "Keeps the constant part c of a damped constant message (sb is overwritten by the damped result)."
-        key = (i, direction)
-        if key not in self._const_b:
-            self._const_b[key] = self.ctx.empty(tuple(sb.shape), self.dtype)
-            self._const_b[key].copy_from(sb)
-        return self._const_b[key]
-
-    def _scratch_for(self, i):
-        if i not in self._scratch:
-            n = self.b_fwd[i].shape[1]
-            self._scratch[i] = (self.ctx.empty((self.batch,), np.float64),
-                                self.ctx.empty((self.batch, n), self.dtype))
-        return self._scratch[i]
 
     def init_message_dag(self, initializer):
         "message_passing.py:211-232"
@@ -334,12 +318,34 @@ class ExpectationPropagation:
         const = isinstance(factor, (GaussianPrior, GaussianLikelihood))
         if const and not d and (factor, direction) in self._const_done:
             return          # undamped constant message: already in place, bit-identical every iteration
+        if const and d:
+            # Constant factor under damping: msg <- d msg + (1 - d) c with the same (c_a, c_b) every
+            # iteration (K12).  c is computed once; the update is ONE in-place kernel - tramp_damp with
+            # the roles swapped, (1 - d) c + d msg, the same products and sum, so the same bits.
+            key = (i_out, direction)
+            if key not in self._const_msg:
+                ca = self.ctx.empty((self.batch,), np.float64)
+                cb = self.ctx.empty(tuple(out_b.shape), self.dtype)
+                if factor.n_prev == 0:
+                    factor.compute_forward_message(self.a_bwd[i_out], self.b_bwd[i_out], out_a=ca, out_b=cb)
+                else:
+                    factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out], out_a=ca, out_b=cb)
+                self._const_msg[key] = (ca, cb)
+            ca, cb = self._const_msg[key]
+            old_key = (out_b.ptr, out_b.version, self.batch)
+            self.ctx._call("tramp_damp", dtype_code(self.dtype), out_b.shape[1], self.batch, 1.0 - float(d),
+                           ca.ptr, cb.ptr, out_a.ptr, out_b.ptr)
+            out_b.version += 1
+            # the consumer's cached projection of this message follows by linearity (O(k), no matrix pass)
+            var = self.variables[i_out]
+            consumer = self.model.prev_factor(var) if direction == "bwd" else self.model.next_factor(var)
+            if hasattr(consumer, "affine_update"):
+                consumer.affine_update("x" if direction == "bwd" else "z", old_key, out_b, cb, float(d),
+                                       token=(id(factor), direction))
+            return
         kw = dict(out_a=out_a, out_b=out_b)
-        if d and not const:
+        if d:
             kw.update(damping=d, old_a=out_a, old_b=out_b)
-        if d and const:
-            sa, sb = self._scratch_for(i_out)
-            kw = dict(out_a=sa, out_b=sb)
         if factor.n_prev == 0:
             factor.compute_forward_message(self.a_bwd[i_out], self.b_bwd[i_out], **kw)
         elif factor.n_next == 0:
@@ -350,23 +356,7 @@ class ExpectationPropagation:
         else:
             factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out],
                                             self.a_bwd[i_in], self.b_bwd[i_in], **kw)
-        old_key = (out_b.ptr, out_b.version, self.batch)
-        if d and const:
-            # msg = d * msg + (1 - d) * const    (K12)
-            n = out_b.shape[1]
-            const_b = self._const_b_for(i_out, direction, sb)       # before sb is damped in place
-            self.ctx._call("tramp_damp", dtype_code(self.dtype), n, self.batch, float(d), out_a.ptr,
-                           out_b.ptr, sa.ptr, sb.ptr)
-            out_a.copy_from(sa)
-            out_b.copy_from(sb)
         out_b.version += 1          # consumers (LinearChannel projection cache) see a new message
-        if d and const:
-            # the consumer's cached projection of this message follows by linearity (O(k), no matrix pass)
-            var = self.variables[i_out]
-            consumer = self.model.prev_factor(var) if direction == "bwd" else self.model.next_factor(var)
-            if hasattr(consumer, "affine_update"):
-                consumer.affine_update("x" if direction == "bwd" else "z", old_key, out_b, const_b, float(d),
-                                       token=(id(factor), direction))
         if const and not d:
             self._const_done.add((factor, direction))
 
