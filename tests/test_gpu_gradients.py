@@ -1,0 +1,91 @@
+"""Moment / log-partition consistency of the device factors, the way the reference's own unit tests
+check its modules (tramp/tests/test_priors.py:57-69 `test_prior_grad_EP_scalar`,
+tramp/tests/test_likelihoods.py:86-92, tramp/checks/check_gradients.py): the posterior a factor
+returns is the gradient of its own log-partition,
+
+    r = dA/db,   v = d2A/db2,   tau = r^2 + v = -2 dA/da      (MAP priors: q = r^2 = -2 dA/da),
+
+here with both sides computed on the GPU through the C ABI (central differences of
+`compute_log_partition` against `compute_*_posterior`).  One-component factors, one (a, b) point
+per ensemble instance, so a whole grid is a single launch.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H = 1e-4            # central-difference step: truncation ~ h^2, rounding ~ eps / h^2
+TOL = 2e-6
+
+
+def grid(seed, n_pts, b_scale=3.0):
+    rs = np.random.RandomState(seed)
+    a = rs.uniform(0.3, 4.0, n_pts)
+    b = rs.uniform(-b_scale, b_scale, (n_pts, 1))
+    return a, b
+
+
+def d1(f, x, h):
+    return (f(x + h) - f(x - h)) / (2 * h)
+
+
+def d2(f, x, h):
+    return (f(x + h) - 2 * f(x) + f(x - h)) / h**2
+
+
+def prior_cases(T, ctx):
+    kw = dict(size=1, ctx=ctx)
+    return [("gb", T.GaussBernoulliPrior(rho=0.3, mean=0.4, var=1.3, **kw), False),
+            ("gauss", T.GaussianPrior(mean=-0.2, var=0.7, **kw), False),
+            ("l1", T.MAP_L1NormPrior(gamma=0.8, **kw), True)]
+
+
+def test_prior_posterior_is_gradient_of_log_partition(ctx):
+    import tramp_amd as T
+    a, b = grid(1, 257)
+    for name, prior, is_map in prior_cases(T, ctx):
+        if is_map:                                   # keep clear of the soft-threshold kinks |b| = gamma
+            b = np.where(np.abs(np.abs(b) - 0.8) < 0.05, b + 0.2 * np.sign(b), b)
+        r, v = prior.compute_forward_posterior(a, b)
+        A_b = lambda bb: np.asarray(prior.compute_log_partition(a, bb))            # noqa: E731
+        A_a = lambda aa: np.asarray(prior.compute_log_partition(aa, b))            # noqa: E731
+        np.testing.assert_allclose(d1(A_b, b, H), r[:, 0], rtol=2e-6, atol=TOL, err_msg=name + ": r = dA/db")
+        np.testing.assert_allclose(d2(A_b, b, H), v, rtol=2e-6, atol=20 * TOL, err_msg=name + ": v = d2A/db2")
+        second = r[:, 0] ** 2 if is_map else r[:, 0] ** 2 + v
+        np.testing.assert_allclose(-2 * d1(A_a, a, H), second, rtol=2e-6, atol=TOL, err_msg=name + ": -2 dA/da")
+
+
+def test_likelihood_posterior_is_gradient_of_log_partition(ctx):
+    import tramp_amd as T
+    a, b = grid(2, 193)
+    rs = np.random.RandomState(3)
+    y_g = rs.randn(a.size, 1)
+    y_s = np.sign(rs.randn(a.size, 1))
+    y_a = np.abs(rs.randn(a.size, 1)) + 0.1
+    for name, lik, y in (("gaussian", T.GaussianLikelihood(y=y_g, var=0.4, ctx=ctx), y_g),
+                         ("sgn", T.SgnLikelihood(y=y_s, ctx=ctx), y_s),
+                         ("abs", T.AbsLikelihood(y=y_a, ctx=ctx), y_a)):
+        r, v = lik.compute_backward_posterior(a, b, y)
+        A_b = lambda bb: np.asarray(lik.compute_log_partition(a, bb, y))            # noqa: E731
+        A_a = lambda aa: np.asarray(lik.compute_log_partition(aa, b, y))            # noqa: E731
+        np.testing.assert_allclose(d1(A_b, b, H), r[:, 0], rtol=2e-6, atol=TOL, err_msg=name + ": r = dA/db")
+        np.testing.assert_allclose(d2(A_b, b, H), v, rtol=2e-6, atol=20 * TOL, err_msg=name + ": v = d2A/db2")
+        np.testing.assert_allclose(-2 * d1(A_a, a, H), r[:, 0] ** 2 + v, rtol=2e-6, atol=TOL,
+                                   err_msg=name + ": -2 dA/da")
+
+
+@pytest.mark.parametrize("name", ["sgn", "abs", "relu"])
+def test_channel_posteriors_are_gradients_of_log_partition(ctx, name):
+    import tramp_amd as T
+    ch = {"sgn": T.SgnChannel, "abs": T.AbsChannel, "relu": T.ReluChannel}[name](ctx=ctx)
+    az, bz = grid(4, 161, 2.0)
+    ax, bx = grid(5, 161, 2.0)
+    rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+    rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+    A = lambda az_, bz_, ax_, bx_: np.asarray(ch.compute_log_partition(az_, bz_, ax_, bx_))      # noqa: E731
+    np.testing.assert_allclose(d1(lambda t: A(az, t, ax, bx), bz, H), rz[:, 0], rtol=2e-6, atol=TOL)
+    np.testing.assert_allclose(d1(lambda t: A(az, bz, ax, t), bx, H), rx[:, 0], rtol=2e-6, atol=TOL)
+    np.testing.assert_allclose(d2(lambda t: A(az, t, ax, bx), bz, H), vz, rtol=2e-6, atol=20 * TOL)
+    np.testing.assert_allclose(d2(lambda t: A(az, bz, ax, t), bx, H), vx, rtol=2e-6, atol=20 * TOL)
+    np.testing.assert_allclose(-2 * d1(lambda t: A(t, bz, ax, bx), az, H), rz[:, 0] ** 2 + vz, rtol=2e-6, atol=TOL)
+    np.testing.assert_allclose(-2 * d1(lambda t: A(az, bz, t, bx), ax, H), rx[:, 0] ** 2 + vx, rtol=2e-6, atol=TOL)

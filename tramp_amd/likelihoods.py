@@ -127,8 +127,9 @@ class GaussianLikelihood(Likelihood):
         "gaussian_likelihood.py:43-49 (host arithmetic; not on the EP path)"
         bz = bz.get() if isinstance(bz, DeviceArray) else np.asarray(bz)
         y = y.get() if isinstance(y, DeviceArray) else np.asarray(y)
-        a = az + self.a
-        return (bz + self.a * y) / a, 1 / a
+        a = np.asarray(az, dtype=np.float64) + self.a
+        col = a[:, None] if a.ndim == 1 and bz.ndim == 2 else a        # one precision per ensemble instance
+        return (bz + self.a * y) / col, 1 / a
 
     def compute_backward_message(self, az, bz, out_a=None, out_b=None, **_):
         "gaussian_likelihood.py:68-71"
