@@ -89,3 +89,47 @@ def test_channel_posteriors_are_gradients_of_log_partition(ctx, name):
     np.testing.assert_allclose(d2(lambda t: A(az, bz, ax, t), bx, H), vx, rtol=2e-6, atol=20 * TOL)
     np.testing.assert_allclose(-2 * d1(lambda t: A(t, bz, ax, bx), az, H), rz[:, 0] ** 2 + vz, rtol=2e-6, atol=TOL)
     np.testing.assert_allclose(-2 * d1(lambda t: A(az, bz, t, bx), ax, H), rx[:, 0] ** 2 + vx, rtol=2e-6, atol=TOL)
+
+
+# tramp/tests/test_channels.py:53-110: channel posteriors against explicit numerical integration of
+# p(z) ~ N(z | az, bz) N(f(z) | ax, bx), on the reference's own three records
+RECORDS = [dict(az=2.1, bz=2.0, ax=2.0, bx=2.0), dict(az=2.0, bz=+1.6, ax=1.5, bx=1.3),
+           dict(az=2.0, bz=-1.6, ax=1.5, bx=1.3)]
+
+
+def explicit_moments(f, breaks, az, bz, ax, bx):
+    from scipy.integrate import quad
+
+    def w(z):
+        x = f(z)
+        return np.exp(-0.5 * az * z * z + bz * z - 0.5 * ax * x * x + bx * x)
+
+    def integral(g):
+        pts = [-30.0] + list(breaks) + [30.0]
+        return sum(quad(lambda z: g(z) * w(z), lo, hi, epsabs=0, epsrel=1e-13, limit=200)[0]
+                   for lo, hi in zip(pts[:-1], pts[1:]))
+    Z = integral(lambda z: 1.0)
+    rz = integral(lambda z: z) / Z
+    rx = integral(f) / Z
+    vz = integral(lambda z: (z - rz) ** 2) / Z
+    vx = integral(lambda z: (f(z) - rx) ** 2) / Z
+    return rz, vz, rx, vx
+
+
+def test_channel_posteriors_match_explicit_integrals(ctx):
+    import tramp_amd as T
+    cases = [(T.AbsChannel(ctx=ctx), np.abs, [0.0]),
+             (T.SgnChannel(ctx=ctx), np.sign, [0.0]),
+             (T.ReluChannel(ctx=ctx), lambda z: max(z, 0.0), [0.0]),
+             (T.LeakyReluChannel(slope=0.1, ctx=ctx), lambda z: z if z > 0 else 0.1 * z, [0.0]),
+             (T.HardTanhChannel(ctx=ctx), lambda z: min(max(z, -1.0), 1.0), [-1.0, 1.0])]
+    for ch, f, breaks in cases:
+        for rec in RECORDS:
+            az, bz, ax, bx = rec["az"], rec["bz"], rec["ax"], rec["bx"]
+            rz, vz, rx, vx = explicit_moments(f, breaks, az, bz, ax, bx)
+            one = lambda t: np.array([t])                                              # noqa: E731
+            rx_hat, vx_hat = ch.compute_forward_posterior(az, one(bz), ax, one(bx))
+            rz_hat, vz_hat = ch.compute_backward_posterior(az, one(bz), ax, one(bx))
+            msg = f"{type(ch).__name__} {rec}"
+            np.testing.assert_allclose([rz_hat[0], vz_hat, rx_hat[0], vx_hat], [rz, vz, rx, vx], rtol=1e-9,
+                                       atol=1e-11, err_msg=msg)
