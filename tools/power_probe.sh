@@ -7,15 +7,16 @@ export TRAMP_MFMA_F64_SHAPE=$MODE
 python3 - <<'PY' &
 import sys, time; sys.path.insert(0,'.')
 import numpy as np, tramp_amd as T, os
-ctx=T.default_context(); dt=T.device.dtype_code(np.float64)
+npdt=np.float32 if os.environ.get("PB_DTYPE")=="f32" else np.float64
+ctx=T.default_context(); dt=T.device.dtype_code(npdt)
 N=65536; M=N//2; B=int(os.environ.get("PB_BATCH","64"))
-Vt=ctx.randn((M,N),np.float64,seed=1,scale=N**-0.5); x=ctx.randn((B,N),np.float64,seed=2); t=ctx.empty((B,M))
+Vt=ctx.randn((M,N),npdt,seed=1,scale=N**-0.5); x=ctx.randn((B,N),npdt,seed=2); t=ctx.empty((B,M),npdt)
 t0=time.time(); n=0
 while time.time()-t0<8:
     for _ in range(20): ctx._call("tramp_matvec_nt", dt, 0, M, N, B, Vt.ptr, x.ptr, t.ptr)
     ctx.sync(); n+=20
 el=time.time()-t0
-print("mode",os.environ.get("TRAMP_MFMA_F64_SHAPE"),"B",B,"avg ms",el/n*1e3,"TFLOP/s",2.0*M*N*B*n/el/1e12, flush=True)
+print("dtype",npdt.__name__,"mode",os.environ.get("TRAMP_MFMA_F64_SHAPE"),"B",B,"avg ms",el/n*1e3,"TFLOP/s",2.0*M*N*B*n/el/1e12, flush=True)
 PY
 PID=$!
 sleep 4
