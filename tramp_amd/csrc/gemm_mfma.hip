@@ -24,6 +24,7 @@
 // One wave: RT x 16 mat rows (NT) or 32 columns (NN) times up to 64 instances:
 // 8 accumulator tiles = 64 VGPRs.
 #include "linear.h"
+#include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -101,16 +102,21 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
         for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = A{0, 0, 0, 0};
 
     V m[RT][kPieces], mn[RT][kPieces], xg[kPieces];
-    if (sbeg < send) {
-        const size_t k0 = sbeg * KS;
+    // only the last k step of the whole contraction can be ragged: every other step loads unguarded
+    // (the guard is a wave-uniform branch, not a per-lane select on every load)
+    auto load_step = [&](auto guarded, size_t k, V (&dst)[RT][kPieces]) {
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) {
-            const bool in = !TAIL || k0 + p * 4 * E + q * E < C;   // C % E == 0: pieces are all-in or all-out
+            const bool in = !decltype(guarded)::value || k + p * 4 * E + q * E < C;   // C % E == 0: pieces are all-in or all-out
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-                m[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k0 + p * 4 * E) : vzero;
-            if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k0 + p * 4 * E) : vzero;
+                dst[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k + p * 4 * E) : vzero;
+            if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k + p * 4 * E) : vzero;
         }
+    };
+    if (sbeg < send) {
+        if (TAIL && sbeg + 1 == nsteps_total) load_step(std::true_type{}, sbeg * KS, m);
+        else load_step(std::false_type{}, sbeg * KS, m);
     }
     for (size_t s = sbeg; s < send; ++s) {
         const int st = (int)((s - sbeg) & 1);
@@ -119,15 +125,8 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
             for (int p = 0; p < kPieces; ++p) xs[st][wave][p][lane] = xg[p];
         }
         if (s + 1 < send) {
-            const size_t k1 = (s + 1) * KS;
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) {
-                const bool in = !TAIL || k1 + p * 4 * E + q * E < C;
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    mn[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k1 + p * 4 * E) : vzero;
-                if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k1 + p * 4 * E) : vzero;
-            }
+            if (TAIL && s + 2 == nsteps_total) load_step(std::true_type{}, (s + 1) * KS, mn);
+            else load_step(std::false_type{}, (s + 1) * KS, mn);
         }
         __syncthreads();
 #pragma unroll
@@ -203,16 +202,21 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
         for (int bt = 0; bt < BT; ++bt) acc[nt][bt] = A{0, 0, 0, 0};
 
     V m[S], mn[S], xg[kPieces];
-    if (sbeg < send) {
-        const size_t k0 = sbeg * KS;
+    // as in the NT kernel: only the contraction's last step is loaded under guards
+    auto load_step = [&](auto guarded, size_t k, V (&dst)[S]) {
+        constexpr bool G = decltype(guarded)::value;
 #pragma unroll
         for (int s4 = 0; s4 < S; ++s4)
-            m[s4] = (!TAIL || k0 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k0 + s4) * C) : vzero;
+            dst[s4] = (!G || k + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k + s4) * C) : vzero;
         if (loads_x) {
 #pragma unroll
             for (int p = 0; p < kPieces; ++p)
-                xg[p] = (!TAIL || k0 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k0 + p * E) : vzero;
+                xg[p] = (!G || k + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k + p * E) : vzero;
         }
+    };
+    if (sbeg < send) {
+        if (TAIL && sbeg + 1 == nsteps_total) load_step(std::true_type{}, sbeg * KS, m);
+        else load_step(std::false_type{}, sbeg * KS, m);
     }
     for (size_t s = sbeg; s < send; ++s) {
         const int st = (int)((s - sbeg) & 1);
@@ -221,15 +225,8 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
             for (int p = 0; p < kPieces; ++p) xs[st][wave][p][lane] = xg[p];
         }
         if (s + 1 < send) {
-            const size_t k1 = (s + 1) * KS;
-#pragma unroll
-            for (int s4 = 0; s4 < S; ++s4)
-                mn[s4] = (!TAIL || k1 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k1 + s4) * C) : vzero;
-            if (loads_x) {
-#pragma unroll
-                for (int p = 0; p < kPieces; ++p)
-                    xg[p] = (!TAIL || k1 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k1 + p * E) : vzero;
-            }
+            if (TAIL && s + 2 == nsteps_total) load_step(std::true_type{}, (s + 1) * KS, mn);
+            else load_step(std::false_type{}, (s + 1) * KS, mn);
         }
         __syncthreads();
 #pragma unroll
