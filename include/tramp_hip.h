@@ -342,6 +342,29 @@ int tramp_conv_message(tramp_ctx* ctx, tramp_conv* conv, int dir, size_t batch,
                        double damping, const double* a_old_d, const void* b_old_d,
                        double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse);
 
+/* ---- gradient channel x = grad z --------------------- */
+/* GradientChannel (tramp/channels/linear/gradient_channel.py:10-118, real=True): one circular
+ * forward-difference filter per axis (d = ndim), x = [batch, d, n] for z = [batch, n]; diagonal in
+ * the Fourier basis with the summed spectrum sum_i |fft(f_i)|^2.  filters_d: [d][n] doubles
+ * (tramp/utils/conv_filters.py:102-119).  Variances: vz = (1 - n_eff) / az, vx = n_eff / (ax d)
+ * (gradient_channel.py:85-97); messages as tramp_conv_message without the projection cache:
+ * dir BWD writes [batch, n] (message to z), dir FWD [batch, d n] (message to x). */
+typedef struct tramp_grad tramp_grad;
+int tramp_grad_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filters_d,
+                      tramp_grad** grad);
+int tramp_grad_destroy(tramp_ctx* ctx, tramp_grad* grad);
+int tramp_grad_spectrum(tramp_ctx* ctx, const tramp_grad* grad, double* s2_d, size_t* count, double* mean);
+int tramp_grad_variance(tramp_ctx* ctx, tramp_grad* grad, int dir, size_t batch,
+                        const double* az_d, const double* ax_d,
+                        double* v_d, double* a_new_d, double* n_eff_d);
+/* GradientChannel.convolve / sample (gradient_channel.py:26-37): x[b, i, :] = w_i * z[b, :]. */
+int tramp_grad_apply(tramp_ctx* ctx, tramp_grad* grad, size_t batch, const void* z_d, void* x_d);
+int tramp_grad_message(tramp_ctx* ctx, tramp_grad* grad, int dir, size_t batch,
+                       const double* az_d, const void* bz_d,
+                       const double* ax_d, const void* bx_d,
+                       double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
 /* Two-pass mixed-radix complex FFT of length h = 2^a 5^b (1024 <= h <= ~1.3 10^6) used by the convolution
  * channel for 1-D sizes n = 2 h (csrc/fft_pow2.hip).  Exported for tests and tools: forward maps natural
  * order to the PERMUTED spectrum (position p holds frequency kfreq[p], tramp_fft_order), inverse maps a
@@ -382,6 +405,12 @@ int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  *      (tramp/algos/message_passing.py:119-127): x = d*old + (1-d)*x. */
 int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
                const double* a_old_d, const void* b_old_d, double* a_d, void* b_d);
+/* Variable.forward_message / backward_message on a tree (tramp/base.py:186-211): out = sum of the k
+ * incoming messages (host arrays of k device pointers, k <= 8) minus message `exclude` (the target's own;
+ * -1: plain sum = Variable.posterior_ab, base.py:152-155). */
+int tramp_message_sum(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k,
+                      const double* const* a_in_d, const void* const* b_in_d, int exclude,
+                      double* a_out_d, void* b_out_d);
 
 /* sum_d[batch] = sum_i (x[b,i] - y[b,i])^2  (y may be NULL): mse / norms for callbacks
  * (tramp/algos/metrics.py:5-8). */

@@ -844,6 +844,61 @@ def stencil_filter(shape, first=None, second=None):
 
 
 # --------------------------------------------------------------------------
+# Widening: gradient channel x = grad z, x of shape (d,) + shape
+#   tramp/channels/linear/gradient_channel.py:10-118 (real=True); conv_filters.py:102-119
+# --------------------------------------------------------------------------
+class GradientOracle:
+    def __init__(self, shape):
+        shape = tuple(shape)
+        self.shape, self.d = shape, len(shape)
+        self.filter = np.stack([stencil_filter(shape, first=[1. if a == ax else 0. for a in range(self.d)])
+                                for ax in range(self.d)])
+        self._axes = tuple(range(1, self.d + 1))
+        self.w_fft_bar = np.fft.fftn(self.filter, axes=self._axes)            # :20-22
+        self.w_fft = np.conjugate(self.w_fft_bar)
+        self.spectrum = (np.absolute(self.w_fft)**2).sum(axis=0)              # :23
+
+    def convolve(self, z):
+        return np.real(np.fft.ifftn(self.w_fft * np.fft.fftn(z)[np.newaxis], axes=self._axes))   # :26-34
+
+    def second_moment(self, tau_z):
+        return tau_z * self.spectrum.mean() / self.d                          # :42-43
+
+    def n_eff(self, az, ax):
+        if ax == 0:
+            return 0.
+        if az / ax == 0:
+            return 1.
+        return np.mean(self.spectrum / (az / ax + self.spectrum))             # :45-55
+
+    def backward_mean_fft(self, az, bz, ax, bx):
+        bx_fft = np.fft.fftn(bx, axes=self._axes)                              # not over the direction axis
+        resolvent = 1 / (az + ax * self.spectrum)
+        return resolvent * (np.fft.fftn(bz) + (self.w_fft_bar * bx_fft).sum(axis=0))   # :57-68
+
+    def backward_mean(self, az, bz, ax, bx):
+        return np.real(np.fft.ifftn(self.backward_mean_fft(az, bz, ax, bx)))
+
+    def forward_mean(self, az, bz, ax, bx):
+        rz_fft = self.backward_mean_fft(az, bz, ax, bx)
+        return np.real(np.fft.ifftn(self.w_fft * rz_fft[np.newaxis], axes=self._axes))   # :74-82
+
+    def backward_variance(self, az, ax):
+        return (1 - self.n_eff(az, ax)) / az                                   # :84-89
+
+    def forward_variance(self, az, ax):
+        if ax == 0:
+            return np.mean(self.spectrum) / az                                 # :92-94
+        return self.n_eff(az, ax) / (ax * self.d)                              # :95-97
+
+    def forward_message(self, az, bz, ax, bx):
+        return ab_new(self.forward_mean(az, bz, ax, bx), self.forward_variance(az, ax), ax, bx)
+
+    def backward_message(self, az, bz, ax, bx):
+        return ab_new(self.backward_mean(az, bz, ax, bx), self.backward_variance(az, ax), az, bz)
+
+
+# --------------------------------------------------------------------------
 # A14  Marchenko-Pastur closed-form linear channel (SE only)
 #   tramp/channels/linear/analytical_linear_channel.py:23-53
 #   tramp/ensembles/marchenko_pastur_ensemble.py:7-45
@@ -1126,6 +1181,26 @@ class RotationFactor(OracleFactor):
         return ax, self.R.T @ bx
 
 
+class GradientFactor(LinearFactor):
+    def __init__(self, shape):
+        self.lin = GradientOracle(shape)
+
+
+class UnitaryFactor(OracleFactor):
+    "tramp/channels/linear/unitary_channel.py:58-72: planar complex (2, N) messages through U / U^H"
+
+    def __init__(self, U):
+        self.U = np.asarray(U)
+
+    def forward(self, az, bz, ax, bx):
+        f = self.U @ (bz[0] + 1j * bz[1])
+        return az, np.stack([f.real, f.imag])
+
+    def backward(self, az, bz, ax, bx):
+        f = self.U.conj().T @ (bx[0] + 1j * bx[1])
+        return ax, np.stack([f.real, f.imag])
+
+
 class MPFactor(OracleFactor):
     def __init__(self, alpha):
         self.mp = MarchenkoPasturOracle(alpha)
@@ -1391,6 +1466,99 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
                 break
         old_rs = rs
     return dict(fwd=fwd, bwd=bwd, r=rs, v=vs, n_iter=n_iter)
+
+
+def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1e-6,
+            wait_increase=5, max_increase=0.2, record=None):
+    """Expectation propagation on a tree-structured model (message_passing.py:211-269,330-357 with
+    the variable nodes of tramp/base.py:152-211).
+
+    ``factors``: {name: OracleFactor}; ``variables``: names; ``edges``: directed (src, dst) name pairs
+    of the model DAG (factor -> variable or variable -> factor); ``shapes``: {variable: shape}.
+    Both message kinds are stored: a factor reads the variable -> factor messages its neighbours
+    sent when the sweep last VISITED them.  Forward sweep: nodes in topological order, a factor sends
+    to its successor, a variable to its successors (sum of all incoming minus the target's own);
+    backward sweep: reverse order, towards predecessors.  Constant damping on factor -> variable
+    messages only (message_passing.py:70-127).  ``record(it, msg, rs, vs)`` after each iteration.
+    """
+    nodes = list(factors) + list(variables)
+    pred = {n: [s for s, t in edges if t == n] for n in nodes}
+    succ = {n: [t for s, t in edges if s == n] for n in nodes}
+    order, indeg = [], {n: len(pred[n]) for n in nodes}
+    ready = [n for n in nodes if indeg[n] == 0]
+    while ready:
+        n = ready.pop(0)
+        order.append(n)
+        for t in succ[n]:
+            indeg[t] -= 1
+            if indeg[t] == 0:
+                ready.append(t)
+    assert len(order) == len(nodes), "model graph has a cycle"
+    msg = {}
+    for s, t in edges:
+        v = s if s in shapes else t
+        msg[(s, t)] = (0., np.zeros(shapes[v]))
+        msg[(t, s)] = (0., np.zeros(shapes[v]))
+    d = damping if damping else 0.
+
+    def damp(old, new):
+        return new if not d else (d * old[0] + (1 - d) * new[0], d * old[1] + (1 - d) * new[1])
+
+    def factor_send(f, direction):
+        fac = factors[f]
+        prev = pred[f][0] if pred[f] else None
+        nxt = succ[f][0] if succ[f] else None
+        target = nxt if direction == "fwd" else prev
+        if target is None:
+            return
+        if fac.kind == "prior":
+            new = fac.forward(None, None, *msg[(nxt, f)])
+        elif fac.kind == "likelihood":
+            new = fac.backward(*msg[(prev, f)], None, None)
+        elif direction == "fwd":
+            new = fac.forward(*msg[(prev, f)], *msg[(nxt, f)])
+        else:
+            new = fac.backward(*msg[(prev, f)], *msg[(nxt, f)])
+        if np.isnan(new[0]) or np.isnan(new[1]).any():
+            raise ValueError(f"{f}->{target} message is nan")
+        msg[(f, target)] = damp(msg[(f, target)], new)
+
+    def variable_send(v, targets):
+        inc = [msg[(f, v)] for f in pred[v] + succ[v]]
+        a_hat = sum(m[0] for m in inc)                                          # base.py:152-155
+        b_hat = sum(m[1] for m in inc)
+        for f in targets:
+            msg[(v, f)] = (a_hat - msg[(f, v)][0], b_hat - msg[(f, v)][1])      # base.py:186-211
+
+    old_rs, n_iter, rs, vs = None, 0, None, None
+    for it in range(max_iter):
+        for n in order:
+            if n in factors:
+                factor_send(n, "fwd")
+            else:
+                variable_send(n, succ[n])
+        for n in reversed(order):
+            if n in factors:
+                factor_send(n, "bwd")
+            else:
+                variable_send(n, pred[n])
+        rs, vs = {}, {}
+        for v in variables:
+            inc = [msg[(f, v)] for f in pred[v] + succ[v]]
+            a_hat = sum(m[0] for m in inc)
+            rs[v] = sum(m[1] for m in inc) / a_hat
+            vs[v] = 1. / a_hat
+        n_iter += 1
+        if record is not None:
+            record(it, msg, rs, vs)
+        if old_rs is not None:
+            tols = [_rms(rs[v] - old_rs[v]) / _rms(rs[v]) for v in variables]
+            if max(tols) < tol:
+                break
+            if it > wait_increase and max(tols) > max_increase:
+                break
+        old_rs = rs
+    return dict(msg=msg, r=rs, v=vs, n_iter=n_iter)
 
 
 def se_chain(factors, max_iter=200, damping=None, tol=1e-6, a0=0.,

@@ -74,6 +74,13 @@ def golden_logz():
 
 
 @pytest.fixture(scope="session")
+def golden_tree():
+    path = os.path.join(GOLDEN, "tree.npz")
+    with np.load(path, allow_pickle=True) as f:
+        return dict(grads=list(f["data"]), unit=list(f["unit"]), ep=list(f["ep"]))
+
+
+@pytest.fixture(scope="session")
 def golden_se():
     return load_golden("se")
 

@@ -171,3 +171,27 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     assert out.returncode == 0, out.stderr
     version, rc, n_ok, einval = out.stdout.strip().split("|")
     assert "gfx950" in version and rc == "0" and n_ok == "1" and einval == "1"
+
+
+def test_tree_model_algebra():
+    "dag_algebra.py:91-130: + places graphs side by side, @ splices dangling outputs onto dangling inputs in order"
+    import tramp_amd as T
+    from tramp_amd.variables import SIMOVariable, MILeafVariable, SILeafVariable, SISOVariable
+    prior, gb = T.GaussianPrior(size=8), T.GaussBernoulliPrior(size=8, rho=0.2)
+    noise, relu = T.GaussianChannel(var=0.1), T.ReluChannel()
+    x, y, z = SIMOVariable(id="x", n_next=2), SILeafVariable(id="y"), MILeafVariable(id="z", n_prev=2)
+    m = (prior @ x @ (noise @ y + (relu + gb) @ z)).to_model()
+    assert not m.is_chain and len(m.variables) == 3 and len(m.factors) == 4
+    assert m.prev_factors(x) == [prior] and set(m.next_factors(x)) == {noise, relu}
+    assert set(m.prev_factors(z)) == {relu, gb} and m.next_factors(z) == []
+    assert m.prev_factors(y) == [noise]
+    order = m.forward_ordering
+    assert order.index(prior) < order.index(x) < order.index(relu) < order.index(z)
+    assert m.init_shapes() == {"x": (8,), "y": (8,), "z": (8,)}
+    chain = (T.GaussBernoulliPrior(size=8) @ SISOVariable(id="x") @ T.ReluChannel() @ SISOVariable(id="z")
+             @ T.GaussianChannel(var=1.0) @ SILeafVariable(id="y")).to_model()
+    assert chain.is_chain and [v.id for v in chain.variables] == ["x", "z", "y"]
+    with pytest.raises(ValueError):                    # dangling output
+        (T.GaussianPrior(size=8) @ SIMOVariable(id="x", n_next=2) @ T.ReluChannel()).to_model()
+    with pytest.raises(ValueError):                    # two factors in a row
+        T.GaussianPrior(size=8) @ T.ReluChannel()

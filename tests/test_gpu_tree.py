@@ -1,0 +1,222 @@
+"""GPU parity of the gradient / unitary channels and of EP on tree-structured models (a variable with
+two children, a leaf with two parents) against vectors captured from the reference
+(tools/make_golden.py `tree`: GradientChannel, UnitaryChannel, the sparse-gradient model of
+examples/sparse/plot_sparse_gradient.py / models/total_variation_model.py) and the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TREE_EDGES = [("GaussianPrior", "x"), ("x", "GaussianLikelihood"), ("x", "GradientChannel"),
+              ("GradientChannel", "z"), ("GaussBernoulliPrior", "z")]
+
+
+def close(a, b, rtol, atol=0.0):
+    np.testing.assert_allclose(np.asarray(a, dtype=float), np.asarray(b, dtype=float), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gradient_channel_matches_reference(ctx, golden_tree, dtype):
+    import tramp_amd as T
+    rt, at = (1e-10, 1e-10) if dtype == np.float64 else (2e-4, 2e-4)
+    for g in golden_tree["grads"]:
+        shape = tuple(g["shape"])
+        ch = T.GradientChannel(shape=shape, dtype=dtype, ctx=ctx)
+        close(ch.second_moment(1.7), g["second_moment"], 1e-12)
+        close(ch.sample(g["z"]), g["x"], rt, at)
+        sc = float(np.abs(g["bx"]).max())
+        for c in g["cases"]:
+            az, ax = c["az"], c["ax"]
+            cond = max(1.0, az, ax)                     # messages are r (a + a_new) - b
+            close(ch.compute_n_eff(az, ax), c["n_eff"], 1e-12, 1e-15)
+            rz, vz = ch.compute_backward_posterior(az, g["bz"], ax, g["bx"])
+            rx, vx = ch.compute_forward_posterior(az, g["bz"], ax, g["bx"])
+            # vz = (1 - n_eff) / az loses eps / az when n_eff -> 1 (see the conv tests)
+            close(vz, c["vz"], max(1e-9, rt), 4e-16 / az)
+            close(vx, c["vx"], max(1e-12, rt))
+            scale_z = max(1.0, float(np.abs(c["rz"]).max()))
+            close(rz, c["rz"], rt, at * scale_z)
+            close(rx, c["rx"], rt, at * max(1.0, float(np.abs(c["rx"]).max())))
+            assert rx.shape == (len(shape),) + shape and rz.shape == shape
+            if dtype == np.float64 and 1e-6 < az < 1e6 and 1e-6 < ax < 1e6:
+                fa, fb = ch.compute_forward_message(az, g["bz"], ax, g["bx"])
+                ba, bb = ch.compute_backward_message(az, g["bz"], ax, g["bx"])
+                close(fa, c["a_fwd"], 1e-9)
+                close(ba, c["a_bwd"], 1e-9)
+                close(fb, c["b_fwd"], 1e-8, 1e-8 * sc * cond)
+                close(bb, c["b_bwd"], 1e-8, 1e-8 * sc * cond)
+
+
+def test_gradient_channel_ensemble_and_damping(ctx):
+    "rows of an ensemble are independent instances; fused damping equals damping the plain message"
+    import tramp_amd as T
+    rs = np.random.RandomState(3)
+    shape, B = (12, 10), 3
+    ch = T.GradientChannel(shape=shape, ctx=ctx)
+    o = orc.GradientOracle(shape)
+    az, ax = rs.uniform(0.5, 2, B), rs.uniform(0.5, 2, B)
+    bz, bx = rs.standard_normal((B,) + shape), rs.standard_normal((B, 2) + shape)
+    fa, fb = ch.compute_forward_message(az, bz, ax, bx)
+    ba, bb = ch.compute_backward_message(az, bz, ax, bx)
+    for b in range(B):
+        a, m = o.forward_message(az[b], bz[b], ax[b], bx[b])
+        close(fa[b], a, 1e-10)
+        close(fb[b], m, 1e-9, 1e-10)
+        a, m = o.backward_message(az[b], bz[b], ax[b], bx[b])
+        close(ba[b], a, 1e-10)
+        close(bb[b], m, 1e-9, 1e-10)
+    d = 0.3
+    old_a = ctx.array(rs.uniform(1, 2, B), np.float64)
+    old_b = ctx.array(rs.standard_normal((B, 2 * 120)), np.float64)
+    want_a, want_b = d * old_a.get() + (1 - d) * fa, d * old_b.get().reshape((B, 2) + shape) + (1 - d) * fb
+    ch.compute_forward_message(ctx.array(az, np.float64), ctx.array(bz.reshape(B, -1), np.float64),
+                               ctx.array(ax, np.float64), ctx.array(bx.reshape(B, -1), np.float64),
+                               out_a=old_a, out_b=old_b, damping=d, old_a=old_a, old_b=old_b)
+    close(old_a.get(), want_a, 1e-12)
+    close(old_b.get().reshape((B, 2) + shape), want_b, 1e-11, 1e-12)
+
+
+def test_gradient_channel_normal_equations_large(ctx):
+    "n = 2^20 (1-D) and 1024 x 1024: (az + ax s) rz_fft = fz + sum_i conj(w_i)^* ... checked on the device result"
+    import tramp_amd as T
+    rs = np.random.RandomState(5)
+    for shape in [(1 << 20,), (1024, 1024)]:
+        ch = T.GradientChannel(shape=shape, ctx=ctx)
+        o = orc.GradientOracle(shape)
+        d = len(shape)
+        az, ax = 1.3, 0.7
+        bz, bx = rs.standard_normal(shape), rs.standard_normal((d,) + shape)
+        rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+        rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+        axes = tuple(range(1, d + 1))
+        lhs = (az + ax * o.spectrum) * np.fft.fftn(rz)
+        rhs = np.fft.fftn(bz) + (o.w_fft_bar * np.fft.fftn(bx, axes=axes)).sum(axis=0)
+        assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(rhs).max()
+        close(rx, o.convolve(rz), 1e-9, 1e-10)                         # rx = grad rz
+        close(az * vz + ax * d * vx, 1.0, 1e-10)                       # az vz + ax d vx = (1 - n_eff) + n_eff
+
+
+def test_unitary_channel_matches_reference(ctx, golden_tree):
+    import tramp_amd as T
+    for u in golden_tree["unit"]:
+        ch = T.UnitaryChannel(u["U"], ctx=ctx)
+        a, b = ch.compute_forward_message(1.3, u["bz"], 0.7, u["bx"])
+        assert a == u["a_fwd"] and b.shape == u["b_fwd"].shape
+        close(b, u["b_fwd"], 1e-12, 1e-13)
+        a, b = ch.compute_backward_message(1.3, u["bz"], 0.7, u["bx"])
+        assert a == u["a_bwd"]
+        close(b, u["b_bwd"], 1e-12, 1e-13)
+        close(ch.sample(u["bz"]), u["x"], 1e-12, 1e-13)
+    with pytest.raises(ValueError):
+        T.UnitaryChannel(np.ones((3, 3)), ctx=ctx)
+
+
+def build_tree(T, ctx, e, y=None, dtype=np.float64):
+    from tramp_amd.variables import SIMOVariable, MILeafVariable
+    shape = tuple(e["shape"])
+    d = len(shape)
+    kw = dict(dtype=dtype, ctx=ctx)
+    y = e["y"] if y is None else y
+    n = int(np.prod(shape))
+    return (T.GaussianPrior(size=shape, **kw) @ SIMOVariable(id="x", n_next=2) @ (
+        T.GaussianLikelihood(y=np.asarray(y).reshape(-1, n) if np.ndim(y) > d else np.asarray(y).reshape(n),
+                             var=e["noise_var"], **kw) + (
+            T.GradientChannel(shape=shape, **kw) + T.GaussBernoulliPrior(size=(d,) + shape, rho=e["rho"], **kw)
+        ) @ MILeafVariable(id="z", n_prev=2))).to_model()
+
+
+class TreeRecorder:
+    def __init__(self):
+        self.iters = []
+
+    def __call__(self, algo, i, max_iter):
+        from tramp_amd.base import Variable
+        rec = {}
+        for (src, dst), m in algo.msg.items():
+            key = f"{src.id if isinstance(src, Variable) else type(src).__name__}->" \
+                  f"{dst.id if isinstance(dst, Variable) else type(dst).__name__}"
+            rec[key + ":a"] = m.a.get().copy()
+            rec[key + ":b"] = m.b.get().copy()
+        for vid, d in algo.get_variables_data().items():
+            rec["r:" + vid], rec["v:" + vid] = np.array(d["r"]), np.array(d["v"])
+        self.iters.append(rec)
+        return False
+
+
+def test_tree_ep_trajectories_match_reference(ctx, golden_tree):
+    """Sparse-gradient model: every message of both kinds and every posterior after each of the first 12
+    iterations, against the reference's own run."""
+    import tramp_amd as T
+    from tramp_amd.tree import TreeExpectationPropagation
+    for e in golden_tree["ep"]:
+        model = build_tree(T, ctx, e)
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        assert isinstance(ep, TreeExpectationPropagation)
+        rec = TreeRecorder()
+        ep.iterate(max_iter=12, callback=rec, damping=e["damping"])
+        tr = e["traj"]
+        shape = tuple(e["shape"])
+        for it, got in enumerate(rec.iters):
+            for key, val in got.items():
+                ref = np.asarray(tr[key][it], dtype=float)
+                if key.endswith(":a") or key.startswith("v:"):
+                    close(np.ravel(val)[0], ref, 1e-8)
+                else:
+                    sc = max(1.0, float(np.abs(ref).max()))
+                    close(np.ravel(val), np.ravel(ref), 1e-7, 1e-8 * sc)
+        assert ep.n_iter == 12
+
+
+def test_tree_ep_ensemble_matches_oracle(ctx, golden_tree):
+    "three instances (different observations) in one ensemble = three oracle runs; fp32 within 1e-3"
+    import tramp_amd as T
+    e = dict(golden_tree["ep"][0])
+    shape = tuple(e["shape"])
+    rs = np.random.RandomState(4)
+    Y = np.stack([e["y"], e["y"] + 0.1 * rs.standard_normal(shape), rs.standard_normal(shape)])
+    runs = []
+    for b in range(3):
+        eb = dict(e, y=Y[b])
+        factors = dict(GaussianPrior=orc.GaussPriorFactor(shape), GaussianLikelihood=orc.GaussLikFactor(Y[b], e["noise_var"]),
+                       GradientChannel=orc.GradientFactor(shape),
+                       GaussBernoulliPrior=orc.GBPriorFactor((1,) + shape, rho=e["rho"]))
+        runs.append(orc.ep_tree(factors, ["x", "z"], TREE_EDGES, dict(x=shape, z=(1,) + shape), max_iter=15,
+                                damping=0.2, tol=0.0, max_increase=np.inf))
+        del eb
+    for dtype, rt in ((np.float64, 1e-8), (np.float32, 2e-3)):
+        model = build_tree(T, ctx, e, y=Y, dtype=dtype)
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        assert ep.batch == 3
+        ep.iterate(max_iter=15, callback=T.PassCallback(), damping=0.2)
+        data = ep.get_variables_data()
+        for b in range(3):
+            close(data["x"]["r"][b], runs[b]["r"]["x"].ravel(), rt, rt)
+            close(data["z"]["r"][b], runs[b]["r"]["z"].ravel(), rt, rt)
+            close(data["x"]["v"][b], runs[b]["v"]["x"], max(rt, 1e-7))
+            close(data["z"]["v"][b], runs[b]["v"]["z"], max(rt, 1e-7))
+
+
+def test_tree_ep_example_setting_matches_oracle(ctx):
+    """The reference example's run (examples/sparse/plot_sparse_gradient.py:63,88-91: rho = 0.04, noise 1e-2,
+    damping 0.1, EarlyStoppingEP(tol=1e-2)) at n = 4096: same stopping iteration and estimate as the oracle,
+    and the estimate improves on the raw observation."""
+    import tramp_amd as T
+    rs = np.random.RandomState(1)
+    n, rho, nv = 4096, 0.04, 1e-2
+    jumps = rs.standard_normal(n) * rs.binomial(1, rho, n)
+    x = np.cumsum(jumps)
+    x -= x.mean()
+    y = x + np.sqrt(nv) * rs.standard_normal(n)
+    factors = dict(GaussianPrior=orc.GaussPriorFactor((n,)), GaussianLikelihood=orc.GaussLikFactor(y, nv),
+                   GradientChannel=orc.GradientFactor((n,)), GaussBernoulliPrior=orc.GBPriorFactor((1, n), rho=rho))
+    want = orc.ep_tree(factors, ["x", "z"], TREE_EDGES, dict(x=(n,), z=(1, n)), max_iter=1000, damping=0.1, tol=1e-2)
+    model = build_tree(T, ctx, dict(shape=(n,), noise_var=nv, rho=rho), y=y)
+    ep = T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=1000, damping=0.1,
+                                                          callback=T.EarlyStoppingEP(tol=1e-2))
+    assert ep.n_iter == want["n_iter"]
+    r = ep.get_variable_data("x")["r"]
+    close(r, want["r"]["x"], 1e-7, 1e-8)
+    close(ep.get_variable_data("z")["r"], want["r"]["z"].ravel(), 1e-7, 1e-8)
+    assert np.mean((r - x) ** 2) < np.mean((y - x) ** 2)

@@ -516,3 +516,61 @@ def test_ep_log_evidence_oracle_matches_reference(golden_logz):
             orc.ep_chain(fs, shapes, max_iter=len(c["A"]), damping=c["damping"], tol=0.0, max_increase=np.inf,
                          record=lambda it, fwd, bwd, rs, vs: As.append(orc.chain_log_evidence(fs, fwd, bwd)))
         close(As, c["A"], rtol=1e-7, atol=1e-8 * np.abs(c["A"]).max())
+
+
+# ---------------------------------------------------------------- trees (gradient channel, multi-factor variables)
+TREE_EDGES = [("GaussianPrior", "x"), ("x", "GaussianLikelihood"), ("x", "GradientChannel"),
+              ("GradientChannel", "z"), ("GaussBernoulliPrior", "z")]
+
+
+def tree_factors(e):
+    shape = tuple(e["shape"])
+    d = len(shape)
+    return dict(GaussianPrior=orc.GaussPriorFactor(shape), GaussianLikelihood=orc.GaussLikFactor(e["y"], e["noise_var"]),
+                GradientChannel=orc.GradientFactor(shape),
+                GaussBernoulliPrior=orc.GBPriorFactor((d,) + shape, rho=e["rho"])), dict(x=shape, z=(d,) + shape)
+
+
+def test_gradient_unitary_oracle_matches_reference(golden_tree):
+    for g in golden_tree["grads"]:
+        o = orc.GradientOracle(g["shape"])
+        np.testing.assert_allclose(o.spectrum, g["spectrum"], atol=1e-13)
+        np.testing.assert_allclose(o.convolve(g["z"]), g["x"], atol=1e-13)
+        assert abs(o.second_moment(1.7) - g["second_moment"]) < 1e-13
+        for c in g["cases"]:
+            with np.errstate(all="ignore"):
+                fa, fb = o.forward_message(c["az"], g["bz"], c["ax"], g["bx"])
+                ba, bb = o.backward_message(c["az"], g["bz"], c["ax"], g["bx"])
+                assert abs(o.n_eff(c["az"], c["ax"]) - c["n_eff"]) < 1e-13
+            np.testing.assert_allclose(fa, c["a_fwd"], rtol=1e-10)
+            np.testing.assert_allclose(fb, c["b_fwd"], rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(ba, c["a_bwd"], rtol=1e-10)
+            np.testing.assert_allclose(bb, c["b_bwd"], rtol=1e-9, atol=1e-10)
+    for u in golden_tree["unit"]:
+        f = orc.UnitaryFactor(u["U"])
+        a, b = f.forward(1.3, u["bz"], 0.7, u["bx"])
+        assert a == u["a_fwd"]
+        np.testing.assert_allclose(b, u["b_fwd"], atol=1e-13)
+        a, b = f.backward(1.3, u["bz"], 0.7, u["bx"])
+        assert a == u["a_bwd"]
+        np.testing.assert_allclose(b, u["b_bwd"], atol=1e-13)
+
+
+def test_tree_ep_oracle_matches_reference(golden_tree):
+    "every message of both kinds (factor -> variable, variable -> factor) and every posterior, per iteration"
+    for e in golden_tree["ep"]:
+        factors, shapes = tree_factors(e)
+        recs = []
+
+        def record(it, msg, rs, vs):
+            recs.append(({k: (v[0], v[1].copy()) for k, v in msg.items()}, dict(rs), dict(vs)))
+        orc.ep_tree(factors, ["x", "z"], TREE_EDGES, shapes, max_iter=12, damping=e["damping"], record=record)
+        tr = e["traj"]
+        assert len(recs) == 12
+        for it, (msg, rs, vs) in enumerate(recs):
+            for (s, t), (a, b) in msg.items():
+                np.testing.assert_allclose(a, tr[f"{s}->{t}:a"][it], rtol=1e-12)
+                np.testing.assert_allclose(b, tr[f"{s}->{t}:b"][it], rtol=1e-11, atol=1e-12)
+            for v in ("x", "z"):
+                np.testing.assert_allclose(rs[v], tr["r:" + v][it], rtol=1e-11, atol=1e-12)
+                np.testing.assert_allclose(vs[v], tr["v:" + v][it], rtol=1e-12)

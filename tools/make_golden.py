@@ -692,6 +692,102 @@ def conv_goldens():
     save("conv", data=np.array(out, dtype=object), ep=np.array(trajs, dtype=object))
 
 
+# ---------------------------------------------------------------- trees: gradient channel, multi-factor variables
+class TreeRecorder:
+    "Every message of both kinds (factor -> variable, variable -> factor), keyed by class name / variable id."
+
+    def __init__(self, stopper):
+        self.stopper = stopper
+        self.iters = []
+
+    @staticmethod
+    def name(node):
+        return node.id if isinstance(node, Variable) else type(node).__name__
+
+    def __call__(self, algo, i, max_iter):
+        if i == 0:
+            self.iters = []
+        rec = {}
+        for source, target, data in algo.message_dag.edges(data=True):
+            key = f"{self.name(source)}->{self.name(target)}"
+            rec[key + ":a"] = float(data["a"])
+            rec[key + ":b"] = np.array(data["b"], dtype=float)
+        for vid, d in algo.get_variables_data().items():
+            rec[f"r:{vid}"] = np.array(d["r"], dtype=float)
+            rec[f"v:{vid}"] = float(d["v"])
+        self.iters.append(rec)
+        return self.stopper(algo, i, max_iter)
+
+
+def tree_goldens():
+    "GradientChannel / UnitaryChannel factor-level vectors and EP on the sparse-gradient tree."
+    from tramp.channels import GradientChannel, UnitaryChannel
+    from tramp.variables import SIMOVariable, MILeafVariable
+    rs = np.random.RandomState(23)
+    grads = []
+    for shape in [(16,), (15,), (6, 8), (3, 4, 5)]:
+        ch = GradientChannel(shape=shape)
+        d = len(shape)
+        bz = rs.standard_normal(shape) * 2
+        bx = rs.standard_normal((d,) + shape) * 3
+        z = rs.standard_normal(shape)
+        cases = []
+        for (az, ax) in [(1.3, 0.7), (2.0, 0.), (1e-11, 5.0), (100.0, 100.0), (0.37, 1e4)]:
+            with np.errstate(all="ignore"):
+                rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+                rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+                af, bf = ch.compute_forward_message(az, bz, ax, bx)
+                ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+            cases.append(dict(az=float(az), ax=float(ax), rz=rz, rx=rx, vz=vz, vx=vx, a_fwd=af, b_fwd=bf,
+                              a_bwd=ab, b_bwd=bb, n_eff=ch.compute_n_eff(az, ax)))
+        grads.append(dict(shape=shape, bz=bz, bx=bx, z=z, x=ch.sample(z), spectrum=ch.spectrum,
+                          second_moment=ch.second_moment(1.7), cases=cases))
+    unit = []
+    for N in (5, 12):
+        A = rs.standard_normal((N, N)) + 1j * rs.standard_normal((N, N))
+        U, _ = np.linalg.qr(A)
+        ch = UnitaryChannel(U)
+        bz = rs.standard_normal((2, N))
+        bx = rs.standard_normal((2, N))
+        af, bf = ch.compute_forward_message(1.3, bz, 0.7, bx)
+        ab, bb = ch.compute_backward_message(1.3, bz, 0.7, bx)
+        unit.append(dict(U=U, bz=bz, bx=bx, a_fwd=af, b_fwd=bf, a_bwd=ab, b_bwd=bb, x=ch.sample(bz)))
+    # EP on the sparse-gradient model (examples/sparse/plot_sparse_gradient.py, models/total_variation_model.py):
+    # x ~ N(0, 1) observed through Gaussian noise, z = grad x with a Gauss-Bernoulli prior on z
+    trajs = []
+    for name, shape, rho, nv, damping in [("grad1d", (64,), 0.06, 1e-2, None), ("grad1d", (64,), 0.06, 1e-2, 0.3),
+                                          ("grad2d", (8, 10), 0.15, 1e-2, None)]:
+        r = np.random.RandomState(9)
+        d = len(shape)
+        zshape = (d,) + shape
+        if d == 1:
+            zp = r.standard_normal(shape) * r.binomial(n=1, size=shape, p=rho)
+            x = np.cumsum(zp)
+            x = x - x.mean()
+        else:
+            x = np.kron(r.standard_normal((2, 2)), np.ones((shape[0] // 2, shape[1] // 2)))
+        y = x + np.sqrt(nv) * r.standard_normal(shape)
+        model = (GaussianPrior(size=shape) @ SIMOVariable(id="x", n_next=2) @ (
+            GaussianLikelihood(y=y, var=nv) + (
+                GradientChannel(shape=shape) + GaussBernoulliPrior(size=zshape, rho=rho)
+            ) @ MILeafVariable(id="z", n_prev=2))).to_model()
+        ep = ExpectationPropagation(model)
+        rec = TreeRecorder(EarlyStoppingEP())
+        err = None
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=30, callback=rec, damping=damping)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        trajs.append(dict(name=name, shape=shape, rho=rho, noise_var=nv, damping=damping, x=x, y=y,
+                          n_iter=ep.n_iter, error=err, n_recorded=len(rec.iters), traj=pack_traj(rec.iters[:12]),
+                          final_r=rec.iters[-1]["r:x"], mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2)),
+                          mse_y=float(np.mean((y - x)**2))))
+        print("tree ep", name, damping, "n_iter", ep.n_iter, err, "mse", trajs[-1]["mse"], "vs y", trajs[-1]["mse_y"])
+    save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
+         ep=np.array(trajs, dtype=object))
+
+
 # ---------------------------------------------------------------- SE
 def se_goldens(skip_slow):
     out = {}
@@ -830,5 +926,7 @@ if __name__ == "__main__":
         unitary_goldens()
     if not only or "logz" in only:
         logz_goldens()
+    if not only or "tree" in only:
+        tree_goldens()
     if not only or "se" in only:
         se_goldens(args.skip_slow)

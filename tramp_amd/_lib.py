@@ -82,6 +82,12 @@ _SIGNATURES = {
     "tramp_conv_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_conv_apply": [vp, vp, sz, vp, vp],
     "tramp_conv_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
+    "tramp_grad_create": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],
+    "tramp_grad_destroy": [vp, vp],
+    "tramp_grad_spectrum": [vp, vp, vp, C.POINTER(sz), C.POINTER(dbl)],
+    "tramp_grad_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
+    "tramp_grad_apply": [vp, vp, sz, vp, vp],
+    "tramp_grad_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_linear_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_conv_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_dft_create": [vp, i32, i32, C.POINTER(sz), C.POINTER(vp)],
@@ -96,6 +102,7 @@ _SIGNATURES = {
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_damp": [vp, i32, sz, sz, dbl, vp, vp, vp, vp],
+    "tramp_message_sum": [vp, i32, sz, sz, i32, C.POINTER(vp), C.POINTER(vp), i32, vp, vp],
     "tramp_sq_dist": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_se_gb_prior": [vp, sz, vp, vp, vp, vp, vp],
     "tramp_se_sgn_lik": [vp, sz, vp, vp, vp],

@@ -246,6 +246,13 @@ class ExpectationPropagation:
     channels' matrices); it is inferred from the observations' leading axis.
     """
 
+    def __new__(cls, model, *args, **kwargs):
+        # tree-structured models (a variable with several parents or children) run on the general scheduler
+        if cls is ExpectationPropagation and not getattr(model, "is_chain", True):
+            from .tree import TreeExpectationPropagation
+            return super().__new__(TreeExpectationPropagation)
+        return super().__new__(cls)
+
     def __init__(self, model, batch=None, ctx=None):
         self.model = model
         self.shapes = model.init_shapes()

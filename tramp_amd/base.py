@@ -106,6 +106,10 @@ class Variable(ReprMixin):
         from .models import DAG
         return DAG(self) @ other
 
+    def __add__(self, other):
+        from .models import DAG
+        return DAG(self) + other
+
 
 class Factor(ReprMixin):
     """Base of priors / channels / likelihoods (tramp/base.py:236-464)."""
@@ -153,6 +157,10 @@ class Factor(ReprMixin):
     def __matmul__(self, other):
         from .models import DAG
         return DAG(self) @ other
+
+    def __add__(self, other):
+        from .models import DAG
+        return DAG(self) + other
 
     # -- message parse / emit (tramp/base.py:275-365)
     def _parse_message_ab(self, message):

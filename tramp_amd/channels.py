@@ -842,6 +842,138 @@ class Blur2DChannel(ConvChannel):
         self.sigma = sigma
 
 
+def gradient_filters(shape):
+    "one forward-difference filter per axis, (d,) + shape (conv_filters.py:102-119)"
+    return np.stack([_along_axis(_fd1, ax, tuple(shape)) for ax in range(len(shape))])
+
+
+class GradientChannel(Channel):
+    """Gradient channel x = grad z (circular forward differences along each of the d axes).
+
+    tramp/channels/linear/gradient_channel.py:10-118 (``real=True``): z has ``shape``, x has
+    ``(d,) + shape``; diagonal in the Fourier basis on the summed spectrum of the d filters
+    (csrc/conv.hip, rocFFT transforms + this library's spectral and update kernels).  Device
+    vectors: z [batch, n], x [batch, d n].
+    """
+
+    def __init__(self, shape, real=True, dtype=np.float64, ctx=None):
+        if not real:
+            raise NotImplementedError("complex GradientChannel (real=False) is outside the HIP path")
+        shape = tuple(int(s) for s in shape)
+        if not 1 <= len(shape) <= 3:
+            raise ValueError("shape must have 1 to 3 axes")
+        self.d = len(shape)
+        self.shape = shape
+        self.real = real
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.filter = gradient_filters(shape)
+        self.N = int(np.prod(shape))
+        self.Nz, self.Nx = self.N, self.d * self.N
+        ctx = self.ctx
+        fd = ctx.array(self.filter.reshape(-1), np.float64)
+        dims = (C.c_size_t * self.d)(*shape)
+        h = C.c_void_p()
+        ctx._call("tramp_grad_create", self._dt, self.d, dims, fd.ptr, C.byref(h))
+        self._handle = h
+        cnt, mean = C.c_size_t(), C.c_double()
+        ctx._call("tramp_grad_spectrum", h, None, C.byref(cnt), C.byref(mean))
+        self._n_half = cnt.value
+        self.spectrum_mean = mean.value
+
+    def __del__(self):
+        try:
+            if self._handle and self.ctx.handle:
+                self.ctx.lib.tramp_grad_destroy(self.ctx.handle, self._handle)
+        except Exception:
+            pass
+        self._handle = None
+
+    def _vec(self, b, x_side):
+        if isinstance(b, DeviceArray):
+            return VecArg(self.ctx, b, self.dtype)
+        full = ((self.d,) + self.shape) if x_side else self.shape
+        n = self.Nx if x_side else self.Nz
+        h = np.asarray(b, dtype=self.dtype)
+        nd = len(full)
+        if h.shape[-nd:] != full or h.ndim not in (nd, nd + 1):
+            raise ValueError(f"expected an array of shape {full} or (batch,)+{full}, got {h.shape}")
+        arg = VecArg(self.ctx, h.reshape(-1, n) if h.ndim == nd + 1 else h.reshape(n), self.dtype)
+        arg.host_shape = h.shape
+        arg._one = h.ndim == nd
+        return arg
+
+    _ret = staticmethod(ConvChannel._ret)
+    _ret_scal = staticmethod(ConvChannel._ret_scal)
+
+    def convolve(self, z):
+        "gradient_channel.py:26-34"
+        zz = self._vec(z, False)
+        x = self.ctx.empty((zz.batch, self.Nx), self.dtype)
+        self.ctx._call("tramp_grad_apply", self._handle, zz.batch, zz.dev.ptr, x.ptr)
+        if zz.was_host:
+            return x.get().reshape(((zz.batch,) if not zz._one else ()) + (self.d,) + self.shape)
+        return x
+
+    def sample(self, Z):
+        return self.convolve(Z)
+
+    def second_moment(self, tau_z):
+        return tau_z * self.spectrum_mean / self.d                     # :42-43
+
+    def device_variance(self, direction, az, ax):
+        ctx = self.ctx
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        a_z = ctx.scalars(az_h)
+        a_x = ctx.scalars(ax, az_h.shape[0])
+        outs = [ctx.empty((az_h.shape[0],), np.float64) for _ in range(3)]
+        ctx._call("tramp_grad_variance", self._handle, direction, az_h.shape[0], a_z.ptr, a_x.ptr,
+                  *[o.ptr for o in outs])
+        return [o.get() for o in outs]
+
+    def compute_n_eff(self, az, ax):
+        return float(self.device_variance(_lib.BWD, az, ax)[2][0])     # :45-55
+
+    def compute_backward_variance(self, az, ax):
+        assert az > 0                                                  # :85-89
+        return float(self.device_variance(_lib.BWD, az, ax)[0][0])
+
+    def compute_forward_variance(self, az, ax):
+        return float(self.device_variance(_lib.FWD, az, ax)[0][0])     # :91-97
+
+    def compute_backward_error(self, az, ax, tau_z):
+        return self.compute_backward_variance(az, ax)                  # :111-113
+
+    def compute_forward_error(self, az, ax, tau_z):
+        return self.compute_forward_variance(az, ax)                   # :115-117
+
+    def _run(self, direction, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+             old_b=None, want_posterior=False):
+        ctx = self.ctx
+        z, x = self._vec(bz, False), self._vec(bx, True)
+        if z.n != self.Nz or x.n != self.Nx or z.batch != x.batch:
+            raise ValueError(f"expected bz [batch,{self.Nz}] and bx [batch,{self.Nx}], got {z.dev.shape} and {x.dev.shape}")
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
+        a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((z.batch, tgt.n), self.dtype)
+        r = ctx.empty((z.batch, tgt.n), self.dtype) if want_posterior else None
+        v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        ctx._call("tramp_grad_message", self._handle, direction, z.batch, a_z.dev.ptr, z.dev.ptr,
+                  a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
+                  old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
+                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None, v.ptr if v is not None else None)
+        return tgt, a_t, a_new, b_new, r, v
+
+    compute_backward_mean = ConvChannel.compute_backward_mean
+    compute_forward_mean = ConvChannel.compute_forward_mean
+    compute_backward_posterior = ConvChannel.compute_backward_posterior
+    compute_forward_posterior = ConvChannel.compute_forward_posterior
+    compute_forward_message = ConvChannel.compute_forward_message
+    compute_backward_message = ConvChannel.compute_backward_message
+
+
 class _UnitaryChannel(Channel):
     """Shared message plumbing of the unitary channels (DFT, rotation): the posterior is not
     needed - (a, b) travel through the change of basis (a unchanged, b transformed)."""
@@ -1003,6 +1135,39 @@ class RotationChannel(_UnitaryChannel):
         return self._message(_lib.BWD, ax, bx, out_a, out_b, damping, old_a, old_b)      # :38-42
 
 
+class UnitaryChannel(RotationChannel):
+    """x = U z with U unitary (tramp/channels/linear/unitary_channel.py:16-97).  A complex vector is
+    the planar real array (2, N) = (real parts, imaginary parts) as in the reference, so U acts as the
+    2N x 2N rotation [[Re U, -Im U], [Im U, Re U]] on the flattened array: the same dense matrix
+    kernels as RotationChannel (device vectors [batch, 2 N])."""
+
+    def __init__(self, U, name="U", dtype=np.float64, ctx=None):
+        U = np.asarray(U)
+        if U.ndim != 2 or U.shape[0] != U.shape[1]:
+            raise ValueError(f"U.shape = {U.shape}")
+        if not np.allclose(U @ U.conj().T, np.identity(U.shape[0])):
+            raise ValueError("U not unitary")
+        self.U = U
+        self.Nc = U.shape[0]
+        R = np.block([[U.real, -U.imag], [U.imag, U.real]])
+        super().__init__(R, name=name, dtype=dtype, ctx=ctx)
+
+    def sample(self, Z):
+        Z = np.asarray(Z)
+        X = self.U @ (Z[0] + 1j * Z[1])
+        return np.stack([X.real, X.imag])
+
+    def _message(self, direction, a_in, b_in, out_a, out_b, damping, old_a, old_b):
+        if isinstance(b_in, DeviceArray):
+            return super()._message(direction, a_in, b_in, out_a, out_b, damping, old_a, old_b)
+        h = np.asarray(b_in)
+        if h.shape[-2:] != (2, self.Nc) or h.ndim not in (2, 3):
+            raise ValueError(f"expected a planar complex array (2, {self.Nc}) or (batch, 2, {self.Nc}), got {h.shape}")
+        flat = h.reshape(2 * self.Nc) if h.ndim == 2 else h.reshape(-1, 2 * self.Nc)
+        a_new, b_new = super()._message(direction, a_in, flat, out_a, out_b, damping, old_a, old_b)
+        return a_new, (b_new.reshape(h.shape) if isinstance(b_new, np.ndarray) else b_new)
+
+
 class AnalyticalLinearChannel(Channel):
     "SE-only linear channel with closed-form spectrum transforms (analytical_linear_channel.py:8-62)"
 
@@ -1059,6 +1224,8 @@ CHANNEL_CLASSES = {
     "laplacian": LaplacianChannel,
     "dft": DFTChannel,
     "rotation": RotationChannel,
+    "gradient": GradientChannel,
+    "unitary": UnitaryChannel,
 }
 
 

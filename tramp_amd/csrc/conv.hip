@@ -210,8 +210,8 @@ __global__ __launch_bounds__(kBlock) void conv_neff_partial_kernel(const double*
 }
 
 __global__ __launch_bounds__(kWave) void conv_variance_kernel(const double* __restrict__ partial, int nblk,
-                                                              double n, double s_mean, int dir,
-                                                              const double* __restrict__ az_d,
+                                                              double n, double s_mean, double fwd_div,
+                                                              int dir, const double* __restrict__ az_d,
                                                               const double* __restrict__ ax_d, double damping,
                                                               const double* __restrict__ a_old,
                                                               double* __restrict__ v_out, double* __restrict__ a_new_out,
@@ -233,7 +233,8 @@ __global__ __launch_bounds__(kWave) void conv_variance_kernel(const double* __re
     if (threadIdx.x != 0) return;
     double v, a_in;
     if (dir == TRAMP_FWD) {
-        v = (ax == 0.0) ? s_mean / az : n_eff / ax;                    // :117-123
+        // conv_channel.py:117-123; gradient_channel.py:91-97 divides by ax * d (fwd_div = d)
+        v = (ax == 0.0) ? s_mean / az : (fwd_div == 1.0 ? n_eff / ax : n_eff / (ax * fwd_div));
         a_in = ax;
     } else {
         v = (1.0 - n_eff) / az;                                        // :111-115
@@ -414,12 +415,12 @@ unsigned grid_for(size_t n) {
 
 int conv_scalars(tramp_ctx* ctx, const tramp_conv* cv, double* partial, int dir, size_t batch, const double* az_d,
                  const double* ax_d, double damping, const double* a_old, double* v_d, double* a_new_d,
-                 double* a_raw, double* n_eff_d) {
+                 double* a_raw, double* n_eff_d, double fwd_div = 1.0) {
     hipLaunchKernelGGL(conv_neff_partial_kernel, dim3((unsigned)cv->nblk, (unsigned)batch), dim3(kBlock), 0,
                        ctx->stream, cv->s2, cv->nh, cv->nhl, cv->nlast, az_d, ax_d, partial);
     hipLaunchKernelGGL(conv_variance_kernel, dim3((unsigned)batch), dim3(kWave), 0, ctx->stream, partial,
-                       cv->nblk, (double)cv->n, cv->s_mean, dir, az_d, ax_d, damping, a_old, v_d, a_new_d, a_raw,
-                       n_eff_d, batch);
+                       cv->nblk, (double)cv->n, cv->s_mean, fwd_div, dir, az_d, ax_d, damping, a_old, v_d, a_new_d,
+                       a_raw, n_eff_d, batch);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
@@ -824,6 +825,349 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
                                (double*)b_new_d, (double*)nullptr);
         else
             hipLaunchKernelGGL((conv_epilogue_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n, a_in, cv->a_raw,
+                               (const float*)b_in, damping, (const float*)b_old_d, (const float*)mean,
+                               (float*)b_new_d, (float*)nullptr);
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    return TRAMP_OK;
+}
+
+// ---------------------------------------------------------------- gradient channel x = grad z
+// GradientChannel (tramp/channels/linear/gradient_channel.py:10-118, real=True): d = ndim circular
+// forward-difference filters f_i, x = (x_1 .. x_d) with x_i = w_i * z, fft(w_i) = conj(fft(f_i)).  It is
+// diagonal in the Fourier basis like the convolution channel, with the resolvent built on the SUMMED
+// spectrum s = sum_i |fft(f_i)|^2:
+//     rz_fft = (fft(bz) + sum_i fft(f_i) fft(bx_i)) / (az + ax s),   rx_i = ifft(conj(fft(f_i)) rz_fft),
+//     n_eff = mean(s / (az/ax + s)),  vz = (1 - n_eff) / az,  vx = n_eff / (ax d).
+// Vectors: z is [batch, n], x is [batch, d, n] (the reference's (d,) + shape, flattened).  The handle embeds
+// a tramp_conv for the shape / half-spectrum geometry, the summed spectrum, the n_eff kernels and the
+// rocFFT plan cache (batch and batch * d transforms of the same shape).
+struct tramp_grad {
+    tramp_conv base;
+    int d;
+    void* wbar_all;             // [d][nh] complex of dtype: fft(f_i)
+    void* gwork;                // fz [B,nh], fx [B,d,nh], fo [B,d,nh], fr [B,d,n], a_raw [B], partial
+    size_t gwork_batch;
+    void* gfz;
+    void* gfx;
+    void* gfo;
+    void* gfr;
+    double* ga_raw;
+    double* gpartial;
+};
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grad_setup_kernel(const double2* __restrict__ w64, int d, size_t nh,
+                                                            typename Cx<T>::type* __restrict__ wbar,
+                                                            double* __restrict__ s2) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nh) return;
+    double s = 0.0;
+    for (int c = 0; c < d; ++c) {
+        const double2 w = w64[(size_t)c * nh + i];
+        typename Cx<T>::type o;
+        o.x = (T)w.x;
+        o.y = (T)w.y;
+        wbar[(size_t)c * nh + i] = o;
+        s += w.x * w.x + w.y * w.y;                                    // gradient_channel.py:23 (sum over axis 0)
+    }
+    s2[i] = s;
+}
+
+// mode 0: fo[b,c,:] = conj(wbar_c) rz_fft / n (forward mean), 1: fo[b,:] = rz_fft / n (backward mean),
+// 2: fo[b,c,:] = conj(wbar_c) fz / n (x = grad z, sampling)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grad_spectral_kernel(int mode, int d, size_t nh, double inv_n,
+                                                               const typename Cx<T>::type* __restrict__ wbar,
+                                                               const double* __restrict__ s2,
+                                                               const double* __restrict__ az_d,
+                                                               const double* __restrict__ ax_d,
+                                                               const typename Cx<T>::type* __restrict__ fz,
+                                                               const typename Cx<T>::type* __restrict__ fx,
+                                                               typename Cx<T>::type* __restrict__ fo) {
+    using C = typename Cx<T>::type;
+    const size_t b = blockIdx.y;
+    const double az = (mode == 2) ? 0.0 : az_d[b];
+    const double ax = (mode == 2) ? 0.0 : ax_d[b];
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nh; i += (size_t)gridDim.x * kBlock) {
+        C rz = fz[b * nh + i];
+        if (mode != 2) {
+            for (int c = 0; c < d; ++c) {
+                const C w = wbar[(size_t)c * nh + i];
+                const C x = fx[(b * d + c) * nh + i];
+                rz.x += w.x * x.x - w.y * x.y;                         // :67 w_fft_bar * bx_fft, summed over axis 0
+                rz.y += w.x * x.y + w.y * x.x;
+            }
+            const T res = (T)(inv_n / (az + ax * s2[i]));              // :66
+            rz.x *= res;
+            rz.y *= res;
+        } else {
+            rz.x *= (T)inv_n;
+            rz.y *= (T)inv_n;
+        }
+        if (mode == 1) fo[b * nh + i] = rz;
+        else
+            for (int c = 0; c < d; ++c) {
+                const C w = wbar[(size_t)c * nh + i];
+                C o;
+                o.x = w.x * rz.x + w.y * rz.y;                         // w_fft = conj(w_fft_bar), :78
+                o.y = w.x * rz.y - w.y * rz.x;
+                fo[(b * d + c) * nh + i] = o;
+            }
+    }
+}
+
+int grad_reserve(tramp_ctx* ctx, tramp_grad* g, size_t batch) {
+    if (batch <= g->gwork_batch) return TRAMP_OK;
+    if (ctx->capturing) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_grad", "workspace growth inside graph capture");
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (g->gwork) (void)hipFree(g->gwork);
+    g->gwork = nullptr;
+    g->gwork_batch = 0;
+    const tramp_conv* cv = &g->base;
+    const size_t csz = 2 * dtype_size(cv->dtype);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t per = up(batch * cv->nh * csz);
+    const size_t perd = up(batch * g->d * cv->nh * csz);
+    const size_t rper = up(batch * g->d * cv->n * dtype_size(cv->dtype));
+    const size_t scal = up(batch * sizeof(double));
+    const size_t part = up(batch * (size_t)cv->nblk * sizeof(double));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&g->gwork, per + 2 * perd + rper + scal + part));
+    char* p = (char*)g->gwork;
+    g->gfz = p;
+    g->gfx = p + per;
+    g->gfo = p + per + perd;
+    g->gfr = p + per + 2 * perd;
+    g->ga_raw = (double*)(p + per + 2 * perd + rper);
+    g->gpartial = (double*)(p + per + 2 * perd + rper + scal);
+    g->gwork_batch = batch;
+    return TRAMP_OK;
+}
+
+template <typename T>
+void launch_grad_spectral(tramp_ctx* ctx, tramp_grad* g, int mode, size_t batch, const double* az_d,
+                          const double* ax_d) {
+    using C = typename Cx<T>::type;
+    const tramp_conv* cv = &g->base;
+    hipLaunchKernelGGL((grad_spectral_kernel<T>), dim3(grid_for(cv->nh), (unsigned)batch), dim3(kBlock), 0, ctx->stream,
+                       mode, g->d, cv->nh, 1.0 / cv->n, (const C*)g->wbar_all, cv->s2, az_d, ax_d, (const C*)g->gfz,
+                       (const C*)g->gfx, (C*)g->gfo);
+}
+
+}  // namespace
+
+extern "C" int tramp_grad_destroy(tramp_ctx* ctx, tramp_grad* g) {
+    if (!g) return TRAMP_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : g->base.plans) {
+        (void)rocfft_execution_info_destroy(p.info_fwd);
+        (void)rocfft_execution_info_destroy(p.info_inv);
+        (void)rocfft_plan_destroy(p.fwd);
+        (void)rocfft_plan_destroy(p.inv);
+        if (p.work_fwd) (void)hipFree(p.work_fwd);
+        if (p.work_inv) (void)hipFree(p.work_inv);
+    }
+    if (g->gwork) (void)hipFree(g->gwork);
+    if (g->wbar_all) (void)hipFree(g->wbar_all);
+    if (g->base.s2) (void)hipFree(g->base.s2);
+    delete g;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_grad_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filters_d,
+                                 tramp_grad** grad) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, grad && dims && filters_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F64 || dtype == TRAMP_F32);
+    TRAMP_REQUIRE(ctx, ndim >= 1 && ndim <= 3);
+    std::call_once(g_rocfft_once, [] { (void)rocfft_setup(); });
+    tramp_grad* g = new tramp_grad();
+    tramp_conv* cv = &g->base;
+    g->d = ndim;
+    g->wbar_all = g->gwork = nullptr;
+    g->gwork_batch = 0;
+    cv->dtype = dtype;
+    cv->ndim = ndim;
+    cv->n = 1;
+    for (int a = 0; a < ndim; ++a) {
+        if (dims[a] == 0) {
+            delete g;
+            return tramp_fail(ctx, TRAMP_EINVAL, "tramp_grad_create", "zero-length axis");
+        }
+        cv->dims[a] = dims[a];
+        cv->n *= dims[a];
+    }
+    cv->nlast = dims[ndim - 1];
+    cv->nhl = cv->nlast / 2 + 1;
+    cv->nh = cv->n / cv->nlast * cv->nhl;
+    cv->nblk = (int)((cv->nh + 4095) / 4096 > 256 ? 256 : (cv->nh + 4095) / 4096);
+    cv->work = nullptr;
+    cv->work_batch = cv->proj_batch = 0;
+    cv->wbar = nullptr;
+    cv->s2 = nullptr;
+    cv->fft2 = nullptr;                                               // rocFFT engine only
+    cv->h = 0;
+    cv->wbar_p = nullptr;
+    cv->s2_p = nullptr;
+    cv->partner = nullptr;
+    cv->leaders = nullptr;
+    cv->nlead = 0;
+    cv->wk = nullptr;
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* pwork = nullptr;
+    double2* w64 = nullptr;
+    auto cleanup = [&](bool failed) {
+        if (w64) (void)hipFree(w64);
+        if (pwork) (void)hipFree(pwork);
+        if (info) (void)rocfft_execution_info_destroy(info);
+        if (plan) (void)rocfft_plan_destroy(plan);
+        if (failed) (void)tramp_grad_destroy(nullptr, g);
+    };
+    int rc = make_plan(ctx, cv, true, true, (size_t)ndim, &plan, &info, &pwork);
+    if (rc) {
+        cleanup(true);
+        return rc;
+    }
+    const size_t csz = 2 * dtype_size(dtype);
+    hipError_t e = hipMalloc(&w64, (size_t)ndim * cv->nh * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&g->wbar_all, (size_t)ndim * cv->nh * csz);
+    if (e == hipSuccess) e = hipMalloc(&cv->s2, cv->nh * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        cleanup(true);
+        return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_grad_create", hipGetErrorString(e));
+    }
+    rc = fft_exec(ctx, plan, info, filters_d, w64);
+    if (rc) {
+        cleanup(true);
+        return rc;
+    }
+    const unsigned gr = (unsigned)((cv->nh + kBlock - 1) / kBlock);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((grad_setup_kernel<double>), dim3(gr), dim3(kBlock), 0, ctx->stream, w64, ndim, cv->nh,
+                           (double2*)g->wbar_all, cv->s2);
+    else
+        hipLaunchKernelGGL((grad_setup_kernel<float>), dim3(gr), dim3(kBlock), 0, ctx->stream, w64, ndim, cv->nh,
+                           (float2*)g->wbar_all, cv->s2);
+    std::vector<double> s2h(cv->nh);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(s2h.data(), cv->s2, cv->nh * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        cleanup(true);
+        return tramp_fail(ctx, TRAMP_EHIP, "tramp_grad_create", hipGetErrorString(e));
+    }
+    long double acc = 0.0L;
+    for (size_t i = 0; i < cv->nh; ++i) {
+        const size_t j = i % cv->nhl;
+        acc += ((j == 0 || 2 * j == cv->nlast) ? 1.0L : 2.0L) * (long double)s2h[i];
+    }
+    cv->s_mean = (double)(acc / (long double)cv->n);
+    cleanup(false);
+    *grad = g;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_grad_spectrum(tramp_ctx* ctx, const tramp_grad* g, double* s2_d, size_t* count, double* mean) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, g);
+    return tramp_conv_spectrum(ctx, &g->base, s2_d, count, mean);
+}
+
+extern "C" int tramp_grad_variance(tramp_ctx* ctx, tramp_grad* g, int dir, size_t batch, const double* az_d,
+                                   const double* ax_d, double* v_d, double* a_new_d, double* n_eff_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, g && az_d && ax_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    if (!batch) return TRAMP_OK;
+    int rc = tramp_ws_reserve(ctx, batch * (size_t)g->base.nblk * sizeof(double));
+    if (rc) return rc;
+    return conv_scalars(ctx, &g->base, ctx->ws, dir, batch, az_d, ax_d, 0.0, nullptr, v_d, a_new_d, nullptr, n_eff_d,
+                        (double)g->d);
+}
+
+extern "C" int tramp_grad_apply(tramp_ctx* ctx, tramp_grad* g, size_t batch, const void* z_d, void* x_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, g && z_d && x_d);
+    if (!batch) return TRAMP_OK;
+    int rc = grad_reserve(ctx, g, batch);
+    if (rc) return rc;
+    ConvPlans *p1 = nullptr, *pd = nullptr;
+    rc = plans_for(ctx, &g->base, batch, &p1);
+    if (rc) return rc;
+    rc = fft_exec(ctx, p1->fwd, p1->info_fwd, z_d, g->gfz);
+    if (rc) return rc;
+    if (g->base.dtype == TRAMP_F64) launch_grad_spectral<double>(ctx, g, 2, batch, nullptr, nullptr);
+    else launch_grad_spectral<float>(ctx, g, 2, batch, nullptr, nullptr);
+    TRAMP_LAUNCH_CHECK(ctx);
+    rc = plans_for(ctx, &g->base, batch * g->d, &pd);                  // may move p1: looked up after its last use
+    if (rc) return rc;
+    return fft_exec(ctx, pd->inv, pd->info_inv, g->gfo, x_d);
+}
+
+extern "C" int tramp_grad_message(tramp_ctx* ctx, tramp_grad* g, int dir, size_t batch, const double* az_d,
+                                  const void* bz_d, const double* ax_d, const void* bx_d, double damping,
+                                  const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d,
+                                  void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, g && az_d && bz_d && ax_d && bx_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!batch) return TRAMP_OK;
+    int rc = grad_reserve(ctx, g, batch);
+    if (rc) return rc;
+    tramp_conv* cv = &g->base;
+    const size_t d = (size_t)g->d, n = cv->n, nh = cv->nh, esz = dtype_size(cv->dtype);
+    {
+        ProfScope ps(ctx, PROF_LIN_SCALARS, 0, 0);
+        rc = conv_scalars(ctx, cv, g->gpartial, dir, batch, az_d, ax_d, damping, a_old_d, v_d, a_new_d, g->ga_raw,
+                          nullptr, (double)g->d);
+        if (rc) return rc;
+    }
+    ConvPlans* p = nullptr;
+    {
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (d + 1) * (n * esz + nh * 2 * esz), 0);
+        rc = plans_for(ctx, cv, batch, &p);
+        if (rc) return rc;
+        rc = fft_exec(ctx, p->fwd, p->info_fwd, bz_d, g->gfz);
+        if (rc) return rc;
+        rc = plans_for(ctx, cv, batch * d, &p);
+        if (rc) return rc;
+        rc = fft_exec(ctx, p->fwd, p->info_fwd, bx_d, g->gfx);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, PROF_LIN_SCALARS, (double)batch * nh * (2 * d + 2) * 2 * esz, 0);
+        const int mode = (dir == TRAMP_FWD) ? 0 : 1;
+        if (cv->dtype == TRAMP_F64) launch_grad_spectral<double>(ctx, g, mode, batch, az_d, ax_d);
+        else launch_grad_spectral<float>(ctx, g, mode, batch, az_d, ax_d);
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    const bool fwd = dir == TRAMP_FWD;
+    const size_t len = fwd ? d * n : n;                               // target vector length per instance
+    const double* a_in = fwd ? ax_d : az_d;
+    const void* b_in = fwd ? bx_d : bz_d;
+    void* mean = r_d ? r_d : (damping != 0.0 ? g->gfr : b_new_d);
+    {
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (fwd ? d : 1) * (n * esz + nh * 2 * esz), 0);
+        rc = plans_for(ctx, cv, fwd ? batch * d : batch, &p);
+        if (rc) return rc;
+        rc = fft_exec(ctx, p->inv, p->info_inv, g->gfo, mean);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, PROF_EW, (double)batch * len * esz * (damping != 0.0 ? 4 : 3), 0);
+        dim3 gr(grid_for(len), (unsigned)batch);
+        if (cv->dtype == TRAMP_F64)
+            hipLaunchKernelGGL((conv_epilogue_kernel<double>), gr, dim3(kBlock), 0, ctx->stream, len, a_in, g->ga_raw,
+                               (const double*)b_in, damping, (const double*)b_old_d, (const double*)mean,
+                               (double*)b_new_d, (double*)nullptr);
+        else
+            hipLaunchKernelGGL((conv_epilogue_kernel<float>), gr, dim3(kBlock), 0, ctx->stream, len, a_in, g->ga_raw,
                                (const float*)b_in, damping, (const float*)b_old_d, (const float*)mean,
                                (float*)b_new_d, (float*)nullptr);
         TRAMP_LAUNCH_CHECK(ctx);

@@ -997,6 +997,59 @@ extern "C" int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, dou
     return TRAMP_OK;
 }
 
+// ---------------------------------------------------------------- variable -> factor message on a tree
+// Variable.forward_message / backward_message (tramp/base.py:186-211): the message a variable of degree
+// k sends to one neighbour is the sum of ALL its incoming messages minus that neighbour's own,
+// (a_hat - a_l, b_hat - b_l), in that order of operations.
+constexpr int kMaxMsgs = 8;
+struct MsgPtrs {
+    const double* a[kMaxMsgs];
+    const void* b[kMaxMsgs];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void message_sum_kernel(size_t n, int k, int exclude, MsgPtrs in,
+                                                             double* __restrict__ a_out, T* __restrict__ b_out) {
+    const size_t b = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        T s = T(0);
+        for (int j = 0; j < k; ++j) s += static_cast<const T*>(in.b[j])[b * n + i];
+        if (exclude >= 0) s -= static_cast<const T*>(in.b[exclude])[b * n + i];
+        b_out[b * n + i] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += in.a[j][b];
+        if (exclude >= 0) s -= in.a[exclude][b];
+        a_out[b] = s;
+    }
+}
+
+extern "C" int tramp_message_sum(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k,
+                                 const double* const* a_in_d, const void* const* b_in_d, int exclude,
+                                 double* a_out_d, void* b_out_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, a_in_d && b_in_d && a_out_d && b_out_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, k >= 1 && k <= kMaxMsgs && exclude < k);
+    if (!n || !batch) return TRAMP_OK;
+    MsgPtrs in{};
+    for (int j = 0; j < k; ++j) {
+        TRAMP_REQUIRE(ctx, a_in_d[j] && b_in_d[j]);
+        in.a[j] = a_in_d[j];
+        in.b[j] = b_in_d[j];
+    }
+    dim3 grid(blocks_for(n, 1), (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((message_sum_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, k, exclude, in,
+                           a_out_d, (double*)b_out_d);
+    else
+        hipLaunchKernelGGL((message_sum_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, k, exclude, in,
+                           a_out_d, (float*)b_out_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void sq_dist_kernel(size_t n, const T* __restrict__ x,
                                                          const T* __restrict__ y, double* __restrict__ partials) {

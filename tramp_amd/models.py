@@ -1,7 +1,7 @@
 """Model / graph algebra (host orchestration, CPU).
 
 Minimal counterpart of tramp/models/{dag_algebra,base_model,generalized_linear_model,
-multi_layer_model}.py for tree-structured models built with ``@``: a bipartite DAG
+multi_layer_model}.py for tree-structured models built with ``@`` and ``+``: a bipartite DAG
 of Factor and Variable nodes held in a networkx DiGraph (networkx >= 2 API; the
 reference needs networkx 1.x), topological order, shape and
 second-moment propagation, channel -> likelihood conversion for observed leaves,
@@ -11,7 +11,7 @@ import networkx as nx
 import numpy as np
 
 from .base import Factor, Variable
-from .channels import (ConvChannel, DFTChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
+from .channels import (ConvChannel, DFTChannel, GradientChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
                        PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
@@ -43,42 +43,95 @@ def channel2likelihood(channel, y, y_name):
     raise NotImplementedError(f"cannot convert {channel} to likelihood")
 
 
-class DAG:
-    """Chain of nodes composed with ``@`` (tramp/models/dag_algebra.py:91-173)."""
+class _Stub:
+    "dangling end of an edge while a graph is being composed (a node's unconnected input or output)"
+    __slots__ = ("kind",)
 
-    def __init__(self, node_or_nodes):
-        self.nodes = list(node_or_nodes) if isinstance(node_or_nodes, (list, tuple)) else [node_or_nodes]
+    def __init__(self, kind):
+        self.kind = kind
+
+
+class DAG:
+    """Composition algebra of tramp/models/dag_algebra.py:91-130 on a networkx DiGraph.
+
+    A single node enters with one dangling stub per missing predecessor / successor.  ``A + B``
+    places two graphs side by side (their dangling ends are listed left to right); ``A @ B``
+    additionally splices A's dangling outputs onto B's dangling inputs, pairwise in that order.
+    A list of nodes is the chain n0 @ n1 @ ...
+    """
+
+    def __init__(self, obj):
+        if isinstance(obj, DAG):
+            self.g, self.ins, self.outs = obj.g, obj.ins, obj.outs
+            return
+        if isinstance(obj, (list, tuple)):
+            d = DAG(obj[0])
+            for node in obj[1:]:
+                d = d @ node
+            self.g, self.ins, self.outs = d.g, d.ins, d.outs
+            return
+        g = nx.DiGraph()
+        g.add_node(obj)
+        self.ins = [_Stub("in") for _ in range(obj.n_prev)]
+        self.outs = [_Stub("out") for _ in range(obj.n_next)]
+        for st in self.ins:
+            g.add_edge(st, obj)
+        for st in self.outs:
+            g.add_edge(obj, st)
+        self.g = g
+
+    @classmethod
+    def _of(cls, g, ins, outs):
+        d = cls.__new__(cls)
+        d.g, d.ins, d.outs = g, ins, outs
+        return d
+
+    def __add__(self, other):
+        other = other if isinstance(other, DAG) else DAG(other)
+        return DAG._of(nx.compose(self.g, other.g), self.ins + other.ins, self.outs + other.outs)
 
     def __matmul__(self, other):
-        if not isinstance(other, DAG):
-            other = DAG(other)
-        return DAG(self.nodes + other.nodes)
+        other = other if isinstance(other, DAG) else DAG(other)
+        g = nx.compose(self.g, other.g)
+        k = min(len(self.outs), len(other.ins))
+        for out_stub, in_stub in zip(self.outs[:k], other.ins[:k]):
+            (src,) = g.predecessors(out_stub)
+            (dst,) = g.successors(in_stub)
+            g.remove_node(out_stub)
+            g.remove_node(in_stub)
+            if isinstance(src, Factor) == isinstance(dst, Factor):
+                raise ValueError(f"{src} @ {dst}: factors and variables must alternate")
+            g.add_edge(src, dst)
+        return DAG._of(g, self.ins + other.ins[k:], other.outs + self.outs[k:])
+
+    @property
+    def nodes(self):
+        return [n for n in nx.topological_sort(self.g) if not isinstance(n, _Stub)]
 
     def to_model(self):
         return Model(self)
 
 
 class Model:
-    """tramp/models/base_model.py:28-148 for SISO chains."""
+    """tramp/models/base_model.py:28-148 for tree-structured (bipartite, acyclic) models."""
 
     def __init__(self, dag):
-        if isinstance(dag, DAG):
-            nodes = dag.nodes
-        else:
-            nodes = list(dag)
-        g = nx.DiGraph()
-        for u, v in zip(nodes[:-1], nodes[1:]):
-            if isinstance(u, Factor) == isinstance(v, Factor):
-                raise ValueError(f"{u} @ {v}: factors and variables must alternate")
-            g.add_edge(u, v)
-        if len(nodes) == 1:
-            g.add_node(nodes[0])
+        dag = dag if isinstance(dag, DAG) else DAG(list(dag))
+        if dag.ins or dag.outs:
+            raise ValueError(f"model graph has {len(dag.ins)} unconnected inputs and {len(dag.outs)} "
+                             "unconnected outputs")
+        g = dag.g
         if not nx.is_directed_acyclic_graph(g):
             raise ValueError("model graph is not a DAG")
         for node in g.nodes:
             if g.in_degree(node) != node.n_prev or g.out_degree(node) != node.n_next:
                 raise ValueError(f"node {node} has {g.in_degree(node)} predecessors / "
                                  f"{g.out_degree(node)} successors, expected {node.n_prev} / {node.n_next}")
+            for nb in list(g.predecessors(node)) + list(g.successors(node)):
+                if isinstance(nb, Factor) == isinstance(node, Factor):
+                    raise ValueError(f"{nb} - {node}: factors and variables must alternate")
+        if g.number_of_nodes() and not nx.is_tree(g.to_undirected()):
+            raise ValueError("model graph is not a tree (loopy or disconnected)")
         self.dag = g
         self.forward_ordering = list(nx.topological_sort(g))
         self.variables = [n for n in self.forward_ordering if isinstance(n, Variable)]
@@ -90,8 +143,16 @@ class Model:
             f.id = f"f_{idx}"                                   # base_model.py:23-25
         self.n_variables = len(self.variables)
         self.n_factors = len(self.factors)
+        self.is_chain = all(v.n_prev == 1 and v.n_next <= 1 for v in self.variables) and \
+            all(f.n_prev <= 1 and f.n_next <= 1 for f in self.factors)
 
     # -- structure helpers for the scheduler
+    def prev_factors(self, variable):
+        return list(self.dag.predecessors(variable))
+
+    def next_factors(self, variable):
+        return list(self.dag.successors(variable))
+
     def prev_factor(self, variable):
         return next(iter(self.dag.predecessors(variable)))
 
@@ -101,65 +162,71 @@ class Model:
 
     def to_observed(self, observations):
         "tramp/models/dag_algebra.py:243-291: observed leaf + its channel -> likelihood"
-        nodes = []
-        order = self.forward_ordering
-        for i, node in enumerate(order):
-            if isinstance(node, Variable) and node.id in observations:
-                if node.n_next != 0:
-                    raise ValueError(f"{node} not a leaf")
+        g = self.dag.copy()
+        for var in self.variables:
+            if var.id not in observations:
                 continue
-            if isinstance(node, Factor) and i + 1 < len(order) and \
-                    isinstance(order[i + 1], Variable) and order[i + 1].id in observations:
-                vid = order[i + 1].id
-                nodes.append(channel2likelihood(node, y=observations[vid], y_name=vid))
-            else:
-                nodes.append(node)
-        return Model(DAG(nodes))
+            if var.n_next != 0 or var.n_prev != 1:
+                raise ValueError(f"{var} not a single-input leaf")
+            (channel,) = g.predecessors(var)
+            lik = channel2likelihood(channel, y=observations[var.id], y_name=var.id)
+            preds = list(g.predecessors(channel))
+            g.remove_node(var)
+            g.remove_node(channel)
+            for p in preds:
+                g.add_edge(p, lik)
+        return Model(DAG._of(g, [], []))
 
     def sample(self, seed=0):
-        "Forward sampling (base_model.py:71-94)"
+        "Forward sampling (base_model.py:71-94): each factor samples its successors from its predecessors"
         if seed != 0:
             np.random.seed(seed)
         X = {}
-        prev = None
         for node in self.forward_ordering:
-            if isinstance(node, Factor):
-                if node.n_next == 0:
-                    continue
-                prev = node.sample() if node.n_prev == 0 else node.sample(prev)
-            else:
-                X[node.id] = prev
+            if not isinstance(node, Factor) or node.n_next == 0:
+                continue
+            args = [X[p.id] for p in self.dag.predecessors(node)]
+            val = node.sample(*args)
+            for succ in self.dag.successors(node):
+                X[succ.id] = val
         return X
+
+    def _out_shape(self, factor, in_shape):
+        if isinstance(factor, Prior):
+            return (factor.size,) if np.isscalar(factor.size) else tuple(factor.size)
+        if isinstance(factor, LinearChannel):
+            return (factor.Nx,)
+        if isinstance(factor, ConvChannel):
+            return tuple(factor.shape)
+        if isinstance(factor, GradientChannel):
+            return (factor.d,) + tuple(factor.shape)
+        if isinstance(factor, DFTChannel):
+            return (2,) + tuple(in_shape)
+        return in_shape
 
     def init_shapes(self):
         "base_model.py:96-109 (shapes from the factors' geometry rather than a dry-run sample)"
         shapes = {}
-        shape = None
         for node in self.forward_ordering:
-            if isinstance(node, Prior):
-                shape = (node.size,) if np.isscalar(node.size) else tuple(node.size)
-            elif isinstance(node, LinearChannel):
-                shape = (node.Nx,)
-            elif isinstance(node, ConvChannel):
-                shape = tuple(node.shape)
-            elif isinstance(node, DFTChannel):
-                shape = (2,) + tuple(shape)
-            if isinstance(node, Variable):
-                shapes[node.id] = shape
-                self.dag.nodes[node]["shape"] = shape
-        return shapes
+            if isinstance(node, Factor) and node.n_next:
+                preds = list(self.dag.predecessors(node))
+                shape = self._out_shape(node, shapes[preds[0].id] if preds else None)
+                for succ in self.dag.successors(node):
+                    shapes[succ.id] = shape
+                    self.dag.nodes[succ]["shape"] = shape
+        return {v.id: shapes[v.id] for v in self.variables}
 
     def get_shapes(self):
         return {v.id: self.dag.nodes[v].get("shape") for v in self.variables}
 
     def init_second_moments(self):
         "base_model.py:111-124"
-        tau = None
         for node in self.forward_ordering:
             if isinstance(node, Factor) and node.n_next:
-                tau = node.second_moment() if node.n_prev == 0 else node.second_moment(tau)
-            elif isinstance(node, Variable):
-                self.dag.nodes[node]["tau"] = tau
+                taus = [self.dag.nodes[p]["tau"] for p in self.dag.predecessors(node)]
+                tau = node.second_moment(*taus)
+                for succ in self.dag.successors(node):
+                    self.dag.nodes[succ]["tau"] = tau
 
     def get_second_moments(self):
         return {v.id: self.dag.nodes[v].get("tau") for v in self.variables}

@@ -1,0 +1,232 @@
+"""Expectation propagation on tree-structured models (variables with several incoming or outgoing
+factors): the schedule of tramp/algos/message_passing.py:249-269 with the variable nodes'
+messages made explicit.
+
+On a chain a SISO variable just relays its two factors' messages, which is what
+`ExpectationPropagation` exploits (no copies).  On a tree a variable of degree k sends each
+neighbour the sum of its incoming messages minus that neighbour's own
+(`Variable.forward_message / backward_message`, tramp/base.py:186-211), *at the moment the sweep
+visits the variable*; a factor later reads that stored value, not the live one (for a leaf with two
+parents this matters: each parent sees the other's message as of the variable's last visit).  So
+every factor-variable adjacency carries two buffers here, factor->variable and variable->factor,
+and the sweeps visit all nodes in topological order, variables included.
+
+Factor updates are the same device calls as on a chain; the variable->factor messages are one
+`tramp_message_sum` launch (or a device copy when the variable has two neighbours).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .algos import ExpectationPropagation
+from .base import Factor, Variable
+from .device import default_context, dtype_code
+from .likelihoods import GaussianLikelihood
+from .priors import GaussianPrior
+
+
+class _Msg:
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+
+class TreeExpectationPropagation(ExpectationPropagation):
+    """Gaussian EP on a tree of factors and variables (tramp/algos/expectation_propagation.py:5-32)."""
+
+    def __init__(self, model, batch=None, ctx=None):
+        self.model = model
+        self.shapes = model.init_shapes()
+        self.variables = model.variables
+        self.factors = model.factors
+        for f in self.factors:
+            if f.n_prev > 1 or f.n_next > 1:
+                raise ValueError(f"{f}: factors with several inputs or outputs are outside the HIP path")
+        for v in self.variables:
+            if v.n_prev == 0:
+                raise ValueError(f"variable {v.id} has no incoming factor")
+            if v.n_prev + v.n_next < 2:
+                raise ValueError(f"variable {v.id} is attached to a single factor; call model.to_observed(...) "
+                                 "for observed leaves")
+        dev_factors = [f for f in self.factors if hasattr(f, "_dt")]
+        dts = {f.dtype for f in dev_factors}
+        if len(dts) != 1:
+            raise ValueError(f"all factors must compute in the same dtype, got {dts}")
+        self.dtype = dts.pop()
+        self.ctx = ctx or next((f._ctx for f in dev_factors if f._ctx is not None), None) or default_context()
+        for f in dev_factors:
+            f._ctx = self.ctx
+        if batch is None:
+            batch = 1
+            for f in self.factors:
+                yd = getattr(f, "_y_dev", None)
+                if yd is not None:
+                    batch = yd.shape[0]
+        self.batch = int(batch)
+        self.n_iter = 0
+        self.n_iter_instance = np.zeros(self.batch, dtype=int)
+        self._allocated = False
+        self._frozen_r = None
+        from .algos import EarlyStoppingEP
+        self.default_stopping = EarlyStoppingEP()
+
+    # -- storage: one (a, b) pair per directed factor<->variable message
+    def _allocate(self):
+        ctx, B, L = self.ctx, self.batch, len(self.variables)
+        g = self.model.dag
+        self.adj = {v: list(g.predecessors(v)) + list(g.successors(v)) for v in self.variables}
+        keys = []
+        for v in self.variables:
+            for f in self.adj[v]:
+                keys += [(f, v), (v, f)]
+        self.msg_keys = keys
+        self.A = ctx.zeros((len(keys), B), np.float64)
+        self.S = ctx.zeros((3 * L, B), np.float64)
+        self.msg = {}
+        for i, (src, dst) in enumerate(keys):
+            var = src if isinstance(src, Variable) else dst
+            n = int(np.prod(self.shapes[var.id]))
+            b = ctx.zeros((B, n), self.dtype)
+            b.version = 0
+            self.msg[(src, dst)] = _Msg(self.A.row(i), b)
+        self.r = [ctx.zeros((B, int(np.prod(self.shapes[v.id]))), self.dtype) for v in self.variables]
+        self._const_msg = {}
+        self._const_done = set()
+        self._allocated = True
+
+    def init_message_dag(self, initializer):
+        "message_passing.py:211-232: every message of both directions starts at the initializer's (a, b)"
+        if not self._allocated:
+            self._allocate()
+        g = self.model.dag
+        for (src, dst), m in self.msg.items():
+            var = src if isinstance(src, Variable) else dst
+            direction = "fwd" if g.has_edge(src, dst) else "bwd"
+            shape = self.shapes[var.id]
+            m.a.fill(initializer.init_a(shape, var.id, direction))
+            m.b.fill(initializer.init_b(shape, var.id, direction))
+            m.b.version += 1
+        for r in self.r:
+            r.fill(0.0)
+        self._const_done = set()
+
+    # -- node updates
+    def _factor_send(self, f, direction):
+        g = self.model.dag
+        prev = next(iter(g.predecessors(f)), None)
+        nxt = next(iter(g.successors(f)), None)
+        target = nxt if direction == "fwd" else prev
+        if target is None:
+            return
+        out = self.msg[(f, target)]
+        d = self.damping
+        const = isinstance(f, (GaussianPrior, GaussianLikelihood))
+        inp = self.msg[(target, f)]
+        if const and not d and (f, direction) in self._const_done:
+            return
+        if const and d:
+            # constant message under damping: computed once, then msg <- d msg + (1 - d) c (as on the chain)
+            if (f, direction) not in self._const_msg:
+                ca = self.ctx.empty((self.batch,), np.float64)
+                cb = self.ctx.empty(tuple(out.b.shape), self.dtype)
+                if f.n_prev == 0:
+                    f.compute_forward_message(inp.a, inp.b, out_a=ca, out_b=cb)
+                else:
+                    f.compute_backward_message(inp.a, inp.b, out_a=ca, out_b=cb)
+                self._const_msg[(f, direction)] = (ca, cb)
+            ca, cb = self._const_msg[(f, direction)]
+            self.ctx._call("tramp_damp", dtype_code(self.dtype), out.b.shape[1], self.batch, 1.0 - float(d),
+                           ca.ptr, cb.ptr, out.a.ptr, out.b.ptr)
+            out.b.version += 1
+            return
+        kw = dict(out_a=out.a, out_b=out.b)
+        if d:
+            kw.update(damping=d, old_a=out.a, old_b=out.b)
+        if f.n_prev == 0:
+            f.compute_forward_message(inp.a, inp.b, **kw)
+        elif f.n_next == 0:
+            f.compute_backward_message(inp.a, inp.b, **kw)
+        else:
+            z, x = self.msg[(prev, f)], self.msg[(nxt, f)]
+            if direction == "fwd":
+                f.compute_forward_message(z.a, z.b, x.a, x.b, **kw)
+            else:
+                f.compute_backward_message(z.a, z.b, x.a, x.b, **kw)
+        out.b.version += 1
+        if const and not d:
+            self._const_done.add((f, direction))
+
+    def _variable_send(self, v, targets):
+        "Variable.forward_message / backward_message (tramp/base.py:186-211)"
+        nbrs = self.adj[v]
+        inc = [self.msg[(f, v)] for f in nbrs]
+        for f in targets:
+            out = self.msg[(v, f)]
+            if len(nbrs) == 2:
+                other = inc[1 - nbrs.index(f)]
+                out.a.copy_from(other.a)
+                out.b.copy_from(other.b)
+            else:
+                k = len(nbrs)
+                ap = (C.c_void_p * k)(*[m.a.ptr for m in inc])
+                bp = (C.c_void_p * k)(*[m.b.ptr for m in inc])
+                self.ctx._call("tramp_message_sum", dtype_code(self.dtype), out.b.shape[1], self.batch, k, ap, bp,
+                               nbrs.index(f), out.a.ptr, out.b.ptr)
+            out.b.version += 1
+
+    def forward_message(self):
+        "message_passing.py:249-255"
+        g = self.model.dag
+        for node in self.model.forward_ordering:
+            if isinstance(node, Factor):
+                self._factor_send(node, "fwd")
+            else:
+                self._variable_send(node, list(g.successors(node)))
+
+    def backward_message(self):
+        "message_passing.py:257-263"
+        g = self.model.dag
+        for node in reversed(self.model.forward_ordering):
+            if isinstance(node, Factor):
+                self._factor_send(node, "bwd")
+            else:
+                self._variable_send(node, list(g.predecessors(node)))
+
+    def update_variables(self):
+        """message_passing.py:265-269: after the backward sweep the message a variable sent to its first
+        parent is the sum of everything else, so posterior = (parent -> v) + (v -> parent)."""
+        dt = dtype_code(self.dtype)
+        for i, v in enumerate(self.variables):
+            f = self.adj[v][0]
+            fv, vf = self.msg[(f, v)], self.msg[(v, f)]
+            n = self.r[i].shape[1]
+            self.ctx._call("tramp_variable_posterior", dt, n, self.batch, fv.a.ptr, fv.b.ptr, vf.a.ptr, vf.b.ptr,
+                           self.r[i].ptr, self.r[i].ptr, self.S.row(3 * i).ptr, self.S.row(3 * i + 1).ptr,
+                           self.S.row(3 * i + 2).ptr)
+
+    def check_message(self):
+        bad = np.isnan(self.A_host)
+        if bad.any():
+            e, b = np.argwhere(bad)[0]
+            src, dst = self.msg_keys[e]
+            raise ValueError(f"message {getattr(src, 'id', src)} -> {getattr(dst, 'id', dst)} (instance {b}): a is nan")
+
+    def get_edges_data(self):
+        "a of every factor->variable message, as {(variable id, factor id): array[batch]}"
+        return {(dst.id, src.id): self.A_host[i].copy() for i, (src, dst) in enumerate(self.msg_keys)
+                if isinstance(dst, Variable)}
+
+    def get_message(self, source, target):
+        """(a, b) of the message source -> target; nodes are given as objects or ids."""
+        def find(x):
+            for n in self.model.forward_ordering:
+                if n is x or getattr(n, "id", None) == x:
+                    return n
+            raise KeyError(x)
+        m = self.msg[(find(source), find(target))]
+        a, b = m.a.get(), m.b.get()
+        return (float(a[0]), b[0]) if self.batch == 1 else (a, b)
+
+    def log_evidence(self):
+        raise NotImplementedError("log_evidence is implemented for chain models")

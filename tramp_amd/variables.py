@@ -15,3 +15,24 @@ class SISOVariable(Variable):
 class SILeafVariable(Variable):
     def __init__(self, id):
         super().__init__(id=id, n_prev=1, n_next=0)
+
+
+class SIMOVariable(Variable):
+    "one incoming factor, n_next outgoing (sub_variables.py:4-7)"
+
+    def __init__(self, id, n_next):
+        super().__init__(id=id, n_prev=1, n_next=n_next)
+
+
+class MISOVariable(Variable):
+    "n_prev incoming factors, one outgoing (sub_variables.py:10-13)"
+
+    def __init__(self, id, n_prev):
+        super().__init__(id=id, n_prev=n_prev, n_next=1)
+
+
+class MILeafVariable(Variable):
+    "leaf with n_prev incoming factors (sub_variables.py:46-49)"
+
+    def __init__(self, id, n_prev):
+        super().__init__(id=id, n_prev=n_prev, n_next=0)
