@@ -1201,6 +1201,19 @@ class UnitaryFactor(OracleFactor):
         return ax, np.stack([f.real, f.imag])
 
 
+class ReshapeFactor(OracleFactor):
+    "tramp/channels/shape/reshape_channel.py:27-31"
+
+    def __init__(self, prev_shape, next_shape):
+        self.prev_shape, self.next_shape = prev_shape, next_shape
+
+    def forward(self, az, bz, ax, bx):
+        return az, bz.reshape(self.next_shape)
+
+    def backward(self, az, bz, ax, bx):
+        return ax, bx.reshape(self.prev_shape)
+
+
 class MPFactor(OracleFactor):
     def __init__(self, alpha):
         self.mp = MarchenkoPasturOracle(alpha)

@@ -220,3 +220,49 @@ def test_tree_ep_example_setting_matches_oracle(ctx):
     close(r, want["r"]["x"], 1e-7, 1e-8)
     close(ep.get_variable_data("z")["r"], want["r"]["z"].ravel(), 1e-7, 1e-8)
     assert np.mean((r - x) ** 2) < np.mean((y - x) ** 2)
+
+
+def test_tree_regression_matches_reference(ctx, golden_tree):
+    """Sparse-gradient regression (total_variation_model.py:67-71): the gradient tree feeding a dense
+    LinearChannel - every message and posterior per iteration, and the stopping iteration."""
+    import tramp_amd as T
+    from tramp_amd.base import Variable
+    for e in golden_tree["reg"]:
+        model = T.sparse_gradient_regression(e["A"], e["y"], tuple(e["shape"]), e["rho"], e["noise_var"], ctx=ctx)
+        assert not model.is_chain and [v.id for v in model.variables if v.n_prev == 2] == ["x'"]
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        iters = []
+
+        class Rec(T.EarlyStoppingEP):
+            def __call__(self, algo, i, max_iter):
+                rec = {}
+                for (src, dst), m in algo.msg.items():
+                    key = f"{src.id if isinstance(src, Variable) else type(src).__name__}->" \
+                          f"{dst.id if isinstance(dst, Variable) else type(dst).__name__}"
+                    rec[key + ":a"], rec[key + ":b"] = m.a.get().copy(), m.b.get().copy()
+                for vid, d in algo.get_variables_data().items():
+                    rec["r:" + vid], rec["v:" + vid] = np.array(d["r"]), np.array(d["v"])
+                iters.append(rec)
+                return super().__call__(algo, i, max_iter)
+        ep.iterate(max_iter=30, callback=Rec(), damping=e["damping"])
+        assert ep.n_iter == e["n_iter"]
+        tr = e["traj"]
+        for it, got in enumerate(iters[:len(tr["v:x"])]):
+            for key, val in got.items():
+                ref = np.asarray(tr[key][it], dtype=float)
+                if key.endswith(":a") or key.startswith("v:"):
+                    close(np.ravel(val)[0], ref, 1e-7)
+                else:
+                    close(np.ravel(val), np.ravel(ref), 1e-6, 1e-7 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_reshape_channel(ctx):
+    import tramp_amd as T
+    ch = T.ReshapeChannel(prev_shape=(3, 4), next_shape=12, ctx=ctx)
+    b = np.arange(12.0).reshape(3, 4)
+    a, out = ch.compute_forward_message(1.5, b, 0.0, np.zeros(12))
+    assert a == 1.5 and out.shape == (12,) and np.array_equal(out, b.ravel())
+    a, out = ch.compute_backward_message(0.0, np.zeros((3, 4)), 2.5, np.arange(12.0))
+    assert a == 2.5 and out.shape == (3, 4) and np.array_equal(out, b)
+    with pytest.raises(ValueError):
+        T.ReshapeChannel(prev_shape=(3, 4), next_shape=11, ctx=ctx)

@@ -574,3 +574,39 @@ def test_tree_ep_oracle_matches_reference(golden_tree):
             for v in ("x", "z"):
                 np.testing.assert_allclose(rs[v], tr["r:" + v][it], rtol=1e-11, atol=1e-12)
                 np.testing.assert_allclose(vs[v], tr["v:" + v][it], rtol=1e-12)
+
+
+REG_EDGES = [("GaussianPrior", "x"), ("x", "GradientChannel"), ("GradientChannel", "x'"), ("GaussBernoulliPrior", "x'"),
+             ("x", "ReshapeChannel"), ("ReshapeChannel", "r"), ("r", "LinearChannel"), ("LinearChannel", "z"),
+             ("z", "GaussianLikelihood")]
+
+
+def reg_factors(e):
+    shape = tuple(e["shape"])
+    d, N = len(shape), int(np.prod(shape))
+    factors = dict(GaussianPrior=orc.GaussPriorFactor(shape), GradientChannel=orc.GradientFactor(shape),
+                   GaussBernoulliPrior=orc.GBPriorFactor((d,) + shape, rho=e["rho"]),
+                   ReshapeChannel=orc.ReshapeFactor(shape, (N,)), LinearChannel=orc.LinearFactor(e["A"]),
+                   GaussianLikelihood=orc.GaussLikFactor(e["y"], e["noise_var"]))
+    return factors, {"x": shape, "x'": (d,) + shape, "r": (N,), "z": (e["M"],)}
+
+
+def test_tree_regression_oracle_matches_reference(golden_tree):
+    "sparse-gradient regression: the gradient tree feeding a dense LinearChannel (total_variation_model.py:67-71)"
+    for e in golden_tree["reg"]:
+        factors, shapes = reg_factors(e)
+        recs = []
+
+        def record(it, msg, rs, vs):
+            recs.append(({k: (v[0], v[1].copy()) for k, v in msg.items()}, dict(rs), dict(vs)))
+        res = orc.ep_tree(factors, ["x", "x'", "r", "z"], REG_EDGES, shapes, max_iter=30, damping=e["damping"],
+                          record=record)
+        assert res["n_iter"] == e["n_iter"]
+        tr = e["traj"]
+        for it, (msg, rs, vs) in enumerate(recs[:len(tr["v:x"])]):
+            for (s, t), (a, b) in msg.items():
+                np.testing.assert_allclose(a, tr[f"{s}->{t}:a"][it], rtol=1e-9)
+                np.testing.assert_allclose(b, tr[f"{s}->{t}:b"][it], rtol=1e-8, atol=1e-9)
+            for v in shapes:
+                np.testing.assert_allclose(rs[v], tr["r:" + v][it], rtol=1e-8, atol=1e-9)
+                np.testing.assert_allclose(vs[v], tr["v:" + v][it], rtol=1e-9)

@@ -784,8 +784,40 @@ def tree_goldens():
                           final_r=rec.iters[-1]["r:x"], mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2)),
                           mse_y=float(np.mean((y - x)**2))))
         print("tree ep", name, damping, "n_iter", ep.n_iter, err, "mse", trajs[-1]["mse"], "vs y", trajs[-1]["mse_y"])
+    # sparse-gradient regression (models/total_variation_model.py:12-25,43-48,67-71, built by hand: the module
+    # itself calls np.product, gone from NumPy 2): the tree above feeding a dense linear measurement
+    from tramp.channels import ReshapeChannel
+    regs = []
+    for name, shape, M, rho, nv, damping in [("gradreg1d", (48,), 30, 0.08, 1e-2, None),
+                                             ("gradreg1d", (48,), 30, 0.08, 1e-2, 0.2),
+                                             ("gradreg2d", (6, 8), 30, 0.2, 1e-2, 0.1)]:
+        r = np.random.RandomState(13)
+        d, N = len(shape), int(np.prod(shape))
+        if d == 1:
+            x = np.cumsum(r.standard_normal(shape) * r.binomial(n=1, size=shape, p=rho))
+            x = x - x.mean()
+        else:
+            x = np.kron(r.standard_normal((2, 2)), np.ones((shape[0] // 2, shape[1] // 2)))
+        A = r.standard_normal((M, N)) / np.sqrt(N)
+        y = A @ x.ravel() + np.sqrt(nv) * r.standard_normal(M)
+        model = (GaussianPrior(size=shape, var=1.0) @ SIMOVariable(id="x", n_next=2) @ (
+            (GradientChannel(shape=shape) + GaussBernoulliPrior(size=(d,) + shape, rho=rho))
+            @ MILeafVariable(id="x'", n_prev=2)) @ ReshapeChannel(prev_shape=shape, next_shape=N)
+            @ V(id="r") @ LinearChannel(A, name="A") @ V(id="z") @ GaussianLikelihood(y, var=nv)).to_model()
+        ep = ExpectationPropagation(model)
+        rec = TreeRecorder(EarlyStoppingEP())
+        err = None
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=30, callback=rec, damping=damping)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        regs.append(dict(name=name, shape=shape, M=M, rho=rho, noise_var=nv, damping=damping, x=x, y=y, A=A,
+                         n_iter=ep.n_iter, error=err, n_recorded=len(rec.iters), traj=pack_traj(rec.iters[:10]),
+                         mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2))))
+        print("tree reg", name, damping, "n_iter", ep.n_iter, err, "mse", regs[-1]["mse"], "var x", x.var())
     save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
-         ep=np.array(trajs, dtype=object))
+         ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object))
 
 
 # ---------------------------------------------------------------- SE

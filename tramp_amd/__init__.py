@@ -17,10 +17,11 @@ from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, Relu
 from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
                        SymmetricDoorChannel, ConvChannel, Blur1DChannel, Blur2DChannel,
-                       DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel,
+                       DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel, ReshapeChannel,
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
-from .variables import SISOVariable, SILeafVariable
-from .models import Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution
+from .variables import SISOVariable, SILeafVariable, SIMOVariable, MISOVariable, MILeafVariable
+from .models import (Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution,
+                     sparse_gradient_regression)
 from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, EarlyStopping,
                     ConstantInit, CustomInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
                     TrackEstimate, TrackMessages, TrackObjective, TrackOverlaps, LogProgress)

@@ -1135,6 +1135,69 @@ class RotationChannel(_UnitaryChannel):
         return self._message(_lib.BWD, ax, bx, out_a, out_b, damping, old_a, old_b)      # :38-42
 
 
+class ReshapeChannel(_UnitaryChannel):
+    """x = z.reshape(next_shape) (tramp/channels/shape/reshape_channel.py:4-37): the messages pass through
+    unchanged.  Device vectors are flat [batch, n] on both sides, so this is a copy (and the hook on which
+    constant damping of the edge is applied)."""
+
+    def __init__(self, prev_shape, next_shape, dtype=np.float64, ctx=None):
+        as_tuple = lambda s: (int(s),) if np.isscalar(s) else tuple(int(v) for v in s)      # noqa: E731
+        self.prev_shape, self.next_shape = as_tuple(prev_shape), as_tuple(next_shape)
+        if int(np.prod(self.prev_shape)) != int(np.prod(self.next_shape)):
+            raise ValueError(f"cannot reshape {self.prev_shape} into {self.next_shape}")
+        self.N = int(np.prod(self.prev_shape))
+        self.repr_init()
+        self._init_device(dtype, ctx)
+
+    def sample(self, Z):
+        return np.asarray(Z).reshape(self.next_shape)
+
+    def _vec(self, b, shape):
+        if isinstance(b, DeviceArray):
+            return VecArg(self.ctx, b, self.dtype)
+        h = np.asarray(b, dtype=self.dtype)
+        nd = len(shape)
+        if h.shape[-nd:] != shape or h.ndim not in (nd, nd + 1):
+            raise ValueError(f"expected an array of shape {shape} or (batch,)+{shape}, got {h.shape}")
+        arg = VecArg(self.ctx, h.reshape(-1, self.N) if h.ndim == nd + 1 else h.reshape(self.N), self.dtype)
+        arg.host_shape = h.shape
+        arg._lead = h.shape[:-nd]
+        return arg
+
+    def _message(self, direction, a_in, b_in, out_a, out_b, damping, old_a, old_b):
+        ctx = self.ctx
+        src_shape, dst_shape = (self.prev_shape, self.next_shape) if direction == _lib.FWD else \
+            (self.next_shape, self.prev_shape)
+        src = self._vec(b_in, src_shape)
+        a = ScalArg(ctx, a_in, src.batch)
+        d = float(damping or 0.0)
+        direct = out_b is not None and not d
+        b_tmp = out_b if direct else ctx.empty((src.batch, self.N), self.dtype)
+        b_tmp.copy_from(src.dev)
+        a_tmp = ctx.empty((src.batch,), np.float64)
+        a_tmp.copy_from(a.dev)
+        if d:
+            ctx._call("tramp_damp", self._dt, self.N, src.batch, d, old_a.ptr, old_b.ptr, a_tmp.ptr, b_tmp.ptr)
+        if out_a is not None:
+            out_a.copy_from(a_tmp)
+            if not direct:
+                out_b.copy_from(b_tmp)
+            return out_a, out_b
+        if src.was_host:
+            av = a_tmp.get()
+            av = float(av[0]) if (a.was_host and a.scalar_like and not src._lead) else av
+            return av, b_tmp.get().reshape(src._lead + dst_shape)
+        return a_tmp, b_tmp
+
+    def compute_forward_message(self, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+                                old_b=None):
+        return self._message(_lib.FWD, az, bz, out_a, out_b, damping, old_a, old_b)      # :27-28
+
+    def compute_backward_message(self, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
+                                 old_b=None):
+        return self._message(_lib.BWD, ax, bx, out_a, out_b, damping, old_a, old_b)      # :30-31
+
+
 class UnitaryChannel(RotationChannel):
     """x = U z with U unitary (tramp/channels/linear/unitary_channel.py:16-97).  A complex vector is
     the planar real array (2, N) = (real parts, imaginary parts) as in the reference, so U acts as the
@@ -1226,6 +1289,7 @@ CHANNEL_CLASSES = {
     "rotation": RotationChannel,
     "gradient": GradientChannel,
     "unitary": UnitaryChannel,
+    "reshape": ReshapeChannel,
 }
 
 

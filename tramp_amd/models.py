@@ -11,7 +11,7 @@ import networkx as nx
 import numpy as np
 
 from .base import Factor, Variable
-from .channels import (ConvChannel, DFTChannel, GradientChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
+from .channels import (ConvChannel, DFTChannel, GradientChannel, ReshapeChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
                        PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
@@ -202,6 +202,8 @@ class Model:
             return (factor.d,) + tuple(factor.shape)
         if isinstance(factor, DFTChannel):
             return (2,) + tuple(in_shape)
+        if isinstance(factor, ReshapeChannel):
+            return tuple(factor.next_shape)
         return in_shape
 
     def init_shapes(self):
@@ -260,6 +262,24 @@ def glm_state_evolution(alpha, prior_type, output_type, **kwargs):
     return (prior @ SISOVariable(id="x") @ linear @ SISOVariable(id="z") @ output).to_model()
 
 
+def sparse_gradient_regression(A, y, x_shape, grad_rho, noise_var, prior_var=1.0, dtype=np.float64, ctx=None):
+    """tramp/models/total_variation_model.py:12-25,43-48,67-71: a signal with a Gauss-Bernoulli prior on its
+    gradient (variable "x'" with two parents: the gradient channel and that prior), observed through the
+    dense matrix A with Gaussian noise.  y: [M] or [instances, M]."""
+    from .channels import GradientChannel, ReshapeChannel
+    from .priors import GaussianPrior, GaussBernoulliPrior
+    from .variables import SIMOVariable, MILeafVariable
+    x_shape = tuple(x_shape)
+    d, N = len(x_shape), int(np.prod(x_shape))
+    kw = dict(dtype=dtype, ctx=ctx)
+    block = (GaussianPrior(size=x_shape, var=prior_var, **kw) @ SIMOVariable(id="x", n_next=2) @ (
+        (GradientChannel(shape=x_shape, **kw) + GaussBernoulliPrior(size=(d,) + x_shape, rho=grad_rho, **kw))
+        @ MILeafVariable(id="x'", n_prev=2))) @ ReshapeChannel(prev_shape=x_shape, next_shape=N, **kw)
+    lin = A if isinstance(A, LinearChannel) else LinearChannel(A, name="A", **kw)
+    return (block @ SISOVariable(id="r") @ lin @ SISOVariable(id="z")
+            @ GaussianLikelihood(y=y, var=noise_var, **kw)).to_model()
+
+
 class MultiLayerModel(Model):
     "tramp/models/multi_layer_model.py:30-49"
 
@@ -285,5 +305,5 @@ class MultiLayerModel(Model):
         super().__init__(DAG(nodes))
 
 
-__all__ = ["DAG", "Model", "MultiLayerModel", "glm_generative", "glm_state_evolution",
+__all__ = ["DAG", "Model", "MultiLayerModel", "glm_generative", "glm_state_evolution", "sparse_gradient_regression",
            "channel2likelihood", "PiecewiseLinearChannel"]
