@@ -266,3 +266,17 @@ def test_reshape_channel(ctx):
     assert a == 2.5 and out.shape == (3, 4) and np.array_equal(out, b)
     with pytest.raises(ValueError):
         T.ReshapeChannel(prev_shape=(3, 4), next_shape=11, ctx=ctx)
+
+
+def test_tree_ep_graph_replay_is_identical(ctx, golden_tree):
+    "iterate(graph=True) replays the captured launch sequence of a tree iteration: same bits as the eager loop"
+    import tramp_amd as T
+    e = golden_tree["reg"][1]
+    outs = []
+    for graph in (False, True):
+        model = T.sparse_gradient_regression(e["A"], e["y"], tuple(e["shape"]), e["rho"], e["noise_var"], ctx=ctx)
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        ep.iterate(max_iter=9, callback=T.PassCallback(), damping=0.2, graph=graph)
+        outs.append({k: (np.array(v["r"]), np.array(v["v"])) for k, v in ep.get_variables_data().items()})
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k][0], outs[1][k][0]) and np.array_equal(outs[0][k][1], outs[1][k][1]), k

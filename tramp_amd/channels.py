@@ -1112,18 +1112,30 @@ class RotationChannel(_UnitaryChannel):
             raise ValueError(f"expected messages of {self.N} components, got {src.n}")
         a = ScalArg(ctx, a_in, src.batch)
         d = float(damping or 0.0)
-        direct = out_b is not None and not d
-        b_tmp = out_b if direct else ctx.empty((src.batch, self.N), self.dtype)
-        ctx._call("tramp_matvec_nt" if direction == _lib.FWD else "tramp_matvec_nn", self._dt, 0, self.N, self.N,
-                  src.batch, self._R_dev.ptr, src.dev.ptr, b_tmp.ptr)
+        mv = "tramp_matvec_nt" if direction == _lib.FWD else "tramp_matvec_nn"
+        if out_a is not None and (not d or (old_a.ptr == out_a.ptr and old_b.ptr == out_b.ptr)):
+            # scheduler path: no per-call temporaries (a captured graph replays these launches); the rotated
+            # message lands in a scratch kept by the channel, then out <- (1 - d) new + d out in place
+            if not d:
+                ctx._call(mv, self._dt, 0, self.N, self.N, src.batch, self._R_dev.ptr, src.dev.ptr, out_b.ptr)
+                out_a.copy_from(a.dev)
+            else:
+                scratch = getattr(self, "_scratch", None)
+                if scratch is None or scratch.shape != (src.batch, self.N):
+                    scratch = self._scratch = ctx.empty((src.batch, self.N), self.dtype)
+                ctx._call(mv, self._dt, 0, self.N, self.N, src.batch, self._R_dev.ptr, src.dev.ptr, scratch.ptr)
+                ctx._call("tramp_damp", self._dt, self.N, src.batch, 1.0 - d, a.dev.ptr, scratch.ptr, out_a.ptr,
+                          out_b.ptr)
+            return out_a, out_b
+        b_tmp = ctx.empty((src.batch, self.N), self.dtype)
+        ctx._call(mv, self._dt, 0, self.N, self.N, src.batch, self._R_dev.ptr, src.dev.ptr, b_tmp.ptr)
         a_tmp = ctx.empty((src.batch,), np.float64)
         a_tmp.copy_from(a.dev)
         if d:
             ctx._call("tramp_damp", self._dt, self.N, src.batch, d, old_a.ptr, old_b.ptr, a_tmp.ptr, b_tmp.ptr)
         if out_a is not None:
             out_a.copy_from(a_tmp)
-            if not direct:
-                out_b.copy_from(b_tmp)
+            out_b.copy_from(b_tmp)
         return self._finish(a, src, a_tmp, b_tmp, out_a, out_b)
 
     def compute_forward_message(self, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None,
@@ -1171,8 +1183,17 @@ class ReshapeChannel(_UnitaryChannel):
         src = self._vec(b_in, src_shape)
         a = ScalArg(ctx, a_in, src.batch)
         d = float(damping or 0.0)
-        direct = out_b is not None and not d
-        b_tmp = out_b if direct else ctx.empty((src.batch, self.N), self.dtype)
+        if out_a is not None and (not d or (old_a.ptr == out_a.ptr and old_b.ptr == out_b.ptr)):
+            # scheduler path, no temporaries (safe under graph capture): in-place damping with the roles
+            # swapped, out <- (1 - d) src + d out
+            if d:
+                ctx._call("tramp_damp", self._dt, self.N, src.batch, 1.0 - d, a.dev.ptr, src.dev.ptr, out_a.ptr,
+                          out_b.ptr)
+            else:
+                out_a.copy_from(a.dev)
+                out_b.copy_from(src.dev)
+            return out_a, out_b
+        b_tmp = ctx.empty((src.batch, self.N), self.dtype)
         b_tmp.copy_from(src.dev)
         a_tmp = ctx.empty((src.batch,), np.float64)
         a_tmp.copy_from(a.dev)
@@ -1180,8 +1201,7 @@ class ReshapeChannel(_UnitaryChannel):
             ctx._call("tramp_damp", self._dt, self.N, src.batch, d, old_a.ptr, old_b.ptr, a_tmp.ptr, b_tmp.ptr)
         if out_a is not None:
             out_a.copy_from(a_tmp)
-            if not direct:
-                out_b.copy_from(b_tmp)
+            out_b.copy_from(b_tmp)
             return out_a, out_b
         if src.was_host:
             av = a_tmp.get()
