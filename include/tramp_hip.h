@@ -405,6 +405,12 @@ int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  *      (tramp/algos/message_passing.py:119-127): x = d*old + (1-d)*x. */
 int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
                const double* a_old_d, const void* b_old_d, double* a_d, void* b_d);
+/* GaussianChannel x = z + N(0, var) as a hidden factor (tramp/channels/noise/gaussian_channel.py:23-33):
+ * (a_new, b_new) = k (a_in, b_in), k = (1/var) / (1/var + a_in); the forward message takes (az, bz), the
+ * backward one (ax, bx).  Constant damping fused (old may alias new). */
+int tramp_gauss_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double var,
+                        const double* a_in_d, const void* b_in_d, double damping,
+                        const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d);
 /* Variable.forward_message / backward_message on a tree (tramp/base.py:186-211): out = sum of the k
  * incoming messages (host arrays of k device pointers, k <= 8) minus message `exclude` (the target's own;
  * -1: plain sum = Variable.posterior_ab, base.py:152-155). */

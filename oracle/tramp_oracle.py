@@ -1201,6 +1201,21 @@ class UnitaryFactor(OracleFactor):
         return ax, np.stack([f.real, f.imag])
 
 
+class GaussChannelFactor(OracleFactor):
+    "tramp/channels/noise/gaussian_channel.py:23-33: x = z + N(0, var) as a hidden factor"
+
+    def __init__(self, var=1):
+        self.a = 1 / var
+
+    def forward(self, az, bz, ax, bx):
+        kz = self.a / (self.a + az)
+        return kz * az, kz * bz
+
+    def backward(self, az, bz, ax, bx):
+        kx = self.a / (self.a + ax)
+        return kx * ax, kx * bx
+
+
 class ReshapeFactor(OracleFactor):
     "tramp/channels/shape/reshape_channel.py:27-31"
 

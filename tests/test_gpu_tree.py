@@ -280,3 +280,37 @@ def test_tree_ep_graph_replay_is_identical(ctx, golden_tree):
         outs.append({k: (np.array(v["r"]), np.array(v["v"])) for k, v in ep.get_variables_data().items()})
     for k in outs[0]:
         assert np.array_equal(outs[0][k][0], outs[1][k][0]) and np.array_equal(outs[0][k][1], outs[1][k][1]), k
+
+
+def test_gauss_channel_hidden_factor_matches_reference(ctx, golden_tree):
+    "GaussianChannel between two variables (noisy 1-bit CS): messages and the EP trajectory of the reference"
+    import tramp_amd as T
+    for c in golden_tree["gch"]:
+        N, M = c["N"], int(c["alpha"] * c["N"])
+        W = np.random.RandomState(c["seed"]).randn(M, N) / np.sqrt(N)
+        g = T.GaussianChannel(var=c["var"], ctx=ctx)
+        bz = c["msgs"]["bz"]
+        a, b = g.compute_forward_message(1.3, bz, 0.7, 2 * bz)
+        close(a, c["msgs"]["fwd"][0], 1e-14)
+        close(b, c["msgs"]["fwd"][1], 1e-14)
+        a, b = g.compute_backward_message(1.3, bz, 0.7, 2 * bz)
+        close(a, c["msgs"]["bwd"][0], 1e-14)
+        close(b, c["msgs"]["bwd"][1], 1e-14)
+        model = (T.GaussBernoulliPrior(size=N, rho=0.3, ctx=ctx) @ T.SISOVariable(id="x")
+                 @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z") @ g @ T.SISOVariable(id="a")
+                 @ T.SgnLikelihood(y=c["y"], ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        iters = []
+
+        class Rec(T.EarlyStoppingEP):
+            def __call__(self, algo, i, max_iter):
+                iters.append({k: (np.array(v["r"]), float(v["v"])) for k, v in algo.get_variables_data().items()})
+                return super().__call__(algo, i, max_iter)
+        ep.iterate(max_iter=40, callback=Rec(), damping=c["damping"])
+        assert ep.n_iter == c["n_iter"]
+        t = c["traj"]
+        for it in range(t["v:x"].shape[0]):
+            for vid in ("x", "z", "a"):
+                close(iters[it][vid][1], t[f"v:{vid}"][it], 1e-6)
+                close(iters[it][vid][0], t[f"r:{vid}"][it], 1e-6, 1e-6 * np.abs(t[f"r:{vid}"][it]).max())
+        close(iters[-1]["x"][0], c["final_r"], 1e-4, 1e-5)

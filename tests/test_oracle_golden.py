@@ -610,3 +610,30 @@ def test_tree_regression_oracle_matches_reference(golden_tree):
             for v in shapes:
                 np.testing.assert_allclose(rs[v], tr["r:" + v][it], rtol=1e-8, atol=1e-9)
                 np.testing.assert_allclose(vs[v], tr["v:" + v][it], rtol=1e-9)
+
+
+def test_gauss_channel_hidden_factor_oracle_matches_reference(golden_tree):
+    "noisy 1-bit CS: GaussBernoulli -> Linear -> GaussianChannel -> SgnLikelihood (gaussian_channel.py:23-33)"
+    for c in golden_tree["gch"]:
+        N, M = c["N"], int(c["alpha"] * c["N"])
+        W = np.random.RandomState(c["seed"]).randn(M, N) / np.sqrt(N)
+        g = orc.GaussChannelFactor(c["var"])
+        bz = c["msgs"]["bz"]
+        for got, want in ((g.forward(1.3, bz, 0.7, 2 * bz), c["msgs"]["fwd"]), (g.backward(1.3, bz, 0.7, 2 * bz), c["msgs"]["bwd"])):
+            close(got[0], want[0], rtol=1e-14)
+            close(got[1], want[1], rtol=1e-14)
+        fs = [orc.GBPriorFactor(N, rho=0.3), orc.LinearFactor(W), g, orc.SgnLikFactor(c["y"])]
+        recs = []
+
+        def record(it, fwd, bwd, rs_, vs_):
+            recs.append(dict(r=[r.copy() for r in rs_], v=list(vs_), fwd=[(a, b.copy()) for a, b in fwd]))
+        with np.errstate(all="ignore"):
+            res = orc.ep_chain(fs, [(N,), (M,), (M,)], max_iter=40, damping=c["damping"], record=record)
+        assert res["n_iter"] == c["n_iter"]
+        t = c["traj"]
+        for it in range(t["v:x"].shape[0]):
+            for i, vid in enumerate(("x", "z", "a")):
+                close(recs[it]["v"][i], t[f"v:{vid}"][it], rtol=1e-6)
+                close(recs[it]["r"][i], t[f"r:{vid}"][it], rtol=1e-6, atol=1e-6 * np.abs(t[f"r:{vid}"][it]).max())
+                close(recs[it]["fwd"][i][0], t[f"fwd:{vid}:a"][it], rtol=1e-6)
+        close(res["r"][0], c["final_r"], rtol=1e-4, atol=1e-5)

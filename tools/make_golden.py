@@ -816,8 +816,29 @@ def tree_goldens():
                          n_iter=ep.n_iter, error=err, n_recorded=len(rec.iters), traj=pack_traj(rec.iters[:10]),
                          mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2))))
         print("tree reg", name, damping, "n_iter", ep.n_iter, err, "mse", regs[-1]["mse"], "var x", x.var())
+    # GaussianChannel as a hidden factor (channels/noise/gaussian_channel.py:23-33): noisy 1-bit compressed
+    # sensing, the classification block of total_variation_model.py:51-56
+    from tramp.channels import GaussianChannel
+    gch = []
+    for seed, N, alpha, var, damping in [(1, 64, 1.5, 0.05, None), (2, 128, 2.0, 0.2, 0.2)]:
+        W, x, _ = teacher_glm(seed, N, alpha, 0.3, "gaussian", 0.0)
+        r = np.random.RandomState(seed + 50)
+        y = np.sign(W @ x + np.sqrt(var) * r.standard_normal(W.shape[0]))
+        ch = GaussianChannel(var=var)
+        bz = r.standard_normal(7)
+        msgs = dict(bz=bz, fwd=ch.compute_forward_message(1.3, bz, 0.7, 2 * bz),
+                    bwd=ch.compute_backward_message(1.3, bz, 0.7, 2 * bz))
+        model = (GaussBernoulliPrior(size=N, rho=0.3) @ V(id="x") @ LinearChannel(W) @ V(id="z")
+                 @ GaussianChannel(var=var) @ V(id="a") @ SgnLikelihood(y=y)).to_model()
+        ep = ExpectationPropagation(model)
+        rec = Recorder(EarlyStoppingEP())
+        with np.errstate(all="ignore"):
+            ep.iterate(max_iter=40, callback=rec, damping=damping)
+        gch.append(dict(seed=seed, N=N, alpha=alpha, var=var, damping=damping, x=x, y=y, msgs=msgs,   # W = regen_W(seed)
+                        n_iter=ep.n_iter, traj=pack_traj(rec.iters[:10]), final_r=rec.iters[-1]["r:x"]))
+        print("gauss channel ep", N, damping, "n_iter", ep.n_iter)
     save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
-         ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object))
+         ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object))
 
 
 # ---------------------------------------------------------------- SE

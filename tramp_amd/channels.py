@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .base import Factor, VecArg, ScalArg, ret_vec, ret_scal
+from .base import Factor, VecArg, ScalArg, out_vec, ret_vec, ret_scal
 from .device import DeviceArray
 from .ensembles import MarchenkoPasturEnsemble
 
@@ -40,9 +40,10 @@ class GaussianChannel(Channel):
     (tramp/models/dag_algebra.py:22-23).
     """
 
-    def __init__(self, var=1):
+    def __init__(self, var=1, dtype=np.float64, ctx=None):
         self.var = var
         self.repr_init()
+        self._init_device(dtype, ctx)
         self.sigma = np.sqrt(var)
         self.a = 1 / var
 
@@ -51,6 +52,24 @@ class GaussianChannel(Channel):
 
     def second_moment(self, tau_z):
         return tau_z + self.var
+
+    def _message(self, a_in, b_in, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None):
+        "as a hidden factor (gaussian_channel.py:23-33): the message shrinks by k = a / (a + a_in)"
+        ctx = self.ctx
+        b = VecArg(ctx, b_in, self.dtype)
+        a = ScalArg(ctx, a_in, b.batch)
+        a_new = out_a if out_a is not None else ctx.empty((b.batch,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, b, self.dtype)
+        ctx._call("tramp_gauss_channel", self._dt, b.n, b.batch, float(self.var), a.dev.ptr, b.dev.ptr,
+                  float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr)
+        return ret_scal(a_new, a, b), ret_vec(b_new, b)
+
+    def compute_forward_message(self, az, bz, ax, bx, **kw):
+        return self._message(az, bz, **kw)
+
+    def compute_backward_message(self, az, bz, ax, bx, **kw):
+        return self._message(ax, bx, **kw)
 
     def compute_forward_state_evolution(self, az, ax, tau_z):
         return self.a / (self.a + az) * az                     # gaussian_channel.py:35-38

@@ -997,6 +997,50 @@ extern "C" int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, dou
     return TRAMP_OK;
 }
 
+// ---------------------------------------------------------------- Gaussian noise channel x = z + N(0, var)
+// GaussianChannel.compute_forward_message / compute_backward_message
+// (tramp/channels/noise/gaussian_channel.py:23-33): the incoming message shrinks by k = a_ch / (a_ch + a_in),
+// (a_new, b_new) = (k a_in, k b_in), a_ch = 1 / var.  Constant damping fused.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gauss_channel_kernel(size_t n, double a_ch, const double* __restrict__ a_in,
+                                                               const T* __restrict__ b_in, double damping,
+                                                               const double* a_old, const T* b_old,
+                                                               double* a_new, T* b_new) {
+    const size_t b = blockIdx.y;
+    const double k = a_ch / (a_ch + a_in[b]);
+    const T kT = T(k), dT = T(damping), omd = T(1.0 - damping);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        T v = kT * b_in[b * n + i];
+        if (damping != 0.0) v = dT * b_old[b * n + i] + omd * v;
+        b_new[b * n + i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double an = k * a_in[b];
+        if (damping != 0.0) an = damping * a_old[b] + (1.0 - damping) * an;
+        a_new[b] = an;
+    }
+}
+
+extern "C" int tramp_gauss_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double var,
+                                   const double* a_in_d, const void* b_in_d, double damping,
+                                   const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, a_in_d && b_in_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, var > 0.0);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!n || !batch) return TRAMP_OK;
+    dim3 grid(blocks_for(n, 1), (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((gauss_channel_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, 1.0 / var, a_in_d,
+                           (const double*)b_in_d, damping, a_old_d, (const double*)b_old_d, a_new_d, (double*)b_new_d);
+    else
+        hipLaunchKernelGGL((gauss_channel_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, 1.0 / var, a_in_d,
+                           (const float*)b_in_d, damping, a_old_d, (const float*)b_old_d, a_new_d, (float*)b_new_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 // ---------------------------------------------------------------- variable -> factor message on a tree
 // Variable.forward_message / backward_message (tramp/base.py:186-211): the message a variable of degree
 // k sends to one neighbour is the sum of ALL its incoming messages minus that neighbour's own,

@@ -25,7 +25,7 @@ def channel2likelihood(channel, y, y_name):
     "tramp/models/dag_algebra.py:21-43"
     kw = dict(dtype=getattr(channel, "dtype", np.float64), ctx=getattr(channel, "_ctx", None))
     if isinstance(channel, GaussianChannel):
-        return GaussianLikelihood(y=y, y_name=y_name, var=channel.var)
+        return GaussianLikelihood(y=y, y_name=y_name, var=channel.var, **kw)
     if isinstance(channel, AbsChannel):
         return AbsLikelihood(y=y, y_name=y_name, **kw)
     if isinstance(channel, SgnChannel):
@@ -246,8 +246,7 @@ def glm_generative(N, alpha, ensemble_type, prior_type, output_type, dtype=np.fl
     prior = get_prior(size=N, prior_type=prior_type, dtype=dtype, ctx=ctx, **_get_kwargs("prior", kwargs))
     linear = get_channel("linear", W=F, name="F", dtype=dtype, ctx=ctx, keep_W=True)
     okw = _get_kwargs("output", kwargs)
-    if output_type != "gaussian":
-        okw.update(dtype=dtype, ctx=ctx)
+    okw.update(dtype=dtype, ctx=ctx)
     output = get_channel(output_type, **okw)
     return (prior @ SISOVariable(id="x") @ linear @ SISOVariable(id="z") @ output
             @ SILeafVariable(id="y")).to_model()
