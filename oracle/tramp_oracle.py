@@ -1643,6 +1643,84 @@ def se_chain(factors, max_iter=200, damping=None, tol=1e-6, a0=0.,
     return dict(fwd=fwd, bwd=bwd, v=vs, tau=taus, n_iter=n_iter)
 
 
+def se_tree(factors, variables, edges, max_iter=200, damping=None, tol=1e-6, a0=0., method="quadpack",
+            record=None):
+    """State evolution on a tree-structured model: the scalar counterpart of ``ep_tree`` (StateEvolution,
+    algos/state_evolution.py:5-27, with Variable.forward_state_evolution / backward_state_evolution,
+    base.py:213-233).  ``record(it, msg, vs)`` after each iteration; msg[(src, dst)] is the scalar a."""
+    nodes = list(factors) + list(variables)
+    pred = {n: [s for s, t in edges if t == n] for n in nodes}
+    succ = {n: [t for s, t in edges if s == n] for n in nodes}
+    order, indeg = [], {n: len(pred[n]) for n in nodes}
+    ready = [n for n in nodes if indeg[n] == 0]
+    while ready:
+        n = ready.pop(0)
+        order.append(n)
+        for t in succ[n]:
+            indeg[t] -= 1
+            if indeg[t] == 0:
+                ready.append(t)
+    taus = {}
+    for n in order:                                               # base_model.py:111-124
+        if n in factors and succ[n]:
+            tau = factors[n].second_moment(*[taus[p] for p in pred[n]])
+            for t in succ[n]:
+                taus[t] = tau
+    msg = {}
+    for s, t in edges:
+        msg[(s, t)] = a0
+        msg[(t, s)] = a0
+    d = damping if damping else 0.
+
+    def factor_send(f, direction):
+        fac = factors[f]
+        prev = pred[f][0] if pred[f] else None
+        nxt = succ[f][0] if succ[f] else None
+        target = nxt if direction == "fwd" else prev
+        if target is None:
+            return
+        if fac.kind == "prior":
+            new = fac.forward_se(None, msg[(nxt, f)], None, method)
+        elif fac.kind == "likelihood":
+            new = fac.backward_se(msg[(prev, f)], None, taus[prev], method)
+        elif direction == "fwd":
+            new = fac.forward_se(msg[(prev, f)], msg[(nxt, f)], taus[prev], method)
+        else:
+            new = fac.backward_se(msg[(prev, f)], msg[(nxt, f)], taus[prev], method)
+        if np.isnan(new):
+            raise ValueError(f"{f}->{target} a is nan")
+        msg[(f, target)] = d * msg[(f, target)] + (1 - d) * new if d else new
+
+    def variable_send(v, targets):
+        a_hat = sum(msg[(f, v)] for f in pred[v] + succ[v])
+        for f in targets:
+            msg[(v, f)] = a_hat - msg[(f, v)]
+
+    old_vs, n_iter, vs = None, 0, None
+    for it in range(max_iter):
+        for n in order:
+            if n in factors:
+                factor_send(n, "fwd")
+            else:
+                variable_send(n, succ[n])
+        for n in reversed(order):
+            if n in factors:
+                factor_send(n, "bwd")
+            else:
+                variable_send(n, pred[n])
+        vs = {v: 1. / sum(msg[(f, v)] for f in pred[v] + succ[v]) for v in variables}
+        n_iter += 1
+        if record is not None:
+            record(it, dict(msg), dict(vs))
+        if old_vs is not None:
+            if max(abs(old_vs[v] - vs[v]) for v in variables) < tol:
+                break
+            if it > 5 and max(vs[v] - old_vs[v] for v in variables) > 0.2:
+                break
+        old_vs = vs
+    return dict(msg=msg, v=vs, tau=taus, n_iter=n_iter)
+
+
 # --------------------------------------------------------------------------
 # Synthetic teacher data (SURVEY.md section 8d; legacy RandomState is version-stable)
 #   tramp/ensembles/gaussian_ensemble.py:11-21

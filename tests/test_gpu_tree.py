@@ -314,3 +314,35 @@ def test_gauss_channel_hidden_factor_matches_reference(ctx, golden_tree):
                 close(iters[it][vid][1], t[f"v:{vid}"][it], 1e-6)
                 close(iters[it][vid][0], t[f"r:{vid}"][it], 1e-6, 1e-6 * np.abs(t[f"r:{vid}"][it]).max())
         close(iters[-1]["x"][0], c["final_r"], 1e-4, 1e-5)
+
+
+def test_tree_state_evolution_matches_reference(ctx, golden_tree):
+    "StateEvolution on a tree model dispatches to the tree recursion; messages and variances per iteration"
+    import tramp_amd as T
+    from tramp_amd.base import Variable
+    from tramp_amd.tree import TreeStateEvolution
+    from tramp_amd.variables import SIMOVariable, MILeafVariable
+    for c in golden_tree["se"]:
+        shape = tuple(c["shape"])
+        d = len(shape)
+        model = (T.GaussianPrior(size=shape, ctx=ctx) @ SIMOVariable(id="x", n_next=2) @ (
+            T.GaussianLikelihood(y=None, var=c["noise_var"], ctx=ctx) + (
+                T.GradientChannel(shape=shape, ctx=ctx) + T.GaussBernoulliPrior(size=(d,) + shape, rho=c["rho"], ctx=ctx)
+            ) @ MILeafVariable(id="z", n_prev=2))).to_model()
+        se = T.StateEvolution(model)
+        assert isinstance(se, TreeStateEvolution)
+        for k, tau in c["tau"].items():
+            close(se.taus[k], tau, 1e-12)
+        iters = []
+
+        def cb(algo, i, max_iter):
+            rec = {f"{s.id if isinstance(s, Variable) else type(s).__name__}->"
+                   f"{t.id if isinstance(t, Variable) else type(t).__name__}:a": float(a) for (s, t), a in algo.msg.items()}
+            rec.update({"v:" + k: float(v["v"]) for k, v in algo.get_variables_data().items()})
+            iters.append(rec)
+            return False
+        se.iterate(max_iter=12, callback=cb, damping=c["damping"])
+        t = c["traj"]
+        for it, rec in enumerate(iters):
+            for k, v in rec.items():
+                close(v, t[k][it], 1e-6)

@@ -637,3 +637,24 @@ def test_gauss_channel_hidden_factor_oracle_matches_reference(golden_tree):
                 close(recs[it]["r"][i], t[f"r:{vid}"][it], rtol=1e-6, atol=1e-6 * np.abs(t[f"r:{vid}"][it]).max())
                 close(recs[it]["fwd"][i][0], t[f"fwd:{vid}:a"][it], rtol=1e-6)
         close(res["r"][0], c["final_r"], rtol=1e-4, atol=1e-5)
+
+
+def test_tree_se_oracle_matches_reference(golden_tree):
+    "state evolution on the sparse-gradient tree: every scalar message and variance per iteration"
+    for c in golden_tree["se"]:
+        shape = tuple(c["shape"])
+        d = len(shape)
+        factors = dict(GaussianPrior=orc.GaussPriorFactor(shape), GaussianLikelihood=orc.GaussLikFactor(None, c["noise_var"]),
+                       GradientChannel=orc.GradientFactor(shape),
+                       GaussBernoulliPrior=orc.GBPriorFactor((d,) + shape, rho=c["rho"]))
+        recs = []
+        res = orc.se_tree(factors, ["x", "z"], TREE_EDGES, max_iter=12, damping=c["damping"], tol=0.0,
+                          record=lambda it, msg, vs: recs.append((msg, vs)))
+        for k, tau in c["tau"].items():
+            close(res["tau"][k], tau, rtol=1e-12)
+        t = c["traj"]
+        for it, (msg, vs) in enumerate(recs):
+            for (s, tt), a in msg.items():
+                close(a, t[f"{s}->{tt}:a"][it], rtol=1e-7)
+            for v in ("x", "z"):
+                close(vs[v], t["v:" + v][it], rtol=1e-7)

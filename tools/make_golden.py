@@ -837,8 +837,33 @@ def tree_goldens():
         gch.append(dict(seed=seed, N=N, alpha=alpha, var=var, damping=damping, x=x, y=y, msgs=msgs,   # W = regen_W(seed)
                         n_iter=ep.n_iter, traj=pack_traj(rec.iters[:10]), final_r=rec.iters[-1]["r:x"]))
         print("gauss channel ep", N, damping, "n_iter", ep.n_iter)
+    # state evolution on the sparse-gradient tree (observed form: a likelihood with y=None in place of the
+    # noise channel + leaf, as glm_state_evolution does)
+    ses = []
+    for shape, rho, nv, damping in [((64,), 0.1, 1e-2, None), ((8, 10), 0.2, 5e-2, 0.2)]:
+        d = len(shape)
+        model = (GaussianPrior(size=shape) @ SIMOVariable(id="x", n_next=2) @ (
+            GaussianLikelihood(y=None, var=nv) + (
+                GradientChannel(shape=shape) + GaussBernoulliPrior(size=(d,) + shape, rho=rho)
+            ) @ MILeafVariable(id="z", n_prev=2))).to_model()
+        se = StateEvolution(model)
+        iters = []
+
+        def cb(algo, i, max_iter):
+            rec = {}
+            for source, target, data in algo.message_dag.edges(data=True):
+                rec[f"{TreeRecorder.name(source)}->{TreeRecorder.name(target)}:a"] = float(data["a"])
+            for vid, dd in algo.get_variables_data().items():
+                rec[f"v:{vid}"] = float(dd["v"])
+            iters.append(rec)
+            return False
+        se.iterate(max_iter=12, callback=cb, damping=damping)
+        ses.append(dict(shape=shape, rho=rho, noise_var=nv, damping=damping, traj=pack_traj(iters),
+                        tau=model.get_second_moments()))
+        print("tree se", shape, damping, {k: v for k, v in iters[-1].items() if k.startswith("v:")})
     save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
-         ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object))
+         ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object),
+         se=np.array(ses, dtype=object))
 
 
 # ---------------------------------------------------------------- SE

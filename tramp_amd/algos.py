@@ -572,6 +572,12 @@ class StateEvolution:
     Messages are host scalars ``a``; the factor errors are closed forms or the
     device quadratures K13/K14 (factor.compute_*_state_evolution)."""
 
+    def __new__(cls, model, *args, **kwargs):
+        if cls is StateEvolution and not getattr(model, "is_chain", True):
+            from .tree import TreeStateEvolution
+            return TreeStateEvolution(model)
+        return super().__new__(cls)
+
     def __init__(self, model):
         self.model = model
         model.init_second_moments()

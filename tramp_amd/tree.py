@@ -230,3 +230,81 @@ class TreeExpectationPropagation(ExpectationPropagation):
 
     def log_evidence(self):
         raise NotImplementedError("log_evidence is implemented for chain models")
+
+
+class TreeStateEvolution:
+    """Scalar state evolution on a tree-structured model (tramp/algos/state_evolution.py:5-27 with
+    Variable.forward_state_evolution / backward_state_evolution, tramp/base.py:213-233): the sweeps of
+    `TreeExpectationPropagation` on the precisions ``a`` alone; factor errors are the closed forms or the
+    device quadratures K13 / K14 (factor.compute_*_state_evolution)."""
+
+    def __init__(self, model):
+        from .algos import EarlyStopping
+        self.model = model
+        model.init_second_moments()
+        self.variables = model.variables
+        self.taus = model.get_second_moments()
+        self.n_iter = 0
+        self.default_stopping = EarlyStopping()
+
+    def _factor_send(self, f, direction, d):
+        g = self.model.dag
+        prev = next(iter(g.predecessors(f)), None)
+        nxt = next(iter(g.successors(f)), None)
+        target = nxt if direction == "fwd" else prev
+        if target is None:
+            return
+        if f.n_prev == 0:
+            new = f.compute_forward_state_evolution(self.msg[(nxt, f)])
+        elif f.n_next == 0:
+            new = f.compute_backward_state_evolution(self.msg[(prev, f)], self.taus[prev.id])
+        elif direction == "fwd":
+            new = f.compute_forward_state_evolution(self.msg[(prev, f)], self.msg[(nxt, f)], self.taus[prev.id])
+        else:
+            new = f.compute_backward_state_evolution(self.msg[(prev, f)], self.msg[(nxt, f)], self.taus[prev.id])
+        if np.any(np.isnan(new)):
+            raise ValueError(f"{f.id}->{target.id} a is nan")
+        self.msg[(f, target)] = d * self.msg[(f, target)] + (1 - d) * new if d else new
+
+    def _variable_send(self, v, targets):
+        a_hat = sum(self.msg[(f, v)] for f in self.adj[v])
+        for f in targets:
+            self.msg[(v, f)] = a_hat - self.msg[(f, v)]
+
+    def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False):
+        from .algos import ConstantInit
+        initializer = initializer or ConstantInit(a=0, b=0)
+        callback = callback or self.default_stopping
+        d = float(damping) if damping else 0.0
+        g = self.model.dag
+        if not warm_start:
+            self.adj = {v: list(g.predecessors(v)) + list(g.successors(v)) for v in self.variables}
+            self.msg = {}
+            for v in self.variables:
+                for f in self.adj[v]:
+                    for src, dst in ((f, v), (v, f)):
+                        self.msg[(src, dst)] = initializer.init_a(None, v.id, "fwd" if g.has_edge(src, dst) else "bwd")
+            self.n_iter = 0
+        order = self.model.forward_ordering
+        for it in range(max_iter):
+            for node in order:
+                if isinstance(node, Factor):
+                    self._factor_send(node, "fwd", d)
+                else:
+                    self._variable_send(node, list(g.successors(node)))
+            for node in reversed(order):
+                if isinstance(node, Factor):
+                    self._factor_send(node, "bwd", d)
+                else:
+                    self._variable_send(node, list(g.predecessors(node)))
+            self.v = [1. / sum(self.msg[(f, v)] for f in self.adj[v]) for v in self.variables]     # base.py:167-170
+            self.n_iter += 1
+            if callback(self, it, max_iter):
+                break
+        return self
+
+    def get_variables_data(self, ids="all", want_r=False):
+        return {v.id: dict(v=self.v[i]) for i, v in enumerate(self.variables) if ids == "all" or v.id in ids}
+
+    def get_edges_data(self):
+        return {(getattr(s, "id", s), getattr(t, "id", t)): a for (s, t), a in self.msg.items()}
