@@ -405,6 +405,15 @@ int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  *      (tramp/algos/message_passing.py:119-127): x = d*old + (1-d)*x. */
 int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
                const double* a_old_d, const void* b_old_d, double* a_d, void* b_d);
+/* MAP_L21NormPrior.compute_forward_posterior + compute_ab_new (tramp/priors/map_L21_norm_prior.py:7-20,69-74),
+ * axis = 0: bx is [batch, d, n], groups are the d components of a site (the total-variation prior on a
+ * gradient field).  count_d[batch]: sites with ||b[:, j]|| > gamma; mask_d[batch, n]: that support, bit-exact
+ * in f64.  Outputs optional as in tramp_l1_prior_fwd. */
+int tramp_l21_prior_fwd(tramp_ctx* ctx, int dtype, int d, size_t n, size_t batch, double gamma,
+                        const double* ax_d, const void* bx_d, double damping,
+                        const double* a_old_d, const void* b_old_d,
+                        double* a_new_d, void* b_new_d, void* r_d, double* v_d,
+                        unsigned long long* count_d, unsigned char* mask_d);
 /* GaussianChannel x = z + N(0, var) as a hidden factor (tramp/channels/noise/gaussian_channel.py:23-33):
  * (a_new, b_new) = k (a_in, b_in), k = (1/var) / (1/var + a_in); the forward message takes (az, bz), the
  * backward one (ax, bx).  Constant damping fused (old may alias new). */

@@ -128,6 +128,28 @@ def l1_prior_message(ax, bx, gamma=1, isotropic=True):
 #   tramp/priors/gaussian_prior.py:63-68,76-79,86-93
 #   tramp/likelihoods/gaussian_likelihood.py:43-49,58-61,68-75
 # --------------------------------------------------------------------------
+# --------------------------------------------------------------------------
+# Widening: group-sparsity MAP prior (the total-variation prior on a gradient field)
+#   tramp/priors/map_L21_norm_prior.py:7-20,69-74 (axis = 0)
+# --------------------------------------------------------------------------
+def l21_support_mask(bx, gamma):
+    return np.linalg.norm(bx, axis=0) > gamma
+
+
+def l21_prior_posterior(ax, bx, gamma=1):
+    with np.errstate(all="ignore"):
+        norm_k = np.linalg.norm(bx, axis=0, keepdims=True)
+        rx = (1 / ax) * (np.maximum(0, 1 - gamma / norm_k) * bx)                       # :12-14
+        norm = np.linalg.norm(bx, axis=0, keepdims=False)
+        v = (norm > gamma) * (1 + (bx**2 / norm**2 - 1) * gamma / norm)                # :17-20
+    return rx, ((1 / ax) * v).mean()
+
+
+def l21_prior_message(ax, bx, gamma=1):
+    rx, vx = l21_prior_posterior(ax, bx, gamma)
+    return ab_new(rx, vx, ax, bx)
+
+
 def gauss_prior_posterior(ax, bx, mean=0, var=1):
     a = ax + 1 / var
     b = bx + mean / var
@@ -1109,6 +1131,16 @@ class GBPriorFactor(OracleFactor):
         return self.rho * (self.mean**2 + self.var)
 
 
+class L21PriorFactor(OracleFactor):
+    kind = "prior"
+
+    def __init__(self, size, gamma=1):
+        self.size, self.gamma = size, gamma
+
+    def forward(self, az, bz, ax, bx):
+        return l21_prior_message(ax, bx, self.gamma)
+
+
 class GaussPriorFactor(OracleFactor):
     kind = "prior"
 
@@ -1497,7 +1529,7 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
 
 
 def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1e-6,
-            wait_increase=5, max_increase=0.2, record=None):
+            wait_increase=5, max_increase=0.2, record=None, a0=0., b0=0.):
     """Expectation propagation on a tree-structured model (message_passing.py:211-269,330-357 with
     the variable nodes of tramp/base.py:152-211).
 
@@ -1525,8 +1557,8 @@ def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1
     msg = {}
     for s, t in edges:
         v = s if s in shapes else t
-        msg[(s, t)] = (0., np.zeros(shapes[v]))
-        msg[(t, s)] = (0., np.zeros(shapes[v]))
+        msg[(s, t)] = (a0, b0 * np.ones(shapes[v]))               # ConstantInit (initial_conditions.py:13-24)
+        msg[(t, s)] = (a0, b0 * np.ones(shapes[v]))
     d = damping if damping else 0.
 
     def damp(old, new):

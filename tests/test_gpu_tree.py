@@ -346,3 +346,65 @@ def test_tree_state_evolution_matches_reference(ctx, golden_tree):
         for it, rec in enumerate(iters):
             for k, v in rec.items():
                 close(v, t[k][it], 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_l21_prior_matches_reference(ctx, golden_tree, dtype):
+    "MAP_L21NormPrior (group soft-threshold along axis 0): posterior, message, exact support"
+    import tramp_amd as T
+    rt = 1e-12 if dtype == np.float64 else 2e-5
+    for c in golden_tree["l21"]:
+        size = tuple(c["size"])
+        pr = T.MAP_L21NormPrior(size=size, gamma=c["gamma"], dtype=dtype, ctx=ctx)
+        r, v = pr.compute_forward_posterior(c["ax"], c["bx"])
+        assert r.shape == size
+        close(r, c["r"], rt, rt)
+        close(v, c["v"], max(rt, 1e-12))
+        a, b = pr.compute_forward_message(c["ax"], c["bx"])
+        close(a, c["a_new"], max(rt * 10, 1e-11))
+        close(b, c["b_new"], rt * 10, rt * 10 * max(1.0, float(np.abs(c["b_new"]).max())))
+        if dtype == np.float64:
+            mask, count = pr.support(c["ax"], c["bx"])
+            assert np.array_equal(mask, c["mask"]) and int(count[0]) == int(c["mask"].sum())
+    # ensemble rows are independent; a zero group gives nan like the reference's 0 * nan
+    c = golden_tree["l21"][0]
+    pr = T.MAP_L21NormPrior(size=tuple(c["size"]), gamma=c["gamma"], ctx=ctx)
+    r2, v2 = pr.compute_forward_posterior(np.array([c["ax"], 2 * c["ax"]]), np.stack([c["bx"], 0.5 * c["bx"]]))
+    close(r2[0], c["r"], 1e-12, 1e-12)
+    want_r, want_v = orc.l21_prior_posterior(2 * c["ax"], 0.5 * c["bx"], c["gamma"])
+    close(r2[1], want_r, 1e-12, 1e-12)
+    close(v2, [c["v"], want_v], 1e-12)
+    bz = c["bx"].copy()
+    bz[:, 0] = 0.0
+    assert np.isnan(pr.compute_forward_posterior(c["ax"], bz)[1])
+    with pytest.raises(NotImplementedError):
+        T.MAP_L21NormPrior(size=(2, 4), axis=1, ctx=ctx)
+
+
+def test_total_variation_ep_matches_reference(ctx, golden_tree):
+    "TV denoising (gradient tree with the L21 prior): reference trajectories from a constant initialisation"
+    import tramp_amd as T
+    from tramp_amd.variables import SIMOVariable, MILeafVariable
+    for e in golden_tree["tv"]:
+        shape = tuple(e["shape"])
+        d, n = len(shape), int(np.prod(shape))
+        model = (T.GaussianPrior(size=shape, ctx=ctx) @ SIMOVariable(id="x", n_next=2) @ (
+            T.GaussianLikelihood(y=e["y"].reshape(n), var=e["noise_var"], ctx=ctx) + (
+                T.GradientChannel(shape=shape, ctx=ctx) + T.MAP_L21NormPrior(size=(d,) + shape, gamma=e["gamma"], ctx=ctx)
+            ) @ MILeafVariable(id="z", n_prev=2))).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        iters = []
+
+        class Rec(T.EarlyStoppingEP):
+            def __call__(self, algo, i, max_iter):
+                iters.append({k: (np.array(v["r"]), float(v["v"])) for k, v in algo.get_variables_data().items()})
+                return super().__call__(algo, i, max_iter)
+        ep.iterate(max_iter=30, callback=Rec(), damping=e["damping"], initializer=T.ConstantInit(a=e["a0"], b=e["b0"]))
+        assert ep.n_iter == e["n_iter"]
+        tr = e["traj"]
+        for it in range(len(tr["v:x"])):
+            for vid in ("x", "z"):
+                close(iters[it][vid][1], tr["v:" + vid][it], 1e-7)
+                close(iters[it][vid][0], np.ravel(tr["r:" + vid][it]), 1e-6, 1e-7)
+        if e["name"] == "tv2d":
+            assert np.mean((iters[-1]["x"][0] - e["x"].ravel()) ** 2) < np.mean((e["y"] - e["x"]) ** 2)

@@ -658,3 +658,38 @@ def test_tree_se_oracle_matches_reference(golden_tree):
                 close(a, t[f"{s}->{tt}:a"][it], rtol=1e-7)
             for v in ("x", "z"):
                 close(vs[v], t["v:" + v][it], rtol=1e-7)
+
+
+def test_l21_prior_and_tv_oracle_match_reference(golden_tree):
+    "MAP_L21NormPrior (axis 0) and total-variation denoising on the gradient tree"
+    for c in golden_tree["l21"]:
+        r, v = orc.l21_prior_posterior(c["ax"], c["bx"], c["gamma"])
+        close(r, c["r"], rtol=1e-14, atol=1e-15)
+        close(v, c["v"], rtol=1e-14)
+        a, b = orc.l21_prior_message(c["ax"], c["bx"], c["gamma"])
+        close(a, c["a_new"], rtol=1e-13)
+        close(b, c["b_new"], rtol=1e-12, atol=1e-13)
+        assert np.array_equal(orc.l21_support_mask(c["bx"], c["gamma"]), c["mask"])
+    for e in golden_tree["tv"]:
+        shape = tuple(e["shape"])
+        d = len(shape)
+        factors = dict(GaussianPrior=orc.GaussPriorFactor(shape), GaussianLikelihood=orc.GaussLikFactor(e["y"], e["noise_var"]),
+                       GradientChannel=orc.GradientFactor(shape),
+                       GaussBernoulliPrior=orc.L21PriorFactor((d,) + shape, gamma=e["gamma"]))
+        edges = [(s.replace("GaussBernoulliPrior", "MAP_L21NormPrior"), t) for s, t in TREE_EDGES]
+        factors["MAP_L21NormPrior"] = factors.pop("GaussBernoulliPrior")
+        recs = []
+        with np.errstate(all="ignore"):
+            res = orc.ep_tree(factors, ["x", "z"], edges, dict(x=shape, z=(d,) + shape), max_iter=30,
+                              damping=e["damping"], a0=e["a0"], b0=e["b0"],
+                              record=lambda it, msg, rs, vs: recs.append((dict(msg), dict(rs), dict(vs))))
+        assert res["n_iter"] == e["n_iter"]
+        tr = e["traj"]
+        for it in range(len(tr["v:x"])):
+            msg, rs, vs = recs[it]
+            for (s, t), (a, b) in msg.items():
+                close(a, tr[f"{s}->{t}:a"][it], rtol=1e-8)
+                close(b, tr[f"{s}->{t}:b"][it], rtol=1e-7, atol=1e-8 * max(1.0, np.abs(tr[f"{s}->{t}:b"][it]).max()))
+            for v in ("x", "z"):
+                close(rs[v], tr["r:" + v][it], rtol=1e-7, atol=1e-8)
+                close(vs[v], tr["v:" + v][it], rtol=1e-8)

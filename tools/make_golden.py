@@ -861,9 +861,49 @@ def tree_goldens():
         ses.append(dict(shape=shape, rho=rho, noise_var=nv, damping=damping, traj=pack_traj(iters),
                         tau=model.get_second_moments()))
         print("tree se", shape, damping, {k: v for k, v in iters[-1].items() if k.startswith("v:")})
+    # MAP_L21NormPrior (axis 0) and total-variation denoising (models/total_variation_model.py:28-40):
+    # the sparse-gradient tree with the group penalty on the gradient field instead of the Gauss-Bernoulli prior
+    from tramp.priors import MAP_L21NormPrior
+    l21 = []
+    for size, gamma in [((2, 9), 1.0), ((3, 4, 5), 0.7), ((1, 12), 2.0)]:
+        pr = MAP_L21NormPrior(size=size, gamma=gamma)
+        bx = rs.standard_normal(size) * 1.5
+        for ax in (1.3, 0.2):
+            r, v = pr.compute_forward_posterior(ax, bx)
+            a_new, b_new = pr.compute_forward_message(ax, bx)
+            l21.append(dict(size=size, gamma=gamma, ax=ax, bx=bx, r=r, v=v, a_new=a_new, b_new=b_new,
+                            mask=np.linalg.norm(bx, axis=0) > gamma))
+    tvs = []
+    for name, shape, gamma, nv, damping, b0 in [("tv1d", (64,), 0.5, 1e-2, 0.3, 1.0), ("tv2d", (8, 10), 0.5, 1e-2, 0.3, 1.0)]:
+        r = np.random.RandomState(31)
+        d = len(shape)
+        if d == 1:
+            x = np.cumsum(r.standard_normal(shape) * r.binomial(n=1, size=shape, p=0.08))
+            x = x - x.mean()
+        else:
+            x = np.kron(r.standard_normal((2, 2)), np.ones((shape[0] // 2, shape[1] // 2)))
+        y = x + np.sqrt(nv) * r.standard_normal(shape)
+        model = (GaussianPrior(size=shape) @ SIMOVariable(id="x", n_next=2) @ (
+            GaussianLikelihood(y=y, var=nv) + (
+                GradientChannel(shape=shape) + MAP_L21NormPrior(size=(d,) + shape, gamma=gamma)
+            ) @ MILeafVariable(id="z", n_prev=2))).to_model()
+        ep = ExpectationPropagation(model)
+        rec = TreeRecorder(EarlyStoppingEP())
+        err = None
+        # b = 0 makes every group norm 0 and the reference's variance 0 * nan: start from a constant b
+        init = ConstantInit(a=0.1, b=b0)
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=30, callback=rec, damping=damping, initializer=init)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        tvs.append(dict(name=name, shape=shape, gamma=gamma, noise_var=nv, damping=damping, a0=0.1, b0=b0, x=x, y=y,
+                        n_iter=ep.n_iter, error=err, traj=pack_traj(rec.iters[:10]) if rec.iters else None,
+                        mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2)) if rec.iters else None))
+        print("tv ep", name, "n_iter", ep.n_iter, err, "mse", tvs[-1]["mse"], "y mse", float(np.mean((y - x)**2)))
     save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
          ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object),
-         se=np.array(ses, dtype=object))
+         se=np.array(ses, dtype=object), l21=np.array(l21, dtype=object), tv=np.array(tvs, dtype=object))
 
 
 # ---------------------------------------------------------------- SE

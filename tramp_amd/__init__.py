@@ -10,7 +10,7 @@ There is no CPU fallback: without the built HIP library the compute methods rais
 """
 from . import _lib
 from .device import Context, DeviceArray, default_context
-from .priors import GaussBernoulliPrior, MAP_L1NormPrior, GaussianPrior, get_prior
+from .priors import GaussBernoulliPrior, MAP_L1NormPrior, MAP_L21NormPrior, GaussianPrior, get_prior
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
                           SymmetricDoorLikelihood, get_likelihood)

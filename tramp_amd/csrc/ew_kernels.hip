@@ -968,6 +968,136 @@ extern "C" int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, siz
     return TRAMP_OK;
 }
 
+// ---------------------------------------------------------------- L21 (group-sparsity) MAP prior
+// MAP_L21NormPrior (tramp/priors/map_L21_norm_prior.py:7-20,69-74), the prior of the total-variation model
+// (models/total_variation_model.py:28-40): groups run along axis 0 of a [d, n] array (d components per site,
+// stride n).  With norm_j = ||b[:, j]||_2:
+//     r[c, j] = max(0, 1 - gamma / norm_j) b[c, j] / a,
+//     v[c, j] = (norm_j > gamma) (1 + (b[c, j]^2 / norm_j^2 - 1) gamma / norm_j) / a,   v = mean over all d n.
+// The expressions are kept in the reference's order (an all-zero group gives 0 * nan = nan there too).
+// Two passes like the other priors: pass 1 sums v and counts the supported sites, pass 2 recomputes r and
+// writes the message.  One thread per site, the d loads of a site are each coalesced across the wave.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void l21_pass1_kernel(int d, size_t n, double gamma, const T* __restrict__ bx,
+                                                           double* __restrict__ partials,
+                                                           unsigned char* __restrict__ mask) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    const T* base = bx + b * (size_t)d * n;
+    double sv = 0.0, cnt = 0.0;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (size_t)gridDim.x * kBlock) {
+        double ss = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double x = (double)base[(size_t)c * n + j];
+            ss += x * x;
+        }
+        const double nrm = sqrt(ss);
+        const double on = nrm > gamma ? 1.0 : 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double x = (double)base[(size_t)c * n + j];
+            sv += on * (1.0 + (x * x / (nrm * nrm) - 1.0) * gamma / nrm);
+        }
+        cnt += on;
+        if (mask) mask[b * n + j] = nrm > gamma ? 1 : 0;
+    }
+    sv = block_sum(sv, smem);
+    __syncthreads();
+    cnt = block_sum(cnt, smem);
+    if (threadIdx.x == 0) {
+        partials[(b * gridDim.x + blockIdx.x) * 2 + 0] = sv;
+        partials[(b * gridDim.x + blockIdx.x) * 2 + 1] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void l21_finish_kernel(const double* __restrict__ partials, int nblk, double dn,
+                                                            const double* __restrict__ ax, double damping,
+                                                            const double* a_old, double* a_new, double* a_raw,
+                                                            double* v_out, unsigned long long* count) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.x;
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += kBlock) {
+        s += partials[(b * nblk + i) * 2 + 0];
+        c += partials[(b * nblk + i) * 2 + 1];
+    }
+    s = block_sum(s, smem);
+    __syncthreads();
+    c = block_sum(c, smem);
+    if (threadIdx.x != 0) return;
+    const double a = ax[b];
+    const double v = (1.0 / a) * (s / dn);
+    const double an = tmath::a_new_of(v, a);
+    a_raw[b] = an;
+    if (a_new) a_new[b] = (damping != 0.0) ? damping * a_old[b] + (1.0 - damping) * an : an;
+    if (v_out) v_out[b] = v;
+    if (count) count[b] = (unsigned long long)c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void l21_pass2_kernel(int d, size_t n, double gamma, const double* __restrict__ ax,
+                                                           const double* __restrict__ a_raw, const T* bx,
+                                                           double damping, const T* b_old, T* b_new, T* r_out) {
+    const size_t b = blockIdx.y;
+    const double a = ax[b];
+    const double asum = a + a_raw[b];
+    const size_t off = b * (size_t)d * n;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (size_t)gridDim.x * kBlock) {
+        double ss = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double x = (double)bx[off + (size_t)c * n + j];
+            ss += x * x;
+        }
+        const double nrm = sqrt(ss);
+        const double shrink = fmax(0.0, 1.0 - gamma / nrm);
+        for (int c = 0; c < d; ++c) {
+            const size_t i = off + (size_t)c * n + j;
+            const double x = (double)bx[i];
+            const double r = (1.0 / a) * (shrink * x);
+            double bn = r * asum - x;
+            if (damping != 0.0) bn = damping * (double)b_old[i] + (1.0 - damping) * bn;
+            if (b_new) b_new[i] = (T)bn;
+            if (r_out) r_out[i] = (T)r;
+        }
+    }
+}
+
+extern "C" int tramp_l21_prior_fwd(tramp_ctx* ctx, int dtype, int d, size_t n, size_t batch, double gamma,
+                                   const double* ax_d, const void* bx_d, double damping, const double* a_old_d,
+                                   const void* b_old_d, double* a_new_d, void* b_new_d, void* r_d, double* v_d,
+                                   unsigned long long* count_d, unsigned char* mask_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax_d && bx_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, d >= 1);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!n || !batch) return TRAMP_OK;
+    TRAMP_REQUIRE(ctx, batch <= 65535);
+    const int nblk = blocks_for(n, 1);
+    int rc = tramp_ws_reserve(ctx, batch * ((size_t)nblk * 2 + 1) * sizeof(double));
+    if (rc) return rc;
+    double* partials = ctx->ws;
+    double* a_raw = ctx->ws + batch * (size_t)nblk * 2;
+    dim3 grid(nblk, (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((l21_pass1_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, d, n, gamma,
+                           (const double*)bx_d, partials, mask_d);
+    else
+        hipLaunchKernelGGL((l21_pass1_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, d, n, gamma,
+                           (const float*)bx_d, partials, mask_d);
+    hipLaunchKernelGGL(l21_finish_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, partials, nblk,
+                       (double)d * (double)n, ax_d, damping, a_old_d, a_new_d, a_raw, v_d, count_d);
+    if (b_new_d || r_d) {
+        if (dtype == TRAMP_F64)
+            hipLaunchKernelGGL((l21_pass2_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, d, n, gamma, ax_d, a_raw,
+                               (const double*)bx_d, damping, (const double*)b_old_d, (double*)b_new_d, (double*)r_d);
+        else
+            hipLaunchKernelGGL((l21_pass2_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, d, n, gamma, ax_d, a_raw,
+                               (const float*)bx_d, damping, (const float*)b_old_d, (float*)b_new_d, (float*)r_d);
+    }
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 // ---------------------------------------------------------------- K12 damping, distances
 template <typename T>
 __global__ __launch_bounds__(kBlock) void damp_kernel(size_t n, double d, const double* __restrict__ a_old,

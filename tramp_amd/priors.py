@@ -187,6 +187,100 @@ class MAP_L1NormPrior(Prior):
         raise NotImplementedError      # as the reference (map_L1_norm_prior.py:84-85)
 
 
+class MAP_L21NormPrior(Prior):
+    r"""MAP prior of the group penalty gamma ||x||_{2,1}: group soft-threshold along ``axis``.
+
+    tramp/priors/map_L21_norm_prior.py:22-80 with ``axis=0``: ``size = (d,) + site shape``, the groups are
+    the d components of a site - the total-variation prior on a gradient field
+    (tramp/models/total_variation_model.py:28-40).  Device vectors are [batch, d n].
+    """
+
+    def __init__(self, size, gamma=1, axis=0, isotropic=True, dtype=np.float64, ctx=None):
+        assert type(size) == tuple and len(size) > 1, "size must be a tuple of length > 1"
+        if axis != 0:
+            raise NotImplementedError("MAP_L21NormPrior on the HIP path groups along axis 0")
+        if not isotropic:
+            raise NotImplementedError("diagonal beliefs for MAP_L21NormPrior are outside the HIP path")
+        self.size = size
+        self.gamma = gamma
+        self.axis = axis
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.N = int(np.prod(size))
+        self.d = size[axis]
+        self.n_sites = self.N // self.d
+
+    def sample(self):
+        import warnings
+        warnings.warn("MAP_L21NormPrior.sample not implemented return zero array as a placeholder")
+        return np.zeros(self.size)                              # map_L21_norm_prior.py:53-58
+
+    def second_moment(self):
+        raise NotImplementedError
+
+    def _vec(self, bx):
+        if isinstance(bx, DeviceArray):
+            return VecArg(self.ctx, bx, self.dtype)
+        h = np.asarray(bx, dtype=self.dtype)
+        nd = len(self.size)
+        if h.shape[-nd:] != tuple(self.size) or h.ndim not in (nd, nd + 1):
+            raise ValueError(f"expected an array of shape {self.size} or (batch,)+{self.size}, got {h.shape}")
+        arg = VecArg(self.ctx, h.reshape(-1, self.N) if h.ndim == nd + 1 else h.reshape(self.N), self.dtype)
+        arg.host_shape = h.shape
+        arg._one = h.ndim == nd
+        return arg
+
+    def _run(self, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None, want_posterior=False,
+             want_support=False):
+        ctx = self.ctx
+        b = self._vec(bx)
+        if b.n != self.N:
+            raise ValueError(f"expected messages of {self.N} components, got {b.n}")
+        a = ScalArg(ctx, ax, b.batch)
+        a_new = out_a if out_a is not None else ctx.empty((b.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((b.batch, self.N), self.dtype)
+        r = ctx.empty((b.batch, self.N), self.dtype) if want_posterior else None
+        v = ctx.empty((b.batch,), np.float64) if want_posterior else None
+        count = ctx.empty((b.batch,), np.uint64) if want_support else None
+        mask = ctx.empty((b.batch, self.n_sites), np.uint8) if want_support else None
+        ctx._call("tramp_l21_prior_fwd", self._dt, self.d, self.n_sites, b.batch, float(self.gamma), a.dev.ptr,
+                  b.dev.ptr, float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr,
+                  r.ptr if r is not None else None, v.ptr if v is not None else None,
+                  count.ptr if count is not None else None, mask.ptr if mask is not None else None)
+        return a, b, a_new, b_new, r, v, count, mask
+
+    @staticmethod
+    def _ret(dev, like):
+        return dev.get().reshape(like.host_shape) if like.was_host else dev
+
+    @staticmethod
+    def _ret_scal(dev, a, like):
+        if a.was_host and like.was_host:
+            h = dev.get()
+            return float(h[0]) if (a.scalar_like and getattr(like, "_one", False)) else h
+        return dev
+
+    def compute_forward_posterior(self, ax, bx):
+        a, b, _, _, r, v, _, _ = self._run(ax, bx, want_posterior=True)          # :69-74
+        return self._ret(r, b), self._ret_scal(v, a, b)
+
+    def compute_forward_message(self, ax, bx, **kw):
+        a, b, a_new, b_new, _, _, _, _ = self._run(ax, bx, **kw)
+        return self._ret_scal(a_new, a, b), self._ret(b_new, b)
+
+    def support(self, ax, bx):
+        "sites with ||b[:, j]|| > gamma (v_group_soft_threshold, :17-20): exact mask and its count"
+        a, b, _, _, _, _, count, mask = self._run(ax, bx, want_support=True)
+        m = mask.get().astype(bool)
+        site_shape = tuple(self.size[1:])
+        return (m.reshape(site_shape) if getattr(b, "_one", False) else m.reshape((b.batch,) + site_shape)), count.get()
+
+    def compute_forward_error(self, ax):
+        raise NotImplementedError      # as the reference (map_L21_norm_prior.py:90-97)
+
+
 class GaussianPrior(Prior):
     r"""Gaussian prior N(x | mean, var): constant message, closed-form errors.
 
@@ -250,6 +344,7 @@ PRIOR_CLASSES = {
     "gauss_bernoulli": GaussBernoulliPrior,
     "gaussian": GaussianPrior,
     "L1_norm": MAP_L1NormPrior,
+    "L21_norm": MAP_L21NormPrior,
 }
 
 
