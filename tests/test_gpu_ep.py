@@ -334,3 +334,43 @@ def test_tracking_callbacks(ctx):
         close(ovl.records[it]["Q"], x @ x / N, 1e-12)
     fwd_x = [r for r in msg.records if r["id"] == "x" and r["direction"] == "fwd"]
     close([r["a"] for r in fwd_x], [ref[it][1] for it in range(6)], 1e-7)
+
+
+def test_contexts_are_reentrant_across_threads(golden_ep):
+    """SURVEY 8b threading: one host thread per context, no shared mutable state in the library.  Four
+    contexts on the same GPU run different EP problems concurrently (ctypes drops the GIL during the
+    calls); every result equals the one obtained alone."""
+    import threading
+    import tramp_amd as T
+
+    def solve(ctx, seed, n_iter):
+        rs = np.random.RandomState(seed)
+        N, M = 384, 256
+        W = rs.randn(M, N) / np.sqrt(N)
+        x = rs.standard_normal(N) * rs.binomial(1, 0.1, N)
+        y = W @ x + 0.1 * rs.standard_normal(M)
+        model = (T.GaussBernoulliPrior(size=N, rho=0.1, ctx=ctx) @ T.SISOVariable(id="x")
+                 @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+                 @ T.GaussianLikelihood(y=y, var=1e-2, ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        ep.iterate(max_iter=n_iter, callback=T.PassCallback(), damping=0.1)
+        return np.array(ep.get_variable_data("x")["r"])
+
+    ctxs = [T.Context(0) for _ in range(4)]
+    alone = [solve(ctxs[i], 10 + i, 40) for i in range(4)]
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = solve(ctxs[i], 10 + i, 40)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(out[i], alone[i]), i
