@@ -420,6 +420,12 @@ int tramp_l21_prior_fwd(tramp_ctx* ctx, int dtype, int d, size_t n, size_t batch
 int tramp_gauss_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double var,
                         const double* a_in_d, const void* b_in_d, double damping,
                         const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d);
+/* BiasChannel x = z + bias (tramp/channels/linear/bias_channel.py:21-29): dir FWD takes (az, bz) and returns
+ * (az, bz + az bias); dir BWD takes (ax, bx) and returns (ax, bx - ax bias).  bias_d: [n], shared by the
+ * ensemble.  Constant damping fused (old may alias new). */
+int tramp_bias_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batch, const void* bias_d,
+                       const double* a_in_d, const void* b_in_d, double damping,
+                       const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d);
 /* Variable.forward_message / backward_message on a tree (tramp/base.py:186-211): out = sum of the k
  * incoming messages (host arrays of k device pointers, k <= 8) minus message `exclude` (the target's own;
  * -1: plain sum = Variable.posterior_ab, base.py:152-155). */

@@ -1248,6 +1248,22 @@ class GaussChannelFactor(OracleFactor):
         return kx * ax, kx * bx
 
 
+class BiasFactor(OracleFactor):
+    "tramp/channels/linear/bias_channel.py:21-29"
+
+    def __init__(self, bias):
+        self.bias = np.asarray(bias, dtype=float)
+
+    def forward(self, az, bz, ax, bx):
+        return az, bz + az * self.bias
+
+    def backward(self, az, bz, ax, bx):
+        return ax, bx - ax * self.bias
+
+    def second_moment(self, tau_z):
+        return tau_z + (self.bias**2).mean()
+
+
 class ReshapeFactor(OracleFactor):
     "tramp/channels/shape/reshape_channel.py:27-31"
 
@@ -1331,6 +1347,19 @@ class SgnLikFactor(OracleFactor):
 
     def backward_se(self, az, ax, tau_z, method="quadpack"):
         return a_new(se_sgn_lik_error(az, tau_z, method), az)
+
+
+class Pwl3Factor(OracleFactor):
+    "three-region channels (HardTanh / HardSigmoid / SymmetricDoor) as chain factors"
+
+    def __init__(self, kind, param=None):
+        self.kind3, self.param = kind, param
+
+    def forward(self, az, bz, ax, bx):
+        return pwl3_channel_message(self.kind3, "fwd", az, bz, ax, bx, self.param)
+
+    def backward(self, az, bz, ax, bx):
+        return pwl3_channel_message(self.kind3, "bwd", az, bz, ax, bx, self.param)
 
 
 class Pwl3LikFactor(OracleFactor):

@@ -408,3 +408,41 @@ def test_total_variation_ep_matches_reference(ctx, golden_tree):
                 close(iters[it][vid][0], np.ravel(tr["r:" + vid][it]), 1e-6, 1e-7)
         if e["name"] == "tv2d":
             assert np.mean((iters[-1]["x"][0] - e["x"].ravel()) ** 2) < np.mean((e["y"] - e["x"]) ** 2)
+
+
+def test_generative_prior_chain_matches_reference(ctx, golden_tree):
+    """VAE-like generative prior (examples/vae_prior/plot_vae.py): Gaussian latent -> Linear -> Bias -> LeakyRelu
+    -> Linear -> Bias -> HardTanh -> Gaussian likelihood; BiasChannel messages and the EP trajectory."""
+    import tramp_amd as T
+    for c in golden_tree["vae"]:
+        D, H, N = c["dims"]
+        bch = T.BiasChannel(c["b1"], ctx=ctx)
+        bb = c["msgs"]["b"]
+        a, b = bch.compute_forward_message(1.3, bb, 0.7, 2 * bb)
+        close(a, c["msgs"]["fwd"][0], 1e-14)
+        close(b, c["msgs"]["fwd"][1], 1e-13, 1e-14)
+        a, b = bch.compute_backward_message(1.3, bb, 0.7, 2 * bb)
+        close(a, c["msgs"]["bwd"][0], 1e-14)
+        close(b, c["msgs"]["bwd"][1], 1e-13, 1e-14)
+        close(bch.second_moment(1.7), c["msgs"]["tau"], 1e-14)
+        V = T.SISOVariable
+        model = (T.GaussianPrior(size=D, ctx=ctx) @ V(id="z") @ T.LinearChannel(c["W1"], ctx=ctx, svd="host") @ V(id="a1")
+                 @ T.BiasChannel(c["b1"], ctx=ctx) @ V(id="a2") @ T.LeakyReluChannel(slope=0.1, ctx=ctx) @ V(id="a3")
+                 @ T.LinearChannel(c["W2"], ctx=ctx, svd="host") @ V(id="a4") @ T.BiasChannel(c["b2"], ctx=ctx)
+                 @ V(id="a5") @ T.HardTanhChannel(ctx=ctx) @ V(id="x")
+                 @ T.GaussianLikelihood(y=c["y"], var=c["noise_var"], ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        iters = []
+
+        def cb(algo, i, max_iter):
+            iters.append({k: (np.array(v["r"]), float(v["v"])) for k, v in algo.get_variables_data().items()})
+            return False
+        ep.iterate(max_iter=40, callback=cb, damping=c["damping"])
+        t = c["traj"]
+        for it in range(t["v:x"].shape[0]):
+            for vid in ("z", "a1", "a2", "a3", "a4", "a5", "x"):
+                close(iters[it][vid][1], t[f"v:{vid}"][it], 1e-6)
+                close(iters[it][vid][0], t[f"r:{vid}"][it], 1e-6, 1e-6 * max(1.0, float(np.abs(t[f"r:{vid}"][it]).max())))
+        mse = float(np.mean((iters[-1]["x"][0] - c["x"]) ** 2))
+        close(mse, c["mse"], 1e-4)
+        assert mse < 0.3 * float(np.mean((c["y"] - c["x"]) ** 2))

@@ -693,3 +693,32 @@ def test_l21_prior_and_tv_oracle_match_reference(golden_tree):
             for v in ("x", "z"):
                 close(rs[v], tr["r:" + v][it], rtol=1e-7, atol=1e-8)
                 close(vs[v], tr["v:" + v][it], rtol=1e-8)
+
+
+def vae_factors(c):
+    D, H, N = c["dims"]
+    return ([orc.GaussPriorFactor(D), orc.LinearFactor(c["W1"]), orc.BiasFactor(c["b1"]), orc.PWLFactor("l-relu", 0.1),
+             orc.LinearFactor(c["W2"]), orc.BiasFactor(c["b2"]), orc.Pwl3Factor("h-tanh"),
+             orc.GaussLikFactor(c["y"], c["noise_var"])],
+            [(D,), (H,), (H,), (H,), (N,), (N,), (N,)], ["z", "a1", "a2", "a3", "a4", "a5", "x"])
+
+
+def test_generative_prior_chain_oracle_matches_reference(golden_tree):
+    "VAE-like prior (examples/vae_prior/plot_vae.py): Linear -> Bias -> LeakyRelu -> Linear -> Bias -> HardTanh"
+    for c in golden_tree["vae"]:
+        g = orc.BiasFactor(c["b1"])
+        bb = c["msgs"]["b"]
+        for got, want in ((g.forward(1.3, bb, 0.7, 2 * bb), c["msgs"]["fwd"]), (g.backward(1.3, bb, 0.7, 2 * bb), c["msgs"]["bwd"])):
+            close(got[0], want[0], rtol=1e-14)
+            close(got[1], want[1], rtol=1e-14)
+        close(g.second_moment(1.7), c["msgs"]["tau"], rtol=1e-14)
+        fs, shapes, ids = vae_factors(c)
+        recs = []
+        with np.errstate(all="ignore"):
+            orc.ep_chain(fs, shapes, max_iter=10, damping=c["damping"], tol=0.0, max_increase=np.inf,
+                         record=lambda it, fwd, bwd, rs_, vs_: recs.append(([r.copy() for r in rs_], list(vs_))))
+        t = c["traj"]
+        for it in range(t["v:x"].shape[0]):
+            for i, vid in enumerate(ids):
+                close(recs[it][1][i], t[f"v:{vid}"][it], rtol=1e-6)
+                close(recs[it][0][i], t[f"r:{vid}"][it], rtol=1e-6, atol=1e-6 * max(1.0, np.abs(t[f"r:{vid}"][it]).max()))

@@ -901,9 +901,43 @@ def tree_goldens():
                         n_iter=ep.n_iter, error=err, traj=pack_traj(rec.iters[:10]) if rec.iters else None,
                         mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2)) if rec.iters else None))
         print("tv ep", name, "n_iter", ep.n_iter, err, "mse", tvs[-1]["mse"], "y mse", float(np.mean((y - x)**2)))
+    # generative (VAE-like) prior as in examples/vae_prior/plot_vae.py: Gaussian latent -> Linear -> Bias ->
+    # LeakyRelu -> Linear -> Bias -> HardTanh, observed through Gaussian noise (denoising)
+    from tramp.channels import BiasChannel
+    vae = []
+    for seed, (D, H, N), nv, damping in [(3, (8, 24, 32), 0.05, 0.3), (4, (6, 20, 40), 0.1, 0.5)]:
+        r = np.random.RandomState(seed)
+        W1, b1 = r.standard_normal((H, D)) / np.sqrt(D), 0.3 * r.standard_normal(H)
+        W2, b2 = r.standard_normal((N, H)) / np.sqrt(H), 0.3 * r.standard_normal(N)
+        z0 = r.standard_normal(D)
+        h = W1 @ z0 + b1
+        h = np.where(h > 0, h, 0.1 * h)
+        x = np.clip(W2 @ h + b2, -1, 1)
+        y = x + np.sqrt(nv) * r.standard_normal(N)
+        bch = BiasChannel(b1)
+        bb = r.standard_normal(H)
+        msgs = dict(b=bb, fwd=bch.compute_forward_message(1.3, bb, 0.7, 2 * bb),
+                    bwd=bch.compute_backward_message(1.3, bb, 0.7, 2 * bb), tau=bch.second_moment(1.7))
+        model = (GaussianPrior(size=D) @ V(id="z") @ LinearChannel(W1, name="W1") @ V(id="a1") @ BiasChannel(b1)
+                 @ V(id="a2") @ LeakyReluChannel(slope=0.1) @ V(id="a3") @ LinearChannel(W2, name="W2") @ V(id="a4")
+                 @ BiasChannel(b2) @ V(id="a5") @ HardTanhChannel() @ V(id="x")
+                 @ GaussianLikelihood(y=y, var=nv)).to_model()
+        ep = ExpectationPropagation(model)
+        rec = Recorder(EarlyStoppingEP())
+        err = None
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=40, callback=rec, damping=damping)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        vae.append(dict(seed=seed, dims=(D, H, N), noise_var=nv, damping=damping, W1=W1, b1=b1, W2=W2, b2=b2, x=x, y=y,
+                        msgs=msgs, n_iter=ep.n_iter, error=err, traj=pack_traj(rec.iters[:10]),
+                        mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2))))
+        print("vae prior ep", (D, H, N), damping, "n_iter", ep.n_iter, err, "mse", vae[-1]["mse"], "y mse", float(np.mean((y - x)**2)))
     save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
          ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object),
-         se=np.array(ses, dtype=object), l21=np.array(l21, dtype=object), tv=np.array(tvs, dtype=object))
+         se=np.array(ses, dtype=object), l21=np.array(l21, dtype=object), tv=np.array(tvs, dtype=object),
+         vae=np.array(vae, dtype=object))
 
 
 # ---------------------------------------------------------------- SE

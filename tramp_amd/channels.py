@@ -78,6 +78,50 @@ class GaussianChannel(Channel):
         return self.a / (self.a + ax) * ax                     # :40-43
 
 
+class BiasChannel(Channel):
+    """x = z + bias (tramp/channels/linear/bias_channel.py:5-33): the precision passes through, the mean
+    message is shifted by a * bias.  One bias vector shared by the ensemble."""
+
+    def __init__(self, bias, dtype=np.float64, ctx=None):
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.bias = np.asarray(bias, dtype=np.float64)
+        self._bias_dev = None
+
+    def sample(self, Z):
+        return Z + self.bias
+
+    def second_moment(self, tau_z):
+        return tau_z + (self.bias**2).mean()                   # :16-18
+
+    def compute_forward_state_evolution(self, az, ax, tau_z):
+        return az                                              # :31-33
+
+    def compute_backward_state_evolution(self, az, ax, tau_z):
+        return ax                                              # :35-37
+
+    def _message(self, direction, a_in, b_in, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None):
+        ctx = self.ctx
+        if self._bias_dev is None:
+            self._bias_dev = ctx.array(self.bias.reshape(-1).astype(self.dtype), self.dtype)
+        b = VecArg(ctx, b_in, self.dtype)
+        if b.n != self._bias_dev.shape[0]:
+            raise ValueError(f"expected messages of {self._bias_dev.shape[0]} components, got {b.n}")
+        a = ScalArg(ctx, a_in, b.batch)
+        a_new = out_a if out_a is not None else ctx.empty((b.batch,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, b, self.dtype)
+        ctx._call("tramp_bias_channel", self._dt, direction, b.n, b.batch, self._bias_dev.ptr, a.dev.ptr, b.dev.ptr,
+                  float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr)
+        return ret_scal(a_new, a, b), ret_vec(b_new, b)
+
+    def compute_forward_message(self, az, bz, ax, bx, **kw):
+        return self._message(_lib.FWD, az, bz, **kw)            # :21-24
+
+    def compute_backward_message(self, az, bz, ax, bx, **kw):
+        return self._message(_lib.BWD, ax, bx, **kw)            # :26-29
+
+
 # ------------------------------------------------------------------ componentwise
 class PiecewiseLinearChannel(Channel):
     """x = f(z), f piecewise linear with two half-line regions (kernel K7).
@@ -1329,6 +1373,7 @@ CHANNEL_CLASSES = {
     "gradient": GradientChannel,
     "unitary": UnitaryChannel,
     "reshape": ReshapeChannel,
+    "bias": BiasChannel,
 }
 
 

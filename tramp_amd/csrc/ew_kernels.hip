@@ -1171,6 +1171,49 @@ extern "C" int tramp_gauss_channel(tramp_ctx* ctx, int dtype, size_t n, size_t b
     return TRAMP_OK;
 }
 
+// ---------------------------------------------------------------- bias channel x = z + bias
+// BiasChannel.compute_forward_message / compute_backward_message (tramp/channels/linear/bias_channel.py:21-29):
+// forward (a_new, b_new) = (az, bz + az bias), backward (ax, bx - ax bias); bias is one vector shared by the
+// ensemble.  sign = +1 forward, -1 backward.  Constant damping fused.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bias_channel_kernel(size_t n, double sign, const T* __restrict__ bias,
+                                                              const double* __restrict__ a_in, const T* __restrict__ b_in,
+                                                              double damping, const double* a_old, const T* b_old,
+                                                              double* a_new, T* b_new) {
+    const size_t b = blockIdx.y;
+    const T sa = T(sign * a_in[b]), dT = T(damping), omd = T(1.0 - damping);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        T v = b_in[b * n + i] + sa * bias[i];
+        if (damping != 0.0) v = dT * b_old[b * n + i] + omd * v;
+        b_new[b * n + i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        a_new[b] = (damping != 0.0) ? damping * a_old[b] + (1.0 - damping) * a_in[b] : a_in[b];
+}
+
+extern "C" int tramp_bias_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batch, const void* bias_d,
+                                  const double* a_in_d, const void* b_in_d, double damping,
+                                  const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, bias_d && a_in_d && b_in_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!n || !batch) return TRAMP_OK;
+    const double sign = dir == TRAMP_FWD ? 1.0 : -1.0;
+    dim3 grid(blocks_for(n, 1), (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((bias_channel_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, sign,
+                           (const double*)bias_d, a_in_d, (const double*)b_in_d, damping, a_old_d,
+                           (const double*)b_old_d, a_new_d, (double*)b_new_d);
+    else
+        hipLaunchKernelGGL((bias_channel_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, sign,
+                           (const float*)bias_d, a_in_d, (const float*)b_in_d, damping, a_old_d,
+                           (const float*)b_old_d, a_new_d, (float*)b_new_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 // ---------------------------------------------------------------- variable -> factor message on a tree
 // Variable.forward_message / backward_message (tramp/base.py:186-211): the message a variable of degree
 // k sends to one neighbour is the sum of ALL its incoming messages minus that neighbour's own,
