@@ -1558,7 +1558,7 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
 
 
 def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1e-6,
-            wait_increase=5, max_increase=0.2, record=None, a0=0., b0=0.):
+            wait_increase=5, max_increase=0.2, record=None, a0=0., b0=0., init=None):
     """Expectation propagation on a tree-structured model (message_passing.py:211-269,330-357 with
     the variable nodes of tramp/base.py:152-211).
 
@@ -1588,6 +1588,9 @@ def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1
         v = s if s in shapes else t
         msg[(s, t)] = (a0, b0 * np.ones(shapes[v]))               # ConstantInit (initial_conditions.py:13-24)
         msg[(t, s)] = (a0, b0 * np.ones(shapes[v]))
+        if init is not None:                                      # init(variable, direction) -> (a, b), e.g. NoisyInit
+            msg[(s, t)] = init(v, "fwd")
+            msg[(t, s)] = init(v, "bwd")
     d = damping if damping else 0.
 
     def damp(old, new):

@@ -23,7 +23,7 @@ from .variables import SISOVariable, SILeafVariable, SIMOVariable, MISOVariable,
 from .models import (Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution,
                      sparse_gradient_regression)
 from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, EarlyStopping,
-                    ConstantInit, CustomInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
+                    ConstantInit, CustomInit, NoisyInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
                     TrackEstimate, TrackMessages, TrackObjective, TrackOverlaps, LogProgress)
 
 __version__ = "0.1.0"

@@ -44,7 +44,7 @@ class ConstantInit:
 
 
 class CustomInit(ConstantInit):
-    "Per-(variable id, direction) constants (initial_conditions.py:45-85), scalar b only."
+    "Per-(variable id, direction) values (initial_conditions.py:45-85): b a constant or an array of the variable's shape."
 
     def __init__(self, a_init=None, b_init=None, a=0, b=0):
         super().__init__(a, b)
@@ -56,6 +56,31 @@ class CustomInit(ConstantInit):
 
     def init_b(self, shape, id, direction):
         return self.b_init.get((id, direction), self.b)
+
+
+class NoisyInit(ConstantInit):
+    "Random initial messages (tramp/algos/initial_conditions.py:27-42); every instance of an ensemble draws its own b"
+
+    def __init__(self, a_mean=0, a_var=0, b_mean=0, b_var=1):
+        self.a_mean, self.a_var, self.b_mean, self.b_var = a_mean, a_var, b_mean, b_var
+        self.a_sigma, self.b_sigma = np.sqrt(a_var), np.sqrt(b_var)
+
+    def init_a(self, shape, id, direction):
+        return self.a_mean + self.a_sigma * np.random.standard_normal()
+
+    def init_b(self, shape, id, direction):
+        return self.b_mean + self.b_sigma * np.random.standard_normal(shape)
+
+
+def fill_message(buf, value):
+    "initial b of one message: a constant, or an array of the variable's shape (shared by the instances) / [batch, n]"
+    if np.ndim(value) == 0:
+        buf.fill(float(value))
+        return
+    h = np.asarray(value, dtype=buf.dtype)
+    B, n = buf.shape
+    h = h.reshape(B, n) if h.size == B * n and B > 1 else np.broadcast_to(h.reshape(1, n), (B, n))
+    buf.set(np.ascontiguousarray(h))
 
 
 # ------------------------------------------------------------------ callbacks
@@ -310,8 +335,8 @@ class ExpectationPropagation:
             shape = self.shapes[v.id]
             self.a_fwd[i].fill(initializer.init_a(shape, v.id, "fwd"))
             self.a_bwd[i].fill(initializer.init_a(shape, v.id, "bwd"))
-            self.b_fwd[i].fill(initializer.init_b(shape, v.id, "fwd"))
-            self.b_bwd[i].fill(initializer.init_b(shape, v.id, "bwd"))
+            fill_message(self.b_fwd[i], initializer.init_b(shape, v.id, "fwd"))
+            fill_message(self.b_bwd[i], initializer.init_b(shape, v.id, "bwd"))
             self.r[i].fill(0.0)
             self.b_fwd[i].version += 1
             self.b_bwd[i].version += 1
@@ -642,5 +667,5 @@ class StateEvolution:
 
 
 __all__ = ["ExpectationPropagation", "StateEvolution", "EarlyStoppingEP", "EarlyStopping", "ConstantInit",
-           "CustomInit", "JoinCallback", "PassCallback", "TrackEvolution", "TrackErrors", "Factor", "Variable",
+           "CustomInit", "NoisyInit", "JoinCallback", "PassCallback", "TrackEvolution", "TrackErrors", "Factor", "Variable",
            "_lib"]

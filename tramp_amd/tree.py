@@ -18,7 +18,7 @@ import ctypes as C
 
 import numpy as np
 
-from .algos import ExpectationPropagation
+from .algos import ExpectationPropagation, fill_message
 from .base import Factor, Variable
 from .device import default_context, dtype_code
 from .likelihoods import GaussianLikelihood
@@ -105,7 +105,7 @@ class TreeExpectationPropagation(ExpectationPropagation):
             direction = "fwd" if g.has_edge(src, dst) else "bwd"
             shape = self.shapes[var.id]
             m.a.fill(initializer.init_a(shape, var.id, direction))
-            m.b.fill(initializer.init_b(shape, var.id, direction))
+            fill_message(m.b, initializer.init_b(shape, var.id, direction))
             m.b.version += 1
         for r in self.r:
             r.fill(0.0)
