@@ -446,3 +446,22 @@ def test_generative_prior_chain_matches_reference(ctx, golden_tree):
         mse = float(np.mean((iters[-1]["x"][0] - c["x"]) ** 2))
         close(mse, c["mse"], 1e-4)
         assert mse < 0.3 * float(np.mean((c["y"] - c["x"]) ** 2))
+
+
+def test_tree_to_observed_equals_direct_likelihood(ctx, golden_tree):
+    "examples/sparse/plot_raccoon_denoise.py:111-119: `noise @ O('y')` on a tree, then to_observed({'y': y})"
+    import tramp_amd as T
+    e = golden_tree["ep"][2]
+    shape = tuple(e["shape"])
+    d = len(shape)
+    generative = (T.GaussianPrior(size=shape, ctx=ctx) @ T.SIMOVariable(id="x", n_next=2) @ (
+        T.GaussianChannel(var=e["noise_var"], ctx=ctx) @ T.SILeafVariable(id="y") + (
+            T.GradientChannel(shape=shape, ctx=ctx) + T.GaussBernoulliPrior(size=(d,) + shape, rho=e["rho"], ctx=ctx)
+        ) @ T.MILeafVariable(id="x'", n_prev=2))).to_model()
+    assert [v.id for v in generative.variables if v.n_next == 0] == ["y", "x'"] or \
+        sorted(v.id for v in generative.variables if v.n_next == 0) == ["x'", "y"]
+    observed = generative.to_observed({"y": e["y"].ravel()})
+    assert sorted(v.id for v in observed.variables) == ["x", "x'"]
+    ep = T.ExpectationPropagation(observed, ctx=ctx).iterate(max_iter=12, callback=T.PassCallback())
+    close(ep.get_variable_data("x")["r"], np.ravel(e["traj"]["r:x"][11]), 1e-7, 1e-8)
+    close(ep.get_variable_data("x'")["r"], np.ravel(e["traj"]["r:z"][11]), 1e-7, 1e-8)
