@@ -426,6 +426,14 @@ int tramp_gauss_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, doubl
 int tramp_bias_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batch, const void* bias_d,
                        const double* a_in_d, const void* b_in_d, double damping,
                        const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d);
+/* SumChannel x = z_1 + ... + z_K (tramp/channels/linear/sum_channel.py:26-43), K <= 8: az_d / bz_d are host
+ * arrays of K device pointers (the messages z_k -> factor).  target = -1: forward message to x
+ * (1 / v_bar, r_bar / v_bar); target = k: backward message to z_k, which also needs the message (ax, bx)
+ * from x.  Constant damping fused (old may alias new). */
+int tramp_sum_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k,
+                      const double* const* az_d, const void* const* bz_d,
+                      const double* ax_d, const void* bx_d, int target, double damping,
+                      const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d);
 /* Variable.forward_message / backward_message on a tree (tramp/base.py:186-211): out = sum of the k
  * incoming messages (host arrays of k device pointers, k <= 8) minus message `exclude` (the target's own;
  * -1: plain sum = Variable.posterior_ab, base.py:152-155). */

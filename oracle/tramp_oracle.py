@@ -1264,6 +1264,31 @@ class BiasFactor(OracleFactor):
         return tau_z + (self.bias**2).mean()
 
 
+class SumFactor(OracleFactor):
+    """tramp/channels/linear/sum_channel.py:26-43: x = sum_k z_k, K inputs.  forward(az, bz, ax, bx) takes lists
+    az, bz; backward returns the K messages."""
+    kind = "multi"
+
+    def __init__(self, n_prev):
+        self.n_prev = n_prev
+
+    def forward(self, az, bz, ax, bx):
+        v_bar = sum(1 / a for a in az)
+        r_bar = sum(b / a for a, b in zip(az, bz))
+        return 1 / v_bar, r_bar / v_bar
+
+    def backward(self, az, bz, ax, bx):
+        v_bar = sum(1 / a for a in az)
+        r_bar = sum(b / a for a, b in zip(az, bz))
+        vx, rx = 1 / ax, bx / ax
+        vk = [vx + v_bar - 1 / a for a in az]
+        rk = [rx - r_bar + b / a for a, b in zip(az, bz)]
+        return [(1 / v, r / v) for v, r in zip(vk, rk)]
+
+    def second_moment(self, *taus):
+        return sum(taus)
+
+
 class ReshapeFactor(OracleFactor):
     "tramp/channels/shape/reshape_channel.py:27-31"
 
@@ -1598,6 +1623,17 @@ def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1
 
     def factor_send(f, direction):
         fac = factors[f]
+        if fac.kind == "multi":                                  # K inputs, one output (SumChannel)
+            nxt = succ[f][0]
+            az, bz = [msg[(p, f)][0] for p in pred[f]], [msg[(p, f)][1] for p in pred[f]]
+            with np.errstate(all="ignore"):
+                if direction == "fwd":
+                    news, tgts = [fac.forward(az, bz, *msg[(nxt, f)])], [nxt]
+                else:
+                    news, tgts = fac.backward(az, bz, *msg[(nxt, f)]), pred[f]
+            for new, t in zip(news, tgts):
+                msg[(f, t)] = damp(msg[(f, t)], new)
+            return
         prev = pred[f][0] if pred[f] else None
         nxt = succ[f][0] if succ[f] else None
         target = nxt if direction == "fwd" else prev

@@ -465,3 +465,78 @@ def test_tree_to_observed_equals_direct_likelihood(ctx, golden_tree):
     ep = T.ExpectationPropagation(observed, ctx=ctx).iterate(max_iter=12, callback=T.PassCallback())
     close(ep.get_variable_data("x")["r"], np.ravel(e["traj"]["r:x"][11]), 1e-7, 1e-8)
     close(ep.get_variable_data("x'")["r"], np.ravel(e["traj"]["r:z"][11]), 1e-7, 1e-8)
+
+
+def test_committee_machine_matches_reference(ctx, golden_tree):
+    """Committee machine (tramp/models/committee_model.py:8-41): K experts sharing the sensing matrix, summed by
+    the K-input SumChannel.  SumChannel messages and every message / posterior of the reference's EP run."""
+    import tramp_amd as T
+    from tramp_amd.base import Variable
+    for c in golden_tree["com"]:
+        K, N, M = c["K"], c["N"], c["M"]
+        m = c["msgs"]
+        sm = T.SumChannel(n_prev=K, ctx=ctx)
+        fa, fb = sm.compute_forward_message(m["az"], m["bz"], m["ax"], m["bx"])
+        close(fa, m["fwd"][0], 1e-13)
+        close(fb, m["fwd"][1], 1e-12, 1e-13)
+        ba, bb = sm.compute_backward_message(m["az"], m["bz"], m["ax"], m["bx"])
+        for k in range(K):
+            close(ba[k], m["bwd"][0][k], 1e-13)
+            close(bb[k], m["bwd"][1][k], 1e-12, 1e-13)
+        F = np.random.RandomState(17 + K).standard_normal((M, N)) / np.sqrt(N)
+        shared = T.LinearChannel(F, ctx=ctx, svd="host")
+        experts = None
+        for k in range(K):
+            lin = shared if k == 0 else T.LinearChannel(F, ctx=ctx, factors=(shared._Uk, shared._sing, shared._Vt, shared.rank))
+            e = (T.GaussianPrior(size=N, var=c["pvars"][k], ctx=ctx) @ T.SISOVariable(id=f"x_{k}") @ lin
+                 @ T.SISOVariable(id=f"z_{k}") @ T.ReluChannel(ctx=ctx) @ T.SISOVariable(id=f"a_{k}"))
+            experts = e if experts is None else experts + e
+        model = (experts @ T.SumChannel(n_prev=K, ctx=ctx) @ T.SISOVariable(id="n")
+                 @ T.GaussianLikelihood(y=c["y"], var=c["noise_var"], ctx=ctx)).to_model()
+        assert not model.is_chain
+        g = model.dag
+
+        def name(node):
+            if isinstance(node, Variable):
+                return node.id
+            ids = sorted(v.id for v in list(g.predecessors(node)) + list(g.successors(node)))
+            return f"{type(node).__name__}[{','.join(ids)}]"
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        iters = []
+
+        def cb(algo, i, max_iter):
+            rec = {}
+            for (src, dst), msg in algo.msg.items():
+                rec[f"{name(src)}->{name(dst)}:a"], rec[f"{name(src)}->{name(dst)}:b"] = msg.a.get().copy(), msg.b.get().copy()
+            for vid, d in algo.get_variables_data().items():
+                rec["r:" + vid], rec["v:" + vid] = np.array(d["r"]), np.array(d["v"])
+            iters.append(rec)
+            return False
+        ep.iterate(max_iter=12, callback=cb, damping=c["damping"])
+        tr = c["traj"]
+        for it, got in enumerate(iters):
+            tol = 1e-7 if it < 6 else 1e-5
+            for key, val in got.items():
+                ref = np.asarray(tr[key][it], dtype=float)
+                if key.endswith(":a") or key.startswith("v:"):
+                    close(np.ravel(val)[0], ref, tol)
+                else:
+                    close(np.ravel(val), np.ravel(ref), tol, tol * max(1.0, float(np.abs(ref).max())))
+
+
+def test_soft_committee_builder_end_to_end(ctx):
+    "committee_model.py:57-73 through sample() -> to_observed() -> EP: the noisy sum is explained by the experts"
+    import tramp_amd as T
+    np.random.seed(3)
+    model = T.soft_committee(K=2, N=32, alpha=3.0, ensemble_type="gaussian", prior_mean=0.0, prior_var=[1.0, 0.5],
+                             noise_var=1e-2, ctx=ctx)
+    X = model.sample()
+    assert set(X) == {"x_0", "z_0", "a_0", "x_1", "z_1", "a_1", "n", "y"} and X["y"].shape == (96,)
+    lins = [f for f in model.factors if isinstance(f, T.LinearChannel)]
+    assert len(lins) == 2 and lins[0]._Vt.ptr == lins[1]._Vt.ptr          # one factorisation, shared
+    observed = model.to_observed({"y": X["y"]})
+    ep = T.ExpectationPropagation(observed, ctx=ctx).iterate(max_iter=50, damping=0.3)
+    data = ep.get_variables_data()
+    assert all(np.all(np.isfinite(d["r"])) for d in data.values())
+    assert np.mean((data["n"]["r"] - X["n"]) ** 2) < 1e-2 * np.mean(X["n"] ** 2)
+    assert np.mean((data["a_0"]["r"] + data["a_1"]["r"] - X["n"]) ** 2) < 1e-2 * np.mean(X["n"] ** 2)

@@ -722,3 +722,49 @@ def test_generative_prior_chain_oracle_matches_reference(golden_tree):
             for i, vid in enumerate(ids):
                 close(recs[it][1][i], t[f"v:{vid}"][it], rtol=1e-6)
                 close(recs[it][0][i], t[f"r:{vid}"][it], rtol=1e-6, atol=1e-6 * max(1.0, np.abs(t[f"r:{vid}"][it]).max()))
+
+
+def committee_graph(c):
+    "names as the generator's: variables by id, factors by class and surrounding variable ids"
+    K, N, M = c["K"], c["N"], c["M"]
+    F = np.random.RandomState(17 + K).standard_normal((M, N)) / np.sqrt(N)
+    factors, edges, shapes = {}, [], {"n": (M,)}
+    summed = ",".join(sorted([f"a_{k}" for k in range(K)] + ["n"]))
+    for k in range(K):
+        p, lin, act = f"GaussianPrior[x_{k}]", f"LinearChannel[x_{k},z_{k}]", f"ReluChannel[a_{k},z_{k}]"
+        factors[p] = orc.GaussPriorFactor(N, var=c["pvars"][k])
+        factors[lin] = orc.LinearFactor(F)
+        factors[act] = orc.PWLFactor("relu")
+        edges += [(p, f"x_{k}"), (f"x_{k}", lin), (lin, f"z_{k}"), (f"z_{k}", act), (act, f"a_{k}"),
+                  (f"a_{k}", f"SumChannel[{summed}]")]
+        shapes.update({f"x_{k}": (N,), f"z_{k}": (M,), f"a_{k}": (M,)})
+    factors[f"SumChannel[{summed}]"] = orc.SumFactor(K)
+    factors["GaussianLikelihood[n]"] = orc.GaussLikFactor(c["y"], c["noise_var"])
+    edges += [(f"SumChannel[{summed}]", "n"), ("n", "GaussianLikelihood[n]")]
+    return F, factors, edges, shapes
+
+
+def test_committee_machine_oracle_matches_reference(golden_tree):
+    "K experts summed by the K-input SumChannel (committee_model.py:8-41): every message, every iteration"
+    for c in golden_tree["com"]:
+        m = c["msgs"]
+        s = orc.SumFactor(c["K"])
+        fa, fb = s.forward(m["az"], m["bz"], m["ax"], m["bx"])
+        close(fa, m["fwd"][0], rtol=1e-14)
+        close(fb, m["fwd"][1], rtol=1e-13)
+        for (a, b), wa, wb in zip(s.backward(m["az"], m["bz"], m["ax"], m["bx"]), m["bwd"][0], m["bwd"][1]):
+            close(a, wa, rtol=1e-14)
+            close(b, wb, rtol=1e-13)
+        F, factors, edges, shapes = committee_graph(c)
+        recs = []
+        orc.ep_tree(factors, list(shapes), edges, shapes, max_iter=12, damping=c["damping"], tol=0.0, max_increase=np.inf,
+                    record=lambda it, msg, rs, vs: recs.append((dict(msg), dict(rs), dict(vs))))
+        tr = c["traj"]
+        for it, (msg, rs, vs) in enumerate(recs):
+            tol = 1e-8 if it < 6 else 1e-6
+            for (s_, t), (a, b) in msg.items():
+                close(a, tr[f"{s_}->{t}:a"][it], rtol=tol)
+                close(b, tr[f"{s_}->{t}:b"][it], rtol=tol, atol=tol * max(1.0, np.abs(tr[f"{s_}->{t}:b"][it]).max()))
+            for v in shapes:
+                close(rs[v], tr["r:" + v][it], rtol=tol, atol=tol)
+                close(vs[v], tr["v:" + v][it], rtol=tol)

@@ -934,10 +934,64 @@ def tree_goldens():
                         msgs=msgs, n_iter=ep.n_iter, error=err, traj=pack_traj(rec.iters[:10]),
                         mse=float(np.mean((rec.iters[-1]["r:x"] - x)**2))))
         print("vae prior ep", (D, H, N), damping, "n_iter", ep.n_iter, err, "mse", vae[-1]["mse"], "y mse", float(np.mean((y - x)**2)))
+    # committee machine (models/committee_model.py:8-41): K experts prior -> x_k -> F -> z_k -> relu -> a_k sharing
+    # the sensing matrix, summed by the K-input SumChannel, observed through Gaussian noise
+    from tramp.channels import SumChannel
+
+    def nb_name(algo, node):
+        "variables by id; factors by class and the ids of the variables around them (several share a class)"
+        if isinstance(node, Variable):
+            return node.id
+        g = algo.model_dag
+        ids = sorted(v.id for v in list(g.predecessors(node)) + list(g.successors(node)))
+        return f"{type(node).__name__}[{','.join(ids)}]"
+
+    com = []
+    for K, N, alpha, pvars, nv, damping in [(2, 24, 2.0, [1.0, 0.5], 1e-2, 0.2), (3, 16, 3.0, [1.0, 0.6, 0.3], 5e-2, 0.3)]:
+        r = np.random.RandomState(17 + K)
+        M = int(alpha * N)
+        F = r.standard_normal((M, N)) / np.sqrt(N)
+        xs = [np.sqrt(v) * r.standard_normal(N) for v in pvars]
+        y = sum(np.maximum(0, F @ x) for x in xs) + np.sqrt(nv) * r.standard_normal(M)
+        experts = None
+        for k in range(K):
+            e = (GaussianPrior(size=N, var=pvars[k]) @ V(id=f"x_{k}") @ LinearChannel(F, name="F") @ V(id=f"z_{k}")
+                 @ ReluChannel() @ V(id=f"a_{k}"))
+            experts = e if experts is None else experts + e
+        model = (experts @ SumChannel(n_prev=K) @ V(id="n") @ GaussianLikelihood(y=y, var=nv)).to_model()
+        ep = ExpectationPropagation(model)
+        iters = []
+
+        def cb(algo, i, max_iter):
+            rec = {}
+            for source, target, data in algo.message_dag.edges(data=True):
+                key = f"{nb_name(algo, source)}->{nb_name(algo, target)}"
+                rec[key + ":a"] = float(data["a"])
+                rec[key + ":b"] = np.array(data["b"], dtype=float)
+            for vid, dd in algo.get_variables_data().items():
+                rec[f"r:{vid}"] = np.array(dd["r"], dtype=float)
+                rec[f"v:{vid}"] = float(dd["v"])
+            iters.append(rec)
+            return False
+        err = None
+        try:
+            with np.errstate(all="ignore"):
+                ep.iterate(max_iter=12, callback=cb, damping=damping)
+        except Exception as e:    # noqa: BLE001
+            err = repr(e)
+        sm = SumChannel(n_prev=K)
+        azs, bzs = list(r.uniform(0.5, 2, K)), [r.standard_normal(5) for _ in range(K)]
+        bxs = r.standard_normal(5)
+        msgs = dict(az=azs, bz=bzs, ax=0.7, bx=bxs, fwd=sm.compute_forward_message(azs, bzs, 0.7, bxs),
+                    bwd=sm.compute_backward_message(azs, bzs, 0.7, bxs))
+        com.append(dict(K=K, N=N, M=M, pvars=pvars, noise_var=nv, damping=damping, xs=xs, y=y, error=err,   # F: first draw of RandomState(17 + K)
+                        msgs=msgs, traj=pack_traj(iters),
+                        mse=[float(np.mean((iters[-1][f"r:x_{k}"] - xs[k])**2)) for k in range(K)]))
+        print("committee ep", K, N, damping, err, "mse", com[-1]["mse"])
     save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
          ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object),
          se=np.array(ses, dtype=object), l21=np.array(l21, dtype=object), tv=np.array(tvs, dtype=object),
-         vae=np.array(vae, dtype=object))
+         vae=np.array(vae, dtype=object), com=np.array(com, dtype=object))
 
 
 # ---------------------------------------------------------------- SE

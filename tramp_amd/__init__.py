@@ -17,11 +17,11 @@ from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, Relu
 from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
                        SymmetricDoorChannel, ConvChannel, Blur1DChannel, Blur2DChannel,
-                       DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel, ReshapeChannel, BiasChannel,
+                       DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel, ReshapeChannel, BiasChannel, SumChannel,
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
 from .variables import SISOVariable, SILeafVariable, SIMOVariable, MISOVariable, MILeafVariable
 from .models import (Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution,
-                     sparse_gradient_regression)
+                     sparse_gradient_regression, committee, soft_committee)
 from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, EarlyStopping,
                     ConstantInit, CustomInit, NoisyInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
                     TrackEstimate, TrackMessages, TrackObjective, TrackOverlaps, LogProgress)

@@ -122,6 +122,66 @@ class BiasChannel(Channel):
         return self._message(_lib.BWD, ax, bx, **kw)            # :26-29
 
 
+class SumChannel(Channel):
+    """x = z_1 + ... + z_K (tramp/channels/linear/sum_channel.py:5-56): the K-input factor of the committee
+    machine (tramp/models/committee_model.py:35).  ``az``, ``bz`` are lists of K messages."""
+
+    n_next = 1
+
+    def __init__(self, n_prev, dtype=np.float64, ctx=None):
+        self.n_prev = n_prev
+        self.repr_init()
+        self._init_device(dtype, ctx)
+
+    def sample(self, *Zs):
+        if len(Zs) != self.n_prev:
+            raise ValueError(f"expect {self.n_prev} arrays")
+        return sum(Zs)
+
+    def second_moment(self, *tau_zs):
+        if len(tau_zs) != self.n_prev:
+            raise ValueError(f"expect {self.n_prev} arrays")
+        return sum(tau_zs)
+
+    def compute_forward_state_evolution(self, az, ax, tau_z):
+        return 1 / sum(1 / a for a in az)                                    # :45-49
+
+    def compute_backward_state_evolution(self, az, ax, tau_z):
+        v_bar = sum(1 / a for a in az)                                       # :51-56
+        return [1 / (1 / ax + v_bar - 1 / a) for a in az]
+
+    def _message(self, target, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None):
+        ctx = self.ctx
+        if len(az) != self.n_prev or len(bz) != self.n_prev:
+            raise ValueError(f"expect {self.n_prev} messages")
+        zs = [VecArg(ctx, b, self.dtype) for b in bz]
+        B, n = zs[0].batch, zs[0].n
+        if any((z.batch, z.n) != (B, n) for z in zs):
+            raise ValueError("the summed messages must have the same shape")
+        azs = [ScalArg(ctx, a, B) for a in az]
+        ap = (C.c_void_p * self.n_prev)(*[a.dev.ptr for a in azs])
+        bp = (C.c_void_p * self.n_prev)(*[z.dev.ptr for z in zs])
+        x = VecArg(ctx, bx, self.dtype) if target >= 0 else None
+        a_x = ScalArg(ctx, ax, B) if target >= 0 else None
+        a_new = out_a if out_a is not None else ctx.empty((B,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, zs[0], self.dtype)
+        ctx._call("tramp_sum_channel", self._dt, n, B, self.n_prev, ap, bp,
+                  a_x.dev.ptr if a_x is not None else None, x.dev.ptr if x is not None else None, target,
+                  float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr)
+        return ret_scal(a_new, azs[0], zs[0]), ret_vec(b_new, zs[0])
+
+    def compute_forward_message(self, az, bz, ax, bx, **kw):
+        return self._message(-1, az, bz, ax, bx, **kw)                        # :26-32
+
+    def compute_backward_message(self, az, bz, ax, bx, target=None, **kw):
+        "message to z_target; without ``target`` the list of all K messages as the reference returns (:34-43)"
+        if target is not None:
+            return self._message(target, az, bz, ax, bx, **kw)
+        outs = [self._message(k, az, bz, ax, bx) for k in range(self.n_prev)]
+        return [o[0] for o in outs], [o[1] for o in outs]
+
+
 # ------------------------------------------------------------------ componentwise
 class PiecewiseLinearChannel(Channel):
     """x = f(z), f piecewise linear with two half-line regions (kernel K7).
@@ -1374,6 +1434,7 @@ CHANNEL_CLASSES = {
     "unitary": UnitaryChannel,
     "reshape": ReshapeChannel,
     "bias": BiasChannel,
+    "sum": SumChannel,
 }
 
 

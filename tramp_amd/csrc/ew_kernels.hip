@@ -1242,6 +1242,68 @@ __global__ __launch_bounds__(kBlock) void message_sum_kernel(size_t n, int k, in
     }
 }
 
+// ---------------------------------------------------------------- sum channel x = z_1 + ... + z_K
+// SumChannel.compute_forward_message / compute_backward_message (tramp/channels/linear/sum_channel.py:26-43):
+//     v_bar = sum_k 1 / a_k,  r_bar = sum_k b_k / a_k;
+//     to x:   (1 / v_bar, r_bar / v_bar);
+//     to z_k: v_k = 1 / ax + v_bar - 1 / a_k,  r_k = bx / ax - r_bar + b_k / a_k,  (1 / v_k, r_k / v_k).
+// target = -1: the forward message; target = k: the backward message to z_k.  Constant damping fused.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_channel_kernel(size_t n, int k, int target, MsgPtrs in,
+                                                             const double* __restrict__ ax, const T* __restrict__ bx,
+                                                             double damping, const double* a_old, const T* b_old,
+                                                             double* a_new, T* b_new) {
+    const size_t b = blockIdx.y;
+    double v_bar = 0.0;
+    for (int j = 0; j < k; ++j) v_bar += 1.0 / in.a[j][b];
+    double v_t = v_bar;
+    if (target >= 0) v_t = 1.0 / ax[b] + v_bar - 1.0 / in.a[target][b];
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        double r_bar = 0.0;
+        for (int j = 0; j < k; ++j) r_bar += (double)static_cast<const T*>(in.b[j])[b * n + i] / in.a[j][b];
+        double r = r_bar;
+        if (target >= 0)
+            r = (double)bx[b * n + i] / ax[b] - r_bar +
+                (double)static_cast<const T*>(in.b[target])[b * n + i] / in.a[target][b];
+        double out = r / v_t;
+        if (damping != 0.0) out = damping * (double)b_old[b * n + i] + (1.0 - damping) * out;
+        b_new[b * n + i] = (T)out;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double an = 1.0 / v_t;
+        if (damping != 0.0) an = damping * a_old[b] + (1.0 - damping) * an;
+        a_new[b] = an;
+    }
+}
+
+extern "C" int tramp_sum_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k,
+                                 const double* const* az_d, const void* const* bz_d, const double* ax_d,
+                                 const void* bx_d, int target, double damping, const double* a_old_d,
+                                 const void* b_old_d, double* a_new_d, void* b_new_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && bz_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, k >= 1 && k <= kMaxMsgs && target >= -1 && target < k);
+    TRAMP_REQUIRE(ctx, target < 0 || (ax_d && bx_d));
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!n || !batch) return TRAMP_OK;
+    MsgPtrs in{};
+    for (int j = 0; j < k; ++j) {
+        TRAMP_REQUIRE(ctx, az_d[j] && bz_d[j]);
+        in.a[j] = az_d[j];
+        in.b[j] = bz_d[j];
+    }
+    dim3 grid(blocks_for(n, 1), (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((sum_channel_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, k, target, in, ax_d,
+                           (const double*)bx_d, damping, a_old_d, (const double*)b_old_d, a_new_d, (double*)b_new_d);
+    else
+        hipLaunchKernelGGL((sum_channel_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, k, target, in, ax_d,
+                           (const float*)bx_d, damping, a_old_d, (const float*)b_old_d, a_new_d, (float*)b_new_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 extern "C" int tramp_message_sum(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k,
                                  const double* const* a_in_d, const void* const* b_in_d, int exclude,
                                  double* a_out_d, void* b_out_d) {

@@ -279,6 +279,46 @@ def sparse_gradient_regression(A, y, x_shape, grad_rho, noise_var, prior_var=1.0
             @ GaussianLikelihood(y=y, var=noise_var, **kw)).to_model()
 
 
+def committee(K, N, alpha, ensemble_type, priors, activation1, activation2, noise_var, dtype=np.float64, ctx=None):
+    """tramp/models/committee_model.py:8-41: K experts prior_k -> x_k -> F -> z_k -> activation1 -> a_k sharing
+    the sensing matrix F, summed by the K-input SumChannel, then activation2 / Gaussian noise / the leaf y.
+    F is factorised once; the K LinearChannel nodes share the device factors."""
+    from .channels import SumChannel
+    if activation1 not in ["abs", "relu", "sgn"]:
+        raise ValueError(f"activation1={activation1} must be abs, sgn or relu")
+    if activation2 not in [None, "abs", "relu", "sgn"]:
+        raise ValueError(f"activation2={activation2} must be None, abs, sgn or relu")
+    if not isinstance(priors, list) or len(priors) != K:
+        raise ValueError(f"priors must be a list of length {K}")
+    M = int(alpha * N)
+    F = get_ensemble(ensemble_type, M=M, N=N).generate()
+    kw = dict(dtype=dtype, ctx=ctx)
+    shared = LinearChannel(F, name="F", keep_W=True, **kw)
+    experts = None
+    for k, prior in enumerate(priors):
+        lin = shared if k == 0 else LinearChannel(F, name="F", keep_W=True, **kw,
+                                                  factors=(shared._Uk, shared._sing, shared._Vt, shared.rank))
+        expert = DAG([get_prior(size=N, **prior, **kw), SISOVariable(id=f"x_{k}"), lin, SISOVariable(id=f"z_{k}"),
+                      get_channel(activation1, **kw), SISOVariable(id=f"a_{k}")])
+        experts = expert if experts is None else experts + expert
+    dag = experts @ SumChannel(n_prev=K, **kw)
+    if activation2 in ["abs", "relu", "sgn"]:
+        dag = dag @ SISOVariable(id="a") @ get_channel(activation2, **kw)
+    if noise_var:
+        dag = dag @ SISOVariable(id="n") @ GaussianChannel(var=noise_var, **kw)
+    return (dag @ SILeafVariable(id="y")).to_model()
+
+
+def soft_committee(K, N, alpha, ensemble_type, prior_mean, prior_var, noise_var, **kw):
+    "committee_model.py:57-73: Gaussian priors, relu experts, linear output"
+    prior_mean = [prior_mean] * K if isinstance(prior_mean, float) else prior_mean
+    prior_var = [prior_var] * K if isinstance(prior_var, float) else prior_var
+    if len(prior_mean) != K or len(prior_var) != K:
+        raise ValueError(f"prior_mean and prior_var must be lists of length {K}")
+    priors = [dict(prior_type="gaussian", mean=m, var=v) for m, v in zip(prior_mean, prior_var)]
+    return committee(K, N, alpha, ensemble_type, priors, "relu", None, noise_var, **kw)
+
+
 class MultiLayerModel(Model):
     "tramp/models/multi_layer_model.py:30-49"
 
@@ -304,5 +344,5 @@ class MultiLayerModel(Model):
         super().__init__(DAG(nodes))
 
 
-__all__ = ["DAG", "Model", "MultiLayerModel", "glm_generative", "glm_state_evolution", "sparse_gradient_regression",
+__all__ = ["DAG", "Model", "MultiLayerModel", "glm_generative", "glm_state_evolution", "sparse_gradient_regression", "committee", "soft_committee",
            "channel2likelihood", "PiecewiseLinearChannel"]

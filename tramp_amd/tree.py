@@ -41,8 +41,8 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.variables = model.variables
         self.factors = model.factors
         for f in self.factors:
-            if f.n_prev > 1 or f.n_next > 1:
-                raise ValueError(f"{f}: factors with several inputs or outputs are outside the HIP path")
+            if f.n_next > 1:
+                raise ValueError(f"{f}: factors with several outputs are outside the HIP path")
         for v in self.variables:
             if v.n_prev == 0:
                 raise ValueError(f"variable {v.id} has no incoming factor")
@@ -114,6 +114,8 @@ class TreeExpectationPropagation(ExpectationPropagation):
     # -- node updates
     def _factor_send(self, f, direction):
         g = self.model.dag
+        if f.n_prev > 1:
+            return self._multi_input_send(f, direction)
         prev = next(iter(g.predecessors(f)), None)
         nxt = next(iter(g.successors(f)), None)
         target = nxt if direction == "fwd" else prev
@@ -156,6 +158,27 @@ class TreeExpectationPropagation(ExpectationPropagation):
         out.b.version += 1
         if const and not d:
             self._const_done.add((f, direction))
+
+    def _multi_input_send(self, f, direction):
+        "K-input, one-output factor (SumChannel): forward to its output, backward one message per input"
+        g = self.model.dag
+        prevs = list(g.predecessors(f))
+        nxt = next(iter(g.successors(f)))
+        zs = [self.msg[(p, f)] for p in prevs]
+        x = self.msg[(nxt, f)]
+        az, bz = [m.a for m in zs], [m.b for m in zs]
+        d = self.damping
+        targets = [(nxt, None)] if direction == "fwd" else [(p, k) for k, p in enumerate(prevs)]
+        for tgt, k in targets:
+            out = self.msg[(f, tgt)]
+            kw = dict(out_a=out.a, out_b=out.b)
+            if d:
+                kw.update(damping=d, old_a=out.a, old_b=out.b)
+            if k is None:
+                f.compute_forward_message(az, bz, x.a, x.b, **kw)
+            else:
+                f.compute_backward_message(az, bz, x.a, x.b, target=k, **kw)
+            out.b.version += 1
 
     def _variable_send(self, v, targets):
         "Variable.forward_message / backward_message (tramp/base.py:186-211)"
@@ -249,6 +272,19 @@ class TreeStateEvolution:
 
     def _factor_send(self, f, direction, d):
         g = self.model.dag
+        if f.n_prev > 1:                                    # K-input factor (SumChannel)
+            prevs = list(g.predecessors(f))
+            nxt = next(iter(g.successors(f)))
+            az, taus = [self.msg[(p, f)] for p in prevs], [self.taus[p.id] for p in prevs]
+            if direction == "fwd":
+                news, tgts = [f.compute_forward_state_evolution(az, self.msg[(nxt, f)], taus)], [nxt]
+            else:
+                news, tgts = f.compute_backward_state_evolution(az, self.msg[(nxt, f)], taus), prevs
+            for new, t in zip(news, tgts):
+                if np.any(np.isnan(new)):
+                    raise ValueError(f"{f.id}->{t.id} a is nan")
+                self.msg[(f, t)] = d * self.msg[(f, t)] + (1 - d) * new if d else new
+            return
         prev = next(iter(g.predecessors(f)), None)
         nxt = next(iter(g.successors(f)), None)
         target = nxt if direction == "fwd" else prev
