@@ -405,6 +405,12 @@ int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  *      (tramp/algos/message_passing.py:119-127): x = d*old + (1-d)*x. */
 int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
                const double* a_old_d, const void* b_old_d, double* a_d, void* b_d);
+/* BinaryPrior p(x) = p+ delta(x - 1) + p- delta(x + 1) (tramp/priors/binary_prior.py:8-62, beliefs/binary.py):
+ * r = tanh(bx + b0), v = mean(1 - r^2), b0 = 0.5 log(p+ / p-); outputs optional as in tramp_gb_prior_fwd. */
+int tramp_binary_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                           const double* ax_d, const void* bx_d, double b0,
+                           double damping, const double* a_old_d, const void* b_old_d,
+                           double* a_new_d, void* b_new_d, void* r_d, double* v_d);
 /* MAP_L21NormPrior.compute_forward_posterior + compute_ab_new (tramp/priors/map_L21_norm_prior.py:7-20,69-74),
  * axis = 0: bx is [batch, d, n], groups are the d components of a site (the total-variation prior on a
  * gradient field).  count_d[batch]: sites with ||b[:, j]|| > gamma; mask_d[batch, n]: that support, bit-exact

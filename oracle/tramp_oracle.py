@@ -1131,6 +1131,23 @@ class GBPriorFactor(OracleFactor):
         return self.rho * (self.mean**2 + self.var)
 
 
+def binary_prior_posterior(ax, bx, p_pos=0.5):
+    "tramp/priors/binary_prior.py:27,52-58; beliefs/binary.py:8-13"
+    b = bx + 0.5 * np.log(p_pos / (1 - p_pos))
+    return np.tanh(b), (1 - np.tanh(b)**2).mean()
+
+
+class BinaryPriorFactor(OracleFactor):
+    kind = "prior"
+
+    def __init__(self, size, p_pos=0.5):
+        self.size, self.p_pos = size, p_pos
+
+    def forward(self, az, bz, ax, bx):
+        r, v = binary_prior_posterior(ax, bx, self.p_pos)
+        return ab_new(r, v, ax, bx)
+
+
 class L21PriorFactor(OracleFactor):
     kind = "prior"
 

@@ -540,3 +540,55 @@ def test_soft_committee_builder_end_to_end(ctx):
     assert all(np.all(np.isfinite(d["r"])) for d in data.values())
     assert np.mean((data["n"]["r"] - X["n"]) ** 2) < 1e-2 * np.mean(X["n"] ** 2)
     assert np.mean((data["a_0"]["r"] + data["a_1"]["r"] - X["n"]) ** 2) < 1e-2 * np.mean(X["n"] ** 2)
+
+
+def test_binary_prior_and_sgn_committee_match_reference(ctx, golden_tree):
+    "BinaryPrior (binary_prior.py:8-62) and the sign committee machine (committee_model.py:44-54), K = 3"
+    import tramp_amd as T
+    from tramp_amd.base import Variable
+    for c in golden_tree["binp"]:
+        for dtype, rt in ((np.float64, 1e-13), (np.float32, 2e-6)):
+            pr = T.BinaryPrior(size=9, p_pos=c["p_pos"], dtype=dtype, ctx=ctx)
+            r, v = pr.compute_forward_posterior(1.3, c["bx"])
+            close(r, c["r"], rt, rt)
+            close(v, c["v"], max(rt, 1e-12) * 10)
+            a, b = pr.compute_forward_message(1.3, c["bx"])
+            close(a, c["a_new"], max(rt * 100, 1e-11))
+            close(b, c["b_new"], rt * 100, rt * 100 * max(1.0, float(np.abs(c["b_new"]).max())))
+    c = golden_tree["sgncom"][0]
+    K, N, M = c["K"], c["N"], c["M"]
+    F = np.random.RandomState(29).standard_normal((M, N)) / np.sqrt(N)
+    shared = T.LinearChannel(F, ctx=ctx, svd="host")
+    experts = None
+    for k in range(K):
+        lin = shared if k == 0 else T.LinearChannel(F, ctx=ctx, factors=(shared._Uk, shared._sing, shared._Vt, shared.rank))
+        e = (T.BinaryPrior(size=N, p_pos=c["p_pos"][k], ctx=ctx) @ T.SISOVariable(id=f"x_{k}") @ lin
+             @ T.SISOVariable(id=f"z_{k}") @ T.SgnChannel(ctx=ctx) @ T.SISOVariable(id=f"a_{k}"))
+        experts = e if experts is None else experts + e
+    model = (experts @ T.SumChannel(n_prev=K, ctx=ctx) @ T.SISOVariable(id="a") @ T.SgnLikelihood(y=c["y"], ctx=ctx)).to_model()
+    g = model.dag
+
+    def name(node):
+        if isinstance(node, Variable):
+            return node.id
+        return f"{type(node).__name__}[{','.join(sorted(v.id for v in list(g.predecessors(node)) + list(g.successors(node))))}]"
+    iters = []
+
+    def cb(algo, i, max_iter):
+        rec = {}
+        for (src, dst), msg in algo.msg.items():
+            rec[f"{name(src)}->{name(dst)}:a"], rec[f"{name(src)}->{name(dst)}:b"] = msg.a.get().copy(), msg.b.get().copy()
+        for vid, d in algo.get_variables_data().items():
+            rec["r:" + vid] = np.array(d["r"])
+        iters.append(rec)
+        return False
+    T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=10, callback=cb, damping=c["damping"])
+    tr = c["traj"]
+    for it, got in enumerate(iters):
+        tol = 1e-6 if it < 5 else 1e-4
+        for key, val in got.items():
+            ref = np.asarray(tr[key][it], dtype=float)
+            if key.endswith(":a") and not key.startswith("r:"):
+                close(np.ravel(val)[0], ref, tol)
+            else:
+                close(np.ravel(val), np.ravel(ref), tol, tol * max(1.0, float(np.abs(ref).max())))

@@ -768,3 +768,46 @@ def test_committee_machine_oracle_matches_reference(golden_tree):
             for v in shapes:
                 close(rs[v], tr["r:" + v][it], rtol=tol, atol=tol)
                 close(vs[v], tr["v:" + v][it], rtol=tol)
+
+
+def sgn_committee_graph(c):
+    K, N, M = c["K"], c["N"], c["M"]
+    F = np.random.RandomState(29).standard_normal((M, N)) / np.sqrt(N)
+    factors, edges, shapes = {}, [], {"a": (M,)}
+    summed = ",".join(sorted([f"a_{k}" for k in range(K)] + ["a"]))
+    for k in range(K):
+        p, lin, act = f"BinaryPrior[x_{k}]", f"LinearChannel[x_{k},z_{k}]", f"SgnChannel[a_{k},z_{k}]"
+        factors[p] = orc.BinaryPriorFactor(N, p_pos=c["p_pos"][k])
+        factors[lin] = orc.LinearFactor(F)
+        factors[act] = orc.PWLFactor("sgn")
+        edges += [(p, f"x_{k}"), (f"x_{k}", lin), (lin, f"z_{k}"), (f"z_{k}", act), (act, f"a_{k}"),
+                  (f"a_{k}", f"SumChannel[{summed}]")]
+        shapes.update({f"x_{k}": (N,), f"z_{k}": (M,), f"a_{k}": (M,)})
+    factors[f"SumChannel[{summed}]"] = orc.SumFactor(K)
+    factors["SgnLikelihood[a]"] = orc.SgnLikFactor(c["y"])
+    edges += [(f"SumChannel[{summed}]", "a"), ("a", "SgnLikelihood[a]")]
+    return F, factors, edges, shapes
+
+
+def test_binary_prior_and_sgn_committee_oracle_match_reference(golden_tree):
+    for c in golden_tree["binp"]:
+        r, v = orc.binary_prior_posterior(1.3, c["bx"], c["p_pos"])
+        close(r, c["r"], rtol=1e-14)
+        close(v, c["v"], rtol=1e-14)
+        a, b = orc.BinaryPriorFactor(9, c["p_pos"]).forward(None, None, 1.3, c["bx"])
+        close(a, c["a_new"], rtol=1e-13)
+        close(b, c["b_new"], rtol=1e-12, atol=1e-13)
+    c = golden_tree["sgncom"][0]
+    F, factors, edges, shapes = sgn_committee_graph(c)
+    recs = []
+    with np.errstate(all="ignore"):
+        orc.ep_tree(factors, list(shapes), edges, shapes, max_iter=10, damping=c["damping"], tol=0.0, max_increase=np.inf,
+                    record=lambda it, msg, rs, vs: recs.append((dict(msg), dict(rs), dict(vs))))
+    tr = c["traj"]
+    for it, (msg, rs, vs) in enumerate(recs):
+        tol = 1e-7 if it < 5 else 1e-5
+        for (s_, t), (a, b) in msg.items():
+            close(a, tr[f"{s_}->{t}:a"][it], rtol=tol)
+            close(b, tr[f"{s_}->{t}:b"][it], rtol=tol, atol=tol * max(1.0, np.abs(tr[f"{s_}->{t}:b"][it]).max()))
+        for v in shapes:
+            close(rs[v], tr["r:" + v][it], rtol=tol, atol=tol)

@@ -988,10 +988,54 @@ def tree_goldens():
                         msgs=msgs, traj=pack_traj(iters),
                         mse=[float(np.mean((iters[-1][f"r:x_{k}"] - xs[k])**2)) for k in range(K)]))
         print("committee ep", K, N, damping, err, "mse", com[-1]["mse"])
+    # sign committee (committee_model.py:44-54): binary priors, sgn experts, majority vote
+    from tramp.priors import BinaryPrior
+    binp = []
+    for p_pos in (0.5, 0.8):
+        pr = BinaryPrior(size=9, p_pos=p_pos)
+        bx = rs.standard_normal(9) * 2
+        r_, v_ = pr.compute_forward_posterior(1.3, bx)
+        a_, b_ = pr.compute_forward_message(1.3, bx)
+        binp.append(dict(p_pos=p_pos, bx=bx, r=r_, v=v_, a_new=a_, b_new=b_))
+    K, N, alpha, p_pos, damping = 3, 16, 4.0, [0.5, 0.6, 0.4], 0.5
+    r = np.random.RandomState(29)
+    M = int(alpha * N)
+    F = r.standard_normal((M, N)) / np.sqrt(N)
+    xs = [np.where(r.uniform(size=N) < p, 1.0, -1.0) for p in p_pos]
+    y = np.sign(sum(np.sign(F @ x) for x in xs))
+    experts = None
+    for k in range(K):
+        e = (BinaryPrior(size=N, p_pos=p_pos[k]) @ V(id=f"x_{k}") @ LinearChannel(F, name="F") @ V(id=f"z_{k}")
+             @ SgnChannel() @ V(id=f"a_{k}"))
+        experts = e if experts is None else experts + e
+    model = (experts @ SumChannel(n_prev=K) @ V(id="a") @ SgnLikelihood(y=y)).to_model()
+    ep = ExpectationPropagation(model)
+    iters = []
+
+    def cb2(algo, i, max_iter):
+        rec = {}
+        for source, target, data in algo.message_dag.edges(data=True):
+            key = f"{nb_name(algo, source)}->{nb_name(algo, target)}"
+            rec[key + ":a"] = float(data["a"])
+            rec[key + ":b"] = np.array(data["b"], dtype=float)
+        for vid, dd in algo.get_variables_data().items():
+            rec[f"r:{vid}"] = np.array(dd["r"], dtype=float)
+            rec[f"v:{vid}"] = float(dd["v"])
+        iters.append(rec)
+        return False
+    err = None
+    try:
+        with np.errstate(all="ignore"):
+            ep.iterate(max_iter=10, callback=cb2, damping=damping)
+    except Exception as e:    # noqa: BLE001
+        err = repr(e)
+    sgncom = dict(K=K, N=N, M=M, p_pos=p_pos, damping=damping, xs=xs, y=y, error=err, traj=pack_traj(iters))   # F: first draw of RandomState(29)
+    print("sgn committee ep", err, "iterations", len(iters), "overlaps", [float(np.mean(np.sign(iters[-1][f"r:x_{k}"]) == xs[k])) for k in range(K)])
     save("tree", data=np.array(grads, dtype=object), unit=np.array(unit, dtype=object),
          ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object),
          se=np.array(ses, dtype=object), l21=np.array(l21, dtype=object), tv=np.array(tvs, dtype=object),
-         vae=np.array(vae, dtype=object), com=np.array(com, dtype=object))
+         vae=np.array(vae, dtype=object), com=np.array(com, dtype=object), binp=np.array(binp, dtype=object),
+         sgncom=np.array([sgncom], dtype=object))
 
 
 # ---------------------------------------------------------------- SE

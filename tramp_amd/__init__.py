@@ -10,7 +10,7 @@ There is no CPU fallback: without the built HIP library the compute methods rais
 """
 from . import _lib
 from .device import Context, DeviceArray, default_context
-from .priors import GaussBernoulliPrior, MAP_L1NormPrior, MAP_L21NormPrior, GaussianPrior, get_prior
+from .priors import GaussBernoulliPrior, MAP_L1NormPrior, MAP_L21NormPrior, BinaryPrior, GaussianPrior, get_prior
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
                           SymmetricDoorLikelihood, get_likelihood)
@@ -21,7 +21,7 @@ from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, Gauss
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
 from .variables import SISOVariable, SILeafVariable, SIMOVariable, MISOVariable, MILeafVariable
 from .models import (Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution,
-                     sparse_gradient_regression, committee, soft_committee)
+                     sparse_gradient_regression, committee, soft_committee, sgn_committee)
 from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, EarlyStopping,
                     ConstantInit, CustomInit, NoisyInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
                     TrackEstimate, TrackMessages, TrackObjective, TrackOverlaps, LogProgress)

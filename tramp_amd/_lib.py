@@ -102,6 +102,7 @@ _SIGNATURES = {
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_damp": [vp, i32, sz, sz, dbl, vp, vp, vp, vp],
+    "tramp_binary_prior_fwd": [vp, i32, sz, sz, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_l21_prior_fwd": [vp, i32, i32, sz, sz, dbl, vp, vp, dbl, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_gauss_channel": [vp, i32, sz, sz, dbl, vp, vp, dbl, vp, vp, vp, vp],
     "tramp_bias_channel": [vp, i32, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp],

@@ -74,6 +74,20 @@ template <typename T> struct L1Op {       // K2; in0 = bx
     }
 };
 
+template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1) + p- delta(x + 1); in0 = bx
+    static constexpr bool HEAVY = false;
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    double b0;                              // natural parameter 0.5 log(p+ / p-), binary_prior.py:27
+    double a_msg;
+    __device__ void setup(size_t b) { a_msg = ax[b]; }
+    __device__ EwOut<T> eval(T x0, T) const {
+        const T t = tmath::tanh_(x0 + T(b0));                    // beliefs/binary.py:8-13
+        return {t, T(1) - t * t, 0u};
+    }
+};
+
 template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
     static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
@@ -620,6 +634,19 @@ extern "C" int tramp_l1_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, count_d, mask_d};
     L1Op<float> of{ax_d, gamma};
     L1Op<double> od{ax_d, gamma};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
+}
+
+extern "C" int tramp_binary_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                      const double* ax_d, const void* bx_d, double b0,
+                                      double damping, const double* a_old_d, const void* b_old_d,
+                                      double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax_d);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    BinaryOp<float> of{ax_d, b0};
+    BinaryOp<double> od{ax_d, b0};
     DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
                    (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
 }

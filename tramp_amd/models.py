@@ -309,6 +309,15 @@ def committee(K, N, alpha, ensemble_type, priors, activation1, activation2, nois
     return (dag @ SILeafVariable(id="y")).to_model()
 
 
+def sgn_committee(K, N, alpha, ensemble_type, p_pos, noise_var, **kw):
+    "committee_model.py:44-54: binary priors, sgn experts, majority vote"
+    p_pos = [p_pos] * K if isinstance(p_pos, float) else p_pos
+    if len(p_pos) != K:
+        raise ValueError(f"p_pos must be a list of length {K}")
+    priors = [dict(prior_type="binary", p_pos=p) for p in p_pos]
+    return committee(K, N, alpha, ensemble_type, priors, "sgn", "sgn", noise_var, **kw)
+
+
 def soft_committee(K, N, alpha, ensemble_type, prior_mean, prior_var, noise_var, **kw):
     "committee_model.py:57-73: Gaussian priors, relu experts, linear output"
     prior_mean = [prior_mean] * K if isinstance(prior_mean, float) else prior_mean
@@ -344,5 +353,5 @@ class MultiLayerModel(Model):
         super().__init__(DAG(nodes))
 
 
-__all__ = ["DAG", "Model", "MultiLayerModel", "glm_generative", "glm_state_evolution", "sparse_gradient_regression", "committee", "soft_committee",
+__all__ = ["DAG", "Model", "MultiLayerModel", "glm_generative", "glm_state_evolution", "sparse_gradient_regression", "committee", "soft_committee", "sgn_committee",
            "channel2likelihood", "PiecewiseLinearChannel"]

@@ -187,6 +187,38 @@ class MAP_L1NormPrior(Prior):
         raise NotImplementedError      # as the reference (map_L1_norm_prior.py:84-85)
 
 
+class BinaryPrior(Prior):
+    r"""Binary prior p(x) = p_+ delta(x - 1) + p_- delta(x + 1).
+
+    tramp/priors/binary_prior.py:8-62 (the prior of the sign committee machine, committee_model.py:44-54).
+    """
+
+    def __init__(self, size, p_pos=0.5, isotropic=True, dtype=np.float64, ctx=None):
+        if not isotropic:
+            raise NotImplementedError("diagonal beliefs for BinaryPrior are outside the HIP path")
+        self.size = size
+        self.p_pos = p_pos
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.p_neg = 1 - p_pos
+        self.b = 0.5 * np.log(self.p_pos / self.p_neg)          # :27
+
+    def sample(self):
+        return np.random.choice([-1, +1], size=self.size, replace=True, p=[self.p_neg, self.p_pos])
+
+    def second_moment(self):
+        return 1.
+
+    def _kernel(self, b, a, damping, old_a, old_b, a_new, b_new, r, v):
+        self.ctx._call("tramp_binary_prior_fwd", self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr, float(self.b),
+                       damping, old_a, old_b, a_new.ptr, b_new.ptr,
+                       r.ptr if r is not None else None, v.ptr if v is not None else None)
+
+    def compute_forward_error(self, ax):
+        raise NotImplementedError("state evolution of the binary prior is outside the HIP path")
+
+
 class MAP_L21NormPrior(Prior):
     r"""MAP prior of the group penalty gamma ||x||_{2,1}: group soft-threshold along ``axis``.
 
@@ -345,6 +377,7 @@ PRIOR_CLASSES = {
     "gaussian": GaussianPrior,
     "L1_norm": MAP_L1NormPrior,
     "L21_norm": MAP_L21NormPrior,
+    "binary": BinaryPrior,
 }
 
 
