@@ -1791,6 +1791,17 @@ def se_tree(factors, variables, edges, max_iter=200, damping=None, tol=1e-6, a0=
 
     def factor_send(f, direction):
         fac = factors[f]
+        if fac.kind == "multi":                                  # SumChannel (sum_channel.py:45-56)
+            nxt = succ[f][0]
+            az = [msg[(p, f)] for p in pred[f]]
+            v_bar = sum(1 / a for a in az)
+            if direction == "fwd":
+                news, tgts = [1 / v_bar], [nxt]
+            else:
+                news, tgts = [1 / (1 / msg[(nxt, f)] + v_bar - 1 / a) for a in az], pred[f]
+            for new, t in zip(news, tgts):
+                msg[(f, t)] = d * msg[(f, t)] + (1 - d) * new if d else new
+            return
         prev = pred[f][0] if pred[f] else None
         nxt = succ[f][0] if succ[f] else None
         target = nxt if direction == "fwd" else prev

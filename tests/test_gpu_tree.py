@@ -592,3 +592,40 @@ def test_binary_prior_and_sgn_committee_match_reference(ctx, golden_tree):
                 close(np.ravel(val)[0], ref, tol)
             else:
                 close(np.ravel(val), np.ravel(ref), tol, tol * max(1.0, float(np.abs(ref).max())))
+
+
+def test_committee_state_evolution_matches_reference(ctx, golden_tree):
+    "TreeStateEvolution through the K-input SumChannel: the reference's 3-minute dblquad run, here milliseconds"
+    import tramp_amd as T
+    from tramp_amd.base import Variable
+    for c in golden_tree["comse"]:
+        K = c["K"]
+        experts = None
+        for k in range(K):
+            e = (T.GaussianPrior(size=None, var=c["pvars"][k], ctx=ctx) @ T.SISOVariable(id=f"x_{k}")
+                 @ T.MarchenkoPasturChannel(alpha=c["alpha"]) @ T.SISOVariable(id=f"z_{k}") @ T.ReluChannel(ctx=ctx)
+                 @ T.SISOVariable(id=f"a_{k}"))
+            experts = e if experts is None else experts + e
+        model = (experts @ T.SumChannel(n_prev=K, ctx=ctx) @ T.SISOVariable(id="n")
+                 @ T.GaussianLikelihood(y=None, var=c["noise_var"], ctx=ctx)).to_model()
+        se = T.StateEvolution(model)
+        for k, tau in c["tau"].items():
+            close(se.taus[k], tau, 1e-12)
+        g = model.dag
+
+        def name(node):
+            if isinstance(node, Variable):
+                return node.id
+            return f"{type(node).__name__}[{','.join(sorted(v.id for v in list(g.predecessors(node)) + list(g.successors(node))))}]"
+        iters = []
+
+        def cb(algo, i, max_iter):
+            rec = {f"{name(s)}->{name(t)}:a": float(a) for (s, t), a in algo.msg.items()}
+            rec.update({"v:" + k: float(v["v"]) for k, v in algo.get_variables_data().items()})
+            iters.append(rec)
+            return False
+        se.iterate(max_iter=6, callback=cb, damping=c["damping"])
+        t = c["traj"]
+        for it, rec in enumerate(iters):
+            for k, v in rec.items():
+                close(v, t[k][it], 1e-5)

@@ -811,3 +811,33 @@ def test_binary_prior_and_sgn_committee_oracle_match_reference(golden_tree):
             close(b, tr[f"{s_}->{t}:b"][it], rtol=tol, atol=tol * max(1.0, np.abs(tr[f"{s_}->{t}:b"][it]).max()))
         for v in shapes:
             close(rs[v], tr["r:" + v][it], rtol=tol, atol=tol)
+
+
+def test_committee_se_oracle_matches_reference(golden_tree):
+    "state evolution through the K-input SumChannel (soft committee, Marchenko-Pastur linear layers)"
+    for c in golden_tree["comse"]:
+        K = c["K"]
+        factors, edges, variables = {}, [], ["n"]
+        summed = ",".join(sorted([f"a_{k}" for k in range(K)] + ["n"]))
+        for k in range(K):
+            p, lin, act = f"GaussianPrior[x_{k}]", f"MarchenkoPasturChannel[x_{k},z_{k}]", f"ReluChannel[a_{k},z_{k}]"
+            factors[p] = orc.GaussPriorFactor(None, var=c["pvars"][k])
+            factors[lin] = orc.MPFactor(c["alpha"])
+            factors[act] = orc.PWLFactor("relu")
+            edges += [(p, f"x_{k}"), (f"x_{k}", lin), (lin, f"z_{k}"), (f"z_{k}", act), (act, f"a_{k}"),
+                      (f"a_{k}", f"SumChannel[{summed}]")]
+            variables += [f"x_{k}", f"z_{k}", f"a_{k}"]
+        factors[f"SumChannel[{summed}]"] = orc.SumFactor(K)
+        factors["GaussianLikelihood[n]"] = orc.GaussLikFactor(None, c["noise_var"])
+        edges += [(f"SumChannel[{summed}]", "n"), ("n", "GaussianLikelihood[n]")]
+        recs = []
+        res = orc.se_tree(factors, variables, edges, max_iter=3, damping=c["damping"], tol=0.0, method="gl",
+                          record=lambda it, msg, vs: recs.append((msg, vs)))
+        for k, tau in c["tau"].items():
+            close(res["tau"][k], tau, rtol=1e-12)
+        t = c["traj"]
+        for it, (msg, vs) in enumerate(recs):
+            for (s_, tt), a in msg.items():
+                close(a, t[f"{s_}->{tt}:a"][it], rtol=2e-5)
+            for v in variables:
+                close(vs[v], t["v:" + v][it], rtol=2e-5)

@@ -988,6 +988,31 @@ def tree_goldens():
                         msgs=msgs, traj=pack_traj(iters),
                         mse=[float(np.mean((iters[-1][f"r:x_{k}"] - xs[k])**2)) for k in range(K)]))
         print("committee ep", K, N, damping, err, "mse", com[-1]["mse"])
+    # state evolution of the soft committee (K = 2, SE is N-free: Marchenko-Pastur linear layers)
+    comse = []
+    for K, alpha, pvars, nv, damping in [(2, 2.0, [1.0, 0.5], 1e-2, None), (3, 1.5, [1.0, 0.6, 0.3], 5e-2, 0.2)]:
+        experts = None
+        for k in range(K):
+            e = (GaussianPrior(size=None, var=pvars[k]) @ V(id=f"x_{k}") @ MarchenkoPasturChannel(alpha=alpha)
+                 @ V(id=f"z_{k}") @ ReluChannel() @ V(id=f"a_{k}"))
+            experts = e if experts is None else experts + e
+        model = (experts @ SumChannel(n_prev=K) @ V(id="n") @ GaussianLikelihood(y=None, var=nv)).to_model()
+        se = StateEvolution(model)
+        its = []
+
+        def cbse(algo, i, max_iter):
+            rec = {}
+            for source, target, data in algo.message_dag.edges(data=True):
+                rec[f"{nb_name(algo, source)}->{nb_name(algo, target)}:a"] = float(data["a"])
+            for vid, dd in algo.get_variables_data().items():
+                rec[f"v:{vid}"] = float(dd["v"])
+            its.append(rec)
+            return False
+        t0 = time.time()
+        se.iterate(max_iter=6, callback=cbse, damping=damping)
+        comse.append(dict(K=K, alpha=alpha, pvars=pvars, noise_var=nv, damping=damping, traj=pack_traj(its),
+                          tau=model.get_second_moments()))
+        print("committee se", K, damping, {k: v for k, v in its[-1].items() if k.startswith("v:")}, f"{time.time()-t0:.0f}s")
     # sign committee (committee_model.py:44-54): binary priors, sgn experts, majority vote
     from tramp.priors import BinaryPrior
     binp = []
@@ -1035,7 +1060,7 @@ def tree_goldens():
          ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object),
          se=np.array(ses, dtype=object), l21=np.array(l21, dtype=object), tv=np.array(tvs, dtype=object),
          vae=np.array(vae, dtype=object), com=np.array(com, dtype=object), binp=np.array(binp, dtype=object),
-         sgncom=np.array([sgncom], dtype=object))
+         sgncom=np.array([sgncom], dtype=object), comse=np.array(comse, dtype=object))
 
 
 # ---------------------------------------------------------------- SE
