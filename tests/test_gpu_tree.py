@@ -629,3 +629,18 @@ def test_committee_state_evolution_matches_reference(ctx, golden_tree):
         for it, rec in enumerate(iters):
             for k, v in rec.items():
                 close(v, t[k][it], 1e-5)
+
+
+def test_tracking_callbacks_on_a_tree(ctx, golden_tree):
+    "TrackMessages / TrackEstimate / JoinCallback work on the tree scheduler (callbacks.py:33-62,111-134)"
+    import tramp_amd as T
+    e = golden_tree["ep"][0]
+    model = build_tree(T, ctx, e)
+    tm, te = T.TrackMessages(), T.TrackEstimate()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=3, callback=T.JoinCallback([tm, te, T.EarlyStoppingEP()]))
+    dirs = {(r["id"], r["direction"]) for r in tm.records}
+    assert ("x", "fwd") in dirs and any(d.startswith("fwd[") for v, d in dirs if v == "z") and len(tm.records) == 3 * 5
+    got = [r for r in tm.records if r["id"] == "x" and r["direction"] == "fwd"]
+    close([r["a"] for r in got], e["traj"]["GaussianPrior->x:a"][:3], 1e-9)
+    assert len(te.records) == 3 * 2

@@ -236,9 +236,19 @@ class TreeExpectationPropagation(ExpectationPropagation):
             raise ValueError(f"message {getattr(src, 'id', src)} -> {getattr(dst, 'id', dst)} (instance {b}): a is nan")
 
     def get_edges_data(self):
-        "a of every factor->variable message, as {(variable id, factor id): array[batch]}"
-        return {(dst.id, src.id): self.A_host[i].copy() for i, (src, dst) in enumerate(self.msg_keys)
-                if isinstance(dst, Variable)}
+        """a of every factor->variable message as {(variable id, direction): array[batch]}, like the chain
+        scheduler; where a variable has several factors on one side the direction carries the factor id,
+        e.g. ("z", "fwd[f_3]")."""
+        g = self.model.dag
+        out = {}
+        for i, (src, dst) in enumerate(self.msg_keys):
+            if not isinstance(dst, Variable):
+                continue
+            fwd = g.has_edge(src, dst)
+            several = (dst.n_prev if fwd else dst.n_next) > 1
+            direction = ("fwd" if fwd else "bwd") + (f"[{src.id}]" if several else "")
+            out[(dst.id, direction)] = self.A_host[i].copy()
+        return out
 
     def get_message(self, source, target):
         """(a, b) of the message source -> target; nodes are given as objects or ids."""
