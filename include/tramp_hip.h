@@ -289,6 +289,13 @@ int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batc
 #define TRAMP_REUSE_T 1
 #define TRAMP_REUSE_U 2
 
+/* Express the channel's OUTPUT side in the left singular basis (x' = Uk^T x; needs M <= N so that Uk is
+ * square): legitimate when the factor behind the output is rotation invariant - an isotropic
+ * GaussianLikelihood, whose message becomes (1/var, Uk^T y / var).  While on, every b / r vector of the
+ * output side passed to or returned by tramp_linear_message / _log_partition is the rotated one, and the
+ * two passes over Uk leave the iteration (u = bx', rx' = w).  The caller rotates y once
+ * (tramp_matvec_nn on Uk) and rotates results back when read (tramp_matvec_nt on Uk). */
+int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on);
 /* Constant damping of a CONSTANT factor's message (tramp/algos/message_passing.py:119-127
  * applied to e.g. GaussianLikelihood's backward message) replaces the message on one side of
  * the channel by  b <- damping * b + (1 - damping) * c  with the same c every iteration.  The

@@ -270,10 +270,14 @@ def test_ep_agrees_with_state_evolution_at_large_n(ctx):
     assert np.all(np.abs(mse - v_se) < 0.25 * v_se), (mse, v_se)
 
 
-def test_damped_constant_message_needs_no_matrix_pass(ctx):
-    """Constant damping of the Gaussian likelihood's (constant) message changes bx every iteration,
-    but affinely: the cached projection u = Uk^T bx follows by linearity (tramp_linear_project_affine),
-    so an iteration runs 3 matrix passes, not 4, and still matches the oracle's EP."""
+def test_matrix_passes_per_iteration(ctx, monkeypatch):
+    """Two exact reformulations keep matrix passes out of the sparse-GLM iteration, both checked against the
+    oracle's plain EP (which does neither):
+    * constant damping of the Gaussian likelihood's constant message changes bx affinely, so the cached
+      projection u = Uk^T bx follows by linearity (tramp_linear_project_affine): 3 passes instead of 4;
+    * that likelihood is rotation invariant, so the output variable is carried in the channel's left singular
+      basis (tramp_linear_set_rotated, M <= N): the two passes over Uk disappear, 2 passes per iteration,
+      and whatever is read of z (posterior, messages) is rotated back."""
     import ctypes as C
     import tramp_amd as T
     N, M, rho, nv, B, d = 256, 128, 0.1, 1e-2, 3, 0.3
@@ -281,30 +285,32 @@ def test_damped_constant_message_needs_no_matrix_pass(ctx):
     W = rs.randn(M, N) / np.sqrt(N)
     X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(B)])
     Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
-    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
-             @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
-             @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
-    ep = T.ExpectationPropagation(model, ctx=ctx)
-    ep.iterate(max_iter=3, callback=T.PassCallback(), damping=d)
-    ctx._call("tramp_profile_enable", 1)
-    ep.iterate(max_iter=4, callback=T.PassCallback(), damping=d, warm_start=True)
-    cnt, ms, by, fl = (C.c_int * 8)(), (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
-    ctx._call("tramp_profile_report", cnt, ms, by, fl)
-    ctx._call("tramp_profile_enable", 0)
-    assert cnt[1] + cnt[2] == 3 * 4, (cnt[1], cnt[2])          # matvec_nt + matvec_nn launches
-    r = ep.get_variables_data()["x"]["r"].reshape(B, N)
     lin = orc.LinearFactor(W, thin=True)
-    for b in range(B):
-        fs = [orc.GBPriorFactor(N, rho=rho), lin, orc.GaussLikFactor(Y[b], nv)]
-        res = orc.ep_chain(fs, [N, M], max_iter=7, damping=d, tol=0.0)
-        close(r[b], res["r"][0], 1e-7)
-    # the raw entry point: p <- d p + (1-d) P c equals the projection of the damped message
-    lin_ch = model.factors[1]
-    with pytest.raises(T._lib.TrampHipError):
-        fresh = T.LinearChannel(W, ctx=ctx, svd="host")
-        Yd = ctx.array(Y)
-        ctx._call("tramp_linear_project_affine", fresh._handle, T._lib.REUSE_U, B, Yd.ptr, 0.5, 1)
-    assert lin_ch._u_key is not None
+    want = [orc.ep_chain([orc.GBPriorFactor(N, rho=rho), lin, orc.GaussLikFactor(Y[b], nv)], [N, M], max_iter=7,
+                         damping=d, tol=0.0) for b in range(B)]
+    for rotate, passes in (("0", 3), ("1", 2)):
+        monkeypatch.setenv("TRAMP_ROTATE_OUTPUT", rotate)
+        model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+                 @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+                 @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        assert bool(ep._rot) == (rotate == "1")
+        ep.iterate(max_iter=3, callback=T.PassCallback(), damping=d)
+        ctx._call("tramp_profile_enable", 1)
+        ep.iterate(max_iter=4, callback=T.PassCallback(), damping=d, warm_start=True)
+        cnt, ms, by, fl = (C.c_int * 8)(), (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+        ctx._call("tramp_profile_report", cnt, ms, by, fl)
+        ctx._call("tramp_profile_enable", 0)
+        assert cnt[1] + cnt[2] == passes * 4, (rotate, cnt[1], cnt[2])      # matvec_nt + matvec_nn launches
+        data = ep.get_variables_data()
+        bz_fwd, bz_bwd = ep.get_message("z", "fwd")[1], ep.get_message("z", "bwd")[1]
+        for b in range(B):
+            close(data["x"]["r"][b], want[b]["r"][0], 1e-7)
+            close(data["z"]["r"][b], want[b]["r"][1], 1e-7)                  # read back in the original basis
+            close(data["z"]["v"][b], want[b]["v"][1], 1e-8)
+            close(bz_fwd[b], want[b]["fwd"][1][1], 1e-7)
+            close(bz_bwd[b], want[b]["bwd"][1][1], 1e-7)
+        close(ep.mse("z", X @ W.T), np.mean((data["z"]["r"] - X @ W.T) ** 2, axis=1), 1e-9)
 
 
 def test_tracking_callbacks(ctx):

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "tramp_grad_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_grad_apply": [vp, vp, sz, vp, vp],
     "tramp_grad_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_linear_set_rotated": [vp, vp, i32],
     "tramp_linear_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_conv_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_dft_create": [vp, i32, i32, C.POINTER(sz), C.POINTER(vp)],

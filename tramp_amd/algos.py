@@ -307,6 +307,64 @@ class ExpectationPropagation:
         self._allocated = False
         self._frozen_r = None
         self.default_stopping = EarlyStoppingEP()
+        self._find_rotations()
+
+    # -- rotated output basis ------------------------------------------------------------
+    def _find_rotations(self):
+        """A dense LinearChannel (M <= N) whose output variable is observed through an isotropic
+        GaussianLikelihood: that likelihood is rotation invariant, so the variable is carried in the
+        channel's left singular basis, z' = Uk^T z, with y' = Uk^T y (rotated once).  Messages, norms,
+        variances and every other variable are unchanged; the two passes over Uk leave the iteration
+        (tramp_linear_set_rotated).  Whatever is read of that variable (posterior mean, messages) is
+        rotated back on the way out, so callers and callbacks see the reference's quantities.
+        TRAMP_ROTATE_OUTPUT=0 disables it."""
+        import os
+        self._rot = {}
+        if os.environ.get("TRAMP_ROTATE_OUTPUT", "1") == "0":
+            return
+        from .channels import LinearChannel
+        for i, v in enumerate(self.variables):
+            lin, lik = self.model.prev_factor(v), self.model.next_factor(v)
+            if type(lin) is LinearChannel and type(lik) is GaussianLikelihood and lik.isotropic \
+                    and lin.Nx <= lin.Nz and lin.rank == lin.Nx and lik._y_dev is not None:
+                self._rot[i] = dict(lin=lin, lik=lik, y_rot=None)
+
+    def _rotate(self, i, src, back):
+        "Uk^T src (into the rotated basis) or Uk src (back), [batch, M] -> new device array"
+        lin = self._rot[i]["lin"]
+        dst = self.ctx.empty(tuple(src.shape), self.dtype)
+        self.ctx._call("tramp_matvec_nt" if back else "tramp_matvec_nn", dtype_code(self.dtype), 0, lin.Nx, lin.Nx,
+                       src.shape[0], lin._Uk.ptr, src.ptr, dst.ptr)
+        return dst
+
+    class _Basis:
+        "while active: the rotated channels skip Uk and their likelihoods present y' = Uk^T y"
+
+        def __init__(self, ep):
+            self.ep = ep
+
+        def __enter__(self):
+            ep = self.ep
+            self.saved = []
+            ep._basis_depth = getattr(ep, "_basis_depth", 0) + 1
+            if ep._basis_depth > 1:
+                return self
+            for i, rot in ep._rot.items():
+                if rot["y_rot"] is None:
+                    rot["y_rot"] = ep._rotate(i, rot["lik"]._y_dev, back=False)
+                ep.ctx._call("tramp_linear_set_rotated", rot["lin"]._handle, 1)
+                rot["lin"]._t_key = rot["lin"]._u_key = None
+                self.saved.append((rot, rot["lik"]._y_dev))
+                rot["lik"]._y_dev = rot["y_rot"]
+            return self
+
+        def __exit__(self, *exc):
+            self.ep._basis_depth -= 1
+            for rot, y in self.saved:
+                rot["lik"]._y_dev = y
+                self.ep.ctx._call("tramp_linear_set_rotated", rot["lin"]._handle, 0)
+                rot["lin"]._t_key = rot["lin"]._u_key = None
+            return False
 
     # -- storage
     def _allocate(self):
@@ -338,9 +396,14 @@ class ExpectationPropagation:
             fill_message(self.b_fwd[i], initializer.init_b(shape, v.id, "fwd"))
             fill_message(self.b_bwd[i], initializer.init_b(shape, v.id, "bwd"))
             self.r[i].fill(0.0)
+            if i in self._rot:                                   # initial messages live in the rotated basis too
+                for buf, d in ((self.b_fwd[i], "fwd"), (self.b_bwd[i], "bwd")):
+                    if np.any(np.asarray(initializer.init_b(shape, v.id, d)) != 0):
+                        buf.copy_from(self._rotate(i, buf, back=False))
             self.b_fwd[i].version += 1
             self.b_bwd[i].version += 1
         self._const_done = set()
+        self._const_msg = {}
 
     # -- one factor update, in place, damping fused where the kernel supports it
     def _update(self, factor, direction, i_in, i_out):
@@ -466,9 +529,10 @@ class ExpectationPropagation:
                     vv[done] = self._frozen_v[i, done]
                 d = dict(v=float(vv[0]) if self.batch == 1 else vv)
                 if want_r:
-                    r = self.r[i].get()
+                    unrot = (lambda a: self._rotate(i, a, back=True)) if i in self._rot else (lambda a: a)
+                    r = unrot(self.r[i]).get()
                     if use_frozen:
-                        r[done] = self._frozen_r[i].get()[done]
+                        r[done] = unrot(self._frozen_r[i]).get()[done]
                     d["r"] = r[0] if self.batch == 1 else r
                 out[v.id] = d
         return out
@@ -487,7 +551,8 @@ class ExpectationPropagation:
     def get_message(self, id, direction):
         i = self.variable_index(id)
         a = (self.a_fwd if direction == "fwd" else self.a_bwd)[i].get()
-        b = (self.b_fwd if direction == "fwd" else self.b_bwd)[i].get()
+        b = (self.b_fwd if direction == "fwd" else self.b_bwd)[i]
+        b = (self._rotate(i, b, back=True) if i in self._rot else b).get()
         return (float(a[0]), b[0]) if self.batch == 1 else (a, b)
 
     def variable_index(self, id):
@@ -498,7 +563,8 @@ class ExpectationPropagation:
         xt = self.ctx.array(np.atleast_2d(np.asarray(x_true, dtype=self.dtype)), self.dtype)
         out = self.ctx.empty((self.batch,), np.float64)
         n = self.r[i].shape[1]
-        self.ctx._call("tramp_sq_dist", dtype_code(self.dtype), n, self.batch, self.r[i].ptr, xt.ptr, out.ptr)
+        r = self._rotate(i, self.r[i], back=True) if i in self._rot else self.r[i]
+        self.ctx._call("tramp_sq_dist", dtype_code(self.dtype), n, self.batch, r.ptr, xt.ptr, out.ptr)
         m = out.get() / n
         return float(m[0]) if self.batch == 1 else m
 
@@ -507,6 +573,10 @@ class ExpectationPropagation:
         tramp/algos/message_passing.py:306-328): node log-partitions minus the fwd-edge ones.  On a
         chain of SISO variables both edges of a variable carry the variable's own (a, b) pair, so
         this is sum_factors A_f - sum_variables A_x.  One value per instance."""
+        with self._Basis(self):
+            return self._log_evidence()
+
+    def _log_evidence(self):
         L = len(self.variables)
         A = np.zeros(self.batch)
         for i, v in enumerate(self.variables):
@@ -564,6 +634,8 @@ class ExpectationPropagation:
             self.n_iter_instance[:] = 0
             self._frozen_r = None
         g = None
+        basis = self._Basis(self)
+        basis.__enter__()
         try:
             for i in range(max_iter):
                 if g is not None:
@@ -584,6 +656,7 @@ class ExpectationPropagation:
                         logger.info("terminated after n_iter=%d iterations", self.n_iter)
                         break
         finally:
+            basis.__exit__(None, None, None)
             if g is not None:
                 self.ctx._call("tramp_graph_destroy", g)
         self.n_iter_instance[self.n_iter_instance == 0] = self.n_iter

@@ -19,6 +19,7 @@ struct tramp_linear {
     void* uc;            //   (tramp_linear_project_affine)
     bool tc_valid, uc_valid;
     double* a_raw;
+    bool rotated;        // output side expressed in the left singular basis: Uk acts as the identity (k == M)
 };
 
 // Epilogue applied to every output element acc = (mat x)[b, idx]:

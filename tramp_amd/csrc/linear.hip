@@ -449,6 +449,36 @@ extern "C" int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, in
     return TRAMP_OK;
 }
 
+// ---------------------------------------------------------------- rotated output basis
+// When the factor behind the channel's output is rotation invariant (an isotropic Gaussian likelihood),
+// the whole problem can be written for x' = Uk^T x instead of x (Uk square: M = k): the likelihood keeps
+// its form with y' = Uk^T y, every message on that side is the rotated one, norms and variances are
+// unchanged - and the channel becomes z -> S Vt z, so the two passes over Uk (u = Uk^T bx, rx = Uk w) drop
+// out of the iteration: u = bx', rx' = w.  The caller rotates y once and rotates results back when read.
+extern "C" int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, lin);
+    if (on && lin->k != lin->M)
+        return tramp_fail(ctx, TRAMP_EINVAL, "tramp_linear_set_rotated", "needs M <= N (square left factor)");
+    lin->rotated = on != 0;
+    lin->proj_batch = 0;                      // cached projections belong to the other basis
+    lin->tc_valid = lin->uc_valid = false;
+    return TRAMP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lin_epi_apply_kernel(size_t len, const T* __restrict__ w, LinEpi epi) {
+    const size_t b = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock)
+        lin_epilogue<T>(epi, b, i, len, (double)w[b * len + i]);
+}
+
+static int lin_copy_u(tramp_ctx* ctx, tramp_linear* lin, size_t batch, const void* bx_d) {
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(lin->u, bx_d, batch * lin->k * dtype_size(lin->dtype), hipMemcpyDeviceToDevice,
+                                        ctx->stream));
+    return TRAMP_OK;
+}
+
 // Brings the handle's projections t = Vt bz and u = Uk^T bx up to date (shared by the message
 // update and the log-partition); `reuse` as in tramp_linear_message.
 int lin_project(tramp_ctx* ctx, tramp_linear* lin, size_t batch, const void* bz_d, const void* bx_d, int reuse) {
@@ -465,7 +495,10 @@ int lin_project(tramp_ctx* ctx, tramp_linear* lin, size_t batch, const void* bz_
         if (rc) return rc;
     }
     plain.out = lin->u;
-    if (!(reuse & TRAMP_REUSE_U)) {
+    if (lin->rotated) {
+        rc = lin_copy_u(ctx, lin, batch, bx_d);
+        if (rc) return rc;
+    } else if (!(reuse & TRAMP_REUSE_U)) {
         rc = matvec_dispatch(ctx, lin->dtype, 0, false, lin->M, lin->k, batch, lin->Uk, bx_d, plain);
         if (rc) return rc;
     }
@@ -490,6 +523,7 @@ extern "C" int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, in
         return tramp_fail(ctx, TRAMP_EINVAL, "tramp_linear_project_affine",
                           "the handle holds no projection of the message being updated");
     const bool is_t = which == TRAMP_REUSE_T;
+    if (!is_t && lin->rotated) return TRAMP_OK;      // u IS the (already damped) message in the rotated basis
     bool& valid = is_t ? lin->tc_valid : lin->uc_valid;
     void* pc = is_t ? lin->tc : lin->uc;
     void* p = is_t ? lin->t : lin->u;
@@ -546,7 +580,10 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
     }
     // 3. u = Uk^T bx  [batch, k]
     plain.out = lin->u;
-    if (!(reuse & TRAMP_REUSE_U)) {
+    if (lin->rotated) {
+        rc = lin_copy_u(ctx, lin, batch, bx_d);
+        if (rc) return rc;
+    } else if (!(reuse & TRAMP_REUSE_U)) {
         rc = matvec_dispatch(ctx, dtype, 0, false, M, k, batch, lin->Uk, bx_d, plain);
         if (rc) return rc;
     }
@@ -571,7 +608,19 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
         epi.a_in = ax_d;
         epi.b_in = bx_d;
         epi.add_b_over_a = 0;
-        rc = matvec_dispatch(ctx, dtype, 0, true, M, k, batch, lin->Uk, lin->w, epi);      // rx = Uk w
+        if (lin->rotated) {                                                                 // rx' = w
+            ProfScope ps(ctx, PROF_EW, (double)batch * k * dtype_size(dtype) * (damping != 0.0 ? 4 : 3), 0);
+            dim3 ge((unsigned)((k + kBlock * 4 - 1) / (kBlock * 4) > 1024 ? 1024 : (k + kBlock * 4 - 1) / (kBlock * 4)),
+                    (unsigned)batch);
+            if (dtype == TRAMP_F64)
+                hipLaunchKernelGGL((lin_epi_apply_kernel<double>), ge, dim3(kBlock), 0, ctx->stream, k,
+                                   (const double*)lin->w, epi);
+            else
+                hipLaunchKernelGGL((lin_epi_apply_kernel<float>), ge, dim3(kBlock), 0, ctx->stream, k,
+                                   (const float*)lin->w, epi);
+            rc = TRAMP_OK;
+        } else
+            rc = matvec_dispatch(ctx, dtype, 0, true, M, k, batch, lin->Uk, lin->w, epi);   // rx = Uk w
     } else {
         epi.a_in = az_d;
         epi.b_in = bz_d;

@@ -68,6 +68,7 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.n_iter_instance = np.zeros(self.batch, dtype=int)
         self._allocated = False
         self._frozen_r = None
+        self._rot = {}                      # the rotated-output shortcut is a chain-scheduler feature
         from .algos import EarlyStoppingEP
         self.default_stopping = EarlyStoppingEP()
 
