@@ -580,9 +580,9 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
     }
     // 3. u = Uk^T bx  [batch, k]
     plain.out = lin->u;
+    const void* u_ptr = lin->u;
     if (lin->rotated) {
-        rc = lin_copy_u(ctx, lin, batch, bx_d);
-        if (rc) return rc;
+        u_ptr = bx_d;                                     // u = Uk^T bx is bx' itself in the rotated basis
     } else if (!(reuse & TRAMP_REUSE_U)) {
         rc = matvec_dispatch(ctx, dtype, 0, false, M, k, batch, lin->Uk, bx_d, plain);
         if (rc) return rc;
@@ -592,10 +592,10 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
     dim3 gm((unsigned)((k + kBlock - 1) / kBlock > 1024 ? 1024 : (k + kBlock - 1) / kBlock), (unsigned)batch);
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((lin_mid_kernel<double>), gm, dim3(kBlock), 0, ctx->stream, (int)k, mode, lin->sing, az_d,
-                           ax_d, (const double*)lin->t, (const double*)lin->u, (double*)lin->w);
+                           ax_d, (const double*)lin->t, (const double*)u_ptr, (double*)lin->w);
     else
         hipLaunchKernelGGL((lin_mid_kernel<float>), gm, dim3(kBlock), 0, ctx->stream, (int)k, mode, lin->sing, az_d,
-                           ax_d, (const float*)lin->t, (const float*)lin->u, (float*)lin->w);
+                           ax_d, (const float*)lin->t, (const float*)u_ptr, (float*)lin->w);
     // 5. back-projection with the fused message update
     LinEpi epi{};
     epi.mode = 1;
