@@ -293,7 +293,8 @@ def run(args):
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
         # measured HBM traffic of the dominant kernel at this shape, if a PMC profile of it is committed.
-        # the dominant tag mixes the Vt pass (k x N) and the Uk pass (M x k); the profile covers the Vt shape.
+        # both matrix passes of an iteration stream Vt (k x N): NT for t = Vt b, NN for the back-projection
+        # (the Uk passes are gone: affine projection update + rotated output basis); the profile covers that shape.
         traffic = None
         traffic_detail = None
         try:
