@@ -295,6 +295,10 @@ int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batc
  * output side passed to or returned by tramp_linear_message / _log_partition is the rotated one, and the
  * two passes over Uk leave the iteration (u = bx', rx' = w).  The caller rotates y once
  * (tramp_matvec_nn on Uk) and rotates results back when read (tramp_matvec_nt on Uk). */
+/* `on` is a bit mask: 1 = the output side as above; 2 = the INPUT side in the right singular basis
+ * (z' = Vt z, k numbers per instance): legitimate behind an isotropic zero-mean GaussianPrior with zero
+ * initial messages - the component of z orthogonal to the rows of Vt then stays exactly zero - and removes
+ * the two passes over Vt (t = bz', rz' = bz' / az + w); z = Vt^T z' when read (tramp_matvec_nn on Vt). */
 int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on);
 /* Constant damping of a CONSTANT factor's message (tramp/algos/message_passing.py:119-127
  * applied to e.g. GaussianLikelihood's backward message) replaces the message on one side of

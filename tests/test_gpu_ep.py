@@ -413,3 +413,60 @@ def test_noisy_and_custom_initial_messages(ctx):
                                                               initializer=T.NoisyInit(a_mean=1.0, b_var=4.0))
         outs.append(np.array(e2.get_variable_data("z")["r"]))
     assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
+
+
+def test_gaussian_prior_input_rotation(ctx, monkeypatch, golden_ep):
+    """Mirror image of the rotated output: behind an isotropic zero-mean GaussianPrior the channel's input is
+    carried as Vt x (k numbers); the two passes over Vt disappear and x = Vt^T x' is expanded when read.
+    Ridge-type GLM (both sides rotated: no matrix pass at all inside the loop) and the two-layer ReLU model,
+    against the oracle's plain EP; non-zero initial messages fall back to the full representation."""
+    import ctypes as C
+    import tramp_amd as T
+    rs = np.random.RandomState(8)
+    N, M, B, nv, d = 192, 96, 2, 1e-2, 0.2
+    W = rs.randn(M, N) / np.sqrt(N)
+    X = rs.standard_normal((B, N))
+    Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
+    want = [orc.ep_chain([orc.GaussPriorFactor(N, var=1.5), orc.LinearFactor(W, thin=True), orc.GaussLikFactor(Y[b], nv)],
+                         [N, M], max_iter=6, damping=d, tol=0.0) for b in range(B)]
+
+    def run(initializer=None):
+        model = (T.GaussianPrior(size=N, var=1.5, ctx=ctx) @ T.SISOVariable(id="x") @ T.LinearChannel(W, ctx=ctx, svd="host")
+                 @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        ep.iterate(max_iter=0, callback=T.PassCallback(), initializer=initializer)     # y' = Uk^T y, once, untimed
+        ctx._call("tramp_profile_enable", 1)
+        ep.iterate(max_iter=6, callback=T.PassCallback(), damping=d, initializer=initializer)
+        cnt, ms, by, fl = (C.c_int * 8)(), (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+        ctx._call("tramp_profile_report", cnt, ms, by, fl)
+        ctx._call("tramp_profile_enable", 0)
+        return ep, cnt[1] + cnt[2]
+    ep, passes = run()
+    assert {r["side"] for r in ep._rot.values()} == {"in", "out"} and passes == 0
+    assert ep.b_fwd[0].shape == (B, M)                                   # x carried as k = M numbers
+    data = ep.get_variables_data()
+    assert data["x"]["r"].shape == (B, N)
+    A = ep.log_evidence()
+    for b in range(B):
+        close(data["x"]["r"][b], want[b]["r"][0], 1e-8)
+        close(data["x"]["v"][b], want[b]["v"][0], 1e-9)
+        close(data["z"]["r"][b], want[b]["r"][1], 1e-8)
+        close(ep.get_message("x", "bwd")[1][b], want[b]["bwd"][0][1], 1e-8)
+        fs = [orc.GaussPriorFactor(N, var=1.5), orc.LinearFactor(W, thin=True), orc.GaussLikFactor(Y[b], nv)]
+        close(A[b], orc.chain_log_evidence(fs, want[b]["fwd"], want[b]["bwd"]), 1e-8)
+    close(ep.mse("x", X), np.mean((data["x"]["r"] - X) ** 2, axis=1), 1e-10)
+    monkeypatch.setenv("TRAMP_ROTATE_INPUT", "0")
+    ep0, passes0 = run()
+    # without it: one back-projection Vt^T w per iteration (the damped constant prior message keeps its
+    # projection up to date affinely, so t = Vt b costs two passes in total)
+    assert {r["side"] for r in ep0._rot.values()} == {"out"} and 6 <= passes0 <= 2 * 6
+    close(ep0.get_variables_data()["x"]["r"], data["x"]["r"], 1e-9)
+    monkeypatch.delenv("TRAMP_ROTATE_INPUT")
+    # a start with b != 0 has a component outside the row space of Vt: the variable stays in full
+    ep1, passes1 = run(T.ConstantInit(a=0.5, b=0.3))
+    assert {r["side"] for r in ep1._rot.values()} == {"out"} and ep1.b_fwd[0].shape == (B, N)
+    w1 = orc.ep_tree(dict(p=orc.GaussPriorFactor(N, var=1.5), l=orc.LinearFactor(W, thin=True), y=orc.GaussLikFactor(Y[0], nv)),
+                     ["x", "z"], [("p", "x"), ("x", "l"), ("l", "z"), ("z", "y")], dict(x=(N,), z=(M,)), max_iter=6,
+                     damping=d, tol=0.0, max_increase=np.inf, a0=0.5, b0=0.3)
+    close(ep1.get_variables_data()["x"]["r"][0], w1["r"]["x"], 1e-8)
+    # two-layer ReLU golden runs exercise the input rotation on the first layer (test_ep_trajectories_match_reference)

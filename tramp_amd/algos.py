@@ -317,24 +317,63 @@ class ExpectationPropagation:
         variances and every other variable are unchanged; the two passes over Uk leave the iteration
         (tramp_linear_set_rotated).  Whatever is read of that variable (posterior mean, messages) is
         rotated back on the way out, so callers and callbacks see the reference's quantities.
-        TRAMP_ROTATE_OUTPUT=0 disables it."""
+        TRAMP_ROTATE_OUTPUT=0 / TRAMP_ROTATE_INPUT=0 disable the two sides."""
         import os
         self._rot = {}
-        if os.environ.get("TRAMP_ROTATE_OUTPUT", "1") == "0":
-            return
         from .channels import LinearChannel
         for i, v in enumerate(self.variables):
+            if os.environ.get("TRAMP_ROTATE_OUTPUT", "1") == "0":
+                break
             lin, lik = self.model.prev_factor(v), self.model.next_factor(v)
             if type(lin) is LinearChannel and type(lik) is GaussianLikelihood and lik.isotropic \
                     and lin.Nx <= lin.Nz and lin.rank == lin.Nx and lik._y_dev is not None:
-                self._rot[i] = dict(lin=lin, lik=lik, y_rot=None)
+                self._rot[i] = dict(side="out", lin=lin, lik=lik, y_rot=None)
+        # mirror image on the input side: an isotropic zero-mean GaussianPrior feeding a dense LinearChannel.
+        # The variable is carried as z' = Vt z (k numbers per instance); the part of z orthogonal to the rows
+        # of Vt only ever sees the prior's b = 0 and stays exactly zero, so nothing is lost (zero initial
+        # messages required - checked in init_message_dag).  Removes the two passes over Vt.
+        if os.environ.get("TRAMP_ROTATE_INPUT", "1") != "0":
+            for i, v in enumerate(self.variables):
+                pri, lin = self.model.prev_factor(v), self.model.next_factor(v)
+                if type(pri) is GaussianPrior and type(lin) is LinearChannel and pri.isotropic \
+                        and np.all(np.asarray(pri.mean) == 0):
+                    self._rot[i] = dict(side="in", lin=lin, k=min(lin.Nx, lin.Nz))
+
+    def _lin_masks(self):
+        "LinearChannel -> tramp_linear_set_rotated mask (1 output side, 2 input side)"
+        masks = {}
+        for rot in self._rot.values():
+            masks[rot["lin"]] = masks.get(rot["lin"], 0) | (1 if rot["side"] == "out" else 2)
+        return masks
+
+    def _apply_basis(self, on):
+        for lin, mask in self._lin_masks().items():
+            self.ctx._call("tramp_linear_set_rotated", lin._handle, mask if on else 0)
+            lin._rot_mask = mask if on else 0
+            lin._t_key = lin._u_key = None
+        for i, rot in self._rot.items():
+            if rot["side"] != "out":
+                continue
+            if on:
+                if rot["y_rot"] is None:
+                    rot["y_rot"] = self._rotate(i, rot["lik"]._y_dev, back=False)
+                rot["y_saved"], rot["lik"]._y_dev = rot["lik"]._y_dev, rot["y_rot"]
+            else:
+                rot["lik"]._y_dev = rot.pop("y_saved")
 
     def _rotate(self, i, src, back):
-        "Uk^T src (into the rotated basis) or Uk src (back), [batch, M] -> new device array"
-        lin = self._rot[i]["lin"]
-        dst = self.ctx.empty(tuple(src.shape), self.dtype)
-        self.ctx._call("tramp_matvec_nt" if back else "tramp_matvec_nn", dtype_code(self.dtype), 0, lin.Nx, lin.Nx,
-                       src.shape[0], lin._Uk.ptr, src.ptr, dst.ptr)
+        """Output side: Uk^T src (into the rotated basis) or Uk src (back), [batch, M].  Input side: back only,
+        Vt^T src, [batch, k] -> [batch, N]."""
+        rot = self._rot[i]
+        lin, dt = rot["lin"], dtype_code(self.dtype)
+        if rot["side"] == "out":
+            dst = self.ctx.empty(tuple(src.shape), self.dtype)
+            self.ctx._call("tramp_matvec_nt" if back else "tramp_matvec_nn", dt, 0, lin.Nx, lin.Nx,
+                           src.shape[0], lin._Uk.ptr, src.ptr, dst.ptr)
+            return dst
+        assert back, "the input side is only ever expanded"
+        dst = self.ctx.empty((src.shape[0], lin.Nz), self.dtype)
+        self.ctx._call("tramp_matvec_nn", dt, 0, rot["k"], lin.Nz, src.shape[0], lin._Vt.ptr, src.ptr, dst.ptr)
         return dst
 
     class _Basis:
@@ -345,25 +384,16 @@ class ExpectationPropagation:
 
         def __enter__(self):
             ep = self.ep
-            self.saved = []
             ep._basis_depth = getattr(ep, "_basis_depth", 0) + 1
-            if ep._basis_depth > 1:
-                return self
-            for i, rot in ep._rot.items():
-                if rot["y_rot"] is None:
-                    rot["y_rot"] = ep._rotate(i, rot["lik"]._y_dev, back=False)
-                ep.ctx._call("tramp_linear_set_rotated", rot["lin"]._handle, 1)
-                rot["lin"]._t_key = rot["lin"]._u_key = None
-                self.saved.append((rot, rot["lik"]._y_dev))
-                rot["lik"]._y_dev = rot["y_rot"]
+            if ep._basis_depth == 1:
+                ep._apply_basis(True)
             return self
 
         def __exit__(self, *exc):
-            self.ep._basis_depth -= 1
-            for rot, y in self.saved:
-                rot["lik"]._y_dev = y
-                self.ep.ctx._call("tramp_linear_set_rotated", rot["lin"]._handle, 0)
-                rot["lin"]._t_key = rot["lin"]._u_key = None
+            ep = self.ep
+            ep._basis_depth -= 1
+            if ep._basis_depth == 0:
+                ep._apply_basis(False)
             return False
 
     # -- storage
@@ -374,8 +404,10 @@ class ExpectationPropagation:
         self.a_fwd = [self.A.row(2 * i) for i in range(L)]
         self.a_bwd = [self.A.row(2 * i + 1) for i in range(L)]
         self.b_fwd, self.b_bwd, self.r = [], [], []
-        for v in self.variables:
+        for i, v in enumerate(self.variables):
             n = int(np.prod(self.shapes[v.id]))
+            if i in self._rot and self._rot[i]["side"] == "in":
+                n = self._rot[i]["k"]                           # carried as z' = Vt z
             self.b_fwd.append(ctx.zeros((B, n), self.dtype))
             self.b_bwd.append(ctx.zeros((B, n), self.dtype))
             self.r.append(ctx.zeros((B, n), self.dtype))
@@ -387,16 +419,29 @@ class ExpectationPropagation:
 
     def init_message_dag(self, initializer):
         "message_passing.py:211-232"
+        for i in [j for j, r in self._rot.items() if r["side"] == "in"]:
+            v = self.variables[i]
+            if any(np.any(np.asarray(initializer.init_b(self.shapes[v.id], v.id, d)) != 0) for d in ("fwd", "bwd")):
+                del self._rot[i]                                # non-zero start: keep this variable in full
+                self._allocated = False
         if not self._allocated:
             self._allocate()
         for i, v in enumerate(self.variables):
             shape = self.shapes[v.id]
+            if i in self._rot and self._rot[i]["side"] == "in":
+                self.a_fwd[i].fill(initializer.init_a(shape, v.id, "fwd"))
+                self.a_bwd[i].fill(initializer.init_a(shape, v.id, "bwd"))
+                for buf in (self.b_fwd[i], self.b_bwd[i], self.r[i]):
+                    buf.fill(0.0)
+                self.b_fwd[i].version += 1
+                self.b_bwd[i].version += 1
+                continue
             self.a_fwd[i].fill(initializer.init_a(shape, v.id, "fwd"))
             self.a_bwd[i].fill(initializer.init_a(shape, v.id, "bwd"))
             fill_message(self.b_fwd[i], initializer.init_b(shape, v.id, "fwd"))
             fill_message(self.b_bwd[i], initializer.init_b(shape, v.id, "bwd"))
             self.r[i].fill(0.0)
-            if i in self._rot:                                   # initial messages live in the rotated basis too
+            if i in self._rot and self._rot[i]["side"] == "out":  # initial messages live in the rotated basis too
                 for buf, d in ((self.b_fwd[i], "fwd"), (self.b_bwd[i], "bwd")):
                     if np.any(np.asarray(initializer.init_b(shape, v.id, d)) != 0):
                         buf.copy_from(self._rotate(i, buf, back=False))
@@ -562,8 +607,8 @@ class ExpectationPropagation:
         i = self.variable_index(id)
         xt = self.ctx.array(np.atleast_2d(np.asarray(x_true, dtype=self.dtype)), self.dtype)
         out = self.ctx.empty((self.batch,), np.float64)
-        n = self.r[i].shape[1]
         r = self._rotate(i, self.r[i], back=True) if i in self._rot else self.r[i]
+        n = r.shape[1]
         self.ctx._call("tramp_sq_dist", dtype_code(self.dtype), n, self.batch, r.ptr, xt.ptr, out.ptr)
         m = out.get() / n
         return float(m[0]) if self.batch == 1 else m
@@ -573,8 +618,18 @@ class ExpectationPropagation:
         tramp/algos/message_passing.py:306-328): node log-partitions minus the fwd-edge ones.  On a
         chain of SISO variables both edges of a variable carry the variable's own (a, b) pair, so
         this is sum_factors A_f - sum_variables A_x.  One value per instance."""
-        with self._Basis(self):
+        active = getattr(self, "_basis_depth", 0) > 0
+        if active:
+            self._apply_basis(False)                            # the formula below runs in the original basis
+        saved = (self.b_fwd, self.b_bwd)
+        try:
+            self.b_fwd = [self._rotate(i, b, back=True) if i in self._rot else b for i, b in enumerate(self.b_fwd)]
+            self.b_bwd = [self._rotate(i, b, back=True) if i in self._rot else b for i, b in enumerate(self.b_bwd)]
             return self._log_evidence()
+        finally:
+            self.b_fwd, self.b_bwd = saved
+            if active:
+                self._apply_basis(True)
 
     def _log_evidence(self):
         L = len(self.variables)

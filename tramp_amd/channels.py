@@ -618,8 +618,10 @@ class LinearChannel(Channel):
         ctx = self.ctx
         z = VecArg(ctx, bz, self.dtype)
         x = VecArg(ctx, bx, self.dtype)
-        if z.n != self.Nz or x.n != self.Nx or z.batch != x.batch:
-            raise ValueError(f"expected bz [batch,{self.Nz}] and bx [batch,{self.Nx}], "
+        # input side carried in the right singular basis by the scheduler (tramp_linear_set_rotated bit 1)
+        nz = min(self.Nx, self.Nz) if getattr(self, "_rot_mask", 0) & 2 else self.Nz
+        if z.n != nz or x.n != self.Nx or z.batch != x.batch:
+            raise ValueError(f"expected bz [batch,{nz}] and bx [batch,{self.Nx}], "
                              f"got {z.dev.shape} and {x.dev.shape}")
         a_z = ScalArg(ctx, az, z.batch)
         a_x = ScalArg(ctx, ax, z.batch)

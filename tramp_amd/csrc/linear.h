@@ -19,7 +19,8 @@ struct tramp_linear {
     void* uc;            //   (tramp_linear_project_affine)
     bool tc_valid, uc_valid;
     double* a_raw;
-    bool rotated;        // output side expressed in the left singular basis: Uk acts as the identity (k == M)
+    int rot;             // bit 0: output side in the left singular basis (Uk acts as the identity, k == M);
+                         // bit 1: input side in the right singular basis (Vt acts as the identity, k-vectors)
 };
 
 // Epilogue applied to every output element acc = (mat x)[b, idx]:

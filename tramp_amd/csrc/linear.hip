@@ -455,12 +455,18 @@ extern "C" int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, in
 // its form with y' = Uk^T y, every message on that side is the rotated one, norms and variances are
 // unchanged - and the channel becomes z -> S Vt z, so the two passes over Uk (u = Uk^T bx, rx = Uk w) drop
 // out of the iteration: u = bx', rx' = w.  The caller rotates y once and rotates results back when read.
+//
+// The mirror image on the INPUT side (bit 1): when the factor behind the channel's input is an isotropic
+// zero-mean Gaussian prior, the input variable z is carried as z' = Vt z (k numbers per instance).  The part
+// of z orthogonal to the rows of Vt sees only that prior, whose message has b = 0, so it stays exactly zero
+// in every message and posterior mean; t = Vt bz is bz' itself and the back-projection Vt^T w is not formed
+// (rz' = bz' / az + w).  Scalars (variances, n_eff) keep using N.  The caller expands z = Vt^T z' when read.
 extern "C" int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on) {
     if (!ctx) return TRAMP_EINVAL;
-    TRAMP_REQUIRE(ctx, lin);
-    if (on && lin->k != lin->M)
+    TRAMP_REQUIRE(ctx, lin && on >= 0 && on <= 3);
+    if ((on & 1) && lin->k != lin->M)
         return tramp_fail(ctx, TRAMP_EINVAL, "tramp_linear_set_rotated", "needs M <= N (square left factor)");
-    lin->rotated = on != 0;
+    lin->rot = on;
     lin->proj_batch = 0;                      // cached projections belong to the other basis
     lin->tc_valid = lin->uc_valid = false;
     return TRAMP_OK;
@@ -490,12 +496,15 @@ int lin_project(tramp_ctx* ctx, tramp_linear* lin, size_t batch, const void* bz_
     LinEpi plain{};
     plain.mode = 0;
     plain.out = lin->t;
-    if (!(reuse & TRAMP_REUSE_T)) {
+    if (lin->rot & 2) {
+        TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(lin->t, bz_d, batch * lin->k * dtype_size(lin->dtype),
+                                            hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (!(reuse & TRAMP_REUSE_T)) {
         rc = matvec_dispatch(ctx, lin->dtype, 0, true, lin->k, lin->N, batch, lin->Vt, bz_d, plain);
         if (rc) return rc;
     }
     plain.out = lin->u;
-    if (lin->rotated) {
+    if (lin->rot & 1) {
         rc = lin_copy_u(ctx, lin, batch, bx_d);
         if (rc) return rc;
     } else if (!(reuse & TRAMP_REUSE_U)) {
@@ -523,7 +532,7 @@ extern "C" int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, in
         return tramp_fail(ctx, TRAMP_EINVAL, "tramp_linear_project_affine",
                           "the handle holds no projection of the message being updated");
     const bool is_t = which == TRAMP_REUSE_T;
-    if (!is_t && lin->rotated) return TRAMP_OK;      // u IS the (already damped) message in the rotated basis
+    if (lin->rot & (is_t ? 2 : 1)) return TRAMP_OK;  // the projection IS the (already damped) message in a rotated basis
     bool& valid = is_t ? lin->tc_valid : lin->uc_valid;
     void* pc = is_t ? lin->tc : lin->uc;
     void* p = is_t ? lin->t : lin->u;
@@ -574,14 +583,17 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
     LinEpi plain{};
     plain.mode = 0;
     plain.out = lin->t;
-    if (!(reuse & TRAMP_REUSE_T)) {
+    const void* t_ptr = lin->t;
+    if (lin->rot & 2) {
+        t_ptr = bz_d;                                     // t = Vt bz is bz' itself
+    } else if (!(reuse & TRAMP_REUSE_T)) {
         rc = matvec_dispatch(ctx, dtype, 0, true, k, N, batch, lin->Vt, bz_d, plain);
         if (rc) return rc;
     }
     // 3. u = Uk^T bx  [batch, k]
     plain.out = lin->u;
     const void* u_ptr = lin->u;
-    if (lin->rotated) {
+    if (lin->rot & 1) {
         u_ptr = bx_d;                                     // u = Uk^T bx is bx' itself in the rotated basis
     } else if (!(reuse & TRAMP_REUSE_U)) {
         rc = matvec_dispatch(ctx, dtype, 0, false, M, k, batch, lin->Uk, bx_d, plain);
@@ -592,10 +604,10 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
     dim3 gm((unsigned)((k + kBlock - 1) / kBlock > 1024 ? 1024 : (k + kBlock - 1) / kBlock), (unsigned)batch);
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((lin_mid_kernel<double>), gm, dim3(kBlock), 0, ctx->stream, (int)k, mode, lin->sing, az_d,
-                           ax_d, (const double*)lin->t, (const double*)u_ptr, (double*)lin->w);
+                           ax_d, (const double*)t_ptr, (const double*)u_ptr, (double*)lin->w);
     else
         hipLaunchKernelGGL((lin_mid_kernel<float>), gm, dim3(kBlock), 0, ctx->stream, (int)k, mode, lin->sing, az_d,
-                           ax_d, (const float*)lin->t, (const float*)u_ptr, (float*)lin->w);
+                           ax_d, (const float*)t_ptr, (const float*)u_ptr, (float*)lin->w);
     // 5. back-projection with the fused message update
     LinEpi epi{};
     epi.mode = 1;
@@ -608,7 +620,7 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
         epi.a_in = ax_d;
         epi.b_in = bx_d;
         epi.add_b_over_a = 0;
-        if (lin->rotated) {                                                                 // rx' = w
+        if (lin->rot & 1) {                                                                 // rx' = w
             ProfScope ps(ctx, PROF_EW, (double)batch * k * dtype_size(dtype) * (damping != 0.0 ? 4 : 3), 0);
             dim3 ge((unsigned)((k + kBlock * 4 - 1) / (kBlock * 4) > 1024 ? 1024 : (k + kBlock * 4 - 1) / (kBlock * 4)),
                     (unsigned)batch);
@@ -625,7 +637,19 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
         epi.a_in = az_d;
         epi.b_in = bz_d;
         epi.add_b_over_a = (k < N) ? 1 : 0;
-        rc = matvec_dispatch(ctx, dtype, 0, false, k, N, batch, lin->Vt, lin->w, epi);     // rz = Vt^T w
+        if (lin->rot & 2) {                                                                 // rz' = bz' / az + w
+            ProfScope ps(ctx, PROF_EW, (double)batch * k * dtype_size(dtype) * (damping != 0.0 ? 4 : 3), 0);
+            dim3 ge((unsigned)((k + kBlock * 4 - 1) / (kBlock * 4) > 1024 ? 1024 : (k + kBlock * 4 - 1) / (kBlock * 4)),
+                    (unsigned)batch);
+            if (dtype == TRAMP_F64)
+                hipLaunchKernelGGL((lin_epi_apply_kernel<double>), ge, dim3(kBlock), 0, ctx->stream, k,
+                                   (const double*)lin->w, epi);
+            else
+                hipLaunchKernelGGL((lin_epi_apply_kernel<float>), ge, dim3(kBlock), 0, ctx->stream, k,
+                                   (const float*)lin->w, epi);
+            rc = TRAMP_OK;
+        } else
+            rc = matvec_dispatch(ctx, dtype, 0, false, k, N, batch, lin->Vt, lin->w, epi);  // rz = Vt^T w
     }
     if (rc) return rc;
     TRAMP_LAUNCH_CHECK(ctx);
