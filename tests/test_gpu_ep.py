@@ -470,3 +470,14 @@ def test_gaussian_prior_input_rotation(ctx, monkeypatch, golden_ep):
                      damping=d, tol=0.0, max_increase=np.inf, a0=0.5, b0=0.3)
     close(ep1.get_variables_data()["x"]["r"][0], w1["r"]["x"], 1e-8)
     # two-layer ReLU golden runs exercise the input rotation on the first layer (test_ep_trajectories_match_reference)
+
+
+def test_device_array_temporaries_can_be_passed_directly(ctx):
+    "Context._call keeps DeviceArray arguments alive for the call (a `.ptr` of a temporary would dangle)"
+    rs = np.random.RandomState(0)
+    R, Cc, B = 64, 96, 3
+    mat, x = rs.standard_normal((R, Cc)), rs.standard_normal((B, Cc))
+    out = ctx.empty((B, R), np.float64)
+    from tramp_amd.device import dtype_code
+    ctx._call("tramp_matvec_nt", dtype_code(np.float64), 0, R, Cc, B, ctx.array(mat, np.float64), ctx.array(x, np.float64), out)
+    np.testing.assert_allclose(out.get(), x @ mat.T, rtol=1e-12, atol=1e-12)

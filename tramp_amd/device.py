@@ -60,7 +60,11 @@ class Context:
 
     # -- plumbing
     def _call(self, name, *args):
-        rc = getattr(self.lib, name)(self.handle, *args)
+        """Call a C entry point.  DeviceArray arguments are passed as their device pointers and stay referenced
+        for the duration of the call (a temporary such as ``ctx.array(x)`` is therefore safe to pass directly;
+        ``ctx.array(x).ptr`` is not - the array dies, and is freed, before the launch is issued)."""
+        raw = [a.ptr if isinstance(a, DeviceArray) else a for a in args]
+        rc = getattr(self.lib, name)(self.handle, *raw)
         if rc != _lib.OK:
             _lib.check(rc, name, self.handle)
 
