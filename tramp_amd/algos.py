@@ -336,7 +336,7 @@ class ExpectationPropagation:
             for i, v in enumerate(self.variables):
                 pri, lin = self.model.prev_factor(v), self.model.next_factor(v)
                 if type(pri) is GaussianPrior and type(lin) is LinearChannel and pri.isotropic \
-                        and np.all(np.asarray(pri.mean) == 0):
+                        and np.all(np.asarray(pri.mean) == 0) and lin.rank == min(lin.Nx, lin.Nz):
                     self._rot[i] = dict(side="in", lin=lin, k=min(lin.Nx, lin.Nz))
 
     def _lin_masks(self):
