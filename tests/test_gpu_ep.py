@@ -238,7 +238,9 @@ def test_ensemble_per_instance_stopping(ctx):
         assert ep.n_iter_instance[b] == res["n_iter"]
         close(d["x"]["r"][b], res["r"][0], 1e-6)
         close(d["x"]["v"][b], res["v"][0], 1e-6)
-    assert ep.n_iter == max(n_iters) and len(set(n_iters)) > 1
+        close(d["z"]["r"][b], res["r"][1], 1e-6)          # carried in the rotated basis, frozen there, rotated back
+        close(d["z"]["v"][b], res["v"][1], 1e-6)
+    assert ep.n_iter == max(n_iters) and len(set(n_iters)) > 1 and 1 in ep._rot
 
 
 def test_ep_agrees_with_state_evolution_at_large_n(ctx):
