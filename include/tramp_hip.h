@@ -470,6 +470,9 @@ int tramp_sq_dist(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  *      tramp/utils/integration.py:13-28.  All arrays are HOST arrays[count]. */
 int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
                       const double* rho, const double* mean, const double* var, double* v);
+/* BinaryPrior.compute_forward_error (tramp/priors/binary_prior.py:82-86, base_prior.py:66-69):
+ * v(ax) = p+ E_{N(ax, ax)}[1 - tanh^2(b + b0)] + p- E_{N(-ax, ax)}[.], host arrays of `count` points. */
+int tramp_se_binary_prior(tramp_ctx* ctx, size_t count, const double* ax, const double* p_pos, double* v);
 /* K13. Likelihood.compute_backward_error for SgnLikelihood (1-D) and AbsLikelihood (2-D)
  *      tramp/likelihoods/base_likelihood.py:78-81, sgn_likelihood.py:79-92,
  *      abs_likelihood.py:60-69.  Requires az > 1/tau_z (TRAMP_EINVAL otherwise,

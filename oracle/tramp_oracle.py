@@ -1137,11 +1137,27 @@ def binary_prior_posterior(ax, bx, p_pos=0.5):
     return np.tanh(b), (1 - np.tanh(b)**2).mean()
 
 
+def se_binary_prior_error(ax, p_pos=0.5, method="quadpack"):
+    "binary_prior.py:82-86, base_prior.py:66-69"
+    b0 = 0.5 * np.log(p_pos / (1 - p_pos))
+
+    def v_func(bx):
+        return 1 - np.tanh(bx + b0)**2
+    return p_pos * gaussian_measure(+ax, np.sqrt(ax), v_func, method) + \
+        (1 - p_pos) * gaussian_measure(-ax, np.sqrt(ax), v_func, method)
+
+
 class BinaryPriorFactor(OracleFactor):
     kind = "prior"
 
     def __init__(self, size, p_pos=0.5):
         self.size, self.p_pos = size, p_pos
+
+    def forward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(se_binary_prior_error(ax, self.p_pos, method), ax)
+
+    def second_moment(self):
+        return 1.
 
     def forward(self, az, bz, ax, bx):
         r, v = binary_prior_posterior(ax, bx, self.p_pos)

@@ -77,7 +77,7 @@ def golden_logz():
 def golden_tree():
     path = os.path.join(GOLDEN, "tree.npz")
     with np.load(path, allow_pickle=True) as f:
-        return dict(grads=list(f["data"]), unit=list(f["unit"]), ep=list(f["ep"]), reg=list(f["reg"]), gch=list(f["gch"]), se=list(f["se"]), l21=list(f["l21"]), tv=list(f["tv"]), vae=list(f["vae"]), com=list(f["com"]), binp=list(f["binp"]), sgncom=list(f["sgncom"]), comse=list(f["comse"]))
+        return dict(grads=list(f["data"]), unit=list(f["unit"]), ep=list(f["ep"]), reg=list(f["reg"]), gch=list(f["gch"]), se=list(f["se"]), l21=list(f["l21"]), tv=list(f["tv"]), vae=list(f["vae"]), com=list(f["com"]), binp=list(f["binp"]), sgncom=list(f["sgncom"]), comse=list(f["comse"]), binse=list(f["binse"]))
 
 
 @pytest.fixture(scope="session")

@@ -644,3 +644,15 @@ def test_tracking_callbacks_on_a_tree(ctx, golden_tree):
     got = [r for r in tm.records if r["id"] == "x" and r["direction"] == "fwd"]
     close([r["a"] for r in got], e["traj"]["GaussianPrior->x:a"][:3], 1e-9)
     assert len(te.records) == 3 * 2
+
+
+def test_binary_prior_state_evolution_matches_reference(ctx, golden_tree):
+    "BinaryPrior.compute_forward_error on the device quadrature (binary_prior.py:82-86)"
+    import tramp_amd as T
+    for c in golden_tree["binse"]:
+        pr = T.BinaryPrior(size=None, p_pos=c["p_pos"], ctx=ctx)
+        close(pr.compute_forward_error(c["ax"]), c["v"], 1e-7, 1e-12)          # the reference's quad stops at ~1e-8 abs
+    pr = T.BinaryPrior(size=None, p_pos=0.5, ctx=ctx)
+    v = pr.compute_forward_error(np.array([0.05, 0.7, 3.0]))
+    assert v.shape == (3,) and np.all(np.diff(v) < 0)
+    close(pr.compute_forward_state_evolution(0.7), 1 / pr.compute_forward_error(0.7) - 0.7, 1e-12)

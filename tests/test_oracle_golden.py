@@ -841,3 +841,9 @@ def test_committee_se_oracle_matches_reference(golden_tree):
                 close(a, t[f"{s_}->{tt}:a"][it], rtol=2e-5)
             for v in variables:
                 close(vs[v], t["v:" + v][it], rtol=2e-5)
+
+
+def test_binary_prior_se_oracle_matches_reference(golden_tree):
+    for c in golden_tree["binse"]:
+        close(orc.se_binary_prior_error(c["ax"], c["p_pos"]), c["v"], rtol=1e-8)
+        close(orc.se_binary_prior_error(c["ax"], c["p_pos"], method="gl"), c["v"], rtol=1e-6)

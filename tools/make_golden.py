@@ -1022,6 +1022,8 @@ def tree_goldens():
         r_, v_ = pr.compute_forward_posterior(1.3, bx)
         a_, b_ = pr.compute_forward_message(1.3, bx)
         binp.append(dict(p_pos=p_pos, bx=bx, r=r_, v=v_, a_new=a_, b_new=b_))
+    binse = [dict(p_pos=p, ax=a, v=BinaryPrior(size=None, p_pos=p).compute_forward_error(a))
+             for p in (0.5, 0.8, 0.1) for a in (0.05, 0.7, 3.0, 25.0)]
     K, N, alpha, p_pos, damping = 3, 16, 4.0, [0.5, 0.6, 0.4], 0.5
     r = np.random.RandomState(29)
     M = int(alpha * N)
@@ -1060,7 +1062,8 @@ def tree_goldens():
          ep=np.array(trajs, dtype=object), reg=np.array(regs, dtype=object), gch=np.array(gch, dtype=object),
          se=np.array(ses, dtype=object), l21=np.array(l21, dtype=object), tv=np.array(tvs, dtype=object),
          vae=np.array(vae, dtype=object), com=np.array(com, dtype=object), binp=np.array(binp, dtype=object),
-         sgncom=np.array([sgncom], dtype=object), comse=np.array(comse, dtype=object))
+         sgncom=np.array([sgncom], dtype=object), comse=np.array(comse, dtype=object),
+         binse=np.array(binse, dtype=object))
 
 
 # ---------------------------------------------------------------- SE

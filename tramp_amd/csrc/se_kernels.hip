@@ -106,6 +106,27 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
         }
         total = acc;
     }
+    if (mode == 4) {
+        // binary prior (binary_prior.py:82-86, base_prior.py:66-69):
+        //   v = p+ E_{N(+ax, ax)}[f] + p- E_{N(-ax, ax)}[f],  f(b) = 1 - tanh(b + b0)^2
+        const double ax = P.p0[pt], p_pos = P.p1[pt];
+        const double b0 = 0.5 * log(p_pos / (1.0 - p_pos));
+        const double s = sqrt(ax);
+        for (int br = 0; br < 2; ++br) {
+            const double m = br ? -ax : ax;
+            const double wt = br ? 1.0 - p_pos : p_pos;
+            double xc = (s > 0) ? (-b0 - m) / s : 0.0;            // where b + b0 crosses 0
+            xc = fmin(fmax(xc, -10.0), 10.0);
+            double acc = 0.0;
+            for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
+                double x, w;
+                graded_node(i, kPanels1D, xc, x, w);
+                const double t = tanh(m + s * x + b0);
+                acc += w * norm_pdf(x) * (1.0 - t * t);
+            }
+            total += wt * acc;
+        }
+    }
     if (mode == 2) {
         // ReluLikelihood: only the flat region has a non-zero variance
         // (piecewise_linear_likelihood.py:124-131): E_{N(0, mz + mz^2 tau)}[ p(z <= 0) v_neg ]
@@ -334,6 +355,20 @@ extern "C" int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
     if (rc) return rc;
     Se1dParams P{din[0], din[1], din[2], din[3], tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 0, P, dout);
+    return se_finish(ctx, count, dout, v);
+}
+
+extern "C" int tramp_se_binary_prior(tramp_ctx* ctx, size_t count, const double* ax, const double* p_pos, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax && p_pos && v);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, ax[i] >= 0.0 && p_pos[i] > 0.0 && p_pos[i] < 1.0);
+    const double* hin[2] = {ax, p_pos};
+    double *din[2], *dout;
+    int rc = se_stage(ctx, count, hin, 2, din, &dout, 0, nullptr);
+    if (rc) return rc;
+    Se1dParams P{din[0], din[1], nullptr, nullptr, tmath::Pwl3Spec{}};
+    hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 4, P, dout);
     return se_finish(ctx, count, dout, v);
 }
 

@@ -216,7 +216,12 @@ class BinaryPrior(Prior):
                        r.ptr if r is not None else None, v.ptr if v is not None else None)
 
     def compute_forward_error(self, ax):
-        raise NotImplementedError("state evolution of the binary prior is outside the HIP path")
+        "binary_prior.py:82-86 through base_prior.py:66-69, device quadrature (tramp_se_binary_prior)"
+        ax_h = np.atleast_1d(np.asarray(ax, dtype=np.float64))
+        n = ax_h.shape[0]
+        pp, v = np.full(n, float(self.p_pos)), np.empty(n)
+        self.ctx._call("tramp_se_binary_prior", n, ax_h.ctypes.data, pp.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(ax) == 0 else v
 
 
 class MAP_L21NormPrior(Prior):
