@@ -359,7 +359,7 @@ class ExpectationPropagation:
                     rot["y_rot"] = self._rotate(i, rot["lik"]._y_dev, back=False)
                 rot["y_saved"], rot["lik"]._y_dev = rot["lik"]._y_dev, rot["y_rot"]
             else:
-                rot["lik"]._y_dev = rot.pop("y_saved")
+                rot["lik"]._y_dev = rot.pop("y_saved", rot["lik"]._y_dev)
 
     def _rotate(self, i, src, back):
         """Output side: Uk^T src (into the rotated basis) or Uk src (back), [batch, M].  Input side: back only,
