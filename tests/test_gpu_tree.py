@@ -236,16 +236,16 @@ def test_tree_regression_matches_reference(ctx, golden_tree):
         class Rec(T.EarlyStoppingEP):
             def __call__(self, algo, i, max_iter):
                 rec = {}
-                for (src, dst), m in algo.msg.items():
+                for (src, dst) in algo.msg:
                     key = f"{src.id if isinstance(src, Variable) else type(src).__name__}->" \
                           f"{dst.id if isinstance(dst, Variable) else type(dst).__name__}"
-                    rec[key + ":a"], rec[key + ":b"] = m.a.get().copy(), m.b.get().copy()
+                    rec[key + ":a"], rec[key + ":b"] = algo.get_message(src, dst)     # z is carried rotated
                 for vid, d in algo.get_variables_data().items():
                     rec["r:" + vid], rec["v:" + vid] = np.array(d["r"]), np.array(d["v"])
                 iters.append(rec)
                 return super().__call__(algo, i, max_iter)
         ep.iterate(max_iter=30, callback=Rec(), damping=e["damping"])
-        assert ep.n_iter == e["n_iter"]
+        assert ep.n_iter == e["n_iter"] and [ep.variables[i].id for i in ep._rot] == ["z"]
         tr = e["traj"]
         for it, got in enumerate(iters[:len(tr["v:x"])]):
             for key, val in got.items():

@@ -68,9 +68,26 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.n_iter_instance = np.zeros(self.batch, dtype=int)
         self._allocated = False
         self._frozen_r = None
-        self._rot = {}                      # the rotated-output shortcut is a chain-scheduler feature
+        self._find_tree_rotations()
         from .algos import EarlyStoppingEP
         self.default_stopping = EarlyStoppingEP()
+
+    def _find_tree_rotations(self):
+        """The rotated OUTPUT basis of the chain scheduler (algos.py `_find_rotations`) for a variable that sits
+        between a dense LinearChannel (M <= N) and an isotropic GaussianLikelihood, e.g. the measurement branch
+        of sparse-gradient regression.  All four messages around that variable live in the rotated basis."""
+        import os
+        from .channels import LinearChannel
+        self._rot = {}
+        if os.environ.get("TRAMP_ROTATE_OUTPUT", "1") == "0":
+            return
+        g = self.model.dag
+        for i, v in enumerate(self.variables):
+            preds, succs = list(g.predecessors(v)), list(g.successors(v))
+            if len(preds) == 1 and len(succs) == 1 and type(preds[0]) is LinearChannel \
+                    and type(succs[0]) is GaussianLikelihood and succs[0].isotropic \
+                    and preds[0].Nx <= preds[0].Nz and preds[0].rank == preds[0].Nx and succs[0]._y_dev is not None:
+                self._rot[i] = dict(side="out", lin=preds[0], lik=succs[0], y_rot=None)
 
     # -- storage: one (a, b) pair per directed factor<->variable message
     def _allocate(self):
@@ -106,7 +123,11 @@ class TreeExpectationPropagation(ExpectationPropagation):
             direction = "fwd" if g.has_edge(src, dst) else "bwd"
             shape = self.shapes[var.id]
             m.a.fill(initializer.init_a(shape, var.id, direction))
-            fill_message(m.b, initializer.init_b(shape, var.id, direction))
+            value = initializer.init_b(shape, var.id, direction)
+            fill_message(m.b, value)
+            i = self.variables.index(var)
+            if i in self._rot and np.any(np.asarray(value) != 0):         # initial messages live in the rotated basis
+                m.b.copy_from(self._rotate(i, m.b, back=False))
             m.b.version += 1
         for r in self.r:
             r.fill(0.0)
@@ -258,8 +279,11 @@ class TreeExpectationPropagation(ExpectationPropagation):
                 if n is x or getattr(n, "id", None) == x:
                     return n
             raise KeyError(x)
-        m = self.msg[(find(source), find(target))]
-        a, b = m.a.get(), m.b.get()
+        src, dst = find(source), find(target)
+        m = self.msg[(src, dst)]
+        var = src if isinstance(src, Variable) else dst
+        i = self.variables.index(var)
+        a, b = m.a.get(), (self._rotate(i, m.b, back=True) if i in self._rot else m.b).get()
         return (float(a[0]), b[0]) if self.batch == 1 else (a, b)
 
     def log_evidence(self):
