@@ -124,12 +124,17 @@ class GaussianLikelihood(Likelihood):
         return X + self.sigma * np.random.standard_normal(X.shape)
 
     def compute_backward_posterior(self, az, bz, y):
-        "gaussian_likelihood.py:43-49 (host arithmetic; not on the EP path)"
-        bz = bz.get() if isinstance(bz, DeviceArray) else np.asarray(bz)
-        y = y.get() if isinstance(y, DeviceArray) else np.asarray(y)
-        a = np.asarray(az, dtype=np.float64) + self.a
-        col = a[:, None] if a.ndim == 1 and bz.ndim == 2 else a        # one precision per ensemble instance
-        return (bz + self.a * y) / col, 1 / a
+        """gaussian_likelihood.py:43-49: r = (bz + y/var) / (az + 1/var), v = 1 / (az + 1/var): kernel K11 on the
+        incoming message and the likelihood's own constant one."""
+        ctx = self.ctx
+        b = VecArg(ctx, bz, self.dtype)
+        a = ScalArg(ctx, az, b.batch)
+        yd = self._y_for(b, y)
+        a0, b0 = ctx.empty((b.batch,), np.float64), out_vec(ctx, b, self.dtype)
+        ctx._call("tramp_gauss_lik_bwd", self._dt, b.n, b.batch, yd, float(self.var), a0, b0)
+        r, v = out_vec(ctx, b, self.dtype), ctx.empty((b.batch,), np.float64)
+        ctx._call("tramp_variable_posterior", self._dt, b.n, b.batch, a.dev, b.dev, a0, b0, None, r, v, None, None)
+        return ret_vec(r, b), ret_scal(v, a, b)
 
     def compute_backward_message(self, az, bz, out_a=None, out_b=None, **_):
         "gaussian_likelihood.py:68-71"

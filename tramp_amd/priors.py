@@ -346,16 +346,16 @@ class GaussianPrior(Prior):
         return self._logz(_lib.LOGZ_GAUSS_PRIOR, ax, bx, params=(self.mean, self.var))
 
     def compute_forward_posterior(self, ax, bx):
-        "gaussian_prior.py:63-68 (host arithmetic on the caller's arrays; not on the EP path)"
-        if isinstance(bx, DeviceArray):
-            bx = bx.get()
-        if isinstance(ax, DeviceArray):
-            ax = ax.get()
-        a = np.asarray(ax) + self.a
-        b = np.asarray(bx) + self.b
-        if np.ndim(a) == 1 and np.ndim(b) == 2:
-            a = a[:, None]
-        return b / a, 1 / (np.asarray(ax) + self.a)
+        """gaussian_prior.py:63-68: r = (bx + mean/var) / (ax + 1/var), v = 1 / (ax + 1/var) - the product of
+        two Gaussian messages, i.e. kernel K11 on the incoming message and the prior's own constant one."""
+        ctx = self.ctx
+        b = VecArg(ctx, bx, self.dtype)
+        a = ScalArg(ctx, ax, b.batch)
+        a0, b0 = ctx.empty((b.batch,), np.float64), out_vec(ctx, b, self.dtype)
+        ctx._call("tramp_gauss_prior_fwd", self._dt, b.n, b.batch, float(self.mean), float(self.var), a0, b0)
+        r, v = out_vec(ctx, b, self.dtype), ctx.empty((b.batch,), np.float64)
+        ctx._call("tramp_variable_posterior", self._dt, b.n, b.batch, a.dev, b.dev, a0, b0, None, r, v, None, None)
+        return ret_vec(r, b), ret_scal(v, a, b)
 
     def compute_forward_message(self, ax, bx, out_a=None, out_b=None, **_):
         "gaussian_prior.py:86-89: bypasses compute_ab_new (and damping sees a constant)"
