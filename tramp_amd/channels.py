@@ -577,23 +577,16 @@ class LinearChannel(Channel):
 
     # -- scalars (K9); host closed forms for host scalars, kernel for device scalars
     def compute_n_eff(self, az, ax):
-        "linear_channel.py:58-67"
-        if ax == 0:
-            return 0.
-        if az / ax == 0:
-            return self.rank / self.Nz
-        return np.sum(self.singular / (az / ax + self.singular)) / self.Nz
+        "linear_channel.py:58-67 (kernel K9, tramp_linear_variance; the forward query leaves az unfloored)"
+        return float(self.device_variance(_lib.FWD, az, ax)[2][0])
 
     def compute_backward_variance(self, az, ax):
-        "linear_channel.py:91-97"
-        az = np.maximum(1e-11, az)
-        return (1 - self.compute_n_eff(az, ax)) / az
+        "linear_channel.py:91-97 (K9; the kernel floors az at 1e-11 like the reference)"
+        return float(self.device_variance(_lib.BWD, az, ax)[0][0])
 
     def compute_forward_variance(self, az, ax):
-        "linear_channel.py:99-105"
-        if ax == 0:
-            return np.mean(self.singular) * self.rank / (self.Nx * az)
-        return self.compute_n_eff(az, ax) / (self.alpha * ax)
+        "linear_channel.py:99-105 (K9)"
+        return float(self.device_variance(_lib.FWD, az, ax)[0][0])
 
     def compute_backward_error(self, az, ax, tau_z):
         return self.compute_backward_variance(az, ax)           # :119-121
