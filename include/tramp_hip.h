@@ -470,6 +470,12 @@ int tramp_sq_dist(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  *      tramp/utils/integration.py:13-28.  All arrays are HOST arrays[count]. */
 int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
                       const double* rho, const double* mean, const double* var, double* v);
+/* K15. AnalyticalLinearChannel / MarchenkoPasturChannel closed forms
+ * (tramp/channels/linear/analytical_linear_channel.py:28-53, tramp/ensembles/marchenko_pastur_ensemble.py:39-45):
+ * dir BWD v = (1 - n_eff) / max(az, 1e-11), dir FWD v = n_eff / (alpha ax) (mean_spectrum / (alpha az) at ax = 0),
+ * n_eff = 1 - eta(ax / az).  Host arrays of `count` points; n_eff optional. */
+int tramp_se_mp_channel(tramp_ctx* ctx, int dir, size_t count, const double* alpha, const double* mean_spectrum,
+                        const double* az, const double* ax, double* v, double* n_eff);
 /* BinaryPrior.compute_forward_error (tramp/priors/binary_prior.py:82-86, base_prior.py:66-69):
  * v(ax) = p+ E_{N(ax, ax)}[1 - tanh^2(b + b0)] + p- E_{N(-ax, ax)}[.], host arrays of `count` points. */
 int tramp_se_binary_prior(tramp_ctx* ctx, size_t count, const double* ax, const double* p_pos, double* v);

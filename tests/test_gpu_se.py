@@ -51,6 +51,16 @@ def test_se_mp_channel(golden_se):
         close(ch.compute_backward_error(c["az"], c["ax"], 1.0), c["vz"], rtol=1e-12)
         close(ch.compute_forward_error(c["az"], c["ax"], 1.0), c["vx"], rtol=1e-12)
         close(ch.second_moment(1.7), c["tau_x"], rtol=1e-12)
+    # kernel K15 against the oracle at the edge points, scalars and arrays
+    from oracle import tramp_oracle as orc
+    mp, mo = T.MarchenkoPasturChannel(alpha=0.5), orc.MarchenkoPasturOracle(0.5)
+    for az, ax in [(1.3, 0.7), (2.0, 0.0), (0.0, 5.0), (1e-11, 5.0)]:
+        close(mp.compute_backward_error(az, ax, 1.0), mo.backward_error(az, ax), rtol=1e-13)
+        close(mp.compute_n_eff(az, ax), mo.n_eff(az, ax), rtol=1e-13)
+        if az > 0:
+            close(mp.compute_forward_error(az, ax, 1.0), mo.forward_error(az, ax), rtol=1e-13)
+    v = mp.compute_backward_error(np.array([1.3, 2.0]), np.array([0.7, 0.7]), 1.0)
+    close(v, [mo.backward_error(1.3, 0.7), mo.backward_error(2.0, 0.7)], rtol=1e-13)
 
 
 def test_se_trajectories(ctx, golden_se):

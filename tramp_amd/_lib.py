@@ -112,6 +112,7 @@ _SIGNATURES = {
     "tramp_sq_dist": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_se_gb_prior": [vp, sz, vp, vp, vp, vp, vp],
     "tramp_se_binary_prior": [vp, sz, vp, vp, vp],
+    "tramp_se_mp_channel": [vp, i32, sz, vp, vp, vp, vp, vp, vp],
     "tramp_se_sgn_lik": [vp, sz, vp, vp, vp],
     "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
     "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from .base import Factor, VecArg, ScalArg, out_vec, ret_vec, ret_scal
-from .device import DeviceArray
+from .device import DeviceArray, default_context
 from .ensembles import MarchenkoPasturEnsemble
 
 
@@ -1381,21 +1381,28 @@ class AnalyticalLinearChannel(Channel):
     def second_moment(self, tau_z):
         return tau_z * (self.ensemble.mean_spectrum / self.alpha)
 
+    def _k15(self, direction, az, ax):
+        "kernel K15 (tramp_se_mp_channel) on arrays of points: (v, n_eff)"
+        if not hasattr(self.ensemble, "compute_F"):
+            raise NotImplementedError("only the Marchenko-Pastur closed form is on the HIP path")
+        ctx = default_context()
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        n = az_h.shape[0]
+        ax_h = np.ascontiguousarray(np.broadcast_to(np.asarray(ax, dtype=np.float64), (n,)))
+        al, ms = np.full(n, float(self.alpha)), np.full(n, float(self.ensemble.mean_spectrum))
+        v, ne = np.empty(n), np.empty(n)
+        ctx._call("tramp_se_mp_channel", direction, n, al.ctypes.data, ms.ctypes.data, az_h.ctypes.data,
+                  ax_h.ctypes.data, v.ctypes.data, ne.ctypes.data)
+        return (float(v[0]), float(ne[0])) if np.ndim(az) == 0 else (v, ne)
+
     def compute_n_eff(self, az, ax):
-        if ax == 0:
-            return 0.
-        if az / ax == 0:
-            return min(1, self.alpha)
-        return 1 - self.ensemble.eta_transform(ax / az)
+        return self._k15(_lib.FWD, az, ax)[1]                   # analytical_linear_channel.py:28-37
 
     def compute_backward_error(self, az, ax, tau_z):
-        az = np.maximum(1e-11, az)
-        return (1 - self.compute_n_eff(az, ax)) / az
+        return self._k15(_lib.BWD, az, ax)[0]                   # :42-46
 
     def compute_forward_error(self, az, ax, tau_z):
-        if ax == 0:
-            return self.ensemble.mean_spectrum / (self.alpha * az)
-        return self.compute_n_eff(az, ax) / (self.alpha * ax)
+        return self._k15(_lib.FWD, az, ax)[0]                   # :48-53
 
 
 class MarchenkoPasturChannel(AnalyticalLinearChannel):

@@ -358,6 +358,55 @@ extern "C" int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
     return se_finish(ctx, count, dout, v);
 }
 
+// ---------------------------------------------------------------- K15: Marchenko-Pastur linear layer
+// AnalyticalLinearChannel.compute_n_eff / compute_backward_error / compute_forward_error
+// (tramp/channels/linear/analytical_linear_channel.py:28-53) with the closed-form eta transform of the
+// Marchenko-Pastur law (tramp/ensembles/marchenko_pastur_ensemble.py:39-45).  One thread per point.
+__global__ void se_mp_kernel(size_t count, int dir, const double* __restrict__ alpha_d,
+                             const double* __restrict__ mean_spectrum_d, const double* __restrict__ az_d,
+                             const double* __restrict__ ax_d, double* __restrict__ v_out, double* __restrict__ n_eff_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double alpha = alpha_d[i], ax = ax_d[i];
+    double az = az_d[i];
+    if (dir == TRAMP_BWD) az = fmax(1e-11, az);                          // :43
+    double n_eff;
+    if (ax == 0.0) n_eff = 0.0;                                          // :30-32
+    else if (az / ax == 0.0) n_eff = fmin(1.0, alpha);                   // :33-35
+    else {
+        const double gamma = ax / az;
+        const double sa = sqrt(alpha);
+        const double zmax = (1.0 + sa) * (1.0 + sa), zmin = (1.0 - sa) * (1.0 - sa);
+        const double root = sqrt(gamma * zmax + 1.0) - sqrt(gamma * zmin + 1.0);
+        const double F = root * root;                                    // marchenko_pastur_ensemble.py:39-41
+        n_eff = 1.0 - (1.0 - F / (4.0 * gamma));                         // :36-37 with eta = 1 - F / (4 gamma)
+    }
+    double v;
+    if (dir == TRAMP_BWD) v = (1.0 - n_eff) / az;                        // :44-46
+    else v = (ax == 0.0) ? mean_spectrum_d[i] / (alpha * az) : n_eff / (alpha * ax);   // :48-53
+    v_out[i] = v;
+    if (n_eff_out) n_eff_out[i] = n_eff;
+}
+
+extern "C" int tramp_se_mp_channel(tramp_ctx* ctx, int dir, size_t count, const double* alpha,
+                                   const double* mean_spectrum, const double* az, const double* ax, double* v,
+                                   double* n_eff) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, alpha && mean_spectrum && az && ax && v);
+    TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, alpha[i] > 0.0);
+    const double* hin[4] = {alpha, mean_spectrum, az, ax};
+    double *din[4], *dout, *dout2 = nullptr;
+    int rc = se_stage(ctx, count, hin, 4, din, &dout, count, &dout2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(se_mp_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, count, dir, din[0],
+                       din[1], din[2], din[3], dout, dout2);
+    if (n_eff)
+        TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(n_eff, dout2, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return se_finish(ctx, count, dout, v);
+}
+
 extern "C" int tramp_se_binary_prior(tramp_ctx* ctx, size_t count, const double* ax, const double* p_pos, double* v) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, ax && p_pos && v);
