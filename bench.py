@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: EP iterations/s x N x instances (msg-components/s) for the sparse GLM
 (GaussBernoulli prior + dense LinearChannel + Gaussian likelihood, Gaussian ensemble,
-alpha = 0.5, fp64) on MI355X.
+alpha = 0.5, fp64) on MI355X - BASELINE.json configs[3]'s per-GPU shard: 64 instances of
+N = 100000, M = 50000 sharing W.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...                       # starts its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+                                                       # (the driver's launcher: only its RANK /
+                                                       #  WORLD_SIZE / MASTER_* environment is used)
 
-A "step" is one full EP iteration (forward sweep, backward sweep, variable posteriors) over
-the rank's batch of independent problem instances that share the sensing matrix W (the
-ensemble axis of BASELINE.json configs[3]).  Instances are sharded across ranks with no
-data-path collective: rank 0 draws W and broadcasts it once over RCCL (setup, untimed), every
-rank factorises it and runs its own instances ("weak" scaling: per-GPU work fixed).
-Setup (W generation, broadcast, factorisation, teacher data) is reported separately, as the
-reference reports svd_time separately (examples/figures/compute_benchmark.py:21-27).
+A "step" is one full EP iteration (forward sweep, backward sweep, variable posteriors, NaN guard +
+stopping-rule readback) over the rank's batch of independent problem instances that share the
+sensing matrix W.  Instances are sharded across ranks with no data-path collective: rank 0 draws W,
+factorises it ONCE and broadcasts the thin factors over RCCL (C ABI: tramp_bcast_matrix; setup,
+untimed); every rank then runs its own instances ("weak" scaling: per-GPU work fixed).  No PyTorch
+anywhere.  Setup (W generation, factorisation, broadcast, teacher data) is reported separately, as
+the reference reports svd_time separately (examples/figures/compute_benchmark.py:21-27).
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+Prints ONE JSON line on rank 0 (see DESIGN.md section 5 for the fields).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -40,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", dest="n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 65536)),
+    ap.add_argument("--size", dest="n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 100000)),
                     help="signal dimension N (not --n: torch.distributed.run would read it as its own option)")
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TRAMP_BENCH_BATCH", 64)),
@@ -49,14 +54,17 @@ def parse():
     ap.add_argument("--rho", type=float, default=0.05)
     ap.add_argument("--noise-var", type=float, default=1e-2)
     ap.add_argument("--damping", type=float, default=0.1)
+    ap.add_argument("--check-every", type=int, default=1,
+                    help="host reads the scalar table (NaN guard + stopping-rule norms) every k-th iteration; "
+                         "1 = every iteration, as the reference does (message_passing.py:345-356)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denoiser", action="store_true")
+    ap.add_argument("--no-se", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=4000)
     ap.add_argument("--save-factors", default=None, metavar="DIR",
                     help="after the setup, dump the thin factors (Uk, Vt, sing) and the observations to DIR")
     ap.add_argument("--load-factors", default=None, metavar="DIR",
-                    help="skip W generation / factorisation and load what --save-factors wrote (used to put the "
-                         "timed region under rocprofv3, which crashes inside rocSOLVER's syevd at k >= 24576)")
+                    help="skip W generation / factorisation and load what --save-factors wrote")
     return ap.parse_args()
 
 
@@ -92,9 +100,9 @@ def cpu_baseline(args):
     iters = 300
     orc.ep_chain(fs, [N, M], max_iter=2, damping=args.damping, tol=0.0)       # warm-up
 
-    def run(n_it):
+    def run(n_it, factors=fs):
         t0 = time.perf_counter()
-        res = orc.ep_chain(fs, [N, M], max_iter=n_it, damping=args.damping, tol=0.0, max_increase=np.inf)
+        res = orc.ep_chain(factors, [N, M], max_iter=n_it, damping=args.damping, tol=0.0, max_increase=np.inf)
         return res["n_iter"], time.perf_counter() - t0
     runs = [run(iters) for _ in range(5)]                                     # median of >= 5 runs
     n_it, dt = sorted(runs, key=lambda r: r[1])[len(runs) // 2]
@@ -103,6 +111,11 @@ def cpu_baseline(args):
                      f"N={N}, alpha={args.alpha}, median of 5 runs of {n_it} iterations ({dt:.2f} s each; "
                      f"+{setup_s:.1f} s SVD setup, untimed), NumPy/OpenBLAS {threads} threads, "
                      f"{os.cpu_count()} host cores ({_cpu_model()})"}
+    # the same EP on the thin factors the HIP path stores (fewer flops per solve than the reference does)
+    fs_thin = [fs[0], orc.LinearFactor(W, thin=True), fs[2]]
+    runs = [run(iters, fs_thin) for _ in range(3)]
+    n_it, dt = sorted(runs, key=lambda r: r[1])[1]
+    out["thin_form_value"] = N * n_it / dt
     try:
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):
@@ -156,12 +169,11 @@ def structured_n1e6(T, ctx, dtype):
     model = (T.GaussBernoulliPrior(size=n, rho=rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x") @ ch
              @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=Y, var=nv, dtype=np_dt, ctx=ctx)).to_model()
     ep = T.ExpectationPropagation(model, ctx=ctx)
-    never = 1 << 30
-    ep.iterate(max_iter=3, callback=T.PassCallback(), damping=0.1, check_every=never)
+    ep.iterate(max_iter=3, callback=T.PassCallback(), damping=0.1)
     ctx.sync()
     K = 20
     t0 = time.perf_counter()
-    ep.iterate(max_iter=K, callback=T.PassCallback(), damping=0.1, warm_start=True, check_every=never)
+    ep.iterate(max_iter=K, callback=T.PassCallback(), damping=0.1, warm_start=True)
     ctx.sync()
     dt = time.perf_counter() - t0
     return {"workload": "sparse deconvolution EP, ConvChannel (circulant, matrix-free), damping 0.1", "n": n, "instances": B,
@@ -176,88 +188,88 @@ class _Shape:
         self.shape = (m, n)
 
 
-def run(args):
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks",
-                  file=sys.stderr)
-            sys.exit(2)
-    dist = None
-    torch = None
-    # TRAMP_BENCH_FORCE_DIST=1 takes the torch.distributed / RCCL path even with one rank
-    # (used to smoke-test the multi-GPU code on a 1-GPU box)
-    if world > 1 or os.environ.get("TRAMP_BENCH_FORCE_DIST") == "1":
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+def teacher_data(T, ctx, ensemble, lin_factors, args, start, stop, np_dt):
+    """x and y = W x + noise for instances [start, stop) of the ensemble; each instance draws from its
+    own seed (ensemble.instance_seeds), so the data do not depend on the rank partition.  W x is formed
+    from the thin factors (Uk (sing * (Vt x))): every rank holds those, only rank 0 ever held W."""
+    Uk, sing_h, Vt = lin_factors
+    M, k = Uk.shape
+    N = Vt.shape[1]
+    B = stop - start
+    X = np.empty((B, N), dtype=np_dt)
+    noise = np.empty((B, M))
+    for j, seed in enumerate(ensemble.instance_seeds(1000, start, stop)):
+        rs = np.random.RandomState(seed % (2**31))
+        X[j] = rs.standard_normal(N) * rs.binomial(1, args.rho, N)
+        noise[j] = rs.standard_normal(M)
+    dt = T.device.dtype_code(np_dt)
+    Xd = ctx.array(X, np_dt)
+    t = ctx.empty((B, k), np_dt)
+    ctx._call("tramp_matvec_nt", dt, 0, k, N, B, Vt.ptr, Xd.ptr, t.ptr)
+    ts = ctx.array(t.get() * sing_h[None, :], np_dt)
+    Zd = ctx.empty((B, M), np_dt)
+    ctx._call("tramp_matvec_nt", dt, 0, M, k, B, Uk.ptr, ts.ptr, Zd.ptr)
+    Y = Zd.get() + np.sqrt(args.noise_var) * noise
+    return X, Y
 
+
+def run(args):
     import tramp_amd as T
     from tramp_amd import ensemble
+    rank, local_rank, world, _, _ = ensemble.env_world()
+    force_dist = os.environ.get("TRAMP_BENCH_FORCE_DIST") == "1"      # RCCL path with one rank (1-GPU smoke test)
     ctx = T.Context(local_rank)
+    comm = ensemble.init_comm(ctx, backend="rccl") if (world > 1 or force_dist) else None
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     N, B = args.n, args.batch
     M = int(args.alpha * N)
+    k = min(M, N)
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
 
     # ---------------- setup (untimed, reported)
     t_setup = time.perf_counter()
     bcast_s = None
+    factorize_s = 0.0
     start, stop = ensemble.shard_range(B * world, rank, world)
     if args.load_factors:
         d = args.load_factors
-        k = min(M, N)
         Uk = ctx.array(np.load(os.path.join(d, "Uk.npy"), mmap_mode="r"), np_dt)
         Vt = ctx.array(np.load(os.path.join(d, "Vt.npy"), mmap_mode="r"), np_dt)
         sing = np.load(os.path.join(d, "sing.npy"))
-        X = np.load(os.path.join(d, "X.npy"))
-        Y = np.load(os.path.join(d, "Y.npy"))
-        assert Uk.shape == (M, k) and Vt.shape == (k, N) and X.shape == (B, N), "factors do not match --size/--batch"
-        tf = time.perf_counter()
-        lin = T.LinearChannel(_Shape(M, N), dtype=np_dt, ctx=ctx,
-                              factors=(Uk, sing, Vt, int(np.sum(sing > 0))))
-        factorize_s = 0.0
+        lin_rank = int(np.sum(sing > 0))
+        assert Uk.shape == (M, k) and Vt.shape == (k, N), "factors do not match --size"
     else:
-        if dist is None:
+        Uk = ctx.empty((M, k), np_dt)
+        Vt = ctx.empty((k, N), np_dt)
+        sing_d = ctx.empty((k,), np.float64)
+        lin_rank = 0
+        if rank == 0:
             W = ctx.randn((M, N), np_dt, seed=1234, scale=1.0 / np.sqrt(N))
-        else:
-            # shared sensing matrix: rank 0 draws it, RCCL broadcast over xGMI to the other ranks
-            Wt = torch.empty((M, N), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device="cuda")
-            W = T.DeviceArray(ctx, (M, N), np_dt, ptr=Wt.data_ptr(), owner=False)
-            if rank == 0:
-                ctx._call("tramp_randn", T.device.dtype_code(np_dt), W.ptr, W.size, 1234, 1.0 / np.sqrt(N))
-                ctx.sync()
-            bcast_s = ensemble.broadcast_tensor(Wt, src=0)
-        # teacher data of this rank's instances: block [start, stop) of the B*world ensemble
-        rs = np.random.RandomState(ensemble.instance_seeds(1000, start, stop)[0] % (2**31))
-        X = (rs.standard_normal((B, N)) * rs.binomial(1, args.rho, (B, N))).astype(np_dt)
-        Xd = ctx.array(X, np_dt)
-        Zd = ctx.empty((B, M), np_dt)
-        ctx._call("tramp_matvec_nt", T.device.dtype_code(np_dt), 0, M, N, B, W.ptr, Xd.ptr, Zd.ptr)
-        Y = Zd.get() + np.sqrt(args.noise_var) * rs.standard_normal((B, M))
-        tf = time.perf_counter()
-        lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device")
-        ctx.sync()
-        factorize_s = time.perf_counter() - tf
-        del W
-        if dist is not None:
-            del Wt
-            torch.cuda.empty_cache()
-        if args.save_factors and rank == 0:
-            os.makedirs(args.save_factors, exist_ok=True)
-            np.save(os.path.join(args.save_factors, "Uk.npy"), lin._Uk.get())
-            np.save(os.path.join(args.save_factors, "Vt.npy"), lin._Vt.get())
-            np.save(os.path.join(args.save_factors, "sing.npy"), lin._sing.get())
-            np.save(os.path.join(args.save_factors, "X.npy"), X)
-            np.save(os.path.join(args.save_factors, "Y.npy"), Y)
+            ctx.sync()
+            tf = time.perf_counter()
+            r_out = C.c_size_t()
+            ctx._call("tramp_linear_factorize", T.device.dtype_code(np_dt), M, N, W.ptr, Uk.ptr, Vt.ptr, sing_d.ptr,
+                      C.byref(r_out))
+            ctx.sync()
+            factorize_s = time.perf_counter() - tf
+            lin_rank = int(r_out.value)
+            del W
+        if comm is not None:
+            # shared sensing matrix: factorised once, ONE broadcast of its thin factors over xGMI
+            bcast_s = comm.broadcast(Vt, root=0) + comm.broadcast(Uk, root=0) + comm.broadcast(sing_d, root=0)
+            lin_rank = int(comm.gather_scalars([lin_rank])[0, 0])
+        sing = sing_d.get()
+    lin = T.LinearChannel(_Shape(M, N), dtype=np_dt, ctx=ctx, factors=(Uk, sing, Vt, lin_rank))
+    X, Y = teacher_data(T, ctx, ensemble, (Uk, sing, Vt), args, start, stop, np_dt)
+    if args.save_factors and rank == 0:
+        os.makedirs(args.save_factors, exist_ok=True)
+        np.save(os.path.join(args.save_factors, "Uk.npy"), Uk.get())
+        np.save(os.path.join(args.save_factors, "Vt.npy"), Vt.get())
+        np.save(os.path.join(args.save_factors, "sing.npy"), sing)
     model = (T.GaussBernoulliPrior(size=N, rho=args.rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x")
              @ lin @ T.SISOVariable(id="z")
              @ T.GaussianLikelihood(y=Y.astype(np_dt), var=args.noise_var, dtype=np_dt, ctx=ctx)).to_model()
@@ -265,16 +277,15 @@ def run(args):
     setup_s = time.perf_counter() - t_setup
 
     # ---------------- warm-up, then EXACTLY K timed steps
-    never = 1 << 30
-    ep.iterate(max_iter=max(args.warmup, 1), callback=T.PassCallback(), damping=args.damping, check_every=never)
+    ep.iterate(max_iter=max(args.warmup, 1), callback=T.PassCallback(), damping=args.damping,
+               check_every=args.check_every)
     ctx._call("tramp_profile_enable", 1)
     barrier()
     t0 = time.perf_counter()
     ep.iterate(max_iter=args.steps, callback=T.PassCallback(), damping=args.damping, warm_start=True,
-               check_every=never)
+               check_every=args.check_every)
     barrier()
     elapsed = time.perf_counter() - t0
-    import ctypes as C
     NT = len(TAGS)
     cnt = (C.c_int * NT)()
     ms = (C.c_double * NT)()
@@ -282,32 +293,36 @@ def run(args):
     fl = (C.c_double * NT)()
     ctx._call("tramp_profile_report", cnt, ms, by, fl)
     ctx._call("tramp_profile_enable", 0)
-    mse = float(np.mean(ep.mse("x", X)))
-    if dist is not None:
-        elapsed = ensemble.max_over_ranks(elapsed, device="cuda")
+    mse_inst = np.atleast_1d(ep.mse("x", X))
+    v_inst = np.atleast_1d(ep.get_variables_data(["x"], want_r=False)["x"]["v"])
+    if comm is not None:
+        elapsed = comm.max(elapsed)
+        gathered = comm.gather_scalars(np.concatenate([mse_inst, v_inst])).reshape(world, 2, B)
+        mse_inst, v_inst = gathered[:, 0].ravel(), gathered[:, 1].ravel()
 
     if rank == 0:
         total_units = float(N) * B * world * args.steps
         kern = {TAGS[i]: {"launches": cnt[i], "ms": ms[i], "bytes": by[i], "flops": fl[i]} for i in range(NT)
                 if cnt[i]}
-        dom = max(kern, key=lambda k: kern[k]["ms"])
+        dom = max(kern, key=lambda kk: kern[kk]["ms"])
         d = kern[dom]
-        # measured HBM traffic of the dominant kernel at this shape, if a PMC profile of it is committed.
-        # both matrix passes of an iteration stream Vt (k x N): NT for t = Vt b, NN for the back-projection
-        # (the Uk passes are gone: affine projection update + rotated output basis); the profile covers that shape.
+        # measured HBM traffic of the dominant kernel at this shape, if a PMC profile of it is committed
+        # (rocprofv3 cannot collect counters from inside this process; tools/profile_bench.sh makes the passes)
         traffic = None
         traffic_detail = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))["entries"]
-            key = f"{dom}:{args.dtype}:R{M}:C{N}:B{B}"
+        for prof in ("r02", "r01"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", prof, "traffic.json")))["entries"]
+            except Exception:                                                 # noqa: BLE001
+                continue
+            key = f"{dom}:{args.dtype}:R{k}:C{N}:B{B}"
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
                 traffic_detail = {"algorithmic_bytes_per_launch": tj[key]["algorithmic_bytes"],
-                                  "shape": f"{M}x{N} pass of the dominant kernel",
-                                  "source": "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                            "passes, FETCH_SIZE doubled per the gfx950 correction)"}
-        except Exception:
-            traffic = None
+                                  "shape": f"{k}x{N} pass of the dominant kernel",
+                                  "source": f"profiles/{prof}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                            "passes of this command, FETCH_SIZE doubled per the gfx950 correction)"}
+                break
         use_mfma = B > 16 and dom.startswith("matvec")     # batch <= 16 streams at the HBM rate
         if use_mfma:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -315,9 +330,6 @@ def run(args):
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": traffic,
                     "traffic_detail": traffic_detail,
                     "peak_measured_issue_rate": MFMA_MEASURED_TFLOPS[args.dtype],
-                    "peak_notes": "register-loop rates on this part (tools/probes): v_mfma_f64_16x16x4 47.5, "
-                                  "v_mfma_f64_4x4x4_4b 76 TFLOP/s; PMC MfmaUtil of the f64 kernels 75.5 % "
-                                  "(profiles/r01/pmc_mfma_util_kernels_N65536.csv)" if args.dtype == "f64" else None,
                     "avg_launch_ms": d["ms"] / d["launches"], "launches": d["launches"],
                     "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
         else:
@@ -333,15 +345,22 @@ def run(args):
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "sparse-GLM EP ensemble: GaussBernoulliPrior(rho=%g) + dense LinearChannel "
                                    "(Gaussian ensemble W shared by the instances) + GaussianLikelihood(var=%g), "
-                                   "damping %g; dense W at N=1e6 (4 TB) cannot exist, this is BASELINE "
-                                   "configs[3]'s per-GPU shard shape" % (args.rho, args.noise_var, args.damping),
+                                   "damping %g, NaN guard and stopping-rule readback every %d iteration(s); BASELINE "
+                                   "configs[3]'s per-GPU shard (64 x N=1e5); configs[1] as written (dense W at "
+                                   "N=1e6, 4 TB) cannot exist" % (args.rho, args.noise_var, args.damping,
+                                                                    args.check_every),
                        "N": N, "M": M, "alpha": args.alpha, "instances_per_gpu": B,
-                       "instances_total": B * world, "parallelism": f"ensemble-shard x{world}"},
+                       "instances_total": B * world, "parallelism": f"ensemble-shard x{world}",
+                       "collectives": "none in the timed region; setup: RCCL broadcast of the thin factors"
+                                      if comm is not None else "none (single rank)"},
             "roofline": roof,
             "kernels": kern,
             "setup": {"total_s": setup_s, "factorize_s": factorize_s,
-                      "broadcast_W_s": bcast_s, "factors_loaded_from": args.load_factors},
-            "mse_after_run": mse,
+                      "broadcast_factors_s": bcast_s, "factors_loaded_from": args.load_factors,
+                      "eigensolver": "spectral divide and conquer + rocSOLVER syevd halves" if k > 46336
+                                     else "rocSOLVER syevd"},
+            "mse_after_run": float(np.mean(mse_inst)),
+            "v_after_run": float(np.mean(v_inst)),
             "device": ctx.device_name(),
         }
         if world == 1 and not args.no_denoiser:
@@ -352,29 +371,23 @@ def run(args):
                 out["structured_n1e6"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 def main():
-    """Single-rank runs retry at half the size if the setup fails (e.g. the eigensolver or an
-    allocation): a smaller honest number beats no number; the size actually run is in `config`."""
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # own launcher: one process per GPU, started BEFORE anything here touches the GPU
+        from tramp_amd import ensemble
+        sys.exit(ensemble.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    while True:
-        try:
-            return run(args)
-        except Exception as e:      # noqa: BLE001
-            if world > 1 or args.n <= 8192 or args.load_factors:
-                raise
-            import gc
-            import traceback
-            traceback.print_exc(file=sys.stderr)
-            print(f"bench.py: run at N={args.n} failed ({e!r}); retrying at N={args.n // 2}", file=sys.stderr)
-            gc.collect()
-            args.n //= 2
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    return run(args)
 
 
 if __name__ == "__main__":

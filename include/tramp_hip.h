@@ -254,12 +254,22 @@ int tramp_linear_create(tramp_ctx* ctx, int dtype, size_t M, size_t N, size_t ra
                         tramp_linear** lin);
 int tramp_linear_destroy(tramp_ctx* ctx, tramp_linear* lin);
 
-/* Device factorisation (setup path): Gram matrix on the
- * smaller side (rocBLAS), symmetric eigensolve (rocSOLVER), thin factors.
+/* Device factorisation (setup path; replaces the two host SVDs of
+ * LinearChannel.__init__, tramp/channels/linear/linear_channel.py:8-15,30-46): Gram matrix on the
+ * smaller side (rocBLAS), symmetric eigensolve (tramp_eigh), thin factors; singular values below
+ * 1e-5 sigma_max are re-resolved from the Gram matrix of their own rows, and the rank uses
+ * np.linalg.matrix_rank's tolerance sigma_max * max(M,N) * eps.
  * W_d [M,N] row-major of `dtype`; outputs as tramp_linear_create expects
  * (caller-allocated).  Computation is always carried out in f64. */
 int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_t N, const void* W_d,
                            void* Uk_d, void* Vt_d, double* sing_d, size_t* rank);
+/* The symmetric eigensolver of tramp_linear_factorize on its own (np.linalg.eigh on the Gram
+ * matrix): rocSOLVER syevd up to n = TRAMP_EIG_CAP (default 46336, its 32-bit limit), above that a
+ * spectral divide and conquer (matrix sign function by Cholesky-form weighted Halley iterations,
+ * rocBLAS level 3 only) halves the problem until the halves fit - this is what lets BASELINE
+ * configs[3] (k = 50000) be set up on the device.  A_d [n, n] symmetric f64 (upper triangle read),
+ * overwritten by the eigenvectors (A_d[i + j n] = component i of eigenvector j); w_d[n] ascending. */
+int tramp_eigh(tramp_ctx* ctx, size_t n, double* A_d, double* w_d);
 
 /* K9. LinearChannel.compute_n_eff / compute_forward_variance / compute_backward_variance
  *     tramp/channels/linear/linear_channel.py:58-67,91-105 (same scalars serve SE:
@@ -310,6 +320,32 @@ int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on);
  * the caller may claim the corresponding TRAMP_REUSE_* bit in the next tramp_linear_message. */
 int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, int which, size_t batch,
                                 const void* c_d, double damping, int c_changed);
+
+/* ---- multi-GPU: ensemble shard over ranks, RCCL over xGMI -------- */
+/* Replaces the sequential loop over problem instances of run_experiments
+ * (tramp/experiments/multiple_experiments.py:30-49): one process per GPU, instances dealt
+ * to the ranks, NO per-iteration collective.  librccl is loaded on first use.
+ *   tramp_comm_unique_id : rank 0 draws the id (ncclGetUniqueId); the host side carries the
+ *                          TRAMP_COMM_ID_BYTES to the other processes (any rendezvous)
+ *   tramp_comm_init      : ncclCommInitRank on the context's device (collective call)
+ *   tramp_bcast_matrix   : in-place ncclBroadcast of `bytes` from `root` on the context's
+ *                          stream - the shared sensing matrix W or its thin factors
+ *   tramp_gather_scalars : ncclAllGather of `count` doubles per rank (per-instance n_iter,
+ *                          v, mse at the end of a run); recv_d holds world*count
+ *   tramp_comm_max       : all-reduce MAX of one host double (elapsed time over ranks),
+ *                          synchronises the stream
+ *   tramp_comm_barrier   : every rank has finished its queued work */
+#define TRAMP_COMM_ID_BYTES 128
+typedef struct tramp_comm tramp_comm;
+int tramp_comm_unique_id(tramp_ctx* ctx, unsigned char* id_out);
+int tramp_comm_init(tramp_ctx* ctx, int rank, int world, const unsigned char* id, tramp_comm** comm);
+int tramp_comm_destroy(tramp_ctx* ctx, tramp_comm* comm);
+int tramp_comm_rank(const tramp_comm* comm, int* rank, int* world);
+int tramp_bcast_matrix(tramp_ctx* ctx, tramp_comm* comm, void* buf_d, size_t bytes, int root);
+int tramp_gather_scalars(tramp_ctx* ctx, tramp_comm* comm, const double* send_d, size_t count,
+                         double* recv_d);
+int tramp_comm_max(tramp_ctx* ctx, tramp_comm* comm, double* value);
+int tramp_comm_barrier(tramp_ctx* ctx, tramp_comm* comm);
 
 /* Building blocks of K8, exported for tests, profiling and the roofline bench:
  *   NT: out[b, r] = sum_c mat[r, c] * x[b, c]     mat [R, C] row-major

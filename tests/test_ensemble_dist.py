@@ -1,9 +1,13 @@
-"""Multi-GPU path on CPU: partition logic, and a world_size-2 gloo run of the setup
-broadcast / gather helpers that bench.py uses with RCCL."""
+"""Multi-GPU path on CPU: partition logic, the rendezvous, and a world_size-2 run of the ensemble
+path (broadcast of W, per-instance EP, gather) on the socket stub of the communicator API, compared
+instance by instance with the 1-rank run."""
+import json
 import os
 import subprocess
 import sys
+import threading
 
+import numpy as np
 import pytest
 
 from tramp_amd import ensemble
@@ -29,11 +33,56 @@ def test_instance_seeds_independent_of_partition():
     assert whole == parts and len(set(whole)) == 10
 
 
-def test_world_size_2_gloo():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29531",
-           os.path.join(ROOT, "tests", "_dist_worker.py")]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "DIST_OK 7 2" in p.stdout
+def test_rendezvous_exchange_threads():
+    "3 ranks in one process: all-gather of byte strings, broadcast, gather, max on the socket stub"
+    port = ensemble.free_port()
+    world, out, errs = 3, {}, []
+
+    def run(rank):
+        try:
+            comm = ensemble.SocketComm(ensemble.Rendezvous(rank, world, "127.0.0.1", port, timeout=60))
+            a = np.arange(6, dtype=np.float64).reshape(2, 3) * (rank == 1)
+            comm.broadcast(a, root=1)
+            g = comm.gather_scalars([rank, 10.0 * rank])
+            out[rank] = (a.copy(), g, comm.max(rank * 2.5), comm.rdv.exchange(bytes([rank]) * (rank + 1)))
+            comm.barrier()
+            comm.close()
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(90) for t in ts]
+    assert not errs, errs
+    for r in range(world):
+        a, g, m, parts = out[r]
+        assert np.array_equal(a, np.arange(6.0).reshape(2, 3))
+        assert np.array_equal(g, np.array([[0, 0], [1, 10], [2, 20]], dtype=np.float64))
+        assert m == 5.0
+        assert parts == [b"\x00", b"\x01\x01", b"\x02\x02\x02"]
+
+
+def _run_world(world):
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    procs = []
+    port = ensemble.free_port()
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py")], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-2000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("DIST_RESULT ")]
+    assert line, outs[0][0][-2000:]
+    return np.array(json.loads(line[0][len("DIST_RESULT "):]))
+
+
+def test_world_size_2_matches_single_rank():
+    """every instance's (n_iter, v, mse) from the 2-rank run equals the 1-rank run's, bit for bit"""
+    one = _run_world(1)
+    two = _run_world(2)
+    assert one.shape == two.shape == (5, 3)
+    assert np.array_equal(one, two), (one, two)
+    assert np.all(one[:, 0] > 3) and np.all(one[:, 2] < 0.5)

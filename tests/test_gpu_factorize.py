@@ -1,0 +1,168 @@
+"""GPU parity of the device setup path (tramp_linear_factorize / tramp_eigh) against the goldens
+captured from the reference's LinearChannel.__init__ (tramp/channels/linear/linear_channel.py:8-15,
+30-46: np.linalg.matrix_rank + full SVD) and against NumPy.
+
+Three eigensolver configurations are exercised on the same cases: rocSOLVER alone, one spectral
+divide-and-conquer split (TRAMP_EIG_CAP below the matrix size - the path BASELINE configs[3] takes at
+k = 50000), and a cap small enough to force recursion.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tramp_amd
+    return tramp_amd
+
+
+class eig_cap:
+    "TRAMP_EIG_CAP is read (getenv) by every tramp_linear_factorize / tramp_eigh call."
+
+    def __init__(self, cap):
+        self.cap = cap
+
+    def __enter__(self):
+        self.old = os.environ.get("TRAMP_EIG_CAP")
+        if self.cap is None:
+            os.environ.pop("TRAMP_EIG_CAP", None)
+        else:
+            os.environ["TRAMP_EIG_CAP"] = str(self.cap)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("TRAMP_EIG_CAP", None)
+        else:
+            os.environ["TRAMP_EIG_CAP"] = self.old
+
+
+def _W(case):
+    if "W" in case:
+        return case["W"]
+    rs = np.random.RandomState(case["seed"])
+    return rs.randn(case["M"], case["N"]) / np.sqrt(case["N"])
+
+
+def _eigh(T, ctx, G):
+    n = G.shape[0]
+    A = ctx.array(np.ascontiguousarray(G), np.float64)
+    w = ctx.empty((n,), np.float64)
+    ctx._call("tramp_eigh", n, A.ptr, w.ptr)
+    V = A.get().T                      # device result is column-major: row-major view is V^T
+    return w.get(), np.ascontiguousarray(V)
+
+
+@pytest.mark.parametrize("cap", [None, 24, 6])
+def test_device_factorization_golden(T, ctx, golden_linear, cap):
+    "spectrum, rank, vz(az=0) and the posteriors of the reference, with the factors computed on the device"
+    for case in golden_linear:
+        W = _W(case)
+        M, N = W.shape
+        k = min(M, N)
+        with eig_cap(cap):
+            ch = T.LinearChannel(W, ctx=ctx, svd="device")
+        assert ch.rank == int(case["rank"]), (M, N, cap)
+        ref = np.asarray(case["spectrum"])
+        np.testing.assert_allclose(ch.spectrum, ref, rtol=0, atol=1e-12 * ref.max())
+        # thin factors reproduce W and are orthonormal on the rank
+        Uk, s, Vt = ch._Uk.get(), ch._sing.get(), ch._Vt.get()
+        r = ch.rank
+        np.testing.assert_allclose((Uk[:, :r] * s[:r]) @ Vt[:r], W, rtol=0, atol=1e-12 * s[0])
+        np.testing.assert_allclose(Vt[:r] @ Vt[:r].T, np.eye(r), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(Uk[:, :r].T @ Uk[:, :r], np.eye(r), rtol=0, atol=1e-11)
+        bz, bx = case["bz"], case["bx"]
+        for c in case["cases"]:
+            az, ax = c["az"], c["ax"]
+            rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+            rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+            cancel = 4e-16 * np.abs(bz).max() / max(az, 1e-11) * N
+            np.testing.assert_allclose(rz, c["rz"], rtol=1e-9, atol=1e-9 * np.abs(c["rz"]).max())
+            np.testing.assert_allclose(rx, c["rx"], rtol=1e-9, atol=1e-9 * np.abs(c["rx"]).max() + 10 * cancel)
+            np.testing.assert_allclose(vx, c["vx"], rtol=1e-9)
+            np.testing.assert_allclose(vz, c["vz"], rtol=1e-9, atol=64 * 2.3e-16 / max(az, 1e-11))
+        if "vz_az0" in case:
+            v, _, _ = ch.device_variance(T._lib.BWD, 0.0, 0.7)
+            np.testing.assert_allclose(v, case["vz_az0"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,cap", [(257, 100), (700, 256), (1500, None)])
+def test_eigh_against_numpy(T, ctx, n, cap):
+    "tramp_eigh on a Marchenko-Pastur Gram matrix: eigenvalues, residual and orthogonality"
+    rs = np.random.RandomState(n)
+    Wm = rs.randn(n, 2 * n) / np.sqrt(2 * n)
+    G = Wm @ Wm.T
+    with eig_cap(cap):
+        w, V = _eigh(T, ctx, G)
+    wr = np.linalg.eigvalsh(G)
+    nG = wr.max()
+    assert np.all(np.diff(w) >= -1e-13 * nG)
+    np.testing.assert_allclose(w, wr, rtol=0, atol=1e-13 * nG)
+    assert np.abs(G @ V - V * w).max() < 1e-13 * nG
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+
+
+def test_eigh_split_point_on_an_eigenvalue(T, ctx):
+    """an eigenvalue 1e-12 away from the split point sigma = trace/n: the residual-certified bound has
+    to take over from the predicted one (factorize.hip, eigh_split)"""
+    n = 300
+    rs = np.random.RandomState(3)
+    Q, _ = np.linalg.qr(rs.randn(n, n))
+    lam = np.linspace(-1.0, 1.0, n)
+    lam[n // 2] = 1e-12
+    lam -= lam.mean() - 0.0                 # trace/n stays ~0: sigma sits (almost) on lam[n/2]
+    G = (Q * lam) @ Q.T
+    G = 0.5 * (G + G.T) + 2.0 * np.eye(n)
+    with eig_cap(200):
+        w, V = _eigh(T, ctx, G)
+    wr = np.linalg.eigvalsh(G)
+    np.testing.assert_allclose(w, wr, rtol=0, atol=1e-13 * wr.max())
+    assert np.abs(G @ V - V * w).max() < 1e-13 * wr.max()
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+
+
+@pytest.mark.parametrize("shape", [(60, 90), (90, 60)])
+@pytest.mark.parametrize("cap", [None, 32])
+def test_factorization_ill_conditioned(T, ctx, shape, cap):
+    """singular values over 12 decades: the Gram route alone stops at 1e-8 sigma_max, the second
+    level (Gram matrix of the trailing block's own rows) recovers them to LAPACK's absolute
+    accuracy, and the rank agrees with np.linalg.matrix_rank"""
+    M, N = shape
+    k = min(M, N)
+    rs = np.random.RandomState(11)
+    U, _ = np.linalg.qr(rs.randn(M, k))
+    V, _ = np.linalg.qr(rs.randn(N, k))
+    s = np.logspace(0, -12, k)
+    s[-3:] = 0.0                                            # and an exact null space
+    W = (U * s) @ V.T
+    with eig_cap(cap):
+        ch = T.LinearChannel(W, ctx=ctx, svd="device")
+    s_ref = np.linalg.svd(W, compute_uv=False)
+    assert ch.rank == np.linalg.matrix_rank(W)
+    np.testing.assert_allclose(ch._sing.get(), s_ref, rtol=0, atol=2e-13)
+    # the resolvent the messages use, against the oracle on LAPACK's factors
+    lin = orc.LinearOracle(W)
+    bz, bx = rs.standard_normal(N), rs.standard_normal(M)
+    for az, ax in ((1.3, 0.7), (1e-3, 10.0), (5.0, 1e4)):
+        rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+        rz_ref, vz_ref = lin.backward_mean(az, bz, ax, bx), lin.backward_variance(az, ax)
+        np.testing.assert_allclose(rz, rz_ref, rtol=1e-7, atol=1e-8 * np.abs(rz_ref).max())
+        np.testing.assert_allclose(vz, vz_ref, rtol=1e-8)
+
+
+def test_factorization_f32_inputs(T, ctx):
+    rs = np.random.RandomState(5)
+    W = (rs.randn(64, 160) / np.sqrt(160)).astype(np.float32)
+    with eig_cap(40):
+        ch = T.LinearChannel(W, dtype=np.float32, ctx=ctx, svd="device")
+    s_ref = np.linalg.svd(W.astype(np.float64), compute_uv=False)
+    np.testing.assert_allclose(ch._sing.get(), s_ref, rtol=1e-6)
+    assert ch.rank == 64
+    Vt = ch._Vt.get().astype(np.float64)
+    np.testing.assert_allclose(Vt @ Vt.T, np.eye(64), atol=5e-6)

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "tramp_linear_create": [vp, i32, sz, sz, sz, vp, vp, vp, C.POINTER(vp)],
     "tramp_linear_destroy": [vp, vp],
     "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],
+    "tramp_eigh": [vp, sz, vp, vp],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_conv_create": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],
@@ -117,6 +118,14 @@ _SIGNATURES = {
     "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
     "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],
     "tramp_randn": [vp, i32, vp, sz, u64, dbl],
+    "tramp_comm_unique_id": [vp, vp],
+    "tramp_comm_init": [vp, i32, i32, vp, C.POINTER(vp)],
+    "tramp_comm_destroy": [vp, vp],
+    "tramp_comm_rank": [vp, C.POINTER(i32), C.POINTER(i32)],
+    "tramp_bcast_matrix": [vp, vp, vp, sz, i32],
+    "tramp_gather_scalars": [vp, vp, vp, sz, vp],
+    "tramp_comm_max": [vp, vp, C.POINTER(dbl)],
+    "tramp_comm_barrier": [vp, vp],
     "tramp_graph_begin": [vp],
     "tramp_graph_end": [vp, C.POINTER(vp)],
     "tramp_graph_launch": [vp, vp],

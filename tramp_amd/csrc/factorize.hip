@@ -4,65 +4,660 @@
 // np.linalg.svd, tramp/channels/linear/linear_channel.py:8-15,37-41) by a Gram-matrix
 // eigendecomposition on the smaller side - library calls are fine here, this is
 // one-time setup, not the per-iteration path:
-//     M <= N:  G = W W^T (rocBLAS syrk)  -> eigh (rocSOLVER syevd) -> U, sigma^2
-//              Vt = Sigma^-1 U^T W (rocBLAS gemm)
-//     M >  N:  G = W^T W -> eigh -> V, sigma^2;  Uk = W V Sigma^-1
+//     M <= N:  G = W W^T  -> eigh -> U, sigma^2;  Vt = Sigma^-1 U^T W
+//     M >  N:  G = W^T W  -> eigh -> V, sigma^2;  Uk = W V Sigma^-1
 // Only Uk, Vt and sigma leave; W itself is not needed by the message kernels.
-// The Gram form squares the condition number: singular values below
-// sqrt(eps)*sigma_max are treated as zero (rank).  Ill-conditioned matrices should use
-// the host LAPACK path (tramp_amd.channels.thin_svd_host).
+//
+// eigh.  rocSOLVER 7.2's syevd indexes the k x k matrix with 32-bit ints and faults for
+// k > 46340 (BASELINE configs[3]: k = 50000).  Above that cap (TRAMP_EIG_CAP, default 46336)
+// the symmetric eigenproblem is halved by a spectral divide and conquer built from
+// rocBLAS level-3 calls and small Cholesky factorisations only:
+//     sigma = trace(G)/k;  S = sign(G - sigma I) by the dynamically weighted Halley iteration
+//     in its Cholesky form  X <- (b/c) X + (a - b/c) X (I + c X^2)^-1   (syrk, potrf, 2 trsm);
+//     the weights (a, b, c) are the optimal ones for the lower bound l = sqrt(1 - |X^2 - I|_F)
+//     that the residual itself certifies, floored at l = 1e-3 so that c <= 1.6e4 and the
+//     Cholesky solve stays accurate (tools/proto_eig_dc.py: backward error 1e-15);
+//     P = (I + S)/2 is the spectral projector above sigma, r = trace(P);
+//     V1 = CholeskyQR2(P[:, :r]), V2 = CholeskyQR2((I - P)[:, r:])  (their Gram matrices are
+//     sub-blocks of P itself because P^2 = P);
+//     V1^T G V1 and V2^T G V2 (r and k - r wide) go to the library eigensolver - or recurse -
+//     and the eigenvectors are rotated back with one gemm each.
+// Every library call sees a sub-block whose (columns x leading dimension) stays below 2^31,
+// so nothing depends on 64-bit entry points.
+//
+// Conditioning.  The Gram form resolves singular values only down to ~1e-8 sigma_max.  The rows
+// of U^T W that belong to eigenvalues below 1e-10 lambda_max are therefore factorised a second
+// time from their own (small) Gram matrix, whose entries are formed without cancellation; the rank
+// then uses NumPy's tolerance sigma_max * max(M,N) * eps (np.linalg.matrix_rank, linear_channel.py:37).
 // All arithmetic in f64; f32 inputs/outputs are converted at the boundary.
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <math.h>
+#include <stdlib.h>
+
+#include <vector>
+
 #include "common.h"
 
-#define RB_CHECK(ctx, call)                                                              \
-    do {                                                                                 \
-        rocblas_status s_ = (call);                                                      \
-        if (s_ != rocblas_status_success)                                                \
-            return tramp_fail(ctx, TRAMP_EHIP, #call, rocblas_status_to_string(s_));     \
-    } while (0)
+namespace {
+
+constexpr double kEps = 2.220446049250313e-16;
+
+// ------------------------------------------------------------------ small kernels
+// NOTE: gridDim.x * blockDim.x wraps at 2^32 in HIP, and k*N = 5e9 at BASELINE configs[3]: every
+// elementwise kernel here is a grid-stride loop over a fixed grid (kRedBlocks blocks).
+#define GRID_STRIDE(idx, total) \
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * kBlock)
 
 // Uk[i, j] = Q[i + (n-1-j) n]   (eigenvector columns, descending eigenvalue order), M <= N case
 __global__ void eigvec_to_uk(const double* __restrict__ Q, size_t n, double* __restrict__ Uk) {
-    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= n * n) return;
-    size_t i = idx / n, j = idx % n;
-    Uk[idx] = Q[i + (n - 1 - j) * n];
+    GRID_STRIDE(idx, n * n) {
+        size_t i = idx / n, j = idx % n;
+        Uk[idx] = Q[i + (n - 1 - j) * n];
+    }
 }
 
 // Vt[j, c] = Q[c + (n-1-j) n]   (row reversal), M > N case
 __global__ void eigvec_to_vt(const double* __restrict__ Q, size_t n, double* __restrict__ Vt) {
-    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= n * n) return;
-    size_t j = idx / n, c = idx % n;
-    Vt[idx] = Q[c + (n - 1 - j) * n];
+    GRID_STRIDE(idx, n * n) {
+        size_t j = idx / n, c = idx % n;
+        Vt[idx] = Q[c + (n - 1 - j) * n];
+    }
 }
 
 __global__ void eig_to_sing(const double* __restrict__ D, size_t n, double* __restrict__ sing) {
-    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j < n) sing[j] = sqrt(fmax(D[n - 1 - j], 0.0));
+    GRID_STRIDE(j, n) sing[j] = sqrt(fmax(D[n - 1 - j], 0.0));
 }
 
-// rows of A [rows, cols] scaled by 1/sing[row] (0 below tol)
+// rows of A [rows, cols] (row-major) scaled by 1/sing[row] (0 at or below tol)
 __global__ void scale_rows_inv(double* __restrict__ A, size_t rows, size_t cols, const double* __restrict__ sing,
                                double tol) {
-    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= rows * cols) return;
-    double s = sing[idx / cols];
-    A[idx] *= (s > tol) ? 1.0 / s : 0.0;
+    GRID_STRIDE(idx, rows * cols) {
+        double s = sing[idx / cols];
+        A[idx] *= (s > tol) ? 1.0 / s : 0.0;
+    }
 }
 
 __global__ void scale_cols_inv(double* __restrict__ A, size_t rows, size_t cols, const double* __restrict__ sing,
                                double tol) {
-    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= rows * cols) return;
-    double s = sing[idx % cols];
-    A[idx] *= (s > tol) ? 1.0 / s : 0.0;
+    GRID_STRIDE(idx, rows * cols) {
+        double s = sing[idx % cols];
+        A[idx] *= (s > tol) ? 1.0 / s : 0.0;
+    }
 }
 
-static inline unsigned nblk(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+// X <- s X + d I   (column-major n x n, ld = n)
+__global__ void scale_add_identity(double* __restrict__ X, size_t n, double s, double d) {
+    const size_t total = n * n;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        double v = s * X[idx];
+        if (idx / n == idx % n) v += d;
+        X[idx] = v;
+    }
+}
+
+// X <- p X + q Y
+__global__ void axpby_inplace(double* __restrict__ X, const double* __restrict__ Y, size_t total, double p, double q) {
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock)
+        X[idx] = p * X[idx] + q * Y[idx];
+}
+
+__global__ void get_diag(const double* __restrict__ X, size_t n, double* __restrict__ d) {
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < n) d[j] = X[j + j * n];
+}
+
+// per-block partial sums of X[idx]^2 (fixed grid -> fixed summation order)
+__global__ void sumsq_partials(const double* __restrict__ X, size_t total, double* __restrict__ part) {
+    __shared__ double sm[kBlock / kWave];
+    double s = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock)
+        s += X[idx] * X[idx];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// |Z - I|_F^2 from the upper triangle of the symmetric Z (column-major; lower triangle not read)
+__global__ void resid_upper_partials(const double* __restrict__ Z, size_t n, double* __restrict__ part) {
+    __shared__ double sm[kBlock / kWave];
+    const size_t total = n * n;
+    double s = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t i = idx % n, j = idx / n;
+        if (i > j) continue;
+        const double z = Z[idx];
+        s += (i == j) ? (z - 1.0) * (z - 1.0) : 2.0 * z * z;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// mode 0: lower <- upper^T (fill the symmetric matrix from its upper triangle)
+// mode 1: X <- (X + X^T)/2
+// one 32x32 tile pair (ti <= tj) per block, staged through LDS so both sides are coalesced
+__global__ void symmetrize_tiles(double* __restrict__ X, size_t n, int mode) {
+    const size_t ti = blockIdx.x, tj = blockIdx.y;
+    if (ti > tj) return;
+    __shared__ double A[32][33], B[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 256 threads: 32 x 8
+    // A = block (rows of ti, cols of tj); B = block (rows of tj, cols of ti)
+    for (int r = ty; r < 32; r += 8) {
+        const size_t ia = ti * 32 + tx, ja = tj * 32 + r;
+        A[r][tx] = (ia < n && ja < n) ? X[ia + ja * n] : 0.0;        // A[col][row]
+        const size_t ib = tj * 32 + tx, jb = ti * 32 + r;
+        B[r][tx] = (ib < n && jb < n) ? X[ib + jb * n] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        // element (row tx, col r) of A and its mirror (row r, col tx) of B
+        const size_t ia = ti * 32 + tx, ja = tj * 32 + r;
+        const size_t ib = tj * 32 + tx, jb = ti * 32 + r;
+        if (ti == tj) {
+            if (ia < n && ja < n) {
+                double v;
+                if (mode == 0) v = (ia <= ja) ? A[r][tx] : A[tx][r];
+                else v = 0.5 * (A[r][tx] + A[tx][r]);
+                X[ia + ja * n] = v;
+            }
+        } else {
+            if (mode == 0) {
+                if (ib < n && jb < n) X[ib + jb * n] = A[tx][r];      // B(row tx, col r) = A(row r, col tx)
+            } else {
+                if (ia < n && ja < n) X[ia + ja * n] = 0.5 * (A[r][tx] + B[tx][r]);
+                if (ib < n && jb < n) X[ib + jb * n] = 0.5 * (B[r][tx] + A[tx][r]);
+            }
+        }
+    }
+}
+
+// columns [0, r) <- (X + I)/2, columns [r, n) <- (I - X)/2 : the two spectral projectors side by side
+__global__ void sign_to_projectors(double* __restrict__ X, size_t n, size_t r) {
+    const size_t total = n * n;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t i = idx % n, j = idx / n;
+        const double id = (i == j) ? 0.5 : 0.0;
+        X[idx] = (j < r) ? id + 0.5 * X[idx] : id - 0.5 * X[idx];
+    }
+}
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+constexpr unsigned kRedBlocks = 4096;
+
+// ------------------------------------------------------------------ blocked level-3 layer
+struct Fz {
+    tramp_ctx* ctx;
+    rocblas_handle h;
+    rocblas_int* info_d;
+    double* part_d;              // kRedBlocks partial sums
+    size_t eig_cap;              // largest n handed to rocSOLVER's syevd
+    int rc;
+    std::vector<void*> owned;
+    int fail(int code, const char* what, const char* detail) {
+        rc = tramp_fail(ctx, code, what, detail);
+        return rc;
+    }
+    double* alloc(size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(double));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fail(TRAMP_ENOMEM, "factorize: hipMalloc", hipGetErrorString(e));
+            return nullptr;
+        }
+        owned.push_back(p);
+        return (double*)p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        for (size_t i = 0; i < owned.size(); ++i)
+            if (owned[i] == p) {
+                owned.erase(owned.begin() + i);
+                break;
+            }
+        (void)hipFree(p);
+    }
+    void release_all() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void* p : owned) (void)hipFree(p);
+        owned.clear();
+    }
+};
+
+#define FZ_RB(fz, call)                                                                             \
+    do {                                                                                            \
+        rocblas_status s_ = (call);                                                                 \
+        if (s_ != rocblas_status_success)                                                           \
+            return (fz).fail(s_ == rocblas_status_memory_error ? TRAMP_ENOMEM : TRAMP_EHIP, #call,  \
+                             rocblas_status_to_string(s_));                                         \
+    } while (0)
+#define FZ_HIP(fz, call)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return (fz).fail(e_ == hipErrorOutOfMemory ? TRAMP_ENOMEM : TRAMP_EHIP, #call,          \
+                             hipGetErrorString(e_));                                                \
+    } while (0)
+#define FZ_OK(expr)                    \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != TRAMP_OK) return rc_; \
+    } while (0)
+
+// tile edge such that (tile x leading dimension) stays below 2^31
+inline size_t tile_for(size_t ld) {
+    size_t t = ((size_t)1 << 31) / (ld ? ld : 1);
+    if (t > 16384) t = 16384;
+    if (t >= 512) t &= ~(size_t)255;
+    return t ? t : 1;
+}
+inline size_t min3(size_t a, size_t b, size_t c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); }
+
+// C (m x n) <- alpha op(A) op(B) + beta C, column-major, any size
+int bgemm(Fz& fz, rocblas_operation tA, rocblas_operation tB, size_t m, size_t n, size_t kk, double alpha,
+          const double* A, size_t lda, const double* B, size_t ldb, double beta, double* C, size_t ldc) {
+    if (!m || !n || !kk) return TRAMP_OK;
+    const size_t T = min3(tile_for(lda), tile_for(ldb), tile_for(ldc));
+    const double one = 1.0;
+    for (size_t j0 = 0; j0 < n; j0 += T) {
+        const size_t nj = n - j0 < T ? n - j0 : T;
+        for (size_t i0 = 0; i0 < m; i0 += T) {
+            const size_t mi = m - i0 < T ? m - i0 : T;
+            for (size_t p0 = 0; p0 < kk; p0 += T) {
+                const size_t kp = kk - p0 < T ? kk - p0 : T;
+                const double* Ap = tA == rocblas_operation_none ? A + i0 + p0 * lda : A + p0 + i0 * lda;
+                const double* Bp = tB == rocblas_operation_none ? B + p0 + j0 * ldb : B + j0 + p0 * ldb;
+                FZ_RB(fz, rocblas_dgemm(fz.h, tA, tB, (rocblas_int)mi, (rocblas_int)nj, (rocblas_int)kp, &alpha, Ap,
+                                        (rocblas_int)lda, Bp, (rocblas_int)ldb, p0 == 0 ? &beta : &one,
+                                        C + i0 + j0 * ldc, (rocblas_int)ldc));
+            }
+        }
+    }
+    return TRAMP_OK;
+}
+
+// upper triangle of C (n x n) <- alpha op(A) op(A)^T + beta C;  op(A) is n x kk
+// (trans none: A is n x kk;  trans transpose: A is kk x n and the product is A^T A)
+int bsyrk_upper(Fz& fz, rocblas_operation trans, size_t n, size_t kk, double alpha, const double* A, size_t lda,
+                double beta, double* C, size_t ldc) {
+    if (!n) return TRAMP_OK;
+    const size_t T = tile_for(lda) < tile_for(ldc) ? tile_for(lda) : tile_for(ldc);
+    const double one = 1.0;
+    const bool nt = trans == rocblas_operation_none;
+    for (size_t j0 = 0; j0 < n; j0 += T) {
+        const size_t nj = n - j0 < T ? n - j0 : T;
+        for (size_t i0 = 0; i0 <= j0; i0 += T) {
+            const size_t mi = n - i0 < T ? n - i0 : T;
+            for (size_t p0 = 0; p0 < kk; p0 += T) {
+                const size_t kp = kk - p0 < T ? kk - p0 : T;
+                const double* Ai = nt ? A + i0 + p0 * lda : A + p0 + i0 * lda;
+                const double* Aj = nt ? A + j0 + p0 * lda : A + p0 + j0 * lda;
+                const double* bp = p0 == 0 ? &beta : &one;
+                if (i0 == j0) {
+                    FZ_RB(fz, rocblas_dsyrk(fz.h, rocblas_fill_upper, trans, (rocblas_int)nj, (rocblas_int)kp, &alpha,
+                                            Aj, (rocblas_int)lda, bp, C + j0 + j0 * ldc, (rocblas_int)ldc));
+                } else {
+                    FZ_RB(fz, rocblas_dgemm(fz.h, nt ? rocblas_operation_none : rocblas_operation_transpose,
+                                            nt ? rocblas_operation_transpose : rocblas_operation_none,
+                                            (rocblas_int)mi, (rocblas_int)nj, (rocblas_int)kp, &alpha, Ai,
+                                            (rocblas_int)lda, Aj, (rocblas_int)lda, bp, C + i0 + j0 * ldc,
+                                            (rocblas_int)ldc));
+                }
+            }
+        }
+    }
+    return TRAMP_OK;
+}
+
+int check_info(Fz& fz, const char* what) {
+    rocblas_int info_h = 0;
+    FZ_HIP(fz, hipMemcpyAsync(&info_h, fz.info_d, sizeof(info_h), hipMemcpyDeviceToHost, fz.ctx->stream));
+    FZ_HIP(fz, hipStreamSynchronize(fz.ctx->stream));
+    if (info_h != 0) return fz.fail(TRAMP_EHIP, what, "factorisation failed (matrix not positive definite / no convergence)");
+    return TRAMP_OK;
+}
+
+constexpr size_t kCholBlock = 4096;
+
+// Z = U^T U (upper), blocked right-looking; only the upper triangle is read and written
+int bpotrf_upper(Fz& fz, double* Z, size_t n, size_t ld) {
+    const double one = 1.0;
+    const size_t T = tile_for(ld);
+    for (size_t j0 = 0; j0 < n; j0 += kCholBlock) {
+        const size_t jb = n - j0 < kCholBlock ? n - j0 : kCholBlock;
+        double* Ujj = Z + j0 + j0 * ld;
+        FZ_RB(fz, rocsolver_dpotrf(fz.h, rocblas_fill_upper, (rocblas_int)jb, Ujj, (rocblas_int)ld, fz.info_d));
+        FZ_OK(check_info(fz, "rocsolver_dpotrf"));
+        const size_t rest = n - j0 - jb;
+        if (!rest) break;
+        double* panel = Z + j0 + (j0 + jb) * ld;                   // jb x rest
+        for (size_t c0 = 0; c0 < rest; c0 += T) {
+            const size_t nc = rest - c0 < T ? rest - c0 : T;
+            FZ_RB(fz, rocblas_dtrsm(fz.h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose,
+                                    rocblas_diagonal_non_unit, (rocblas_int)jb, (rocblas_int)nc, &one, Ujj,
+                                    (rocblas_int)ld, panel + c0 * ld, (rocblas_int)ld));
+        }
+        FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, rest, jb, -1.0, panel, ld, 1.0,
+                          Z + (j0 + jb) + (j0 + jb) * ld, ld));
+    }
+    return TRAMP_OK;
+}
+
+// X (n x nrhs) <- (U^T U)^-1 X
+int bpotrs_upper(Fz& fz, const double* U, size_t n, size_t ldu, double* X, size_t nrhs, size_t ldx) {
+    const double one = 1.0;
+    const size_t T = tile_for(ldx);
+    // U^T T = X
+    for (size_t i0 = 0; i0 < n; i0 += kCholBlock) {
+        const size_t ib = n - i0 < kCholBlock ? n - i0 : kCholBlock;
+        for (size_t c0 = 0; c0 < nrhs; c0 += T) {
+            const size_t nc = nrhs - c0 < T ? nrhs - c0 : T;
+            FZ_RB(fz, rocblas_dtrsm(fz.h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose,
+                                    rocblas_diagonal_non_unit, (rocblas_int)ib, (rocblas_int)nc, &one,
+                                    U + i0 + i0 * ldu, (rocblas_int)ldu, X + i0 + c0 * ldx, (rocblas_int)ldx));
+        }
+        const size_t rest = n - i0 - ib;
+        if (rest)
+            FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, rest, nrhs, ib, -1.0,
+                        U + i0 + (i0 + ib) * ldu, ldu, X + i0, ldx, 1.0, X + i0 + ib, ldx));
+    }
+    // U Y = T
+    const size_t nblocks = (n + kCholBlock - 1) / kCholBlock;
+    for (size_t b = nblocks; b-- > 0;) {
+        const size_t i0 = b * kCholBlock;
+        const size_t ib = n - i0 < kCholBlock ? n - i0 : kCholBlock;
+        for (size_t c0 = 0; c0 < nrhs; c0 += T) {
+            const size_t nc = nrhs - c0 < T ? nrhs - c0 : T;
+            FZ_RB(fz, rocblas_dtrsm(fz.h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
+                                    rocblas_diagonal_non_unit, (rocblas_int)ib, (rocblas_int)nc, &one,
+                                    U + i0 + i0 * ldu, (rocblas_int)ldu, X + i0 + c0 * ldx, (rocblas_int)ldx));
+        }
+        if (i0)
+            FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, i0, nrhs, ib, -1.0, U + i0 * ldu, ldu,
+                        X + i0, ldx, 1.0, X, ldx));
+    }
+    return TRAMP_OK;
+}
+
+// X (m x n) <- X U^-1, U upper n x n
+int btrsm_right_upper(Fz& fz, const double* U, size_t n, size_t ldu, double* X, size_t m, size_t ldx) {
+    const double one = 1.0;
+    for (size_t j0 = 0; j0 < n; j0 += kCholBlock) {
+        const size_t jb = n - j0 < kCholBlock ? n - j0 : kCholBlock;
+        if (j0)
+            FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, m, jb, j0, -1.0, X, ldx, U + j0 * ldu, ldu,
+                        1.0, X + j0 * ldx, ldx));
+        FZ_RB(fz, rocblas_dtrsm(fz.h, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
+                                rocblas_diagonal_non_unit, (rocblas_int)m, (rocblas_int)jb, &one, U + j0 + j0 * ldu,
+                                (rocblas_int)ldu, X + j0 * ldx, (rocblas_int)ldx));
+    }
+    return TRAMP_OK;
+}
+
+int reduce_partials(Fz& fz, double* out) {
+    static thread_local double host[kRedBlocks];
+    FZ_HIP(fz, hipMemcpyAsync(host, fz.part_d, sizeof(host), hipMemcpyDeviceToHost, fz.ctx->stream));
+    FZ_HIP(fz, hipStreamSynchronize(fz.ctx->stream));
+    double s = 0.0;
+    for (unsigned i = 0; i < kRedBlocks; ++i) s += host[i];
+    *out = s;
+    return TRAMP_OK;
+}
+
+// dynamically weighted Halley weights for the lower bound l (Nakatsukasa, Bai, Gygi 2010)
+void halley_weights(double l, double* a, double* b, double* c) {
+    const double l2 = l * l;
+    const double dd = cbrt(4.0 * (1.0 / l2 - 1.0) / l2);
+    const double sqd = sqrt(1.0 + dd);
+    *a = sqd + sqrt(2.0 - dd + 2.0 * (2.0 - l2) / (l2 * sqd));
+    *b = (*a - 1.0) * (*a - 1.0) / 4.0;
+    *c = *a + *b - 1.0;
+}
+
+// orthonormal basis of the columns Y (m x r, ld) by two Cholesky-QR passes.  gram0: an r x r matrix
+// holding Y^T Y in its upper triangle if the caller has it for free (consumed), else nullptr.
+int cholqr2(Fz& fz, double* Y, size_t m, size_t r, size_t ld, double* gram /* r x r scratch, ld = r */, bool have_gram) {
+    if (!r) return TRAMP_OK;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass || !have_gram) FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, r, m, 1.0, Y, ld, 0.0, gram, r));
+        FZ_OK(bpotrf_upper(fz, gram, r, r));
+        FZ_OK(btrsm_right_upper(fz, gram, r, r, Y, m, ld));
+    }
+    return TRAMP_OK;
+}
+
+int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth);
+
+// one spectral split of the symmetric A (n x n, full storage, ld = n); eigenvectors overwrite A,
+// ascending eigenvalues go to w_d[n]
+int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
+    hipStream_t st = fz.ctx->stream;
+    const size_t nn = n * n;
+    double* X = fz.alloc(nn);
+    double* Y = fz.alloc(nn);
+    double* Z = fz.alloc(nn);
+    double* dg = fz.alloc(n);
+    if (!X || !Y || !Z || !dg) return fz.rc;
+    std::vector<double> hd(n);
+    // sigma = mean eigenvalue
+    hipLaunchKernelGGL(get_diag, dim3(nblk(n)), dim3(kBlock), 0, st, A, n, dg);
+    FZ_HIP(fz, hipMemcpyAsync(hd.data(), dg, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    double sigma = 0.0;
+    for (size_t i = 0; i < n; ++i) sigma += hd[i];
+    sigma /= (double)n;
+    FZ_HIP(fz, hipMemcpyAsync(X, A, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(scale_add_identity, dim3(kRedBlocks), dim3(kBlock), 0, st, X, n, 1.0, -sigma);
+    hipLaunchKernelGGL(sumsq_partials, dim3(kRedBlocks), dim3(kBlock), 0, st, X, nn, fz.part_d);
+    double fro2 = 0.0;
+    FZ_OK(reduce_partials(fz, &fro2));
+    if (!isfinite(fro2)) return fz.fail(TRAMP_EINVAL, "factorize", "matrix is not finite");
+    if (!(fro2 > 0.0)) {
+        // A = sigma I exactly: any orthonormal basis is an eigenbasis
+        hipLaunchKernelGGL(scale_add_identity, dim3(kRedBlocks), dim3(kBlock), 0, st, A, n, 0.0, 1.0);
+        for (size_t i = 0; i < n; ++i) hd[i] = sigma;
+        FZ_HIP(fz, hipMemcpyAsync(w_d, hd.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+        FZ_HIP(fz, hipStreamSynchronize(st));
+        fz.release(X);
+        fz.release(Y);
+        fz.release(Z);
+        fz.release(dg);
+        return TRAMP_OK;
+    }
+    hipLaunchKernelGGL(scale_add_identity, dim3(kRedBlocks), dim3(kBlock), 0, st, X, n, 1.0 / sqrt(fro2), 0.0);
+
+    // weights: follow the predicted lower bound l_pred of the smallest |eigenvalue| of X (floored at
+    // l_floor: c <= 1.6e4 keeps the Cholesky solve accurate); when the prediction says "converged"
+    // but the residual e = |X^2 - I|_F does not - an eigenvalue closer to sigma than l0 assumed -
+    // the bound the residual certifies, sqrt(1 - e), takes over (tools/proto_eig_dc.py)
+    const double l_floor = 1e-3;
+    double l_pred = 1e-8;
+    const double tol = 1e-13 * (double)n + 1e-12;
+    bool converged = false;
+    for (int it = 0; it < 60; ++it) {
+        // Z0 = X X^T (upper), e = |Z0 - I|_F
+        FZ_OK(bsyrk_upper(fz, rocblas_operation_none, n, n, 1.0, X, n, 0.0, Z, n));
+        hipLaunchKernelGGL(resid_upper_partials, dim3(kRedBlocks), dim3(kBlock), 0, st, Z, n, fz.part_d);
+        double e2 = 0.0;
+        FZ_OK(reduce_partials(fz, &e2));
+        const double e = sqrt(e2);
+        if (getenv("TRAMP_EIG_VERBOSE")) fprintf(stderr, "[tramp eigh] n=%zu depth=%d it=%d resid=%.3e l_pred=%.3e\n", n, depth, it, e, l_pred);
+        if (!isfinite(e)) return fz.fail(TRAMP_EHIP, "factorize", "sign iteration produced non-finite values");
+        if (e < tol) {
+            converged = true;
+            break;
+        }
+        double l;
+        if (l_pred < 1.0 - 1e-8) l = l_pred;
+        else l = e < 1.0 ? sqrt(1.0 - e) : 0.0;
+        if (l < l_floor) l = l_floor;
+        if (l > 1.0 - 1e-12) l = 1.0 - 1e-12;
+        double a, b, c;
+        halley_weights(l, &a, &b, &c);
+        l_pred = l_pred * (a + b * l_pred * l_pred) / (1.0 + c * l_pred * l_pred);
+        if (l_pred > 1.0) l_pred = 1.0;
+        hipLaunchKernelGGL(scale_add_identity, dim3(kRedBlocks), dim3(kBlock), 0, st, Z, n, c, 1.0);
+        FZ_OK(bpotrf_upper(fz, Z, n, n));
+        FZ_HIP(fz, hipMemcpyAsync(Y, X, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+        FZ_OK(bpotrs_upper(fz, Z, n, n, Y, n, n));
+        hipLaunchKernelGGL(axpby_inplace, dim3(kRedBlocks), dim3(kBlock), 0, st, X, Y, nn, b / c, a - b / c);
+        const unsigned nt = (unsigned)((n + 31) / 32);
+        hipLaunchKernelGGL(symmetrize_tiles, dim3(nt, nt), dim3(kBlock), 0, st, X, n, 1);
+    }
+    if (!converged) return fz.fail(TRAMP_EHIP, "factorize", "matrix sign iteration did not converge");
+
+    // rank of the upper projector
+    hipLaunchKernelGGL(get_diag, dim3(nblk(n)), dim3(kBlock), 0, st, X, n, dg);
+    FZ_HIP(fz, hipMemcpyAsync(hd.data(), dg, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    double tr = 0.0;
+    for (size_t i = 0; i < n; ++i) tr += hd[i];
+    const long long rr = llround(0.5 * ((double)n + tr));
+    if (rr <= 0 || rr >= (long long)n)
+        return fz.fail(TRAMP_ENOTSUP, "factorize", "spectral split left one side empty");
+    const size_t r = (size_t)rr, q = n - r;
+    hipLaunchKernelGGL(sign_to_projectors, dim3(kRedBlocks), dim3(kBlock), 0, st, X, n, r);
+    // X = [ P[:, :r] | (I-P)[:, r:] ]  ->  [ V1 | V2 ];  the first Gram matrices are blocks of X itself
+    double* V1 = X;
+    double* V2 = X + r * n;
+    FZ_HIP(fz, hipMemcpy2DAsync(Z, r * sizeof(double), X, n * sizeof(double), r * sizeof(double), r,
+                                hipMemcpyDeviceToDevice, st));
+    FZ_OK(cholqr2(fz, V1, n, r, n, Z, true));
+    FZ_HIP(fz, hipMemcpy2DAsync(Z, q * sizeof(double), X + r + r * n, n * sizeof(double), q * sizeof(double), q,
+                                hipMemcpyDeviceToDevice, st));
+    FZ_OK(cholqr2(fz, V2, n, q, n, Z, true));
+    // B1 = V1^T A V1 (r x r), B2 = V2^T A V2 (q x q), both in Z
+    double* B1 = Z;
+    double* B2 = Z + r * r;
+    FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, r, n, 1.0, A, n, V1, n, 0.0, Y, n));
+    FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, r, r, n, 1.0, V1, n, Y, n, 0.0, B1, r));
+    FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, q, n, 1.0, A, n, V2, n, 0.0, Y, n));
+    FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, q, q, n, 1.0, V2, n, Y, n, 0.0, B2, q));
+    fz.release(Y);
+    // below sigma first (ascending order)
+    FZ_OK(eigh_rec(fz, B2, q, w_d, depth + 1));
+    FZ_OK(eigh_rec(fz, B1, r, w_d + q, depth + 1));
+    FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, q, q, 1.0, V2, n, B2, q, 0.0, A, n));
+    FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, r, r, 1.0, V1, n, B1, r, 0.0, A + q * n, n));
+    fz.release(X);
+    fz.release(Z);
+    fz.release(dg);
+    return TRAMP_OK;
+}
+
+// symmetric eigendecomposition: A (n x n column-major, upper triangle valid) -> eigenvectors in A,
+// ascending eigenvalues in w_d
+int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth) {
+    if (n <= fz.eig_cap) {
+        double* E = fz.alloc(n);
+        if (!E) return fz.rc;
+        FZ_RB(fz, rocsolver_dsyevd(fz.h, rocblas_evect_original, rocblas_fill_upper, (rocblas_int)n, A,
+                                   (rocblas_int)n, w_d, E, fz.info_d));
+        FZ_OK(check_info(fz, "rocsolver_dsyevd"));
+        fz.release(E);
+        return TRAMP_OK;
+    }
+    if (depth > 8) return fz.fail(TRAMP_ENOTSUP, "factorize", "spectral divide and conquer recursed too deep");
+    const unsigned nt = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(symmetrize_tiles, dim3(nt, nt), dim3(kBlock), 0, fz.ctx->stream, A, n, 0);
+    return eigh_split(fz, A, n, w_d, depth);
+}
+
+size_t eig_cap_from_env() {
+    size_t cap = 46336;
+    if (const char* s = getenv("TRAMP_EIG_CAP")) {
+        long v = atol(s);
+        if (v >= 2 && v <= 46336) cap = (size_t)v;
+    }
+    return cap;
+}
+
+int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, double* V64, double* sing_d,
+                  size_t* rank_out) {
+    tramp_ctx* ctx = fz.ctx;
+    hipStream_t st = ctx->stream;
+    const size_t k = M < N ? M : N, big = M > N ? M : N;
+    double* G = fz.alloc(k * k);
+    double* D = fz.alloc(k);
+    if (!G || !D) return fz.rc;
+    // row-major W [M,N] is the column-major matrix A = W^T [N,M], lda = N
+    if (M <= N)
+        FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, M, N, 1.0, W64, N, 0.0, G, M));   // A^T A = W W^T
+    else
+        FZ_OK(bsyrk_upper(fz, rocblas_operation_none, N, M, 1.0, W64, N, 0.0, G, N));        // A A^T = W^T W
+    FZ_OK(eigh_rec(fz, G, k, D, 0));
+    hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D, k, sing_d);
+    // the thin factor on the long side, rows/columns still carrying their singular value
+    if (M <= N) {
+        hipLaunchKernelGGL(eigvec_to_uk, dim3(kRedBlocks), dim3(kBlock), 0, st, G, k, U64);
+        // Vt_cm [N,k] = A [N,M] * Y^T, Y_cm [k,M] = Uk memory (ldb = k)
+        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_transpose, N, k, M, 1.0, W64, N, U64, k, 0.0, V64, N));
+    } else {
+        hipLaunchKernelGGL(eigvec_to_vt, dim3(kRedBlocks), dim3(kBlock), 0, st, G, k, V64);
+        // Uk_cm^T: C_cm [k,M] = X^T [k,N] * A [N,M], X_cm [N,k] = Vt memory (lda = N)
+        FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, k, M, N, 1.0, V64, N, W64, N, 0.0, U64, k));
+    }
+    std::vector<double> sh(k);
+    FZ_HIP(fz, hipMemcpyAsync(sh.data(), sing_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    const double smax = sh[0];
+    // second level for the singular values the Gram form cannot resolve (below 1e-5 sigma_max):
+    // the c trailing singular directions are re-factorised from the Gram matrix of their own rows
+    size_t c = 0;
+    while (c < k && sh[k - 1 - c] <= 1e-5 * smax) ++c;
+    if (c > 0 && smax > 0.0) {
+        const size_t j0 = k - c;
+        double* G2 = fz.alloc(c * c);
+        double* D2 = fz.alloc(c);
+        double* Qd = fz.alloc(c * c);
+        double* Vo = fz.alloc(N * c);
+        double* Uo = fz.alloc(c * M);
+        if (!G2 || !D2 || !Qd || !Vo || !Uo) return fz.rc;
+        // column-major views: Vt memory = [N, k] (column j = right direction j), Uk memory = [k, M]
+        // (row j = left direction j).  The block's own Gram matrix comes from the LONG side.
+        double* Vc = V64 + j0 * N;                                               // N x c, ld N
+        double* Ur = U64 + j0;                                                   // c x M, ld k
+        if (M <= N)
+            FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, c, N, 1.0, Vc, N, 0.0, G2, c));
+        else
+            FZ_OK(bsyrk_upper(fz, rocblas_operation_none, c, M, 1.0, Ur, k, 0.0, G2, c));
+        FZ_OK(eigh_rec(fz, G2, c, D2, 0));
+        hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D2, c, sing_d + j0);
+        // Qd (row-major) = eigenvectors in descending order = Qrev; as column-major it is Qrev^T
+        hipLaunchKernelGGL(eigvec_to_uk, dim3(kRedBlocks), dim3(kBlock), 0, st, G2, c, Qd);
+        // right directions: Vc <- Vc Qrev;  left directions: Ur <- Qrev^T Ur
+        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_transpose, N, c, c, 1.0, Vc, N, Qd, c, 0.0, Vo, N));
+        FZ_HIP(fz, hipMemcpyAsync(Vc, Vo, N * c * sizeof(double), hipMemcpyDeviceToDevice, st));
+        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, c, M, c, 1.0, Qd, c, Ur, k, 0.0, Uo, c));
+        FZ_HIP(fz, hipMemcpy2DAsync(Ur, k * sizeof(double), Uo, c * sizeof(double), c * sizeof(double), M,
+                                    hipMemcpyDeviceToDevice, st));
+        fz.release(G2);
+        fz.release(D2);
+        fz.release(Qd);
+        fz.release(Vo);
+        fz.release(Uo);
+        FZ_HIP(fz, hipMemcpyAsync(sh.data(), sing_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
+        FZ_HIP(fz, hipStreamSynchronize(st));
+    }
+    // rank with NumPy's tolerance (np.linalg.matrix_rank), floored at what two Gram levels resolve
+    double tol = smax * (double)big * kEps;
+    const double floor_tol = smax * 64.0 * kEps * sqrt((double)k);
+    if (tol < floor_tol) tol = floor_tol;
+    size_t r = 0;
+    for (size_t j = 0; j < k; ++j) r += sh[j] > tol;
+    *rank_out = r;
+    if (M <= N)
+        hipLaunchKernelGGL(scale_rows_inv, dim3(kRedBlocks), dim3(kBlock), 0, st, V64, k, N, sing_d, tol);
+    else
+        hipLaunchKernelGGL(scale_cols_inv, dim3(kRedBlocks), dim3(kBlock), 0, st, U64, M, k, sing_d, tol);
+    FZ_HIP(fz, hipGetLastError());
+    fz.release(G);
+    fz.release(D);
+    return TRAMP_OK;
+}
+
+}  // namespace
 
 extern "C" int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_t N, const void* W_d, void* Uk_d,
                                       void* Vt_d, double* sing_d, size_t* rank_out) {
@@ -70,143 +665,72 @@ extern "C" int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_
     TRAMP_REQUIRE(ctx, W_d && Uk_d && Vt_d && sing_d && rank_out && M > 0 && N > 0);
     TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
     TRAMP_REQUIRE(ctx, M < (1u << 30) && N < (1u << 30));
-    const size_t k = M < N ? M : N;
-    // rocSOLVER 7.2 has no 64-bit syevd: its kernels index the k x k matrix with 32-bit ints
-    // (observed: GPU memory fault at k = 50000).  Refuse instead of faulting.
-    if (k * k >= (1ull << 31))
-        return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_linear_factorize",
-                          "min(M,N) > 46340 exceeds rocSOLVER's 32-bit indexing; factorise on the host "
-                          "or pass precomputed factors");
     TRAMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    rocblas_handle h = nullptr;
-    RB_CHECK(ctx, rocblas_create_handle(&h));
+    const size_t k = M < N ? M : N;
+    Fz fz{};
+    fz.ctx = ctx;
+    fz.rc = TRAMP_OK;
+    fz.eig_cap = eig_cap_from_env();
+    rocblas_status rs = rocblas_create_handle(&fz.h);
+    if (rs != rocblas_status_success) return tramp_fail(ctx, TRAMP_EHIP, "rocblas_create_handle", rocblas_status_to_string(rs));
     int rc = TRAMP_OK;
-    double *W64 = nullptr, *G = nullptr, *D = nullptr, *E = nullptr, *U64 = nullptr, *V64 = nullptr;
-    rocblas_int* info = nullptr;
-    const double one = 1.0, zero = 0.0;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(ctx->stream);
+    double *W64 = nullptr, *U64 = nullptr, *V64 = nullptr;
+    auto body = [&]() -> int {
+        FZ_RB(fz, rocblas_set_stream(fz.h, ctx->stream));
+        FZ_RB(fz, rocblas_set_pointer_mode(fz.h, rocblas_pointer_mode_host));
+        fz.info_d = (rocblas_int*)fz.alloc(1);
+        fz.part_d = fz.alloc(kRedBlocks);
+        if (!fz.info_d || !fz.part_d) return fz.rc;
         if (dtype == TRAMP_F32) {
-            if (W64) (void)hipFree(W64);
-            if (U64) (void)hipFree(U64);
-            if (V64) (void)hipFree(V64);
+            W64 = fz.alloc(M * N);
+            U64 = fz.alloc(M * k);
+            V64 = fz.alloc(k * N);
+            if (!W64 || !U64 || !V64) return fz.rc;
+            FZ_OK(tramp_convert(ctx, TRAMP_F64, W64, TRAMP_F32, W_d, M * N));
+        } else {
+            W64 = (double*)W_d;
+            U64 = (double*)Uk_d;
+            V64 = (double*)Vt_d;
         }
-        if (G) (void)hipFree(G);
-        if (D) (void)hipFree(D);
-        if (E) (void)hipFree(E);
-        if (info) (void)hipFree(info);
-        (void)rocblas_destroy_handle(h);
+        FZ_OK(factorize_f64(fz, M, N, W64, U64, V64, sing_d, rank_out));
+        if (dtype == TRAMP_F32) {
+            FZ_OK(tramp_convert(ctx, TRAMP_F32, Uk_d, TRAMP_F64, U64, M * k));
+            FZ_OK(tramp_convert(ctx, TRAMP_F32, Vt_d, TRAMP_F64, V64, k * N));
+        }
+        FZ_HIP(fz, hipStreamSynchronize(ctx->stream));
+        return TRAMP_OK;
     };
-#define F_CHECK(expr)                      \
-    do {                                   \
-        rc = (expr);                       \
-        if (rc != TRAMP_OK) {              \
-            cleanup();                     \
-            return rc;                     \
-        }                                  \
-    } while (0)
-#define F_HIP(call)                                                                   \
-    do {                                                                              \
-        hipError_t e_ = (call);                                                       \
-        if (e_ != hipSuccess) {                                                       \
-            cleanup();                                                                \
-            return tramp_fail(ctx, e_ == hipErrorOutOfMemory ? TRAMP_ENOMEM : TRAMP_EHIP, #call, hipGetErrorString(e_)); \
-        }                                                                             \
-    } while (0)
-#define F_RB(call)                                                                    \
-    do {                                                                              \
-        rocblas_status s_ = (call);                                                   \
-        if (s_ != rocblas_status_success) {                                           \
-            cleanup();                                                                \
-            return tramp_fail(ctx, s_ == rocblas_status_memory_error ? TRAMP_ENOMEM : TRAMP_EHIP, #call, rocblas_status_to_string(s_)); \
-        }                                                                             \
-    } while (0)
+    rc = body();
+    fz.release_all();
+    (void)rocblas_destroy_handle(fz.h);
+    return rc;
+}
 
-    F_RB(rocblas_set_stream(h, ctx->stream));
-    F_RB(rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
-    if (dtype == TRAMP_F32) {
-        F_HIP(hipMalloc((void**)&W64, M * N * sizeof(double)));
-        F_HIP(hipMalloc((void**)&U64, M * k * sizeof(double)));
-        F_HIP(hipMalloc((void**)&V64, k * N * sizeof(double)));
-        F_CHECK(tramp_convert(ctx, TRAMP_F64, W64, TRAMP_F32, W_d, M * N));
-    } else {
-        W64 = (double*)W_d;
-        U64 = (double*)Uk_d;
-        V64 = (double*)Vt_d;
-    }
-    F_HIP(hipMalloc((void**)&G, k * k * sizeof(double)));
-    F_HIP(hipMalloc((void**)&D, k * sizeof(double)));
-    F_HIP(hipMalloc((void**)&E, k * sizeof(double)));
-    F_HIP(hipMalloc((void**)&info, sizeof(rocblas_int)));
-    // row-major W [M,N] is the column-major matrix A = W^T [N,M], lda = N
-    if (M <= N) {
-        // G = A^T A = W W^T  (upper triangle)
-        F_RB(rocblas_dsyrk(h, rocblas_fill_upper, rocblas_operation_transpose, (rocblas_int)M, (rocblas_int)N, &one,
-                           W64, (rocblas_int)N, &zero, G, (rocblas_int)M));
-    } else {
-        // G = A A^T = W^T W
-        F_RB(rocblas_dsyrk(h, rocblas_fill_upper, rocblas_operation_none, (rocblas_int)N, (rocblas_int)M, &one, W64,
-                           (rocblas_int)N, &zero, G, (rocblas_int)N));
-    }
-    F_RB(rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_upper, (rocblas_int)k, G, (rocblas_int)k, D, E,
-                          info));
-    rocblas_int info_h = 0;
-    F_HIP(hipMemcpyAsync(&info_h, info, sizeof(info_h), hipMemcpyDeviceToHost, ctx->stream));
-    F_HIP(hipStreamSynchronize(ctx->stream));
-    if (info_h != 0) {
-        cleanup();
-        return tramp_fail(ctx, TRAMP_EHIP, "rocsolver_dsyevd", "eigensolver did not converge");
-    }
-    hipLaunchKernelGGL(eig_to_sing, dim3(nblk(k)), dim3(kBlock), 0, ctx->stream, D, k, sing_d);
-    // rank tolerance of the Gram route: sqrt(eps * max(M,N)) * sigma_max
-    double smax = 0.0;
-    F_HIP(hipMemcpyAsync(&smax, sing_d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    F_HIP(hipStreamSynchronize(ctx->stream));
-    const double tol = smax * sqrt(2.220446049250313e-16 * (double)(M > N ? M : N));
-    if (M <= N) {
-        hipLaunchKernelGGL(eigvec_to_uk, dim3(nblk(k * k)), dim3(kBlock), 0, ctx->stream, G, k, U64);
-        // Vt_cm [N,k] = A [N,M] * Y^T, Y_cm [k,M] = Uk memory (ldb = k)
-        F_RB(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)N, (rocblas_int)k,
-                           (rocblas_int)M, &one, W64, (rocblas_int)N, U64, (rocblas_int)k, &zero, V64,
-                           (rocblas_int)N));
-        hipLaunchKernelGGL(scale_rows_inv, dim3(nblk(k * N)), dim3(kBlock), 0, ctx->stream, V64, k, N, sing_d, tol);
-    } else {
-        hipLaunchKernelGGL(eigvec_to_vt, dim3(nblk(k * k)), dim3(kBlock), 0, ctx->stream, G, k, V64);
-        // Uk_cm^T: C_cm [k,M] = X^T [k,N] * A [N,M], X_cm [N,k] = Vt memory (lda = N)
-        F_RB(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)k, (rocblas_int)M,
-                           (rocblas_int)N, &one, V64, (rocblas_int)N, W64, (rocblas_int)N, &zero, U64,
-                           (rocblas_int)k));
-        hipLaunchKernelGGL(scale_cols_inv, dim3(nblk(M * k)), dim3(kBlock), 0, ctx->stream, U64, M, k, sing_d, tol);
-    }
-    // rank = #{sing > tol}
-    {
-        double* sh = (double*)malloc(k * sizeof(double));
-        if (!sh) {
-            cleanup();
-            return TRAMP_ENOMEM;
-        }
-        hipError_t e = hipMemcpyAsync(sh, sing_d, k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        size_t r = 0;
-        for (size_t j = 0; j < k; ++j) r += sh[j] > tol;
-        free(sh);
-        if (e != hipSuccess) {
-            cleanup();
-            return tramp_fail(ctx, TRAMP_EHIP, "rank readback", hipGetErrorString(e));
-        }
-        *rank_out = r;
-    }
-    if (dtype == TRAMP_F32) {
-        F_CHECK(tramp_convert(ctx, TRAMP_F32, Uk_d, TRAMP_F64, U64, M * k));
-        F_CHECK(tramp_convert(ctx, TRAMP_F32, Vt_d, TRAMP_F64, V64, k * N));
-    }
-    {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) {
-            cleanup();
-            return tramp_fail(ctx, TRAMP_EHIP, "factorize kernels", hipGetErrorString(e));
-        }
-    }
-    cleanup();
-    return TRAMP_OK;
+/* Symmetric eigendecomposition on the device (the eigensolver of tramp_linear_factorize on its own):
+ * A_d [n, n] symmetric (either storage order), overwritten by the eigenvectors as COLUMNS of the
+ * column-major matrix (A_d[i + j n] = component i of eigenvector j); w_d[n] ascending eigenvalues. */
+extern "C" int tramp_eigh(tramp_ctx* ctx, size_t n, double* A_d, double* w_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, A_d && w_d && n > 0 && n < (1u << 30));
+    TRAMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Fz fz{};
+    fz.ctx = ctx;
+    fz.rc = TRAMP_OK;
+    fz.eig_cap = eig_cap_from_env();
+    rocblas_status rs = rocblas_create_handle(&fz.h);
+    if (rs != rocblas_status_success) return tramp_fail(ctx, TRAMP_EHIP, "rocblas_create_handle", rocblas_status_to_string(rs));
+    auto body = [&]() -> int {
+        FZ_RB(fz, rocblas_set_stream(fz.h, ctx->stream));
+        FZ_RB(fz, rocblas_set_pointer_mode(fz.h, rocblas_pointer_mode_host));
+        fz.info_d = (rocblas_int*)fz.alloc(1);
+        fz.part_d = fz.alloc(kRedBlocks);
+        if (!fz.info_d || !fz.part_d) return fz.rc;
+        FZ_OK(eigh_rec(fz, A_d, n, w_d, 0));
+        FZ_HIP(fz, hipStreamSynchronize(ctx->stream));
+        return TRAMP_OK;
+    };
+    int rc = body();
+    fz.release_all();
+    (void)rocblas_destroy_handle(fz.h);
+    return rc;
 }
