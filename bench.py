@@ -126,33 +126,86 @@ def cpu_baseline(args):
     return out
 
 
+def _timed(ctx, fn, reps):
+    for _ in range(3):
+        fn()
+    e0, e1 = ctx.event(), ctx.event()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    return e0.elapsed_ms(e1) / reps
+
+
 def denoiser_roofline(T, ctx, dtype):
-    """Gauss-Bernoulli denoiser (K1) at the BASELINE vector size N = 1e6: single instance
-    (latency regime, data stays in cache) and a 64-instance ensemble (512 MB per array, past
-    the 256 MB Infinity Cache); plus 4096 instances of n = 4096, where an instance fits one
-    workgroup's registers and the update is a single pass.  Algorithmic traffic 2T bytes per component."""
+    """Gauss-Bernoulli denoiser (K1) at the BASELINE vector size N = 1e6.  Algorithmic traffic 2T bytes per
+    component (read the message, write the new one).
+      B64            64 instances (512 MB per array, past the 256 MB Infinity Cache), the form EP runs: the
+                     kernel that writes the prior's input message (here the convolution channel's inverse
+                     FFT, the N = 1e6 operator) also leaves sum v_i (csrc/prior_hint.h), the prior update is
+                     ONE streaming pass.  The time charged is that pass PLUS what the moments add to the
+                     producer (producer with hint - producer without).
+      B64_standalone the prior called on a message whose producer is unknown: moments pass + update pass
+                     (3T bytes moved for 2T algorithmic).
+      B1             one instance (latency regime, data stays in cache); B4096_n4096: an instance fits one
+                     workgroup's registers, single launch."""
     out = {}
     np_dt = np.float64 if dtype == "f64" else np.float32
+    esz = np.dtype(np_dt).itemsize
     for B, N in ((1, 1_000_000), (64, 1_000_000), (4096, 4096)):
         bx = ctx.randn((B, N), np_dt, seed=3, scale=1.5)
         ax = ctx.scalars(1.3, B)
         p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
         a_new = ctx.empty((B,), np.float64)
         b_new = ctx.empty((B, N), np_dt)
-        for _ in range(3):
-            p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)
-        reps = 50 if B == 1 else 10
-        e0, e1 = ctx.event(), ctx.event()
-        e0.record()
-        for _ in range(reps):
-            p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)
-        e1.record()
-        ms = e0.elapsed_ms(e1) / reps
-        alg = 2 * np.dtype(np_dt).itemsize * N * B
-        out[f"B{B}" if N == 1_000_000 else f"B{B}_n{N}"] = {"n": N, "batch": B, "us_per_update": ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
-                        "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
-                        "components_per_sec": N * B / (ms * 1e-3)}
+        ms = _timed(ctx, lambda: p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new), 50 if B == 1 else 10)
+        alg = 2 * esz * N * B
+        key = {1: "B1", 64: "B64_standalone", 4096: f"B{B}_n{N}"}[B]
+        out[key] = {"n": N, "batch": B, "us_per_update": ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
+                    "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS, "components_per_sec": N * B / (ms * 1e-3),
+                    "form": "moments pass + update pass (3T moved)" if B == 64 else
+                            ("single launch, instance in registers" if B == 4096 else "two launches, cache resident")}
         del bx, b_new
+    # the fused form, measured on the pair (producer, prior) that EP runs at N = 1e6
+    try:
+        B, N = 64, 1_000_000
+        rs = np.random.RandomState(3)
+        ch = T.ConvChannel(rs.randn(N) / np.sqrt(N), dtype=np_dt, ctx=ctx)
+        p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
+        az, ax = ctx.scalars(1.3, B), ctx.scalars(0.9, B)
+        bz = ctx.randn((B, N), np_dt, seed=4, scale=1.2)
+        bx = ctx.randn((B, N), np_dt, seed=5, scale=1.0)
+        a_msg, b_msg = ctx.empty((B,), np.float64), ctx.empty((B, N), np_dt)
+        a_new, b_new = ctx.empty((B,), np.float64), ctx.empty((B, N), np_dt)
+        k = p.moment_hint()
+
+        def producer(hint):
+            if hint:
+                ctx._call("tramp_prior_hint", k[0], k[1], k[2], k[3], N, B, b_msg.ptr, a_msg.ptr)
+            ch.compute_backward_message(az, bz, ax, bx, out_a=a_msg, out_b=b_msg)
+
+        ms_plain = _timed(ctx, lambda: producer(False), 10)
+        ms_hint = _timed(ctx, lambda: producer(True), 10)
+        armed0, used0 = ctx.prior_hint_stats()
+
+        def pair():
+            producer(True)
+            p.compute_forward_message(a_msg, b_msg, out_a=a_new, out_b=b_new)
+
+        ms_pair = _timed(ctx, pair, 10)
+        armed1, used1 = ctx.prior_hint_stats()
+        ms_prior = ms_pair - ms_hint
+        extra = max(ms_hint - ms_plain, 0.0)
+        alg = 2 * esz * N * B
+        tot = ms_prior + extra
+        out["B64"] = {"n": N, "batch": B, "us_per_update": tot * 1e3, "us_prior_pass": ms_prior * 1e3,
+                      "us_added_to_producer": extra * 1e3, "us_producer": ms_plain * 1e3,
+                      "algorithmic_GBps": alg / tot / 1e6, "frac_of_hbm_peak": alg / tot / 1e6 / HBM_PEAK_GBS,
+                      "components_per_sec": N * B / (tot * 1e-3),
+                      "fused_updates": int(used1 - used0), "producers_armed": int(armed1 - armed0),
+                      "form": "producer-fused moments (ConvChannel inverse-FFT epilogue) + ONE update pass (2T moved)"}
+    except Exception as e:                                                    # noqa: BLE001
+        out["B64"] = {"error": repr(e)}
     return out
 
 
@@ -379,6 +432,10 @@ def run(args):
 
 def main():
     args = parse()
+    wd = int(os.environ.get("TRAMP_BENCH_WATCHDOG", 0))
+    if wd > 0:
+        import faulthandler          # dump every thread's Python stack to stderr if the run is still going after wd s
+        faulthandler.dump_traceback_later(wd, repeat=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # own launcher: one process per GPU, started BEFORE anything here touches the GPU
         from tramp_amd import ensemble

@@ -67,6 +67,9 @@ int tramp_device_count(int* n);
  * workspace; holds no globals, re-entrant across contexts. */
 int tramp_ctx_create(int device, tramp_ctx** ctx);
 int tramp_ctx_destroy(tramp_ctx* ctx);
+/* HIP's current device is per host thread: when one thread drives contexts on several GPUs it
+ * makes a context current before using it (the allocating entry points do so themselves). */
+int tramp_ctx_make_current(tramp_ctx* ctx);
 const char* tramp_last_error(const tramp_ctx* ctx);
 int tramp_sync(tramp_ctx* ctx);
 /* Raw hipStream_t of the context (for interop with other HIP users). */
@@ -241,6 +244,20 @@ int tramp_diag_factor(tramp_ctx* ctx, int dtype, int which, size_t count,
                       double p0, double p1, double p2,
                       void* a_new_d, void* b_new_d, void* r_d, void* v_d);
 
+/* Producer-fused moments.  An isotropic prior update needs v = mean_i v_i over the message it
+ * receives before it can write anything (tramp/base.py:250-255) - a whole extra read of b.  The
+ * kernel that WRITES that message already holds every b_i: announce the consumer before the
+ * producing call and, if that kernel supports it (dense channel back-projection / rotated-basis
+ * epilogues, the inverse FFT's fused message update), it leaves the partial sums of v_i; the next
+ * tramp_gb_prior_fwd / tramp_l1_prior_fwd on exactly (a_d, b_d) then reads b ONCE (2T bytes per
+ * component).  kind 1: GaussBernoulli (p0, p1, p2) = (rho, mean, var);
+ * kind 2: L1 (p0 = gamma); kind 0 clears.  No producer, no match or TRAMP_PRIOR_FUSE=0: the prior
+ * simply runs its own first pass - results agree to reduction-order rounding. */
+int tramp_prior_hint(tramp_ctx* ctx, int kind, double p0, double p1, double p2, size_t n, size_t batch,
+                     const void* b_d, const double* a_d);
+/* how many producers left moments / how many prior updates consumed them, since the context was made */
+int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed, unsigned long long* used);
+
 /* ---- dense linear channel x = W z --------------------------------------- */
 /* LinearChannel.__init__ (tramp/channels/linear/linear_channel.py:30-46): the
  * factorisation is supplied by the caller (host LAPACK or tramp_linear_factorize)
@@ -320,6 +337,28 @@ int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on);
  * the caller may claim the corresponding TRAMP_REUSE_* bit in the next tramp_linear_message. */
 int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, int which, size_t batch,
                                 const void* c_d, double damping, int c_changed);
+
+/* ---- EP bookkeeping on the device ------------------------------ */
+/* Per problem instance: the NaN guard of MessagePassing.check_message
+ * (tramp/algos/message_passing.py:187-209) and the stopping rule of EarlyStoppingEP
+ * (tramp/algos/callbacks.py:250-286) as launches behind the sweeps - captured with them in a
+ * hipGraph; the host polls the header every k iterations.
+ *   A_d [n_edges, batch]  precisions of the factor->variable messages
+ *   S_d [3 n_vars, batch] per variable: v, sum (r - r_old)^2, sum r^2   (tramp_variable_posterior)
+ *   state_d int32 [4 + 2 batch]: [0] iterations completed (the kernel increments it), [1] instances
+ *        still running, [2] NaN code (0, or 1 + edge * batch + instance), [3] instances diverged;
+ *        status[batch] (0 running, 1 converged, 2 diverged); n_iter[batch] (stopping iteration)
+ *   v_prev_d, v_frozen_d [n_vars, batch], a_frozen_d [n_edges, batch]: the previous iterate's
+ *        variances, and what a stopped instance reports (a diverged instance reports the PREVIOUS
+ *        iterate's mean and variance, as the reference restores its previous message dag).
+ * tol < 0 never converges, max_increase = +inf never gives up (NaN guard only).
+ * tramp_ep_freeze copies, for the instances that stopped in the iteration the monitor just closed,
+ * the current (converged) or previous (diverged) posterior mean into frozen_d [batch, n]. */
+int tramp_ep_monitor(tramp_ctx* ctx, int n_vars, int n_edges, size_t batch, const double* A_d,
+                     const double* S_d, double tol, double max_increase, int wait_increase,
+                     int* state_d, double* v_prev_d, double* v_frozen_d, double* a_frozen_d);
+int tramp_ep_freeze(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const int* state_d,
+                    const void* r_cur_d, const void* r_prev_d, void* frozen_d);
 
 /* ---- multi-GPU: ensemble shard over ranks, RCCL over xGMI -------- */
 /* Replaces the sequential loop over problem instances of run_experiments

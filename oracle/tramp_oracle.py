@@ -1560,6 +1560,8 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
     bwd = [(0, np.zeros(shapes[i])) for i in range(L)]
     d = damping if damping else 0.
     old_rs = None
+    old_state = None
+    status = "max_iter"
     n_iter = 0
     rs = vs = None
 
@@ -1608,11 +1610,17 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
         if old_rs is not None:
             tols = [_rms(n - o) / _rms(n) for o, n in zip(old_rs, rs)]
             if max(tols) < tol:
+                status = "converged"
                 break
             if it > wait_increase and max(tols) > max_increase:
+                # callbacks.py:277-283: "restoring old message dag" - messages AND posteriors go back to
+                # the iteration before the increase; n_iter keeps counting the abandoned iteration
+                fwd, bwd, rs, vs = old_state
+                status = "diverged"
                 break
         old_rs = rs
-    return dict(fwd=fwd, bwd=bwd, r=rs, v=vs, n_iter=n_iter)
+        old_state = (list(fwd), list(bwd), rs, vs)
+    return dict(fwd=fwd, bwd=bwd, r=rs, v=vs, n_iter=n_iter, status=status)
 
 
 def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1e-6,

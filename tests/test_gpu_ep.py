@@ -95,8 +95,8 @@ def test_ep_trajectory_fp32(ctx, golden_ep):
         t = c["traj"]
         for it in range(5):
             for vid in ids:
-                close(rec.iters[it]["vars"][vid]["r"], t[f"r:{vid}"][it], 2e-3)
-                close(rec.iters[it]["vars"][vid]["v"], t[f"v:{vid}"][it], 2e-3)
+                close(rec.iters[it]["vars"][vid]["r"], t[f"r:{vid}"][it], 1e-3)
+                close(rec.iters[it]["vars"][vid]["v"], t[f"v:{vid}"][it], 1e-3)
 
 
 @pytest.mark.parametrize("batch", [2, 5, 16])

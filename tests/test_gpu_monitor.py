@@ -1,0 +1,104 @@
+"""GPU parity of the device-side EP bookkeeping (csrc/monitor.hip): per-instance stopping rule and NaN
+guard of the reference's EarlyStoppingEP / check_message (tramp/algos/callbacks.py:250-286,
+tramp/algos/message_passing.py:187-209) evaluated on the device behind the sweeps, the host polling
+every k iterations.  Oracle: ep_chain on each instance alone (which, like the reference, goes back to
+the previous iterate when it gives up after an increase)."""
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tramp_amd
+    return tramp_amd
+
+
+def _glm(T, ctx, B, N=256, M=128, rho=0.1, nv=1e-2, seed=31):
+    rs = np.random.RandomState(seed)
+    W = orc.gaussian_ensemble(rs, M, N)
+    X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(B)])
+    Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
+    model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=Y if B > 1 else Y[0], var=nv, ctx=ctx)).to_model()
+    fs = lambda b: [orc.GBPriorFactor(N, rho=rho), orc.LinearFactor(W), orc.GaussLikFactor(Y[b], nv)]   # noqa: E731
+    return model, fs, X, (N, M)
+
+
+def _close(a, b, rtol=1e-6):
+    b = np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), b, rtol=rtol, atol=rtol * np.abs(b).max())
+
+
+@pytest.mark.parametrize("batch", [1, 6])
+def test_per_instance_rule_against_single_runs(T, ctx, batch):
+    """tol and max_increase chosen so that the ensemble mixes instances that converge and instances that
+    give up: each one must report what its own run would have (status, n_iter, r, v)."""
+    model, fs, X, (N, M) = _glm(T, ctx, batch)
+    rule = dict(tol=2e-3, wait_increase=5, max_increase=0.03)
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=100, callback=T.EarlyStoppingEP(**rule), damping=0.1)
+    d = ep.get_variables_data()
+    statuses = []
+    for b in range(batch):
+        res = orc.ep_chain(fs(b), [N, M], max_iter=100, damping=0.1, **rule)
+        statuses.append(res["status"])
+        assert {0: "max_iter", 1: "converged", 2: "diverged"}[int(ep.status[b])] == res["status"], b
+        assert ep.n_iter_instance[b] == res["n_iter"], b
+        r = np.atleast_2d(d["x"]["r"])[b]
+        v = np.atleast_1d(d["x"]["v"])[b]
+        _close(r, res["r"][0])
+        _close(v, res["v"][0])
+        _close(np.atleast_2d(d["z"]["r"])[b], res["r"][1])
+    assert ep.n_iter == max(ep.n_iter_instance)
+    if batch > 1:
+        assert "diverged" in statuses       # the give-up branch (previous iterate restored) was exercised
+
+
+@pytest.mark.parametrize("variant", ["check_every", "graph"])
+def test_poll_cadence_and_graph_replay_do_not_change_results(T, ctx, variant):
+    model, fs, X, (N, M) = _glm(T, ctx, 6)
+    outs = []
+    for kw in (dict(), dict(check_every=5) if variant == "check_every" else dict(graph=True)):
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        ep.iterate(max_iter=200, damping=0.1, **kw)
+        d = ep.get_variables_data()
+        outs.append((ep.n_iter, ep.status.copy(), ep.n_iter_instance.copy(), d["x"]["r"].copy(), d["x"]["v"].copy(),
+                     d["z"]["r"].copy(), {k: v.copy() for k, v in ep.get_edges_data().items()}))
+    a, b = outs
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.all(a[1] == 1) and len(set(a[2])) > 1            # all converged, at different iterations
+    for i in (3, 4, 5):
+        assert np.array_equal(a[i], b[i])
+    for k in a[6]:
+        assert np.array_equal(a[6][k], b[6][k])
+
+
+def test_nan_guard_names_the_message(T, ctx):
+    model, fs, X, (N, M) = _glm(T, ctx, 3)
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=2, callback=T.PassCallback())
+    # poison one instance's message precision on the device, then go on
+    A = ep.A.get()
+    A[1, 2] = np.nan
+    ep.A.set(A)
+    with pytest.raises(ValueError, match=r"message into x \\(instance 2\\): a is nan"):
+        ep.iterate(max_iter=3, callback=T.PassCallback(), warm_start=True, check_every=3)
+
+
+def test_mse_validates_the_shape_of_the_true_signal(T, ctx):
+    model, fs, X, (N, M) = _glm(T, ctx, 4)
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=5, callback=T.PassCallback())
+    m = ep.mse("x", X)
+    r = ep.get_variables_data()["x"]["r"]
+    _close(m, np.mean((r - X)**2, axis=1), 1e-10)
+    m1 = ep.mse("x", X[0])                                    # one signal shared by the ensemble
+    _close(m1, np.mean((r - X[0])**2, axis=1), 1e-10)
+    for bad in (X[:2], X[:, :N - 1], np.zeros(N + 1)):
+        with pytest.raises(ValueError):
+            ep.mse("x", bad)

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "tramp_device_count": [C.POINTER(i32)],
     "tramp_ctx_create": [i32, C.POINTER(vp)],
     "tramp_ctx_destroy": [vp],
+    "tramp_ctx_make_current": [vp],
     "tramp_sync": [vp],
     "tramp_ctx_stream": [vp, C.POINTER(vp)],
     "tramp_device_name": [vp, C.c_char_p, sz],
@@ -75,6 +76,8 @@ _SIGNATURES = {
     "tramp_linear_destroy": [vp, vp],
     "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],
     "tramp_eigh": [vp, sz, vp, vp],
+    "tramp_prior_hint": [vp, i32, dbl, dbl, dbl, sz, sz, vp, vp],
+    "tramp_prior_hint_stats": [vp, C.POINTER(u64), C.POINTER(u64)],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_conv_create": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],
@@ -118,6 +121,8 @@ _SIGNATURES = {
     "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
     "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],
     "tramp_randn": [vp, i32, vp, sz, u64, dbl],
+    "tramp_ep_monitor": [vp, i32, i32, sz, vp, vp, dbl, dbl, i32, vp, vp, vp, vp],
+    "tramp_ep_freeze": [vp, i32, sz, sz, vp, vp, vp, vp],
     "tramp_comm_unique_id": [vp, vp],
     "tramp_comm_init": [vp, i32, i32, vp, C.POINTER(vp)],
     "tramp_comm_destroy": [vp, vp],

@@ -110,16 +110,19 @@ class EarlyStoppingEP:
         self.max_increase = max_increase
 
     def __call__(self, algo, i, max_iter):
+        # host-side evaluation (the chain scheduler runs this rule on the device instead when it covers all
+        # variables, csrc/monitor.hip); per instance: an instance that meets the rule, or gives up after an
+        # increase, is frozen and the others go on
         if i == 0:
             return False                      # old_rs = None on the first iteration
         tols = algo.relative_change(self.ids)          # [n_vars, batch]
-        worst = tols.max(axis=0)
-        algo.mark_converged(worst < self.tol)
-        if np.all(worst < self.tol):
-            logger.info("early stopping all tolerances (on r) are below tol=%.2e", self.tol)
-            return True
-        if i > self.wait_increase and np.any(worst > self.max_increase):
-            logger.info("increase=%s above max_increase=%.2e", worst.max(), self.max_increase)
+        with np.errstate(invalid="ignore"):
+            worst = tols.max(axis=0)
+            algo.mark_converged(worst < self.tol)
+            if i > self.wait_increase:
+                algo.mark_diverged(worst > self.max_increase)
+        if np.all(algo.status != 0):
+            logger.info("early stopping: every instance is below tol=%.2e or has given up", self.tol)
             return True
         return False
 
@@ -304,8 +307,8 @@ class ExpectationPropagation:
         self.batch = int(batch)
         self.n_iter = 0
         self.n_iter_instance = np.zeros(self.batch, dtype=int)
+        self.status = np.zeros(self.batch, dtype=int)
         self._allocated = False
-        self._frozen_r = None
         self.default_stopping = EarlyStoppingEP()
         self._find_rotations()
 
@@ -415,7 +418,30 @@ class ExpectationPropagation:
             buf.version = 0
         self._const_msg = {}
         self._const_done = set()
+        self._allocate_monitor(2 * L)
         self._allocated = True
+
+    def _allocate_monitor(self, n_edges):
+        """Device-side bookkeeping (csrc/monitor.hip): previous posterior means (the variable-posterior
+        kernel ping-pongs between r and r_prev, so the previous iterate costs no traffic), what a stopped
+        instance reports (frozen r, v, a), and the state words the host polls."""
+        ctx, B, L = self.ctx, self.batch, len(self.variables)
+        self.r_prev = [ctx.zeros(r.shape, self.dtype) for r in self.r]
+        self._frozen_r = [ctx.zeros(r.shape, self.dtype) for r in self.r]
+        self._state = ctx.zeros((4 + 2 * B,), np.int32)
+        self._v_prev = ctx.zeros((L, B), np.float64)
+        self._v_frozen = ctx.zeros((L, B), np.float64)
+        self._a_frozen = ctx.zeros((n_edges, B), np.float64)
+        self._n_edges = n_edges
+        self._reset_monitor()
+
+    def _reset_monitor(self):
+        B, L = self.batch, len(self.variables)
+        self.ctx._call("tramp_memset", self._state, 0, self._state.nbytes)
+        self.status = np.zeros(B, dtype=int)                 # 0 running / max_iter, 1 converged, 2 diverged
+        self.n_iter_instance = np.zeros(B, dtype=int)
+        self._frozen_v = np.zeros((L, B))
+        self._frozen_A = np.zeros((self._n_edges, B))
 
     def init_message_dag(self, initializer):
         "message_passing.py:211-232"
@@ -449,6 +475,7 @@ class ExpectationPropagation:
             self.b_bwd[i].version += 1
         self._const_done = set()
         self._const_msg = {}
+        self.ctx._call("tramp_prior_hint", 0, 0.0, 0.0, 0.0, 0, 0, None, None)   # messages rewritten: no stale moments
 
     # -- one factor update, in place, damping fused where the kernel supports it
     def _update(self, factor, direction, i_in, i_out):
@@ -486,6 +513,13 @@ class ExpectationPropagation:
         kw = dict(out_a=out_a, out_b=out_b)
         if d:
             kw.update(damping=d, old_a=out_a, old_b=out_b)
+        if direction == "bwd":
+            # producer-fused moments (csrc/prior_hint.h): when the consumer of this message is a separable
+            # prior, the kernel that writes the message also leaves sum v_i, and the prior reads it once
+            hint = self._moment_hint(i_out)
+            if hint is not None:
+                self.ctx._call("tramp_prior_hint", hint[0], hint[1], hint[2], hint[3], out_b.shape[1], self.batch,
+                               out_b.ptr, out_a.ptr)
         if factor.n_prev == 0:
             factor.compute_forward_message(self.a_bwd[i_out], self.b_bwd[i_out], **kw)
         elif factor.n_next == 0:
@@ -499,6 +533,13 @@ class ExpectationPropagation:
         out_b.version += 1          # consumers (LinearChannel projection cache) see a new message
         if const and not d:
             self._const_done.add((factor, direction))
+
+    def _moment_hint(self, i):
+        "the prior that consumes the backward message into variable i, if it can use fused moments"
+        if i in self._rot:
+            return None                 # the stored message lives in a rotated basis
+        f = self.model.prev_factor(self.variables[i])
+        return f.moment_hint() if f.n_prev == 0 and hasattr(f, "moment_hint") else None
 
     def forward_message(self):
         "message_passing.py:249-255"
@@ -515,12 +556,51 @@ class ExpectationPropagation:
         dt = dtype_code(self.dtype)
         for i in range(len(self.variables)):
             n = self.r[i].shape[1]
+            # reads the previous mean from r, writes the new one to r_prev, then the two swap roles
             self.ctx._call("tramp_variable_posterior", dt, n, self.batch, self.a_fwd[i].ptr,
                            self.b_fwd[i].ptr, self.a_bwd[i].ptr, self.b_bwd[i].ptr, self.r[i].ptr,
-                           self.r[i].ptr, self.S.row(3 * i).ptr, self.S.row(3 * i + 1).ptr,
+                           self.r_prev[i].ptr, self.S.row(3 * i).ptr, self.S.row(3 * i + 1).ptr,
                            self.S.row(3 * i + 2).ptr)
+            self.r[i], self.r_prev[i] = self.r_prev[i], self.r[i]
+
+    def _swap_r(self):
+        for i in range(len(self.variables)):
+            self.r[i], self.r_prev[i] = self.r_prev[i], self.r[i]
+
+    def _monitor_step(self, tol, max_increase, wait_increase):
+        "NaN guard + per-instance stopping rule of the iteration just launched, on the device (monitor.hip)"
+        L = len(self.variables)
+        self.ctx._call("tramp_ep_monitor", L, self._n_edges, self.batch, self.A, self.S, float(tol),
+                       float(max_increase), int(wait_increase), self._state, self._v_prev, self._v_frozen,
+                       self._a_frozen)
+        dt = dtype_code(self.dtype)
+        for i in range(L):
+            self.ctx._call("tramp_ep_freeze", dt, self.r[i].shape[1], self.batch, self._state, self.r[i],
+                           self.r_prev[i], self._frozen_r[i])
+
+    def _poll_monitor(self):
+        """Read the state words; raises on a NaN message (message_passing.py:187-209), otherwise updates
+        status / n_iter_instance / frozen scalars and returns the number of instances still running."""
+        st = self._state.get()
+        if st[2]:
+            e, b = divmod(int(st[2]) - 1, self.batch)
+            raise ValueError(self._edge_name(e) + f" (instance {b}): a is nan")
+        B = self.batch
+        status, n_it = st[4:4 + B], st[4 + B:4 + 2 * B]
+        newly = (status != 0) & (self.status == 0)
+        if newly.any():
+            self._frozen_v[:, newly] = self._v_frozen.get()[:, newly]
+            self._frozen_A[:, newly] = self._a_frozen.get()[:, newly]
+            self.status[newly] = status[newly]
+            self.n_iter_instance[newly] = getattr(self, "_n0", 0) + n_it[newly]
+        return int(st[1])
+
+    def _edge_name(self, e):
+        v = self.variables[e // 2]
+        return f"{'fwd' if e % 2 == 0 else 'bwd'} message into {v.id}"
 
     def _read_scalars(self):
+        self._S_prev_host = getattr(self, "S_host", None)
         self.A_host = self.A.get()
         self.S_host = self.S.get()
 
@@ -529,9 +609,7 @@ class ExpectationPropagation:
         bad = np.isnan(self.A_host)
         if bad.any():
             e, b = np.argwhere(bad)[0]
-            v = self.variables[e // 2]
-            d = "fwd" if e % 2 == 0 else "bwd"
-            raise ValueError(f"{d} message into {v.id} (instance {b}): a is nan")
+            raise ValueError(self._edge_name(int(e)) + f" (instance {b}): a is nan")
         if (self.A_host < 0).any():
             logger.warning("negative a in messages")
 
@@ -544,29 +622,49 @@ class ExpectationPropagation:
             return np.sqrt(sd) / np.sqrt(sn)
 
     def mark_converged(self, mask):
-        """Record the instances that meet the stopping rule for the first time and freeze their
-        result: the reference would have stopped each instance's own run here, the ensemble keeps
-        iterating until all are done (instances never interact, so the others are unaffected)."""
-        newly = mask & (self.n_iter_instance == 0)
+        """Host-side twin of the device monitor, for callbacks that evaluate their own rule on the host
+        (e.g. EarlyStoppingEP on a subset of the variables): record the instances that meet the rule for
+        the first time and freeze their result.  The reference would have stopped each instance's own
+        run here; the ensemble keeps iterating until all are done (instances never interact)."""
+        newly = mask & (self.status == 0)
         if not newly.any():
             return
         self.n_iter_instance[newly] = self.n_iter
-        if self.batch == 1:
-            return
-        if self._frozen_r is None:
-            self._frozen_r = [self.ctx.zeros(r.shape, self.dtype) for r in self.r]
-            self._frozen_v = np.zeros((len(self.variables), self.batch))
+        self.status[newly] = 1
+        self._frozen_A[:, newly] = self.A_host[:, newly]
         for b in np.flatnonzero(newly):
             for i in range(len(self.variables)):
                 self._frozen_r[i].row(int(b)).copy_from(self.r[i].row(int(b)))
                 self._frozen_v[i, b] = self.S_host[3 * i, b]
 
-    def get_variables_data(self, ids="all", want_r=True, frozen=False):
-        """{id: dict(r=..., v=...)} of the current iteration; ``frozen=True`` returns, for
-        instances that already met the stopping rule, the estimate at THEIR stopping iteration."""
+    def mark_diverged(self, mask):
+        """An instance whose relative change exceeds max_increase gives up: it reports the iterate BEFORE the
+        increase (the reference restores its previous message dag, callbacks.py:277-283).  The previous
+        means are at hand where the variable-posterior kernel ping-pongs (chain scheduler); the previous
+        variances when the scalar table was read every iteration."""
+        newly = mask & (self.status == 0)
+        if not newly.any():
+            return
+        self.n_iter_instance[newly] = self.n_iter
+        self.status[newly] = 2
+        self._frozen_A[:, newly] = self.A_host[:, newly]
+        prev_r = getattr(self, "r_prev", None) if self._device_monitor else None
+        S_prev = self._S_prev_host if getattr(self, "_S_prev_host", None) is not None else self.S_host
+        for b in np.flatnonzero(newly):
+            for i in range(len(self.variables)):
+                src = prev_r[i] if prev_r is not None else self.r[i]
+                self._frozen_r[i].row(int(b)).copy_from(src.row(int(b)))
+                self._frozen_v[i, b] = S_prev[3 * i, b]
+
+    def get_variables_data(self, ids="all", want_r=True, frozen=None):
+        """{id: dict(r=..., v=...)}.  An instance that has stopped (converged, or given up after an
+        increase: ``self.status``) reports the estimate of ITS stopping iteration - for a diverged one
+        the iterate before the increase, as the reference restores its previous message dag
+        (callbacks.py:277-283) - while the ensemble keeps iterating for the others.  ``frozen=False``
+        returns the current iterate of every instance."""
         out = {}
-        done = (self.n_iter_instance > 0) & (self.n_iter_instance < self.n_iter)
-        use_frozen = frozen and self._frozen_r is not None and done.any()
+        done = self.status != 0
+        use_frozen = (frozen is None or frozen) and done.any()
         for i, v in enumerate(self.variables):
             if ids == "all" or v.id in ids:
                 vv = self.S_host[3 * i].copy()
@@ -575,9 +673,12 @@ class ExpectationPropagation:
                 d = dict(v=float(vv[0]) if self.batch == 1 else vv)
                 if want_r:
                     unrot = (lambda a: self._rotate(i, a, back=True)) if i in self._rot else (lambda a: a)
-                    r = unrot(self.r[i]).get()
-                    if use_frozen:
-                        r[done] = unrot(self._frozen_r[i]).get()[done]
+                    if use_frozen and done.all():
+                        r = unrot(self._frozen_r[i]).get()
+                    else:
+                        r = unrot(self.r[i]).get()
+                        if use_frozen:
+                            r[done] = unrot(self._frozen_r[i]).get()[done]
                     d["r"] = r[0] if self.batch == 1 else r
                 out[v.id] = d
         return out
@@ -588,9 +689,12 @@ class ExpectationPropagation:
     def get_edges_data(self):
         "a of every factor->variable edge, as {(variable id, direction): array[batch]}"
         out = {}
+        A = self.A_host.copy()
+        done = self.status != 0
+        A[:, done] = self._frozen_A[:, done]                  # a stopped instance: the values of its last iteration
         for i, v in enumerate(self.variables):
-            out[(v.id, "fwd")] = self.A_host[2 * i].copy()
-            out[(v.id, "bwd")] = self.A_host[2 * i + 1].copy()
+            out[(v.id, "fwd")] = A[2 * i]
+            out[(v.id, "bwd")] = A[2 * i + 1]
         return out
 
     def get_message(self, id, direction):
@@ -604,11 +708,20 @@ class ExpectationPropagation:
         return [v.id for v in self.variables].index(id)
 
     def mse(self, id, x_true):
+        """mean squared error of the current posterior mean against ``x_true``: [n] (one signal shared by
+        the ensemble) or [batch, n]."""
         i = self.variable_index(id)
-        xt = self.ctx.array(np.atleast_2d(np.asarray(x_true, dtype=self.dtype)), self.dtype)
-        out = self.ctx.empty((self.batch,), np.float64)
         r = self._rotate(i, self.r[i], back=True) if i in self._rot else self.r[i]
         n = r.shape[1]
+        x = np.asarray(x_true, dtype=self.dtype)
+        if x.size == n:
+            x = np.broadcast_to(x.reshape(1, n), (self.batch, n))
+        elif x.size == self.batch * n and x.shape[0] == self.batch:
+            x = x.reshape(self.batch, n)
+        else:
+            raise ValueError(f"x_true for {id!r} must have shape ({n},) or ({self.batch}, {n}), got {x.shape}")
+        xt = self.ctx.array(np.ascontiguousarray(x), self.dtype)
+        out = self.ctx.empty((self.batch,), np.float64)
         self.ctx._call("tramp_sq_dist", dtype_code(self.dtype), n, self.batch, r.ptr, xt.ptr, out.ptr)
         m = out.get() / n
         return float(m[0]) if self.batch == 1 else m
@@ -656,65 +769,118 @@ class ExpectationPropagation:
         return -self.log_evidence()                        # expectation_propagation.py:29-32
 
     # -- main loop
-    def _capture_iteration(self):
-        "Record one steady-state iteration (all launches of the three sweeps) into a hipGraph."
+    _device_monitor = True       # chain scheduler: stopping rule and NaN guard run on the device (monitor.hip)
+
+    def _one_iteration(self, mon):
+        self.forward_message()
+        self.backward_message()
+        self.update_variables()
+        if mon is not None:
+            self._monitor_step(*mon)
+
+    def _capture_iterations(self, mon, count):
+        """Record `count` steady-state iterations (every launch of the three sweeps and of the monitor) into
+        one hipGraph.  Two when the monitor is on: the variable-posterior kernel ping-pongs between r and
+        r_prev, so the launch sequence repeats with period two."""
         import ctypes as C
         self.ctx._call("tramp_graph_begin")
         try:
-            self.forward_message()
-            self.backward_message()
-            self.update_variables()
+            for _ in range(count):
+                self._one_iteration(mon)
         finally:
             g = C.c_void_p()
             self.ctx._call("tramp_graph_end", C.byref(g))
         return g
 
+    @staticmethod
+    def _split_callback(callback):
+        """(stopping rule the device monitor can run, callbacks that stay on the host).  The monitor takes an
+        EarlyStoppingEP over all variables (also inside a JoinCallback); anything else - subclasses,
+        wrappers, a rule on a subset of the variables - keeps its host-side evaluation."""
+        members = list(callback.callbacks) if type(callback) is JoinCallback else [callback]
+        stop = [cb for cb in members if type(cb) is EarlyStoppingEP and cb.ids == "all"]
+        if len(stop) != 1:
+            return None, members
+        return stop[0], [cb for cb in members if cb is not stop[0] and type(cb) is not PassCallback]
+
     def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False,
                 check_every=1, graph=False):
-        """message_passing.py:330-357.  ``check_every`` > 1 reads the scalar table (NaN guard,
-        stopping rule) only every k-th iteration - the sweeps themselves never wait on the host.
-        ``graph=True`` captures the third iteration's launch sequence in a hipGraph and replays
-        it afterwards (launch-bound small problems); results are identical to the eager loop."""
+        """message_passing.py:330-357.  The NaN guard and the per-instance stopping rule run on the device
+        after every iteration (csrc/monitor.hip); ``check_every`` = k makes the host look at their state
+        words - and run the remaining host callbacks - only every k-th iteration, the sweeps themselves
+        never wait on the host.  An instance that stops keeps the estimate of its own stopping iteration
+        (``status``, ``n_iter_instance``, get_variables_data) while the others go on; k > 1 only delays the
+        moment the loop notices that all are done.  ``graph=True`` captures the steady-state launch sequence
+        in a hipGraph and replays it (launch-bound small problems); results are identical to the eager loop."""
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
         if damping is not None and damping is not False and not isinstance(damping, float):
             raise ValueError("damping must be None or a float (constant damping)")
         self.damping = float(damping) if damping else 0.0
+        check_every = max(int(check_every), 1)
         if warm_start:
             if not self._allocated:
                 raise ValueError("message dag was never initialized")
         else:
             self.init_message_dag(initializer)
             self.n_iter = 0
+        if self._device_monitor:
+            self._reset_monitor()            # a warm start begins a new run of the stopping rule (i = 0 again)
+            stopper, host_cbs = self._split_callback(callback)
+            mon = ((stopper.tol, stopper.max_increase, stopper.wait_increase) if stopper is not None
+                   else (-1.0, np.inf, 0))
+        else:
+            stopper, host_cbs, mon = None, [callback], None
+            self.status[:] = 0
             self.n_iter_instance[:] = 0
-            self._frozen_r = None
-        g = None
+        n0 = self._n0 = self.n_iter
+        period = 2 if mon is not None else 1           # r / r_prev ping-pong: the launch sequence has period two
+        graphs = {}
         basis = self._Basis(self)
         basis.__enter__()
         try:
-            for i in range(max_iter):
-                if g is not None:
-                    self.ctx._call("tramp_graph_launch", g)
-                elif graph and i == 2:
+            i = 0
+            while i < max_iter:
+                par = i % period
+                if graph and i >= 2:
                     # iterations 0 and 1 ran eagerly: buffers exist, caches are in steady state
-                    g = self._capture_iteration()
-                    self.ctx._call("tramp_graph_launch", g)
+                    if par not in graphs:
+                        graphs[par] = self._capture_iterations(mon, 1)     # (the Python-side swaps happen here)
+                        self.ctx._call("tramp_graph_launch", graphs[par])
+                    else:
+                        self.ctx._call("tramp_graph_launch", graphs[par])
+                        if mon is not None:
+                            self._swap_r()
                 else:
-                    self.forward_message()
-                    self.backward_message()
-                    self.update_variables()
-                self.n_iter += 1
-                if (i + 1) % check_every == 0 or i == max_iter - 1:
-                    self._read_scalars()
+                    self._one_iteration(mon)
+                step = 1
+                first, i = i, i + step
+                self.n_iter += step
+                # poll when a multiple of check_every was crossed, and at the end
+                if i // check_every == first // check_every and i < max_iter:
+                    continue
+                self._read_scalars()
+                running = None
+                if mon is not None:
+                    running = self._poll_monitor()
+                else:
                     self.check_message()
-                    if callback(self, i, max_iter):
-                        logger.info("terminated after n_iter=%d iterations", self.n_iter)
-                        break
+                stop = False
+                for cb in host_cbs:
+                    stop = bool(cb(self, i - 1, max_iter)) or stop
+                if stopper is not None and running == 0:
+                    logger.info("early stopping: every instance has met the rule (tol=%.2e) or given up", stopper.tol)
+                    stop = True
+                if stop:
+                    logger.info("terminated after n_iter=%d iterations", self.n_iter)
+                    break
         finally:
             basis.__exit__(None, None, None)
-            if g is not None:
+            for g in graphs.values():
                 self.ctx._call("tramp_graph_destroy", g)
-        self.n_iter_instance[self.n_iter_instance == 0] = self.n_iter
+        if stopper is not None and self.status.all():
+            self.n_iter = int(self.n_iter_instance.max())          # the iteration the last instance stopped at
+        self.n_iter_instance[self.status == 0] = self.n_iter       # still running: cut short by max_iter
         return self
 
 

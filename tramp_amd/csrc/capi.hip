@@ -1,5 +1,6 @@
 // capi.hip - context, device memory and timing entry points of the C ABI.
 #include "common.h"
+#include "prior_hint.h"
 
 extern "C" const char* tramp_version(void) { return "tramp_hip 0.1 (gfx950)"; }
 
@@ -57,6 +58,7 @@ extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->hint_ws) (void)hipFree(ctx->hint_ws);
     if (ctx->hscratch) (void)hipHostFree(ctx->hscratch);
     if (ctx->prof) {
         for (int i = 0; i < ctx->prof_cap; ++i) {
@@ -112,6 +114,7 @@ extern "C" int tramp_graph_end(tramp_ctx* ctx, tramp_graph** out) {
     tg->graph = g;
     tg->exec = ex;
     *out = tg;
+    ctx->graphs_alive += 1;      // the graph holds raw pointers into ctx->ws / hint_ws: no growth until it is gone
     return TRAMP_OK;
 }
 
@@ -127,6 +130,7 @@ extern "C" int tramp_graph_destroy(tramp_ctx* ctx, tramp_graph* graph) {
     (void)hipGraphExecDestroy(graph->exec);
     (void)hipGraphDestroy(graph->graph);
     delete graph;
+    if (ctx->graphs_alive > 0) ctx->graphs_alive -= 1;
     return TRAMP_OK;
 }
 
@@ -173,6 +177,11 @@ int tramp_ws_reserve(tramp_ctx* ctx, size_t bytes) {
     if (ctx->capturing)
         return tramp_fail(ctx, TRAMP_EINVAL, "workspace", "would have to grow during graph capture; run the "
                           "sequence eagerly once first");
+    if (ctx->graphs_alive > 0)
+        return tramp_fail(ctx, TRAMP_ENOTSUP, "workspace", "a captured graph of this context still points into the "
+                          "workspace, which this call would have to re-allocate; destroy the graph first or use "
+                          "another context for the larger call");
+    (void)hipSetDevice(ctx->device);
     size_t nb = ctx->ws_bytes;
     while (nb < bytes) nb *= 2;
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -184,6 +193,49 @@ int tramp_ws_reserve(tramp_ctx* ctx, size_t bytes) {
         return tramp_fail(ctx, TRAMP_ENOMEM, "workspace", "hipMalloc failed");
     }
     ctx->ws_bytes = nb;
+    return TRAMP_OK;
+}
+
+/* One process may hold contexts on several GPUs.  HIP's "current device" is per host thread: the
+ * entry points that allocate set it themselves, everything else (launches on ctx->stream) needs the
+ * caller to make the context current when it switches between contexts on one thread.  The Python
+ * mirror does this in Context._call. */
+extern "C" int tramp_ctx_make_current(tramp_ctx* ctx) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return TRAMP_OK;
+}
+
+bool prior_hint_arm(tramp_ctx* ctx, const void* out_buf, size_t len, size_t batch, int nblk, PriorHintDev* dev) {
+    dev->kind = PRIOR_HINT_NONE;
+    TrampPriorHint& h = ctx->hint;
+    if (!h.kind || h.buf != out_buf || h.n != len || h.batch != batch || nblk <= 0) return false;
+    const size_t need = batch * (size_t)nblk * sizeof(double);
+    if (need > ctx->hint_ws_bytes) {
+        if (ctx->capturing || ctx->graphs_alive) return false;      // never move a buffer a graph points at
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->hint_ws) (void)hipFree(ctx->hint_ws);
+        ctx->hint_ws = nullptr;
+        ctx->hint_ws_bytes = 0;
+        if (hipMalloc((void**)&ctx->hint_ws, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        ctx->hint_ws_bytes = need;
+    }
+    h.partials = ctx->hint_ws;
+    h.nblk = nblk;
+    h.ready = true;
+    ctx->hint_armed += 1;
+    *dev = PriorHintDev{h.kind, h.p0, h.p1, h.p2, h.a_msg, h.partials, nblk};
+    return true;
+}
+
+extern "C" int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed, unsigned long long* used) {
+    if (!ctx || !armed || !used) return TRAMP_EINVAL;
+    *armed = ctx->hint_armed;
+    *used = ctx->hint_used;
     return TRAMP_OK;
 }
 

@@ -26,6 +26,18 @@ struct TrampProfRec {
     double bytes, flops;
 };
 
+// host side of prior_hint.h: what tramp_prior_hint announced and whether a producer honoured it
+struct TrampPriorHint {
+    int kind;                 // 0 = none
+    double p0, p1, p2;
+    const void* buf;          // the message buffer b the prior will read
+    const double* a_msg;      // its precision array
+    size_t n, batch;
+    double* partials;         // owned by the context (hint_ws)
+    int nblk;                 // set by the producer
+    bool ready;               // a producer has left the partials of the CURRENT contents of buf
+};
+
 struct tramp_ctx {
     int device;
     hipStream_t stream;
@@ -40,6 +52,12 @@ struct tramp_ctx {
     bool capturing;      // inside tramp_graph_begin/end
     TrampProfRec* prof;
     int prof_cap, prof_n;
+    // producer-fused prior moments (prior_hint.h)
+    TrampPriorHint hint;
+    double* hint_ws;
+    size_t hint_ws_bytes;
+    unsigned long long hint_armed, hint_used;   // producers that left moments / prior updates that ran single-pass
+    int graphs_alive;    // captured graphs hold raw workspace pointers: no growth while > 0
 };
 
 // RAII scope: records start/stop events on the context's stream when profiling is on.

@@ -802,7 +802,7 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     if (cv->fft2) {
         // 4+5. own engine: the inverse transform's last pass applies the message update as it stores
         ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz * (damping != 0.0 ? 3 : 2) + nh * 2 * esz), 0);
-        Fft2Epi epi{a_in, cv->a_raw, b_in, damping, b_old_d, b_new_d, r_d};
+        Fft2Epi epi{a_in, cv->a_raw, b_in, damping, b_old_d, b_new_d, r_d, PriorHintDev{}};
         rc = fft2_inverse(ctx, cv->fft2, batch, cv->fo, nullptr, &epi);
         if (rc) return rc;
         return TRAMP_OK;

@@ -23,6 +23,7 @@
 // Built with -ffp-contract=off so that f64 branch masks see the same operands as
 // the NumPy reference (no FMA contraction).
 #include "common.h"
+#include "prior_hint.h"
 #include "tramp_math.h"
 
 using tmath::RV;
@@ -512,6 +513,182 @@ __global__ __launch_bounds__(kBlock) void ew_single(Op op, size_t n, const T* __
     }
 }
 
+// ---------------------------------------------------------------- streaming tile form (large n)
+// Launch shape measured with tools/probes/probe_copy.hip: a block that owns ONE contiguous tile of
+// 256 x U 16-byte pieces, no loop, all loads issued before the first use, grid = tiles x instances
+// (workgroups are dispatched in address order, so HBM sees a sequential stream).  The grid-stride
+// kernels above (<= 1024 blocks per instance, each block folding the partials before it streams)
+// stay for ragged n.  Three kernels:
+//   ew_moments_tile  pass 1: (r_i, v_i) per component, sum v_i per tile        -> partials[inst, tile]
+//   ew_finalize      one block per instance: fixed-order fold, a_new, scalars -> scal[inst] = a_in + a_new
+//   ew_apply_tile    pass 2: b_new = r (a_in + a_new) - b (+ damping), r recomputed (light ops) or
+//                    read back from the scratch (heavy ops)
+// With producer-fused moments (prior_hint.h) only the last two run: the prior reads b once.
+constexpr int kTileU = 2;      // probe_copy: 5.85 TB/s (U = 2) vs 5.77 (U = 4) vs 4.25 (U = 8); 6.2 with streaming stores
+
+// 16-byte store that does not allocate in the caches (outputs larger than the Infinity Cache)
+template <typename T> struct NativeVec;
+template <> struct NativeVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct NativeVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <typename T, bool NTS>
+__device__ __forceinline__ void store_vec(typename Vec<T>::type* dst, const typename Vec<T>::type& v) {
+    if (NTS) {
+        using N = typename NativeVec<T>::type;
+        __builtin_nontemporal_store(*reinterpret_cast<const N*>(&v), reinterpret_cast<N*>(dst));
+    } else {
+        *dst = v;
+    }
+}
+
+template <typename T, typename Op, int U>
+__global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_t inst0, const T* __restrict__ in0,
+                                                          const T* __restrict__ in1, T* __restrict__ rbuf,
+                                                          double* __restrict__ partials,
+                                                          unsigned long long* __restrict__ pcount,
+                                                          uint8_t* __restrict__ mask_out) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    __shared__ double smem[kBlock / kWave];
+    __shared__ unsigned long long smem_u[kBlock / kWave];
+    const size_t b = inst0 + blockIdx.y;
+    op.setup(b);
+    const size_t nv = n / VN;
+    const size_t base = (size_t)blockIdx.x * kBlock * U + threadIdx.x;
+    const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
+    const V* p1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
+    V* pr = rbuf ? reinterpret_cast<V*>(rbuf + (size_t)blockIdx.y * n) : nullptr;
+    uint8_t* mo = mask_out ? mask_out + b * n : nullptr;
+    V v0[U], v1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * kBlock;
+        if (i < nv) {
+            v0[u] = p0[i];
+            if (Op::NIN > 1) v1[u] = p1[i];
+        }
+    }
+    double acc = 0.0;
+    unsigned long long cnt = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * kBlock;
+        if (i < nv) {
+            V vr;
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                const T x0 = vget<T>(v0[u], j);
+                const T x1 = (Op::NIN > 1) ? vget<T>(v1[u], j) : x0;
+                EwOut<T> o = op.eval(x0, x1);
+                acc += (double)o.v;
+                if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
+                cnt += o.mask & 1u;
+                vset<T>(vr, j, o.r);
+                if (mo) mo[i * VN + j] = (uint8_t)o.mask;
+            }
+            if (pr) pr[i] = vr;
+        }
+    }
+    acc = block_sum(acc, smem);
+    if (pcount) cnt = block_sum_u64(cnt, smem_u);
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+        if (pcount) pcount[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = cnt;
+    }
+}
+
+// One block per instance of the chunk.  partials[(pinst0 + blockIdx.x) * nblk + i]: the chunk-relative
+// layout of ew_moments_tile has pinst0 = 0, a producer's partials are indexed by the global instance.
+__global__ __launch_bounds__(kBlock) void ew_finalize(size_t n, size_t inst0, size_t pinst0,
+                                                      const double* __restrict__ a_in_d,
+                                                      const double* __restrict__ partials,
+                                                      const unsigned long long* __restrict__ pcount, int nblk,
+                                                      MsgOut out, double* __restrict__ scal) {
+    __shared__ double smem[kBlock / kWave];
+    __shared__ unsigned long long smem_u[kBlock / kWave];
+    const size_t bl = blockIdx.x, b = inst0 + bl;
+    const double* pp = partials + (pinst0 + bl) * (size_t)nblk;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += kBlock) s += pp[i];
+    s = block_sum(s, smem);
+    unsigned long long c = 0;
+    if (out.count) {
+        for (int i = threadIdx.x; i < nblk; i += kBlock) c += pcount[(pinst0 + bl) * (size_t)nblk + i];
+        c = block_sum_u64(c, smem_u);
+    }
+    if (threadIdx.x == 0) {
+        const double v = s / (double)n;
+        const double a_in = a_in_d[b];
+        const double a_new = tmath::a_new_of(v, a_in);
+        const double d = out.damping;
+        out.a_new[b] = (d != 0.0) ? d * out.a_old[b] + (1.0 - d) * a_new : a_new;
+        if (out.v) out.v[b] = v;
+        if (out.count) out.count[b] = c;
+        scal[bl] = a_in + a_new;
+    }
+}
+
+// RECOMPUTE = true: r from op.eval on the inputs; false: r from the scratch written by pass 1.
+template <typename T, typename Op, int U, bool RECOMPUTE, bool NTS>
+__global__ __launch_bounds__(kBlock) void ew_apply_tile(Op op, size_t n, size_t inst0, const T* __restrict__ in0,
+                                                        const T* __restrict__ in1, const T* __restrict__ rbuf,
+                                                        const double* __restrict__ scal, MsgOut out) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    const size_t bl = blockIdx.y, b = inst0 + bl;
+    const size_t nv = n / VN;
+    const size_t base = (size_t)blockIdx.x * kBlock * U + threadIdx.x;
+    const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
+    const V* p1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
+    const V* pr = RECOMPUTE ? nullptr : reinterpret_cast<const V*>(rbuf + bl * n);
+    const V* bold = out.b_old ? reinterpret_cast<const V*>(reinterpret_cast<const T*>(out.b_old) + b * n) : nullptr;
+    V* bo = reinterpret_cast<V*>(reinterpret_cast<T*>(out.b_new) + b * n);
+    V* ro = out.r ? reinterpret_cast<V*>(reinterpret_cast<T*>(out.r) + b * n) : nullptr;
+    V v0[U], v1[U], vold[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * kBlock;
+        if (i < nv) {
+            if (RECOMPUTE) {
+                v0[u] = p0[i];
+                if (Op::NIN > 1) v1[u] = p1[i];
+            } else {
+                v0[u] = (Op::TARGET == 0) ? p0[i] : p1[i];        // the target message b
+                v1[u] = pr[i];                                    // r
+            }
+            if (bold) vold[u] = bold[i];
+        }
+    }
+    if (RECOMPUTE) op.setup(b);
+    const T vinv = T(scal[bl]);
+    const T dT = T(out.damping), omd = T(1.0 - out.damping);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * kBlock;
+        if (i < nv) {
+            V vo, vr;
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                T r, tgt;
+                if (RECOMPUTE) {
+                    const T x0 = vget<T>(v0[u], j);
+                    const T x1 = (Op::NIN > 1) ? vget<T>(v1[u], j) : x0;
+                    r = op.eval(x0, x1).r;
+                    tgt = (Op::TARGET == 0) ? x0 : x1;
+                } else {
+                    r = vget<T>(v1[u], j);
+                    tgt = vget<T>(v0[u], j);
+                }
+                T bn = r * vinv - tgt;
+                if (bold) bn = dT * vget<T>(vold[u], j) + omd * bn;
+                vset<T>(vo, j, bn);
+                vset<T>(vr, j, r);
+            }
+            store_vec<T, NTS>(&bo[i], vo);
+            if (ro) store_vec<T, NTS>(&ro[i], vr);
+        }
+    }
+}
+
 // Instances are processed in chunks small enough that pass 2 finds r and b in the
 // 256 MiB Infinity Cache: HBM then sees each input once and b_new once (2T / 3T per
 // component, the algorithmic minimum) although the update is two launches.
@@ -522,9 +699,74 @@ static size_t env_size(const char* name, size_t dflt) {
     return v >= 0 ? (size_t)v : dflt;
 }
 
+// Streaming-tile realisation of one update.  `hint` != nullptr: a producer left sum v_i partials for
+// this very message (prior_hint.h): no pass 1, the message is read once.
+template <typename T, typename Op>
+static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
+                     const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int U = kTileU;
+    const size_t nv = n / VN;
+    const unsigned ntile = (unsigned)((nv + (size_t)kBlock * U - 1) / ((size_t)kBlock * U));
+    if (hint) {
+        store_r = false;
+        ctx->hint_used += 1;
+    }
+    const size_t r_bytes = store_r ? ((batch * n * sizeof(T) + 255) / 256) * 256 : 0;
+    const size_t scal_bytes = ((batch * sizeof(double) + 255) / 256) * 256;
+    const size_t part_bytes = hint ? 0 : batch * (size_t)ntile * (sizeof(double) + sizeof(unsigned long long));
+    int rc = tramp_ws_reserve(ctx, r_bytes + scal_bytes + part_bytes);
+    if (rc) return rc;
+    char* ws = reinterpret_cast<char*>(ctx->ws);
+    T* rbuf = store_r ? reinterpret_cast<T*>(ws) : nullptr;
+    double* scal = reinterpret_cast<double*>(ws + r_bytes);
+    double* partials = reinterpret_cast<double*>(ws + r_bytes + scal_bytes);
+    unsigned long long* pcount = (out.count && !hint) ? reinterpret_cast<unsigned long long*>(partials + batch * (size_t)ntile) : nullptr;
+    MsgOut o = out;
+    if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
+    const T* p0 = reinterpret_cast<const T*>(in0);
+    const T* p1 = reinterpret_cast<const T*>(in1);
+    ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
+    for (size_t inst0 = 0; inst0 < batch; inst0 += 65535) {
+        const unsigned nb = (unsigned)((batch - inst0 < 65535) ? batch - inst0 : 65535);
+        dim3 grid(ntile, nb), block(kBlock);
+        if (hint) {
+            hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, inst0, a_in_d, hint->partials,
+                               (const unsigned long long*)nullptr, hint->nblk, o, scal + inst0);
+        } else {
+            hipLaunchKernelGGL((ew_moments_tile<T, Op, U>), grid, block, 0, ctx->stream, op, n, inst0, p0, p1,
+                               rbuf ? rbuf + inst0 * n : nullptr, partials + inst0 * ntile,
+                               pcount ? pcount + inst0 * ntile : nullptr, out.mask);
+            hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, (size_t)0, a_in_d,
+                               partials + inst0 * ntile, pcount ? pcount + inst0 * ntile : nullptr, (int)ntile, o,
+                               scal + inst0);
+        }
+        // outputs past the Infinity Cache are streamed around the caches (+6 % on the box's copy rate)
+        const bool nts = (double)n * (double)batch * sizeof(T) > 192.0 * 1024 * 1024;
+        if (store_r) {
+            if (nts)
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, true>), grid, block, 0, ctx->stream, op, n, inst0, p0,
+                                   p1, rbuf + inst0 * n, scal + inst0, o);
+            else
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, false>), grid, block, 0, ctx->stream, op, n, inst0,
+                                   p0, p1, rbuf + inst0 * n, scal + inst0, o);
+        } else {
+            if (nts)
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, true>), grid, block, 0, ctx->stream, op, n, inst0, p0,
+                                   p1, (const T*)nullptr, scal + inst0, o);
+            else
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, false>), grid, block, 0, ctx->stream, op, n, inst0, p0,
+                                   p1, (const T*)nullptr, scal + inst0, o);
+        }
+    }
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 template <typename T, typename Op>
 static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0,
-                        const void* in1, const double* a_in_d, const MsgOut& out) {
+                        const void* in1, const double* a_in_d, const MsgOut& out,
+                        const TrampPriorHint* hint = nullptr) {
     TRAMP_REQUIRE(ctx, in0 && out.a_new && out.b_new && a_in_d);
     TRAMP_REQUIRE(ctx, Op::NIN == 1 || in1);
     if (n == 0 || batch == 0) return TRAMP_OK;
@@ -550,6 +792,8 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
         TRAMP_LAUNCH_CHECK(ctx);
         return TRAMP_OK;
     }
+    static const size_t tile_env = env_size("TRAMP_EW_TILE", 1);            // 0: grid-stride kernels only
+    if (vec && tile_env) return run_tiles<T, Op>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
     // chunk: inputs (+ r scratch) of `cb` instances within the cache budget
     size_t cb = (chunk_mb << 20) / (n * sizeof(T) * (Op::NIN + (store_r ? 1 : 0)));
     if (cb < 1) cb = 1;
@@ -607,6 +851,55 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
     } while (0)
 
 // ---------------------------------------------------------------- C ABI: K1, K2, K4, K5, K7
+// ---- producer-fused moments: host side (prior_hint.h)
+static void gb_natural(double rho, double mean, double var, double* a0, double* b0, double* eta) {
+    // natural parameters of the prior (gauss_bernoulli_prior.py:32-36)
+    *a0 = 1.0 / var;
+    *b0 = mean / var;
+    *eta = 0.5 * (*b0 * *b0 / *a0 + log(2 * tmath::kPi / *a0)) - log(rho / (1 - rho));
+}
+
+extern "C" int tramp_prior_hint(tramp_ctx* ctx, int kind, double p0, double p1, double p2, size_t n, size_t batch,
+                                const void* b_d, const double* a_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    ctx->hint.kind = PRIOR_HINT_NONE;
+    ctx->hint.ready = false;
+    if (kind == PRIOR_HINT_NONE) return TRAMP_OK;
+    TRAMP_REQUIRE(ctx, (kind == PRIOR_HINT_GB || kind == PRIOR_HINT_L1) && b_d && a_d && n > 0 && batch > 0);
+    static const size_t fuse_env = getenv("TRAMP_PRIOR_FUSE") ? (size_t)atol(getenv("TRAMP_PRIOR_FUSE")) : 1;
+    if (!fuse_env) return TRAMP_OK;
+    TrampPriorHint& h = ctx->hint;
+    if (kind == PRIOR_HINT_GB) {
+        TRAMP_REQUIRE(ctx, p0 > 0.0 && p0 < 1.0 && p2 > 0.0);
+        gb_natural(p0, p1, p2, &h.p0, &h.p1, &h.p2);
+    } else {
+        TRAMP_REQUIRE(ctx, p0 >= 0.0);
+        h.p0 = p0;
+        h.p1 = h.p2 = 0.0;
+    }
+    h.kind = kind;
+    h.buf = b_d;
+    h.a_msg = a_d;
+    h.n = n;
+    h.batch = batch;
+    h.partials = nullptr;
+    h.nblk = 0;
+    return TRAMP_OK;
+}
+
+// The hint is consumed by the first prior call after it, whether it matches or not.
+static const TrampPriorHint* take_hint(tramp_ctx* ctx, TrampPriorHint* copy, int kind, double p0, double p1,
+                                       double p2, size_t n, size_t batch, const void* b_d, const double* a_d,
+                                       const MsgOut& out) {
+    *copy = ctx->hint;
+    ctx->hint.kind = PRIOR_HINT_NONE;
+    ctx->hint.ready = false;
+    const bool ok = copy->ready && copy->kind == kind && copy->p0 == p0 && copy->p1 == p1 && copy->p2 == p2 &&
+                    copy->n == n && copy->batch == batch && copy->buf == b_d && copy->a_msg == a_d &&
+                    copy->partials && copy->nblk > 0 && !out.count && !out.mask;
+    return ok ? copy : nullptr;
+}
+
 extern "C" int tramp_gb_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
                                   const double* ax_d, const void* bx_d, double rho, double mean,
                                   double var, double damping, const double* a_old_d,
@@ -614,14 +907,15 @@ extern "C" int tramp_gb_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
                                   double* v_d) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, ax_d && rho > 0.0 && rho < 1.0 && var > 0.0);
-    // natural parameters of the prior (gauss_bernoulli_prior.py:32-36)
-    const double a0 = 1.0 / var, b0 = mean / var;
-    const double eta = 0.5 * (b0 * b0 / a0 + log(2 * tmath::kPi / a0)) - log(rho / (1 - rho));
+    double a0, b0, eta;
+    gb_natural(rho, mean, var, &a0, &b0, &eta);
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    TrampPriorHint hc;
+    const TrampPriorHint* hint = take_hint(ctx, &hc, PRIOR_HINT_GB, a0, b0, eta, n, batch, bx_d, ax_d, out);
     GbOp<float> of{ax_d, a0, b0, eta};
     GbOp<double> od{ax_d, a0, b0, eta};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out, hint)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out, hint)));
 }
 
 extern "C" int tramp_l1_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
@@ -632,10 +926,12 @@ extern "C" int tramp_l1_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, ax_d && gamma >= 0.0);
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, count_d, mask_d};
+    TrampPriorHint hc;
+    const TrampPriorHint* hint = take_hint(ctx, &hc, PRIOR_HINT_L1, gamma, 0.0, 0.0, n, batch, bx_d, ax_d, out);
     L1Op<float> of{ax_d, gamma};
     L1Op<double> od{ax_d, gamma};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out, hint)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out, hint)));
 }
 
 extern "C" int tramp_binary_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,

@@ -602,11 +602,15 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
     FZ_HIP(fz, hipMemcpyAsync(sh.data(), sing_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
     FZ_HIP(fz, hipStreamSynchronize(st));
     const double smax = sh[0];
-    // second level for the singular values the Gram form cannot resolve (below 1e-5 sigma_max):
-    // the c trailing singular directions are re-factorised from the Gram matrix of their own rows
-    size_t c = 0;
-    while (c < k && sh[k - 1 - c] <= 1e-5 * smax) ++c;
-    if (c > 0 && smax > 0.0) {
+    // further levels for the singular values a Gram matrix cannot resolve (below 1e-5 of its largest):
+    // the trailing singular directions are re-factorised from the Gram matrix of their own rows, whose
+    // entries are formed without cancellation; each level gains five more decades (three levels reach
+    // 1e-15 sigma_max, LAPACK's absolute accuracy)
+    size_t lo = 0;
+    for (int level = 0; level < 3 && smax > 0.0; ++level) {
+        size_t c = 0;
+        while (c < k - lo && sh[k - 1 - c] <= 1e-5 * sh[lo]) ++c;
+        if (c == 0 || c == k - lo) break;
         const size_t j0 = k - c;
         double* G2 = fz.alloc(c * c);
         double* D2 = fz.alloc(c);
@@ -639,6 +643,8 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
         fz.release(Uo);
         FZ_HIP(fz, hipMemcpyAsync(sh.data(), sing_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
         FZ_HIP(fz, hipStreamSynchronize(st));
+        lo = j0;
+        if (!(sh[lo] > 0.0)) break;
     }
     // rank with NumPy's tolerance (np.linalg.matrix_rank), floored at what two Gram levels resolve
     double tol = smax * (double)big * kEps;

@@ -1,6 +1,7 @@
 // fft_pow2.h - internal interface of the two-pass mixed-radix (2^a 5^b) complex FFT (fft_pow2.hip).
 #pragma once
 #include "common.h"
+#include "prior_hint.h"
 
 // h = G * LB; stage lists of the two passes (radices 5 / 4 / 2), with for every stage the stride
 // between a butterfly's legs (sub) and the factor that turns an offset into a w_h exponent (mul).
@@ -36,6 +37,7 @@ struct Fft2Epi {
     const void* b_old;    // may alias out
     void* out;            // [batch, 2 h]; null: no epilogue (plain store)
     void* r_out;          // optional
+    PriorHintDev hint;    // kind != 0: the consumer is a separable prior - leave sum v_i per tile (prior_hint.h)
 };
 
 // false when h is not 2^a 5^b or does not split into a [G <= 320] x [512 <= LB <= 4096] pair

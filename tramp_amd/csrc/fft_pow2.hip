@@ -207,6 +207,9 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
         const C* bold = epi.damping != 0.0 ? reinterpret_cast<const C*>(epi.b_old) + tf * h : nullptr;
         C* bo = reinterpret_cast<C*>(epi.out) + tf * h;
         C* ro = epi.r_out ? reinterpret_cast<C*>(epi.r_out) + tf * h : nullptr;
+        double vi = 0.0;
+        PriorHintEval<T> he;
+        if (epi.hint.kind) he.setup(epi.hint, tf);
         for (int g = r0; g < G; g += rstep) {
             const size_t i = (size_t)g * LB + c0 + c;
             const C r = tile[g * P + c], bi = bin[i];
@@ -218,6 +221,20 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
             }
             bo[i] = bn;
             if (ro) ro[i] = r;
+            if (epi.hint.kind) vi += he.v(bn.x) + he.v(bn.y);
+        }
+        if (epi.hint.kind) {
+            // sum over the workgroup (up to 16 waves; the tile's LDS is free again after the barrier)
+            __syncthreads();
+            double* red = reinterpret_cast<double*>(smem_raw);
+            vi = wave_sum(vi);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vi;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+                for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t += red[w];
+                epi.hint.partials[tf * (size_t)epi.hint.nblk + blockIdx.x % tiles_per_tf] = t;
+            }
         }
         return;
     }
@@ -457,9 +474,13 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
         // `in` (the permuted spectrum) is overwritten by the block pass
         hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh,
                            (C*)const_cast<void*>(in), (const C*)pl->tw_blk);
-        if (epi && epi->out)
+        if (epi && epi->out) {
+            Fft2Epi e2 = *epi;
+            // message length 2 h reals per instance, one partial per tile
+            prior_hint_arm(ctx, e2.out, 2 * sh.h, batch, (int)(sh.LB / kC1), &e2.hint);
             hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh,
-                               (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, *epi);
+                               (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, e2);
+        }
         else
             hipLaunchKernelGGL((fft_strided_kernel<T, true>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh, (const C*)in,
                                (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, Fft2Epi{});

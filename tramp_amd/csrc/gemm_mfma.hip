@@ -688,10 +688,10 @@ void gemm_nt4_ring_kernel(size_t R, size_t C, size_t B, const double* __restrict
 
 // ------------------------------------------------------------------------------ fold + epilogue
 template <typename T>
-__device__ __forceinline__ void mfma_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
+__device__ __forceinline__ T mfma_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
     if (e.mode == 0) {
         reinterpret_cast<T*>(e.out)[b * len + idx] = T(acc);
-        return;
+        return T(acc);
     }
     const T bin = reinterpret_cast<const T*>(e.b_in)[b * len + idx];
     const double a_in = e.a_in[b];
@@ -705,17 +705,31 @@ __device__ __forceinline__ void mfma_epilogue(const LinEpi& e, size_t b, size_t 
     }
     reinterpret_cast<T*>(e.out)[b * len + idx] = bn;
     if (e.r_out) reinterpret_cast<T*>(e.r_out)[b * len + idx] = T(r);
+    return bn;
 }
 
+// Sums the split-K partials in fixed order and applies the message update.  When the consumer of the
+// message is a separable prior (prior_hint.h) the block also leaves sum_i v_i of that prior's
+// posterior, so that the prior update needs no pass of its own over the message.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void mfma_fold_kernel(size_t len, size_t B, int nsplit,
                                                            const double* __restrict__ partials, LinEpi epi) {
+    __shared__ double smem[kBlock / kWave];
     const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const size_t b = blockIdx.y;
-    if (idx >= len) return;
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += partials[((size_t)k * B + b) * len + idx];
-    mfma_epilogue<T>(epi, b, idx, len, s);
+    double vi = 0.0;
+    PriorHintEval<T> he;
+    if (epi.hint.kind) he.setup(epi.hint, b);
+    if (idx < len) {
+        double s = 0.0;
+        for (int k = 0; k < nsplit; ++k) s += partials[((size_t)k * B + b) * len + idx];
+        const T bn = mfma_epilogue<T>(epi, b, idx, len, s);
+        if (epi.hint.kind) vi = he.v(bn);
+    }
+    if (epi.hint.kind) {
+        vi = block_sum(vi, smem);
+        if (threadIdx.x == 0) epi.hint.partials[b * (size_t)epi.hint.nblk + blockIdx.x] = vi;
+    }
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -803,7 +817,9 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
 #undef LAUNCH_NT4
 #undef LAUNCH_NN4
             dim3 g4((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
-            hipLaunchKernelGGL((mfma_fold_kernel<T>), g4, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, epi);
+            LinEpi e4 = epi;
+            lin_arm_hint(ctx, e4, len, batch, (int)g4.x);
+            hipLaunchKernelGGL((mfma_fold_kernel<T>), g4, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, e4);
             TRAMP_LAUNCH_CHECK(ctx);
             return TRAMP_OK;
         }
@@ -835,7 +851,9 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
 #undef LAUNCH_NT
 #undef LAUNCH_NN
     dim3 g2((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
-    hipLaunchKernelGGL((mfma_fold_kernel<T>), g2, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, epi);
+    LinEpi e2 = epi;
+    lin_arm_hint(ctx, e2, len, batch, (int)g2.x);
+    hipLaunchKernelGGL((mfma_fold_kernel<T>), g2, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, e2);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }

@@ -1,6 +1,7 @@
 // linear.h - internal types shared by linear.hip and gemm_mfma.hip.
 #pragma once
 #include "common.h"
+#include "prior_hint.h"
 
 struct tramp_linear {
     int dtype;
@@ -36,7 +37,12 @@ struct LinEpi {
     const void* b_old;        // [batch, len] or null
     void* out;                // [batch, len]
     void* r_out;              // [batch, len] or null
+    PriorHintDev hint;        // kind != 0: also leave sum v_i partials of the consuming prior (prior_hint.h)
 };
+
+// If the context holds a hint for the buffer this epilogue writes (same length and batch), arm the
+// epilogue with it.  `nblk` = blocks per instance of the kernel that will apply the epilogue.
+bool lin_arm_hint(tramp_ctx* ctx, LinEpi& epi, size_t len, size_t batch, int nblk);
 
 int lin_square(tramp_ctx* ctx, const double* in, double* out, size_t n);
 

@@ -76,10 +76,10 @@ __global__ __launch_bounds__(kBlock) void lin_variance_kernel(const double* __re
 
 // ---------------------------------------------------------------- fused epilogue
 template <typename T>
-__device__ __forceinline__ void lin_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
+__device__ __forceinline__ T lin_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
     if (e.mode == 0) {
         reinterpret_cast<T*>(e.out)[b * len + idx] = T(acc);
-        return;
+        return T(acc);
     }
     const T bin = reinterpret_cast<const T*>(e.b_in)[b * len + idx];
     const double a_in = e.a_in[b];
@@ -94,6 +94,13 @@ __device__ __forceinline__ void lin_epilogue(const LinEpi& e, size_t b, size_t i
     }
     reinterpret_cast<T*>(e.out)[b * len + idx] = bn;
     if (e.r_out) reinterpret_cast<T*>(e.r_out)[b * len + idx] = T(r);
+    return bn;
+}
+
+bool lin_arm_hint(tramp_ctx* ctx, LinEpi& epi, size_t len, size_t batch, int nblk) {
+    epi.hint.kind = PRIOR_HINT_NONE;
+    if (epi.mode != 1) return false;
+    return prior_hint_arm(ctx, epi.out, len, batch, nblk, &epi.hint);
 }
 
 // ---------------------------------------------------------------- NT: row dot products
@@ -223,12 +230,22 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void nn_fold_kernel(size_t C, int nb, int nchunk,
                                                          const double* __restrict__ partials, size_t b0,
                                                          LinEpi epi) {
+    __shared__ double smem[kBlock / kWave];
     const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const int b = blockIdx.y;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < nchunk; ++k) s += partials[((size_t)k * nb + b) * C + c];
-    lin_epilogue<T>(epi, b0 + b, c, C, s);
+    double vi = 0.0;
+    PriorHintEval<T> he;
+    if (epi.hint.kind) he.setup(epi.hint, b0 + b);
+    if (c < C) {
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += partials[((size_t)k * nb + b) * C + c];
+        const T bn = lin_epilogue<T>(epi, b0 + b, c, C, s);
+        if (epi.hint.kind) vi = he.v(bn);
+    }
+    if (epi.hint.kind) {                       // uniform across the block
+        vi = block_sum(vi, smem);
+        if (threadIdx.x == 0) epi.hint.partials[(b0 + b) * (size_t)epi.hint.nblk + blockIdx.x] = vi;
+    }
 }
 
 // ---------------------------------------------------------------- launchers (VALU path)
@@ -271,9 +288,12 @@ static int launch_nn(tramp_ctx* ctx, size_t R, size_t C, int nb, const T* mat, c
 
 template <typename T>
 int matvec_valu(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch, const void* mat_d, const void* x_d,
-                const LinEpi& epi) {
+                const LinEpi& epi_in) {
     const T* mat = reinterpret_cast<const T*>(mat_d);
     const T* x = reinterpret_cast<const T*>(x_d);
+    LinEpi epi = epi_in;
+    epi.hint.kind = PRIOR_HINT_NONE;
+    if (!nt) lin_arm_hint(ctx, epi, C, batch, (int)((C + kBlock - 1) / kBlock));   // nn_fold_kernel's grid
     for (size_t b0 = 0; b0 < batch; b0 += TRAMP_GEMV_MAX_BATCH) {
         const int nb = (int)((batch - b0 < TRAMP_GEMV_MAX_BATCH) ? batch - b0 : TRAMP_GEMV_MAX_BATCH);
         int rc = TRAMP_OK;
@@ -474,9 +494,19 @@ extern "C" int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int o
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void lin_epi_apply_kernel(size_t len, const T* __restrict__ w, LinEpi epi) {
+    __shared__ double smem[kBlock / kWave];
     const size_t b = blockIdx.y;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock)
-        lin_epilogue<T>(epi, b, i, len, (double)w[b * len + i]);
+    double vi = 0.0;
+    PriorHintEval<T> he;
+    if (epi.hint.kind) he.setup(epi.hint, b);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
+        const T bn = lin_epilogue<T>(epi, b, i, len, (double)w[b * len + i]);
+        if (epi.hint.kind) vi += he.v(bn);
+    }
+    if (epi.hint.kind) {
+        vi = block_sum(vi, smem);
+        if (threadIdx.x == 0) epi.hint.partials[b * (size_t)epi.hint.nblk + blockIdx.x] = vi;
+    }
 }
 
 static int lin_copy_u(tramp_ctx* ctx, tramp_linear* lin, size_t batch, const void* bx_d) {
@@ -641,6 +671,7 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
             ProfScope ps(ctx, PROF_EW, (double)batch * k * dtype_size(dtype) * (damping != 0.0 ? 4 : 3), 0);
             dim3 ge((unsigned)((k + kBlock * 4 - 1) / (kBlock * 4) > 1024 ? 1024 : (k + kBlock * 4 - 1) / (kBlock * 4)),
                     (unsigned)batch);
+            lin_arm_hint(ctx, epi, k, batch, (int)ge.x);
             if (dtype == TRAMP_F64)
                 hipLaunchKernelGGL((lin_epi_apply_kernel<double>), ge, dim3(kBlock), 0, ctx->stream, k,
                                    (const double*)lin->w, epi);

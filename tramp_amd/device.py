@@ -5,6 +5,7 @@ Ownership: the Python wrapper owns device buffers through
 allocate; outputs go to caller-provided buffers.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -46,6 +47,9 @@ class Event:
         self.handle = None
 
 
+_tls = threading.local()
+
+
 class Context:
     """One per GPU: a HIP stream plus the reduction workspace (tramp_ctx)."""
 
@@ -64,6 +68,10 @@ class Context:
         for the duration of the call (a temporary such as ``ctx.array(x)`` is therefore safe to pass directly;
         ``ctx.array(x).ptr`` is not - the array dies, and is freed, before the launch is issued)."""
         raw = [a.ptr if isinstance(a, DeviceArray) else a for a in args]
+        if getattr(_tls, "current", None) is not self:
+            # HIP's current device is per host thread: switch when this thread last drove another context
+            self.lib.tramp_ctx_make_current(self.handle)
+            _tls.current = self
         rc = getattr(self.lib, name)(self.handle, *raw)
         if rc != _lib.OK:
             _lib.check(rc, name, self.handle)
@@ -88,6 +96,12 @@ class Context:
 
     def event(self):
         return Event(self)
+
+    def prior_hint_stats(self):
+        "(producers that left fused prior moments, prior updates that consumed them) - csrc/prior_hint.h"
+        a, u = C.c_ulonglong(), C.c_ulonglong()
+        self._call("tramp_prior_hint_stats", C.byref(a), C.byref(u))
+        return a.value, u.value
 
     def close(self):
         if self.handle:

@@ -110,6 +110,10 @@ class GaussBernoulliPrior(Prior):
             return a_new, b_new
         return super().compute_forward_message(ax, bx, **kw)
 
+    def moment_hint(self):
+        "(kind, p0, p1, p2) for tramp_prior_hint: the producer of this prior's input message can leave sum v_i"
+        return (1, float(self.rho), float(self.mean), float(self.var)) if self.isotropic else None
+
     def compute_forward_error(self, ax):
         """SE error E_b[v(ax, b)] (base_prior.py:66-69, beliefs_measure
         gauss_bernoulli_prior.py:116-122): quadrature kernel K13."""
@@ -182,6 +186,9 @@ class MAP_L1NormPrior(Prior):
             a_new, b_new, _, _ = self._diag(ax, bx)
             return a_new, b_new
         return super().compute_forward_message(ax, bx, **kw)
+
+    def moment_hint(self):
+        return (2, float(self.gamma), 0.0, 0.0) if self.isotropic else None
 
     def compute_forward_error(self, ax):
         raise NotImplementedError      # as the reference (map_L1_norm_prior.py:84-85)

@@ -33,6 +33,8 @@ class _Msg:
 
 
 class TreeExpectationPropagation(ExpectationPropagation):
+    _device_monitor = False      # stopping rule and NaN guard evaluated on the host, on the scalar tables
+
     """Gaussian EP on a tree of factors and variables (tramp/algos/expectation_propagation.py:5-32)."""
 
     def __init__(self, model, batch=None, ctx=None):
@@ -66,8 +68,8 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.batch = int(batch)
         self.n_iter = 0
         self.n_iter_instance = np.zeros(self.batch, dtype=int)
+        self.status = np.zeros(self.batch, dtype=int)
         self._allocated = False
-        self._frozen_r = None
         self._find_tree_rotations()
         from .algos import EarlyStoppingEP
         self.default_stopping = EarlyStoppingEP()
@@ -111,6 +113,7 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.r = [ctx.zeros((B, int(np.prod(self.shapes[v.id]))), self.dtype) for v in self.variables]
         self._const_msg = {}
         self._const_done = set()
+        self._allocate_monitor(len(keys))
         self._allocated = True
 
     def init_message_dag(self, initializer):
