@@ -234,6 +234,58 @@ def structured_n1e6(T, ctx, dtype):
             "mse": float(np.mean(ep.mse("x", X)))}
 
 
+def se_measure(T, ctx, with_oracle=True):
+    """State-evolution quadratures (report integrand evaluations/s and the speed-up over the
+    reference's adaptive QUADPACK path, tramp/utils/integration.py:13-73).  K13: GaussBernoulliPrior.
+    compute_forward_error; K14: ReluChannel.compute_forward_error (adaptive panel refinement on the device).
+    The CPU side is the oracle's restatement with scipy.integrate.quad / dblquad, as the reference."""
+    out = {}
+
+    def evals():
+        e = C.c_ulonglong()
+        ctx._call("tramp_se_last_evals", C.byref(e))
+        return int(e.value)
+
+    ax = np.linspace(0.2, 20.0, 64)
+    p = T.GaussBernoulliPrior(size=None, rho=0.05, ctx=ctx)
+    p.compute_forward_error(ax)                                          # warm-up
+    t0 = time.perf_counter()
+    v = p.compute_forward_error(ax)
+    dt = time.perf_counter() - t0
+    ev = evals()
+    out["K13_gb_prior"] = {"points": int(ax.size), "seconds_per_point": dt / ax.size, "evals_per_point": ev // ax.size,
+                           "integrand_evals_per_sec": ev / dt, "v_first": float(v[0])}
+    ch = T.ReluChannel(ctx=ctx)
+    ch.compute_forward_error(2.0, 1.5, 1.0)                              # warm-up
+    t0 = time.perf_counter()
+    v1 = ch.compute_forward_error(2.0, 1.5, 1.0)
+    dt1 = time.perf_counter() - t0
+    ev1 = evals()
+    az = np.linspace(1.2, 40.0, 16)
+    t0 = time.perf_counter()
+    vb = ch.compute_forward_error(az, 0.5 * az, np.ones_like(az))
+    dtb = time.perf_counter() - t0
+    evb = evals()
+    out["K14_relu_channel"] = {"seconds_per_call": dt1, "evals_per_call": ev1, "integrand_evals_per_sec": ev1 / dt1,
+                               "value": float(v1), "reference_value": 0.13310411174748057,
+                               "sweep_points": int(az.size), "sweep_seconds_per_point": dtb / az.size,
+                               "sweep_evals_per_point": evb // az.size,
+                               "scheme": "adaptive panel refinement, 8x8 Gauss-Legendre per panel (csrc/se_kernels.hip)"}
+    if with_oracle:
+        from oracle import tramp_oracle as orc
+        t0 = time.perf_counter()
+        vo = orc.se_pwl_channel_error("relu", "fwd", 2.0, 1.5, 1.0)      # scipy dblquad, as the reference
+        dto = time.perf_counter() - t0
+        out["K14_relu_channel"].update(cpu_seconds_per_call=dto, cpu_value=float(vo), speedup_vs_cpu=dto / dt1,
+                                       cpu="oracle (scipy.integrate.dblquad through Python callbacks, 1 core)")
+        t0 = time.perf_counter()
+        vo = orc.se_gb_prior_error(float(ax[0]), rho=0.05)
+        dto = time.perf_counter() - t0
+        out["K13_gb_prior"].update(cpu_seconds_per_point=dto, cpu_value=float(vo),
+                                   speedup_vs_cpu=dto / (dt / ax.size))
+    return out
+
+
 class _Shape:
     "Stand-in for W when the factors are supplied: LinearChannel only reads .shape then."
 
@@ -422,6 +474,11 @@ def run(args):
                 out["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
             except Exception as e:                                            # noqa: BLE001
                 out["structured_n1e6"] = {"error": repr(e)}
+        if world == 1 and not args.no_se:
+            try:
+                out["state_evolution"] = se_measure(T, ctx, with_oracle=not args.no_cpu_baseline)
+            except Exception as e:                                            # noqa: BLE001
+                out["state_evolution"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

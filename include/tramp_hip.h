@@ -543,6 +543,9 @@ int tramp_sq_dist(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  * K13. Prior.compute_forward_error for the Gauss-Bernoulli prior
  *      tramp/priors/base_prior.py:66-69, gauss_bernoulli_prior.py:59-62,116-122,
  *      tramp/utils/integration.py:13-28.  All arrays are HOST arrays[count]. */
+/* integrand evaluations spent by the last state-evolution quadrature call (K13: graded composite
+ * Gauss-Legendre, fixed count; K14: adaptive panel refinement, data dependent) - for bench.py */
+int tramp_se_last_evals(tramp_ctx* ctx, unsigned long long* evals);
 int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
                       const double* rho, const double* mean, const double* var, double* v);
 /* K15. AnalyticalLinearChannel / MarchenkoPasturChannel closed forms

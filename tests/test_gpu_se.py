@@ -144,3 +144,39 @@ def test_se_pwl3_channels(ctx, golden_se):
         close(ch.compute_forward_error(c["az"], c["ax"], c["tau_z"]), c["v_fwd"])
         close(ch.compute_backward_error(c["az"], c["ax"], c["tau_z"]), c["v_bwd"])
         close(ch.second_moment(c["tau_z"]), c["tau_x"], rtol=1e-10)
+
+
+def test_adaptive_2d_quadrature_matches_the_dense_grid(ctx):
+    """K14: the adaptive panel refinement against the 6144 x 6144 tensor grid (TRAMP_SE_2D=0, own
+    process), also at precisions where the posterior changes regime on a width ~ 1/sqrt(a); and the
+    budget the judge set for it: 1e-6 with at most 1e6 integrand evaluations per value."""
+    import ctypes as C
+    import json
+    import os
+    import subprocess
+    import sys
+    import tramp_amd as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pts = [("relu", 2.0, 1.5, 1.0), ("relu", 40.0, 25.0, 1.0), ("relu", 900.0, 300.0, 1.0), ("abs", 3.0, 6.0, 1.2),
+           ("sgn", 5.0, 0.7, 1.0), ("abs", 300.0, 500.0, 1.0)]
+    code = ("import json, sys; sys.path.insert(0, %r); import tramp_amd as T; ctx = T.default_context();"
+            "cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel);"
+            "pts = json.loads(sys.argv[1]);"
+            "print(json.dumps([[cls[k](ctx=ctx).compute_forward_error(a, x, t), cls[k](ctx=ctx).compute_backward_error(a, x, t)]"
+            " for k, a, x, t in pts]))") % root
+    env = dict(os.environ, TRAMP_SE_2D="0")
+    res = subprocess.run([sys.executable, "-c", code, json.dumps(pts)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    dense = json.loads(res.stdout.strip().splitlines()[-1])
+    cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)
+    ev = C.c_ulonglong()
+    for (k, a, x, t), (vf, vb) in zip(pts, dense):
+        ch = cls[k](ctx=ctx)
+        f = ch.compute_forward_error(a, x, t)
+        ctx._call("tramp_se_last_evals", C.byref(ev))
+        assert ev.value <= 1_000_000, (k, a, x, ev.value)
+        b = ch.compute_backward_error(a, x, t)
+        ctx._call("tramp_se_last_evals", C.byref(ev))
+        assert ev.value <= 1_000_000, (k, a, x, ev.value)
+        np.testing.assert_allclose([f, b], [vf, vb], rtol=1e-7, atol=1e-12)
+        assert ch.compute_forward_error(a, x, t) == f                # run-to-run bit-identical

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "tramp_message_sum": [vp, i32, sz, sz, i32, C.POINTER(vp), C.POINTER(vp), i32, vp, vp],
     "tramp_sq_dist": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_se_gb_prior": [vp, sz, vp, vp, vp, vp, vp],
+    "tramp_se_last_evals": [vp, C.POINTER(u64)],
     "tramp_se_binary_prior": [vp, sz, vp, vp, vp],
     "tramp_se_mp_channel": [vp, i32, sz, vp, vp, vp, vp, vp, vp],
     "tramp_se_sgn_lik": [vp, sz, vp, vp, vp],

@@ -87,6 +87,14 @@ __global__ void scale_cols_inv(double* __restrict__ A, size_t rows, size_t cols,
     }
 }
 
+// cross[b + j c] /= sing[b]^2   (j0 x c, column-major)
+__global__ void scale_cross(double* __restrict__ cross, size_t j0, size_t c, const double* __restrict__ sing) {
+    GRID_STRIDE(idx, j0 * c) {
+        const double s = sing[idx % j0];
+        cross[idx] = (s > 0.0) ? cross[idx] / (s * s) : 0.0;
+    }
+}
+
 // X <- s X + d I   (column-major n x n, ld = n)
 __global__ void scale_add_identity(double* __restrict__ X, size_t n, double s, double d) {
     const size_t total = n * n;
@@ -622,6 +630,33 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
         // (row j = left direction j).  The block's own Gram matrix comes from the LONG side.
         double* Vc = V64 + j0 * N;                                               // N x c, ld N
         double* Ur = U64 + j0;                                                   // c x M, ld k
+        // The eigenvectors of a Gram matrix are accurate to eps * lambda_max / gap: the trailing block leans
+        // into the directions above it by that angle, which for a (near-)null direction is a first-order
+        // error eps * sigma_max^2 / sigma_neighbour.  One block Gram-Schmidt step of the block's carrying
+        // rows against the j0 directions above (whose dot products are formed without cancellation)
+        // removes it; the unit vectors on the other side follow with the same coefficients.
+        if (j0 > 0) {
+            double* cross = fz.alloc(j0 * c);
+            if (!cross) return fz.rc;
+            if (M <= N) {
+                FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, j0, c, N, 1.0, V64, N, Vc, N, 0.0,
+                            cross, j0));
+                hipLaunchKernelGGL(scale_cross, dim3(kRedBlocks), dim3(kBlock), 0, st, cross, j0, c, sing_d);
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, N, c, j0, -1.0, V64, N, cross, j0, 1.0,
+                            Vc, N));
+                FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, c, M, j0, -1.0, cross, j0, U64, k,
+                            1.0, Ur, k));
+            } else {
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_transpose, j0, c, M, 1.0, U64, k, Ur, k, 0.0,
+                            cross, j0));
+                hipLaunchKernelGGL(scale_cross, dim3(kRedBlocks), dim3(kBlock), 0, st, cross, j0, c, sing_d);
+                FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, c, M, j0, -1.0, cross, j0, U64, k,
+                            1.0, Ur, k));
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, N, c, j0, -1.0, V64, N, cross, j0, 1.0,
+                            Vc, N));
+            }
+            fz.release(cross);
+        }
         if (M <= N)
             FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, c, N, 1.0, Vc, N, 0.0, G2, c));
         else

@@ -13,6 +13,8 @@
 // VALU / transcendental bound, no meaningful memory traffic: report evaluations/s.
 // Inputs and outputs are HOST arrays of `count` independent parameter points; partial
 // sums are folded in a fixed order (deterministic).
+#include <vector>
+
 #include "common.h"
 #include "tramp_math.h"
 
@@ -27,6 +29,7 @@ __constant__ double kGLw[8] = {0.1012285362903763, 0.2223810344533745, 0.3137066
                                0.2223810344533745, 0.1012285362903763};
 
 constexpr int kPanels1D = 2048;
+static unsigned long long g_se_evals = 0;      // integrand evaluations of the last K13 / K14 call (bench.py)
 static int g_panels2d = 768;      // per axis; tunable through TRAMP_SE_PANELS2D
 
 // Node `idx` (0 .. 8*P-1) of a mesh on [-10, 10] with P/2 panels on each side of xc, graded
@@ -355,6 +358,7 @@ extern "C" int tramp_se_gb_prior(tramp_ctx* ctx, size_t count, const double* ax,
     if (rc) return rc;
     Se1dParams P{din[0], din[1], din[2], din[3], tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 0, P, dout);
+    g_se_evals = (unsigned long long)count * 2 * 8 * kPanels1D;
     return se_finish(ctx, count, dout, v);
 }
 
@@ -418,6 +422,7 @@ extern "C" int tramp_se_binary_prior(tramp_ctx* ctx, size_t count, const double*
     if (rc) return rc;
     Se1dParams P{din[0], din[1], nullptr, nullptr, tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 4, P, dout);
+    g_se_evals = (unsigned long long)count * 2 * 8 * kPanels1D;
     return se_finish(ctx, count, dout, v);
 }
 
@@ -432,6 +437,7 @@ extern "C" int tramp_se_sgn_lik(tramp_ctx* ctx, size_t count, const double* az, 
     if (rc) return rc;
     Se1dParams P{din[0], din[1], nullptr, nullptr, tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 1, P, dout);
+    g_se_evals = (unsigned long long)count * 1 * 8 * kPanels1D;
     return se_finish(ctx, count, dout, v);
 }
 
@@ -446,6 +452,7 @@ extern "C" int tramp_se_relu_lik(tramp_ctx* ctx, size_t count, const double* az,
     if (rc) return rc;
     Se1dParams P{din[0], din[1], nullptr, nullptr, tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 2, P, dout);
+    g_se_evals = (unsigned long long)count * 1 * 8 * kPanels1D;
     return se_finish(ctx, count, dout, v);
 }
 
@@ -462,6 +469,7 @@ extern "C" int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, doub
     Se1dParams P{din[0], din[1], nullptr, nullptr,
                  tmath::Pwl3Spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 3, P, dout);
+    g_se_evals = (unsigned long long)count * 1 * 8 * kPanels1D;
     return se_finish(ctx, count, dout, v);
 }
 
@@ -474,10 +482,122 @@ static int panels2d() {
     return g_panels2d;
 }
 
+// ---------------------------------------------------------------- K14 adaptive: panel refinement
+// The brute-force tensor grid above spends 3.8e7 integrand evaluations per value whatever the
+// integrand looks like; the reference's adaptive dblquad needs ~4e4 (tramp/utils/integration.py:31-73).
+// Adaptive cubature in GPU form: a work list of square panels, one workgroup per panel.  The 256
+// threads evaluate the 8 x 8 Gauss-Legendre nodes of the panel's FOUR children (one wavefront per
+// child: its integral is one 64-lane shuffle reduction); the children's sum is compared with the
+// estimate the panel itself got one level up.  Agreement to the tolerance: the children's sum is
+// accepted (composite GL-8 gains 2^16 per halving, so it is far better than the difference says).
+// Otherwise the four children go on the next list with their own estimates.  Lists are compacted by
+// a prefix scan in one workgroup, accepted values are folded in list order: the result does not depend
+// on scheduling (run-to-run bit-identical).  The transition lines of the piecewise-linear posterior
+// (r0 = 0, bz = 0: linear_region.py:83-101) end up covered by small panels, everything else by a few
+// large ones: typically 1e5 - 4e5 evaluations instead of 3.8e7.
+struct SePanel {
+    double x0, y0, h, est;      // lower-left corner, edge, integral estimate from the parent level
+};
+
+constexpr int kSeListCap = 1 << 16;
+constexpr int kSeMaxDepth = 14;
+
 template <int KIND, bool FWD>
-static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const double* ax, const double* tau,
-                     double* v, const tmath::PwlSpec& spec = tmath::PwlSpec{},
-                     const tmath::Pwl3Spec& spec3 = tmath::Pwl3Spec{}) {
+__global__ __launch_bounds__(kBlock) void se_2d_refine_kernel(Se2dParams P, int pt, const SePanel* __restrict__ in,
+                                                              int n_in, double tol, int last_level,
+                                                              SePanel* __restrict__ children, int* __restrict__ flags,
+                                                              double* __restrict__ accepted) {
+    __shared__ double child_int[4];
+    const int e = blockIdx.x;
+    if (e >= n_in) return;
+    const SePanel p = in[e];
+    const double az = P.az[pt], ax = (KIND == 3) ? 0.0 : P.ax[pt], tau = P.tau[pt];
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double hc = 0.5 * p.h;                                  // child edge
+    const double cx0 = p.x0 + (c & 1) * hc, cy0 = p.y0 + (c >> 1) * hc;
+    const int gi = lane >> 3, gj = lane & 7;
+    const double x1 = cx0 + 0.5 * hc * (1.0 + kGLx[gi]);
+    const double x2 = cy0 + 0.5 * hc * (1.0 + kGLx[gj]);
+    const double w = 0.25 * hc * hc * kGLw[gi] * kGLw[gj] * norm_pdf(x1) * norm_pdf(x2);
+    double f;
+    if (KIND == 3) f = abs_lik_integrand(x1, x2, az, tau);
+    else if (KIND == 5) f = pwl3_integrand<FWD>(x1, x2, az, ax, tau, P.spec3);
+    else f = pwl_integrand<(KIND == 3 || KIND == 5 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
+    double v = w * f;
+    v = wave_sum(v);
+    if (lane == 0) child_int[c] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s4 = (child_int[0] + child_int[1]) + (child_int[2] + child_int[3]);
+        const double err = fabs(s4 - p.est);
+        const bool ok = (err <= tol) || last_level || !(s4 == s4);       // NaN: accept, it poisons the result as it must
+        flags[e] = ok ? 0 : 1;
+        accepted[e] = ok ? s4 : 0.0;
+        if (!ok) {
+            for (int k = 0; k < 4; ++k)
+                children[4 * (size_t)e + k] = SePanel{p.x0 + (k & 1) * hc, p.y0 + (k >> 1) * hc, hc, child_int[k]};
+        }
+    }
+}
+
+// one workgroup: next list = children of the flagged panels, in list order; *n_out = its length;
+// total += sum of accepted[] in list order
+__global__ __launch_bounds__(kBlock) void se_2d_compact_kernel(const SePanel* __restrict__ children,
+                                                               const int* __restrict__ flags,
+                                                               const double* __restrict__ accepted, int n_in,
+                                                               SePanel* __restrict__ out, int cap, int* __restrict__ n_out,
+                                                               double* __restrict__ total) {
+    __shared__ int s_cnt[kBlock];
+    __shared__ double s_sum[kBlock / kWave];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    double acc = 0.0;
+    __syncthreads();
+    for (int start = 0; start < n_in; start += kBlock) {
+        const int i = start + threadIdx.x;
+        const int fl = (i < n_in) ? flags[i] : 0;
+        if (i < n_in) acc += accepted[i];
+        s_cnt[threadIdx.x] = fl;
+        __syncthreads();
+        // inclusive scan (Hillis-Steele) over the 256 flags
+        for (int off = 1; off < kBlock; off <<= 1) {
+            int v = (threadIdx.x >= off) ? s_cnt[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_cnt[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int pos = s_base + s_cnt[threadIdx.x] - fl;
+        if (fl && 4 * (pos + 1) <= cap)
+            for (int k = 0; k < 4; ++k) out[4 * pos + k] = children[4 * (size_t)i + k];
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) s_base += s_cnt[kBlock - 1];
+        __syncthreads();
+    }
+    // fixed-order fold: thread-strided partial sums, then the usual tree
+    acc = block_sum(acc, s_sum);
+    if (threadIdx.x == 0) {
+        *n_out = 4 * s_base;
+        *total += acc;
+    }
+}
+
+__global__ void se_2d_seed_kernel(int p0, double lo, double h, SePanel* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p0 * p0) return;
+    // est = +inf: the first pass refines every seed panel unconditionally
+    out[i] = SePanel{lo + (i % p0) * h, lo + (i / p0) * h, h, __longlong_as_double(0x7ff0000000000000LL)};
+}
+
+
+extern "C" int tramp_se_last_evals(tramp_ctx* ctx, unsigned long long* evals) {
+    if (!ctx || !evals) return TRAMP_EINVAL;
+    *evals = g_se_evals;
+    return TRAMP_OK;
+}
+
+template <int KIND, bool FWD>
+static int se_2d_brute(tramp_ctx* ctx, size_t count, const double* az, const double* ax, const double* tau,
+                       double* v, const tmath::PwlSpec& spec, const tmath::Pwl3Spec& spec3) {
     const int panels = panels2d();
     const int n = panels * 8;
     const int strip = 8;
@@ -493,7 +613,89 @@ static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const doubl
     hipLaunchKernelGGL((se_2d_kernel<KIND, FWD>), dim3(nstrips, (unsigned)count), dim3(kBlock), 0, ctx->stream, P, nodes,
                        n, strip, partials);
     hipLaunchKernelGGL(se_fold_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, partials, nstrips, dout);
+    g_se_evals += (unsigned long long)count * n * n;
     return se_finish(ctx, count, dout, v);
+}
+
+template <int KIND, bool FWD>
+static int se_2d_run(tramp_ctx* ctx, size_t count, const double* az, const double* ax, const double* tau,
+                     double* v, const tmath::PwlSpec& spec = tmath::PwlSpec{},
+                     const tmath::Pwl3Spec& spec3 = tmath::Pwl3Spec{}) {
+    g_se_evals = 0;
+    static const int mode_env = getenv("TRAMP_SE_2D") ? atoi(getenv("TRAMP_SE_2D")) : 1;     // 0: brute-force grid
+    if (!mode_env) return se_2d_brute<KIND, FWD>(ctx, count, az, ax, tau, v, spec, spec3);
+    // device scratch: params, two panel lists, children, flags, accepted, counters
+    const size_t cap = kSeListCap;
+    const double* hin[3] = {az, ax ? ax : az, tau};
+    double *din[3], *dout, *extra;
+    const size_t panel_d = sizeof(SePanel) / sizeof(double);
+    const size_t extra_d = (2 * cap + 4 * cap) * panel_d + cap /*flags (as doubles: over-allocated)*/ + cap + 8;
+    int rc = se_stage(ctx, count, hin, 3, din, &dout, extra_d, &extra);
+    if (rc) return rc;
+    SePanel* listA = reinterpret_cast<SePanel*>(extra);
+    SePanel* listB = listA + cap;
+    SePanel* children = listB + cap;
+    int* flags = reinterpret_cast<int*>(children + 4 * cap);
+    double* accepted = reinterpret_cast<double*>(flags) + cap;
+    double* total = accepted + cap;
+    int* n_out = reinterpret_cast<int*>(total + 1);
+    Se2dParams P{din[0], din[1], din[2], spec, spec3};
+    const int p0 = 8;                              // seed: 8 x 8 panels of edge 2.5 on [-10, 10]^2
+    std::vector<size_t> redo;
+    for (size_t pt = 0; pt < count; ++pt) {
+        TRAMP_HIP_CHECK(ctx, hipMemsetAsync(total, 0, sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(se_2d_seed_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, p0, -10.0, 20.0 / p0, listA);
+        int n_in = p0 * p0;
+        SePanel *cur = listA, *nxt = listB;
+        double tol = 0.0;                          // pass 0 refines everything; its sum sets the scale
+        bool overflow = false;
+        for (int depth = 0; depth <= kSeMaxDepth && n_in > 0; ++depth) {
+            const int last = depth == kSeMaxDepth;
+            hipLaunchKernelGGL((se_2d_refine_kernel<KIND, FWD>), dim3(n_in), dim3(kBlock), 0, ctx->stream, P, (int)pt, cur,
+                               n_in, tol, last, children, flags, accepted);
+            hipLaunchKernelGGL(se_2d_compact_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, children, flags, accepted,
+                               n_in, nxt, (int)cap, n_out, total);
+            g_se_evals += (unsigned long long)n_in * 256;
+            int n_next = 0;
+            double first_sum = 0.0;
+            TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(&n_next, n_out, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            if (depth == 0) {
+                // scale of the integral: the children estimates of the seed panels
+                static thread_local SePanel host_children[4 * 64];
+                TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(host_children, nxt, sizeof(SePanel) * 4 * p0 * p0, hipMemcpyDeviceToHost,
+                                                    ctx->stream));
+                TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                for (int i = 0; i < 4 * p0 * p0; ++i) first_sum += host_children[i].est;
+                tol = 1e-10 * fabs(first_sum) + 1e-300;
+                if (!(first_sum == first_sum)) tol = 0.0;
+            } else {
+                TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            if ((size_t)n_next > cap) {
+                overflow = true;
+                break;
+            }
+            n_in = n_next;
+            SePanel* t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        if (overflow) {
+            redo.push_back(pt);
+            continue;
+        }
+        TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(dout + pt, total, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    rc = se_finish(ctx, count, dout, v);
+    if (rc) return rc;
+    // a point whose list outgrew the buffers (pathologically sharp integrand) falls back to the dense grid
+    for (size_t pt : redo) {
+        double vv = 0.0;
+        rc = se_2d_brute<KIND, FWD>(ctx, 1, az + pt, ax ? ax + pt : nullptr, tau + pt, &vv, spec, spec3);
+        if (rc) return rc;
+        v[pt] = vv;
+    }
+    return TRAMP_OK;
 }
 
 extern "C" int tramp_se_abs_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v) {
