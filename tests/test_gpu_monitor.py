@@ -86,7 +86,7 @@ def test_nan_guard_names_the_message(T, ctx):
     A = ep.A.get()
     A[1, 2] = np.nan
     ep.A.set(A)
-    with pytest.raises(ValueError, match=r"message into x \\(instance 2\\): a is nan"):
+    with pytest.raises(ValueError, match=r"message into x \(instance 2\): a is nan"):
         ep.iterate(max_iter=3, callback=T.PassCallback(), warm_start=True, check_every=3)
 
 

@@ -66,8 +66,8 @@ __global__ void eigvec_to_vt(const double* __restrict__ Q, size_t n, double* __r
     }
 }
 
-__global__ void eig_to_sing(const double* __restrict__ D, size_t n, double* __restrict__ sing) {
-    GRID_STRIDE(j, n) sing[j] = sqrt(fmax(D[n - 1 - j], 0.0));
+__global__ void eig_to_sing(const double* __restrict__ D, size_t n, double* __restrict__ sing, double scale) {
+    GRID_STRIDE(j, n) sing[j] = scale * sqrt(fmax(D[n - 1 - j], 0.0));
 }
 
 // rows of A [rows, cols] (row-major) scaled by 1/sing[row] (0 at or below tol)
@@ -595,7 +595,7 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
     else
         FZ_OK(bsyrk_upper(fz, rocblas_operation_none, N, M, 1.0, W64, N, 0.0, G, N));        // A A^T = W^T W
     FZ_OK(eigh_rec(fz, G, k, D, 0));
-    hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D, k, sing_d);
+    hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D, k, sing_d, 1.0);
     // the thin factor on the long side, rows/columns still carrying their singular value
     if (M <= N) {
         hipLaunchKernelGGL(eigvec_to_uk, dim3(kRedBlocks), dim3(kBlock), 0, st, G, k, U64);
@@ -657,12 +657,16 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
             }
             fz.release(cross);
         }
+        // the block's Gram matrix in units of its own largest singular value: the library eigensolver is
+        // handed an O(1) matrix whatever the absolute scale (1e-20 ... 1e-44 here)
+        const double s0 = sh[j0] > 0.0 ? sh[j0] : 1.0;
+        const double gscale = (1.0 / s0) * (1.0 / s0);
         if (M <= N)
-            FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, c, N, 1.0, Vc, N, 0.0, G2, c));
+            FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, c, N, gscale, Vc, N, 0.0, G2, c));
         else
-            FZ_OK(bsyrk_upper(fz, rocblas_operation_none, c, M, 1.0, Ur, k, 0.0, G2, c));
+            FZ_OK(bsyrk_upper(fz, rocblas_operation_none, c, M, gscale, Ur, k, 0.0, G2, c));
         FZ_OK(eigh_rec(fz, G2, c, D2, 0));
-        hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D2, c, sing_d + j0);
+        hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D2, c, sing_d + j0, s0);
         // Qd (row-major) = eigenvectors in descending order = Qrev; as column-major it is Qrev^T
         hipLaunchKernelGGL(eigvec_to_uk, dim3(kRedBlocks), dim3(kBlock), 0, st, G2, c, Qd);
         // right directions: Vc <- Vc Qrev;  left directions: Ur <- Qrev^T Ur

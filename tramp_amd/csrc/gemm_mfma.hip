@@ -743,9 +743,30 @@ bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch) {
     return (R % e) == 0 && R >= e && (C % e) == 0 && C >= e;
 }
 
-// Split-K factor.  Default 8 (= XCDs: split index == XCD under the round-robin dispatch).
-static int pick_split(tramp_ctx* ctx, bool nt, size_t len, size_t nsteps, int forced) {
-    int s = forced > 0 ? forced : kSplit;
+// Split-K factor: a multiple of 8 (= XCDs: blockIdx = block * nsplit + split, so a split stays on one
+// XCD under the round-robin dispatch).  The workgroups of one pass are all alike, and 3 of them fit a CU
+// (150-160 VGPRs), so a launch runs in ceil(#workgroups / 768) rounds: with 8 splits the 50000 x 100000
+// row-dot pass has 1568 workgroups = 2.04 rounds and pays for 3 (measured 46.3 TFLOP/s against 52.0 with
+// 32 splits = 8.2 -> 9 rounds; profiles/r02/sweep_split_100000.txt).  Take the smallest multiple of 8 whose
+// last round is at least 90 % full, else the best one up to 32 (more splits only add partial traffic).
+static int pick_split(tramp_ctx* ctx, bool nt, size_t nblocks, size_t nchunk, size_t nsteps, int forced) {
+    int s = kSplit;
+    if (forced > 0) {
+        s = forced;
+    } else {
+        const double slots = 3.0 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+        double best = -1.0;
+        for (int cand = 8; cand <= 32; cand += 8) {
+            if ((size_t)cand * 16 > nsteps && cand > 8) break;          // keep >= 16 k-steps per split
+            const double rounds = (double)nblocks * cand * (double)nchunk / slots;
+            const double eff = rounds / ceil(rounds);
+            if (eff > best + 1e-9) {
+                best = eff;
+                s = cand;
+            }
+            if (eff >= 0.9) break;
+        }
+    }
     if ((size_t)s > nsteps) s = (int)(nsteps ? nsteps : 1);
     return s;
 }
@@ -759,7 +780,11 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     const size_t nsteps = (kdim + kstep_of<T>() - 1) / kstep_of<T>();
     static const int split_env = getenv("TRAMP_MFMA_SPLIT") ? atoi(getenv("TRAMP_MFMA_SPLIT")) : 0;
     static const int pad_env = getenv("TRAMP_MFMA_LDS_PAD") ? atoi(getenv("TRAMP_MFMA_LDS_PAD")) : 0;
-    const unsigned nsplit = (unsigned)pick_split(ctx, nt, len, nsteps, split_env);
+    const unsigned nchunk0 = (unsigned)((batch + 63) / 64);
+    static const int rt_probe = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 4;
+    const size_t rows_per_wg = 64 * (size_t)(rt_probe == 1 ? 1 : (rt_probe == 4 ? 4 : 2));
+    const size_t nblocks = nt ? (R + rows_per_wg - 1) / rows_per_wg : (C + 64 * E - 1) / (64 * E);
+    const unsigned nsplit = (unsigned)pick_split(ctx, nt, nblocks, nchunk0, nsteps, split_env);
     const size_t sps = (nsteps + nsplit - 1) / nsplit;
     int rc = tramp_ws_reserve(ctx, (size_t)nsplit * batch * len * sizeof(double));
     if (rc) return rc;

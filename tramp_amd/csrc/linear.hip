@@ -323,6 +323,8 @@ static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t 
     TRAMP_REQUIRE(ctx, mat_d && x_d && epi.out);
     if (!R || !C || !batch) return TRAMP_OK;
     // measured on MI355X: the VALU GEMV wins up to 2 instances (6.1 vs 5.7 TB/s), MFMA from 3 on
+    static const int algo_env = getenv("TRAMP_MATVEC_ALGO") ? atoi(getenv("TRAMP_MATVEC_ALGO")) : 0;   // debugging
+    if (algo == 0 && algo_env) algo = algo_env;
     bool mfma = (algo == 2) || (algo == 0 && batch > 2);
     if (mfma && !gemm_mfma_supported(dtype, nt, R, C, batch)) {
         if (algo == 2) return tramp_fail(ctx, TRAMP_ENOTSUP, "mfma path", "shape/dtype not supported");

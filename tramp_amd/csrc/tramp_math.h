@@ -76,6 +76,41 @@ inline double fast_rcp(double x) { return 1.0 / x; }
 inline float fast_rcp(float x) { return 1.0f / x; }
 #endif
 
+// erfcx for the streaming kernels (K4, K7).  The library's f64 erfcx costs 130-160 instructions on
+// gfx950 (three range branches, all taken by some lane of a wave); here: erfcx(x) = t g(t), t = 4/(4 + |x|),
+// g a degree-7 polynomial on one of 32 intervals of t (erfcx_table.h, fitted to mpmath, relative error
+// 8e-16), four 16-byte table loads (2 KiB table, L1-resident) and seven FMAs; x < 0 by
+// erfcx(x) = 2 exp(x^2) - erfcx(-x).  No branch mask depends on an erfcx value.
+#if defined(__HIP_DEVICE_COMPILE__)
+}  // namespace tmath
+#include "erfcx_table.h"
+namespace tmath {
+__device__ __forceinline__ double erfcx_hot(double x) {
+    const double w = ::fabs(x);
+    const double t = 4.0 * fast_rcp(4.0 + w);
+    const double tk = t * (double)kErfcxK;
+    const int k = (tk >= 0.0 && tk < (double)kErfcxK) ? (int)tk : (tk >= (double)kErfcxK ? kErfcxK - 1 : 0);
+    const double s = ::fma(2.0, tk - (double)k, -1.0);
+    const double2* p = reinterpret_cast<const double2*>(kErfcxTable[k]);
+    const double2 c01 = p[0], c23 = p[1], c45 = p[2], c67 = p[3];
+    double acc = c67.y;
+    acc = ::fma(acc, s, c67.x);
+    acc = ::fma(acc, s, c45.y);
+    acc = ::fma(acc, s, c45.x);
+    acc = ::fma(acc, s, c23.y);
+    acc = ::fma(acc, s, c23.x);
+    acc = ::fma(acc, s, c01.y);
+    acc = ::fma(acc, s, c01.x);
+    double e = t * acc;
+    if (x < 0.0) e = 2.0 * ::exp(x * x) - e;
+    return e;
+}
+__device__ __forceinline__ float erfcx_hot(float x) { return ::erfcxf(x); }
+#else
+inline double erfcx_hot(double x) { return erfcx_(x); }
+inline float erfcx_hot(float x) { return erfcx_(x); }
+#endif
+
 // scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal.
 template <typename T> TM_HD T expit(T x) {
     T e = exp_(-fabs_(x));
@@ -185,7 +220,7 @@ TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0, T
     T y0 = (zb - r0) / c.s0;                   // exact: mask operand (zb = 0 for Sgn/Abs/Relu)
     T sd = T(side);
     T x = sd * (y0 * T(0.70710678118654752440));
-    T e = erfcx_(x);
+    T e = erfcx_hot(x);
     T ie = fast_rcp(e);
     T g1 = T(kSqrt2OverPi) * (sd * ie);
     T g2 = T(kTwoOverSqrtPi) * (x * ie);
@@ -199,6 +234,34 @@ TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0, T
         h.mask = u < LogPhiCut<T>::value;
         h.logp = h.mask ? (log_(T(0.5) * e) - T(0.5) * (u * u)) : T(0);
     }
+    return h;
+}
+
+// Variant for the two-region merge of pwl_posterior_fast: instead of logp = log(0.5 erfcx) - u^2/2 it
+// returns the FACTOR f = 0.5 erfcx (1 where the reference's log_Phi mask replaces the term by 0), its
+// reciprocal, and the exponent part q = -u^2/2 (0 under the mask) - the softmax over two regions needs
+// only the ratio of the two probabilities, so no logarithm is ever taken (two f64 logs, ~200
+// instructions per component, saved).
+template <typename T> struct HalfLineF { T mean, var, f, inv_f, q; bool mask; };
+
+template <typename T>
+TM_HD HalfLineF<T> halfline_factor(T b, const RegionConst<T>& c, int side, T& r0, T zb = T(0)) {
+    r0 = b / c.a;                              // exact: mask operand
+    T y0 = (zb - r0) / c.s0;                   // exact: mask operand (zb = 0 for Sgn/Abs/Relu)
+    T sd = T(side);
+    T x = sd * (y0 * T(0.70710678118654752440));
+    T e = erfcx_hot(x);
+    T ie = fast_rcp(e);
+    T g1 = T(kSqrt2OverPi) * (sd * ie);
+    T g2 = T(kTwoOverSqrtPi) * (x * ie);
+    HalfLineF<T> h;
+    h.mean = r0 + c.s0 * g1;
+    h.var = c.v0 * (T(1) + g2 - g1 * g1);
+    T u = -sd * y0;
+    h.mask = u < LogPhiCut<T>::value;
+    h.f = h.mask ? T(0.5) * e : T(1);
+    h.inv_f = h.mask ? T(2) * ie : T(1);
+    h.q = h.mask ? T(-0.5) * (u * u) : T(0);
     return h;
 }
 
@@ -396,7 +459,7 @@ template <typename T, int KIND> TM_HD PwlConst<T> pwl_const(double az, double ax
 
 template <typename T, int KIND, bool FWD>
 TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
-    T rs[2], vs[2], As[2];
+    T rs[2], vs[2], Qs[2], fs[2], ifs[2];
     unsigned mask = 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -406,10 +469,12 @@ TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
         const int side = (k == 0) ? +1 : -1;
         T b = bz + slope * (bx - c.ax * x0);
         T r0;
-        HalfLine<T> h = halfline_fast<T, true>(b, c.reg[k], side, r0, KIND < 3 ? T(0) : c.zb);
-        // 0.5 r0^2 / v0 = 0.5 r0^2 a
-        As[k] = c.reg[k].half_log2piv0 + T(0.5) * (r0 * r0) * c.reg[k].a + h.logp
+        HalfLineF<T> h = halfline_factor<T>(b, c.reg[k], side, r0, KIND < 3 ? T(0) : c.zb);
+        // log-partition of the region = Qs + log(fs):  0.5 r0^2 / v0 = 0.5 r0^2 a
+        Qs[k] = c.reg[k].half_log2piv0 + T(0.5) * (r0 * r0) * c.reg[k].a + h.q
                 - T(0.5) * c.ax * (x0 * x0) + bx * x0;
+        fs[k] = h.f;
+        ifs[k] = h.inv_f;
         if (FWD) {
             rs[k] = slope * h.mean + x0;
             vs[k] = slope * slope * h.var;
@@ -419,14 +484,15 @@ TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
         }
         mask |= (h.mask ? 1u : 0u) << k;
     }
-    // softmax over two regions = logistic of the difference: one exp, one reciprocal; the
-    // small probability is formed directly (e * r), never as 1 - big
-    const T dA = As[0] - As[1];
-    const T ee = exp_(-fabs_(dA));
-    const T rr = fast_rcp(T(1) + ee);
-    const T big = rr, small = ee * rr;
-    const T p0 = dA < T(0) ? small : big;
-    const T p1 = dA < T(0) ? big : small;
+    // softmax over two regions (piecewise_linear_channel.py:27-29) = logistic of A0 - A1:
+    //   t = exp(A1 - A0) = (f1 / f0) exp(-(Q0 - Q1)),  p0 = 1 / (1 + t),  p1 = t / (1 + t).
+    // The exponent is applied in two halves so that exp never saturates while t itself is finite; the
+    // small probability is formed directly (rr, or t * rr), never as 1 - big.
+    const T E = exp_(T(-0.5) * (Qs[0] - Qs[1]));
+    const T t = ((fs[1] * ifs[0]) * E) * E;
+    const T rr = fast_rcp(T(1) + t);
+    const T p0 = rr;
+    const T p1 = (t > T(1e300)) ? T(1) : t * rr;            // t = inf: rr = 0, t * rr would be NaN
     PwlOut<T> o;
     o.r = p0 * rs[0] + p1 * rs[1];
     T d = rs[0] - rs[1];
