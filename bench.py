@@ -455,6 +455,7 @@ def run(args):
                                    "N=1e6, 4 TB) cannot exist" % (args.rho, args.noise_var, args.damping,
                                                                     args.check_every),
                        "N": N, "M": M, "alpha": args.alpha, "instances_per_gpu": B,
+                       "fallback_from": getattr(args, "fallback_from", None),
                        "instances_total": B * world, "parallelism": f"ensemble-shard x{world}",
                        "collectives": "none in the timed region; setup: RCCL broadcast of the thin factors"
                                       if comm is not None else "none (single rank)"},
@@ -501,7 +502,20 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    return run(args)
+    try:
+        return run(args)
+    except Exception as e:      # noqa: BLE001
+        # a single rank that cannot set up the configured size (e.g. out of memory on a shared box) reports a
+        # smaller honest number rather than none - and SAYS so: config.fallback_from holds the size that failed
+        if world > 1 or args.n <= 65536 or args.load_factors:
+            raise
+        import gc
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        print(f"bench.py: run at N={args.n} failed ({e!r}); retrying at N=65536", file=sys.stderr)
+        gc.collect()
+        args.fallback_from, args.n = args.n, 65536
+        return run(args)
 
 
 if __name__ == "__main__":

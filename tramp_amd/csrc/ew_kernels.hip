@@ -540,8 +540,11 @@ __device__ __forceinline__ void store_vec(typename Vec<T>::type* dst, const type
     }
 }
 
+// A block owns `tpb` CONSECUTIVE tiles (a contiguous chunk of the instance): the per-instance setup of the
+// functor (a log and a division for the Gauss-Bernoulli prior) and the block reduction are paid once per
+// chunk, not once per 1024 components, while neighbouring blocks still stream neighbouring addresses.
 template <typename T, typename Op, int U>
-__global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_t inst0, const T* __restrict__ in0,
+__global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_t inst0, int tpb, const T* __restrict__ in0,
                                                           const T* __restrict__ in1, T* __restrict__ rbuf,
                                                           double* __restrict__ partials,
                                                           unsigned long long* __restrict__ pcount,
@@ -553,39 +556,42 @@ __global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_
     const size_t b = inst0 + blockIdx.y;
     op.setup(b);
     const size_t nv = n / VN;
-    const size_t base = (size_t)blockIdx.x * kBlock * U + threadIdx.x;
     const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
     const V* p1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
     V* pr = rbuf ? reinterpret_cast<V*>(rbuf + (size_t)blockIdx.y * n) : nullptr;
     uint8_t* mo = mask_out ? mask_out + b * n : nullptr;
-    V v0[U], v1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const size_t i = base + (size_t)u * kBlock;
-        if (i < nv) {
-            v0[u] = p0[i];
-            if (Op::NIN > 1) v1[u] = p1[i];
-        }
-    }
     double acc = 0.0;
     unsigned long long cnt = 0;
+    for (int tile = 0; tile < tpb; ++tile) {
+        const size_t base = ((size_t)blockIdx.x * tpb + tile) * kBlock * U + threadIdx.x;
+        if (base - threadIdx.x >= nv) break;
+        V v0[U], v1[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const size_t i = base + (size_t)u * kBlock;
-        if (i < nv) {
-            V vr;
-#pragma unroll
-            for (int j = 0; j < VN; ++j) {
-                const T x0 = vget<T>(v0[u], j);
-                const T x1 = (Op::NIN > 1) ? vget<T>(v1[u], j) : x0;
-                EwOut<T> o = op.eval(x0, x1);
-                acc += (double)o.v;
-                if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
-                cnt += o.mask & 1u;
-                vset<T>(vr, j, o.r);
-                if (mo) mo[i * VN + j] = (uint8_t)o.mask;
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
+                v0[u] = p0[i];
+                if (Op::NIN > 1) v1[u] = p1[i];
             }
-            if (pr) pr[i] = vr;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
+                V vr;
+#pragma unroll
+                for (int j = 0; j < VN; ++j) {
+                    const T x0 = vget<T>(v0[u], j);
+                    const T x1 = (Op::NIN > 1) ? vget<T>(v1[u], j) : x0;
+                    EwOut<T> o = op.eval(x0, x1);
+                    acc += (double)o.v;
+                    if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
+                    cnt += o.mask & 1u;
+                    vset<T>(vr, j, o.r);
+                    if (mo) mo[i * VN + j] = (uint8_t)o.mask;
+                }
+                if (pr) pr[i] = vr;
+            }
         }
     }
     acc = block_sum(acc, smem);
@@ -629,62 +635,65 @@ __global__ __launch_bounds__(kBlock) void ew_finalize(size_t n, size_t inst0, si
 
 // RECOMPUTE = true: r from op.eval on the inputs; false: r from the scratch written by pass 1.
 template <typename T, typename Op, int U, bool RECOMPUTE, bool NTS>
-__global__ __launch_bounds__(kBlock) void ew_apply_tile(Op op, size_t n, size_t inst0, const T* __restrict__ in0,
+__global__ __launch_bounds__(kBlock) void ew_apply_tile(Op op, size_t n, size_t inst0, int tpb, const T* __restrict__ in0,
                                                         const T* __restrict__ in1, const T* __restrict__ rbuf,
                                                         const double* __restrict__ scal, MsgOut out) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     const size_t bl = blockIdx.y, b = inst0 + bl;
     const size_t nv = n / VN;
-    const size_t base = (size_t)blockIdx.x * kBlock * U + threadIdx.x;
     const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
     const V* p1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
     const V* pr = RECOMPUTE ? nullptr : reinterpret_cast<const V*>(rbuf + bl * n);
     const V* bold = out.b_old ? reinterpret_cast<const V*>(reinterpret_cast<const T*>(out.b_old) + b * n) : nullptr;
     V* bo = reinterpret_cast<V*>(reinterpret_cast<T*>(out.b_new) + b * n);
     V* ro = out.r ? reinterpret_cast<V*>(reinterpret_cast<T*>(out.r) + b * n) : nullptr;
-    V v0[U], v1[U], vold[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const size_t i = base + (size_t)u * kBlock;
-        if (i < nv) {
-            if (RECOMPUTE) {
-                v0[u] = p0[i];
-                if (Op::NIN > 1) v1[u] = p1[i];
-            } else {
-                v0[u] = (Op::TARGET == 0) ? p0[i] : p1[i];        // the target message b
-                v1[u] = pr[i];                                    // r
-            }
-            if (bold) vold[u] = bold[i];
-        }
-    }
     if (RECOMPUTE) op.setup(b);
     const T vinv = T(scal[bl]);
     const T dT = T(out.damping), omd = T(1.0 - out.damping);
+    for (int tile = 0; tile < tpb; ++tile) {
+        const size_t base = ((size_t)blockIdx.x * tpb + tile) * kBlock * U + threadIdx.x;
+        if (base - threadIdx.x >= nv) break;
+        V v0[U], v1[U], vold[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const size_t i = base + (size_t)u * kBlock;
-        if (i < nv) {
-            V vo, vr;
-#pragma unroll
-            for (int j = 0; j < VN; ++j) {
-                T r, tgt;
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
                 if (RECOMPUTE) {
-                    const T x0 = vget<T>(v0[u], j);
-                    const T x1 = (Op::NIN > 1) ? vget<T>(v1[u], j) : x0;
-                    r = op.eval(x0, x1).r;
-                    tgt = (Op::TARGET == 0) ? x0 : x1;
+                    v0[u] = p0[i];
+                    if (Op::NIN > 1) v1[u] = p1[i];
                 } else {
-                    r = vget<T>(v1[u], j);
-                    tgt = vget<T>(v0[u], j);
+                    v0[u] = (Op::TARGET == 0) ? p0[i] : p1[i];        // the target message b
+                    v1[u] = pr[i];                                    // r
                 }
-                T bn = r * vinv - tgt;
-                if (bold) bn = dT * vget<T>(vold[u], j) + omd * bn;
-                vset<T>(vo, j, bn);
-                vset<T>(vr, j, r);
+                if (bold) vold[u] = bold[i];
             }
-            store_vec<T, NTS>(&bo[i], vo);
-            if (ro) store_vec<T, NTS>(&ro[i], vr);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
+                V vo, vr;
+#pragma unroll
+                for (int j = 0; j < VN; ++j) {
+                    T r, tgt;
+                    if (RECOMPUTE) {
+                        const T x0 = vget<T>(v0[u], j);
+                        const T x1 = (Op::NIN > 1) ? vget<T>(v1[u], j) : x0;
+                        r = op.eval(x0, x1).r;
+                        tgt = (Op::TARGET == 0) ? x0 : x1;
+                    } else {
+                        r = vget<T>(v1[u], j);
+                        tgt = vget<T>(v0[u], j);
+                    }
+                    T bn = r * vinv - tgt;
+                    if (bold) bn = dT * vget<T>(vold[u], j) + omd * bn;
+                    vset<T>(vo, j, bn);
+                    vset<T>(vr, j, r);
+                }
+                store_vec<T, NTS>(&bo[i], vo);
+                if (ro) store_vec<T, NTS>(&ro[i], vr);
+            }
         }
     }
 }
@@ -707,7 +716,13 @@ static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* 
     constexpr int VN = Vec<T>::N;
     constexpr int U = kTileU;
     const size_t nv = n / VN;
-    const unsigned ntile = (unsigned)((nv + (size_t)kBlock * U - 1) / ((size_t)kBlock * U));
+    const size_t tiles = (nv + (size_t)kBlock * U - 1) / ((size_t)kBlock * U);
+    // consecutive tiles per block: enough blocks to fill the chip several times over, setup amortised
+    int tpb = 8;
+    while (tpb > 1 && (tiles / tpb) * batch < 4096) tpb >>= 1;
+    static const size_t tpb_env = env_size("TRAMP_EW_TPB", 0);
+    if (tpb_env) tpb = (int)tpb_env;
+    const unsigned ntile = (unsigned)((tiles + tpb - 1) / tpb);          // blocks (= partials) per instance
     if (hint) {
         store_r = false;
         ctx->hint_used += 1;
@@ -734,7 +749,7 @@ static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* 
             hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, inst0, a_in_d, hint->partials,
                                (const unsigned long long*)nullptr, hint->nblk, o, scal + inst0);
         } else {
-            hipLaunchKernelGGL((ew_moments_tile<T, Op, U>), grid, block, 0, ctx->stream, op, n, inst0, p0, p1,
+            hipLaunchKernelGGL((ew_moments_tile<T, Op, U>), grid, block, 0, ctx->stream, op, n, inst0, tpb, p0, p1,
                                rbuf ? rbuf + inst0 * n : nullptr, partials + inst0 * ntile,
                                pcount ? pcount + inst0 * ntile : nullptr, out.mask);
             hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, (size_t)0, a_in_d,
@@ -745,18 +760,18 @@ static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* 
         const bool nts = (double)n * (double)batch * sizeof(T) > 192.0 * 1024 * 1024;
         if (store_r) {
             if (nts)
-                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, true>), grid, block, 0, ctx->stream, op, n, inst0, p0,
-                                   p1, rbuf + inst0 * n, scal + inst0, o);
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, true>), grid, block, 0, ctx->stream, op, n, inst0, tpb,
+                                   p0, p1, rbuf + inst0 * n, scal + inst0, o);
             else
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, false>), grid, block, 0, ctx->stream, op, n, inst0,
-                                   p0, p1, rbuf + inst0 * n, scal + inst0, o);
+                                   tpb, p0, p1, rbuf + inst0 * n, scal + inst0, o);
         } else {
             if (nts)
-                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, true>), grid, block, 0, ctx->stream, op, n, inst0, p0,
-                                   p1, (const T*)nullptr, scal + inst0, o);
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, true>), grid, block, 0, ctx->stream, op, n, inst0, tpb,
+                                   p0, p1, (const T*)nullptr, scal + inst0, o);
             else
-                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, false>), grid, block, 0, ctx->stream, op, n, inst0, p0,
-                                   p1, (const T*)nullptr, scal + inst0, o);
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, false>), grid, block, 0, ctx->stream, op, n, inst0, tpb,
+                                   p0, p1, (const T*)nullptr, scal + inst0, o);
         }
     }
     TRAMP_LAUNCH_CHECK(ctx);
