@@ -655,6 +655,24 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
                 FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, N, c, j0, -1.0, V64, N, cross, j0, 1.0,
                             Vc, N));
             }
+            // ... and the directions above re-orthogonalised against the corrected block on the UNIT side (the
+            // first step moved the block's unit vectors by up to the tilt; without this the two groups would
+            // be left non-orthogonal by that angle): D = S_b^T S_c, S_b -= S_c D^T, carrying rows alike.
+            if (M <= N) {
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_transpose, j0, c, M, 1.0, U64, k, Ur, k, 0.0,
+                            cross, j0));
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, j0, M, c, -1.0, cross, j0, Ur, k, 1.0,
+                            U64, k));
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_transpose, N, j0, c, -1.0, Vc, N, cross, j0,
+                            1.0, V64, N));
+            } else {
+                FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, j0, c, N, 1.0, V64, N, Vc, N, 0.0,
+                            cross, j0));
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_transpose, N, j0, c, -1.0, Vc, N, cross, j0,
+                            1.0, V64, N));
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, j0, M, c, -1.0, cross, j0, Ur, k, 1.0,
+                            U64, k));
+            }
             fz.release(cross);
         }
         // the block's Gram matrix in units of its own largest singular value: the library eigensolver is
