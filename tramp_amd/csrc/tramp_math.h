@@ -85,6 +85,7 @@ inline float fast_rcp(float x) { return 1.0f / x; }
 }  // namespace tmath
 #include "erfcx_table.h"
 namespace tmath {
+__device__ __forceinline__ double exp_fast(double x);
 __device__ __forceinline__ double erfcx_hot(double x) {
     const double w = ::fabs(x);
     const double t = 4.0 * fast_rcp(4.0 + w);
@@ -102,7 +103,7 @@ __device__ __forceinline__ double erfcx_hot(double x) {
     acc = ::fma(acc, s, c01.y);
     acc = ::fma(acc, s, c01.x);
     double e = t * acc;
-    if (x < 0.0) e = 2.0 * ::exp(x * x) - e;
+    if (x < 0.0) e = 2.0 * exp_fast(x * x) - e;
     return e;
 }
 __device__ __forceinline__ float erfcx_hot(float x) { return ::erfcxf(x); }
@@ -111,10 +112,57 @@ inline double erfcx_hot(double x) { return erfcx_(x); }
 inline float erfcx_hot(float x) { return erfcx_(x); }
 #endif
 
-// scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal.
+// exp(x) for x <= 0 in f64 on the device: the library routine carries overflow handling and a two-level
+// reduction it does not need here (~46 VALU instructions); n = rint(x log2 e), r = x - n ln2 (two parts),
+// degree-12 Taylor polynomial on |r| <= ln2/2 (truncation 2e-16), one ldexp: ~22 instructions, 1-2 ulp.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double exp_fast(double x);
+__device__ __forceinline__ double exp_nonpos(double x) { return exp_fast(x); }
+// any argument: the result saturates to 0 below -745.2 and to +inf above 709.78 like the library's
+__device__ __forceinline__ double exp_fast(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = ::fma(n, -6.93147180369123816490e-01, x);
+    r = ::fma(n, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;                 // 1/12!
+    p = ::fma(p, r, 2.50521083854417187751e-08);            // 1/11!
+    p = ::fma(p, r, 2.75573192239858906526e-07);            // 1/10!
+    p = ::fma(p, r, 2.75573192239858906526e-06);            // 1/9!
+    p = ::fma(p, r, 2.48015873015873015873e-05);            // 1/8!
+    p = ::fma(p, r, 1.98412698412698412698e-04);            // 1/7!
+    p = ::fma(p, r, 1.38888888888888888889e-03);            // 1/6!
+    p = ::fma(p, r, 8.33333333333333333333e-03);            // 1/5!
+    p = ::fma(p, r, 4.16666666666666666667e-02);            // 1/4!
+    p = ::fma(p, r, 1.66666666666666666667e-01);            // 1/3!
+    p = ::fma(p, r, 0.5);
+    p = ::fma(p, r, 1.0);
+    p = ::fma(p, r, 1.0);
+    // two-step scaling: |n| can reach 1075, beyond one ldexp's exact range for the intermediate
+    const int ni = (int)n, n1 = ni / 2;
+    const double e = ::ldexp(::ldexp(p, n1), ni - n1);
+    return x < -745.2 ? 0.0 : (x > 709.79 ? __builtin_inf() : e);      // -inf -> 0, +inf -> inf; NaN propagates through p
+}
+__device__ __forceinline__ float exp_nonpos(float x) { return ::expf(x); }
+__device__ __forceinline__ float exp_fast(float x) { return ::expf(x); }
+// 1/x for x in [1, 2]: hardware estimate + two Newton steps, no special cases to guard
+__device__ __forceinline__ double rcp_1to2(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = ::fma(::fma(-x, r, 1.0), r, r);
+    return ::fma(::fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ float rcp_1to2(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+inline double exp_nonpos(double x) { return std::exp(x); }
+inline float exp_nonpos(float x) { return std::exp(x); }
+inline double exp_fast(double x) { return std::exp(x); }
+inline float exp_fast(float x) { return std::exp(x); }
+inline double rcp_1to2(double x) { return 1.0 / x; }
+inline float rcp_1to2(float x) { return 1.0f / x; }
+#endif
+
+// scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal of 1 + e in [1, 2].
 template <typename T> TM_HD T expit(T x) {
-    T e = exp_(-fabs_(x));
-    T r = fast_rcp(T(1) + e);
+    T e = exp_nonpos(-fabs_(x));
+    T r = rcp_1to2(T(1) + e);
     return x < T(0) ? e * r : r;
 }
 
@@ -503,7 +551,7 @@ TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
     //   t = exp(A1 - A0) = (f1 / f0) exp(-(Q0 - Q1)),  p0 = 1 / (1 + t),  p1 = t / (1 + t).
     // The exponent is applied in two halves so that exp never saturates while t itself is finite; the
     // small probability is formed directly (rr, or t * rr), never as 1 - big.
-    const T E = exp_(T(-0.5) * (Qs[0] - Qs[1]));
+    const T E = exp_fast(T(-0.5) * (Qs[0] - Qs[1]));
     const T t = ((fs[1] * ifs[0]) * E) * E;
     const T rr = fast_rcp(T(1) + t);
     const T p0 = rr;
