@@ -84,7 +84,7 @@ template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1)
     double a_msg;
     __device__ void setup(size_t b) { a_msg = ax[b]; }
     __device__ EwOut<T> eval(T x0, T) const {
-        const T t = tmath::tanh_(x0 + T(b0));                    // beliefs/binary.py:8-13
+        const T t = tmath::tanh_hot(x0 + T(b0));                 // beliefs/binary.py:8-13
         return {t, T(1) - t * t, 0u};
     }
 };
@@ -1263,6 +1263,73 @@ __global__ __launch_bounds__(kBlock) void var_post_kernel(size_t n, const double
     }
 }
 
+// Streaming-tile form of the same pass (n a multiple of the 16-byte vector): a block owns `tpb` consecutive
+// tiles of 256 x U vectors (launch shape of tools/probes/probe_copy.hip), 16-byte loads and stores.
+template <typename T, int U>
+__global__ __launch_bounds__(kBlock) void var_post_tile(size_t n, int tpb, const double* __restrict__ a1,
+                                                        const T* __restrict__ b1, const double* __restrict__ a2,
+                                                        const T* __restrict__ b2, const T* __restrict__ r_old,
+                                                        T* __restrict__ r, double* __restrict__ v,
+                                                        double* __restrict__ partials) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    const double a_hat = 0.0 + a1[b] + a2[b];
+    const T ah = T(a_hat);
+    const size_t nv = n / VN;
+    const V* p1 = reinterpret_cast<const V*>(b1 + b * n);
+    const V* p2 = reinterpret_cast<const V*>(b2 + b * n);
+    const V* po = r_old ? reinterpret_cast<const V*>(r_old + b * n) : nullptr;
+    V* pr = reinterpret_cast<V*>(r + b * n);
+    double sd = 0.0, sn = 0.0;
+    for (int tile = 0; tile < tpb; ++tile) {
+        const size_t base = ((size_t)blockIdx.x * tpb + tile) * kBlock * U + threadIdx.x;
+        if (base - threadIdx.x >= nv) break;
+        V x1[U], x2[U], xo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
+                x1[u] = p1[i];
+                x2[u] = p2[i];
+                if (po) xo[u] = po[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
+                V out;
+#pragma unroll
+                for (int j = 0; j < VN; ++j) {
+                    const T ri = (vget<T>(x1[u], j) + vget<T>(x2[u], j)) / ah;
+                    const T old = po ? vget<T>(xo[u], j) : T(0);
+                    const double dd = (double)ri - (double)old;
+                    sd += dd * dd;
+                    sn += (double)ri * (double)ri;
+                    vset<T>(out, j, ri);
+                }
+                pr[i] = out;
+            }
+        }
+    }
+    sd = block_sum(sd, smem);
+    sn = block_sum(sn, smem);
+    if (threadIdx.x == 0) {
+        partials[(b * gridDim.x + blockIdx.x) * 2 + 0] = sd;
+        partials[(b * gridDim.x + blockIdx.x) * 2 + 1] = sn;
+        if (blockIdx.x == 0 && v) v[b] = 1.0 / a_hat;
+    }
+}
+
+// tiles per block of a streaming pass: enough blocks to fill the chip several times over
+static inline int tiles_per_block(size_t tiles, size_t batch) {
+    int tpb = 8;
+    while (tpb > 1 && (tiles / tpb) * batch < 4096) tpb >>= 1;
+    return tpb;
+}
+
 // out_q[b] = sum_k partials[(b*nblk + k)*nq + q]; one block per instance.
 __global__ __launch_bounds__(kBlock) void fold_partials_kernel(const double* __restrict__ partials, int nblk,
                                                                int nq, double* out0, double* out1) {
@@ -1286,12 +1353,25 @@ extern "C" int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, siz
     TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
     if (!n || !batch) return TRAMP_OK;
     TRAMP_REQUIRE(ctx, batch <= 65535);
-    const int nblk = blocks_for(n, 1);
+    const size_t vn = dtype == TRAMP_F64 ? 2 : 4;
+    const bool tiled = (n % vn) == 0;
+    constexpr int U = kTileU;
+    const size_t tiles = (n / vn + (size_t)kBlock * U - 1) / ((size_t)kBlock * U);
+    const int tpb = tiles_per_block(tiles, batch);
+    const int nblk = tiled ? (int)((tiles + tpb - 1) / tpb) : blocks_for(n, 1);
     int rc = tramp_ws_reserve(ctx, batch * (size_t)nblk * 2 * sizeof(double));
     if (rc) return rc;
     dim3 grid(nblk, (unsigned)batch);
     ProfScope prof(ctx, PROF_VAR_POST, 3.0 * dtype_size(dtype) * (double)n * (double)batch, 0.0);
-    if (dtype == TRAMP_F64)
+    if (tiled && dtype == TRAMP_F64)
+        hipLaunchKernelGGL((var_post_tile<double, U>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
+                           (const double*)b1_d, a2_d, (const double*)b2_d, (const double*)r_old_d, (double*)r_d, v_d,
+                           ctx->ws);
+    else if (tiled)
+        hipLaunchKernelGGL((var_post_tile<float, U>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
+                           (const float*)b1_d, a2_d, (const float*)b2_d, (const float*)r_old_d, (float*)r_d, v_d,
+                           ctx->ws);
+    else if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((var_post_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, a1_d,
                            (const double*)b1_d, a2_d, (const double*)b2_d, (const double*)r_old_d,
                            (double*)r_d, v_d, ctx->ws);
@@ -1448,12 +1528,64 @@ __global__ __launch_bounds__(kBlock) void damp_kernel(size_t n, double d, const 
     if (blockIdx.x == 0 && threadIdx.x == 0) a[b] = d * a_old[b] + (1.0 - d) * a[b];
 }
 
+// streaming-tile form (n a multiple of the 16-byte vector)
+template <typename T, int U>
+__global__ __launch_bounds__(kBlock) void damp_tile(size_t n, int tpb, double d, const double* __restrict__ a_old,
+                                                    const T* __restrict__ b_old, double* __restrict__ a, T* __restrict__ bb) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    const size_t b = blockIdx.y;
+    const T dT = T(d), omd = T(1.0 - d);
+    const size_t nv = n / VN;
+    const V* po = reinterpret_cast<const V*>(b_old + b * n);
+    V* pb = reinterpret_cast<V*>(bb + b * n);
+    for (int tile = 0; tile < tpb; ++tile) {
+        const size_t base = ((size_t)blockIdx.x * tpb + tile) * kBlock * U + threadIdx.x;
+        if (base - threadIdx.x >= nv) break;
+        V xo[U], xb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
+                xo[u] = po[i];
+                xb[u] = pb[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nv) {
+                V out;
+#pragma unroll
+                for (int j = 0; j < VN; ++j) vset<T>(out, j, dT * vget<T>(xo[u], j) + omd * vget<T>(xb[u], j));
+                pb[i] = out;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a[b] = d * a_old[b] + (1.0 - d) * a[b];
+}
+
 extern "C" int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
                           const double* a_old_d, const void* b_old_d, double* a_d, void* b_d) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, a_old_d && b_old_d && a_d && b_d);
     TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
     if (!n || !batch || damping == 0.0) return TRAMP_OK;
+    const size_t vn = dtype == TRAMP_F64 ? 2 : 4;
+    if ((n % vn) == 0) {
+        constexpr int U = kTileU;
+        const size_t tiles = (n / vn + (size_t)kBlock * U - 1) / ((size_t)kBlock * U);
+        const int tpb = tiles_per_block(tiles, batch);
+        dim3 g((unsigned)((tiles + tpb - 1) / tpb), (unsigned)batch);
+        if (dtype == TRAMP_F64)
+            hipLaunchKernelGGL((damp_tile<double, U>), g, dim3(kBlock), 0, ctx->stream, n, tpb, damping, a_old_d,
+                               (const double*)b_old_d, a_d, (double*)b_d);
+        else
+            hipLaunchKernelGGL((damp_tile<float, U>), g, dim3(kBlock), 0, ctx->stream, n, tpb, damping, a_old_d,
+                               (const float*)b_old_d, a_d, (float*)b_d);
+        TRAMP_LAUNCH_CHECK(ctx);
+        return TRAMP_OK;
+    }
     dim3 grid(blocks_for(n, 1), (unsigned)batch);
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((damp_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, damping, a_old_d,
