@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-denoiser", action="store_true")
     ap.add_argument("--no-se", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=4000)
+    ap.add_argument("--cpu-n-thin", type=int, default=12000)
     ap.add_argument("--save-factors", default=None, metavar="DIR",
                     help="after the setup, dump the thin factors (Uk, Vt, sing) and the observations to DIR")
     ap.add_argument("--load-factors", default=None, metavar="DIR",
@@ -123,6 +124,25 @@ def cpu_baseline(args):
         out["single_thread_value"] = N * n1 / dt1
     except Exception:                                                          # noqa: BLE001
         pass
+    # a larger sample in thin form (one economy SVD): the largest N whose setup stays within ~a minute on the host
+    try:
+        N2 = args.cpu_n_thin
+        M2 = int(args.alpha * N2)
+        rs = np.random.RandomState(2)
+        W2 = orc.gaussian_ensemble(rs, M2, N2)
+        x2 = orc.gb_sample(rs, N2, args.rho)
+        y2 = W2 @ x2 + np.sqrt(args.noise_var) * rs.standard_normal(M2)
+        t0 = time.perf_counter()
+        lin2 = orc.LinearFactor(W2, thin="economy")
+        setup2 = time.perf_counter() - t0
+        fs2 = [orc.GBPriorFactor(N2, rho=args.rho), lin2, orc.GaussLikFactor(y2, args.noise_var)]
+        t0 = time.perf_counter()
+        res = orc.ep_chain(fs2, [N2, M2], max_iter=100, damping=args.damping, tol=0.0, max_increase=np.inf)
+        dt2 = time.perf_counter() - t0
+        out["thin_form_large"] = {"N": N2, "value": N2 * res["n_iter"] / dt2, "iterations": res["n_iter"],
+                                  "seconds": dt2, "svd_setup_s": setup2}
+    except Exception as e:                                                     # noqa: BLE001
+        out["thin_form_large"] = {"error": repr(e)}
     return out
 
 

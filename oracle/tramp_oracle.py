@@ -785,6 +785,26 @@ class LinearThinOracle(LinearOracle):
         return self.Uk @ (sg * (t + sg * u) / D)
 
 
+class LinearEconomyOracle(LinearThinOracle):
+    """LinearThinOracle built from ONE economy SVD (no matrix_rank pass, no full V): the CPU baseline of
+    bench.py at sizes where the reference's two full SVDs would take minutes.  Same formulas."""
+
+    def __init__(self, W):
+        W = np.asarray(W, dtype=float)
+        self.W = W
+        self.Nx, self.Nz = W.shape
+        self.alpha = self.Nx / self.Nz
+        U, s, VT = np.linalg.svd(W, full_matrices=False)
+        self.rank = int(np.sum(s > s.max() * max(W.shape) * np.finfo(float).eps))     # np.linalg.matrix_rank
+        spectrum = np.zeros(self.Nz)
+        spectrum[:len(s)] = s**2
+        self.spectrum = spectrum
+        self.singular = spectrum[:self.rank]
+        self.sigma = s
+        self.Vk = VT.T
+        self.Uk = U
+
+
 # --------------------------------------------------------------------------
 # Widening (SURVEY 8f rank 3): circular convolution channel x = w * z, real signals
 #   tramp/channels/linear/conv_channel.py:13-149 (real=True)
@@ -1195,7 +1215,7 @@ class GaussPriorFactor(OracleFactor):
 
 class LinearFactor(OracleFactor):
     def __init__(self, W, thin=False):
-        self.lin = (LinearThinOracle if thin else LinearOracle)(W)
+        self.lin = (LinearEconomyOracle if thin == "economy" else LinearThinOracle if thin else LinearOracle)(W)
 
     def forward(self, az, bz, ax, bx):
         return self.lin.forward_message(az, bz, ax, bx)

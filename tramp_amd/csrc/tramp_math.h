@@ -108,8 +108,8 @@ __device__ __forceinline__ double erfcx_hot(double x) {
 }
 __device__ __forceinline__ float erfcx_hot(float x) { return ::erfcxf(x); }
 #else
-inline double erfcx_hot(double x) { return erfcx_(x); }
-inline float erfcx_hot(float x) { return erfcx_(x); }
+TM_HD double erfcx_hot(double x) { return erfcx_(x); }      // host pass / plain C++ (tests/host_math)
+TM_HD float erfcx_hot(float x) { return erfcx_(x); }
 #endif
 
 // exp(x) for x <= 0 in f64 on the device: the library routine carries overflow handling and a two-level
@@ -151,12 +151,12 @@ __device__ __forceinline__ double rcp_1to2(double x) {
 }
 __device__ __forceinline__ float rcp_1to2(float x) { return __builtin_amdgcn_rcpf(x); }
 #else
-inline double exp_nonpos(double x) { return std::exp(x); }
-inline float exp_nonpos(float x) { return std::exp(x); }
-inline double exp_fast(double x) { return std::exp(x); }
-inline float exp_fast(float x) { return std::exp(x); }
-inline double rcp_1to2(double x) { return 1.0 / x; }
-inline float rcp_1to2(float x) { return 1.0f / x; }
+TM_HD double exp_nonpos(double x) { return ::exp(x); }
+TM_HD float exp_nonpos(float x) { return ::expf(x); }
+TM_HD double exp_fast(double x) { return ::exp(x); }
+TM_HD float exp_fast(float x) { return ::expf(x); }
+TM_HD double rcp_1to2(double x) { return 1.0 / x; }
+TM_HD float rcp_1to2(float x) { return 1.0f / x; }
 #endif
 
 // tanh for the streaming kernels: sign(x) (1 - e)/(1 + e), e = exp(-2|x|) in (0, 1]; for |x| < 0.25 the
@@ -183,8 +183,8 @@ __device__ __forceinline__ double tanh_hot(double x) {
 }
 __device__ __forceinline__ float tanh_hot(float x) { return ::tanhf(x); }
 #else
-inline double tanh_hot(double x) { return std::tanh(x); }
-inline float tanh_hot(float x) { return std::tanh(x); }
+TM_HD double tanh_hot(double x) { return ::tanh(x); }
+TM_HD float tanh_hot(float x) { return ::tanhf(x); }
 #endif
 
 // scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal of 1 + e in [1, 2].
