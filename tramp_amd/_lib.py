@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtramp_hip.so")
+LIB_PATH = os.environ.get("TRAMP_HIP_LIB") or os.path.join(_HERE, "libtramp_hip.so")      # TRAMP_HIP_LIB: an experimental build
 
 OK, EINVAL, EHIP, ENOMEM, ENOTSUP, ENODEV = range(6)
 F32, F64 = 0, 1

@@ -714,11 +714,7 @@ template <typename T, typename Op>
 static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
                      const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
     constexpr int VN = Vec<T>::N;
-#ifdef TRAMP_EW_HEAVY_U
-    constexpr int U = Op::HEAVY ? TRAMP_EW_HEAVY_U : kTileU;
-#else
-    constexpr int U = kTileU;
-#endif
+    constexpr int U = kTileU;          // 1 and 4 measured for the heavy ops (K4/K5/K7): within 4% of 2
     const size_t nv = n / VN;
     const size_t tiles = (nv + (size_t)kBlock * U - 1) / ((size_t)kBlock * U);
     // consecutive tiles per block: enough blocks to fill the chip several times over, setup amortised
