@@ -99,6 +99,7 @@ template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
     __device__ void setup(size_t b) {
         a_msg = az[b];
         c = tmath::region_const<T>(a_msg);
+        tmath::erfcx_setup<T>();
     }
     __device__ EwOut<T> eval(T x0, T x1) const {
         RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, x1, c);
@@ -132,6 +133,7 @@ template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
         a_msg = az[b];
         c = tmath::region_const<T>(a_msg);
         sT = T(slope_neg);
+        tmath::erfcx_setup<T>();
     }
     __device__ EwOut<T> eval(T x0, T x1) const {
         RV<T> o = tmath::relu_lik_posterior<T>(x0, x1, sT, c);
@@ -191,6 +193,7 @@ template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 
         const double z = az[b], x = ax[b];
         c = tmath::pwl_const<T, KIND>(z, x, spec);
         a_msg = FWD ? x : z;
+        tmath::erfcx_setup<T>();
     }
     __device__ EwOut<T> eval(T x0, T x1) const {
         tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD>(x0, x1, c);
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_
     uint8_t* mo = mask_out ? mask_out + b * n : nullptr;
     double acc = 0.0;
     unsigned long long cnt = 0;
+    // (requesting the inputs of tile t+1 before tile t is evaluated was measured: no gain, +30 VGPRs)
     for (int tile = 0; tile < tpb; ++tile) {
         const size_t base = ((size_t)blockIdx.x * tpb + tile) * kBlock * U + threadIdx.x;
         if (base - threadIdx.x >= nv) break;
