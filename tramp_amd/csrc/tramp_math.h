@@ -54,6 +54,8 @@ TM_HD double fabs_(double x) { return ::fabs(x); }
 TM_HD float fabs_(float x) { return ::fabsf(x); }
 TM_HD double fmax_(double a, double b) { return ::fmax(a, b); }
 TM_HD float fmax_(float a, float b) { return ::fmaxf(a, b); }
+TM_HD double fmin_(double a, double b) { return ::fmin(a, b); }
+TM_HD float fmin_(float a, float b) { return ::fminf(a, b); }
 TM_HD double erf_(double x) { return ::erf(x); }
 TM_HD float erf_(float x) { return ::erff(x); }
 TM_HD double fma_(double a, double b, double c) { return ::fma(a, b, c); }
@@ -85,7 +87,8 @@ inline float fast_rcp(float x) { return 1.0f / x; }
 }  // namespace tmath
 #include "erfcx_table.h"
 namespace tmath {
-__device__ __forceinline__ double exp_fast(double x);
+__device__ __forceinline__ double exp_clamped(double x);
+__device__ __forceinline__ double rcp_pos(double x);
 // The table is read from LDS, coefficient-major ([j][k], 8-byte entries): rows 16..31 (x <= 4, i.e. all
 // but the far tail) sit in 16 different bank pairs, so the 8 ds_read_b64 of one evaluation are
 // conflict-free whatever rows the lanes of a wave need.  (Read straight from global memory the same
@@ -99,8 +102,8 @@ __device__ __forceinline__ void erfcx_lds_init() {
     __syncthreads();
 }
 __device__ __forceinline__ double erfcx_hot(double x) {
-    const double w = ::fabs(x);
-    const double t = 4.0 * fast_rcp(4.0 + w);
+    const double w = ::fmin(::fabs(x), 1e300);                // erfcx(1e300) = 5.6e-301; a NaN x reaches the caller through x itself
+    const double t = 4.0 * rcp_pos(4.0 + w);
     const double tk = t * (double)kErfcxK;
     const int k = (tk >= 0.0 && tk < (double)kErfcxK) ? (int)tk : (tk >= (double)kErfcxK ? kErfcxK - 1 : 0);
     const double s = ::fma(2.0, tk - (double)k, -1.0);
@@ -109,7 +112,7 @@ __device__ __forceinline__ double erfcx_hot(double x) {
 #pragma unroll
     for (int j = kErfcxD - 1; j >= 0; --j) acc = ::fma(acc, s, p[j * kErfcxK]);
     double e = t * acc;
-    if (x < 0.0) e = 2.0 * exp_fast(x * x) - e;
+    if (x < 0.0) e = 2.0 * exp_clamped(x * x) - e;
     return e;
 }
 __device__ __forceinline__ float erfcx_hot(float x) { return ::erfcxf(x); }
@@ -128,10 +131,9 @@ template <typename T> TM_HD void erfcx_setup() {
 // reduction it does not need here (~46 VALU instructions); n = rint(x log2 e), r = x - n ln2 (two parts),
 // degree-12 Taylor polynomial on |r| <= ln2/2 (truncation 2e-16), one ldexp: ~22 instructions, 1-2 ulp.
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ double exp_fast(double x);
-__device__ __forceinline__ double exp_nonpos(double x) { return exp_fast(x); }
-// any argument: the result saturates to 0 below -745.2 and to +inf above 709.78 like the library's
-__device__ __forceinline__ double exp_fast(double x) {
+// core: exp(x) for |x| within the f64 range (callers clamp); v_ldexp_f64 scales by any n in one step,
+// denormal results included (tools/probes/probe_rcp_ldexp.hip)
+__device__ __forceinline__ double exp_core(double x) {
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = ::fma(n, -6.93147180369123816490e-01, x);
     r = ::fma(n, -1.90821492927058770002e-10, r);
@@ -148,20 +150,35 @@ __device__ __forceinline__ double exp_fast(double x) {
     p = ::fma(p, r, 0.5);
     p = ::fma(p, r, 1.0);
     p = ::fma(p, r, 1.0);
-    // two-step scaling: |n| can reach 1075, beyond one ldexp's exact range for the intermediate
-    const int ni = (int)n, n1 = ni / 2;
-    const double e = ::ldexp(::ldexp(p, n1), ni - n1);
+    return ::ldexp(p, (int)n);
+}
+// any argument: the result saturates to 0 below -745.2 and to +inf above 709.78 like the library's
+__device__ __forceinline__ double exp_fast(double x) {
+    const double e = exp_core(x);
     return x < -745.2 ? 0.0 : (x > 709.79 ? __builtin_inf() : e);      // -inf -> 0, +inf -> inf; NaN propagates through p
 }
+__device__ __forceinline__ double exp_nonpos(double x) { return exp_fast(x); }
+// Saturating by clamping the ARGUMENT (two instructions instead of two compare + select pairs); a NaN
+// argument is swallowed by the clamp (maxNum / minNum), so these are for call sites whose result is
+// multiplied into, or added to, a quantity that carries the NaN anyway.
+__device__ __forceinline__ double exp_clamped(double x) { return exp_core(::fmin(::fmax(x, -746.0), 709.78)); }
+__device__ __forceinline__ double exp_clamped_nonpos(double x) { return exp_core(::fmax(x, -746.0)); }
+__device__ __forceinline__ float exp_clamped(float x) { return ::expf(x); }
+__device__ __forceinline__ float exp_clamped_nonpos(float x) { return ::expf(x); }
 __device__ __forceinline__ float exp_nonpos(float x) { return ::expf(x); }
 __device__ __forceinline__ float exp_fast(float x) { return ::expf(x); }
 // 1/x for x in [1, 2]: hardware estimate + two Newton steps, no special cases to guard
+// v_rcp_f64 is good to 4.6e-8 (tools/probes/probe_rcp_ldexp.hip): one cubic step r (1 + e + e^2),
+// e = 1 - x r, brings it to ~1e-22 before rounding (three FMAs; two Newton steps need four)
 __device__ __forceinline__ double rcp_1to2(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = ::fma(::fma(-x, r, 1.0), r, r);
-    return ::fma(::fma(-x, r, 1.0), r, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = ::fma(-x, r, 1.0);
+    return ::fma(::fma(e, e, e), r, r);
 }
 __device__ __forceinline__ float rcp_1to2(float x) { return __builtin_amdgcn_rcpf(x); }
+// 1/x for finite normal x > 0 (callers clamp to <= 1e300): the same, no 0 / inf / NaN guards
+__device__ __forceinline__ double rcp_pos(double x) { return rcp_1to2(x); }
+__device__ __forceinline__ float rcp_pos(float x) { return __builtin_amdgcn_rcpf(x); }
 #else
 TM_HD double exp_nonpos(double x) { return ::exp(x); }
 TM_HD float exp_nonpos(float x) { return ::expf(x); }
@@ -169,7 +186,17 @@ TM_HD double exp_fast(double x) { return ::exp(x); }
 TM_HD float exp_fast(float x) { return ::expf(x); }
 TM_HD double rcp_1to2(double x) { return 1.0 / x; }
 TM_HD float rcp_1to2(float x) { return 1.0f / x; }
+TM_HD double rcp_pos(double x) { return 1.0 / x; }
+TM_HD float rcp_pos(float x) { return 1.0f / x; }
+TM_HD double exp_clamped(double x) { return ::exp(x); }
+TM_HD float exp_clamped(float x) { return ::expf(x); }
+TM_HD double exp_clamped_nonpos(double x) { return ::exp(x); }
+TM_HD float exp_clamped_nonpos(float x) { return ::expf(x); }
 #endif
+// largest operand handed to rcp_pos (1/x stays a normal number)
+template <typename T> struct RcpCap;
+template <> struct RcpCap<double> { static constexpr double value = 1e300; };
+template <> struct RcpCap<float> { static constexpr float value = 1e37f; };
 
 // tanh for the streaming kernels: sign(x) (1 - e)/(1 + e), e = exp(-2|x|) in (0, 1]; for |x| < 0.25 the
 // quotient loses up to 3 bits to cancellation, where the odd series x (1 - x^2/3 + 2x^4/15 - ...) is used
@@ -201,7 +228,7 @@ TM_HD float tanh_hot(float x) { return ::tanhf(x); }
 
 // scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal of 1 + e in [1, 2].
 template <typename T> TM_HD T expit(T x) {
-    T e = exp_nonpos(-fabs_(x));
+    T e = exp_clamped_nonpos(-fabs_(x));      // NaN x: see exp_clamped (the callers' b/a factor carries it)
     T r = rcp_1to2(T(1) + e);
     return x < T(0) ? e * r : r;
 }
@@ -316,7 +343,7 @@ TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0, T
     T sd = T(side);
     T x = sd * (y0 * T(0.70710678118654752440));
     T e = erfcx_hot(x);
-    T ie = fast_rcp(e);
+    T ie = rcp_pos(fmin_(e, RcpCap<T>::value));       // e = inf (x << 0) -> ~0; NaN travels through x and r0
     T g1 = T(kSqrt2OverPi) * (sd * ie);
     T g2 = T(kTwoOverSqrtPi) * (x * ie);
     HalfLine<T> h;
@@ -354,7 +381,7 @@ TM_HD HalfLineF<T> halfline_factor(T b, const RegionConst<T>& c, int side, T& r0
     }
     T x = sd * (y0 * T(0.70710678118654752440));
     T e = erfcx_hot(x);
-    T ie = fast_rcp(e);
+    T ie = rcp_pos(fmin_(e, RcpCap<T>::value));       // e = inf (x << 0) -> ~0; NaN travels through x and r0
     T g1 = T(kSqrt2OverPi) * (sd * ie);
     T g2 = T(kTwoOverSqrtPi) * (x * ie);
     HalfLineF<T> h;
@@ -591,11 +618,11 @@ TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
     //   t = exp(A1 - A0) = (f1 / f0) exp(-(Q0 - Q1)),  p0 = 1 / (1 + t),  p1 = t / (1 + t).
     // The exponent is applied in two halves so that exp never saturates while t itself is finite; the
     // small probability is formed directly (rr, or t * rr), never as 1 - big.
-    const T E = exp_fast(T(-0.5) * (Qs[0] - Qs[1]));
-    const T t = ((fs[1] * ifs[0]) * E) * E;
-    const T rr = fast_rcp(T(1) + t);
+    const T E = exp_clamped(T(-0.5) * (Qs[0] - Qs[1]));
+    const T t = fmin_(((fs[1] * ifs[0]) * E) * E, RcpCap<T>::value);     // capped: p0 = 1e-300 stands for 0, p1 = t rr = 1
+    const T rr = rcp_pos(T(1) + t);
     const T p0 = rr;
-    const T p1 = (rr == T(0)) ? T(1) : t * rr;              // t = inf (or beyond 1/denorm): rr = 0, t * rr would be NaN
+    const T p1 = t * rr;
     PwlOut<T> o;
     o.r = p0 * rs[0] + p1 * rs[1];
     T d = rs[0] - rs[1];
