@@ -108,7 +108,7 @@ template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
 };
 
 template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
-    static constexpr bool HEAVY = true;
+    static constexpr bool HEAVY = false;      // 64 instructions per component (tanh_hot): recomputed in pass 2 (5T moved, not 6T)
     static constexpr int NIN = 2;
     static constexpr int TARGET = 0;
     const double* az;

@@ -15,6 +15,12 @@
 #else
 #define TM_HD inline
 #endif
+// true when the predicate holds on every active lane of the wave (device); the plain predicate elsewhere
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TM_WAVE_ALL(p) (__all((p) ? 1 : 0) != 0)
+#else
+#define TM_WAVE_ALL(p) (p)
+#endif
 
 namespace tmath {
 
@@ -105,7 +111,7 @@ __device__ __forceinline__ double erfcx_hot(double x) {
     const double w = ::fmin(::fabs(x), 1e300);                // erfcx(1e300) = 5.6e-301; a NaN x reaches the caller through x itself
     const double t = 4.0 * rcp_pos(4.0 + w);
     const double tk = t * (double)kErfcxK;
-    const int k = (tk >= 0.0 && tk < (double)kErfcxK) ? (int)tk : (tk >= (double)kErfcxK ? kErfcxK - 1 : 0);
+    const int k = min((int)tk, kErfcxK - 1);                   // t in (0, 1]: tk in (0, K]
     const double s = ::fma(2.0, tk - (double)k, -1.0);
     const double* p = g_erfcx_lds + k;
     double acc = p[kErfcxD * kErfcxK];
@@ -364,7 +370,7 @@ TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0, T
 // reciprocal, and the exponent part q = -u^2/2 (0 under the mask) - the softmax over two regions needs
 // only the ratio of the two probabilities, so no logarithm is ever taken (two f64 logs, ~200
 // instructions per component, saved).
-template <typename T> struct HalfLineF { T mean, var, f, inv_f, q; bool mask; };
+template <typename T> struct HalfLineF { T mean, var, e, ie, y0; bool mask; };
 
 template <typename T>
 TM_HD HalfLineF<T> halfline_factor(T b, const RegionConst<T>& c, int side, T& r0, T zb = T(0)) {
@@ -387,11 +393,10 @@ TM_HD HalfLineF<T> halfline_factor(T b, const RegionConst<T>& c, int side, T& r0
     HalfLineF<T> h;
     h.mean = r0 + c.s0 * g1;
     h.var = c.v0 * (T(1) + g2 - g1 * g1);
-    T u = -sd * y0;
-    h.mask = u < LogPhiCut<T>::value;
-    h.f = h.mask ? T(0.5) * e : T(1);
-    h.inv_f = h.mask ? T(2) * ie : T(1);
-    h.q = h.mask ? T(-0.5) * (u * u) : T(0);
+    h.mask = -sd * y0 < LogPhiCut<T>::value;          // u = -side y0, the argument of log_Phi
+    h.e = e;
+    h.ie = ie;
+    h.y0 = y0;
     return h;
 }
 
@@ -561,7 +566,7 @@ TM_HD PwlOut<T> pwl_posterior(T bz, T bx, T az, T ax) {
 // KIND 3 = generic pair of half-line regions [zb, inf) and (-inf, zb] with run-time slopes and
 // offsets: LeakyReluChannel (slopes 1 / s, zb = 0; piecewise_linear_channel.py:72-77) and
 // AsymmetricAbsChannel (slopes +1 / -1, zb = shift; :94-99).
-template <typename T> struct PwlConst { RegionConst<T> reg[2]; T az, ax; T slope[2], x0[2], zb; };
+template <typename T> struct PwlConst { RegionConst<T> reg[2]; T az, ax; T slope[2], x0[2], zb, s_ratio; };
 
 template <int KIND> TM_HD PwlSpec pwl_spec_of(const PwlSpec& rt) {
     if (KIND == 3) return rt;
@@ -584,42 +589,86 @@ template <typename T, int KIND> TM_HD PwlConst<T> pwl_const(double az, double ax
         c.x0[k] = T(sp.x0[k]);
         c.reg[k] = region_const<T>((double)(c.az + c.slope[k] * c.slope[k] * c.ax));
     }
+    c.s_ratio = c.reg[1].s0 * c.reg[0].inv_s0;        // exp(hl_1 - hl_0), hl = 0.5 log(2 pi v0)
     return c;
 }
 
 template <typename T, int KIND, bool FWD>
 TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
-    T rs[2], vs[2], Qs[2], fs[2], ifs[2];
+    T rs[2], vs[2], r0s[2];
+    HalfLineF<T> h[2];
     unsigned mask = 0;
+    const T zb = KIND < 3 ? T(0) : c.zb;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        // compile-time constants for Sgn/Abs/Relu (folds the 0 / 1 slopes away), run-time for KIND 3
-        const T slope = KIND < 3 ? T(pwl_slope(KIND < 3 ? KIND : 0, k)) : c.slope[k];
-        const T x0 = KIND < 3 ? T(pwl_x0(KIND < 3 ? KIND : 0, k)) : c.x0[k];
         const int side = (k == 0) ? +1 : -1;
-        T b = bz + slope * (bx - c.ax * x0);
-        T r0;
-        HalfLineF<T> h = halfline_factor<T>(b, c.reg[k], side, r0, KIND < 3 ? T(0) : c.zb);
-        // log-partition of the region = Qs + log(fs):  0.5 r0^2 / v0 = 0.5 r0^2 a
-        Qs[k] = c.reg[k].half_log2piv0 + T(0.5) * (r0 * r0) * c.reg[k].a + h.q
-                - T(0.5) * c.ax * (x0 * x0) + bx * x0;
-        fs[k] = h.f;
-        ifs[k] = h.inv_f;
-        if (FWD) {
-            rs[k] = slope * h.mean + x0;
-            vs[k] = slope * slope * h.var;
+        // Sgn/Abs/Relu: slopes in {0, 1, -1} and offsets in {0, 1, -1} are compile-time, and the products
+        // with 0 and 1 are not formed at all (IEEE arithmetic may not fold x * 0); KIND 3: run-time table
+        const double sl = pwl_slope(KIND < 3 ? KIND : 0, k), xc = pwl_x0(KIND < 3 ? KIND : 0, k);
+        T b;
+        if (KIND < 3) {
+            const T inner = (xc == 0.0) ? bx : bx - c.ax * T(xc);
+            b = (sl == 0.0) ? bz : (sl == 1.0 ? bz + inner : bz - inner);
         } else {
-            rs[k] = h.mean;
-            vs[k] = h.var;
+            b = bz + c.slope[k] * (bx - c.ax * c.x0[k]);
         }
-        mask |= (h.mask ? 1u : 0u) << k;
+        h[k] = halfline_factor<T>(b, c.reg[k], side, r0s[k], zb);
+        if (!FWD) {
+            rs[k] = h[k].mean;
+            vs[k] = h[k].var;
+        } else if (KIND < 3) {
+            const T m = (sl == 0.0) ? T(0) : (sl == 1.0 ? h[k].mean : -h[k].mean);
+            rs[k] = (xc == 0.0) ? m : (sl == 0.0 ? T(xc) : m + T(xc));
+            vs[k] = (sl == 0.0) ? T(0) : h[k].var;
+        } else {
+            rs[k] = c.slope[k] * h[k].mean + c.x0[k];
+            vs[k] = c.slope[k] * c.slope[k] * h[k].var;
+        }
+        mask |= (h[k].mask ? 1u : 0u) << k;
     }
-    // softmax over two regions (piecewise_linear_channel.py:27-29) = logistic of A0 - A1:
-    //   t = exp(A1 - A0) = (f1 / f0) exp(-(Q0 - Q1)),  p0 = 1 / (1 + t),  p1 = t / (1 + t).
-    // The exponent is applied in two halves so that exp never saturates while t itself is finite; the
-    // small probability is formed directly (rr, or t * rr), never as 1 - big.
-    const T E = exp_clamped(T(-0.5) * (Qs[0] - Qs[1]));
-    const T t = fmin_(((fs[1] * ifs[0]) * E) * E, RcpCap<T>::value);     // capped: p0 = 1e-300 stands for 0, p1 = t rr = 1
+    // softmax over two regions (piecewise_linear_channel.py:27-29) = logistic of A0 - A1 with the region
+    // log-partitions (linear_region.py:55-64)
+    //   A_k = 0.5 a_k r0_k^2 + hl_k + [log(0.5 erfcx(x_k)) - 0.5 u_k^2] + X_k,   X_k = -0.5 ax x0_k^2 + bx x0_k,
+    // hl_k = 0.5 log(2 pi v0_k), u_k^2 = a_k (zb - r0_k)^2, the bracket replaced by 0 where u_k >= 30 (the
+    // reference's log_Phi mask).  t = exp(A1 - A0), p0 = 1 / (1 + t), p1 = t / (1 + t): the small
+    // probability is formed directly, never as 1 - big.
+    T t;
+    if (TM_WAVE_ALL(mask == 3u)) {
+        // no lane is under the mask: 0.5 a r0^2 - 0.5 u^2 = a zb (r0 - zb / 2) in closed form (0 for zb = 0:
+        // the Gaussian normaliser cancels the tail exponent), exp(hl_1 - hl_0) = s0_1 / s0_0 per instance,
+        // no logarithm - and for Abs / Relu (X_k = 0) no exponential either
+        const T ratio = (h[1].e * h[0].ie) * c.s_ratio;
+        if (KIND == 1 || KIND == 2) {
+            t = ratio;
+        } else {
+            T D;
+            if (KIND == 0) {
+                D = T(-2) * bx;                                  // X_1 - X_0 = bx (x0_1 - x0_0)
+            } else {
+                T Dk[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    Dk[k] = c.reg[k].a * zb * (r0s[k] - T(0.5) * zb) - T(0.5) * c.ax * (c.x0[k] * c.x0[k]) + bx * c.x0[k];
+                D = Dk[1] - Dk[0];
+            }
+            const T E = exp_clamped(T(0.5) * D);                 // applied in two halves: t finite whenever it can be
+            t = (ratio * E) * E;
+        }
+    } else {
+        T Qs[2], fs[2], ifs[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const T x0 = KIND < 3 ? T(pwl_x0(KIND < 3 ? KIND : 0, k)) : c.x0[k];
+            const T u = h[k].y0;
+            Qs[k] = c.reg[k].half_log2piv0 + T(0.5) * (r0s[k] * r0s[k]) * c.reg[k].a
+                    + (h[k].mask ? T(-0.5) * (u * u) : T(0)) - T(0.5) * c.ax * (x0 * x0) + bx * x0;
+            fs[k] = h[k].mask ? T(0.5) * h[k].e : T(1);
+            ifs[k] = h[k].mask ? T(2) * h[k].ie : T(1);
+        }
+        const T E = exp_clamped(T(-0.5) * (Qs[0] - Qs[1]));
+        t = ((fs[1] * ifs[0]) * E) * E;
+    }
+    t = fmin_(t, RcpCap<T>::value);                              // capped: p0 = 1e-300 stands for 0, p1 = t rr = 1
     const T rr = rcp_pos(T(1) + t);
     const T p0 = rr;
     const T p1 = t * rr;
