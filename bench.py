@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-denoiser", action="store_true")
     ap.add_argument("--no-se", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=4000)
-    ap.add_argument("--cpu-n-thin", type=int, default=12000)
+    ap.add_argument("--cpu-n-thin", type=int, default=8000)
     ap.add_argument("--save-factors", default=None, metavar="DIR",
                     help="after the setup, dump the thin factors (Uk, Vt, sing) and the observations to DIR")
     ap.add_argument("--load-factors", default=None, metavar="DIR",
@@ -226,6 +226,53 @@ def denoiser_roofline(T, ctx, dtype):
                       "form": "producer-fused moments (ConvChannel inverse-FFT epilogue) + ONE update pass (2T moved)"}
     except Exception as e:                                                    # noqa: BLE001
         out["B64"] = {"error": repr(e)}
+    return out
+
+
+# VALU instructions per component of the first pass (profiles/r02/elementwise_traffic_and_instructions.txt,
+# rocprofv3 --pmc SQ_INSTS_VALU of these very launches); a wave64 f64 instruction occupies a SIMD for 4 cycles
+VALU_PER_COMPONENT_F64 = {"l1_prior": 33 + 28, "sgn_lik": 92 + 11, "abs_lik": 64 + 64 + 11, "relu_bwd": 207 + 11,
+                          "relu_fwd": 190 + 11, "sgn_bwd": 234 + 11, "abs_bwd": 204 + 11}
+
+
+def factor_updates_n1e6(T, ctx, dtype):
+    """The other componentwise factor updates of the hot path at the BASELINE vector size, 64 x 1e6: L1 prior
+    (K2, 2T algorithmic bytes per component), sign / abs likelihoods (K4 / K5, 3T), Relu / Sgn / Abs channels
+    (K7, 3T).  K4 and K7 are f64-VALU-bound (erfcx, exp, reciprocals per component): besides the fraction of
+    the HBM peak the line carries the fraction of the chip's f64 VALU issue rate their instruction count
+    amounts to (1024 SIMDs x 16 lanes per cycle at 2.4 GHz)."""
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    esz = np.dtype(np_dt).itemsize
+    B, N = 64, 1_000_000
+    bz = ctx.randn((B, N), np_dt, seed=1, scale=1.5)
+    bx = ctx.randn((B, N), np_dt, seed=2, scale=1.5)
+    y = ctx.array(np.sign(np.random.RandomState(0).standard_normal((B, N))).astype(np_dt), np_dt)
+    az, ax = ctx.scalars(1.3, B), ctx.scalars(0.7, B)
+    kw = dict(out_a=ctx.empty((B,), np.float64), out_b=ctx.empty((B, N), np_dt))
+    l1 = T.MAP_L1NormPrior(size=N, gamma=1.0, dtype=np_dt, ctx=ctx)
+    sg = T.SgnLikelihood(y=y, dtype=np_dt, ctx=ctx)
+    ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
+    relu, sgn, abs_ = (T.ReluChannel(dtype=np_dt, ctx=ctx), T.SgnChannel(dtype=np_dt, ctx=ctx),
+                       T.AbsChannel(dtype=np_dt, ctx=ctx))
+    cases = [("l1_prior", "K2", 2, lambda: l1.compute_forward_message(ax, bx, **kw)),
+             ("sgn_lik", "K4", 3, lambda: sg.compute_backward_message(az, bz, **kw)),
+             ("abs_lik", "K5", 3, lambda: ab.compute_backward_message(az, bz, **kw)),
+             ("relu_bwd", "K7", 3, lambda: relu.compute_backward_message(az, bz, ax, bx, **kw)),
+             ("relu_fwd", "K7", 3, lambda: relu.compute_forward_message(az, bz, ax, bx, **kw)),
+             ("sgn_bwd", "K7", 3, lambda: sgn.compute_backward_message(az, bz, ax, bx, **kw)),
+             ("abs_bwd", "K7", 3, lambda: abs_.compute_backward_message(az, bz, ax, bx, **kw))]
+    out = {"n": N, "batch": B}
+    for name, kern, nT, fn in cases:
+        ms = _timed(ctx, fn, 8)
+        alg = nT * esz * N * B
+        rec = {"kernel": kern, "us_per_update": ms * 1e3, "algorithmic_bytes_per_component": nT * esz,
+               "algorithmic_GBps": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
+               "components_per_sec": N * B / (ms * 1e-3)}
+        if dtype == "f64":
+            instr = VALU_PER_COMPONENT_F64[name]
+            rec["valu_instructions_per_component"] = instr
+            rec["frac_of_f64_valu_issue_peak"] = instr * N * B / 64.0 * 4.0 / 1024.0 / 2.4e9 / (ms * 1e-3)
+        out[name] = rec
     return out
 
 
@@ -494,6 +541,10 @@ def run(args):
         }
         if world == 1 and not args.no_denoiser:
             out["denoiser_n1e6"] = denoiser_roofline(T, ctx, args.dtype)
+            try:
+                out["factor_updates_n1e6"] = factor_updates_n1e6(T, ctx, args.dtype)
+            except Exception as e:                                            # noqa: BLE001
+                out["factor_updates_n1e6"] = {"error": repr(e)}
             try:
                 out["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
             except Exception as e:                                            # noqa: BLE001
