@@ -95,6 +95,7 @@ inline float fast_rcp(float x) { return 1.0f / x; }
 namespace tmath {
 __device__ __forceinline__ double exp_clamped(double x);
 __device__ __forceinline__ double rcp_pos(double x);
+__device__ __forceinline__ float exp_clamped(float x);
 // The table is read from LDS, coefficient-major ([j][k], 8-byte entries): rows 16..31 (x <= 4, i.e. all
 // but the far tail) sit in 16 different bank pairs, so the 8 ds_read_b64 of one evaluation are
 // conflict-free whatever rows the lanes of a wave need.  (Read straight from global memory the same
@@ -105,6 +106,13 @@ __shared__ double g_erfcx_lds[(kErfcxD + 1) * kErfcxK];
 __device__ __forceinline__ void erfcx_lds_init() {
     for (int i = threadIdx.x; i < (kErfcxD + 1) * kErfcxK; i += blockDim.x)
         g_erfcx_lds[i] = kErfcxTable[i % kErfcxK][i / kErfcxK];
+    __syncthreads();
+}
+// f32 kernels: their own table (degree 4, 4-byte entries: the 32 rows sit in 32 different banks)
+__shared__ float g_erfcx_lds_f[(kErfcxDF + 1) * kErfcxKF];
+__device__ __forceinline__ void erfcx_lds_init_f() {
+    for (int i = threadIdx.x; i < (kErfcxDF + 1) * kErfcxKF; i += blockDim.x)
+        g_erfcx_lds_f[i] = kErfcxTableF[i % kErfcxKF][i / kErfcxKF];
     __syncthreads();
 }
 __device__ __forceinline__ double erfcx_hot(double x) {
@@ -121,7 +129,22 @@ __device__ __forceinline__ double erfcx_hot(double x) {
     if (x < 0.0) e = 2.0 * exp_clamped(x * x) - e;
     return e;
 }
-__device__ __forceinline__ float erfcx_hot(float x) { return ::erfcxf(x); }
+// f32: the same construction on the float table (4e-7 relative for x >= 0, a few ulp of float; the library's
+// erfcxf is ~45 instructions)
+__device__ __forceinline__ float erfcx_hot(float x) {
+    const float w = ::fminf(::fabsf(x), 1e37f);
+    const float t = 4.0f * __builtin_amdgcn_rcpf(4.0f + w);
+    const float tk = t * (float)kErfcxKF;
+    const int k = min((int)tk, kErfcxKF - 1);
+    const float s = ::fmaf(2.0f, tk - (float)k, -1.0f);
+    const float* p = g_erfcx_lds_f + k;
+    float acc = p[kErfcxDF * kErfcxKF];
+#pragma unroll
+    for (int j = kErfcxDF - 1; j >= 0; --j) acc = ::fmaf(acc, s, p[j * kErfcxKF]);
+    float e = t * acc;
+    if (x < 0.0f) e = 2.0f * exp_clamped(x * x) - e;
+    return e;
+}
 #else
 TM_HD double erfcx_hot(double x) { return erfcx_(x); }      // host pass / plain C++ (tests/host_math)
 TM_HD float erfcx_hot(float x) { return erfcx_(x); }
@@ -130,6 +153,7 @@ TM_HD float erfcx_hot(float x) { return erfcx_(x); }
 template <typename T> TM_HD void erfcx_setup() {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (sizeof(T) == 8) erfcx_lds_init();
+    else erfcx_lds_init_f();
 #endif
 }
 
@@ -169,8 +193,15 @@ __device__ __forceinline__ double exp_nonpos(double x) { return exp_fast(x); }
 // multiplied into, or added to, a quantity that carries the NaN anyway.
 __device__ __forceinline__ double exp_clamped(double x) { return exp_core(::fmin(::fmax(x, -746.0), 709.78)); }
 __device__ __forceinline__ double exp_clamped_nonpos(double x) { return exp_core(::fmax(x, -746.0)); }
-__device__ __forceinline__ float exp_clamped(float x) { return ::expf(x); }
-__device__ __forceinline__ float exp_clamped_nonpos(float x) { return ::expf(x); }
+// f32: two-part reduction, v_exp_f32 on |r| <= ln2 / 2, one ldexp (~1e-7 relative; expf is ~15 instructions)
+__device__ __forceinline__ float exp_core(float x) {
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = ::fmaf(n, -6.93145751953125e-01f, x);
+    r = ::fmaf(n, -1.42860682030941723e-06f, r);
+    return ::ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+}
+__device__ __forceinline__ float exp_clamped(float x) { return exp_core(::fminf(::fmaxf(x, -104.0f), 88.7f)); }
+__device__ __forceinline__ float exp_clamped_nonpos(float x) { return exp_core(::fmaxf(x, -104.0f)); }
 __device__ __forceinline__ float exp_nonpos(float x) { return ::expf(x); }
 __device__ __forceinline__ float exp_fast(float x) { return ::expf(x); }
 // 1/x for x in [1, 2]: hardware estimate + two Newton steps, no special cases to guard
