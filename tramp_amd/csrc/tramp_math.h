@@ -67,27 +67,10 @@ TM_HD float erf_(float x) { return ::erff(x); }
 TM_HD double fma_(double a, double b, double c) { return ::fma(a, b, c); }
 TM_HD float fma_(float a, float b, float c) { return ::fmaf(a, b, c); }
 
-// Reciprocal without the IEEE division fix-up sequence (about 5 instead of ~25 instructions in
-// f64): hardware estimate + two Newton steps, within 1 ulp for normal operands; 0 -> inf,
-// inf -> 0 as 1/x.  Used only where no branch mask depends on the quotient.
-#if defined(__HIP_DEVICE_COMPILE__)
-TM_HD double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = (e == e && fabs(e) < 1.0) ? fma(r, e, r) : r;      // skip the refinement for 0 / inf / nan
-    e = fma(-x, r, 1.0);
-    return (e == e && fabs(e) < 1.0) ? fma(r, e, r) : r;
-}
-TM_HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-#else
-inline double fast_rcp(double x) { return 1.0 / x; }
-inline float fast_rcp(float x) { return 1.0f / x; }
-#endif
-
 // erfcx for the streaming kernels (K4, K7).  The library's f64 erfcx costs 130-160 instructions on
 // gfx950 (three range branches, all taken by some lane of a wave); here: erfcx(x) = t g(t), t = 4/(4 + |x|),
 // g a degree-7 polynomial on one of 32 intervals of t (erfcx_table.h, fitted to mpmath, relative error
-// 8e-16), four 16-byte table loads (2 KiB table, L1-resident) and seven FMAs; x < 0 by
+// 3e-15; f32: degree 4, own table), eight LDS reads (see below) and seven FMAs; x < 0 by
 // erfcx(x) = 2 exp(x^2) - erfcx(-x).  No branch mask depends on an erfcx value.
 #if defined(__HIP_DEVICE_COMPILE__)
 }  // namespace tmath
@@ -204,7 +187,7 @@ __device__ __forceinline__ float exp_clamped(float x) { return exp_core(::fminf(
 __device__ __forceinline__ float exp_clamped_nonpos(float x) { return exp_core(::fmaxf(x, -104.0f)); }
 __device__ __forceinline__ float exp_nonpos(float x) { return ::expf(x); }
 __device__ __forceinline__ float exp_fast(float x) { return ::expf(x); }
-// 1/x for x in [1, 2]: hardware estimate + two Newton steps, no special cases to guard
+// 1/x for x in [1, 2]: hardware estimate + one cubic correction, no special cases to guard
 // v_rcp_f64 is good to 4.6e-8 (tools/probes/probe_rcp_ldexp.hip): one cubic step r (1 + e + e^2),
 // e = 1 - x r, brings it to ~1e-22 before rounding (three FMAs; two Newton steps need four)
 __device__ __forceinline__ double rcp_1to2(double x) {
