@@ -52,7 +52,7 @@ def table(name, dirs):
     return per
 
 
-ks = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True))
+ks = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if ks:
     shutil.copy(ks[-1], os.path.join(dst, "kernel_stats_default_bench_N100000.csv"))
 for f, n in (("bench_under_rocprof.json", "bench_under_rocprof_N100000.json"),):
