@@ -146,23 +146,21 @@ template <typename T> TM_HD void erfcx_setup() {
 #if defined(__HIP_DEVICE_COMPILE__)
 // core: exp(x) for |x| within the f64 range (callers clamp); v_ldexp_f64 scales by any n in one step,
 // denormal results included (tools/probes/probe_rcp_ldexp.hip)
+// The Taylor coefficients are read through the scalar cache (uniform address: s_load into SGPRs, which a
+// v_fma_f64 takes as an operand): as literals the compiler materialises each in a VGPR pair first - 13
+// v_mov_b64 per evaluation on the VALU that these kernels are bound by.
+__constant__ double kExpTaylor[13] = {
+    2.08767569878680989792e-09,             // 1/12!
+    2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06, 2.48015873015873015873e-05,
+    1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
+    1.66666666666666666667e-01, 0.5, 1.0, 1.0};
 __device__ __forceinline__ double exp_core(double x) {
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = ::fma(n, -6.93147180369123816490e-01, x);
     r = ::fma(n, -1.90821492927058770002e-10, r);
-    double p = 2.08767569878680989792e-09;                 // 1/12!
-    p = ::fma(p, r, 2.50521083854417187751e-08);            // 1/11!
-    p = ::fma(p, r, 2.75573192239858906526e-07);            // 1/10!
-    p = ::fma(p, r, 2.75573192239858906526e-06);            // 1/9!
-    p = ::fma(p, r, 2.48015873015873015873e-05);            // 1/8!
-    p = ::fma(p, r, 1.98412698412698412698e-04);            // 1/7!
-    p = ::fma(p, r, 1.38888888888888888889e-03);            // 1/6!
-    p = ::fma(p, r, 8.33333333333333333333e-03);            // 1/5!
-    p = ::fma(p, r, 4.16666666666666666667e-02);            // 1/4!
-    p = ::fma(p, r, 1.66666666666666666667e-01);            // 1/3!
-    p = ::fma(p, r, 0.5);
-    p = ::fma(p, r, 1.0);
-    p = ::fma(p, r, 1.0);
+    double p = kExpTaylor[0];
+#pragma unroll
+    for (int i = 1; i < 13; ++i) p = ::fma(p, r, kExpTaylor[i]);
     return ::ldexp(p, (int)n);
 }
 // any argument: the result saturates to 0 below -745.2 and to +inf above 709.78 like the library's
@@ -222,20 +220,17 @@ template <> struct RcpCap<float> { static constexpr float value = 1e37f; };
 // quotient loses up to 3 bits to cancellation, where the odd series x (1 - x^2/3 + 2x^4/15 - ...) is used
 // instead (the library's f64 tanh is ~170 instructions on gfx950; this is ~45).
 #if defined(__HIP_DEVICE_COMPILE__)
+__constant__ double kTanhSeries[8] = {-929569.0 / 638512875.0, 21844.0 / 6081075.0, -1382.0 / 155925.0, 62.0 / 2835.0,
+                                      -17.0 / 315.0,          2.0 / 15.0,          -1.0 / 3.0,         1.0};     // scalar-cache operands, as kExpTaylor
 __device__ __forceinline__ double tanh_hot(double x) {
     const double ax = ::fabs(x);
     const double e = exp_fast(-2.0 * ax);
     const double big = (1.0 - e) * rcp_1to2(1.0 + e);
     const double x2 = x * x;
     // odd Taylor series to x^15 on |x| < 0.25: truncation 1.4e-13 relative
-    double p = -929569.0 / 638512875.0;
-    p = ::fma(p, x2, 21844.0 / 6081075.0);
-    p = ::fma(p, x2, -1382.0 / 155925.0);
-    p = ::fma(p, x2, 62.0 / 2835.0);
-    p = ::fma(p, x2, -17.0 / 315.0);
-    p = ::fma(p, x2, 2.0 / 15.0);
-    p = ::fma(p, x2, -1.0 / 3.0);
-    p = ::fma(p, x2, 1.0);
+    double p = kTanhSeries[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) p = ::fma(p, x2, kTanhSeries[i]);
     const double small = ax * p;
     const double t = ax < 0.25 ? small : big;
     return x < 0.0 ? -t : t;
