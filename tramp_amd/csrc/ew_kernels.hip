@@ -201,6 +201,11 @@ template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 
     }
 };
 
+// Only the L1 prior reports a support count (MAP_L1NormPrior's mask, map_L1_norm_prior.py:16-17): the other
+// ops do not carry the 64-bit counter through their loops.
+template <typename Op> struct OpCounts { static constexpr bool value = false; };
+template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };
+
 // ---------------------------------------------------------------- pass 1: moments
 template <typename T> __device__ __forceinline__ bool not_finite(T x) { return (x - x) != T(0); }
 
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, size_t inst0
                 EwOut<T> o = op.eval(vget<T>(v0, j), vget<T>(v1, j));
                 acc += (double)o.v;
                 if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
-                cnt += o.mask & 1u;
+                if (OpCounts<Op>::value) cnt += o.mask & 1u;
                 vset<T>(vr, j, o.r);
                 if (mo) mo[i * VN + j] = (uint8_t)o.mask;
             }
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, size_t inst0
             EwOut<T> o = op.eval(x0, x1);
             acc += (double)o.v;
             if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
-            cnt += o.mask & 1u;
+            if (OpCounts<Op>::value) cnt += o.mask & 1u;
             if (pr) pr[i] = o.r;
             if (mo) mo[i] = (uint8_t)o.mask;
         }
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void ew_single(Op op, size_t n, const T* __
                 EwOut<T> o = op.eval((Op::TARGET == 0) ? xt : xo, (Op::TARGET == 0) ? xo : xt);
                 acc += (double)o.v;
                 if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
-                cnt += o.mask & 1u;
+                if (OpCounts<Op>::value) cnt += o.mask & 1u;
                 vset<T>(rr[k], j, o.r);
             }
         }
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_
                     EwOut<T> o = op.eval(x0, x1);
                     acc += (double)o.v;
                     if (not_finite(o.r)) acc += __longlong_as_double(0x7ff8000000000000LL);
-                    cnt += o.mask & 1u;
+                    if (OpCounts<Op>::value) cnt += o.mask & 1u;
                     vset<T>(vr, j, o.r);
                     if (mo) mo[i * VN + j] = (uint8_t)o.mask;
                 }
