@@ -231,8 +231,8 @@ def denoiser_roofline(T, ctx, dtype):
 
 # VALU instructions per component of the first pass (profiles/r02/elementwise_traffic_and_instructions.txt,
 # rocprofv3 --pmc SQ_INSTS_VALU of these very launches); a wave64 f64 instruction occupies a SIMD for 4 cycles
-VALU_PER_COMPONENT_F64 = {"l1_prior": 33 + 28, "sgn_lik": 92 + 11, "abs_lik": 64 + 64 + 11, "relu_bwd": 207 + 11,
-                          "relu_fwd": 190 + 11, "sgn_bwd": 234 + 11, "abs_bwd": 204 + 11}
+VALU_PER_COMPONENT_F64 = {"l1_prior": 33 + 28, "sgn_lik": 81 + 11, "abs_lik": 63 + 60, "relu_bwd": 184 + 11,
+                          "relu_fwd": 167 + 11, "sgn_bwd": 202 + 11, "abs_bwd": 182 + 11}
 
 
 def factor_updates_n1e6(T, ctx, dtype):

@@ -8,7 +8,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def pmc(d):
-    fs = sorted(glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True))
+    fs = sorted(glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(set)
     if not fs:
