@@ -556,10 +556,33 @@ def run(args):
                 out["state_evolution"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        emit_result(out)
     if comm is not None:
         comm.barrier()
         comm.close()
+
+
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at
+    init, rocBLAS / rocSOLVER may warn): keep the real stdout aside for the result line and point fd 1 at
+    stderr for everything else, C libraries included."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_result(out):
+    line = (json.dumps(out) + "\n").encode()
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        os.write(1, line)
+    else:
+        os.write(_RESULT_FD, line)
 
 
 def main():
@@ -572,6 +595,7 @@ def main():
         # own launcher: one process per GPU, started BEFORE anything here touches the GPU
         from tramp_amd import ensemble
         sys.exit(ensemble.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    claim_stdout()             # after the launcher branch: the rank processes inherit the real stdout
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
