@@ -394,7 +394,10 @@ def run(args):
     rank, local_rank, world, _, _ = ensemble.env_world()
     force_dist = os.environ.get("TRAMP_BENCH_FORCE_DIST") == "1"      # RCCL path with one rank (1-GPU smoke test)
     ctx = T.Context(local_rank)
-    comm = ensemble.init_comm(ctx, backend="rccl") if (world > 1 or force_dist) else None
+    comm = None
+    if world > 1 or force_dist:
+        comm = ensemble.init_comm_or_sockets(ctx, log=lambda m: print("bench.py: " + m, file=sys.stderr))
+    every_rank_factorises = comm is not None and comm.backend != "rccl"
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     N, B = args.n, args.batch
     M = int(args.alpha * N)
@@ -422,7 +425,7 @@ def run(args):
         Vt = ctx.empty((k, N), np_dt)
         sing_d = ctx.empty((k,), np.float64)
         lin_rank = 0
-        if rank == 0:
+        if rank == 0 or every_rank_factorises:
             W = ctx.randn((M, N), np_dt, seed=1234, scale=1.0 / np.sqrt(N))
             ctx.sync()
             tf = time.perf_counter()
@@ -433,7 +436,7 @@ def run(args):
             factorize_s = time.perf_counter() - tf
             lin_rank = int(r_out.value)
             del W
-        if comm is not None:
+        if comm is not None and not every_rank_factorises:
             # shared sensing matrix: factorised once, ONE broadcast of its thin factors over xGMI
             bcast_s = comm.broadcast(Vt, root=0) + comm.broadcast(Uk, root=0) + comm.broadcast(sing_d, root=0)
             lin_rank = int(comm.gather_scalars([lin_rank])[0, 0])
@@ -527,8 +530,10 @@ def run(args):
                        "N": N, "M": M, "alpha": args.alpha, "instances_per_gpu": B,
                        "fallback_from": getattr(args, "fallback_from", None),
                        "instances_total": B * world, "parallelism": f"ensemble-shard x{world}",
-                       "collectives": "none in the timed region; setup: RCCL broadcast of the thin factors"
-                                      if comm is not None else "none (single rank)"},
+                       "collectives": ("none (single rank)" if comm is None else
+                                       "none in the timed region; RCCL unavailable: factors computed on every rank, "
+                                       "results gathered over host sockets" if every_rank_factorises else
+                                       "none in the timed region; setup: RCCL broadcast of the thin factors")},
             "roofline": roof,
             "kernels": kern,
             "setup": {"total_s": setup_s, "factorize_s": factorize_s,

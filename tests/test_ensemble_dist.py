@@ -62,6 +62,54 @@ def test_rendezvous_exchange_threads():
         assert parts == [b"\x00", b"\x01\x01", b"\x02\x02\x02"]
 
 
+class _NoRccl:
+    "a device context whose RCCL entry points fail (library missing / IPC refused), on chosen ranks only"
+    def __init__(self, fails):
+        self.fails = fails
+
+    def _call(self, name, *args):
+        if self.fails:
+            raise RuntimeError(name + ": librccl not available")
+        if name == "tramp_comm_unique_id":
+            return 0
+        raise RuntimeError(name + ": no GPU in this test")           # tramp_comm_init on the ranks that got an id
+
+
+@pytest.mark.parametrize("failing", [(0, 1, 2), (0,), (2,)])
+def test_rccl_failure_falls_back_to_sockets_on_every_rank(failing):
+    """whichever rank cannot build the RCCL communicator, ALL ranks end up on the socket communicator, in step
+    (the bench then computes the shared factors on every rank instead of receiving a broadcast)"""
+    port = ensemble.free_port()
+    world, out, errs, logs = 3, {}, [], []
+
+    def run(rank):
+        try:
+            # env_world reads os.environ, shared by the threads: hand each thread its own view
+            comm = _init_with_env(lambda: (rank, rank, world, "127.0.0.1", port), _NoRccl(rank in failing), logs)
+            out[rank] = (comm.backend, comm.max(float(rank)), comm.gather_scalars([rank]).ravel().tolist())
+            comm.barrier()
+            comm.close()
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(90) for t in ts]
+    assert not errs, errs
+    assert all(out[r] == ("socket", 2.0, [0.0, 1.0, 2.0]) for r in range(world)), out
+    assert logs and "socket communicator" in logs[0]
+
+
+def _init_with_env(env_fn, ctx, logs):
+    "init_comm_or_sockets with a per-thread env_world"
+    import types
+    mod = types.ModuleType("ensemble_view")
+    mod.__dict__.update(ensemble.__dict__)
+    mod.env_world = env_fn
+    fn = types.FunctionType(ensemble.init_comm_or_sockets.__code__, mod.__dict__)
+    return fn(ctx, timeout=60.0, log=logs.append)
+
+
 def _run_world(world):
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     procs = []

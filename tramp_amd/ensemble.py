@@ -210,9 +210,17 @@ class RcclComm:
         self.ctx, self.rdv = ctx, rdv
         self.rank, self.world = rdv.rank, rdv.world
         uid = (C.c_ubyte * 128)()
+        failure = None
         if self.rank == 0:
-            ctx._call("tramp_comm_unique_id", uid)
-        blob = rdv.exchange(bytes(uid) if self.rank == 0 else b"")[0]
+            try:
+                ctx._call("tramp_comm_unique_id", uid)
+            except Exception as e:              # noqa: BLE001  (the exchange below still happens: ranks stay in step)
+                failure = e
+        blob = rdv.exchange(bytes(uid) if (self.rank == 0 and failure is None) else b"")[0]
+        if failure is not None:
+            raise failure
+        if len(blob) != 128:
+            raise RuntimeError("rank 0 could not create an RCCL unique id")
         uid = (C.c_ubyte * 128).from_buffer_copy(blob)
         h = C.c_void_p()
         ctx._call("tramp_comm_init", self.rank, self.world, uid, C.byref(h))
@@ -265,6 +273,31 @@ def init_comm(ctx=None, backend="rccl", timeout=600.0):
     if ctx is None:
         raise ValueError("the RCCL communicator needs a device context")
     return RcclComm(ctx, rdv)
+
+
+def init_comm_or_sockets(ctx, timeout=600.0, log=None):
+    """RCCL communicator if EVERY rank can build one, else the socket communicator on the same rendezvous
+    (host values only: barrier / max / gather - no device broadcast; the caller then computes the shared
+    factors on every rank instead of receiving them).  The ranks agree on the outcome over the sockets."""
+    rank, _, world, addr, port = env_world()
+    rdv = Rendezvous(rank, world, addr, port, timeout=timeout)
+    comm, err = None, b""
+    try:
+        comm = RcclComm(ctx, rdv)
+    except Exception as e:                      # noqa: BLE001  (library missing, IPC refused, ...)
+        err = repr(e).encode()
+    errs = rdv.exchange(err)
+    if not any(errs):
+        return comm
+    if log:
+        log("RCCL unavailable on %d of %d ranks (%s): socket communicator, factors computed on every rank"
+            % (sum(1 for e in errs if e), world, next(e for e in errs if e).decode(errors="replace")))
+    if comm is not None:
+        try:
+            comm.ctx._call("tramp_comm_destroy", comm._h)
+        except Exception:                       # noqa: BLE001
+            pass
+    return SocketComm(rdv)
 
 
 def free_port():
