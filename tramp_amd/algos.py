@@ -567,12 +567,16 @@ class ExpectationPropagation:
         for i in range(len(self.variables)):
             self.r[i], self.r_prev[i] = self.r_prev[i], self.r[i]
 
-    def _monitor_step(self, tol, max_increase, wait_increase):
-        "NaN guard + per-instance stopping rule of the iteration just launched, on the device (monitor.hip)"
+    def _monitor_step(self, tol, max_increase, wait_increase, can_stop=True):
+        """NaN guard + per-instance stopping rule of the iteration just launched, on the device (monitor.hip).
+        can_stop=False (no stopping rule given: tol = -1): only the guard - no instance can ever stop, the
+        freeze launches (one per variable) would copy nothing."""
         L = len(self.variables)
         self.ctx._call("tramp_ep_monitor", L, self._n_edges, self.batch, self.A, self.S, float(tol),
                        float(max_increase), int(wait_increase), self._state, self._v_prev, self._v_frozen,
                        self._a_frozen)
+        if not can_stop:
+            return
         dt = dtype_code(self.dtype)
         for i in range(L):
             self.ctx._call("tramp_ep_freeze", dt, self.r[i].shape[1], self.batch, self._state, self.r[i],
@@ -827,8 +831,8 @@ class ExpectationPropagation:
         if self._device_monitor:
             self._reset_monitor()            # a warm start begins a new run of the stopping rule (i = 0 again)
             stopper, host_cbs = self._split_callback(callback)
-            mon = ((stopper.tol, stopper.max_increase, stopper.wait_increase) if stopper is not None
-                   else (-1.0, np.inf, 0))
+            mon = ((stopper.tol, stopper.max_increase, stopper.wait_increase, True) if stopper is not None
+                   else (-1.0, np.inf, 0, False))
         else:
             stopper, host_cbs, mon = None, [callback], None
             self.status[:] = 0
