@@ -1,0 +1,36 @@
+"""The bench line on a real device, at a size that takes seconds: stdout carries exactly ONE line, the JSON
+result with the contract's keys (libraries such as RCCL print banners; they must not reach stdout), with and
+without the multi-rank code path (RCCL in a world of one)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+@pytest.mark.parametrize("force_dist", [False, True])
+def test_bench_prints_one_json_line(force_dist):
+    env = dict(os.environ)
+    if force_dist:
+        env["TRAMP_BENCH_FORCE_DIST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2048", "--batch", "4", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-denoiser", "--no-se"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["dtype"] == "f64"
+    assert d["config"]["N"] == 2048 and d["config"]["instances_per_gpu"] == 4
+    assert d["value"] > 0 and d["roofline"]["bound"] in ("hbm", "mfma")
+    if force_dist:
+        assert "RCCL" in d["config"]["collectives"]
