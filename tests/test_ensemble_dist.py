@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -134,3 +135,14 @@ def test_world_size_2_matches_single_rank():
     assert one.shape == two.shape == (5, 3)
     assert np.array_equal(one, two), (one, two)
     assert np.all(one[:, 0] > 3) and np.all(one[:, 2] < 0.5)
+
+
+def test_launcher_returns_when_a_rank_dies(tmp_path):
+    "one rank exits with an error while the other would wait forever: the launcher stops it and reports failure"
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                      "time.sleep(600)\n")
+    t0 = time.time()
+    rc = ensemble.launch_ranks(2, [str(script)], grace=1.0)
+    assert rc != 0 and time.time() - t0 < 60

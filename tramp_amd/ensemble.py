@@ -308,7 +308,7 @@ def free_port():
     return p
 
 
-def launch_ranks(world, argv, env=None, port=None):
+def launch_ranks(world, argv, env=None, port=None, grace=30.0):
     """Start `world` copies of `argv` (one per GPU) with the launcher environment set, wait for them,
     return the largest exit code.  The caller must not have initialised the GPU: the children do."""
     port = port or free_port()
@@ -319,7 +319,26 @@ def launch_ranks(world, argv, env=None, port=None):
                  MASTER_PORT=str(port))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
-    rc = 0
+    # a rank that dies leaves the others waiting in a collective: once one has failed, the rest get a grace
+    # period and are then stopped (these very processes, by handle), so that the launcher always returns
+    rc, failed_at = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
     for p in procs:
         rc = max(rc, abs(p.wait()))
     return rc
