@@ -336,55 +336,69 @@ __global__ __launch_bounds__(kBlock) void conv_spectral_perm_kernel(int mode, si
                                                                     const double* __restrict__ ax_d,
                                                                     const typename Cx<T>::type* __restrict__ fz,
                                                                     const typename Cx<T>::type* __restrict__ fx,
-                                                                    typename Cx<T>::type* __restrict__ fo) {
+                                                                    typename Cx<T>::type* __restrict__ fo, size_t batch,
+                                                                    int ipb) {
     using C = typename Cx<T>::type;
     constexpr int LINE = 128 / (int)sizeof(C);
-    const size_t b = blockIdx.y;
-    const double az = (mode == 2) ? 0.0 : az_d[b];
-    const double ax = (mode == 2) ? 0.0 : ax_d[b];
-    const size_t base = b * h;
+    // blockIdx.y owns `ipb` consecutive instances: the per-bin tables (filter spectrum, |w|^2, twiddle, partner:
+    // 44 bytes per bin in f64, as much as the three spectra of ONE instance) are read once per group
+    const size_t b_lo = (size_t)blockIdx.y * ipb;
+    const size_t b_hi = (b_lo + ipb < batch) ? b_lo + ipb : batch;
     const C zero = {};
+    auto unpack = [](C a, C bq, C tw) {           // ((a + conj b) - i tw (a - conj b)) / 2
+        const C cb = cx_conj(bq);
+        C sum = {a.x + cb.x, a.y + cb.y}, dif = {a.x - cb.x, a.y - cb.y};
+        const C td = cx_mul(tw, dif);             // -i td = (td.y, -td.x)
+        C r = {T(0.5) * (sum.x + td.y), T(0.5) * (sum.y - td.x)};
+        return r;
+    };
+    auto repack = [](C y, C yq, C tw) {           // ((y + conj yq) + i conj(tw) (y - conj yq)) / 2
+        const C cb = cx_conj(yq);
+        C sum = {y.x + cb.x, y.y + cb.y}, dif = {y.x - cb.x, y.y - cb.y};
+        const C td = cx_mul(cx_conj(tw), dif);    // i td = (-td.y, td.x)
+        C r = {T(0.5) * (sum.x - td.y), T(0.5) * (sum.y + td.x)};
+        return r;
+    };
     for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < nlead * LINE; idx += (size_t)gridDim.x * kBlock) {
         const size_t p = (size_t)leaders[idx / LINE] * LINE + (idx % LINE);
         const int pp = partner[p];
         // each pair once: inside a self-paired line (or when the lines do not close) by its lower position
         if ((!closed || (size_t)pp / LINE == p / LINE) && (size_t)pp < p) continue;
-        const C zp = fz[base + p], xp = (mode == 2) ? zero : fx[base + p];
         if (p == 0) {                                  // bins 0 and h, both real
-            C xz0 = {zp.x + zp.y, T(0)}, xzh = {zp.x - zp.y, T(0)};
-            C xx0 = {xp.x + xp.y, T(0)}, xxh = {xp.x - xp.y, T(0)};
-            C wn = {(T)wbar_nyq, T(0)};
-            const C y0 = spectral_bin<T>(mode, xz0, xx0, wbar_p[0], s2_p[0], az, ax, inv_h);
-            const C yh = spectral_bin<T>(mode, xzh, xxh, wn, s2_nyq, az, ax, inv_h);
-            C o = {T(0.5) * (y0.x + yh.x), T(0.5) * (y0.x - yh.x)};
-            fo[base] = o;
+            const C w0 = wbar_p[0];
+            const double s0 = s2_p[0];
+            const C wn = {(T)wbar_nyq, T(0)};
+            for (size_t b = b_lo; b < b_hi; ++b) {
+                const double az = (mode == 2) ? 0.0 : az_d[b], ax = (mode == 2) ? 0.0 : ax_d[b];
+                const C zp = fz[b * h], xp = (mode == 2) ? zero : fx[b * h];
+                C xz0 = {zp.x + zp.y, T(0)}, xzh = {zp.x - zp.y, T(0)};
+                C xx0 = {xp.x + xp.y, T(0)}, xxh = {xp.x - xp.y, T(0)};
+                const C y0 = spectral_bin<T>(mode, xz0, xx0, w0, s0, az, ax, inv_h);
+                const C yh = spectral_bin<T>(mode, xzh, xxh, wn, s2_nyq, az, ax, inv_h);
+                C o = {T(0.5) * (y0.x + yh.x), T(0.5) * (y0.x - yh.x)};
+                fo[b * h] = o;
+            }
             continue;
         }
-        const C zq = fz[base + pp], xq = (mode == 2) ? zero : fx[base + pp];
         const C w = wk[p];
         const C wq = {-w.x, w.y};                     // w^(h-k) = -conj(w^k)
-        auto unpack = [](C a, C bq, C tw) {           // ((a + conj b) - i tw (a - conj b)) / 2
-            const C cb = cx_conj(bq);
-            C sum = {a.x + cb.x, a.y + cb.y}, dif = {a.x - cb.x, a.y - cb.y};
-            const C td = cx_mul(tw, dif);             // -i td = (td.y, -td.x)
-            C r = {T(0.5) * (sum.x + td.y), T(0.5) * (sum.y - td.x)};
-            return r;
-        };
-        auto repack = [](C y, C yq, C tw) {           // ((y + conj yq) + i conj(tw) (y - conj yq)) / 2
-            const C cb = cx_conj(yq);
-            C sum = {y.x + cb.x, y.y + cb.y}, dif = {y.x - cb.x, y.y - cb.y};
-            const C td = cx_mul(cx_conj(tw), dif);    // i td = (-td.y, td.x)
-            C r = {T(0.5) * (sum.x - td.y), T(0.5) * (sum.y + td.x)};
-            return r;
-        };
-        const C xzk = unpack(zp, zq, w), xzq = unpack(zq, zp, wq);
-        const C xxk = (mode == 2) ? zero : unpack(xp, xq, w), xxq = (mode == 2) ? zero : unpack(xq, xp, wq);
-        const C yk = spectral_bin<T>(mode, xzk, xxk, wbar_p[p], s2_p[p], az, ax, inv_h);
-        const C yq = spectral_bin<T>(mode, xzq, xxq, wbar_p[pp], s2_p[pp], az, ax, inv_h);
-        fo[base + p] = repack(yk, yq, w);
-        if ((size_t)pp != p) fo[base + pp] = repack(yq, yk, wq);
+        const C wbp = wbar_p[p], wbq = wbar_p[pp];
+        const double s2p = s2_p[p], s2q = s2_p[pp];
+        for (size_t b = b_lo; b < b_hi; ++b) {
+            const double az = (mode == 2) ? 0.0 : az_d[b], ax = (mode == 2) ? 0.0 : ax_d[b];
+            const size_t base = b * h;
+            const C zp = fz[base + p], xp = (mode == 2) ? zero : fx[base + p];
+            const C zq = fz[base + pp], xq = (mode == 2) ? zero : fx[base + pp];
+            const C xzk = unpack(zp, zq, w), xzq = unpack(zq, zp, wq);
+            const C xxk = (mode == 2) ? zero : unpack(xp, xq, w), xxq = (mode == 2) ? zero : unpack(xq, xp, wq);
+            const C yk = spectral_bin<T>(mode, xzk, xxk, wbp, s2p, az, ax, inv_h);
+            const C yq = spectral_bin<T>(mode, xzq, xxq, wbq, s2q, az, ax, inv_h);
+            fo[base + p] = repack(yk, yq, w);
+            if ((size_t)pp != p) fo[base + pp] = repack(yq, yk, wq);
+        }
     }
 }
+
 
 // ---- message update on the inverse-transformed mean (tramp/channels/base_channel.py:9-17,
 // tramp/base.py:245-254), damping fused; r may be updated in place.
@@ -528,10 +542,16 @@ template <typename T>
 void launch_spectral(tramp_ctx* ctx, tramp_conv* cv, int mode, size_t batch, const double* az_d, const double* ax_d) {
     using C = typename Cx<T>::type;
     if (cv->fft2) {
-        dim3 g(grid_for(cv->h / 2), (unsigned)batch);
+        // instances per block: as many as keep >= ~2000 blocks in flight, at most 8
+        static const int ipb_env = getenv("TRAMP_CONV_IPB") ? atoi(getenv("TRAMP_CONV_IPB")) : 0;
+        int ipb = 8;
+        while (ipb > 1 && (size_t)grid_for(cv->h / 2) * ((batch + ipb - 1) / ipb) < 2048) ipb >>= 1;
+        if (ipb_env > 0) ipb = ipb_env;
+        dim3 g(grid_for(cv->h / 2), (unsigned)((batch + ipb - 1) / ipb));
         hipLaunchKernelGGL((conv_spectral_perm_kernel<T>), g, dim3(kBlock), 0, ctx->stream, mode, cv->h, 1.0 / cv->h,
                            (const C*)cv->wbar_p, cv->s2_p, cv->wbar_nyq, cv->s2_nyq, cv->partner, cv->leaders, cv->nlead,
-                           cv->lines_closed ? 1 : 0, (const C*)cv->wk, az_d, ax_d, (const C*)cv->fz, (const C*)cv->fx, (C*)cv->fo);
+                           cv->lines_closed ? 1 : 0, (const C*)cv->wk, az_d, ax_d, (const C*)cv->fz, (const C*)cv->fx, (C*)cv->fo,
+                           batch, ipb);
     } else {
         dim3 g(grid_for(cv->nh), (unsigned)batch);
         hipLaunchKernelGGL((conv_spectral_kernel<T>), g, dim3(kBlock), 0, ctx->stream, mode, cv->nh, 1.0 / cv->n,
