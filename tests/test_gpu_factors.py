@@ -348,7 +348,7 @@ def test_batch_matches_per_instance_oracle(T, ctx, batch):
         close(ar[b], a); close(br[b], bb_, scale=10 * np.abs(bb_).max())
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 4099])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 4099, 8191, 70001, 70002])
 def test_ragged_and_empty_sizes(T, ctx, n):
     rs = np.random.RandomState(n)
     b = rs.standard_normal(n) * 2
@@ -365,6 +365,24 @@ def test_ragged_and_empty_sizes(T, ctx, n):
     a_new, b_new = lk.compute_backward_message(0.9, b)
     a_ref, b_ref = orc.sgn_lik_message(0.9, b, y)
     close(a_new, a_ref); close(b_new, b_ref, scale=10 * np.abs(b_ref).max())
+    # the two-region channels and the abs likelihood on the same ragged length, three instances (tile tails with
+    # part of a wave inactive, the non-vector kernels for odd n)
+    B = 3
+    bz = rs.standard_normal((B, n)) * 1.5; bx = rs.standard_normal((B, n)) * 1.5
+    az = np.array([1.3, 0.6, 2.2]); ax = np.array([0.7, 1.9, 0.4])
+    for kind in ("relu", "sgn", "abs"):
+        ch = {"relu": T.ReluChannel, "sgn": T.SgnChannel, "abs": T.AbsChannel}[kind](ctx=ctx)
+        for direction in ("fwd", "bwd"):
+            fn = ch.compute_forward_message if direction == "fwd" else ch.compute_backward_message
+            a_dev, b_dev = fn(az, bz, ax, bx)
+            for i in range(B):
+                a_ref, b_ref = orc.pwl_channel_message(kind, direction, az[i], bz[i], ax[i], bx[i])
+                close(a_dev[i], a_ref); close(b_dev[i], b_ref, scale=10 * np.abs(b_ref).max())
+    ya = np.abs(rs.standard_normal((B, n)))
+    a_dev, b_dev = T.AbsLikelihood(y=ya, ctx=ctx).compute_backward_message(az, bz)
+    for i in range(B):
+        a_ref, b_ref = orc.abs_lik_message(az[i], bz[i], ya[i])
+        close(a_dev[i], a_ref); close(b_dev[i], b_ref, scale=10 * np.abs(b_ref).max())
 
 
 def test_damping_fused(T, ctx):
