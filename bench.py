@@ -550,6 +550,14 @@ def run(args):
                 out["factor_updates_n1e6"] = factor_updates_n1e6(T, ctx, args.dtype)
             except Exception as e:                                            # noqa: BLE001
                 out["factor_updates_n1e6"] = {"error": repr(e)}
+            if args.dtype == "f64":
+                # BASELINE configs[2] (1-bit CS at N = 1e6) is an fp32 configuration: the same kernels on f32 messages
+                # (half the bytes: the 64-instance working set is 2 x 256 MB, i.e. partly Infinity-Cache resident)
+                try:
+                    out["denoiser_n1e6_f32"] = denoiser_roofline(T, ctx, "f32")
+                    out["factor_updates_n1e6_f32"] = factor_updates_n1e6(T, ctx, "f32")
+                except Exception as e:                                        # noqa: BLE001
+                    out["denoiser_n1e6_f32"] = {"error": repr(e)}
             try:
                 out["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
             except Exception as e:                                            # noqa: BLE001
