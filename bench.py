@@ -6,8 +6,8 @@ N = 100000, M = 50000 sharing W.
 
     python bench.py --gpus 1 --steps K --warmup W
     python bench.py --gpus N ...                       # starts its own N rank processes
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-                                                       # (the driver's launcher: only its RANK /
+    <launcher with one process per GPU> bench.py --gpus N ...
+                                                       # (the driver's launcher: only its RANK / LOCAL_RANK /
                                                        #  WORLD_SIZE / MASTER_* environment is used)
 
 A "step" is one full EP iteration (forward sweep, backward sweep, variable posteriors, NaN guard +
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", dest="n", type=int, default=int(os.environ.get("TRAMP_BENCH_N", 100000)),
-                    help="signal dimension N (not --n: torch.distributed.run would read it as its own option)")
+                    help="signal dimension N (not --n: the driver's launcher would read that as its own option)")
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TRAMP_BENCH_BATCH", 64)),
                     help="instances per GPU")

@@ -163,7 +163,7 @@ class Rendezvous:
 
 
 def env_world():
-    "(rank, local_rank, world, addr, port) from the launcher's environment (torchrun's names)"
+    "(rank, local_rank, world, addr, port) from the launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)"
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", 0))),
             int(os.environ.get("WORLD_SIZE", 1)), os.environ.get("MASTER_ADDR", "127.0.0.1"),
             int(os.environ.get("MASTER_PORT", 29500)))
@@ -203,7 +203,7 @@ class SocketComm:
 
 
 class RcclComm:
-    """RCCL communicator of one device context (C ABI, csrc/comm.hip).  Device arrays in, no torch."""
+    """RCCL communicator of one device context (C ABI, csrc/comm.hip).  Device arrays in, plain pointers out."""
     backend = "rccl"
 
     def __init__(self, ctx, rdv):
