@@ -57,6 +57,23 @@ constexpr int kSplit = 8;     // == number of XCDs
 constexpr int kPieces = 2;    // 16-byte pieces per lane per row (NT) / per x fragment, per step
 template <typename T> constexpr int kstep_of() { return 4 * kPieces * Mx<T>::E; }   // f64: 16, f32: 32
 
+// Work item of a workgroup: (tile = row / column block x split, 64-instance chunk).  Ensembles of more than 64
+// instances have several chunks per tile, each streaming the same piece of the matrix.  In the one-dimensional
+// launch sibling chunks are 8 workgroups apart: the same XCD under the round-robin dispatch and adjacent in
+// time, so the second chunk finds the tile in that XCD's L2 and HBM sees the matrix once per pass, not once
+// per chunk.  (gridDim.y > 1: the plain two-dimensional launch, tile = blockIdx.x, chunk = blockIdx.y.)
+__device__ __forceinline__ void wg_item(size_t B, size_t& tile, size_t& chunk) {
+    if (gridDim.y > 1 || B <= 64) {
+        tile = blockIdx.x;
+        chunk = blockIdx.y;
+        return;
+    }
+    const size_t nchunk = (B + 63) / 64;
+    const size_t g = blockIdx.x / kSplit, xcd = blockIdx.x % kSplit;
+    chunk = g % nchunk;
+    tile = (g / nchunk) * kSplit + xcd;
+}
+
 // ------------------------------------------------------------------------------ NT
 // Workgroup: 4 waves x (RT*16) rows; grid.x = row_blocks * kSplit; grid.y = batch chunks of 64.
 // lane (j = l&15, q = l>>4), piece p, element e  <->  column k0 + p*4E + q*E + e.
@@ -72,8 +89,10 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     __shared__ V xs[2][BT][kPieces][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
-    const size_t rb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-    const size_t bchunk = (size_t)blockIdx.y * 64;
+    size_t tile_id, chunk_id;
+    wg_item(B, tile_id, chunk_id);
+    const size_t rb = tile_id / nsplit, split = tile_id % nsplit;
+    const size_t bchunk = chunk_id * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;          // instances in this chunk
     const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
     const size_t nsteps_total = (C + KS - 1) / KS;      // a ragged k tail is zero-filled
@@ -178,8 +197,10 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     __shared__ V xs[2][BT][kPieces][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
-    const size_t cb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-    const size_t bchunk = (size_t)blockIdx.y * 64;
+    size_t tile_id, chunk_id;
+    wg_item(B, tile_id, chunk_id);
+    const size_t cb = tile_id / nsplit, split = tile_id % nsplit;
+    const size_t bchunk = chunk_id * 64;
     const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
     const size_t col0 = cb * (64 * E) + (size_t)wave * (16 * E);
     const size_t nsteps_total = (R + KS - 1) / KS;      // a ragged k tail is zero-filled
@@ -771,6 +792,14 @@ static int pick_split(tramp_ctx* ctx, bool nt, size_t nblocks, size_t nchunk, si
     return s;
 }
 
+// launch shape for wg_item: one-dimensional with sibling chunks interleaved when it can be (tiles in groups
+// of 8), else (tile, chunk); TRAMP_MFMA_CHUNK_2D=1 forces the latter
+static dim3 chunk_grid(size_t ntile, unsigned nchunk) {
+    static const int flat = getenv("TRAMP_MFMA_CHUNK_2D") ? !atoi(getenv("TRAMP_MFMA_CHUNK_2D")) : 1;
+    if (flat && nchunk > 1 && ntile % kSplit == 0 && ntile * nchunk < (1ull << 31)) return dim3((unsigned)(ntile * nchunk), 1);
+    return dim3((unsigned)ntile, nchunk);
+}
+
 template <typename T>
 static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch, const T* mat, const T* x,
                        const LinEpi& epi) {
@@ -854,7 +883,7 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
         if (rt_env == 4) {
             constexpr int RT = 4;
             const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid((unsigned)(nrb * nsplit), nchunk);
+            dim3 grid = chunk_grid(nrb * nsplit, nchunk);
             if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
         } else if (rt_env == 1) {
             constexpr int RT = 1;
@@ -869,7 +898,7 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
         }
     } else {
         const size_t ncb = (C + 64 * E - 1) / (64 * E);
-        dim3 grid((unsigned)(ncb * nsplit), nchunk);
+        dim3 grid = chunk_grid(ncb * nsplit, nchunk);
         if (tail) { BY_BT(LAUNCH_NN, true) } else { BY_BT(LAUNCH_NN, false) }
     }
 #undef BY_BT
