@@ -388,6 +388,33 @@ def teacher_data(T, ctx, ensemble, lin_factors, args, start, stop, np_dt):
     return X, Y
 
 
+def whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, lin_factors, args, np_dt, total, steps=5):
+    """BASELINE configs[3] in full - all 8 x 64 = 512 instances - on ONE GPU (it fits: 60 GB of factors + ~15 GB of
+    messages and split-K partials).  An auxiliary figure, never `value`: it shows what the dense passes do when a
+    matrix tile feeds more than one 64-instance accumulator chunk (sibling chunks share the tile through L2, HBM
+    sees the matrix once per pass: DESIGN 4.1)."""
+    N, k = lin_factors[2].shape[1], lin_factors[2].shape[0]
+    X, Y = teacher_data(T, ctx, ensemble, lin_factors, args, 0, total, np_dt)
+    model = (T.GaussBernoulliPrior(size=N, rho=args.rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x")
+             @ lin @ T.SISOVariable(id="z")
+             @ T.GaussianLikelihood(y=Y.astype(np_dt), var=args.noise_var, dtype=np_dt, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=2, callback=T.PassCallback(), damping=args.damping, check_every=args.check_every)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ep.iterate(max_iter=steps, callback=T.PassCallback(), damping=args.damping, warm_start=True,
+               check_every=args.check_every)
+    ctx.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    mse = float(np.mean(ep.mse("x", X)))
+    return {"instances": total, "steps": steps, "ms_per_step": ms, "value": N * total / (ms * 1e-3),
+            "unit": "msg-components/s",
+            "dense_passes_TFLOPs_lower_bound": 4.0 * k * N * total / (ms * 1e-3) / 1e12,
+            "mse_after_run": mse,
+            "note": "whole step time charged to the two matrix passes; same kernels, factors and stopping-rule cadence "
+                    "as the headline line"}
+
+
 def run(args):
     import tramp_amd as T
     from tramp_amd import ensemble
@@ -566,6 +593,13 @@ def run(args):
                 out["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
             except Exception as e:                                            # noqa: BLE001
                 out["structured_n1e6"] = {"error": repr(e)}
+        if world == 1 and not args.no_denoiser and not args.load_factors:
+            try:
+                del ep, model
+                out["ensemble_x8_one_gpu"] = whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, (Uk, sing, Vt), args, np_dt,
+                                                                       8 * B)
+            except Exception as e:                                            # noqa: BLE001
+                out["ensemble_x8_one_gpu"] = {"error": repr(e)}
         if world == 1 and not args.no_se:
             try:
                 out["state_evolution"] = se_measure(T, ctx, with_oracle=not args.no_cpu_baseline)
