@@ -651,6 +651,7 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    failure = None
     try:
         return run(args)
     except Exception as e:      # noqa: BLE001
@@ -658,13 +659,19 @@ def main():
         # smaller honest number rather than none - and SAYS so: config.fallback_from holds the size that failed
         if world > 1 or args.n <= 65536 or args.load_factors:
             raise
-        import gc
         import traceback
         traceback.print_exc(file=sys.stderr)
-        print(f"bench.py: run at N={args.n} failed ({e!r}); retrying at N=65536", file=sys.stderr)
-        gc.collect()
-        args.fallback_from, args.n = args.n, 65536
-        return run(args)
+        failure = repr(e)
+        # the failed run()'s frame holds W, Uk, Vt and the context: cut the traceback loose so that the retry
+        # below does not start with those device buffers still allocated
+        traceback.clear_frames(e.__traceback__)
+        e.__traceback__ = None
+    # outside the handler: `e` is gone, the failed run's device arrays are collectable
+    import gc
+    gc.collect()
+    print(f"bench.py: run at N={args.n} failed ({failure}); retrying at N=65536", file=sys.stderr)
+    args.fallback_from, args.n = args.n, 65536
+    return run(args)
 
 
 if __name__ == "__main__":

@@ -376,6 +376,7 @@ int tramp_ep_freeze(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const int
  *   tramp_comm_barrier   : every rank has finished its queued work */
 #define TRAMP_COMM_ID_BYTES 128
 typedef struct tramp_comm tramp_comm;
+int tramp_comm_available(tramp_ctx* ctx);   /* TRAMP_OK if librccl maps and resolves; no collective, no device call */
 int tramp_comm_unique_id(tramp_ctx* ctx, unsigned char* id_out);
 int tramp_comm_init(tramp_ctx* ctx, int rank, int world, const unsigned char* id, tramp_comm** comm);
 int tramp_comm_destroy(tramp_ctx* ctx, tramp_comm* comm);

@@ -63,30 +63,57 @@ def test_rendezvous_exchange_threads():
         assert parts == [b"\x00", b"\x01\x01", b"\x02\x02\x02"]
 
 
-class _NoRccl:
-    "a device context whose RCCL entry points fail (library missing / IPC refused), on chosen ranks only"
-    def __init__(self, fails):
-        self.fails = fails
+class _FakeRcclCtx:
+    """A device context whose RCCL entry points behave as told, on this rank only:
+    "no_lib"  the probe (tramp_comm_available) fails - library missing;
+    "no_init" the probe passes, tramp_comm_init fails (IPC refused, duplicate device);
+    "ok"      tramp_comm_init hands out a communicator handle.
+    Records every call; tramp_comm_destroy is counted wherever it comes from (the _call path or __del__'s
+    direct library call)."""
+    def __init__(self, mode):
+        self.mode = mode
+        self.calls = []
+        self.handle = 1
+        self.lib = self
+
+    def tramp_comm_destroy(self, ctx_handle, h):         # RcclComm.__del__ goes through ctx.lib
+        self.calls.append("tramp_comm_destroy")
+        return 0
 
     def _call(self, name, *args):
-        if self.fails:
-            raise RuntimeError(name + ": librccl not available")
+        self.calls.append(name)
+        if name == "tramp_comm_available":
+            if self.mode == "no_lib":
+                raise RuntimeError(name + ": librccl not available")
+            return 0
         if name == "tramp_comm_unique_id":
             return 0
-        raise RuntimeError(name + ": no GPU in this test")           # tramp_comm_init on the ranks that got an id
+        if name == "tramp_comm_init":
+            if self.mode == "ok":
+                args[3]._obj.value = 0xC0FFEE             # C.byref(handle)
+                return 0
+            raise RuntimeError(name + ": hipIpcGetMemHandle: invalid argument")
+        if name == "tramp_comm_destroy":
+            return 0
+        raise RuntimeError(name + ": no GPU in this test")
 
 
-@pytest.mark.parametrize("failing", [(0, 1, 2), (0,), (2,)])
-def test_rccl_failure_falls_back_to_sockets_on_every_rank(failing):
+@pytest.mark.parametrize("modes", [("no_lib", "no_lib", "no_lib"), ("no_lib", "ok", "ok"), ("ok", "ok", "no_lib"),
+                                   ("no_init", "no_init", "no_init"), ("ok", "no_init", "ok"), ("no_init", "ok", "ok")])
+def test_rccl_failure_falls_back_to_sockets_on_every_rank(modes):
     """whichever rank cannot build the RCCL communicator, ALL ranks end up on the socket communicator, in step
-    (the bench then computes the shared factors on every rank instead of receiving a broadcast)"""
+    (the bench then computes the shared factors on every rank instead of receiving a broadcast).  A missing
+    library is found by the probe, before any rank enters the collective init; a communicator that did come up
+    on a healthy rank is destroyed exactly once."""
+    import gc
     port = ensemble.free_port()
     world, out, errs, logs = 3, {}, [], []
+    ctxs = [_FakeRcclCtx(m) for m in modes]
 
     def run(rank):
         try:
             # env_world reads os.environ, shared by the threads: hand each thread its own view
-            comm = _init_with_env(lambda: (rank, rank, world, "127.0.0.1", port), _NoRccl(rank in failing), logs)
+            comm = _init_with_env(lambda: (rank, rank, world, "127.0.0.1", port), ctxs[rank], logs)
             out[rank] = (comm.backend, comm.max(float(rank)), comm.gather_scalars([rank]).ravel().tolist())
             comm.barrier()
             comm.close()
@@ -99,6 +126,12 @@ def test_rccl_failure_falls_back_to_sockets_on_every_rank(failing):
     assert not errs, errs
     assert all(out[r] == ("socket", 2.0, [0.0, 1.0, 2.0]) for r in range(world)), out
     assert logs and "socket communicator" in logs[0]
+    gc.collect()
+    for c in ctxs:
+        if "no_lib" in modes:
+            assert "tramp_comm_init" not in c.calls and "tramp_comm_unique_id" not in c.calls, c.calls
+        inits_ok = c.mode == "ok" and "tramp_comm_init" in c.calls
+        assert c.calls.count("tramp_comm_destroy") == (1 if inits_ok else 0), (c.mode, c.calls)
 
 
 def _init_with_env(env_fn, ctx, logs):

@@ -124,6 +124,7 @@ _SIGNATURES = {
     "tramp_randn": [vp, i32, vp, sz, u64, dbl],
     "tramp_ep_monitor": [vp, i32, i32, sz, vp, vp, dbl, dbl, i32, vp, vp, vp, vp],
     "tramp_ep_freeze": [vp, i32, sz, sz, vp, vp, vp, vp],
+    "tramp_comm_available": [vp],
     "tramp_comm_unique_id": [vp, vp],
     "tramp_comm_init": [vp, i32, i32, vp, C.POINTER(vp)],
     "tramp_comm_destroy": [vp, vp],

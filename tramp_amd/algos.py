@@ -711,11 +711,24 @@ class ExpectationPropagation:
     def variable_index(self, id):
         return [v.id for v in self.variables].index(id)
 
-    def mse(self, id, x_true):
-        """mean squared error of the current posterior mean against ``x_true``: [n] (one signal shared by
-        the ensemble) or [batch, n]."""
+    def mse(self, id, x_true, frozen=None):
+        """mean squared error of the posterior mean against ``x_true``: [n] (one signal shared by the ensemble)
+        or [batch, n].  As in get_variables_data, an instance that has stopped reports the estimate of ITS
+        stopping iteration (for one that gave up: the iterate before the increase); ``frozen=False`` scores the
+        current iterate of every instance."""
         i = self.variable_index(id)
-        r = self._rotate(i, self.r[i], back=True) if i in self._rot else self.r[i]
+        done = self.status != 0
+        use_frozen = (frozen is None or frozen) and done.any()
+        src = self.r[i]
+        if use_frozen:
+            if done.all():
+                src = self._frozen_r[i]
+            else:
+                src = self.ctx.empty(tuple(self.r[i].shape), self.dtype)
+                src.copy_from(self.r[i])
+                for b in np.flatnonzero(done):
+                    src.row(int(b)).copy_from(self._frozen_r[i].row(int(b)))
+        r = self._rotate(i, src, back=True) if i in self._rot else src
         n = r.shape[1]
         x = np.asarray(x_true, dtype=self.dtype)
         if x.size == n:

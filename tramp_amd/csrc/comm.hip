@@ -86,6 +86,14 @@ struct tramp_comm {
         if (r_ != ncclSuccess) return tramp_fail(ctx, TRAMP_EHIP, #call, (R)->GetErrorString(r_)); \
     } while (0)
 
+// Can this process reach RCCL at all (library maps, every symbol resolves)?  No collective, no device call:
+// the ranks exchange this flag over their rendezvous BEFORE anyone enters ncclCommInitRank, so that one
+// rank without the library cannot leave the others waiting in the bootstrap.
+extern "C" int tramp_comm_available(tramp_ctx* ctx) {
+    if (!ctx) return TRAMP_EINVAL;
+    return rccl(ctx) ? TRAMP_OK : TRAMP_ENOTSUP;
+}
+
 extern "C" int tramp_comm_unique_id(tramp_ctx* ctx, unsigned char* id_out) {
     if (!ctx || !id_out) return TRAMP_EINVAL;
     const Rccl* R = rccl(ctx);

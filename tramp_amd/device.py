@@ -61,6 +61,9 @@ class Context:
             raise _lib.TrampHipError(rc, f"tramp_ctx_create(device={device})")
         self.handle = h
         self.device = int(device)
+        # tramp_ctx_create made `device` HIP's current device on this thread without telling the cache below:
+        # a context this thread drove before must call tramp_ctx_make_current again before its next launch
+        _tls.current = None
 
     # -- plumbing
     def _call(self, name, *args):
@@ -107,6 +110,8 @@ class Context:
         if self.handle:
             self.lib.tramp_ctx_destroy(self.handle)
             self.handle = None
+        if getattr(_tls, "current", None) is self:
+            _tls.current = None
 
     # -- arrays
     def empty(self, shape, dtype=np.float64):

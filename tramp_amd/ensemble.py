@@ -223,6 +223,7 @@ class RcclComm:
             raise RuntimeError("rank 0 could not create an RCCL unique id")
         uid = (C.c_ubyte * 128).from_buffer_copy(blob)
         h = C.c_void_p()
+        self._h = None
         ctx._call("tramp_comm_init", self.rank, self.world, uid, C.byref(h))
         self._h = h
 
@@ -250,15 +251,23 @@ class RcclComm:
         self.ctx._call("tramp_comm_barrier", self._h)
 
     def close(self):
-        if self._h:
-            self.ctx._call("tramp_comm_destroy", self._h)
-            self._h = None
+        self.abort()
         self.rdv.close()
+
+    def abort(self):
+        "destroy the communicator ONCE and forget the handle; the rendezvous stays open (socket fallback uses it)"
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self.ctx._call("tramp_comm_destroy", h)
+            except Exception:                   # noqa: BLE001
+                pass
 
     def __del__(self):
         try:
-            if self._h and self.ctx.handle:
-                self.ctx.lib.tramp_comm_destroy(self.ctx.handle, self._h)
+            h, self._h = getattr(self, "_h", None), None
+            if h and self.ctx.handle:
+                self.ctx.lib.tramp_comm_destroy(self.ctx.handle, h)
         except Exception:
             pass
 
@@ -278,26 +287,39 @@ def init_comm(ctx=None, backend="rccl", timeout=600.0):
 def init_comm_or_sockets(ctx, timeout=600.0, log=None):
     """RCCL communicator if EVERY rank can build one, else the socket communicator on the same rendezvous
     (host values only: barrier / max / gather - no device broadcast; the caller then computes the shared
-    factors on every rank instead of receiving them).  The ranks agree on the outcome over the sockets."""
+    factors on every rank instead of receiving them).  The ranks agree on the outcome over the sockets, in
+    two steps: (1) every rank probes the library (tramp_comm_available: dlopen + symbols, no collective) and
+    the flags are exchanged BEFORE anyone enters ncclCommInitRank - a rank without RCCL can therefore not
+    leave the others waiting in the bootstrap; (2) after the init the ranks exchange its outcome, and a rank
+    whose communicator did come up drops it (RcclComm.abort) when another rank's did not."""
     rank, _, world, addr, port = env_world()
     rdv = Rendezvous(rank, world, addr, port, timeout=timeout)
+
+    def fall_back(errs, stage):
+        if log:
+            log("RCCL unavailable on %d of %d ranks at %s (%s): socket communicator, factors computed on every rank"
+                % (sum(1 for e in errs if e), world, stage, next(e for e in errs if e).decode(errors="replace")))
+        return SocketComm(rdv)
+
+    err = b""
+    try:
+        ctx._call("tramp_comm_available")
+    except Exception as e:                      # noqa: BLE001  (library missing, a symbol missing)
+        err = repr(e).encode()
+    errs = rdv.exchange(err)
+    if any(errs):
+        return fall_back(errs, "probe")
     comm, err = None, b""
     try:
         comm = RcclComm(ctx, rdv)
-    except Exception as e:                      # noqa: BLE001  (library missing, IPC refused, ...)
+    except Exception as e:                      # noqa: BLE001  (IPC refused, duplicate device, ...)
         err = repr(e).encode()
     errs = rdv.exchange(err)
     if not any(errs):
         return comm
-    if log:
-        log("RCCL unavailable on %d of %d ranks (%s): socket communicator, factors computed on every rank"
-            % (sum(1 for e in errs if e), world, next(e for e in errs if e).decode(errors="replace")))
     if comm is not None:
-        try:
-            comm.ctx._call("tramp_comm_destroy", comm._h)
-        except Exception:                       # noqa: BLE001
-            pass
-    return SocketComm(rdv)
+        comm.abort()
+    return fall_back(errs, "init")
 
 
 def free_port():
