@@ -395,6 +395,10 @@ int tramp_matvec_nt(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, siz
                     const void* mat_d, const void* x_d, void* out_d);
 int tramp_matvec_nn(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
                     const void* mat_d, const void* x_d, void* out_d);
+/* Launch shape the last MFMA matrix pass of this context chose: split-K factor, number of 64-instance chunks,
+ * and whether sibling chunks of a matrix tile were interleaved in a one-dimensional grid (ensembles > 64).
+ * Lets the tests assert that they reach the launch configurations the large runs use. */
+int tramp_matvec_last_launch(tramp_ctx* ctx, int* nsplit, int* nchunk, int* flat_chunks);
 
 /* ---- convolution channel x = w * z ------------------ */
 /* ConvChannel (tramp/channels/linear/conv_channel.py:13-149), real signals of 1-3 axes

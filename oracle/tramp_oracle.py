@@ -1643,6 +1643,80 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
     return dict(fwd=fwd, bwd=bwd, r=rs, v=vs, n_iter=n_iter, status=status)
 
 
+def ep_glm_thin_batch(Uk, sigma, Vt, Y, rho, noise_var, damping=None, n_iter=10, rank=None):
+    """ep_chain for the sparse GLM (GaussBernoulli prior - LinearThinOracle - Gaussian likelihood) on an ENSEMBLE
+    of instances that share W = Uk diag(sigma) Vt: messages are [B, n] arrays, every scalar (a, v) a [B] array,
+    the four matrix-vector products of an iteration become four GEMMs (Vt, Uk, Uk, Vt) - the host counterpart
+    of what the HIP path runs per iteration on the headline shape (bench.py cpu_baseline "like_for_like").
+    Same order of updates and same formulas as ep_chain + LinearThinOracle (pinned against them in
+    tests/test_oracle_golden.py); no stopping rule: exactly n_iter iterations.  Returns dict(r, v, fwd, bwd)."""
+    Uk, Vt, sigma = np.asarray(Uk), np.asarray(Vt), np.asarray(sigma, dtype=float)
+    Y = np.atleast_2d(np.asarray(Y, dtype=float))
+    B, M = Y.shape
+    k, N = Vt.shape
+    rank = int(np.sum(sigma > 0)) if rank is None else int(rank)
+    sing2 = sigma[:rank]**2
+    alpha = M / N
+    d = damping if damping else 0.
+    col = lambda a: np.asarray(a, dtype=float).reshape(B, 1)
+
+    def n_eff(az, ax):                                                    # linear_channel.py:58-67, per instance
+        out = np.zeros(B)
+        for b in range(B):
+            if ax[b] == 0:
+                out[b] = 0.
+            elif az[b] / ax[b] == 0:
+                out[b] = rank / N
+            else:
+                out[b] = np.sum(sing2 / (az[b] / ax[b] + sing2)) / N
+        return out
+
+    def damp(old, new):
+        if not d:
+            return new
+        return (d * old[0] + (1 - d) * new[0], d * old[1] + (1 - d) * new[1])
+
+    fx = (np.zeros(B), np.zeros((B, N)))       # prior -> x
+    bx = (np.zeros(B), np.zeros((B, N)))       # channel -> x
+    fz = (np.zeros(B), np.zeros((B, M)))       # channel -> z
+    bz = (np.zeros(B), np.zeros((B, M)))       # likelihood -> z
+    for _ in range(n_iter):
+        # forward sweep: prior, then the channel's forward message (linear_channel.py:85-89,99-105)
+        r, v = [], []
+        for b in range(B):
+            rb, vb = gb_prior_posterior(bx[0][b], bx[1][b], rho)
+            r.append(rb)
+            v.append(vb)
+        an, bn = ab_new(np.stack(r), col(v), col(bx[0]), bx[1])
+        fx = damp(fx, (an.ravel(), bn))
+        az, bzv, ax, bxv = fx[0], fx[1], bz[0], bz[1]
+        t = bzv @ Vt.T
+        u = bxv @ Uk
+        D = col(az) + col(ax) * sigma[None, :]**2
+        rx = (sigma[None, :] * (t + sigma[None, :] * u) / D) @ Uk.T
+        ne = n_eff(az, ax)
+        vx = np.where(ax == 0, np.mean(sing2) * rank / (M * np.where(az == 0, 1., az)),
+                      ne / (alpha * np.where(ax == 0, 1., ax)))
+        an, bn = ab_new(rx, col(vx), col(ax), bxv)
+        fz = damp(fz, (an.ravel(), bn))
+        # backward sweep: likelihood (constant message), then the channel's backward message (:69-83,91-97)
+        bz = damp(bz, (np.full(B, 1. / noise_var), Y / noise_var))
+        az, bzv, ax, bxv = fx[0], fx[1], bz[0], bz[1]
+        t = bzv @ Vt.T
+        u = bxv @ Uk
+        D = col(az) + col(ax) * sigma[None, :]**2
+        if k == N:
+            rz = ((t + sigma[None, :] * u) / D) @ Vt
+        else:
+            rz = bzv / col(az) + ((1 / D - 1 / col(az)) * t + sigma[None, :] * u / D) @ Vt
+        vz = (1 - n_eff(np.maximum(1e-11, az), ax)) / np.maximum(1e-11, az)
+        an, bn = ab_new(rz, col(vz), col(az), bzv)
+        bx = damp(bx, (an.ravel(), bn))
+    ahx, ahz = fx[0] + bx[0], fz[0] + bz[0]
+    return dict(r=[(fx[1] + bx[1]) / col(ahx), (fz[1] + bz[1]) / col(ahz)], v=[1. / ahx, 1. / ahz],
+                fwd=[fx, fz], bwd=[bx, bz])
+
+
 def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1e-6,
             wait_increase=5, max_increase=0.2, record=None, a0=0., b0=0., init=None):
     """Expectation propagation on a tree-structured model (message_passing.py:211-269,330-357 with

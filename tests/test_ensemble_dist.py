@@ -179,3 +179,40 @@ def test_launcher_returns_when_a_rank_dies(tmp_path):
     t0 = time.time()
     rc = ensemble.launch_ranks(2, [str(script)], grace=1.0)
     assert rc != 0 and time.time() - t0 < 60
+
+
+def test_bench_rank_logic_world_8():
+    """bench.py's rank logic at the world size of BASELINE configs[3] (8 ranks x 64 instances = 512) on the socket
+    communicator: every instance draws the same signal whatever the partition (the reference's sequential loop over
+    seeds, tramp/experiments/multiple_experiments.py:30-49), and rank 0's gathered per-instance results come back in
+    instance order."""
+    import argparse
+    import bench
+    world, B, N, M = 8, 64, 24, 12
+    args = argparse.Namespace(rho=0.3)
+    X1, n1 = bench.teacher_signals(ensemble, args, 0, world * B, N, M, np.float64)
+    assert len({tuple(r) for r in X1.round(12).tolist()}) == world * B            # 512 different instances
+    port = ensemble.free_port()
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            comm = ensemble.SocketComm(ensemble.Rendezvous(rank, world, "127.0.0.1", port, timeout=60))
+            start, stop = ensemble.shard_range(world * B, rank, world)
+            assert stop - start == B
+            X, noise = bench.teacher_signals(ensemble, args, start, stop, N, M, np.float64)
+            a, b = bench.gather_instances(comm, [X.sum(axis=1), noise[:, 0]], world, B)
+            out[rank] = (X, noise, a, b, comm.max(float(rank)))
+            comm.barrier()
+            comm.close()
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs
+    for r in range(world):
+        X, noise, a, b, mx = out[r]
+        assert np.array_equal(X, X1[r * B:(r + 1) * B]) and np.array_equal(noise, n1[r * B:(r + 1) * B])
+        assert np.array_equal(a, X1.sum(axis=1)) and np.array_equal(b, n1[:, 0]) and mx == world - 1.0

@@ -34,6 +34,26 @@ def test_bench_prints_one_json_line(force_dist):
     assert d["value"] > 0 and d["roofline"]["bound"] in ("hbm", "mfma")
     if force_dist:
         assert "RCCL" in d["config"]["collectives"]
+    # the factors are checked against W itself before W is freed, and the observations come from W x
+    res = d["setup"]["factor_residuals"]
+    assert res["max"] <= 1e-9 and res["probes"] == 4 and d["setup"]["teacher_z"].startswith("W x")
+    for key in ("vt_rows_orthonormal", "uk_cols_orthonormal", "reconstruction", "gram"):
+        assert 0 <= res[key] <= 1e-9, (key, res)
+    assert "peak_measured_issue_rate" not in d["roofline"]
+    tts = d["time_to_solution"]
+    assert tts["headline"]["n_iter"] > 3 and tts["headline"]["total_s"] > tts["headline"]["iterate_s"] > 0
+    assert sum(tts["headline"]["status_counts"]) == 4
+    assert tts["n1000"]["total_s_median"] > 0 and all(5 < n < 200 for n in tts["n1000"]["n_iter"])
+    assert all(m < 2e-2 for m in tts["n1000"]["mse"])
+
+
+def test_bench_refuses_wrong_factors():
+    "a factorisation that does not reproduce W stops the run (exit code 3, no result line)"
+    env = dict(os.environ, TRAMP_BENCH_CORRUPT_FACTORS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2048", "--batch", "4", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-denoiser", "--no-se", "--no-tts"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and r.stdout == "" and "FACTOR RESIDUALS ABOVE TOLERANCE" in r.stderr, r.stderr[-2000:]
 
 
 def test_two_ranks_on_one_gpu_fall_back_to_sockets():
@@ -64,3 +84,4 @@ def test_two_ranks_on_one_gpu_fall_back_to_sockets():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["instances_total"] == 16
     assert "RCCL" in d["config"]["collectives"]
+    assert d["setup"]["factor_residuals"]["max"] <= 1e-9

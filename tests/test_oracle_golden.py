@@ -268,6 +268,31 @@ def test_ep_trajectories(golden_ep):
                 close(recs[it]["v"][i], t[f"v:{vid}"][it], rtol=tol)
 
 
+@pytest.mark.parametrize("damping", [None, 0.1])
+@pytest.mark.parametrize("M,N", [(100, 200), (120, 120), (90, 60)])
+def test_batched_thin_ep_matches_the_chain_scheduler(M, N, damping):
+    """ep_glm_thin_batch (the host counterpart of the ensemble run, used by bench.py's like-for-like CPU baseline)
+    against ep_chain - itself pinned on the reference's trajectories above - instance by instance."""
+    rs = np.random.RandomState(M + N)
+    B, rho, nv = 3, 0.1, 1e-2
+    W = orc.gaussian_ensemble(rs, M, N)
+    X = np.stack([orc.gb_sample(rs, N, rho) for _ in range(B)])
+    Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
+    lin = orc.LinearFactor(W, thin=True)
+    L = lin.lin
+    res = orc.ep_glm_thin_batch(L.Uk, L.sigma, L.Vk.T, Y, rho, nv, damping=damping, n_iter=8, rank=L.rank)
+    for b in range(B):
+        ref = orc.ep_chain([orc.GBPriorFactor(N, rho=rho), lin, orc.GaussLikFactor(Y[b], nv)], [N, M], max_iter=8,
+                           damping=damping, tol=0.0, max_increase=np.inf)
+        for i in range(2):
+            close(res["r"][i][b], ref["r"][i], rtol=1e-9, atol=1e-11)
+            close(res["v"][i][b], ref["v"][i], rtol=1e-10)
+            close(res["fwd"][i][0][b], ref["fwd"][i][0], rtol=1e-9)
+            close(res["bwd"][i][0][b], ref["bwd"][i][0], rtol=1e-9)
+            sc = np.abs(ref["bwd"][i][1]).max()
+            close(res["bwd"][i][1][b], ref["bwd"][i][1], rtol=1e-9, atol=1e-10 * sc)
+
+
 def test_se_scalar_rows(golden_se):
     for c in golden_se["gb_prior"]:
         v = orc.se_gb_prior_error(c["ax"], c["rho"], c["mean"], c["var"])

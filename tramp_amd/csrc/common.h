@@ -58,6 +58,9 @@ struct tramp_ctx {
     size_t hint_ws_bytes;
     unsigned long long hint_armed, hint_used;   // producers that left moments / prior updates that ran single-pass
     int graphs_alive;    // captured graphs hold raw workspace pointers: no growth while > 0
+    // launch shape of the last MFMA matrix pass (tramp_matvec_last_launch): split-K factor, 64-instance chunks,
+    // whether sibling chunks were interleaved in a one-dimensional grid
+    int last_nsplit, last_nchunk, last_flat;
 };
 
 // RAII scope: records start/stop events on the context's stream when profiling is on.

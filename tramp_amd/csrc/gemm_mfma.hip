@@ -823,6 +823,9 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     const int bt = (nchunk > 1) ? 4 : (int)((btail + 15) / 16);
     dim3 block(kBlock);
     const bool tail = (kdim % kstep_of<T>()) != 0;
+    ctx->last_nsplit = (int)nsplit;
+    ctx->last_nchunk = (int)nchunk;
+    ctx->last_flat = 0;
 #define LAUNCH_NT(BTv, TAILv) hipLaunchKernelGGL((gemm_nt_kernel<T, BTv, RT, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
 #define LAUNCH_NN(BTv, TAILv) hipLaunchKernelGGL((gemm_nn_kernel<T, BTv, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
 #define BY_BT(M_, TAILv)                       \
@@ -884,6 +887,7 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
             constexpr int RT = 4;
             const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
             dim3 grid = chunk_grid(nrb * nsplit, nchunk);
+            ctx->last_flat = nchunk > 1 && grid.y == 1;
             if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
         } else if (rt_env == 1) {
             constexpr int RT = 1;
@@ -899,6 +903,7 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     } else {
         const size_t ncb = (C + 64 * E - 1) / (64 * E);
         dim3 grid = chunk_grid(ncb * nsplit, nchunk);
+        ctx->last_flat = nchunk > 1 && grid.y == 1;
         if (tail) { BY_BT(LAUNCH_NN, true) } else { BY_BT(LAUNCH_NN, false) }
     }
 #undef BY_BT

@@ -355,6 +355,14 @@ extern "C" int tramp_matvec_nn(tramp_ctx* ctx, int dtype, int algo, size_t R, si
     return matvec_dispatch(ctx, dtype, algo, false, R, C, batch, mat_d, x_d, epi);
 }
 
+extern "C" int tramp_matvec_last_launch(tramp_ctx* ctx, int* nsplit, int* nchunk, int* flat_chunks) {
+    if (!ctx) return TRAMP_EINVAL;
+    if (nsplit) *nsplit = ctx->last_nsplit;
+    if (nchunk) *nchunk = ctx->last_nchunk;
+    if (flat_chunks) *flat_chunks = ctx->last_flat;
+    return TRAMP_OK;
+}
+
 // ---------------------------------------------------------------- spectral coefficients
 // w = f(t, u) on [batch, k]; tiny next to the matrix passes.
 template <typename T>
