@@ -243,6 +243,22 @@ int tramp_diag_factor(tramp_ctx* ctx, int dtype, int which, size_t count,
                       const void* a_d, const void* b_d, const void* in2_d,
                       double p0, double p1, double p2,
                       void* a_new_d, void* b_new_d, void* r_d, void* v_d);
+/* The same for every separable factor built here, parameters as an array (the inputs of the reference's own
+ * factor tests: tramp/tests/test_priors.py:17-51, tramp/tests/test_likelihoods.py:22-83).  which / params:
+ *   TRAMP_DIAG_GB {rho, mean, var}      gauss_bernoulli_prior.py:70-77     TRAMP_DIAG_L1 {gamma}   map_L1_norm_prior.py:66-71
+ *   TRAMP_DIAG_SGN_LIK {}  (in2 = y)    sgn_likelihood.py:32-37            TRAMP_DIAG_ABS_LIK {}   abs_likelihood.py:31-36
+ *   TRAMP_DIAG_GAUSS_PRIOR {mean, var}  gaussian_prior.py:63-68            TRAMP_DIAG_GAUSS_LIK {var}  gaussian_likelihood.py:43-49
+ *   TRAMP_DIAG_BINARY {b0 = 0.5 log(p+/p-)}  binary_prior.py:27,52-58
+ *   TRAMP_DIAG_RELU_LIK {slope of the negative side; 0 = Relu}  piecewise_linear_likelihood.py:9-63,279-291
+ *   TRAMP_DIAG_PWL3_LIK {z_lo, z_hi, slope pos/mid/neg, x0 pos/mid/neg}  piecewise_linear_likelihood.py:156-218,293-320
+ * (the Gaussian factors' MESSAGES are constants in the reference, gaussian_prior.py:86-89: the host mirror
+ * returns those; a_new / b_new here are the generic compute_ab_new of the posterior) */
+enum { TRAMP_DIAG_GB = 0, TRAMP_DIAG_L1 = 1, TRAMP_DIAG_SGN_LIK = 2, TRAMP_DIAG_ABS_LIK = 3, TRAMP_DIAG_GAUSS_PRIOR = 4,
+       TRAMP_DIAG_GAUSS_LIK = 5, TRAMP_DIAG_BINARY = 6, TRAMP_DIAG_RELU_LIK = 7, TRAMP_DIAG_PWL3_LIK = 8 };
+int tramp_diag_factor_p(tramp_ctx* ctx, int dtype, int which, size_t count,
+                        const void* a_d, const void* b_d, const void* in2_d,
+                        const double* params, int nparams,
+                        void* a_new_d, void* b_new_d, void* r_d, void* v_d);
 
 /* Producer-fused moments.  An isotropic prior update needs v = mean_i v_i over the message it
  * receives before it can write anything (tramp/base.py:250-255) - a whole extra read of b.  The

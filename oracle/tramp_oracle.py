@@ -1151,10 +1151,11 @@ class GBPriorFactor(OracleFactor):
         return self.rho * (self.mean**2 + self.var)
 
 
-def binary_prior_posterior(ax, bx, p_pos=0.5):
+def binary_prior_posterior(ax, bx, p_pos=0.5, isotropic=True):
     "tramp/priors/binary_prior.py:27,52-58; beliefs/binary.py:8-13"
     b = bx + 0.5 * np.log(p_pos / (1 - p_pos))
-    return np.tanh(b), (1 - np.tanh(b)**2).mean()
+    v = 1 - np.tanh(b)**2
+    return np.tanh(b), (v.mean() if isotropic else v)
 
 
 def se_binary_prior_error(ax, p_pos=0.5, method="quadpack"):

@@ -81,6 +81,34 @@ def golden_tree():
 
 
 @pytest.fixture(scope="session")
+def golden_diag():
+    return load_golden("diag")
+
+
+def diag_oracle_posterior(orc, c):
+    """(r, v) arrays of one tests/golden/diag.npz case from the oracle's isotropic=False forms"""
+    a, b, kw, n = c["a"], c["b"], c["kwargs"], c["name"]
+    if c["family"] == "prior":
+        if n == "gaussian":
+            return orc.gauss_prior_posterior(a, b, kw.get("mean", 0), kw.get("var", 1))
+        if n == "gauss_bernoulli":
+            return orc.gb_prior_posterior(a, b, kw.get("rho", 0.5), kw.get("mean", 0), kw.get("var", 1), isotropic=False)
+        if n == "binary":
+            return orc.binary_prior_posterior(a, b, kw.get("p_pos", 0.5), isotropic=False)
+        return orc.l1_prior_posterior(a, b, kw.get("gamma", 1), isotropic=False)
+    y = c["y"]
+    if n == "gaussian":
+        return orc.gauss_lik_posterior(a, b, y, kw.get("var", 1))
+    if n == "abs":
+        return orc.abs_lik_posterior(a, b, y, isotropic=False)
+    if n == "sgn":
+        return orc.sgn_lik_posterior(a, b, y, isotropic=False)
+    if n in ("relu", "l-relu"):
+        return orc.relu_lik_posterior(a, b, y, kw.get("slope", 0.), isotropic=False)
+    return orc.pwl3_lik_posterior(n, a, b, y, isotropic=False, param=kw.get("width"))
+
+
+@pytest.fixture(scope="session")
 def golden_se():
     return load_golden("se")
 

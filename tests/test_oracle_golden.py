@@ -268,6 +268,26 @@ def test_ep_trajectories(golden_ep):
                 close(recs[it]["v"][i], t[f"v:{vid}"][it], rtol=tol)
 
 
+def test_diagonal_beliefs_oracle_matches_reference(golden_diag):
+    """isotropic=False forms (every factor-level test of the reference runs in this mode: tests/test_priors.py:17-51,
+    tests/test_likelihoods.py:22-83): posteriors as arrays, messages with the element-wise clip of base.py:250-255;
+    the Gaussian factors answer with their constant message whatever comes in (gaussian_prior.py:86-89,
+    gaussian_likelihood.py:68-71)."""
+    from tests.conftest import diag_oracle_posterior
+    assert len(golden_diag) == 44
+    for c in golden_diag:
+        with np.errstate(all="ignore"):
+            r, v = diag_oracle_posterior(orc, c)
+        tag = (c["family"], c["name"], c["inputs"], c["kwargs"])
+        np.testing.assert_allclose(r, c["r"], rtol=1e-14, atol=1e-15, err_msg=str(tag))
+        np.testing.assert_allclose(np.broadcast_to(v, c["v"].shape), c["v"], rtol=1e-13, atol=1e-16, err_msg=str(tag))
+        if c["name"] == "gaussian":
+            continue
+        an, bn = orc.ab_new(r, v, c["a"], c["b"])
+        np.testing.assert_allclose(an, c["a_new"], rtol=1e-11, err_msg=str(tag))
+        np.testing.assert_allclose(bn, c["b_new"], rtol=1e-11, atol=1e-12 * np.abs(c["b_new"]).max(), err_msg=str(tag))
+
+
 @pytest.mark.parametrize("damping", [None, 0.1])
 @pytest.mark.parametrize("M,N", [(100, 200), (120, 120), (90, 60)])
 def test_batched_thin_ep_matches_the_chain_scheduler(M, N, damping):

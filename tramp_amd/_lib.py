@@ -15,6 +15,8 @@ SGN, ABS, RELU = 0, 1, 2
 FWD, BWD = 0, 1
 GEMV_MAX_BATCH = 8
 REUSE_T, REUSE_U = 1, 2
+(DIAG_GB, DIAG_L1, DIAG_SGN_LIK, DIAG_ABS_LIK, DIAG_GAUSS_PRIOR, DIAG_GAUSS_LIK, DIAG_BINARY, DIAG_RELU_LIK,
+ DIAG_PWL3_LIK) = range(9)
 (LOGZ_GB_PRIOR, LOGZ_GAUSS_PRIOR, LOGZ_L1_PRIOR, LOGZ_GAUSS_LIK, LOGZ_SGN_LIK, LOGZ_ABS_LIK, LOGZ_PWL_SGN,
  LOGZ_PWL_ABS, LOGZ_PWL_RELU, LOGZ_VARIABLE) = range(10)
 
@@ -72,6 +74,7 @@ _SIGNATURES = {
     "tramp_pwl3_lik_bwd": [vp, i32, sz, sz, dbl, dbl, vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_se_pwl3_lik": [vp, sz, dbl, dbl, vp, vp, vp, vp, vp],
     "tramp_diag_factor": [vp, i32, i32, sz, vp, vp, vp, dbl, dbl, dbl, vp, vp, vp, vp],
+    "tramp_diag_factor_p": [vp, i32, i32, sz, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "tramp_linear_create": [vp, i32, sz, sz, sz, vp, vp, vp, C.POINTER(vp)],
     "tramp_linear_destroy": [vp, vp],
     "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],

@@ -133,10 +133,47 @@ class Factor(ReprMixin):
         "tramp/base.py:245-248"
         return np.clip(inv(v) - a, self.AMIN, self.AMAX)
 
+    # ``isotropic=False``: a is an array like b, variances stay per component, compute_ab_new clips element-wise
+    # (tramp/base.py:250-255) - kernel K1d..K7d, tramp_diag_factor_p.  Subclasses set _diag_which and _diag_params().
+    _diag_which = None
+
+    def _diag_params(self):
+        return ()
+
+    def _diag(self, a, b, y=None):
+        "(a_new, b_new, r, v) as host arrays of b's shape"
+        import ctypes as C
+        if self._diag_which is None:
+            raise NotImplementedError(f"diagonal beliefs are not built for {type(self).__name__}")
+        ctx = self.ctx
+        bh = np.asarray(b, dtype=self.dtype)
+        bd = ctx.array(bh)
+        ad = ctx.array(np.broadcast_to(np.asarray(a, dtype=self.dtype), bh.shape).copy())
+        yd = ctx.array(np.broadcast_to(np.asarray(y, dtype=self.dtype), bh.shape).copy()) if y is not None else None
+        par = [float(x) for x in self._diag_params()]
+        arr = (C.c_double * max(len(par), 1))(*par)
+        outs = [ctx.empty(bh.shape, self.dtype) for _ in range(4)]
+        ctx._call("tramp_diag_factor_p", self._dt, int(self._diag_which), bd.size, ad, bd, yd, arr, len(par), *outs)
+        return [o.get() for o in outs]
+
     def _logz(self, kind, a0, v0, a1=None, v1=None, params=(0.0, 0.0, 0.0), mean=True):
         """Log-partition through tramp_log_partition: the kernel returns the sum
         over the components; ``mean`` divides by n as the reference's priors / likelihoods do."""
         ctx = self.ctx
+        if not getattr(self, "isotropic", True) and np.ndim(a0) > 0 and not isinstance(v0, DeviceArray):
+            # diagonal beliefs: every component has its own precision - n instances of one component each,
+            # then the reference's A.mean() (e.g. gauss_bernoulli_prior.py:79-83) on the host
+            vh = np.asarray(v0, dtype=self.dtype).reshape(-1, 1)
+            ah = np.broadcast_to(np.asarray(a0, dtype=np.float64).ravel(), (vh.shape[0],)).copy()
+            wh = None
+            if v1 is not None:
+                wh = (v1.get() if isinstance(v1, DeviceArray) else np.asarray(v1, dtype=self.dtype)).reshape(-1, 1)
+            iso, self.isotropic = self.isotropic, True
+            try:
+                per = np.atleast_1d(self._logz(kind, ah, vh, a1, wh, params, mean=False))
+            finally:
+                self.isotropic = iso
+            return float(per.mean()) if mean else float(per.sum())
         v = VecArg(ctx, v0, self.dtype)
         a = ScalArg(ctx, a0, v.batch)
         w = VecArg(ctx, v1, self.dtype) if v1 is not None else None

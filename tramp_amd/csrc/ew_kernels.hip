@@ -1177,31 +1177,76 @@ extern "C" int tramp_gauss_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t b
     return TRAMP_OK;
 }
 
-// ---------------------------------------------------------------- diagonal beliefs (K1d..K5d)
+// ---------------------------------------------------------------- diagonal beliefs (K1d..K7d)
+// isotropic=False: the precision a is an array like b, the posterior variance stays per component and
+// compute_ab_new clips element-wise (tramp/base.py:250-255) - one independent component per thread, no reduction.
+// The mode every factor-level test of the reference runs in (tests/test_priors.py:17-51, test_likelihoods.py:22-83).
+struct DiagParams { double p[8]; };
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, const T* __restrict__ a,
                                                       const T* __restrict__ b, const T* __restrict__ in2,
-                                                      double p0, double p1, double p2,
+                                                      DiagParams P,
                                                       T* __restrict__ a_new, T* __restrict__ b_new,
                                                       T* __restrict__ r_out, T* __restrict__ v_out) {
+    const double p0 = P.p[0], p1 = P.p[1], p2 = P.p[2];
     double a0 = 0, b0 = 0, eta = 0;
-    if (which == 0) {
+    if (which == TRAMP_DIAG_GB) {
         a0 = 1.0 / p2;
         b0 = p1 / p2;
         eta = 0.5 * (b0 * b0 / a0 + log(2 * tmath::kPi / a0)) - log(p0 / (1 - p0));
+    } else if (which == TRAMP_DIAG_GAUSS_PRIOR) {          // p0 = mean, p1 = var (gaussian_prior.py:13-17)
+        a0 = 1.0 / p1;
+        b0 = p0 / p1;
+    } else if (which == TRAMP_DIAG_GAUSS_LIK) {            // p0 = var (gaussian_likelihood.py:13-17)
+        a0 = 1.0 / p0;
     }
+    tmath::Pwl3Spec spec{p0, p1, {P.p[2], P.p[3], P.p[4]}, {P.p[5], P.p[6], P.p[7]}};
+    tmath::erfcx_setup<T>();                               // the half-line moments read erfcx from the LDS table
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) {
         T ai = a[i], bi = b[i];
         RV<T> o;
-        if (which == 0) {
-            T at = ai + T(a0);
-            o = tmath::gb_posterior<T>(bi, at, tmath::log_(T(2 * tmath::kPi) / at), T(b0), T(eta));
-        } else if (which == 1) {
-            o = tmath::l1_posterior<T>(bi, T(1) / ai, T(p0));
-        } else if (which == 2) {
-            o = tmath::sgn_lik_posterior<T>(bi, in2[i], ai, T(1) / ai);
-        } else {
-            o = tmath::abs_lik_posterior<T>(bi, in2[i]);
+        switch (which) {
+            case TRAMP_DIAG_GB: {
+                T at = ai + T(a0);
+                o = tmath::gb_posterior<T>(bi, at, tmath::log_(T(2 * tmath::kPi) / at), T(b0), T(eta));
+                break;
+            }
+            case TRAMP_DIAG_L1:
+                o = tmath::l1_posterior<T>(bi, T(1) / ai, T(p0));
+                break;
+            case TRAMP_DIAG_SGN_LIK:
+                o = tmath::sgn_lik_posterior<T>(bi, in2[i], ai, T(1) / ai);
+                break;
+            case TRAMP_DIAG_ABS_LIK:
+                o = tmath::abs_lik_posterior<T>(bi, in2[i]);
+                break;
+            case TRAMP_DIAG_GAUSS_PRIOR: {                 // gaussian_prior.py:63-68
+                const T at = ai + T(a0);
+                o.r = (bi + T(b0)) / at;
+                o.v = T(1) / at;
+                break;
+            }
+            case TRAMP_DIAG_GAUSS_LIK: {                   // gaussian_likelihood.py:43-49
+                const T at = ai + T(a0);
+                o.r = (bi + T(a0) * in2[i]) / at;
+                o.v = T(1) / at;
+                break;
+            }
+            case TRAMP_DIAG_BINARY: {                      // p0 = b0 (binary_prior.py:27,52-58; beliefs/binary.py:8-13)
+                const T t = tmath::tanh_(bi + T(p0));
+                o.r = t;
+                o.v = T(1) - t * t;
+                break;
+            }
+            case TRAMP_DIAG_RELU_LIK:                      // p0 = slope of the negative side (0: Relu)
+                o = tmath::relu_lik_posterior<T>(bi, in2[i], T(p0), tmath::region_const<T>((double)ai));
+                break;
+            default: {                                     // TRAMP_DIAG_PWL3_LIK
+                tmath::PwlOut<T> w = tmath::pwl3_lik_posterior<T>(bi, in2[i], ai, spec);
+                o.r = w.r;
+                o.v = w.v;
+            }
         }
         // element-wise compute_ab_new (tramp/base.py:250-255)
         double an = tmath::a_new_of((double)o.v, (double)ai);
@@ -1213,25 +1258,47 @@ __global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, c
     }
 }
 
-extern "C" int tramp_diag_factor(tramp_ctx* ctx, int dtype, int which, size_t count, const void* a_d,
-                                 const void* b_d, const void* in2_d, double p0, double p1, double p2,
-                                 void* a_new_d, void* b_new_d, void* r_d, void* v_d) {
+extern "C" int tramp_diag_factor_p(tramp_ctx* ctx, int dtype, int which, size_t count, const void* a_d,
+                                   const void* b_d, const void* in2_d, const double* params, int nparams,
+                                   void* a_new_d, void* b_new_d, void* r_d, void* v_d) {
     if (!ctx) return TRAMP_EINVAL;
-    TRAMP_REQUIRE(ctx, which >= 0 && which <= 3 && a_d && b_d);
-    TRAMP_REQUIRE(ctx, which < 2 || in2_d);
+    TRAMP_REQUIRE(ctx, which >= 0 && which <= TRAMP_DIAG_PWL3_LIK && a_d && b_d && nparams >= 0 && nparams <= 8);
+    TRAMP_REQUIRE(ctx, nparams == 0 || params);
+    const bool needs_y = which == TRAMP_DIAG_SGN_LIK || which == TRAMP_DIAG_ABS_LIK || which == TRAMP_DIAG_GAUSS_LIK ||
+                         which == TRAMP_DIAG_RELU_LIK || which == TRAMP_DIAG_PWL3_LIK;
+    TRAMP_REQUIRE(ctx, !needs_y || in2_d);
+    static const int need[] = {3, 1, 0, 0, 2, 1, 1, 1, 8};
+    TRAMP_REQUIRE(ctx, nparams >= need[which]);
+    DiagParams P{};
+    for (int i = 0; i < nparams; ++i) P.p[i] = params[i];
+    if (which == TRAMP_DIAG_GB) TRAMP_REQUIRE(ctx, P.p[0] > 0.0 && P.p[0] < 1.0 && P.p[2] > 0.0);
+    if (which == TRAMP_DIAG_GAUSS_PRIOR) TRAMP_REQUIRE(ctx, P.p[1] > 0.0);
+    if (which == TRAMP_DIAG_GAUSS_LIK) TRAMP_REQUIRE(ctx, P.p[0] > 0.0);
+    if (which == TRAMP_DIAG_RELU_LIK) TRAMP_REQUIRE(ctx, P.p[0] >= 0.0);
+    if (which == TRAMP_DIAG_PWL3_LIK)
+        TRAMP_REQUIRE(ctx, P.p[0] < P.p[1] && P.p[2] >= 0.0 && P.p[3] >= 0.0 && P.p[4] >= 0.0);
     if (!count) return TRAMP_OK;
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((diag_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, which,
-                           count, (const double*)a_d, (const double*)b_d, (const double*)in2_d, p0, p1, p2,
+                           count, (const double*)a_d, (const double*)b_d, (const double*)in2_d, P,
                            (double*)a_new_d, (double*)b_new_d, (double*)r_d, (double*)v_d);
     else if (dtype == TRAMP_F32)
         hipLaunchKernelGGL((diag_kernel<float>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, which,
-                           count, (const float*)a_d, (const float*)b_d, (const float*)in2_d, p0, p1, p2,
+                           count, (const float*)a_d, (const float*)b_d, (const float*)in2_d, P,
                            (float*)a_new_d, (float*)b_new_d, (float*)r_d, (float*)v_d);
     else
         return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
+}
+
+extern "C" int tramp_diag_factor(tramp_ctx* ctx, int dtype, int which, size_t count, const void* a_d,
+                                 const void* b_d, const void* in2_d, double p0, double p1, double p2,
+                                 void* a_new_d, void* b_new_d, void* r_d, void* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, which >= 0 && which <= TRAMP_DIAG_ABS_LIK);
+    const double params[3] = {p0, p1, p2};
+    return tramp_diag_factor_p(ctx, dtype, which, count, a_d, b_d, in2_d, params, 3, a_new_d, b_new_d, r_d, v_d);
 }
 
 // ---------------------------------------------------------------- K11 variable posterior + norms

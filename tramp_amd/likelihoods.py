@@ -14,7 +14,6 @@ class Likelihood(Factor):
     "tramp/likelihoods/base_likelihood.py:6-118"
     n_next = 0
     n_prev = 1
-    _which_diag = None
     _kernel_extra = ()
 
     def get_size(self, y):
@@ -57,16 +56,6 @@ class Likelihood(Factor):
                   old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr,
                   r.ptr if r is not None else None, v.ptr if v is not None else None)
         return a, b, a_new, b_new, r, v
-
-    def _diag(self, az, bz, y):
-        ctx = self.ctx
-        b = ctx.array(np.asarray(bz, dtype=self.dtype))
-        a = ctx.array(np.broadcast_to(np.asarray(az, dtype=self.dtype), b.shape).copy())
-        yd = ctx.array(np.asarray(y, dtype=self.dtype))
-        outs = [ctx.empty(b.shape, self.dtype) for _ in range(4)]
-        ctx._call("tramp_diag_factor", self._dt, self._which_diag, b.size, a.ptr, b.ptr, yd.ptr, 0.0, 0.0, 0.0,
-                  *[o.ptr for o in outs])
-        return [o.get() for o in outs]
 
     def compute_backward_message(self, az, bz, **kw):
         "Likelihood.compute_backward_message (base_likelihood.py:25-28)"
@@ -120,12 +109,20 @@ class GaussianLikelihood(Likelihood):
         self._set_y(y)
         self._b_dev = None      # y / var, formed once on the device (gaussian_likelihood.py:17)
 
+    _diag_which = _lib.DIAG_GAUSS_LIK
+
+    def _diag_params(self):
+        return (self.var,)
+
     def sample(self, X):
         return X + self.sigma * np.random.standard_normal(X.shape)
 
     def compute_backward_posterior(self, az, bz, y):
         """gaussian_likelihood.py:43-49: r = (bz + y/var) / (az + 1/var), v = 1 / (az + 1/var): kernel K11 on the
         incoming message and the likelihood's own constant one."""
+        if not self.isotropic:
+            _, _, r, v = self._diag(az, bz, y)
+            return r, v
         ctx = self.ctx
         b = VecArg(ctx, bz, self.dtype)
         a = ScalArg(ctx, az, b.batch)
@@ -138,6 +135,8 @@ class GaussianLikelihood(Likelihood):
 
     def compute_backward_message(self, az, bz, out_a=None, out_b=None, **_):
         "gaussian_likelihood.py:68-71"
+        if not self.isotropic:
+            return self.a, self.a * np.asarray(self.y, dtype=self.dtype)
         ctx = self.ctx
         b = VecArg(ctx, bz, self.dtype)
         a = ScalArg(ctx, az, b.batch)
@@ -160,7 +159,7 @@ class SgnLikelihood(Likelihood):
     _logz_kind = _lib.LOGZ_SGN_LIK
     "tramp/likelihoods/sgn_likelihood.py:9-98 (K4)"
     _kernel_name = "tramp_sgn_lik_bwd"
-    _which_diag = 2
+    _diag_which = _lib.DIAG_SGN_LIK
 
     def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
         self.y_name = y_name
@@ -188,7 +187,7 @@ class AbsLikelihood(Likelihood):
     _logz_kind = _lib.LOGZ_ABS_LIK
     "tramp/likelihoods/abs_likelihood.py:8-72 (K5)"
     _kernel_name = "tramp_abs_lik_bwd"
-    _which_diag = 3
+    _diag_which = _lib.DIAG_ABS_LIK
 
     def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
         self.y_name = y_name
@@ -217,10 +216,12 @@ class ReluLikelihood(Likelihood):
     z = y, y == 0 leaves a truncated normal on (-inf, 0]."""
     _kernel_name = "tramp_relu_lik_bwd"
     _slope = 0.0
+    _diag_which = _lib.DIAG_RELU_LIK
+
+    def _diag_params(self):
+        return (self._slope,)
 
     def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
-        if not isotropic:
-            raise NotImplementedError("diagonal beliefs are not built for the piecewise-linear likelihoods")
         self.y_name = y_name
         self.size = self.get_size(y)
         self.isotropic = isotropic
@@ -262,10 +263,12 @@ class ThreeRegionLikelihood(Likelihood):
     _z = (-1.0, 1.0)
     _slopes = (0.0, 1.0, 0.0)     # pos, mid, neg
     _x0 = (1.0, 0.0, -1.0)
+    _diag_which = _lib.DIAG_PWL3_LIK
+
+    def _diag_params(self):
+        return tuple(self._z) + tuple(self._slopes) + tuple(self._x0)
 
     def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
-        if not isotropic:
-            raise NotImplementedError("diagonal beliefs are not built for the piecewise-linear likelihoods")
         self.y_name = y_name
         self.size = self.get_size(y)
         self.isotropic = isotropic

@@ -34,10 +34,16 @@ class Prior(Factor):
 
     def compute_forward_message(self, ax, bx, **kw):
         "Prior.compute_forward_message (base_prior.py:13-16)"
+        if not self.isotropic:
+            a_new, b_new, _, _ = self._diag(ax, bx)
+            return a_new, b_new
         a, b, a_new, b_new, _, _ = self._message(self._kernel, ax, bx, **kw)
         return ret_scal(a_new, a, b), ret_vec(b_new, b)
 
     def compute_forward_posterior(self, ax, bx):
+        if not self.isotropic:
+            _, _, r, v = self._diag(ax, bx)
+            return r, v
         a, b, _, _, r, v = self._message(self._kernel, ax, bx, want_posterior=True)
         return ret_vec(r, b), ret_scal(v, a, b)
 
@@ -89,26 +95,10 @@ class GaussBernoulliPrior(Prior):
                        a_new.ptr, b_new.ptr, r.ptr if r is not None else None,
                        v.ptr if v is not None else None)
 
-    def _diag(self, ax, bx):
-        ctx = self.ctx
-        b = ctx.array(np.asarray(bx, dtype=self.dtype))
-        a = ctx.array(np.broadcast_to(np.asarray(ax, dtype=self.dtype), b.shape).copy())
-        outs = [ctx.empty(b.shape, self.dtype) for _ in range(4)]
-        ctx._call("tramp_diag_factor", self._dt, 0, b.size, a.ptr, b.ptr, None, float(self.rho),
-                  float(self.mean), float(self.var), *[o.ptr for o in outs])
-        return [o.get() for o in outs]      # a_new, b_new, r, v
+    _diag_which = _lib.DIAG_GB
 
-    def compute_forward_posterior(self, ax, bx):
-        if not self.isotropic:
-            _, _, r, v = self._diag(ax, bx)
-            return r, v
-        return super().compute_forward_posterior(ax, bx)
-
-    def compute_forward_message(self, ax, bx, **kw):
-        if not self.isotropic:
-            a_new, b_new, _, _ = self._diag(ax, bx)
-            return a_new, b_new
-        return super().compute_forward_message(ax, bx, **kw)
+    def _diag_params(self):
+        return (self.rho, self.mean, self.var)
 
     def moment_hint(self):
         "(kind, p0, p1, p2) for tramp_prior_hint: the producer of this prior's input message can leave sum v_i"
@@ -166,26 +156,10 @@ class MAP_L1NormPrior(Prior):
                      out_vec(ctx, b, self.dtype), None, None, count, mask)
         return mask.get().reshape(b.host_shape).astype(bool), count.get()
 
-    def _diag(self, ax, bx):
-        ctx = self.ctx
-        b = ctx.array(np.asarray(bx, dtype=self.dtype))
-        a = ctx.array(np.broadcast_to(np.asarray(ax, dtype=self.dtype), b.shape).copy())
-        outs = [ctx.empty(b.shape, self.dtype) for _ in range(4)]
-        ctx._call("tramp_diag_factor", self._dt, 1, b.size, a.ptr, b.ptr, None, float(self.gamma), 0.0, 0.0,
-                  *[o.ptr for o in outs])
-        return [o.get() for o in outs]
+    _diag_which = _lib.DIAG_L1
 
-    def compute_forward_posterior(self, ax, bx):
-        if not self.isotropic:
-            _, _, r, v = self._diag(ax, bx)
-            return r, v
-        return super().compute_forward_posterior(ax, bx)
-
-    def compute_forward_message(self, ax, bx, **kw):
-        if not self.isotropic:
-            a_new, b_new, _, _ = self._diag(ax, bx)
-            return a_new, b_new
-        return super().compute_forward_message(ax, bx, **kw)
+    def _diag_params(self):
+        return (self.gamma,)
 
     def moment_hint(self):
         return (2, float(self.gamma), 0.0, 0.0) if self.isotropic else None
@@ -201,8 +175,6 @@ class BinaryPrior(Prior):
     """
 
     def __init__(self, size, p_pos=0.5, isotropic=True, dtype=np.float64, ctx=None):
-        if not isotropic:
-            raise NotImplementedError("diagonal beliefs for BinaryPrior are outside the HIP path")
         self.size = size
         self.p_pos = p_pos
         self.isotropic = isotropic
@@ -210,6 +182,11 @@ class BinaryPrior(Prior):
         self._init_device(dtype, ctx)
         self.p_neg = 1 - p_pos
         self.b = 0.5 * np.log(self.p_pos / self.p_neg)          # :27
+
+    _diag_which = _lib.DIAG_BINARY
+
+    def _diag_params(self):
+        return (self.b,)
 
     def sample(self):
         return np.random.choice([-1, +1], size=self.size, replace=True, p=[self.p_neg, self.p_pos])
@@ -342,6 +319,11 @@ class GaussianPrior(Prior):
         self.a = 1 / var
         self.b = mean / var
 
+    _diag_which = _lib.DIAG_GAUSS_PRIOR
+
+    def _diag_params(self):
+        return (self.mean, self.var)
+
     def sample(self):
         return self.mean + self.sigma * np.random.standard_normal(self.size)
 
@@ -355,6 +337,9 @@ class GaussianPrior(Prior):
     def compute_forward_posterior(self, ax, bx):
         """gaussian_prior.py:63-68: r = (bx + mean/var) / (ax + 1/var), v = 1 / (ax + 1/var) - the product of
         two Gaussian messages, i.e. kernel K11 on the incoming message and the prior's own constant one."""
+        if not self.isotropic:
+            _, _, r, v = self._diag(ax, bx)
+            return r, v
         ctx = self.ctx
         b = VecArg(ctx, bx, self.dtype)
         a = ScalArg(ctx, ax, b.batch)
@@ -366,6 +351,8 @@ class GaussianPrior(Prior):
 
     def compute_forward_message(self, ax, bx, out_a=None, out_b=None, **_):
         "gaussian_prior.py:86-89: bypasses compute_ab_new (and damping sees a constant)"
+        if not self.isotropic:
+            return self.a * np.ones_like(ax), self.b * np.ones_like(bx)
         ctx = self.ctx
         b = VecArg(ctx, bx, self.dtype)
         a = ScalArg(ctx, ax, b.batch)
