@@ -283,44 +283,115 @@ def denoiser_roofline(T, ctx, dtype):
         del bx, b_new
     # the fused form, measured on the pair (producer, prior) that EP runs at N = 1e6
     try:
-        B, N = 64, 1_000_000
-        rs = np.random.RandomState(3)
-        ch = T.ConvChannel(rs.randn(N) / np.sqrt(N), dtype=np_dt, ctx=ctx)
-        p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
-        az, ax = ctx.scalars(1.3, B), ctx.scalars(0.9, B)
-        bz = ctx.randn((B, N), np_dt, seed=4, scale=1.2)
-        bx = ctx.randn((B, N), np_dt, seed=5, scale=1.0)
-        a_msg, b_msg = ctx.empty((B,), np.float64), ctx.empty((B, N), np_dt)
-        a_new, b_new = ctx.empty((B,), np.float64), ctx.empty((B, N), np_dt)
-        k = p.moment_hint()
-
-        def producer(hint):
-            if hint:
-                ctx._call("tramp_prior_hint", k[0], k[1], k[2], k[3], N, B, b_msg.ptr, a_msg.ptr)
-            ch.compute_backward_message(az, bz, ax, bx, out_a=a_msg, out_b=b_msg)
-
-        ms_plain = _timed(ctx, lambda: producer(False), 10)
-        ms_hint = _timed(ctx, lambda: producer(True), 10)
-        armed0, used0 = ctx.prior_hint_stats()
-
-        def pair():
-            producer(True)
-            p.compute_forward_message(a_msg, b_msg, out_a=a_new, out_b=b_new)
-
-        ms_pair = _timed(ctx, pair, 10)
-        armed1, used1 = ctx.prior_hint_stats()
-        ms_prior = ms_pair - ms_hint
-        extra = max(ms_hint - ms_plain, 0.0)
-        alg = 2 * esz * N * B
-        tot = ms_prior + extra
-        out["B64"] = {"n": N, "batch": B, "us_per_update": tot * 1e3, "us_prior_pass": ms_prior * 1e3,
-                      "us_added_to_producer": extra * 1e3, "us_producer": ms_plain * 1e3,
-                      "algorithmic_GBps": alg / tot / 1e6, "frac_of_hbm_peak": alg / tot / 1e6 / HBM_PEAK_GBS,
-                      "components_per_sec": N * B / (tot * 1e-3),
-                      "fused_updates": int(used1 - used0), "producers_armed": int(armed1 - armed0),
-                      "form": "producer-fused moments (ConvChannel inverse-FFT epilogue) + ONE update pass (2T moved)"}
+        out["B64"] = fused_updates_n1e6(T, ctx, dtype, only=("gb_prior",))["gb_prior"]
     except Exception as e:                                                    # noqa: BLE001
         out["B64"] = {"error": repr(e)}
+    return out
+
+
+def _event_samples(ctx, fns, reps):
+    """per-call HIP-event timings (ms) of several callables, interleaved (a b a b ...) so that clock / thermal
+    drift hits them alike; returns one list of samples per callable"""
+    for fn in fns:
+        for _ in range(2):
+            fn()
+    samples = [[] for _ in fns]
+    for _ in range(reps):
+        for k, fn in enumerate(fns):
+            e0, e1 = ctx.event(), ctx.event()
+            e0.record()
+            fn()
+            e1.record()
+            samples[k].append((e0, e1))
+    ctx.sync()
+    return [[a.elapsed_ms(b) for a, b in ss] for ss in samples]
+
+
+def fused_updates_n1e6(T, ctx, dtype, only=None):
+    """Producer-fused updates at N = 1e6 x 64 (csrc/prior_hint.h), on the pairs EP runs there with the matrix-free
+    ConvChannel: its backward update writes the prior's input message (GaussBernoulli, L1), its forward update the
+    likelihood's (sign, abs).  The kernel that writes the message leaves sum v_i; the consumer's update is finalize
+    + ONE streaming pass.  Charged time = that pass + what the moments add to the producer, the latter measured as
+    the median of interleaved per-call event timings of the producer with and without the hint (signed; its
+    median absolute deviation is reported - a rocprofv3 kernel trace of the same pair is under profiles/r03)."""
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    esz = np.dtype(np_dt).itemsize
+    B, N = 64, 1_000_000
+    rs = np.random.RandomState(3)
+    ch = T.ConvChannel(rs.randn(N) / np.sqrt(N), dtype=np_dt, ctx=ctx)
+    az, ax = ctx.scalars(1.3, B), ctx.scalars(0.9, B)
+    bz = ctx.randn((B, N), np_dt, seed=4, scale=1.2)
+    bx = ctx.randn((B, N), np_dt, seed=5, scale=1.0)
+    a_msg, b_msg = ctx.empty((B,), np.float64), ctx.empty((B, N), np_dt)
+    a_new, b_new = ctx.empty((B,), np.float64), ctx.empty((B, N), np_dt)
+    y = ctx.array(np.sign(np.random.RandomState(0).standard_normal((B, N))).astype(np_dt), np_dt)
+    gb = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
+    l1 = T.MAP_L1NormPrior(size=N, gamma=1.0, dtype=np_dt, ctx=ctx)
+    sg = T.SgnLikelihood(y=y, dtype=np_dt, ctx=ctx)
+    ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
+
+    def prior_case(p):
+        k = p.moment_hint()
+        arm = lambda: ctx._call("tramp_prior_hint", k[0], k[1], k[2], k[3], N, B, b_msg.ptr, a_msg.ptr)   # noqa: E731
+        prod = lambda: ch.compute_backward_message(az, bz, ax, bx, out_a=a_msg, out_b=b_msg)              # noqa: E731
+        cons = lambda: p.compute_forward_message(a_msg, b_msg, out_a=a_new, out_b=b_new)                  # noqa: E731
+        return arm, prod, cons, 2
+
+    def lik_case(lk):
+        kind, yd = lk.lik_hint(B, N)
+        arm = lambda: ctx._call("tramp_lik_hint", kind, N, B, b_msg.ptr, a_msg.ptr, yd.ptr)               # noqa: E731
+        prod = lambda: ch.compute_forward_message(az, bz, ax, bx, out_a=a_msg, out_b=b_msg)               # noqa: E731
+        cons = lambda: lk.compute_backward_message(a_msg, b_msg, out_a=a_new, out_b=b_new)                # noqa: E731
+        return arm, prod, cons, 3
+
+    cases = {"gb_prior": lambda: prior_case(gb), "l1_prior": lambda: prior_case(l1),
+             "sgn_lik": lambda: lik_case(sg), "abs_lik": lambda: lik_case(ab)}
+    out = {}
+    for name, mk in cases.items():
+        if only and name not in only:
+            continue
+        try:
+            arm, prod, cons, nT = mk()
+
+            def plain():                 # a hint left armed by an earlier call would be honoured again: clear it
+                ctx._call("tramp_prior_hint", 0, 0.0, 0.0, 0.0, 0, 0, None, None)
+                prod()
+
+            def with_hint():
+                arm()
+                prod()
+
+            def pair():
+                arm()
+                prod()
+                cons()
+
+            armed0, used0 = ctx.prior_hint_stats()
+            s_plain, s_hint, s_pair = _event_samples(ctx, [plain, with_hint, pair], 12)
+            armed1, used1 = ctx.prior_hint_stats()
+            arm_none = lambda: ctx._call("tramp_prior_hint", 0, 0.0, 0.0, 0.0, 0, 0, None, None)      # noqa: E731
+            arm_none()
+            ms_alone = _timed(ctx, cons, 8)                                   # the same update with no producer known
+            med = lambda v: float(np.median(v))                               # noqa: E731
+            added = np.asarray(s_hint) - np.asarray(s_plain)
+            ms_cons = med(np.asarray(s_pair) - np.asarray(s_hint))
+            ms_added = med(added)
+            mad = float(np.median(np.abs(added - ms_added)))
+            tot = ms_cons + max(ms_added, 0.0)
+            alg = nT * esz * N * B
+            out[name] = {"n": N, "batch": B, "us_per_update": tot * 1e3, "us_consumer_pass": ms_cons * 1e3,
+                         "us_prior_pass": ms_cons * 1e3,
+                         "us_added_to_producer": ms_added * 1e3, "us_added_to_producer_mad": mad * 1e3,
+                         "us_producer": med(s_plain) * 1e3, "us_standalone": ms_alone * 1e3,
+                         "algorithmic_bytes_per_component": nT * esz,
+                         "algorithmic_GBps": alg / tot / 1e6, "frac_of_hbm_peak": alg / tot / 1e6 / HBM_PEAK_GBS,
+                         "standalone_frac_of_hbm_peak": alg / ms_alone / 1e6 / HBM_PEAK_GBS,
+                         "components_per_sec": N * B / (tot * 1e-3),
+                         "fused_updates": int(used1 - used0), "producers_armed": int(armed1 - armed0),
+                         "form": "producer-fused moments (ConvChannel inverse-FFT epilogue) + ONE update pass "
+                                 f"({nT}T moved by the update; a likelihood's producer reads y once more)"}
+        except Exception as e:                                                # noqa: BLE001
+            out[name] = {"error": repr(e)}
     return out
 
 
@@ -799,6 +870,12 @@ def run(args):
             time.sleep(3.0)
             out["denoiser_n1e6"] = denoiser_roofline(T, ctx, args.dtype)
             try:
+                out["fused_updates_n1e6"] = fused_updates_n1e6(T, ctx, args.dtype,
+                                                               only=("l1_prior", "sgn_lik", "abs_lik"))
+                out["fused_updates_n1e6"]["gb_prior"] = out["denoiser_n1e6"].get("B64")
+            except Exception as e:                                            # noqa: BLE001
+                out["fused_updates_n1e6"] = {"error": repr(e)}
+            try:
                 out["factor_updates_n1e6"] = factor_updates_n1e6(T, ctx, args.dtype)
             except Exception as e:                                            # noqa: BLE001
                 out["factor_updates_n1e6"] = {"error": repr(e)}
@@ -807,6 +884,8 @@ def run(args):
                 # (half the bytes: the 64-instance working set is 2 x 256 MB, i.e. partly Infinity-Cache resident)
                 try:
                     out["denoiser_n1e6_f32"] = denoiser_roofline(T, ctx, "f32")
+                    out["fused_updates_n1e6_f32"] = fused_updates_n1e6(T, ctx, "f32",
+                                                                       only=("l1_prior", "sgn_lik", "abs_lik"))
                     out["factor_updates_n1e6_f32"] = factor_updates_n1e6(T, ctx, "f32")
                 except Exception as e:                                        # noqa: BLE001
                     out["denoiser_n1e6_f32"] = {"error": repr(e)}

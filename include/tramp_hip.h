@@ -271,6 +271,13 @@ int tramp_diag_factor_p(tramp_ctx* ctx, int dtype, int which, size_t count,
  * simply runs its own first pass - results agree to reduction-order rounding. */
 int tramp_prior_hint(tramp_ctx* ctx, int kind, double p0, double p1, double p2, size_t n, size_t batch,
                      const void* b_d, const double* a_d);
+/* The same at the other end of the chain: the message (a_d, b_d) about to be written (the dense channel's forward
+ * update, the inverse FFT's fused update) feeds tramp_sgn_lik_bwd (kind 3, sgn_likelihood.py:32-37) or
+ * tramp_abs_lik_bwd (kind 4, abs_likelihood.py:31-36) with the static observation y_d: the producer reads y_i once
+ * more and leaves sum v_i; the likelihood update is then finalize + ONE pass (read bz and y, write b_new: the 3T
+ * algorithmic bytes of SURVEY section 8d) instead of two (5T / 6T moved). */
+int tramp_lik_hint(tramp_ctx* ctx, int kind, size_t n, size_t batch, const void* b_d, const double* a_d,
+                   const void* y_d);
 /* how many producers left moments / how many prior updates consumed them, since the context was made */
 int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed, unsigned long long* used);
 

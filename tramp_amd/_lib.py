@@ -80,6 +80,7 @@ _SIGNATURES = {
     "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],
     "tramp_eigh": [vp, sz, vp, vp],
     "tramp_prior_hint": [vp, i32, dbl, dbl, dbl, sz, sz, vp, vp],
+    "tramp_lik_hint": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_prior_hint_stats": [vp, C.POINTER(u64), C.POINTER(u64)],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],

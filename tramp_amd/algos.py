@@ -520,6 +520,11 @@ class ExpectationPropagation:
             if hint is not None:
                 self.ctx._call("tramp_prior_hint", hint[0], hint[1], hint[2], hint[3], out_b.shape[1], self.batch,
                                out_b.ptr, out_a.ptr)
+        elif factor.n_prev:
+            # the same towards a sign / abs likelihood: its input message is the one this channel writes
+            hint = self._lik_hint(i_out, out_b.shape[1])
+            if hint is not None:
+                self.ctx._call("tramp_lik_hint", hint[0], out_b.shape[1], self.batch, out_b.ptr, out_a.ptr, hint[1])
         if factor.n_prev == 0:
             factor.compute_forward_message(self.a_bwd[i_out], self.b_bwd[i_out], **kw)
         elif factor.n_next == 0:
@@ -540,6 +545,13 @@ class ExpectationPropagation:
             return None                 # the stored message lives in a rotated basis
         f = self.model.prev_factor(self.variables[i])
         return f.moment_hint() if f.n_prev == 0 and hasattr(f, "moment_hint") else None
+
+    def _lik_hint(self, i, n):
+        "the likelihood that consumes the forward message into variable i, if it can use fused moments"
+        if i in self._rot:
+            return None
+        f = self.model.next_factor(self.variables[i])
+        return f.lik_hint(self.batch, n) if f is not None and f.n_next == 0 and hasattr(f, "lik_hint") else None
 
     def forward_message(self):
         "message_passing.py:249-255"

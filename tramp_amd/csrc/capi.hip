@@ -228,7 +228,7 @@ bool prior_hint_arm(tramp_ctx* ctx, const void* out_buf, size_t len, size_t batc
     h.nblk = nblk;
     h.ready = true;
     ctx->hint_armed += 1;
-    *dev = PriorHintDev{h.kind, h.p0, h.p1, h.p2, h.a_msg, h.partials, nblk};
+    *dev = PriorHintDev{h.kind, h.p0, h.p1, h.p2, h.a_msg, h.partials, nblk, h.y, h.n};
     return true;
 }
 

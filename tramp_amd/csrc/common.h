@@ -32,6 +32,7 @@ struct TrampPriorHint {
     double p0, p1, p2;
     const void* buf;          // the message buffer b the prior will read
     const double* a_msg;      // its precision array
+    const void* y;            // likelihood kinds: the observation array the consumer will be called with
     size_t n, batch;
     double* partials;         // owned by the context (hint_ws)
     int nblk;                 // set by the producer

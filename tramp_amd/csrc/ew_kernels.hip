@@ -904,6 +904,31 @@ extern "C" int tramp_prior_hint(tramp_ctx* ctx, int kind, double p0, double p1, 
     h.kind = kind;
     h.buf = b_d;
     h.a_msg = a_d;
+    h.y = nullptr;
+    h.n = n;
+    h.batch = batch;
+    h.partials = nullptr;
+    h.nblk = 0;
+    return TRAMP_OK;
+}
+
+// The likelihood twin: "the message (a_d, b_d) I am about to write feeds tramp_sgn_lik_bwd / tramp_abs_lik_bwd with
+// the observation y_d".  kind: PRIOR_HINT_SGN_LIK (3) or PRIOR_HINT_ABS_LIK (4); 0 clears.
+extern "C" int tramp_lik_hint(tramp_ctx* ctx, int kind, size_t n, size_t batch, const void* b_d, const double* a_d,
+                              const void* y_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    ctx->hint.kind = PRIOR_HINT_NONE;
+    ctx->hint.ready = false;
+    if (kind == PRIOR_HINT_NONE) return TRAMP_OK;
+    TRAMP_REQUIRE(ctx, (kind == PRIOR_HINT_SGN_LIK || kind == PRIOR_HINT_ABS_LIK) && b_d && a_d && y_d && n > 0 && batch > 0);
+    static const size_t fuse_env = getenv("TRAMP_PRIOR_FUSE") ? (size_t)atol(getenv("TRAMP_PRIOR_FUSE")) : 1;
+    if (!fuse_env) return TRAMP_OK;
+    TrampPriorHint& h = ctx->hint;
+    h.kind = kind;
+    h.p0 = h.p1 = h.p2 = 0.0;
+    h.buf = b_d;
+    h.a_msg = a_d;
+    h.y = y_d;
     h.n = n;
     h.batch = batch;
     h.partials = nullptr;
@@ -914,13 +939,13 @@ extern "C" int tramp_prior_hint(tramp_ctx* ctx, int kind, double p0, double p1, 
 // The hint is consumed by the first prior call after it, whether it matches or not.
 static const TrampPriorHint* take_hint(tramp_ctx* ctx, TrampPriorHint* copy, int kind, double p0, double p1,
                                        double p2, size_t n, size_t batch, const void* b_d, const double* a_d,
-                                       const MsgOut& out) {
+                                       const MsgOut& out, const void* y_d = nullptr) {
     *copy = ctx->hint;
     ctx->hint.kind = PRIOR_HINT_NONE;
     ctx->hint.ready = false;
     const bool ok = copy->ready && copy->kind == kind && copy->p0 == p0 && copy->p1 == p1 && copy->p2 == p2 &&
                     copy->n == n && copy->batch == batch && copy->buf == b_d && copy->a_msg == a_d &&
-                    copy->partials && copy->nblk > 0 && !out.count && !out.mask;
+                    copy->y == y_d && copy->partials && copy->nblk > 0 && !out.count && !out.mask;
     return ok ? copy : nullptr;
 }
 
@@ -978,10 +1003,12 @@ extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, az_d);
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    TrampPriorHint hc;
+    const TrampPriorHint* hint = take_hint(ctx, &hc, PRIOR_HINT_SGN_LIK, 0.0, 0.0, 0.0, n, batch, bz_d, az_d, out, y_d);
     SgnLikOp<float> of{az_d};
     SgnLikOp<double> od{az_d};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out, hint)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out, hint)));
 }
 
 extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
@@ -991,10 +1018,12 @@ extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, az_d);
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    TrampPriorHint hc;
+    const TrampPriorHint* hint = take_hint(ctx, &hc, PRIOR_HINT_ABS_LIK, 0.0, 0.0, 0.0, n, batch, bz_d, az_d, out, y_d);
     AbsLikOp<float> of{az_d};
     AbsLikOp<double> od{az_d};
-    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
-                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out, hint)),
+                   (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out, hint)));
 }
 
 extern "C" int tramp_relu_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double slope_neg,

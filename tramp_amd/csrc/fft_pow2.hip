@@ -221,7 +221,7 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
             }
             bo[i] = bn;
             if (ro) ro[i] = r;
-            if (epi.hint.kind) vi += he.v(bn.x) + he.v(bn.y);
+            if (epi.hint.kind) vi += he.v(bn.x, 2 * i) + he.v(bn.y, 2 * i + 1);
         }
         if (epi.hint.kind) {
             // sum over the workgroup (up to 16 waves; the tile's LDS is free again after the barrier)
@@ -463,7 +463,8 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
         (void)hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done[slot] = true;
     }
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024)
+    // (the epilogue kernel also carries the 2 KiB erfcx table of a sign-likelihood consumer, prior_hint.h)
+    if (lds1 + 4096 > 160 * 1024 || lds2 > 160 * 1024)
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "transform too long for the LDS tile");
     if (!inverse) {
         hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh, (const C*)in,

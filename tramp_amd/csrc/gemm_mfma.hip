@@ -745,7 +745,7 @@ __global__ __launch_bounds__(kBlock) void mfma_fold_kernel(size_t len, size_t B,
         double s = 0.0;
         for (int k = 0; k < nsplit; ++k) s += partials[((size_t)k * B + b) * len + idx];
         const T bn = mfma_epilogue<T>(epi, b, idx, len, s);
-        if (epi.hint.kind) vi = he.v(bn);
+        if (epi.hint.kind) vi = he.v(bn, idx);
     }
     if (epi.hint.kind) {
         vi = block_sum(vi, smem);

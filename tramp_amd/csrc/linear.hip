@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void nn_fold_kernel(size_t C, int nb, int n
         double s = 0.0;
         for (int k = 0; k < nchunk; ++k) s += partials[((size_t)k * nb + b) * C + c];
         const T bn = lin_epilogue<T>(epi, b0 + b, c, C, s);
-        if (epi.hint.kind) vi = he.v(bn);
+        if (epi.hint.kind) vi = he.v(bn, c);
     }
     if (epi.hint.kind) {                       // uniform across the block
         vi = block_sum(vi, smem);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void lin_epi_apply_kernel(size_t len, const
     if (epi.hint.kind) he.setup(epi.hint, b);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
         const T bn = lin_epilogue<T>(epi, b, i, len, (double)w[b * len + i]);
-        if (epi.hint.kind) vi += he.v(bn);
+        if (epi.hint.kind) vi += he.v(bn, i);
     }
     if (epi.hint.kind) {
         vi = block_sum(vi, smem);

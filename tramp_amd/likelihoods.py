@@ -57,6 +57,16 @@ class Likelihood(Factor):
                   r.ptr if r is not None else None, v.ptr if v is not None else None)
         return a, b, a_new, b_new, r, v
 
+    _lik_hint_kind = None
+
+    def lik_hint(self, batch, n):
+        """(kind, y device array) for tramp_lik_hint: the producer of this likelihood's input message can leave
+        sum v_i (csrc/prior_hint.h), or None"""
+        yd = self._y_dev
+        if self._lik_hint_kind is None or not self.isotropic or yd is None or yd.shape != (batch, n):
+            return None
+        return self._lik_hint_kind, yd
+
     def compute_backward_message(self, az, bz, **kw):
         "Likelihood.compute_backward_message (base_likelihood.py:25-28)"
         if not self.isotropic:
@@ -160,6 +170,7 @@ class SgnLikelihood(Likelihood):
     "tramp/likelihoods/sgn_likelihood.py:9-98 (K4)"
     _kernel_name = "tramp_sgn_lik_bwd"
     _diag_which = _lib.DIAG_SGN_LIK
+    _lik_hint_kind = 3          # csrc/prior_hint.h PRIOR_HINT_SGN_LIK
 
     def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
         self.y_name = y_name
@@ -188,6 +199,7 @@ class AbsLikelihood(Likelihood):
     "tramp/likelihoods/abs_likelihood.py:8-72 (K5)"
     _kernel_name = "tramp_abs_lik_bwd"
     _diag_which = _lib.DIAG_ABS_LIK
+    _lik_hint_kind = 4          # PRIOR_HINT_ABS_LIK
 
     def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
         self.y_name = y_name
