@@ -28,18 +28,39 @@ def build(T, ctx, c, dtype):
     return cls(y=c["y"], isotropic=False, dtype=dtype, ctx=ctx, **kw)
 
 
-def close(x, ref, dtype, atol):
-    np.testing.assert_allclose(np.asarray(x, dtype=np.float64), ref, rtol=RTOL[dtype], atol=atol, equal_nan=True)
+def close(x, ref, dtype, atol, what):
+    x, ref = np.asarray(x, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert x.shape == ref.shape, what
+    assert np.array_equal(np.isnan(x), np.isnan(ref)), what
+    err = np.abs(x - ref)
+    lim = RTOL[dtype] * np.abs(ref) + atol
+    bad = ~(err <= lim) & ~np.isnan(ref)
+    assert not bad.any(), (what, int(bad.sum()), "worst at", int(np.nanargmax(err - lim)),
+                           x.ravel()[np.nanargmax(err - lim)], ref.ravel()[np.nanargmax(err - lim)])
+
+
+def v_scale(c):
+    """the magnitude the component variance is a DIFFERENCE of (so that eps of it is the rounding floor of v, whoever
+    evaluates the formula): abs likelihood y^2 (1 - tanh^2), binary prior 1 - tanh^2, truncated normals v0 (1 - ...)"""
+    a, n = c["a"], c["name"]
+    if c["family"] == "likelihood" and n == "abs":
+        return c["y"] ** 2 + 0 * a
+    if c["family"] == "prior" and n == "binary":
+        return 1.0 + 0 * a
+    if c["family"] == "likelihood" and n not in ("gaussian",):
+        return 1.0 / a + np.abs(c["v"])
+    return np.abs(c["v"])
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_diagonal_beliefs_match_reference_and_oracle(ctx, golden_diag, dtype):
     import tramp_amd as T
     seen = set()
+    k = 400 * EPS[dtype]
     for c in golden_diag:
         if dtype == np.float32 and c["inputs"] == "edge":
             continue                                   # precisions of 1e-12 .. 1e12 next to b of 1e11: outside f32 by construction
-        tag = (c["family"], c["name"], c["inputs"], c["kwargs"])
+        tag = (c["family"], c["name"], c["inputs"], c["kwargs"], np.dtype(dtype).name)
         f = build(T, ctx, c, dtype)
         assert not f.isotropic
         a, b = c["a"], c["b"]
@@ -53,20 +74,22 @@ def test_diagonal_beliefs_match_reference_and_oracle(ctx, golden_diag, dtype):
         with np.errstate(all="ignore"):
             r_o, v_o = diag_oracle_posterior(orc, c)
         v_o = np.broadcast_to(v_o, b.shape)
-        k = 200 * EPS[dtype]
-        for ref_r, ref_v in ((c["r"], c["v"]), (r_o, v_o)):
-            close(r, ref_r, dtype, k * np.nanmax(np.abs(ref_r)))
-            close(v, ref_v, dtype, k * np.nanmax(np.abs(ref_v)) + (1e-6 * np.nanmax(np.abs(ref_v)) if dtype == np.float32 else 0))
+        dv = k * v_scale(c)                                                  # rounding floor of v, per component
+        for src, ref_r, ref_v in (("reference", c["r"], c["v"]), ("oracle", r_o, v_o)):
+            close(r, ref_r, dtype, k * (np.abs(ref_r) + np.sqrt(1.0 / a)), tag + (src, "r"))
+            close(v, ref_v, dtype, dv, tag + (src, "v"))
         if c["name"] == "gaussian":                                          # constant messages, whatever comes in
             np.testing.assert_allclose(a_new, c["a_new"], rtol=1e-6 if dtype == np.float32 else 1e-14)
             np.testing.assert_allclose(b_new, c["b_new"], rtol=1e-6 if dtype == np.float32 else 1e-14, atol=1e-300)
         else:
-            # a_new = clip(1/v - a): conditioned on 1/v = a + a_new; b_new = r (a + a_new) - b on |r| (a + a_new) + |b|
-            cond_a = np.abs(a) + np.abs(c["a_new"])
-            tol_v = RTOL[dtype] if dtype == np.float32 else 1e-11      # relative error of v feeds 1/v
-            close(a_new, c["a_new"], dtype, cond_a * (tol_v + 64 * EPS[dtype]))
-            cond_b = np.abs(c["r"]) * cond_a + np.abs(b)
-            close(b_new, c["b_new"], dtype, np.nan_to_num(cond_b, nan=0.0) * (tol_v + 1e3 * EPS[dtype]) + 1e-300)
+            # a_new = clip(1/v - a): an error dv of v is dv / v^2 of 1/v; b_new = r (a + a_new) - b
+            with np.errstate(all="ignore"):
+                da = (dv + RTOL[dtype] * np.abs(c["v"]) * (dtype == np.float32)) / np.maximum(c["v"], 1e-20) ** 2
+                da = np.nan_to_num(np.minimum(da, 2e11), nan=0.0) + k * (np.abs(a) + np.abs(c["a_new"]))
+            close(a_new, c["a_new"], dtype, da, tag + ("a_new",))
+            cond_b = np.nan_to_num(np.abs(c["r"]) * (np.abs(a) + np.abs(c["a_new"])) + np.abs(b), nan=0.0)
+            close(b_new, c["b_new"], dtype, np.nan_to_num(np.abs(c["r"]), nan=0.0) * da + (k + RTOL[dtype] * (dtype == np.float32)) * cond_b + 1e-300,
+                  tag + ("b_new",))
         if getattr(f, "_logz_kind", None) is not None or c["family"] == "prior" and c["name"] != "binary":
             A = f.compute_log_partition(a, b) if c["family"] == "prior" else f.compute_log_partition(a, b, c["y"])
             assert isinstance(A, float)

@@ -456,11 +456,18 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
                                  : reinterpret_cast<const void*>(fft_strided_kernel<T, false>);
         const void* f2 = inverse ? reinterpret_cast<const void*>(fft_block_kernel<T, true>)
                                  : reinterpret_cast<const void*>(fft_block_kernel<T, false>);
-        if (inverse)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fft_strided_kernel<T, true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // dynamic LDS up to the CU's 160 KiB minus what the kernel declares statically (the epilogue kernel
+        // carries the erfcx table of a sign-likelihood consumer): asking for more fails with "invalid argument"
+        auto allow = [](const void* f) {
+            hipFuncAttributes fa{};
+            size_t stat = 0;
+            if (hipFuncGetAttributes(&fa, f) == hipSuccess) stat = fa.sharedSizeBytes;
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - stat)) != hipSuccess)
+                (void)hipGetLastError();
+        };
+        if (inverse) allow(reinterpret_cast<const void*>(fft_strided_kernel<T, true, true>));
+        allow(f1);
+        allow(f2);
         attr_done[slot] = true;
     }
     // (the epilogue kernel also carries the 2 KiB erfcx table of a sign-likelihood consumer, prior_hint.h)
