@@ -719,11 +719,10 @@ static size_t env_size(const char* name, size_t dflt) {
 
 // Streaming-tile realisation of one update.  `hint` != nullptr: a producer left sum v_i partials for
 // this very message (prior_hint.h): no pass 1, the message is read once.
-template <typename T, typename Op>
-static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
-                     const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
+template <typename T, typename Op, int U>
+static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
+                       const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
     constexpr int VN = Vec<T>::N;
-    constexpr int U = kTileU;          // 1 and 4 measured for the heavy ops (K4/K5/K7): within 4% of 2
     const size_t nv = n / VN;
     const size_t tiles = (nv + (size_t)kBlock * U - 1) / ((size_t)kBlock * U);
     // consecutive tiles per block: enough blocks to fill the chip several times over, setup amortised
@@ -785,6 +784,19 @@ static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* 
     }
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
+}
+
+template <typename T, typename Op>
+static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
+                     const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
+    // pieces per thread and tile: 1 and 4 measured for the heavy ops (K4/K5/K7): within 4% of 2.  The light ops
+    // (Gauss-Bernoulli, L1, abs likelihood: recomputed in the apply pass) also exist with one piece per thread
+    // (TRAMP_EW_U=1; tools/probes/probe_copy.hip: the flat one-piece copy streams 6 % faster than the U = 2 tile)
+    static const size_t u_env = env_size("TRAMP_EW_U", kTileU);
+    if constexpr (!Op::HEAVY) {
+        if (u_env == 1) return run_tiles_u<T, Op, 1>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
+    }
+    return run_tiles_u<T, Op, kTileU>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
 }
 
 template <typename T, typename Op>

@@ -120,7 +120,12 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = A{0, 0, 0, 0};
 
-    V m[RT][kPieces], mn[RT][kPieces], xg[kPieces];
+    // Two register sets for the matrix pieces, used alternately (the k loop is unrolled by two): the loads of step
+    // s + 1 are issued before the barrier of step s and first READ after the barrier of step s + 1, a whole MFMA
+    // block (64 MFMAs) later.  With one set copied into the other mid-block (the earlier form) the compiler had to
+    // wait for those loads a few MFMAs after issuing them: every wave sat in s_waitcnt for an HBM round trip per
+    // k step (profiles/r02/pmc_wave_waits_matrix_passes_B64.txt: 17-24 % of the wave cycles).
+    V ma[RT][kPieces], mb[RT][kPieces], xg[kPieces];
     // only the last k step of the whole contraction can be ragged: every other step loads unguarded
     // (the guard is a wave-uniform branch, not a per-lane select on every load)
     auto load_step = [&](auto guarded, size_t k, V (&dst)[RT][kPieces]) {
@@ -130,24 +135,26 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
                 dst[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k + p * 4 * E) : vzero;
-            if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k + p * 4 * E) : vzero;
+            xg[p] = in ? *reinterpret_cast<const V*>(xp + k + p * 4 * E) : vzero;      // every wave (clamped row): no branch
         }
     };
-    if (sbeg < send) {
-        if (TAIL && sbeg + 1 == nsteps_total) load_step(std::true_type{}, sbeg * KS, m);
-        else load_step(std::false_type{}, sbeg * KS, m);
-    }
-    for (size_t s = sbeg; s < send; ++s) {
-        const int st = (int)((s - sbeg) & 1);
-        if (loads_x) {
+    // Every call issues the same number of loads on every path - past the end of the split the last step is
+    // simply loaded again - and nothing is under a wave-dependent branch: the compiler's s_waitcnt vmcnt(N) is
+    // a static count that has to be right for EVERY path into the MFMA block, so a path with fewer loads in
+    // flight (last iteration, a wave that stages no x) forces a small N, which in the steady state waits for
+    // loads that were issued a moment ago.
+    auto load_any = [&](size_t s, V (&dst)[RT][kPieces]) {
+        const size_t sc = s < send ? s : send - 1;
+        if (TAIL && sc + 1 == nsteps_total) load_step(std::true_type{}, sc * KS, dst);
+        else load_step(std::false_type{}, sc * KS, dst);
+    };
+    auto stage_x = [&](int st) {
+        if (BT == 4 || loads_x) {
 #pragma unroll
             for (int p = 0; p < kPieces; ++p) xs[st][wave][p][lane] = xg[p];
         }
-        if (s + 1 < send) {
-            if (TAIL && s + 2 == nsteps_total) load_step(std::true_type{}, (s + 1) * KS, mn);
-            else load_step(std::false_type{}, (s + 1) * KS, mn);
-        }
-        __syncthreads();
+    };
+    auto mfma_block = [&](int st, const V (&m)[RT][kPieces]) {
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) {
 #pragma unroll
@@ -159,10 +166,23 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
                     for (int rt = 0; rt < RT; ++rt) acc[rt][bt] = Mx<T>::mfma(a[e], m[rt][p][e], acc[rt][bt]);
             }
         }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) m[rt][p] = mn[rt][p];
+    };
+    size_t s = sbeg;
+    if (s < send) load_any(s, ma);
+    for (; s + 1 < send; s += 2) {                 // pairs of k steps
+        stage_x(0);
+        load_any(s + 1, mb);
+        __syncthreads();
+        mfma_block(0, ma);
+        stage_x(1);
+        load_any(s + 2, ma);
+        __syncthreads();
+        mfma_block(1, mb);
+    }
+    if (s < send) {                                // odd step count: the last one
+        stage_x(0);
+        __syncthreads();
+        mfma_block(0, ma);
     }
     // D[row = drow(l>>4, reg)][col = l&15]: row -> instance, col -> mat row
     double* pout = partials + (split * B) * R;
@@ -222,34 +242,29 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) acc[nt][bt] = A{0, 0, 0, 0};
 
-    V m[S], mn[S], xg[kPieces];
-    // as in the NT kernel: only the contraction's last step is loaded under guards
+    V ma[S], mb[S], xg[kPieces];        // two alternating register sets, as in the NT kernel
+    // only the contraction's last step is loaded under guards
     auto load_step = [&](auto guarded, size_t k, V (&dst)[S]) {
         constexpr bool G = decltype(guarded)::value;
 #pragma unroll
         for (int s4 = 0; s4 < S; ++s4)
             dst[s4] = (!G || k + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k + s4) * C) : vzero;
-        if (loads_x) {
 #pragma unroll
-            for (int p = 0; p < kPieces; ++p)
-                xg[p] = (!G || k + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k + p * E) : vzero;
-        }
+        for (int p = 0; p < kPieces; ++p)
+            xg[p] = (!G || k + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k + p * E) : vzero;
     };
-    if (sbeg < send) {
-        if (TAIL && sbeg + 1 == nsteps_total) load_step(std::true_type{}, sbeg * KS, m);
-        else load_step(std::false_type{}, sbeg * KS, m);
-    }
-    for (size_t s = sbeg; s < send; ++s) {
-        const int st = (int)((s - sbeg) & 1);
-        if (loads_x) {
+    auto load_any = [&](size_t s, V (&dst)[S]) {           // same loads on every path, as in the NT kernel
+        const size_t sc = s < send ? s : send - 1;
+        if (TAIL && sc + 1 == nsteps_total) load_step(std::true_type{}, sc * KS, dst);
+        else load_step(std::false_type{}, sc * KS, dst);
+    };
+    auto stage_x = [&](int st) {
+        if (BT == 4 || loads_x) {
 #pragma unroll
             for (int p = 0; p < kPieces; ++p) xs[st][wave][p][lane] = xg[p];
         }
-        if (s + 1 < send) {
-            if (TAIL && s + 2 == nsteps_total) load_step(std::true_type{}, (s + 1) * KS, mn);
-            else load_step(std::false_type{}, (s + 1) * KS, mn);
-        }
-        __syncthreads();
+    };
+    auto mfma_block = [&](int st, const V (&m)[S]) {
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) {
 #pragma unroll
@@ -262,8 +277,23 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
                         acc[nt][bt] = Mx<T>::mfma(a[e], m[p * E + e][nt], acc[nt][bt]);
             }
         }
-#pragma unroll
-        for (int s4 = 0; s4 < S; ++s4) m[s4] = mn[s4];
+    };
+    size_t s = sbeg;
+    if (s < send) load_any(s, ma);
+    for (; s + 1 < send; s += 2) {                 // pairs of k steps
+        stage_x(0);
+        load_any(s + 1, mb);
+        __syncthreads();
+        mfma_block(0, ma);
+        stage_x(1);
+        load_any(s + 2, ma);
+        __syncthreads();
+        mfma_block(1, mb);
+    }
+    if (s < send) {                                // odd step count: the last one
+        stage_x(0);
+        __syncthreads();
+        mfma_block(0, ma);
     }
     double* pout = partials + (split * B) * C;
     const size_t c = col0 + E * j;

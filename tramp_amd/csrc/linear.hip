@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void gemv_nt_kernel(size_t R, size_t C, int
     const int lane = threadIdx.x & 63;
     const size_t wave = (size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const size_t r0 = wave * ROWS;
-    if (r0 >= R) return;
+    if (!epi.hint.kind && r0 >= R) return;          // with fused moments every wave reaches the block reduction
     T acc[ROWS][NB];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i)
@@ -153,13 +153,42 @@ __global__ __launch_bounds__(kBlock) void gemv_nt_kernel(size_t R, size_t C, int
             }
         }
     }
+    if (!epi.hint.kind) {
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i)
+        for (int i = 0; i < ROWS; ++i)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NB; ++b) {
+                double s = wave_sum((double)acc[i][b]);
+                if (lane == 0 && b < nb && r0 + i < R) lin_epilogue<T>(epi, b0 + b, r0 + i, R, s);
+            }
+        return;
+    }
+    // producer-fused moments (prior_hint.h): lane 0 of each wave evaluates v_i of the consumer on the ROWS values it
+    // stores, the block leaves one partial per instance
+    __shared__ double hsm[kBlock / kWave];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b >= nb) break;                                   // uniform
+        PriorHintEval<T> he;
+        he.setup(epi.hint, b0 + b);                           // all threads (may stage the erfcx table: a barrier)
+        double vi = 0.0;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
             double s = wave_sum((double)acc[i][b]);
-            if (lane == 0 && b < nb && r0 + i < R) lin_epilogue<T>(epi, b0 + b, r0 + i, R, s);
+            if (lane == 0 && r0 + i < R) {
+                const T bn = lin_epilogue<T>(epi, b0 + b, r0 + i, R, s);
+                vi += he.v(bn, r0 + i);
+            }
         }
+        __syncthreads();
+        if (lane == 0) hsm[threadIdx.x >> 6] = vi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kBlock / kWave; ++w) t += hsm[w];
+            epi.hint.partials[(b0 + b) * (size_t)epi.hint.nblk + blockIdx.x] = t;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- NN: column accumulation
@@ -294,6 +323,7 @@ int matvec_valu(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch, const
     LinEpi epi = epi_in;
     epi.hint.kind = PRIOR_HINT_NONE;
     if (!nt) lin_arm_hint(ctx, epi, C, batch, (int)((C + kBlock - 1) / kBlock));   // nn_fold_kernel's grid
+    else if (batch <= 4) lin_arm_hint(ctx, epi, R, batch, (int)(((R + 3) / 4 + 3) / 4));   // gemv_nt_kernel's grid (ROWS = 4)
     for (size_t b0 = 0; b0 < batch; b0 += TRAMP_GEMV_MAX_BATCH) {
         const int nb = (int)((batch - b0 < TRAMP_GEMV_MAX_BATCH) ? batch - b0 : TRAMP_GEMV_MAX_BATCH);
         int rc = TRAMP_OK;
