@@ -766,19 +766,25 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
         }
         // outputs past the Infinity Cache are streamed around the caches (+6 % on the box's copy rate)
         const bool nts = (double)n * (double)batch * sizeof(T) > 192.0 * 1024 * 1024;
+        // the apply pass of the light ops has next to no per-block setup to amortise: shorter runs per block
+        // stream faster (fused Gauss-Bernoulli / L1 update at 64 x 1e6: 173 / 180 us with 2 tiles per block
+        // against 192 / 190 with 8; gpurun_out/r03/fused1.log)
+        static const size_t tpb_apply_env = env_size("TRAMP_EW_TPB_APPLY", 0);
+        int tpa = tpb_apply_env ? (int)tpb_apply_env : (Op::HEAVY ? tpb : (tpb > 2 ? 2 : tpb));
+        dim3 grid_a((unsigned)((tiles + tpa - 1) / tpa), nb);
         if (store_r) {
             if (nts)
-                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, true>), grid, block, 0, ctx->stream, op, n, inst0, tpb,
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, true>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
                                    p0, p1, rbuf + inst0 * n, scal + inst0, o);
             else
-                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, false>), grid, block, 0, ctx->stream, op, n, inst0,
-                                   tpb, p0, p1, rbuf + inst0 * n, scal + inst0, o);
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, false>), grid_a, block, 0, ctx->stream, op, n, inst0,
+                                   tpa, p0, p1, rbuf + inst0 * n, scal + inst0, o);
         } else {
             if (nts)
-                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, true>), grid, block, 0, ctx->stream, op, n, inst0, tpb,
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, true>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
                                    p0, p1, (const T*)nullptr, scal + inst0, o);
             else
-                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, false>), grid, block, 0, ctx->stream, op, n, inst0, tpb,
+                hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, false>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
                                    p0, p1, (const T*)nullptr, scal + inst0, o);
         }
     }

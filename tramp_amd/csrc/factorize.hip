@@ -35,6 +35,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include <vector>
 
@@ -230,6 +231,18 @@ struct Fz {
         (void)hipStreamSynchronize(ctx->stream);
         for (void* p : owned) (void)hipFree(p);
         owned.clear();
+    }
+    // TRAMP_EIG_VERBOSE=1: wall time of each phase of the setup path on stderr (synchronises the stream)
+    double t_last = 0.0;
+    void tick(const char* what, size_t n = 0) {
+        static const bool on = getenv("TRAMP_EIG_VERBOSE") != nullptr;
+        if (!on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double now = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+        if (t_last > 0.0) fprintf(stderr, "[tramp factorize] %-28s n=%-6zu %8.3f s\n", what, n, now - t_last);
+        t_last = now;
     }
 };
 
@@ -483,6 +496,7 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
     double l_pred = 1e-8;
     const double tol = 1e-13 * (double)n + 1e-12;
     bool converged = false;
+    fz.tick("split: scale", n);
     for (int it = 0; it < 60; ++it) {
         // Z0 = X X^T (upper), e = |Z0 - I|_F
         FZ_OK(bsyrk_upper(fz, rocblas_operation_none, n, n, 1.0, X, n, 0.0, Z, n));
@@ -512,6 +526,7 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
         hipLaunchKernelGGL(axpby_inplace, dim3(kRedBlocks), dim3(kBlock), 0, st, X, Y, nn, b / c, a - b / c);
         const unsigned nt = (unsigned)((n + 31) / 32);
         hipLaunchKernelGGL(symmetrize_tiles, dim3(nt, nt), dim3(kBlock), 0, st, X, n, 1);
+        fz.tick("split: sign iteration", n);
     }
     if (!converged) return fz.fail(TRAMP_EHIP, "factorize", "matrix sign iteration did not converge");
 
@@ -535,6 +550,7 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
     FZ_HIP(fz, hipMemcpy2DAsync(Z, q * sizeof(double), X + r + r * n, n * sizeof(double), q * sizeof(double), q,
                                 hipMemcpyDeviceToDevice, st));
     FZ_OK(cholqr2(fz, V2, n, q, n, Z, true));
+    fz.tick("split: projector bases", n);
     // B1 = V1^T A V1 (r x r), B2 = V2^T A V2 (q x q), both in Z
     double* B1 = Z;
     double* B2 = Z + r * r;
@@ -543,11 +559,13 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
     FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, q, n, 1.0, A, n, V2, n, 0.0, Y, n));
     FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, q, q, n, 1.0, V2, n, Y, n, 0.0, B2, q));
     fz.release(Y);
+    fz.tick("split: project A on bases", n);
     // below sigma first (ascending order)
     FZ_OK(eigh_rec(fz, B2, q, w_d, depth + 1));
     FZ_OK(eigh_rec(fz, B1, r, w_d + q, depth + 1));
     FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, q, q, 1.0, V2, n, B2, q, 0.0, A, n));
     FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, r, r, 1.0, V1, n, B1, r, 0.0, A + q * n, n));
+    fz.tick("split: rotate back", n);
     fz.release(X);
     fz.release(Z);
     fz.release(dg);
@@ -564,6 +582,7 @@ int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth) {
                                    (rocblas_int)n, w_d, E, fz.info_d));
         FZ_OK(check_info(fz, "rocsolver_dsyevd"));
         fz.release(E);
+        fz.tick("rocsolver syevd", n);
         return TRAMP_OK;
     }
     if (depth > 8) return fz.fail(TRAMP_ENOTSUP, "factorize", "spectral divide and conquer recursed too deep");
@@ -589,11 +608,13 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
     double* G = fz.alloc(k * k);
     double* D = fz.alloc(k);
     if (!G || !D) return fz.rc;
+    fz.tick("start", k);
     // row-major W [M,N] is the column-major matrix A = W^T [N,M], lda = N
     if (M <= N)
         FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, M, N, 1.0, W64, N, 0.0, G, M));   // A^T A = W W^T
     else
         FZ_OK(bsyrk_upper(fz, rocblas_operation_none, N, M, 1.0, W64, N, 0.0, G, N));        // A A^T = W^T W
+    fz.tick("gram matrix", k);
     FZ_OK(eigh_rec(fz, G, k, D, 0));
     hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D, k, sing_d, 1.0);
     // the thin factor on the long side, rows/columns still carrying their singular value
@@ -606,6 +627,7 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
         // Uk_cm^T: C_cm [k,M] = X^T [k,N] * A [N,M], X_cm [N,k] = Vt memory (lda = N)
         FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, k, M, N, 1.0, V64, N, W64, N, 0.0, U64, k));
     }
+    fz.tick("long-side factor (gemm)", k);
     std::vector<double> sh(k);
     FZ_HIP(fz, hipMemcpyAsync(sh.data(), sing_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
     FZ_HIP(fz, hipStreamSynchronize(st));

@@ -840,7 +840,7 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     static const int split_env = getenv("TRAMP_MFMA_SPLIT") ? atoi(getenv("TRAMP_MFMA_SPLIT")) : 0;
     static const int pad_env = getenv("TRAMP_MFMA_LDS_PAD") ? atoi(getenv("TRAMP_MFMA_LDS_PAD")) : 0;
     const unsigned nchunk0 = (unsigned)((batch + 63) / 64);
-    static const int rt_probe = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 4;
+    static const int rt_probe = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 2;
     const size_t rows_per_wg = 64 * (size_t)(rt_probe == 1 ? 1 : (rt_probe == 4 ? 4 : 2));
     const size_t nblocks = nt ? (R + rows_per_wg - 1) / rows_per_wg : (C + 64 * E - 1) / (64 * E);
     const unsigned nsplit = (unsigned)pick_split(ctx, nt, nblocks, nchunk0, nsteps, split_env);
@@ -912,7 +912,10 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
         }
     }
     if (nt) {
-        static const int rt_env = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 4;   // measured: 54 (RT=4) vs 51 (RT=2) TFLOP/s in f64
+        // 16-row tiles per wave.  Round 3, with the alternating register sets: RT = 2 (160 VGPRs, 3 waves per SIMD)
+        // 56.1 TFLOP/s against 53.4 for RT = 4 (256 VGPRs, 2 waves) on the 50000 x 100000 x 64 f64 pass; before
+        // (loads waited for inside the MFMA block) it was the other way round, 51 against 54.
+        static const int rt_env = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 2;
         if (rt_env == 4) {
             constexpr int RT = 4;
             const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
@@ -927,7 +930,8 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
         } else {
             constexpr int RT = 2;
             const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid((unsigned)(nrb * nsplit), nchunk);
+            dim3 grid = chunk_grid(nrb * nsplit, nchunk);
+            ctx->last_flat = nchunk > 1 && grid.y == 1;
             if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
         }
     } else {
