@@ -181,6 +181,40 @@ __global__ void symmetrize_tiles(double* __restrict__ X, size_t n, int mode) {
 }
 
 // columns [0, r) <- (X + I)/2, columns [r, n) <- (I - X)/2 : the two spectral projectors side by side
+// y = X v for a symmetric X in FULL column-major storage: y_j = <column j, v>; one wave per column, 16-byte loads
+__global__ __launch_bounds__(kBlock) void symv_full(const double* __restrict__ X, size_t n, const double* __restrict__ v,
+                                                    double* __restrict__ y) {
+    const size_t j = (size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const int lane = threadIdx.x & 63;
+    const double* col = X + j * n;
+    double acc = 0.0;
+    if ((n & 1) == 0) {
+        const size_t nv = n / 2;
+        for (size_t i = lane; i < nv; i += 64) {
+            const double2 a = reinterpret_cast<const double2*>(col)[i];
+            const double2 b = reinterpret_cast<const double2*>(v)[i];
+            acc += a.x * b.x + a.y * b.y;
+        }
+    } else {
+        for (size_t i = lane; i < n; i += 64) acc += col[i] * v[i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[j] = acc;
+}
+__global__ void vec_scale_copy(const double* __restrict__ src, size_t n, double s, double* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] = s * src[i];
+}
+__global__ void vec_init(double* __restrict__ v, size_t n) {      // a fixed, unstructured start vector
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull;
+        z ^= z >> 31;
+        z *= 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 29;
+        v[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+
 __global__ void sign_to_projectors(double* __restrict__ X, size_t n, size_t r) {
     const size_t total = n * n;
     for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
@@ -200,6 +234,7 @@ struct Fz {
     rocblas_int* info_d;
     double* part_d;              // kRedBlocks partial sums
     size_t eig_cap;              // largest n handed to rocSOLVER's syevd
+    size_t sub_cap;              // ... inside a split (depth >= 1)
     int rc;
     std::vector<void*> owned;
     int fail(int code, const char* what, const char* detail) {
@@ -436,6 +471,33 @@ void halley_weights(double l, double* a, double* b, double* c) {
     *c = *a + *b - 1.0;
 }
 
+// |X|_2 of a symmetric X (full storage) by power iteration: an estimate from BELOW (Rayleigh quotients), `iters`
+// passes over the matrix (n^2 doubles each - milliseconds next to the n^3 steps it scales)
+int norm2_power(Fz& fz, const double* X, size_t n, int iters, double* out) {
+    hipStream_t st = fz.ctx->stream;
+    double* v = fz.alloc(n);
+    double* y = fz.alloc(n);
+    if (!v || !y) return fz.rc;
+    hipLaunchKernelGGL(vec_init, dim3(nblk(n)), dim3(kBlock), 0, st, v, n);
+    double est = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(symv_full, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, X, n, v, y);
+        hipLaunchKernelGGL(sumsq_partials, dim3(kRedBlocks), dim3(kBlock), 0, st, y, n, fz.part_d);
+        double yy = 0.0;
+        FZ_OK(reduce_partials(fz, &yy));
+        hipLaunchKernelGGL(sumsq_partials, dim3(kRedBlocks), dim3(kBlock), 0, st, v, n, fz.part_d);
+        double vv = 0.0;
+        FZ_OK(reduce_partials(fz, &vv));
+        if (!(yy > 0.0) || !(vv > 0.0) || !isfinite(yy)) break;
+        est = sqrt(yy / vv);
+        hipLaunchKernelGGL(vec_scale_copy, dim3(nblk(n)), dim3(kBlock), 0, st, y, n, 1.0 / sqrt(yy), v);
+    }
+    fz.release(v);
+    fz.release(y);
+    *out = est;
+    return TRAMP_OK;
+}
+
 // orthonormal basis of the columns Y (m x r, ld) by two Cholesky-QR passes.  gram0: an r x r matrix
 // holding Y^T Y in its upper triangle if the caller has it for free (consumed), else nullptr.
 int cholqr2(Fz& fz, double* Y, size_t m, size_t r, size_t ld, double* gram /* r x r scratch, ld = r */, bool have_gram) {
@@ -486,14 +548,23 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
         fz.release(dg);
         return TRAMP_OK;
     }
-    hipLaunchKernelGGL(scale_add_identity, dim3(kRedBlocks), dim3(kBlock), 0, st, X, n, 1.0 / sqrt(fro2), 0.0);
+    // X0 = (A - sigma I) / s with s just above |A - sigma I|_2: the power iteration estimates the norm from below,
+    // 6 % of headroom keeps the spectrum of X0 inside [-1, 1] (a slightly larger eigenvalue would still converge).
+    // Scaled by the Frobenius norm instead (the earlier form) the smallest |eigenvalue| of X0 - the l0 the
+    // iteration count depends on - is sqrt(n)-ish smaller: one or two more n^3 steps at n = 50 000.
+    double nrm2 = 0.0;
+    FZ_OK(norm2_power(fz, X, n, 24, &nrm2));
+    double scale0 = 1.06 * nrm2;
+    if (!(scale0 > 0.0) || !(scale0 <= sqrt(fro2))) scale0 = sqrt(fro2);
+    hipLaunchKernelGGL(scale_add_identity, dim3(kRedBlocks), dim3(kBlock), 0, st, X, n, 1.0 / scale0, 0.0);
 
     // weights: follow the predicted lower bound l_pred of the smallest |eigenvalue| of X (floored at
     // l_floor: c <= 1.6e4 keeps the Cholesky solve accurate); when the prediction says "converged"
     // but the residual e = |X^2 - I|_F does not - an eigenvalue closer to sigma than l0 assumed -
     // the bound the residual certifies, sqrt(1 - e), takes over (tools/proto_eig_dc.py)
     const double l_floor = 1e-3;
-    double l_pred = 1e-8;
+    double l_pred = 1e-8 * (sqrt(fro2) / scale0);          // the same prior as before, in the new units
+    if (l_pred > 1e-5) l_pred = 1e-5;
     const double tol = 1e-13 * (double)n + 1e-12;
     bool converged = false;
     fz.tick("split: scale", n);
@@ -575,7 +646,8 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
 // symmetric eigendecomposition: A (n x n column-major, upper triangle valid) -> eigenvectors in A,
 // ascending eigenvalues in w_d
 int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth) {
-    if (n <= fz.eig_cap) {
+    const size_t cap = (depth == 0 || fz.sub_cap > fz.eig_cap) ? fz.eig_cap : fz.sub_cap;
+    if (n <= cap) {
         double* E = fz.alloc(n);
         if (!E) return fz.rc;
         FZ_RB(fz, rocsolver_dsyevd(fz.h, rocblas_evect_original, rocblas_fill_upper, (rocblas_int)n, A,
@@ -592,8 +664,20 @@ int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth) {
 }
 
 size_t eig_cap_from_env() {
+    // rocSOLVER's limit is 46336 (32-bit indexing); its syevd is bound by the memory-bound tridiagonalisation
+    // (n = 28802: 23.8 s, n = 21198: 8.5 s on MI355X) while a spectral split runs at the rocBLAS level-3 rate,
+    // so the halves of a forced split are split again down to this size (gpurun_out/r03/factorize1.log)
     size_t cap = 46336;
     if (const char* s = getenv("TRAMP_EIG_CAP")) {
+        long v = atol(s);
+        if (v >= 2 && v <= 46336) cap = (size_t)v;
+    }
+    return cap;
+}
+
+size_t eig_subcap_from_env() {
+    size_t cap = 16384;
+    if (const char* s = getenv("TRAMP_EIG_SUBCAP")) {
         long v = atol(s);
         if (v >= 2 && v <= 46336) cap = (size_t)v;
     }
@@ -756,6 +840,7 @@ extern "C" int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_
     fz.ctx = ctx;
     fz.rc = TRAMP_OK;
     fz.eig_cap = eig_cap_from_env();
+    fz.sub_cap = eig_subcap_from_env();
     rocblas_status rs = rocblas_create_handle(&fz.h);
     if (rs != rocblas_status_success) return tramp_fail(ctx, TRAMP_EHIP, "rocblas_create_handle", rocblas_status_to_string(rs));
     int rc = TRAMP_OK;
@@ -802,6 +887,7 @@ extern "C" int tramp_eigh(tramp_ctx* ctx, size_t n, double* A_d, double* w_d) {
     fz.ctx = ctx;
     fz.rc = TRAMP_OK;
     fz.eig_cap = eig_cap_from_env();
+    fz.sub_cap = eig_subcap_from_env();
     rocblas_status rs = rocblas_create_handle(&fz.h);
     if (rs != rocblas_status_success) return tramp_fail(ctx, TRAMP_EHIP, "rocblas_create_handle", rocblas_status_to_string(rs));
     auto body = [&]() -> int {

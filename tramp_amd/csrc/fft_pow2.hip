@@ -175,28 +175,6 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
     } else {
         for (int g = r0; g < G; g += rstep) tile[g * P + c] = src[(size_t)g * LB + c0 + c];
     }
-    // Fused message update: the old message(s) this thread will combine with its outputs do not depend on the
-    // transform - request them NOW, so that the epilogue finds them in registers instead of paying an HBM round
-    // trip per row sweep after the last stage (up to kPre sweeps; longer tiles keep the load in the epilogue loop).
-    constexpr int kPre = 5;
-    C bin_pre[kPre], bold_pre[kPre];
-    bool preloaded = false;
-    if constexpr (EPI) {
-        preloaded = (G + rstep - 1) / rstep <= kPre;
-        if (preloaded) {
-            const C* bin = reinterpret_cast<const C*>(epi.b_in) + tf * h;
-            const C* bold = epi.damping != 0.0 ? reinterpret_cast<const C*>(epi.b_old) + tf * h : nullptr;
-#pragma unroll
-            for (int it = 0; it < kPre; ++it) {
-                const int g = r0 + it * rstep;
-                if (g < G) {
-                    const size_t i = (size_t)g * LB + c0 + c;
-                    bin_pre[it] = bin[i];
-                    if (bold) bold_pre[it] = bold[i];
-                }
-            }
-        }
-    }
     // this tile's twiddles (one per stage, leg offset and column) go to LDS while the tile loads are in
     // flight: the stage loops then never wait on global memory
     C* twl = tile + (size_t)G * P;
@@ -232,29 +210,18 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
         double vi = 0.0;
         PriorHintEval<T> he;
         if (epi.hint.kind) he.setup(epi.hint, tf);
-        auto update = [&](int g, const C bi, const C bp) {
+        for (int g = r0; g < G; g += rstep) {
             const size_t i = (size_t)g * LB + c0 + c;
-            const C r = tile[g * P + c];
+            const C r = tile[g * P + c], bi = bin[i];
             C bn = {r.x * asum - bi.x, r.y * asum - bi.y};
             if (bold) {
+                const C bp = bold[i];
                 bn.x = d * bp.x + omd * bn.x;
                 bn.y = d * bp.y + omd * bn.y;
             }
             bo[i] = bn;
             if (ro) ro[i] = r;
             if (epi.hint.kind) vi += he.v(bn.x, 2 * i) + he.v(bn.y, 2 * i + 1);
-        };
-        if (preloaded) {
-#pragma unroll
-            for (int it = 0; it < kPre; ++it) {
-                const int g = r0 + it * rstep;
-                if (g < G) update(g, bin_pre[it], bold_pre[it]);
-            }
-        } else {
-            for (int g = r0; g < G; g += rstep) {
-                const size_t i = (size_t)g * LB + c0 + c;
-                update(g, bin[i], bold ? bold[i] : C{});
-            }
         }
         if (epi.hint.kind) {
             // sum over the workgroup (up to 16 waves; the tile's LDS is free again after the barrier)
@@ -517,8 +484,15 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
                            (C*)const_cast<void*>(in), (const C*)pl->tw_blk);
         if (epi && epi->out) {
             Fft2Epi e2 = *epi;
-            // message length 2 h reals per instance, one partial per tile
-            prior_hint_arm(ctx, e2.out, 2 * sh.h, batch, (int)(sh.LB / kC1), &e2.hint);
+            // message length 2 h reals per instance, one partial per tile.  This pass is bound by its own
+            // arithmetic (butterflies, twiddles), so moments evaluated here cost their full VALU time: worth it for
+            // the priors and the f64 sign likelihood (64 x 1e6: 467-574 us fused against 571-622 on its own), not for
+            // the abs likelihood (432-509 against 438-466) or the f32 likelihoods (363 against 242):
+            // gpurun_out/r03/fused1.log, fused2.log.  The dense channel's fold kernels arm for every kind.
+            e2.hint.kind = PRIOR_HINT_NONE;
+            const int hk = ctx->hint.kind;
+            if (hk == PRIOR_HINT_GB || hk == PRIOR_HINT_L1 || (hk == PRIOR_HINT_SGN_LIK && sizeof(T) == 8))
+                prior_hint_arm(ctx, e2.out, 2 * sh.h, batch, (int)(sh.LB / kC1), &e2.hint);
             hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh,
                                (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, e2);
         }
