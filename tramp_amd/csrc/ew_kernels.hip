@@ -90,7 +90,7 @@ template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1)
 };
 
 template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
-    static constexpr bool HEAVY = sizeof(T) == 8;      // f32: cheap enough to recompute in pass 2 (252 vs 309 us at 64 x 1e6)
+    static constexpr bool HEAVY = false;     // recomputed in pass 2 (5T moved, not 6T): f32 252 vs 309 us, f64 580 vs 616 us at 64 x 1e6
     static constexpr int NIN = 2;
     static constexpr int TARGET = 0;
     const double* az;
