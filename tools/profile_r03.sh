@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-3 profiles (run on the GPU box through gpurun): rocprofv3 kernel-trace stats of the DEFAULT bench command
+# and separate --pmc passes over the kernels alone (never --pmc together with a trace domain other than
+# --kernel-trace).  Usage: tools/profile_r03.sh [stats|pmc_mat|pmc_waits|pmc_ew|fused|all]
+set -u
+WHAT=${1:-all}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_r03
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
+  # rocprofv3 (ROCm 7.2) segfaults inside rocSOLVER's syevd for k >= 24576: TRAMP_EIG_CAP=16384 keeps every
+  # library eigensolve below that (the spectral split simply recurses once more); everything else is the default.
+  TRAMP_EIG_CAP=16384 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+  tail -3 $OUT/stats.err
+fi
+cd $REPO
+if [ "$WHAT" = pmc_mat ] || [ "$WHAT" = all ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_mat -- python3 tools/pmc_kernels.py 100000 64 > $OUT/fetch_mat.out 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_mat -- python3 tools/pmc_kernels.py 100000 64 > $OUT/write_mat.out 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_mfma_mat -- python3 tools/pmc_kernels.py 100000 64 > $OUT/mfma_mat.out 2>&1
+fi
+if [ "$WHAT" = pmc_waits ] || [ "$WHAT" = all ]; then
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_waits_a -- python3 tools/pmc_kernels.py 100000 64 > $OUT/waits_a.out 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/pmc_waits_b -- python3 tools/pmc_kernels.py 100000 64 > $OUT/waits_b.out 2>&1
+fi
+if [ "$WHAT" = pmc_ew ] || [ "$WHAT" = all ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_ew -- python3 tools/pmc_ew.py > $OUT/fetch_ew.out 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_ew -- python3 tools/pmc_ew.py > $OUT/write_ew.out 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_valu_ew -- python3 tools/pmc_ew.py > $OUT/valu_ew.out 2>&1
+fi
+if [ "$WHAT" = fused ] || [ "$WHAT" = all ]; then
+  # kernel durations of the producer with and without the fused moments, and of the consumer's single pass
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fused_trace -- python3 tools/bench_fused.py f64 > $OUT/fused_trace.out 2>&1
+fi
+for d in $OUT/pmc_*; do echo "== $d"; python3 tools/pmc_parse.py $d 2>/dev/null | cut -c1-500; done > $OUT/pmc_summary.txt 2>&1
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
+find $OUT -name "*counter_collection.csv" -size +8M -delete
+find $OUT -name "*.db" -delete
+du -sh $OUT
