@@ -350,6 +350,14 @@ int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batc
  * initial messages - the component of z orthogonal to the rows of Vt then stays exactly zero - and removes
  * the two passes over Vt (t = bz', rz' = bz' / az + w); z = Vt^T z' when read (tramp_matvec_nn on Vt). */
 int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on);
+/* Transposed copies of the thin factors, kept resident beside them (the caller owns both): Vtt_d [N, k] = Vt^T,
+ * Ukt_d [k, M] = Uk^T, either may be NULL.  The products over the ROWS of Vt / Uk (t = Vt bz, rx = Uk w) then run as
+ * column passes over the copy whenever the ensemble takes the matrix-core path (batch > 2): 256 contiguous bytes per
+ * matrix row and load instruction instead of 64 - same flops, same bytes streamed once, 5 % faster at 50000 x 100000
+ * x 64.  Costs N k T bytes of the 288 GB (40 GB at N = 1e5, f64).  TRAMP_LINEAR_TRANSPOSED=0 ignores the copies. */
+int tramp_linear_set_transposed(tramp_ctx* ctx, tramp_linear* lin, const void* Vtt_d, const void* Ukt_d);
+/* dst [C, R] = src [R, C]^T (32 x 32 LDS tiles) */
+int tramp_transpose(tramp_ctx* ctx, int dtype, size_t R, size_t C, const void* src_d, void* dst_d);
 /* Constant damping of a CONSTANT factor's message (tramp/algos/message_passing.py:119-127
  * applied to e.g. GaussianLikelihood's backward message) replaces the message on one side of
  * the channel by  b <- damping * b + (1 - damping) * c  with the same c every iteration.  The

@@ -25,3 +25,6 @@ timeit("NT(Vt)", lambda: ctx._call("tramp_matvec_nt", dt, ALGO, M, N, B, Vt.ptr,
 timeit("NN(Vt)", lambda: ctx._call("tramp_matvec_nn", dt, ALGO, M, N, B, Vt.ptr, y.ptr, r.ptr), M, N)
 timeit("NT(U)", lambda: ctx._call("tramp_matvec_nt", dt, ALGO, M, M, B, U.ptr, y.ptr, t.ptr), M, M)
 timeit("NN(U)", lambda: ctx._call("tramp_matvec_nn", dt, ALGO, M, M, B, U.ptr, y.ptr, t.ptr), M, M)
+# the row-dot pass t = Vt x as a column pass over the transposed copy V [N, M] (same flops, same bytes)
+V = ctx.randn((N, M), np_dt, seed=9, scale=N ** -0.5)
+timeit("NN(V=Vt^T)", lambda: ctx._call("tramp_matvec_nn", dt, ALGO, N, M, B, V.ptr, x.ptr, t.ptr), N, M)

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "tramp_fft_bench": [vp, i32, sz, sz, i32, vp, vp, C.POINTER(dbl), C.POINTER(dbl)],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
+    "tramp_linear_set_transposed": [vp, vp, vp, vp],
+    "tramp_transpose": [vp, i32, sz, sz, vp, vp],
     "tramp_matvec_last_launch": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_damp": [vp, i32, sz, sz, dbl, vp, vp, vp, vp],
