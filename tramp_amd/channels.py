@@ -561,12 +561,15 @@ class LinearChannel(Channel):
         self._tt_tried = set()
 
     def _ensure_transposed(self, direction, batch):
-        """Ensembles on the matrix-core path (batch > 2): keep Vt^T (and, for forward messages outside the rotated
-        basis, Uk^T) resident beside the factors, so that the products over their ROWS run as column passes
-        (tramp_linear_set_transposed: 5 % faster at 50000 x 100000 x 64).  Made on first use, only while the copy
-        leaves more than a third of the device memory free; TRAMP_LINEAR_TRANSPOSED=0 turns it off."""
+        """TRAMP_LINEAR_TRANSPOSED=1 (off by default): ensembles on the matrix-core path (batch > 2) keep Vt^T (and, for
+        forward messages outside the rotated basis, Uk^T) resident beside the factors, so that the products over
+        their ROWS run as column passes (tramp_linear_set_transposed).  Made on first use, only while the copy
+        leaves more than a third of the device memory free.  Measured at 50000 x 100000 x 64, f64: the pass alone
+        57.9 against 55.8 TFLOP/s, but the EP iteration 23.29 against 23.24 ms - under sustained load both passes
+        sit on the package power limit and the faster kernel only lowers the clock (gpurun_out/r03/bench3.json), so
+        the 40 GB are not spent by default."""
         import os
-        if batch <= 2 or os.environ.get("TRAMP_LINEAR_TRANSPOSED", "1") == "0":
+        if batch <= 2 or os.environ.get("TRAMP_LINEAR_TRANSPOSED", "0") != "1":
             return
         rot = getattr(self, "_rot_mask", 0)
         want = []

@@ -370,7 +370,9 @@ static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t 
 // out = mat x over the ROWS of mat [R, C] (a row-dot pass).  When a transposed copy matT [C, R] is resident and the
 // ensemble takes the MFMA path, the same product runs as a column pass over the copy: the column kernel reads 256
 // contiguous bytes per matrix row and instruction where the row-dot kernel reads 64, and keeps the matrix pipe
-// 87 % busy against 81 % (50000 x 100000 x 64, f64: 57.7 against 54.9 TFLOP/s; profiles/r03).  Same flops, same bytes.
+// 87 % busy against 81 % (50000 x 100000 x 64, f64: 57.9 against 55.8 TFLOP/s alone; profiles/r03).  Same flops, same
+// bytes.  In the EP loop both passes sit on the package power limit and the iteration does not get shorter (23.29
+// against 23.24 ms), so the host side only makes the copies on request (TRAMP_LINEAR_TRANSPOSED=1).
 static int rowdot_dispatch(tramp_ctx* ctx, int dtype, size_t R, size_t C, size_t batch, const void* mat_d,
                            const void* matT_d, const void* x_d, const LinEpi& epi) {
     static const int use_t = getenv("TRAMP_LINEAR_TRANSPOSED") ? atoi(getenv("TRAMP_LINEAR_TRANSPOSED")) : 1;
