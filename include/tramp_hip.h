@@ -388,7 +388,18 @@ int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, int which, si
  * the current (converged) or previous (diverged) posterior mean into frozen_d [batch, n]. */
 int tramp_ep_monitor(tramp_ctx* ctx, int n_vars, int n_edges, size_t batch, const double* A_d,
                      const double* S_d, double tol, double max_increase, int wait_increase,
-                     int* state_d, double* v_prev_d, double* v_frozen_d, double* a_frozen_d);
+                     int* state_d, double* v_prev_d, double* v_frozen_d, double* a_frozen_d,
+                     const double* A_prev_d /* precisions before this iteration, or NULL */);
+/* "restoring old message dag" per instance (tramp/algos/callbacks.py:277-283, message_passing.py:187-209):
+ * the scheduler snapshots the messages before an iteration, tramp_ep_freeze keeps - per message buffer, with
+ * (cur, prev, frozen) = (live message, snapshot, frozen message) - what an instance that stops in this iteration
+ * would have left behind (the live message if it converged, the snapshot if it gave up), and at the end of the run
+ * tramp_ep_restore / tramp_ep_restore_a put those back into the live buffers / the precision table for every
+ * stopped instance (all != 0: for every instance - a NaN was found, everybody goes back one iteration). */
+int tramp_ep_restore(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const int* state_d,
+                     const void* frozen_d, void* live_d, int all);
+int tramp_ep_restore_a(tramp_ctx* ctx, int n_edges, size_t batch, const int* state_d, const double* a_frozen_d,
+                       double* A_d, int all);
 int tramp_ep_freeze(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const int* state_d,
                     const void* r_cur_d, const void* r_prev_d, void* frozen_d);
 

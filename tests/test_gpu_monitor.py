@@ -102,3 +102,69 @@ def test_mse_validates_the_shape_of_the_true_signal(T, ctx):
     for bad in (X[:2], X[:, :N - 1], np.zeros(N + 1)):
         with pytest.raises(ValueError):
             ep.mse("x", bad)
+
+
+@pytest.mark.parametrize("batch", [1, 6])
+def test_stopped_instances_get_their_messages_back(T, ctx, batch):
+    """"restoring old message dag" (tramp/algos/callbacks.py:277-283) per instance: after the run every instance
+    holds the MESSAGES its own run would have left - those of its stopping iteration if it converged, those of the
+    iteration before the increase if it gave up - although the ensemble kept iterating for the others."""
+    model, fs, X, (N, M) = _glm(T, ctx, batch)
+    rule = dict(tol=2e-3, wait_increase=5, max_increase=0.03)
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=100, callback=T.EarlyStoppingEP(**rule), damping=0.1)
+    assert ep._restore
+    seen = set()
+    edges = ep.get_edges_data()
+    for b in range(batch):
+        res = orc.ep_chain(fs(b), [N, M], max_iter=100, damping=0.1, **rule)
+        seen.add(res["status"])
+        for i, vid in enumerate(("x", "z")):
+            for direction, ref in (("fwd", res["fwd"][i]), ("bwd", res["bwd"][i])):
+                a, bmsg = ep.get_message(vid, direction)
+                _close(np.atleast_1d(a)[b], ref[0], 1e-7)
+                _close(np.atleast_2d(bmsg)[b], ref[1], 1e-6)
+                _close(np.atleast_1d(edges[(vid, direction)])[b], ref[0], 1e-7)
+    if batch > 1:
+        assert seen == {"converged", "diverged"}
+    # and a warm start goes on from there: the same as a fresh run of the oracle continued from its final state is
+    # not available, but the restored state must at least be a fixed input: two warm starts of one iteration agree
+    m0 = [ep.get_message(v, d)[1].copy() for v in ("x", "z") for d in ("fwd", "bwd")]
+    ep2 = T.ExpectationPropagation(model, ctx=ctx)
+    ep2.iterate(max_iter=100, callback=T.EarlyStoppingEP(**rule), damping=0.1, restore_messages=False)
+    m1 = [ep2.get_message(v, d)[1] for v in ("x", "z") for d in ("fwd", "bwd")]
+    if batch > 1:
+        assert any(np.abs(a - b).max() > 1e-9 for a, b in zip(m0, m1))      # without the restore the live messages moved on
+
+
+def test_nan_restores_the_previous_messages(T, ctx):
+    "a NaN found after an iteration: every instance goes back to the messages before it, then ValueError (message_passing.py:187-209)"
+    model, fs, X, (N, M) = _glm(T, ctx, 3)
+    ref = T.ExpectationPropagation(model, ctx=ctx)
+    ref.iterate(max_iter=2, callback=T.PassCallback(), damping=0.1)
+    want = {(v, d): ref.get_message(v, d) for v in ("x", "z") for d in ("fwd", "bwd")}
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=2, callback=T.PassCallback(), damping=0.1, restore_messages=True)
+    lik = model.next_factor(ep.variables[0])                # the channel: its backward update runs every iteration
+    real = lik.compute_backward_message
+    calls = []
+
+    def poisoned(*args, **kw):
+        out = real(*args, **kw)
+        calls.append(1)
+        if "out_a" in kw:
+            a = kw["out_a"].get()
+            a[1] = np.nan
+            kw["out_a"].set(a)
+        return out
+    lik.compute_backward_message = poisoned
+    try:
+        with pytest.raises(ValueError, match="a is nan"):
+            ep.iterate(max_iter=1, callback=T.PassCallback(), damping=0.1, warm_start=True, restore_messages=True)
+    finally:
+        del lik.compute_backward_message
+    assert calls
+    for (v, d), (a_ref, b_ref) in want.items():
+        a, b = ep.get_message(v, d)
+        np.testing.assert_array_equal(a, a_ref)
+        np.testing.assert_array_equal(b, b_ref)

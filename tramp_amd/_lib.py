@@ -129,7 +129,9 @@ _SIGNATURES = {
     "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
     "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],
     "tramp_randn": [vp, i32, vp, sz, u64, dbl],
-    "tramp_ep_monitor": [vp, i32, i32, sz, vp, vp, dbl, dbl, i32, vp, vp, vp, vp],
+    "tramp_ep_monitor": [vp, i32, i32, sz, vp, vp, dbl, dbl, i32, vp, vp, vp, vp, vp],
+    "tramp_ep_restore": [vp, i32, sz, sz, vp, vp, vp, i32],
+    "tramp_ep_restore_a": [vp, i32, sz, vp, vp, vp, i32],
     "tramp_ep_freeze": [vp, i32, sz, sz, vp, vp, vp, vp],
     "tramp_comm_available": [vp],
     "tramp_comm_unique_id": [vp, vp],

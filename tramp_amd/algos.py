@@ -402,6 +402,7 @@ class ExpectationPropagation:
     # -- storage
     def _allocate(self):
         ctx, B, L = self.ctx, self.batch, len(self.variables)
+        self._snap = None                                    # snapshot / frozen messages belong to the old buffers
         self.A = ctx.zeros((2 * L, B), np.float64)           # a of every factor->variable edge
         self.S = ctx.zeros((3 * L, B), np.float64)           # per variable: v, sum (r-r_old)^2, sum r^2
         self.a_fwd = [self.A.row(2 * i) for i in range(L)]
@@ -584,15 +585,56 @@ class ExpectationPropagation:
         can_stop=False (no stopping rule given: tol = -1): only the guard - no instance can ever stop, the
         freeze launches (one per variable) would copy nothing."""
         L = len(self.variables)
+        snap = getattr(self, "_snap", None) if self._restore else None
         self.ctx._call("tramp_ep_monitor", L, self._n_edges, self.batch, self.A, self.S, float(tol),
                        float(max_increase), int(wait_increase), self._state, self._v_prev, self._v_frozen,
-                       self._a_frozen)
+                       self._a_frozen, snap["A"] if snap else None)
         if not can_stop:
             return
         dt = dtype_code(self.dtype)
         for i in range(L):
             self.ctx._call("tramp_ep_freeze", dt, self.r[i].shape[1], self.batch, self._state, self.r[i],
                            self.r_prev[i], self._frozen_r[i])
+        if snap:
+            # the MESSAGES an instance that stops now would have left behind: the live ones if it converged, the
+            # snapshot taken before this iteration if it gave up (callbacks.py:277-283)
+            for live, prev, frozen in self._message_triples():
+                self.ctx._call("tramp_ep_freeze", dt, live.shape[1], self.batch, self._state, live, prev, frozen)
+
+    # -- "restoring old message dag" (message_passing.py:187-209, callbacks.py:233-240,277-283)
+    _restore = False
+
+    def _message_triples(self):
+        s = self._snap
+        return ([(b, s["fwd"][i], s["frozen_fwd"][i]) for i, b in enumerate(self.b_fwd)]
+                + [(b, s["bwd"][i], s["frozen_bwd"][i]) for i, b in enumerate(self.b_bwd)])
+
+    def _allocate_snapshot(self):
+        ctx = self.ctx
+        mk = lambda bufs: [ctx.zeros(tuple(b.shape), self.dtype) for b in bufs]          # noqa: E731
+        self._snap = dict(fwd=mk(self.b_fwd), bwd=mk(self.b_bwd), frozen_fwd=mk(self.b_fwd), frozen_bwd=mk(self.b_bwd),
+                          A=ctx.zeros(tuple(self.A.shape), np.float64))
+
+    def _take_snapshot(self):
+        "the message dag as it stands before an iteration (the reference deep-copies it every iteration)"
+        s = self._snap
+        for live, prev, _ in self._message_triples():
+            prev.copy_from(live)
+        s["A"].copy_from(self.A)
+
+    def _restore_messages(self, everybody=False):
+        """every stopped instance gets the messages of ITS stopping iteration back (everybody=True: all instances
+        go back to the snapshot - a NaN was found); consumers' cached projections of the old buffers are void"""
+        dt = dtype_code(self.dtype)
+        s = self._snap
+        for live, prev, frozen in self._message_triples():
+            self.ctx._call("tramp_ep_restore", dt, live.shape[1], self.batch, self._state,
+                           prev if everybody else frozen, live, int(everybody))
+            live.version += 1
+        self.ctx._call("tramp_ep_restore_a", self._n_edges, self.batch, self._state,
+                       s["A"] if everybody else self._a_frozen, self.A, int(everybody))
+        self.ctx._call("tramp_prior_hint", 0, 0.0, 0.0, 0.0, 0, 0, None, None)
+        self._const_done = set()
 
     def _poll_monitor(self):
         """Read the state words; raises on a NaN message (message_passing.py:187-209), otherwise updates
@@ -600,6 +642,9 @@ class ExpectationPropagation:
         st = self._state.get()
         if st[2]:
             e, b = divmod(int(st[2]) - 1, self.batch)
+            if self._restore:
+                logger.warning("restoring old message dag")
+                self._restore_messages(everybody=True)
             raise ValueError(self._edge_name(e) + f" (instance {b}): a is nan")
         B = self.batch
         status, n_it = st[4:4 + B], st[4 + B:4 + 2 * B]
@@ -801,6 +846,8 @@ class ExpectationPropagation:
     _device_monitor = True       # chain scheduler: stopping rule and NaN guard run on the device (monitor.hip)
 
     def _one_iteration(self, mon):
+        if self._restore:
+            self._take_snapshot()
         self.forward_message()
         self.backward_message()
         self.update_variables()
@@ -833,14 +880,20 @@ class ExpectationPropagation:
         return stop[0], [cb for cb in members if cb is not stop[0] and type(cb) is not PassCallback]
 
     def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False,
-                check_every=1, graph=False):
+                check_every=1, graph=False, restore_messages=None):
         """message_passing.py:330-357.  The NaN guard and the per-instance stopping rule run on the device
         after every iteration (csrc/monitor.hip); ``check_every`` = k makes the host look at their state
         words - and run the remaining host callbacks - only every k-th iteration, the sweeps themselves
         never wait on the host.  An instance that stops keeps the estimate of its own stopping iteration
         (``status``, ``n_iter_instance``, get_variables_data) while the others go on; k > 1 only delays the
         moment the loop notices that all are done.  ``graph=True`` captures the steady-state launch sequence
-        in a hipGraph and replays it (launch-bound small problems); results are identical to the eager loop."""
+        in a hipGraph and replays it (launch-bound small problems); results are identical to the eager loop.
+        ``restore_messages`` (default: on whenever the device runs a stopping rule): the reference's "restoring
+        old message dag" per instance - the messages are snapshot before every iteration (one device copy of each),
+        an instance that gives up after an increase gets the previous iteration's messages back, a converged one
+        keeps those of its stopping iteration, and a NaN puts every instance back one iteration before ValueError
+        is raised (message_passing.py:187-209, callbacks.py:233-240,277-283); a warm start then continues each
+        instance from where its own run would have stopped."""
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
         if damping is not None and damping is not False and not isinstance(damping, float):
@@ -862,6 +915,10 @@ class ExpectationPropagation:
             stopper, host_cbs, mon = None, [callback], None
             self.status[:] = 0
             self.n_iter_instance[:] = 0
+        self._restore = bool(self._device_monitor and (restore_messages if restore_messages is not None
+                                                       else stopper is not None))
+        if self._restore and getattr(self, "_snap", None) is None:
+            self._allocate_snapshot()
         n0 = self._n0 = self.n_iter
         period = 2 if mon is not None else 1           # r / r_prev ping-pong: the launch sequence has period two
         graphs = {}
@@ -907,6 +964,8 @@ class ExpectationPropagation:
             basis.__exit__(None, None, None)
             for g in graphs.values():
                 self.ctx._call("tramp_graph_destroy", g)
+        if self._restore and stopper is not None and self.status.any():
+            self._restore_messages()
         if stopper is not None and self.status.all():
             self.n_iter = int(self.n_iter_instance.max())          # the iteration the last instance stopped at
         self.n_iter_instance[self.status == 0] = self.n_iter       # still running: cut short by max_iter

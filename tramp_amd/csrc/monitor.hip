@@ -24,7 +24,8 @@ __global__ __launch_bounds__(kBlock) void ep_monitor_kernel(int L, int E, size_t
                                                             const double* __restrict__ S, double tol,
                                                             double max_increase, int wait_increase,
                                                             int* __restrict__ state, double* __restrict__ v_prev,
-                                                            double* __restrict__ v_frozen, double* __restrict__ a_frozen) {
+                                                            double* __restrict__ v_frozen, double* __restrict__ a_frozen,
+                                                            const double* __restrict__ A_prev) {
     __shared__ int s_running, s_nan, s_div;
     int* status = state + 4;
     int* n_iter = state + 4 + B;
@@ -61,9 +62,12 @@ __global__ __launch_bounds__(kBlock) void ep_monitor_kernel(int L, int E, size_t
                     n_iter[b] = i + 1;
                     for (int l = 0; l < L; ++l)
                         v_frozen[(size_t)l * B + b] = (st == 1) ? S[(size_t)(3 * l) * B + b] : v_prev[(size_t)l * B + b];
-                    // the message precisions of the stopping iteration (a diverged instance keeps the
-                    // diverged ones: only means and variances are rolled back)
-                    for (int e = 0; e < E; ++e) a_frozen[(size_t)e * B + b] = A[(size_t)e * B + b];
+                    // the message precisions of the stopping iteration; with a snapshot of the previous iteration's
+                    // messages (A_prev: restore_messages) a diverged instance goes back to those, as the reference
+                    // restores its whole previous message dag (callbacks.py:277-283) - without one it keeps the
+                    // diverged precisions and only means and variances are rolled back
+                    const double* Asrc = (st == 2 && A_prev) ? A_prev : A;
+                    for (int e = 0; e < E; ++e) a_frozen[(size_t)e * B + b] = Asrc[(size_t)e * B + b];
                 }
             }
             if (st == 0) atomicAdd(&s_running, 1);
@@ -83,12 +87,13 @@ __global__ __launch_bounds__(kBlock) void ep_monitor_kernel(int L, int E, size_t
 
 extern "C" int tramp_ep_monitor(tramp_ctx* ctx, int n_vars, int n_edges, size_t batch, const double* A_d,
                                 const double* S_d, double tol, double max_increase, int wait_increase,
-                                int* state_d, double* v_prev_d, double* v_frozen_d, double* a_frozen_d) {
+                                int* state_d, double* v_prev_d, double* v_frozen_d, double* a_frozen_d,
+                                const double* A_prev_d) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, n_vars > 0 && n_edges > 0 && batch > 0 && A_d && S_d && state_d && v_prev_d && v_frozen_d &&
                            a_frozen_d);
     hipLaunchKernelGGL(ep_monitor_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, n_vars, n_edges, batch, A_d, S_d,
-                       tol, max_increase, wait_increase, state_d, v_prev_d, v_frozen_d, a_frozen_d);
+                       tol, max_increase, wait_increase, state_d, v_prev_d, v_frozen_d, a_frozen_d, A_prev_d);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
@@ -121,6 +126,58 @@ extern "C" int tramp_ep_freeze(tramp_ctx* ctx, int dtype, size_t n, size_t batch
                            (const float*)r_cur_d, (const float*)r_prev_d, (float*)frozen_d);
     else
         return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// ---- restore: every instance that has stopped gets the messages of ITS stopping iteration back (what a run of
+// that instance alone would have left behind: the current ones if it converged, the previous iteration's if it
+// gave up after an increase - MessagePassing.reset_message_dag(old_message_dag), callbacks.py:277-283)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ep_restore_kernel(size_t n, size_t B, const int* __restrict__ state,
+                                                            const T* __restrict__ frozen, T* __restrict__ live, int all) {
+    const size_t b = blockIdx.y;
+    if (!all && state[4 + b] == 0) return;
+    const T* src = frozen + b * n;
+    T* dst = live + b * n;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
+}
+
+extern "C" int tramp_ep_restore(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const int* state_d,
+                                const void* frozen_d, void* live_d, int all) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, n > 0 && batch > 0 && batch <= 65535 && state_d && frozen_d && live_d);
+    size_t g = (n + (size_t)kBlock * 8 - 1) / ((size_t)kBlock * 8);
+    if (g > 256) g = 256;
+    dim3 grid((unsigned)g, (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((ep_restore_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, batch, state_d,
+                           (const double*)frozen_d, (double*)live_d, all);
+    else if (dtype == TRAMP_F32)
+        hipLaunchKernelGGL((ep_restore_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, batch, state_d,
+                           (const float*)frozen_d, (float*)live_d, all);
+    else
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// the precision table A [E, B] (instance fastest): columns of the stopped instances from a_frozen
+__global__ __launch_bounds__(kBlock) void ep_restore_a_kernel(int E, size_t B, const int* __restrict__ state,
+                                                              const double* __restrict__ a_frozen, double* __restrict__ A,
+                                                              int all) {
+    for (size_t b = threadIdx.x; b < B; b += kBlock) {
+        if (!all && state[4 + b] == 0) continue;
+        for (int e = 0; e < E; ++e) A[(size_t)e * B + b] = a_frozen[(size_t)e * B + b];
+    }
+}
+
+extern "C" int tramp_ep_restore_a(tramp_ctx* ctx, int n_edges, size_t batch, const int* state_d, const double* a_frozen_d,
+                                  double* A_d, int all) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, n_edges > 0 && batch > 0 && state_d && a_frozen_d && A_d);
+    hipLaunchKernelGGL(ep_restore_a_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, n_edges, batch, state_d, a_frozen_d, A_d,
+                       all);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
