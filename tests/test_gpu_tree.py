@@ -198,6 +198,47 @@ def test_tree_ep_ensemble_matches_oracle(ctx, golden_tree):
             close(data["z"]["v"][b], runs[b]["v"]["z"], max(rt, 1e-7))
 
 
+def test_tree_ep_per_instance_stopping_on_the_device(ctx, golden_tree):
+    """The tree scheduler's stopping rule and NaN guard run on the device as the chain's (csrc/monitor.hip): each
+    instance of an ensemble stops at the iteration its own run would (MessagePassing.iterate,
+    message_passing.py:345-356 with EarlyStoppingEP, callbacks.py:250-286) and reports that iterate; polling every
+    4th iteration changes nothing; every message of a stopped instance is the one of its stopping iteration."""
+    import tramp_amd as T
+    e = dict(golden_tree["ep"][0])
+    shape = tuple(e["shape"])
+    rs = np.random.RandomState(4)
+    Y = np.stack([e["y"], e["y"] + 0.3 * rs.standard_normal(shape), 2.0 * rs.standard_normal(shape),
+                  0.05 * rs.standard_normal(shape)])
+    B = Y.shape[0]
+    rule = dict(tol=3e-4, wait_increase=5, max_increase=0.2)
+    runs = []
+    for b in range(B):
+        factors = dict(GaussianPrior=orc.GaussPriorFactor(shape), GaussianLikelihood=orc.GaussLikFactor(Y[b], e["noise_var"]),
+                       GradientChannel=orc.GradientFactor(shape),
+                       GaussBernoulliPrior=orc.GBPriorFactor((1,) + shape, rho=e["rho"]))
+        runs.append(orc.ep_tree(factors, ["x", "z"], TREE_EDGES, dict(x=shape, z=(1,) + shape), max_iter=200,
+                                damping=0.2, **rule))
+    assert len({r["n_iter"] for r in runs}) > 1                       # the instances stop at different iterations
+    outs = []
+    for kw in (dict(), dict(check_every=4)):
+        model = build_tree(T, ctx, e, y=Y)
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        assert type(ep).__name__ == "TreeExpectationPropagation" and ep._device_monitor
+        ep.iterate(max_iter=200, callback=T.EarlyStoppingEP(**rule), damping=0.2, **kw)
+        assert ep._restore
+        data = ep.get_variables_data()
+        for b in range(B):
+            assert ep.n_iter_instance[b] == runs[b]["n_iter"], (b, ep.n_iter_instance, [r["n_iter"] for r in runs])
+            assert {1: "converged", 2: "diverged", 0: "max_iter"}[int(ep.status[b])] == runs[b]["status"]
+            close(data["x"]["r"][b], runs[b]["r"]["x"].ravel(), 1e-7, 1e-8)
+            close(data["z"]["r"][b], runs[b]["r"]["z"].ravel(), 1e-7, 1e-8)
+            close(data["x"]["v"][b], runs[b]["v"]["x"], 1e-7)
+        outs.append((ep.n_iter_instance.copy(), data["x"]["r"].copy(), {k: ep.get_message(*k)[1].copy() for k in ep.msg}))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert np.array_equal(outs[0][2][k], outs[1][2][k])
+
+
 def test_tree_ep_example_setting_matches_oracle(ctx):
     """The reference example's run (examples/sparse/plot_sparse_gradient.py:63,88-91: rho = 0.04, noise 1e-2,
     damping 0.1, EarlyStoppingEP(tol=1e-2)) at n = 4096: same stopping iteration and estimate as the oracle,

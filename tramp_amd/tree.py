@@ -33,7 +33,11 @@ class _Msg:
 
 
 class TreeExpectationPropagation(ExpectationPropagation):
-    _device_monitor = False      # stopping rule and NaN guard evaluated on the host, on the scalar tables
+    # stopping rule, NaN guard and the per-instance freeze / restore run on the device as on a chain (csrc/monitor.hip:
+    # the precision table simply has one row per directed factor<->variable message); TRAMP_TREE_MONITOR=host keeps the
+    # host-side evaluation on the scalar tables
+    import os as _os
+    _device_monitor = _os.environ.get("TRAMP_TREE_MONITOR", "device") != "host"
 
     """Gaussian EP on a tree of factors and variables (tramp/algos/expectation_propagation.py:5-32)."""
 
@@ -94,6 +98,7 @@ class TreeExpectationPropagation(ExpectationPropagation):
     # -- storage: one (a, b) pair per directed factor<->variable message
     def _allocate(self):
         ctx, B, L = self.ctx, self.batch, len(self.variables)
+        self._snap = None
         g = self.model.dag
         self.adj = {v: list(g.predecessors(v)) + list(g.successors(v)) for v in self.variables}
         keys = []
@@ -249,16 +254,37 @@ class TreeExpectationPropagation(ExpectationPropagation):
             f = self.adj[v][0]
             fv, vf = self.msg[(f, v)], self.msg[(v, f)]
             n = self.r[i].shape[1]
-            self.ctx._call("tramp_variable_posterior", dt, n, self.batch, fv.a.ptr, fv.b.ptr, vf.a.ptr, vf.b.ptr,
-                           self.r[i].ptr, self.r[i].ptr, self.S.row(3 * i).ptr, self.S.row(3 * i + 1).ptr,
-                           self.S.row(3 * i + 2).ptr)
+            if self._device_monitor:
+                # previous mean read from r, new one written to r_prev, then the two swap roles: the iterate before
+                # an increase stays at hand for an instance that gives up (as the chain scheduler)
+                self.ctx._call("tramp_variable_posterior", dt, n, self.batch, fv.a.ptr, fv.b.ptr, vf.a.ptr, vf.b.ptr,
+                               self.r[i].ptr, self.r_prev[i].ptr, self.S.row(3 * i).ptr, self.S.row(3 * i + 1).ptr,
+                               self.S.row(3 * i + 2).ptr)
+                self.r[i], self.r_prev[i] = self.r_prev[i], self.r[i]
+            else:
+                self.ctx._call("tramp_variable_posterior", dt, n, self.batch, fv.a.ptr, fv.b.ptr, vf.a.ptr, vf.b.ptr,
+                               self.r[i].ptr, self.r[i].ptr, self.S.row(3 * i).ptr, self.S.row(3 * i + 1).ptr,
+                               self.S.row(3 * i + 2).ptr)
+
+    def _edge_name(self, e):
+        src, dst = self.msg_keys[e]
+        return f"message {getattr(src, 'id', src)} -> {getattr(dst, 'id', dst)}"
+
+    def _message_triples(self):
+        s = self._snap
+        return [(m.b, s["prev"][k], s["frozen"][k]) for k, m in self.msg.items()]
+
+    def _allocate_snapshot(self):
+        ctx = self.ctx
+        self._snap = dict(prev={k: ctx.zeros(tuple(m.b.shape), self.dtype) for k, m in self.msg.items()},
+                          frozen={k: ctx.zeros(tuple(m.b.shape), self.dtype) for k, m in self.msg.items()},
+                          A=ctx.zeros(tuple(self.A.shape), np.float64))
 
     def check_message(self):
         bad = np.isnan(self.A_host)
         if bad.any():
             e, b = np.argwhere(bad)[0]
-            src, dst = self.msg_keys[e]
-            raise ValueError(f"message {getattr(src, 'id', src)} -> {getattr(dst, 'id', dst)} (instance {b}): a is nan")
+            raise ValueError(self._edge_name(int(e)) + f" (instance {b}): a is nan")
 
     def get_edges_data(self):
         """a of every factor->variable message as {(variable id, direction): array[batch]}, like the chain
@@ -266,13 +292,17 @@ class TreeExpectationPropagation(ExpectationPropagation):
         e.g. ("z", "fwd[f_3]")."""
         g = self.model.dag
         out = {}
+        A = self.A_host.copy()
+        done = self.status != 0
+        if done.any() and self._device_monitor:
+            A[:, done] = self._frozen_A[:, done]              # a stopped instance: the values of its stopping iteration
         for i, (src, dst) in enumerate(self.msg_keys):
             if not isinstance(dst, Variable):
                 continue
             fwd = g.has_edge(src, dst)
             several = (dst.n_prev if fwd else dst.n_next) > 1
             direction = ("fwd" if fwd else "bwd") + (f"[{src.id}]" if several else "")
-            out[(dst.id, direction)] = self.A_host[i].copy()
+            out[(dst.id, direction)] = A[i].copy()
         return out
 
     def get_message(self, source, target):
