@@ -1795,6 +1795,7 @@ def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1
             msg[(v, f)] = (a_hat - msg[(f, v)][0], b_hat - msg[(f, v)][1])      # base.py:186-211
 
     old_rs, n_iter, rs, vs = None, 0, None, None
+    old_state, status = None, "max_iter"
     for it in range(max_iter):
         for n in order:
             if n in factors:
@@ -1818,11 +1819,19 @@ def ep_tree(factors, variables, edges, shapes, max_iter=200, damping=None, tol=1
         if old_rs is not None:
             tols = [_rms(rs[v] - old_rs[v]) / _rms(rs[v]) for v in variables]
             if max(tols) < tol:
+                status = "converged"
                 break
             if it > wait_increase and max(tols) > max_increase:
+                # callbacks.py:277-283 "restoring old message dag": messages and posteriors of the iteration before
+                # the increase (every message is replaced, never mutated, so a shallow copy of the dict holds them)
+                old_msg, rs, vs = old_state
+                msg.clear()
+                msg.update(old_msg)
+                status = "diverged"
                 break
         old_rs = rs
-    return dict(msg=msg, r=rs, v=vs, n_iter=n_iter)
+        old_state = (dict(msg), rs, vs)
+    return dict(msg=msg, r=rs, v=vs, n_iter=n_iter, status=status)
 
 
 def se_chain(factors, max_iter=200, damping=None, tol=1e-6, a0=0.,
