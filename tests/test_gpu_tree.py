@@ -233,7 +233,9 @@ def test_tree_ep_per_instance_stopping_on_the_device(ctx, golden_tree):
             close(data["x"]["r"][b], runs[b]["r"]["x"].ravel(), 1e-7, 1e-8)
             close(data["z"]["r"][b], runs[b]["r"]["z"].ravel(), 1e-7, 1e-8)
             close(data["x"]["v"][b], runs[b]["v"]["x"], 1e-7)
-        outs.append((ep.n_iter_instance.copy(), data["x"]["r"].copy(), {k: ep.get_message(*k)[1].copy() for k in ep.msg}))
+        name = lambda n: getattr(n, "id", None) or type(n).__name__                     # noqa: E731
+        outs.append((ep.n_iter_instance.copy(), data["x"]["r"].copy(),
+                     {(name(s_), name(t_)): ep.get_message(s_, t_)[1].copy() for (s_, t_) in ep.msg}))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     for k in outs[0][2]:
         assert np.array_equal(outs[0][2][k], outs[1][2][k])
