@@ -33,6 +33,26 @@ if [ "$WHAT" = fused ] || [ "$WHAT" = all ]; then
   # kernel durations of the producer with and without the fused moments, and of the consumer's single pass
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fused_trace -- python3 tools/bench_fused.py f64 > $OUT/fused_trace.out 2>&1
 fi
+# the default bench also runs auxiliary figures with the same kernels at other shapes (the 512-instance ensemble, the
+# N = 1000 time-to-solution runs): per (kernel, grid) statistics keep the headline's launches apart
+python3 - "$OUT" <<'PY'
+import collections, csv, glob, os, sys
+out = sys.argv[1]
+fs = sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+if fs:
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[-1])):
+        name = r["Kernel_Name"]
+        if not any(k in name for k in ("gemm_n", "mfma_fold", "gemv_n", "nn_fold", "ew_", "var_post", "lin_", "ep_", "damp")):
+            continue
+        grid = "x".join(r.get(k, "") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+        agg[(name.split("(")[0][:90], grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(out, "kernel_stats_by_grid.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_threads", "calls", "avg_ns", "min_ns", "max_ns", "total_ns"])
+        for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, g, len(v), sum(v) / len(v), min(v), max(v), sum(v)])
+PY
 for d in $OUT/pmc_*; do echo "== $d"; python3 tools/pmc_parse.py $d 2>/dev/null | cut -c1-500; done > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
 find $OUT -name "*counter_collection.csv" -size +8M -delete
