@@ -75,6 +75,7 @@ TM_HD float fma_(float a, float b, float c) { return ::fmaf(a, b, c); }
 #if defined(__HIP_DEVICE_COMPILE__)
 }  // namespace tmath
 #include "erfcx_table.h"
+#include "erfcx_utable.h"
 namespace tmath {
 __device__ __forceinline__ double exp_clamped(double x);
 __device__ __forceinline__ double rcp_pos(double x);
@@ -86,9 +87,25 @@ __device__ __forceinline__ float exp_clamped(float x);
 // pace: 487 us for the 109-instruction sign likelihood against 280 us for the 163-instruction abs one.)
 // Every kernel that evaluates erfcx_hot calls erfcx_lds_init() first (all threads; it ends in a barrier).
 __shared__ double g_erfcx_lds[(kErfcxD + 1) * kErfcxK];
+// Round 3: a second table on a UNIFORM grid of x in [-3, 8) (erfcx_utable.h: 352 intervals of 1/32, degree 7, 22 KiB of
+// LDS): the interval comes from one fma and a conversion - no reciprocal - and negative arguments need no exp(x^2),
+// 23 instructions per evaluation instead of 31 (x >= 0) + 24 (x < 0, both run in every wave).  Taken when every lane
+// of the wave is inside the grid, else the whole wave evaluates the reciprocal-mapped table below.  Rows that differ
+// by a multiple of 32 share a bank pair (any 32 of 352 rows collide somewhere): the reads take 2-3 passes, on a pipe
+// the VALU-bound kernels do not otherwise use.  TRAMP_ERFCX_UNIFORM=0 at build time (-DTRAMP_ERFCX_UNIFORM=0) removes it.
+#ifndef TRAMP_ERFCX_UNIFORM
+#define TRAMP_ERFCX_UNIFORM 1
+#endif
+#if TRAMP_ERFCX_UNIFORM
+__shared__ double g_erfcx_ulds[(kErfcxUD + 1) * kErfcxUK];
+#endif
 __device__ __forceinline__ void erfcx_lds_init() {
     for (int i = threadIdx.x; i < (kErfcxD + 1) * kErfcxK; i += blockDim.x)
         g_erfcx_lds[i] = kErfcxTable[i % kErfcxK][i / kErfcxK];
+#if TRAMP_ERFCX_UNIFORM
+    for (int i = threadIdx.x; i < (kErfcxUD + 1) * kErfcxUK; i += blockDim.x)
+        g_erfcx_ulds[i] = kErfcxUTable[i % kErfcxUK][i / kErfcxUK];
+#endif
     __syncthreads();
 }
 // f32 kernels: their own table (degree 4, 4-byte entries: the 32 rows sit in 32 different banks)
@@ -99,6 +116,18 @@ __device__ __forceinline__ void erfcx_lds_init_f() {
     __syncthreads();
 }
 __device__ __forceinline__ double erfcx_hot(double x) {
+#if TRAMP_ERFCX_UNIFORM
+    if (TM_WAVE_ALL(x >= kErfcxULo && x < kErfcxUHi)) {      // a NaN fails the test: the wave takes the general path
+        const double tk = ::fma(x, kErfcxUPer, -kErfcxULo * kErfcxUPer);      // in [0, K)
+        const int k = min((int)tk, kErfcxUK - 1);
+        const double s = ::fma(2.0, tk - (double)k, -1.0);
+        const double* p = g_erfcx_ulds + k;
+        double acc = p[kErfcxUD * kErfcxUK];
+#pragma unroll
+        for (int j = kErfcxUD - 1; j >= 0; --j) acc = ::fma(acc, s, p[j * kErfcxUK]);
+        return acc;
+    }
+#endif
     const double w = ::fmin(::fabs(x), 1e300);                // erfcx(1e300) = 5.6e-301; a NaN x reaches the caller through x itself
     const double t = 4.0 * rcp_pos(4.0 + w);
     const double tk = t * (double)kErfcxK;
