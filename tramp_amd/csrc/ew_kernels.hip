@@ -193,7 +193,7 @@ template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 
         const double z = az[b], x = ax[b];
         c = tmath::pwl_const<T, KIND>(z, x, spec);
         a_msg = FWD ? x : z;
-        tmath::erfcx_setup<T>();
+        tmath::erfcx_setup<T, true>();
     }
     __device__ EwOut<T> eval(T x0, T x1) const {
         tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD>(x0, x1, c);

@@ -92,19 +92,22 @@ __shared__ double g_erfcx_lds[(kErfcxD + 1) * kErfcxK];
 // 23 instructions per evaluation instead of 31 (x >= 0) + 24 (x < 0, both run in every wave).  Taken when every lane
 // of the wave is inside the grid, else the whole wave evaluates the reciprocal-mapped table below.  Rows that differ
 // by a multiple of 32 share a bank pair (any 32 of 352 rows collide somewhere): the reads take 2-3 passes, on a pipe
-// the VALU-bound kernels do not otherwise use.  TRAMP_ERFCX_UNIFORM=0 at build time (-DTRAMP_ERFCX_UNIFORM=0) removes it.
+// the VALU-bound kernels do not otherwise use.  Used by the two-region channels K7 (erfcx_hot<true>: 64 x 1e6 f64
+// 0.72-0.78 -> 0.63-0.71 ms); the sign likelihood, one evaluation per pass and closer to the memory bound, is faster
+// on the small conflict-free table (580 against 619 us) and keeps it.  -DTRAMP_ERFCX_UNIFORM=0 removes the grid table.
 #ifndef TRAMP_ERFCX_UNIFORM
 #define TRAMP_ERFCX_UNIFORM 1
 #endif
 #if TRAMP_ERFCX_UNIFORM
 __shared__ double g_erfcx_ulds[(kErfcxUD + 1) * kErfcxUK];
 #endif
-__device__ __forceinline__ void erfcx_lds_init() {
+template <bool UNI = false> __device__ __forceinline__ void erfcx_lds_init() {
     for (int i = threadIdx.x; i < (kErfcxD + 1) * kErfcxK; i += blockDim.x)
         g_erfcx_lds[i] = kErfcxTable[i % kErfcxK][i / kErfcxK];
 #if TRAMP_ERFCX_UNIFORM
-    for (int i = threadIdx.x; i < (kErfcxUD + 1) * kErfcxUK; i += blockDim.x)
-        g_erfcx_ulds[i] = kErfcxUTable[i % kErfcxUK][i / kErfcxUK];
+    if (UNI)
+        for (int i = threadIdx.x; i < (kErfcxUD + 1) * kErfcxUK; i += blockDim.x)
+            g_erfcx_ulds[i] = kErfcxUTable[i % kErfcxUK][i / kErfcxUK];
 #endif
     __syncthreads();
 }
@@ -115,9 +118,9 @@ __device__ __forceinline__ void erfcx_lds_init_f() {
         g_erfcx_lds_f[i] = kErfcxTableF[i % kErfcxKF][i / kErfcxKF];
     __syncthreads();
 }
-__device__ __forceinline__ double erfcx_hot(double x) {
+template <bool UNI = false> __device__ __forceinline__ double erfcx_hot(double x) {
 #if TRAMP_ERFCX_UNIFORM
-    if (TM_WAVE_ALL(x >= kErfcxULo && x < kErfcxUHi)) {      // a NaN fails the test: the wave takes the general path
+    if (UNI && TM_WAVE_ALL(x >= kErfcxULo && x < kErfcxUHi)) {      // a NaN fails the test: the wave takes the general path
         const double tk = ::fma(x, kErfcxUPer, -kErfcxULo * kErfcxUPer);      // in [0, K)
         const int k = min((int)tk, kErfcxUK - 1);
         const double s = ::fma(2.0, tk - (double)k, -1.0);
@@ -143,7 +146,7 @@ __device__ __forceinline__ double erfcx_hot(double x) {
 }
 // f32: the same construction on the float table (4e-7 relative for x >= 0, a few ulp of float; the library's
 // erfcxf is ~45 instructions)
-__device__ __forceinline__ float erfcx_hot(float x) {
+template <bool UNI = false> __device__ __forceinline__ float erfcx_hot(float x) {
     const float w = ::fminf(::fabsf(x), 1e37f);
     const float t = 4.0f * __builtin_amdgcn_rcpf(4.0f + w);
     const float tk = t * (float)kErfcxKF;
@@ -158,13 +161,14 @@ __device__ __forceinline__ float erfcx_hot(float x) {
     return e;
 }
 #else
-TM_HD double erfcx_hot(double x) { return erfcx_(x); }      // host pass / plain C++ (tests/host_math)
-TM_HD float erfcx_hot(float x) { return erfcx_(x); }
+template <bool UNI = false> TM_HD double erfcx_hot(double x) { return erfcx_(x); }      // host pass / plain C++ (tests/host_math)
+template <bool UNI = false> TM_HD float erfcx_hot(float x) { return erfcx_(x); }
 #endif
-// Called by all threads of a block before the first erfcx_hot<T> (Op::setup): stages the f64 table in LDS.
-template <typename T> TM_HD void erfcx_setup() {
+// Called by all threads of a block before the first erfcx_hot (Op::setup): stages the table(s) in LDS.
+// UNI: also the uniform-grid table that erfcx_hot<true> reads.
+template <typename T, bool UNI = false> TM_HD void erfcx_setup() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (sizeof(T) == 8) erfcx_lds_init();
+    if (sizeof(T) == 8) erfcx_lds_init<UNI>();
     else erfcx_lds_init_f();
 #endif
 }
@@ -424,7 +428,7 @@ TM_HD HalfLineF<T> halfline_factor(T b, const RegionConst<T>& c, int side, T& r0
         y0 = (zb - r0) / c.s0;
     }
     T x = sd * (y0 * T(0.70710678118654752440));
-    T e = erfcx_hot(x);
+    T e = erfcx_hot<true>(x);
     T ie = rcp_pos(fmin_(e, RcpCap<T>::value));       // e = inf (x << 0) -> ~0; NaN travels through x and r0
     T g1 = T(kSqrt2OverPi) * (sd * ie);
     T g2 = T(kTwoOverSqrtPi) * (x * ie);
