@@ -307,10 +307,31 @@ extern "C" int tramp_d2h(tramp_ctx* ctx, void* dst_h, const void* src_d, size_t 
     return TRAMP_OK;
 }
 
+// device-to-device copy as a KERNEL on the context's stream (16-byte pieces, tail by bytes): the schedulers copy
+// messages between launches (variable -> factor relays on a tree, the per-iteration snapshot of restore_messages) and a
+// hipMemcpyAsync in the middle of a kernel sequence goes through the copy engine and its cross-queue signals
+__global__ __launch_bounds__(256) void d2d_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16,
+                                                   unsigned char* __restrict__ dtail, const unsigned char* __restrict__ stail,
+                                                   unsigned ntail) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < ntail) dtail[threadIdx.x] = stail[threadIdx.x];
+}
+
 extern "C" int tramp_d2d(tramp_ctx* ctx, void* dst_d, const void* src_d, size_t bytes) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, (dst_d && src_d) || bytes == 0);
     if (!bytes) return TRAMP_OK;
+    if (((uintptr_t)dst_d | (uintptr_t)src_d) % 16 == 0) {
+        const size_t n16 = bytes / 16;
+        const unsigned ntail = (unsigned)(bytes % 16);
+        size_t g = (n16 + 255) / 256;
+        if (g > 65536) g = 65536;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(d2d_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, (uint4*)dst_d, (const uint4*)src_d, n16,
+                           (unsigned char*)dst_d + n16 * 16, (const unsigned char*)src_d + n16 * 16, ntail);
+        TRAMP_LAUNCH_CHECK(ctx);
+        return TRAMP_OK;
+    }
     TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(dst_d, src_d, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return TRAMP_OK;
 }
