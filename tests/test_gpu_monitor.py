@@ -168,3 +168,25 @@ def test_nan_restores_the_previous_messages(T, ctx):
         a, b = ep.get_message(v, d)
         np.testing.assert_array_equal(a, a_ref)
         np.testing.assert_array_equal(b, b_ref)
+
+
+def test_device_array_dropped_during_capture_does_not_invalidate_it(T, ctx):
+    """Python may garbage-collect a device array at any moment, also between tramp_graph_begin and tramp_graph_end:
+    its free (a stream synchronisation + hipFree) waits for the end of the capture instead of invalidating it."""
+    import ctypes as C
+    a, b = ctx.zeros((4, 1000)), ctx.zeros((4, 1000))
+    victim = ctx.zeros((8, 4096))
+    b.copy_from(a)
+    ctx.sync()
+    ctx._call("tramp_graph_begin")
+    try:
+        a.fill(2.0)
+        del victim                                   # -> DeviceArray.__del__ -> tramp_buf_free inside the capture
+        b.copy_from(a)
+    finally:
+        g = C.c_void_p()
+        ctx._call("tramp_graph_end", C.byref(g))
+    ctx._call("tramp_graph_launch", g)
+    ctx.sync()
+    ctx._call("tramp_graph_destroy", g)
+    assert np.all(b.get() == 2.0)

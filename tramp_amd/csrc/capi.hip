@@ -1,6 +1,9 @@
 // capi.hip - context, device memory and timing entry points of the C ABI.
 #include "common.h"
 #include "prior_hint.h"
+#include <stdlib.h>
+
+static void flush_deferred_frees(tramp_ctx* ctx);
 
 extern "C" const char* tramp_version(void) { return "tramp_hip 0.1 (gfx950)"; }
 
@@ -58,6 +61,8 @@ extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    flush_deferred_frees(ctx);
+    free(ctx->deferred_free);
     if (ctx->hint_ws) (void)hipFree(ctx->hint_ws);
     if (ctx->hscratch) (void)hipHostFree(ctx->hscratch);
     if (ctx->prof) {
@@ -95,6 +100,7 @@ extern "C" int tramp_graph_end(tramp_ctx* ctx, tramp_graph** out) {
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(ctx->stream, &g);
     ctx->capturing = false;
+    flush_deferred_frees(ctx);
     if (e != hipSuccess || !g) {
         (void)hipGetLastError();
         return tramp_fail(ctx, TRAMP_EHIP, "hipStreamEndCapture", hipGetErrorString(e));
@@ -280,9 +286,28 @@ extern "C" int tramp_buf_alloc(tramp_ctx* ctx, size_t bytes, void** dptr) {
     return TRAMP_OK;
 }
 
+static void flush_deferred_frees(tramp_ctx* ctx) {
+    if (!ctx->deferred_n) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < ctx->deferred_n; ++i) (void)hipFree(ctx->deferred_free[i]);
+    ctx->deferred_n = 0;
+}
+
 extern "C" int tramp_buf_free(tramp_ctx* ctx, void* dptr) {
     if (!ctx) return TRAMP_EINVAL;
     if (!dptr) return TRAMP_OK;
+    if (ctx->capturing) {
+        // inside tramp_graph_begin / _end: a synchronisation or a free here would invalidate the capture
+        if (ctx->deferred_n == ctx->deferred_cap) {
+            const int cap = ctx->deferred_cap ? 2 * ctx->deferred_cap : 64;
+            void** p = (void**)realloc(ctx->deferred_free, (size_t)cap * sizeof(void*));
+            if (!p) return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_buf_free", "deferred list");
+            ctx->deferred_free = p;
+            ctx->deferred_cap = cap;
+        }
+        ctx->deferred_free[ctx->deferred_n++] = dptr;
+        return TRAMP_OK;
+    }
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     TRAMP_HIP_CHECK(ctx, hipFree(dptr));
     return TRAMP_OK;

@@ -62,6 +62,10 @@ struct tramp_ctx {
     // launch shape of the last MFMA matrix pass (tramp_matvec_last_launch): split-K factor, 64-instance chunks,
     // whether sibling chunks were interleaved in a one-dimensional grid
     int last_nsplit, last_nchunk, last_flat;
+    // buffers released while a stream capture is open (the host language's garbage collector may drop a device array at
+    // any moment): hipStreamSynchronize / hipFree would invalidate the capture, so they wait for tramp_graph_end
+    void** deferred_free;
+    int deferred_n, deferred_cap;
 };
 
 // RAII scope: records start/stop events on the context's stream when profiling is on.
