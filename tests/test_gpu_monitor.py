@@ -176,12 +176,15 @@ def test_device_array_dropped_during_capture_does_not_invalidate_it(T, ctx):
     import ctypes as C
     a, b = ctx.zeros((4, 1000)), ctx.zeros((4, 1000))
     victim = ctx.zeros((8, 4096))
+    channel = T.LinearChannel(np.random.RandomState(0).randn(6, 9), ctx=ctx, svd="host")
+    event = ctx.event()
     b.copy_from(a)
     ctx.sync()
     ctx._call("tramp_graph_begin")
     try:
         a.fill(2.0)
         del victim                                   # -> DeviceArray.__del__ -> tramp_buf_free inside the capture
+        del channel, event                           # -> tramp_linear_destroy / tramp_event_destroy: held until the end
         b.copy_from(a)
     finally:
         g = C.c_void_p()

@@ -599,8 +599,7 @@ class LinearChannel(Channel):
 
     def __del__(self):
         try:
-            if self._handle and self.ctx.handle:
-                self.ctx.lib.tramp_linear_destroy(self.ctx.handle, self._handle)
+            self.ctx.release("tramp_linear_destroy", self._handle)
         except Exception:
             pass
         self._handle = None
@@ -789,8 +788,7 @@ class ConvChannel(Channel):
 
     def __del__(self):
         try:
-            if self._handle and self.ctx.handle:
-                self.ctx.lib.tramp_conv_destroy(self.ctx.handle, self._handle)
+            self.ctx.release("tramp_conv_destroy", self._handle)
         except Exception:
             pass
         self._handle = None
@@ -1041,8 +1039,7 @@ class GradientChannel(Channel):
 
     def __del__(self):
         try:
-            if self._handle and self.ctx.handle:
-                self.ctx.lib.tramp_grad_destroy(self.ctx.handle, self._handle)
+            self.ctx.release("tramp_grad_destroy", self._handle)
         except Exception:
             pass
         self._handle = None
@@ -1191,8 +1188,7 @@ class DFTChannel(_UnitaryChannel):
 
     def __del__(self):
         try:
-            if self._handle and self.ctx.handle:
-                self.ctx.lib.tramp_dft_destroy(self.ctx.handle, self._handle)
+            self.ctx.release("tramp_dft_destroy", self._handle)
         except Exception:
             pass
         self._handle = None

@@ -40,8 +40,7 @@ class Event:
 
     def __del__(self):
         try:
-            if self.handle and self.ctx.handle:
-                self.ctx.lib.tramp_event_destroy(self.ctx.handle, self.handle)
+            self.ctx.release("tramp_event_destroy", self.handle)
         except Exception:
             pass
         self.handle = None
@@ -75,9 +74,39 @@ class Context:
             # HIP's current device is per host thread: switch when this thread last drove another context
             self.lib.tramp_ctx_make_current(self.handle)
             _tls.current = self
-        rc = getattr(self.lib, name)(self.handle, *raw)
+        if name == "tramp_graph_begin":
+            self._capturing = True
+        try:
+            rc = getattr(self.lib, name)(self.handle, *raw)
+        finally:
+            if name == "tramp_graph_end":
+                self._capturing = False
+                self._flush_released()
         if rc != _lib.OK:
+            if name == "tramp_graph_begin":
+                self._capturing = False
             _lib.check(rc, name, self.handle)
+
+    # Destructors of wrapper objects (channel handles, events, communicators) run whenever Python's garbage collector
+    # decides - also in the middle of a stream capture, where their hipFree / synchronisation would invalidate the
+    # capture.  They hand the destroy call to release(): executed at once, or right after tramp_graph_end.
+    _capturing = False
+
+    def release(self, fn_name, handle):
+        if not handle or not self.handle:
+            return
+        if self._capturing:
+            self.__dict__.setdefault("_released", []).append((fn_name, handle))
+        else:
+            getattr(self.lib, fn_name)(self.handle, handle)
+
+    def _flush_released(self):
+        pending, self._released = self.__dict__.get("_released", []), []
+        for fn_name, handle in pending:
+            try:
+                getattr(self.lib, fn_name)(self.handle, handle)
+            except Exception:                   # noqa: BLE001
+                pass
 
     def sync(self):
         self._call("tramp_sync")
