@@ -222,7 +222,7 @@ def time_to_solution_n1000(T, ctx, args):
         model = (T.GaussBernoulliPrior(size=N, rho=rho, ctx=ctx) @ T.SISOVariable(id="x") @ lin
                  @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=y, var=nv, ctx=ctx)).to_model()
         ep = T.ExpectationPropagation(model, ctx=ctx)
-        ep.iterate(max_iter=1000, callback=T.EarlyStoppingEP(tol=1e-6), damping=0.1, check_every=4)
+        ep.iterate(max_iter=1000, callback=T.EarlyStoppingEP(tol=1e-6), damping=0.1, check_every=4, graph=True)
         r = ep.get_variables_data(["x"])["x"]["r"]
         t2 = time.perf_counter()
         if seed:
@@ -238,7 +238,8 @@ def time_to_solution_n1000(T, ctx, args):
             "reference_source": "examples/figures/benchmark.pdf right panel at alpha=0.5 (BASELINE.md section 1; "
                                 "hardware unstated; includes the SVD, benchmark.py:22)",
             "includes": "H2D of W, device factorisation (Gram + rocSOLVER syevd + one GEMM), EP to the stopping "
-                        "rule (device-side monitor, host poll every 4 iterations), D2H of the estimate"}
+                        "rule (device-side monitor, hipGraph replay, host poll every 4 iterations, messages snapshot every "
+                        "iteration for the restore), D2H of the estimate"}
 
 
 def _timed(ctx, fn, reps):
