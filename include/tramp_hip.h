@@ -345,6 +345,28 @@ int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, size_t batc
  * output side passed to or returned by tramp_linear_message / _log_partition is the rotated one, and the
  * two passes over Uk leave the iteration (u = bx', rx' = w).  The caller rotates y once
  * (tramp_matvec_nn on Uk) and rotates results back when read (tramp_matvec_nt on Uk). */
+/* ---- LinearChannel(precompute_svd=False) ---------------------------------------
+ * tramp/channels/linear/linear_channel.py:43-46, 79-82: C = W^T W is kept and (az I + ax C) rz = bz + W^T bx is
+ * solved on every call (np.linalg.solve); spectrum = np.linalg.eigvalsh(C) is ASCENDING and singular = spectrum[:rank]
+ * keeps its smallest `rank` entries (a quirk of the reference that n_eff and the variances inherit; reproduced).
+ * W_d [M, N] row-major in `dtype` is borrowed and must outlive the handle.  create forms C and its spectrum
+ * (read back with tramp_lsolve_spectrum into N host doubles); tramp_lsolve_set_rank passes the rank the caller found
+ * (np.linalg.matrix_rank(W)) and must precede the first message.  tramp_lsolve_message has the argument meaning of
+ * tramp_linear_message (no projection cache).  A matrix that is not positive definite (az = 0 with singular C)
+ * returns TRAMP_EINVAL "singular matrix" (numpy raises LinAlgError there).  Not capturable in a graph; N <= 46336. */
+typedef struct tramp_lsolve tramp_lsolve;
+int tramp_lsolve_create(tramp_ctx* ctx, int dtype, size_t M, size_t N, const void* W_d, tramp_lsolve** out);
+int tramp_lsolve_destroy(tramp_ctx* ctx, tramp_lsolve* ls);
+int tramp_lsolve_spectrum(tramp_ctx* ctx, const tramp_lsolve* ls, double* spectrum_host);
+int tramp_lsolve_set_rank(tramp_ctx* ctx, tramp_lsolve* ls, size_t rank);
+int tramp_lsolve_message(tramp_ctx* ctx, tramp_lsolve* ls, int dir, size_t batch, const double* az_d,
+                         const void* bz_d, const double* ax_d, const void* bx_d, double damping,
+                         const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d, void* r_d,
+                         double* v_d);
+/* log-partition of the channel (linear_channel.py:127-132) with rz from the solve: out_d [batch] */
+int tramp_lsolve_log_partition(tramp_ctx* ctx, tramp_lsolve* ls, size_t batch, const double* az_d, const void* bz_d,
+                               const double* ax_d, const void* bx_d, double* out_d);
+
 /* `on` is a bit mask: 1 = the output side as above; 2 = the INPUT side in the right singular basis
  * (z' = Vt z, k numbers per instance): legitimate behind an isotropic zero-mean GaussianPrior with zero
  * initial messages - the component of z orthogonal to the rows of Vt then stays exactly zero - and removes
@@ -508,6 +530,18 @@ int tramp_fft_order(tramp_ctx* ctx, size_t h, size_t count, unsigned long long* 
 /* average milliseconds of `reps` forward and `reps` inverse transforms (tools/bench_fft.py) */
 int tramp_fft_bench(tramp_ctx* ctx, int dtype, size_t h, size_t batch, int reps, void* in_d, void* out_d,
                     double* ms_fwd, double* ms_inv);
+/* The same engine in 1-3 dimensions (what the 2-D / 3-D convolution and gradient channels run:
+ * conv_channel.py:81-109, gradient_channel.py:56-76 call np.fft.fftn there).  real_dims[ndim]: shape of the REAL
+ * signal (last axis even); data: `batch` packed signals, i.e. complex arrays [d0][d1][n_last / 2] with
+ * z[..][j] = x[..][2j] + i x[..][2j+1].  Forward: every axis transformed, position p of axis a holding frequency
+ * kfreq[p] (tramp_fftn_order); inverse (input overwritten): natural order, unnormalised.  ENOTSUP for shapes outside
+ * the engine (an axis not 2^a 5^b, n_last / 2 not a multiple of the 128-byte line); tramp_fftn_supported asks without
+ * a device call (returns 1 / 0). */
+int tramp_fftn(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_dims, size_t batch, int inverse,
+               void* in_d, void* out_d);
+int tramp_fftn_order(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_dims, int axis,
+                     unsigned long long* kfreq_host);
+int tramp_fftn_supported(int dtype, int ndim, const size_t* real_dims);
 
 /* ---- unitary channels: DFT and dense rotation ------------------------------- */
 /* DFTChannel (tramp/channels/linear/dft_channel.py:7-77, real=True): x = fftn(z, norm="ortho").

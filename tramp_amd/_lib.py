@@ -97,6 +97,12 @@ _SIGNATURES = {
     "tramp_grad_apply": [vp, vp, sz, vp, vp],
     "tramp_grad_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_linear_set_rotated": [vp, vp, i32],
+    "tramp_lsolve_create": [vp, i32, sz, sz, vp, C.POINTER(vp)],
+    "tramp_lsolve_destroy": [vp, vp],
+    "tramp_lsolve_spectrum": [vp, vp, vp],
+    "tramp_lsolve_set_rank": [vp, vp, sz],
+    "tramp_lsolve_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_lsolve_log_partition": [vp, vp, sz, vp, vp, vp, vp, vp],
     "tramp_linear_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_conv_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_dft_create": [vp, i32, i32, C.POINTER(sz), C.POINTER(vp)],
@@ -107,6 +113,9 @@ _SIGNATURES = {
     "tramp_fft_len": [vp, i32, sz, sz, i32, vp, vp],
     "tramp_fft_order": [vp, sz, sz, vp],
     "tramp_fft_bench": [vp, i32, sz, sz, i32, vp, vp, C.POINTER(dbl), C.POINTER(dbl)],
+    "tramp_fftn": [vp, i32, i32, C.POINTER(sz), sz, i32, vp, vp],
+    "tramp_fftn_order": [vp, i32, i32, C.POINTER(sz), i32, vp],
+    "tramp_fftn_supported": [i32, i32, C.POINTER(sz)],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_linear_set_transposed": [vp, vp, vp, vp],

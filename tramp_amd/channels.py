@@ -511,6 +511,12 @@ class LinearChannel(Channel):
     device: only Uk [M,k], Vt [k,N], sing enter the posterior (see csrc/linear.hip).
     """
 
+    def __new__(cls, W=None, precompute_svd=True, *args, **kwargs):
+        # precompute_svd=False is a different device object (csrc/solve.hip); still a LinearChannel for isinstance
+        if cls is LinearChannel and not precompute_svd:
+            return super().__new__(SolveLinearChannel)
+        return super().__new__(cls)
+
     def __init__(self, W, precompute_svd=True, name="W", dtype=np.float64, ctx=None, svd="auto",
                  factors=None, keep_W=False):
         self.name = name
@@ -518,9 +524,6 @@ class LinearChannel(Channel):
         self.precompute_svd = precompute_svd
         self.repr_init()
         self._init_device(dtype, ctx)
-        if not precompute_svd:
-            raise NotImplementedError("the per-call np.linalg.solve branch (linear_channel.py:79-82) "
-                                      "is not part of the HIP path; use precompute_svd=True")
         self.alpha = self.Nx / self.Nz
         ctx = self.ctx
         k = min(self.Nx, self.Nz)
@@ -747,6 +750,122 @@ class LinearChannel(Channel):
     def compute_backward_message(self, az, bz, ax, bx, **kw):
         t, a, a_new, b_new, _, _ = self._run(_lib.BWD, az, bz, ax, bx, **kw)
         return ret_scal(a_new, a, t), ret_vec(b_new, t)
+
+
+class SolveLinearChannel(LinearChannel):
+    """LinearChannel(W, precompute_svd=False): the reference's branch that keeps C = W^T W and solves
+    (az I + ax C) rz = bz + W^T bx on every call (tramp/channels/linear/linear_channel.py:43-46, 79-82) - on the
+    device one Cholesky factorisation per instance and call (csrc/solve.hip: rocSOLVER potrf / potrs), the matrix
+    products on W itself by the channel's own matrix kernels.  Built by ``LinearChannel(W, precompute_svd=False)``.
+
+    As in the reference ``spectrum = eigvalsh(C)`` is ASCENDING here and ``singular = spectrum[:rank]`` keeps its
+    first - smallest - ``rank`` entries; n_eff and the variances follow that array, so for Nz > rank they differ
+    from the precompute_svd=True channel exactly as the reference's two branches differ.  ``rank`` is
+    np.linalg.matrix_rank(W) for a host array; for a device-resident W it is counted from the spectrum
+    (sigma > sigma_max * max(M, N) * eps, resolved only down to ~1e-8 sigma_max by the Gram form).
+    The scheduler never rotates this channel into a singular basis and cannot capture it in a hipGraph."""
+
+    def __init__(self, W, precompute_svd=False, name="W", dtype=np.float64, ctx=None, svd="auto", factors=None,
+                 keep_W=True):
+        if precompute_svd:
+            raise ValueError("SolveLinearChannel is the precompute_svd=False branch")
+        self.name = name
+        self.Nx, self.Nz = (int(s) for s in W.shape)
+        self.precompute_svd = False
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.alpha = self.Nx / self.Nz
+        ctx = self.ctx
+        on_dev = isinstance(W, DeviceArray)
+        self._Wd = W if on_dev and W.dtype == self.dtype else (
+            W.astype(self.dtype) if on_dev else ctx.array(np.asarray(W, dtype=self.dtype), self.dtype))
+        self.W = W
+        h = C.c_void_p()
+        ctx._call("tramp_lsolve_create", self._dt, self.Nx, self.Nz, self._Wd.ptr, C.byref(h))
+        self._handle = h
+        spec = (C.c_double * self.Nz)()
+        ctx._call("tramp_lsolve_spectrum", self._handle, spec)
+        self.spectrum = np.frombuffer(spec, dtype=np.float64).copy()            # ascending (:44)
+        if on_dev:
+            s = np.sqrt(np.maximum(self.spectrum, 0.0))
+            self.rank = int(np.sum(s > s.max() * max(self.Nx, self.Nz) * np.finfo(np.float64).eps))
+        else:
+            self.rank = int(np.linalg.matrix_rank(np.asarray(W, dtype=np.float64)))   # :37
+        ctx._call("tramp_lsolve_set_rank", self._handle, self.rank)
+        self.singular = self.spectrum[:self.rank]                               # :46
+        self._t_key = self._u_key = None
+        self._Vtt = self._Ukt = None
+
+    def __del__(self):
+        try:
+            self.ctx.release("tramp_lsolve_destroy", self._handle)
+        except Exception:
+            pass
+        self._handle = None
+
+    def sample(self, Z):
+        W = self.W.get() if isinstance(self.W, DeviceArray) else self.W
+        return W @ Z
+
+    def device_variance(self, direction, az, ax):
+        "(v, a_new, n_eff) from the reference's closed forms over `singular` (linear_channel.py:58-67, 91-105)"
+        az = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        ax = np.broadcast_to(np.asarray(ax, dtype=np.float64), az.shape)
+        v, a_new, n_eff = np.empty_like(az), np.empty_like(az), np.empty_like(az)
+        for i, (a_z, a_x) in enumerate(zip(az, ax)):
+            azc = max(1e-11, a_z) if direction == _lib.BWD else a_z
+            if a_x == 0:
+                ne = 0.0
+            elif azc / a_x == 0:
+                ne = self.rank / self.Nz
+            else:
+                ne = float(np.sum(self.singular / (azc / a_x + self.singular))) / self.Nz
+            if direction == _lib.BWD:
+                vi, a_in = (1 - ne) / azc, a_z
+            elif a_x == 0:
+                vi, a_in = float(np.mean(self.singular)) * self.rank / (self.Nx * a_z), a_x
+            else:
+                vi, a_in = ne / (self.alpha * a_x), a_x
+            v[i], n_eff[i] = vi, ne
+            a_new[i] = self.compute_a_new(vi, a_in)
+        return [v, a_new, n_eff]
+
+    def _run(self, direction, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None,
+             want_posterior=False):
+        ctx = self.ctx
+        z = VecArg(ctx, bz, self.dtype)
+        x = VecArg(ctx, bx, self.dtype)
+        if z.n != self.Nz or x.n != self.Nx or z.batch != x.batch:
+            raise ValueError(f"expected bz [batch,{self.Nz}] and bx [batch,{self.Nx}], "
+                             f"got {z.dev.shape} and {x.dev.shape}")
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
+        a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((tgt.batch, tgt.n), self.dtype)
+        r = ctx.empty((tgt.batch, tgt.n), self.dtype) if want_posterior else None
+        v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        ctx._call("tramp_lsolve_message", self._handle, direction, z.batch, a_z.dev.ptr, z.dev.ptr, a_x.dev.ptr,
+                  x.dev.ptr, float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr,
+                  r.ptr if r is not None else None, v.ptr if v is not None else None)
+        return tgt, a_t, a_new, b_new, r, v
+
+    def compute_log_partition(self, az, bz, ax, bx):
+        "linear_channel.py:127-132 with rz from the solve"
+        ctx = self.ctx
+        z = VecArg(ctx, bz, self.dtype)
+        x = VecArg(ctx, bx, self.dtype)
+        a_z = ScalArg(ctx, az, z.batch)
+        a_x = ScalArg(ctx, ax, z.batch)
+        out = ctx.empty((z.batch,), np.float64)
+        ctx._call("tramp_lsolve_log_partition", self._handle, z.batch, a_z.dev.ptr, z.dev.ptr, a_x.dev.ptr, x.dev.ptr,
+                  out.ptr)
+        res = out.get()
+        return float(res[0]) if (a_z.was_host and a_z.scalar_like and z.was_host and len(z.host_shape) == 1) else res
+
+    def affine_update(self, side, old_key, msg, c, damping, token=None):
+        return False                                                          # no cached projections to carry along
 
 
 class ConvChannel(Channel):

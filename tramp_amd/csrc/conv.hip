@@ -65,6 +65,14 @@ struct tramp_conv {
     size_t nlead;
     bool lines_closed;
     void* wk;                   // [h] unpack twiddle exp(-2 pi i kfreq(p) / n)
+    // own engine in 2 / 3 dimensions (and short 1-D signals): FftNdPlan, every axis in its own permuted order; the
+    // tables above hold [D][h] filter bins (D = 1, or the d filters of the gradient channel), wk [hl] by last-axis
+    // position, plus the last-axis Nyquist bins of every outer position
+    FftNdPlan* fftn;
+    size_t hl;                  // n_last / 2
+    int ncomp;                  // D
+    void* wbar_nq;              // [D][h / hl] complex
+    double* s2_nq;              // [h / hl]
     void* fzc;                  // transforms of the constant part of a damped constant message
     void* fxc;
     bool fzc_valid, fxc_valid;
@@ -447,6 +455,12 @@ void conv_free_fft2(tramp_conv* cv) {
     if (cv->leaders) (void)hipFree(cv->leaders);
     cv->leaders = nullptr;
     if (cv->wk) (void)hipFree(cv->wk);
+    if (cv->fftn) fftnd_plan_destroy(cv->fftn);
+    if (cv->wbar_nq) (void)hipFree(cv->wbar_nq);
+    if (cv->s2_nq) (void)hipFree(cv->s2_nq);
+    cv->fftn = nullptr;
+    cv->wbar_nq = nullptr;
+    cv->s2_nq = nullptr;
     cv->fft2 = nullptr;
     cv->wbar_p = cv->wk = nullptr;
     cv->s2_p = nullptr;
@@ -527,14 +541,252 @@ int conv_setup_fft2(tramp_ctx* ctx, tramp_conv* cv, const double2* w64, const st
     return TRAMP_OK;
 }
 
+// ---- spectral solve on the permuted packed spectrum in any number of dimensions, D filter components.
+// The packed image z[..][j] = x[..][2j] + i x[..][2j+1] has the complex transform Z = E + i O (E, O: transforms of the even
+// and odd columns, period hl in the last frequency), X[k] = E[k] + w^kl O[k].  With q = (-k_outer, hl - kl):
+// conj Z[q] = E[k] - i O[k], so the pair (position p of k, partner position of q) untangles as in one dimension.  In the
+// column kl = 0 the partner is (-k_outer, 0) and the pair carries FOUR bins: (k_outer, 0), (k_outer, hl) and the two of
+// -k_outer (w = 1 and w = -1); the Nyquist bins of the filters sit in their own small tables.
+//   rz = (fz + sum_c t_c fx_c) / (az + ax s);  mode 0: out_c = conj(t_c) rz, 1: out = rz, 2: out_c = conj(t_c) fz
+template <typename T, int D>
+__device__ __forceinline__ void spectral_bin_nd(int mode, typename Cx<T>::type xz, const typename Cx<T>::type* xx,
+                                                const typename Cx<T>::type* t, double s, double az, double ax, double inv,
+                                                typename Cx<T>::type* out) {
+    using C = typename Cx<T>::type;
+    C rz = xz;
+    T res = (T)inv;
+    if (mode != 2) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const C wx = cx_mul(t[c], xx[c]);
+            rz.x += wx.x;
+            rz.y += wx.y;
+        }
+        res = (T)(inv / (az + ax * s));
+    }
+    rz.x *= res;
+    rz.y *= res;
+    if (mode == 1) {
+        out[0] = rz;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) out[c] = cx_mul(cx_conj(t[c]), rz);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void spectral_perm_nd_kernel(
+    int mode, size_t h, size_t hl, double inv_h, const typename Cx<T>::type* __restrict__ wbar_p,
+    const typename Cx<T>::type* __restrict__ wbar_nq, const double* __restrict__ s2_p, const double* __restrict__ s2_nq,
+    const int* __restrict__ partner, const typename Cx<T>::type* __restrict__ wk, const double* __restrict__ az_d,
+    const double* __restrict__ ax_d, const typename Cx<T>::type* __restrict__ fz,
+    const typename Cx<T>::type* __restrict__ fx, typename Cx<T>::type* __restrict__ fo, size_t batch, int ipb) {
+    using C = typename Cx<T>::type;
+    const size_t b_lo = (size_t)blockIdx.y * ipb;
+    const size_t b_hi = (b_lo + ipb < batch) ? b_lo + ipb : batch;
+    const size_t nrow = h / hl;
+    const int nout = (mode == 1) ? 1 : D;
+    const C zero = {};
+    auto unpack = [](C a, C bq, C tw) {           // ((a + conj b) - i tw (a - conj b)) / 2
+        const C cb = cx_conj(bq);
+        C sum = {a.x + cb.x, a.y + cb.y}, dif = {a.x - cb.x, a.y - cb.y};
+        const C td = cx_mul(tw, dif);
+        C r = {T(0.5) * (sum.x + td.y), T(0.5) * (sum.y - td.x)};
+        return r;
+    };
+    auto repack = [](C y, C yq, C tw) {           // ((y + conj yq) + i conj(tw) (y - conj yq)) / 2
+        const C cb = cx_conj(yq);
+        C sum = {y.x + cb.x, y.y + cb.y}, dif = {y.x - cb.x, y.y - cb.y};
+        const C td = cx_mul(cx_conj(tw), dif);
+        C r = {T(0.5) * (sum.x - td.y), T(0.5) * (sum.y + td.x)};
+        return r;
+    };
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < h; p += (size_t)gridDim.x * kBlock) {
+        const size_t pp = (size_t)partner[p];
+        if (pp < p) continue;                       // each pair once, by its lower position
+        const bool col0 = (p % hl) == 0;
+        C tp[D], tq[D], tnp[D], tnq[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            tp[c] = wbar_p[(size_t)c * h + p];
+            tq[c] = wbar_p[(size_t)c * h + pp];
+            tnp[c] = tnq[c] = zero;
+        }
+        const double sp = s2_p[p], sq = s2_p[pp];
+        double snp = 0.0, snq = 0.0;
+        C w = {T(1), T(0)};
+        if (col0) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                tnp[c] = wbar_nq[(size_t)c * nrow + p / hl];
+                tnq[c] = wbar_nq[(size_t)c * nrow + pp / hl];
+            }
+            snp = s2_nq[p / hl];
+            snq = s2_nq[pp / hl];
+        } else {
+            w = wk[p % hl];
+        }
+        const C wq = {-w.x, w.y};                  // w^(hl - kl) = -conj(w^kl); in column 0: the Nyquist twiddle -1
+        for (size_t b = b_lo; b < b_hi; ++b) {
+            const double az = (mode == 2) ? 0.0 : az_d[b], ax = (mode == 2) ? 0.0 : ax_d[b];
+            const C zp = fz[b * h + p], zq = fz[b * h + pp];
+            C xp[D], xq[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                xp[c] = (mode == 2) ? zero : fx[(b * D + c) * h + p];
+                xq[c] = (mode == 2) ? zero : fx[(b * D + c) * h + pp];
+            }
+            C xxk[D], xxq[D], yk[D], yq[D];
+            if (!col0) {
+                const C xzk = unpack(zp, zq, w), xzq = unpack(zq, zp, wq);
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    xxk[c] = unpack(xp[c], xq[c], w);
+                    xxq[c] = unpack(xq[c], xp[c], wq);
+                }
+                spectral_bin_nd<T, D>(mode, xzk, xxk, tp, sp, az, ax, inv_h, yk);
+                spectral_bin_nd<T, D>(mode, xzq, xxq, tq, sq, az, ax, inv_h, yq);
+                for (int c = 0; c < nout; ++c) {
+                    fo[(b * nout + c) * h + p] = repack(yk[c], yq[c], w);
+                    if (pp != p) fo[(b * nout + c) * h + pp] = repack(yq[c], yk[c], wq);
+                }
+            } else {
+                // bins (k, 0) and (k, hl) of this row [w = 1, -1], then the same two of the partner row
+                C ya[D], yb[D];
+                for (int side = 0; side < 2; ++side) {
+                    const C a = side ? zq : zp, bq = side ? zp : zq;
+                    const C xz0 = unpack(a, bq, w), xzn = unpack(a, bq, wq);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        xxk[c] = unpack(side ? xq[c] : xp[c], side ? xp[c] : xq[c], w);
+                        xxq[c] = unpack(side ? xq[c] : xp[c], side ? xp[c] : xq[c], wq);
+                    }
+                    spectral_bin_nd<T, D>(mode, xz0, xxk, side ? tq : tp, side ? sq : sp, az, ax, inv_h, ya);
+                    spectral_bin_nd<T, D>(mode, xzn, xxq, side ? tnq : tnp, side ? snq : snp, az, ax, inv_h, yb);
+                    for (int c = 0; c < nout; ++c) {
+                        // Z' = E' + i O',  E' = (Y0 + Yn) / 2,  O' = (Y0 - Yn) / 2
+                        const C e = {T(0.5) * (ya[c].x + yb[c].x), T(0.5) * (ya[c].y + yb[c].y)};
+                        const C o = {T(0.5) * (ya[c].x - yb[c].x), T(0.5) * (ya[c].y - yb[c].y)};
+                        const C zo = {e.x - o.y, e.y + o.x};
+                        fo[(b * nout + c) * h + (side ? pp : p)] = zo;
+                    }
+                    if (pp == p) break;
+                }
+            }
+        }
+    }
+}
+
+// Tables of the N-D own engine.  D components; w64: natural-order half spectra [D][nh] (device, f64), s2h: the (summed)
+// squared modulus [nh] on the host.  conv_1d: the one-dimensional convolution channel keeps its two-pass plan with
+// the fused epilogue when that one applies.
+int conv_setup_fftn(tramp_ctx* ctx, tramp_conv* cv, int D, const double2* w64, const std::vector<double>& s2h) {
+    const char* eng = getenv("TRAMP_CONV_FFT");
+    if (eng && strcmp(eng, "rocfft") == 0) return TRAMP_OK;
+    if (cv->fft2 || !fftnd_supported(cv->dtype, cv->ndim, cv->dims)) return TRAMP_OK;
+    if (cv->n / 2 > 0x7fffffffull) return TRAMP_OK;          // partner table is int
+    int rc = fftnd_plan_create(ctx, cv->dtype, cv->ndim, cv->dims, &cv->fftn);
+    if (rc) return rc;
+    const FftNdPlan* pl = cv->fftn;
+    const size_t h = pl->h, hl = cv->nlast / 2, nrow = h / hl, nh = cv->nh, nhl = cv->nhl;
+    std::vector<double2> wnat((size_t)D * nh);
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(wnat.data(), w64, wnat.size() * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // per axis: frequency of each position and position of each frequency
+    std::vector<size_t> kf[3], pos[3];
+    for (int a = 0; a < cv->ndim; ++a) {
+        const size_t len = pl->dims[a];
+        kf[a].resize(len);
+        pos[a].resize(len);
+        for (size_t i = 0; i < len; ++i) {
+            kf[a][i] = fftnd_kfreq(pl, a, i);
+            pos[a][kf[a][i]] = i;
+        }
+    }
+    const int nd = cv->ndim;
+    std::vector<int> partner(h);
+    std::vector<double> s2p(h), s2n(nrow);
+    std::vector<double2> wp((size_t)D * h), wn((size_t)D * nrow), wk64(hl);
+    for (size_t il = 0; il < hl; ++il) {
+        const double ang = -2.0 * 3.14159265358979323846 * (double)kf[nd - 1][il] / (double)cv->nlast;
+        wk64[il] = double2{cos(ang), sin(ang)};
+    }
+    for (size_t row = 0; row < nrow; ++row) {
+        // outer positions of this row, their frequencies, the natural row index and the partner row
+        size_t rem = row, nat_row = 0, prow = 0, stride_nat = 1, stride_pos = 1;
+        for (int a = nd - 2; a >= 0; --a) {
+            const size_t len = pl->dims[a], i = rem % len, k = kf[a][i];
+            rem /= len;
+            nat_row += k * stride_nat;
+            prow += pos[a][(len - k) % len] * stride_pos;
+            stride_nat *= len;
+            stride_pos *= len;
+        }
+        for (int c = 0; c < D; ++c) wn[(size_t)c * nrow + row] = wnat[(size_t)c * nh + nat_row * nhl + hl];
+        s2n[row] = s2h[nat_row * nhl + hl];
+        for (size_t il = 0; il < hl; ++il) {
+            const size_t kl = kf[nd - 1][il], p = row * hl + il;
+            partner[p] = (int)(prow * hl + pos[nd - 1][(hl - kl) % hl]);
+            for (int c = 0; c < D; ++c) wp[(size_t)c * h + p] = wnat[(size_t)c * nh + nat_row * nhl + kl];
+            s2p[p] = s2h[nat_row * nhl + kl];
+        }
+    }
+    const bool f64 = cv->dtype == TRAMP_F64;
+    const size_t csz = 2 * dtype_size(cv->dtype);
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->wbar_p, (size_t)D * h * csz));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->wbar_nq, (size_t)D * nrow * csz));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->wk, hl * csz));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->s2_p, h * sizeof(double)));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->s2_nq, nrow * sizeof(double)));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->partner, h * sizeof(int)));
+    auto put = [&](void* dst, const std::vector<double2>& src) -> hipError_t {
+        if (f64) return hipMemcpy(dst, src.data(), src.size() * sizeof(double2), hipMemcpyHostToDevice);
+        std::vector<float2> t(src.size());
+        for (size_t i = 0; i < src.size(); ++i) t[i] = float2{(float)src[i].x, (float)src[i].y};
+        return hipMemcpy(dst, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice);
+    };
+    TRAMP_HIP_CHECK(ctx, put(cv->wbar_p, wp));
+    TRAMP_HIP_CHECK(ctx, put(cv->wbar_nq, wn));
+    TRAMP_HIP_CHECK(ctx, put(cv->wk, wk64));
+    TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->s2_p, s2p.data(), h * sizeof(double), hipMemcpyHostToDevice));
+    TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->s2_nq, s2n.data(), nrow * sizeof(double), hipMemcpyHostToDevice));
+    TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->partner, partner.data(), h * sizeof(int), hipMemcpyHostToDevice));
+    cv->h = h;
+    cv->hl = hl;
+    cv->ncomp = D;
+    return TRAMP_OK;
+}
+
+template <typename T, int D>
+void launch_spectral_nd_t(tramp_ctx* ctx, const tramp_conv* cv, int mode, size_t batch, const double* az_d,
+                          const double* ax_d, const void* fz, const void* fx, void* fo) {
+    using C = typename Cx<T>::type;
+    int ipb = 8;
+    while (ipb > 1 && (size_t)grid_for(cv->h) * ((batch + ipb - 1) / ipb) < 2048) ipb >>= 1;
+    dim3 g(grid_for(cv->h), (unsigned)((batch + ipb - 1) / ipb));
+    hipLaunchKernelGGL((spectral_perm_nd_kernel<T, D>), g, dim3(kBlock), 0, ctx->stream, mode, cv->h, cv->hl, 1.0 / cv->h,
+                       (const C*)cv->wbar_p, (const C*)cv->wbar_nq, cv->s2_p, cv->s2_nq, cv->partner, (const C*)cv->wk, az_d,
+                       ax_d, (const C*)fz, (const C*)fx, (C*)fo, batch, ipb);
+}
+
+template <typename T>
+void launch_spectral_nd(tramp_ctx* ctx, const tramp_conv* cv, int mode, size_t batch, const double* az_d,
+                        const double* ax_d, const void* fz, const void* fx, void* fo) {
+    if (cv->ncomp == 1) launch_spectral_nd_t<T, 1>(ctx, cv, mode, batch, az_d, ax_d, fz, fx, fo);
+    else if (cv->ncomp == 2) launch_spectral_nd_t<T, 2>(ctx, cv, mode, batch, az_d, ax_d, fz, fx, fo);
+    else launch_spectral_nd_t<T, 3>(ctx, cv, mode, batch, az_d, ax_d, fz, fx, fo);
+}
+
 // forward transform of [batch, n] reals into the engine's spectrum buffer
 int conv_forward(tramp_ctx* ctx, tramp_conv* cv, ConvPlans* p, size_t batch, const void* in, void* spec) {
     if (cv->fft2) return fft2_forward(ctx, cv->fft2, batch, in, spec);
+    if (cv->fftn) return fftnd_forward(ctx, cv->fftn, batch, in, spec);
     return fft_exec(ctx, p->fwd, p->info_fwd, in, spec);
 }
 
 int conv_inverse(tramp_ctx* ctx, tramp_conv* cv, ConvPlans* p, size_t batch, void* spec, void* out) {
     if (cv->fft2) return fft2_inverse(ctx, cv->fft2, batch, spec, out);
+    if (cv->fftn) return fftnd_inverse(ctx, cv->fftn, batch, spec, out);
     return fft_exec(ctx, p->inv, p->info_inv, spec, out);
 }
 
@@ -552,6 +804,8 @@ void launch_spectral(tramp_ctx* ctx, tramp_conv* cv, int mode, size_t batch, con
                            (const C*)cv->wbar_p, cv->s2_p, cv->wbar_nyq, cv->s2_nyq, cv->partner, cv->leaders, cv->nlead,
                            cv->lines_closed ? 1 : 0, (const C*)cv->wk, az_d, ax_d, (const C*)cv->fz, (const C*)cv->fx, (C*)cv->fo,
                            batch, ipb);
+    } else if (cv->fftn) {
+        launch_spectral_nd<T>(ctx, cv, mode, batch, az_d, ax_d, cv->fz, cv->fx, cv->fo);
     } else {
         dim3 g(grid_for(cv->nh), (unsigned)batch);
         hipLaunchKernelGGL((conv_spectral_kernel<T>), g, dim3(kBlock), 0, ctx->stream, mode, cv->nh, 1.0 / cv->n,
@@ -589,6 +843,11 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
     cv->wbar = nullptr;
     cv->s2 = nullptr;
     cv->fft2 = nullptr;
+    cv->fftn = nullptr;
+    cv->hl = 0;
+    cv->ncomp = 1;
+    cv->wbar_nq = nullptr;
+    cv->s2_nq = nullptr;
     cv->h = 0;
     cv->wbar_p = nullptr;
     cv->s2_p = nullptr;
@@ -657,6 +916,7 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
     cv->s_mean = (double)(acc / (long double)cv->n);
     // own FFT engine for 1-D power-of-two sizes (TRAMP_CONV_FFT=rocfft keeps the library transforms)
     rc = conv_setup_fft2(ctx, cv, w64, s2h);
+    if (!rc) rc = conv_setup_fftn(ctx, cv, 1, w64, s2h);     // 2-D / 3-D, and short 1-D signals
     if (rc) {
         cleanup(true);
         return rc;
@@ -715,7 +975,7 @@ extern "C" int tramp_conv_apply(tramp_ctx* ctx, tramp_conv* cv, size_t batch, co
     int rc = conv_reserve(ctx, cv, batch);
     if (rc) return rc;
     ConvPlans* p = nullptr;
-    if (!cv->fft2) {
+    if (!cv->fft2 && !cv->fftn) {
         rc = plans_for(ctx, cv, batch, &p);
         if (rc) return rc;
     }
@@ -751,14 +1011,14 @@ extern "C" int tramp_conv_project_affine(tramp_ctx* ctx, tramp_conv* cv, int whi
     const size_t esz = dtype_size(cv->dtype);
     if (c_changed || !valid) {
         ConvPlans* pl = nullptr;
-        int rc = cv->fft2 ? TRAMP_OK : plans_for(ctx, cv, batch, &pl);
+        int rc = (cv->fft2 || cv->fftn) ? TRAMP_OK : plans_for(ctx, cv, batch, &pl);
         if (rc) return rc;
         ProfScope ps(ctx, PROF_FFT, (double)batch * (cv->n * esz + cv->nh * 2 * esz), 0);
         rc = conv_forward(ctx, cv, pl, batch, c_d, pc);
         if (rc) return rc;
         valid = true;
     }
-    const size_t count = batch * (cv->fft2 ? cv->h : cv->nh) * 2;      // real and imaginary parts alike
+    const size_t count = batch * ((cv->fft2 || cv->fftn) ? cv->h : cv->nh) * 2;      // real and imaginary parts alike
     ProfScope ps(ctx, PROF_LIN_SCALARS, 3.0 * count * esz, 0);
     if (cv->dtype == TRAMP_F64)
         hipLaunchKernelGGL((conv_axpby_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, count,
@@ -785,7 +1045,7 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     if (cv->work != work_before || cv->proj_batch != batch) reuse = 0;
     cv->proj_batch = batch;
     ConvPlans* p = nullptr;
-    if (!cv->fft2) {
+    if (!cv->fft2 && !cv->fftn) {
         rc = plans_for(ctx, cv, batch, &p);
         if (rc) return rc;
     }
@@ -966,11 +1226,34 @@ int grad_reserve(tramp_ctx* ctx, tramp_grad* g, size_t batch) {
     return TRAMP_OK;
 }
 
+// transforms of `count` signals of the channel's shape (count = batch or batch * d): own engine or rocFFT
+int grad_forward(tramp_ctx* ctx, tramp_grad* g, size_t count, const void* in, void* spec) {
+    tramp_conv* cv = &g->base;
+    if (cv->fftn) return fftnd_forward(ctx, cv->fftn, count, in, spec);
+    ConvPlans* p = nullptr;
+    int rc = plans_for(ctx, cv, count, &p);
+    if (rc) return rc;
+    return fft_exec(ctx, p->fwd, p->info_fwd, in, spec);
+}
+
+int grad_inverse(tramp_ctx* ctx, tramp_grad* g, size_t count, void* spec, void* out) {
+    tramp_conv* cv = &g->base;
+    if (cv->fftn) return fftnd_inverse(ctx, cv->fftn, count, spec, out);
+    ConvPlans* p = nullptr;
+    int rc = plans_for(ctx, cv, count, &p);
+    if (rc) return rc;
+    return fft_exec(ctx, p->inv, p->info_inv, spec, out);
+}
+
 template <typename T>
 void launch_grad_spectral(tramp_ctx* ctx, tramp_grad* g, int mode, size_t batch, const double* az_d,
                           const double* ax_d) {
     using C = typename Cx<T>::type;
     const tramp_conv* cv = &g->base;
+    if (cv->fftn) {
+        launch_spectral_nd<T>(ctx, cv, mode, batch, az_d, ax_d, g->gfz, g->gfx, g->gfo);
+        return;
+    }
     hipLaunchKernelGGL((grad_spectral_kernel<T>), dim3(grid_for(cv->nh), (unsigned)batch), dim3(kBlock), 0, ctx->stream,
                        mode, g->d, cv->nh, 1.0 / cv->n, (const C*)g->wbar_all, cv->s2, az_d, ax_d, (const C*)g->gfz,
                        (const C*)g->gfx, (C*)g->gfo);
@@ -992,6 +1275,7 @@ extern "C" int tramp_grad_destroy(tramp_ctx* ctx, tramp_grad* g) {
     if (g->gwork) (void)hipFree(g->gwork);
     if (g->wbar_all) (void)hipFree(g->wbar_all);
     if (g->base.s2) (void)hipFree(g->base.s2);
+    conv_free_fft2(&g->base);
     delete g;
     return TRAMP_OK;
 }
@@ -1027,7 +1311,12 @@ extern "C" int tramp_grad_create(tramp_ctx* ctx, int dtype, int ndim, const size
     cv->work_batch = cv->proj_batch = 0;
     cv->wbar = nullptr;
     cv->s2 = nullptr;
-    cv->fft2 = nullptr;                                               // rocFFT engine only
+    cv->fft2 = nullptr;
+    cv->fftn = nullptr;
+    cv->hl = 0;
+    cv->ncomp = ndim;
+    cv->wbar_nq = nullptr;
+    cv->s2_nq = nullptr;
     cv->h = 0;
     cv->wbar_p = nullptr;
     cv->s2_p = nullptr;
@@ -1087,6 +1376,11 @@ extern "C" int tramp_grad_create(tramp_ctx* ctx, int dtype, int ndim, const size
         acc += ((j == 0 || 2 * j == cv->nlast) ? 1.0L : 2.0L) * (long double)s2h[i];
     }
     cv->s_mean = (double)(acc / (long double)cv->n);
+    rc = conv_setup_fftn(ctx, cv, ndim, w64, s2h);                     // own FFT engine when the shape allows
+    if (rc) {
+        cleanup(true);
+        return rc;
+    }
     cleanup(false);
     *grad = g;
     return TRAMP_OK;
@@ -1116,17 +1410,12 @@ extern "C" int tramp_grad_apply(tramp_ctx* ctx, tramp_grad* g, size_t batch, con
     if (!batch) return TRAMP_OK;
     int rc = grad_reserve(ctx, g, batch);
     if (rc) return rc;
-    ConvPlans *p1 = nullptr, *pd = nullptr;
-    rc = plans_for(ctx, &g->base, batch, &p1);
-    if (rc) return rc;
-    rc = fft_exec(ctx, p1->fwd, p1->info_fwd, z_d, g->gfz);
+    rc = grad_forward(ctx, g, batch, z_d, g->gfz);
     if (rc) return rc;
     if (g->base.dtype == TRAMP_F64) launch_grad_spectral<double>(ctx, g, 2, batch, nullptr, nullptr);
     else launch_grad_spectral<float>(ctx, g, 2, batch, nullptr, nullptr);
     TRAMP_LAUNCH_CHECK(ctx);
-    rc = plans_for(ctx, &g->base, batch * g->d, &pd);                  // may move p1: looked up after its last use
-    if (rc) return rc;
-    return fft_exec(ctx, pd->inv, pd->info_inv, g->gfo, x_d);
+    return grad_inverse(ctx, g, batch * g->d, g->gfo, x_d);
 }
 
 extern "C" int tramp_grad_message(tramp_ctx* ctx, tramp_grad* g, int dir, size_t batch, const double* az_d,
@@ -1148,16 +1437,11 @@ extern "C" int tramp_grad_message(tramp_ctx* ctx, tramp_grad* g, int dir, size_t
                           nullptr, (double)g->d);
         if (rc) return rc;
     }
-    ConvPlans* p = nullptr;
     {
         ProfScope ps(ctx, PROF_FFT, (double)batch * (d + 1) * (n * esz + nh * 2 * esz), 0);
-        rc = plans_for(ctx, cv, batch, &p);
+        rc = grad_forward(ctx, g, batch, bz_d, g->gfz);
         if (rc) return rc;
-        rc = fft_exec(ctx, p->fwd, p->info_fwd, bz_d, g->gfz);
-        if (rc) return rc;
-        rc = plans_for(ctx, cv, batch * d, &p);
-        if (rc) return rc;
-        rc = fft_exec(ctx, p->fwd, p->info_fwd, bx_d, g->gfx);
+        rc = grad_forward(ctx, g, batch * d, bx_d, g->gfx);
         if (rc) return rc;
     }
     {
@@ -1174,9 +1458,7 @@ extern "C" int tramp_grad_message(tramp_ctx* ctx, tramp_grad* g, int dir, size_t
     void* mean = r_d ? r_d : (damping != 0.0 ? g->gfr : b_new_d);
     {
         ProfScope ps(ctx, PROF_FFT, (double)batch * (fwd ? d : 1) * (n * esz + nh * 2 * esz), 0);
-        rc = plans_for(ctx, cv, fwd ? batch * d : batch, &p);
-        if (rc) return rc;
-        rc = fft_exec(ctx, p->inv, p->info_inv, g->gfo, mean);
+        rc = grad_inverse(ctx, g, fwd ? batch * d : batch, g->gfo, mean);
         if (rc) return rc;
     }
     {

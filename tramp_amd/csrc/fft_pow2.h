@@ -44,10 +44,46 @@ struct Fft2Epi {
 bool fft2_shape(size_t h, Fft2Shape* sh);
 // frequency held by position p of a forward-transformed array
 size_t fft2_kfreq(const Fft2Shape& sh, size_t p);
-int fft2_plan_create(tramp_ctx* ctx, int dtype, size_t h, Fft2Plan** out);
+int fft2_plan_create(tramp_ctx* ctx, int dtype, size_t h, Fft2Plan** out, bool block_only = false);
 void fft2_plan_destroy(Fft2Plan* pl);
 // natural order -> permuted spectrum (out of place; in and out may coincide)
 int fft2_forward(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, const void* in, void* out);
 // permuted spectrum (overwritten) -> natural order, unnormalised (x h)
 int fft2_inverse(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, void* spectrum, void* out,
                  const Fft2Epi* epi = nullptr);
+
+// ---- N-dimensional transforms (2-D / 3-D convolution and gradient channels): the packed real signal is a complex
+// array [d0][d1][hl] (hl = n_last / 2); the last axis is transformed by the block pass (one pass, several rows per
+// workgroup) or the two-pass engine above, every outer axis by one or two STRIDED passes of the same tile kernel
+// (rows of the tile are lines of the inner axes).  Each axis keeps its own permuted order: position p of axis a holds
+// frequency fftnd_kfreq(plan, a, p).
+struct FftAxisPass {
+    int G, Q, nA;       // tile rows; tile row g is array row a * G * Q + g * Q + q of the axis (q < Q, a < nA)
+    size_t W, n;        // complex elements per array row (the inner axes together); axis length
+    int nst, r[8], sub[8], off[8], ntw;
+    size_t mul[8];      // twiddle of stage s, leg offset bl: w_n^((bl * Q + q) * mul[s])
+    int axis;
+};
+
+struct FftNdPlan {
+    int dtype, ndim;
+    size_t dims[3];     // complex dims: outer axes then hl
+    size_t h;           // their product
+    Fft2Plan* row;      // last axis (shape.G == 1: block pass only)
+    int npass;
+    FftAxisPass pass[4];
+    void* tw_hi[2];     // two-level twiddle tables of the outer axes
+    void* tw_lo[2];
+    int nrad[2], rad[2][16];
+};
+
+// real dims [ndim] (last axis even); false: some axis is not 2^a 5^b / too long / the lines do not tile
+bool fftnd_supported(int dtype, int ndim, const size_t* real_dims);
+int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_dims, FftNdPlan** out);
+void fftnd_plan_destroy(FftNdPlan* pl);
+size_t fftnd_kfreq(const FftNdPlan* pl, int axis, size_t p);
+int fftnd_forward(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, const void* in, void* out);
+// spectrum is overwritten
+int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spectrum, void* out);
+// single block pass for h <= 4096 (G = 1)
+bool fft2_block_shape(size_t h, Fft2Shape* sh);

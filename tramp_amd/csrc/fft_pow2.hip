@@ -250,23 +250,29 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
 }
 
 // ---------------------------------------------------------------- pass 2: inside blocks of LB
+// A workgroup takes tile_pts consecutive points (a whole number of blocks of LB: the stage structure repeats with
+// period L <= LB, so several short blocks share one tile); in and out may coincide.
 template <typename T, bool INV>
-__global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, typename C2<T>::type* __restrict__ data,
-                                                        const typename C2<T>::type* __restrict__ tw_blk) {
+__global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typename C2<T>::type* __restrict__ in,
+                                                        typename C2<T>::type* __restrict__ out,
+                                                        const typename C2<T>::type* __restrict__ tw_blk, int tile_pts,
+                                                        size_t total_pts) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
-    const int LB = (int)sh.LB;
-    const int nthr = blockDim.x;                      // 64 ... 256 threads per block (TRAMP_FFT_BLOCK_THREADS)
-    C* blk = data + (size_t)blockIdx.x * LB;          // blocks of all transforms are contiguous
+    const int nthr = blockDim.x;                      // 64 ... 512 threads per block (TRAMP_FFT_BLOCK_THREADS)
+    const size_t first = (size_t)blockIdx.x * tile_pts;
+    const int npts = (int)((total_pts - first < (size_t)tile_pts) ? total_pts - first : (size_t)tile_pts);
+    const C* blk = in + first;                        // blocks of all transforms are contiguous
+    C* dst = out + first;
     if constexpr (sizeof(T) == 4) {
-        for (int i = threadIdx.x; i < LB / 2; i += nthr)
+        for (int i = threadIdx.x; i < npts / 2; i += nthr)
             reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(blk)[i];
     } else {
-        for (int i = threadIdx.x; i < LB; i += nthr) tile[i] = blk[i];
+        for (int i = threadIdx.x; i < npts; i += nthr) tile[i] = blk[i];
     }
     // the stage twiddles are the same for every block: a small table, copied to LDS beside the tile
-    C* twl = tile + LB;
+    C* twl = tile + tile_pts;
     for (int i = threadIdx.x; i < sh.ntw2; i += nthr) twl[i] = tw_blk[i];
     __syncthreads();
     for (int st = 0; st < sh.n2; ++st) {
@@ -275,17 +281,82 @@ __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, typename 
         const int sub = sh.sub2[s];                   // L / r, L the current sub-length
         const int L = sub * r;
         const C* tws = twl + sh.off2[s];
-        for (int b = threadIdx.x; b < LB / r; b += nthr) {
+        for (int b = threadIdx.x; b < npts / r; b += nthr) {
             const int m = b % sub, base = (b / sub) * L + m;
             bfly_at<C, INV>(tile, base, sub, r, tws[m]);
         }
         __syncthreads();
     }
     if constexpr (sizeof(T) == 4) {
-        for (int i = threadIdx.x; i < LB / 2; i += nthr)
-            reinterpret_cast<float4*>(blk)[i] = reinterpret_cast<const float4*>(tile)[i];
+        for (int i = threadIdx.x; i < npts / 2; i += nthr)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
     } else {
-        for (int i = threadIdx.x; i < LB; i += nthr) blk[i] = tile[i];
+        for (int i = threadIdx.x; i < npts; i += nthr) dst[i] = tile[i];
+    }
+}
+
+// ---------------------------------------------------------------- strided pass along an outer axis (N-D)
+// Tile [G][C]: G rows of the axis (Q * W elements apart), C consecutive elements of the inner axes (one 128-byte
+// line per row).  The twiddles depend on the row only, not on the column.
+template <typename T, bool INV>
+__global__ __launch_bounds__(1024) void fft_axis_kernel(FftAxisPass ps, const typename C2<T>::type* __restrict__ in,
+                                                       typename C2<T>::type* __restrict__ out,
+                                                       const typename C2<T>::type* __restrict__ tw_hi,
+                                                       const typename C2<T>::type* __restrict__ tw_lo) {
+    using C = typename C2<T>::type;
+    extern __shared__ unsigned char smem_raw[];
+    C* tile = reinterpret_cast<C*>(smem_raw);
+    constexpr int kC1 = c1_of<T>();
+    constexpr int P = kC1 + 1;
+    const int G = ps.G;
+    const size_t ncg = ps.W / kC1;
+    size_t t = blockIdx.x;
+    const size_t cg = t % ncg;
+    t /= ncg;
+    const int q = (int)(t % ps.Q);
+    t /= ps.Q;
+    const size_t a = t % ps.nA, o = t / ps.nA;
+    const size_t base = (o * ps.n + a * (size_t)G * ps.Q + q) * ps.W + cg * kC1;
+    const size_t rs = (size_t)ps.Q * ps.W;
+    const C* src = in + base;
+    C* dst = out + base;
+    const int c = threadIdx.x % kC1, r0 = threadIdx.x / kC1;
+    const int rstep = blockDim.x / kC1;
+    if constexpr (sizeof(T) == 4) {
+        const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
+        for (int g = q0; g < G; g += 2 * rstep) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)g * rs + 2 * c2);
+            tile[g * P + 2 * c2] = C{v.x, v.y};
+            tile[g * P + 2 * c2 + 1] = C{v.z, v.w};
+        }
+    } else {
+        for (int g = r0; g < G; g += rstep) tile[g * P + c] = src[(size_t)g * rs + c];
+    }
+    C* twl = tile + (size_t)G * P;
+    for (int s = 0; s < ps.nst; ++s)
+        for (int bl = threadIdx.x; bl < ps.sub[s]; bl += blockDim.x)
+            twl[ps.off[s] + bl] = twiddle<C>(tw_hi, tw_lo, ((size_t)bl * ps.Q + q) * ps.mul[s]);
+    __syncthreads();
+    for (int st = 0; st < ps.nst; ++st) {
+        const int s = INV ? ps.nst - 1 - st : st;
+        const int r = ps.r[s];
+        const int sg = ps.sub[s];
+        const int nb = G / r;
+        const C* tws = twl + ps.off[s];
+        for (int b = r0; b < nb; b += rstep) {
+            const int bl = b % sg, bh = b / sg;
+            bfly_at<C, INV>(tile, (bh * r * sg + bl) * P + c, sg * P, r, tws[bl]);
+        }
+        __syncthreads();
+    }
+    if constexpr (sizeof(T) == 4) {
+        const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
+        for (int g = q0; g < G; g += 2 * rstep) {
+            const C x = tile[g * P + 2 * c2], y = tile[g * P + 2 * c2 + 1];
+            *reinterpret_cast<float4*>(dst + (size_t)g * rs + 2 * c2) = float4{x.x, x.y, y.x, y.y};
+        }
+    } else {
+        for (int g = r0; g < G; g += rstep) dst[(size_t)g * rs + c] = tile[g * P + c];
     }
 }
 
@@ -379,6 +450,27 @@ bool fft2_shape(size_t h, Fft2Shape* sh) {
     return true;
 }
 
+// One block pass only: h <= 4096 points stay in a single LDS tile (G = 1, no strided stages).
+bool fft2_block_shape(size_t h, Fft2Shape* sh) {
+    if (h < 2 || h > 4096 || (h & 1)) return false;
+    memset(sh, 0, sizeof(*sh));
+    sh->h = h;
+    sh->LB = h;
+    sh->G = 1;
+    sh->n1 = 0;
+    sh->n2 = radices_of(h, sh->r2);
+    if (sh->n2 < 1 || sh->n2 > 8) return false;
+    size_t L = h;
+    for (int s = 0; s < sh->n2; ++s) {
+        sh->sub2[s] = (int)(L / sh->r2[s]);
+        sh->mul2[s] = h / L;
+        L /= sh->r2[s];
+    }
+    sh->ntw1 = sh->ntw2 = 0;
+    for (int s = 0; s < sh->n2; ++s) { sh->off2[s] = sh->ntw2; sh->ntw2 += sh->sub2[s]; }
+    return true;
+}
+
 // frequency held by position p after the forward transform: mixed-radix digit reversal
 size_t fft2_kfreq(const Fft2Shape& sh, size_t p) {
     size_t k = 0, weight = 1, len = sh.h;
@@ -409,11 +501,11 @@ static int plan_create_t(tramp_ctx* ctx, Fft2Plan* pl) {
     return TRAMP_OK;
 }
 
-int fft2_plan_create(tramp_ctx* ctx, int dtype, size_t h, Fft2Plan** out) {
+int fft2_plan_create(tramp_ctx* ctx, int dtype, size_t h, Fft2Plan** out, bool block_only) {
     Fft2Plan* pl = new Fft2Plan();
     pl->dtype = dtype;
     pl->tw_hi = pl->tw_lo = pl->tw_blk = nullptr;
-    if (!fft2_shape(h, &pl->shape)) {
+    if (!(block_only ? fft2_block_shape(h, &pl->shape) : fft2_shape(h, &pl->shape))) {
         delete pl;
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2_plan_create", "length is not 2^a 5^b within the two-pass range");
     }
@@ -441,8 +533,13 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
     const Fft2Shape& sh = pl->shape;
     constexpr int kC1 = c1_of<T>();
     const size_t lds1 = ((size_t)sh.G * (kC1 + 1) + (size_t)sh.ntw1 * kC1) * sizeof(C);
-    const size_t lds2 = (sh.LB + (size_t)sh.ntw2) * sizeof(C);
-    const unsigned g1 = (unsigned)(batch * (sh.LB / kC1)), g2 = (unsigned)(batch * (sh.h / sh.LB));
+    // block pass: one block of LB per workgroup behind the strided pass; alone (G == 1) as many short blocks as
+    // make a tile of ~2048 points
+    const size_t total_pts = batch * sh.h;
+    int tile_pts = (int)sh.LB;
+    if (sh.G == 1 && sh.LB < 2048) tile_pts = (int)(sh.LB * (2048 / sh.LB));
+    const size_t lds2 = ((size_t)tile_pts + (size_t)sh.ntw2) * sizeof(C);
+    const unsigned g1 = (unsigned)(batch * (sh.LB / kC1)), g2 = (unsigned)((total_pts + tile_pts - 1) / tile_pts);
     // threads per workgroup, measured at 64 x 5 10^5: f64 0.56 ms with 512 / 512 against 0.63 with 256 / 256
     // (more butterflies in flight per LDS tile); f32 is best at 256 / 256
     static const int env_blk = getenv("TRAMP_FFT_BLOCK_THREADS") ? atoi(getenv("TRAMP_FFT_BLOCK_THREADS")) : 0;
@@ -473,15 +570,24 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
     // (the epilogue kernel also carries the 2 KiB erfcx table of a sign-likelihood consumer, prior_hint.h)
     if (lds1 + 4096 > 160 * 1024 || lds2 > 160 * 1024)
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "transform too long for the LDS tile");
-    if (!inverse) {
+    if (sh.G == 1) {
+        // the whole transform is one block pass, out of place
+        if (epi && epi->out) return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "no fused epilogue on the block-only pass");
+        if (inverse)
+            hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh, (const C*)in,
+                               (C*)out, (const C*)pl->tw_blk, tile_pts, total_pts);
+        else
+            hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh, (const C*)in,
+                               (C*)out, (const C*)pl->tw_blk, tile_pts, total_pts);
+    } else if (!inverse) {
         hipLaunchKernelGGL((fft_strided_kernel<T, false>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh, (const C*)in,
                            (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, Fft2Epi{});
-        hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh, (C*)out,
-                           (const C*)pl->tw_blk);
+        hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh, (const C*)out,
+                           (C*)out, (const C*)pl->tw_blk, tile_pts, total_pts);
     } else {
         // `in` (the permuted spectrum) is overwritten by the block pass
-        hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh,
-                           (C*)const_cast<void*>(in), (const C*)pl->tw_blk);
+        hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh, (const C*)in,
+                           (C*)const_cast<void*>(in), (const C*)pl->tw_blk, tile_pts, total_pts);
         if (epi && epi->out) {
             Fft2Epi e2 = *epi;
             // message length 2 h reals per instance, one partial per tile.  This pass is bound by its own
@@ -512,6 +618,234 @@ int fft2_forward(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, const void* i
 int fft2_inverse(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, void* spectrum, void* out, const Fft2Epi* epi) {
     return pl->dtype == TRAMP_F64 ? fft2_run_t<double>(ctx, pl, batch, true, spectrum, out, epi)
                                   : fft2_run_t<float>(ctx, pl, batch, true, spectrum, out, epi);
+}
+
+// ---------------------------------------------------------------- N-D plans
+namespace {
+
+constexpr size_t kAxisGmax = 512;      // tile rows of a strided axis pass (f64: 512 x 9 x 16 B = 72 KiB of LDS)
+
+bool smooth25(size_t v) {
+    if (!v) return false;
+    while (v % 2 == 0) v /= 2;
+    while (v % 5 == 0) v /= 5;
+    return v == 1;
+}
+
+// the one or two strided passes of an axis of length n over rows of W complex elements
+bool axis_passes(size_t n, size_t W, int axis, FftAxisPass* out, int* np, int* rad, int* nrad) {
+    *np = 0;
+    *nrad = 0;
+    if (n == 1) return true;
+    if (!smooth25(n)) return false;
+    size_t ga = n, gb = 1;
+    if (n > kAxisGmax) {
+        double best = 1e300;
+        ga = 0;
+        for (size_t d = 2; d <= kAxisGmax; ++d) {
+            if (n % d || !smooth25(d) || n / d > kAxisGmax) continue;
+            const double cost = fabs(log((double)(n / d) / (double)d));
+            if (cost < best) { best = cost; gb = d; ga = n / d; }
+        }
+        if (!ga) return false;
+    }
+    auto finish = [&](FftAxisPass& ps) {
+        ps.W = W;
+        ps.n = n;
+        ps.axis = axis;
+        ps.ntw = 0;
+        for (int s = 0; s < ps.nst; ++s) {
+            ps.off[s] = ps.ntw;
+            ps.ntw += ps.sub[s];
+            rad[(*nrad)++] = ps.r[s];
+        }
+    };
+    FftAxisPass& p1 = out[(*np)++];
+    memset(&p1, 0, sizeof(p1));
+    p1.G = (int)ga;
+    p1.Q = (int)gb;
+    p1.nA = 1;
+    p1.nst = radices_of(ga, p1.r);
+    if (p1.nst < 1 || p1.nst > 8) return false;
+    size_t prod = 1;
+    int rows = (int)ga;
+    for (int s = 0; s < p1.nst; ++s) {
+        rows /= p1.r[s];
+        p1.sub[s] = rows;
+        p1.mul[s] = prod;
+        prod *= p1.r[s];
+    }
+    finish(p1);
+    if (gb > 1) {
+        FftAxisPass& p2 = out[(*np)++];
+        memset(&p2, 0, sizeof(p2));
+        p2.G = (int)gb;
+        p2.Q = 1;
+        p2.nA = (int)ga;
+        p2.nst = radices_of(gb, p2.r);
+        if (p2.nst < 1 || p2.nst > 8) return false;
+        size_t L = gb;
+        for (int s = 0; s < p2.nst; ++s) {
+            p2.sub[s] = (int)(L / p2.r[s]);
+            p2.mul[s] = n / L;
+            L /= p2.r[s];
+        }
+        finish(p2);
+    }
+    return true;
+}
+
+template <typename T>
+int axis_tables_t(tramp_ctx* ctx, size_t n, void** hi, void** lo) {
+    using C = typename C2<T>::type;
+    const size_t nhi = (n + 1023) >> 10;
+    TRAMP_HIP_CHECK(ctx, hipMalloc(hi, nhi * sizeof(C)));
+    TRAMP_HIP_CHECK(ctx, hipMalloc(lo, 1024 * sizeof(C)));
+    hipLaunchKernelGGL((fft_tables_kernel<T>), dim3(4), dim3(256), 0, ctx->stream, n, nhi, (C*)*hi, (C*)*lo);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+template <typename T>
+int axis_run_t(tramp_ctx* ctx, const FftNdPlan* pl, const FftAxisPass& ps, size_t batch, bool inverse, void* data) {
+    using C = typename C2<T>::type;
+    constexpr int kC1 = c1_of<T>();
+    size_t outer = batch;
+    for (int a = 0; a < ps.axis; ++a) outer *= pl->dims[a];
+    const size_t tiles = outer * ps.nA * ps.Q * (ps.W / kC1);
+    if (tiles > 0x7fffffffull) return tramp_fail(ctx, TRAMP_ENOTSUP, "fftnd", "too many tiles for one launch");
+    const size_t lds = ((size_t)ps.G * (kC1 + 1) + (size_t)ps.ntw) * sizeof(C);
+    // threads: a quarter of the tile's points (one radix-4 butterfly each), within [64, 512]
+    int thr = (ps.G * kC1 / 4 + 63) / 64 * 64;
+    thr = thr < 64 ? 64 : (thr > 512 ? 512 : thr);
+    static bool attr_done[4] = {false, false, false, false};
+    const int slot = (sizeof(T) == 8 ? 0 : 2) + (inverse ? 1 : 0);
+    const void* f = inverse ? reinterpret_cast<const void*>(fft_axis_kernel<T, true>)
+                            : reinterpret_cast<const void*>(fft_axis_kernel<T, false>);
+    if (!attr_done[slot]) {
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_done[slot] = true;
+    }
+    const int ax = ps.axis;
+    if (inverse)
+        hipLaunchKernelGGL((fft_axis_kernel<T, true>), dim3((unsigned)tiles), dim3(thr), lds, ctx->stream, ps, (const C*)data,
+                           (C*)data, (const C*)pl->tw_hi[ax], (const C*)pl->tw_lo[ax]);
+    else
+        hipLaunchKernelGGL((fft_axis_kernel<T, false>), dim3((unsigned)tiles), dim3(thr), lds, ctx->stream, ps, (const C*)data,
+                           (C*)data, (const C*)pl->tw_hi[ax], (const C*)pl->tw_lo[ax]);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+// the last axis alone: block pass for hl <= 4096, the two-pass engine above that
+bool row_shape(size_t hl, Fft2Shape* sh, bool* block_only) {
+    if (fft2_block_shape(hl, sh)) {
+        *block_only = true;
+        return true;
+    }
+    *block_only = false;
+    return fft2_shape(hl, sh);
+}
+
+}  // namespace
+
+bool fftnd_supported(int dtype, int ndim, const size_t* rd) {
+    if (ndim < 1 || ndim > 3 || (dtype != TRAMP_F64 && dtype != TRAMP_F32)) return false;
+    const size_t nl = rd[ndim - 1];
+    if (nl < 4 || (nl & 1)) return false;
+    const size_t hl = nl / 2;
+    const size_t c1 = dtype == TRAMP_F64 ? c1_of<double>() : c1_of<float>();
+    Fft2Shape sh;
+    bool blk;
+    if (!row_shape(hl, &sh, &blk)) return false;
+    if (ndim > 1 && hl % c1) return false;                  // the strided passes move whole 128-byte lines
+    size_t W = hl;
+    FftAxisPass tmp[2];
+    int np, rad[16], nrad;
+    for (int a = ndim - 2; a >= 0; --a) {
+        if (!axis_passes(rd[a], W, a, tmp, &np, rad, &nrad)) return false;
+        W *= rd[a];
+    }
+    return true;
+}
+
+int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* rd, FftNdPlan** out) {
+    if (!fftnd_supported(dtype, ndim, rd))
+        return tramp_fail(ctx, TRAMP_ENOTSUP, "fftnd_plan_create", "shape outside the own FFT engine");
+    FftNdPlan* pl = new FftNdPlan();
+    memset(pl, 0, sizeof(*pl));
+    pl->dtype = dtype;
+    pl->ndim = ndim;
+    pl->h = 1;
+    for (int a = 0; a < ndim; ++a) {
+        pl->dims[a] = a == ndim - 1 ? rd[a] / 2 : rd[a];
+        pl->h *= pl->dims[a];
+    }
+    const size_t hl = pl->dims[ndim - 1];
+    Fft2Shape sh;
+    bool blk = false;
+    (void)row_shape(hl, &sh, &blk);
+    int rc = fft2_plan_create(ctx, dtype, hl, &pl->row, blk);
+    // outer axes, innermost first in the forward order
+    size_t W = hl;
+    for (int a = ndim - 2; a >= 0 && !rc; --a) {
+        int np = 0;
+        if (!axis_passes(pl->dims[a], W, a, pl->pass + pl->npass, &np, pl->rad[a], &pl->nrad[a])) rc = TRAMP_ENOTSUP;
+        pl->npass += np;
+        if (!rc && pl->dims[a] > 1)
+            rc = dtype == TRAMP_F64 ? axis_tables_t<double>(ctx, pl->dims[a], &pl->tw_hi[a], &pl->tw_lo[a])
+                                    : axis_tables_t<float>(ctx, pl->dims[a], &pl->tw_hi[a], &pl->tw_lo[a]);
+        W *= pl->dims[a];
+    }
+    if (rc) {
+        fftnd_plan_destroy(pl);
+        return rc;
+    }
+    *out = pl;
+    return TRAMP_OK;
+}
+
+void fftnd_plan_destroy(FftNdPlan* pl) {
+    if (!pl) return;
+    fft2_plan_destroy(pl->row);
+    for (int a = 0; a < 2; ++a) {
+        if (pl->tw_hi[a]) (void)hipFree(pl->tw_hi[a]);
+        if (pl->tw_lo[a]) (void)hipFree(pl->tw_lo[a]);
+    }
+    delete pl;
+}
+
+size_t fftnd_kfreq(const FftNdPlan* pl, int axis, size_t p) {
+    if (axis == pl->ndim - 1) return fft2_kfreq(pl->row->shape, p);
+    size_t k = 0, weight = 1, len = pl->dims[axis];
+    for (int s = 0; s < pl->nrad[axis]; ++s) {
+        const int r = pl->rad[axis][s];
+        len /= r;
+        k += (p / len) * weight;
+        p %= len;
+        weight *= r;
+    }
+    return k;
+}
+
+int fftnd_forward(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, const void* in, void* out) {
+    const size_t rows = batch * (pl->h / pl->dims[pl->ndim - 1]);
+    int rc = fft2_forward(ctx, pl->row, rows, in, out);
+    for (int i = 0; i < pl->npass && !rc; ++i)
+        rc = pl->dtype == TRAMP_F64 ? axis_run_t<double>(ctx, pl, pl->pass[i], batch, false, out)
+                                    : axis_run_t<float>(ctx, pl, pl->pass[i], batch, false, out);
+    return rc;
+}
+
+int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spectrum, void* out) {
+    int rc = TRAMP_OK;
+    for (int i = pl->npass - 1; i >= 0 && !rc; --i)
+        rc = pl->dtype == TRAMP_F64 ? axis_run_t<double>(ctx, pl, pl->pass[i], batch, true, spectrum)
+                                    : axis_run_t<float>(ctx, pl, pl->pass[i], batch, true, spectrum);
+    if (rc) return rc;
+    const size_t rows = batch * (pl->h / pl->dims[pl->ndim - 1]);
+    return fft2_inverse(ctx, pl->row, rows, spectrum, out);
 }
 
 // ---------------------------------------------------------------- exported for tests / tools
@@ -562,4 +896,37 @@ extern "C" int tramp_fft_bench(tramp_ctx* ctx, int dtype, size_t h, size_t batch
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     fft2_plan_destroy(pl);
     return rc;
+}
+
+// N-D complex transform of the packed signal (tests / tools): real dims [ndim], data [batch] x packed complex
+extern "C" int tramp_fftn(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_dims, size_t batch, int inverse,
+                          void* in_d, void* out_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, in_d && out_d && real_dims);
+    FftNdPlan* pl = nullptr;
+    int rc = fftnd_plan_create(ctx, dtype, ndim, real_dims, &pl);
+    if (rc) return rc;
+    rc = inverse ? fftnd_inverse(ctx, pl, batch, in_d, out_d) : fftnd_forward(ctx, pl, batch, in_d, out_d);
+    (void)hipStreamSynchronize(ctx->stream);
+    fftnd_plan_destroy(pl);
+    return rc;
+}
+
+// frequency held by each position of one axis after tramp_fftn's forward transform
+extern "C" int tramp_fftn_order(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_dims, int axis,
+                                unsigned long long* kfreq_h) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, kfreq_h && real_dims && axis >= 0 && axis < ndim);
+    FftNdPlan* pl = nullptr;
+    int rc = fftnd_plan_create(ctx, dtype, ndim, real_dims, &pl);
+    if (rc) return rc;
+    for (size_t p = 0; p < pl->dims[axis]; ++p) kfreq_h[p] = fftnd_kfreq(pl, axis, p);
+    (void)hipStreamSynchronize(ctx->stream);
+    fftnd_plan_destroy(pl);
+    return TRAMP_OK;
+}
+
+// 1 when the own engine takes this shape (no device call)
+extern "C" int tramp_fftn_supported(int dtype, int ndim, const size_t* real_dims) {
+    return real_dims && fftnd_supported(dtype, ndim, real_dims) ? 1 : 0;
 }

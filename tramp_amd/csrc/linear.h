@@ -47,6 +47,10 @@ struct LinEpi {
 bool lin_arm_hint(tramp_ctx* ctx, LinEpi& epi, size_t len, size_t batch, int nblk);
 
 int lin_square(tramp_ctx* ctx, const double* in, double* out, size_t n);
+// kernel K9 on an explicit list of squared singular values (solve.hip: the precompute_svd=False channel)
+int lin_variance_launch(tramp_ctx* ctx, const double* s2, int k, int rank, double Nx, double Nz, int dir, size_t batch,
+                        const double* az_d, const double* ax_d, double damping, const double* a_old_d, double* v_d,
+                        double* a_new_d, double* a_raw_d, double* n_eff_d);
 
 // MFMA GEMM path (gemm_mfma.hip)
 bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch);

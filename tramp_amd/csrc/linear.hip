@@ -560,6 +560,15 @@ extern "C" int tramp_linear_variance(tramp_ctx* ctx, const tramp_linear* lin, in
     return TRAMP_OK;
 }
 
+int lin_variance_launch(tramp_ctx* ctx, const double* s2, int k, int rank, double Nx, double Nz, int dir, size_t batch,
+                        const double* az_d, const double* ax_d, double damping, const double* a_old_d, double* v_d,
+                        double* a_new_d, double* a_raw_d, double* n_eff_d) {
+    hipLaunchKernelGGL(lin_variance_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, s2, k, rank, Nx, Nz, dir,
+                       az_d, ax_d, damping, a_old_d, v_d, a_new_d, a_raw_d, n_eff_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 // ---------------------------------------------------------------- rotated output basis
 // When the factor behind the channel's output is rotation invariant (an isotropic Gaussian likelihood),
 // the whole problem can be written for x' = Uk^T x instead of x (Uk square: M = k): the likelihood keeps
