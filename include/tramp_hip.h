@@ -475,6 +475,13 @@ int tramp_matvec_last_launch(tramp_ctx* ctx, int* nsplit, int* nchunk, int* flat
 typedef struct tramp_conv tramp_conv;
 int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filter_d,
                       tramp_conv** conv);
+/* ConvChannel(filter, real=False) (conv_channel.py:25-32): x, w, z complex.  filter_d: planar [2, n] doubles (real parts,
+ * then imaginary parts); every message / mean vector of the handle is the planar array [batch, 2, n] of `dtype`, so the
+ * vector length per instance is 2 n.  Same entry points afterwards (tramp_conv_variance / apply / message; the spectrum
+ * returned by tramp_conv_spectrum is the full one, n bins, in the engine's internal order); tramp_conv_project_affine
+ * returns ENOTSUP. */
+int tramp_conv_create_complex(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filter_d,
+                              tramp_conv** conv);
 int tramp_conv_destroy(tramp_ctx* ctx, tramp_conv* conv);
 /* Half spectrum |fft(f)|^2 (last axis n_last/2+1 bins; *count entries, device copy optional)
  * and the mean of the FULL spectrum (ConvChannel.second_moment, conv_channel.py:66-67). */
@@ -552,6 +559,8 @@ int tramp_fftn_supported(int dtype, int ndim, const size_t* real_dims);
 typedef struct tramp_dft tramp_dft;
 int tramp_dft_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, tramp_dft** dft);
 int tramp_dft_destroy(tramp_ctx* ctx, tramp_dft* dft);
+/* real=False (dft_channel.py:31-45): z is complex as well - b_in of FWD and b_new of BWD are planar [batch, 2, n] */
+int tramp_dft_set_complex_input(tramp_ctx* ctx, tramp_dft* dft, int on);
 int tramp_dft_message(tramp_ctx* ctx, tramp_dft* dft, int dir, size_t batch,
                       const double* a_in_d, const void* b_in_d,
                       double damping, const double* a_old_d, const void* b_old_d,

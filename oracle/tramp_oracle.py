@@ -746,6 +746,31 @@ class LinearOracle:
         return ab_new(rz, vz, az, bz)
 
 
+class LinearSolveOracle(LinearOracle):
+    """LinearChannel(W, precompute_svd=False) as the reference runs it (linear_channel.py:43-46, 79-82): C = W^T W,
+    spectrum = eigvalsh(C) in ASCENDING order, singular = spectrum[:rank] (its smallest entries - the variances
+    inherit that), means from np.linalg.solve, log-partition over the whole spectrum (:127-132)."""
+
+    def __init__(self, W):
+        W = np.asarray(W, dtype=float)
+        self.W = W
+        self.Nx, self.Nz = W.shape
+        self.rank = np.linalg.matrix_rank(W)                     # :37
+        self.alpha = self.Nx / self.Nz
+        self.C = W.T @ W                                         # :43
+        self.spectrum = np.linalg.eigvalsh(self.C)               # :44
+        self.singular = self.spectrum[:self.rank]                # :46
+
+    def backward_mean(self, az, bz, ax, bx):
+        return self.backward_mean_solve(az, bz, ax, bx)          # :79-82
+
+    def log_partition(self, az, bz, ax, bx):
+        rz = self.backward_mean(az, bz, ax, bx)
+        b = bz + self.W.T @ bx
+        a = az + ax * self.spectrum
+        return 0.5 * np.sum(b * rz) + 0.5 * np.sum(np.log(2 * np.pi / a))
+
+
 class LinearThinOracle(LinearOracle):
     """Same results from the thin factorisation the HIP path stores.
 
@@ -861,6 +886,51 @@ class ConvOracle:
 
     def backward_message(self, az, bz, ax, bx):
         return ab_new(self.backward_mean(az, bz, ax, bx), self.backward_variance(az, ax), az, bz)
+
+
+class ComplexConvOracle(ConvOracle):
+    """ConvChannel(filter, real=False) (conv_channel.py:25-32, 57-63, 83-103): x, w, z complex; every vector is the planar
+    real array (2,) + shape (tramp/utils/misc.py:13-27), ensemble axes in front."""
+
+    def __init__(self, filt):
+        filt = np.asarray(filt, dtype=np.complex128)
+        self.shape = filt.shape
+        self.w_fft_bar = np.fft.fftn(filt)
+        self.w_fft = np.conjugate(self.w_fft_bar)
+        self.spectrum = np.absolute(self.w_fft)**2
+        self._axes = tuple(range(-filt.ndim, 0))
+
+    @staticmethod
+    def _c(Z, nd):
+        Z = np.asarray(Z)
+        return np.take(Z, 0, axis=-nd - 1) + 1j * np.take(Z, 1, axis=-nd - 1)
+
+    def _p(self, z):
+        return np.stack([z.real, z.imag], axis=-len(self.shape) - 1)
+
+    def _fft(self, Z):
+        return np.fft.fftn(self._c(Z, len(self.shape)), axes=self._axes)
+
+    def _ifft(self, a):
+        return self._p(np.fft.ifftn(a, axes=self._axes))
+
+
+class ComplexDFTOracle:
+    "DFTChannel(real=False) (dft_channel.py:31-67): planar in, planar out, norm='ortho'"
+
+    def __init__(self, ndim):
+        self.nd = ndim
+        self._axes = tuple(range(-ndim, 0))
+
+    def forward_message(self, az, bz, ax, bx):
+        z = ComplexConvOracle._c(bz, self.nd)
+        x = np.fft.fftn(z, axes=self._axes, norm="ortho")
+        return az, np.stack([x.real, x.imag], axis=-self.nd - 1)
+
+    def backward_message(self, az, bz, ax, bx):
+        x = ComplexConvOracle._c(bx, self.nd)
+        z = np.fft.ifftn(x, axes=self._axes, norm="ortho")
+        return ax, np.stack([z.real, z.imag], axis=-self.nd - 1)
 
 
 def gaussian_filter(sigma, N):

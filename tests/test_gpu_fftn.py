@@ -36,7 +36,7 @@ SHAPES = [(16,), (64,), (8192,), (16384,), (20000,), (8, 16), (16, 32), (10, 32)
 def test_fftn_matches_numpy(ctx, shape, dtype):
     import tramp_amd as T
     dt = T.device.dtype_code(dtype)
-    if not T._lib.lib().tramp_fftn_supported(dt, len(shape), _dims(shape)):
+    if not T._lib.load().tramp_fftn_supported(dt, len(shape), _dims(shape)):
         assert dtype == np.float32 and len(shape) > 1 and (shape[-1] // 2) % 16       # f32 lines hold 16 complex
         return
     B = 3
@@ -66,7 +66,7 @@ def test_fftn_unsupported_shapes(ctx):
     dt = T.device.dtype_code(np.float64)
     buf = ctx.empty((1, 4096), np.float64)
     for shape in [(15,), (6, 16), (8, 24), (8, 8), (3, 4, 16), (600000, 16)]:
-        assert not T._lib.lib().tramp_fftn_supported(dt, len(shape), _dims(shape))
+        assert not T._lib.load().tramp_fftn_supported(dt, len(shape), _dims(shape))
         with pytest.raises(T._lib.TrampHipError):
             ctx._call("tramp_fftn", dt, len(shape), _dims(shape), 1, 0, buf.ptr, buf.ptr)
 
@@ -159,3 +159,140 @@ def test_gradient_channel_on_own_engine(ctx, shape, dtype, monkeypatch):
             np.testing.assert_allclose(np.asarray(r["bwd"][1][b]).reshape(shape), b_b, rtol=0, atol=tol * np.abs(b_b).max())
     np.testing.assert_allclose(np.asarray(res["own"]["smp"]).reshape((d,) + shape), ref.convolve(bz[0]), rtol=0,
                                atol=tol * 4 * np.abs(bz[0]).max())
+
+
+DFT_SHAPES = [(64,), (1000,), (8192,), (16, 32), (10, 160), (640, 32), (4, 8, 16), (15,), (6, 8)]
+
+
+@pytest.mark.parametrize("shape", DFT_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("real", [True, False])
+def test_dft_channel_real_and_complex_input(ctx, shape, dtype, real):
+    """DFTChannel messages (dft_channel.py:47-67) on the own engine (shapes it takes) and on rocFFT (15, 6x8), for
+    real z and for complex z (real=False: planar [2, ...] arrays on both sides), with damping."""
+    import tramp_amd as T
+    rs = np.random.RandomState(len(shape) + int(real))
+    B, n = 3, int(np.prod(shape))
+    ch = T.DFTChannel(real=real, shape=shape, dtype=dtype, ctx=ctx)
+    az, ax = rs.uniform(0.5, 2, B), rs.uniform(0.5, 2, B)
+    zc = rs.standard_normal((B,) + shape) + (0 if real else 1j * rs.standard_normal((B,) + shape))
+    xc = rs.standard_normal((B,) + shape) + 1j * rs.standard_normal((B,) + shape)
+    planar = lambda c: np.stack([c.real, c.imag], axis=1)          # noqa: E731  [B, 2, ...]
+    bz = zc.real if real else planar(zc)
+    bx = planar(xc)
+    axes = tuple(range(1, len(shape) + 1))
+    tol = 1e-12 if dtype == np.float64 else 3e-5
+    a_f, b_f = ch.compute_forward_message(az, bz.astype(dtype), ax, bx.astype(dtype))
+    ref_f = planar(np.fft.fftn(zc, axes=axes, norm="ortho"))
+    np.testing.assert_allclose(a_f, az, rtol=1e-15)
+    np.testing.assert_allclose(np.asarray(b_f).reshape(ref_f.shape), ref_f, rtol=0, atol=tol * np.abs(ref_f).max() * np.sqrt(n))
+    a_b, b_b = ch.compute_backward_message(az, bz.astype(dtype), ax, bx.astype(dtype))
+    inv = np.fft.ifftn(xc, axes=axes, norm="ortho")
+    ref_b = inv.real if real else planar(inv)
+    np.testing.assert_allclose(a_b, ax, rtol=1e-15)
+    np.testing.assert_allclose(np.asarray(b_b).reshape(ref_b.shape), ref_b, rtol=0, atol=tol * np.abs(inv).max() * np.sqrt(n))
+    # one instance, host vectors in the reference's shapes
+    a1, b1 = ch.compute_forward_message(1.5, bz[0].astype(dtype), 0.5, bx[0].astype(dtype))
+    assert np.asarray(b1).shape == (2,) + shape and a1 == 1.5
+    a2, b2 = ch.compute_backward_message(1.5, bz[0].astype(dtype), 0.5, bx[0].astype(dtype))
+    assert np.asarray(b2).shape == (shape if real else (2,) + shape) and a2 == 0.5
+    np.testing.assert_allclose(b2, ref_b[0], rtol=0, atol=tol * np.abs(inv).max() * np.sqrt(n))
+
+
+def _load_complex_goldens():
+    import os
+    from tests.conftest import GOLDEN
+    with np.load(os.path.join(GOLDEN, "conv_complex.npz"), allow_pickle=True) as f:
+        return list(f["data"]), list(f["dft"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_complex_conv_channel_matches_reference_goldens(ctx, dtype):
+    """ConvChannel(real=False) against the reference's own outputs (conv_channel.py:25-32, 81-109): posteriors, messages,
+    x = w * z, n_eff and second moment; shapes on the own engine (16, 64, 8x16, 16x32, 4x4x16) and on rocFFT (15, 6x8, 3x4x5)."""
+    import tramp_amd as T
+    conv, _ = _load_complex_goldens()
+    tol = 1e-11 if dtype == np.float64 else 3e-4
+    chans = {}
+    for c in conv:
+        key = tuple(c["shape"])
+        if key not in chans:
+            chans[key] = T.ConvChannel(c["filter"], real=False, dtype=dtype, ctx=ctx)
+        ch = chans[key]
+        az, ax, bz, bx = c["az"], c["ax"], c["bz"].astype(dtype), c["bx"].astype(dtype)
+        np.testing.assert_allclose(ch.compute_n_eff(az, ax), c["n_eff"], rtol=max(tol, 1e-9))
+        np.testing.assert_allclose(ch.second_moment(1.7), c["tau"], rtol=max(tol, 1e-9))
+        rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+        rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+        assert np.asarray(rz).shape == (2,) + key
+        np.testing.assert_allclose(rz, c["rz"], rtol=0, atol=tol * np.abs(c["rz"]).max())
+        np.testing.assert_allclose(rx, c["rx"], rtol=0, atol=tol * np.abs(c["rx"]).max())
+        np.testing.assert_allclose([vz, vx], [c["vz"], c["vx"]], rtol=max(tol, 1e-9))
+        a_b, b_b = ch.compute_backward_message(az, bz, ax, bx)
+        a_f, b_f = ch.compute_forward_message(az, bz, ax, bx)
+        np.testing.assert_allclose(a_b, c["a_bwd"], rtol=max(tol, 1e-9), atol=max(tol, 1e-9) / c["vz"])
+        np.testing.assert_allclose(a_f, c["a_fwd"], rtol=max(tol, 1e-9), atol=max(tol, 1e-9) / c["vx"])
+        sb = np.abs(c["rz"]).max() / c["vz"] + np.abs(bz).max()
+        sf = np.abs(c["rx"]).max() / c["vx"] + np.abs(bx).max()
+        np.testing.assert_allclose(b_b, c["b_bwd"], rtol=0, atol=tol * sb)
+        np.testing.assert_allclose(b_f, c["b_fwd"], rtol=0, atol=tol * sf)
+        np.testing.assert_allclose(ch.sample(bz), c["sample"], rtol=0, atol=tol * np.abs(c["sample"]).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_complex_dft_channel_matches_reference_goldens(ctx, dtype):
+    import tramp_amd as T
+    _, dft = _load_complex_goldens()
+    tol = 1e-12 if dtype == np.float64 else 3e-5
+    for c in dft:
+        shape = tuple(c["shape"])
+        ch = T.DFTChannel(real=False, shape=shape, dtype=dtype, ctx=ctx)
+        a_f, b_f = ch.compute_forward_message(1.3, c["bz"].astype(dtype), 0.7, c["bx"].astype(dtype))
+        a_b, b_b = ch.compute_backward_message(1.3, c["bz"].astype(dtype), 0.7, c["bx"].astype(dtype))
+        assert (a_f, a_b) == (c["a_fwd"], c["a_bwd"])
+        sc = np.sqrt(np.prod(shape))
+        np.testing.assert_allclose(b_f, c["b_fwd"], rtol=0, atol=tol * np.abs(c["b_fwd"]).max() * sc)
+        np.testing.assert_allclose(b_b, c["b_bwd"], rtol=0, atol=tol * np.abs(c["b_bwd"]).max() * sc)
+        np.testing.assert_allclose(ch.sample(c["bz"].astype(dtype)), c["sample"], rtol=0,
+                                   atol=tol * np.abs(c["sample"]).max() * sc)
+
+
+@pytest.mark.parametrize("shape", [(4096,), (64, 64), (640, 32), (8, 16, 32)], ids=lambda s: "x".join(map(str, s)))
+def test_complex_conv_channel_larger_shapes_and_damping(ctx, shape, monkeypatch):
+    "Own engine against the oracle and against rocFFT at sizes with strided passes; an ensemble with damping."
+    import tramp_amd as T
+    from oracle import tramp_oracle as orc
+    rs = np.random.RandomState(len(shape))
+    f = np.zeros(shape, dtype=complex)
+    idx = tuple(slice(0, 3) for _ in shape)
+    f[idx] = rs.standard_normal(f[idx].shape) + 1j * rs.standard_normal(f[idx].shape)
+    B = 3
+    az, ax = rs.uniform(0.5, 2, B), rs.uniform(0.5, 2, B)
+    bz, bx = rs.standard_normal((B, 2) + shape), rs.standard_normal((B, 2) + shape)
+    o = orc.ComplexConvOracle(f)
+    out = {}
+    for eng in ("own", "rocfft"):
+        if eng == "rocfft":
+            monkeypatch.setenv("TRAMP_CONV_FFT", "rocfft")
+        else:
+            monkeypatch.delenv("TRAMP_CONV_FFT", raising=False)
+        ch = T.ConvChannel(f, real=False, ctx=ctx)
+        out[eng] = (ch.compute_forward_message(az, bz, ax, bx), ch.compute_backward_message(az, bz, ax, bx))
+        # damping through the device entry (old message = the incoming one)
+        old_a, old_b = ctx.array(np.full(B, 0.9)), ctx.array(bx.reshape(B, -1).copy())
+        a_d, b_d = ch.compute_forward_message(ctx.array(az), ctx.array(bz.reshape(B, -1)), ctx.array(ax),
+                                              ctx.array(bx.reshape(B, -1)), damping=0.25, old_a=old_a, old_b=old_b,
+                                              out_a=ctx.empty((B,), np.float64), out_b=ctx.empty((B, 2 * int(np.prod(shape)))))
+        out[eng + "_damped"] = (a_d.get(), b_d.get())
+    for b in range(B):
+        ra, rb = o.forward_message(az[b], bz[b], ax[b], bx[b])
+        qa, qb = o.backward_message(az[b], bz[b], ax[b], bx[b])
+        for eng in ("own", "rocfft"):
+            (a_f, b_f), (a_b, b_b) = out[eng]
+            np.testing.assert_allclose(a_f[b], ra, rtol=1e-9)
+            np.testing.assert_allclose(b_f[b], rb, rtol=0, atol=1e-11 * np.abs(rb).max())
+            np.testing.assert_allclose(a_b[b], qa, rtol=1e-9)
+            np.testing.assert_allclose(b_b[b], qb, rtol=0, atol=1e-11 * np.abs(qb).max())
+            a_d, b_d = out[eng + "_damped"]
+            np.testing.assert_allclose(a_d[b], 0.25 * 0.9 + 0.75 * ra, rtol=1e-9)
+            np.testing.assert_allclose(b_d[b].reshape(rb.shape), 0.25 * bx[b] + 0.75 * rb, rtol=0, atol=1e-11 * np.abs(rb).max())

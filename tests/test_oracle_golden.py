@@ -892,3 +892,64 @@ def test_binary_prior_se_oracle_matches_reference(golden_tree):
     for c in golden_tree["binse"]:
         close(orc.se_binary_prior_error(c["ax"], c["p_pos"]), c["v"], rtol=1e-8)
         close(orc.se_binary_prior_error(c["ax"], c["p_pos"], method="gl"), c["v"], rtol=1e-6)
+
+
+def test_linear_solve_oracle_matches_reference_goldens():
+    """LinearChannel(precompute_svd=False): the oracle's restatement against the reference's own outputs
+    (tests/golden/solve.npz from tools/make_golden_solve.py), including the ascending-spectrum `singular`."""
+    from tests.conftest import load_golden
+    from oracle import tramp_oracle as orc
+    cases = load_golden("solve")
+    assert len(cases) == 20
+    for c in cases:
+        o = orc.LinearSolveOracle(c["W"])
+        assert o.rank == c["rank"]
+        np.testing.assert_allclose(o.spectrum, c["spectrum"], rtol=0, atol=1e-13 * max(1.0, c["spectrum"].max()))
+        az, ax, bz, bx = c["az"], c["ax"], c["bz"], c["bx"]
+        np.testing.assert_allclose(o.n_eff(az, ax), c["n_eff"], rtol=1e-9)
+        np.testing.assert_allclose(o.backward_mean(az, bz, ax, bx), c["rz"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(o.forward_mean(az, bz, ax, bx), c["rx"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(o.backward_variance(az, ax), c["vz"], rtol=1e-9)
+        np.testing.assert_allclose(o.forward_variance(az, ax), c["vx"], rtol=1e-9)
+        a_b, b_b = o.backward_message(az, bz, ax, bx)
+        a_f, b_f = o.forward_message(az, bz, ax, bx)
+        np.testing.assert_allclose([a_b, a_f], [c["a_bwd"], c["a_fwd"]], rtol=1e-9)
+        np.testing.assert_allclose(b_b, c["b_bwd"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(b_f, c["b_fwd"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(o.log_partition(az, bz, ax, bx), c["logZ"], rtol=1e-10)
+    # the quirk is real: for the wide matrix the variances differ from the precompute_svd=True channel
+    wide = next(c for c in cases if c["name"] == "wide_8x12")
+    assert abs(orc.LinearOracle(wide["W"]).backward_variance(wide["az"], wide["ax"]) - wide["vz"]) > 1e-3
+
+
+def test_complex_conv_and_dft_oracles_match_reference_goldens():
+    """real=False: ConvChannel and DFTChannel on planar complex vectors, the oracle's restatement against the reference's
+    own outputs (tests/golden/conv_complex.npz from tools/make_golden_conv_complex.py)."""
+    import os
+    from tests.conftest import GOLDEN
+    from oracle import tramp_oracle as orc
+    with np.load(os.path.join(GOLDEN, "conv_complex.npz"), allow_pickle=True) as f:
+        conv, dft = list(f["data"]), list(f["dft"])
+    assert len(conv) == 16 and len(dft) == 8
+    for c in conv:
+        o = orc.ComplexConvOracle(c["filter"])
+        az, ax, bz, bx = c["az"], c["ax"], c["bz"], c["bx"]
+        np.testing.assert_allclose(o.n_eff(az, ax), c["n_eff"], rtol=1e-12)
+        np.testing.assert_allclose(o.second_moment(1.7), c["tau"], rtol=1e-12)
+        np.testing.assert_allclose(o.backward_mean(az, bz, ax, bx), c["rz"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(o.forward_mean(az, bz, ax, bx), c["rx"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose([o.backward_variance(az, ax), o.forward_variance(az, ax)], [c["vz"], c["vx"]], rtol=1e-12)
+        a_b, b_b = o.backward_message(az, bz, ax, bx)
+        a_f, b_f = o.forward_message(az, bz, ax, bx)
+        np.testing.assert_allclose([a_b, a_f], [c["a_bwd"], c["a_fwd"]], rtol=1e-10)
+        np.testing.assert_allclose(b_b, c["b_bwd"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(b_f, c["b_fwd"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(o.convolve(bz), c["sample"], rtol=1e-10, atol=1e-12)
+    for c in dft:
+        o = orc.ComplexDFTOracle(len(c["shape"]))
+        a_f, b_f = o.forward_message(1.3, c["bz"], 0.7, c["bx"])
+        a_b, b_b = o.backward_message(1.3, c["bz"], 0.7, c["bx"])
+        assert (a_f, a_b) == (c["a_fwd"], c["a_bwd"])
+        np.testing.assert_allclose(b_f, c["b_fwd"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(b_b, c["b_bwd"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(b_f, c["sample"], rtol=1e-12, atol=1e-13)

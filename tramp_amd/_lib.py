@@ -85,6 +85,7 @@ _SIGNATURES = {
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_conv_create": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],
+    "tramp_conv_create_complex": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],
     "tramp_conv_destroy": [vp, vp],
     "tramp_conv_spectrum": [vp, vp, vp, C.POINTER(sz), C.POINTER(dbl)],
     "tramp_conv_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
@@ -107,6 +108,7 @@ _SIGNATURES = {
     "tramp_conv_project_affine": [vp, vp, i32, sz, vp, dbl, i32],
     "tramp_dft_create": [vp, i32, i32, C.POINTER(sz), C.POINTER(vp)],
     "tramp_dft_destroy": [vp, vp],
+    "tramp_dft_set_complex_input": [vp, vp, i32],
     "tramp_dft_message": [vp, vp, i32, sz, vp, vp, dbl, vp, vp, vp, vp],
     "tramp_log_partition": [vp, i32, i32, sz, sz, dbl, dbl, dbl, vp, vp, vp, vp, vp],
     "tramp_linear_log_partition": [vp, vp, sz, vp, vp, vp, vp, i32, vp],

@@ -880,24 +880,29 @@ class ConvChannel(Channel):
     """
 
     def __init__(self, filter, real=True, name="W", dtype=np.float64, ctx=None):
-        if not real:
-            raise NotImplementedError("complex ConvChannel (real=False) is outside the HIP path")
-        filter = np.asarray(filter, dtype=np.float64)
+        filter = np.asarray(filter, dtype=np.float64 if real else np.complex128)
         if not 1 <= filter.ndim <= 3:
             raise ValueError("filter must have 1 to 3 axes")
         self.shape = filter.shape
-        self.real = real
+        self.real = bool(real)
         self.name = name
         self.repr_init()
         self._init_device(dtype, ctx)
         self.filter = filter
-        self.N = int(np.prod(self.shape))
+        n = int(np.prod(self.shape))
+        # real=False (conv_channel.py:25-32): x, w, z complex; every vector is the planar real array (2,) + shape
+        self._vshape = tuple(self.shape) if real else (2,) + tuple(self.shape)
+        self.N = n if real else 2 * n                           # vector length per instance on the device
         self.Nx = self.Nz = self.N
         ctx = self.ctx
-        fd = ctx.array(filter.reshape(-1), np.float64)
         dims = (C.c_size_t * filter.ndim)(*self.shape)
         h = C.c_void_p()
-        ctx._call("tramp_conv_create", self._dt, filter.ndim, dims, fd.ptr, C.byref(h))
+        if real:
+            fd = ctx.array(filter.reshape(-1), np.float64)
+            ctx._call("tramp_conv_create", self._dt, filter.ndim, dims, fd.ptr, C.byref(h))
+        else:
+            fd = ctx.array(np.concatenate([filter.real.reshape(-1), filter.imag.reshape(-1)]), np.float64)
+            ctx._call("tramp_conv_create_complex", self._dt, filter.ndim, dims, fd.ptr, C.byref(h))
         self._handle = h
         cnt, mean = C.c_size_t(), C.c_double()
         ctx._call("tramp_conv_spectrum", h, None, C.byref(cnt), C.byref(mean))
@@ -914,7 +919,9 @@ class ConvChannel(Channel):
 
     @property
     def half_spectrum(self):
-        "|rfftn(filter)|^2 flattened (last axis n_last // 2 + 1 bins)."
+        "|rfftn(filter)|^2 flattened (last axis n_last // 2 + 1 bins); real=False: the full |fftn(filter)|^2."
+        if not self.real:
+            return (np.abs(np.fft.fftn(self.filter))**2).reshape(-1)
         out = self.ctx.empty((self._n_half,), np.float64)
         self.ctx._call("tramp_conv_spectrum", self._handle, out.ptr, None, None)
         return out.get()
@@ -924,9 +931,9 @@ class ConvChannel(Channel):
         if isinstance(b, DeviceArray):
             return VecArg(self.ctx, b, self.dtype)
         h = np.asarray(b, dtype=self.dtype)
-        nd = len(self.shape)
-        if h.shape[-nd:] != tuple(self.shape) or h.ndim not in (nd, nd + 1):
-            raise ValueError(f"expected an array of shape {self.shape} or (batch,)+{self.shape}, got {h.shape}")
+        nd = len(self._vshape)
+        if h.shape[-nd:] != self._vshape or h.ndim not in (nd, nd + 1):
+            raise ValueError(f"expected an array of shape {self._vshape} or (batch,)+{self._vshape}, got {h.shape}")
         arg = VecArg(self.ctx, h.reshape(-1, self.N) if h.ndim == nd + 1 else h.reshape(self.N), self.dtype)
         arg.host_shape = h.shape
         arg._one = h.ndim == nd
@@ -1007,7 +1014,11 @@ class ConvChannel(Channel):
         return tgt, a_t, a_new, b_new, r, v
 
     _affine_entry = "tramp_conv_project_affine"
-    affine_update = LinearChannel.affine_update
+
+    def affine_update(self, side, old_key, msg, c, damping, token=None):
+        if not self.real:
+            return False                                               # the complex channel keeps no separate constant part
+        return LinearChannel.affine_update(self, side, old_key, msg, c, damping, token)
 
     def compute_backward_mean(self, az, bz, ax, bx):
         return self.compute_backward_posterior(az, bz, ax, bx)[0]      # :81-103
@@ -1278,15 +1289,13 @@ class _UnitaryChannel(Channel):
 
 
 class DFTChannel(_UnitaryChannel):
-    """x = fftn(z, norm="ortho") for real z (tramp/channels/linear/dft_channel.py:7-77).
+    """x = fftn(z, norm="ortho") (tramp/channels/linear/dft_channel.py:7-77), z real (``real=True``) or complex.
 
     A complex vector is the planar real array [2, n] as in the reference; on the device
     [batch, 2 n].  ``shape`` is only needed for transforms over more than one axis."""
 
     def __init__(self, real=True, shape=None, dtype=np.float64, ctx=None):
-        if not real:
-            raise NotImplementedError("complex input (real=False) is outside the HIP path")
-        self.real = real
+        self.real = bool(real)
         self.shape = None if shape is None else tuple(int(v) for v in np.atleast_1d(shape))
         self.repr_init()
         self._init_device(dtype, ctx)
@@ -1304,6 +1313,8 @@ class DFTChannel(_UnitaryChannel):
         h = C.c_void_p()
         self.ctx._call("tramp_dft_create", self._dt, len(dims), arr, C.byref(h))
         self._handle, self._n = h, n
+        if not self.real:
+            self.ctx._call("tramp_dft_set_complex_input", h, 1)
 
     def __del__(self):
         try:
@@ -1326,17 +1337,21 @@ class DFTChannel(_UnitaryChannel):
         n_tot = int(np.prod(h.shape[-nd:]))
         arg = VecArg(self.ctx, h.reshape(-1, n_tot) if h.ndim == nd + 1 else h.reshape(n_tot), self.dtype)
         lead = h.shape[:-nd]
-        self._out_shape = lead + (core if planar else (2,) + core)
+        self._lead, self._core = lead, core
         return arg
 
     def _message(self, direction, a_in, b_in, out_a, out_b, damping, old_a, old_b):
         ctx = self.ctx
-        src = self._vec(b_in, planar=(direction == _lib.BWD))
-        n = src.n if direction == _lib.FWD else src.n // 2
+        planar_in = direction == _lib.BWD or not self.real          # x is always complex, z when real=False
+        planar_out = direction == _lib.FWD or not self.real
+        src = self._vec(b_in, planar=planar_in)
+        if not isinstance(b_in, DeviceArray):
+            self._out_shape = self._lead + ((2,) + self._core if planar_out else self._core)
+        n = src.n // 2 if planar_in else src.n
         self._ensure(n)
         a = ScalArg(ctx, a_in, src.batch)
         a_new = out_a if out_a is not None else ctx.empty((src.batch,), np.float64)
-        n_out = 2 * n if direction == _lib.FWD else n
+        n_out = 2 * n if planar_out else n
         b_new = out_b if out_b is not None else ctx.empty((src.batch, n_out), self.dtype)
         ctx._call("tramp_dft_message", self._handle, direction, src.batch, a.dev.ptr, src.dev.ptr,
                   float(damping or 0.0), old_a.ptr if old_a is not None else None,

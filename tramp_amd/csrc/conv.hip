@@ -69,6 +69,7 @@ struct tramp_conv {
     // tables above hold [D][h] filter bins (D = 1, or the d filters of the gradient channel), wk [hl] by last-axis
     // position, plus the last-axis Nyquist bins of every outer position
     FftNdPlan* fftn;
+    bool cplx;                  // real=False: complex signals and filter, full spectra [n], planar vectors [2, n]
     size_t hl;                  // n_last / 2
     int ncomp;                  // D
     void* wbar_nq;              // [D][h / hl] complex
@@ -116,6 +117,10 @@ int make_plan_dims(tramp_ctx* ctx, int ndim, const size_t* dims, rocfft_transfor
 
 int make_plan(tramp_ctx* ctx, const tramp_conv* cv, bool forward, bool f64, size_t batch, rocfft_plan* plan,
               rocfft_execution_info* info, void** work) {
+    if (cv->cplx)
+        return make_plan_dims(ctx, cv->ndim, cv->dims,
+                              forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse, f64,
+                              batch, plan, info, work);
     return make_plan_dims(ctx, cv->ndim, cv->dims,
                           forward ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse, f64,
                           batch, plan, info, work);
@@ -158,7 +163,7 @@ int conv_reserve(tramp_ctx* ctx, tramp_conv* cv, size_t batch) {
     const size_t per = ((batch * cv->nh * csz + 255) / 256) * 256;
     const size_t scal = ((batch * sizeof(double) + 255) / 256) * 256;
     const size_t part = ((batch * (size_t)cv->nblk * sizeof(double) + 255) / 256) * 256;
-    const size_t rper = ((batch * cv->n * dtype_size(cv->dtype) + 255) / 256) * 256;
+    const size_t rper = ((batch * cv->n * (cv->cplx ? 2 : 1) * dtype_size(cv->dtype) + 255) / 256) * 256;
     TRAMP_HIP_CHECK(ctx, hipMalloc(&cv->work, 5 * per + rper + scal + part));
     char* p = (char*)cv->work;
     cv->fz = p;
@@ -815,6 +820,11 @@ void launch_spectral(tramp_ctx* ctx, tramp_conv* cv, int mode, size_t batch, con
 
 }  // namespace
 
+// complex channel (real=False), defined at the end of this file.  mode 0 / 1: forward / backward message, 2: x = w * z
+int conv_complex_run(tramp_ctx* ctx, tramp_conv* cv, int mode, size_t batch, const double* az_d, const void* bz_d,
+                     const double* ax_d, const void* bx_d, double damping, const double* a_old_d, const void* b_old_d,
+                     double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse);
+
 extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filter_d,
                                  tramp_conv** conv) {
     if (!ctx) return TRAMP_EINVAL;
@@ -844,6 +854,7 @@ extern "C" int tramp_conv_create(tramp_ctx* ctx, int dtype, int ndim, const size
     cv->s2 = nullptr;
     cv->fft2 = nullptr;
     cv->fftn = nullptr;
+    cv->cplx = false;
     cv->hl = 0;
     cv->ncomp = 1;
     cv->wbar_nq = nullptr;
@@ -972,6 +983,8 @@ extern "C" int tramp_conv_apply(tramp_ctx* ctx, tramp_conv* cv, size_t batch, co
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, cv && z_d && x_d);
     if (!batch) return TRAMP_OK;
+    if (cv->cplx) return conv_complex_run(ctx, cv, 2, batch, nullptr, z_d, nullptr, nullptr, 0.0, nullptr, nullptr, nullptr, x_d,
+                                          nullptr, nullptr, 0);
     int rc = conv_reserve(ctx, cv, batch);
     if (rc) return rc;
     ConvPlans* p = nullptr;
@@ -1001,6 +1014,7 @@ extern "C" int tramp_conv_project_affine(tramp_ctx* ctx, tramp_conv* cv, int whi
     TRAMP_REQUIRE(ctx, cv && c_d);
     TRAMP_REQUIRE(ctx, which == TRAMP_REUSE_T || which == TRAMP_REUSE_U);
     if (!batch) return TRAMP_OK;
+    if (cv->cplx) return tramp_fail(ctx, TRAMP_ENOTSUP, "tramp_conv_project_affine", "complex channel");
     if (!cv->work || cv->proj_batch != batch || batch > cv->work_batch)
         return tramp_fail(ctx, TRAMP_EINVAL, "tramp_conv_project_affine",
                           "the handle holds no transform of the message being updated");
@@ -1039,6 +1053,9 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
     TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
     if (!batch) return TRAMP_OK;
+    if (cv->cplx)
+        return conv_complex_run(ctx, cv, dir == TRAMP_FWD ? 0 : 1, batch, az_d, bz_d, ax_d, bx_d, damping, a_old_d, b_old_d,
+                                a_new_d, b_new_d, r_d, v_d, reuse);
     const void* work_before = cv->work;
     int rc = conv_reserve(ctx, cv, batch);
     if (rc) return rc;
@@ -1313,6 +1330,7 @@ extern "C" int tramp_grad_create(tramp_ctx* ctx, int dtype, int ndim, const size
     cv->s2 = nullptr;
     cv->fft2 = nullptr;
     cv->fftn = nullptr;
+    cv->cplx = false;
     cv->hl = 0;
     cv->ncomp = ndim;
     cv->wbar_nq = nullptr;
@@ -1500,6 +1518,12 @@ struct tramp_dft {
     size_t work_batch;
     void* c0;
     void* c1;
+    // own FFT engine on the full complex array (fft_pow2.hip, every axis in its permuted order): the two index
+    // tables translate between positions of the transform and natural (row-major) frequencies
+    FftNdPlan* fftn;
+    int* nat_of_pos;     // [n]
+    int* pos_of_nat;     // [n]
+    bool complex_in;     // real=False: z is complex too (planar [2, n] on both sides)
 };
 
 namespace {
@@ -1516,15 +1540,18 @@ __global__ __launch_bounds__(kBlock) void dft_pack_real_kernel(size_t count, con
     }
 }
 
-// planar [batch, 2, n] -> interleaved [batch, n]
+// planar [batch, 2, n] -> interleaved [batch, n]; with `idx`, position i takes element idx[i] (the transform's
+// permuted order)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void dft_pack_planar_kernel(size_t n, const T* __restrict__ in,
-                                                                 typename Cx<T>::type* __restrict__ out) {
+                                                                 typename Cx<T>::type* __restrict__ out,
+                                                                 const int* __restrict__ idx) {
     const size_t b = blockIdx.y;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const size_t j = idx ? (size_t)idx[i] : i;
         typename Cx<T>::type c;
-        c.x = in[b * 2 * n + i];
-        c.y = in[b * 2 * n + n + i];
+        c.x = in[b * 2 * n + j];
+        c.y = in[b * 2 * n + n + j];
         out[b * n + i] = c;
     }
 }
@@ -1534,11 +1561,12 @@ __global__ __launch_bounds__(kBlock) void dft_pack_planar_kernel(size_t n, const
 template <typename T>
 __global__ __launch_bounds__(kBlock) void dft_unpack_kernel(size_t n, int planar, T scale,
                                                             const typename Cx<T>::type* __restrict__ in,
-                                                            double damping, const T* b_old, T* out) {
+                                                            double damping, const T* b_old, T* out,
+                                                            const int* __restrict__ idx) {
     const size_t b = blockIdx.y;
     const T d = T(damping), omd = T(1.0 - damping);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        const typename Cx<T>::type c = in[b * n + i];
+        const typename Cx<T>::type c = in[b * n + (idx ? (size_t)idx[i] : i)];   // idx: where frequency i sits
         if (planar) {
             T re = c.x * scale, im = c.y * scale;
             const size_t o = b * 2 * n + i;
@@ -1566,6 +1594,8 @@ __global__ void dft_scalar_kernel(size_t batch, const double* __restrict__ a_in,
 
 }  // namespace
 
+extern "C" int tramp_dft_destroy(tramp_ctx* ctx, tramp_dft* h);
+
 extern "C" int tramp_dft_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, tramp_dft** dft) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, dft && dims);
@@ -1586,7 +1616,51 @@ extern "C" int tramp_dft_create(tramp_ctx* ctx, int dtype, int ndim, const size_
     }
     h->work = nullptr;
     h->work_batch = 0;
+    h->fftn = nullptr;
+    h->nat_of_pos = h->pos_of_nat = nullptr;
+    h->complex_in = false;
+    const char* eng = getenv("TRAMP_CONV_FFT");
+    if (!(eng && strcmp(eng, "rocfft") == 0) && h->n <= 0x7fffffffull && fftnd_supported(dtype, ndim, h->dims, false)) {
+        int rc = fftnd_plan_create(ctx, dtype, ndim, h->dims, &h->fftn, false);
+        if (rc) {
+            delete h;
+            return rc;
+        }
+        std::vector<int> nat(h->n), pos(h->n);
+        std::vector<size_t> kf[3];
+        for (int a = 0; a < ndim; ++a) {
+            kf[a].resize(h->dims[a]);
+            for (size_t i = 0; i < h->dims[a]; ++i) kf[a][i] = fftnd_kfreq(h->fftn, a, i);
+        }
+        for (size_t p = 0; p < h->n; ++p) {
+            size_t rem = p, k = 0, stride = 1;
+            for (int a = ndim - 1; a >= 0; --a) {
+                k += kf[a][rem % h->dims[a]] * stride;
+                rem /= h->dims[a];
+                stride *= h->dims[a];
+            }
+            nat[p] = (int)k;
+            pos[k] = (int)p;
+        }
+        hipError_t e = hipMalloc((void**)&h->nat_of_pos, h->n * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&h->pos_of_nat, h->n * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(h->nat_of_pos, nat.data(), h->n * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->pos_of_nat, pos.data(), h->n * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)tramp_dft_destroy(ctx, h);
+            return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_dft_create", hipGetErrorString(e));
+        }
+    }
     *dft = h;
+    return TRAMP_OK;
+}
+
+// real=False (dft_channel.py:31-45): z is complex as well, carried as the planar array [2, n] like x
+extern "C" int tramp_dft_set_complex_input(tramp_ctx* ctx, tramp_dft* h, int on) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, h);
+    h->complex_in = on != 0;
     return TRAMP_OK;
 }
 
@@ -1602,6 +1676,9 @@ extern "C" int tramp_dft_destroy(tramp_ctx* ctx, tramp_dft* h) {
         if (p.work_inv) (void)hipFree(p.work_inv);
     }
     if (h->work) (void)hipFree(h->work);
+    if (h->fftn) fftnd_plan_destroy(h->fftn);
+    if (h->nat_of_pos) (void)hipFree(h->nat_of_pos);
+    if (h->pos_of_nat) (void)hipFree(h->pos_of_nat);
     delete h;
     return TRAMP_OK;
 }
@@ -1630,7 +1707,7 @@ extern "C" int tramp_dft_message(tramp_ctx* ctx, tramp_dft* h, int dir, size_t b
     DftPlans* pl = nullptr;
     for (auto& p : h->plans)
         if (p.batch == batch) pl = &p;
-    if (!pl) {
+    if (!pl && !h->fftn) {
         if (ctx->capturing) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_dft", "FFT plan creation inside graph capture");
         DftPlans p{};
         p.batch = batch;
@@ -1649,40 +1726,283 @@ extern "C" int tramp_dft_message(tramp_ctx* ctx, tramp_dft* h, int dir, size_t b
     dim3 g(grid_for(n), (unsigned)batch);
     hipLaunchKernelGGL(dft_scalar_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, batch, a_in_d,
                        damping, a_old_d, a_new_d);
+    const bool own = h->fftn != nullptr;
+    const bool real_in = fwd && !h->complex_in;                 // the only real-valued input
+    const bool planar_out = fwd || h->complex_in;
+    // backward on the own engine: the inverse transform wants the spectrum in its permuted order
+    const int* pack_idx = (own && !fwd) ? h->nat_of_pos : nullptr;
+    // forward on the own engine: frequency k sits at position pos_of_nat[k] of the transform's output
+    const int* unpack_idx = (own && fwd) ? h->pos_of_nat : nullptr;
     {
-        ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (fwd ? 3 : 4), 0);
+        ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (real_in ? 3 : 4), 0);
         if (h->dtype == TRAMP_F64) {
-            if (fwd)
+            if (real_in)
                 hipLaunchKernelGGL((dft_pack_real_kernel<double>), dim3(grid_for(batch * n)), dim3(kBlock), 0,
                                    ctx->stream, batch * n, (const double*)b_in_d, (double2*)h->c0);
             else
                 hipLaunchKernelGGL((dft_pack_planar_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n,
-                                   (const double*)b_in_d, (double2*)h->c0);
+                                   (const double*)b_in_d, (double2*)h->c0, pack_idx);
         } else {
-            if (fwd)
+            if (real_in)
                 hipLaunchKernelGGL((dft_pack_real_kernel<float>), dim3(grid_for(batch * n)), dim3(kBlock), 0,
                                    ctx->stream, batch * n, (const float*)b_in_d, (float2*)h->c0);
             else
                 hipLaunchKernelGGL((dft_pack_planar_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n,
-                                   (const float*)b_in_d, (float2*)h->c0);
+                                   (const float*)b_in_d, (float2*)h->c0, pack_idx);
         }
         TRAMP_LAUNCH_CHECK(ctx);
     }
     {
         ProfScope ps(ctx, PROF_FFT, (double)batch * n * 4 * esz, 0);
-        int rc = fwd ? fft_exec(ctx, pl->fwd, pl->info_fwd, h->c0, h->c1)
-                     : fft_exec(ctx, pl->inv, pl->info_inv, h->c0, h->c1);
+        int rc;
+        if (own) rc = fwd ? fftnd_forward(ctx, h->fftn, batch, h->c0, h->c1) : fftnd_inverse(ctx, h->fftn, batch, h->c0, h->c1);
+        else rc = fwd ? fft_exec(ctx, pl->fwd, pl->info_fwd, h->c0, h->c1) : fft_exec(ctx, pl->inv, pl->info_inv, h->c0, h->c1);
         if (rc) return rc;
     }
     {
-        ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (fwd ? 4 : 3), 0);
+        ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (planar_out ? 4 : 3), 0);
         if (h->dtype == TRAMP_F64)
-            hipLaunchKernelGGL((dft_unpack_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n, fwd ? 1 : 0, scale,
-                               (const double2*)h->c1, damping, (const double*)b_old_d, (double*)b_new_d);
+            hipLaunchKernelGGL((dft_unpack_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n, planar_out ? 1 : 0, scale,
+                               (const double2*)h->c1, damping, (const double*)b_old_d, (double*)b_new_d, unpack_idx);
         else
-            hipLaunchKernelGGL((dft_unpack_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n, fwd ? 1 : 0,
-                               (float)scale, (const float2*)h->c1, damping, (const float*)b_old_d, (float*)b_new_d);
+            hipLaunchKernelGGL((dft_unpack_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n, planar_out ? 1 : 0,
+                               (float)scale, (const float2*)h->c1, damping, (const float*)b_old_d, (float*)b_new_d,
+                               unpack_idx);
         TRAMP_LAUNCH_CHECK(ctx);
     }
+    return TRAMP_OK;
+}
+
+// ---------------------------------------------------------------- complex convolution channel (real=False)
+// ConvChannel(filter, real=False) (tramp/channels/linear/conv_channel.py:14-32, 81-109): x, w, z complex, every vector the
+// planar real array [2, n] (real parts, then imaginary parts).  The spectra are full complex transforms of n points and
+// the update is purely elementwise in the Fourier basis - no Hermitian pairing.  Own FFT engine on the complex array when
+// the shape allows (tables stored in the transform's permuted order, so the elementwise kernel is the natural-order one),
+// rocFFT complex plans otherwise.  Scalars: n_eff is the plain mean over the n bins (conv_channel.py:69-79).
+namespace {
+
+// interleaved [batch, n] -> planar [batch, 2, n]; with a_in: message update b_new = r (a_in + a_raw) - b_in on the way
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cplx_unpack_kernel(size_t n, const typename Cx<T>::type* __restrict__ c,
+                                                             const double* __restrict__ a_in,
+                                                             const double* __restrict__ a_raw, const T* __restrict__ b_in,
+                                                             double damping, const T* b_old, T* out, T* r_out) {
+    const size_t b = blockIdx.y;
+    const T asum = a_in ? (T)(a_in[b] + a_raw[b]) : T(1);
+    const T d = (T)damping, omd = (T)(1.0 - damping);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const typename Cx<T>::type v = c[b * n + i];
+        const size_t o = b * 2 * n + i;
+        T re = v.x, im = v.y;
+        if (r_out) {
+            r_out[o] = re;
+            r_out[o + n] = im;
+        }
+        if (a_in) {
+            re = re * asum - b_in[o];
+            im = im * asum - b_in[o + n];
+            if (damping != 0.0) {
+                re = d * b_old[o] + omd * re;
+                im = d * b_old[o + n] + omd * im;
+            }
+        }
+        out[o] = re;
+        out[o + n] = im;
+    }
+}
+
+template <typename T>
+int conv_complex_run_t(tramp_ctx* ctx, tramp_conv* cv, int mode, size_t batch, const double* az_d, const void* bz_d,
+                       const double* ax_d, const void* bx_d, double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse) {
+    using C = typename Cx<T>::type;
+    const void* work_before = cv->work;
+    int rc = conv_reserve(ctx, cv, batch);
+    if (rc) return rc;
+    if (cv->work != work_before || cv->proj_batch != batch || mode == 2) reuse = 0;
+    cv->proj_batch = (mode == 2) ? 0 : batch;
+    ConvPlans* p = nullptr;
+    if (!cv->fftn) {
+        rc = plans_for(ctx, cv, batch, &p);
+        if (rc) return rc;
+    }
+    const size_t n = cv->n, esz = dtype_size(cv->dtype);
+    const dim3 g(grid_for(n), (unsigned)batch);
+    if (mode != 2) {
+        ProfScope ps(ctx, PROF_LIN_SCALARS, 0, 0);
+        rc = conv_scalars(ctx, cv, cv->partial, mode == 0 ? TRAMP_FWD : TRAMP_BWD, batch, az_d, ax_d, damping, a_old_d, v_d,
+                          a_new_d, cv->a_raw, nullptr);
+        if (rc) return rc;
+    }
+    // planar -> interleaved (staged in fo) -> spectrum
+    auto forward = [&](const void* src, void* spec) -> int {
+        hipLaunchKernelGGL((dft_pack_planar_kernel<T>), g, dim3(kBlock), 0, ctx->stream, n, (const T*)src, (C*)cv->fo,
+                           (const int*)nullptr);
+        ProfScope ps(ctx, PROF_FFT, (double)batch * n * 4 * esz, 0);
+        return conv_forward(ctx, cv, p, batch, cv->fo, spec);
+    };
+    if (!(reuse & TRAMP_REUSE_T)) {
+        rc = forward(bz_d, cv->fz);
+        if (rc) return rc;
+    }
+    if (mode != 2 && !(reuse & TRAMP_REUSE_U)) {
+        rc = forward(bx_d, cv->fx);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, PROF_LIN_SCALARS, (double)batch * n * 6 * esz, 0);
+        hipLaunchKernelGGL((conv_spectral_kernel<T>), g, dim3(kBlock), 0, ctx->stream, mode, n, 1.0 / n, (const C*)cv->wbar,
+                           cv->s2_p ? cv->s2_p : cv->s2, az_d, ax_d, (const C*)cv->fz, (const C*)cv->fx, (C*)cv->fo);
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(ctx, PROF_FFT, (double)batch * n * 4 * esz, 0);
+        rc = conv_inverse(ctx, cv, p, batch, cv->fo, cv->fzc);            // interleaved mean
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, PROF_EW, (double)batch * n * 2 * esz * (damping != 0.0 ? 4 : 3), 0);
+        if (mode == 2)
+            hipLaunchKernelGGL((cplx_unpack_kernel<T>), g, dim3(kBlock), 0, ctx->stream, n, (const C*)cv->fzc,
+                               (const double*)nullptr, (const double*)nullptr, (const T*)nullptr, 0.0, (const T*)nullptr,
+                               (T*)b_new_d, (T*)nullptr);
+        else
+            hipLaunchKernelGGL((cplx_unpack_kernel<T>), g, dim3(kBlock), 0, ctx->stream, n, (const C*)cv->fzc,
+                               mode == 0 ? ax_d : az_d, (const double*)cv->a_raw, (const T*)(mode == 0 ? bx_d : bz_d), damping,
+                               (const T*)b_old_d, (T*)b_new_d, (T*)r_d);
+        TRAMP_LAUNCH_CHECK(ctx);
+    }
+    return TRAMP_OK;
+}
+
+}  // namespace
+
+int conv_complex_run(tramp_ctx* ctx, tramp_conv* cv, int mode, size_t batch, const double* az_d, const void* bz_d,
+                     const double* ax_d, const void* bx_d, double damping, const double* a_old_d, const void* b_old_d,
+                     double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse) {
+    return cv->dtype == TRAMP_F64
+               ? conv_complex_run_t<double>(ctx, cv, mode, batch, az_d, bz_d, ax_d, bx_d, damping, a_old_d, b_old_d, a_new_d,
+                                            b_new_d, r_d, v_d, reuse)
+               : conv_complex_run_t<float>(ctx, cv, mode, batch, az_d, bz_d, ax_d, bx_d, damping, a_old_d, b_old_d, a_new_d,
+                                           b_new_d, r_d, v_d, reuse);
+}
+
+// filter_d: planar [2, n] f64 (real parts, imaginary parts)
+extern "C" int tramp_conv_create_complex(tramp_ctx* ctx, int dtype, int ndim, const size_t* dims, const double* filter_d,
+                                         tramp_conv** conv) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, conv && dims && filter_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F64 || dtype == TRAMP_F32);
+    TRAMP_REQUIRE(ctx, ndim >= 1 && ndim <= 3);
+    std::call_once(g_rocfft_once, [] { (void)rocfft_setup(); });
+    tramp_conv* cv = new tramp_conv();
+    cv->dtype = dtype;
+    cv->ndim = ndim;
+    cv->n = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (dims[d] == 0) {
+            delete cv;
+            return tramp_fail(ctx, TRAMP_EINVAL, "tramp_conv_create_complex", "zero-length axis");
+        }
+        cv->dims[d] = dims[d];
+        cv->n *= dims[d];
+    }
+    cv->cplx = true;
+    cv->nlast = dims[ndim - 1];
+    cv->nhl = 1;                                  // every bin of the full spectrum counts once (herm_weight)
+    cv->nh = cv->n;
+    cv->nblk = (int)((cv->nh + 4095) / 4096 > 256 ? 256 : (cv->nh + 4095) / 4096);
+    cv->ncomp = 1;
+    cv->work = cv->wbar = cv->wbar_p = cv->wk = cv->wbar_nq = nullptr;
+    cv->s2 = cv->s2_p = cv->s2_nq = nullptr;
+    cv->partner = cv->leaders = nullptr;
+    cv->fft2 = nullptr;
+    cv->fftn = nullptr;
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* pwork = nullptr;
+    double2 *wi = nullptr, *w64 = nullptr;
+    auto cleanup = [&](bool failed) {
+        if (wi) (void)hipFree(wi);
+        if (w64) (void)hipFree(w64);
+        if (pwork) (void)hipFree(pwork);
+        if (info) (void)rocfft_execution_info_destroy(info);
+        if (plan) (void)rocfft_plan_destroy(plan);
+        if (failed) (void)tramp_conv_destroy(ctx, cv);
+    };
+    const size_t n = cv->n, csz = 2 * dtype_size(dtype);
+    int rc = make_plan(ctx, cv, true, true, 1, &plan, &info, &pwork);       // f64 complex forward, setup only
+    if (rc) {
+        cleanup(true);
+        return rc;
+    }
+    hipError_t e = hipMalloc((void**)&wi, n * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void**)&w64, n * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&cv->wbar, n * csz);
+    if (e == hipSuccess) e = hipMalloc((void**)&cv->s2, n * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        cleanup(true);
+        return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_conv_create_complex", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((dft_pack_planar_kernel<double>), dim3(grid_for(n), 1), dim3(kBlock), 0, ctx->stream, n, filter_d, wi,
+                       (const int*)nullptr);
+    rc = fft_exec(ctx, plan, info, wi, w64);
+    if (rc) {
+        cleanup(true);
+        return rc;
+    }
+    std::vector<double2> wh(n);
+    e = hipMemcpyAsync(wh.data(), w64, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        cleanup(true);
+        return tramp_fail(ctx, TRAMP_EHIP, "tramp_conv_create_complex", hipGetErrorString(e));
+    }
+    // own engine: the tables go into the transform's permuted order (the spectral kernel is elementwise)
+    const char* eng = getenv("TRAMP_CONV_FFT");
+    std::vector<double2> wt(wh);
+    if (!(eng && strcmp(eng, "rocfft") == 0) && fftnd_supported(dtype, ndim, cv->dims, false)) {
+        rc = fftnd_plan_create(ctx, dtype, ndim, cv->dims, &cv->fftn, false);
+        if (rc) {
+            cleanup(true);
+            return rc;
+        }
+        cv->h = n;
+        std::vector<size_t> kf[3];
+        for (int a = 0; a < ndim; ++a) {
+            kf[a].resize(cv->dims[a]);
+            for (size_t i = 0; i < cv->dims[a]; ++i) kf[a][i] = fftnd_kfreq(cv->fftn, a, i);
+        }
+        for (size_t p = 0; p < n; ++p) {
+            size_t rem = p, k = 0, stride = 1;
+            for (int a = ndim - 1; a >= 0; --a) {
+                k += kf[a][rem % cv->dims[a]] * stride;
+                rem /= cv->dims[a];
+                stride *= cv->dims[a];
+            }
+            wt[p] = wh[k];
+        }
+    }
+    std::vector<double> s2h(n);
+    long double acc = 0.0L;
+    for (size_t i = 0; i < n; ++i) {
+        s2h[i] = wt[i].x * wt[i].x + wt[i].y * wt[i].y;                    // conv_channel.py:45
+        acc += (long double)s2h[i];
+    }
+    cv->s_mean = (double)(acc / (long double)n);
+    if (dtype == TRAMP_F64) e = hipMemcpy(cv->wbar, wt.data(), n * csz, hipMemcpyHostToDevice);
+    else {
+        std::vector<float2> wf(n);
+        for (size_t i = 0; i < n; ++i) wf[i] = float2{(float)wt[i].x, (float)wt[i].y};
+        e = hipMemcpy(cv->wbar, wf.data(), n * csz, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMemcpy(cv->s2, s2h.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        cleanup(true);
+        return tramp_fail(ctx, TRAMP_EHIP, "tramp_conv_create_complex", hipGetErrorString(e));
+    }
+    cleanup(false);
+    *conv = cv;
     return TRAMP_OK;
 }

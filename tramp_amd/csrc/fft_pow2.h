@@ -77,9 +77,11 @@ struct FftNdPlan {
     int nrad[2], rad[2][16];
 };
 
-// real dims [ndim] (last axis even); false: some axis is not 2^a 5^b / too long / the lines do not tile
-bool fftnd_supported(int dtype, int ndim, const size_t* real_dims);
-int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_dims, FftNdPlan** out);
+// real dims [ndim] (last axis even); false: some axis is not 2^a 5^b / too long / the lines do not tile.
+// packed_real = false: the dims are those of a COMPLEX array (DFT channel, complex convolutions), no halving
+bool fftnd_supported(int dtype, int ndim, const size_t* real_dims, bool packed_real = true);
+int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_dims, FftNdPlan** out,
+                      bool packed_real = true);
 void fftnd_plan_destroy(FftNdPlan* pl);
 size_t fftnd_kfreq(const FftNdPlan* pl, int axis, size_t p);
 int fftnd_forward(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, const void* in, void* out);

@@ -750,11 +750,11 @@ bool row_shape(size_t hl, Fft2Shape* sh, bool* block_only) {
 
 }  // namespace
 
-bool fftnd_supported(int dtype, int ndim, const size_t* rd) {
+bool fftnd_supported(int dtype, int ndim, const size_t* rd, bool packed_real) {
     if (ndim < 1 || ndim > 3 || (dtype != TRAMP_F64 && dtype != TRAMP_F32)) return false;
     const size_t nl = rd[ndim - 1];
-    if (nl < 4 || (nl & 1)) return false;
-    const size_t hl = nl / 2;
+    if (packed_real && (nl < 4 || (nl & 1))) return false;
+    const size_t hl = packed_real ? nl / 2 : nl;
     const size_t c1 = dtype == TRAMP_F64 ? c1_of<double>() : c1_of<float>();
     Fft2Shape sh;
     bool blk;
@@ -770,8 +770,8 @@ bool fftnd_supported(int dtype, int ndim, const size_t* rd) {
     return true;
 }
 
-int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* rd, FftNdPlan** out) {
-    if (!fftnd_supported(dtype, ndim, rd))
+int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* rd, FftNdPlan** out, bool packed_real) {
+    if (!fftnd_supported(dtype, ndim, rd, packed_real))
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fftnd_plan_create", "shape outside the own FFT engine");
     FftNdPlan* pl = new FftNdPlan();
     memset(pl, 0, sizeof(*pl));
@@ -779,7 +779,7 @@ int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* rd, Fft
     pl->ndim = ndim;
     pl->h = 1;
     for (int a = 0; a < ndim; ++a) {
-        pl->dims[a] = a == ndim - 1 ? rd[a] / 2 : rd[a];
+        pl->dims[a] = (a == ndim - 1 && packed_real) ? rd[a] / 2 : rd[a];
         pl->h *= pl->dims[a];
     }
     const size_t hl = pl->dims[ndim - 1];
