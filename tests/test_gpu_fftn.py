@@ -296,3 +296,17 @@ def test_complex_conv_channel_larger_shapes_and_damping(ctx, shape, monkeypatch)
             a_d, b_d = out[eng + "_damped"]
             np.testing.assert_allclose(a_d[b], 0.25 * 0.9 + 0.75 * ra, rtol=1e-9)
             np.testing.assert_allclose(b_d[b].reshape(rb.shape), 0.25 * bx[b] + 0.75 * rb, rtol=0, atol=1e-11 * np.abs(rb).max())
+
+
+def test_gradient_channel_real_false_returns_complex(ctx):
+    "real=False only drops np.real() in the reference (gradient_channel.py:32-33, 73-74, 82-83): complex results, same values"
+    import tramp_amd as T
+    rs = np.random.RandomState(1)
+    shape = (8, 16)
+    a, b = T.GradientChannel(shape, ctx=ctx), T.GradientChannel(shape, real=False, ctx=ctx)
+    bz, bx = rs.standard_normal(shape), rs.standard_normal((2,) + shape)
+    ra, va = a.compute_forward_posterior(1.2, bz, 0.8, bx)
+    rb, vb = b.compute_forward_posterior(1.2, bz, 0.8, bx)
+    assert np.iscomplexobj(rb) and not np.iscomplexobj(ra) and va == vb
+    assert np.array_equal(rb.real, ra) and not rb.imag.any()
+    assert np.iscomplexobj(b.sample(bz)) and np.array_equal(b.sample(bz).real, a.sample(bz))

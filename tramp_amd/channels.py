@@ -1143,8 +1143,6 @@ class GradientChannel(Channel):
     """
 
     def __init__(self, shape, real=True, dtype=np.float64, ctx=None):
-        if not real:
-            raise NotImplementedError("complex GradientChannel (real=False) is outside the HIP path")
         shape = tuple(int(s) for s in shape)
         if not 1 <= len(shape) <= 3:
             raise ValueError("shape must have 1 to 3 axes")
@@ -1188,7 +1186,13 @@ class GradientChannel(Channel):
         arg._one = h.ndim == nd
         return arg
 
-    _ret = staticmethod(ConvChannel._ret)
+    def _ret(self, dev, like):
+        """real=False only drops the reference's np.real() (gradient_channel.py:32-33, 73-74, 82-83): with the real
+        inputs the channel takes, host results come back as complex arrays whose imaginary part is zero (round-off in
+        the reference, exactly zero here)."""
+        out = ConvChannel._ret(dev, like)
+        return out.astype(np.complex128) if (not self.real and like.was_host) else out
+
     _ret_scal = staticmethod(ConvChannel._ret_scal)
 
     def convolve(self, z):
@@ -1197,7 +1201,8 @@ class GradientChannel(Channel):
         x = self.ctx.empty((zz.batch, self.Nx), self.dtype)
         self.ctx._call("tramp_grad_apply", self._handle, zz.batch, zz.dev.ptr, x.ptr)
         if zz.was_host:
-            return x.get().reshape(((zz.batch,) if not zz._one else ()) + (self.d,) + self.shape)
+            out = x.get().reshape(((zz.batch,) if not zz._one else ()) + (self.d,) + self.shape)
+            return out if self.real else out.astype(np.complex128)
         return x
 
     def sample(self, Z):

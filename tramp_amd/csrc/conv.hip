@@ -1099,10 +1099,16 @@ extern "C" int tramp_conv_message(tramp_ctx* ctx, tramp_conv* cv, int dir, size_
     if (cv->fft2) {
         // 4+5. own engine: the inverse transform's last pass applies the message update as it stores
         ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz * (damping != 0.0 ? 3 : 2) + nh * 2 * esz), 0);
-        Fft2Epi epi{a_in, cv->a_raw, b_in, damping, b_old_d, b_new_d, r_d, PriorHintDev{}};
+        Fft2Epi epi{a_in, cv->a_raw, b_in, damping, b_old_d, b_new_d, r_d, PriorHintDev{}, 0};
         rc = fft2_inverse(ctx, cv->fft2, batch, cv->fo, nullptr, &epi);
         if (rc) return rc;
         return TRAMP_OK;
+    }
+    if (cv->fftn) {
+        // the same on the N-D plans: the last (row) pass of the inverse stores the message
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (n * esz * (damping != 0.0 ? 3 : 2) + nh * 2 * esz), 0);
+        Fft2Epi epi{a_in, cv->a_raw, b_in, damping, b_old_d, b_new_d, r_d, PriorHintDev{}, 0};
+        return fftnd_inverse(ctx, cv->fftn, batch, cv->fo, nullptr, &epi);
     }
     // 4. back to the signal domain; the mean lands in r_d when asked for, else in b_new_d
     //    (scratch under damping: b_old usually IS b_new and must survive the transform)
@@ -1473,6 +1479,13 @@ extern "C" int tramp_grad_message(tramp_ctx* ctx, tramp_grad* g, int dir, size_t
     const size_t len = fwd ? d * n : n;                               // target vector length per instance
     const double* a_in = fwd ? ax_d : az_d;
     const void* b_in = fwd ? bx_d : bz_d;
+    if (cv->fftn) {
+        // own engine: the last pass of the inverse stores the message update (d signals per instance going forward:
+        // the scalar tables are indexed by instance = signal / d, which rows_per_inst folds in)
+        ProfScope ps(ctx, PROF_FFT, (double)batch * (fwd ? d : 1) * (n * esz * (damping != 0.0 ? 3 : 2) + nh * 2 * esz), 0);
+        Fft2Epi epi{a_in, g->ga_raw, b_in, damping, b_old_d, b_new_d, r_d, PriorHintDev{}, 0};
+        return fftnd_inverse_signals(ctx, cv->fftn, batch, fwd ? d : 1, g->gfo, &epi);
+    }
     void* mean = r_d ? r_d : (damping != 0.0 ? g->gfr : b_new_d);
     {
         ProfScope ps(ctx, PROF_FFT, (double)batch * (fwd ? d : 1) * (n * esz + nh * 2 * esz), 0);

@@ -38,6 +38,7 @@ struct Fft2Epi {
     void* out;            // [batch, 2 h]; null: no epilogue (plain store)
     void* r_out;          // optional
     PriorHintDev hint;    // kind != 0: the consumer is a separable prior - leave sum v_i per tile (prior_hint.h)
+    size_t rows_per_inst; // transforms per problem instance (N-D: the rows of one signal); 0 counts as 1
 };
 
 // false when h is not 2^a 5^b or does not split into a [G <= 320] x [512 <= LB <= 4096] pair
@@ -85,7 +86,10 @@ int fftnd_plan_create(tramp_ctx* ctx, int dtype, int ndim, const size_t* real_di
 void fftnd_plan_destroy(FftNdPlan* pl);
 size_t fftnd_kfreq(const FftNdPlan* pl, int axis, size_t p);
 int fftnd_forward(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, const void* in, void* out);
-// spectrum is overwritten
-int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spectrum, void* out);
+// spectrum is overwritten; with an epilogue the last pass stores the message update instead of the mean
+int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spectrum, void* out,
+                  const Fft2Epi* epi = nullptr);
+int fftnd_inverse_signals(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, size_t signals, void* spectrum,
+                          const Fft2Epi* epi);
 // single block pass for h <= 4096 (G = 1)
 bool fft2_block_shape(size_t h, Fft2Shape* sh);

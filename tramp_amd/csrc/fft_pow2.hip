@@ -201,7 +201,8 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
     }
     if constexpr (EPI) {
         // message update on the way out: the complex value is the pair (r[2 i], r[2 i + 1]) of the mean
-        const T asum = (T)(epi.a_in[tf] + epi.a_raw[tf]);
+        const size_t inst = epi.rows_per_inst > 1 ? tf / epi.rows_per_inst : tf;
+        const T asum = (T)(epi.a_in[inst] + epi.a_raw[inst]);
         const T d = (T)epi.damping, omd = (T)(1.0 - epi.damping);
         const C* bin = reinterpret_cast<const C*>(epi.b_in) + tf * h;
         const C* bold = epi.damping != 0.0 ? reinterpret_cast<const C*>(epi.b_old) + tf * h : nullptr;
@@ -252,11 +253,11 @@ __global__ __launch_bounds__(1024) void fft_strided_kernel(Fft2Shape sh, const t
 // ---------------------------------------------------------------- pass 2: inside blocks of LB
 // A workgroup takes tile_pts consecutive points (a whole number of blocks of LB: the stage structure repeats with
 // period L <= LB, so several short blocks share one tile); in and out may coincide.
-template <typename T, bool INV>
+template <typename T, bool INV, bool EPI = false>
 __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typename C2<T>::type* __restrict__ in,
                                                         typename C2<T>::type* __restrict__ out,
                                                         const typename C2<T>::type* __restrict__ tw_blk, int tile_pts,
-                                                        size_t total_pts) {
+                                                        size_t total_pts, Fft2Epi epi = Fft2Epi{}) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
@@ -286,6 +287,30 @@ __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typ
             bfly_at<C, INV>(tile, base, sub, r, tws[m]);
         }
         __syncthreads();
+    }
+    if constexpr (EPI) {
+        // message update on the way out (block-only inverse of the N-D plans): the complex value is the pair
+        // (r[2 i], r[2 i + 1]) of the mean; rows of LB points, rows_per_inst of them per problem instance
+        const T d = (T)epi.damping, omd = (T)(1.0 - epi.damping);
+        const C* bin = reinterpret_cast<const C*>(epi.b_in) + first;
+        const C* bold = epi.damping != 0.0 ? reinterpret_cast<const C*>(epi.b_old) + first : nullptr;
+        C* bo = reinterpret_cast<C*>(epi.out) + first;
+        C* ro = epi.r_out ? reinterpret_cast<C*>(epi.r_out) + first : nullptr;
+        const size_t pts_per_inst = (epi.rows_per_inst ? epi.rows_per_inst : 1) * sh.LB;
+        for (int i = threadIdx.x; i < npts; i += nthr) {
+            const size_t inst = (first + i) / pts_per_inst;
+            const T asum = (T)(epi.a_in[inst] + epi.a_raw[inst]);
+            const C r = tile[i], bi = bin[i];
+            C bn = {r.x * asum - bi.x, r.y * asum - bi.y};
+            if (bold) {
+                const C bp = bold[i];
+                bn.x = d * bp.x + omd * bn.x;
+                bn.y = d * bp.y + omd * bn.y;
+            }
+            bo[i] = bn;
+            if (ro) ro[i] = r;
+        }
+        return;
     }
     if constexpr (sizeof(T) == 4) {
         for (int i = threadIdx.x; i < npts / 2; i += nthr)
@@ -563,6 +588,7 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
                 (void)hipGetLastError();
         };
         if (inverse) allow(reinterpret_cast<const void*>(fft_strided_kernel<T, true, true>));
+        if (inverse) allow(reinterpret_cast<const void*>(fft_block_kernel<T, true, true>));
         allow(f1);
         allow(f2);
         attr_done[slot] = true;
@@ -572,8 +598,13 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
         return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "transform too long for the LDS tile");
     if (sh.G == 1) {
         // the whole transform is one block pass, out of place
-        if (epi && epi->out) return tramp_fail(ctx, TRAMP_ENOTSUP, "fft2", "no fused epilogue on the block-only pass");
-        if (inverse)
+        if (epi && epi->out && !inverse) return tramp_fail(ctx, TRAMP_EINVAL, "fft2", "epilogue on a forward transform");
+        if (inverse && epi && epi->out) {
+            Fft2Epi e2 = *epi;
+            e2.hint.kind = PRIOR_HINT_NONE;
+            hipLaunchKernelGGL((fft_block_kernel<T, true, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh,
+                               (const C*)in, (C*)out, (const C*)pl->tw_blk, tile_pts, total_pts, e2);
+        } else if (inverse)
             hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh, (const C*)in,
                                (C*)out, (const C*)pl->tw_blk, tile_pts, total_pts);
         else
@@ -597,7 +628,8 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
             // gpurun_out/r03/fused1.log, fused2.log.  The dense channel's fold kernels arm for every kind.
             e2.hint.kind = PRIOR_HINT_NONE;
             const int hk = ctx->hint.kind;
-            if (hk == PRIOR_HINT_GB || hk == PRIOR_HINT_L1 || (hk == PRIOR_HINT_SGN_LIK && sizeof(T) == 8))
+            if (e2.rows_per_inst <= 1 &&
+                (hk == PRIOR_HINT_GB || hk == PRIOR_HINT_L1 || (hk == PRIOR_HINT_SGN_LIK && sizeof(T) == 8)))
                 prior_hint_arm(ctx, e2.out, 2 * sh.h, batch, (int)(sh.LB / kC1), &e2.hint);
             hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh,
                                (const C*)in, (C*)out, (const C*)pl->tw_hi, (const C*)pl->tw_lo, e2);
@@ -838,14 +870,28 @@ int fftnd_forward(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, const void*
     return rc;
 }
 
-int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spectrum, void* out) {
+int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spectrum, void* out, const Fft2Epi* epi) {
     int rc = TRAMP_OK;
     for (int i = pl->npass - 1; i >= 0 && !rc; --i)
         rc = pl->dtype == TRAMP_F64 ? axis_run_t<double>(ctx, pl, pl->pass[i], batch, true, spectrum)
                                     : axis_run_t<float>(ctx, pl, pl->pass[i], batch, true, spectrum);
     if (rc) return rc;
-    const size_t rows = batch * (pl->h / pl->dims[pl->ndim - 1]);
-    return fft2_inverse(ctx, pl->row, rows, spectrum, out);
+    const size_t rpi = pl->h / pl->dims[pl->ndim - 1];
+    if (epi && epi->out) {
+        Fft2Epi e2 = *epi;
+        e2.rows_per_inst = rpi * (epi->rows_per_inst ? epi->rows_per_inst : 1);
+        return fft2_inverse(ctx, pl->row, batch * rpi, spectrum, out, &e2);
+    }
+    return fft2_inverse(ctx, pl->row, batch * rpi, spectrum, out);
+}
+
+// `signals` consecutive signals share one problem instance (the d components of a gradient): the epilogue's scalar
+// tables are indexed by instance
+int fftnd_inverse_signals(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, size_t signals, void* spectrum,
+                          const Fft2Epi* epi) {
+    Fft2Epi e2 = *epi;
+    e2.rows_per_inst = signals;
+    return fftnd_inverse(ctx, pl, batch * signals, spectrum, nullptr, &e2);
 }
 
 // ---------------------------------------------------------------- exported for tests / tools
