@@ -471,6 +471,48 @@ def structured_n1e6(T, ctx, dtype):
             "mse": float(np.mean(ep.mse("x", X)))}
 
 
+def structured_2d(T, ctx, dtype):
+    """The 2-D counterpart: sparse deconvolution of 1024 x 1024 images (ConvChannel with a dense random 2-D circulant
+    filter, tramp/channels/linear/conv_channel.py:13-149 over two axes), 64 instances, on the N-D plans of the own FFT
+    engine - and the same model with the channel built on rocFFT (TRAMP_CONV_FFT=rocfft), which the own engine replaced
+    on the iteration path.  An auxiliary figure, never `value`."""
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    shape, B, rho, nv = (1024, 1024), 64, 0.05, 1e-3
+    n = shape[0] * shape[1]
+    rs = np.random.RandomState(4)
+    X = (rs.standard_normal((B, n)) * rs.binomial(1, rho, (B, n))).astype(np_dt)
+    filt = rs.standard_normal(shape) / np.sqrt(n)
+    out = {"workload": "sparse deconvolution EP, ConvChannel (dense random 2-D circulant filter) on 1024 x 1024 images, "
+                       "damping 0.1; device-side NaN guard / stopping rule every iteration, host poll every 10",
+           "shape": list(shape), "instances": B}
+    Y = None
+    for eng in ("own", "rocfft"):
+        if eng == "rocfft":
+            os.environ["TRAMP_CONV_FFT"] = "rocfft"
+        try:
+            ch = T.ConvChannel(filt, dtype=np_dt, ctx=ctx)
+            if Y is None:
+                Y = ch.convolve(ctx.array(X, np_dt)).get() + np.sqrt(nv) * rs.standard_normal((B, n)).astype(np_dt)
+            model = (T.GaussBernoulliPrior(size=shape, rho=rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x") @ ch
+                     @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=Y, var=nv, dtype=np_dt, ctx=ctx)).to_model()
+            ep = T.ExpectationPropagation(model, ctx=ctx)
+            ep.iterate(max_iter=3, callback=T.PassCallback(), damping=0.1, check_every=10)
+            ctx.sync()
+            K = 20
+            t0 = time.perf_counter()
+            ep.iterate(max_iter=K, callback=T.PassCallback(), damping=0.1, warm_start=True, check_every=10)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            key = "" if eng == "own" else "_rocfft"
+            out["ms_per_iteration" + key] = dt / K * 1e3
+            out["msg_components_per_sec" + key] = n * B * K / dt
+            out["mse" + key] = float(np.mean(ep.mse("x", X)))
+            del ep, model, ch
+        finally:
+            os.environ.pop("TRAMP_CONV_FFT", None)
+    return out
+
+
 def se_measure(T, ctx, with_oracle=True):
     """State-evolution quadratures (report integrand evaluations/s and the speed-up over the
     reference's adaptive QUADPACK path, tramp/utils/integration.py:13-73).  K13: GaussBernoulliPrior.
@@ -894,6 +936,10 @@ def run(args):
                 out["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
             except Exception as e:                                            # noqa: BLE001
                 out["structured_n1e6"] = {"error": repr(e)}
+            try:
+                out["structured_2d"] = structured_2d(T, ctx, args.dtype)
+            except Exception as e:                                            # noqa: BLE001
+                out["structured_2d"] = {"error": repr(e)}
         if world == 1 and not args.no_denoiser and not args.load_factors:
             try:
                 del ep, model

@@ -556,13 +556,142 @@ class ExpectationPropagation:
 
     def forward_message(self):
         "message_passing.py:249-255"
+        if getattr(self, "_adaptive", False):
+            return self._adaptive_forward()
         for i, v in enumerate(self.variables):
             self._update(self.model.prev_factor(v), "fwd", i - 1, i)
 
     def backward_message(self):
         "message_passing.py:257-263"
+        if getattr(self, "_adaptive", False):
+            return self._adaptive_backward()
         for i in reversed(range(len(self.variables))):
             self._update(self.model.next_factor(self.variables[i]), "bwd", i + 1, i)
+
+    # -- adaptive damping (tramp/algos/message_passing.py:151-185) -------------------------------------------------
+    # The reference keeps FOUR messages per SISO variable x between its factors f (before) and g (after):
+    #   f -> x and x -> g (direction fwd), g -> x and x -> f (direction bwd).  Without adaptive damping the message a
+    # variable passes on is the one it received from the other side, so the chain scheduler stores two; here the
+    # pass-through edges are damped on their own (damp_message runs on every edge) and get their own buffers
+    # (a_vf / b_vf: x -> g, a_vb / b_vb: x -> f).  Every instance of the ensemble searches its own step beta.
+    def _adaptive_allocate(self, fresh):
+        ctx, B = self.ctx, self.batch
+        if fresh or getattr(self, "a_vf", None) is None:
+            self.a_vf = [ctx.empty((B,), np.float64) for _ in self.variables]
+            self.a_vb = [ctx.empty((B,), np.float64) for _ in self.variables]
+            self.b_vf = [ctx.empty(tuple(b.shape), self.dtype) for b in self.b_fwd]
+            self.b_vb = [ctx.empty(tuple(b.shape), self.dtype) for b in self.b_bwd]
+            # message_passing.py:211-232: every edge starts from the initializer's value for its direction
+            for i in range(len(self.variables)):
+                self.a_vf[i].copy_from(self.a_fwd[i])
+                self.b_vf[i].copy_from(self.b_fwd[i])
+                self.a_vb[i].copy_from(self.a_bwd[i])
+                self.b_vb[i].copy_from(self.b_bwd[i])
+                self.b_vf[i].version = self.b_vb[i].version = 0
+        self._ad_mask = ctx.zeros((4 + B,), np.int32)
+        self._ad_out = ctx.empty((B,), np.float64)
+        self._ad_new = {}                                    # message length -> (a_new, b_new, a_cand, b_cand)
+
+    def _ad_buffers(self, n):
+        if n not in self._ad_new:
+            ctx, B = self.ctx, self.batch
+            self._ad_new[n] = (ctx.empty((B,), np.float64), ctx.empty((B, n), self.dtype),
+                               ctx.empty((B,), np.float64), ctx.empty((B, n), self.dtype))
+        return self._ad_new[n]
+
+    def _var_logz(self, a1, b1, a2, b2):
+        "Variable.log_partition of two messages (tramp/base.py:146-175), one value per instance"
+        self.ctx._call("tramp_log_partition", dtype_code(self.dtype), 9, b1.shape[1], self.batch, 0.0, 0.0, 0.0,
+                       a1.ptr, b1.ptr, a2.ptr, b2.ptr, self._ad_out.ptr)
+        return self._ad_out.get()
+
+    def _adaptive_edge(self, new_a, new_b, live_a, live_b, objective):
+        """compute_adaptive_damping (message_passing.py:151-185) for one edge and every instance: the first
+        beta = 1, 1/2, ... 1/512 whose candidate old + beta (new - old) does not lower A_target - A_edge, else the old
+        message stays.  ``objective(a, b)`` evaluates that difference with the edge's message replaced."""
+        B, n, dt = self.batch, live_b.shape[1], dtype_code(self.dtype)
+        if self.n_iter == 0:                                 # :152-153: the first iteration is not damped
+            live_a.copy_from(new_a)
+            live_b.copy_from(new_b)
+            live_b.version = getattr(live_b, "version", 0) + 1
+            return
+        with np.errstate(all="ignore"):
+            A_old = np.atleast_1d(objective(live_a, live_b))
+        remaining = np.ones(B, dtype=bool)
+        _, _, ca, cb = self._ad_buffers(n)
+        for k in range(10):
+            ca.copy_from(new_a)
+            cb.copy_from(new_b)
+            if k:
+                # candidate = (1 - beta) old + beta new; instances that already accepted hold their new message in
+                # the live buffer - their candidate is meaningless and masked out below
+                self.ctx._call("tramp_damp", dt, n, B, 1.0 - 0.5**k, live_a.ptr, live_b.ptr, ca.ptr, cb.ptr)
+            with np.errstate(all="ignore"):
+                dA = np.atleast_1d(objective(ca, cb)) - A_old
+            accept = remaining & (dA >= 0)                   # NaN / inf - inf compare False, as in the reference
+            if accept.any():
+                mask = np.zeros(4 + B, dtype=np.int32)
+                mask[4:] = accept
+                self._ad_mask.set(mask)
+                self.ctx._call("tramp_ep_restore", dt, n, B, self._ad_mask, cb, live_b, 0)
+                self.ctx._call("tramp_ep_restore_a", 1, B, self._ad_mask, ca, live_a, 0)
+                remaining &= ~accept
+            if not remaining.any():
+                break
+        live_b.version = getattr(live_b, "version", 0) + 1
+
+    def _factor_logz(self, f, i_var, side, a, b):
+        """log-partition of factor f with ONE of its incoming messages replaced by (a, b): side "z" = the message from the
+        variable before it (x_{i_var} -> f), side "x" = the message from the variable after it (x_{i_var} -> f)"""
+        if f.n_prev == 0:
+            return f.compute_log_partition(a, b)
+        if f.n_next == 0:
+            return f.compute_log_partition(a, b)
+        if side == "z":
+            return f.compute_log_partition(a, b, self.a_vb[i_var + 1], self.b_vb[i_var + 1])
+        return f.compute_log_partition(self.a_vf[i_var - 1], self.b_vf[i_var - 1], a, b)
+
+    def _adaptive_forward(self):
+        m = self.model
+        for i, v in enumerate(self.variables):
+            f, g = m.prev_factor(v), m.next_factor(v)
+            na, nb, _, _ = self._ad_buffers(self.b_fwd[i].shape[1])
+            # f -> x_i from the messages INTO f: x_{i-1} -> f and x_i -> f
+            kw = dict(out_a=na, out_b=nb)
+            if f.n_prev == 0:
+                f.compute_forward_message(self.a_vb[i], self.b_vb[i], **kw)
+            else:
+                f.compute_forward_message(self.a_vf[i - 1], self.b_vf[i - 1], self.a_vb[i], self.b_vb[i], **kw)
+            # target x_i: A_x(f -> x, g -> x) - A_x(f -> x, x -> f)      (message_passing.py:158-167)
+            self._adaptive_edge(na, nb, self.a_fwd[i], self.b_fwd[i],
+                                lambda a, b, i=i: self._var_logz(a, b, self.a_bwd[i], self.b_bwd[i])
+                                - self._var_logz(a, b, self.a_vb[i], self.b_vb[i]))
+            if g is None:
+                continue
+            # x_i -> g: the variable passes on what it got from f (base.py:183-194); target g, edge pair (x -> g, g -> x)
+            self._adaptive_edge(self.a_fwd[i], self.b_fwd[i], self.a_vf[i], self.b_vf[i],
+                                lambda a, b, i=i, g=g: np.atleast_1d(self._factor_logz(g, i, "z", a, b))
+                                - self._var_logz(a, b, self.a_bwd[i], self.b_bwd[i]))
+
+    def _adaptive_backward(self):
+        m = self.model
+        for i in reversed(range(len(self.variables))):
+            v = self.variables[i]
+            f, g = m.prev_factor(v), m.next_factor(v)
+            if g is not None:
+                na, nb, _, _ = self._ad_buffers(self.b_bwd[i].shape[1])
+                kw = dict(out_a=na, out_b=nb)
+                if g.n_next == 0:
+                    g.compute_backward_message(self.a_vf[i], self.b_vf[i], **kw)
+                else:
+                    g.compute_backward_message(self.a_vf[i], self.b_vf[i], self.a_vb[i + 1], self.b_vb[i + 1], **kw)
+                self._adaptive_edge(na, nb, self.a_bwd[i], self.b_bwd[i],
+                                    lambda a, b, i=i: self._var_logz(a, b, self.a_fwd[i], self.b_fwd[i])
+                                    - self._var_logz(a, b, self.a_vf[i], self.b_vf[i]))
+            # x_i -> f: what came from g; target f, edge pair (x -> f, f -> x)
+            self._adaptive_edge(self.a_bwd[i], self.b_bwd[i], self.a_vb[i], self.b_vb[i],
+                                lambda a, b, i=i, f=f: np.atleast_1d(self._factor_logz(f, i, "x", a, b))
+                                - self._var_logz(a, b, self.a_fwd[i], self.b_fwd[i]))
 
     def update_variables(self):
         "message_passing.py:265-269 -> Variable.posterior_rv (base.py:157-161), kernel K11"
@@ -896,17 +1025,32 @@ class ExpectationPropagation:
         instance from where its own run would have stopped."""
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
-        if damping is not None and damping is not False and not isinstance(damping, float):
-            raise ValueError("damping must be None or a float (constant damping)")
-        self.damping = float(damping) if damping else 0.0
+        adaptive = isinstance(damping, str) and damping == "adaptive"
+        if damping is not None and damping is not False and not isinstance(damping, float) and not adaptive:
+            raise ValueError("damping must be None, a float (constant damping) or 'adaptive'")
+        self.damping = 0.0 if adaptive else (float(damping) if damping else 0.0)
         check_every = max(int(check_every), 1)
+        if adaptive:
+            # message_passing.py:151-185: a step-halving search on the node objectives, per edge - host-orchestrated here
+            # (every candidate costs log-partition evaluations whose per-instance values come back to the host)
+            if graph:
+                raise ValueError("adaptive damping cannot be captured in a hipGraph")
+            if self._rot and (warm_start or self._allocated):
+                if warm_start:
+                    raise ValueError("adaptive damping cannot warm-start a run that carried variables in a rotated basis")
+            if self._rot:
+                self._rot = {}                               # all messages in the original basis
+                self._allocated = False
+        self._adaptive = adaptive
         if warm_start:
             if not self._allocated:
                 raise ValueError("message dag was never initialized")
         else:
             self.init_message_dag(initializer)
             self.n_iter = 0
-        if self._device_monitor:
+        if adaptive:
+            self._adaptive_allocate(fresh=not warm_start)
+        if self._device_monitor and not adaptive:
             self._reset_monitor()            # a warm start begins a new run of the stopping rule (i = 0 again)
             stopper, host_cbs = self._split_callback(callback)
             mon = ((stopper.tol, stopper.max_increase, stopper.wait_increase, True) if stopper is not None
@@ -915,8 +1059,8 @@ class ExpectationPropagation:
             stopper, host_cbs, mon = None, [callback], None
             self.status[:] = 0
             self.n_iter_instance[:] = 0
-        self._restore = bool(self._device_monitor and (restore_messages if restore_messages is not None
-                                                       else stopper is not None))
+        self._restore = bool(self._device_monitor and not adaptive and
+                             (restore_messages if restore_messages is not None else stopper is not None))
         if self._restore and getattr(self, "_snap", None) is None:
             self._allocate_snapshot()
         n0 = self._n0 = self.n_iter
