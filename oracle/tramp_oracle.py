@@ -1714,6 +1714,64 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
     return dict(fwd=fwd, bwd=bwd, r=rs, v=vs, n_iter=n_iter, status=status)
 
 
+def ep_chain_adaptive(factors, shapes, max_iter=10, record=None):
+    """ep_chain with ``damping="adaptive"`` (tramp/algos/message_passing.py:108-117, 151-185): every edge of the message
+    dag - the factor -> variable edges AND the variable -> factor edges a SISO variable passes its messages through
+    (base.py:183-205) - searches beta = 1, 1/2 ... 1/512 for the first candidate old + beta (new - old) with
+    dA = (A_target - A_edge)(candidate) - (A_target - A_edge)(old) >= 0, keeps the old message if none has, and takes the
+    new one undamped in the first iteration.  A_target is the log-partition of the node the message goes INTO with all its
+    incoming messages, A_edge that of the edge's variable with the two messages of the edge.
+
+    Four messages per variable i between factors f = factors[i] and g = factors[i + 1]:
+    ff (f -> x), vf (x -> g), fb (g -> x), vb (x -> f).  No stopping rule: exactly max_iter iterations.
+    ``record(it, state)`` receives dict(ff, vf, fb, vb, r, v) after every iteration."""
+    L = len(factors) - 1
+    zero = lambda i: (0., np.zeros(shapes[i]))                            # noqa: E731  ConstantInit(a=0, b=0)
+    ff, vf, fb, vb = ([zero(i) for i in range(L)] for _ in range(4))
+    V = lambda m1, m2: variable_log_partition(m1[0] + m2[0], m1[1] + m2[1])      # noqa: E731
+
+    def F(f, i_var, side, m):
+        "log-partition of factor f with the message from variable i_var replaced by m"
+        if f.kind == "prior":
+            return f.log_partition(None, None, m[0], m[1])
+        if f.kind == "likelihood":
+            return f.log_partition(m[0], m[1], None, None)
+        if side == "z":
+            return f.log_partition(m[0], m[1], vb[i_var + 1][0], vb[i_var + 1][1])
+        return f.log_partition(vf[i_var - 1][0], vf[i_var - 1][1], m[0], m[1])
+
+    def damp(it, old, new, objective):
+        if it == 0:
+            return new                                                    # :152-153
+        with np.errstate(all="ignore"):
+            A_old = objective(old)
+            for n in range(10):
+                beta = 1 / 2**n
+                cand = (old[0] + beta * (new[0] - old[0]), old[1] + beta * (new[1] - old[1]))
+                if objective(cand) - A_old >= 0:
+                    return cand
+        return old
+
+    for it in range(max_iter):
+        for i in range(L):                                                # forward sweep: f_i, x_i, f_{i+1}, ...
+            f, g = factors[i], factors[i + 1]
+            new = f.forward(None, None, vb[i][0], vb[i][1]) if f.kind == "prior" else \
+                f.forward(vf[i - 1][0], vf[i - 1][1], vb[i][0], vb[i][1])
+            ff[i] = damp(it, ff[i], new, lambda m, i=i: V(m, fb[i]) - V(m, vb[i]))
+            vf[i] = damp(it, vf[i], ff[i], lambda m, i=i, g=g: F(g, i, "z", m) - V(m, fb[i]))
+        for i in reversed(range(L)):                                      # backward sweep
+            f, g = factors[i], factors[i + 1]
+            new = g.backward(vf[i][0], vf[i][1], None, None) if g.kind == "likelihood" else \
+                g.backward(vf[i][0], vf[i][1], vb[i + 1][0], vb[i + 1][1])
+            fb[i] = damp(it, fb[i], new, lambda m, i=i: V(m, ff[i]) - V(m, vf[i]))
+            vb[i] = damp(it, vb[i], fb[i], lambda m, i=i, f=f: F(f, i, "x", m) - V(m, ff[i]))
+        rs = [(ff[i][1] + fb[i][1]) / (ff[i][0] + fb[i][0]) for i in range(L)]
+        vs = [1. / (ff[i][0] + fb[i][0]) for i in range(L)]
+        if record is not None:
+            record(it, dict(ff=list(ff), vf=list(vf), fb=list(fb), vb=list(vb), r=rs, v=vs))
+    return dict(ff=ff, vf=vf, fb=fb, vb=vb, r=rs, v=vs)
+
+
 def ep_glm_thin_batch(Uk, sigma, Vt, Y, rho, noise_var, damping=None, n_iter=10, rank=None):
     """ep_chain for the sparse GLM (GaussBernoulli prior - LinearThinOracle - Gaussian likelihood) on an ENSEMBLE
     of instances that share W = Uk diag(sigma) Vt: messages are [B, n] arrays, every scalar (a, v) a [B] array,

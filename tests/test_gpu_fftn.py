@@ -310,3 +310,61 @@ def test_gradient_channel_real_false_returns_complex(ctx):
     assert np.iscomplexobj(rb) and not np.iscomplexobj(ra) and va == vb
     assert np.array_equal(rb.real, ra) and not rb.imag.any()
     assert np.iscomplexobj(b.sample(bz)) and np.array_equal(b.sample(bz).real, a.sample(bz))
+
+
+def _piecewise_image(shape, rs, rho=0.05):
+    img = np.cumsum(np.cumsum(rs.standard_normal(shape) * rs.binomial(1, rho, shape), axis=0), axis=1)
+    return img - img.mean()
+
+
+@pytest.mark.parametrize("shape", [(32, 64), (8, 16, 32)], ids=lambda s: "x".join(map(str, s)))
+def test_tree_ep_on_own_engine_matches_oracle_and_rocfft(ctx, shape, monkeypatch):
+    """The sparse-gradient tree model (examples/sparse/plot_sparse_gradient.py) on images / volumes whose transforms
+    run on the own N-D engine: same trajectory end point as the CPU oracle's tree EP and as the same model on rocFFT;
+    graph replay identical to the eager loop."""
+    import tramp_amd as T
+    from oracle import tramp_oracle as orc
+    from tests.test_gpu_tree import TREE_EDGES, build_tree
+    rs = np.random.RandomState(7)
+    d, n, rho, nv = len(shape), int(np.prod(shape)), 0.05, 1e-2
+    x = _piecewise_image(shape, rs)
+    y = x + np.sqrt(nv) * rs.standard_normal(shape)
+    factors = dict(GaussianPrior=orc.GaussPriorFactor(shape), GaussianLikelihood=orc.GaussLikFactor(y, nv),
+                   GradientChannel=orc.GradientFactor(shape), GaussBernoulliPrior=orc.GBPriorFactor((d,) + shape, rho=rho))
+    want = orc.ep_tree(factors, ["x", "z"], TREE_EDGES, dict(x=shape, z=(d,) + shape), max_iter=12, damping=0.1, tol=0.0)
+    res = {}
+    for eng, graph in (("own", False), ("own", True), ("rocfft", False)):
+        if eng == "rocfft":
+            monkeypatch.setenv("TRAMP_CONV_FFT", "rocfft")
+        else:
+            monkeypatch.delenv("TRAMP_CONV_FFT", raising=False)
+        model = build_tree(T, ctx, dict(shape=shape, noise_var=nv, rho=rho), y=y)
+        ep = T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=12, damping=0.1, callback=T.PassCallback(),
+                                                              graph=graph)
+        res[(eng, graph)] = (np.asarray(ep.get_variable_data("x")["r"]).reshape(shape),
+                             np.asarray(ep.get_variable_data("z")["r"]).reshape((d,) + shape))
+    assert np.array_equal(res[("own", False)][0], res[("own", True)][0])
+    assert np.array_equal(res[("own", False)][1], res[("own", True)][1])
+    for key in (("own", False), ("rocfft", False)):
+        np.testing.assert_allclose(res[key][0], want["r"]["x"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(res[key][1], want["r"]["z"], rtol=1e-7, atol=1e-8)
+
+
+def test_conv2d_ep_graph_replay_on_own_engine(ctx):
+    "A 2-D deconvolution EP on the N-D plans: iterate(graph=True) gives the bits of the eager loop"
+    import tramp_amd as T
+    rs = np.random.RandomState(3)
+    shape, B, rho, nv = (32, 64), 2, 0.1, 1e-3
+    n = shape[0] * shape[1]
+    f = rs.standard_normal(shape) / np.sqrt(n)
+    X = rs.standard_normal((B, n)) * rs.binomial(1, rho, (B, n))
+    outs = []
+    for graph in (False, True):
+        ch = T.ConvChannel(f, ctx=ctx)
+        Y = ch.convolve(X.reshape((B,) + shape)).reshape(B, n) + np.sqrt(nv) * np.random.RandomState(4).standard_normal((B, n))
+        model = (T.GaussBernoulliPrior(size=shape, rho=rho, ctx=ctx) @ T.SISOVariable(id="x") @ ch @ T.SISOVariable(id="z")
+                 @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+        ep = T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=10, damping=0.1, callback=T.PassCallback(), graph=graph)
+        outs.append(np.asarray(ep.get_variables_data()["x"]["r"]).copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.mean((outs[0].reshape(B, n) - X) ** 2) < 0.2 * np.mean(X ** 2)

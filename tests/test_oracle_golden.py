@@ -953,3 +953,37 @@ def test_complex_conv_and_dft_oracles_match_reference_goldens():
         np.testing.assert_allclose(b_f, c["b_fwd"], rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(b_b, c["b_bwd"], rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(b_f, c["sample"], rtol=1e-12, atol=1e-13)
+
+
+def test_adaptive_damping_oracle_matches_reference_trajectories():
+    """ep_chain_adaptive (the four-messages-per-variable step search of message_passing.py:151-185) against the
+    reference's own trajectories (tests/golden/adaptive.npz, tools/make_golden_adaptive.py): every message of every
+    edge and the posteriors, iteration by iteration."""
+    from tests.conftest import load_golden
+    from oracle import tramp_oracle as orc
+    cases = load_golden("adaptive")
+    assert len(cases) == 4
+    for c in cases:
+        N, M = c["N"], int(c["alpha"] * c["N"])
+        rs = np.random.RandomState(c["seed"])
+        W = rs.randn(M, N) / np.sqrt(N)
+        assert W.sum() == c["W_sum"]
+        lik = {"gaussian": lambda: orc.GaussLikFactor(c["y"], 0.01), "sgn": lambda: orc.SgnLikFactor(c["y"]),
+               "abs": lambda: orc.AbsLikFactor(c["y"])}[c["output"]]()
+        recs = []
+        orc.ep_chain_adaptive([orc.GBPriorFactor(N, rho=c["rho"]), orc.LinearFactor(W), lik], [N, M],
+                              max_iter=c["n_iter"], record=lambda it, st: recs.append(st))
+        assert len(recs) == c["n_iter"]
+        damped = sum(1 for b in c["betas"] if b[3] < 1 and b[4])
+        assert damped >= 3                                       # the goldens do exercise the search
+        for it, st in enumerate(recs):
+            t = c["traj"][it]
+            rt = 1e-9 if it < 3 else 1e-7
+            for i, vid in enumerate(("x", "z")):
+                for key, m in ((f"fwd:f->{vid}", st["ff"][i]), (f"fwd:{vid}->f", st["vf"][i]),
+                               (f"bwd:f->{vid}", st["fb"][i]), (f"bwd:{vid}->f", st["vb"][i])):
+                    np.testing.assert_allclose(m[0], t[key][0], rtol=rt, err_msg=f"{c['output']} it {it} {key} a")
+                    np.testing.assert_allclose(m[1], t[key][1], rtol=rt, atol=rt * np.abs(t[key][1]).max(),
+                                               err_msg=f"{c['output']} it {it} {key} b")
+                np.testing.assert_allclose(st["r"][i], t[f"r:{vid}"], rtol=rt, atol=rt * np.abs(t[f"r:{vid}"]).max())
+                np.testing.assert_allclose(st["v"][i], t[f"v:{vid}"], rtol=rt)

@@ -13,7 +13,7 @@
 //             reported like numpy's LinAlgError("Singular matrix");
 //             rx = rz W^T                       (tramp_matvec_nt) for the forward direction;
 //             variances from the n_eff formula over `singular` (kernel K9, linear.hip) and the message
-//             a_new = clip(1 / v - a), b_new = r / v - b (tramp/base.py:245-255), damping fused.
+//             a_new = clip(1 / v - a), b_new = r (a + a_new) - b (tramp/base.py:245-255), damping fused.
 // One quirk of the reference is reproduced on purpose: with precompute_svd=False `singular = spectrum[:rank]` is cut
 // from the ASCENDING eigenvalues of eigvalsh (linear_channel.py:44-46), i.e. it keeps the rank SMALLEST eigenvalues
 // (zeros first when Nz > rank), and n_eff - hence every variance - follows that array.  tramp_lsolve_set_rank takes
@@ -40,7 +40,7 @@ struct tramp_lsolve {
     size_t group;
     double* g;            // [batch][N] right-hand sides / solutions
     void* tmp;            // [batch][max(M, N)] dtype
-    double* scal;         // v, a_raw [batch] each
+    double* scal;         // a_raw [batch]: the clipped, undamped a_new of the call
     rocblas_int* info;    // [group]
     size_t batch_cap;
 };
