@@ -10,7 +10,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tramp_amd as T
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
