@@ -522,11 +522,13 @@ int tramp_grad_variance(tramp_ctx* ctx, tramp_grad* grad, int dir, size_t batch,
                         double* v_d, double* a_new_d, double* n_eff_d);
 /* GradientChannel.convolve / sample (gradient_channel.py:26-37): x[b, i, :] = w_i * z[b, :]. */
 int tramp_grad_apply(tramp_ctx* ctx, tramp_grad* grad, size_t batch, const void* z_d, void* x_d);
+/* `reuse` as in tramp_conv_message: TRAMP_REUSE_T / _U promise that bz / bx hold what the previous message call on this
+ * handle transformed (same batch), so the forward and the backward update of one iteration share their 1 + d transforms. */
 int tramp_grad_message(tramp_ctx* ctx, tramp_grad* grad, int dir, size_t batch,
                        const double* az_d, const void* bz_d,
                        const double* ax_d, const void* bx_d,
                        double damping, const double* a_old_d, const void* b_old_d,
-                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d, int reuse);
 
 /* Two-pass mixed-radix complex FFT of length h = 2^a 5^b (1024 <= h <= ~1.3 10^6) used by the convolution
  * channel for 1-D sizes n = 2 h (csrc/fft_pow2.hip).  Exported for tests and tools: forward maps natural

@@ -368,3 +368,38 @@ def test_conv2d_ep_graph_replay_on_own_engine(ctx):
         outs.append(np.asarray(ep.get_variables_data()["x"]["r"]).copy())
     assert np.array_equal(outs[0], outs[1])
     assert np.mean((outs[0].reshape(B, n) - X) ** 2) < 0.2 * np.mean(X ** 2)
+
+
+@pytest.mark.parametrize("shape", [(16, 32), (12, 10)], ids=lambda s: "x".join(map(str, s)))
+def test_gradient_channel_shares_transforms_between_directions(ctx, shape):
+    """Device-resident messages that were not rewritten since the previous call are not transformed again
+    (TRAMP_REUSE_T / _U, as the convolution channel): same results as a fresh channel; a rewritten buffer (version bump)
+    is transformed anew.  (16, 32) runs on the own engine, (12, 10) on rocFFT."""
+    import tramp_amd as T
+    rs = np.random.RandomState(2)
+    B, d, n = 2, len(shape), int(np.prod(shape))
+    az, ax = ctx.array(rs.uniform(0.5, 2, B)), ctx.array(rs.uniform(0.5, 2, B))
+    bz, bx = ctx.array(rs.standard_normal((B, n))), ctx.array(rs.standard_normal((B, d * n)))
+    bz.version = bx.version = 0
+    ch = T.GradientChannel(shape, ctx=ctx)
+
+    def both(channel):
+        f = channel.compute_forward_message(az, bz, ax, bx)
+        b = channel.compute_backward_message(az, bz, ax, bx)       # second call: both transforms reused on `ch`
+        return f[0].get(), f[1].get(), b[0].get(), b[1].get()
+
+    got = both(ch)
+    want = both(T.GradientChannel(shape, ctx=ctx))
+    bz.version = bx.version = None                                  # unversioned: never reused
+    plain = both(T.GradientChannel(shape, ctx=ctx))
+    for g, w, p in zip(got, want, plain):
+        assert np.array_equal(g, w) and np.array_equal(g, p)
+    # rewrite bz in place: the version bump invalidates its transform, bx's stays
+    bz.version = bx.version = 0
+    both(ch)
+    bz.set(rs.standard_normal((B, n)))
+    bz.version += 1
+    again = both(ch)
+    fresh = both(T.GradientChannel(shape, ctx=ctx))
+    for g, w in zip(again, fresh):
+        assert np.array_equal(g, w)

@@ -96,7 +96,7 @@ _SIGNATURES = {
     "tramp_grad_spectrum": [vp, vp, vp, C.POINTER(sz), C.POINTER(dbl)],
     "tramp_grad_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_grad_apply": [vp, vp, sz, vp, vp],
-    "tramp_grad_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_grad_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_linear_set_rotated": [vp, vp, i32],
     "tramp_lsolve_create": [vp, i32, sz, sz, vp, C.POINTER(vp)],
     "tramp_lsolve_destroy": [vp, vp],

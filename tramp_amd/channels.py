@@ -1200,6 +1200,7 @@ class GradientChannel(Channel):
         zz = self._vec(z, False)
         x = self.ctx.empty((zz.batch, self.Nx), self.dtype)
         self.ctx._call("tramp_grad_apply", self._handle, zz.batch, zz.dev.ptr, x.ptr)
+        self._t_key = self._u_key = None                               # the call reuses the transform buffers
         if zz.was_host:
             out = x.get().reshape(((zz.batch,) if not zz._one else ()) + (self.d,) + self.shape)
             return out if self.real else out.astype(np.complex128)
@@ -1250,10 +1251,18 @@ class GradientChannel(Channel):
         b_new = out_b if out_b is not None else ctx.empty((z.batch, tgt.n), self.dtype)
         r = ctx.empty((z.batch, tgt.n), self.dtype) if want_posterior else None
         v = ctx.empty((z.batch,), np.float64) if want_posterior else None
+        # the transforms of device-resident messages that have not been rewritten since the last call stay in the handle
+        reuse = 0
+        kz, kx = LinearChannel._proj_key(bz, z), LinearChannel._proj_key(bx, x)
+        if kz is not None and kz == getattr(self, "_t_key", None):
+            reuse |= _lib.REUSE_T
+        if kx is not None and kx == getattr(self, "_u_key", None):
+            reuse |= _lib.REUSE_U
+        self._t_key, self._u_key = kz, kx
         ctx._call("tramp_grad_message", self._handle, direction, z.batch, a_z.dev.ptr, z.dev.ptr,
                   a_x.dev.ptr, x.dev.ptr, float(damping or 0.0),
                   old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None,
-                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None, v.ptr if v is not None else None)
+                  a_new.ptr, b_new.ptr, r.ptr if r is not None else None, v.ptr if v is not None else None, reuse)
         return tgt, a_t, a_new, b_new, r, v
 
     compute_backward_mean = ConvChannel.compute_backward_mean

@@ -1151,6 +1151,7 @@ struct tramp_grad {
     void* wbar_all;             // [d][nh] complex of dtype: fft(f_i)
     void* gwork;                // fz [B,nh], fx [B,d,nh], fo [B,d,nh], fr [B,d,n], a_raw [B], partial
     size_t gwork_batch;
+    size_t gproj_batch;         // batch of the transforms currently held in gfz / gfx (TRAMP_REUSE_T / _U)
     void* gfz;
     void* gfx;
     void* gfo;
@@ -1246,6 +1247,7 @@ int grad_reserve(tramp_ctx* ctx, tramp_grad* g, size_t batch) {
     g->ga_raw = (double*)(p + per + 2 * perd + rper);
     g->gpartial = (double*)(p + per + 2 * perd + rper + scal);
     g->gwork_batch = batch;
+    g->gproj_batch = 0;
     return TRAMP_OK;
 }
 
@@ -1315,6 +1317,7 @@ extern "C" int tramp_grad_create(tramp_ctx* ctx, int dtype, int ndim, const size
     g->d = ndim;
     g->wbar_all = g->gwork = nullptr;
     g->gwork_batch = 0;
+    g->gproj_batch = 0;
     cv->dtype = dtype;
     cv->ndim = ndim;
     cv->n = 1;
@@ -1434,6 +1437,7 @@ extern "C" int tramp_grad_apply(tramp_ctx* ctx, tramp_grad* g, size_t batch, con
     if (!batch) return TRAMP_OK;
     int rc = grad_reserve(ctx, g, batch);
     if (rc) return rc;
+    g->gproj_batch = 0;                                               // gfz is overwritten below
     rc = grad_forward(ctx, g, batch, z_d, g->gfz);
     if (rc) return rc;
     if (g->base.dtype == TRAMP_F64) launch_grad_spectral<double>(ctx, g, 2, batch, nullptr, nullptr);
@@ -1445,14 +1449,17 @@ extern "C" int tramp_grad_apply(tramp_ctx* ctx, tramp_grad* g, size_t batch, con
 extern "C" int tramp_grad_message(tramp_ctx* ctx, tramp_grad* g, int dir, size_t batch, const double* az_d,
                                   const void* bz_d, const double* ax_d, const void* bx_d, double damping,
                                   const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d,
-                                  void* r_d, double* v_d) {
+                                  void* r_d, double* v_d, int reuse) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, g && az_d && bz_d && ax_d && bx_d && a_new_d && b_new_d);
     TRAMP_REQUIRE(ctx, dir == TRAMP_FWD || dir == TRAMP_BWD);
     TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
     if (!batch) return TRAMP_OK;
+    const void* work_before = g->gwork;
     int rc = grad_reserve(ctx, g, batch);
     if (rc) return rc;
+    if (g->gwork != work_before || g->gproj_batch != batch) reuse = 0;
+    g->gproj_batch = batch;
     tramp_conv* cv = &g->base;
     const size_t d = (size_t)g->d, n = cv->n, nh = cv->nh, esz = dtype_size(cv->dtype);
     {
@@ -1462,11 +1469,17 @@ extern "C" int tramp_grad_message(tramp_ctx* ctx, tramp_grad* g, int dir, size_t
         if (rc) return rc;
     }
     {
-        ProfScope ps(ctx, PROF_FFT, (double)batch * (d + 1) * (n * esz + nh * 2 * esz), 0);
-        rc = grad_forward(ctx, g, batch, bz_d, g->gfz);
-        if (rc) return rc;
-        rc = grad_forward(ctx, g, batch * d, bx_d, g->gfx);
-        if (rc) return rc;
+        // transforms of the incoming messages, shared by the two directions of one iteration (TRAMP_REUSE_T / _U)
+        const double cnt = ((reuse & TRAMP_REUSE_T) ? 0.0 : 1.0) + ((reuse & TRAMP_REUSE_U) ? 0.0 : (double)d);
+        ProfScope ps(ctx, PROF_FFT, (double)batch * cnt * (n * esz + nh * 2 * esz), 0);
+        if (!(reuse & TRAMP_REUSE_T)) {
+            rc = grad_forward(ctx, g, batch, bz_d, g->gfz);
+            if (rc) return rc;
+        }
+        if (!(reuse & TRAMP_REUSE_U)) {
+            rc = grad_forward(ctx, g, batch * d, bx_d, g->gfx);
+            if (rc) return rc;
+        }
     }
     {
         ProfScope ps(ctx, PROF_LIN_SCALARS, (double)batch * nh * (2 * d + 2) * 2 * esz, 0);
