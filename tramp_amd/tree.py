@@ -109,12 +109,32 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.A = ctx.zeros((len(keys), B), np.float64)
         self.S = ctx.zeros((3 * L, B), np.float64)
         self.msg = {}
+        # A SISO variable (one factor before, one after) passes on to one what it received from the other
+        # (base.py:183-205), and each direction's messages change only in that direction's sweep, before the variable is
+        # visited: its two outgoing messages ARE the incoming ones of the other side - the same buffers, no copy (the
+        # chain scheduler stores its variables this way too).  NOT so for a leaf with two parents or a root with two
+        # children: there an outgoing message of one direction would alias an incoming one of the OTHER direction, which
+        # changes a sweep earlier than the copy would (measured: a different trajectory).  TRAMP_TREE_ALIAS=0: copies.
+        import os
+        alias = os.environ.get("TRAMP_TREE_ALIAS", "1") != "0"
+        siso = {v for v in self.variables if len(list(g.predecessors(v))) == 1 and len(list(g.successors(v))) == 1}
+        self._aliased = set()
         for i, (src, dst) in enumerate(keys):
+            if alias and isinstance(src, Variable) and src in siso:
+                continue                                       # filled in below
             var = src if isinstance(src, Variable) else dst
             n = int(np.prod(self.shapes[var.id]))
             b = ctx.zeros((B, n), self.dtype)
             b.version = 0
             self.msg[(src, dst)] = _Msg(self.A.row(i), b)
+        if alias:
+            for v in self.variables:
+                if v in siso:
+                    f0, f1 = self.adj[v]
+                    self.msg[(v, f0)] = self.msg[(f1, v)]
+                    self.msg[(v, f1)] = self.msg[(f0, v)]
+                    self._aliased.update([(v, f0), (v, f1)])
+            self.msg = {k: self.msg[k] for k in keys}          # keep the order of msg_keys (edge numbering of the monitor)
         self.r = [ctx.zeros((B, int(np.prod(self.shapes[v.id]))), self.dtype) for v in self.variables]
         self._const_msg = {}
         self._const_done = set()
@@ -215,6 +235,8 @@ class TreeExpectationPropagation(ExpectationPropagation):
         nbrs = self.adj[v]
         inc = [self.msg[(f, v)] for f in nbrs]
         for f in targets:
+            if (v, f) in self._aliased:
+                continue                                       # the outgoing message is the other side's incoming buffer
             out = self.msg[(v, f)]
             if len(nbrs) == 2:
                 other = inc[1 - nbrs.index(f)]
