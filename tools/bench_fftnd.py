@@ -56,8 +56,12 @@ def run(kind, shape, B, engine):
 
 if len(sys.argv) > 3 and sys.argv[3] == "one":
     # profiling: one case on the engine TRAMP_CONV_FFT selects
+    # python tools/bench_fftnd.py f64 10 one [conv|grad] [AxBxC] [instances]
     eng = "rocfft" if os.environ.get("TRAMP_CONV_FFT") == "rocfft" else "own"
-    print("grad 4096x4096 x4", eng, run("grad", (4096, 4096), 4, eng)[0], "ms")
+    kind1 = sys.argv[4] if len(sys.argv) > 4 else "grad"
+    shape1 = tuple(int(v) for v in sys.argv[5].split("x")) if len(sys.argv) > 5 else (4096, 4096)
+    B1 = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+    print(kind1, "x".join(map(str, shape1)), f"x{B1}", np_dt.__name__, eng, run(kind1, shape1, B1, eng)[0], "ms")
     sys.exit(0)
 
 for kind, shape, B in CASES:

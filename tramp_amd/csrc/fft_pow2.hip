@@ -748,8 +748,14 @@ int axis_run_t(tramp_ctx* ctx, const FftNdPlan* pl, const FftAxisPass& ps, size_
     if (tiles > 0x7fffffffull) return tramp_fail(ctx, TRAMP_ENOTSUP, "fftnd", "too many tiles for one launch");
     const size_t lds = ((size_t)ps.G * (kC1 + 1) + (size_t)ps.ntw) * sizeof(C);
     // threads: a quarter of the tile's points (one radix-4 butterfly each), within [64, 512]
-    int thr = (ps.G * kC1 / 4 + 63) / 64 * 64;
+    static const int env_thr = getenv("TRAMP_FFT_AXIS_THREADS") ? atoi(getenv("TRAMP_FFT_AXIS_THREADS")) : 0;
+    // points per thread: 4 in f64, 8 in f32 (measured: f32 1024^2 x 64 gradient pair 4.36 -> 4.17 ms, 128^3 0.90 -> 0.85;
+    // f64 is best at 4: tools/sweep_fftnd.sh)
+    static const int env_div = getenv("TRAMP_FFT_AXIS_DIV") ? atoi(getenv("TRAMP_FFT_AXIS_DIV")) : 0;
+    const int div = env_div > 0 ? env_div : (sizeof(T) == 8 ? 4 : 8);
+    int thr = (ps.G * kC1 / div + 63) / 64 * 64;
     thr = thr < 64 ? 64 : (thr > 512 ? 512 : thr);
+    if (env_thr) thr = env_thr;
     static bool attr_done[4] = {false, false, false, false};
     const int slot = (sizeof(T) == 8 ? 0 : 2) + (inverse ? 1 : 0);
     const void* f = inverse ? reinterpret_cast<const void*>(fft_axis_kernel<T, true>)
