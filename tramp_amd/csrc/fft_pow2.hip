@@ -320,6 +320,100 @@ __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typ
     }
 }
 
+// ---------------------------------------------------------------- a whole small image in one workgroup (2-D)
+// [n0][hl] complex points of one packed image fit one LDS tile: the row stages (as the block pass, rows are contiguous) and
+// the column stages (as the axis pass: lanes run along a row, legs sg rows apart) in ONE launch - small images are bound by
+// launches, not by memory.  Forward: rows, then columns; inverse: columns, then rows, then the optional message update.
+template <typename T, bool INV, bool EPI = false>
+__global__ __launch_bounds__(1024) void fft_image_kernel(Fft2Shape sh, FftAxisPass ps,
+                                                        const typename C2<T>::type* __restrict__ in,
+                                                        typename C2<T>::type* __restrict__ out,
+                                                        const typename C2<T>::type* __restrict__ tw_blk,
+                                                        const typename C2<T>::type* __restrict__ tw_hi,
+                                                        const typename C2<T>::type* __restrict__ tw_lo,
+                                                        Fft2Epi epi = Fft2Epi{}) {
+    using C = typename C2<T>::type;
+    extern __shared__ unsigned char smem_raw[];
+    C* tile = reinterpret_cast<C*>(smem_raw);
+    const int nthr = blockDim.x;
+    const int hl = (int)sh.LB, G = ps.G, npts = G * hl;
+    const size_t first = (size_t)blockIdx.x * npts;
+    const C* src = in + first;
+    C* dst = out + first;
+    if constexpr (sizeof(T) == 4) {
+        for (int i = threadIdx.x; i < npts / 2; i += nthr)
+            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < npts; i += nthr) tile[i] = src[i];
+    }
+    C* twr = tile + npts;                             // row stages: the block pass's table
+    C* twc = twr + sh.ntw2;                           // column stages: w_n0^(bl mul[s])
+    for (int i = threadIdx.x; i < sh.ntw2; i += nthr) twr[i] = tw_blk[i];
+    for (int s = 0; s < ps.nst; ++s)
+        for (int bl = threadIdx.x; bl < ps.sub[s]; bl += nthr)
+            twc[ps.off[s] + bl] = twiddle<C>(tw_hi, tw_lo, (size_t)bl * ps.mul[s]);
+    __syncthreads();
+    auto rows = [&]() {
+        for (int st = 0; st < sh.n2; ++st) {
+            const int s = INV ? sh.n2 - 1 - st : st;
+            const int r = sh.r2[s], sub = sh.sub2[s], L = sub * r;
+            const C* tws = twr + sh.off2[s];
+            for (int b = threadIdx.x; b < npts / r; b += nthr) {
+                const int m = b % sub;
+                bfly_at<C, INV>(tile, (b / sub) * L + m, sub, r, tws[m]);
+            }
+            __syncthreads();
+        }
+    };
+    auto cols = [&]() {
+        for (int st = 0; st < ps.nst; ++st) {
+            const int s = INV ? ps.nst - 1 - st : st;
+            const int r = ps.r[s], sg = ps.sub[s], nb = G / r;
+            const C* tws = twc + ps.off[s];
+            for (int idx = threadIdx.x; idx < nb * hl; idx += nthr) {
+                const int c = idx % hl, b = idx / hl;
+                const int bl = b % sg, bh = b / sg;
+                bfly_at<C, INV>(tile, (bh * r * sg + bl) * hl + c, sg * hl, r, tws[bl]);
+            }
+            __syncthreads();
+        }
+    };
+    if (!INV) {
+        rows();
+        cols();
+    } else {
+        cols();
+        rows();
+    }
+    if constexpr (EPI) {
+        const T d = (T)epi.damping, omd = (T)(1.0 - epi.damping);
+        const C* bin = reinterpret_cast<const C*>(epi.b_in) + first;
+        const C* bold = epi.damping != 0.0 ? reinterpret_cast<const C*>(epi.b_old) + first : nullptr;
+        C* bo = reinterpret_cast<C*>(epi.out) + first;
+        C* ro = epi.r_out ? reinterpret_cast<C*>(epi.r_out) + first : nullptr;
+        const size_t inst = blockIdx.x / (epi.rows_per_inst ? epi.rows_per_inst : 1);   // here: images per instance
+        const T asum = (T)(epi.a_in[inst] + epi.a_raw[inst]);
+        for (int i = threadIdx.x; i < npts; i += nthr) {
+            const C r = tile[i], bi = bin[i];
+            C bn = {r.x * asum - bi.x, r.y * asum - bi.y};
+            if (bold) {
+                const C bp = bold[i];
+                bn.x = d * bp.x + omd * bn.x;
+                bn.y = d * bp.y + omd * bn.y;
+            }
+            bo[i] = bn;
+            if (ro) ro[i] = r;
+        }
+        return;
+    }
+    if constexpr (sizeof(T) == 4) {
+        for (int i = threadIdx.x; i < npts / 2; i += nthr)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
+    } else {
+        for (int i = threadIdx.x; i < npts; i += nthr) dst[i] = tile[i];
+    }
+}
+
 // ---------------------------------------------------------------- strided pass along an outer axis (N-D)
 // Tile [G][C]: G rows of the axis (Q * W elements apart), C consecutive elements of the inner axes (one 128-byte
 // line per row).  The twiddles depend on the row only, not on the column.
@@ -776,6 +870,49 @@ int axis_run_t(tramp_ctx* ctx, const FftNdPlan* pl, const FftAxisPass& ps, size_
     return TRAMP_OK;
 }
 
+// one launch per transform for a 2-D image that fits one tile: block-only rows, one axis pass, n0 * hl points in LDS
+bool image_fits(const FftNdPlan* pl) {
+    static const bool off = getenv("TRAMP_FFT_IMAGE") && atoi(getenv("TRAMP_FFT_IMAGE")) == 0;
+    if (off || pl->ndim != 2 || pl->npass != 1 || pl->row->shape.G != 1 || pl->pass[0].Q != 1) return false;
+    const size_t pts = pl->h, csz = pl->dtype == TRAMP_F64 ? 16 : 8;
+    const size_t lds = (pts + (size_t)pl->row->shape.ntw2 + (size_t)pl->pass[0].ntw) * csz;
+    return pts <= 4096 && lds <= 96 * 1024;
+}
+
+template <typename T>
+int image_run_t(tramp_ctx* ctx, const FftNdPlan* pl, size_t images, bool inverse, const void* in, void* out,
+                const Fft2Epi* epi) {
+    using C = typename C2<T>::type;
+    const Fft2Shape& sh = pl->row->shape;
+    const FftAxisPass& ps = pl->pass[0];
+    const size_t lds = (pl->h + (size_t)sh.ntw2 + (size_t)ps.ntw) * sizeof(C);
+    int thr = (int)((pl->h / 4 + 63) / 64 * 64);
+    thr = thr < 64 ? 64 : (thr > 512 ? 512 : thr);
+    static bool attr_done[2] = {false, false};
+    const int slot = sizeof(T) == 8 ? 0 : 1;
+    if (!attr_done[slot]) {
+        for (const void* f : {reinterpret_cast<const void*>(fft_image_kernel<T, false>),
+                              reinterpret_cast<const void*>(fft_image_kernel<T, true>),
+                              reinterpret_cast<const void*>(fft_image_kernel<T, true, true>)})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                (void)hipGetLastError();
+        attr_done[slot] = true;
+    }
+    const dim3 grid((unsigned)images), blk(thr);
+    const C *hi = (const C*)pl->tw_hi[0], *lo = (const C*)pl->tw_lo[0], *tb = (const C*)pl->row->tw_blk;
+    if (!inverse)
+        hipLaunchKernelGGL((fft_image_kernel<T, false>), grid, blk, lds, ctx->stream, sh, ps, (const C*)in, (C*)out, tb, hi, lo,
+                           Fft2Epi{});
+    else if (epi && epi->out)
+        hipLaunchKernelGGL((fft_image_kernel<T, true, true>), grid, blk, lds, ctx->stream, sh, ps, (const C*)in, (C*)out, tb, hi,
+                           lo, *epi);
+    else
+        hipLaunchKernelGGL((fft_image_kernel<T, true>), grid, blk, lds, ctx->stream, sh, ps, (const C*)in, (C*)out, tb, hi, lo,
+                           Fft2Epi{});
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 // the last axis alone: block pass for hl <= 4096, the two-pass engine above that
 bool row_shape(size_t hl, Fft2Shape* sh, bool* block_only) {
     if (fft2_block_shape(hl, sh)) {
@@ -868,6 +1005,9 @@ size_t fftnd_kfreq(const FftNdPlan* pl, int axis, size_t p) {
 }
 
 int fftnd_forward(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, const void* in, void* out) {
+    if (image_fits(pl))
+        return pl->dtype == TRAMP_F64 ? image_run_t<double>(ctx, pl, batch, false, in, out, nullptr)
+                                      : image_run_t<float>(ctx, pl, batch, false, in, out, nullptr);
     const size_t rows = batch * (pl->h / pl->dims[pl->ndim - 1]);
     int rc = fft2_forward(ctx, pl->row, rows, in, out);
     for (int i = 0; i < pl->npass && !rc; ++i)
@@ -877,6 +1017,13 @@ int fftnd_forward(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, const void*
 }
 
 int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spectrum, void* out, const Fft2Epi* epi) {
+    if (image_fits(pl)) {
+        Fft2Epi e2 = epi ? *epi : Fft2Epi{};
+        e2.hint.kind = PRIOR_HINT_NONE;
+        // rows_per_inst counts IMAGES per instance for this kernel (the d components of a gradient)
+        return pl->dtype == TRAMP_F64 ? image_run_t<double>(ctx, pl, batch, true, spectrum, out, epi ? &e2 : nullptr)
+                                      : image_run_t<float>(ctx, pl, batch, true, spectrum, out, epi ? &e2 : nullptr);
+    }
     int rc = TRAMP_OK;
     for (int i = pl->npass - 1; i >= 0 && !rc; --i)
         rc = pl->dtype == TRAMP_F64 ? axis_run_t<double>(ctx, pl, pl->pass[i], batch, true, spectrum)
