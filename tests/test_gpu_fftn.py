@@ -403,3 +403,46 @@ def test_gradient_channel_shares_transforms_between_directions(ctx, shape):
     fresh = both(T.GradientChannel(shape, ctx=ctx))
     for g, w in zip(again, fresh):
         assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("shape,dtype", [((4096, 4096), np.float64), ((4096, 4096), np.float32), ((256, 256, 512), np.float32)],
+                         ids=["4096x4096-f64", "4096x4096-f32", "256x256x512-f32"])
+def test_fftn_full_size_properties(ctx, shape, dtype):
+    """At image scale (three passes per transform; the sizes of tools/bench_tree.py) through size-independent properties:
+    the inverse of the forward transform is h times the input; Parseval; and the transform of a plane wave is one peak at
+    the position the per-axis orders predict."""
+    import tramp_amd as T
+    dt = T.device.dtype_code(dtype)
+    n = int(np.prod(shape))
+    B = 2
+    x = ctx.randn((B, n), dtype, seed=5)
+    y, z = ctx.empty((B, n), dtype), ctx.empty((B, n), dtype)
+    ctx._call("tramp_fftn", dt, len(shape), _dims(shape), B, 0, x.ptr, y.ptr)
+    xh = x.get()
+    yh = y.get()
+    tol = 1e-12 if dtype == np.float64 else 2e-4
+    e_in = float(np.sum(xh.astype(np.float64) ** 2))
+    e_out = float(np.sum(yh.astype(np.float64) ** 2)) / (n // 2)
+    assert abs(e_out - e_in) < (1e-11 if dtype == np.float64 else 1e-4) * e_in
+    ctx._call("tramp_fftn", dt, len(shape), _dims(shape), B, 1, y.ptr, z.ptr)
+    zh = z.get() / (n // 2)
+    assert np.abs(zh - xh).max() < tol * 10 * np.abs(xh).max()
+    # plane wave of the packed array with frequency (k0, .., kl): exp(2 pi i (k . j / dims))
+    cshape = shape[:-1] + (shape[-1] // 2,)
+    ks = tuple(int(c // 3 + 1) for c in cshape)
+    phase = sum(np.arange(c).reshape([-1 if a == i else 1 for a in range(len(cshape))]) * (k / c)
+                for i, (c, k) in enumerate(zip(cshape, ks)))
+    w = np.exp(2j * np.pi * phase)
+    wave = np.empty(shape, dtype=dtype)
+    wave[..., 0::2], wave[..., 1::2] = w.real, w.imag
+    wd = ctx.array(wave.reshape(1, n), dtype)
+    od = ctx.empty((1, n), dtype)
+    ctx._call("tramp_fftn", dt, len(shape), _dims(shape), 1, 0, wd.ptr, od.ptr)
+    cdt = np.complex128 if dtype == np.float64 else np.complex64
+    spec = od.get().view(cdt).reshape(cshape)
+    orders = [np.asarray(o) for o in globals()["orders"](ctx, T, dtype, shape)]
+    pos = tuple(int(np.where(o == k)[0][0]) for o, k in zip(orders, ks))
+    peak = spec[pos]
+    assert abs(peak - n // 2) < (1e-9 if dtype == np.float64 else 1e-3) * (n // 2)
+    spec[pos] = 0
+    assert np.abs(spec).max() < (1e-9 if dtype == np.float64 else 2e-3) * (n // 2)
