@@ -116,3 +116,46 @@ def test_ep_with_solve_channel_equals_svd_channel_for_full_column_rank(ctx, damp
     assert res[True][0] == res[False][0]
     for k in (1, 2, 3):
         np.testing.assert_allclose(res[False][k], res[True][k], rtol=1e-6, atol=1e-8)
+
+
+def test_solve_channel_groups_of_instances_in_subprocess():
+    """More instances than one strided batch of N x N systems holds (scratch limited to 1 MB: 7 instances of a 200 x 200
+    system in groups of 3): the loop over groups gives every instance its own solve.  The limit is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np, tramp_amd as T
+from oracle import tramp_oracle as orc
+ctx = T.default_context()
+rs = np.random.RandomState(6)
+M, N, B = 150, 200, 7
+W = rs.randn(M, N) / np.sqrt(N)
+ch = T.LinearChannel(W, precompute_svd=False, ctx=ctx)
+o = orc.LinearSolveOracle(W)
+az, ax = rs.uniform(0.5, 2, B), rs.uniform(0.5, 2, B)
+bz, bx = rs.randn(B, N), rs.randn(B, M)
+a_b, b_b = ch.compute_backward_message(az, bz, ax, bx)
+a_f, b_f = ch.compute_forward_message(az, bz, ax, bx)
+for b in range(B):
+    ra, rb = o.backward_message(az[b], bz[b], ax[b], bx[b])
+    assert abs(a_b[b] - ra) < 1e-9 * ra and np.abs(b_b[b] - rb).max() < 1e-10 * np.abs(rb).max(), b
+    ra, rb = o.forward_message(az[b], bz[b], ax[b], bx[b])
+    assert abs(a_f[b] - ra) < 1e-9 * ra and np.abs(b_f[b] - rb).max() < 1e-10 * np.abs(rb).max(), b
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRAMP_LSOLVE_SCRATCH_MB="1")
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+
+
+def test_adaptive_damping_on_a_tree_model_is_refused(ctx):
+    import tramp_amd as T
+    from tests.test_gpu_tree import build_tree
+    rs = np.random.RandomState(0)
+    model = build_tree(T, ctx, dict(shape=(16,), noise_var=0.01, rho=0.1), y=rs.randn(16))
+    with pytest.raises(NotImplementedError, match="chain"):
+        T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=2, damping="adaptive")

@@ -1035,6 +1035,8 @@ class ExpectationPropagation:
             # (every candidate costs log-partition evaluations whose per-instance values come back to the host)
             if graph:
                 raise ValueError("adaptive damping cannot be captured in a hipGraph")
+            if not getattr(self.model, "is_chain", True):
+                raise NotImplementedError("adaptive damping is implemented for chain models (SISO variables)")
             if self._rot and (warm_start or self._allocated):
                 if warm_start:
                     raise ValueError("adaptive damping cannot warm-start a run that carried variables in a rotated basis")

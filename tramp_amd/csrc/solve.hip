@@ -21,6 +21,8 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -145,7 +147,9 @@ int ls_reserve(tramp_ctx* ctx, tramp_lsolve* ls, size_t batch) {
     ls->info = nullptr;
     ls->batch_cap = 0;
     const size_t nn = ls->N * ls->N * sizeof(double);
-    size_t group = ((size_t)2 << 30) / nn;
+    // instances factorised per strided-batched call: what fits TRAMP_LSOLVE_SCRATCH_MB (default 2048) of N x N systems
+    static const size_t scratch_mb = getenv("TRAMP_LSOLVE_SCRATCH_MB") ? (size_t)atol(getenv("TRAMP_LSOLVE_SCRATCH_MB")) : 2048;
+    size_t group = (scratch_mb << 20) / nn;
     if (group < 1) group = 1;
     if (group > batch) group = batch;
     const size_t mx = ls->M > ls->N ? ls->M : ls->N;
