@@ -79,7 +79,7 @@ def _conv_case(shape, seed):
     return f, rs
 
 
-CH_SHAPES = [(64,), (8, 16), (16, 32), (10, 160), (64, 64), (640, 32), (4, 8, 32), (2, 5, 64)]
+CH_SHAPES = [(64,), (4096,), (8192,), (16384,), (8, 16), (16, 32), (10, 160), (64, 64), (640, 32), (4, 8, 32), (2, 5, 64)]
 
 
 @pytest.mark.parametrize("shape", CH_SHAPES, ids=lambda s: "x".join(map(str, s)))

@@ -481,7 +481,9 @@ int conv_setup_fft2(tramp_ctx* ctx, tramp_conv* cv, const double2* w64, const st
     if (cv->ndim != 1 || cv->n < 2 || (cv->n & 1)) return TRAMP_OK;
     const size_t h = cv->n / 2;
     Fft2Shape shp;
-    if (!fft2_shape(h, &shp)) return TRAMP_OK;           // not 2^a 5^b in the two-pass range: rocFFT
+    // 1024 <= h <= 4096: the whole transform is one block pass (one launch, message update fused into it); above: two passes
+    const bool blk = h >= 1024 && fft2_block_shape(h, &shp);
+    if (!blk && !fft2_shape(h, &shp)) return TRAMP_OK;   // not 2^a 5^b in the engine's range: the N-D plans or rocFFT
     std::vector<double2> wnat(cv->nh);
     TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(wnat.data(), w64, cv->nh * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -540,7 +542,7 @@ int conv_setup_fft2(tramp_ctx* ctx, tramp_conv* cv, const double2* w64, const st
     }
     TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->s2_p, s2p.data(), h * sizeof(double), hipMemcpyHostToDevice));
     TRAMP_HIP_CHECK(ctx, hipMemcpy(cv->partner, partner.data(), h * sizeof(int), hipMemcpyHostToDevice));
-    int rc = fft2_plan_create(ctx, cv->dtype, h, &cv->fft2);
+    int rc = fft2_plan_create(ctx, cv->dtype, h, &cv->fft2, blk);
     if (rc) return rc;
     cv->h = h;
     return TRAMP_OK;
