@@ -164,13 +164,19 @@ def test_gradient_channel_on_own_engine(ctx, shape, dtype, monkeypatch):
 DFT_SHAPES = [(64,), (1000,), (8192,), (16, 32), (10, 160), (640, 32), (4, 8, 16), (15,), (6, 8)]
 
 
-@pytest.mark.parametrize("shape", DFT_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", DFT_SHAPES + [(640, 32), (1024, 4, 16)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("real", [True, False])
-def test_dft_channel_real_and_complex_input(ctx, shape, dtype, real):
-    """DFTChannel messages (dft_channel.py:47-67) on the own engine (shapes it takes) and on rocFFT (15, 6x8), for
-    real z and for complex z (real=False: planar [2, ...] arrays on both sides), with damping."""
+@pytest.mark.parametrize("engine", ["own", "rocfft"])
+def test_dft_channel_real_and_complex_input(ctx, shape, dtype, real, engine, monkeypatch):
+    """DFTChannel messages (dft_channel.py:47-67) on rocFFT (the default) and on the own engine's natural-order transforms
+    (TRAMP_DFT_FFT=own; shapes it does not take - 15, 6x8, a last axis beyond one block - stay on rocFFT), for real z and
+    for complex z (real=False: planar [2, ...] arrays on both sides)."""
     import tramp_amd as T
+    if engine == "own":
+        monkeypatch.setenv("TRAMP_DFT_FFT", "own")
+    else:
+        monkeypatch.delenv("TRAMP_DFT_FFT", raising=False)
     rs = np.random.RandomState(len(shape) + int(real))
     B, n = 3, int(np.prod(shape))
     ch = T.DFTChannel(real=real, shape=shape, dtype=dtype, ctx=ctx)
@@ -240,8 +246,13 @@ def test_complex_conv_channel_matches_reference_goldens(ctx, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_complex_dft_channel_matches_reference_goldens(ctx, dtype):
+@pytest.mark.parametrize("engine", ["own", "rocfft"])
+def test_complex_dft_channel_matches_reference_goldens(ctx, dtype, engine, monkeypatch):
     import tramp_amd as T
+    if engine == "own":
+        monkeypatch.setenv("TRAMP_DFT_FFT", "own")
+    else:
+        monkeypatch.delenv("TRAMP_DFT_FFT", raising=False)
     _, dft = _load_complex_goldens()
     tol = 1e-12 if dtype == np.float64 else 3e-5
     for c in dft:

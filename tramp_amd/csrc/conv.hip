@@ -1546,11 +1546,8 @@ struct tramp_dft {
     size_t work_batch;
     void* c0;
     void* c1;
-    // own FFT engine on the full complex array (fft_pow2.hip, every axis in its permuted order): the two index
-    // tables translate between positions of the transform and natural (row-major) frequencies
+    // own FFT engine on the full complex array in its natural-order mode (fft_pow2.h: fftnd_forward_nat / _inverse_nat)
     FftNdPlan* fftn;
-    int* nat_of_pos;     // [n]
-    int* pos_of_nat;     // [n]
     bool complex_in;     // real=False: z is complex too (planar [2, n] on both sides)
 };
 
@@ -1645,39 +1642,26 @@ extern "C" int tramp_dft_create(tramp_ctx* ctx, int dtype, int ndim, const size_
     h->work = nullptr;
     h->work_batch = 0;
     h->fftn = nullptr;
-    h->nat_of_pos = h->pos_of_nat = nullptr;
     h->complex_in = false;
-    const char* eng = getenv("TRAMP_CONV_FFT");
-    if (!(eng && strcmp(eng, "rocfft") == 0) && h->n <= 0x7fffffffull && fftnd_supported(dtype, ndim, h->dims, false)) {
+    // The spectrum is this channel's MESSAGE, so it has to leave in natural order - a plain library transform.  The own engine
+    // can deliver that at no extra pass (fft_pow2.h natural-order mode: last axis <= 4096 complex) and is then level with
+    // rocFFT at 1024 x 1024 (1.04x f64, 0.96x f32) but behind it at 4096 x 4096 (0.86x: the second pass of a long axis must
+    // go out of place) and on small arrays (0.6-0.8x, launch-bound); a gather through an index table after a permuted-order
+    // transform was slower everywhere (0.5-0.98x).  tools/bench_dft.py, profiles/r03/bench_dft_*.txt.  So: rocFFT by
+    // default, TRAMP_DFT_FFT=own selects the own engine where it applies.
+    const char* eng = getenv("TRAMP_DFT_FFT");
+    if (eng && strcmp(eng, "own") == 0 && fftnd_supported(dtype, ndim, h->dims, false)) {
         int rc = fftnd_plan_create(ctx, dtype, ndim, h->dims, &h->fftn, false);
-        if (rc) {
-            delete h;
-            return rc;
-        }
-        std::vector<int> nat(h->n), pos(h->n);
-        std::vector<size_t> kf[3];
-        for (int a = 0; a < ndim; ++a) {
-            kf[a].resize(h->dims[a]);
-            for (size_t i = 0; i < h->dims[a]; ++i) kf[a][i] = fftnd_kfreq(h->fftn, a, i);
-        }
-        for (size_t p = 0; p < h->n; ++p) {
-            size_t rem = p, k = 0, stride = 1;
-            for (int a = ndim - 1; a >= 0; --a) {
-                k += kf[a][rem % h->dims[a]] * stride;
-                rem /= h->dims[a];
-                stride *= h->dims[a];
+        if (!rc) {
+            if (fftnd_natural_ok(h->fftn)) rc = fftnd_enable_natural(ctx, h->fftn);
+            else {
+                fftnd_plan_destroy(h->fftn);
+                h->fftn = nullptr;
             }
-            nat[p] = (int)k;
-            pos[k] = (int)p;
         }
-        hipError_t e = hipMalloc((void**)&h->nat_of_pos, h->n * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void**)&h->pos_of_nat, h->n * sizeof(int));
-        if (e == hipSuccess) e = hipMemcpy(h->nat_of_pos, nat.data(), h->n * sizeof(int), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(h->pos_of_nat, pos.data(), h->n * sizeof(int), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
+        if (rc) {
             (void)tramp_dft_destroy(ctx, h);
-            return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_dft_create", hipGetErrorString(e));
+            return rc;
         }
     }
     *dft = h;
@@ -1705,8 +1689,6 @@ extern "C" int tramp_dft_destroy(tramp_ctx* ctx, tramp_dft* h) {
     }
     if (h->work) (void)hipFree(h->work);
     if (h->fftn) fftnd_plan_destroy(h->fftn);
-    if (h->nat_of_pos) (void)hipFree(h->nat_of_pos);
-    if (h->pos_of_nat) (void)hipFree(h->pos_of_nat);
     delete h;
     return TRAMP_OK;
 }
@@ -1757,10 +1739,9 @@ extern "C" int tramp_dft_message(tramp_ctx* ctx, tramp_dft* h, int dir, size_t b
     const bool own = h->fftn != nullptr;
     const bool real_in = fwd && !h->complex_in;                 // the only real-valued input
     const bool planar_out = fwd || h->complex_in;
-    // backward on the own engine: the inverse transform wants the spectrum in its permuted order
-    const int* pack_idx = (own && !fwd) ? h->nat_of_pos : nullptr;
-    // forward on the own engine: frequency k sits at position pos_of_nat[k] of the transform's output
-    const int* unpack_idx = (own && fwd) ? h->pos_of_nat : nullptr;
+    const int* pack_idx = nullptr;                               // (index tables: unused since the natural-order passes)
+    const int* unpack_idx = nullptr;
+    void* spec = h->c1;
     {
         ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (real_in ? 3 : 4), 0);
         if (h->dtype == TRAMP_F64) {
@@ -1783,7 +1764,8 @@ extern "C" int tramp_dft_message(tramp_ctx* ctx, tramp_dft* h, int dir, size_t b
     {
         ProfScope ps(ctx, PROF_FFT, (double)batch * n * 4 * esz, 0);
         int rc;
-        if (own) rc = fwd ? fftnd_forward(ctx, h->fftn, batch, h->c0, h->c1) : fftnd_inverse(ctx, h->fftn, batch, h->c0, h->c1);
+        if (own) rc = fwd ? fftnd_forward_nat(ctx, h->fftn, batch, h->c0, h->c1, &spec)
+                          : fftnd_inverse_nat(ctx, h->fftn, batch, h->c0, h->c1, &spec);
         else rc = fwd ? fft_exec(ctx, pl->fwd, pl->info_fwd, h->c0, h->c1) : fft_exec(ctx, pl->inv, pl->info_inv, h->c0, h->c1);
         if (rc) return rc;
     }
@@ -1791,10 +1773,10 @@ extern "C" int tramp_dft_message(tramp_ctx* ctx, tramp_dft* h, int dir, size_t b
         ProfScope ps(ctx, PROF_EW, (double)batch * n * esz * (planar_out ? 4 : 3), 0);
         if (h->dtype == TRAMP_F64)
             hipLaunchKernelGGL((dft_unpack_kernel<double>), g, dim3(kBlock), 0, ctx->stream, n, planar_out ? 1 : 0, scale,
-                               (const double2*)h->c1, damping, (const double*)b_old_d, (double*)b_new_d, unpack_idx);
+                               (const double2*)spec, damping, (const double*)b_old_d, (double*)b_new_d, unpack_idx);
         else
             hipLaunchKernelGGL((dft_unpack_kernel<float>), g, dim3(kBlock), 0, ctx->stream, n, planar_out ? 1 : 0,
-                               (float)scale, (const float2*)h->c1, damping, (const float*)b_old_d, (float*)b_new_d,
+                               (float)scale, (const float2*)spec, damping, (const float*)b_old_d, (float*)b_new_d,
                                unpack_idx);
         TRAMP_LAUNCH_CHECK(ctx);
     }

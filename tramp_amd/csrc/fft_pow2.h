@@ -76,6 +76,9 @@ struct FftNdPlan {
     void* tw_hi[2];     // two-level twiddle tables of the outer axes
     void* tw_lo[2];
     int nrad[2], rad[2][16];
+    // natural-order mode (fftnd_enable_natural): position -> frequency of the outer axes, frequency -> position of the last
+    int* kf_dev[2];
+    int* pos_last_dev;
 };
 
 // real dims [ndim] (last axis even); false: some axis is not 2^a 5^b / too long / the lines do not tile.
@@ -91,5 +94,13 @@ int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spect
                   const Fft2Epi* epi = nullptr);
 int fftnd_inverse_signals(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, size_t signals, void* spectrum,
                           const Fft2Epi* epi);
+// Natural-order transforms (the DFT channel, whose spectrum IS the message): the un-permutation costs no pass - the last
+// pass of every outer axis writes (forward) or reads (inverse) its rows at the place of their frequency, the block pass of
+// the last axis permutes inside LDS.  Needs the block-only last axis (n_last <= 4096 complex).  `a` (input, clobbered) and
+// `b` are two buffers of batch * h complex; *result is the one that holds the answer.
+bool fftnd_natural_ok(const FftNdPlan* pl);
+int fftnd_enable_natural(tramp_ctx* ctx, FftNdPlan* pl);
+int fftnd_forward_nat(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* a, void* b, void** result);
+int fftnd_inverse_nat(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* a, void* b, void** result);
 // single block pass for h <= 4096 (G = 1)
 bool fft2_block_shape(size_t h, Fft2Shape* sh);

@@ -17,6 +17,7 @@
 // Each pass reads and writes every point once: 2 x (read + write) per transform.
 // The inverse runs pass 2 then pass 1 with conjugated twiddles and the transposed butterflies.
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "fft_pow2.h"
@@ -257,7 +258,8 @@ template <typename T, bool INV, bool EPI = false>
 __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typename C2<T>::type* __restrict__ in,
                                                         typename C2<T>::type* __restrict__ out,
                                                         const typename C2<T>::type* __restrict__ tw_blk, int tile_pts,
-                                                        size_t total_pts, Fft2Epi epi = Fft2Epi{}) {
+                                                        size_t total_pts, Fft2Epi epi = Fft2Epi{},
+                                                        const int* __restrict__ pos_of_freq = nullptr, int nat_mode = 0) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
@@ -266,7 +268,12 @@ __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typ
     const int npts = (int)((total_pts - first < (size_t)tile_pts) ? total_pts - first : (size_t)tile_pts);
     const C* blk = in + first;                        // blocks of all transforms are contiguous
     C* dst = out + first;
-    if constexpr (sizeof(T) == 4) {
+    const int LBi = (int)sh.LB;
+    if (nat_mode == 2) {
+        // natural-order spectrum in: element k of a row goes to the position the inverse stages expect (the permutation
+        // happens in LDS, the global reads stay contiguous)
+        for (int i = threadIdx.x; i < npts; i += nthr) tile[(i / LBi) * LBi + pos_of_freq[i % LBi]] = blk[i];
+    } else if constexpr (sizeof(T) == 4) {
         for (int i = threadIdx.x; i < npts / 2; i += nthr)
             reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(blk)[i];
     } else {
@@ -312,7 +319,9 @@ __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typ
         }
         return;
     }
-    if constexpr (sizeof(T) == 4) {
+    if (nat_mode == 1) {
+        for (int i = threadIdx.x; i < npts; i += nthr) dst[i] = tile[(i / LBi) * LBi + pos_of_freq[i % LBi]];
+    } else if constexpr (sizeof(T) == 4) {
         for (int i = threadIdx.x; i < npts / 2; i += nthr)
             reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
     } else {
@@ -421,7 +430,8 @@ template <typename T, bool INV>
 __global__ __launch_bounds__(1024) void fft_axis_kernel(FftAxisPass ps, const typename C2<T>::type* __restrict__ in,
                                                        typename C2<T>::type* __restrict__ out,
                                                        const typename C2<T>::type* __restrict__ tw_hi,
-                                                       const typename C2<T>::type* __restrict__ tw_lo) {
+                                                       const typename C2<T>::type* __restrict__ tw_lo,
+                                                       const int* __restrict__ rowmap = nullptr, int map_mode = 0) {
     using C = typename C2<T>::type;
     extern __shared__ unsigned char smem_raw[];
     C* tile = reinterpret_cast<C*>(smem_raw);
@@ -435,21 +445,29 @@ __global__ __launch_bounds__(1024) void fft_axis_kernel(FftAxisPass ps, const ty
     const int q = (int)(t % ps.Q);
     t /= ps.Q;
     const size_t a = t % ps.nA, o = t / ps.nA;
-    const size_t base = (o * ps.n + a * (size_t)G * ps.Q + q) * ps.W + cg * kC1;
-    const size_t rs = (size_t)ps.Q * ps.W;
-    const C* src = in + base;
-    C* dst = out + base;
+    // tile row g is row a G Q + g Q + q of the axis; natural-order mode (rowmap: position -> frequency) reads (2) or
+    // writes (1) that row at the place of its frequency instead - whole 128-byte lines either way
+    const size_t row0 = a * (size_t)G * ps.Q + q;
+    const size_t col0 = o * ps.n * ps.W + cg * kC1;
+    auto row_in = [&](int g) -> size_t {
+        const size_t r = row0 + (size_t)g * ps.Q;
+        return col0 + (size_t)(map_mode == 2 ? (size_t)rowmap[r] : r) * ps.W;
+    };
+    auto row_out = [&](int g) -> size_t {
+        const size_t r = row0 + (size_t)g * ps.Q;
+        return col0 + (size_t)(map_mode == 1 ? (size_t)rowmap[r] : r) * ps.W;
+    };
     const int c = threadIdx.x % kC1, r0 = threadIdx.x / kC1;
     const int rstep = blockDim.x / kC1;
     if constexpr (sizeof(T) == 4) {
         const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
         for (int g = q0; g < G; g += 2 * rstep) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)g * rs + 2 * c2);
+            const float4 v = *reinterpret_cast<const float4*>(in + row_in(g) + 2 * c2);
             tile[g * P + 2 * c2] = C{v.x, v.y};
             tile[g * P + 2 * c2 + 1] = C{v.z, v.w};
         }
     } else {
-        for (int g = r0; g < G; g += rstep) tile[g * P + c] = src[(size_t)g * rs + c];
+        for (int g = r0; g < G; g += rstep) tile[g * P + c] = in[row_in(g) + c];
     }
     C* twl = tile + (size_t)G * P;
     for (int s = 0; s < ps.nst; ++s)
@@ -472,10 +490,10 @@ __global__ __launch_bounds__(1024) void fft_axis_kernel(FftAxisPass ps, const ty
         const int c2 = threadIdx.x % (kC1 / 2), q0 = threadIdx.x / (kC1 / 2);
         for (int g = q0; g < G; g += 2 * rstep) {
             const C x = tile[g * P + 2 * c2], y = tile[g * P + 2 * c2 + 1];
-            *reinterpret_cast<float4*>(dst + (size_t)g * rs + 2 * c2) = float4{x.x, x.y, y.x, y.y};
+            *reinterpret_cast<float4*>(out + row_out(g) + 2 * c2) = float4{x.x, x.y, y.x, y.y};
         }
     } else {
-        for (int g = r0; g < G; g += rstep) dst[(size_t)g * rs + c] = tile[g * P + c];
+        for (int g = r0; g < G; g += rstep) out[row_out(g) + c] = tile[g * P + c];
     }
 }
 
@@ -833,7 +851,9 @@ int axis_tables_t(tramp_ctx* ctx, size_t n, void** hi, void** lo) {
 }
 
 template <typename T>
-int axis_run_t(tramp_ctx* ctx, const FftNdPlan* pl, const FftAxisPass& ps, size_t batch, bool inverse, void* data) {
+int axis_run_t(tramp_ctx* ctx, const FftNdPlan* pl, const FftAxisPass& ps, size_t batch, bool inverse, void* data,
+               void* data_out = nullptr, const int* rowmap = nullptr, int map_mode = 0) {
+    if (!data_out) data_out = data;
     using C = typename C2<T>::type;
     constexpr int kC1 = c1_of<T>();
     size_t outer = batch;
@@ -862,10 +882,10 @@ int axis_run_t(tramp_ctx* ctx, const FftNdPlan* pl, const FftAxisPass& ps, size_
     const int ax = ps.axis;
     if (inverse)
         hipLaunchKernelGGL((fft_axis_kernel<T, true>), dim3((unsigned)tiles), dim3(thr), lds, ctx->stream, ps, (const C*)data,
-                           (C*)data, (const C*)pl->tw_hi[ax], (const C*)pl->tw_lo[ax]);
+                           (C*)data_out, (const C*)pl->tw_hi[ax], (const C*)pl->tw_lo[ax], rowmap, map_mode);
     else
         hipLaunchKernelGGL((fft_axis_kernel<T, false>), dim3((unsigned)tiles), dim3(thr), lds, ctx->stream, ps, (const C*)data,
-                           (C*)data, (const C*)pl->tw_hi[ax], (const C*)pl->tw_lo[ax]);
+                           (C*)data_out, (const C*)pl->tw_hi[ax], (const C*)pl->tw_lo[ax], rowmap, map_mode);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }
@@ -987,7 +1007,9 @@ void fftnd_plan_destroy(FftNdPlan* pl) {
     for (int a = 0; a < 2; ++a) {
         if (pl->tw_hi[a]) (void)hipFree(pl->tw_hi[a]);
         if (pl->tw_lo[a]) (void)hipFree(pl->tw_lo[a]);
+        if (pl->kf_dev[a]) (void)hipFree(pl->kf_dev[a]);
     }
+    if (pl->pos_last_dev) (void)hipFree(pl->pos_last_dev);
     delete pl;
 }
 
@@ -1036,6 +1058,105 @@ int fftnd_inverse(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* spect
         return fft2_inverse(ctx, pl->row, batch * rpi, spectrum, out, &e2);
     }
     return fft2_inverse(ctx, pl->row, batch * rpi, spectrum, out);
+}
+
+// ---- natural-order mode
+bool fftnd_natural_ok(const FftNdPlan* pl) { return pl->row->shape.G == 1; }
+
+int fftnd_enable_natural(tramp_ctx* ctx, FftNdPlan* pl) {
+    if (pl->pos_last_dev) return TRAMP_OK;
+    if (!fftnd_natural_ok(pl)) return tramp_fail(ctx, TRAMP_ENOTSUP, "fftnd natural order", "last axis longer than one block");
+    const int nd = pl->ndim;
+    const size_t hl = pl->dims[nd - 1];
+    std::vector<int> pos(hl);
+    for (size_t p = 0; p < hl; ++p) pos[fftnd_kfreq(pl, nd - 1, p)] = (int)p;
+    TRAMP_HIP_CHECK(ctx, hipMalloc((void**)&pl->pos_last_dev, hl * sizeof(int)));
+    TRAMP_HIP_CHECK(ctx, hipMemcpy(pl->pos_last_dev, pos.data(), hl * sizeof(int), hipMemcpyHostToDevice));
+    for (int a = 0; a < nd - 1; ++a) {
+        const size_t n = pl->dims[a];
+        std::vector<int> kf(n);
+        for (size_t p = 0; p < n; ++p) kf[p] = (int)fftnd_kfreq(pl, a, p);
+        TRAMP_HIP_CHECK(ctx, hipMalloc((void**)&pl->kf_dev[a], n * sizeof(int)));
+        TRAMP_HIP_CHECK(ctx, hipMemcpy(pl->kf_dev[a], kf.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return TRAMP_OK;
+}
+
+namespace {
+
+template <typename T>
+int row_run_nat_t(tramp_ctx* ctx, const FftNdPlan* pl, size_t rows, bool inverse, const void* in, void* out) {
+    using C = typename C2<T>::type;
+    const Fft2Shape& sh = pl->row->shape;
+    const size_t total_pts = rows * sh.h;
+    int tile_pts = (int)sh.LB;
+    if (sh.LB < 2048) tile_pts = (int)(sh.LB * (2048 / sh.LB));
+    const size_t lds = ((size_t)tile_pts + (size_t)sh.ntw2) * sizeof(C);
+    const unsigned g = (unsigned)((total_pts + tile_pts - 1) / tile_pts);
+    const int thr = sizeof(T) == 8 ? 512 : 256;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[sizeof(T) == 8 ? 0 : 1]) {
+        for (const void* f : {reinterpret_cast<const void*>(fft_block_kernel<T, false>),
+                              reinterpret_cast<const void*>(fft_block_kernel<T, true>)})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                (void)hipGetLastError();
+        attr_done[sizeof(T) == 8 ? 0 : 1] = true;
+    }
+    if (inverse)
+        hipLaunchKernelGGL((fft_block_kernel<T, true>), dim3(g), dim3(thr), lds, ctx->stream, sh, (const C*)in, (C*)out,
+                           (const C*)pl->row->tw_blk, tile_pts, total_pts, Fft2Epi{}, pl->pos_last_dev, 2);
+    else
+        hipLaunchKernelGGL((fft_block_kernel<T, false>), dim3(g), dim3(thr), lds, ctx->stream, sh, (const C*)in, (C*)out,
+                           (const C*)pl->row->tw_blk, tile_pts, total_pts, Fft2Epi{}, pl->pos_last_dev, 1);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+template <typename T>
+int fftnd_nat_t(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, bool inverse, void* a, void* b, void** result) {
+    const size_t rows = batch * (pl->h / pl->dims[pl->ndim - 1]);
+    void *cur = a, *other = b;
+    int rc = TRAMP_OK;
+    if (!inverse) {
+        rc = row_run_nat_t<T>(ctx, pl, rows, false, cur, other);
+        std::swap(cur, other);
+        for (int i = 0; i < pl->npass && !rc; ++i) {
+            const FftAxisPass& ps = pl->pass[i];
+            const bool last_of_axis = ps.Q == 1;                 // single pass, or the second of two
+            const bool hop = last_of_axis && ps.nA > 1;          // its rows land in other tiles' ranges: out of place
+            rc = axis_run_t<T>(ctx, pl, ps, batch, false, cur, hop ? other : cur, last_of_axis ? pl->kf_dev[ps.axis] : nullptr,
+                               last_of_axis ? 1 : 0);
+            if (hop) std::swap(cur, other);
+        }
+        *result = cur;
+        return rc;
+    }
+    for (int i = pl->npass - 1; i >= 0 && !rc; --i) {
+        const FftAxisPass& ps = pl->pass[i];
+        const bool last_of_axis = ps.Q == 1;                     // runs FIRST in the inverse: reads rows by frequency
+        const bool hop = last_of_axis && ps.nA > 1;
+        rc = axis_run_t<T>(ctx, pl, ps, batch, true, cur, hop ? other : cur, last_of_axis ? pl->kf_dev[ps.axis] : nullptr,
+                           last_of_axis ? 2 : 0);
+        if (hop) std::swap(cur, other);
+    }
+    if (rc) return rc;
+    rc = row_run_nat_t<T>(ctx, pl, rows, true, cur, other);
+    *result = other;
+    return rc;
+}
+
+}  // namespace
+
+int fftnd_forward_nat(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* a, void* b, void** result) {
+    if (!pl->pos_last_dev) return tramp_fail(ctx, TRAMP_EINVAL, "fftnd_forward_nat", "natural order not enabled");
+    return pl->dtype == TRAMP_F64 ? fftnd_nat_t<double>(ctx, pl, batch, false, a, b, result)
+                                  : fftnd_nat_t<float>(ctx, pl, batch, false, a, b, result);
+}
+
+int fftnd_inverse_nat(tramp_ctx* ctx, const FftNdPlan* pl, size_t batch, void* a, void* b, void** result) {
+    if (!pl->pos_last_dev) return tramp_fail(ctx, TRAMP_EINVAL, "fftnd_inverse_nat", "natural order not enabled");
+    return pl->dtype == TRAMP_F64 ? fftnd_nat_t<double>(ctx, pl, batch, true, a, b, result)
+                                  : fftnd_nat_t<float>(ctx, pl, batch, true, a, b, result);
 }
 
 // `signals` consecutive signals share one problem instance (the d components of a gradient): the epilogue's scalar
