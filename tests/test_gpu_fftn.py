@@ -100,7 +100,7 @@ def test_conv_channel_on_own_engine(ctx, shape, dtype, monkeypatch):
         if eng == "rocfft":
             monkeypatch.setenv("TRAMP_CONV_FFT", "rocfft")
         else:
-            monkeypatch.delenv("TRAMP_CONV_FFT", raising=False)
+            monkeypatch.setenv("TRAMP_CONV_FFT", "own")
         ch = T.ConvChannel(f, dtype=dtype, ctx=ctx)
         res[eng] = dict(fwd=ch.compute_forward_message(az, bz.astype(dtype), ax, bx.astype(dtype)),
                         bwd=ch.compute_backward_message(az, bz.astype(dtype), ax, bx.astype(dtype)),
@@ -140,7 +140,7 @@ def test_gradient_channel_on_own_engine(ctx, shape, dtype, monkeypatch):
         if eng == "rocfft":
             monkeypatch.setenv("TRAMP_CONV_FFT", "rocfft")
         else:
-            monkeypatch.delenv("TRAMP_CONV_FFT", raising=False)
+            monkeypatch.setenv("TRAMP_CONV_FFT", "own")
         ch = T.GradientChannel(shape, dtype=dtype, ctx=ctx)
         res[eng] = dict(fwd=ch.compute_forward_message(az, bz.astype(dtype), ax, bx.astype(dtype)),
                         bwd=ch.compute_backward_message(az, bz.astype(dtype), ax, bx.astype(dtype)),
@@ -213,10 +213,11 @@ def _load_complex_goldens():
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_complex_conv_channel_matches_reference_goldens(ctx, dtype):
+def test_complex_conv_channel_matches_reference_goldens(ctx, dtype, monkeypatch):
     """ConvChannel(real=False) against the reference's own outputs (conv_channel.py:25-32, 81-109): posteriors, messages,
     x = w * z, n_eff and second moment; shapes on the own engine (16, 64, 8x16, 16x32, 4x4x16) and on rocFFT (15, 6x8, 3x4x5)."""
     import tramp_amd as T
+    monkeypatch.setenv("TRAMP_CONV_FFT", "own")          # small shapes: the default would be rocFFT
     conv, _ = _load_complex_goldens()
     tol = 1e-11 if dtype == np.float64 else 3e-4
     chans = {}
@@ -286,7 +287,7 @@ def test_complex_conv_channel_larger_shapes_and_damping(ctx, shape, monkeypatch)
         if eng == "rocfft":
             monkeypatch.setenv("TRAMP_CONV_FFT", "rocfft")
         else:
-            monkeypatch.delenv("TRAMP_CONV_FFT", raising=False)
+            monkeypatch.setenv("TRAMP_CONV_FFT", "own")
         ch = T.ConvChannel(f, real=False, ctx=ctx)
         out[eng] = (ch.compute_forward_message(az, bz, ax, bx), ch.compute_backward_message(az, bz, ax, bx))
         # damping through the device entry (old message = the incoming one)
@@ -348,7 +349,7 @@ def test_tree_ep_on_own_engine_matches_oracle_and_rocfft(ctx, shape, monkeypatch
         if eng == "rocfft":
             monkeypatch.setenv("TRAMP_CONV_FFT", "rocfft")
         else:
-            monkeypatch.delenv("TRAMP_CONV_FFT", raising=False)
+            monkeypatch.setenv("TRAMP_CONV_FFT", "own")
         model = build_tree(T, ctx, dict(shape=shape, noise_var=nv, rho=rho), y=y)
         ep = T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=12, damping=0.1, callback=T.PassCallback(),
                                                               graph=graph)
@@ -361,9 +362,10 @@ def test_tree_ep_on_own_engine_matches_oracle_and_rocfft(ctx, shape, monkeypatch
         np.testing.assert_allclose(res[key][1], want["r"]["z"], rtol=1e-7, atol=1e-8)
 
 
-def test_conv2d_ep_graph_replay_on_own_engine(ctx):
+def test_conv2d_ep_graph_replay_on_own_engine(ctx, monkeypatch):
     "A 2-D deconvolution EP on the N-D plans: iterate(graph=True) gives the bits of the eager loop"
     import tramp_amd as T
+    monkeypatch.setenv("TRAMP_CONV_FFT", "own")
     rs = np.random.RandomState(3)
     shape, B, rho, nv = (32, 64), 2, 0.1, 1e-3
     n = shape[0] * shape[1]
@@ -382,11 +384,12 @@ def test_conv2d_ep_graph_replay_on_own_engine(ctx):
 
 
 @pytest.mark.parametrize("shape", [(16, 32), (12, 10)], ids=lambda s: "x".join(map(str, s)))
-def test_gradient_channel_shares_transforms_between_directions(ctx, shape):
+def test_gradient_channel_shares_transforms_between_directions(ctx, shape, monkeypatch):
     """Device-resident messages that were not rewritten since the previous call are not transformed again
     (TRAMP_REUSE_T / _U, as the convolution channel): same results as a fresh channel; a rewritten buffer (version bump)
     is transformed anew.  (16, 32) runs on the own engine, (12, 10) on rocFFT."""
     import tramp_amd as T
+    monkeypatch.setenv("TRAMP_CONV_FFT", "own")
     rs = np.random.RandomState(2)
     B, d, n = 2, len(shape), int(np.prod(shape))
     az, ax = ctx.array(rs.uniform(0.5, 2, B)), ctx.array(rs.uniform(0.5, 2, B))

@@ -21,7 +21,7 @@ def run(kind, shape, B, engine):
     if engine == "rocfft":
         os.environ["TRAMP_CONV_FFT"] = "rocfft"
     else:
-        os.environ.pop("TRAMP_CONV_FFT", None)
+        os.environ["TRAMP_CONV_FFT"] = "own"
     n, d = int(np.prod(shape)), len(shape)
     if kind == "grad":
         ch = T.GradientChannel(shape, dtype=np_dt, ctx=ctx)
@@ -58,6 +58,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "one":
     # profiling: one case on the engine TRAMP_CONV_FFT selects
     # python tools/bench_fftnd.py f64 10 one [conv|grad] [AxBxC] [instances]
     eng = "rocfft" if os.environ.get("TRAMP_CONV_FFT") == "rocfft" else "own"
+    os.environ.setdefault("TRAMP_CONV_FFT", "own")
     kind1 = sys.argv[4] if len(sys.argv) > 4 else "grad"
     shape1 = tuple(int(v) for v in sys.argv[5].split("x")) if len(sys.argv) > 5 else (4096, 4096)
     B1 = int(sys.argv[6]) if len(sys.argv) > 6 else 4

@@ -21,7 +21,7 @@ for eng in ("own", "rocfft"):
     if eng == "rocfft":
         os.environ["TRAMP_CONV_FFT"] = "rocfft"
     else:
-        os.environ.pop("TRAMP_CONV_FFT", None)
+        os.environ["TRAMP_CONV_FFT"] = "own"
     ch = T.ConvChannel(f, ctx=ctx)
     Y = ch.convolve(X.reshape((B,) + shape)).reshape(B, n) + np.sqrt(nv) * np.random.RandomState(4).standard_normal((B, n))
     for graph in (False, True):

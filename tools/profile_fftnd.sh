@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/prof_fftnd
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for eng in own rocfft; do
-  if [ $eng = rocfft ]; then export TRAMP_CONV_FFT=rocfft; else unset TRAMP_CONV_FFT; fi
+  export TRAMP_CONV_FFT=$eng
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$eng -- python3 $REPO/tools/bench_fftnd.py f64 5 one > $OUT/$eng.out 2>&1
   f=$(find $OUT/$eng -name "*kernel_stats.csv" | head -1)
   echo "== $eng"; cat $OUT/$eng.out | tail -3

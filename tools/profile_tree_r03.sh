@@ -6,13 +6,13 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_tree_r03
 mkdir -p $OUT
 for eng in own rocfft; do
-  if [ $eng = rocfft ]; then export TRAMP_CONV_FFT=rocfft; else unset TRAMP_CONV_FFT; fi
+  export TRAMP_CONV_FFT=$eng
   echo "== engine $eng" >> $OUT/bench_tree.txt
   python3 tools/bench_tree.py 1024 4 f64 sgrad >> $OUT/bench_tree.txt 2>&1
   python3 tools/bench_tree.py 4096 4 f64 sgrad >> $OUT/bench_tree.txt 2>&1
   python3 tools/bench_tree.py 4096 4 f32 tv >> $OUT/bench_tree.txt 2>&1
 done
-unset TRAMP_CONV_FFT
+export TRAMP_CONV_FFT=own
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/tools/bench_tree.py 4096 4 f64 sgrad > $OUT/trace.out 2>&1
 cd $REPO

@@ -472,14 +472,26 @@ void conv_free_fft2(tramp_conv* cv) {
     cv->partner = nullptr;
 }
 
+// Which engine transforms a signal of `points` complex points per instance.  Measured (tools/sweep_engine_defaults.sh,
+// profiles/r03/sweep_engine_defaults.txt): the own engine wins where the transforms are bound by memory - 256 x 256 and up
+// 1.05-1.27x, a 10^6-point gradient channel 2x - and loses 10-30 % on small arrays (128 x 128, 32^3, n <= 8192), which are
+// bound by launches and latency and where rocFFT has fused small-size kernels.  Default: own engine from 32768 points;
+// TRAMP_CONV_FFT=own / =rocfft force one everywhere (the tests run both), TRAMP_CONV_FFT_MIN_POINTS moves the threshold.
+bool own_engine_wanted(size_t points) {
+    const char* eng = getenv("TRAMP_CONV_FFT");
+    if (eng && strcmp(eng, "rocfft") == 0) return false;
+    if (eng && strcmp(eng, "own") == 0) return true;
+    static const size_t min_points = getenv("TRAMP_CONV_FFT_MIN_POINTS") ? (size_t)atol(getenv("TRAMP_CONV_FFT_MIN_POINTS")) : 32768;
+    return points >= min_points;
+}
+
 // Tables of the own-FFT engine: the filter bins and the unpack twiddles in the transform's
 // permuted order, and the k <-> h-k partner positions.  w64: natural-order half spectrum (device),
 // s2h: its squared modulus (host).
 int conv_setup_fft2(tramp_ctx* ctx, tramp_conv* cv, const double2* w64, const std::vector<double>& s2h) {
-    const char* eng = getenv("TRAMP_CONV_FFT");
-    if (eng && strcmp(eng, "rocfft") == 0) return TRAMP_OK;
     if (cv->ndim != 1 || cv->n < 2 || (cv->n & 1)) return TRAMP_OK;
     const size_t h = cv->n / 2;
+    if (!own_engine_wanted(h)) return TRAMP_OK;
     Fft2Shape shp;
     // 1024 <= h <= 4096: the whole transform is one block pass (one launch, message update fused into it); above: two passes
     const bool blk = h >= 1024 && fft2_block_shape(h, &shp);
@@ -688,8 +700,7 @@ __global__ __launch_bounds__(kBlock) void spectral_perm_nd_kernel(
 // squared modulus [nh] on the host.  conv_1d: the one-dimensional convolution channel keeps its two-pass plan with
 // the fused epilogue when that one applies.
 int conv_setup_fftn(tramp_ctx* ctx, tramp_conv* cv, int D, const double2* w64, const std::vector<double>& s2h) {
-    const char* eng = getenv("TRAMP_CONV_FFT");
-    if (eng && strcmp(eng, "rocfft") == 0) return TRAMP_OK;
+    if (!own_engine_wanted(cv->n / 2)) return TRAMP_OK;
     if (cv->fft2 || !fftnd_supported(cv->dtype, cv->ndim, cv->dims)) return TRAMP_OK;
     if (cv->n / 2 > 0x7fffffffull) return TRAMP_OK;          // partner table is int
     int rc = fftnd_plan_create(ctx, cv->dtype, cv->ndim, cv->dims, &cv->fftn);
@@ -1970,9 +1981,8 @@ extern "C" int tramp_conv_create_complex(tramp_ctx* ctx, int dtype, int ndim, co
         return tramp_fail(ctx, TRAMP_EHIP, "tramp_conv_create_complex", hipGetErrorString(e));
     }
     // own engine: the tables go into the transform's permuted order (the spectral kernel is elementwise)
-    const char* eng = getenv("TRAMP_CONV_FFT");
     std::vector<double2> wt(wh);
-    if (!(eng && strcmp(eng, "rocfft") == 0) && fftnd_supported(dtype, ndim, cv->dims, false)) {
+    if (own_engine_wanted(n) && fftnd_supported(dtype, ndim, cv->dims, false)) {
         rc = fftnd_plan_create(ctx, dtype, ndim, cv->dims, &cv->fftn, false);
         if (rc) {
             cleanup(true);
