@@ -460,3 +460,28 @@ def test_fftn_full_size_properties(ctx, shape, dtype):
     assert abs(peak - n // 2) < (1e-9 if dtype == np.float64 else 1e-3) * (n // 2)
     spec[pos] = 0
     assert np.abs(spec).max() < (1e-9 if dtype == np.float64 else 2e-3) * (n // 2)
+
+
+@pytest.mark.parametrize("kind", ["conv", "grad"])
+def test_nd_channels_extreme_precisions(ctx, kind, monkeypatch):
+    "The N-D spectral solve at precisions spanning sixteen decades (the clip range of base.py:238-255), against the oracle"
+    import tramp_amd as T
+    from oracle import tramp_oracle as orc
+    monkeypatch.setenv("TRAMP_CONV_FFT", "own")
+    shape = (16, 32)
+    rs = np.random.RandomState(8)
+    if kind == "conv":
+        f = np.zeros(shape)
+        f[:3, :3] = rs.standard_normal((3, 3))
+        ch, o, xs = T.ConvChannel(f, ctx=ctx), orc.ConvOracle(f), shape
+    else:
+        ch, o, xs = T.GradientChannel(shape, ctx=ctx), orc.GradientOracle(shape), (2,) + shape
+    bz, bx = rs.standard_normal(shape), rs.standard_normal(xs)
+    for az, ax in [(1e-8, 1.0), (1.0, 1e-8), (1e8, 1.0), (1.0, 1e8), (1e-6, 1e6), (1e6, 1e-6), (1e-11, 1e-3)]:
+        rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+        rx, vx = ch.compute_forward_posterior(az, bz, ax, bx)
+        wz, wx = o.backward_mean(az, bz, ax, bx), o.forward_mean(az, bz, ax, bx)
+        np.testing.assert_allclose(rz, wz, rtol=0, atol=1e-9 * np.abs(wz).max(), err_msg=f"rz az={az} ax={ax}")
+        np.testing.assert_allclose(rx, wx, rtol=0, atol=1e-9 * max(np.abs(wx).max(), 1e-300), err_msg=f"rx az={az} ax={ax}")
+        np.testing.assert_allclose(vz, o.backward_variance(az, ax), rtol=1e-6, atol=1e-12 / az)
+        np.testing.assert_allclose(vx, o.forward_variance(az, ax), rtol=1e-6, atol=1e-12 / max(ax, 1e-300))
