@@ -584,6 +584,10 @@ int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
  *      (tramp/algos/message_passing.py:119-127): x = d*old + (1-d)*x. */
 int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
                const double* a_old_d, const void* b_old_d, double* a_d, void* b_d);
+/* three operands: (a, b) = d * (a_old, b_old) + (1 - d) * (a_src, b_src); the output may alias either input (what a
+ * scheduler that alternates two sets of message buffers needs for a damped constant message) */
+int tramp_damp_to(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping, const double* a_old_d,
+                  const void* b_old_d, const double* a_src_d, const void* b_src_d, double* a_d, void* b_d);
 /* BinaryPrior p(x) = p+ delta(x - 1) + p- delta(x + 1) (tramp/priors/binary_prior.py:8-62, beliefs/binary.py):
  * r = tanh(bx + b0), v = mean(1 - r^2), b0 = 0.5 log(p+ / p-); outputs optional as in tramp_gb_prior_fwd. */
 int tramp_binary_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "tramp_matvec_last_launch": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_damp": [vp, i32, sz, sz, dbl, vp, vp, vp, vp],
+    "tramp_damp_to": [vp, i32, sz, sz, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_binary_prior_fwd": [vp, i32, sz, sz, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_l21_prior_fwd": [vp, i32, i32, sz, sz, dbl, vp, vp, dbl, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_gauss_channel": [vp, i32, sz, sz, dbl, vp, vp, dbl, vp, vp, vp, vp],

@@ -483,9 +483,18 @@ class ExpectationPropagation:
         d = self.damping
         out_a = self.a_fwd[i_out] if direction == "fwd" else self.a_bwd[i_out]
         out_b = self.b_fwd[i_out] if direction == "fwd" else self.b_bwd[i_out]
+        # Alternating message buffers (restore_messages on the chain scheduler, _take_snapshot): the set written in
+        # the previous iteration IS the snapshot.  This iteration's messages go into the other set; the previous value
+        # of a message (for damping) and the backward messages the forward sweep reads - not rewritten yet in this
+        # iteration - come from the previous set.
+        pp = self._pp_active()
+        prev = self._snap if pp else None
+        old_a = (prev["a_fwd"] if direction == "fwd" else prev["a_bwd"])[i_out] if pp else out_a
+        old_b = (prev["fwd"] if direction == "fwd" else prev["bwd"])[i_out] if pp else out_b
+        a_bwd, b_bwd = (prev["a_bwd"], prev["bwd"]) if (pp and direction == "fwd") else (self.a_bwd, self.b_bwd)
         const = isinstance(factor, (GaussianPrior, GaussianLikelihood))
-        if const and not d and (factor, direction) in self._const_done:
-            return          # undamped constant message: already in place, bit-identical every iteration
+        if const and not d and (factor, direction, out_b.ptr) in self._const_done:
+            return          # undamped constant message: already in place (in this buffer), bit-identical every iteration
         if const and d:
             # Constant factor under damping: msg <- d msg + (1 - d) c with the same (c_a, c_b) every
             # iteration (K12).  c is computed once; the update is ONE in-place kernel - tramp_damp with
@@ -495,14 +504,18 @@ class ExpectationPropagation:
                 ca = self.ctx.empty((self.batch,), np.float64)
                 cb = self.ctx.empty(tuple(out_b.shape), self.dtype)
                 if factor.n_prev == 0:
-                    factor.compute_forward_message(self.a_bwd[i_out], self.b_bwd[i_out], out_a=ca, out_b=cb)
+                    factor.compute_forward_message(a_bwd[i_out], b_bwd[i_out], out_a=ca, out_b=cb)
                 else:
                     factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out], out_a=ca, out_b=cb)
                 self._const_msg[key] = (ca, cb)
             ca, cb = self._const_msg[key]
-            old_key = (out_b.ptr, out_b.version, self.batch)
-            self.ctx._call("tramp_damp", dtype_code(self.dtype), out_b.shape[1], self.batch, 1.0 - float(d),
-                           ca.ptr, cb.ptr, out_a.ptr, out_b.ptr)
+            old_key = (old_b.ptr, old_b.version, self.batch)
+            if pp:          # (1 - d) c + d previous message, written into this iteration's buffer: the same products and sum
+                self.ctx._call("tramp_damp_to", dtype_code(self.dtype), out_b.shape[1], self.batch, 1.0 - float(d),
+                               ca.ptr, cb.ptr, old_a.ptr, old_b.ptr, out_a.ptr, out_b.ptr)
+            else:
+                self.ctx._call("tramp_damp", dtype_code(self.dtype), out_b.shape[1], self.batch, 1.0 - float(d),
+                               ca.ptr, cb.ptr, out_a.ptr, out_b.ptr)
             out_b.version += 1
             # the consumer's cached projection of this message follows by linearity (O(k), no matrix pass)
             var = self.variables[i_out]
@@ -513,7 +526,7 @@ class ExpectationPropagation:
             return
         kw = dict(out_a=out_a, out_b=out_b)
         if d:
-            kw.update(damping=d, old_a=out_a, old_b=out_b)
+            kw.update(damping=d, old_a=old_a, old_b=old_b)
         if direction == "bwd":
             # producer-fused moments (csrc/prior_hint.h): when the consumer of this message is a separable
             # prior, the kernel that writes the message also leaves sum v_i, and the prior reads it once
@@ -527,18 +540,17 @@ class ExpectationPropagation:
             if hint is not None:
                 self.ctx._call("tramp_lik_hint", hint[0], out_b.shape[1], self.batch, out_b.ptr, out_a.ptr, hint[1])
         if factor.n_prev == 0:
-            factor.compute_forward_message(self.a_bwd[i_out], self.b_bwd[i_out], **kw)
+            factor.compute_forward_message(a_bwd[i_out], b_bwd[i_out], **kw)
         elif factor.n_next == 0:
             factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out], **kw)
         elif direction == "fwd":
-            factor.compute_forward_message(self.a_fwd[i_in], self.b_fwd[i_in],
-                                           self.a_bwd[i_out], self.b_bwd[i_out], **kw)
+            factor.compute_forward_message(self.a_fwd[i_in], self.b_fwd[i_in], a_bwd[i_out], b_bwd[i_out], **kw)
         else:
             factor.compute_backward_message(self.a_fwd[i_out], self.b_fwd[i_out],
                                             self.a_bwd[i_in], self.b_bwd[i_in], **kw)
         out_b.version += 1          # consumers (LinearChannel projection cache) see a new message
         if const and not d:
-            self._const_done.add((factor, direction))
+            self._const_done.add((factor, direction, out_b.ptr))
 
     def _moment_hint(self, i):
         "the prior that consumes the backward message into variable i, if it can use fused moments"
@@ -738,14 +750,49 @@ class ExpectationPropagation:
         return ([(b, s["fwd"][i], s["frozen_fwd"][i]) for i, b in enumerate(self.b_fwd)]
                 + [(b, s["bwd"][i], s["frozen_bwd"][i]) for i, b in enumerate(self.b_bwd)])
 
+    # The chain scheduler does not copy: it alternates two sets of message buffers (b vectors and the precision table),
+    # so the set written in the previous iteration is the snapshot (`_snap["fwd"], ["bwd"], ["A"]` ARE that set).
+    # tools/bench_restore_overhead.py: the four copies cost +16 % per iteration at 10^6 x 64.  Schedulers that keep
+    # separate variable -> factor buffers (tree.py) copy instead (_pingpong = False).
+    _pingpong = True
+
+    def _pp_active(self):
+        return bool(self._restore and self._pingpong and getattr(self, "_snap", None) is not None)
+
     def _allocate_snapshot(self):
-        ctx = self.ctx
-        mk = lambda bufs: [ctx.zeros(tuple(b.shape), self.dtype) for b in bufs]          # noqa: E731
-        self._snap = dict(fwd=mk(self.b_fwd), bwd=mk(self.b_bwd), frozen_fwd=mk(self.b_fwd), frozen_bwd=mk(self.b_bwd),
-                          A=ctx.zeros(tuple(self.A.shape), np.float64))
+        ctx, L = self.ctx, len(self.variables)
+
+        def mk(bufs):
+            out = [ctx.zeros(tuple(b.shape), self.dtype) for b in bufs]
+            for b in out:
+                b.version = 0
+            return out
+        A2 = ctx.zeros(tuple(self.A.shape), np.float64)
+        self._snap = dict(fwd=mk(self.b_fwd), bwd=mk(self.b_bwd), frozen_fwd=mk(self.b_fwd), frozen_bwd=mk(self.b_bwd), A=A2,
+                          a_fwd=[A2.row(2 * i) for i in range(L)], a_bwd=[A2.row(2 * i + 1) for i in range(L)])
+
+    def _sync_snapshot(self):
+        "both sets hold the current messages (start of a run: the first forward sweep reads the previous set's backward ones)"
+        s = self._snap
+        for live, prev, _ in self._message_triples():
+            prev.copy_from(live)
+            prev.version = getattr(prev, "version", 0) + 1
+        s["A"].copy_from(self.A)
+
+    def _swap_sets(self):
+        s = self._snap
+        self.b_fwd, s["fwd"] = s["fwd"], self.b_fwd
+        self.b_bwd, s["bwd"] = s["bwd"], self.b_bwd
+        self.A, s["A"] = s["A"], self.A
+        self.a_fwd, s["a_fwd"] = s["a_fwd"], self.a_fwd
+        self.a_bwd, s["a_bwd"] = s["a_bwd"], self.a_bwd
 
     def _take_snapshot(self):
-        "the message dag as it stands before an iteration (the reference deep-copies it every iteration)"
+        """the message dag as it stands before an iteration (the reference deep-copies it every iteration): here the set
+        of buffers just written becomes the snapshot and the other set receives this iteration's messages"""
+        if self._pingpong:
+            self._swap_sets()
+            return
         s = self._snap
         for live, prev, _ in self._message_triples():
             prev.copy_from(live)
@@ -1070,6 +1117,8 @@ class ExpectationPropagation:
         graphs = {}
         basis = self._Basis(self)
         basis.__enter__()
+        if self._pp_active():
+            self._sync_snapshot()
         try:
             i = 0
             while i < max_iter:
@@ -1080,6 +1129,8 @@ class ExpectationPropagation:
                         graphs[par] = self._capture_iterations(mon, 1)     # (the Python-side swaps happen here)
                         self.ctx._call("tramp_graph_launch", graphs[par])
                     else:
+                        if self._pp_active():
+                            self._swap_sets()            # what _take_snapshot did when this iteration was captured
                         self.ctx._call("tramp_graph_launch", graphs[par])
                         if mon is not None:
                             self._swap_r()

@@ -1642,19 +1642,21 @@ extern "C" int tramp_l21_prior_fwd(tramp_ctx* ctx, int dtype, int d, size_t n, s
 // ---------------------------------------------------------------- K12 damping, distances
 template <typename T>
 __global__ __launch_bounds__(kBlock) void damp_kernel(size_t n, double d, const double* __restrict__ a_old,
-                                                      const T* __restrict__ b_old, double* __restrict__ a,
-                                                      T* __restrict__ bb) {
+                                                      const T* __restrict__ b_old, double* a, T* bb,
+                                                      const double* a_src = nullptr, const T* b_src = nullptr) {
     const size_t b = blockIdx.y;
     const T dT = T(d), omd = T(1.0 - d);
+    const T* src = b_src ? b_src : bb;                 // three-operand form (tramp_damp_to): the second term comes from src
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
-        bb[b * n + i] = dT * b_old[b * n + i] + omd * bb[b * n + i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a[b] = d * a_old[b] + (1.0 - d) * a[b];
+        bb[b * n + i] = dT * b_old[b * n + i] + omd * src[b * n + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a[b] = d * a_old[b] + (1.0 - d) * (a_src ? a_src[b] : a[b]);
 }
 
 // streaming-tile form (n a multiple of the 16-byte vector)
 template <typename T, int U>
 __global__ __launch_bounds__(kBlock) void damp_tile(size_t n, int tpb, double d, const double* __restrict__ a_old,
-                                                    const T* __restrict__ b_old, double* __restrict__ a, T* __restrict__ bb) {
+                                                    const T* __restrict__ b_old, double* a, T* bb,
+                                                    const double* a_src = nullptr, const T* b_src = nullptr) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     const size_t b = blockIdx.y;
@@ -1662,6 +1664,7 @@ __global__ __launch_bounds__(kBlock) void damp_tile(size_t n, int tpb, double d,
     const size_t nv = n / VN;
     const V* po = reinterpret_cast<const V*>(b_old + b * n);
     V* pb = reinterpret_cast<V*>(bb + b * n);
+    const V* ps = reinterpret_cast<const V*>((b_src ? b_src : bb) + b * n);
     for (int tile = 0; tile < tpb; ++tile) {
         const size_t base = ((size_t)blockIdx.x * tpb + tile) * kBlock * U + threadIdx.x;
         if (base - threadIdx.x >= nv) break;
@@ -1671,7 +1674,7 @@ __global__ __launch_bounds__(kBlock) void damp_tile(size_t n, int tpb, double d,
             const size_t i = base + (size_t)u * kBlock;
             if (i < nv) {
                 xo[u] = po[i];
-                xb[u] = pb[i];
+                xb[u] = ps[i];
             }
         }
 #pragma unroll
@@ -1685,8 +1688,11 @@ __global__ __launch_bounds__(kBlock) void damp_tile(size_t n, int tpb, double d,
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) a[b] = d * a_old[b] + (1.0 - d) * a[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a[b] = d * a_old[b] + (1.0 - d) * (a_src ? a_src[b] : a[b]);
 }
+
+static int damp_launch(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping, const double* a_old_d,
+                       const void* b_old_d, const double* a_src_d, const void* b_src_d, double* a_d, void* b_d);
 
 extern "C" int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping,
                           const double* a_old_d, const void* b_old_d, double* a_d, void* b_d) {
@@ -1694,6 +1700,21 @@ extern "C" int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, dou
     TRAMP_REQUIRE(ctx, a_old_d && b_old_d && a_d && b_d);
     TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
     if (!n || !batch || damping == 0.0) return TRAMP_OK;
+    return damp_launch(ctx, dtype, n, batch, damping, a_old_d, b_old_d, nullptr, nullptr, a_d, b_d);
+}
+
+// three operands: (a, b) = d (a_old, b_old) + (1 - d) (a_src, b_src); the output may alias either input
+extern "C" int tramp_damp_to(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping, const double* a_old_d,
+                             const void* b_old_d, const double* a_src_d, const void* b_src_d, double* a_d, void* b_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, a_old_d && b_old_d && a_src_d && b_src_d && a_d && b_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    if (!n || !batch) return TRAMP_OK;
+    return damp_launch(ctx, dtype, n, batch, damping, a_old_d, b_old_d, a_src_d, b_src_d, a_d, b_d);
+}
+
+static int damp_launch(tramp_ctx* ctx, int dtype, size_t n, size_t batch, double damping, const double* a_old_d,
+                       const void* b_old_d, const double* a_src_d, const void* b_src_d, double* a_d, void* b_d) {
     const size_t vn = dtype == TRAMP_F64 ? 2 : 4;
     if ((n % vn) == 0) {
         constexpr int U = kTileU;
@@ -1702,20 +1723,20 @@ extern "C" int tramp_damp(tramp_ctx* ctx, int dtype, size_t n, size_t batch, dou
         dim3 g((unsigned)((tiles + tpb - 1) / tpb), (unsigned)batch);
         if (dtype == TRAMP_F64)
             hipLaunchKernelGGL((damp_tile<double, U>), g, dim3(kBlock), 0, ctx->stream, n, tpb, damping, a_old_d,
-                               (const double*)b_old_d, a_d, (double*)b_d);
+                               (const double*)b_old_d, a_d, (double*)b_d, a_src_d, (const double*)b_src_d);
         else
             hipLaunchKernelGGL((damp_tile<float, U>), g, dim3(kBlock), 0, ctx->stream, n, tpb, damping, a_old_d,
-                               (const float*)b_old_d, a_d, (float*)b_d);
+                               (const float*)b_old_d, a_d, (float*)b_d, a_src_d, (const float*)b_src_d);
         TRAMP_LAUNCH_CHECK(ctx);
         return TRAMP_OK;
     }
     dim3 grid(blocks_for(n, 1), (unsigned)batch);
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((damp_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, damping, a_old_d,
-                           (const double*)b_old_d, a_d, (double*)b_d);
+                           (const double*)b_old_d, a_d, (double*)b_d, a_src_d, (const double*)b_src_d);
     else
         hipLaunchKernelGGL((damp_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, damping, a_old_d,
-                           (const float*)b_old_d, a_d, (float*)b_d);
+                           (const float*)b_old_d, a_d, (float*)b_d, a_src_d, (const float*)b_src_d);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }

@@ -38,6 +38,7 @@ class TreeExpectationPropagation(ExpectationPropagation):
     # host-side evaluation on the scalar tables
     import os as _os
     _device_monitor = _os.environ.get("TRAMP_TREE_MONITOR", "device") != "host"
+    _pingpong = False          # separate variable -> factor buffers: the per-iteration snapshot is a copy here
 
     """Gaussian EP on a tree of factors and variables (tramp/algos/expectation_propagation.py:5-32)."""
 
