@@ -38,7 +38,10 @@ class TreeExpectationPropagation(ExpectationPropagation):
     # host-side evaluation on the scalar tables
     import os as _os
     _device_monitor = _os.environ.get("TRAMP_TREE_MONITOR", "device") != "host"
-    _pingpong = False          # separate variable -> factor buffers: the per-iteration snapshot is a copy here
+    # restore_messages: as on the chain the snapshot is not a copy - two sets of message objects alternate (self.msg is the
+    # set this iteration writes, self._msg_prev the one the previous iteration wrote).  A message not yet rewritten in
+    # this iteration is read from the previous set (_latest), its value before the update (for damping) too (_old).
+    _pingpong = True
 
     """Gaussian EP on a tree of factors and variables (tramp/algos/expectation_propagation.py:5-32)."""
 
@@ -162,6 +165,56 @@ class TreeExpectationPropagation(ExpectationPropagation):
             r.fill(0.0)
         self._const_done = set()
 
+    # -- alternating message sets
+    def _latest(self, key):
+        m = self.msg[key]
+        if not self._pp_active() or id(m) in self._written:
+            return m
+        return self._msg_prev[key]
+
+    def _old(self, key):
+        return self._msg_prev[key] if self._pp_active() else self.msg[key]
+
+    def _mark(self, m):
+        m.b.version += 1
+        if self._pp_active():
+            self._written.add(id(m))
+
+    def _allocate_snapshot(self):
+        ctx, B = self.ctx, self.batch
+        A2 = ctx.zeros(tuple(self.A.shape), np.float64)
+        prev = {}
+        for i, k in enumerate(self.msg_keys):
+            if k in self._aliased:
+                continue
+            b = ctx.zeros(tuple(self.msg[k].b.shape), self.dtype)
+            b.version = 0
+            prev[k] = _Msg(A2.row(i), b)
+        for v in self.variables:                               # the same aliases as in the live set
+            f = self.adj[v]
+            if len(f) == 2 and (v, f[0]) in self._aliased:
+                prev[(v, f[0])] = prev[(f[1], v)]
+                prev[(v, f[1])] = prev[(f[0], v)]
+        self._msg_prev = {k: prev[k] for k in self.msg_keys}
+        self._written = set()
+        self._snap = dict(frozen={k: ctx.zeros(tuple(m.b.shape), self.dtype) for k, m in self.msg.items()}, A=A2)
+
+    def _message_triples(self):
+        s = self._snap
+        return [(m.b, self._msg_prev[k].b, s["frozen"][k]) for k, m in self.msg.items()]
+
+    def _sync_snapshot(self):
+        for live, prev, _ in self._message_triples():
+            prev.copy_from(live)
+            prev.version += 1
+        self._snap["A"].copy_from(self.A)
+        self._written = set()
+
+    def _swap_sets(self):
+        self.msg, self._msg_prev = self._msg_prev, self.msg
+        self.A, self._snap["A"] = self._snap["A"], self.A
+        self._written = set()
+
     # -- node updates
     def _factor_send(self, f, direction):
         g = self.model.dag
@@ -173,10 +226,13 @@ class TreeExpectationPropagation(ExpectationPropagation):
         if target is None:
             return
         out = self.msg[(f, target)]
+        old = self._old((f, target))
         d = self.damping
         const = isinstance(f, (GaussianPrior, GaussianLikelihood))
-        inp = self.msg[(target, f)]
-        if const and not d and (f, direction) in self._const_done:
+        inp = self._latest((target, f))
+        if const and not d and (f, direction, out.b.ptr) in self._const_done:
+            if self._pp_active():
+                self._written.add(id(out))                     # already in this buffer
             return
         if const and d:
             # constant message under damping: computed once, then msg <- d msg + (1 - d) c (as on the chain)
@@ -189,52 +245,56 @@ class TreeExpectationPropagation(ExpectationPropagation):
                     f.compute_backward_message(inp.a, inp.b, out_a=ca, out_b=cb)
                 self._const_msg[(f, direction)] = (ca, cb)
             ca, cb = self._const_msg[(f, direction)]
-            self.ctx._call("tramp_damp", dtype_code(self.dtype), out.b.shape[1], self.batch, 1.0 - float(d),
-                           ca.ptr, cb.ptr, out.a.ptr, out.b.ptr)
-            out.b.version += 1
+            if old is not out:
+                self.ctx._call("tramp_damp_to", dtype_code(self.dtype), out.b.shape[1], self.batch, 1.0 - float(d),
+                               ca.ptr, cb.ptr, old.a.ptr, old.b.ptr, out.a.ptr, out.b.ptr)
+            else:
+                self.ctx._call("tramp_damp", dtype_code(self.dtype), out.b.shape[1], self.batch, 1.0 - float(d),
+                               ca.ptr, cb.ptr, out.a.ptr, out.b.ptr)
+            self._mark(out)
             return
         kw = dict(out_a=out.a, out_b=out.b)
         if d:
-            kw.update(damping=d, old_a=out.a, old_b=out.b)
+            kw.update(damping=d, old_a=old.a, old_b=old.b)
         if f.n_prev == 0:
             f.compute_forward_message(inp.a, inp.b, **kw)
         elif f.n_next == 0:
             f.compute_backward_message(inp.a, inp.b, **kw)
         else:
-            z, x = self.msg[(prev, f)], self.msg[(nxt, f)]
+            z, x = self._latest((prev, f)), self._latest((nxt, f))
             if direction == "fwd":
                 f.compute_forward_message(z.a, z.b, x.a, x.b, **kw)
             else:
                 f.compute_backward_message(z.a, z.b, x.a, x.b, **kw)
-        out.b.version += 1
+        self._mark(out)
         if const and not d:
-            self._const_done.add((f, direction))
+            self._const_done.add((f, direction, out.b.ptr))
 
     def _multi_input_send(self, f, direction):
         "K-input, one-output factor (SumChannel): forward to its output, backward one message per input"
         g = self.model.dag
         prevs = list(g.predecessors(f))
         nxt = next(iter(g.successors(f)))
-        zs = [self.msg[(p, f)] for p in prevs]
-        x = self.msg[(nxt, f)]
+        zs = [self._latest((p, f)) for p in prevs]
+        x = self._latest((nxt, f))
         az, bz = [m.a for m in zs], [m.b for m in zs]
         d = self.damping
         targets = [(nxt, None)] if direction == "fwd" else [(p, k) for k, p in enumerate(prevs)]
         for tgt, k in targets:
-            out = self.msg[(f, tgt)]
+            out, old = self.msg[(f, tgt)], self._old((f, tgt))
             kw = dict(out_a=out.a, out_b=out.b)
             if d:
-                kw.update(damping=d, old_a=out.a, old_b=out.b)
+                kw.update(damping=d, old_a=old.a, old_b=old.b)
             if k is None:
                 f.compute_forward_message(az, bz, x.a, x.b, **kw)
             else:
                 f.compute_backward_message(az, bz, x.a, x.b, target=k, **kw)
-            out.b.version += 1
+            self._mark(out)
 
     def _variable_send(self, v, targets):
         "Variable.forward_message / backward_message (tramp/base.py:186-211)"
         nbrs = self.adj[v]
-        inc = [self.msg[(f, v)] for f in nbrs]
+        inc = [self._latest((f, v)) for f in nbrs]
         for f in targets:
             if (v, f) in self._aliased:
                 continue                                       # the outgoing message is the other side's incoming buffer
@@ -249,7 +309,7 @@ class TreeExpectationPropagation(ExpectationPropagation):
                 bp = (C.c_void_p * k)(*[m.b.ptr for m in inc])
                 self.ctx._call("tramp_message_sum", dtype_code(self.dtype), out.b.shape[1], self.batch, k, ap, bp,
                                nbrs.index(f), out.a.ptr, out.b.ptr)
-            out.b.version += 1
+            self._mark(out)
 
     def forward_message(self):
         "message_passing.py:249-255"
@@ -292,16 +352,6 @@ class TreeExpectationPropagation(ExpectationPropagation):
     def _edge_name(self, e):
         src, dst = self.msg_keys[e]
         return f"message {getattr(src, 'id', src)} -> {getattr(dst, 'id', dst)}"
-
-    def _message_triples(self):
-        s = self._snap
-        return [(m.b, s["prev"][k], s["frozen"][k]) for k, m in self.msg.items()]
-
-    def _allocate_snapshot(self):
-        ctx = self.ctx
-        self._snap = dict(prev={k: ctx.zeros(tuple(m.b.shape), self.dtype) for k, m in self.msg.items()},
-                          frozen={k: ctx.zeros(tuple(m.b.shape), self.dtype) for k, m in self.msg.items()},
-                          A=ctx.zeros(tuple(self.A.shape), np.float64))
 
     def check_message(self):
         bad = np.isnan(self.A_host)
