@@ -193,3 +193,46 @@ def test_device_array_dropped_during_capture_does_not_invalidate_it(T, ctx):
     ctx.sync()
     ctx._call("tramp_graph_destroy", g)
     assert np.all(b.get() == 2.0)
+
+
+@pytest.mark.parametrize("damping", [None, 0.3])
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("kind", ["chain", "conv", "tree"])
+def test_alternating_message_buffers_change_no_bit(T, ctx, kind, graph, damping):
+    """restore_messages keeps the previous iteration's messages by alternating two sets of buffers (algos.py
+    _take_snapshot, tree.py _swap_sets) instead of copying: with and without it every message and posterior has the same
+    bits after an odd and an even number of iterations, eager and as a hipGraph replay, with and without damping
+    (Gaussian factors: the constant-message and projection-cache paths)."""
+    rs = np.random.RandomState(17)
+    if kind == "chain":
+        model, _, _, _ = _glm(T, ctx, 3)
+        ids = ["x", "z"]
+    elif kind == "conv":
+        n, B = 4096, 2
+        f = rs.standard_normal(n) / 64
+        Y = rs.standard_normal((B, n))
+        model = (T.GaussianPrior(size=n, ctx=ctx) @ T.SISOVariable(id="x") @ T.ConvChannel(f, ctx=ctx)
+                 @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=Y, var=0.05, ctx=ctx)).to_model()
+        ids = ["x", "z"]
+    else:
+        from tests.test_gpu_tree import build_tree
+        model = build_tree(T, ctx, dict(shape=(64,), noise_var=0.01, rho=0.1), y=rs.standard_normal((2, 64)))
+        ids = ["x", "z"]
+    for n_it in (6, 7):
+        out = {}
+        for restore in (False, True):
+            ep = T.ExpectationPropagation(model, ctx=ctx)
+            ep.iterate(max_iter=n_it, callback=T.EarlyStoppingEP(tol=1e-300), damping=damping, graph=graph,
+                       restore_messages=restore)
+            d = ep.get_variables_data()
+            rec = {("r", v): np.asarray(d[v]["r"]).copy() for v in ids}
+            rec.update({("v", v): np.asarray(d[v]["v"]).copy() for v in ids})
+            rec.update({("a",) + k: np.asarray(a).copy() for k, a in ep.get_edges_data().items()})
+            if kind != "tree":
+                for v in ids:
+                    for direction in ("fwd", "bwd"):
+                        rec[("b", v, direction)] = np.asarray(ep.get_message(v, direction)[1]).copy()
+            out[restore] = rec
+        assert out[False].keys() == out[True].keys()
+        for k in out[False]:
+            assert np.array_equal(out[False][k], out[True][k]), (kind, graph, damping, n_it, k)
