@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import tramp_amd as T
 ctx = T.default_context()
 N, M, rho, nv = 1000, 500, 0.05, 1e-2
-for restore in (False, True, None):
+for restore in ((None, True, False) if len(sys.argv) > 1 else (False, True, None)):
     for graph in (False, True):
         ts = []
         for seed in range(6):
