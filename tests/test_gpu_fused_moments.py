@@ -162,6 +162,32 @@ def test_conv_channel_inverse_fft_leaves_prior_moments(T, ctx):
         np.testing.assert_allclose(r[b], res["r"][0], rtol=1e-6, atol=1e-8 * np.abs(res["r"][0]).max())
 
 
+@pytest.mark.parametrize("shape", [(8192,), (128, 128), (16, 64, 32)], ids=lambda s: "x".join(map(str, s)))
+def test_block_pass_epilogue_leaves_prior_moments(T, ctx, shape):
+    """The one-block-pass inverse (short 1-D signals) and the last pass of the N-D plans are producers as well: the
+    Gauss-Bernoulli prior behind a 1-D / 2-D / 3-D convolution channel runs single-pass, same EP as the oracle.
+    (Up to 4096 components the prior is one workgroup that ignores the hint: the 1-D case is just above.)"""
+    rs = np.random.RandomState(9)
+    n, B, rho, nv = int(np.prod(shape)), 3, 0.1, 1e-3
+    f = rs.standard_normal(shape) / np.sqrt(n)
+    ch = T.ConvChannel(f, ctx=ctx)
+    X = rs.standard_normal((B, n)) * rs.binomial(1, rho, (B, n))
+    Y = ch.convolve(ctx.array(X)).get() + np.sqrt(nv) * rs.standard_normal((B, n))
+    model = (T.GaussBernoulliPrior(size=shape, rho=rho, ctx=ctx) @ T.SISOVariable(id="x") @ ch
+             @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    armed0, used0 = ctx.prior_hint_stats()
+    ep.iterate(max_iter=8, callback=T.PassCallback(), damping=0.1)
+    armed1, used1 = ctx.prior_hint_stats()
+    assert armed1 - armed0 == 8 and used1 - used0 == 7
+    r = np.asarray(ep.get_variables_data()["x"]["r"]).reshape(B, n)
+    fac = orc.ConvFactor(f)
+    for b in range(B):
+        res = orc.ep_chain([orc.GBPriorFactor(shape, rho=rho), fac, orc.GaussLikFactor(Y[b].reshape(shape), nv)],
+                           [shape, shape], max_iter=8, damping=0.1, tol=0.0, max_increase=np.inf)
+        np.testing.assert_allclose(r[b], res["r"][0].reshape(n), rtol=1e-6, atol=1e-8 * np.abs(res["r"][0]).max())
+
+
 # ---- the likelihood twin (tramp_lik_hint): the channel's FORWARD update leaves sum v_i of the sign / abs likelihood
 # that consumes its message (sgn_likelihood.py:32-37, abs_likelihood.py:31-36), the likelihood update is one pass
 def _liks(T, rs, batch, m, dtype, ctx):

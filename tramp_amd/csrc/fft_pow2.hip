@@ -304,6 +304,11 @@ __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typ
         C* bo = reinterpret_cast<C*>(epi.out) + first;
         C* ro = epi.r_out ? reinterpret_cast<C*>(epi.r_out) + first : nullptr;
         const size_t pts_per_inst = (epi.rows_per_inst ? epi.rows_per_inst : 1) * sh.LB;
+        // producer-fused moments (prior_hint.h): armed only when a tile lies inside ONE instance (fft2_run_t checks)
+        double vi = 0.0;
+        PriorHintEval<T> he;
+        const size_t inst0 = first / pts_per_inst;
+        if (epi.hint.kind) he.setup(epi.hint, inst0);
         for (int i = threadIdx.x; i < npts; i += nthr) {
             const size_t inst = (first + i) / pts_per_inst;
             const T asum = (T)(epi.a_in[inst] + epi.a_raw[inst]);
@@ -316,6 +321,22 @@ __global__ __launch_bounds__(1024) void fft_block_kernel(Fft2Shape sh, const typ
             }
             bo[i] = bn;
             if (ro) ro[i] = r;
+            if (epi.hint.kind) {
+                const size_t idx = 2 * (first + i - inst0 * pts_per_inst);
+                vi += he.v(bn.x, idx) + he.v(bn.y, idx + 1);
+            }
+        }
+        if (epi.hint.kind) {
+            __syncthreads();
+            double* red = reinterpret_cast<double*>(smem_raw);
+            vi = wave_sum(vi);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vi;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+                for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t += red[w];
+                epi.hint.partials[inst0 * (size_t)epi.hint.nblk + (first - inst0 * pts_per_inst) / tile_pts] = t;
+            }
         }
         return;
     }
@@ -714,6 +735,13 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
         if (inverse && epi && epi->out) {
             Fft2Epi e2 = *epi;
             e2.hint.kind = PRIOR_HINT_NONE;
+            // producer-fused moments for the consumer of this message, as the two-pass epilogue below: one partial per tile,
+            // tiles inside one instance (an instance = rows_per_inst rows of LB points)
+            const size_t ppi = (e2.rows_per_inst ? e2.rows_per_inst : 1) * sh.LB;
+            const int hk = ctx->hint.kind;
+            if (ppi % (size_t)tile_pts == 0 &&
+                (hk == PRIOR_HINT_GB || hk == PRIOR_HINT_L1 || (hk == PRIOR_HINT_SGN_LIK && sizeof(T) == 8)))
+                prior_hint_arm(ctx, e2.out, 2 * ppi, total_pts / ppi, (int)(ppi / (size_t)tile_pts), &e2.hint);
             hipLaunchKernelGGL((fft_block_kernel<T, true, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh,
                                (const C*)in, (C*)out, (const C*)pl->tw_blk, tile_pts, total_pts, e2);
         } else if (inverse)
