@@ -1065,7 +1065,7 @@ class ExpectationPropagation:
         moment the loop notices that all are done.  ``graph=True`` captures the steady-state launch sequence
         in a hipGraph and replays it (launch-bound small problems); results are identical to the eager loop.
         ``restore_messages`` (default: on whenever the device runs a stopping rule): the reference's "restoring
-        old message dag" per instance - the messages are snapshot before every iteration (one device copy of each),
+        old message dag" per instance - the messages are snapshot before every iteration (two alternating sets of buffers, no copies),
         an instance that gives up after an increase gets the previous iteration's messages back, a converged one
         keeps those of its stopping iteration, and a NaN puts every instance back one iteration before ValueError
         is raised (message_passing.py:187-209, callbacks.py:233-240,277-283); a warm start then continues each
