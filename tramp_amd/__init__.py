@@ -14,7 +14,7 @@ from .priors import GaussBernoulliPrior, MAP_L1NormPrior, MAP_L21NormPrior, Bina
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
                           SymmetricDoorLikelihood, get_likelihood)
-from .channels import (LinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
+from .channels import (LinearChannel, SolveLinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
                        SymmetricDoorChannel, ConvChannel, Blur1DChannel, Blur2DChannel,
                        DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel, ReshapeChannel, BiasChannel, SumChannel,
