@@ -280,6 +280,12 @@ int tramp_lik_hint(tramp_ctx* ctx, int kind, size_t n, size_t batch, const void*
                    const void* y_d);
 /* how many producers left moments / how many prior updates consumed them, since the context was made */
 int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed, unsigned long long* used);
+/* Resident single-pass updates (csrc/ew_resident.h): large batches of large instances of the separable factors
+ * (tramp_gb_prior_fwd, tramp_l1_prior_fwd, ...) are streamed ONCE through a grid of resident workgroups whose
+ * registers hold the window that waits for its instance mean (tramp/base.py:245-255), instead of twice through the
+ * tile kernels.  Same entry points, same results to reduction-order rounding, run-to-run reproducible; chosen by shape
+ * (TRAMP_EW_RESIDENT=0 turns it off).  How many updates took that form since the context was made: */
+int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs);
 
 /* ---- dense linear channel x = W z --------------------------------------- */
 /* LinearChannel.__init__ (tramp/channels/linear/linear_channel.py:30-46): the

@@ -1,0 +1,156 @@
+"""GPU parity of the resident single-pass factor updates (tramp_amd/csrc/ew_resident.h) through the C ABI.
+
+Large batches of large instances take a pipeline of resident workgroups that hands tile sums to combiner workgroups
+through self-validating 8-byte granules.  What can go wrong there that the tile kernels cannot get wrong: a granule of
+a PREVIOUS launch read as fresh (the same shapes twice with different data), the overlapping last tile of an instance
+(ragged tile counts; outputs aliasing inputs), per-instance scalars crossing instances (different precisions, one NaN
+instance), the support count's second slot array, damping against the buffer being overwritten.  Every case also
+asserts that the resident form actually ran (ctx.resident_runs()).
+
+Reference: tramp/base.py:245-255 (compute_ab_new), priors/gauss_bernoulli_prior.py:70-77,
+priors/map_L1_norm_prior.py:66-71, restated in oracle/tramp_oracle.py.
+fp64: 1e-9 relative, fp32: 1e-3; counts exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+from tests.test_gpu_factors import close, close_a
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tramp_amd
+    return tramp_amd
+
+
+def num_cu(ctx):
+    "compute units of the device: parsed from tramp_device_name's '... (gfx950, 256 CUs)'"
+    return int(ctx.device_name().rsplit(",", 1)[1].split()[0])
+
+
+def shape_for(ctx, dtype, ragged=True):
+    """(batch, n): enough 16 KiB tiles for the pipeline's minimum (4 rounds of 2 x CUs - 8 tiles), instances that
+    are not a whole number of tiles (the last tile overlaps its predecessor) unless ragged=False."""
+    comps = 2048 if dtype == np.float64 else 4096          # components per tile
+    tiles = 7
+    n = tiles * comps - (comps // 2 + 2 * (16 // np.dtype(dtype).itemsize) if ragged else 0)
+    need = 4 * (2 * num_cu(ctx) - 8) + 16
+    return (need + tiles - 1) // tiles, n
+
+
+def gb_reference(ax, bx, rho):
+    out_a, out_b = [], []
+    for a, b in zip(ax, bx):
+        an, bn = orc.gb_prior_message(a, b.astype(np.float64), rho=rho)
+        out_a.append(an); out_b.append(bn)
+    return np.array(out_a), np.stack(out_b)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ragged", [True, False])
+def test_gb_prior_resident_vs_oracle_and_no_stale_granules(T, ctx, dtype, ragged):
+    B, n = shape_for(ctx, dtype, ragged)
+    rs = np.random.RandomState(11)
+    p = T.GaussBernoulliPrior(size=n, rho=0.07, dtype=dtype, ctx=ctx)
+    a_dev = ctx.empty((B,), np.float64); b_dev = ctx.empty((B, n), dtype)
+    prev = None
+    for trial in range(3):          # same shapes, same workspace, DIFFERENT data: a granule left by the previous launch would show
+        ax = rs.uniform(0.3, 3.0, B)
+        bx = (rs.standard_normal((B, n)) * rs.uniform(0.5, 3.0, (B, 1))).astype(dtype)
+        runs0 = ctx.resident_runs()
+        p.compute_forward_message(ctx.scalars(ax), ctx.array(bx, dtype), out_a=a_dev, out_b=b_dev)
+        assert ctx.resident_runs() == runs0 + 1, "the resident single-pass form did not run"
+        a_ref, b_ref = gb_reference(ax, bx, 0.07)
+        a_new, b_new = a_dev.get(), b_dev.get()
+        for i in range(B):
+            close_a(a_new[i], a_ref[i], ax[i], dtype)
+            close(b_new[i], b_ref[i], dtype, scale=10 * np.abs(b_ref[i]).max())
+        if prev is not None:
+            assert not np.array_equal(prev, a_new)
+        prev = a_new.copy()
+    # run-to-run reproducible: fixed-order fold of the tile sums, no float atomics
+    a1 = a_dev.get().copy(); b1 = b_dev.get().copy()
+    p.compute_forward_message(ctx.scalars(ax), ctx.array(bx, dtype), out_a=a_dev, out_b=b_dev)
+    assert np.array_equal(a1, a_dev.get()) and np.array_equal(b1, b_dev.get())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_l1_prior_resident_count_and_message(T, ctx, dtype):
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(5)
+    gamma = 0.8
+    ax = rs.uniform(0.5, 2.0, B)
+    bx = (rs.standard_normal((B, n)) * 1.5).astype(dtype)
+    l1 = T.MAP_L1NormPrior(size=n, gamma=gamma, dtype=dtype, ctx=ctx)
+    a_dev = ctx.empty((B,), np.float64); b_dev = ctx.empty((B, n), dtype); cnt = ctx.empty((B,), np.uint64)
+    bx_d = ctx.array(bx, dtype); ax_d = ctx.scalars(ax)
+    runs0 = ctx.resident_runs()
+    ctx._call("tramp_l1_prior_fwd", l1._dt, n, B, ax_d.ptr, bx_d.ptr, float(gamma), 0.0, None, None,
+              a_dev.ptr, b_dev.ptr, None, None, cnt.ptr, None)
+    assert ctx.resident_runs() == runs0 + 1
+    a_new, b_new, c = a_dev.get(), b_dev.get(), cnt.get()
+    for i in range(B):
+        # the support test on the operands of the working precision (map_L1_norm_prior.py:16-17)
+        assert int(c[i]) == int((np.abs(bx[i]) > dtype(gamma)).sum())
+        a_ref, b_ref = orc.l1_prior_message(ax[i], bx[i].astype(np.float64), gamma=gamma)
+        close_a(a_new[i], a_ref, ax[i], dtype)
+        close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_resident_damping_in_place_and_aliased_input(T, ctx, dtype):
+    """damping against the buffer that is being overwritten (out_b = old_b: what the EP scheduler does), then the
+    update written over its own input (out_b = bx): every piece is read and written by exactly one tile"""
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(9)
+    d = 0.3
+    ax = rs.uniform(0.5, 2.0, B); bx = (rs.standard_normal((B, n)) * 2).astype(dtype)
+    old_a = rs.uniform(0.5, 2.0, B); old_b = rs.standard_normal((B, n)).astype(dtype)
+    p = T.GaussBernoulliPrior(size=n, rho=0.2, dtype=dtype, ctx=ctx)
+    oa = ctx.scalars(old_a); ob = ctx.array(old_b, dtype)
+    runs0 = ctx.resident_runs()
+    p.compute_forward_message(ctx.scalars(ax), ctx.array(bx, dtype), out_a=oa, out_b=ob, damping=d, old_a=oa, old_b=ob)
+    assert ctx.resident_runs() == runs0 + 1
+    a_ref, b_ref = gb_reference(ax, bx, 0.2)
+    a_new, b_new = oa.get(), ob.get()
+    for i in range(B):
+        close_a(a_new[i], d * old_a[i] + (1 - d) * a_ref[i], ax[i], dtype)
+        close(b_new[i], d * old_b[i].astype(np.float64) + (1 - d) * b_ref[i], dtype, scale=10 * np.abs(b_ref[i]).max())
+    bio = ctx.array(bx, dtype); ao = ctx.empty((B,), np.float64)
+    p.compute_forward_message(ctx.scalars(ax), bio, out_a=ao, out_b=bio)
+    assert ctx.resident_runs() == runs0 + 2
+    b_new = bio.get()
+    for i in range(B):
+        close(b_new[i], b_ref[i], dtype, scale=10 * np.abs(b_ref[i]).max())
+
+
+def test_resident_nan_stays_in_its_instance(T, ctx):
+    dtype = np.float64
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(2)
+    bx = rs.standard_normal((B, n))
+    bad = [1, B - 2]
+    bx[bad[0], n - 3] = np.nan              # inside the overlapped last tile
+    bx[bad[1], 17] = np.inf
+    p = T.GaussBernoulliPrior(size=n, rho=0.2, ctx=ctx)
+    runs0 = ctx.resident_runs()
+    a_new, _ = p.compute_forward_message(np.full(B, 1.1), bx)
+    assert ctx.resident_runs() == runs0 + 1
+    assert np.isnan(a_new[bad]).all() and np.isfinite(np.delete(a_new, bad)).all()
+
+
+def test_shapes_the_window_does_not_cover_take_the_tile_kernels(T, ctx):
+    "one instance larger than the pipeline's window; a batch too small to fill it; odd n: same results, other kernels"
+    rs = np.random.RandomState(4)
+    p_args = dict(rho=0.1, ctx=ctx)
+    for B, n in [(1, 2048 * (2 * num_cu(ctx) + 40)), (2, 70001), (3, 20000)]:
+        bx = rs.standard_normal((B, n))
+        runs0 = ctx.resident_runs()
+        a_new, b_new = T.GaussBernoulliPrior(size=n, **p_args).compute_forward_message(np.full(B, 1.2), bx)
+        assert ctx.resident_runs() == runs0
+        for i in range(B):
+            a_ref, b_ref = orc.gb_prior_message(1.2, bx[i], rho=0.1)
+            close(a_new[i], a_ref); close(b_new[i], b_ref, scale=10 * np.abs(b_ref).max())

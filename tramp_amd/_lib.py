@@ -82,6 +82,7 @@ _SIGNATURES = {
     "tramp_prior_hint": [vp, i32, dbl, dbl, dbl, sz, sz, vp, vp],
     "tramp_lik_hint": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_prior_hint_stats": [vp, C.POINTER(u64), C.POINTER(u64)],
+    "tramp_resident_stats": [vp, C.POINTER(u64)],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_conv_create": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],

@@ -245,6 +245,12 @@ extern "C" int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed,
     return TRAMP_OK;
 }
 
+extern "C" int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs) {
+    if (!ctx || !runs) return TRAMP_EINVAL;
+    *runs = ctx->resident_runs;
+    return TRAMP_OK;
+}
+
 extern "C" int tramp_sync(tramp_ctx* ctx) {
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -58,6 +58,7 @@ struct tramp_ctx {
     double* hint_ws;
     size_t hint_ws_bytes;
     unsigned long long hint_armed, hint_used;   // producers that left moments / prior updates that ran single-pass
+    unsigned long long resident_runs;           // factor updates that took the resident single-pass pipeline (ew_resident.h)
     int graphs_alive;    // captured graphs hold raw workspace pointers: no growth while > 0
     // launch shape of the last MFMA matrix pass (tramp_matvec_last_launch): split-K factor, 64-instance chunks,
     // whether sibling chunks were interleaved in a one-dimensional grid

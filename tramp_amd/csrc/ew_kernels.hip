@@ -26,188 +26,9 @@
 #include "prior_hint.h"
 #include "tramp_math.h"
 
-using tmath::RV;
+#include "ew_ops.h"
+#include "ew_resident_host.h"
 
-// ---------------------------------------------------------------- functors
-// Each Op: setup(b) loads the per-instance scalars; eval(in0, in1) -> (r, v, mask);
-// a_msg / TARGET select the message being updated.
-template <typename T> struct EwOut { T r, v; unsigned mask; };
-
-template <typename T> struct GbOp {       // K1; in0 = bx
-    static constexpr bool HEAVY = false;
-    static constexpr int NIN = 1;
-    static constexpr int TARGET = 0;
-    const double* ax;
-    double a0, b0, eta;
-    tmath::GbConst<T> k;
-    double a_msg;
-    __device__ void setup(size_t b) {
-        a_msg = ax[b];
-        const double ad = a_msg + a0;
-        const double inv = 1.0 / ad;
-        k.inv_a = T(inv);
-        k.c1 = T(0.5 * inv);
-        k.c0 = T(0.5 * log(2 * tmath::kPi / ad) - eta);
-        k.b0 = T(b0);
-    }
-    __device__ EwOut<T> eval(T x0, T) const {
-        RV<T> o = tmath::gb_posterior_fast<T>(x0, k);
-        return {o.r, o.v, 0u};
-    }
-};
-
-template <typename T> struct L1Op {       // K2; in0 = bx
-    static constexpr bool HEAVY = false;
-    static constexpr int NIN = 1;
-    static constexpr int TARGET = 0;
-    const double* ax;
-    double gamma;
-    T inv_ax, gT;
-    double a_msg;
-    __device__ void setup(size_t b) {
-        a_msg = ax[b];
-        inv_ax = T(1.0 / a_msg);
-        gT = T(gamma);
-    }
-    __device__ EwOut<T> eval(T x0, T) const {
-        RV<T> o = tmath::l1_posterior<T>(x0, inv_ax, gT);
-        return {o.r, o.v, tmath::l1_support<T>(x0, gT) ? 1u : 0u};
-    }
-};
-
-template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1) + p- delta(x + 1); in0 = bx
-    static constexpr bool HEAVY = false;
-    static constexpr int NIN = 1;
-    static constexpr int TARGET = 0;
-    const double* ax;
-    double b0;                              // natural parameter 0.5 log(p+ / p-), binary_prior.py:27
-    double a_msg;
-    __device__ void setup(size_t b) { a_msg = ax[b]; }
-    __device__ EwOut<T> eval(T x0, T) const {
-        const T t = tmath::tanh_hot(x0 + T(b0));                 // beliefs/binary.py:8-13
-        return {t, T(1) - t * t, 0u};
-    }
-};
-
-template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
-    static constexpr bool HEAVY = false;     // recomputed in pass 2 (5T moved, not 6T): f32 252 vs 309 us, f64 580 vs 616 us at 64 x 1e6
-    static constexpr int NIN = 2;
-    static constexpr int TARGET = 0;
-    const double* az;
-    tmath::RegionConst<T> c;
-    double a_msg;
-    __device__ void setup(size_t b) {
-        a_msg = az[b];
-        c = tmath::region_const<T>(a_msg);
-        tmath::erfcx_setup<T>();
-    }
-    __device__ EwOut<T> eval(T x0, T x1) const {
-        RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, x1, c);
-        return {o.r, o.v, 0u};
-    }
-};
-
-template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
-    static constexpr bool HEAVY = false;      // 64 instructions per component (tanh_hot): recomputed in pass 2 (5T moved, not 6T)
-    static constexpr int NIN = 2;
-    static constexpr int TARGET = 0;
-    const double* az;
-    double a_msg;
-    __device__ void setup(size_t b) { a_msg = az[b]; }
-    __device__ EwOut<T> eval(T x0, T x1) const {
-        RV<T> o = tmath::abs_lik_posterior<T>(x0, x1);
-        return {o.r, o.v, 0u};
-    }
-};
-
-template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
-    static constexpr bool HEAVY = true;
-    static constexpr int NIN = 2;
-    static constexpr int TARGET = 0;
-    const double* az;
-    double slope_neg;
-    tmath::RegionConst<T> c;
-    T sT;
-    double a_msg;
-    __device__ void setup(size_t b) {
-        a_msg = az[b];
-        c = tmath::region_const<T>(a_msg);
-        sT = T(slope_neg);
-        tmath::erfcx_setup<T>();
-    }
-    __device__ EwOut<T> eval(T x0, T x1) const {
-        RV<T> o = tmath::relu_lik_posterior<T>(x0, x1, sT, c);
-        return {o.r, o.v, 0u};
-    }
-};
-
-template <typename T> struct Pwl3LikOp {  // three-region likelihoods; in0 = bz, in1 = y
-    static constexpr bool HEAVY = true;
-    static constexpr int NIN = 2;
-    static constexpr int TARGET = 0;
-    const double* az;
-    tmath::Pwl3Spec spec;
-    T azT;
-    double a_msg;
-    __device__ void setup(size_t b) {
-        a_msg = az[b];
-        azT = T(a_msg);
-    }
-    __device__ EwOut<T> eval(T x0, T x1) const {
-        tmath::PwlOut<T> o = tmath::pwl3_lik_posterior<T>(x0, x1, azT, spec);
-        return {o.r, o.v, o.mask};
-    }
-};
-
-template <typename T, bool FWD> struct Pwl3Op {   // three-region channels; in0 = bz, in1 = bx
-    static constexpr bool HEAVY = true;
-    static constexpr int NIN = 2;
-    static constexpr int TARGET = FWD ? 1 : 0;
-    const double* az;
-    const double* ax;
-    tmath::Pwl3Spec spec;
-    T azT, axT;
-    double a_msg;
-    __device__ void setup(size_t b) {
-        const double z = az[b], x = ax[b];
-        azT = T(z);
-        axT = T(x);
-        a_msg = FWD ? x : z;
-    }
-    __device__ EwOut<T> eval(T x0, T x1) const {
-        tmath::PwlOut<T> o = tmath::pwl3_posterior<T, FWD>(x0, x1, azT, axT, spec);
-        return {o.r, o.v, o.mask};
-    }
-};
-
-template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 = bx
-    static constexpr bool HEAVY = true;
-    static constexpr int NIN = 2;
-    static constexpr int TARGET = FWD ? 1 : 0;
-    const double* az;
-    const double* ax;
-    tmath::PwlSpec spec;          // used by KIND 3 only
-    tmath::PwlConst<T> c;
-    double a_msg;
-    __device__ void setup(size_t b) {
-        const double z = az[b], x = ax[b];
-        c = tmath::pwl_const<T, KIND>(z, x, spec);
-        a_msg = FWD ? x : z;
-        tmath::erfcx_setup<T, true>();
-    }
-    __device__ EwOut<T> eval(T x0, T x1) const {
-        tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD>(x0, x1, c);
-        return {o.r, o.v, o.mask};
-    }
-};
-
-// Only the L1 prior reports a support count (MAP_L1NormPrior's mask, map_L1_norm_prior.py:16-17): the other
-// ops do not carry the 64-bit counter through their loops.
-template <typename Op> struct OpCounts { static constexpr bool value = false; };
-template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };
-
-// ---------------------------------------------------------------- pass 1: moments
-template <typename T> __device__ __forceinline__ bool not_finite(T x) { return (x - x) != T(0); }
 
 // Reads the inputs once, evaluates (r_i, v_i), stores r_i to the chunk scratch and reduces
 // sum(v_i) per block.  `inst0` is the first instance of the chunk (blockIdx.y is relative).
@@ -269,17 +90,6 @@ __global__ __launch_bounds__(kBlock) void ew_pass1(Op op, size_t n, size_t inst0
 }
 
 // ---------------------------------------------------------------- pass 2: message update
-struct MsgOut {
-    double damping;
-    const double* a_old;
-    const void* b_old;
-    double* a_new;
-    void* b_new;
-    void* r;
-    double* v;
-    unsigned long long* count;
-    uint8_t* mask;
-};
 
 // Generic for every factor: folds the partials (same order in every block), forms
 // a_new = clip(1/v - a) and writes b_new = r (a + a_new) - b (tramp/base.py:250-255) with the
@@ -535,9 +345,6 @@ __global__ __launch_bounds__(kBlock) void ew_single(Op op, size_t n, const T* __
 constexpr int kTileU = 2;      // probe_copy: 5.85 TB/s (U = 2) vs 5.77 (U = 4) vs 4.25 (U = 8); 6.2 with streaming stores
 
 // 16-byte store that does not allocate in the caches (outputs larger than the Infinity Cache)
-template <typename T> struct NativeVec;
-template <> struct NativeVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
-template <> struct NativeVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
 template <typename T, bool NTS>
 __device__ __forceinline__ void store_vec(typename Vec<T>::type* dst, const typename Vec<T>::type& v) {
     if (NTS) {
@@ -814,6 +621,14 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
     if (n == 0 || batch == 0) return TRAMP_OK;
     TRAMP_REQUIRE(ctx, out.damping == 0.0 || (out.a_old && out.b_old));
     constexpr int VN = Vec<T>::N;
+    // large batches of large instances: the resident single-pass pipeline (each byte crosses HBM once).  A producer
+    // that already left the moments (hint) makes the plain apply pass the cheaper single pass.
+    if constexpr (ResidentOp<Op>::value) {
+        if (!hint) {
+            const int rc = run_resident<T, Op>(ctx, op, n, batch, in0, in1, a_in_d, out);
+            if (rc != kResNotEligible) return rc;
+        }
+    }
     const bool vec = (n % VN) == 0;
     const int nblk = blocks_for(n, VN);
     // heavy factors (erfcx / log / tanh per component) park r in a scratch; light ones recompute

@@ -1,0 +1,225 @@
+// ew_ops.h - the componentwise factors as functors (K1-K7 and the piecewise-linear family).
+// Each Op: stage() brings the erfcx table(s) into LDS (all threads of the block; ends in a barrier, no-op for the ops
+// without erfcx), prepare(b) forms the per-instance scalars (pure: no memory but the precision arrays), setup(b) =
+// stage() + prepare(b); eval(in0, in1) -> (r, v, mask); a_msg / TARGET select the message being updated.
+// Shared by ew_kernels.hip (tile kernels), ew_resident.h (resident single-pass pipeline) and tools/probes.
+#pragma once
+#include "common.h"
+#include "tramp_math.h"
+
+using tmath::RV;
+
+// ---------------------------------------------------------------- functors
+// Each Op: setup(b) loads the per-instance scalars; eval(in0, in1) -> (r, v, mask);
+// a_msg / TARGET select the message being updated.
+template <typename T> struct EwOut { T r, v; unsigned mask; };
+
+template <typename T> struct GbOp {       // K1; in0 = bx
+    static constexpr bool HEAVY = false;
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    double a0, b0, eta;
+    tmath::GbConst<T> k;
+    double a_msg;
+    __device__ static void stage() {}
+    __device__ void prepare(size_t b) {
+        a_msg = ax[b];
+        const double ad = a_msg + a0;
+        const double inv = 1.0 / ad;
+        k.inv_a = T(inv);
+        k.c1 = T(0.5 * inv);
+        k.c0 = T(0.5 * log(2 * tmath::kPi / ad) - eta);
+        k.b0 = T(b0);
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T) const {
+        RV<T> o = tmath::gb_posterior_fast<T>(x0, k);
+        return {o.r, o.v, 0u};
+    }
+};
+
+template <typename T> struct L1Op {       // K2; in0 = bx
+    static constexpr bool HEAVY = false;
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    double gamma;
+    T inv_ax, gT;
+    double a_msg;
+    __device__ static void stage() {}
+    __device__ void prepare(size_t b) {
+        a_msg = ax[b];
+        inv_ax = T(1.0 / a_msg);
+        gT = T(gamma);
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T) const {
+        RV<T> o = tmath::l1_posterior<T>(x0, inv_ax, gT);
+        return {o.r, o.v, tmath::l1_support<T>(x0, gT) ? 1u : 0u};
+    }
+};
+
+template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1) + p- delta(x + 1); in0 = bx
+    static constexpr bool HEAVY = false;
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    double b0;                              // natural parameter 0.5 log(p+ / p-), binary_prior.py:27
+    double a_msg;
+    __device__ static void stage() {}
+    __device__ void prepare(size_t b) { a_msg = ax[b]; }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T) const {
+        const T t = tmath::tanh_hot(x0 + T(b0));                 // beliefs/binary.py:8-13
+        return {t, T(1) - t * t, 0u};
+    }
+};
+
+template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
+    static constexpr bool HEAVY = false;     // recomputed in pass 2 (5T moved, not 6T): f32 252 vs 309 us, f64 580 vs 616 us at 64 x 1e6
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    tmath::RegionConst<T> c;
+    double a_msg;
+    __device__ static void stage() {tmath::erfcx_setup<T>(); }
+    __device__ void prepare(size_t b) {
+        a_msg = az[b];
+        c = tmath::region_const<T>(a_msg);
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, x1, c);
+        return {o.r, o.v, 0u};
+    }
+};
+
+template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
+    static constexpr bool HEAVY = false;      // 64 instructions per component (tanh_hot): recomputed in pass 2 (5T moved, not 6T)
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    double a_msg;
+    __device__ static void stage() {}
+    __device__ void prepare(size_t b) { a_msg = az[b]; }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        RV<T> o = tmath::abs_lik_posterior<T>(x0, x1);
+        return {o.r, o.v, 0u};
+    }
+};
+
+template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
+    static constexpr bool HEAVY = true;
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    double slope_neg;
+    tmath::RegionConst<T> c;
+    T sT;
+    double a_msg;
+    __device__ static void stage() {tmath::erfcx_setup<T>(); }
+    __device__ void prepare(size_t b) {
+        a_msg = az[b];
+        c = tmath::region_const<T>(a_msg);
+        sT = T(slope_neg);
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        RV<T> o = tmath::relu_lik_posterior<T>(x0, x1, sT, c);
+        return {o.r, o.v, 0u};
+    }
+};
+
+template <typename T> struct Pwl3LikOp {  // three-region likelihoods; in0 = bz, in1 = y
+    static constexpr bool HEAVY = true;
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = 0;
+    const double* az;
+    tmath::Pwl3Spec spec;
+    T azT;
+    double a_msg;
+    __device__ static void stage() {}
+    __device__ void prepare(size_t b) {
+        a_msg = az[b];
+        azT = T(a_msg);
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        tmath::PwlOut<T> o = tmath::pwl3_lik_posterior<T>(x0, x1, azT, spec);
+        return {o.r, o.v, o.mask};
+    }
+};
+
+template <typename T, bool FWD> struct Pwl3Op {   // three-region channels; in0 = bz, in1 = bx
+    static constexpr bool HEAVY = true;
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = FWD ? 1 : 0;
+    const double* az;
+    const double* ax;
+    tmath::Pwl3Spec spec;
+    T azT, axT;
+    double a_msg;
+    __device__ static void stage() {}
+    __device__ void prepare(size_t b) {
+        const double z = az[b], x = ax[b];
+        azT = T(z);
+        axT = T(x);
+        a_msg = FWD ? x : z;
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        tmath::PwlOut<T> o = tmath::pwl3_posterior<T, FWD>(x0, x1, azT, axT, spec);
+        return {o.r, o.v, o.mask};
+    }
+};
+
+template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 = bx
+    static constexpr bool HEAVY = true;
+    static constexpr int NIN = 2;
+    static constexpr int TARGET = FWD ? 1 : 0;
+    const double* az;
+    const double* ax;
+    tmath::PwlSpec spec;          // used by KIND 3 only
+    tmath::PwlConst<T> c;
+    double a_msg;
+    __device__ static void stage() {tmath::erfcx_setup<T, true>(); }
+    __device__ void prepare(size_t b) {
+        const double z = az[b], x = ax[b];
+        c = tmath::pwl_const<T, KIND>(z, x, spec);
+        a_msg = FWD ? x : z;
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T x1) const {
+        tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD>(x0, x1, c);
+        return {o.r, o.v, o.mask};
+    }
+};
+
+// Only the L1 prior reports a support count (MAP_L1NormPrior's mask, map_L1_norm_prior.py:16-17): the other
+// ops do not carry the 64-bit counter through their loops.
+template <typename Op> struct OpCounts { static constexpr bool value = false; };
+template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };
+
+// ---------------------------------------------------------------- pass 1: moments
+template <typename T> __device__ __forceinline__ bool not_finite(T x) { return (x - x) != T(0); }
+
+// Where an update leaves its results (tramp/base.py:250-255): the message (a_new, b_new), optionally damped against
+// (a_old, b_old), and on request the posterior (r, v), the L1 support count and the branch masks.
+struct MsgOut {
+    double damping;
+    const double* a_old;
+    const void* b_old;
+    double* a_new;
+    void* b_new;
+    void* r;
+    double* v;
+    unsigned long long* count;
+    uint8_t* mask;
+};
+
+// native 16-byte vector of the element type (the nontemporal builtins take these, not double2 / float4)
+template <typename T> struct NativeVec;
+template <> struct NativeVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct NativeVec<float> { typedef float type __attribute__((ext_vector_type(4))); };

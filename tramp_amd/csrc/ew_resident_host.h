@@ -1,0 +1,23 @@
+// ew_resident_host.h - host side of the resident single-pass updates (ew_resident.h): eligibility, workspace, launch.
+// The kernels are instantiated in ew_resident_{prior,lik,pwl}.hip (one translation unit per factor family: each
+// instantiation unrolls its pipeline ring three times over, seconds of compile time apiece); ew_kernels.hip sees only
+// the declaration of run_resident and the trait that says which factors have the resident form.
+#pragma once
+#include "ew_ops.h"
+
+constexpr int kResNotEligible = 1000;      // run_resident: "take the tile kernels" (not an error)
+
+// The shape the pipeline is built for (tools/probes/probe_resident.hip on MI355X, 64 x 1e6: U = 4 pieces per thread and
+// tile, loads one iteration ahead, update three iterations behind, two 256-thread workgroups per CU: Gauss-Bernoulli
+// 207 us f64 / 94 us f32; deeper rings spill, U = 8 with one workgroup per CU is 5-10 % slower, U = 2 15 % slower).
+constexpr int kResU = 4, kResDL = 1, kResDA = 3;
+
+template <typename Op> struct ResidentOp { static constexpr bool value = false; };
+template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value = true; };
+template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value = true; };
+
+// TRAMP_OK: the update ran (launched) in the resident form; kResNotEligible: shape or outputs it does not cover;
+// anything else: an error, ctx->err is set.
+template <typename T, typename Op>
+int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const void* in0, const void* in1,
+                 const double* a_in_d, const MsgOut& out);

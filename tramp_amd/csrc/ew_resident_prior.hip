@@ -1,0 +1,6 @@
+// ew_resident_prior.hip - resident single-pass updates of the vector denoisers (K1 Gauss-Bernoulli, K2 L1).
+#include "ew_resident_impl.h"
+RES_INSTANTIATE(double, GbOp<double>)
+RES_INSTANTIATE(float, GbOp<float>)
+RES_INSTANTIATE(double, L1Op<double>)
+RES_INSTANTIATE(float, L1Op<float>)

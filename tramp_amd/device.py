@@ -135,6 +135,12 @@ class Context:
         self._call("tramp_prior_hint_stats", C.byref(a), C.byref(u))
         return a.value, u.value
 
+    def resident_runs(self):
+        "factor updates that took the resident single-pass pipeline since the context was made - csrc/ew_resident.h"
+        r = C.c_ulonglong()
+        self._call("tramp_resident_stats", C.byref(r))
+        return r.value
+
     def close(self):
         if self.handle:
             self.lib.tramp_ctx_destroy(self.handle)
