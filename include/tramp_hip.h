@@ -169,6 +169,19 @@ int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
                       double damping, const double* a_old_d, const void* b_old_d,
                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
 
+/* Sign observations packed one bit per component for tramp_sgn_lik_bwd_bits: y_d[batch][n] in {-1, +1} ->
+ * bits_d[batch][8 ceil(n / 64)] bytes, bit j of byte q of a row = (y[8 q + j] == +1).  *bad_h = entries that are
+ * neither -1 nor +1 (then the packed form must not be used).  Synchronises the stream (done once, at construction:
+ * SgnLikelihood holds a static observation, tramp/likelihoods/sgn_likelihood.py:14-19). */
+int tramp_sgn_pack(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const void* y_d, void* bits_d,
+                   unsigned long long* bad_h);
+/* tramp_sgn_lik_bwd (sgn_likelihood.py:32-37 + base_likelihood.py:25-28) with the packed observation beside y_d:
+ * batches of large instances stream bz and one BIT of y per component through the resident pipeline (2T + n/8 bytes
+ * moved instead of 3T); any other shape, a wanted posterior (r_d) or an armed producer hint takes tramp_sgn_lik_bwd on
+ * y_d.  bits_d may be NULL. */
+int tramp_sgn_lik_bwd_bits(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const double* az_d, const void* bz_d,
+                           const void* y_d, const void* bits_d, double damping, const double* a_old_d,
+                           const void* b_old_d, double* a_new_d, void* b_new_d, void* r_d, double* v_d);
 /* K5. AbsLikelihood.compute_backward_posterior  (y >= 0)
  *     tramp/likelihoods/abs_likelihood.py:31-36, tramp/beliefs/binary.py:8-13. */
 int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
@@ -286,6 +299,9 @@ int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed, unsigned l
  * tile kernels.  Same entry points, same results to reduction-order rounding, run-to-run reproducible; chosen by shape
  * (TRAMP_EW_RESIDENT=0 turns it off).  How many updates took that form since the context was made: */
 int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs);
+/* *yes = 1 when updates of `batch` instances of n components in `dtype` take the resident form (a host-side shape
+ * test: the scheduler asks before it arms a producer for a consumer that would not use the moments) */
+int tramp_resident_covers(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int* yes);
 
 /* ---- dense linear channel x = W z --------------------------------------- */
 /* LinearChannel.__init__ (tramp/channels/linear/linear_channel.py:30-46): the

@@ -154,3 +154,73 @@ def test_shapes_the_window_does_not_cover_take_the_tile_kernels(T, ctx):
         for i in range(B):
             a_ref, b_ref = orc.gb_prior_message(1.2, bx[i], rho=0.1)
             close(a_new[i], a_ref); close(b_new[i], b_ref, scale=10 * np.abs(b_ref).max())
+
+
+def sgn_reference(az, bz, y):
+    out_a, out_b = [], []
+    for a, b, yy in zip(az, bz, y):
+        an, bn = orc.sgn_lik_message(a, b.astype(np.float64), yy.astype(np.float64))
+        out_a.append(an); out_b.append(bn)
+    return np.array(out_a), np.stack(out_b)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sign_observation_packs_one_bit_per_component(T, ctx, dtype):
+    rs = np.random.RandomState(3)
+    for B, n in [(3, 1), (2, 63), (2, 64), (3, 65), (2, 1000), (1, 4099)]:
+        y = np.where(rs.standard_normal((B, n)) > 0, 1.0, -1.0).astype(dtype)
+        lk = T.SgnLikelihood(y=y, dtype=dtype, ctx=ctx)
+        assert lk._bits is not None and lk._bits.shape == (B, ((n + 63) // 64) * 8)
+        bits = np.unpackbits(lk._bits.get(), axis=1, bitorder="little")
+        assert np.array_equal(bits[:, :n], (y > 0).astype(np.uint8)) and not bits[:, n:].any()
+    # an observation outside {-1, +1} (np.sign(0) = 0): no packed form, the update reads y itself
+    y0 = np.array([[1.0, -1.0, 0.0, 1.0]], dtype=dtype)
+    assert T.SgnLikelihood(y=y0, dtype=dtype, ctx=ctx)._bits is None
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sgn_likelihood_resident_on_packed_observation(T, ctx, dtype):
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(13)
+    y = np.where(rs.standard_normal((B, n)) > 0, 1.0, -1.0).astype(dtype)
+    lk = T.SgnLikelihood(y=y, dtype=dtype, ctx=ctx)
+    a_dev = ctx.empty((B,), np.float64); b_dev = ctx.empty((B, n), dtype)
+    for trial in range(2):
+        az = rs.uniform(0.4, 2.5, B)
+        bz = (rs.standard_normal((B, n)) * 1.5).astype(dtype)
+        runs0 = ctx.resident_runs()
+        lk.compute_backward_message(ctx.scalars(az), ctx.array(bz, dtype), out_a=a_dev, out_b=b_dev)
+        assert ctx.resident_runs() == runs0 + 1
+        a_ref, b_ref = sgn_reference(az, bz, y)
+        a_new, b_new = a_dev.get(), b_dev.get()
+        for i in range(B):
+            close_a(a_new[i], a_ref[i], az[i], dtype)
+            close(b_new[i], b_ref[i], dtype, scale=10 * np.abs(b_ref[i]).max())
+    # the same update on the unpacked observation (y handed in again: the tile kernels or the resident 3T form)
+    a2, b2 = lk._message(ctx.scalars(az), ctx.array(bz, dtype), y=ctx.array(y, dtype))[2:4]
+    close(a2.get(), a_new, dtype); close(b2.get(), b_new, dtype, scale=10 * np.abs(b_new).max())
+    # damped, in place
+    d = 0.4
+    old_a = rs.uniform(0.5, 2.0, B); old_b = rs.standard_normal((B, n)).astype(dtype)
+    oa = ctx.scalars(old_a); ob = ctx.array(old_b, dtype)
+    lk.compute_backward_message(ctx.scalars(az), ctx.array(bz, dtype), out_a=oa, out_b=ob, damping=d, old_a=oa, old_b=ob)
+    got = ob.get()
+    for i in range(B):
+        close(got[i], d * old_b[i].astype(np.float64) + (1 - d) * b_ref[i], dtype, scale=10 * np.abs(b_ref[i]).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_abs_likelihood_resident(T, ctx, dtype):
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(17)
+    y = np.abs(rs.standard_normal((B, n))).astype(dtype)
+    az = rs.uniform(0.4, 2.5, B)
+    bz = (rs.standard_normal((B, n)) * 1.5).astype(dtype)
+    lk = T.AbsLikelihood(y=y, dtype=dtype, ctx=ctx)
+    runs0 = ctx.resident_runs()
+    a_new, b_new = lk.compute_backward_message(az, bz)
+    assert ctx.resident_runs() == runs0 + 1
+    for i in range(B):
+        a_ref, b_ref = orc.abs_lik_message(az[i], bz[i].astype(np.float64), y[i].astype(np.float64))
+        close_a(a_new[i], a_ref, az[i], dtype)
+        close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())

@@ -50,20 +50,20 @@ template <typename T, typename Op> __global__ void ref_apply(Op op, size_t n, co
 
 struct Buffers {
     size_t n, batch;
-    void *in0, *in1, *out, *ref;
+    void *in0, *in1, *in1_buf, *out, *ref, *bits;
     double *a_in, *a_new, *a_ref, *sums;
     void* ws;
     size_t ws_bytes;
     int num_cu;
 };
 
-template <typename T, typename Op, int U, int DL, int DA, int BPC, int DBG, int FL = 0>
+template <typename T, typename Op, int U, int DL, int DA, int BPC, int DBG, int FL = 0, int NT = 256>
 static float run_variant(const Buffers& B, Op op, int reps) {
     constexpr int blocks_per_cu = BPC;
     constexpr int VN = Vec<T>::N;
     ResArgs A{};
     A.n = B.n; A.nv = B.n / VN; A.batch = (unsigned)B.batch;
-    A.tiles = (unsigned)((A.nv + (size_t)kBlock * U - 1) / ((size_t)kBlock * U));
+    A.tiles = (unsigned)((A.nv + (size_t)NT * U - 1) / ((size_t)NT * U));
     A.total = (unsigned long long)A.batch * A.tiles;
     const unsigned P = (unsigned)(blocks_per_cu * B.num_cu);
     const unsigned PS = P - kResCombiners;          // streaming workgroups
@@ -74,14 +74,16 @@ static float run_variant(const Buffers& B, Op op, int reps) {
     A.slots = (unsigned long long*)ws; ws += A.total * 8;
     A.cslots = (unsigned long long*)ws; ws += A.total * 8;
     A.scal = (unsigned long long*)ws;
-    A.out = MsgOut{0.0, nullptr, nullptr, B.a_new, B.out, nullptr, nullptr, nullptr, nullptr};
+    A.dummy = ws + ((B.batch * 8 + 255) / 256) * 256;
+    A.bits = (const uint8_t*)B.bits; A.bits_stride = ((B.n + 63) / 64) * 8;
+    A.out = MsgOut{(FL & 1) ? 0.25 : 0.0, (FL & 1) ? B.a_in : nullptr, (FL & 1) ? B.in1_buf : nullptr, B.a_new, B.out, nullptr, nullptr, nullptr, nullptr};
     if (A.tiles > (unsigned)(PS * (DA - 2) + 1) || false) { printf("   (tiles %u do not fit the window)\n", A.tiles); return -1.f; }
     int occ = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (ew_resident<T, Op, U, DL, DA, FL, BPC, DBG>), kBlock, 0));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (ew_resident<T, Op, U, DL, DA, FL, BPC, DBG, NT>), NT, 0));
     if (occ < blocks_per_cu) { printf("   (occupancy %d < %d)\n", occ, blocks_per_cu); return -1.f; }
     auto launch = [&] {
         hipLaunchKernelGGL((ew_res_prepare<Op>), dim3((unsigned)((A.total + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, op, A, ops);
-        hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, FL, BPC, DBG>), dim3(P), dim3(kBlock), 0, 0, (const Op*)ops, A, (const T*)B.in0, (const T*)B.in1);
+        hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, FL, BPC, DBG, NT>), dim3(P), dim3(NT), 0, 0, (const Op*)ops, A, (const T*)B.in0, (const T*)B.in1);
     };
     launch(); launch();
     CK(hipDeviceSynchronize());
@@ -121,51 +123,66 @@ template <typename T, typename Op> static void reference(const Buffers& B, Op op
     CK(hipDeviceSynchronize());
 }
 
-#define VARIANTF(T, Op, op, U, DL, DA, BPC, DBG, FL, alg)                                                              \
+#define VARIANTN(T, Op, op, U, DL, DA, BPC, DBG, FL, NT, alg)                                                              \
     {                                                                                                        \
-        float ms = run_variant<T, Op, U, DL, DA, BPC, DBG, FL>(B, op, 9);                                             \
+        float ms = run_variant<T, Op, U, DL, DA, BPC, DBG, FL, NT>(B, op, 9);                                             \
         if (ms > 0) {                                                                                        \
-            printf("%-10s %s U=%d DL=%d DA=%d wg/CU=%d flags=%d %s: %8.1f us  %6.0f GB/s algorithmic = %.3f of 8 TB/s\n", #Op, sizeof(T) == 8 ? "f64" : "f32", \
-                   U, DL, DA, BPC, FL, DBG ? "no-sync" : "sync   ", ms * 1e3, (alg) / ms / 1e6, (alg) / ms / 1e6 / 8000.0);  \
+            printf("%-10s %s NT=%d U=%d DL=%d DA=%d wg/CU=%d flags=%d %s: %8.1f us  %6.0f GB/s algorithmic = %.3f of 8 TB/s\n", #Op, sizeof(T) == 8 ? "f64" : "f32", \
+                   NT, U, DL, DA, BPC, FL, DBG ? "no-sync" : "sync   ", ms * 1e3, (alg) / ms / 1e6, (alg) / ms / 1e6 / 8000.0);  \
             fflush(stdout);                                                                                  \
-            if (!DBG) compare<T>(B, true);                                                                   \
+            if (!DBG && !((FL) & 1)) compare<T>(B, true);                                                                   \
         }                                                                                                    \
     }
 
+#define VARIANTF(T, Op, op, U, DL, DA, BPC, DBG, FL, alg) VARIANTN(T, Op, op, U, DL, DA, BPC, DBG, FL, 256, alg)
 #define VARIANT(T, Op, op, U, DL, DA, BPC, DBG, alg) VARIANTF(T, Op, op, U, DL, DA, BPC, DBG, 0, alg)
 
+template <typename T> __global__ void pack_kernel(size_t n, size_t stride, const T* y, uint8_t* bits) {
+    const size_t b = blockIdx.y, q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= stride) return;
+    unsigned byte = 0;
+    for (int j = 0; j < 8; ++j) if (q * 8 + j < n && y[b * n + q * 8 + j] > T(0)) byte |= 1u << j;
+    bits[b * stride + q] = (uint8_t)byte;
+}
+template <typename T> __global__ void sign_kernel(T* p, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = p[i] > T(0) ? T(1) : T(-1);
+}
+
 template <typename T> static void sweep(Buffers& B) {
-    const double alg2 = 2.0 * sizeof(T) * B.n * B.batch;
+    const double alg2 = 2.0 * sizeof(T) * B.n * B.batch, alg3 = 1.5 * alg2;
     hipLaunchKernelGGL((fill_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in0, B.n * B.batch, 1.3);
+    hipLaunchKernelGGL((fill_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in1_buf, B.n * B.batch, 0.7);
+    hipLaunchKernelGGL((sign_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in1_buf, B.n * B.batch);
+    const size_t stride = ((B.n + 63) / 64) * 8;
+    hipLaunchKernelGGL((pack_kernel<T>), dim3((unsigned)((stride + 255) / 256), (unsigned)B.batch), dim3(256), 0, 0, B.n, stride, (const T*)B.in1_buf, (uint8_t*)B.bits);
     CK(hipDeviceSynchronize());
+    B.in1 = B.in1_buf;
     {
-        GbOp<T> op{};
-        op.ax = B.a_in; op.a0 = 1.0; op.b0 = 0.0; op.eta = 0.5 * log(2 * M_PI) - log(0.05 / 0.95) ;   // any plausible constants
-        reference<T, GbOp<T>>(B, op);
-        using Op = GbOp<T>;
-        //            U DL DA wg/CU nosync
-        VARIANT(T, Op, op, 4, 1, 3, 2, 0, alg2)
-        VARIANT(T, Op, op, 8, 1, 3, 1, 0, alg2)
-        VARIANTF(T, Op, op, 4, 1, 3, 2, 0, 8, alg2)
+        SgnLikOp<T> op{};
+        op.az = B.a_in;
+        reference<T, SgnLikOp<T>>(B, op);
+        using Op = SgnLikOp<T>;
+        //                 U DL DA wg/CU nosync flags NT
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 0, 256, alg3)
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16, 256, alg3)
     }
     {
-        L1Op<T> op{};
-        op.ax = B.a_in; op.gamma = 1.0;
-        reference<T, L1Op<T>>(B, op);
-        using Op = L1Op<T>;
-        VARIANT(T, Op, op, 4, 1, 3, 2, 1, alg2)
-        VARIANT(T, Op, op, 4, 2, 3, 2, 1, alg2)
-        VARIANT(T, Op, op, 4, 3, 3, 2, 1, alg2)
-        VARIANT(T, Op, op, 2, 2, 3, 2, 1, alg2)
-        VARIANT(T, Op, op, 2, 4, 3, 2, 1, alg2)
-        VARIANT(T, Op, op, 1, 4, 3, 2, 1, alg2)
-        VARIANT(T, Op, op, 1, 8, 3, 2, 1, alg2)
-        VARIANTF(T, Op, op, 4, 1, 3, 2, 1, 8, alg2)
-        VARIANTF(T, Op, op, 4, 2, 3, 2, 1, 8, alg2)
-        VARIANT(T, Op, op, 8, 1, 3, 1, 1, alg2)
-        VARIANT(T, Op, op, 8, 2, 3, 1, 1, alg2)
-        VARIANT(T, Op, op, 4, 1, 3, 2, 0, alg2)
-        VARIANT(T, Op, op, 4, 2, 3, 2, 0, alg2)
+        SgnLikBitsOp<T> op{};
+        op.az = B.a_in;
+        using Op = SgnLikBitsOp<T>;
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 0, 256, alg3)
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16, 256, alg3)
+        VARIANTN(T, Op, op, 4, 2, 3, 2, 0, 0, 256, alg3)
+        VARIANTN(T, Op, op, 4, 1, 3, 1, 0, 0, 512, alg3)
+    }
+    {
+        AbsLikOp<T> op{};
+        op.az = B.a_in;
+        hipLaunchKernelGGL((fill_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in1_buf, B.n * B.batch, 0.7);
+        reference<T, AbsLikOp<T>>(B, op);
+        using Op = AbsLikOp<T>;
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 0, 256, alg3)
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16, 256, alg3)
     }
 }
 
@@ -178,7 +195,7 @@ int main(int argc, char** argv) {
     printf("device %s, %d CUs; %zu instances x %zu\n", prop.name, B.num_cu, B.batch, B.n);
     const size_t bytes = B.n * B.batch * 8;
     CK(hipMalloc(&B.in0, bytes)); CK(hipMalloc(&B.out, bytes)); CK(hipMalloc(&B.ref, bytes));
-    B.in1 = nullptr;
+    B.in1 = nullptr; CK(hipMalloc(&B.in1_buf, bytes)); CK(hipMalloc(&B.bits, bytes / 32 + 4096));
     CK(hipMalloc(&B.a_in, B.batch * 8)); CK(hipMalloc(&B.a_new, B.batch * 8)); CK(hipMalloc(&B.a_ref, B.batch * 8)); CK(hipMalloc(&B.sums, B.batch * 8));
     B.ws_bytes = 64 << 20; CK(hipMalloc(&B.ws, B.ws_bytes));
     std::vector<double> a(B.batch);

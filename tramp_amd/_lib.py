@@ -63,6 +63,8 @@ _SIGNATURES = {
     "tramp_gauss_prior_fwd": [vp, i32, sz, sz, dbl, dbl, vp, vp],
     "tramp_gauss_lik_bwd": [vp, i32, sz, sz, vp, dbl, vp, vp],
     "tramp_sgn_lik_bwd": [vp, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_sgn_pack": [vp, i32, sz, sz, vp, vp, C.POINTER(u64)],
+    "tramp_sgn_lik_bwd_bits": [vp, i32, sz, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_abs_lik_bwd": [vp, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_relu_lik_bwd": [vp, i32, sz, sz, dbl, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_se_relu_lik": [vp, sz, vp, vp, vp],
@@ -83,6 +85,7 @@ _SIGNATURES = {
     "tramp_lik_hint": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_prior_hint_stats": [vp, C.POINTER(u64), C.POINTER(u64)],
     "tramp_resident_stats": [vp, C.POINTER(u64)],
+    "tramp_resident_covers": [vp, i32, sz, sz, C.POINTER(i32)],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],
     "tramp_conv_create": [vp, i32, i32, C.POINTER(sz), vp, C.POINTER(vp)],

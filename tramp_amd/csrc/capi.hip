@@ -245,6 +245,13 @@ extern "C" int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed,
     return TRAMP_OK;
 }
 
+bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size);
+extern "C" int tramp_resident_covers(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int* yes) {
+    if (!ctx || !yes || (dtype != TRAMP_F32 && dtype != TRAMP_F64)) return TRAMP_EINVAL;
+    *yes = resident_covers(ctx, n, batch, dtype == TRAMP_F32 ? 4 : 8) ? 1 : 0;
+    return TRAMP_OK;
+}
+
 extern "C" int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs) {
     if (!ctx || !runs) return TRAMP_EINVAL;
     *runs = ctx->resident_runs;

@@ -612,6 +612,19 @@ static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* 
     return run_tiles_u<T, Op, kTileU>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
 }
 
+bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size) {
+    static const size_t on = env_size("TRAMP_EW_RESIDENT", 1);
+    static const size_t min_rounds = env_size("TRAMP_EW_RESIDENT_MIN_ROUNDS", 4);
+    const size_t vn = 16 / elem_size, tv = (size_t)kBlock * kResU;
+    if (!on || !ctx || ctx->num_cu < 16 || batch == 0 || (n % vn) != 0) return false;
+    const size_t nv = n / vn;
+    // smaller instances: one workgroup each (ew_single); the tile offsets are 32-bit
+    if (n <= (size_t)kBlock * kSingleVpt * vn || nv < tv || nv > 0x7fffffffull || batch > 0x3fffffffull) return false;
+    const size_t ps = (size_t)2 * ctx->num_cu - 8, tiles = (nv + tv - 1) / tv;
+    // an instance must fit the window of rounds the pipeline keeps in flight, and there must be rounds to overlap
+    return tiles <= ps * (kResDA - 2) + 1 && batch * tiles >= min_rounds * ps;
+}
+
 template <typename T, typename Op>
 static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0,
                         const void* in1, const double* a_in_d, const MsgOut& out,
@@ -842,6 +855,85 @@ extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     SgnLikOp<double> od{az_d};
     DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out, hint)),
                    (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out, hint)));
+}
+
+// ---- sign observations packed one bit per component (the resident form of K4 then moves 2T + n/8 bytes)
+// One thread per 8 components: a byte of the row (bit j of byte q = component 8 q + j is +1); rows of
+// stride = 8 ceil(n / 64) bytes, the padding bits zero.  bad counts the entries that are neither -1 nor +1.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sgn_pack_kernel(size_t n, size_t stride, const T* __restrict__ y,
+                                                          uint8_t* __restrict__ bits,
+                                                          unsigned long long* __restrict__ bad) {
+    const size_t b = blockIdx.y;
+    const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned nb = 0;
+    if (q < stride) {
+        unsigned byte = 0;
+        for (int j = 0; j < 8; ++j) {
+            const size_t i = q * 8 + j;
+            if (i < n) {
+                const T v = y[b * n + i];
+                if (v == T(1)) byte |= 1u << j;
+                else if (!(v == T(-1))) nb += 1;
+            }
+        }
+        bits[b * stride + q] = (uint8_t)byte;
+    }
+    if (__any(nb != 0) && nb) atomicAdd(bad, (unsigned long long)nb);
+}
+
+extern "C" int tramp_sgn_pack(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const void* y_d, void* bits_d,
+                              unsigned long long* bad_h) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, y_d && bits_d && bad_h && batch <= 65535);
+    *bad_h = 0;
+    if (n == 0 || batch == 0) return TRAMP_OK;
+    const size_t stride = ((n + 63) / 64) * 8;
+    int rc = tramp_ws_reserve(ctx, 256);
+    if (rc) return rc;
+    unsigned long long* bad_d = reinterpret_cast<unsigned long long*>(ctx->ws);
+    TRAMP_HIP_CHECK(ctx, hipMemsetAsync(bad_d, 0, 8, ctx->stream));
+    dim3 grid((unsigned)((stride + kBlock - 1) / kBlock), (unsigned)batch);
+    if (dtype == TRAMP_F32)
+        hipLaunchKernelGGL(sgn_pack_kernel<float>, grid, dim3(kBlock), 0, ctx->stream, n, stride,
+                           reinterpret_cast<const float*>(y_d), reinterpret_cast<uint8_t*>(bits_d), bad_d);
+    else if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL(sgn_pack_kernel<double>, grid, dim3(kBlock), 0, ctx->stream, n, stride,
+                           reinterpret_cast<const double*>(y_d), reinterpret_cast<uint8_t*>(bits_d), bad_d);
+    else
+        return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    TRAMP_LAUNCH_CHECK(ctx);
+    TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(bad_h, bad_d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const double* az_d,
+                                 const void* bz_d, const void* y_d, double damping, const double* a_old_d,
+                                 const void* b_old_d, double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+
+extern "C" int tramp_sgn_lik_bwd_bits(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                                      const double* az_d, const void* bz_d, const void* y_d, const void* bits_d,
+                                      double damping, const double* a_old_d, const void* b_old_d,
+                                      double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && y_d);
+    // a producer that left the moments (prior_hint.h), shapes the resident pipeline does not cover, a wanted
+    // posterior: the update on the unpacked observation
+    if (bits_d && !r_d && bz_d && a_new_d && b_new_d && n && batch && (damping == 0.0 || (a_old_d && b_old_d)) &&
+        !(ctx->hint.ready && ctx->hint.kind == PRIOR_HINT_SGN_LIK) &&
+        resident_covers(ctx, n, batch, dtype == TRAMP_F32 ? 4 : 8)) {
+        MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, nullptr, v_d, nullptr, nullptr};
+        const size_t stride = ((n + 63) / 64) * 8;
+        int rc = kResNotEligible;
+        if (dtype == TRAMP_F32) rc = run_resident<float>(ctx, SgnLikBitsOp<float>{az_d}, n, batch, bz_d, nullptr, az_d, out, bits_d, stride);
+        else if (dtype == TRAMP_F64) rc = run_resident<double>(ctx, SgnLikBitsOp<double>{az_d}, n, batch, bz_d, nullptr, az_d, out, bits_d, stride);
+        if (rc != kResNotEligible) {
+            if (rc == TRAMP_OK) { ctx->hint.kind = PRIOR_HINT_NONE; ctx->hint.ready = false; }     // consumed, as take_hint does
+            return rc;
+        }
+    }
+    return tramp_sgn_lik_bwd(ctx, dtype, n, batch, az_d, bz_d, y_d, damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d);
 }
 
 extern "C" int tramp_abs_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,

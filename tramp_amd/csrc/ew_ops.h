@@ -95,6 +95,27 @@ template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
     }
 };
 
+// K4 with the observation packed one bit per component (y in {-1, +1} is static: 2T + 1/64 T moved instead of 3T);
+// only the resident pipeline reads it (ew_resident.h, ResArgs::bits).  eval's second argument is y rebuilt from its bit.
+template <typename T> struct SgnLikBitsOp {   // in0 = bz
+    static constexpr bool HEAVY = false;
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* az;
+    tmath::RegionConst<T> c;
+    double a_msg;
+    __device__ static void stage() { tmath::erfcx_setup<T>(); }
+    __device__ void prepare(size_t b) {
+        a_msg = az[b];
+        c = tmath::region_const<T>(a_msg);
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T y) const {
+        RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, y, c);
+        return {o.r, o.v, 0u};
+    }
+};
+
 template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
     static constexpr bool HEAVY = false;      // 64 instructions per component (tanh_hot): recomputed in pass 2 (5T moved, not 6T)
     static constexpr int NIN = 2;
@@ -199,6 +220,9 @@ template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 
 
 // Only the L1 prior reports a support count (MAP_L1NormPrior's mask, map_L1_norm_prior.py:16-17): the other
 // ops do not carry the 64-bit counter through their loops.
+template <typename Op> struct OpBits { static constexpr bool value = false; };
+template <typename T> struct OpBits<SgnLikBitsOp<T>> { static constexpr bool value = true; };
+
 template <typename Op> struct OpCounts { static constexpr bool value = false; };
 template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };
 

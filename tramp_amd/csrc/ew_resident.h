@@ -42,6 +42,8 @@ struct ResArgs {
     unsigned long long* slots;        // [batch][tiles] bits of the tile sums of v_i
     unsigned long long* cslots;       // [batch][tiles] support counts (L1 prior) or nullptr
     unsigned long long* scal;         // [batch] bits of a_in + a_new
+    const uint8_t* bits;              // OpBits factors: the second input, one bit per component, rows of bits_stride bytes
+    size_t bits_stride;
     void* dummy;                      // 256 U 16-byte pieces: where the overlap of an instance's last tile is "stored"
     MsgOut out;
 };
@@ -154,28 +156,53 @@ template <bool COUNT> __device__ __forceinline__ void res_combiner(const ResArgs
     }
 }
 
+// block reductions for NT = 256 or 512 threads (fixed order: run-to-run reproducible)
+template <int NT> __device__ __forceinline__ double res_block_sum(double v, double* smem) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    double t = smem[0];
+#pragma unroll
+    for (int i = 1; i < NT / kWave; ++i) t += smem[i];
+    return t;
+}
+template <int NT> __device__ __forceinline__ unsigned long long res_block_sum_u64(unsigned long long v, unsigned long long* smem) {
+    v = wave_sum_u64(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    unsigned long long t = smem[0];
+#pragma unroll
+    for (int i = 1; i < NT / kWave; ++i) t += smem[i];
+    return t;
+}
+
 // Flags: which rarely wanted outputs this instantiation writes (compile time: no branch in the stream).
-constexpr int kResDamp = 1, kResStoreR = 2, kResMask = 4, kResNtLoad = 8;
+constexpr int kResDamp = 1, kResStoreR = 2, kResMask = 4, kResNtLoad = 8, kResSchedBarrier = 16, kResRegR = 32;
 
 // DBG (probes only): 1 = no slots, no combiner, no polling (the pipeline as a plain stream with a constant scalar).
 // Every tile is FULL: the last tile of an instance starts at nv - 256 U, overlapping its predecessor; the overlap is
 // evaluated twice, counted once and stored once (the second copy goes to a dummy tile: a select on the address, so the
 // stream has no per-lane control flow at all, and every piece is written by exactly one tile - outputs may alias inputs).
-template <typename T, typename Op, int U, int DL, int DA, int FLAGS, int BPC = kResBlocksPerCU, int DBG = 0>
-__global__ __launch_bounds__(kBlock, BPC) void ew_resident(const Op* __restrict__ ops, ResArgs A,
+// NT threads per workgroup (256 or 512), BPC workgroups per CU: NT x BPC = 512 threads per CU = two waves per SIMD.
+template <typename T, typename Op, int U, int DL, int DA, int FLAGS, int BPC = kResBlocksPerCU, int DBG = 0, int NT = kBlock>
+__global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __restrict__ ops, ResArgs A,
                                                            const T* __restrict__ in0, const T* __restrict__ in1) {
     using V = typename Vec<T>::type;
     using NV = typename NativeVec<T>::type;
     constexpr int VN = Vec<T>::N;
     constexpr int R = DL + DA + 1;
-    constexpr unsigned TV = kBlock * U;                       // 16-byte pieces per tile
-    constexpr bool COUNT = OpCounts<Op>::value;
+    constexpr unsigned TV = NT * U;                       // 16-byte pieces per tile
+    constexpr bool COUNT = OpCounts<Op>::value, BITS = OpBits<Op>::value;
     constexpr bool DAMP = (FLAGS & kResDamp) != 0, STORE_R = (FLAGS & kResStoreR) != 0, MASK = (FLAGS & kResMask) != 0;
-    __shared__ double smem[kBlock / kWave];
-    __shared__ unsigned long long smem_u[kBlock / kWave];
+    __shared__ double smem[NT / kWave];
+    __shared__ unsigned long long smem_u[NT / kWave];
     // r of the rounds that wait for their mean: in LDS (each thread parks and fetches its own pieces: no barrier), so the
     // register ring holds only the messages b.  (With r in registers too every factor but the two priors spilled.)
-    __shared__ V r_lds[DA + 1][U][kBlock];
+    __shared__ V r_lds[(FLAGS & kResRegR) ? 1 : DA + 1][U][NT];
     const unsigned tid = threadIdx.x;
     if (blockIdx.x < kResCombiners) {
         if (DBG != 1 && tid < kWave) res_combiner<COUNT>(A, blockIdx.x);
@@ -193,6 +220,7 @@ __global__ __launch_bounds__(kBlock, BPC) void ew_resident(const Op* __restrict_
 
     // ring of rounds in flight: x0 / x1 hold the inputs until the moments are taken, then x0 the target message b
     V x0[R][U], x1[R][U], xold[R][U];
+    unsigned xb[R][U];                         // BITS: the byte that holds this piece's bits of the packed second input
     unsigned lm = 0;                           // LDS slot of the round whose moments are taken: (j - DL) mod (DA + 1)
     unsigned r_inst[R], r_tile[R];
     bool r_live[R];
@@ -227,8 +255,9 @@ __global__ __launch_bounds__(kBlock, BPC) void ew_resident(const Op* __restrict_
             const unsigned off = min(l_tile * TV, nv - TV) + tid;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                x0[s][u] = res_ld<T, (FLAGS & kResNtLoad) != 0>(&p0[base + off + u * kBlock]);
-                if (Op::NIN > 1) x1[s][u] = res_ld<T, (FLAGS & kResNtLoad) != 0>(&p1[base + off + u * kBlock]);
+                x0[s][u] = res_ld<T, (FLAGS & kResNtLoad) != 0>(&p0[base + off + u * NT]);
+                if (Op::NIN > 1) x1[s][u] = res_ld<T, (FLAGS & kResNtLoad) != 0>(&p1[base + off + u * NT]);
+                if (BITS) xb[s][u] = A.bits[(size_t)l_inst * A.bits_stride + (((size_t)(off + u * NT) * VN) >> 3)];
             }
             l_inst += A.adv_q;
             l_tile += A.adv_r;
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(kBlock, BPC) void ew_resident(const Op* __restrict_
             const size_t base = (size_t)r_inst[sN] * nv;
             const unsigned off = min(r_tile[sN] * TV, nv - TV) + tid;
 #pragma unroll
-            for (int u = 0; u < U; ++u) xold[sN][u] = pold[base + off + u * kBlock];
+            for (int u = 0; u < U; ++u) xold[sN][u] = pold[base + off + u * NT];
         }
         // ---- moments of round j - DL
         if (STEADY || (j >= (unsigned long long)DL && r_live[sM])) {
@@ -253,13 +282,14 @@ __global__ __launch_bounds__(kBlock, BPC) void ew_resident(const Op* __restrict_
             unsigned long long cnt = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const unsigned i = off + u * kBlock;
+                const unsigned i = off + u * NT;
                 const bool counts = i >= first;
                 V vr;
 #pragma unroll
                 for (int c = 0; c < VN; ++c) {
                     const T a0 = vget<T>(x0[sM][u], c);
-                    const T a1 = (Op::NIN > 1) ? vget<T>(x1[sM][u], c) : a0;
+                    T a1 = (Op::NIN > 1) ? vget<T>(x1[sM][u], c) : a0;
+                    if (BITS) a1 = ((xb[sM][u] >> (((i * VN) & 7u) + c)) & 1u) ? T(1) : T(-1);
                     EwOut<T> o = op.eval(a0, a1);
                     double vi = (double)o.v;
                     if (not_finite(o.r)) vi = __longlong_as_double(0x7ff8000000000000LL);
@@ -273,18 +303,19 @@ __global__ __launch_bounds__(kBlock, BPC) void ew_resident(const Op* __restrict_
                     }
                 }
                 if (STORE_R) {
-                    V* dst = counts ? &pr[base + i] : reinterpret_cast<V*>(A.dummy) + tid + u * kBlock;
+                    V* dst = counts ? &pr[base + i] : reinterpret_cast<V*>(A.dummy) + tid + u * NT;
                     __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&vr), reinterpret_cast<NV*>(dst));
                 }
                 // keep (b, r): b in the ring, r in LDS
                 if (Op::TARGET != 0) x0[sM][u] = x1[sM][u];
-                r_lds[lm][u][tid] = vr;
+                if (FLAGS & kResRegR) x1[sM][u] = vr;
+                else r_lds[lm][u][tid] = vr;
                 // one 16-byte piece at a time: interleaving all U evaluations (the scheduler's choice when left alone) needs
                 // U times the temporaries, and the ring leaves no room for them
-                __builtin_amdgcn_sched_barrier(0);
+                if (FLAGS & kResSchedBarrier) __builtin_amdgcn_sched_barrier(0);
             }
-            acc = block_sum(acc, smem);
-            if (COUNT) cnt = block_sum_u64(cnt, smem_u);
+            acc = res_block_sum<NT>(acc, smem);
+            if (COUNT) cnt = res_block_sum_u64<NT>(cnt, smem_u);
             if (tid == 0 && DBG != 1) {
                 unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
                 if (ab == kResSentinel) ab = 0x7ff8000000000000ull;
@@ -312,14 +343,14 @@ __global__ __launch_bounds__(kBlock, BPC) void ew_resident(const Op* __restrict_
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 V vo;
-                const V vr = r_lds[la][u][tid];
+                const V vr = (FLAGS & kResRegR) ? x1[sA][u] : r_lds[la][u][tid];
 #pragma unroll
                 for (int c = 0; c < VN; ++c) {
                     T bn = vget<T>(vr, c) * vinv - vget<T>(x0[sA][u], c);
                     if (DAMP) bn = dT * vget<T>(xold[sA][u], c) + omd * bn;
                     vset<T>(vo, c, bn);
                 }
-                V* dst = (off + u * kBlock >= first) ? &pb[base + off + u * kBlock] : reinterpret_cast<V*>(A.dummy) + tid + u * kBlock;
+                V* dst = (off + u * NT >= first) ? &pb[base + off + u * NT] : reinterpret_cast<V*>(A.dummy) + tid + u * NT;
                 __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&vo), reinterpret_cast<NV*>(dst));
             }
         }

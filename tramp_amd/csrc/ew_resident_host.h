@@ -15,9 +15,19 @@ constexpr int kResU = 4, kResDL = 1, kResDA = 3;
 template <typename Op> struct ResidentOp { static constexpr bool value = false; };
 template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value = true; };
+template <typename T> struct ResidentOp<SgnLikOp<T>> { static constexpr bool value = true; };
+template <typename T> struct ResidentOp<AbsLikOp<T>> { static constexpr bool value = true; };
+template <typename T> struct ResidentOp<SgnLikBitsOp<T>> { static constexpr bool value = true; };
+// (the two-region channels K7 are bound by their arithmetic, not by the second pass: their resident form measured
+// no faster in f64 - the erfcx tables beside the parked r leave room for one workgroup per CU - and slower in f32)
+
+// The shape test (instances of at least one tile that fit the pipeline's window, enough tiles for four rounds, 16-byte
+// rows).  Shared with the producers of prior_hint.h: an FFT epilogue whose consumer takes the resident form leaves no
+// moments (they cost it +45...65 us at 64 x 1e6, more than the resident update costs over the plain apply pass).
+bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size);
 
 // TRAMP_OK: the update ran (launched) in the resident form; kResNotEligible: shape or outputs it does not cover;
 // anything else: an error, ctx->err is set.
 template <typename T, typename Op>
 int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const void* in0, const void* in1,
-                 const double* a_in_d, const MsgOut& out);
+                 const double* a_in_d, const MsgOut& out, const void* bits = nullptr, size_t bits_stride = 0);

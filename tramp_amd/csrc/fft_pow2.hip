@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "fft_pow2.h"
+#include "ew_resident_host.h"
 
 namespace {
 
@@ -739,7 +740,7 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
             // tiles inside one instance (an instance = rows_per_inst rows of LB points)
             const size_t ppi = (e2.rows_per_inst ? e2.rows_per_inst : 1) * sh.LB;
             const int hk = ctx->hint.kind;
-            if (ppi % (size_t)tile_pts == 0 &&
+            if (ppi % (size_t)tile_pts == 0 && !resident_covers(ctx, 2 * ppi, total_pts / ppi, sizeof(T)) &&
                 (hk == PRIOR_HINT_GB || hk == PRIOR_HINT_L1 || (hk == PRIOR_HINT_SGN_LIK && sizeof(T) == 8)))
                 prior_hint_arm(ctx, e2.out, 2 * ppi, total_pts / ppi, (int)(ppi / (size_t)tile_pts), &e2.hint);
             hipLaunchKernelGGL((fft_block_kernel<T, true, true>), dim3(g2), dim3(blk_threads), lds2, ctx->stream, sh,
@@ -768,7 +769,7 @@ static int fft2_run_t(tramp_ctx* ctx, const Fft2Plan* pl, size_t batch, bool inv
             // gpurun_out/r03/fused1.log, fused2.log.  The dense channel's fold kernels arm for every kind.
             e2.hint.kind = PRIOR_HINT_NONE;
             const int hk = ctx->hint.kind;
-            if (e2.rows_per_inst <= 1 &&
+            if (e2.rows_per_inst <= 1 && !resident_covers(ctx, 2 * sh.h, batch, sizeof(T)) &&
                 (hk == PRIOR_HINT_GB || hk == PRIOR_HINT_L1 || (hk == PRIOR_HINT_SGN_LIK && sizeof(T) == 8)))
                 prior_hint_arm(ctx, e2.out, 2 * sh.h, batch, (int)(sh.LB / kC1), &e2.hint);
             hipLaunchKernelGGL((fft_strided_kernel<T, true, true>), dim3(g1), dim3(str_threads), lds1, ctx->stream, sh,

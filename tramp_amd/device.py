@@ -135,6 +135,12 @@ class Context:
         self._call("tramp_prior_hint_stats", C.byref(a), C.byref(u))
         return a.value, u.value
 
+    def resident_covers(self, dtype, n, batch):
+        "do updates of `batch` instances of n components take the resident single-pass form? (csrc/ew_resident.h)"
+        yes = C.c_int()
+        self._call("tramp_resident_covers", _DT[np.dtype(dtype)], int(n), int(batch), C.byref(yes))
+        return bool(yes.value)
+
     def resident_runs(self):
         "factor updates that took the resident single-pass pipeline since the context was made - csrc/ew_resident.h"
         r = C.c_ulonglong()
