@@ -61,6 +61,11 @@ def parse():
     ap.add_argument("--no-denoiser", action="store_true")
     ap.add_argument("--no-se", action="store_true")
     ap.add_argument("--no-tts", action="store_true", help="skip the time-to-solution runs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[4] EP legs")
+    ap.add_argument("--cs1bit-n", type=int, default=int(os.environ.get("TRAMP_BENCH_CS1BIT_N", 49152)),
+                    help="N of the 1-bit CS leg (fp32, alpha = 0.7, 64 instances)")
+    ap.add_argument("--twolayer-n", type=int, default=int(os.environ.get("TRAMP_BENCH_TWOLAYER_N", 65536)),
+                    help="input size of the two-layer leg (fp32, alpha = 0.5 per layer, 64 instances)")
     ap.add_argument("--cpu-n", type=int, default=4000)
     ap.add_argument("--cpu-n-thin", type=int, default=8000)
     ap.add_argument("--save-factors", default=None, metavar="DIR",
@@ -261,8 +266,9 @@ def denoiser_roofline(T, ctx, dtype):
                      FFT, the N = 1e6 operator) also leaves sum v_i (csrc/prior_hint.h), the prior update is
                      ONE streaming pass.  The time charged is that pass PLUS what the moments add to the
                      producer (producer with hint - producer without).
-      B64_standalone the prior called on a message whose producer is unknown: moments pass + update pass
-                     (3T bytes moved for 2T algorithmic).
+      B64_standalone the prior called on a message whose producer is unknown: the resident single-pass pipeline
+                     (csrc/ew_resident.h; 2T moved) - the tile kernels' moments pass + update pass (3T) where the
+                     shape is outside the pipeline's window.
       B1             one instance (latency regime, data stays in cache); B4096_n4096: an instance fits one
                      workgroup's registers, single launch."""
     out = {}
@@ -274,12 +280,21 @@ def denoiser_roofline(T, ctx, dtype):
         p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
         a_new = ctx.empty((B,), np.float64)
         b_new = ctx.empty((B, N), np_dt)
-        ms = _timed(ctx, lambda: p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new), 50 if B == 1 else 10)
+        call = lambda: p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)      # noqa: E731
+        runs0 = ctx.resident_runs()
+        if B == 64:
+            # per-call HIP-event samples, median: the first calls after the dense loop run on a package that is still
+            # coming back from its power limit (a mean over 10 calls read 7 % high)
+            ms = float(np.median(_event_samples(ctx, [call], 30)[0]))
+        else:
+            ms = _timed(ctx, call, 50 if B == 1 else 10)
+        resident = ctx.resident_runs() > runs0
         alg = 2 * esz * N * B
         key = {1: "B1", 64: "B64_standalone", 4096: f"B{B}_n{N}"}[B]
         out[key] = {"n": N, "batch": B, "us_per_update": ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
                     "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS, "components_per_sec": N * B / (ms * 1e-3),
-                    "form": "moments pass + update pass (3T moved)" if B == 64 else
+                    "form": ("resident single-pass pipeline (csrc/ew_resident.h): every byte crosses HBM once, 2T moved"
+                             if resident else "moments pass + update pass (3T moved)") if B == 64 else
                             ("single launch, instance in registers" if B == 4096 else "two launches, cache resident")}
         del bx, b_new
     # the fused form, measured on the pair (producer, prior) that EP runs at N = 1e6
@@ -430,11 +445,20 @@ def factor_updates_n1e6(T, ctx, dtype):
              ("abs_bwd", "K7", 3, lambda: abs_.compute_backward_message(az, bz, ax, bx, **kw))]
     out = {"n": N, "batch": B}
     for name, kern, nT, fn in cases:
-        ms = _timed(ctx, fn, 8)
+        runs0 = ctx.resident_runs()
+        ms = float(np.median(_event_samples(ctx, [fn], 12)[0]))
+        resident = ctx.resident_runs() > runs0
         alg = nT * esz * N * B
         rec = {"kernel": kern, "us_per_update": ms * 1e3, "algorithmic_bytes_per_component": nT * esz,
                "algorithmic_GBps": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
-               "components_per_sec": N * B / (ms * 1e-3)}
+               "components_per_sec": N * B / (ms * 1e-3),
+               "form": "resident single-pass pipeline (csrc/ew_resident.h)" if resident else
+                       "tile kernels: moments pass + update pass"}
+        if resident and name == "sgn_lik":
+            # y in {-1, +1} travels as one bit per component: what the update MOVES is 2T + 1/8 byte, the
+            # algorithmic 3T of SURVEY 8d stays the yardstick of frac_of_hbm_peak
+            rec["moved_bytes_per_component"] = 2 * esz + 0.125
+            rec["moved_GBps"] = (2 * esz + 0.125) * N * B / ms / 1e6
         if dtype == "f64":
             instr = VALU_PER_COMPONENT_F64[name]
             rec["valu_instructions_per_component"] = instr
@@ -691,6 +715,113 @@ def whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, lin_factors, args, np_dt, t
                     "as the headline line"}
 
 
+def _tag_report(ctx):
+    NT = len(TAGS)
+    cnt, ms, by, fl = (C.c_int * NT)(), (C.c_double * NT)(), (C.c_double * NT)(), (C.c_double * NT)()
+    ctx._call("tramp_profile_report", cnt, ms, by, fl)
+    return {TAGS[i]: {"launches": cnt[i], "ms": ms[i], "bytes": by[i], "flops": fl[i]} for i in range(NT) if cnt[i]}
+
+
+def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1):
+    """BASELINE configs[2] (1-bit compressed sensing, alpha = 0.7, fp32) and configs[4] (two-layer ReLU GLM) as EP
+    ensembles of B instances sharing their Gaussian-ensemble matrices, at the largest N whose factorisation fits the
+    bench's time budget (the named sizes fit the memory, not a few minutes of set-up; the full-size
+    two-layer run is profiles/r04/twolayer_N200000_f32.json).  Same protocol as the headline: factors from
+    tramp_linear_factorize (timed, reported), `warmup` untimed iterations, `steps` timed ones with PassCallback (no
+    instance freezes), per-kernel HIP-event times for the roofline of the dominant kernel."""
+    import gc
+    dt = T.device.dtype_code(np_dt)
+    dname = "f64" if np_dt == np.float64 else "f32"
+    rs = np.random.RandomState(7)
+
+    def dev_matvec(Wd, M_, N_, Xh):
+        Xd = ctx.array(Xh.astype(np_dt), np_dt)
+        Zd = ctx.empty((Xh.shape[0], M_), np_dt)
+        ctx._call("tramp_matvec_nt", dt, 0, M_, N_, Xh.shape[0], Wd.ptr, Xd.ptr, Zd.ptr)
+        return Zd.get().astype(np.float64)
+
+    ctx.sync()
+    t0 = time.perf_counter()
+    if which == "cs1bit":
+        rho = 0.25
+        M = int(0.7 * N) // 4 * 4
+        W = ctx.randn((M, N), np_dt, seed=11, scale=N ** -0.5)
+        X = rs.standard_normal((B, N)) * rs.binomial(1, rho, (B, N))
+        Y = np.sign(dev_matvec(W, M, N, X))
+        Y[Y == 0] = 1.0
+        ctx.sync()
+        tf = time.perf_counter()
+        lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device")
+        ctx.sync()
+        fact_s = time.perf_counter() - tf
+        del W
+        model = (T.GaussBernoulliPrior(size=N, rho=rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x") @ lin
+                 @ T.SISOVariable(id="z") @ T.SgnLikelihood(y=Y.astype(np_dt), dtype=np_dt, ctx=ctx)).to_model()
+        shape = {"N": N, "M": M, "alpha": 0.7, "rho": rho}
+        workload = ("BASELINE configs[2]: 1-bit compressed sensing EP, GaussBernoulliPrior(rho=0.25) + dense "
+                    "LinearChannel (Gaussian ensemble) + SgnLikelihood, alpha = 0.7")
+        flops_per_iter = 4.0 * M * N * B * 2            # two posterior solves x (row-dot + column pass) in the thin basis
+        k_dense = min(M, N)
+
+        def score(ep):      # sign retrieval: overlap of the normalised estimate with the signal
+            r = np.asarray(ep.get_variables_data()["x"]["r"]).reshape(B, N)
+            return {"overlap": float(np.mean(np.sum(r * X, 1) / (np.linalg.norm(r, axis=1) * np.linalg.norm(X, axis=1))))}
+    else:
+        M1, M2 = N // 2, N // 4
+        W1 = ctx.randn((M1, N), np_dt, seed=12, scale=N ** -0.5)
+        W2 = ctx.randn((M2, M1), np_dt, seed=13, scale=M1 ** -0.5)
+        X = rs.standard_normal((B, N))
+        A1 = np.maximum(0, dev_matvec(W1, M1, N, X))
+        Y = dev_matvec(W2, M2, M1, A1) + 0.1 * rs.standard_normal((B, M2))
+        ctx.sync()
+        tf = time.perf_counter()
+        l1 = T.LinearChannel(W1, dtype=np_dt, ctx=ctx, svd="device")
+        del W1
+        l2 = T.LinearChannel(W2, dtype=np_dt, ctx=ctx, svd="device")
+        del W2
+        ctx.sync()
+        fact_s = time.perf_counter() - tf
+        model = T.MultiLayerModel([T.GaussianPrior(size=N, dtype=np_dt, ctx=ctx), l1, T.ReluChannel(dtype=np_dt, ctx=ctx),
+                                   l2, T.GaussianLikelihood(y=Y.astype(np_dt), var=1e-2, dtype=np_dt, ctx=ctx)],
+                                  ids=["x", "z1", "a1", "z2", "y"])
+        shape = {"N": N, "M1": M1, "M2": M2, "alpha_layers": 0.5}
+        workload = ("BASELINE configs[4]: two-layer GLM EP, GaussianPrior -> LinearChannel(W1) -> ReluChannel -> "
+                    "LinearChannel(W2) -> GaussianLikelihood(var=0.01), alpha = 0.5 per layer")
+
+        def score(ep):
+            return {"mse_hidden": float(np.mean(ep.mse("a1", A1)))}
+    setup_s = time.perf_counter() - t0
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=max(warmup, 1), callback=T.PassCallback(), damping=damping, check_every=1 << 30)
+    ctx._call("tramp_profile_enable", 1)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ep.iterate(max_iter=steps, callback=T.PassCallback(), damping=damping, warm_start=True, check_every=1 << 30)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    kern = _tag_report(ctx)
+    ctx._call("tramp_profile_enable", 0)
+    dom = max(kern, key=lambda kk: kern[kk]["ms"])
+    d = kern[dom]
+    mat = [kern[t] for t in ("matvec_nt", "matvec_nn") if t in kern]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else None
+    out = {"workload": workload, "dtype": dname, "instances": B, **shape, "steps": steps, "warmup": warmup,
+           "damping": damping, "ms_per_iteration": el / steps * 1e3,
+           "msg_components_per_sec": float(N) * B * steps / el,
+           "setup": {"total_s": setup_s, "factorize_s": fact_s},
+           "kernels": kern,
+           "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dname],
+                        "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dname] if ach else None,
+                        "avg_launch_ms": d["ms"] / d["launches"], "launches": d["launches"], "traffic": None},
+           "dense_passes_TFLOPs": (sum(m["flops"] for m in mat) / (sum(m["ms"] for m in mat) * 1e-3) / 1e12) if mat else None,
+           "elementwise_GBps_algorithmic": (kern["ew_factor_update"]["bytes"] / (kern["ew_factor_update"]["ms"] * 1e-3) / 1e9)
+           if "ew_factor_update" in kern else None,
+           **score(ep)}
+    del ep, model
+    gc.collect()
+    return out
+
+
 def run(args):
     import tramp_amd as T
     from tramp_amd import ensemble
@@ -769,7 +900,12 @@ def run(args):
             bcast_s = float(sum(secs))
             nbytes = float(sum(arr.nbytes for _, arr in parts))
             bcast_detail = {"bytes": nbytes, "seconds": bcast_s, "GBps": nbytes / max(bcast_s, 1e-9) / 1e9,
-                            "pieces": {name: {"bytes": arr.nbytes, "seconds": sec}
+                            "backend": comm.backend, "world": world,
+                            "decision": "RCCL ncclBroadcast of the thin factors in <= 1 GiB pieces (csrc/comm.hip); "
+                                        "the socket fallback (every rank factorises) is taken only when RCCL refuses "
+                                        "the communicator",
+                            "pieces": {name: {"bytes": arr.nbytes, "seconds": sec,
+                                              "GBps": arr.nbytes / max(sec, 1e-9) / 1e9}
                                        for (name, arr), sec in zip(parts, secs)}}
             lin_rank = int(comm.gather_scalars([lin_rank])[0, 0])
             Z = Zd_all.get()[start:stop]
@@ -877,7 +1013,12 @@ def run(args):
             "kernels": kern,
             "setup": {"total_s": setup_s, "factorize_s": factorize_s,
                       "factor_residuals": residuals, "teacher_z": z_source,
-                      "broadcast_factors_s": bcast_s, "broadcast": bcast_detail,
+                      "broadcast_factors_s": bcast_s,
+                      "broadcast": bcast_detail if bcast_detail is not None else (
+                          None if comm is None else
+                          {"backend": comm.backend, "world": world, "seconds": 0.0,
+                           "decision": "RCCL refused the communicator (e.g. two ranks on one device): every rank computed "
+                                       "the factors itself, results travel over host sockets"}),
                       "factors_loaded_from": args.load_factors,
                       "eigensolver": "spectral divide and conquer + rocSOLVER syevd halves" if k > 46336
                                      else "rocSOLVER syevd"},
@@ -942,7 +1083,7 @@ def run(args):
                 out["structured_2d"] = {"error": repr(e)}
         if world == 1 and not args.no_denoiser and not args.load_factors:
             try:
-                del ep, model
+                ep = model = None                                             # noqa: F841
                 out["ensemble_x8_one_gpu"] = whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, (Uk, sing, Vt), args, np_dt,
                                                                        8 * B)
             except Exception as e:                                            # noqa: BLE001
@@ -958,6 +1099,17 @@ def run(args):
                 out["cpu_baseline"]["like_for_like"] = cpu_like_for_like((Uk, sing, Vt, lin_rank), Y, args)
             except Exception as e:                                            # noqa: BLE001
                 out["cpu_baseline"]["like_for_like"] = {"error": repr(e)}
+        if world == 1 and not args.no_configs:
+            # BASELINE configs[2] and configs[4] as EP runs (the headline's factors are released first)
+            import gc
+            ep = model = lin = Uk = Vt = None             # noqa: F841  (60 GB of factors and the message buffers go)
+            gc.collect()
+            for key, which, n_cfg in (("config2_cs1bit", "cs1bit", args.cs1bit_n), ("config4_twolayer", "twolayer", args.twolayer_n)):
+                try:
+                    out[key] = other_config(T, ctx, which, n_cfg, 64, np.float32)
+                except Exception as e:                                        # noqa: BLE001
+                    out[key] = {"error": repr(e)}
+                gc.collect()
         emit_result(out)
     if comm is not None:
         # the line is out: a peer that died after the timed region must not turn a finished measurement into a

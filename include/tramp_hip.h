@@ -238,7 +238,10 @@ int tramp_pwl3_channel(tramp_ctx* ctx, int dtype, int dir, size_t n, size_t batc
 /* Three-region LIKELIHOODS with the same region table as tramp_pwl3_channel (y_d observed):
  * HardTanhLikelihood, HardSigmoidLikelihood, SymmetricDoorLikelihood
  * (tramp/likelihoods/piecewise_linear_likelihood.py:9-63,156-205,293-320): what
- * Model.to_observed turns an observed three-region output channel into. */
+ * Model.to_observed turns an observed three-region output channel into.  z_lo == z_hi with a sloped middle region
+ * leaves two half lines: AsymmetricAbsLikelihood (:260-265, registry key "a-abs") is slopes (1, any, -1), x0 = 0,
+ * z_lo = z_hi = shift.  A sloped region contributes -az z^2/2 + bz z - log|slope| (the reference subtracts
+ * log(slope): NaN for the descending branch, so its AsymmetricAbsLikelihood is NaN everywhere - DESIGN 10.3). */
 int tramp_pwl3_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
                        double z_lo, double z_hi, const double* slopes3, const double* x03,
                        const double* az_d, const void* bz_d, const void* y_d,
@@ -704,6 +707,19 @@ int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, double z_hi,
                       const double* az, const double* tau_z, double* v);
 
 /* ---- log-partitions -------------------------------- */
+/* Log-partition of a factor given as a TABLE OF LINEAR REGIONS - the rest of the piecewise-linear family (LeakyRelu,
+ * AsymmetricAbs, HardTanh, HardSigmoid, SymmetricDoor and their observed twins), restated as the reference loops:
+ * regions_h = nreg (2 or 3) host rows (zmin, zmax, slope, x0) in the reference's order, +-INFINITY for open ends.
+ * mode 0, a channel: A_k = truncated_normal_logZ(b/a, 1/a, zmin, zmax) - ax x0^2 / 2 + bx x0 with a = az + slope^2 ax,
+ *   b = bz + slope (bx - ax x0) (tramp/utils/linear_region.py:55-64); out[b] = sum_i logsumexp_k A_k
+ *   (tramp/channels/activation/piecewise_linear_channel.py:55-58); v1_d = bx.
+ * mode 1, a likelihood: a flat region holds truncated.A(az, bz, zmin, zmax) where y == x0, a sloped one
+ *   -az z^2 / 2 + bz z - log|slope| where z = (y - x0)/slope lies strictly inside, -inf otherwise
+ *   (tramp/likelihoods/piecewise_linear_likelihood.py:52-61); out[b] = sum_i logsumexp_k (the host takes the mean,
+ *   :216-219); v1_d = y, ax_d unused.  (The reference writes log(slope): NaN on a descending branch.) */
+int tramp_region_log_partition(tramp_ctx* ctx, int dtype, int mode, int nreg, const double* regions_h, size_t n,
+                               size_t batch, const double* az_d, const void* bz_d, const double* ax_d,
+                               const void* v1_d, double* out_d);
 /* Terms of the EP log-evidence (tramp/algos/message_passing.py:306-328): out_d[b] = SUM over the
  * n components of the factor's / variable's log-partition, formed in double.  The caller divides
  * by n where the reference takes the mean (priors, likelihoods: e.g. gauss_bernoulli_prior.py:79-83,

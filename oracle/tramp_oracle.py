@@ -252,6 +252,23 @@ def _switch(x, y):
     return np.where(sw, y, x), np.where(sw, x, y)
 
 
+def pwl_log_Phi_masks(kind, az, bz, ax, bx):
+    """The boolean index arrays `nonzero = (x < 30)` that log_Phi (tramp/utils/truncated_normal.py:21-29) takes for
+    the (pos, neg) regions of a Sgn / Abs / Relu channel: x = -s (0 - r0)/sqrt(v0) with (r0, v0) from
+    LinearRegion.get_r0_v0 (utils/linear_region.py:32-37) and s = +1 / -1 (G0_inf, :218-221), every operation as the
+    reference orders it."""
+    bz = np.asarray(bz, dtype=float)
+    bx = np.asarray(bx, dtype=float)
+    out = []
+    for side, slope, x0 in PWL_REGIONS[kind]:
+        a = az + slope**2 * ax
+        b = bz + slope * (bx - ax * x0)
+        r0, v0 = b / a, 1 / a
+        y0 = (0 - r0) / np.sqrt(v0)
+        out.append((-side * y0) < 30)
+    return out
+
+
 def interval_branch_masks(x, y, thresh=1e-7):
     """(close, neg, pos, other) of truncated_normal.py:68-82 for FINITE bounds, on the switched pair."""
     x, y = _switch(np.asarray(x, dtype=float), np.asarray(y, dtype=float))
@@ -1590,6 +1607,129 @@ def pwl_channel_log_partition(kind, az, bz, ax, bx, param=None):
     As = [pwl_region_terms(side, slope, x0, az, np.asarray(bz, float), ax, np.asarray(bx, float), zb)[2]
           for side, slope, x0, zb in pwl_regions(kind, param)]
     return np.logaddexp(As[0], As[1]).sum()
+
+
+# --------------------------------------------------------------------------
+# Region tables: the rest of the piecewise-linear family, region by region as the
+# reference loops.  A region is (zmin, zmax, slope, x0); the tables are the reference constructors'
+# (channels/activation/piecewise_linear_channel.py:72-132, likelihoods/piecewise_linear_likelihood.py:244-320).
+# --------------------------------------------------------------------------
+def f2_regions(name, likelihood=False, **kw):
+    inf = np.inf
+    if name == "relu":
+        return [(0., inf, 1., 0.), (-inf, 0., 0., 0.)]
+    if name == "l-relu":
+        return [(0., inf, 1., 0.), (-inf, 0., float(kw["slope"]), 0.)]
+    if name == "a-abs":
+        s = float(kw.get("shift", 1e-4))
+        return [(s, inf, 1., 0.), (-inf, s, -1., 0.)]
+    if name == "h-tanh":
+        return [(1., inf, 0., 1.), (-1., 1., 1., 0.), (-inf, -1., 0., -1.)]
+    if name == "h-sigm":
+        L = 3. if likelihood else 2.5          # the likelihood twin uses l = 3 (:302-309), the channel 2.5 (:117-123)
+        return [(L, inf, 0., 1.), (-L, L, 1 / (2 * L), 0.5), (-inf, -L, 0., 0.)]
+    if name == "door":
+        w = float(kw["width"])
+        return [(w, inf, 0., 1.), (-w, w, 0., -1.), (-inf, -w, 0., 1.)]
+    raise KeyError(name)
+
+
+def _scipy_logsumexp(As):
+    "scipy.special.logsumexp(As, axis=0): the maximum is taken out unless it is not finite"
+    A = np.stack(As)
+    with np.errstate(all="ignore"):
+        m = np.max(A, axis=0)
+        m = np.where(np.isfinite(m), m, 0.)
+        return np.log(np.sum(np.exp(A - m), axis=0)) + m
+
+
+def region_trunc_logZ(zmin, zmax, r0, v0):
+    "truncated_normal_logZ (tramp/utils/truncated_normal.py:294-298)"
+    _, _, logp = _region_moments(zmin, zmax, r0, v0)
+    return 0.5 * np.log(2 * np.pi * v0) + 0.5 * r0**2 / v0 + logp
+
+
+def region_channel_log_partition(regions, az, bz, ax, bx):
+    "LinearRegion.log_partitions (utils/linear_region.py:55-64), PiecewiseLinearChannel.compute_log_partition (:55-58)"
+    bz = np.asarray(bz, dtype=float)
+    bx = np.asarray(bx, dtype=float)
+    As = []
+    for zmin, zmax, slope, x0 in regions:
+        a = az + slope**2 * ax
+        b = bz + slope * (bx - ax * x0)
+        As.append(region_trunc_logZ(zmin, zmax, b / a, 1 / a) - 0.5 * ax * x0**2 + bx * x0)
+    return _scipy_logsumexp(As).sum()
+
+
+def _region_lik_terms(regions, az, bz, y, abs_slope):
+    """LinearRegionLikelihood.backward_mean / backward_variance / log_partitions (:31-61).  abs_slope=False is the
+    reference as written (np.log(slope): NaN on a descending branch); True takes the Jacobian |slope|."""
+    bz = np.asarray(bz, dtype=float)
+    y = np.asarray(y, dtype=float) + np.zeros_like(bz)
+    rs, vs, As = [], [], []
+    for zmin, zmax, slope, x0 in regions:
+        if slope == 0:
+            contains = (y == x0)
+            m, v, _ = _region_moments(zmin, zmax, bz / az, 1 / az)
+            r_k, v_k = m, v
+            A_k = region_trunc_logZ(zmin, zmax, bz / az, 1 / az)
+        else:
+            z = (y - x0) / slope
+            contains = (zmin < z) & (z < zmax)
+            r_k, v_k = z, np.zeros_like(z)
+            with np.errstate(all="ignore"):
+                A_k = -0.5 * az * (z**2) + bz * z - np.log(abs(slope) if abs_slope else slope)
+        rs.append(np.where(contains, r_k, 0))
+        vs.append(np.where(contains, v_k, 0))
+        As.append(np.where(contains, A_k, -np.inf))
+    return rs, vs, As
+
+
+def region_lik_log_partition(regions, az, bz, y, abs_slope=False):
+    "PiecewiseLinearLikelihood.compute_log_partition (:216-219)"
+    _, _, As = _region_lik_terms(regions, az, bz, y, abs_slope)
+    return _scipy_logsumexp(As).mean()
+
+
+def region_lik_posterior(regions, az, bz, y, isotropic=True, abs_slope=False):
+    "PiecewiseLinearLikelihood.compute_backward_posterior (:198-214): softmax of the regions' log-partitions"
+    rs, vs, As = _region_lik_terms(regions, az, bz, y, abs_slope)
+    A = np.stack(As)
+    with np.errstate(all="ignore"):
+        e = np.exp(A - A.max(axis=0, keepdims=True))
+        ps = e / e.sum(axis=0, keepdims=True)
+    r = sum(p_ * r_ for p_, r_ in zip(ps, rs))
+    v = sum(p_ * v_ for p_, v_ in zip(ps, vs))
+    n = len(rs)
+    for i in range(n):
+        for j in range(i + 1, n):
+            v = v + ps[i] * ps[j] * (rs[i] - rs[j])**2
+    if isotropic:
+        v = v.mean()
+    return r, v
+
+
+def aabs_lik_message(az, bz, y, shift=1e-4, abs_slope=True):
+    "AsymmetricAbsLikelihood (:260-265) through ab_new; abs_slope=False reproduces the reference's NaNs"
+    r, v = region_lik_posterior(f2_regions("a-abs", shift=shift), az, bz, y, abs_slope=abs_slope)
+    return ab_new(r, v, az, bz)
+
+
+def se_aabs_lik_error(az, tau_z, shift=1e-4, nz=4001, nxi=128):
+    """beliefs_measure (:120-146, 210-214) for the two sloped regions of AsymmetricAbs: E over z ~ N(0, tau_z),
+    xi ~ N(0, 1) of v(bz = mz z + sqrt(mz) xi, y = y(z)) with the |slope| Jacobian - a dense trapezoid in z (the
+    integrand has kinks at +-shift) times Gauss-Hermite in xi."""
+    mz = az - 1 / tau_z
+    assert mz > 0
+    regions = f2_regions("a-abs", shift=shift)
+    s0 = np.sqrt(tau_z)
+    z = np.linspace(-9 * s0, 9 * s0, nz)
+    xi, w = np.polynomial.hermite_e.hermegauss(nxi)
+    y = np.where(z >= shift, z, -z)
+    bz = mz * z[:, None] + np.sqrt(mz) * xi[None, :]
+    _, v = region_lik_posterior(regions, az, bz, y[:, None], isotropic=False, abs_slope=True)
+    f = (np.nan_to_num(v) @ (w / np.sqrt(2 * np.pi))) * np.exp(-0.5 * z**2 / tau_z) / np.sqrt(2 * np.pi * tau_z)
+    return np.trapezoid(f, z)
 
 
 def variable_log_partition(a, b):

@@ -60,6 +60,13 @@ def golden_pwl3_lik():
 
 
 @pytest.fixture(scope="session")
+def golden_f2_logz():
+    "log-partitions of the rest of the piecewise-linear family, from the reference (tools/make_golden_f2.py)"
+    with np.load(os.path.join(GOLDEN, "f2_logz.npz"), allow_pickle=True) as f:
+        return list(f["cases"])
+
+
+@pytest.fixture(scope="session")
 def golden_unitary():
     path = os.path.join(GOLDEN, "unitary.npz")
     with np.load(path, allow_pickle=True) as f:

@@ -21,8 +21,8 @@ def test_bench_prints_one_json_line(force_dist):
     if force_dist:
         env["TRAMP_BENCH_FORCE_DIST"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2048", "--batch", "4", "--steps", "3",
-                        "--warmup", "1", "--no-cpu-baseline", "--no-denoiser", "--no-se"], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--no-cpu-baseline", "--no-denoiser", "--no-se", "--cs1bit-n", "2048",
+                        "--twolayer-n", "2048"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = r.stdout.splitlines()
     assert len(lines) == 1, r.stdout[:2000]
@@ -45,13 +45,21 @@ def test_bench_prints_one_json_line(force_dist):
     assert sum(tts["headline"]["status_counts"]) == 4
     assert tts["n1000"]["total_s_median"] > 0 and all(5 < n < 200 for n in tts["n1000"]["n_iter"])
     assert all(m < 2e-2 for m in tts["n1000"]["mse"])
+    # BASELINE configs[2] / configs[4] ride in the same line: EP ms per iteration, msg-components/s, dominant kernel
+    c2, c4 = d["config2_cs1bit"], d["config4_twolayer"]
+    assert "error" not in c2 and "error" not in c4, (c2, c4)
+    assert c2["dtype"] == c4["dtype"] == "f32" and c2["N"] == 2048 and c2["M"] == 1432 and c4["M1"] == 1024 and c4["M2"] == 512
+    for c in (c2, c4):
+        assert c["ms_per_iteration"] > 0 and c["msg_components_per_sec"] > 0 and c["setup"]["factorize_s"] > 0
+        assert c["roofline"]["kernel"] in c["kernels"] and c["roofline"]["avg_launch_ms"] > 0
+    assert c2["overlap"] > 0.3 and c4["mse_hidden"] < 0.5
 
 
 def test_bench_refuses_wrong_factors():
     "a factorisation that does not reproduce W stops the run (exit code 3, no result line)"
     env = dict(os.environ, TRAMP_BENCH_CORRUPT_FACTORS="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2048", "--batch", "4", "--steps", "2",
-                        "--warmup", "1", "--no-cpu-baseline", "--no-denoiser", "--no-se", "--no-tts"], env=env, cwd=ROOT,
+                        "--warmup", "1", "--no-cpu-baseline", "--no-denoiser", "--no-se", "--no-tts", "--no-configs"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 3 and r.stdout == "" and "FACTOR RESIDUALS ABOVE TOLERANCE" in r.stderr, r.stderr[-2000:]
 
@@ -67,7 +75,7 @@ def test_two_ranks_on_one_gpu_fall_back_to_sockets():
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "2048",
-                                       "--batch", "8", "--steps", "3", "--warmup", "1"], env=env, cwd=ROOT,
+                                       "--batch", "8", "--steps", "3", "--warmup", "1", "--no-configs"], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     try:

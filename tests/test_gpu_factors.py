@@ -259,19 +259,23 @@ def test_pwl3_interval_branch_masks_bit_exact(T, ctx, golden_factors):
 
 
 def test_pwl_branch_masks_bit_exact(T, ctx, golden_factors):
-    """log_Phi 'x < 30' masks: same comparison on the same f64 operands as the reference."""
+    """log_Phi 'x < 30' masks.  (1) Against the mask the REFERENCE produced (tools/make_golden.py: log_Phi on
+    x = ..., 29.9, nextafter(30, 0), 30, nextafter(30, 31), ...): with az = 1 the sign channel's pos region has
+    r0 = bz, v0 = 1, so its log_Phi argument is bz itself, bit for bit, and the neg region's is -bz.  (2) On the
+    golden channel cases, against the oracle's restatement of the same operand chain."""
+    g = golden_factors["log_Phi"]
+    xs, ref_mask = np.asarray(g["x"], dtype=np.float64), np.asarray(g["mask"], dtype=bool)
+    assert ref_mask.tolist() == (xs < 30).tolist() and ref_mask.sum() == 10           # the fixture itself
+    sgn = T.SgnChannel(ctx=ctx)
+    m_pos, _ = sgn.branch_masks(1.0, xs, 0.7, np.zeros_like(xs))
+    _, m_neg = sgn.branch_masks(1.0, -xs, 0.7, np.zeros_like(xs))
+    assert np.array_equal(m_pos, ref_mask) and np.array_equal(m_neg, ref_mask)
     cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)
     for c in golden_factors["pwl"]:
         ch = cls[c["kind"]](ctx=ctx)
         with np.errstate(all="ignore"):
             m_pos, m_neg = ch.branch_masks(c["az"], c["bz"], c["ax"], c["bx"])
-            exp = []
-            for side, slope, x0 in orc.PWL_REGIONS[c["kind"]]:
-                a = c["az"] + slope**2 * c["ax"]
-                b = c["bz"] + slope * (c["bx"] - c["ax"] * x0)
-                r0, v0 = b / a, 1 / a
-                y0 = (0 - r0) / np.sqrt(v0)
-                exp.append((-side * y0) < 30)
+            exp = orc.pwl_log_Phi_masks(c["kind"], c["az"], c["bz"], c["ax"], c["bx"])
         assert np.array_equal(m_pos, exp[0])
         assert np.array_equal(m_neg, exp[1])
 
@@ -494,6 +498,14 @@ def test_large_properties_pwl_channels_full_size(T, ctx, dtype, kind):
         a_in = 0.7 if d == "fwd" else 1.3
         close_a(a1.get()[0], a_ref, a_in, dtype)
         close(b1.get()[0], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+        if dtype == np.float64 and d == "bwd":
+            # the masks at full size, on device-generated messages stretched so that both sides of the threshold occur
+            wide = ctx.array(bz.get() * 40.0, dtype)
+            m_pos, m_neg = ch.branch_masks(az, wide, ax, bx)
+            exp = orc.pwl_log_Phi_masks(kind, 1.3, wide.get()[0], 0.7, bxh)
+            assert np.array_equal(m_pos[0] if m_pos.ndim == 2 else m_pos, exp[0])
+            assert np.array_equal(m_neg[0] if m_neg.ndim == 2 else m_neg, exp[1])
+            assert 0 < exp[0].sum() < N and 0 < exp[1].sum() < N
         if kind in ("sgn", "abs"):
             # z -> -z: sgn is odd (x -> -x as well), abs is even (x unchanged)
             nz = ctx.array(-bz.get(), dtype)

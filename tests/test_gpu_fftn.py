@@ -485,3 +485,36 @@ def test_nd_channels_extreme_precisions(ctx, kind, monkeypatch):
         np.testing.assert_allclose(rx, wx, rtol=0, atol=1e-9 * max(np.abs(wx).max(), 1e-300), err_msg=f"rx az={az} ax={ax}")
         np.testing.assert_allclose(vz, o.backward_variance(az, ax), rtol=1e-6, atol=1e-12 / az)
         np.testing.assert_allclose(vx, o.forward_variance(az, ax), rtol=1e-6, atol=1e-12 / max(ax, 1e-300))
+
+
+@pytest.mark.parametrize("kind", ["conv", "dft"])
+def test_complex_channels_inside_an_ep_model(ctx, kind):
+    """ConvChannel(real=False) / DFTChannel(real=False) as nodes of a model: the planar (2,) + shape vectors have to
+    reach the scheduler's message buffers (Model._out_shape).  Gaussian prior + linear channel + Gaussian likelihood:
+    EP is exact, the posterior mean of the input has a closed form in the Fourier basis."""
+    import tramp_amd as T
+    rs = np.random.RandomState(5)
+    n, nv = 256, 0.05
+    z = rs.standard_normal(n) + 1j * rs.standard_normal(n)
+    if kind == "conv":
+        f = np.zeros(n, dtype=complex)
+        f[:4] = rs.standard_normal(4) + 1j * rs.standard_normal(4)
+        ch = T.ConvChannel(f, real=False, ctx=ctx)
+        w_hat = np.fft.fft(f)                                   # circular convolution: x = ifft(w_hat fft(z))
+        x = np.fft.ifft(w_hat * np.fft.fft(z))
+    else:
+        ch = T.DFTChannel(real=False, ctx=ctx)
+        x = np.fft.fft(z, norm="ortho")
+    y = x + np.sqrt(nv) * (rs.standard_normal(n) + 1j * rs.standard_normal(n))
+    planar = lambda c: np.stack([c.real, c.imag])               # noqa: E731
+    model = (T.GaussianPrior(size=(2, n), ctx=ctx) @ T.SISOVariable(id="z") @ ch @ T.SISOVariable(id="x")
+             @ T.GaussianLikelihood(y=planar(y).reshape(1, -1), var=nv, ctx=ctx)).to_model()
+    assert model.get_shapes() == {"z": (2, n), "x": (2, n)}
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    ep.iterate(max_iter=5)
+    r = np.asarray(ep.get_variables_data()["z"]["r"]).reshape(2, n)
+    if kind == "conv":
+        ref = np.fft.ifft(np.conj(w_hat) * np.fft.fft(y) / nv / (1 + np.abs(w_hat)**2 / nv))
+    else:
+        ref = np.fft.ifft(y, norm="ortho") / (1 + nv)
+    np.testing.assert_allclose(r[0] + 1j * r[1], ref, rtol=0, atol=1e-9 * np.abs(ref).max())

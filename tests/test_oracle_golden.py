@@ -987,3 +987,43 @@ def test_adaptive_damping_oracle_matches_reference_trajectories():
                                                err_msg=f"{c['output']} it {it} {key} b")
                 np.testing.assert_allclose(st["r"][i], t[f"r:{vid}"], rtol=rt, atol=rt * np.abs(t[f"r:{vid}"]).max())
                 np.testing.assert_allclose(st["v"][i], t[f"v:{vid}"], rtol=rt)
+
+
+# -- the rest of the piecewise-linear family: log-partitions, and the AsymmetricAbs likelihood (section 8f rank 2)
+def test_f2_log_partitions_oracle_matches_reference(golden_f2_logz):
+    for c in golden_f2_logz:
+        if c["family"] == "channel":
+            reg = orc.f2_regions(c["name"], **c["kwargs"])
+            close(orc.region_channel_log_partition(reg, c["az"], c["bz"], c["ax"], c["bx"]), c["A"], rtol=1e-11)
+        else:
+            reg = orc.f2_regions(c["name"], likelihood=True, **c["kwargs"])
+            A = orc.region_lik_log_partition(reg, c["az"], c["bz"], c["y"])
+            r, v = orc.region_lik_posterior(reg, c["az"], c["bz"], c["y"])
+            if c["name"] == "a-abs":
+                # the reference as written: np.log(-1) on the descending branch poisons every output
+                assert np.isnan(c["A"]) and np.isnan(A) and np.isnan(c["v"]) and np.isnan(v) and np.isnan(c["r"]).all()
+            else:
+                close(A, c["A"], rtol=1e-11)
+                close(r, c["r"], rtol=1e-10, atol=1e-12); close(v, c["v"], rtol=1e-10)
+
+
+def test_aabs_likelihood_with_the_jacobian_is_the_abs_likelihood_away_from_the_kink():
+    """with log|slope| the two branches of AsymmetricAbs weigh as softmax(+-bz y): for y > |shift| the posterior is
+    AbsLikelihood's (abs_likelihood.py:31-36); -shift < y <= shift pins z = -y; y <= -shift is incompatible (NaN)"""
+    rs = np.random.RandomState(1)
+    for shift in (1e-4, 0.3):
+        reg = orc.f2_regions("a-abs", shift=shift)
+        y = np.abs(rs.standard_normal(200)) + shift + 1e-3
+        bz = 2 * rs.standard_normal(200)
+        r, v = orc.region_lik_posterior(reg, 1.3, bz, y, isotropic=False, abs_slope=True)
+        r_abs, v_abs = orc.abs_lik_posterior(1.3, bz, y, isotropic=False)
+        close(r, r_abs, rtol=1e-12); close(v, v_abs, rtol=1e-9, atol=1e-12)      # y^2 (1 - tanh^2) cancels where tanh -> 1
+        A = orc.region_lik_log_partition(reg, 1.3, bz, y, abs_slope=True)
+        close(A, orc.abs_lik_log_partition(1.3, bz, y), rtol=1e-12)
+        y2 = np.array([shift, 0.5 * shift, 0.0, -0.5 * shift])
+        r2, v2 = orc.region_lik_posterior(reg, 1.3, np.ones(4), y2, isotropic=False, abs_slope=True)
+        close(r2, -y2); close(v2, 0 * y2)
+        r3, _ = orc.region_lik_posterior(reg, 1.3, np.ones(2), np.array([-shift, -1.0]), isotropic=False, abs_slope=True)
+        assert np.isnan(r3).all()
+    # SE error: the abs likelihood's minus the slab |z| <= shift
+    close(orc.se_aabs_lik_error(1.7, 1.0, shift=1e-4), orc.se_abs_lik_error(1.7, 1.0), rtol=1e-5)

@@ -191,6 +191,40 @@ class Factor(ReprMixin):
             return float(res[0])
         return res
 
+    def _logz_regions(self, mode, regions, az, bz, v1, ax=None, mean=False):
+        """Log-partition of a factor given as a table of linear regions [(zmin, zmax, slope, x0)] in the reference's
+        order, through tramp_region_log_partition: mode 0 = channel (v1 = bx, summed,
+        piecewise_linear_channel.py:55-58), mode 1 = likelihood (v1 = y, mean, piecewise_linear_likelihood.py:216-219)."""
+        ctx = self.ctx
+        reg = np.ascontiguousarray(np.asarray(regions, dtype=np.float64).reshape(-1, 4))
+        if not getattr(self, "isotropic", True) and np.ndim(az) > 0 and not isinstance(bz, DeviceArray):
+            # diagonal beliefs: n instances of one component each, then the reference's mean / sum on the host
+            vh = np.asarray(bz, dtype=self.dtype).reshape(-1, 1)
+            ah = np.broadcast_to(np.asarray(az, dtype=np.float64).ravel(), (vh.shape[0],)).copy()
+            wh = (v1.get() if isinstance(v1, DeviceArray) else np.asarray(v1, dtype=self.dtype)).reshape(-1, 1)
+            axh = None if ax is None else np.broadcast_to(np.asarray(ax, dtype=np.float64).ravel(), (vh.shape[0],)).copy()
+            iso, self.isotropic = self.isotropic, True
+            try:
+                per = np.atleast_1d(self._logz_regions(mode, reg, ah, vh, wh, ax=axh, mean=False))
+            finally:
+                self.isotropic = iso
+            return float(per.mean()) if mean else float(per.sum())
+        v = VecArg(ctx, bz, self.dtype)
+        a = ScalArg(ctx, az, v.batch)
+        w = VecArg(ctx, v1, self.dtype)
+        aa = ScalArg(ctx, ax, v.batch) if ax is not None else None
+        if (w.batch, w.n) != (v.batch, v.n):
+            raise ValueError(f"shapes {v.dev.shape} and {w.dev.shape} differ")
+        out = ctx.empty((v.batch,), np.float64)
+        ctx._call("tramp_region_log_partition", self._dt, int(mode), reg.shape[0], reg.ctypes.data, v.n, v.batch,
+                  a.dev.ptr, v.dev.ptr, aa.dev.ptr if aa is not None else None, w.dev.ptr, out.ptr)
+        res = out.get()
+        if mean:
+            res = res / v.n
+        if a.was_host and a.scalar_like and v.was_host and len(v.host_shape) == 1:
+            return float(res[0])
+        return res
+
     def __matmul__(self, other):
         from .models import DAG
         return DAG(self) @ other

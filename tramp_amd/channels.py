@@ -236,7 +236,8 @@ class PiecewiseLinearChannel(Channel):
         kinds = {_lib.SGN: _lib.LOGZ_PWL_SGN, _lib.ABS: _lib.LOGZ_PWL_ABS, _lib.RELU: _lib.LOGZ_PWL_RELU}
         kind = kinds.get(getattr(self, "_kind", None)) if type(self) in (SgnChannel, AbsChannel, ReluChannel) else None
         if kind is None:
-            raise NotImplementedError(f"{type(self).__name__}.compute_log_partition is not on the HIP path")
+            # the rest of the family: the reference's loop over its region table (linear_region.py:55-64)
+            return self._logz_regions(0, self._regions(), az, bz, bx, ax=ax, mean=False)
         return self._logz(kind, az, bz, a1=ax, v1=bx, mean=False)
 
     def compute_forward_posterior(self, az, bz, ax, bx):
@@ -307,6 +308,11 @@ class TwoHalfLineChannel(PiecewiseLinearChannel):
     def sample(self, Z):
         sp, sn, xp, xn, zc = self._spec
         return np.where(Z >= zc, xp + sp * Z, xn + sn * Z)
+
+    def _regions(self):
+        "[pos, neg] rows (zmin, zmax, slope, x0) as the reference's constructors list them"
+        sp, sn, xp, xn, zc = self._spec
+        return [(zc, np.inf, sp, xp), (-np.inf, zc, sn, xn)]
 
     def second_moment(self, tau_z):
         "piecewise_linear_channel.py:21-25: sum_k p_k (rx_k^2 + vx_k) for z ~ N(0, tau_z)"
@@ -397,6 +403,12 @@ class ThreeRegionChannel(PiecewiseLinearChannel):
         zlo, zhi = self._z
         (sp, sm, sn), (xp, xm, xn) = self._slopes, self._x0
         return np.where(Z >= zhi, xp + sp * Z, np.where(Z >= zlo, xm + sm * Z, xn + sn * Z))
+
+    def _regions(self):
+        "[pos, mid, neg] rows (zmin, zmax, slope, x0)"
+        zlo, zhi = self._z
+        (sp, sm, sn), (xp, xm, xn) = self._slopes, self._x0
+        return [(zhi, np.inf, sp, xp), (zlo, zhi, sm, xm), (-np.inf, zlo, sn, xn)]
 
     def second_moment(self, tau_z):
         "piecewise_linear_channel.py:21-25 with the truncated moments of N(0, tau_z) per region"

@@ -1047,8 +1047,9 @@ extern "C" int tramp_pwl3_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
                                   const void* y_d, double damping, const double* a_old_d, const void* b_old_d,
                                   double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
     if (!ctx) return TRAMP_EINVAL;
-    TRAMP_REQUIRE(ctx, az_d && slopes3 && x03 && z_lo < z_hi);
-    TRAMP_REQUIRE(ctx, slopes3[0] >= 0.0 && slopes3[1] >= 0.0 && slopes3[2] >= 0.0);   // log(slope)
+    // z_lo == z_hi with a SLOPED middle region: that region is empty (AsymmetricAbsLikelihood's two half lines); a
+    // flat one needs a proper interval for its truncated normal.  Descending branches enter with log|slope|.
+    TRAMP_REQUIRE(ctx, az_d && slopes3 && x03 && (z_lo < z_hi || (z_lo == z_hi && slopes3[1] != 0.0)));
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     tmath::Pwl3Spec spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}};
     Pwl3LikOp<float> of{az_d, spec};
@@ -1230,7 +1231,7 @@ extern "C" int tramp_diag_factor_p(tramp_ctx* ctx, int dtype, int which, size_t 
     if (which == TRAMP_DIAG_GAUSS_LIK) TRAMP_REQUIRE(ctx, P.p[0] > 0.0);
     if (which == TRAMP_DIAG_RELU_LIK) TRAMP_REQUIRE(ctx, P.p[0] >= 0.0);
     if (which == TRAMP_DIAG_PWL3_LIK)
-        TRAMP_REQUIRE(ctx, P.p[0] < P.p[1] && P.p[2] >= 0.0 && P.p[3] >= 0.0 && P.p[4] >= 0.0);
+        TRAMP_REQUIRE(ctx, P.p[0] < P.p[1] || (P.p[0] == P.p[1] && P.p[3] != 0.0));     // as tramp_pwl3_lik_bwd
     if (!count) return TRAMP_OK;
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((diag_kernel<double>), dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, which,

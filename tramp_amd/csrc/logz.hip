@@ -49,6 +49,68 @@ __device__ __forceinline__ double pwl_logZ(double bz, double bx, double az, doub
     return logaddexp(As[0], As[1]);                   // piecewise_linear_channel.py:55-58
 }
 
+// ---- region tables: the rest of the piecewise-linear family (LeakyRelu, AsymmetricAbs, HardTanh, HardSigmoid,
+// SymmetricDoor and the likelihood twins), literally as the reference loops over its regions
+struct RegionTable {
+    int nreg;
+    double zmin[3], zmax[3], slope[3], x0[3];
+};
+
+// truncated_normal_logZ (tramp/utils/truncated_normal.py:294-298) through truncated_normal_log_proba (:269-281):
+// G0_inf = log_Phi with its x < 30 mask on a half line, G0 = log(1/2) + F0 on a finite interval
+__device__ __forceinline__ double trunc_logZ(double r0, double v0, double zmin, double zmax) {
+    double g0;
+    if (zmax == INFINITY) g0 = tmath::halfline_at<double>(r0, v0, +1, zmin).logp;
+    else if (zmin == -INFINITY) g0 = tmath::halfline_at<double>(r0, v0, -1, zmax).logp;
+    else g0 = tmath::interval_moments<double>(r0, v0, zmin, zmax).logp;
+    return 0.5 * log(k2Pi * v0) + 0.5 * r0 * r0 / v0 + g0;
+}
+
+// scipy.special.logsumexp over <= 3 terms: the maximum is taken out unless it is not finite
+__device__ __forceinline__ double logsumexp3(const double* A, int n) {
+    double m = A[0];
+    for (int k = 1; k < n; ++k) m = (A[k] > m || m != m) ? A[k] : m;          // np.max: NaN wins
+    for (int k = 0; k < n; ++k) if (A[k] != A[k]) m = A[k];
+    const double mm = (m - m == 0.0) ? m : 0.0;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += exp(A[k] - mm);
+    return log(s) + mm;
+}
+
+// mode 0: channel, v1 = bx (linear_region.py:55-64, piecewise_linear_channel.py:55-58, summed);
+// mode 1: likelihood, v1 = y (piecewise_linear_likelihood.py:52-61, 216-219; the host takes the mean).
+// log|slope|: the reference writes np.log(self.slope), NaN for the descending branch of AsymmetricAbsLikelihood - its
+// every output is NaN; the Jacobian of y = x0 + slope z is |slope|.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void region_logz_kernel(RegionTable R, int mode, size_t n,
+                                                             const double* __restrict__ az_d,
+                                                             const double* __restrict__ ax_d, const T* __restrict__ v0,
+                                                             const T* __restrict__ v1, double* __restrict__ partials) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    const double az = az_d[b], ax = ax_d ? ax_d[b] : 0.0;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const double bz = (double)v0[b * n + i], w = (double)v1[b * n + i];
+        double As[3];
+        for (int k = 0; k < R.nreg; ++k) {
+            const double slope = R.slope[k], x0 = R.x0[k];
+            if (mode == 0) {
+                const double a = az + slope * slope * ax, bb = bz + slope * (w - ax * x0);
+                As[k] = trunc_logZ(bb / a, 1.0 / a, R.zmin[k], R.zmax[k]) - 0.5 * ax * x0 * x0 + w * x0;
+            } else if (slope == 0.0) {
+                As[k] = (w == x0) ? trunc_logZ(bz / az, 1.0 / az, R.zmin[k], R.zmax[k]) : -INFINITY;
+            } else {
+                const double z = (w - x0) / slope;
+                As[k] = (R.zmin[k] < z && z < R.zmax[k]) ? -0.5 * az * (z * z) + bz * z - log(fabs(slope)) : -INFINITY;
+            }
+        }
+        acc += logsumexp3(As, R.nreg);
+    }
+    acc = block_sum(acc, smem);
+    if (threadIdx.x == 0) partials[b * gridDim.x + blockIdx.x] = acc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void logz_kernel(LogzParams P, size_t n, const T* __restrict__ v0,
                                                       const T* __restrict__ v1, double* __restrict__ partials) {
@@ -195,6 +257,39 @@ extern "C" int tramp_log_partition(tramp_ctx* ctx, int dtype, int kind, size_t n
     else
         hipLaunchKernelGGL((logz_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, P, n, (const float*)v0_d,
                            needs_v1 ? (const float*)v1_d : nullptr, ctx->ws);
+    hipLaunchKernelGGL(logz_fold_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, ctx->ws, nblk, out_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_region_log_partition(tramp_ctx* ctx, int dtype, int mode, int nreg, const double* regions_h,
+                                          size_t n, size_t batch, const double* az_d, const void* bz_d,
+                                          const double* ax_d, const void* v1_d, double* out_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, regions_h && az_d && bz_d && v1_d && out_d && (nreg == 2 || nreg == 3));
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, (mode == 0 && ax_d) || mode == 1);
+    RegionTable R{};
+    R.nreg = nreg;
+    for (int k = 0; k < nreg; ++k) {
+        R.zmin[k] = regions_h[4 * k];
+        R.zmax[k] = regions_h[4 * k + 1];
+        R.slope[k] = regions_h[4 * k + 2];
+        R.x0[k] = regions_h[4 * k + 3];
+        TRAMP_REQUIRE(ctx, R.zmin[k] < R.zmax[k]);                     // linear_region.py:17
+    }
+    if (!batch) return TRAMP_OK;
+    if (!n) return tramp_fill_f64(ctx, out_d, batch, 0.0);
+    const int nblk = blocks_for(n, 1);
+    int rc = tramp_ws_reserve(ctx, batch * (size_t)nblk * sizeof(double));
+    if (rc) return rc;
+    dim3 grid(nblk, (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((region_logz_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, R, mode, n, az_d,
+                           mode == 0 ? ax_d : nullptr, (const double*)bz_d, (const double*)v1_d, ctx->ws);
+    else
+        hipLaunchKernelGGL((region_logz_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, R, mode, n, az_d,
+                           mode == 0 ? ax_d : nullptr, (const float*)bz_d, (const float*)v1_d, ctx->ws);
     hipLaunchKernelGGL(logz_fold_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, ctx->ws, nblk, out_d);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;

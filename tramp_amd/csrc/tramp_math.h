@@ -854,7 +854,7 @@ TM_HD PwlOut<T> pwl3_lik_posterior(T bz, T y, T az, const Pwl3Spec& sp) {
             const bool in = (k == 0) ? (z > T(sp.zhi)) : (k == 1 ? (z > T(sp.zlo) && z < T(sp.zhi)) : (z < T(sp.zlo)));
             if (in) {
                 rs[k] = z;
-                As[k] = -T(0.5) * az * (z * z) + bz * z - log_(slope);
+                As[k] = -T(0.5) * az * (z * z) + bz * z - log_(fabs_(slope));   // the Jacobian |slope| (the reference: log(slope))
             }
         }
     }

@@ -88,7 +88,14 @@ class Likelihood(Factor):
     def compute_log_partition(self, az, bz, y=None):
         "mean over the components of the likelihood's log-partition (e.g. sgn_likelihood.py:39-41)"
         if self._logz_kind is None:
-            raise NotImplementedError(f"{type(self).__name__}.compute_log_partition is not on the HIP path")
+            if not hasattr(self, "_regions"):
+                raise NotImplementedError(f"{type(self).__name__}.compute_log_partition is not on the HIP path")
+            # the observed piecewise-linear outputs: the reference's loop over its region table
+            # (piecewise_linear_likelihood.py:52-61, 216-219)
+            yy = self.y if y is None else y
+            if isinstance(yy, DeviceArray) or np.ndim(yy) == 0:
+                yy = self._y_for(VecArg(self.ctx, bz, self.dtype), None)
+            return self._logz_regions(1, self._regions(), az, bz, yy, mean=True)
         b = VecArg(self.ctx, bz, self.dtype)
         yd = self._y_for(b, y)
         return self._logz(self._logz_kind, az, bz, v1=yd, params=self._logz_params)
@@ -283,6 +290,10 @@ class ReluLikelihood(Likelihood):
     def sample(self, X):
         return np.where(X >= 0, X, self._slope * X)
 
+    def _regions(self):
+        "[pos, neg] rows (zmin, zmax, slope, x0) (piecewise_linear_likelihood.py:279-291)"
+        return [(0.0, np.inf, 1.0, 0.0), (-np.inf, 0.0, float(self._slope), 0.0)]
+
     def compute_backward_error(self, az, tau_z):
         "beliefs_measure (piecewise_linear_likelihood.py:120-146): only flat regions carry variance"
         az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
@@ -330,6 +341,12 @@ class ThreeRegionLikelihood(Likelihood):
                               self._x0_h.ctypes.data)
         self._set_y(y)
 
+    def _regions(self):
+        "[pos, mid, neg] rows (zmin, zmax, slope, x0)"
+        zlo, zhi = self._z
+        (sp, sm, sn), (xp, xm, xn) = self._slopes, self._x0
+        return [(zhi, np.inf, sp, xp), (zlo, zhi, sm, xm), (-np.inf, zlo, sn, xn)]
+
     def sample(self, Z):
         "sum of the regions' outputs: x0 + slope z on [zmin, zmax), zero elsewhere (:22-25, 168-170)"
         zlo, zhi = self._z
@@ -371,7 +388,83 @@ class SymmetricDoorLikelihood(ThreeRegionLikelihood):
         super().__init__(y, y_name, isotropic, dtype, ctx)
 
 
+class AsymmetricAbsLikelihood(ThreeRegionLikelihood):
+    """y = |z| observed with the kink moved to z = shift (piecewise_linear_likelihood.py:260-265): regions
+    pos (shift, inf) with y = z and neg (-inf, shift) with y = -z.  Both pin z: y > |shift| is compatible with
+    z = +-y (weights softmax(+-bz y): the abs likelihood's tanh), -shift < y <= shift only with z = -y, y <= -shift
+    with neither (NaN, as the reference's softmax of two -inf).
+
+    The reference itself returns NaN for EVERY input: LinearRegionLikelihood.log_partitions (:52-61) subtracts
+    np.log(self.slope) and the descending branch has slope = -1.  The Jacobian of y = x0 + slope z is |slope|;
+    that is what the kernel takes (log|-1| = 0).  ``reference_nan=True`` reproduces the reference's outputs bit for
+    bit instead.  On the device it is the three-region likelihood kernel with an empty middle
+    region (z_lo = z_hi = shift)."""
+    _logz_kind = None
+
+    def __init__(self, y, y_name="y", isotropic=True, shift=1e-4, reference_nan=False, dtype=np.float64, ctx=None):
+        self.shift = shift
+        self.reference_nan = bool(reference_nan)
+        self._z = (float(shift), float(shift))
+        self._slopes = (1.0, 1.0, -1.0)        # pos, (empty) mid, neg
+        self._x0 = (0.0, 0.0, 0.0)
+        super().__init__(y, y_name, isotropic, dtype, ctx)
+        self.name = "a-abs"
+
+    def _regions(self):
+        s = float(self.shift)
+        return [(s, np.inf, 1.0, 0.0), (-np.inf, s, -1.0, 0.0)]
+
+    def sample(self, Z):
+        return np.where(Z >= self.shift, Z, -Z)
+
+    def _nan_like(self, bz):
+        b = np.asarray(bz.get() if isinstance(bz, DeviceArray) else bz, dtype=np.float64)
+        return np.full(b.shape, np.nan)
+
+    def compute_backward_message(self, az, bz, **kw):
+        if self.reference_nan:
+            nb = self._nan_like(bz)
+            return (np.nan if nb.ndim == 1 else np.full(nb.shape[0], np.nan)), nb
+        return super().compute_backward_message(az, bz, **kw)
+
+    def compute_backward_posterior(self, az, bz, y):
+        if self.reference_nan:
+            nb = self._nan_like(bz)
+            return nb, (np.nan if nb.ndim == 1 or not self.isotropic else np.full(nb.shape[0], np.nan))
+        return super().compute_backward_posterior(az, bz, y)
+
+    def compute_log_partition(self, az, bz, y=None):
+        if self.reference_nan:
+            return float("nan")
+        return super().compute_log_partition(az, bz, y)
+
+    def compute_backward_error(self, az, tau_z):
+        """E[v] over z ~ N(0, tau_z), bz = mz z + sqrt(mz) xi (beliefs_measure :120-146): the posterior is the abs
+        likelihood's wherever both branches are compatible (|z| > |shift|) and a point mass elsewhere, so the error
+        is tramp_se_abs_lik minus the slab |z| <= |shift|, which a 64 x 64 Gauss rule on the host integrates."""
+        if self.reference_nan:
+            return float("nan") if np.ndim(az) == 0 else np.full(np.shape(az), np.nan)
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        tz = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        if np.any(az_h - 1 / tz <= 0):
+            raise AssertionError("az must be greater than 1/tau_z")
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_abs_lik", az_h.shape[0], az_h.ctypes.data, tz.ctypes.data, v.ctypes.data)
+        s = abs(float(self.shift))
+        if s > 0:
+            zg, zw = np.polynomial.legendre.leggauss(64)
+            xg, xw = np.polynomial.hermite_e.hermegauss(64)
+            z = s * zg[:, None]                                   # the slab, both signs
+            for i, (a_, t_) in enumerate(zip(az_h, tz)):
+                mz = a_ - 1 / t_
+                bz = mz * z + np.sqrt(mz) * xg[None, :]
+                f = (z**2) / np.cosh(bz * np.abs(z))**2 * np.exp(-0.5 * z**2 / t_) / np.sqrt(2 * np.pi * t_)
+                v[i] -= s * float(zw @ (f @ (xw / np.sqrt(2 * np.pi))))
+        return float(v[0]) if np.ndim(az) == 0 else v
+
+
 LIKELIHOOD_CLASSES = {
+    "a-abs": AsymmetricAbsLikelihood,
     "relu": ReluLikelihood,
     "l-relu": LeakyReluLikelihood,
     "gaussian": GaussianLikelihood,

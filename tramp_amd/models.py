@@ -11,10 +11,10 @@ import networkx as nx
 import numpy as np
 
 from .base import Factor, Variable
-from .channels import (ConvChannel, DFTChannel, GradientChannel, ReshapeChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
+from .channels import (AsymmetricAbsChannel, ConvChannel, DFTChannel, GradientChannel, ReshapeChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
                        PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
-from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, ReluLikelihood,
+from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, AsymmetricAbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
                           SymmetricDoorLikelihood, Likelihood)
 from .priors import Prior, get_prior
@@ -28,6 +28,8 @@ def channel2likelihood(channel, y, y_name):
         return GaussianLikelihood(y=y, y_name=y_name, var=channel.var, **kw)
     if isinstance(channel, AbsChannel):
         return AbsLikelihood(y=y, y_name=y_name, **kw)
+    if isinstance(channel, AsymmetricAbsChannel):
+        return AsymmetricAbsLikelihood(y=y, y_name=y_name, shift=channel.shift, **kw)
     if isinstance(channel, SgnChannel):
         return SgnLikelihood(y=y, y_name=y_name, **kw)
     if isinstance(channel, ReluChannel):
@@ -197,11 +199,13 @@ class Model:
         if isinstance(factor, LinearChannel):
             return (factor.Nx,)
         if isinstance(factor, ConvChannel):
-            return tuple(factor.shape)
+            # real=False: planar complex vectors (2,) + shape (channels.py ConvChannel._vshape)
+            return tuple(factor._vshape)
         if isinstance(factor, GradientChannel):
             return (factor.d,) + tuple(factor.shape)
         if isinstance(factor, DFTChannel):
-            return (2,) + tuple(in_shape)
+            # real=True: z real -> x planar complex; real=False: z is already planar (2,) + shape, x has its shape
+            return (2,) + tuple(in_shape) if factor.real else tuple(in_shape)
         if isinstance(factor, ReshapeChannel):
             return tuple(factor.next_shape)
         return in_shape
