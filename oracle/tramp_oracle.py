@@ -1715,21 +1715,27 @@ def aabs_lik_message(az, bz, y, shift=1e-4, abs_slope=True):
     return ab_new(r, v, az, bz)
 
 
-def se_aabs_lik_error(az, tau_z, shift=1e-4, nz=4001, nxi=128):
+def se_aabs_lik_error(az, tau_z, shift=1e-4, nz=400, nxi=160):
     """beliefs_measure (:120-146, 210-214) for the two sloped regions of AsymmetricAbs: E over z ~ N(0, tau_z),
-    xi ~ N(0, 1) of v(bz = mz z + sqrt(mz) xi, y = y(z)) with the |slope| Jacobian - a dense trapezoid in z (the
-    integrand has kinks at +-shift) times Gauss-Hermite in xi."""
+    xi ~ N(0, 1) of v(bz = mz z + sqrt(mz) xi, y = y(z)) with the |slope| Jacobian.  v jumps at |z| = |shift| (one
+    compatible branch inside, two outside): Gauss-Legendre on the three segments, Gauss-Hermite in xi."""
     mz = az - 1 / tau_z
     assert mz > 0
     regions = f2_regions("a-abs", shift=shift)
-    s0 = np.sqrt(tau_z)
-    z = np.linspace(-9 * s0, 9 * s0, nz)
+    s0, s = np.sqrt(tau_z), abs(shift)
     xi, w = np.polynomial.hermite_e.hermegauss(nxi)
-    y = np.where(z >= shift, z, -z)
-    bz = mz * z[:, None] + np.sqrt(mz) * xi[None, :]
-    _, v = region_lik_posterior(regions, az, bz, y[:, None], isotropic=False, abs_slope=True)
-    f = (np.nan_to_num(v) @ (w / np.sqrt(2 * np.pi))) * np.exp(-0.5 * z**2 / tau_z) / np.sqrt(2 * np.pi * tau_z)
-    return np.trapezoid(f, z)
+    g, gw = np.polynomial.legendre.leggauss(nz)
+    total = 0.
+    for lo, hi in ((-10 * s0, -s), (-s, s), (s, 10 * s0)):
+        if hi <= lo:
+            continue
+        z = 0.5 * (hi - lo) * g + 0.5 * (hi + lo)
+        y = np.where(z >= shift, z, -z)
+        bz = mz * z[:, None] + np.sqrt(mz) * xi[None, :]
+        _, v = region_lik_posterior(regions, az, bz, y[:, None], isotropic=False, abs_slope=True)
+        f = (np.nan_to_num(v) @ (w / np.sqrt(2 * np.pi))) * np.exp(-0.5 * z**2 / tau_z) / np.sqrt(2 * np.pi * tau_z)
+        total += 0.5 * (hi - lo) * float(gw @ f)
+    return total
 
 
 def variable_log_partition(a, b):

@@ -500,7 +500,7 @@ def test_complex_channels_inside_an_ep_model(ctx, kind):
         f = np.zeros(n, dtype=complex)
         f[:4] = rs.standard_normal(4) + 1j * rs.standard_normal(4)
         ch = T.ConvChannel(f, real=False, ctx=ctx)
-        w_hat = np.fft.fft(f)                                   # circular convolution: x = ifft(w_hat fft(z))
+        w_hat = np.conjugate(np.fft.fft(f))                     # conv_channel.py:42-55: x = ifft(conj(fft(filter)) fft(z))
         x = np.fft.ifft(w_hat * np.fft.fft(z))
     else:
         ch = T.DFTChannel(real=False, ctx=ctx)
@@ -509,7 +509,7 @@ def test_complex_channels_inside_an_ep_model(ctx, kind):
     planar = lambda c: np.stack([c.real, c.imag])               # noqa: E731
     model = (T.GaussianPrior(size=(2, n), ctx=ctx) @ T.SISOVariable(id="z") @ ch @ T.SISOVariable(id="x")
              @ T.GaussianLikelihood(y=planar(y).reshape(1, -1), var=nv, ctx=ctx)).to_model()
-    assert model.get_shapes() == {"z": (2, n), "x": (2, n)}
+    assert model.init_shapes() == {"z": (2, n), "x": (2, n)}
     ep = T.ExpectationPropagation(model, ctx=ctx)
     ep.iterate(max_iter=5)
     r = np.asarray(ep.get_variables_data()["z"]["r"]).reshape(2, n)

@@ -196,7 +196,8 @@ class Factor(ReprMixin):
         order, through tramp_region_log_partition: mode 0 = channel (v1 = bx, summed,
         piecewise_linear_channel.py:55-58), mode 1 = likelihood (v1 = y, mean, piecewise_linear_likelihood.py:216-219)."""
         ctx = self.ctx
-        reg = np.ascontiguousarray(np.asarray(regions, dtype=np.float64).reshape(-1, 4))
+        # the table as the kernels of the working precision hold it (a kink at float32(1e-4), not at 1e-4)
+        reg = np.ascontiguousarray(np.asarray(regions, dtype=self.dtype).astype(np.float64).reshape(-1, 4))
         if not getattr(self, "isotropic", True) and np.ndim(az) > 0 and not isinstance(bz, DeviceArray):
             # diagonal beliefs: n instances of one component each, then the reference's mean / sum on the host
             vh = np.asarray(bz, dtype=self.dtype).reshape(-1, 1)
