@@ -1022,6 +1022,7 @@ def run(args):
                       "factors_loaded_from": args.load_factors,
                       "eigensolver": "spectral divide and conquer + rocSOLVER syevd halves" if k > 46336
                                      else "rocSOLVER syevd"},
+            "env_overrides": T.switches.overrides(),       # {} = every library switch at its default (tramp_amd/switches.py)
             "mse_after_run": float(np.mean(mse_inst)),
             "v_after_run": float(np.mean(v_inst)),
             "device": ctx.device_name(),

@@ -397,13 +397,6 @@ int tramp_lsolve_log_partition(tramp_ctx* ctx, tramp_lsolve* ls, size_t batch, c
  * initial messages - the component of z orthogonal to the rows of Vt then stays exactly zero - and removes
  * the two passes over Vt (t = bz', rz' = bz' / az + w); z = Vt^T z' when read (tramp_matvec_nn on Vt). */
 int tramp_linear_set_rotated(tramp_ctx* ctx, tramp_linear* lin, int on);
-/* Transposed copies of the thin factors, kept resident beside them (the caller owns both): Vtt_d [N, k] = Vt^T,
- * Ukt_d [k, M] = Uk^T, either may be NULL.  The products over the ROWS of Vt / Uk (t = Vt bz, rx = Uk w) then run as
- * column passes over the copy whenever the ensemble takes the matrix-core path (batch > 2): 256 contiguous bytes per
- * matrix row and load instruction instead of 64 - same flops, same bytes streamed once; the pass alone is 4 % faster
- * at 50000 x 100000 x 64, the power-limited EP iteration is not, so the host mirror makes the copies only on request.
- * Costs N k T bytes of the 288 GB (40 GB at N = 1e5, f64).  TRAMP_LINEAR_TRANSPOSED=0 ignores the copies. */
-int tramp_linear_set_transposed(tramp_ctx* ctx, tramp_linear* lin, const void* Vtt_d, const void* Ukt_d);
 /* dst [C, R] = src [R, C]^T (32 x 32 LDS tiles) */
 int tramp_transpose(tramp_ctx* ctx, int dtype, size_t R, size_t C, const void* src_d, void* dst_d);
 /* Constant damping of a CONSTANT factor's message (tramp/algos/message_passing.py:119-127

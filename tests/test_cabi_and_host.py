@@ -191,3 +191,22 @@ def test_tree_model_algebra():
         (T.GaussianPrior(size=8) @ SIMOVariable(id="x", n_next=2) @ T.ReluChannel()).to_model()
     with pytest.raises(ValueError):                    # two factors in a row
         T.GaussianPrior(size=8) @ T.ReluChannel()
+
+
+def test_every_environment_switch_is_in_the_one_table():
+    """tramp_amd/switches.py lists every TRAMP_* variable the library reads - no more, no fewer - with its default;
+    bench.py reports the ones found set (env_overrides), so a result line says by itself that it ran on the defaults."""
+    import glob
+    import re
+    from tramp_amd import switches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    pat = re.compile(r'(?:getenv|env_size|environ\.get)\(\s*"(TRAMP_[A-Z0-9_]+)"')
+    for path in glob.glob(os.path.join(root, "tramp_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "tramp_amd", "*.py")):
+        if path.endswith("switches.py"):
+            continue
+        found |= set(pat.findall(open(path).read()))
+    assert found == set(switches.SWITCHES), (sorted(found - set(switches.SWITCHES)), sorted(set(switches.SWITCHES) - found))
+    assert switches.overrides({"TRAMP_EW_RESIDENT": "0", "HOME": "/x", "TRAMP_UNKNOWN": "1"}) == {"TRAMP_EW_RESIDENT": "0"}
+    assert all(kind in ("select", "tune", "debug") for _, kind, _ in switches.SWITCHES.values())
+    assert switches.markdown_table().count("\n") == len(switches.SWITCHES) + 1

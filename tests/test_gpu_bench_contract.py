@@ -32,6 +32,7 @@ def test_bench_prints_one_json_line(force_dist):
     assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["dtype"] == "f64"
     assert d["config"]["N"] == 2048 and d["config"]["instances_per_gpu"] == 4
     assert d["value"] > 0 and d["roofline"]["bound"] in ("hbm", "mfma")
+    assert d["env_overrides"] == {}                    # the line ran on the library's defaults (tramp_amd/switches.py)
     if force_dist:
         assert "RCCL" in d["config"]["collectives"]
     # the factors are checked against W itself before W is freed, and the observations come from W x

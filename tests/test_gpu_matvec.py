@@ -109,37 +109,6 @@ def test_mfma_deterministic(ctx):
     assert np.array_equal(a, b)
 
 
-def test_f64_4x4x4_block_kernels_in_subprocess():
-    """The alternative f64 MFMA kernels (v_mfma_f64_4x4x4_4b, TRAMP_MFMA_F64_SHAPE=4; not the
-    default, see gemm_mfma.hip) give the same results: run a few shapes in a child process
-    because the choice is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys
-sys.path.insert(0, ".")
-import numpy as np, tramp_amd as T
-ctx = T.default_context(); dt = T.device.dtype_code(np.float64)
-rs = np.random.RandomState(0)
-for (R, C, B) in [(96, 160, 64), (130, 70, 37), (512, 1024, 64), (64, 30, 5), (34, 258, 130)]:
-    M = rs.randn(R, C); Xn = rs.randn(B, C); Xt = rs.randn(B, R)
-    o1 = ctx.empty((B, R)); o2 = ctx.empty((B, C))
-    Md, Xnd, Xtd = ctx.array(M), ctx.array(Xn), ctx.array(Xt)      # keep the buffers alive across the launches
-    ctx._call("tramp_matvec_nt", dt, 2, R, C, B, Md.ptr, Xnd.ptr, o1.ptr)
-    ctx._call("tramp_matvec_nn", dt, 2, R, C, B, Md.ptr, Xtd.ptr, o2.ptr)
-    assert np.abs(o1.get() - Xn @ M.T).max() < 1e-11 * C, (R, C, B, "nt")
-    assert np.abs(o2.get() - Xt @ M).max() < 1e-11 * R, (R, C, B, "nn")
-print("ok")
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({}, {"TRAMP_MFMA_RING": "1"}):          # plain 4x4x4 kernels; loader/consumer ring variant (NT)
-        env = dict(os.environ, TRAMP_MFMA_F64_SHAPE="4", **extra)
-        res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True,
-                             timeout=300)
-        assert res.returncode == 0 and "ok" in res.stdout, str(extra) + res.stdout + res.stderr
-
-
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(1, 1), (33, 65), (100, 7), (257, 1030), (2048, 96)])
 def test_transpose(ctx, shape, dtype):
@@ -149,39 +118,3 @@ def test_transpose(ctx, shape, dtype):
     src, dst = ctx.array(a, dtype), ctx.zeros((C, R), dtype)
     ctx._call("tramp_transpose", T.device.dtype_code(dtype), R, C, src, dst)
     assert np.array_equal(dst.get(), a.T)
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(96, 160), (160, 96), (130, 258)])
-def test_linear_channel_transposed_copies(ctx, shape, dtype, monkeypatch):
-    """Ensembles on the matrix-core path keep Vt^T / Uk^T resident and run the row-dot products as column passes over
-    the copies (tramp_linear_set_transposed): same messages as without the copies and as the oracle's LinearChannel
-    (tramp/channels/linear/linear_channel.py:69-117)."""
-    import tramp_amd as T
-    from oracle import tramp_oracle as orc
-    M, N = shape
-    B = 5
-    rs = np.random.RandomState(M)
-    W = rs.randn(M, N) / np.sqrt(N)
-    az, ax = rs.uniform(0.5, 2, B), rs.uniform(0.5, 2, B)
-    bz, bx = rs.standard_normal((B, N)), rs.standard_normal((B, M))
-    out = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("TRAMP_LINEAR_TRANSPOSED", flag)
-        ch = T.LinearChannel(W, dtype=dtype, ctx=ctx, svd="host")
-        fwd = ch.compute_forward_message(az, bz.astype(dtype), ax, bx.astype(dtype))
-        bwd = ch.compute_backward_message(az, bz.astype(dtype), ax, bx.astype(dtype))
-        assert (ch._Vtt is not None) == (flag == "1") and (ch._Ukt is not None) == (flag == "1")
-        if flag == "1":
-            assert ch._Vtt.shape == (N, min(M, N)) and ch._Ukt.shape == (min(M, N), M)
-            np.testing.assert_array_equal(ch._Vtt.get(), ch._Vt.get().T)
-        out[flag] = (fwd, bwd)
-    tol = 1e-11 if dtype == np.float64 else 2e-4
-    lin = orc.LinearOracle(W)
-    for d in (0, 1):
-        for b in range(B):
-            ref = (lin.forward_message if d == 0 else lin.backward_message)(az[b], bz[b], ax[b], bx[b])
-            for flag in ("1", "0"):
-                a_new, b_new = out[flag][d]
-                np.testing.assert_allclose(a_new[b], ref[0], rtol=max(tol, 1e-9))
-                np.testing.assert_allclose(b_new[b], ref[1], rtol=tol, atol=tol * np.abs(ref[1]).max())

@@ -8,6 +8,7 @@ sys.path.insert(0, '.')
 import tramp_amd as T
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+ONLY_K7 = len(sys.argv) > 3 and sys.argv[3] == "k7"
 ctx = T.default_context()
 for np_dt in (np.float64, np.float32):
     bz = ctx.randn((B, N), np_dt, seed=1, scale=1.5); bx = ctx.randn((B, N), np_dt, seed=2, scale=1.5)
@@ -21,15 +22,16 @@ for np_dt in (np.float64, np.float32):
     ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
     relu, sgn, abs_ = T.ReluChannel(dtype=np_dt, ctx=ctx), T.SgnChannel(dtype=np_dt, ctx=ctx), T.AbsChannel(dtype=np_dt, ctx=ctx)
     for _ in range(2):
-        gb.compute_forward_message(ax, bx, **kw)
-        l1.compute_forward_message(ax, bx, **kw)
-        sg.compute_backward_message(az, bz, **kw)
-        ab.compute_backward_message(az, bz, **kw)
+        if not ONLY_K7:
+            gb.compute_forward_message(ax, bx, **kw)
+            l1.compute_forward_message(ax, bx, **kw)
+            sg.compute_backward_message(az, bz, **kw)
+            ab.compute_backward_message(az, bz, **kw)
         relu.compute_backward_message(az, bz, ax, bx, **kw)
         relu.compute_forward_message(az, bz, ax, bx, **kw)
         sgn.compute_backward_message(az, bz, ax, bx, **kw)
         abs_.compute_backward_message(az, bz, ax, bx, **kw)
-    if N % 2 == 0:
+    if N % 2 == 0 and not ONLY_K7:
         # fused pair: producer (inverse FFT with the message update) + single-pass prior
         ch = T.ConvChannel(np.random.RandomState(3).randn(N) / np.sqrt(N), dtype=np_dt, ctx=ctx)
         a_msg, b_msg = ctx.empty((B,)), ctx.empty((B, N), np_dt)

@@ -11,6 +11,7 @@ There is no CPU fallback: without the built HIP library the compute methods rais
 from . import _lib
 from .device import Context, DeviceArray, default_context
 from .priors import GaussBernoulliPrior, MAP_L1NormPrior, MAP_L21NormPrior, BinaryPrior, GaussianPrior, get_prior
+from . import switches
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, AsymmetricAbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
                           SymmetricDoorLikelihood, get_likelihood)

@@ -125,7 +125,6 @@ _SIGNATURES = {
     "tramp_fftn_supported": [i32, i32, C.POINTER(sz)],
     "tramp_matvec_nt": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
-    "tramp_linear_set_transposed": [vp, vp, vp, vp],
     "tramp_transpose": [vp, i32, sz, sz, vp, vp],
     "tramp_matvec_last_launch": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],

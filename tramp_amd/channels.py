@@ -572,45 +572,6 @@ class LinearChannel(Channel):
                   self._Vt.ptr, self._sing.ptr, C.byref(h))
         self._handle = h
         self._t_key = self._u_key = None
-        self._Vtt = self._Ukt = None
-        self._tt_tried = set()
-
-    def _ensure_transposed(self, direction, batch):
-        """TRAMP_LINEAR_TRANSPOSED=1 (off by default): ensembles on the matrix-core path (batch > 2) keep Vt^T (and, for
-        forward messages outside the rotated basis, Uk^T) resident beside the factors, so that the products over
-        their ROWS run as column passes (tramp_linear_set_transposed).  Made on first use, only while the copy
-        leaves more than a third of the device memory free.  Measured at 50000 x 100000 x 64, f64: the pass alone
-        57.9 against 55.8 TFLOP/s, but the EP iteration 23.29 against 23.24 ms - under sustained load both passes
-        sit on the package power limit and the faster kernel only lowers the clock (gpurun_out/r03/bench3.json), so
-        the 40 GB are not spent by default."""
-        import os
-        if batch <= 2 or os.environ.get("TRAMP_LINEAR_TRANSPOSED", "0") != "1":
-            return
-        rot = getattr(self, "_rot_mask", 0)
-        want = []
-        if not rot & 2 and self._Vtt is None:
-            want.append("Vtt")
-        if direction == _lib.FWD and not rot & 1 and self._Ukt is None:
-            want.append("Ukt")
-        changed = False
-        for name in want:
-            if name in self._tt_tried:
-                continue
-            self._tt_tried.add(name)
-            src = self._Vt if name == "Vtt" else self._Uk
-            free, total = self.ctx.mem_info()
-            if free - src.nbytes < total // 3:
-                continue
-            R, Cc = src.shape
-            try:
-                dst = self.ctx.empty((Cc, R), self.dtype)
-                self.ctx._call("tramp_transpose", self._dt, R, Cc, src, dst)
-            except Exception:                   # noqa: BLE001  (out of memory: the row-dot kernels stay)
-                continue
-            setattr(self, "_" + name, dst)
-            changed = True
-        if changed:
-            self.ctx._call("tramp_linear_set_transposed", self._handle, self._Vtt, self._Ukt)
 
     def __del__(self):
         try:
@@ -671,7 +632,6 @@ class LinearChannel(Channel):
                              f"got {z.dev.shape} and {x.dev.shape}")
         a_z = ScalArg(ctx, az, z.batch)
         a_x = ScalArg(ctx, ax, z.batch)
-        self._ensure_transposed(direction, z.batch)
         tgt, a_t = (x, a_x) if direction == _lib.FWD else (z, a_z)
         a_new = out_a if out_a is not None else ctx.empty((z.batch,), np.float64)
         b_new = out_b if out_b is not None else ctx.empty((tgt.batch, tgt.n), self.dtype)
@@ -806,7 +766,6 @@ class SolveLinearChannel(LinearChannel):
         ctx._call("tramp_lsolve_set_rank", self._handle, self.rank)
         self.singular = self.spectrum[:self.rank]                               # :46
         self._t_key = self._u_key = None
-        self._Vtt = self._Ukt = None
 
     def __del__(self):
         try:

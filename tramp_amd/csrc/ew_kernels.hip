@@ -16,7 +16,7 @@
 //     parks r_i in a scratch and pass 2 (one generic kernel) reads it back - the
 //     transcendental math runs once; these are f64-VALU-bound, not HBM-bound.
 // Chunking instances so that the re-reads hit the 256 MiB Infinity Cache was measured and
-// did NOT pay (TRAMP_EW_CHUNK_MB keeps the knob; default off).
+// did NOT pay (measured in round 2; the knob is gone).
 // 16-byte vector loads/stores, 64-wide shuffles, one LDS hop per block; no atomics:
 // results are run-to-run reproducible.
 //
@@ -535,8 +535,6 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
     // consecutive tiles per block: enough blocks to fill the chip several times over, setup amortised
     int tpb = 8;
     while (tpb > 1 && (tiles / tpb) * batch < 4096) tpb >>= 1;
-    static const size_t tpb_env = env_size("TRAMP_EW_TPB", 0);
-    if (tpb_env) tpb = (int)tpb_env;
     const unsigned ntile = (unsigned)((tiles + tpb - 1) / tpb);          // blocks (= partials) per instance
     if (hint) {
         store_r = false;
@@ -576,8 +574,7 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
         // the apply pass of the light ops has next to no per-block setup to amortise: shorter runs per block
         // stream faster (fused Gauss-Bernoulli / L1 update at 64 x 1e6: 173 / 180 us with 2 tiles per block
         // against 192 / 190 with 8; gpurun_out/r03/fused1.log)
-        static const size_t tpb_apply_env = env_size("TRAMP_EW_TPB_APPLY", 0);
-        int tpa = tpb_apply_env ? (int)tpb_apply_env : (Op::HEAVY ? tpb : (tpb > 2 ? 2 : tpb));
+        const int tpa = Op::HEAVY ? tpb : (tpb > 2 ? 2 : tpb);
         dim3 grid_a((unsigned)((tiles + tpa - 1) / tpa), nb);
         if (store_r) {
             if (nts)
@@ -599,16 +596,12 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
     return TRAMP_OK;
 }
 
+// pieces per thread and tile: 1 and 4 measured for the heavy ops (K4 / K5 / K7): within 4 % of 2; one piece per thread
+// for the light ops measured too (the flat one-piece copy of tools/probes/probe_copy.hip streams 6 % faster than the
+// U = 2 tile): not better in the update
 template <typename T, typename Op>
 static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
                      const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
-    // pieces per thread and tile: 1 and 4 measured for the heavy ops (K4/K5/K7): within 4% of 2.  The light ops
-    // (Gauss-Bernoulli, L1, abs likelihood: recomputed in the apply pass) also exist with one piece per thread
-    // (TRAMP_EW_U=1; tools/probes/probe_copy.hip: the flat one-piece copy streams 6 % faster than the U = 2 tile)
-    static const size_t u_env = env_size("TRAMP_EW_U", kTileU);
-    if constexpr (!Op::HEAVY) {
-        if (u_env == 1) return run_tiles_u<T, Op, 1>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
-    }
     return run_tiles_u<T, Op, kTileU>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
 }
 
@@ -645,15 +638,12 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
     const bool vec = (n % VN) == 0;
     const int nblk = blocks_for(n, VN);
     // heavy factors (erfcx / log / tanh per component) park r in a scratch; light ones recompute
-    static const size_t mode_env = env_size("TRAMP_EW_MODE", 2);           // 0 store, 1 recompute, 2 auto
-    static const size_t chunk_mb = env_size("TRAMP_EW_CHUNK_MB", 0);        // 0: whole batch per launch
-    const bool store_r = mode_env == 0 || (mode_env == 2 && Op::HEAVY);
-    static const size_t single_env = env_size("TRAMP_EW_SINGLE", 1);        // 0: always two-pass
+    const bool store_r = Op::HEAVY;
     // heavy factors hold 200+ VGPRs with the tile resident (1 wave/SIMD, 16 serial evaluations per
     // thread): single launch only when each thread has <= 2 vectors or instances alone fill the chip
     const size_t tile = (size_t)kBlock * kSingleVpt * VN;
     const bool single_ok = n <= tile && (!Op::HEAVY || n <= tile / 4 || batch >= 1024);
-    if (single_env && vec && !out.mask && single_ok) {
+    if (vec && !out.mask && single_ok) {
         MsgOut o = out;
         if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
         ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
@@ -662,13 +652,10 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
         TRAMP_LAUNCH_CHECK(ctx);
         return TRAMP_OK;
     }
-    static const size_t tile_env = env_size("TRAMP_EW_TILE", 1);            // 0: grid-stride kernels only
-    if (vec && tile_env) return run_tiles<T, Op>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
-    // chunk: inputs (+ r scratch) of `cb` instances within the cache budget
-    size_t cb = (chunk_mb << 20) / (n * sizeof(T) * (Op::NIN + (store_r ? 1 : 0)));
-    if (cb < 1) cb = 1;
-    if (cb > batch || chunk_mb == 0) cb = batch;
-    if (cb > 65535) cb = 65535;
+    if (vec) return run_tiles<T, Op>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
+    // ragged n (not a whole number of 16-byte pieces): the grid-stride kernels, <= 65535 instances per launch.
+    // (Chunks of instances sized for the Infinity Cache between the passes were measured: 0.96-1.24 ms against 0.96.)
+    const size_t cb = batch > 65535 ? 65535 : batch;
     const size_t r_bytes = store_r ? ((cb * n * sizeof(T) + 255) / 256) * 256 : 0;
     const size_t need = r_bytes + cb * (size_t)nblk * (sizeof(double) + sizeof(unsigned long long));
     int rc = tramp_ws_reserve(ctx, need);

@@ -196,7 +196,7 @@ template <typename T, bool FWD> struct Pwl3Op {   // three-region channels; in0 
     }
 };
 
-template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 = bx
+template <typename T, int KIND, bool FWD, bool UNI = true> struct PwlOp {   // K7; in0 = bz, in1 = bx
     static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
     static constexpr int TARGET = FWD ? 1 : 0;
@@ -205,7 +205,7 @@ template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 
     tmath::PwlSpec spec;          // used by KIND 3 only
     tmath::PwlConst<T> c;
     double a_msg;
-    __device__ static void stage() {tmath::erfcx_setup<T, true>(); }
+    __device__ static void stage() { tmath::erfcx_setup<T, UNI>(); }
     __device__ void prepare(size_t b) {
         const double z = az[b], x = ax[b];
         c = tmath::pwl_const<T, KIND>(z, x, spec);
@@ -213,7 +213,7 @@ template <typename T, int KIND, bool FWD> struct PwlOp {   // K7; in0 = bz, in1 
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T x1) const {
-        tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD>(x0, x1, c);
+        tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD, UNI>(x0, x1, c);
         return {o.r, o.v, o.mask};
     }
 };

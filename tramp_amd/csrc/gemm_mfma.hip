@@ -313,430 +313,6 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     }
 }
 
-// ------------------------------------------------------------------------------ f64 on 4x4x4 blocks
-// v_mfma_f64_4x4x4_4b_f64 (4 blocks of D[4x4] += A[4x4] B[4x4], 512 flop) issues every 16.5
-// cycles per SIMD on this part - 76 TFLOP/s chip-wide in a register-only loop - where
-// v_mfma_f64_16x16x4_f64 (2048 flop) needs ~105 cycles, 47 TFLOP/s (tools/probes/probe_mfma64.hip).
-// Lane layout (tools/probes/probe_mfma4_layout.hip): with k = lane >> 4, blk = (lane >> 2) & 3,
-//     A[blk][i][k] sits in lane 16 k + 4 blk + i,  B[blk][k][n] in lane 16 k + 4 blk + n,
-//     D[blk][i][n] in lane 16 i + 4 blk + n.
-// Taking A = matrix makes (4 blk + i) = lane & 15 the matrix row (NT) / column pair (NN) and
-// k = lane >> 4 the contraction slot: exactly the lane -> memory mapping of the 16x16x4
-// kernels above, so the global loads are unchanged.  B = x for a tile of 4 instances does
-// not depend on blk: the four blocks read the same 16 LDS entries (broadcast), which are laid
-// out contiguously per tile ([tile][k][n], 256 B) so the reads are bank-conflict free.
-// One MFMA = 16 rows x 4 instances x 4 k; 16 accumulator doubles per 16 rows x 64 instances.
-// STATUS (measured, N = 65536 x 64): 50-52 TFLOP/s against 54-57 for the 16x16x4 kernels, so
-// these are NOT the default (TRAMP_MFMA_F64_SHAPE=4 selects them; parity-tested).  The reason
-// turned out not to be the kernel structure but the package power limit: rocm-smi reads
-// 1340-1380 W (TBP 1400 W) with sclk throttled to 2250-2290 MHz for every variant at batch 64,
-// 1170 W at 70 TFLOP/s when the same MFMA stream runs without HBM traffic, 1325 W for the
-// HBM-bound batch 16 (tools/power_probe.sh).  P ~ 730 W + 6.3 W per TFLOP/s + 79 W per TB/s fits all
-// three and puts the wall of this contraction (16 flop per matrix byte) at 55 TFLOP/s - where
-// the 16x16x4 kernels already are; the 4x4x4 shape spends slightly more energy per flop.
-__device__ __forceinline__ double mfma4(double a, double b, double c) {
-    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-
-template <int BT, int RT, bool TAIL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
-void gemm_nt4_kernel(size_t R, size_t C, size_t B, const double* __restrict__ mat, const double* __restrict__ x,
-                     size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
-    using V = v2d;
-    constexpr int E = 2;
-    constexpr int KS = 4 * kPieces * E;            // 16 columns per step
-    constexpr int NT4 = 4 * BT;                    // instance tiles of 4
-    __shared__ V xs[2][kPieces][BT * 64];          // [stage][piece][tile * 16 + k * 4 + n]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const size_t rb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-    const size_t bchunk = (size_t)blockIdx.y * 64;
-    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
-    const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
-    const size_t nsteps_total = (C + KS - 1) / KS;
-    const size_t sbeg = split * steps_per_split;
-    size_t send = sbeg + steps_per_split;
-    if (send > nsteps_total) send = nsteps_total;
-    const V vzero = {};
-    const double* mp[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        size_t r = row0 + rt * 16 + j;
-        if (r >= R) r = R - 1;
-        mp[rt] = mat + r * C + q * E;
-    }
-    size_t xb = bchunk + (size_t)wave * 16 + j;
-    if (xb >= B) xb = B - 1;
-    const double* xp = x + xb * C + q * E;
-    const bool loads_x = wave < BT;
-    const int wr = 64 * wave + 16 * (j >> 2) + 4 * q + (j & 3);   // instance 16 w + j -> tile 4 w + j/4, n = j%4
-    const int rd = 4 * q + (lane & 3);
-
-    double acc[RT][NT4];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int t = 0; t < NT4; ++t) acc[rt][t] = 0.0;
-
-    V m[RT][kPieces], mn[RT][kPieces], xg[kPieces];
-    if (sbeg < send) {
-        const size_t k0 = sbeg * KS;
-#pragma unroll
-        for (int p = 0; p < kPieces; ++p) {
-            const bool in = !TAIL || k0 + p * 4 * E + q * E < C;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                m[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k0 + p * 4 * E) : vzero;
-            if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k0 + p * 4 * E) : vzero;
-        }
-    }
-    for (size_t s = sbeg; s < send; ++s) {
-        const int st = (int)((s - sbeg) & 1);
-        if (loads_x) {
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) xs[st][p][wr] = xg[p];
-        }
-        if (s + 1 < send) {
-            const size_t k1 = (s + 1) * KS;
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) {
-                const bool in = !TAIL || k1 + p * 4 * E + q * E < C;
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    mn[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k1 + p * 4 * E) : vzero;
-                if (loads_x) xg[p] = in ? *reinterpret_cast<const V*>(xp + k1 + p * 4 * E) : vzero;
-            }
-        }
-        __syncthreads();
-        // software pipeline over the (piece, tile pair) stages: the x fragments of stage i+1 are
-        // read from LDS while the 4 RT MFMAs of stage i issue (one ds_read_b128 feeds 2 RT MFMAs)
-        constexpr int NST = kPieces * (NT4 / 2);
-        V xa = xs[st][0][rd], xc = xs[st][0][16 + rd];
-#pragma unroll
-        for (int sg = 0; sg < NST; ++sg) {
-            const int p = sg / (NT4 / 2), t = 2 * (sg % (NT4 / 2));
-            V na = xa, nc = xc;
-            if (sg + 1 < NST) {
-                const int p1 = (sg + 1) / (NT4 / 2), t1 = 2 * ((sg + 1) % (NT4 / 2));
-                na = xs[st][p1][t1 * 16 + rd];
-                nc = xs[st][p1][(t1 + 1) * 16 + rd];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    acc[rt][t] = mfma4(m[rt][p][e], xa[e], acc[rt][t]);
-                    acc[rt][t + 1] = mfma4(m[rt][p][e], xc[e], acc[rt][t + 1]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            xa = na;
-            xc = nc;
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) m[rt][p] = mn[rt][p];
-    }
-    // D[blk][i][n] in lane 16 i + 4 blk + n: mat row 4 blk + i, instance n of the tile
-    double* pout = partials + (split * B) * R;
-    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dn = lane & 3;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const size_t r = row0 + rt * 16 + drow;
-        if (r < R) {
-#pragma unroll
-            for (int t = 0; t < NT4; ++t) {
-                const size_t b = 4 * t + dn;
-                if (b < nb) pout[(bchunk + b) * R + r] = acc[rt][t];
-            }
-        }
-    }
-}
-
-template <int BT, bool TAIL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 3)))
-void gemm_nn4_kernel(size_t R, size_t C, size_t B, const double* __restrict__ mat, const double* __restrict__ x,
-                     size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
-    using V = v2d;
-    constexpr int E = 2;
-    constexpr int KS = 4 * kPieces * E;
-    constexpr int S = kPieces * E;                 // rows per lane per step
-    constexpr int NT4 = 4 * BT;
-    __shared__ V xs[2][kPieces][BT * 64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const size_t cb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-    const size_t bchunk = (size_t)blockIdx.y * 64;
-    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
-    const size_t col0 = cb * (64 * E) + (size_t)wave * (16 * E);
-    const size_t nsteps_total = (R + KS - 1) / KS;
-    const size_t sbeg = split * steps_per_split;
-    size_t send = sbeg + steps_per_split;
-    if (send > nsteps_total) send = nsteps_total;
-    const V vzero = {};
-    size_t cl = col0 + E * j;
-    if (cl + E > C) cl = C - E;
-    const double* mp = mat + cl + (size_t)(S * q) * C;
-    size_t xb = bchunk + (size_t)wave * 16 + j;
-    if (xb >= B) xb = B - 1;
-    const double* xp = x + xb * R + S * q;
-    const bool loads_x = wave < BT;
-    const int wr = 64 * wave + 16 * (j >> 2) + 4 * q + (j & 3);
-    const int rd = 4 * q + (lane & 3);
-
-    double acc[E][NT4];
-#pragma unroll
-    for (int nt = 0; nt < E; ++nt)
-#pragma unroll
-        for (int t = 0; t < NT4; ++t) acc[nt][t] = 0.0;
-
-    V m[S], mn[S], xg[kPieces];
-    if (sbeg < send) {
-        const size_t k0 = sbeg * KS;
-#pragma unroll
-        for (int s4 = 0; s4 < S; ++s4)
-            m[s4] = (!TAIL || k0 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k0 + s4) * C) : vzero;
-        if (loads_x) {
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p)
-                xg[p] = (!TAIL || k0 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k0 + p * E) : vzero;
-        }
-    }
-    for (size_t s = sbeg; s < send; ++s) {
-        const int st = (int)((s - sbeg) & 1);
-        if (loads_x) {
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) xs[st][p][wr] = xg[p];
-        }
-        if (s + 1 < send) {
-            const size_t k1 = (s + 1) * KS;
-#pragma unroll
-            for (int s4 = 0; s4 < S; ++s4)
-                mn[s4] = (!TAIL || k1 + S * q + s4 < R) ? *reinterpret_cast<const V*>(mp + (k1 + s4) * C) : vzero;
-            if (loads_x) {
-#pragma unroll
-                for (int p = 0; p < kPieces; ++p)
-                    xg[p] = (!TAIL || k1 + S * q + p * E < R) ? *reinterpret_cast<const V*>(xp + k1 + p * E) : vzero;
-            }
-        }
-        __syncthreads();
-        // stages of 4 instance tiles (16 MFMAs); the next stage's x fragments are read meanwhile
-        // (reading two stages ahead measured no faster)
-        constexpr int NST = kPieces * (NT4 / 4);
-        V xa[4], na[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) xa[tt] = xs[st][0][tt * 16 + rd];
-#pragma unroll
-        for (int sg = 0; sg < NST; ++sg) {
-            const int p = sg / (NT4 / 4), t0 = 4 * (sg % (NT4 / 4));
-            if (sg + 1 < NST) {
-                const int p1 = (sg + 1) / (NT4 / 4), t1 = 4 * ((sg + 1) % (NT4 / 4));
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) na[tt] = xs[st][p1][(t1 + tt) * 16 + rd];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                    for (int nt = 0; nt < E; ++nt)
-                        acc[nt][t0 + tt] = mfma4(m[p * E + e][nt], xa[tt][e], acc[nt][t0 + tt]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (sg + 1 < NST) {
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) xa[tt] = na[tt];
-            }
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < S; ++s4) m[s4] = mn[s4];
-    }
-    double* pout = partials + (split * B) * C;
-    const int dj = 4 * ((lane >> 2) & 3) + (lane >> 4), dn = lane & 3;
-    const size_t c = col0 + E * dj;
-    if (c + E <= C) {
-#pragma unroll
-        for (int t = 0; t < NT4; ++t) {
-            const size_t b = 4 * t + dn;
-            if (b < nb)
-                *reinterpret_cast<double2*>(pout + (bchunk + b) * C + c) = double2{acc[0][t], acc[1][t]};
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------ f64, specialised waves
-// 8 waves per workgroup, one workgroup per CU: waves 0-3 are CONSUMERS (one per SIMD; MFMA and
-// LDS reads only, never a global load), waves 4-7 are LOADERS (global -> registers -> LDS, two
-// k steps in flight).  A step's operands live in one of two LDS slots: the matrix tile of the
-// workgroup (256 rows x 16 columns) as 32 fragments in MFMA lane order and the x tile (64
-// instances x 16 columns) as [piece][tile][k][n]; one workgroup barrier per step hands slot
-// s+1 to the consumers while the loaders already have slots s+2 and s+3 in flight.
-// tools/probes/probe_mfma4_lds.hip: a wave fed this way from LDS sustains 70-76 TFLOP/s chip-wide,
-// and with the loads switched off (TRAMP_MFMA_RING_DBG=1) this kernel runs at 69-70 TFLOP/s;
-// with them it lands on the same power wall as every other variant (50 TFLOP/s at 1375 W).
-// Kept, off by default (TRAMP_MFMA_F64_SHAPE=4 TRAMP_MFMA_RING=1), as the evidence for that.
-constexpr int kRingRT = 4;                                   // 16-row tiles per consumer wave
-constexpr int kRingMatFrag = 4 * kRingRT * kPieces;          // 32 matrix fragments (1 KiB each) per slot
-// (padded to a multiple of 4 fragments so that every loader wave has the same, branch-free work)
-template <int BT> constexpr int ring_slot_v2d() { return ((kRingMatFrag + BT * kPieces + 3) / 4) * 4 * 64; }
-
-template <int BT, bool TAIL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_nt4_ring_kernel(size_t R, size_t C, size_t B, const double* __restrict__ mat, const double* __restrict__ x,
-                          size_t steps_per_split, unsigned nsplit, double* __restrict__ partials) {
-    using V = v2d;
-    constexpr int E = 2, RT = kRingRT;
-    constexpr int KS = 4 * kPieces * E;
-    constexpr int NT4 = 4 * BT;
-    constexpr int NXF = BT * kPieces;                        // x fragments per slot
-    constexpr int NF = kRingMatFrag + NXF;                   // fragments per slot
-    constexpr int NFL = (NF + 3) / 4;                        // fragments per loader wave
-    constexpr int SLOT = ring_slot_v2d<BT>();
-    extern __shared__ V ring[];                              // [2][SLOT]
-    const unsigned dbg = nsplit >> 16;                       // experiment knob (0 in production)
-    nsplit &= 0xffffu;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const size_t rb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-    const size_t bchunk = (size_t)blockIdx.y * 64;
-    const size_t nb = (B - bchunk < 64) ? B - bchunk : 64;
-    const size_t nsteps_total = (C + KS - 1) / KS;
-    const size_t sbeg = split * steps_per_split;
-    size_t send = sbeg + steps_per_split;
-    if (send > nsteps_total) send = nsteps_total;
-    const size_t nst = send > sbeg ? send - sbeg : 0;
-    const V vzero = {};
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------ loader
-        const int lw = wave - 4;
-        const double* fp[NFL];                                // per-lane source of fragment i (column offset added per step)
-        int dst[NFL];                                         // per-lane destination inside a slot (V units)
-        int pofs[NFL];
-#pragma unroll
-        for (int i = 0; i < NFL; ++i) {
-            const int f = lw + 4 * i;
-            if (f < kRingMatFrag) {
-                const int cw = f / (RT * kPieces), rt = (f / kPieces) % RT, p = f % kPieces;
-                size_t r = rb * (64 * RT) + (size_t)cw * (16 * RT) + rt * 16 + j;
-                if (r >= R) r = R - 1;
-                fp[i] = mat + r * C + q * E;
-                pofs[i] = p * 4 * E;
-                dst[i] = f * 64 + lane;
-            } else if (f < NF) {
-                const int g = (f - kRingMatFrag) / kPieces, p = (f - kRingMatFrag) % kPieces;
-                size_t xb = bchunk + (size_t)g * 16 + j;
-                if (xb >= B) xb = B - 1;
-                fp[i] = x + xb * C + q * E;
-                pofs[i] = p * 4 * E;
-                dst[i] = kRingMatFrag * 64 + p * (BT * 64) + 64 * g + 16 * (j >> 2) + 4 * q + (j & 3);
-            } else {                                          // padding fragment: harmless load, junk slot
-                fp[i] = mat + q * E;
-                pofs[i] = 0;
-                dst[i] = f * 64 + lane;
-            }
-        }
-        V buf[2][NFL];
-        auto issue = [&](size_t s, int set) {
-            const size_t k0 = (sbeg + s) * KS;
-#pragma unroll
-            for (int i = 0; i < NFL; ++i) {
-                if (TAIL) {
-                    const bool in = k0 + pofs[i] + q * E < C;
-                    buf[set][i] = in ? *reinterpret_cast<const V*>(fp[i] + k0 + pofs[i]) : vzero;
-                } else {
-                    buf[set][i] = *reinterpret_cast<const V*>(fp[i] + k0 + pofs[i]);
-                }
-            }
-        };
-        auto store = [&](size_t s, int set) {
-            V* slot = ring + (s & 1) * SLOT;
-#pragma unroll
-            for (int i = 0; i < NFL; ++i) slot[dst[i]] = buf[set][i];
-        };
-        // slots 0, 1, 2 in flight before the first barrier; slot 0 is stored right away
-        if (nst > 0) issue(0, 0);
-        if (nst > 1) issue(1, 1);
-        if (nst > 0) store(0, 0);
-        if (nst > 2) issue(2, 0);
-        __syncthreads();                                     // slot 0 visible
-        // consumers work on slot s; slot s+1 is handed over at the barrier that ends step s.
-        // Unrolled by two so that the register set of every load / store is a compile-time
-        // constant (a run-time set index makes the compiler wait for each load right away).
-        if (dbg == 1) {                                      // barriers only: consumer-side ceiling
-            for (size_t s = 0; s < nst; ++s) __syncthreads();
-            return;
-        }
-        for (size_t s = 0; s < nst; s += 2) {
-            if (s + 1 < nst) store(s + 1, 1);
-            if (s + 3 < nst) issue(s + 3, 1);
-            __syncthreads();
-            if (s + 1 < nst) {
-                if (s + 2 < nst) store(s + 2, 0);
-                if (s + 4 < nst) issue(s + 4, 0);
-                __syncthreads();
-            }
-        }
-        return;
-    }
-    // ---------------------------------------------------------------- consumer
-    const size_t row0 = rb * (64 * RT) + (size_t)wave * (16 * RT);
-    const int rd = 4 * q + (lane & 3);
-    double acc[RT][NT4];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int t = 0; t < NT4; ++t) acc[rt][t] = 0.0;
-    __syncthreads();
-    for (size_t s = 0; s < nst; ++s) {
-        const V* slot = ring + (s & 1) * SLOT;
-        const V* xs = slot + kRingMatFrag * 64;
-        V m[RT][kPieces];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int p = 0; p < kPieces; ++p) m[rt][p] = slot[((wave * RT + rt) * kPieces + p) * 64 + lane];
-        constexpr int NST = kPieces * (NT4 / 2);
-        V xa = xs[rd], xc = xs[16 + rd];
-#pragma unroll
-        for (int sg = 0; sg < NST; ++sg) {
-            const int p = sg / (NT4 / 2), t = 2 * (sg % (NT4 / 2));
-            V na = xa, nc = xc;
-            if (sg + 1 < NST) {
-                const int p1 = (sg + 1) / (NT4 / 2), t1 = 2 * ((sg + 1) % (NT4 / 2));
-                na = xs[p1 * (BT * 64) + t1 * 16 + rd];
-                nc = xs[p1 * (BT * 64) + (t1 + 1) * 16 + rd];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    acc[rt][t] = mfma4(m[rt][p][e], xa[e], acc[rt][t]);
-                    acc[rt][t + 1] = mfma4(m[rt][p][e], xc[e], acc[rt][t + 1]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            xa = na;
-            xc = nc;
-        }
-        __syncthreads();
-    }
-    double* pout = partials + (split * B) * R;
-    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dn = lane & 3;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const size_t r = row0 + rt * 16 + drow;
-        if (r < R) {
-#pragma unroll
-            for (int t = 0; t < NT4; ++t) {
-                const size_t b = 4 * t + dn;
-                if (b < nb) pout[(bchunk + b) * R + r] = acc[rt][t];
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------ fold + epilogue
 template <typename T>
 __device__ __forceinline__ T mfma_epilogue(const LinEpi& e, size_t b, size_t idx, size_t len, double acc) {
@@ -840,8 +416,7 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
     static const int split_env = getenv("TRAMP_MFMA_SPLIT") ? atoi(getenv("TRAMP_MFMA_SPLIT")) : 0;
     static const int pad_env = getenv("TRAMP_MFMA_LDS_PAD") ? atoi(getenv("TRAMP_MFMA_LDS_PAD")) : 0;
     const unsigned nchunk0 = (unsigned)((batch + 63) / 64);
-    static const int rt_probe = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 2;
-    const size_t rows_per_wg = 64 * (size_t)(rt_probe == 1 ? 1 : (rt_probe == 4 ? 4 : 2));
+    const size_t rows_per_wg = 64 * 2;                 // RT = 2 sixteen-row tiles per wave
     const size_t nblocks = nt ? (R + rows_per_wg - 1) / rows_per_wg : (C + 64 * E - 1) / (64 * E);
     const unsigned nsplit = (unsigned)pick_split(ctx, nt, nblocks, nchunk0, nsteps, split_env);
     const size_t sps = (nsteps + nsplit - 1) / nsplit;
@@ -865,75 +440,15 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
         case 3: M_(3, TAILv); break;           \
         default: M_(4, TAILv); break;          \
     }
-    // 16: v_mfma_f64_16x16x4 kernels (default, 54-55 TFLOP/s at batch 64); 4: the 4x4x4-block kernels
-    // (50-52 TFLOP/s today although the instruction itself issues 1.6x faster - see the note above them)
-    static const int shape_env = getenv("TRAMP_MFMA_F64_SHAPE") ? atoi(getenv("TRAMP_MFMA_F64_SHAPE")) : 16;
-    static const int ring_env = getenv("TRAMP_MFMA_RING") ? atoi(getenv("TRAMP_MFMA_RING")) : 0;
-    static const int ring_dbg = getenv("TRAMP_MFMA_RING_DBG") ? atoi(getenv("TRAMP_MFMA_RING_DBG")) : 0;
-    if constexpr (sizeof(T) == 8) {
-        if (shape_env == 4) {
-            constexpr int RT = 4;
-#define LAUNCH_NT4(BTv, TAILv) hipLaunchKernelGGL((gemm_nt4_kernel<BTv, RT, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
-#define LAUNCH_NN4(BTv, TAILv) hipLaunchKernelGGL((gemm_nn4_kernel<BTv, TAILv>), grid, block, pad_env, ctx->stream, R, C, batch, mat, x, sps, nsplit, ctx->ws)
-            if (nt && ring_env) {
-                const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-                dim3 grid((unsigned)(nrb * nsplit), nchunk);
-#define LAUNCH_NTR(BTv, TAILv)                                                                                         \
-    do {                                                                                                               \
-        const size_t lds = 2 * (size_t)ring_slot_v2d<BTv>() * sizeof(v2d);                                            \
-        static bool attr_done = false;                                                                                 \
-        if (!attr_done) {                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_ring_kernel<BTv, TAILv>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-            attr_done = true;                                                                                          \
-        }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt4_ring_kernel<BTv, TAILv>), grid, dim3(512), lds, ctx->stream, R, C, batch, mat, x, \
-                           sps, nsplit | ((unsigned)ring_dbg << 16), ctx->ws);                                                                    \
-    } while (0)
-                if (tail) { BY_BT(LAUNCH_NTR, true) } else { BY_BT(LAUNCH_NTR, false) }
-#undef LAUNCH_NTR
-            } else if (nt) {
-                const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-                dim3 grid((unsigned)(nrb * nsplit), nchunk);
-                if (tail) { BY_BT(LAUNCH_NT4, true) } else { BY_BT(LAUNCH_NT4, false) }
-            } else {
-                const size_t ncb = (C + 64 * E - 1) / (64 * E);
-                dim3 grid((unsigned)(ncb * nsplit), nchunk);
-                if (tail) { BY_BT(LAUNCH_NN4, true) } else { BY_BT(LAUNCH_NN4, false) }
-            }
-#undef LAUNCH_NT4
-#undef LAUNCH_NN4
-            dim3 g4((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
-            LinEpi e4 = epi;
-            lin_arm_hint(ctx, e4, len, batch, (int)g4.x);
-            hipLaunchKernelGGL((mfma_fold_kernel<T>), g4, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, e4);
-            TRAMP_LAUNCH_CHECK(ctx);
-            return TRAMP_OK;
-        }
-    }
     if (nt) {
         // 16-row tiles per wave.  Round 3, with the alternating register sets: RT = 2 (160 VGPRs, 3 waves per SIMD)
         // 56.1 TFLOP/s against 53.4 for RT = 4 (256 VGPRs, 2 waves) on the 50000 x 100000 x 64 f64 pass; before
         // (loads waited for inside the MFMA block) it was the other way round, 51 against 54.
-        static const int rt_env = getenv("TRAMP_NT_RT") ? atoi(getenv("TRAMP_NT_RT")) : 2;
-        if (rt_env == 4) {
-            constexpr int RT = 4;
-            const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid = chunk_grid(nrb * nsplit, nchunk);
-            ctx->last_flat = nchunk > 1 && grid.y == 1;
-            if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
-        } else if (rt_env == 1) {
-            constexpr int RT = 1;
-            const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid((unsigned)(nrb * nsplit), nchunk);
-            if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
-        } else {
-            constexpr int RT = 2;
-            const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
-            dim3 grid = chunk_grid(nrb * nsplit, nchunk);
-            ctx->last_flat = nchunk > 1 && grid.y == 1;
-            if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
-        }
+        constexpr int RT = 2;
+        const size_t nrb = (R + 64 * RT - 1) / (64 * RT);
+        dim3 grid = chunk_grid(nrb * nsplit, nchunk);
+        ctx->last_flat = nchunk > 1 && grid.y == 1;
+        if (tail) { BY_BT(LAUNCH_NT, true) } else { BY_BT(LAUNCH_NT, false) }
     } else {
         const size_t ncb = (C + 64 * E - 1) / (64 * E);
         dim3 grid = chunk_grid(ncb * nsplit, nchunk);

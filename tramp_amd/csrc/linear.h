@@ -8,8 +8,6 @@ struct tramp_linear {
     size_t M, N, k, rank;
     const void* Uk;      // [M, k]
     const void* Vt;      // [k, N]
-    const void* Vtt;     // optional [N, k]: Vt transposed (tramp_linear_set_transposed): row-dot passes over Vt run as
-    const void* Ukt;     // optional [k, M]: Uk transposed    column passes over the copy when the MFMA path is taken
     const double* sing;  // [k]
     double* s2;          // [k] spectrum = sing^2 (owned)
     void* work;          // owned: t, u, w [batch, k] + a_raw[batch]

@@ -367,21 +367,15 @@ static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t 
     return matvec_valu<float>(ctx, nt, R, C, batch, mat_d, x_d, epi);
 }
 
-// out = mat x over the ROWS of mat [R, C] (a row-dot pass).  When a transposed copy matT [C, R] is resident and the
-// ensemble takes the MFMA path, the same product runs as a column pass over the copy: the column kernel reads 256
-// contiguous bytes per matrix row and instruction where the row-dot kernel reads 64, and keeps the matrix pipe
-// 87 % busy against 81 % (50000 x 100000 x 64, f64: 57.9 against 55.8 TFLOP/s alone; profiles/r03).  Same flops, same
-// bytes.  In the EP loop both passes sit on the package power limit and the iteration does not get shorter (23.29
-// against 23.24 ms), so the host side only makes the copies on request (TRAMP_LINEAR_TRANSPOSED=1).
+// out = mat x over the ROWS of mat [R, C] (a row-dot pass).  (Round 3 measured the same product as a column pass over a
+// resident transposed copy: 57.9 against 55.8 TFLOP/s for the pass alone, 23.29 against 23.24 ms for the EP iteration -
+// both passes sit on the package power limit - at 40 GB of extra HBM; DESIGN 9.2.  The copies left the library.)
 static int rowdot_dispatch(tramp_ctx* ctx, int dtype, size_t R, size_t C, size_t batch, const void* mat_d,
-                           const void* matT_d, const void* x_d, const LinEpi& epi) {
-    static const int use_t = getenv("TRAMP_LINEAR_TRANSPOSED") ? atoi(getenv("TRAMP_LINEAR_TRANSPOSED")) : 1;
-    if (matT_d && use_t && batch > 2 && gemm_mfma_supported(dtype, false, C, R, batch))
-        return matvec_dispatch(ctx, dtype, 0, false, C, R, batch, matT_d, x_d, epi);
+                           const void* x_d, const LinEpi& epi) {
     return matvec_dispatch(ctx, dtype, 0, true, R, C, batch, mat_d, x_d, epi);
 }
 
-// dst [C, R] = src [R, C]^T through 32 x 32 LDS tiles (setup: the transposed copies of the thin factors)
+// dst [C, R] = src [R, C]^T through 32 x 32 LDS tiles (tramp_transpose: a utility of the set-up path)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void transpose_kernel(size_t R, size_t C, const T* __restrict__ src, T* __restrict__ dst) {
     __shared__ T tile[32][33];
@@ -407,14 +401,6 @@ extern "C" int tramp_transpose(tramp_ctx* ctx, int dtype, size_t R, size_t C, co
         hipLaunchKernelGGL((transpose_kernel<float>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, R, C,
                            (const float*)src_d, (float*)dst_d);
     TRAMP_LAUNCH_CHECK(ctx);
-    return TRAMP_OK;
-}
-
-extern "C" int tramp_linear_set_transposed(tramp_ctx* ctx, tramp_linear* lin, const void* Vtt_d, const void* Ukt_d) {
-    if (!ctx) return TRAMP_EINVAL;
-    TRAMP_REQUIRE(ctx, lin);
-    lin->Vtt = Vtt_d;
-    lin->Ukt = Ukt_d;
     return TRAMP_OK;
 }
 
@@ -630,7 +616,7 @@ int lin_project(tramp_ctx* ctx, tramp_linear* lin, size_t batch, const void* bz_
         TRAMP_HIP_CHECK(ctx, hipMemcpyAsync(lin->t, bz_d, batch * lin->k * dtype_size(lin->dtype),
                                             hipMemcpyDeviceToDevice, ctx->stream));
     } else if (!(reuse & TRAMP_REUSE_T)) {
-        rc = rowdot_dispatch(ctx, lin->dtype, lin->k, lin->N, batch, lin->Vt, lin->Vtt, bz_d, plain);
+        rc = rowdot_dispatch(ctx, lin->dtype, lin->k, lin->N, batch, lin->Vt, bz_d, plain);
         if (rc) return rc;
     }
     plain.out = lin->u;
@@ -670,7 +656,7 @@ extern "C" int tramp_linear_project_affine(tramp_ctx* ctx, tramp_linear* lin, in
         LinEpi plain{};
         plain.mode = 0;
         plain.out = pc;
-        int rc = is_t ? rowdot_dispatch(ctx, lin->dtype, lin->k, lin->N, batch, lin->Vt, lin->Vtt, c_d, plain)
+        int rc = is_t ? rowdot_dispatch(ctx, lin->dtype, lin->k, lin->N, batch, lin->Vt, c_d, plain)
                       : matvec_dispatch(ctx, lin->dtype, 0, false, lin->M, lin->k, batch, lin->Uk, c_d, plain);
         if (rc) return rc;
         valid = true;
@@ -717,7 +703,7 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
     if (lin->rot & 2) {
         t_ptr = bz_d;                                     // t = Vt bz is bz' itself
     } else if (!(reuse & TRAMP_REUSE_T)) {
-        rc = rowdot_dispatch(ctx, dtype, k, N, batch, lin->Vt, lin->Vtt, bz_d, plain);
+        rc = rowdot_dispatch(ctx, dtype, k, N, batch, lin->Vt, bz_d, plain);
         if (rc) return rc;
     }
     // 3. u = Uk^T bx  [batch, k]
@@ -762,7 +748,7 @@ extern "C" int tramp_linear_message(tramp_ctx* ctx, tramp_linear* lin, int dir, 
                                    (const float*)lin->w, epi);
             rc = TRAMP_OK;
         } else
-            rc = rowdot_dispatch(ctx, dtype, M, k, batch, lin->Uk, lin->Ukt, lin->w, epi);   // rx = Uk w
+            rc = rowdot_dispatch(ctx, dtype, M, k, batch, lin->Uk, lin->w, epi);   // rx = Uk w
     } else {
         epi.a_in = az_d;
         epi.b_in = bz_d;

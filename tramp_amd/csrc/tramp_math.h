@@ -414,7 +414,7 @@ TM_HD HalfLine<T> halfline_fast(T b, const RegionConst<T>& c, int side, T& r0, T
 // instructions per component, saved).
 template <typename T> struct HalfLineF { T mean, var, e, ie, y0; bool mask; };
 
-template <typename T>
+template <typename T, bool UNI = true>
 TM_HD HalfLineF<T> halfline_factor(T b, const RegionConst<T>& c, int side, T& r0, T zb = T(0)) {
     // The reference's mask is u = -side (zb - b/a)/s0 < cut with IEEE divisions.  The reciprocal forms
     // below differ from those by a few ulp, which can only matter within ~1e-12 of the threshold: there
@@ -428,7 +428,7 @@ TM_HD HalfLineF<T> halfline_factor(T b, const RegionConst<T>& c, int side, T& r0
         y0 = (zb - r0) / c.s0;
     }
     T x = sd * (y0 * T(0.70710678118654752440));
-    T e = erfcx_hot<true>(x);
+    T e = erfcx_hot<UNI>(x);
     T ie = rcp_pos(fmin_(e, RcpCap<T>::value));       // e = inf (x << 0) -> ~0; NaN travels through x and r0
     T g1 = T(kSqrt2OverPi) * (sd * ie);
     T g2 = T(kTwoOverSqrtPi) * (x * ie);
@@ -635,7 +635,9 @@ template <typename T, int KIND> TM_HD PwlConst<T> pwl_const(double az, double ax
     return c;
 }
 
-template <typename T, int KIND, bool FWD>
+// UNI: erfcx from the uniform-grid table (22 KiB of LDS) or from the small reciprocal-mapped one (2 KiB; the resident
+// pipeline, whose LDS holds the parked posterior means)
+template <typename T, int KIND, bool FWD, bool UNI = true>
 TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
     T rs[2], vs[2], r0s[2];
     HalfLineF<T> h[2];
@@ -654,7 +656,7 @@ TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
         } else {
             b = bz + c.slope[k] * (bx - c.ax * c.x0[k]);
         }
-        h[k] = halfline_factor<T>(b, c.reg[k], side, r0s[k], zb);
+        h[k] = halfline_factor<T, UNI>(b, c.reg[k], side, r0s[k], zb);
         if (!FWD) {
             rs[k] = h[k].mean;
             vs[k] = h[k].var;

@@ -1,0 +1,58 @@
+"""Every environment variable the library reads, with its default and what it is for - the ONE table.
+
+None of them is needed to run anything: the defaults are what `bench.py` and the test suite run (bench.py records the
+TRAMP_* variables it finds set as ``env_overrides``; tests/test_cabi_and_host.py checks that every getenv / environ.get in
+the sources is listed here and nothing else is).  Kinds: `select` chooses between implementations that are all parity
+tested, `tune` moves a launch-shape parameter whose default was measured, `debug` is for diagnosis only.
+"""
+
+SWITCHES = {
+    # name: (default, kind, meaning)
+    "TRAMP_HIP_LIB": ("tramp_amd/libtramp_hip.so", "select", "path of the C-ABI library to load (an experimental build)"),
+    # componentwise updates (csrc/ew_kernels.hip, ew_resident.h)
+    "TRAMP_EW_RESIDENT": ("1", "select", "0: never take the resident single-pass pipeline (the tile kernels' two passes instead)"),
+    "TRAMP_EW_RESIDENT_MIN_ROUNDS": ("4", "tune", "rounds of 2 x CUs - 8 tiles below which the pipeline is not worth its fill and drain"),
+    "TRAMP_PRIOR_FUSE": ("1", "select", "0: producers never leave prior / likelihood moments (csrc/prior_hint.h)"),
+    # dense linear channel (csrc/linear.hip, gemm_mfma.hip)
+    "TRAMP_MATVEC_ALGO": ("0", "debug", "force a matrix-pass engine: 1 GEMV (VALU), 2 MFMA; 0 = by batch size"),
+    "TRAMP_MFMA_SPLIT": ("0", "tune", "split-K factor of the MFMA passes; 0 = chosen from the grid size"),
+    "TRAMP_MFMA_LDS_PAD": ("0", "tune", "extra dynamic LDS per workgroup of the MFMA passes (occupancy experiments)"),
+    "TRAMP_MFMA_CHUNK_2D": ("0", "tune", "1: 64-instance chunks on the grid's y axis instead of interleaved in x"),
+    "TRAMP_ROTATE_INPUT": ("1", "select", "0: keep the linear channel's input variable in the canonical basis (algos.py)"),
+    "TRAMP_ROTATE_OUTPUT": ("1", "select", "0: keep the linear channel's output variable in the canonical basis (algos.py)"),
+    "TRAMP_LSOLVE_SCRATCH_MB": ("2048", "tune", "MB of N x N systems SolveLinearChannel factorises per strided-batched call"),
+    # factorisation (csrc/factorize.hip)
+    "TRAMP_EIG_CAP": ("46336", "tune", "largest symmetric eigenproblem handed to rocSOLVER syevd whole; above it the spectral split"),
+    "TRAMP_EIG_SUBCAP": ("16384", "tune", "halves of a forced split are split again down to this size"),
+    "TRAMP_EIG_VERBOSE": (None, "debug", "set: phase timings of the factorisation on stderr"),
+    # structured channels (csrc/conv.hip, fft_pow2.hip)
+    "TRAMP_CONV_FFT": ("auto", "select", "own | rocfft: FFT engine of the convolution / gradient channels"),
+    "TRAMP_CONV_FFT_MIN_POINTS": ("32768", "tune", "signals shorter than this go to rocFFT under TRAMP_CONV_FFT=auto"),
+    "TRAMP_CONV_IPB": ("0", "tune", "images per workgroup of the one-launch small-image kernel; 0 = chosen from the shape"),
+    "TRAMP_DFT_FFT": ("auto", "select", "own | rocfft: FFT engine of DFTChannel"),
+    "TRAMP_FFT_BLOCK_THREADS": ("0", "tune", "threads of the own engine's block pass; 0 = by length"),
+    "TRAMP_FFT_STRIDED_THREADS": ("0", "tune", "threads of the own engine's strided pass; 0 = by length"),
+    "TRAMP_FFT_AXIS_THREADS": ("0", "tune", "threads of the own engine's long-axis pass (N-D transforms)"),
+    "TRAMP_FFT_AXIS_DIV": ("0", "tune", "columns per workgroup divisor of the long-axis pass"),
+    "TRAMP_FFT_IMAGE": ("1", "select", "0: never take the one-launch small-image transform"),
+    # state evolution (csrc/se_kernels.hip)
+    "TRAMP_SE_2D": ("1", "select", "0: brute-force grid instead of the adaptive Gauss-Legendre panels for the 2-D averages"),
+    "TRAMP_SE_PANELS2D": ("768", "tune", "panels per axis of the 2-D state-evolution quadrature (8 ... 4096)"),
+    # tree scheduler (tree.py)
+    "TRAMP_TREE_ALIAS": ("1", "select", "0: no aliasing of the tree scheduler's message buffers"),
+    "TRAMP_TREE_MONITOR": ("device", "select", "host: the tree scheduler's stopping rule on the host"),
+}
+
+
+def overrides(environ=None):
+    "the TRAMP_* variables of `environ` (default os.environ) that the library reads: {} means 'all defaults'"
+    import os
+    env = os.environ if environ is None else environ
+    return {k: env[k] for k in sorted(SWITCHES) if k in env}
+
+
+def markdown_table():
+    rows = ["| variable | default | kind | meaning |", "|---|---|---|---|"]
+    for k, (d, kind, doc) in SWITCHES.items():
+        rows.append(f"| `{k}` | {'unset' if d is None else '`' + str(d) + '`'} | {kind} | {doc} |")
+    return "\n".join(rows)
