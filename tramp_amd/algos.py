@@ -752,8 +752,9 @@ class ExpectationPropagation:
 
     # The chain scheduler does not copy: it alternates two sets of message buffers (b vectors and the precision table),
     # so the set written in the previous iteration is the snapshot (`_snap["fwd"], ["bwd"], ["A"]` ARE that set).
-    # tools/bench_restore_overhead.py: the four copies cost +16 % per iteration at 10^6 x 64.  Schedulers that keep
-    # separate variable -> factor buffers (tree.py) copy instead (_pingpong = False).
+    # tools/bench_restore_overhead.py: the four copies cost +16 % per iteration at 10^6 x 64.  The tree scheduler
+    # (tree.py) alternates its buffer sets the same way; a scheduler that cannot sets _pingpong = False and gets the
+    # copying branch of _take_snapshot.
     _pingpong = True
 
     def _pp_active(self):
@@ -1064,7 +1065,9 @@ class ExpectationPropagation:
         (``status``, ``n_iter_instance``, get_variables_data) while the others go on; k > 1 only delays the
         moment the loop notices that all are done.  ``graph=True`` captures the steady-state launch sequence
         in a hipGraph and replays it (launch-bound small problems); results are identical to the eager loop.
-        ``restore_messages`` (default: on whenever the device runs a stopping rule): the reference's "restoring
+        ``restore_messages`` (default: on whenever the device runs a stopping rule; it keeps a second set of message
+        buffers and a frozen set per edge - three times the message memory, about 3 GB per variable at 10^6 x 64 f64 -
+        and one freeze kernel per message and iteration; pass False where neither fits): the reference's "restoring
         old message dag" per instance - the messages are snapshot before every iteration (two alternating sets of buffers, no copies),
         an instance that gives up after an increase gets the previous iteration's messages back, a converged one
         keeps those of its stopping iteration, and a NaN puts every instance back one iteration before ValueError
@@ -1088,8 +1091,16 @@ class ExpectationPropagation:
                 if warm_start:
                     raise ValueError("adaptive damping cannot warm-start a run that carried variables in a rotated basis")
             if self._rot:
+                self._rot_saved = self._rot                  # a later non-adaptive run gets its rotated bases back
                 self._rot = {}                               # all messages in the original basis
                 self._allocated = False
+        elif getattr(self, "_rot_saved", None) and not warm_start:
+            # back from an adaptive run: the rotated-basis fast path again, and no stale variable -> factor buffers
+            self._rot, self._rot_saved = self._rot_saved, None
+            self._allocated = False
+            for nm in ("a_vf", "b_vf", "a_vb", "b_vb"):
+                if hasattr(self, nm):
+                    delattr(self, nm)
         self._adaptive = adaptive
         if warm_start:
             if not self._allocated:
@@ -1098,7 +1109,9 @@ class ExpectationPropagation:
             self.init_message_dag(initializer)
             self.n_iter = 0
         if adaptive:
-            self._adaptive_allocate(fresh=not warm_start)
+            # a warm start after a NON-adaptive run: the variable -> factor buffers are from before it, rebuild them
+            self._adaptive_allocate(fresh=(not warm_start) or not getattr(self, "_prev_adaptive", False))
+        self._prev_adaptive = adaptive
         if self._device_monitor and not adaptive:
             self._reset_monitor()            # a warm start begins a new run of the stopping rule (i = 0 again)
             stopper, host_cbs = self._split_callback(callback)

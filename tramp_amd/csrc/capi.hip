@@ -288,6 +288,9 @@ extern "C" int tramp_mem_info(tramp_ctx* ctx, size_t* free_bytes, size_t* total_
 extern "C" int tramp_buf_alloc(tramp_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return TRAMP_EINVAL;
     *dptr = nullptr;
+    // A buffer born inside tramp_graph_begin / _end would be baked into the captured kernel nodes and could be freed
+    // (deferred, below) before the first replay: no allocation while a capture is open - the caller allocates first.
+    if (ctx->capturing) return tramp_fail(ctx, TRAMP_EINVAL, "tramp_buf_alloc", "allocation inside a graph capture");
     if (bytes == 0) bytes = 16;
     TRAMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(dptr, bytes);

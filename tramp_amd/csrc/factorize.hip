@@ -498,6 +498,30 @@ int norm2_power(Fz& fz, const double* X, size_t n, int iters, double* out) {
     return TRAMP_OK;
 }
 
+// |X (X v) - v| / |v| on a probe vector: 0 for a matrix sign (X^2 = I); two passes over the matrix.  The certificate
+// of a sign iteration that stopped on the PREDICTED contraction of its last step (no n^3 residual of the result).
+int involution_defect(Fz& fz, const double* X, size_t n, double* out) {
+    hipStream_t st = fz.ctx->stream;
+    double* v = fz.alloc(n);
+    double* y = fz.alloc(n);
+    double* z = fz.alloc(n);
+    if (!v || !y || !z) return fz.rc;
+    hipLaunchKernelGGL(vec_init, dim3(nblk(n)), dim3(kBlock), 0, st, v, n);
+    hipLaunchKernelGGL(symv_full, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, X, n, v, y);
+    hipLaunchKernelGGL(symv_full, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, X, n, y, z);
+    hipLaunchKernelGGL(sumsq_partials, dim3(kRedBlocks), dim3(kBlock), 0, st, v, n, fz.part_d);
+    double vv = 0.0, dd = 0.0;
+    FZ_OK(reduce_partials(fz, &vv));
+    hipLaunchKernelGGL(axpby_inplace, dim3(kRedBlocks), dim3(kBlock), 0, st, z, v, n, -1.0, 1.0);      // z <- z - v
+    hipLaunchKernelGGL(sumsq_partials, dim3(kRedBlocks), dim3(kBlock), 0, st, z, n, fz.part_d);
+    FZ_OK(reduce_partials(fz, &dd));
+    fz.release(v);
+    fz.release(y);
+    fz.release(z);
+    *out = (vv > 0.0 && isfinite(dd)) ? sqrt(dd / vv) : INFINITY;
+    return TRAMP_OK;
+}
+
 // orthonormal basis of the columns Y (m x r, ld) by two Cholesky-QR passes.  gram0: an r x r matrix
 // holding Y^T Y in its upper triangle if the caller has it for free (consumed), else nullptr.
 int cholqr2(Fz& fz, double* Y, size_t m, size_t r, size_t ld, double* gram /* r x r scratch, ld = r */, bool have_gram) {
@@ -608,8 +632,14 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
         // floor - no further n^3 product to confirm it.  (Stopping one step earlier, at the 1e-10 that the step from
         // 9e-2 leaves, costs three digits in the factors: 2.8e-10 against 3.6e-13 in |Vt Vt^T t - t| at k = 50 000.)
         if (e < 1e-4) {
-            converged = true;
-            break;
+            // ... but it IS checked, at O(n^2): X must square to the identity on a probe vector (a norm estimate that
+            // was too low, or weights clamped at l_floor, would leave a defect far above rounding: iterate on)
+            double defect = INFINITY;
+            FZ_OK(involution_defect(fz, X, n, &defect));
+            if (defect <= 1e-10 * sqrt((double)n)) {
+                converged = true;
+                break;
+            }
         }
     }
     if (!converged) return fz.fail(TRAMP_EHIP, "factorize", "matrix sign iteration did not converge");

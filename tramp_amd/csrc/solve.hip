@@ -35,7 +35,7 @@ struct tramp_lsolve {
     const void* W;        // borrowed [M, N] row-major, dtype
     double* C;            // [N, N] W^T W (upper triangle referenced)
     double* spectrum;     // [N] ascending
-    double* sing2;        // [rank] = spectrum[:rank] floored at 0: the reference's `singular`
+    double* sing2;        // [rank] = spectrum[:rank] as computed (tramp_lsolve_set_rank copies it): the reference's `singular`
     rocblas_handle h;
     // per-call scratch, grown on demand
     double* A;            // [group][N][N]
