@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-se", action="store_true")
     ap.add_argument("--no-tts", action="store_true", help="skip the time-to-solution runs")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[4] EP legs")
+    ap.add_argument("--no-digits", action="store_true", help="skip the opt-in int8-digit engine leg (csrc/gemm_sliced.h)")
     ap.add_argument("--cs1bit-n", type=int, default=int(os.environ.get("TRAMP_BENCH_CS1BIT_N", 49152)),
                     help="N of the 1-bit CS leg (fp32, alpha = 0.7, 64 instances)")
     ap.add_argument("--twolayer-n", type=int, default=int(os.environ.get("TRAMP_BENCH_TWOLAYER_N", 65536)),
@@ -715,6 +716,52 @@ def whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, lin_factors, args, np_dt, t
                     "as the headline line"}
 
 
+def digit_engine(T, ctx, ep, lin, X, args, N, B):
+    """The same EP loop with the dense passes on the int8 matrix cores (LinearChannel.attach_digits, csrc/gemm_sliced.h):
+    an OPT-IN engine, reported beside the headline and never as it.  For each digit count: the time of K steps (as the
+    headline times them), the passes' average launch, and how far the estimate after K steps from zero messages is from
+    the one the f64 matrix-core passes give."""
+    def fresh(k):
+        ep.iterate(max_iter=k, callback=T.PassCallback(), damping=args.damping, check_every=args.check_every)
+        return ep.get_variables_data(["x"])["x"]["r"].reshape(B, N).copy()
+
+    r_ref = fresh(args.steps)
+    res = {"note": "opt-in engine: both operands of the dense passes in signed radix-256 digits, exact int32 accumulation on "
+                   "v_mfma_i32_16x16x64_i8 (7 digits = 54 bits per operand, 8 = 62); the headline above is the f64 "
+                   "matrix-core engine"}
+    for digits in (7, 8):
+        ctx.sync()
+        t0 = time.perf_counter()
+        lin.attach_digits(digits)
+        ctx.sync()
+        attach_s = time.perf_counter() - t0
+        nbytes = ctx.digits_info(lin._Vt)[2] + ctx.digits_info(lin._Uk)[2]
+        r_dig = fresh(args.steps)
+        ep.iterate(max_iter=max(args.warmup, 1), callback=T.PassCallback(), damping=args.damping, check_every=args.check_every)
+        ctx._call("tramp_profile_enable", 1)
+        ctx.sync()
+        t0 = time.perf_counter()
+        ep.iterate(max_iter=args.steps, callback=T.PassCallback(), damping=args.damping, warm_start=True,
+                   check_every=args.check_every)
+        ctx.sync()
+        el = time.perf_counter() - t0
+        rep = _tag_report(ctx)
+        ctx._call("tramp_profile_enable", 0)
+        mse = float(np.mean(np.atleast_1d(ep.mse("x", X))))
+        lin.detach_digits()
+        dev = np.max(np.abs(r_dig - r_ref), axis=1) / np.max(np.abs(r_ref), axis=1)
+        passes = {k: {"avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"],
+                      "f64_equivalent_TFLOPs": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                      "digit_bytes_GBps": v["bytes"] * digits / 8.0 / (v["ms"] * 1e-3) / 1e9}
+                  for k, v in rep.items() if k.startswith("matvec")}
+        res[f"digits{digits}"] = {"ms_per_step": el / args.steps * 1e3, "value": float(N) * B * args.steps / el,
+                                  "unit": "msg-components/s", "passes": passes, "attach_s": attach_s,
+                                  "digit_copies_bytes": int(nbytes),
+                                  "max_rel_deviation_of_r_after_K_steps_vs_f64_engine": float(dev.max()),
+                                  "mse_after_run": mse}
+    return res
+
+
 def _tag_report(ctx):
     NT = len(TAGS)
     cnt, ms, by, fl = (C.c_int * NT)(), (C.c_double * NT)(), (C.c_double * NT)(), (C.c_double * NT)()
@@ -1100,6 +1147,11 @@ def run(args):
                 out["cpu_baseline"]["like_for_like"] = cpu_like_for_like((Uk, sing, Vt, lin_rank), Y, args)
             except Exception as e:                                            # noqa: BLE001
                 out["cpu_baseline"]["like_for_like"] = {"error": repr(e)}
+        if world == 1 and not args.no_digits and args.dtype == "f64" and B > 2:
+            try:
+                out["int8_digit_engine"] = digit_engine(T, ctx, ep, lin, X, args, N, B)
+            except Exception as e:                                            # noqa: BLE001
+                out["int8_digit_engine"] = {"error": repr(e)}
         if world == 1 and not args.no_configs:
             # BASELINE configs[2] and configs[4] as EP runs (the headline's factors are released first)
             import gc

@@ -473,7 +473,8 @@ int tramp_comm_barrier(tramp_ctx* ctx, tramp_comm* comm);
 /* Building blocks of K8, exported for tests, profiling and the roofline bench:
  *   NT: out[b, r] = sum_c mat[r, c] * x[b, c]     mat [R, C] row-major
  *   NN: out[b, c] = sum_r mat[r, c] * x[b, r]
- * algo: 0 = auto, 1 = VALU GEMV, 2 = MFMA. */
+ * algo: 0 = auto (the digit copy of mat_d when one is attached, else MFMA from 3 instances on, else the GEMV),
+ *       1 = VALU GEMV, 2 = f64 / f32 MFMA (never the digit copy), 3 = the digit copy (error without one). */
 int tramp_matvec_nt(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
                     const void* mat_d, const void* x_d, void* out_d);
 int tramp_matvec_nn(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, size_t batch,
@@ -482,6 +483,22 @@ int tramp_matvec_nn(tramp_ctx* ctx, int dtype, int algo, size_t R, size_t C, siz
  * and whether sibling chunks of a matrix tile were interleaved in a one-dimensional grid (ensembles > 64).
  * Lets the tests assert that they reach the launch configurations the large runs use. */
 int tramp_matvec_last_launch(tramp_ctx* ctx, int* nsplit, int* nchunk, int* flat_chunks);
+
+/* Opt-in engine for the same two passes (csrc/gemm_sliced.h): a resident matrix [R, C] gets a copy in signed radix-256
+ * digits (`digits` per element against a per-row power-of-two scale; 0 = by dtype: 7 for f64, 4 for f32; 6 / 7 / 8
+ * allowed) laid out in int8 matrix-core operand order, and every pass over `mat_d` with more than two instances then
+ * runs on v_mfma_i32_16x16x64_i8 with exact int32 accumulation (x is split the same way per pass); results agree with
+ * the exact product to ~2^(2 - 8 digits) max|row| sum|x| - 7 digits: the error of an f64 FMA chain, 8: twenty times
+ * below it.  which: bit 0 = the row-dot form (tramp_matvec_nt, (rows/16) x (C/64) x digits KiB), bit 1 = the column
+ * form (tramp_matvec_nn: a digit copy of the transpose).  The copy is keyed by the device pointer and must be
+ * detached (or re-attached) when the matrix changes or is freed; tramp_ctx_destroy drops all copies.
+ * Replaces the same reference products as tramp_matvec_nt / _nn (tramp/channels/linear/linear_channel.py:85-118). */
+int tramp_matrix_attach_digits(tramp_ctx* ctx, int dtype, size_t R, size_t C, const void* mat_d, int digits, int which);
+/* mat_d == NULL: every copy of the context */
+int tramp_matrix_detach_digits(tramp_ctx* ctx, const void* mat_d);
+int tramp_matrix_digits_info(tramp_ctx* ctx, const void* mat_d, int* digits, int* which, size_t* bytes);
+/* dense passes of this context that ran on a digit copy */
+int tramp_sliced_stats(tramp_ctx* ctx, unsigned long long* runs);
 
 /* ---- convolution channel x = w * z ------------------ */
 /* ConvChannel (tramp/channels/linear/conv_channel.py:13-149), real signals of 1-3 axes

@@ -1,7 +1,9 @@
 // Host build of tramp_amd/csrc/tramp_math.h: a UNIT-TEST HARNESS for the per-component
 // arithmetic (tests/test_host_math.py compares it with the oracle on the CPU).  It is test
 // infrastructure only - nothing in tramp_amd/ loads it, and it is not a CPU fallback.
-// erfcx on the host is a stand-in (exp(x^2) erfc(x)), so agreement is ~1e-12, not bitwise.
+// The special functions of the streaming kernels (table erfcx, polynomial exp, tanh, the corrected reciprocal) are the
+// DEVICE expressions; only the primitives of tmath::hw differ (hardware estimates, where a table is read from) and the
+// library erfcx of the literal forms is a stand-in (exp(x^2) erfc(x): agreement ~1e-12 there, not bitwise).
 #include <cstddef>
 #include <cstdint>
 
@@ -96,4 +98,27 @@ void hm_relu_lik_f64(size_t n, const double* bz, const double* y, double az, dou
     }
 }
 double hm_a_new(double v, double a) { return a_new_of(v, a); }
+// which: 0 erfcx_hot<false>, 1 erfcx_hot<true> (uniform-grid table), 2 exp_fast, 3 exp_clamped, 4 tanh_hot, 5 rcp_pos, 6 expit
+void hm_special_f64(int which, size_t n, const double* x, double* out) {
+    for (size_t i = 0; i < n; ++i) {
+        switch (which) {
+            case 0: out[i] = erfcx_hot<false>(x[i]); break;
+            case 1: out[i] = erfcx_hot<true>(x[i]); break;
+            case 2: out[i] = exp_fast(x[i]); break;
+            case 3: out[i] = exp_clamped(x[i]); break;
+            case 4: out[i] = tanh_hot(x[i]); break;
+            case 5: out[i] = rcp_pos(x[i]); break;
+            default: out[i] = expit<double>(x[i]); break;
+        }
+    }
+}
+void hm_special_f32(int which, size_t n, const float* x, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        switch (which) {
+            case 0: out[i] = erfcx_hot<false>(x[i]); break;
+            case 3: out[i] = exp_clamped(x[i]); break;
+            default: out[i] = expit<float>(x[i]); break;
+        }
+    }
+}
 }

@@ -127,6 +127,10 @@ _SIGNATURES = {
     "tramp_matvec_nn": [vp, i32, i32, sz, sz, sz, vp, vp, vp],
     "tramp_transpose": [vp, i32, sz, sz, vp, vp],
     "tramp_matvec_last_launch": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+    "tramp_matrix_attach_digits": [vp, i32, sz, sz, vp, i32, i32],
+    "tramp_matrix_detach_digits": [vp, vp],
+    "tramp_matrix_digits_info": [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)],
+    "tramp_sliced_stats": [vp, C.POINTER(u64)],
     "tramp_variable_posterior": [vp, i32, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_damp": [vp, i32, sz, sz, dbl, vp, vp, vp, vp],
     "tramp_damp_to": [vp, i32, sz, sz, dbl, vp, vp, vp, vp, vp, vp],

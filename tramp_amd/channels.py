@@ -5,6 +5,7 @@ channels/linear/analytical_linear_channel.py,
 channels/activation/piecewise_linear_channel.py, channels/noise/gaussian_channel.py.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -530,7 +531,7 @@ class LinearChannel(Channel):
         return super().__new__(cls)
 
     def __init__(self, W, precompute_svd=True, name="W", dtype=np.float64, ctx=None, svd="auto",
-                 factors=None, keep_W=False):
+                 factors=None, keep_W=False, digits=None):
         self.name = name
         self.Nx, self.Nz = (int(s) for s in W.shape)
         self.precompute_svd = precompute_svd
@@ -572,8 +573,32 @@ class LinearChannel(Channel):
                   self._Vt.ptr, self._sing.ptr, C.byref(h))
         self._handle = h
         self._t_key = self._u_key = None
+        # opt-in: the dense passes of ensembles on the int8 matrix cores (csrc/gemm_sliced.h).  digits=None reads the
+        # switch TRAMP_MATVEC_DIGITS (0 = off, the default); 7 is f64-equivalent, 4 is the f32 setting.
+        if digits is None:
+            digits = int(os.environ.get("TRAMP_MATVEC_DIGITS", "0"))
+        self.digits = 0
+        if digits:
+            self.attach_digits(int(digits))
+
+    def attach_digits(self, digits=0):
+        """Digit copies of the factors (Vt in both forms; Uk likewise when it is not the identity of a rotated basis):
+        ~2 x digits / itemsize the memory of the factors on top of them.  digits=0: by dtype (7 / 4)."""
+        self.ctx.attach_digits(self._Vt, digits, 3)
+        self.ctx.attach_digits(self._Uk, digits, 3)
+        self.digits = self.ctx.digits_info(self._Vt)[0]
+
+    def detach_digits(self):
+        self.ctx.detach_digits(self._Vt)
+        self.ctx.detach_digits(self._Uk)
+        self.digits = 0
 
     def __del__(self):
+        try:
+            if getattr(self, "digits", 0):
+                self.detach_digits()
+        except Exception:
+            pass
         try:
             self.ctx.release("tramp_linear_destroy", self._handle)
         except Exception:

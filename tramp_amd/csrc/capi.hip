@@ -1,5 +1,6 @@
 // capi.hip - context, device memory and timing entry points of the C ABI.
 #include "common.h"
+#include "linear.h"
 #include "prior_hint.h"
 #include <stdlib.h>
 
@@ -61,6 +62,7 @@ extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    gemm_sliced_ctx_destroy(ctx);
     flush_deferred_frees(ctx);
     free(ctx->deferred_free);
     if (ctx->hint_ws) (void)hipFree(ctx->hint_ws);

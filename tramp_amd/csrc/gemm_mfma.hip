@@ -458,10 +458,15 @@ static int gemm_mfma_t(tramp_ctx* ctx, bool nt, size_t R, size_t C, size_t batch
 #undef BY_BT
 #undef LAUNCH_NT
 #undef LAUNCH_NN
-    dim3 g2((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch);
+    return mfma_fold(ctx, sizeof(T) == 8 ? TRAMP_F64 : TRAMP_F32, len, batch, (int)nsplit, ctx->ws, epi);
+}
+
+int mfma_fold(tramp_ctx* ctx, int dtype, size_t len, size_t batch, int nsplit, const double* partials, const LinEpi& epi) {
+    dim3 g2((unsigned)((len + kBlock - 1) / kBlock), (unsigned)batch), block(kBlock);
     LinEpi e2 = epi;
     lin_arm_hint(ctx, e2, len, batch, (int)g2.x);
-    hipLaunchKernelGGL((mfma_fold_kernel<T>), g2, block, 0, ctx->stream, len, batch, (int)nsplit, ctx->ws, e2);
+    if (dtype == TRAMP_F64) hipLaunchKernelGGL((mfma_fold_kernel<double>), g2, block, 0, ctx->stream, len, batch, nsplit, partials, e2);
+    else hipLaunchKernelGGL((mfma_fold_kernel<float>), g2, block, 0, ctx->stream, len, batch, nsplit, partials, e2);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;
 }

@@ -54,3 +54,10 @@ int lin_variance_launch(tramp_ctx* ctx, const double* s2, int k, int rank, doubl
 bool gemm_mfma_supported(int dtype, bool nt, size_t R, size_t C, size_t batch);
 int gemm_mfma(tramp_ctx* ctx, int dtype, bool nt, size_t R, size_t C, size_t batch, const void* mat_d,
               const void* x_d, const LinEpi& epi);
+// split-K fold + message-update epilogue of gemm_mfma.hip on partials [nsplit][batch][len] (shared with gemm_sliced.hip)
+int mfma_fold(tramp_ctx* ctx, int dtype, size_t len, size_t batch, int nsplit, const double* partials, const LinEpi& epi);
+
+// int8-digit engine (gemm_sliced.hip): runs the pass if a digit copy of mat_d is attached in the wanted form
+int gemm_sliced_try(tramp_ctx* ctx, int dtype, bool nt, size_t R, size_t C, size_t batch, const void* mat_d, const void* x_d,
+                    const LinEpi& epi, bool* taken);
+void gemm_sliced_ctx_destroy(tramp_ctx* ctx);

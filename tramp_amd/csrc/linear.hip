@@ -355,13 +355,19 @@ static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t 
     // measured on MI355X: the VALU GEMV wins up to 2 instances (6.1 vs 5.7 TB/s), MFMA from 3 on
     static const int algo_env = getenv("TRAMP_MATVEC_ALGO") ? atoi(getenv("TRAMP_MATVEC_ALGO")) : 0;   // debugging
     if (algo == 0 && algo_env) algo = algo_env;
+    ProfScope prof(ctx, nt ? PROF_MATVEC_NT : PROF_MATVEC_NN, (double)R * (double)C * dtype_size(dtype),
+                   2.0 * (double)R * (double)C * (double)batch);
+    if (algo == 3 || (algo == 0 && batch > 2)) {      // an attached int8-digit copy of this matrix (gemm_sliced.hip) takes the pass
+        bool taken = false;
+        const int rc = gemm_sliced_try(ctx, dtype, nt, R, C, batch, mat_d, x_d, epi, &taken);
+        if (taken) return rc;
+        if (algo == 3) return tramp_fail(ctx, TRAMP_ENOTSUP, "digit pass", "no digit copy of this matrix is attached in this form");
+    }
     bool mfma = (algo == 2) || (algo == 0 && batch > 2);
     if (mfma && !gemm_mfma_supported(dtype, nt, R, C, batch)) {
         if (algo == 2) return tramp_fail(ctx, TRAMP_ENOTSUP, "mfma path", "shape/dtype not supported");
         mfma = false;
     }
-    ProfScope prof(ctx, nt ? PROF_MATVEC_NT : PROF_MATVEC_NN, (double)R * (double)C * dtype_size(dtype),
-                   2.0 * (double)R * (double)C * (double)batch);
     if (mfma) return gemm_mfma(ctx, dtype, nt, R, C, batch, mat_d, x_d, epi);
     if (dtype == TRAMP_F64) return matvec_valu<double>(ctx, nt, R, C, batch, mat_d, x_d, epi);
     return matvec_valu<float>(ctx, nt, R, C, batch, mat_d, x_d, epi);

@@ -12,9 +12,17 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define TM_HD __host__ __device__ __forceinline__
+#define TM_TABLE __device__ const            // coefficient tables: device globals (staged into LDS by the kernels)
+#define TM_SCALAR_TABLE __constant__         // short coefficient lists read through the scalar cache
 #else
 #define TM_HD inline
+#define TM_TABLE static const
+#define TM_SCALAR_TABLE static const
 #endif
+// The arithmetic below is ONE set of expressions for the device and for the host harness (tests/host_math); what differs
+// is confined to the primitives of namespace tmath::hw further down - the hardware's reciprocal / exp2 estimates, where
+// a coefficient table is read from (LDS on the device, the table itself on the host), the wave-wide vote and the
+// library's erfcx (glibc has none).
 // true when the predicate holds on every active lane of the wave (device); the plain predicate elsewhere
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TM_WAVE_ALL(p) (__all((p) ? 1 : 0) != 0)
@@ -72,14 +80,21 @@ TM_HD float fma_(float a, float b, float c) { return ::fmaf(a, b, c); }
 // g a degree-7 polynomial on one of 32 intervals of t (erfcx_table.h, fitted to mpmath, relative error
 // 3e-15; f32: degree 4, own table), eight LDS reads (see below) and seven FMAs; x < 0 by
 // erfcx(x) = 2 exp(x^2) - erfcx(-x).  No branch mask depends on an erfcx value.
-#if defined(__HIP_DEVICE_COMPILE__)
 }  // namespace tmath
+#if defined(__HIPCC__)
 #include "erfcx_table.h"
 #include "erfcx_utable.h"
+#else
+#define __device__              // the generated tables say `__device__ const`: plain constants for a host compiler
+#include "erfcx_table.h"
+#include "erfcx_utable.h"
+#undef __device__
+#endif
 namespace tmath {
-__device__ __forceinline__ double exp_clamped(double x);
-__device__ __forceinline__ double rcp_pos(double x);
-__device__ __forceinline__ float exp_clamped(float x);
+#ifndef TRAMP_ERFCX_UNIFORM
+#define TRAMP_ERFCX_UNIFORM 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 // The table is read from LDS, coefficient-major ([j][k], 8-byte entries): rows 16..31 (x <= 4, i.e. all
 // but the far tail) sit in 16 different bank pairs, so the 8 ds_read_b64 of one evaluation are
 // conflict-free whatever rows the lanes of a wave need.  (Read straight from global memory the same
@@ -95,9 +110,6 @@ __shared__ double g_erfcx_lds[(kErfcxD + 1) * kErfcxK];
 // the VALU-bound kernels do not otherwise use.  Used by the two-region channels K7 (erfcx_hot<true>: 64 x 1e6 f64
 // 0.72-0.78 -> 0.63-0.71 ms); the sign likelihood, one evaluation per pass and closer to the memory bound, is faster
 // on the small conflict-free table (580 against 619 us) and keeps it.  -DTRAMP_ERFCX_UNIFORM=0 removes the grid table.
-#ifndef TRAMP_ERFCX_UNIFORM
-#define TRAMP_ERFCX_UNIFORM 1
-#endif
 #if TRAMP_ERFCX_UNIFORM
 __shared__ double g_erfcx_ulds[(kErfcxUD + 1) * kErfcxUK];
 #endif
@@ -118,76 +130,53 @@ __device__ __forceinline__ void erfcx_lds_init_f() {
         g_erfcx_lds_f[i] = kErfcxTableF[i % kErfcxKF][i / kErfcxKF];
     __syncthreads();
 }
-template <bool UNI = false> __device__ __forceinline__ double erfcx_hot(double x) {
-#if TRAMP_ERFCX_UNIFORM
-    if (UNI && TM_WAVE_ALL(x >= kErfcxULo && x < kErfcxUHi)) {      // a NaN fails the test: the wave takes the general path
-        const double tk = ::fma(x, kErfcxUPer, -kErfcxULo * kErfcxUPer);      // in [0, K)
-        const int k = min((int)tk, kErfcxUK - 1);
-        const double s = ::fma(2.0, tk - (double)k, -1.0);
-        const double* p = g_erfcx_ulds + k;
-        double acc = p[kErfcxUD * kErfcxUK];
-#pragma unroll
-        for (int j = kErfcxUD - 1; j >= 0; --j) acc = ::fma(acc, s, p[j * kErfcxUK]);
-        return acc;
-    }
 #endif
-    const double w = ::fmin(::fabs(x), 1e300);                // erfcx(1e300) = 5.6e-301; a NaN x reaches the caller through x itself
-    const double t = 4.0 * rcp_pos(4.0 + w);
-    const double tk = t * (double)kErfcxK;
-    const int k = min((int)tk, kErfcxK - 1);                   // t in (0, 1]: tk in (0, K]
-    const double s = ::fma(2.0, tk - (double)k, -1.0);
-    const double* p = g_erfcx_lds + k;
-    double acc = p[kErfcxD * kErfcxK];
-#pragma unroll
-    for (int j = kErfcxD - 1; j >= 0; --j) acc = ::fma(acc, s, p[j * kErfcxK]);
-    double e = t * acc;
-    if (x < 0.0) e = 2.0 * exp_clamped(x * x) - e;
-    return e;
-}
-// f32: the same construction on the float table (4e-7 relative for x >= 0, a few ulp of float; the library's
-// erfcxf is ~45 instructions)
-template <bool UNI = false> __device__ __forceinline__ float erfcx_hot(float x) {
-    const float w = ::fminf(::fabsf(x), 1e37f);
-    const float t = 4.0f * __builtin_amdgcn_rcpf(4.0f + w);
-    const float tk = t * (float)kErfcxKF;
-    const int k = min((int)tk, kErfcxKF - 1);
-    const float s = ::fmaf(2.0f, tk - (float)k, -1.0f);
-    const float* p = g_erfcx_lds_f + k;
-    float acc = p[kErfcxDF * kErfcxKF];
-#pragma unroll
-    for (int j = kErfcxDF - 1; j >= 0; --j) acc = ::fmaf(acc, s, p[j * kErfcxKF]);
-    float e = t * acc;
-    if (x < 0.0f) e = 2.0f * exp_clamped(x * x) - e;
-    return e;
-}
-#else
-template <bool UNI = false> TM_HD double erfcx_hot(double x) { return erfcx_(x); }      // host pass / plain C++ (tests/host_math)
-template <bool UNI = false> TM_HD float erfcx_hot(float x) { return erfcx_(x); }
-#endif
-// Called by all threads of a block before the first erfcx_hot (Op::setup): stages the table(s) in LDS.
-// UNI: also the uniform-grid table that erfcx_hot<true> reads.
-template <typename T, bool UNI = false> TM_HD void erfcx_setup() {
+
+// ---- the primitives that differ between the device and the host harness ---------------------------------------------
+namespace hw {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (sizeof(T) == 8) erfcx_lds_init<UNI>();
-    else erfcx_lds_init_f();
+// v_rcp_f64 is good to 4.6e-8, v_rcp_f32 / v_exp_f32 to ~1 ulp of f32 (tools/probes/probe_rcp_ldexp.hip)
+__device__ __forceinline__ double rcp_est(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ __forceinline__ float rcp_est(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float exp2_est(float x) { return __builtin_amdgcn_exp2f(x); }
+// coefficient j of interval k: the LDS images staged by erfcx_lds_init (coefficient-major)
+__device__ __forceinline__ double erfcx_coef(int j, int k) { return g_erfcx_lds[j * kErfcxK + k]; }
+__device__ __forceinline__ float erfcx_coef_f(int j, int k) { return g_erfcx_lds_f[j * kErfcxKF + k]; }
+#if TRAMP_ERFCX_UNIFORM
+__device__ __forceinline__ double erfcx_ucoef(int j, int k) { return g_erfcx_ulds[j * kErfcxUK + k]; }
 #endif
+#else
+// host harness: an f32 division stands for the f64 estimate (1e-7 instead of 4.6e-8: the cubic correction of rcp_1to2
+// ends below 1e-20 either way), the correctly rounded f32 operations for the f32 estimates, the tables where they are
+TM_HD double rcp_est(double x) {
+    int e;
+    const double m = ::frexp(x, &e);
+    return ::ldexp((double)(1.0f / (float)m), -e);
 }
+TM_HD float rcp_est(float x) { return 1.0f / x; }
+TM_HD float exp2_est(float x) { return ::exp2f(x); }
+TM_HD double erfcx_coef(int j, int k) { return kErfcxTable[k][j]; }
+TM_HD float erfcx_coef_f(int j, int k) { return kErfcxTableF[k][j]; }
+#if TRAMP_ERFCX_UNIFORM
+TM_HD double erfcx_ucoef(int j, int k) { return kErfcxUTable[k][j]; }
+#endif
+#endif
+}  // namespace hw
 
 // exp(x) for x <= 0 in f64 on the device: the library routine carries overflow handling and a two-level
 // reduction it does not need here (~46 VALU instructions); n = rint(x log2 e), r = x - n ln2 (two parts),
 // degree-12 Taylor polynomial on |r| <= ln2/2 (truncation 2e-16), one ldexp: ~22 instructions, 1-2 ulp.
-#if defined(__HIP_DEVICE_COMPILE__)
 // core: exp(x) for |x| within the f64 range (callers clamp); v_ldexp_f64 scales by any n in one step,
 // denormal results included (tools/probes/probe_rcp_ldexp.hip)
 // The Taylor coefficients are read through the scalar cache (uniform address: s_load into SGPRs, which a
 // v_fma_f64 takes as an operand): as literals the compiler materialises each in a VGPR pair first - 13
 // v_mov_b64 per evaluation on the VALU that these kernels are bound by.
-__constant__ double kExpTaylor[13] = {
+TM_SCALAR_TABLE double kExpTaylor[13] = {
     2.08767569878680989792e-09,             // 1/12!
     2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06, 2.48015873015873015873e-05,
     1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
     1.66666666666666666667e-01, 0.5, 1.0, 1.0};
-__device__ __forceinline__ double exp_core(double x) {
+TM_HD double exp_core(double x) {
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = ::fma(n, -6.93147180369123816490e-01, x);
     r = ::fma(n, -1.90821492927058770002e-10, r);
@@ -197,53 +186,91 @@ __device__ __forceinline__ double exp_core(double x) {
     return ::ldexp(p, (int)n);
 }
 // any argument: the result saturates to 0 below -745.2 and to +inf above 709.78 like the library's
-__device__ __forceinline__ double exp_fast(double x) {
+TM_HD double exp_fast(double x) {
     const double e = exp_core(x);
     return x < -745.2 ? 0.0 : (x > 709.79 ? __builtin_inf() : e);      // -inf -> 0, +inf -> inf; NaN propagates through p
 }
-__device__ __forceinline__ double exp_nonpos(double x) { return exp_fast(x); }
+TM_HD double exp_nonpos(double x) { return exp_fast(x); }
 // Saturating by clamping the ARGUMENT (two instructions instead of two compare + select pairs); a NaN
 // argument is swallowed by the clamp (maxNum / minNum), so these are for call sites whose result is
 // multiplied into, or added to, a quantity that carries the NaN anyway.
-__device__ __forceinline__ double exp_clamped(double x) { return exp_core(::fmin(::fmax(x, -746.0), 709.78)); }
-__device__ __forceinline__ double exp_clamped_nonpos(double x) { return exp_core(::fmax(x, -746.0)); }
+TM_HD double exp_clamped(double x) { return exp_core(::fmin(::fmax(x, -746.0), 709.78)); }
+TM_HD double exp_clamped_nonpos(double x) { return exp_core(::fmax(x, -746.0)); }
 // f32: two-part reduction, v_exp_f32 on |r| <= ln2 / 2, one ldexp (~1e-7 relative; expf is ~15 instructions)
-__device__ __forceinline__ float exp_core(float x) {
+TM_HD float exp_core(float x) {
     const float n = __builtin_rintf(x * 1.44269504088896341f);
     float r = ::fmaf(n, -6.93145751953125e-01f, x);
     r = ::fmaf(n, -1.42860682030941723e-06f, r);
-    return ::ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+    return ::ldexpf(hw::exp2_est(r * 1.44269504088896341f), (int)n);
 }
-__device__ __forceinline__ float exp_clamped(float x) { return exp_core(::fminf(::fmaxf(x, -104.0f), 88.7f)); }
-__device__ __forceinline__ float exp_clamped_nonpos(float x) { return exp_core(::fmaxf(x, -104.0f)); }
-__device__ __forceinline__ float exp_nonpos(float x) { return ::expf(x); }
-__device__ __forceinline__ float exp_fast(float x) { return ::expf(x); }
+TM_HD float exp_clamped(float x) { return exp_core(::fminf(::fmaxf(x, -104.0f), 88.7f)); }
+TM_HD float exp_clamped_nonpos(float x) { return exp_core(::fmaxf(x, -104.0f)); }
+TM_HD float exp_nonpos(float x) { return ::expf(x); }
+TM_HD float exp_fast(float x) { return ::expf(x); }
 // 1/x for x in [1, 2]: hardware estimate + one cubic correction, no special cases to guard
 // v_rcp_f64 is good to 4.6e-8 (tools/probes/probe_rcp_ldexp.hip): one cubic step r (1 + e + e^2),
 // e = 1 - x r, brings it to ~1e-22 before rounding (three FMAs; two Newton steps need four)
-__device__ __forceinline__ double rcp_1to2(double x) {
-    const double r = __builtin_amdgcn_rcp(x);
+TM_HD double rcp_1to2(double x) {
+    const double r = hw::rcp_est(x);
     const double e = ::fma(-x, r, 1.0);
     return ::fma(::fma(e, e, e), r, r);
 }
-__device__ __forceinline__ float rcp_1to2(float x) { return __builtin_amdgcn_rcpf(x); }
+TM_HD float rcp_1to2(float x) { return hw::rcp_est(x); }
 // 1/x for finite normal x > 0 (callers clamp to <= 1e300): the same, no 0 / inf / NaN guards
-__device__ __forceinline__ double rcp_pos(double x) { return rcp_1to2(x); }
-__device__ __forceinline__ float rcp_pos(float x) { return __builtin_amdgcn_rcpf(x); }
-#else
-TM_HD double exp_nonpos(double x) { return ::exp(x); }
-TM_HD float exp_nonpos(float x) { return ::expf(x); }
-TM_HD double exp_fast(double x) { return ::exp(x); }
-TM_HD float exp_fast(float x) { return ::expf(x); }
-TM_HD double rcp_1to2(double x) { return 1.0 / x; }
-TM_HD float rcp_1to2(float x) { return 1.0f / x; }
-TM_HD double rcp_pos(double x) { return 1.0 / x; }
-TM_HD float rcp_pos(float x) { return 1.0f / x; }
-TM_HD double exp_clamped(double x) { return ::exp(x); }
-TM_HD float exp_clamped(float x) { return ::expf(x); }
-TM_HD double exp_clamped_nonpos(double x) { return ::exp(x); }
-TM_HD float exp_clamped_nonpos(float x) { return ::expf(x); }
+TM_HD double rcp_pos(double x) { return rcp_1to2(x); }
+TM_HD float rcp_pos(float x) { return hw::rcp_est(x); }
+
+template <bool UNI = false> TM_HD double erfcx_hot(double x) {
+#if TRAMP_ERFCX_UNIFORM
+    if (UNI && TM_WAVE_ALL(x >= kErfcxULo && x < kErfcxUHi)) {      // a NaN fails the test: the wave takes the general path
+        const double tk = ::fma(x, kErfcxUPer, -kErfcxULo * kErfcxUPer);      // in [0, K)
+        const int ki = (int)tk;
+        const int k = ki < kErfcxUK - 1 ? ki : kErfcxUK - 1;
+        const double s = ::fma(2.0, tk - (double)k, -1.0);
+        double acc = hw::erfcx_ucoef(kErfcxUD, k);
+#pragma unroll
+        for (int j = kErfcxUD - 1; j >= 0; --j) acc = ::fma(acc, s, hw::erfcx_ucoef(j, k));
+        return acc;
+    }
 #endif
+    const double w = ::fmin(::fabs(x), 1e300);                // erfcx(1e300) = 5.6e-301; a NaN x reaches the caller through x itself
+    const double t = 4.0 * rcp_pos(4.0 + w);
+    const double tk = t * (double)kErfcxK;
+    const int ki = (int)tk;
+    const int k = ki < kErfcxK - 1 ? ki : kErfcxK - 1;         // t in (0, 1]: tk in (0, K]
+    const double s = ::fma(2.0, tk - (double)k, -1.0);
+    double acc = hw::erfcx_coef(kErfcxD, k);
+#pragma unroll
+    for (int j = kErfcxD - 1; j >= 0; --j) acc = ::fma(acc, s, hw::erfcx_coef(j, k));
+    double e = t * acc;
+    if (x < 0.0) e = 2.0 * exp_clamped(x * x) - e;
+    return e;
+}
+// f32: the same construction on the float table (4e-7 relative for x >= 0, a few ulp of float; the library's
+// erfcxf is ~45 instructions)
+template <bool UNI = false> TM_HD float erfcx_hot(float x) {
+    const float w = ::fminf(::fabsf(x), 1e37f);
+    const float t = 4.0f * hw::rcp_est(4.0f + w);
+    const float tk = t * (float)kErfcxKF;
+    const int ki = (int)tk;
+    const int k = ki < kErfcxKF - 1 ? ki : kErfcxKF - 1;
+    const float s = ::fmaf(2.0f, tk - (float)k, -1.0f);
+    float acc = hw::erfcx_coef_f(kErfcxDF, k);
+#pragma unroll
+    for (int j = kErfcxDF - 1; j >= 0; --j) acc = ::fmaf(acc, s, hw::erfcx_coef_f(j, k));
+    float e = t * acc;
+    if (x < 0.0f) e = 2.0f * exp_clamped(x * x) - e;
+    return e;
+}
+// Called by all threads of a block before the first erfcx_hot (Op::setup): stages the table(s) in LDS.
+// UNI: also the uniform-grid table that erfcx_hot<true> reads.
+template <typename T, bool UNI = false> TM_HD void erfcx_setup() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (sizeof(T) == 8) erfcx_lds_init<UNI>();
+    else erfcx_lds_init_f();
+#endif
+}
+
 // largest operand handed to rcp_pos (1/x stays a normal number)
 template <typename T> struct RcpCap;
 template <> struct RcpCap<double> { static constexpr double value = 1e300; };
@@ -252,10 +279,9 @@ template <> struct RcpCap<float> { static constexpr float value = 1e37f; };
 // tanh for the streaming kernels: sign(x) (1 - e)/(1 + e), e = exp(-2|x|) in (0, 1]; for |x| < 0.25 the
 // quotient loses up to 3 bits to cancellation, where the odd series x (1 - x^2/3 + 2x^4/15 - ...) is used
 // instead (the library's f64 tanh is ~170 instructions on gfx950; this is ~45).
-#if defined(__HIP_DEVICE_COMPILE__)
-__constant__ double kTanhSeries[8] = {-929569.0 / 638512875.0, 21844.0 / 6081075.0, -1382.0 / 155925.0, 62.0 / 2835.0,
-                                      -17.0 / 315.0,          2.0 / 15.0,          -1.0 / 3.0,         1.0};     // scalar-cache operands, as kExpTaylor
-__device__ __forceinline__ double tanh_hot(double x) {
+TM_SCALAR_TABLE double kTanhSeries[8] = {-929569.0 / 638512875.0, 21844.0 / 6081075.0, -1382.0 / 155925.0, 62.0 / 2835.0,
+                                         -17.0 / 315.0,          2.0 / 15.0,          -1.0 / 3.0,         1.0};     // scalar-cache operands, as kExpTaylor
+TM_HD double tanh_hot(double x) {
     const double ax = ::fabs(x);
     const double e = exp_fast(-2.0 * ax);
     const double big = (1.0 - e) * rcp_1to2(1.0 + e);
@@ -268,11 +294,7 @@ __device__ __forceinline__ double tanh_hot(double x) {
     const double t = ax < 0.25 ? small : big;
     return x < 0.0 ? -t : t;
 }
-__device__ __forceinline__ float tanh_hot(float x) { return ::tanhf(x); }
-#else
-TM_HD double tanh_hot(double x) { return ::tanh(x); }
 TM_HD float tanh_hot(float x) { return ::tanhf(x); }
-#endif
 
 // scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal of 1 + e in [1, 2].
 template <typename T> TM_HD T expit(T x) {

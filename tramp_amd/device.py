@@ -147,6 +147,29 @@ class Context:
         self._call("tramp_resident_stats", C.byref(r))
         return r.value
 
+    # -- int8-digit copies of resident matrices (csrc/gemm_sliced.h; opt-in engine of the dense passes)
+    def attach_digits(self, mat, digits=0, which=3):
+        """Give the resident matrix `mat` [R, C] a copy in signed radix-256 digits: every tramp_matvec_nt / _nn pass over
+        it with more than two instances then runs on the int8 matrix cores (digits: 0 = 7 for f64, 4 for f32; which:
+        1 row-dot form, 2 column form, 3 both).  Detach before the matrix changes or is released."""
+        R, Cc = mat.shape
+        self._call("tramp_matrix_attach_digits", _DT[np.dtype(mat.dtype)], int(R), int(Cc), mat.ptr, int(digits), int(which))
+
+    def detach_digits(self, mat=None):
+        self._call("tramp_matrix_detach_digits", None if mat is None else mat.ptr)
+
+    def digits_info(self, mat):
+        "(digits, forms, device bytes) of the digit copy attached to `mat`; digits == 0: none"
+        dg, w, b = C.c_int(), C.c_int(), C.c_size_t()
+        self._call("tramp_matrix_digits_info", mat.ptr, C.byref(dg), C.byref(w), C.byref(b))
+        return dg.value, w.value, b.value
+
+    def sliced_runs(self):
+        "dense passes that ran on a digit copy since the context was made"
+        r = C.c_ulonglong()
+        self._call("tramp_sliced_stats", C.byref(r))
+        return r.value
+
     def close(self):
         if self.handle:
             self.lib.tramp_ctx_destroy(self.handle)

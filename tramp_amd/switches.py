@@ -14,7 +14,8 @@ SWITCHES = {
     "TRAMP_EW_RESIDENT_MIN_ROUNDS": ("4", "tune", "rounds of 2 x CUs - 8 tiles below which the pipeline is not worth its fill and drain"),
     "TRAMP_PRIOR_FUSE": ("1", "select", "0: producers never leave prior / likelihood moments (csrc/prior_hint.h)"),
     # dense linear channel (csrc/linear.hip, gemm_mfma.hip)
-    "TRAMP_MATVEC_ALGO": ("0", "debug", "force a matrix-pass engine: 1 GEMV (VALU), 2 MFMA; 0 = by batch size"),
+    "TRAMP_MATVEC_ALGO": ("0", "debug", "force a matrix-pass engine: 1 GEMV (VALU), 2 f64 / f32 MFMA, 3 the int8-digit copy; 0 = the digit copy if attached, else by batch size"),
+    "TRAMP_MATVEC_DIGITS": ("0", "select", "radix-256 digits of the int8 copies LinearChannel attaches to its factors (csrc/gemm_sliced.h): 0 none, 7 f64-equivalent, 8, 6, 4 (f32)"),
     "TRAMP_MFMA_SPLIT": ("0", "tune", "split-K factor of the MFMA passes; 0 = chosen from the grid size"),
     "TRAMP_MFMA_LDS_PAD": ("0", "tune", "extra dynamic LDS per workgroup of the MFMA passes (occupancy experiments)"),
     "TRAMP_MFMA_CHUNK_2D": ("0", "tune", "1: 64-instance chunks on the grid's y axis instead of interleaved in x"),
