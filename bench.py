@@ -732,7 +732,7 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
     for digits in (7, 8):
         ctx.sync()
         t0 = time.perf_counter()
-        lin.attach_digits(digits)
+        lin.attach_digits(digits, uk=not (ep._lin_masks().get(lin, 0) & 1))      # output side rotated: Uk is not in the loop
         ctx.sync()
         attach_s = time.perf_counter() - t0
         nbytes = ctx.digits_info(lin._Vt)[2] + ctx.digits_info(lin._Uk)[2]

@@ -54,6 +54,12 @@ def test_bench_prints_one_json_line(force_dist):
         assert c["ms_per_iteration"] > 0 and c["msg_components_per_sec"] > 0 and c["setup"]["factorize_s"] > 0
         assert c["roofline"]["kernel"] in c["kernels"] and c["roofline"]["avg_launch_ms"] > 0
     assert c2["overlap"] > 0.3 and c4["mse_hidden"] < 0.5
+    # the opt-in int8-digit engine rides under its own key: same loop, estimates equal to the f64 engine's to ~1e-13
+    dg = d["int8_digit_engine"]
+    assert "error" not in dg, dg
+    for key in ("digits7", "digits8"):
+        assert dg[key]["ms_per_step"] > 0 and dg[key]["passes"] and dg[key]["digit_copies_bytes"] > 0
+        assert dg[key]["max_rel_deviation_of_r_after_K_steps_vs_f64_engine"] < 1e-11
 
 
 def test_bench_refuses_wrong_factors():

@@ -581,11 +581,13 @@ class LinearChannel(Channel):
         if digits:
             self.attach_digits(int(digits))
 
-    def attach_digits(self, digits=0):
-        """Digit copies of the factors (Vt in both forms; Uk likewise when it is not the identity of a rotated basis):
-        ~2 x digits / itemsize the memory of the factors on top of them.  digits=0: by dtype (7 / 4)."""
+    def attach_digits(self, digits=0, uk=True):
+        """Digit copies of the factors: Vt in both forms and (uk=True) Uk likewise - ~2 x digits / itemsize the memory of
+        the factors on top of them.  uk=False when the scheduler carries the output side in the left singular basis
+        (Uk then only rotates y once).  digits=0: by dtype (7 / 4)."""
         self.ctx.attach_digits(self._Vt, digits, 3)
-        self.ctx.attach_digits(self._Uk, digits, 3)
+        if uk:
+            self.ctx.attach_digits(self._Uk, digits, 3)
         self.digits = self.ctx.digits_info(self._Vt)[0]
 
     def detach_digits(self):
