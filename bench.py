@@ -769,7 +769,7 @@ def _tag_report(ctx):
     return {TAGS[i]: {"launches": cnt[i], "ms": ms[i], "bytes": by[i], "flops": fl[i]} for i in range(NT) if cnt[i]}
 
 
-def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1):
+def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, with_digits=True):
     """BASELINE configs[2] (1-bit compressed sensing, alpha = 0.7, fp32) and configs[4] (two-layer ReLU GLM) as EP
     ensembles of B instances sharing their Gaussian-ensemble matrices, at the largest N whose factorisation fits the
     bench's time budget (the named sizes fit the memory, not a few minutes of set-up; the full-size
@@ -864,6 +864,32 @@ def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1):
            "elementwise_GBps_algorithmic": (kern["ew_factor_update"]["bytes"] / (kern["ew_factor_update"]["ms"] * 1e-3) / 1e9)
            if "ew_factor_update" in kern else None,
            **score(ep)}
+    if with_digits:
+        # the same loop with the dense passes on the int8 matrix cores (4 radix-256 digits = 30 bits for f32 operands;
+        # csrc/gemm_sliced.h): opt-in engine, its own sub-key
+        try:
+            lins = [f for f in model.factors if type(f) is T.LinearChannel]
+            masks = ep._lin_masks()
+            for f in lins:
+                f.attach_digits(0, uk=not (masks.get(f, 0) & 1))
+            ep.iterate(max_iter=max(warmup, 1), callback=T.PassCallback(), damping=damping, check_every=1 << 30)
+            ctx._call("tramp_profile_enable", 1)
+            ctx.sync()
+            t0 = time.perf_counter()
+            ep.iterate(max_iter=steps, callback=T.PassCallback(), damping=damping, warm_start=True, check_every=1 << 30)
+            ctx.sync()
+            el2 = time.perf_counter() - t0
+            k2 = _tag_report(ctx)
+            ctx._call("tramp_profile_enable", 0)
+            m2 = [k2[t] for t in ("matvec_nt", "matvec_nn") if t in k2]
+            out["int8_digits"] = {"digits": lins[0].digits, "ms_per_iteration": el2 / steps * 1e3,
+                                  "msg_components_per_sec": float(N) * B * steps / el2,
+                                  "dense_passes_f32_equivalent_TFLOPs": (sum(m["flops"] for m in m2) / (sum(m["ms"] for m in m2) * 1e-3) / 1e12)
+                                  if m2 else None, **score(ep)}
+            for f in lins:
+                f.detach_digits()
+        except Exception as e:                                                # noqa: BLE001
+            out["int8_digits"] = {"error": repr(e)}
     del ep, model
     gc.collect()
     return out
@@ -1159,7 +1185,7 @@ def run(args):
             gc.collect()
             for key, which, n_cfg in (("config2_cs1bit", "cs1bit", args.cs1bit_n), ("config4_twolayer", "twolayer", args.twolayer_n)):
                 try:
-                    out[key] = other_config(T, ctx, which, n_cfg, 64, np.float32)
+                    out[key] = other_config(T, ctx, which, n_cfg, 64, np.float32, with_digits=not args.no_digits)
                 except Exception as e:                                        # noqa: BLE001
                     out[key] = {"error": repr(e)}
                 gc.collect()

@@ -2263,3 +2263,69 @@ def gaussian_ensemble(rs, M, N):
 def gb_sample(rs, N, rho, mean=0., var=1.):
     g = mean + np.sqrt(var) * rs.standard_normal(N)
     return g * rs.binomial(n=1, size=N, p=rho)
+
+
+# ---- the int8-digit engine of the dense passes (tramp_amd/csrc/gemm_sliced.h): an integer restatement -------------
+# Not an algorithm of the reference (its products are numpy's `V @ x`, tramp/channels/linear/linear_channel.py:85-118):
+# this restates the DEVICE arithmetic - digit split, exact integer accumulation per split and weight, the order of the
+# f64 operations that combine them - so that the GPU result can be compared BIT FOR BIT (integer work), and the result
+# itself against the exact product.
+def digit_scale(amax):
+    "per-row power-of-two scale 2^(ilogb(max) + 1): 1 for a zero row, NaN for a non-finite one, 2^-1021 under subnormal maxima"
+    amax = np.asarray(amax, dtype=np.float64)
+    sc = np.ones_like(amax)
+    fin = np.isfinite(amax)
+    pos = fin & (amax > 0)
+    m, e = np.frexp(np.where(pos, amax, 1.0))           # amax = m 2^e, m in [0.5, 1): ilogb + 1 = e
+    sc = np.where(pos, np.ldexp(1.0, np.maximum(e, -1021)), sc)
+    return np.where(fin, sc, np.nan)
+
+
+def digit_split(a, S):
+    """a [rows, k] -> (digits int64 [S, rows, k] in [-128, 127] (|digit 0| <= 65), scale [rows]) with
+    a ~ scale sum_i digits[i] 2^-(6 + 8 i): N = rint(a 2^(6 + 8 (S - 1)) / scale), balanced base-256 digits of N."""
+    a = np.asarray(a, dtype=np.float64)
+    sc = digit_scale(np.max(np.abs(a), axis=1) if a.shape[1] else np.zeros(a.shape[0]))
+    inv = np.where(np.isnan(sc), 0.0, 2.0 ** (6 + 8 * (S - 1)) / np.where(np.isnan(sc), 1.0, sc))
+    with np.errstate(invalid="ignore"):
+        N = np.rint(np.where(np.isfinite(a), a, 0.0) * inv[:, None]).astype(np.int64)
+    dig = np.empty((S,) + a.shape, dtype=np.int64)
+    for i in range(S - 1, 0, -1):
+        d = ((N & 0xff) ^ 0x80) - 0x80                  # the low byte as a signed one
+        dig[i] = d
+        N = (N - d) >> 8
+    dig[0] = N
+    return dig, sc
+
+
+def digit_matvec(mat, x, S=7):
+    """out[b, r] = sum_c mat[r, c] x[b, c] as the device computes it (gemm_sliced.hip:run_sliced + gemm_sliced_kernel +
+    mfma_fold_kernel, mode 0): k blocks of 64, splits = the smallest multiple of 8 that keeps a split below
+    2^31 / (S 2^14) contraction indices (at most the number of k blocks), per split and weight d = i + j < S the exact
+    integer sum, s = sum_{d = S-1 .. 0} (double) acc_d 2^-(12 + 8 d), partial = (s row_scale) x_scale, splits added in
+    order."""
+    mat, x = np.asarray(mat, dtype=np.float64), np.asarray(x, dtype=np.float64)
+    R, k = mat.shape
+    A, rs = digit_split(mat, S)
+    X, xs = digit_split(x, S)
+    nkb = (k + 63) // 64
+    kmax = (131072 // S) // 64
+    nsplit = 8
+    while (nkb + nsplit - 1) // nsplit > kmax:
+        nsplit += 8
+    nsplit = min(nsplit, nkb)
+    kps = (nkb + nsplit - 1) // nsplit
+    out = np.zeros((x.shape[0], R))
+    for sp in range(nsplit):
+        c0, c1 = sp * kps * 64, min((sp + 1) * kps * 64, k)
+        s = np.zeros((x.shape[0], R))
+        for d in range(S - 1, -1, -1):
+            acc = np.zeros((x.shape[0], R), dtype=np.int64)
+            if c1 > c0:
+                for i in range(d + 1):
+                    acc += X[d - i][:, c0:c1] @ A[i][:, c0:c1].T
+            assert np.all(np.abs(acc) < 2 ** 31)        # what the device holds in an int32
+            s = s + acc.astype(np.float64) * 2.0 ** -(12 + 8 * d)
+        with np.errstate(invalid="ignore"):
+            out = out + (s * rs[None, :]) * xs[:, None]
+    return out

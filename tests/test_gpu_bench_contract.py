@@ -54,6 +54,8 @@ def test_bench_prints_one_json_line(force_dist):
         assert c["ms_per_iteration"] > 0 and c["msg_components_per_sec"] > 0 and c["setup"]["factorize_s"] > 0
         assert c["roofline"]["kernel"] in c["kernels"] and c["roofline"]["avg_launch_ms"] > 0
     assert c2["overlap"] > 0.3 and c4["mse_hidden"] < 0.5
+    assert c2["int8_digits"]["digits"] == c4["int8_digits"]["digits"] == 4                 # the f32 setting of the opt-in engine
+    assert abs(c2["int8_digits"]["overlap"] - c2["overlap"]) < 1e-2 and abs(c4["int8_digits"]["mse_hidden"] - c4["mse_hidden"]) < 1e-2
     # the opt-in int8-digit engine rides under its own key: same loop, estimates equal to the f64 engine's to ~1e-13
     dg = d["int8_digit_engine"]
     assert "error" not in dg, dg

@@ -1,6 +1,8 @@
 """GPU parity of the opt-in int8-digit engine of the dense passes (csrc/gemm_sliced.h, tramp_matrix_attach_digits):
 the same two products as tests/test_gpu_matvec.py, on v_mfma_i32_16x16x64_i8 with exact int32 accumulation, against
 a long-double host product; its error against the f64 matrix-core pass; special values; the LinearChannel switch."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -80,6 +82,20 @@ def test_digit_pass_f32(ctx, kind, shape, B):
     np.testing.assert_allclose(out, ref, rtol=3e-7, atol=3e-7 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("kind", ["nt", "nn"])
+@pytest.mark.parametrize("shape", [(16, 64), (100, 37), (333, 4100), (48, 20000), (130, 70)])
+@pytest.mark.parametrize("B", [3, 64, 70])
+@pytest.mark.parametrize("digits", [4, 6, 7, 8])
+def test_digit_pass_bit_exact_against_the_integer_restatement(ctx, kind, shape, B, digits):
+    """Integer work: the device's digits, its exact int32 sums per split and weight and the order of its f64 operations
+    are restated in oracle/tramp_oracle.py:digit_matvec - the two agree bit for bit."""
+    import tramp_amd as T
+    mat, x = data(*shape, B, kind, seed=digits)
+    out = run(ctx, T, kind, 0, mat, x, np.float64, digits)
+    ref = orc.digit_matvec(mat if kind == "nt" else mat.T, x, digits)
+    assert np.array_equal(out, ref)
+
+
 def test_forms_and_engine_selection(ctx):
     import tramp_amd as T
     mat, x = data(64, 256, 8, "nt")
@@ -109,6 +125,13 @@ def test_forms_and_engine_selection(ctx):
     assert ctx.digits_info(md)[:2] == (8, 3)
     ctx.detach_digits(md)
     assert ctx.digits_info(md) == (0, 0, 0)
+    # releasing the matrix drops its digit copy (the next allocation may get the same address)
+    ctx.attach_digits(md, 7, 1)
+    ptr = md.ptr
+    md.__del__()                                               # what dropping the last reference does
+    dg, forms, nbytes = C.c_int(), C.c_int(), C.c_size_t()
+    ctx._call("tramp_matrix_digits_info", ptr, C.byref(dg), C.byref(forms), C.byref(nbytes))
+    assert dg.value == 0
 
 
 def test_special_values(ctx):

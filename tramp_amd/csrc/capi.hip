@@ -327,6 +327,9 @@ extern "C" int tramp_buf_free(tramp_ctx* ctx, void* dptr) {
         return TRAMP_OK;
     }
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // a digit copy keyed by this pointer (gemm_sliced.hip) must not outlive the matrix: the next allocation may get
+    // the same address
+    if (ctx->sliced_reg) (void)tramp_matrix_detach_digits(ctx, dptr);
     TRAMP_HIP_CHECK(ctx, hipFree(dptr));
     return TRAMP_OK;
 }

@@ -146,8 +146,17 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_sliced_kernel(size_t R, size_t
     constexpr int NF = BT * S;                         // x fragments per k block
     __shared__ __attribute__((aligned(16))) int8_t xs[2][NF][kSlFrag];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const size_t rb = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-    const size_t bchunk = (size_t)blockIdx.y * 64;
+    // (tile = row block x split, 64-instance chunk).  Ensembles of more than 64 instances, one-dimensional launch: the
+    // sibling chunks of a tile are 8 workgroups apart - the same XCD under the round-robin dispatch and adjacent in
+    // time, so the second chunk finds the tile's digits in that XCD's L2 (as wg_item in gemm_mfma.hip)
+    size_t tile_id = blockIdx.x, chunk_id = blockIdx.y;
+    if (gridDim.y == 1 && B > 64) {
+        const size_t nchunk = (B + 63) / 64, g = blockIdx.x / 8, xcd = blockIdx.x % 8;
+        chunk_id = g % nchunk;
+        tile_id = (g / nchunk) * 8 + xcd;
+    }
+    const size_t rb = tile_id / nsplit, split = tile_id % nsplit;
+    const size_t bchunk = chunk_id * 64;
     const size_t ntile = (R + 15) / 16;
     size_t rt = rb * 4 + wave;
     const bool live = rt < ntile;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_sliced_kernel(size_t R, size_t
     size_t kb1 = kb0 + kb_per_split;
     if (kb1 > nkb) kb1 = nkb;
     const int8_t* mp = mat_s + ((rt * nkb + kb0) * S) * kSlFrag + lane * 16;
-    const int8_t* xp = x_s + ((kb0 * nbt + blockIdx.y * 4) * S) * kSlFrag + lane * 16;
+    const int8_t* xp = x_s + ((kb0 * nbt + chunk_id * 4) * S) * kSlFrag + lane * 16;
     const size_t x_step = nbt * S * kSlFrag;
 
     v4i acc[S][BT];

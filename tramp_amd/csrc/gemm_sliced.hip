@@ -209,12 +209,15 @@ static int run_sliced(tramp_ctx* ctx, const SlicedMat& m, size_t batch, const T*
                        batch, nbt * 16, m.kdim, m.kdim, x, amax, nbt, xfr, xscale);
     const size_t nrb = (m.ntile + 3) / 4;
     if (nrb * nsplit > 0x7fffffffull) return tramp_fail(ctx, TRAMP_ENOTSUP, "digit pass", "grid");
-    hipLaunchKernelGGL((gemm_sliced_kernel<S, 4>), dim3((unsigned)(nrb * nsplit), (unsigned)nchunk), dim3(kBlock), 0, ctx->stream,
+    const size_t ntile = nrb * nsplit;
+    const bool flat = nchunk > 1 && ntile % 8 == 0 && ntile * nchunk < (1ull << 31);        // sibling chunks interleaved
+    const dim3 grid = flat ? dim3((unsigned)(ntile * nchunk), 1) : dim3((unsigned)ntile, (unsigned)nchunk);
+    hipLaunchKernelGGL((gemm_sliced_kernel<S, 4>), grid, dim3(kBlock), 0, ctx->stream,
                        len, m.nkb, batch, nbt, (const int8_t*)m.frags, (const double*)m.scale, (const int8_t*)xfr, (const double*)xscale, kps,
                        (unsigned)nsplit, partials);
     ctx->last_nsplit = (int)nsplit;
     ctx->last_nchunk = (int)nchunk;
-    ctx->last_flat = 0;
+    ctx->last_flat = flat ? 1 : 0;
     ctx->sliced_runs++;
     return mfma_fold(ctx, m.dtype, len, batch, (int)nsplit, partials, epi);
 }
