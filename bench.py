@@ -772,8 +772,7 @@ def _tag_report(ctx):
 def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, with_digits=True):
     """BASELINE configs[2] (1-bit compressed sensing, alpha = 0.7, fp32) and configs[4] (two-layer ReLU GLM) as EP
     ensembles of B instances sharing their Gaussian-ensemble matrices, at the largest N whose factorisation fits the
-    bench's time budget (the named sizes fit the memory, not a few minutes of set-up; the full-size
-    two-layer run is profiles/r04/twolayer_N200000_f32.json).  Same protocol as the headline: factors from
+    bench's time budget (the named sizes do not fit the f64 factorisation's working set on one GPU: DESIGN 10.4).  Same protocol as the headline: factors from
     tramp_linear_factorize (timed, reported), `warmup` untimed iterations, `steps` timed ones with PassCallback (no
     instance freezes), per-kernel HIP-event times for the roofline of the dominant kernel."""
     import gc

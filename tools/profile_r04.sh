@@ -37,7 +37,7 @@ if fs:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[-1])):
         name = r["Kernel_Name"]
-        if not any(k in name for k in ("gemm_n", "mfma_fold", "gemv_n", "nn_fold", "ew_", "var_post", "lin_", "ep_", "damp")):
+        if not any(k in name for k in ("gemm_n", "gemm_sliced", "sl_", "mfma_fold", "gemv_n", "nn_fold", "ew_", "var_post", "lin_", "ep_", "damp")):
             continue
         grid = "x".join(r.get(k, "") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
         agg[(name.split("(")[0][:110], grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
