@@ -212,9 +212,19 @@ static int run_sliced(tramp_ctx* ctx, const SlicedMat& m, size_t batch, const T*
     const size_t ntile = nrb * nsplit;
     const bool flat = nchunk > 1 && ntile % 8 == 0 && ntile * nchunk < (1ull << 31);        // sibling chunks interleaved
     const dim3 grid = flat ? dim3((unsigned)(ntile * nchunk), 1) : dim3((unsigned)ntile, (unsigned)nchunk);
-    hipLaunchKernelGGL((gemm_sliced_kernel<S, 4>), grid, dim3(kBlock), 0, ctx->stream,
-                       len, m.nkb, batch, nbt, (const int8_t*)m.frags, (const double*)m.scale, (const int8_t*)xfr, (const double*)xscale, kps,
-                       (unsigned)nsplit, partials);
+    // instance tiles per workgroup: a single chunk of fewer than 49 instances skips the MFMAs of its empty tiles
+    const int bt = nchunk > 1 ? 4 : (int)((batch + 15) / 16);
+#define SL_LAUNCH(BTv)                                                                                                         \
+    hipLaunchKernelGGL((gemm_sliced_kernel<S, BTv>), grid, dim3(kBlock), 0, ctx->stream, len, m.nkb, batch, nbt,               \
+                       (const int8_t*)m.frags, (const double*)m.scale, (const int8_t*)xfr, (const double*)xscale, kps,         \
+                       (unsigned)nsplit, partials)
+    switch (bt) {
+        case 1: SL_LAUNCH(1); break;
+        case 2: SL_LAUNCH(2); break;
+        case 3: SL_LAUNCH(3); break;
+        default: SL_LAUNCH(4); break;
+    }
+#undef SL_LAUNCH
     ctx->last_nsplit = (int)nsplit;
     ctx->last_nchunk = (int)nchunk;
     ctx->last_flat = flat ? 1 : 0;
