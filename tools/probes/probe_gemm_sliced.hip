@@ -63,7 +63,7 @@ template <int S> static void check(size_t R, size_t C, size_t B) {
     CK(hipMalloc(&partials, nsplit * B * R * 8)); CK(hipMalloc(&out, B * R * 8));
     hipLaunchKernelGGL((sl_absmax_kernel<double, false>), dim3((unsigned)R, 1), dim3(kBlock), 0, 0, R, C, C, dm, am);
     hipLaunchKernelGGL((sl_absmax_kernel<double, false>), dim3((unsigned)B, 1), dim3(kBlock), 0, 0, B, C, C, dx, ax);
-    hipLaunchKernelGGL((sl_slice_kernel<double, S, false, false>), dim3((unsigned)((nkb * 4 + kBlock - 1) / kBlock), (unsigned)(ntile * 16)), dim3(kBlock), 0, 0,
+    hipLaunchKernelGGL((sl_slice_kernel<double, S, false, false>), dim3((unsigned)((nkb * 4 + 15) / 16), (unsigned)ntile), dim3(kBlock), 0, 0,
                        R, ntile * 16, C, C, dm, am, nkb, ms, rs);
     hipLaunchKernelGGL((sl_slice_kernel<double, S, false, true>), dim3((unsigned)((nbt * 16 + kBlock - 1) / kBlock), (unsigned)(nkb * 4)), dim3(kBlock), 0, 0,
                        B, nbt * 16, C, C, dx, ax, nbt, xs, xsc);

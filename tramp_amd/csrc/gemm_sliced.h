@@ -89,21 +89,31 @@ template <typename T, int S, bool TR, bool X>
 __global__ __launch_bounds__(kBlock) void sl_slice_kernel(size_t R, size_t Rpad, size_t C, size_t ld, const T* __restrict__ mat,
                                                           const unsigned long long* __restrict__ amax, size_t n_inner,
                                                           int8_t* __restrict__ out, double* __restrict__ scale) {
-    // thread -> (r, kg): r fastest when adjacent logical rows are adjacent in memory (TR) or for x (16 instances of a
-    // fragment line up in its 16-byte columns), kg fastest when the row itself is contiguous
+    // thread -> (r, kg): r fastest, so that the 16 rows of a tile line up in the 16-byte columns of a fragment (256
+    // contiguous bytes per store instruction and k group; with kg fastest the digit stores were 16-byte pieces 256
+    // bytes apart: 0.8 TB/s).  The contiguous-row matrix form (neither TR nor X) takes a block of 16 rows x 16 groups and
+    // reads its 16 x 256 elements through LDS, row by row in 2 KiB wave-contiguous pieces.
+    constexpr bool staged = !TR && !X;
     size_t r, kg;
-    if (TR || X) {
+    if (staged) {
+        r = (blockIdx.y + (size_t)blockIdx.z * gridDim.y) * 16 + (threadIdx.x & 15);
+        kg = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    } else {
         r = (size_t)blockIdx.x * kBlock + threadIdx.x;
         kg = blockIdx.y + (size_t)blockIdx.z * gridDim.y;
-    } else {
-        kg = (size_t)blockIdx.x * kBlock + threadIdx.x;
-        r = blockIdx.y + (size_t)blockIdx.z * gridDim.y;
     }
     const size_t nkg = (C + kSlK - 1) / kSlK * 4;          // Rpad: rows of whole tiles to write (rows >= R are zeros)
-    if (r >= Rpad || kg >= nkg) return;
+    if (!staged && (r >= Rpad || kg >= nkg)) return;    // (staged: every thread of the block reaches the barrier below)
     double sc = 1.0;
     if (r < R) sc = sl_scale_of(amax[r]);
-    if (kg == 0) scale[r] = sc;
+    if (kg == 0 && r < Rpad) scale[r] = sc;
+    __shared__ T stage[staged ? 16 : 1][staged ? kBlock + 1 : 1];
+    if (staged) {
+        const size_t r0 = (blockIdx.y + (size_t)blockIdx.z * gridDim.y) * 16, c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) stage[i][threadIdx.x] = (r0 + i < R && c < C) ? mat[(r0 + i) * ld + c] : T(0);
+        __syncthreads();
+    }
     // exact: sc is a power of two >= 2^-1021, the product a power-of-two multiple of a with |.| <= 2^(6 + 8 (S - 1)) <= 2^62
     const double inv = (sc == sc) ? __longlong_as_double((long long)(1023 + 6 + 8 * (S - 1)) << 52) / sc : 0.0;
     unsigned dig[S][4];
@@ -115,7 +125,8 @@ __global__ __launch_bounds__(kBlock) void sl_slice_kernel(size_t R, size_t Rpad,
     for (int e = 0; e < 16; ++e) {
         const size_t c = kg * 16 + e;
         long long N = 0;
-        if (r < R && c < C) N = (long long)__builtin_rint((double)(TR ? mat[c * ld + r] : mat[r * ld + c]) * inv);
+        if (staged) N = (long long)__builtin_rint((double)stage[threadIdx.x & 15][(threadIdx.x >> 4) * 16 + e] * inv);
+        else if (r < R && c < C) N = (long long)__builtin_rint((double)(TR ? mat[c * ld + r] : mat[r * ld + c]) * inv);
 #pragma unroll
         for (int i = S - 1; i > 0; --i) {
             const long long d = (long long)(signed char)(N & 0xff);
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void sl_slice_kernel(size_t R, size_t Rpad,
         }
         dig[0][e >> 2] |= ((unsigned)N & 0xffu) << (8 * (e & 3));
     }
+    if (staged && (r >= Rpad || kg >= nkg)) return;
     const size_t tile_r = r / 16, kb = kg / 4;
     const size_t frag0 = (X ? kb * n_inner + tile_r : tile_r * n_inner + kb) * S;
     const size_t within = ((kg % 4) * 16 + (r % 16)) * 16;

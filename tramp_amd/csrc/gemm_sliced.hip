@@ -53,8 +53,8 @@ static int slice_matrix(tramp_ctx* ctx, SlicedMat& m, const T* mat) {
     const size_t nkg = m.nkb * 4;
     if (m.nt) {
         hipLaunchKernelGGL((sl_absmax_kernel<T, false>), dim3((unsigned)m.rows, 1), dim3(kBlock), 0, ctx->stream, m.rows, m.kdim, ld, mat, amax);
-        const unsigned gy = (unsigned)(rows_pad < 32768 ? rows_pad : 32768), gz = (unsigned)((rows_pad + gy - 1) / gy);
-        hipLaunchKernelGGL((sl_slice_kernel<T, S, false, false>), dim3((unsigned)((nkg + kBlock - 1) / kBlock), gy, gz), dim3(kBlock), 0, ctx->stream,
+        const unsigned gy = (unsigned)(m.ntile < 32768 ? m.ntile : 32768), gz = (unsigned)((m.ntile + gy - 1) / gy);
+        hipLaunchKernelGGL((sl_slice_kernel<T, S, false, false>), dim3((unsigned)((nkg + 15) / 16), gy, gz), dim3(kBlock), 0, ctx->stream,
                            m.rows, rows_pad, m.kdim, ld, mat, amax, m.nkb, m.frags, m.scale);
     } else {
         hipLaunchKernelGGL((sl_absmax_kernel<T, true>), dim3((unsigned)((m.rows + kBlock - 1) / kBlock), 64), dim3(kBlock), 0, ctx->stream, m.rows, m.kdim, ld, mat, amax);
