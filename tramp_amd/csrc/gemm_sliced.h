@@ -66,8 +66,24 @@ __global__ __launch_bounds__(kBlock) void sl_absmax_kernel(size_t R, size_t C, s
     } else {
         const size_t r = blockIdx.x;
         unsigned long long m = 0;
-        for (size_t c = c0 + threadIdx.x; c < c1; c += kBlock) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(fabs((double)mat[r * ld + c]));
+        constexpr int E = 16 / sizeof(T);               // elements per 16-byte piece
+        const T* row = mat + r * ld;
+        size_t c = c0;
+        if (((size_t)row & 15) == 0 && (c0 % E) == 0) {   // whole pieces, 16 bytes per lane and load
+            typedef T VT __attribute__((ext_vector_type(E)));
+            const size_t npiece = (c1 - c0) / E;
+            for (size_t i = threadIdx.x; i < npiece; i += kBlock) {
+                const VT v = *reinterpret_cast<const VT*>(row + c0 + i * E);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned long long b = (unsigned long long)__double_as_longlong(fabs((double)v[e]));
+                    m = b > m ? b : m;
+                }
+            }
+            c = c0 + npiece * E;
+        }
+        for (c += threadIdx.x; c < c1; c += kBlock) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(fabs((double)row[c]));
             m = b > m ? b : m;
         }
 #pragma unroll
