@@ -1054,7 +1054,7 @@ def run(args):
         # (rocprofv3 cannot collect counters from inside this process; tools/profile_bench.sh makes the passes)
         traffic = None
         traffic_detail = None
-        for prof in ("r03", "r02", "r01"):
+        for prof in ("r04", "r03", "r02", "r01"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof, "traffic.json")))["entries"]
             except Exception:                                                 # noqa: BLE001
