@@ -766,6 +766,18 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
         rep = _tag_report(ctx)
         ctx._call("tramp_profile_enable", 0)
         mse = float(np.mean(np.atleast_1d(ep.mse("x", X))))
+        to_rule = None
+        if digits == 7 and not args.no_tts:
+            # from zero messages to EarlyStoppingEP(tol=1e-6) on every instance, as time_to_solution.headline does on
+            # the f64 engine: the iteration counts per instance are the comparison
+            ctx.sync()
+            t0 = time.perf_counter()
+            ep.iterate(max_iter=1000, callback=T.EarlyStoppingEP(tol=1e-6), damping=args.damping, check_every=args.check_every)
+            ctx.sync()
+            to_rule = {"iterate_s": time.perf_counter() - t0, "n_iter": int(ep.n_iter),
+                       "n_iter_per_instance": ep.n_iter_instance.tolist(),
+                       "status_counts": np.bincount(ep.status, minlength=3).tolist(),
+                       "mse": float(np.mean(np.atleast_1d(ep.mse("x", X))))}
         lin.detach_digits()
         dev = np.max(np.abs(r_dig - r_ref), axis=1) / np.max(np.abs(r_ref), axis=1)
         passes = {k: {"avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"],
@@ -777,6 +789,8 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
                                   "digit_copies_bytes": int(nbytes),
                                   "max_rel_deviation_of_r_after_K_steps_vs_f64_engine": float(dev.max()),
                                   "mse_after_run": mse}
+        if to_rule is not None:
+            res[f"digits{digits}"]["to_stopping_rule"] = to_rule
     return res
 
 
@@ -1132,6 +1146,7 @@ def run(args):
                     "headline": {"factorize_s": factorize_s, "iterate_s": it_s, "total_s": factorize_s + it_s,
                                  "n_iter": int(ep.n_iter),
                                  "n_iter_per_instance": [int(ep.n_iter_instance.min()), int(ep.n_iter_instance.max())],
+                                 "n_iter_of_each_instance": ep.n_iter_instance.tolist(),
                                  "status_counts": np.bincount(ep.status, minlength=3).tolist(),
                                  "mse": float(np.mean(mse_c)),
                                  "rule": "EarlyStoppingEP(tol=1e-6) per instance on the device (csrc/monitor.hip)"}}
