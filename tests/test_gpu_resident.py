@@ -224,3 +224,34 @@ def test_abs_likelihood_resident(T, ctx, dtype):
         a_ref, b_ref = orc.abs_lik_message(az[i], bz[i].astype(np.float64), y[i].astype(np.float64))
         close_a(a_new[i], a_ref, az[i], dtype)
         close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_binary_prior_and_relu_likelihood_resident(T, ctx, dtype):
+    """The two further separable updates on the resident pipeline (BinaryPrior: priors/binary_prior.py:27,52-58;
+    ReluLikelihood: likelihoods/piecewise_linear_likelihood.py:9-63,279-291) against the oracle, the form asserted."""
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(23)
+    ax = rs.uniform(0.4, 2.5, B)
+    bx = (rs.standard_normal((B, n)) * 1.2).astype(dtype)
+    pr = T.BinaryPrior(size=n, p_pos=0.3, dtype=dtype, ctx=ctx)
+    runs0 = ctx.resident_runs()
+    a_new, b_new = pr.compute_forward_message(ax, bx)
+    assert ctx.resident_runs() == runs0 + 1
+    for i in range(0, B, 7):
+        r, v = orc.binary_prior_posterior(ax[i], bx[i].astype(np.float64), p_pos=0.3)
+        a_ref, b_ref = orc.ab_new(r, v, ax[i], bx[i].astype(np.float64))
+        close_a(a_new[i], a_ref, ax[i], dtype)
+        close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+    z = rs.standard_normal((B, n))
+    y = np.maximum(z, 0.0).astype(dtype)
+    az = rs.uniform(0.4, 2.5, B)
+    bz = (rs.standard_normal((B, n)) * 1.5).astype(dtype)
+    lk = T.ReluLikelihood(y=y, dtype=dtype, ctx=ctx)
+    runs0 = ctx.resident_runs()
+    a_new, b_new = lk.compute_backward_message(az, bz)
+    assert ctx.resident_runs() == runs0 + 1
+    for i in range(0, B, 7):
+        a_ref, b_ref = orc.relu_lik_message(az[i], bz[i].astype(np.float64), y[i].astype(np.float64))
+        close_a(a_new[i], a_ref, az[i], dtype)
+        close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())

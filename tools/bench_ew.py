@@ -26,8 +26,13 @@ for np_dt in (np.float64, np.float32):
     sg = T.SgnLikelihood(y=y, dtype=np_dt, ctx=ctx)
     ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
     relu, sgn, abs_ = T.ReluChannel(dtype=np_dt, ctx=ctx), T.SgnChannel(dtype=np_dt, ctx=ctx), T.AbsChannel(dtype=np_dt, ctx=ctx)
+    bp = T.BinaryPrior(size=N, p_pos=0.3, dtype=np_dt, ctx=ctx)
+    yr = ctx.array(np.maximum(np.random.RandomState(1).standard_normal((B, N)), 0.0).astype(np_dt), np_dt)
+    rl = T.ReluLikelihood(y=yr, dtype=np_dt, ctx=ctx)
     cases = [("gb_prior", 2, lambda: gb.compute_forward_message(ax, bx, **kw)),
              ("l1_prior", 2, lambda: l1.compute_forward_message(ax, bx, **kw)),
+             ("binary_prior", 2, lambda: bp.compute_forward_message(ax, bx, **kw)),
+             ("relu_lik", 3, lambda: rl.compute_backward_message(az, bz, **kw)),
              ("sgn_lik", 3, lambda: sg.compute_backward_message(az, bz, **kw)),
              ("abs_lik", 3, lambda: ab.compute_backward_message(az, bz, **kw)),
              ("relu_bwd", 3, lambda: relu.compute_backward_message(az, bz, ax, bx, **kw)),
@@ -37,5 +42,5 @@ for np_dt in (np.float64, np.float32):
     for name, nT, fn in cases:
         ms = timeit(fn, 20 if B * N < 4e6 else 5)
         alg = nT * es * N * B
-        print(f"{name:9s} {np_dt.__name__} B={B} N={N}: {ms*1e3:9.1f} us  {alg/ms/1e6:7.0f} GB/s algorithmic ({alg/ms/1e6/8000*100:4.1f}% of 8 TB/s)  {N*B/ms/1e6:8.1f} Gcomp/s", flush=True)
-    del bz, bx, y, b_new
+        print(f"{name:12s} {np_dt.__name__} B={B} N={N}: {ms*1e3:9.1f} us  {alg/ms/1e6:7.0f} GB/s algorithmic ({alg/ms/1e6/8000*100:4.1f}% of 8 TB/s)  {N*B/ms/1e6:8.1f} Gcomp/s", flush=True)
+    del bz, bx, y, yr, b_new

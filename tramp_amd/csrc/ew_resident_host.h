@@ -18,6 +18,8 @@ template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value =
 template <typename T> struct ResidentOp<SgnLikOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<AbsLikOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<SgnLikBitsOp<T>> { static constexpr bool value = true; };
+template <typename T> struct ResidentOp<BinaryOp<T>> { static constexpr bool value = true; };
+template <typename T> struct ResidentOp<ReluLikOp<T>> { static constexpr bool value = true; };
 // (the two-region channels K7 are bound by their arithmetic, not by the second pass: their resident form measured
 // no faster in f64 - the erfcx tables beside the parked r leave room for one workgroup per CU - and slower in f32)
 

@@ -6,3 +6,5 @@ RES_INSTANTIATE(double, AbsLikOp<double>)
 RES_INSTANTIATE(float, AbsLikOp<float>)
 RES_INSTANTIATE(double, SgnLikBitsOp<double>)
 RES_INSTANTIATE(float, SgnLikBitsOp<float>)
+RES_INSTANTIATE(double, ReluLikOp<double>)
+RES_INSTANTIATE(float, ReluLikOp<float>)

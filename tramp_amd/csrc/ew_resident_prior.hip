@@ -4,3 +4,5 @@ RES_INSTANTIATE(double, GbOp<double>)
 RES_INSTANTIATE(float, GbOp<float>)
 RES_INSTANTIATE(double, L1Op<double>)
 RES_INSTANTIATE(float, L1Op<float>)
+RES_INSTANTIATE(double, BinaryOp<double>)
+RES_INSTANTIATE(float, BinaryOp<float>)
