@@ -486,7 +486,7 @@ int tramp_matvec_last_launch(tramp_ctx* ctx, int* nsplit, int* nchunk, int* flat
 
 /* Opt-in engine for the same two passes (csrc/gemm_sliced.h): a resident matrix [R, C] gets a copy in signed radix-256
  * digits (`digits` per element against a per-row power-of-two scale; 0 = by dtype: 7 for f64, 4 for f32; 6 / 7 / 8
- * allowed) laid out in int8 matrix-core operand order, and every pass over `mat_d` with more than two instances then
+ * allowed) laid out in int8 matrix-core operand order, and every pass over `mat_d` then
  * runs on v_mfma_i32_16x16x64_i8 with exact int32 accumulation (x is split the same way per pass); results agree with
  * the exact product to ~2^(2 - 8 digits) max|row| sum|x| - 7 digits: the error of an f64 FMA chain, 8: twenty times
  * below it.  which: bit 0 = the row-dot form (tramp_matvec_nt, (rows/16) x (C/64) x digits KiB), bit 1 = the column

@@ -40,7 +40,7 @@ def data(R, Cc, B, kind, seed=0):
 
 @pytest.mark.parametrize("kind", ["nt", "nn"])
 @pytest.mark.parametrize("shape", [(16, 64), (333, 4100), (100, 37), (37, 100), (5, 7), (1000, 500), (48, 20000)])
-@pytest.mark.parametrize("B", [3, 50, 64, 70, 130])
+@pytest.mark.parametrize("B", [1, 2, 3, 50, 64, 70, 130])
 @pytest.mark.parametrize("digits", [7, 8])
 def test_digit_pass_f64(ctx, kind, shape, B, digits):
     """Worst-case bound of the header: with u = 2^(2 - 8 digits), |error| <= u (4 (digits - 1) k max|row| max|x| +
@@ -113,7 +113,7 @@ def test_forms_and_engine_selection(ctx):
     ctx._call("tramp_matvec_nt", dt, 3, 64, 256, 8, md.ptr, xd.ptr, out.ptr)
     assert ctx.sliced_runs() == n0 + 2
     ctx._call("tramp_matvec_nt", dt, 2, 64, 256, 8, md.ptr, xd.ptr, out.ptr)       # forced f64 MFMA
-    ctx._call("tramp_matvec_nt", dt, 0, 64, 256, 2, md.ptr, xd.ptr, out.ptr)       # two instances: the GEMV
+    ctx._call("tramp_matvec_nt", dt, 1, 64, 256, 2, md.ptr, xd.ptr, out.ptr)       # forced GEMV
     y = ctx.array(np.ones((8, 64)), np.float64)
     o2 = ctx.zeros((8, 256), np.float64)
     ctx._call("tramp_matvec_nn", dt, 0, 64, 256, 8, md.ptr, y.ptr, o2.ptr)         # no column form attached: f64 MFMA

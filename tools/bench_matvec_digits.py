@@ -26,11 +26,11 @@ def timeit(fn, reps=6):
     return e0.elapsed_ms(e1) / reps
 
 
-for B in (3, 8, 16, 24, 32, 40, 48, 64, 128, 512):
+for B in (1, 2, 3, 8, 16, 24, 32, 40, 48, 64, 128, 512):
     x, y = ctx.randn((B, N), np.float64, seed=2), ctx.randn((B, M), np.float64, seed=3)
     t, r = ctx.empty((B, M), np.float64), ctx.empty((B, N), np.float64)
     row = f"B={B:4d}"
-    for algo, name in ((2, "f64 MFMA"), (3, f"{D} digits")):
+    for algo, name in ((1 if B <= 2 else 2, "f64 GEMV" if B <= 2 else "f64 MFMA"), (3, f"{D} digits")):
         a = timeit(lambda: ctx._call("tramp_matvec_nt", dt, algo, M, N, B, Vt.ptr, x.ptr, t.ptr))
         b = timeit(lambda: ctx._call("tramp_matvec_nn", dt, algo, M, N, B, Vt.ptr, y.ptr, r.ptr))
         row += f"   {name}: row-dot {a:7.3f} ms  column {b:7.3f} ms"

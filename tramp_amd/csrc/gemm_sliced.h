@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void sl_absmax_kernel(size_t R, size_t C, s
         constexpr int E = 16 / sizeof(T);               // elements per 16-byte piece
         const T* row = mat + r * ld;
         size_t c = c0;
-        if (((size_t)row & 15) == 0 && (c0 % E) == 0) {   // whole pieces, 16 bytes per lane and load
+        if (c0 < c1 && ((size_t)row & 15) == 0 && (c0 % E) == 0) {   // whole pieces, 16 bytes per lane and load (c0 >= c1: an empty chunk)
             typedef T VT __attribute__((ext_vector_type(E)));
             const size_t npiece = (c1 - c0) / E;
             for (size_t i = threadIdx.x; i < npiece; i += kBlock) {

@@ -357,7 +357,8 @@ static int matvec_dispatch(tramp_ctx* ctx, int dtype, int algo, bool nt, size_t 
     if (algo == 0 && algo_env) algo = algo_env;
     ProfScope prof(ctx, nt ? PROF_MATVEC_NT : PROF_MATVEC_NN, (double)R * (double)C * dtype_size(dtype),
                    2.0 * (double)R * (double)C * (double)batch);
-    if (algo == 3 || (algo == 0 && batch > 2)) {      // an attached int8-digit copy of this matrix (gemm_sliced.hip) takes the pass
+    if (algo == 3 || algo == 0) {      // an attached int8-digit copy of this matrix (gemm_sliced.hip) takes the pass, at any batch:
+                                       // 7 bytes per element instead of 8 even where the pass only streams
         bool taken = false;
         const int rc = gemm_sliced_try(ctx, dtype, nt, R, C, batch, mat_d, x_d, epi, &taken);
         if (taken) return rc;

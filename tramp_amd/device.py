@@ -150,7 +150,7 @@ class Context:
     # -- int8-digit copies of resident matrices (csrc/gemm_sliced.h; opt-in engine of the dense passes)
     def attach_digits(self, mat, digits=0, which=3):
         """Give the resident matrix `mat` [R, C] a copy in signed radix-256 digits: every tramp_matvec_nt / _nn pass over
-        it with more than two instances then runs on the int8 matrix cores (digits: 0 = 7 for f64, 4 for f32; which:
+        it then runs on the int8 matrix cores (digits: 0 = 7 for f64, 4 for f32; which:
         1 row-dot form, 2 column form, 3 both).  Detach before the matrix changes or is released."""
         R, Cc = mat.shape
         self._call("tramp_matrix_attach_digits", _DT[np.dtype(mat.dtype)], int(R), int(Cc), mat.ptr, int(digits), int(which))
