@@ -83,8 +83,8 @@ def test_digit_pass_f32(ctx, kind, shape, B):
 
 
 @pytest.mark.parametrize("kind", ["nt", "nn"])
-@pytest.mark.parametrize("shape", [(16, 64), (100, 37), (333, 4100), (48, 20000), (130, 70)])
-@pytest.mark.parametrize("B", [3, 64, 70])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (17, 65), (16, 64), (100, 37), (333, 4100), (48, 20000), (130, 70)])
+@pytest.mark.parametrize("B", [1, 3, 64, 70])
 @pytest.mark.parametrize("digits", [4, 6, 7, 8])
 def test_digit_pass_bit_exact_against_the_integer_restatement(ctx, kind, shape, B, digits):
     """Integer work: the device's digits, its exact int32 sums per split and weight and the order of its f64 operations
