@@ -180,5 +180,11 @@ def test_ep_ensemble_on_the_digit_engine(ctx, digits):
     for b in range(batch):
         res = orc.ep_chain([orc.GBPriorFactor(N, rho=rho), lf, orc.GaussLikFactor(Y[b], nv)], [N, M], max_iter=8, damping=0.1, tol=0.0)
         np.testing.assert_allclose(r[b], res["r"][0], rtol=1e-6, atol=1e-6 * np.abs(res["r"][0]).max())
+    # the steady state captured in a hipGraph (the digit split of x is part of the captured launch sequence) gives the
+    # same estimates, bit for bit
+    n1 = ctx.sliced_runs()
+    ep.iterate(max_iter=8, callback=T.PassCallback(), damping=0.1, graph=True)
+    assert ctx.sliced_runs() > n1
+    assert np.array_equal(ep.get_variables_data()["x"]["r"].reshape(batch, N), r)
     lin.detach_digits()
     assert lin.digits == 0 and ctx.digits_info(lin._Vt)[0] == 0
