@@ -743,6 +743,31 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
         ep.iterate(max_iter=k, callback=T.PassCallback(), damping=args.damping, check_every=args.check_every)
         return ep.get_variables_data(["x"])["x"]["r"].reshape(B, N).copy()
 
+    def pass_errors():
+        """The row-dot pass at the headline size on both engines against a long-double product, for 48 sampled rows of
+        the resident factor and all instances: the f64-equivalence of the digits where it is used (k = N terms)."""
+        Vt = lin._Vt
+        k_rows, n_cols = Vt.shape
+        np_dt = Vt.dtype
+        dt = T.device.dtype_code(np_dt)
+        x = ctx.randn((B, n_cols), np_dt, seed=99)
+        out = ctx.empty((B, k_rows), np_dt)
+        rows = np.linspace(0, k_rows - 1, 48).astype(int)
+        Vh = np.stack([Vt.row(int(i)).get() for i in rows]).astype(np.longdouble)
+        exact = x.get().astype(np.longdouble) @ Vh.T
+        err = {}
+        ctx._call("tramp_matvec_nt", dt, 2, k_rows, n_cols, B, Vt.ptr, x.ptr, out.ptr)
+        err["f64_matrix_cores"] = float(np.max(np.abs(out.get()[:, rows] - exact)))
+        for dg in (7, 8):
+            ctx.attach_digits(Vt, dg, 1)
+            ctx._call("tramp_matvec_nt", dt, 3, k_rows, n_cols, B, Vt.ptr, x.ptr, out.ptr)
+            err[f"digits{dg}"] = float(np.max(np.abs(out.get()[:, rows] - exact)))
+            ctx.detach_digits(Vt)
+        err["max_abs_exact"] = float(np.max(np.abs(exact)))
+        err["terms"] = int(n_cols)
+        err["sample"] = "48 rows of Vt x all instances, unit Gaussian x; max |pass - long double product|"
+        return err
+
     r_ref = fresh(args.steps)
     res = {"note": "opt-in engine: both operands of the dense passes in signed radix-256 digits, exact int32 accumulation on "
                    "v_mfma_i32_16x16x64_i8 (7 digits = 54 bits per operand, 8 = 62); the headline above is the f64 "
@@ -791,6 +816,10 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
                                   "mse_after_run": mse}
         if to_rule is not None:
             res[f"digits{digits}"]["to_stopping_rule"] = to_rule
+    try:
+        res["row_dot_pass_error_vs_long_double"] = pass_errors()
+    except Exception as e:                                                    # noqa: BLE001
+        res["row_dot_pass_error_vs_long_double"] = {"error": repr(e)}
     return res
 
 

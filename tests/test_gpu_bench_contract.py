@@ -62,6 +62,8 @@ def test_bench_prints_one_json_line(force_dist):
     for key in ("digits7", "digits8"):
         assert dg[key]["ms_per_step"] > 0 and dg[key]["passes"] and dg[key]["digit_copies_bytes"] > 0
         assert dg[key]["max_rel_deviation_of_r_after_K_steps_vs_f64_engine"] < 1e-11
+    pe = dg["row_dot_pass_error_vs_long_double"]
+    assert "error" not in pe and pe["digits8"] <= pe["f64_matrix_cores"] * 1.5 + 1e-300 and pe["digits7"] < 1e-11 * pe["max_abs_exact"]
     # and it reaches the stopping rule in the same number of iterations, instance by instance
     assert dg["digits7"]["to_stopping_rule"]["n_iter_per_instance"] == tts["headline"]["n_iter_of_each_instance"]
 
