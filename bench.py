@@ -437,7 +437,12 @@ def factor_updates_n1e6(T, ctx, dtype):
     ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
     relu, sgn, abs_ = (T.ReluChannel(dtype=np_dt, ctx=ctx), T.SgnChannel(dtype=np_dt, ctx=ctx),
                        T.AbsChannel(dtype=np_dt, ctx=ctx))
+    bp = T.BinaryPrior(size=N, p_pos=0.3, dtype=np_dt, ctx=ctx)
+    yr = ctx.array(np.maximum(np.random.RandomState(1).standard_normal((B, N)), 0.0).astype(np_dt), np_dt)
+    rl = T.ReluLikelihood(y=yr, dtype=np_dt, ctx=ctx)
     cases = [("l1_prior", "K2", 2, lambda: l1.compute_forward_message(ax, bx, **kw)),
+             ("binary_prior", "binary", 2, lambda: bp.compute_forward_message(ax, bx, **kw)),
+             ("relu_lik", "relu likelihood", 3, lambda: rl.compute_backward_message(az, bz, **kw)),
              ("sgn_lik", "K4", 3, lambda: sg.compute_backward_message(az, bz, **kw)),
              ("abs_lik", "K5", 3, lambda: ab.compute_backward_message(az, bz, **kw)),
              ("relu_bwd", "K7", 3, lambda: relu.compute_backward_message(az, bz, ax, bx, **kw)),
@@ -460,7 +465,7 @@ def factor_updates_n1e6(T, ctx, dtype):
             # algorithmic 3T of SURVEY 8d stays the yardstick of frac_of_hbm_peak
             rec["moved_bytes_per_component"] = 2 * esz + 0.125
             rec["moved_GBps"] = (2 * esz + 0.125) * N * B / ms / 1e6
-        if dtype == "f64":
+        if dtype == "f64" and name in VALU_PER_COMPONENT_F64:
             instr = VALU_PER_COMPONENT_F64[name]
             rec["valu_instructions_per_component"] = instr
             rec["frac_of_f64_valu_issue_peak"] = instr * N * B / 64.0 * 4.0 / 1024.0 / 2.4e9 / (ms * 1e-3)
