@@ -157,13 +157,28 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     auto mfma_block = [&](int st, const V (&m)[RT][kPieces]) {
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) {
+            if constexpr (sizeof(T) == 8) {
+                // f64: the matrix operand is held over the BT MFMAs that share it and the x operand changes every MFMA (the
+                // other way round - x held over RT MFMAs - the same launch pair takes 0.6 % longer under the power limit,
+                // same bits: tools/ab_matvec_pair.py, three alternations on one box)
+                V a[BT];
 #pragma unroll
-            for (int bt = 0; bt < BT; ++bt) {
-                const V a = xs[st][bt][p][lane];
+                for (int bt = 0; bt < BT; ++bt) a[bt] = xs[st][bt][p][lane];
 #pragma unroll
                 for (int e = 0; e < E; ++e)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][bt] = Mx<T>::mfma(a[e], m[rt][p][e], acc[rt][bt]);
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = Mx<T>::mfma(a[bt][e], m[rt][p][e], acc[rt][bt]);
+            } else {
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    const V a = xs[st][bt][p][lane];
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][bt] = Mx<T>::mfma(a[e], m[rt][p][e], acc[rt][bt]);
+                }
             }
         }
     };
@@ -267,14 +282,26 @@ void gemm_nn_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     auto mfma_block = [&](int st, const V (&m)[S]) {
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) {
+            if constexpr (sizeof(T) == 8) {             // as in the row-dot kernel
+                V a[BT];
 #pragma unroll
-            for (int bt = 0; bt < BT; ++bt) {
-                const V a = xs[st][bt][p][lane];
+                for (int bt = 0; bt < BT; ++bt) a[bt] = xs[st][bt][p][lane];
 #pragma unroll
                 for (int e = 0; e < E; ++e)
 #pragma unroll
                     for (int nt = 0; nt < E; ++nt)
-                        acc[nt][bt] = Mx<T>::mfma(a[e], m[p * E + e][nt], acc[nt][bt]);
+#pragma unroll
+                        for (int bt = 0; bt < BT; ++bt) acc[nt][bt] = Mx<T>::mfma(a[bt][e], m[p * E + e][nt], acc[nt][bt]);
+            } else {
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    const V a = xs[st][bt][p][lane];
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+#pragma unroll
+                        for (int nt = 0; nt < E; ++nt)
+                            acc[nt][bt] = Mx<T>::mfma(a[e], m[p * E + e][nt], acc[nt][bt]);
+                }
             }
         }
     };
