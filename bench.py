@@ -812,7 +812,9 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
         dev = np.max(np.abs(r_dig - r_ref), axis=1) / np.max(np.abs(r_ref), axis=1)
         passes = {k: {"avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"],
                       "f64_equivalent_TFLOPs": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                      "digit_bytes_GBps": v["bytes"] * digits / 8.0 / (v["ms"] * 1e-3) / 1e9}
+                      "digit_bytes_GBps": v["bytes"] * digits / 8.0 / (v["ms"] * 1e-3) / 1e9,
+                      "digit_bytes_frac_of_hbm_peak": v["bytes"] * digits / 8.0 / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "int8_TOPs": v["flops"] * (digits * (digits + 1) / 2) / (v["ms"] * 1e-3) / 1e12}
                   for k, v in rep.items() if k.startswith("matvec")}
         res[f"digits{digits}"] = {"ms_per_step": el / args.steps * 1e3, "value": float(N) * B * args.steps / el,
                                   "unit": "msg-components/s", "passes": passes, "attach_s": attach_s,
