@@ -255,3 +255,33 @@ def test_binary_prior_and_relu_likelihood_resident(T, ctx, dtype):
         a_ref, b_ref = orc.relu_lik_message(az[i], bz[i].astype(np.float64), y[i].astype(np.float64))
         close_a(a_new[i], a_ref, az[i], dtype)
         close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_resident_pipeline_on_seeded_random_shapes_around_its_limits(T, ctx, dtype):
+    """Shapes drawn around the eligibility limits of the pipeline (tiles per instance from 1 to past the window, batches
+    that just fill or just miss the minimum number of rounds, instance lengths that end inside a tile): whatever form
+    runs (the context says which), every instance agrees with the oracle and nothing is left from a previous shape."""
+    rs = np.random.RandomState(20260)
+    comps = 2048 if dtype == np.float64 else 4096          # components per 16 KiB tile
+    vn = 2 if dtype == np.float64 else 4
+    ps = 2 * num_cu(ctx) - 8
+    took = {True: 0, False: 0}
+    for trial in range(14):
+        tiles = int(rs.choice([1, 2, 3, 5, 9, 17, 33, ps - 1, ps + 1, ps + 2]))
+        n = tiles * comps - int(rs.randint(0, comps // vn)) * vn          # ends inside the last tile, whole 16-byte pieces
+        n = max(n, vn)
+        want = 4 * ps + int(rs.randint(-2, 3)) * tiles                    # rounds just under / over the minimum
+        B = int(np.clip(want // tiles + int(rs.randint(0, 2)), 1, max(1, (96 << 20) // (n * np.dtype(dtype).itemsize))))
+        ax = rs.uniform(0.3, 3.0, B)
+        bx = (rs.standard_normal((B, n)) * rs.uniform(0.5, 3.0, (B, 1))).astype(dtype)
+        covers = ctx.resident_covers(dtype, n, B)
+        runs0 = ctx.resident_runs()
+        a_new, b_new = T.GaussBernoulliPrior(size=n, rho=0.07, dtype=dtype, ctx=ctx).compute_forward_message(ax, bx)
+        assert (ctx.resident_runs() == runs0 + 1) == covers, (tiles, n, B, covers)
+        took[covers] += 1
+        for i in sorted(set([0, B // 2, B - 1])):
+            a_ref, b_ref = orc.gb_prior_message(ax[i], bx[i].astype(np.float64), rho=0.07)
+            close_a(a_new[i], a_ref, ax[i], dtype)
+            close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+    assert took[True] >= 2 and took[False] >= 2, took
