@@ -36,12 +36,12 @@ __global__ void fold8(size_t len, size_t B, int nsplit, const double* partials, 
     out[b * len + idx] = s;
 }
 
-template <int S, int DBG = 0>
+template <int S, int DBG = 0, int NW = 4>
 static void launch(size_t R, size_t nkb, size_t B, size_t nbt, const int8_t* ms, const double* rs, const int8_t* xs, const double* xsc,
                    unsigned nsplit, double* partials) {
-    const size_t ntile = (R + 15) / 16, nrb = (ntile + 3) / 4;
+    const size_t ntile = (R + 15) / 16, nrb = (ntile + NW - 1) / NW;
     const size_t kps = (nkb + nsplit - 1) / nsplit;
-    hipLaunchKernelGGL((gemm_sliced_kernel<S, 4, DBG>), dim3((unsigned)(nrb * nsplit), (unsigned)((B + 63) / 64)), dim3(kBlock), 0, 0,
+    hipLaunchKernelGGL((gemm_sliced_kernel<S, 4, DBG, NW>), dim3((unsigned)(nrb * nsplit), (unsigned)((B + 63) / 64)), dim3(NW * 64), 0, 0,
                        R, nkb, B, nbt, ms, rs, xs, xsc, kps, nsplit, partials);
 }
 
@@ -86,7 +86,7 @@ template <int S> static void check(size_t R, size_t C, size_t B) {
     hipFree(dm); hipFree(dx); hipFree(am); hipFree(ax); hipFree(rs); hipFree(xsc); hipFree(ms); hipFree(xs); hipFree(partials); hipFree(out);
 }
 
-template <int S, int DBG = 0> static void speed(size_t R, size_t C, size_t B, unsigned nsplit, bool zero = false) {
+template <int S, int DBG = 0, int NW = 4> static void speed(size_t R, size_t C, size_t B, unsigned nsplit, bool zero = false) {
     const size_t nkb = (C + 63) / 64, ntile = (R + 15) / 16, nbt = (B + 63) / 64 * 4;
     int8_t *ms, *xs;
     double *rs, *xsc, *partials;
@@ -96,16 +96,16 @@ template <int S, int DBG = 0> static void speed(size_t R, size_t C, size_t B, un
     hipLaunchKernelGGL(fill_bytes, dim3(8192), dim3(256), 0, 0, xs, nkb * nbt * S * kSlFrag);
     if (zero) { CK(hipMemset(ms, 0, ntile * nkb * S * kSlFrag)); CK(hipMemset(xs, 0, nkb * nbt * S * kSlFrag)); }
     CK(hipMemset(rs, 0, ntile * 16 * 8)); CK(hipMemset(xsc, 0, nbt * 16 * 8));
-    for (int i = 0; i < 2; ++i) launch<S, DBG>(R, nkb, B, nbt, ms, rs, xs, xsc, nsplit, partials);
+    for (int i = 0; i < 2; ++i) launch<S, DBG, NW>(R, nkb, B, nbt, ms, rs, xs, xsc, nsplit, partials);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 10;
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) launch<S, DBG>(R, nkb, B, nbt, ms, rs, xs, xsc, nsplit, partials);
+    for (int i = 0; i < reps; ++i) launch<S, DBG, NW>(R, nkb, B, nbt, ms, rs, xs, xsc, nsplit, partials);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms_; hipEventElapsedTime(&ms_, e0, e1); ms_ /= reps;
     const double bytes = (double)ntile * nkb * S * kSlFrag, flops = 2.0 * R * C * B;
-    printf("S=%d%s%s  %zu x %zu x %zu split %u: %8.3f ms  matrix stream %6.0f GB/s (%.3f of 8 TB/s)  f64-equivalent %6.1f TFLOP/s  int8 %7.1f TOP/s\n", S, DBG ? " [matrix not advanced]" : "", zero ? " [zero data]" : "", R, C, B, nsplit,
+    printf("S=%d NW=%d%s%s  %zu x %zu x %zu split %u: %8.3f ms  matrix stream %6.0f GB/s (%.3f of 8 TB/s)  f64-equivalent %6.1f TFLOP/s  int8 %7.1f TOP/s\n", S, NW, DBG ? " [matrix not advanced]" : "", zero ? " [zero data]" : "", R, C, B, nsplit,
            ms_, bytes / ms_ / 1e6, bytes / ms_ / 1e6 / 8000.0, flops / ms_ / 1e9, flops * (S * (S + 1) / 2) / ms_ / 1e9);
     fflush(stdout);
     hipFree(ms); hipFree(xs); hipFree(rs); hipFree(xsc); hipFree(partials);
@@ -119,8 +119,13 @@ int main(int argc, char** argv) {
     check<6>(333, 4100, 50);
     check<4>(333, 4100, 50);
     check<7>(300, 18000, 20);
-    speed<8>(R, C, B, 8);
     speed<7>(R, C, B, 8);
+    speed<7, 0, 8>(R, C, B, 8);
+    speed<7>(R, C, B, 8);
+    speed<7, 0, 8>(R, C, B, 8);
+    speed<7, 0, 8>(R, C, B, 16);
+    speed<8>(R, C, B, 8);
+    speed<8, 0, 8>(R, C, B, 8);
     speed<7>(R, C, B, 16);
     speed<7>(R, C, B, 8, true);
     speed<7, 1>(R, C, B, 8);

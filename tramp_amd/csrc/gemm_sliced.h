@@ -161,13 +161,14 @@ __global__ __launch_bounds__(kBlock) void sl_slice_kernel(size_t R, size_t Rpad,
 }
 
 // ---------------------------------------------------------------------------------------------- the pass
-// Workgroup: 4 waves, wave w owns row tile 4 rb + w (16 matrix rows) against BT x 16 instances; blockIdx.x = rb nsplit +
+// Workgroup: NW waves (4, or 8 = one workgroup per CU), wave w owns row tile NW rb + w (16 matrix rows) against BT x 16
+// instances; blockIdx.x = rb nsplit +
 // split (split == XCD under the round-robin dispatch, as in gemm_mfma.hip), blockIdx.y = chunk of 64 instances.
 // Per k block and wave: S matrix fragments global -> registers (two alternating sets), BT S x fragments global -> LDS
 // (two buffers, each wave moves its quarter), S (S + 1) / 2 x BT MFMAs.  One barrier per k block.
 // DBG (probes only): 1 = the matrix pointer does not advance (every k block re-reads the first: the pass without HBM)
-template <int S, int BT, int DBG = 0>
-__global__ __launch_bounds__(kBlock, 2) void gemm_sliced_kernel(size_t R, size_t nkb, size_t B, size_t nbt,
+template <int S, int BT, int DBG = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_sliced_kernel(size_t R, size_t nkb, size_t B, size_t nbt,
                                                                  const int8_t* __restrict__ mat_s, const double* __restrict__ row_scale,
                                                                  const int8_t* __restrict__ x_s, const double* __restrict__ x_scale,
                                                                  size_t kb_per_split, unsigned nsplit, double* __restrict__ partials) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_sliced_kernel(size_t R, size_t
     const size_t rb = tile_id / nsplit, split = tile_id % nsplit;
     const size_t bchunk = chunk_id * 64;
     const size_t ntile = (R + 15) / 16;
-    size_t rt = rb * 4 + wave;
+    size_t rt = rb * NW + wave;
     const bool live = rt < ntile;
     if (!live) rt = ntile - 1;                         // a wave past the last tile computes on valid memory and stores nothing
     const size_t kb0 = split * kb_per_split;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_sliced_kernel(size_t R, size_t
 #pragma unroll
         for (int i = 0; i < S; ++i) dst[i] = *reinterpret_cast<const v4i*>(mp + i * kSlFrag);
 #pragma unroll
-        for (int f = wave; f < NF; f += 4)
+        for (int f = wave; f < NF; f += NW)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp + f * kSlFrag),
                                              (__attribute__((address_space(3))) void*)&xs[buf][f][0], 16, 0, 0);
         if (DBG != 1) mp += S * kSlFrag;

@@ -207,7 +207,10 @@ static int run_sliced(tramp_ctx* ctx, const SlicedMat& m, size_t batch, const T*
     const unsigned gy = (unsigned)(nkg < 32768 ? nkg : 32768), gz = (unsigned)((nkg + gy - 1) / gy);
     hipLaunchKernelGGL((sl_slice_kernel<T, S, false, true>), dim3((unsigned)((nbt * 16 + kBlock - 1) / kBlock), gy, gz), dim3(kBlock), 0, ctx->stream,
                        batch, nbt * 16, m.kdim, m.kdim, x, amax, nbt, xfr, xscale);
-    const size_t nrb = (m.ntile + 3) / 4;
+    // waves per workgroup: 8 (one workgroup per CU) halve the x fragments a CU pulls through L2 per matrix byte -
+    // 1.3-2.7 % on the power-bound pass with 7 digits and fewer (tools/probes/probe_gemm_sliced.hip), nothing with 8
+    constexpr int NW = S == 8 ? 4 : 8;
+    const size_t nrb = (m.ntile + NW - 1) / NW;
     if (nrb * nsplit > 0x7fffffffull) return tramp_fail(ctx, TRAMP_ENOTSUP, "digit pass", "grid");
     const size_t ntile = nrb * nsplit;
     const bool flat = nchunk > 1 && ntile % 8 == 0 && ntile * nchunk < (1ull << 31);        // sibling chunks interleaved
@@ -215,7 +218,7 @@ static int run_sliced(tramp_ctx* ctx, const SlicedMat& m, size_t batch, const T*
     // instance tiles per workgroup: a single chunk of fewer than 49 instances skips the MFMAs of its empty tiles
     const int bt = nchunk > 1 ? 4 : (int)((batch + 15) / 16);
 #define SL_LAUNCH(BTv)                                                                                                         \
-    hipLaunchKernelGGL((gemm_sliced_kernel<S, BTv>), grid, dim3(kBlock), 0, ctx->stream, len, m.nkb, batch, nbt,               \
+    hipLaunchKernelGGL((gemm_sliced_kernel<S, BTv, 0, NW>), grid, dim3(NW * 64), 0, ctx->stream, len, m.nkb, batch, nbt,         \
                        (const int8_t*)m.frags, (const double*)m.scale, (const int8_t*)xfr, (const double*)xscale, kps,         \
                        (unsigned)nsplit, partials)
     switch (bt) {
