@@ -765,9 +765,11 @@ class SolveLinearChannel(LinearChannel):
     The scheduler never rotates this channel into a singular basis and cannot capture it in a hipGraph."""
 
     def __init__(self, W, precompute_svd=False, name="W", dtype=np.float64, ctx=None, svd="auto", factors=None,
-                 keep_W=True):
+                 keep_W=True, digits=None):
         if precompute_svd:
             raise ValueError("SolveLinearChannel is the precompute_svd=False branch")
+        if digits:
+            raise ValueError("digits: the int8-digit engine serves the factorised channel (precompute_svd=True) only")
         self.name = name
         self.Nx, self.Nz = (int(s) for s in W.shape)
         self.precompute_svd = False
