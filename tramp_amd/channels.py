@@ -764,6 +764,9 @@ class SolveLinearChannel(LinearChannel):
     (sigma > sigma_max * max(M, N) * eps, resolved only down to ~1e-8 sigma_max by the Gram form).
     The scheduler never rotates this channel into a singular basis and cannot capture it in a hipGraph."""
 
+    def attach_digits(self, digits=0, uk=True):
+        raise ValueError("the int8-digit engine serves the factorised channel (precompute_svd=True) only")
+
     def __init__(self, W, precompute_svd=False, name="W", dtype=np.float64, ctx=None, svd="auto", factors=None,
                  keep_W=True, digits=None):
         if precompute_svd:
