@@ -106,12 +106,12 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     for (int rt = 0; rt < RT; ++rt) {
         size_t r = row0 + rt * 16 + j;
         if (r >= R) r = R - 1;
-        mp[rt] = mat + r * C + q * E;
+        mp[rt] = mat + r * C + q * (kPieces * E);
     }
     // x loader: wave w stages batch tile w
     size_t xb = bchunk + (size_t)wave * 16 + j;
     if (xb >= B) xb = B - 1;
-    const T* xp = x + xb * C + q * E;
+    const T* xp = x + xb * C + q * (kPieces * E);
     const bool loads_x = wave < BT;
 
     A acc[RT][BT];
@@ -131,11 +131,11 @@ void gemm_nt_kernel(size_t R, size_t C, size_t B, const T* __restrict__ mat, con
     auto load_step = [&](auto guarded, size_t k, V (&dst)[RT][kPieces]) {
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) {
-            const bool in = !decltype(guarded)::value || k + p * 4 * E + q * E < C;   // C % E == 0: pieces are all-in or all-out
+            const bool in = !decltype(guarded)::value || k + p * E + q * (kPieces * E) < C;   // C % E == 0: pieces are all-in or all-out
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-                dst[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k + p * 4 * E) : vzero;
-            xg[p] = in ? *reinterpret_cast<const V*>(xp + k + p * 4 * E) : vzero;      // every wave (clamped row): no branch
+                dst[rt][p] = in ? *reinterpret_cast<const V*>(mp[rt] + k + p * E) : vzero;
+            xg[p] = in ? *reinterpret_cast<const V*>(xp + k + p * E) : vzero;      // every wave (clamped row): no branch
         }
     };
     // Every call issues the same number of loads on every path - past the end of the split the last step is
