@@ -67,6 +67,13 @@ def parse():
                     help="N of the 1-bit CS leg (fp32, alpha = 0.7, 64 instances)")
     ap.add_argument("--twolayer-n", type=int, default=int(os.environ.get("TRAMP_BENCH_TWOLAYER_N", 65536)),
                     help="input size of the two-layer leg (fp32, alpha = 0.5 per layer, 64 instances)")
+    ap.add_argument("--full", action="store_true",
+                    help="every auxiliary leg (f32 duplicates, fused-moment pairs, every elementwise factor, structured "
+                         "channels, the 512-instance run, the N=4000 reference-formulation CPU sample, digits8): minutes "
+                         "more; all of it goes to bench_extra.json, the stdout line stays compact")
+    ap.add_argument("--extra-out", default=os.path.join(ROOT, "bench_extra.json"), metavar="PATH",
+                    help="where the full report (every leg, every kernel tag) is written; the ONE stdout line holds "
+                         "the contract's keys only and stays below 4 KB")
     ap.add_argument("--cpu-n", type=int, default=4000)
     ap.add_argument("--cpu-n-thin", type=int, default=0,
                     help="also time the oracle's thin-form EP at this N on the host (one economy SVD: ~40 s at 8000); 0 = skip")
@@ -263,7 +270,7 @@ def _timed(ctx, fn, reps):
     return e0.elapsed_ms(e1) / reps
 
 
-def denoiser_roofline(T, ctx, dtype):
+def denoiser_roofline(T, ctx, dtype, shapes=((1, 1_000_000), (64, 1_000_000), (4096, 4096)), fused=True):
     """Gauss-Bernoulli denoiser (K1) at the BASELINE vector size N = 1e6.  Algorithmic traffic 2T bytes per
     component (read the message, write the new one).
       B64            64 instances (512 MB per array, past the 256 MB Infinity Cache), the form EP runs: the
@@ -279,7 +286,7 @@ def denoiser_roofline(T, ctx, dtype):
     out = {}
     np_dt = np.float64 if dtype == "f64" else np.float32
     esz = np.dtype(np_dt).itemsize
-    for B, N in ((1, 1_000_000), (64, 1_000_000), (4096, 4096)):
+    for B, N in shapes:
         bx = ctx.randn((B, N), np_dt, seed=3, scale=1.5)
         ax = ctx.scalars(1.3, B)
         p = T.GaussBernoulliPrior(size=N, rho=0.05, dtype=np_dt, ctx=ctx)
@@ -302,11 +309,10 @@ def denoiser_roofline(T, ctx, dtype):
                              if resident else "moments pass + update pass (3T moved)") if B == 64 else
                             ("single launch, instance in registers" if B == 4096 else "two launches, cache resident")}
         del bx, b_new
-    # the fused form, measured on the pair (producer, prior) that EP runs at N = 1e6
-    try:
-        out["B64"] = fused_updates_n1e6(T, ctx, dtype, only=("gb_prior",))["gb_prior"]
-    except Exception as e:                                                    # noqa: BLE001
-        out["B64"] = {"error": repr(e)}
+    if fused:
+        # the producer-fused form (csrc/prior_hint.h), measured on the pair (producer, prior); since round 4 the
+        # standalone resident pipeline is what EP runs at this shape, the pair is a --full comparison
+        out["B64_fused_pair"] = fused_updates_n1e6(T, ctx, dtype, only=("gb_prior",))["gb_prior"]
     return out
 
 
@@ -359,7 +365,10 @@ def fused_updates_n1e6(T, ctx, dtype, only=None):
         return arm, prod, cons, 2
 
     def lik_case(lk):
-        kind, yd = lk.lik_hint(B, N)
+        h = lk.lik_hint(B, N)
+        if h is None:                      # the packed resident update covers this shape: no producer-fused form exists
+            return None
+        kind, yd = h
         arm = lambda: ctx._call("tramp_lik_hint", kind, N, B, b_msg.ptr, a_msg.ptr, yd.ptr)               # noqa: E731
         prod = lambda: ch.compute_forward_message(az, bz, ax, bx, out_a=a_msg, out_b=b_msg)               # noqa: E731
         cons = lambda: lk.compute_backward_message(a_msg, b_msg, out_a=a_new, out_b=b_new)                # noqa: E731
@@ -372,7 +381,12 @@ def fused_updates_n1e6(T, ctx, dtype, only=None):
         if only and name not in only:
             continue
         try:
-            arm, prod, cons, nT = mk()
+            case = mk()
+            if case is None:
+                out[name] = {"skipped": "no producer-fused form at this shape: the resident single-pass update runs "
+                                        "(see factor_updates_n1e6)"}
+                continue
+            arm, prod, cons, nT = case
 
             def plain():                 # a hint left armed by an earlier call would be honoured again: clear it
                 ctx._call("tramp_prior_hint", 0, 0.0, 0.0, 0.0, 0, 0, None, None)
@@ -409,8 +423,11 @@ def fused_updates_n1e6(T, ctx, dtype, only=None):
                          "standalone_frac_of_hbm_peak": alg / ms_alone / 1e6 / HBM_PEAK_GBS,
                          "components_per_sec": N * B / (tot * 1e-3),
                          "fused_updates": int(used1 - used0), "producers_armed": int(armed1 - armed0),
-                         "form": "producer-fused moments (ConvChannel inverse-FFT epilogue) + ONE update pass "
-                                 f"({nT}T moved by the update; a likelihood's producer reads y once more)"}
+                         "form": ("producer-fused moments (ConvChannel inverse-FFT epilogue) + ONE update pass "
+                                  f"({nT}T moved by the update; a likelihood's producer reads y once more)")
+                                 if used1 > used0 else
+                                 "hint armed but NOT taken (fused_updates = 0): the consumer ran its standalone form; "
+                                 "us_per_update is that form plus the producer's extra time"}
         except Exception as e:                                                # noqa: BLE001
             out[name] = {"error": repr(e)}
     return out
@@ -422,7 +439,7 @@ VALU_PER_COMPONENT_F64 = {"l1_prior": 33 + 28, "sgn_lik": 81 + 11, "abs_lik": 63
                           "relu_fwd": 167 + 11, "sgn_bwd": 202 + 11, "abs_bwd": 182 + 11}
 
 
-def factor_updates_n1e6(T, ctx, dtype):
+def factor_updates_n1e6(T, ctx, dtype, only=None):
     """The other componentwise factor updates of the hot path at the BASELINE vector size, 64 x 1e6: L1 prior
     (K2, 2T algorithmic bytes per component), sign / abs likelihoods (K4 / K5, 3T), Relu / Sgn / Abs channels
     (K7, 3T).  K4 and K7 are f64-VALU-bound (erfcx, exp, reciprocals per component): besides the fraction of
@@ -433,28 +450,36 @@ def factor_updates_n1e6(T, ctx, dtype):
     B, N = 64, 1_000_000
     bz = ctx.randn((B, N), np_dt, seed=1, scale=1.5)
     bx = ctx.randn((B, N), np_dt, seed=2, scale=1.5)
-    y = ctx.array(np.sign(np.random.RandomState(0).standard_normal((B, N))).astype(np_dt), np_dt)
     az, ax = ctx.scalars(1.3, B), ctx.scalars(0.7, B)
     kw = dict(out_a=ctx.empty((B,), np.float64), out_b=ctx.empty((B, N), np_dt))
-    l1 = T.MAP_L1NormPrior(size=N, gamma=1.0, dtype=np_dt, ctx=ctx)
-    sg = T.SgnLikelihood(y=y, dtype=np_dt, ctx=ctx)
-    ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
+    want = lambda *names: only is None or any(n in only for n in names)          # noqa: E731
+    cases = []
+    if want("l1_prior"):
+        l1 = T.MAP_L1NormPrior(size=N, gamma=1.0, dtype=np_dt, ctx=ctx)
+        cases.append(("l1_prior", "K2", 2, lambda: l1.compute_forward_message(ax, bx, **kw)))
+    if want("binary_prior"):
+        bp = T.BinaryPrior(size=N, p_pos=0.3, dtype=np_dt, ctx=ctx)
+        cases.append(("binary_prior", "binary", 2, lambda: bp.compute_forward_message(ax, bx, **kw)))
+    if want("relu_lik"):
+        yr = ctx.array(np.maximum(np.random.RandomState(1).standard_normal((B, N)), 0.0).astype(np_dt), np_dt)
+        rl = T.ReluLikelihood(y=yr, dtype=np_dt, ctx=ctx)
+        cases.append(("relu_lik", "relu likelihood", 3, lambda: rl.compute_backward_message(az, bz, **kw)))
+    if want("sgn_lik", "abs_lik"):
+        y = ctx.array(np.sign(np.random.RandomState(0).standard_normal((B, N))).astype(np_dt), np_dt)
+        sg = T.SgnLikelihood(y=y, dtype=np_dt, ctx=ctx)
+        ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
+        cases.append(("sgn_lik", "K4", 3, lambda: sg.compute_backward_message(az, bz, **kw)))
+        cases.append(("abs_lik", "K5", 3, lambda: ab.compute_backward_message(az, bz, **kw)))
     relu, sgn, abs_ = (T.ReluChannel(dtype=np_dt, ctx=ctx), T.SgnChannel(dtype=np_dt, ctx=ctx),
                        T.AbsChannel(dtype=np_dt, ctx=ctx))
-    bp = T.BinaryPrior(size=N, p_pos=0.3, dtype=np_dt, ctx=ctx)
-    yr = ctx.array(np.maximum(np.random.RandomState(1).standard_normal((B, N)), 0.0).astype(np_dt), np_dt)
-    rl = T.ReluLikelihood(y=yr, dtype=np_dt, ctx=ctx)
-    cases = [("l1_prior", "K2", 2, lambda: l1.compute_forward_message(ax, bx, **kw)),
-             ("binary_prior", "binary", 2, lambda: bp.compute_forward_message(ax, bx, **kw)),
-             ("relu_lik", "relu likelihood", 3, lambda: rl.compute_backward_message(az, bz, **kw)),
-             ("sgn_lik", "K4", 3, lambda: sg.compute_backward_message(az, bz, **kw)),
-             ("abs_lik", "K5", 3, lambda: ab.compute_backward_message(az, bz, **kw)),
-             ("relu_bwd", "K7", 3, lambda: relu.compute_backward_message(az, bz, ax, bx, **kw)),
-             ("relu_fwd", "K7", 3, lambda: relu.compute_forward_message(az, bz, ax, bx, **kw)),
-             ("sgn_bwd", "K7", 3, lambda: sgn.compute_backward_message(az, bz, ax, bx, **kw)),
-             ("abs_bwd", "K7", 3, lambda: abs_.compute_backward_message(az, bz, ax, bx, **kw))]
+    cases += [("relu_bwd", "K7", 3, lambda: relu.compute_backward_message(az, bz, ax, bx, **kw)),
+              ("relu_fwd", "K7", 3, lambda: relu.compute_forward_message(az, bz, ax, bx, **kw)),
+              ("sgn_bwd", "K7", 3, lambda: sgn.compute_backward_message(az, bz, ax, bx, **kw)),
+              ("abs_bwd", "K7", 3, lambda: abs_.compute_backward_message(az, bz, ax, bx, **kw))]
     out = {"n": N, "batch": B}
     for name, kern, nT, fn in cases:
+        if only and name not in only:
+            continue
         runs0 = ctx.resident_runs()
         ms = float(np.median(_event_samples(ctx, [fn], 12)[0]))
         resident = ctx.resident_runs() > runs0
@@ -743,7 +768,7 @@ def whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, lin_factors, args, np_dt, t
     return res
 
 
-def digit_engine(T, ctx, ep, lin, X, args, N, B):
+def digit_engine(T, ctx, ep, lin, X, args, N, B, digit_counts=(7, 8), with_pass_errors=True):
     """The same EP loop with the dense passes on the int8 matrix cores (LinearChannel.attach_digits, csrc/gemm_sliced.h):
     an OPT-IN engine, reported beside the headline and never as it.  For each digit count: the time of K steps (as the
     headline times them), the passes' average launch, and how far the estimate after K steps from zero messages is from
@@ -767,7 +792,7 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
         err = {}
         ctx._call("tramp_matvec_nt", dt, 2, k_rows, n_cols, B, Vt.ptr, x.ptr, out.ptr)
         err["f64_matrix_cores"] = float(np.max(np.abs(out.get()[:, rows] - exact)))
-        for dg in (7, 8):
+        for dg in digit_counts:
             ctx.attach_digits(Vt, dg, 1)
             ctx._call("tramp_matvec_nt", dt, 3, k_rows, n_cols, B, Vt.ptr, x.ptr, out.ptr)
             err[f"digits{dg}"] = float(np.max(np.abs(out.get()[:, rows] - exact)))
@@ -781,7 +806,7 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
     res = {"note": "opt-in engine: both operands of the dense passes in signed radix-256 digits, exact int32 accumulation on "
                    "v_mfma_i32_16x16x64_i8 (7 digits = 54 bits per operand, 8 = 62); the headline above is the f64 "
                    "matrix-core engine"}
-    for digits in (7, 8):
+    for digits in digit_counts:
         ctx.sync()
         t0 = time.perf_counter()
         lin.attach_digits(digits, uk=not (ep._lin_masks().get(lin, 0) & 1))      # output side rotated: Uk is not in the loop
@@ -827,10 +852,8 @@ def digit_engine(T, ctx, ep, lin, X, args, N, B):
                                   "mse_after_run": mse}
         if to_rule is not None:
             res[f"digits{digits}"]["to_stopping_rule"] = to_rule
-    try:
+    if with_pass_errors:
         res["row_dot_pass_error_vs_long_double"] = pass_errors()
-    except Exception as e:                                                    # noqa: BLE001
-        res["row_dot_pass_error_vs_long_double"] = {"error": repr(e)}
     return res
 
 
@@ -1140,12 +1163,11 @@ def run(args):
             "value": total_units / elapsed, "unit": "msg-components/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "sparse-GLM EP ensemble: GaussBernoulliPrior(rho=%g) + dense LinearChannel "
-                                   "(Gaussian ensemble W shared by the instances) + GaussianLikelihood(var=%g), "
-                                   "damping %g, NaN guard and stopping-rule readback every %d iteration(s); BASELINE "
-                                   "configs[3]'s per-GPU shard (64 x N=1e5); configs[1] as written (dense W at "
-                                   "N=1e6, 4 TB) cannot exist" % (args.rho, args.noise_var, args.damping,
-                                                                    args.check_every),
+            "config": {"workload": "sparse-GLM EP: GaussBernoulliPrior(rho=%g) + dense LinearChannel (Gaussian ensemble W "
+                                   "shared by the instances) + GaussianLikelihood(var=%g), damping %g, stopping-rule "
+                                   "readback every %d iteration(s); BASELINE configs[3] per-GPU shard (64 x N=1e5; "
+                                   "configs[1]'s dense W at N=1e6 is 4 TB)" % (args.rho, args.noise_var, args.damping,
+                                                                                  args.check_every),
                        "N": N, "M": M, "alpha": args.alpha, "instances_per_gpu": B,
                        "fallback_from": getattr(args, "fallback_from", None),
                        "instances_total": B * world, "parallelism": f"ensemble-shard x{world}",
@@ -1171,103 +1193,116 @@ def run(args):
             "v_after_run": float(np.mean(v_inst)),
             "device": ctx.device_name(),
         }
-        if world == 1 and not args.no_tts:
+        legs = []                # (key, thunk) of every auxiliary leg, in run order; each is timed and isolated
+
+        def leg(key, fn, cond=True):
+            if cond:
+                legs.append((key, fn))
+
+        def tts():
             # time to solution as the reference publishes it (setup INCLUDED): the headline ensemble from the zero
             # initial messages to EarlyStoppingEP(tol=1e-6) on every instance, plus configs[0] at N = 1000
-            try:
-                ctx.sync()
-                t0 = time.perf_counter()
-                ep.iterate(max_iter=1000, callback=T.EarlyStoppingEP(tol=1e-6), damping=args.damping,
-                           check_every=args.check_every)
-                ctx.sync()
-                it_s = time.perf_counter() - t0
-                mse_c = np.atleast_1d(ep.mse("x", X))
-                out["time_to_solution"] = {
-                    "headline": {"factorize_s": factorize_s, "iterate_s": it_s, "total_s": factorize_s + it_s,
+            ctx.sync()
+            t0 = time.perf_counter()
+            ep.iterate(max_iter=1000, callback=T.EarlyStoppingEP(tol=1e-6), damping=args.damping,
+                       check_every=args.check_every)
+            ctx.sync()
+            it_s = time.perf_counter() - t0
+            mse_c = np.atleast_1d(ep.mse("x", X))
+            return {"headline": {"factorize_s": factorize_s, "iterate_s": it_s, "total_s": factorize_s + it_s,
                                  "n_iter": int(ep.n_iter),
                                  "n_iter_per_instance": [int(ep.n_iter_instance.min()), int(ep.n_iter_instance.max())],
                                  "n_iter_of_each_instance": ep.n_iter_instance.tolist(),
                                  "status_counts": np.bincount(ep.status, minlength=3).tolist(),
                                  "mse": float(np.mean(mse_c)),
-                                 "rule": "EarlyStoppingEP(tol=1e-6) per instance on the device (csrc/monitor.hip)"}}
-                out["time_to_solution"]["n1000"] = time_to_solution_n1000(T, ctx, args)
-            except Exception as e:                                            # noqa: BLE001
-                out.setdefault("time_to_solution", {})["error"] = repr(e)
-        if world == 1 and not args.no_digits and args.dtype == "f64" and B > 2:
-            try:
-                out["int8_digit_engine"] = digit_engine(T, ctx, ep, lin, X, args, N, B)
-            except Exception as e:                                            # noqa: BLE001
-                out["int8_digit_engine"] = {"error": repr(e)}
-        if world == 1 and not args.no_denoiser:
-            # the vector-kernel figures are separate measurements: let the package come back from the 1300 W of the
-            # timed dense loop first (the Gauss-Bernoulli update itself runs at the power limit)
+                                 "rule": "EarlyStoppingEP(tol=1e-6) per instance on the device (csrc/monitor.hip)"},
+                    "n1000": time_to_solution_n1000(T, ctx, args)}
+
+        def quick_vector_kernels():
+            # the two vector-kernel figures of the compact line at BASELINE's vector size, 64 x 1e6: the Gauss-Bernoulli
+            # denoiser (K1, f64) and the Relu channel's backward update (K7, both dtypes).  Separate measurements: let
+            # the package come back from the 1300 W of the timed dense loop first
             ctx.sync()
             time.sleep(3.0)
-            out["denoiser_n1e6"] = denoiser_roofline(T, ctx, args.dtype)
-            try:
-                out["fused_updates_n1e6"] = fused_updates_n1e6(T, ctx, args.dtype,
-                                                               only=("l1_prior", "sgn_lik", "abs_lik"))
-                out["fused_updates_n1e6"]["gb_prior"] = out["denoiser_n1e6"].get("B64")
-            except Exception as e:                                            # noqa: BLE001
-                out["fused_updates_n1e6"] = {"error": repr(e)}
-            try:
-                out["factor_updates_n1e6"] = factor_updates_n1e6(T, ctx, args.dtype)
-            except Exception as e:                                            # noqa: BLE001
-                out["factor_updates_n1e6"] = {"error": repr(e)}
+            r = {"denoiser_n1e6": denoiser_roofline(T, ctx, "f64", shapes=((64, 1_000_000), (1, 1_000_000)), fused=False)}
+            for dn in ("f64", "f32"):
+                r["factor_updates_n1e6" + ("" if dn == "f64" else "_f32")] = factor_updates_n1e6(T, ctx, dn, only=("relu_bwd",))
+            return r
+
+        def full_vector_kernels():
+            ctx.sync()
+            time.sleep(3.0)
+            r = {"denoiser_n1e6": denoiser_roofline(T, ctx, args.dtype)}
+            r["fused_updates_n1e6"] = fused_updates_n1e6(T, ctx, args.dtype, only=("l1_prior",))
+            r["factor_updates_n1e6"] = factor_updates_n1e6(T, ctx, args.dtype)
             if args.dtype == "f64":
                 # BASELINE configs[2] (1-bit CS at N = 1e6) is an fp32 configuration: the same kernels on f32 messages
                 # (half the bytes: the 64-instance working set is 2 x 256 MB, i.e. partly Infinity-Cache resident)
-                try:
-                    out["denoiser_n1e6_f32"] = denoiser_roofline(T, ctx, "f32")
-                    out["fused_updates_n1e6_f32"] = fused_updates_n1e6(T, ctx, "f32",
-                                                                       only=("l1_prior", "sgn_lik", "abs_lik"))
-                    out["factor_updates_n1e6_f32"] = factor_updates_n1e6(T, ctx, "f32")
-                except Exception as e:                                        # noqa: BLE001
-                    out["denoiser_n1e6_f32"] = {"error": repr(e)}
-            try:
-                out["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
-            except Exception as e:                                            # noqa: BLE001
-                out["structured_n1e6"] = {"error": repr(e)}
-            try:
-                out["structured_2d"] = structured_2d(T, ctx, args.dtype)
-            except Exception as e:                                            # noqa: BLE001
-                out["structured_2d"] = {"error": repr(e)}
-        if world == 1 and not args.no_denoiser and not args.load_factors:
-            try:
-                ep = model = None                                             # noqa: F841
-                out["ensemble_x8_one_gpu"] = whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, (Uk, sing, Vt), args, np_dt,
-                                                                       8 * B, with_digits=not args.no_digits and args.dtype == "f64")
-            except Exception as e:                                            # noqa: BLE001
-                out["ensemble_x8_one_gpu"] = {"error": repr(e)}
-        if world == 1 and not args.no_se:
-            try:
-                out["state_evolution"] = se_measure(T, ctx, with_oracle=not args.no_cpu_baseline)
-            except Exception as e:                                            # noqa: BLE001
-                out["state_evolution"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+                r["denoiser_n1e6_f32"] = denoiser_roofline(T, ctx, "f32")
+                r["factor_updates_n1e6_f32"] = factor_updates_n1e6(T, ctx, "f32")
+            r["structured_n1e6"] = structured_n1e6(T, ctx, args.dtype)
+            r["structured_2d"] = structured_2d(T, ctx, args.dtype)
+            return r
+
+        single = world == 1
+        leg("time_to_solution", tts, single and not args.no_tts)
+        leg("int8_digit_engine",
+            lambda: digit_engine(T, ctx, ep, lin, X, args, N, B, digit_counts=(7, 8) if args.full else (7,),
+                                 with_pass_errors=args.full),
+            single and not args.no_digits and args.dtype == "f64" and B > 2)
+        leg("*vector_kernels", full_vector_kernels if args.full else quick_vector_kernels, single and not args.no_denoiser)
+        leg("state_evolution", lambda: se_measure(T, ctx, with_oracle=not args.no_cpu_baseline), single and not args.no_se)
+
+        def cpu_leg():
+            lfl = cpu_like_for_like((Uk, sing, Vt, lin_rank), Y, args, iters=3 if args.full else 1)
+            if "value" in lfl and not args.full:
+                return lfl
+            # the reference formulation (full SVD, one instance, N = 4000): --full, or when the host cannot hold the factors
             small = cpu_baseline(args)
-            try:
-                lfl = cpu_like_for_like((Uk, sing, Vt, lin_rank), Y, args)
-            except Exception as e:                                            # noqa: BLE001
-                lfl = {"error": repr(e)}
             if "value" in lfl:
-                # the baseline of THIS workload on top: the headline shape, factors and observations on the host cores
-                # (VERDICT r3 weak 5); the reference formulation at N = 4000 one level down
-                out["cpu_baseline"] = dict(lfl, reference_formulation_single_instance=small, like_for_like=lfl)
-            else:
-                out["cpu_baseline"] = dict(small, like_for_like=lfl)
-        if world == 1 and not args.no_configs:
-            # BASELINE configs[2] and configs[4] as EP runs (the headline's factors are released first)
-            import gc
-            ep = model = lin = Uk = Vt = None             # noqa: F841  (60 GB of factors and the message buffers go)
-            gc.collect()
-            for key, which, n_cfg in (("config2_cs1bit", "cs1bit", args.cs1bit_n), ("config4_twolayer", "twolayer", args.twolayer_n)):
-                try:
-                    out[key] = other_config(T, ctx, which, n_cfg, 64, np.float32, with_digits=not args.no_digits)
-                except Exception as e:                                        # noqa: BLE001
-                    out[key] = {"error": repr(e)}
+                return dict(lfl, reference_formulation_single_instance=small)
+            return dict(small, like_for_like=lfl)
+        leg("cpu_baseline", cpu_leg, single and not args.no_cpu_baseline)
+
+        def x8():
+            nonlocal ep, model
+            ep = model = None
+            return whole_ensemble_on_one_gpu(T, ctx, ensemble, lin, (Uk, sing, Vt), args, np_dt, 8 * B,
+                                             with_digits=not args.no_digits and args.dtype == "f64")
+        leg("ensemble_x8_one_gpu", x8, single and args.full and not args.no_denoiser and not args.load_factors)
+
+        def cfg(which, n_cfg):
+            def go():
+                # BASELINE configs[2] and configs[4] as EP runs (the headline's factors are released first)
+                nonlocal ep, model, lin, Uk, Vt
+                import gc
+                ep = model = lin = Uk = Vt = None             # (60 GB of factors and the message buffers go)
                 gc.collect()
-        emit_result(out)
+                try:
+                    return other_config(T, ctx, which, n_cfg, 64, np.float32, with_digits=args.full and not args.no_digits)
+                finally:
+                    gc.collect()
+            return go
+        leg("config2_cs1bit", cfg("cs1bit", args.cs1bit_n), single and not args.no_configs)
+        leg("config4_twolayer", cfg("twolayer", args.twolayer_n), single and not args.no_configs)
+
+        out["leg_seconds"] = {}
+        for key, fn in legs:
+            t_leg = time.perf_counter()
+            try:
+                res = fn()
+            except Exception as e:                                            # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                res = {"error": repr(e)}
+                if key.startswith("*"):
+                    res = {key[1:]: res}
+            if key.startswith("*"):
+                out.update(res)
+            else:
+                out[key] = res
+            out["leg_seconds"][key.lstrip("*")] = round(time.perf_counter() - t_leg, 2)
+        emit_result(out, args)
     if comm is not None:
         # the line is out: a peer that died after the timed region must not turn a finished measurement into a
         # hang or a failure of rank 0
@@ -1292,13 +1327,118 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
-def emit_result(out):
-    line = (json.dumps(out) + "\n").encode()
+def _sig(x, digits=6):
+    "numbers of the compact line: 6 significant digits"
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _dig(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+LINE_LIMIT = 4096
+
+
+def _error_paths(d, path=""):
+    "every leg (sub-dict, any depth) of the report that carries an 'error' key"
+    found = []
+    if isinstance(d, dict):
+        if "error" in d:
+            found.append(path)
+        for k, v in d.items():
+            found += _error_paths(v, f"{path}.{k}" if path else str(k))
+    return found
+
+
+def compact_line(out, extra_path):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline` and a handful of scalars for the other
+    configs, strict JSON below 4 KB (the driver reads an 8 KB tail: the 27 KB line of round 4 was cut).  Everything
+    else lives in the full report (`extra`)."""
+    cfg = out["config"]
+    roof = out["roofline"]
+    line = {k: _sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg["workload"][:300], "N": cfg["N"], "M": cfg["M"], "alpha": cfg["alpha"],
+                      "instances_per_gpu": cfg["instances_per_gpu"], "instances_total": cfg["instances_total"],
+                      "parallelism": cfg["parallelism"], "collectives": cfg["collectives"][:160],
+                      "fallback_from": cfg["fallback_from"]}
+    line["roofline"] = {k: _sig(roof.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                       "avg_launch_ms", "launches")}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict) and "value" in cb:
+        line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"][:400]}
+    elif cb is not None:
+        line["cpu_baseline"] = {"value": None, "error": str(_dig(cb, "error", default=cb))[:200]}
+    line["setup_s"] = _sig(_dig(out, "setup", "total_s"))
+    line["factorize_s"] = _sig(_dig(out, "setup", "factorize_s"))
+    line["factor_residual_max"] = _sig(_dig(out, "setup", "factor_residuals", "max"))
+    line["mse_after_run"] = _sig(out.get("mse_after_run"))
+    line["env_overrides"] = out.get("env_overrides")
+    line["device"] = out.get("device")
+    # at most five scalars for the other configs and kernels
+    line["config2_cs1bit_ms"] = _sig(_dig(out, "config2_cs1bit", "ms_per_iteration"))
+    line["config4_twolayer_ms"] = _sig(_dig(out, "config4_twolayer", "ms_per_iteration"))
+    line["int8_digits7_ms"] = _sig(_dig(out, "int8_digit_engine", "digits7", "ms_per_step"))
+    line["denoiser_gb_f64_frac"] = _sig(_dig(out, "denoiser_n1e6", "B64_standalone", "frac_of_hbm_peak"))
+    line["k7_relu_bwd_frac"] = {"f64": _sig(_dig(out, "factor_updates_n1e6", "relu_bwd", "frac_of_hbm_peak")),
+                                "f32": _sig(_dig(out, "factor_updates_n1e6_f32", "relu_bwd", "frac_of_hbm_peak"))}
+    errs = _error_paths(out)
+    if errs:
+        line["legs_with_errors"] = errs[:8]
+    line["extra"] = os.path.basename(extra_path) if extra_path else None
+    return line
+
+
+def _jsonable(x):
+    "strict JSON: NaN / inf become null, NumPy scalars and arrays their Python values"
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return _jsonable(x.tolist())
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        return x if np.isfinite(x) else None
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    return x
+
+
+def emit_result(out, args=None):
+    """stdout: the compact line (compact_line).  The full report - every leg, every kernel tag - goes to
+    `--extra-out` (bench_extra.json beside bench.py; also gpurun_out/ when that directory exists) and to stderr."""
+    extra_path = getattr(args, "extra_out", None)
+    out = _jsonable(out)
+    full = json.dumps(out, allow_nan=False, default=str)
+    for path in filter(None, (extra_path, os.path.join(ROOT, "gpurun_out", "bench_extra.json")
+                              if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)):
+        try:
+            with open(path, "w") as f:
+                f.write(full + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    print("bench.py: full report: " + full, file=sys.stderr)
+    line = compact_line(out, extra_path)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:                       # cannot happen with the fields above; never print a cut line
+        for k in ("env_overrides", "device", "legs_with_errors"):
+            line.pop(k, None)
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:120]
+        line["config"]["workload"] = line["config"]["workload"][:120]
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    data = (text + "\n").encode()
     sys.stdout.flush()
-    if _RESULT_FD is None:
-        os.write(1, line)
-    else:
-        os.write(_RESULT_FD, line)
+    os.write(1 if _RESULT_FD is None else _RESULT_FD, data)
 
 
 def main():

@@ -210,3 +210,24 @@ def test_every_environment_switch_is_in_the_one_table():
     assert switches.overrides({"TRAMP_EW_RESIDENT": "0", "HOME": "/x", "TRAMP_UNKNOWN": "1"}) == {"TRAMP_EW_RESIDENT": "0"}
     assert all(kind in ("select", "tune", "debug") for _, kind, _ in switches.SWITCHES.values())
     assert switches.markdown_table().count("\n") == len(switches.SWITCHES) + 1
+
+
+def test_bench_compact_line_from_a_full_report():
+    """bench.py's stdout line built from round 4's 27 KB report (the one the driver could not parse): below 4 KB,
+    strict JSON, carries value / roofline / cpu_baseline and the scalars of the other configs."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_default_N100000_final_library_run4.json")))
+    full["mse_after_run"] = float("nan")                       # a NaN in a leg must not produce a non-strict line
+    line = bench.compact_line(bench._jsonable(full), "bench_extra.json")
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) < bench.LINE_LIMIT
+    back = json.loads(text)
+    assert back["value"] > 1e8 and 0.5 < back["roofline"]["frac"] < 1 and back["roofline"]["bound"] == "mfma"
+    assert back["cpu_baseline"]["value"] > 0 and back["cpu_baseline"]["kind"] == "port" and back["cpu_baseline"]["cores"] == 64
+    assert back["config2_cs1bit_ms"] > 0 and back["config4_twolayer_ms"] > 0 and back["int8_digits7_ms"] > 0
+    assert back["mse_after_run"] is None and len(back["config"]["workload"]) <= 300
+    assert "fused_updates_n1e6.sgn_lik" in back["legs_with_errors"]     # round 4's stale leg is named, not hidden

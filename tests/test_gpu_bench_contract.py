@@ -13,22 +13,58 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline")
+LINE_LIMIT = 4096          # the driver reads an 8 KB tail of stdout; round 4's 27 KB line was cut and went unparsed
+
+
+def strict_line(stdout):
+    "exactly one line, strict JSON (no NaN / Infinity literals), below the limit"
+    lines = stdout.splitlines()
+    assert len(lines) == 1, stdout[:2000]
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
+
+    def no_constants(name):
+        raise AssertionError(f"non-strict JSON constant {name} in the bench line")
+    return json.loads(lines[0], parse_constant=no_constants)
+
+
+def error_paths(d, path=""):
+    "every sub-dict that carries an 'error' key"
+    found = []
+    if isinstance(d, dict):
+        if "error" in d:
+            found.append(path or "/")
+        for k, v in d.items():
+            found += error_paths(v, f"{path}/{k}")
+    elif isinstance(d, list):
+        for i, v in enumerate(d):
+            found += error_paths(v, f"{path}[{i}]")
+    return found
 
 
 @pytest.mark.parametrize("force_dist", [False, True])
-def test_bench_prints_one_json_line(force_dist):
+def test_bench_prints_one_json_line(force_dist, tmp_path):
     env = dict(os.environ)
+    extra = str(tmp_path / "bench_extra.json")
     if force_dist:
         env["TRAMP_BENCH_FORCE_DIST"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2048", "--batch", "4", "--steps", "3",
                         "--warmup", "1", "--no-cpu-baseline", "--no-denoiser", "--no-se", "--cs1bit-n", "2048",
-                        "--twolayer-n", "2048"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--twolayer-n", "2048", "--full", "--extra-out", extra], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = r.stdout.splitlines()
-    assert len(lines) == 1, r.stdout[:2000]
-    d = json.loads(lines[0])
+    line = strict_line(r.stdout)
     for k in KEYS:
-        assert k in d, k
+        assert k in line, k
+    assert error_paths(line) == [] and "legs_with_errors" not in line, line
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["avg_launch_ms"] > 0 and line["roofline"]["launches"] > 0
+    assert len(line["config"]["workload"]) <= 300
+    assert line["config2_cs1bit_ms"] > 0 and line["config4_twolayer_ms"] > 0 and line["int8_digits7_ms"] > 0
+    assert line["factorize_s"] > 0 and line["factor_residual_max"] <= 1e-9
+    # the full report (every leg) is a file beside the line, strict JSON as well, and no leg in it failed
+    d = json.load(open(extra))
+    assert error_paths(d) == [], error_paths(d)
+    assert d["value"] == pytest.approx(line["value"], rel=1e-5) and d["ms_per_step"] == pytest.approx(line["ms_per_step"], rel=1e-5)
+    assert d["roofline"]["frac"] == pytest.approx(line["roofline"]["frac"], rel=1e-5)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["dtype"] == "f64"
     assert d["config"]["N"] == 2048 and d["config"]["instances_per_gpu"] == 4
     assert d["value"] > 0 and d["roofline"]["bound"] in ("hbm", "mfma")
@@ -68,6 +104,25 @@ def test_bench_prints_one_json_line(force_dist):
     assert dg["digits7"]["to_stopping_rule"]["n_iter_per_instance"] == tts["headline"]["n_iter_of_each_instance"]
 
 
+def test_default_legs_compact_line(tmp_path):
+    """The default (not --full) legs at a small size, CPU baseline included: the line carries `cpu_baseline` and the
+    five scalars, stays below the limit, and the vector-kernel legs report no error."""
+    extra = str(tmp_path / "x.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2048", "--batch", "4", "--steps", "3",
+                        "--warmup", "1", "--cs1bit-n", "2048", "--twolayer-n", "2048", "--extra-out", extra],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = strict_line(r.stdout)
+    assert error_paths(line) == [] and "legs_with_errors" not in line, line
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "msg-components/s"
+    assert 0 < line["denoiser_gb_f64_frac"] < 1 and 0 < line["k7_relu_bwd_frac"]["f64"] < 1 and 0 < line["k7_relu_bwd_frac"]["f32"] < 1
+    d = json.load(open(extra))
+    assert error_paths(d) == [], error_paths(d)
+    assert set(d["leg_seconds"]) >= {"time_to_solution", "int8_digit_engine", "vector_kernels", "state_evolution",
+                                     "cpu_baseline", "config2_cs1bit", "config4_twolayer"}
+
+
 def test_bench_refuses_wrong_factors():
     "a factorisation that does not reproduce W stops the run (exit code 3, no result line)"
     env = dict(os.environ, TRAMP_BENCH_CORRUPT_FACTORS="1")
@@ -100,9 +155,7 @@ def test_two_ranks_on_one_gpu_fall_back_to_sockets():
         pytest.skip("the two ranks did not finish within 240 s")
     assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
     assert outs[1][0] == ""                                  # rank 1 prints nothing on stdout
-    lines = outs[0][0].splitlines()
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = strict_line(outs[0][0])
     assert d["n_gpus"] == 2 and d["config"]["instances_total"] == 16
     assert "RCCL" in d["config"]["collectives"]
-    assert d["setup"]["factor_residuals"]["max"] <= 1e-9
+    assert d["factor_residual_max"] <= 1e-9
