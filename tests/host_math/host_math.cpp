@@ -37,6 +37,18 @@ static void pwl(size_t n, const T* bz, const T* bx, double az, double ax, T* r, 
     }
 }
 
+// fast: 0 literal region form, 1 pwl_posterior_fast on the uniform erfcx grid (UNI), 2 pwl_posterior_fast with the small table
+// (UNI = false: the form the resident pipeline instantiates)
+template <typename T, int KIND, bool FWD>
+static void pwl_any(size_t n, const T* bz, const T* bx, double az, double ax, T* r, T* v, uint8_t* mask, int fast) {
+    PwlConst<T> c = pwl_const<T, KIND>(az, ax);
+    for (size_t i = 0; i < n; ++i) {
+        PwlOut<T> o = fast == 0 ? pwl_posterior<T, KIND, FWD>(bz[i], bx[i], T(az), T(ax))
+                                : (fast == 1 ? pwl_posterior_fast<T, KIND, FWD, true>(bz[i], bx[i], c)
+                                             : pwl_posterior_fast<T, KIND, FWD, false>(bz[i], bx[i], c));
+        r[i] = o.r; v[i] = o.v; mask[i] = (uint8_t)o.mask;
+    }
+}
 extern "C" {
 void hm_gb_f64(size_t n, const double* bx, double ax, double rho, double mean, double var, double* r, double* v, int fast) { gb<double>(n, bx, ax, rho, mean, var, r, v, fast); }
 void hm_gb_f32(size_t n, const float* bx, double ax, double rho, double mean, double var, float* r, float* v, int fast) { gb<float>(n, bx, ax, rho, mean, var, r, v, fast); }
@@ -71,6 +83,19 @@ void hm_pwl_f64(int kind, int fwd, size_t n, const double* bz, const double* bx,
         case 5: pwl<double, 2, true>(n, bz, bx, az, ax, r, v, mask, fast); break;
     }
 }
+#define HM_PWL_ANY(NAME, T)                                                                                                   \
+    void NAME(int kind, int fwd, size_t n, const T* bz, const T* bx, double az, double ax, T* r, T* v, uint8_t* mask, int fast) { \
+        switch (kind * 2 + (fwd ? 1 : 0)) {                                                                                   \
+            case 0: pwl_any<T, 0, false>(n, bz, bx, az, ax, r, v, mask, fast); break;                                        \
+            case 1: pwl_any<T, 0, true>(n, bz, bx, az, ax, r, v, mask, fast); break;                                         \
+            case 2: pwl_any<T, 1, false>(n, bz, bx, az, ax, r, v, mask, fast); break;                                        \
+            case 3: pwl_any<T, 1, true>(n, bz, bx, az, ax, r, v, mask, fast); break;                                         \
+            case 4: pwl_any<T, 2, false>(n, bz, bx, az, ax, r, v, mask, fast); break;                                        \
+            case 5: pwl_any<T, 2, true>(n, bz, bx, az, ax, r, v, mask, fast); break;                                         \
+        }                                                                                                                     \
+    }
+HM_PWL_ANY(hm_pwl_any_f64, double)
+HM_PWL_ANY(hm_pwl_any_f32, float)
 void hm_pwl3_f64(int fwd, size_t n, const double* bz, const double* bx, double az, double ax, double zlo, double zhi,
                  const double* slopes3, const double* x03, double* r, double* v, uint8_t* mask) {
     Pwl3Spec sp{zlo, zhi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}};

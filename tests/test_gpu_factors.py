@@ -514,3 +514,24 @@ def test_large_properties_pwl_channels_full_size(T, ctx, dtype, kind):
             close(a3.get(), a1.get(), dtype)
             sign = -1.0 if (kind == "sgn" or d == "bwd") else 1.0
             close(b3.get(), sign * b1.get(), dtype, scale=10 * np.abs(b_ref).max())
+
+
+@pytest.mark.parametrize("kind", ["sgn", "abs", "relu"])
+def test_pwl_channels_non_finite_messages_give_nan(T, ctx, kind):
+    """A NaN or infinite component of either incoming message makes the reference's posterior NaN at that component, in
+    every channel and both directions (inf - inf in the region log-partitions, linear_region.py:55-64; checked on the
+    reference itself when this test was written), and hence a_new NaN.  Sgn forward used to return a finite r there (its
+    regions have slope 0 and never look at the truncated mean)."""
+    cls = dict(sgn=T.SgnChannel, abs=T.AbsChannel, relu=T.ReluChannel)
+    ch = cls[kind](ctx=ctx)
+    for which in ("bz", "bx"):
+        for val in (np.nan, np.inf, -np.inf):
+            bz = np.array([0.3, 0.5, -0.2, 1.0, -1.5, 0.7]); bx = np.array([0.1, 0.2, 0.3, -0.4, 0.5, -0.6])
+            (bz if which == "bz" else bx)[1] = val
+            for post, msg in ((ch.compute_forward_posterior, ch.compute_forward_message),
+                              (ch.compute_backward_posterior, ch.compute_backward_message)):
+                r, v = post(1.3, bz, 0.7, bx)
+                r = np.ravel(r)
+                assert np.isnan(r[1]) and np.all(np.isfinite(np.delete(r, 1))) and np.isnan(v), (kind, which, val, r, v)
+                a_new, _ = msg(1.3, bz, 0.7, bx)
+                assert np.isnan(a_new)

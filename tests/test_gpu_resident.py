@@ -285,3 +285,111 @@ def test_resident_pipeline_on_seeded_random_shapes_around_its_limits(T, ctx, dty
             close_a(a_new[i], a_ref, ax[i], dtype)
             close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())
     assert took[True] >= 2 and took[False] >= 2, took
+
+
+# ---- the two-region channels K7 on the pipeline (round 5: moment form + one-value erfcx table, csrc/ew_resident_pwl.hip)
+PWL_CLS = dict(sgn="SgnChannel", abs="AbsChannel", relu="ReluChannel")
+
+
+def pwl_reference(kind, direction, az, bz, ax, bx):
+    out_a, out_b = [], []
+    for i in range(len(az)):
+        with np.errstate(all="ignore"):
+            an, bn = orc.pwl_channel_message(kind, direction, az[i], bz[i].astype(np.float64), ax[i], bx[i].astype(np.float64))
+        out_a.append(an); out_b.append(bn)
+    return np.array(out_a), np.stack(out_b)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind", ["sgn", "abs", "relu"])
+def test_pwl_channels_resident_vs_oracle(T, ctx, kind, dtype):
+    """Both directions of Sgn / Abs / Relu on the resident pipeline (piecewise_linear_channel.py:27-53 through
+    channels/base_channel.py:9-17), per-instance precisions, the same shapes twice with different data; the resident form
+    must actually run, and agree with the tile kernels (TRAMP_EW_RESIDENT_K7=0 is what every other K7 test covers)."""
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(21)
+    ch = getattr(T, PWL_CLS[kind])(dtype=dtype, ctx=ctx)
+    a_dev = ctx.empty((B,), np.float64); b_dev = ctx.empty((B, n), dtype)
+    for trial in range(2):
+        az, ax = rs.uniform(0.5, 3.0, B), rs.uniform(0.3, 2.0, B)
+        bz = (rs.standard_normal((B, n)) * rs.uniform(0.5, 2.0, (B, 1))).astype(dtype)
+        bx = (rs.standard_normal((B, n)) * rs.uniform(0.5, 2.0, (B, 1))).astype(dtype)
+        for direction, fn, a_in, tgt in (("fwd", ch.compute_forward_message, ax, bx), ("bwd", ch.compute_backward_message, az, bz)):
+            runs0 = ctx.resident_runs()
+            fn(ctx.scalars(az), ctx.array(bz, dtype), ctx.scalars(ax), ctx.array(bx, dtype), out_a=a_dev, out_b=b_dev)
+            assert ctx.resident_runs() == runs0 + 1, "the resident single-pass form did not run"
+            a_ref, b_ref = pwl_reference(kind, direction, az, bz, ax, bx)
+            a_new, b_new = a_dev.get(), b_dev.get()
+            for i in range(B):
+                close_a(a_new[i], a_ref[i], a_in[i], dtype)
+                # b_new = r (a_in + a_new) - b: conditioned on |r| (a_in + a_new) and |b|
+                sc = 10 * max(np.abs(b_ref[i]).max(), np.abs(tgt[i]).max().astype(np.float64))
+                close(b_new[i], b_ref[i], dtype, scale=sc)
+
+
+@pytest.mark.parametrize("kind", ["sgn", "abs", "relu"])
+def test_pwl_resident_flagged_instances_are_redone(T, ctx, kind):
+    """A component outside the moment form's domain (an erfcx argument below -5 or above 8, a message within 2 % of the
+    reference's log_Phi mask threshold, an infinity, a NaN) flags its instance; the redo kernel runs that instance again
+    on the region-by-region form.  The flagged instances must equal what the tile kernels give (same evaluation), the
+    others the oracle; a NaN stays in its own instance."""
+    dtype = np.float64
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(3)
+    az, ax = rs.uniform(0.8, 2.0, B), rs.uniform(0.5, 1.5, B)
+    bz = rs.standard_normal((B, n)); bx = rs.standard_normal((B, n))
+    flagged = {2: (5, 14.0), 7: (n - 3, -11.0), B - 3: (100, 29.8 * np.sqrt(az[B - 3])), B - 1: (9, np.nan), 11: (n // 2, np.inf)}
+    for i, (j, val) in flagged.items():
+        bz[i, j] = val
+    ch = getattr(T, PWL_CLS[kind])(ctx=ctx)
+    for direction, fn in (("fwd", ch.compute_forward_message), ("bwd", ch.compute_backward_message)):
+        a_dev = ctx.empty((B,), np.float64); b_dev = ctx.empty((B, n), dtype)
+        runs0 = ctx.resident_runs()
+        fn(ctx.scalars(az), ctx.array(bz, dtype), ctx.scalars(ax), ctx.array(bx, dtype), out_a=a_dev, out_b=b_dev)
+        assert ctx.resident_runs() == runs0 + 1
+        a_res, b_res = a_dev.get().copy(), b_dev.get().copy()
+        # the tile kernels on the same data: instance by instance below the pipeline's window (a batch of one)
+        for i in sorted(flagged):
+            a1, b1 = fn(az[i], bz[i], ax[i], bx[i])
+            if np.isnan(a1):
+                assert np.isnan(a_res[i])
+                continue
+            assert a_res[i] == pytest.approx(a1, rel=1e-12)
+            np.testing.assert_allclose(b_res[i], np.ravel(b1), rtol=1e-10, atol=1e-10 * np.abs(b1).max())
+        assert np.isnan(a_res[B - 1]) and np.isnan(a_res[11])   # NaN and inf poison their own instance, as in the reference
+        clean = [i for i in range(B) if i not in flagged]
+        assert np.all(np.isfinite(a_res[clean])) and np.all(np.isfinite(b_res[clean]))
+        a_ref, b_ref = pwl_reference(kind, direction, az[clean[:6]], bz[clean[:6]], ax[clean[:6]], bx[clean[:6]])
+        for k, i in enumerate(clean[:6]):
+            close_a(a_res[i], a_ref[k], (ax if direction == "fwd" else az)[i], dtype)
+            close(b_res[i], b_ref[k], dtype, scale=10 * np.abs(b_ref[k]).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pwl_resident_damping_and_aliased_output(T, ctx, dtype):
+    """damping against the buffer being overwritten (what the EP scheduler does) runs on the pipeline; an update written
+    over its own input cannot be redone from its inputs, so it takes the tile kernels - same numbers either way"""
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(8)
+    d = 0.25
+    az, ax = rs.uniform(0.8, 2.0, B), rs.uniform(0.5, 1.5, B)
+    bz = rs.standard_normal((B, n)).astype(dtype); bx = rs.standard_normal((B, n)).astype(dtype)
+    old_a = rs.uniform(0.5, 2.0, B); old_b = rs.standard_normal((B, n)).astype(dtype)
+    ch = T.ReluChannel(dtype=dtype, ctx=ctx)
+    oa = ctx.scalars(old_a); ob = ctx.array(old_b, dtype)
+    runs0 = ctx.resident_runs()
+    ch.compute_backward_message(ctx.scalars(az), ctx.array(bz, dtype), ctx.scalars(ax), ctx.array(bx, dtype), out_a=oa, out_b=ob,
+                                damping=d, old_a=oa, old_b=ob)
+    assert ctx.resident_runs() == runs0 + 1
+    a_ref, b_ref = pwl_reference("relu", "bwd", az, bz, ax, bx)
+    a_new, b_new = oa.get(), ob.get()
+    for i in range(0, B, 7):
+        close_a(a_new[i], d * old_a[i] + (1 - d) * a_ref[i], az[i], dtype)
+        close(b_new[i], d * old_b[i].astype(np.float64) + (1 - d) * b_ref[i], dtype, scale=10 * max(np.abs(b_ref[i]).max(), 1.0))
+    bio = ctx.array(bz, dtype); ao = ctx.empty((B,), np.float64)
+    runs0 = ctx.resident_runs()
+    ch.compute_backward_message(ctx.scalars(az), bio, ctx.scalars(ax), ctx.array(bx, dtype), out_a=ao, out_b=bio)
+    assert ctx.resident_runs() == runs0, "an in-place update must not take the lean pipeline (it could not be redone)"
+    b_new = bio.get()
+    for i in range(0, B, 7):
+        close(b_new[i], b_ref[i], dtype, scale=10 * max(np.abs(b_ref[i]).max(), 1.0))

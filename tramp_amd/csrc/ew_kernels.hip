@@ -602,7 +602,13 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
 template <typename T, typename Op>
 static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
                      const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
-    return run_tiles_u<T, Op, kTileU>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
+    // two-input heavy factors (K7): one piece per thread and tile - 326 us against 396 (U = 2) and 357 (U = 4) for the
+    // moments pass at 64 x 1e6 f64 (tools/probes/probe_k7.hip, round 5: the evaluation's temporaries times U is what the
+    // compiler's schedule keeps live)
+    if constexpr (Op::HEAVY && Op::NIN > 1 && sizeof(T) == 8)
+        return run_tiles_u<T, Op, 1>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
+    else
+        return run_tiles_u<T, Op, kTileU>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
 }
 
 bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size) {
@@ -955,6 +961,18 @@ template <typename T, int KIND>
 static int pwl_dir(tramp_ctx* ctx, int dir, size_t n, size_t batch, const double* az_d,
                    const void* bz_d, const double* ax_d, const void* bx_d, const MsgOut& out,
                    const tmath::PwlSpec& spec = tmath::PwlSpec{}) {
+    // Sgn / Abs / Relu at large shapes: the resident single-pass pipeline (ew_resident_pwl.hip: 512 threads x 2 pieces, the
+    // 13 KiB one-value erfcx table beside the parked r).
+    static const size_t res_k7 = env_size("TRAMP_EW_RESIDENT_K7", 1);
+    if constexpr (KIND < 3) {
+        if (res_k7 && n && batch && bz_d && bx_d && az_d && ax_d && out.a_new && out.b_new &&
+            (out.damping == 0.0 || (out.a_old && out.b_old))) {
+            int rc;
+            if (dir == TRAMP_FWD) rc = run_resident<T>(ctx, PwlOp<T, KIND, true, true, true>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, ax_d, out);
+            else rc = run_resident<T>(ctx, PwlOp<T, KIND, false, true, true>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, az_d, out);
+            if (rc != kResNotEligible) return rc;
+        }
+    }
     if (dir == TRAMP_FWD) {
         PwlOp<T, KIND, true> op{az_d, ax_d, spec};
         return run_two_pass<T>(ctx, op, n, batch, bz_d, bx_d, ax_d, out);

@@ -196,7 +196,9 @@ template <typename T, bool FWD> struct Pwl3Op {   // three-region channels; in0 
     }
 };
 
-template <typename T, int KIND, bool FWD, bool UNI = true> struct PwlOp {   // K7; in0 = bz, in1 = bx
+// LEAN (the resident pipeline): the moment form only; a wave with a lane outside its domain still evaluates it and
+// reports the instance through `eval_ok` = false, for the caller to redo on the literal form (ew_resident.h: redo flags)
+template <typename T, int KIND, bool FWD, bool UNI = true, bool LEAN = false> struct PwlOp {   // K7; in0 = bz, in1 = bx
     static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
     static constexpr int TARGET = FWD ? 1 : 0;
@@ -205,6 +207,8 @@ template <typename T, int KIND, bool FWD, bool UNI = true> struct PwlOp {   // K
     tmath::PwlSpec spec;          // used by KIND 3 only
     tmath::PwlConst<T> c;
     double a_msg;
+    using Full = PwlOp<T, KIND, FWD, UNI, false>;      // the form with the region-by-region fall-back (redo of a flagged instance)
+    __device__ __host__ Full full() const { return Full{az, ax, spec}; }
     __device__ static void stage() { tmath::erfcx_setup<T, UNI>(); }
     __device__ void prepare(size_t b) {
         const double z = az[b], x = ax[b];
@@ -213,8 +217,14 @@ template <typename T, int KIND, bool FWD, bool UNI = true> struct PwlOp {   // K
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T x1) const {
-        tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD, UNI>(x0, x1, c);
-        return {o.r, o.v, o.mask};
+        if constexpr (LEAN && KIND < 3) {
+            tmath::PwlOut<T> o;
+            const bool ok = tmath::pwl_moment_form<T, KIND, FWD, UNI, false>(x0, x1, c, o);
+            return {o.r, o.v, o.mask | (ok ? 0u : 0x80000000u)};
+        } else {
+            tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD, UNI>(x0, x1, c);
+            return {o.r, o.v, o.mask};
+        }
     }
 };
 
@@ -222,6 +232,11 @@ template <typename T, int KIND, bool FWD, bool UNI = true> struct PwlOp {   // K
 // ops do not carry the 64-bit counter through their loops.
 template <typename Op> struct OpBits { static constexpr bool value = false; };
 template <typename T> struct OpBits<SgnLikBitsOp<T>> { static constexpr bool value = true; };
+
+// Lean ops (the resident pipeline's K7): eval() covers the moment form's domain only and reports a lane outside it in bit
+// 31 of EwOut::mask; the pipeline flags the instance and a second kernel redoes it on Op::Full (ew_resident.h).
+template <typename Op> struct OpLean { static constexpr bool value = false; };
+template <typename T, int KIND, bool FWD, bool UNI> struct OpLean<PwlOp<T, KIND, FWD, UNI, true>> { static constexpr bool value = true; };
 
 template <typename Op> struct OpCounts { static constexpr bool value = false; };
 template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };

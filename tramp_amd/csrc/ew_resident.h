@@ -44,6 +44,7 @@ struct ResArgs {
     unsigned long long* scal;         // [batch] bits of a_in + a_new
     const uint8_t* bits;              // OpBits factors: the second input, one bit per component, rows of bits_stride bytes
     size_t bits_stride;
+    unsigned* redo;                   // [batch] lean ops: instance i had a lane outside the lean form's domain (ew_res_redo)
     void* dummy;                      // 256 U 16-byte pieces: where the overlap of an instance's last tile is "stored"
     MsgOut out;
 };
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void ew_res_prepare(Op op, ResArgs A, Op* _
     }
     if (i < A.batch) {
         A.scal[i] = kResSentinel;
+        if (A.redo) A.redo[i] = 0u;
         Op o = op;
         o.prepare(i);
         ops[i] = o;
@@ -182,6 +184,11 @@ template <int NT> __device__ __forceinline__ unsigned long long res_block_sum_u6
 
 // Flags: which rarely wanted outputs this instantiation writes (compile time: no branch in the stream).
 constexpr int kResDamp = 1, kResStoreR = 2, kResMask = 4, kResNtLoad = 8, kResSchedBarrier = 16, kResRegR = 32;
+// kResReloadB: the target message b is NOT kept in the register ring while its round waits for the mean; it is loaded a
+// second time one iteration before the update (DL + DA - 1 rounds, ~100 MB of traffic, after its first read: served by the
+// 256 MB Infinity Cache, so HBM still sees it once).  The ring then holds two rounds of inputs instead of five of b: the
+// heavy two-input factors (K7) evaluate without spilling.
+constexpr int kResReloadB = 64;
 
 // DBG (probes only): 1 = no slots, no combiner, no polling (the pipeline as a plain stream with a constant scalar).
 // Every tile is FULL: the last tile of an instance starts at nv - 256 U, overlapping its predecessor; the overlap is
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
     constexpr unsigned TV = NT * U;                       // 16-byte pieces per tile
     constexpr bool COUNT = OpCounts<Op>::value, BITS = OpBits<Op>::value;
     constexpr bool DAMP = (FLAGS & kResDamp) != 0, STORE_R = (FLAGS & kResStoreR) != 0, MASK = (FLAGS & kResMask) != 0;
+    constexpr bool RELOAD = (FLAGS & kResReloadB) != 0;
     __shared__ double smem[NT / kWave];
     __shared__ unsigned long long smem_u[NT / kWave];
     // r of the rounds that wait for their mean: in LDS (each thread parks and fetches its own pieces: no barrier), so the
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
     const T dT = T(A.out.damping), omd = T(1.0 - A.out.damping);
 
     // ring of rounds in flight: x0 / x1 hold the inputs until the moments are taken, then x0 the target message b
-    V x0[R][U], x1[R][U], xold[R][U];
+    V x0[R][U], x1[R][U], xold[R][U], xt[R][U];
+    const V* ptgt = (Op::TARGET == 0) ? p0 : p1;
     unsigned xb[R][U];                         // BITS: the byte that holds this piece's bits of the packed second input
     unsigned lm = 0;                           // LDS slot of the round whose moments are taken: (j - DL) mod (DA + 1)
     unsigned r_inst[R], r_tile[R];
@@ -272,6 +281,12 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
 #pragma unroll
             for (int u = 0; u < U; ++u) xold[sN][u] = pold[base + off + u * NT];
         }
+        if (RELOAD && (STEADY || (r_live[sN] && j + 1 >= (unsigned long long)(DL + DA)))) {
+            const size_t base = (size_t)r_inst[sN] * nv;
+            const unsigned off = min(r_tile[sN] * TV, nv - TV) + tid;
+#pragma unroll
+            for (int u = 0; u < U; ++u) xt[sN][u] = ptgt[base + off + u * NT];
+        }
         // ---- moments of round j - DL
         if (STEADY || (j >= (unsigned long long)DL && r_live[sM])) {
             const Op op = ops[r_inst[sM]];
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
             const unsigned off = min(first, nv - TV) + tid;
             double acc = 0.0;
             unsigned long long cnt = 0;
+            unsigned bad = 0;                                           // lean ops: a lane outside the form's domain
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const unsigned i = off + u * NT;
@@ -291,6 +307,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                     T a1 = (Op::NIN > 1) ? vget<T>(x1[sM][u], c) : a0;
                     if (BITS) a1 = ((xb[sM][u] >> (((i * VN) & 7u) + c)) & 1u) ? T(1) : T(-1);
                     EwOut<T> o = op.eval(a0, a1);
+                    if (OpLean<Op>::value) bad |= o.mask;
                     double vi = (double)o.v;
                     if (not_finite(o.r)) vi = __longlong_as_double(0x7ff8000000000000LL);
                     acc += counts ? vi : 0.0;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                     if (MASK) {
                         uint8_t* mo = counts ? A.out.mask + (size_t)r_inst[sM] * A.n + (size_t)i * VN + c
                                              : reinterpret_cast<uint8_t*>(A.dummy) + tid;
-                        *mo = (uint8_t)o.mask;
+                        *mo = (uint8_t)o.mask;          // (lean ops have no mask output: run_resident refuses out.mask)
                     }
                 }
                 if (STORE_R) {
@@ -307,12 +324,16 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                     __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&vr), reinterpret_cast<NV*>(dst));
                 }
                 // keep (b, r): b in the ring, r in LDS
-                if (Op::TARGET != 0) x0[sM][u] = x1[sM][u];
+                if (Op::TARGET != 0 && !RELOAD) x0[sM][u] = x1[sM][u];
                 if (FLAGS & kResRegR) x1[sM][u] = vr;
                 else r_lds[lm][u][tid] = vr;
                 // one 16-byte piece at a time: interleaving all U evaluations (the scheduler's choice when left alone) needs
                 // U times the temporaries, and the ring leaves no room for them
                 if (FLAGS & kResSchedBarrier) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (OpLean<Op>::value) {
+                // every writer stores the same 1: no atomic; the redo kernel runs after this one (stream order)
+                if (__any((bad >> 31) != 0) && (tid & (kWave - 1)) == 0) A.redo[r_inst[sM]] = 1u;
             }
             acc = res_block_sum<NT>(acc, smem);
             if (COUNT) cnt = res_block_sum_u64<NT>(cnt, smem_u);
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                 const V vr = (FLAGS & kResRegR) ? x1[sA][u] : r_lds[la][u][tid];
 #pragma unroll
                 for (int c = 0; c < VN; ++c) {
-                    T bn = vget<T>(vr, c) * vinv - vget<T>(x0[sA][u], c);
+                    T bn = vget<T>(vr, c) * vinv - vget<T>(RELOAD ? xt[sA][u] : x0[sA][u], c);
                     if (DAMP) bn = dT * vget<T>(xold[sA][u], c) + omd * bn;
                     vset<T>(vo, c, bn);
                 }
@@ -375,4 +396,47 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
             constexpr int s = decltype(sc)::value;
             if (j0 + s < Jw) body(std::integral_constant<int, (s + R - 1) % R>{}, No{}, j0 + s);
         });
+}
+
+
+// ---- redo of the instances a lean op flagged (A.redo): one workgroup per instance, the whole update again on Op::Full
+// (the form with the region-by-region fall-back), two sweeps over the instance.  Launched behind every lean resident
+// update; a workgroup whose instance is not flagged leaves at once.  Flags are raised by components within ~2 % of the
+// reference's log_Phi mask threshold (|y0| >= 29.4: 29 standard deviations), NaN and infinite messages and erfcx
+// arguments outside the table - none of which a converging EP run produces - so the sweep's speed does not matter; its
+// results are those of the tile kernels (same Op::eval, fixed summation order).
+template <typename T, typename FullOp>
+__global__ __launch_bounds__(kBlock) void ew_res_redo(FullOp op, size_t n, const unsigned* __restrict__ redo, const T* __restrict__ in0,
+                                                      const T* __restrict__ in1, const double* __restrict__ a_in_d, MsgOut out) {
+    const size_t b = blockIdx.x;
+    if (!redo[b]) return;
+    __shared__ double smem[kBlock / kWave];
+    op.setup(b);
+    const T* p0 = in0 + b * n;
+    const T* p1 = (FullOp::NIN > 1) ? in1 + b * n : nullptr;
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += kBlock) {
+        const T x0 = p0[i], x1 = (FullOp::NIN > 1) ? p1[i] : x0;
+        const EwOut<T> o = op.eval(x0, x1);
+        acc += not_finite(o.r) ? __longlong_as_double(0x7ff8000000000000LL) : (double)o.v;
+    }
+    acc = block_sum(acc, smem);                     // every thread holds the sum
+    const double v = acc / (double)n;
+    const double a_in = a_in_d[b];
+    const double a_new = tmath::a_new_of(v, a_in);
+    const double d = out.damping;
+    if (threadIdx.x == 0) {
+        out.a_new[b] = (d != 0.0) ? d * out.a_old[b] + (1.0 - d) * a_new : a_new;
+        if (out.v) out.v[b] = v;
+    }
+    const T vinv = T(a_in + a_new), dT = T(d), omd = T(1.0 - d);
+    const T* bold = (d != 0.0) ? reinterpret_cast<const T*>(out.b_old) + b * n : nullptr;
+    T* bo = reinterpret_cast<T*>(out.b_new) + b * n;
+    for (size_t i = threadIdx.x; i < n; i += kBlock) {
+        const T x0 = p0[i], x1 = (FullOp::NIN > 1) ? p1[i] : x0;
+        const T r = op.eval(x0, x1).r;
+        T bn = r * vinv - ((FullOp::TARGET == 0) ? x0 : x1);
+        if (bold) bn = dT * bold[i] + omd * bn;
+        bo[i] = bn;
+    }
 }

@@ -12,6 +12,14 @@ constexpr int kResNotEligible = 1000;      // run_resident: "take the tile kerne
 // 207 us f64 / 94 us f32; deeper rings spill, U = 8 with one workgroup per CU is 5-10 % slower, U = 2 15 % slower).
 constexpr int kResU = 4, kResDL = 1, kResDA = 3;
 
+// Threads per workgroup and 16-byte pieces per thread and tile (NT x U = 1024 pieces per tile for every factor).  The
+// two-region channels K7 run 512 threads x 2 pieces: four waves per SIMD with <= 128 registers each hide the latency of
+// their ~100-instruction evaluation, which two waves per SIMD do not (round 5; tools/probes/probe_k7.hip).
+// FLAGS: extra kernel flags (ew_resident.h); 64 = kResReloadB, the target message is read a second time instead of being
+// held in registers.
+template <typename Op> struct ResShape { static constexpr int U = kResU, NT = kBlock, FLAGS = 0; };
+template <typename T, int KIND, bool FWD, bool UNI, bool LEAN> struct ResShape<PwlOp<T, KIND, FWD, UNI, LEAN>> { static constexpr int U = 4, NT = 256, FLAGS = 0; };
+
 template <typename Op> struct ResidentOp { static constexpr bool value = false; };
 template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value = true; };
@@ -20,8 +28,7 @@ template <typename T> struct ResidentOp<AbsLikOp<T>> { static constexpr bool val
 template <typename T> struct ResidentOp<SgnLikBitsOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<BinaryOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<ReluLikOp<T>> { static constexpr bool value = true; };
-// (the two-region channels K7 are bound by their arithmetic, not by the second pass: their resident form measured
-// no faster in f64 - the erfcx tables beside the parked r leave room for one workgroup per CU - and slower in f32)
+// (the two-region channels K7 enter through pwl_dir in ew_kernels.hip: ew_resident_pwl.hip)
 
 // The shape test (instances of at least one tile that fit the pipeline's window, enough tiles for four rounds, 16-byte
 // rows).  Shared with the producers of prior_hint.h: an FFT epilogue whose consumer takes the resident form leaves no

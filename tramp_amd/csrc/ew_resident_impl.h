@@ -9,15 +9,26 @@ template <typename T, typename Op>
 int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const void* in0, const void* in1,
                  const double* a_in_d, const MsgOut& out, const void* bits, size_t bits_stride) {
     constexpr int VN = Vec<T>::N;
-    constexpr int U = kResU, DL = kResDL, DA = kResDA, BPC = kResBlocksPerCU;
-    constexpr size_t TV = (size_t)kBlock * U;
+    constexpr int XF = ResShape<Op>::FLAGS;
+    constexpr int U = ResShape<Op>::U, NT = ResShape<Op>::NT, DL = kResDL, DA = kResDA, BPC = kResBlocksPerCU;
+    constexpr size_t TV = (size_t)NT * U;
+    static_assert(TV == (size_t)kBlock * kResU, "resident_covers (ew_kernels.hip) counts tiles of kBlock x kResU pieces");
     if (out.mask || out.r || !resident_covers(ctx, n, batch, sizeof(T))) return kResNotEligible;
+    constexpr bool LEAN = OpLean<Op>::value;
+    if (LEAN) {
+        // a flagged instance is redone FROM ITS INPUTS after the pipeline has written its outputs: no in-place updates
+        const char *o0 = reinterpret_cast<const char*>(out.b_new), *o1 = o0 + batch * n * sizeof(T);
+        for (const void* in : {in0, in1}) {
+            const char* i0 = reinterpret_cast<const char*>(in);
+            if (i0 && i0 < o1 && o0 < i0 + batch * n * sizeof(T)) return kResNotEligible;
+        }
+    }
     const size_t nv = n / VN;
     // all workgroups must be resident at once: two per CU by the launch bounds, checked once per instantiation
     static int occ_plain = -1, occ_damp = -1;
     if (occ_plain < 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_plain, ew_resident<T, Op, U, DL, DA, kResSchedBarrier, BPC>, kBlock, 0) != hipSuccess) occ_plain = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_damp, ew_resident<T, Op, U, DL, DA, kResDamp | kResSchedBarrier, BPC>, kBlock, 0) != hipSuccess) occ_damp = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_plain, ew_resident<T, Op, U, DL, DA, kResSchedBarrier | XF, BPC, 0, NT>, NT, 0) != hipSuccess) occ_plain = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_damp, ew_resident<T, Op, U, DL, DA, kResDamp | kResSchedBarrier | XF, BPC, 0, NT>, NT, 0) != hipSuccess) occ_damp = 0;
     }
     const bool damp = out.damping != 0.0;
     if ((damp ? occ_damp : occ_plain) < BPC) return kResNotEligible;
@@ -36,8 +47,9 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
     const size_t slot_bytes = ((A.total * 8 + 255) / 256) * 256;
     const size_t scal_bytes = ((batch * 8 + 255) / 256) * 256;
     const size_t dummy_bytes = TV * 16;
+    const size_t redo_bytes = LEAN ? ((batch * 4 + 255) / 256) * 256 : 0;
     const bool count = OpCounts<Op>::value;
-    int rc = tramp_ws_reserve(ctx, ops_bytes + slot_bytes * (count ? 2 : 1) + scal_bytes + dummy_bytes);
+    int rc = tramp_ws_reserve(ctx, ops_bytes + slot_bytes * (count ? 2 : 1) + scal_bytes + dummy_bytes + redo_bytes);
     if (rc) return rc;
     char* ws = reinterpret_cast<char*>(ctx->ws);
     Op* ops = reinterpret_cast<Op*>(ws);
@@ -52,6 +64,8 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
     A.scal = reinterpret_cast<unsigned long long*>(ws);
     ws += scal_bytes;
     A.dummy = ws;
+    ws += dummy_bytes;
+    A.redo = LEAN ? reinterpret_cast<unsigned*>(ws) : nullptr;
     A.bits = reinterpret_cast<const uint8_t*>(bits);
     A.bits_stride = bits_stride;
     if (OpBits<Op>::value && !bits) return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "packed observation");
@@ -62,9 +76,16 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
     const T* p0 = reinterpret_cast<const T*>(in0);
     const T* p1 = reinterpret_cast<const T*>(in1);
     if (damp)
-        hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, kResDamp | kResSchedBarrier, BPC>), dim3(P), dim3(kBlock), 0, ctx->stream, (const Op*)ops, A, p0, p1);
+        hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, kResDamp | kResSchedBarrier | XF, BPC, 0, NT>), dim3(P), dim3(NT), 0, ctx->stream, (const Op*)ops, A, p0, p1);
     else
-        hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, kResSchedBarrier, BPC>), dim3(P), dim3(kBlock), 0, ctx->stream, (const Op*)ops, A, p0, p1);
+        hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, kResSchedBarrier | XF, BPC, 0, NT>), dim3(P), dim3(NT), 0, ctx->stream, (const Op*)ops, A, p0, p1);
+    if constexpr (LEAN) {
+        // the flagged instances again, on the form with the fall-back (ew_res_redo); MsgOut as the caller gave it
+        MsgOut o = out;
+        if (!damp) { o.a_old = nullptr; o.b_old = nullptr; o.damping = 0.0; }
+        hipLaunchKernelGGL((ew_res_redo<T, typename Op::Full>), dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, op.full(), n,
+                           (const unsigned*)A.redo, p0, p1, a_in_d, o);
+    }
     TRAMP_LAUNCH_CHECK(ctx);
     ctx->resident_runs += 1;
     return TRAMP_OK;

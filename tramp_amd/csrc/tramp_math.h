@@ -83,11 +83,11 @@ TM_HD float fma_(float a, float b, float c) { return ::fmaf(a, b, c); }
 }  // namespace tmath
 #if defined(__HIPCC__)
 #include "erfcx_table.h"
-#include "erfcx_utable.h"
+#include "erfcx_ttable.h"
 #else
 #define __device__              // the generated tables say `__device__ const`: plain constants for a host compiler
 #include "erfcx_table.h"
-#include "erfcx_utable.h"
+#include "erfcx_ttable.h"
 #undef __device__
 #endif
 namespace tmath {
@@ -102,32 +102,36 @@ namespace tmath {
 // pace: 487 us for the 109-instruction sign likelihood against 280 us for the 163-instruction abs one.)
 // Every kernel that evaluates erfcx_hot calls erfcx_lds_init() first (all threads; it ends in a barrier).
 __shared__ double g_erfcx_lds[(kErfcxD + 1) * kErfcxK];
-// Round 3: a second table on a UNIFORM grid of x in [-3, 8) (erfcx_utable.h: 352 intervals of 1/32, degree 7, 22 KiB of
-// LDS): the interval comes from one fma and a conversion - no reciprocal - and negative arguments need no exp(x^2),
-// 23 instructions per evaluation instead of 31 (x >= 0) + 24 (x < 0, both run in every wave).  Taken when every lane
-// of the wave is inside the grid, else the whole wave evaluates the reciprocal-mapped table below.  Rows that differ
-// by a multiple of 32 share a bank pair (any 32 of 352 rows collide somewhere): the reads take 2-3 passes, on a pipe
-// the VALU-bound kernels do not otherwise use.  Used by the two-region channels K7 (erfcx_hot<true>: 64 x 1e6 f64
-// 0.72-0.78 -> 0.63-0.71 ms); the sign likelihood, one evaluation per pass and closer to the memory bound, is faster
-// on the small conflict-free table (580 against 619 us) and keeps it.  -DTRAMP_ERFCX_UNIFORM=0 removes the grid table.
+// Round 5: the second table holds ONE value per grid point, erfcx(x_k) at x_k = -5 + k / 128 (erfcx_ttable.h, 13 KiB of
+// LDS; f32: k / 64, 3.3 KiB): erfcx' = 2 x erfcx - 2/sqrt(pi) gives every Taylor coefficient about x_k from that value by
+// a three-term recurrence, so an evaluation is one 8-byte LDS read and ~30 VALU instructions, no reciprocal, and no
+// exp(x^2) for negative arguments.  (Round 3's table held a degree-7 polynomial per interval of 1/32: eight reads per
+// evaluation, rows colliding in the banks - the LDS, not the VALU, set the pace of the two-region channels K7:
+// tools/probes/probe_k7.hip, 427 us against 358 us for the moments pass at 64 x 1e6.)  Taken when every lane of the wave
+// is inside [-5, 8), else the whole wave evaluates the reciprocal-mapped table below.  Used by K7 (erfcx_hot<true>,
+// pwl_moment_form).  -DTRAMP_ERFCX_UNIFORM=0 removes it.
 #if TRAMP_ERFCX_UNIFORM
-__shared__ double g_erfcx_ulds[(kErfcxUD + 1) * kErfcxUK];
+__shared__ double g_erfcx_tlds[kErfcxTK];
+__shared__ float g_erfcx_tlds_f[kErfcxTKF];
 #endif
 template <bool UNI = false> __device__ __forceinline__ void erfcx_lds_init() {
     for (int i = threadIdx.x; i < (kErfcxD + 1) * kErfcxK; i += blockDim.x)
         g_erfcx_lds[i] = kErfcxTable[i % kErfcxK][i / kErfcxK];
 #if TRAMP_ERFCX_UNIFORM
     if (UNI)
-        for (int i = threadIdx.x; i < (kErfcxUD + 1) * kErfcxUK; i += blockDim.x)
-            g_erfcx_ulds[i] = kErfcxUTable[i % kErfcxUK][i / kErfcxUK];
+        for (int i = threadIdx.x; i < kErfcxTK; i += blockDim.x) g_erfcx_tlds[i] = kErfcxTTable[i];
 #endif
     __syncthreads();
 }
 // f32 kernels: their own table (degree 4, 4-byte entries: the 32 rows sit in 32 different banks)
 __shared__ float g_erfcx_lds_f[(kErfcxDF + 1) * kErfcxKF];
-__device__ __forceinline__ void erfcx_lds_init_f() {
+template <bool UNI = false> __device__ __forceinline__ void erfcx_lds_init_f() {
     for (int i = threadIdx.x; i < (kErfcxDF + 1) * kErfcxKF; i += blockDim.x)
         g_erfcx_lds_f[i] = kErfcxTableF[i % kErfcxKF][i / kErfcxKF];
+#if TRAMP_ERFCX_UNIFORM
+    if (UNI)
+        for (int i = threadIdx.x; i < kErfcxTKF; i += blockDim.x) g_erfcx_tlds_f[i] = kErfcxTTableF[i];
+#endif
     __syncthreads();
 }
 #endif
@@ -143,7 +147,8 @@ __device__ __forceinline__ float exp2_est(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ double erfcx_coef(int j, int k) { return g_erfcx_lds[j * kErfcxK + k]; }
 __device__ __forceinline__ float erfcx_coef_f(int j, int k) { return g_erfcx_lds_f[j * kErfcxKF + k]; }
 #if TRAMP_ERFCX_UNIFORM
-__device__ __forceinline__ double erfcx_ucoef(int j, int k) { return g_erfcx_ulds[j * kErfcxUK + k]; }
+__device__ __forceinline__ double erfcx_tval(int k) { return g_erfcx_tlds[k]; }
+__device__ __forceinline__ float erfcx_tval_f(int k) { return g_erfcx_tlds_f[k]; }
 #endif
 #else
 // host harness: an f32 division stands for the f64 estimate (1e-7 instead of 4.6e-8: the cubic correction of rcp_1to2
@@ -158,7 +163,8 @@ TM_HD float exp2_est(float x) { return ::exp2f(x); }
 TM_HD double erfcx_coef(int j, int k) { return kErfcxTable[k][j]; }
 TM_HD float erfcx_coef_f(int j, int k) { return kErfcxTableF[k][j]; }
 #if TRAMP_ERFCX_UNIFORM
-TM_HD double erfcx_ucoef(int j, int k) { return kErfcxUTable[k][j]; }
+TM_HD double erfcx_tval(int k) { return kErfcxTTable[k]; }
+TM_HD float erfcx_tval_f(int k) { return kErfcxTTableF[k]; }
 #endif
 #endif
 }  // namespace hw
@@ -221,22 +227,50 @@ TM_HD double rcp_pos(double x) { return rcp_1to2(x); }
 TM_HD float rcp_pos(float x) { return hw::rcp_est(x); }
 
 #if TRAMP_ERFCX_UNIFORM
-// erfcx on the uniform grid, for x KNOWN to lie in [kErfcxULo, kErfcxUHi) (the caller's wave vote)
-TM_HD double erfcx_ugrid(double x) {
-    const double tk = ::fma(x, kErfcxUPer, -kErfcxULo * kErfcxUPer);      // in [0, K)
-    const int ki = (int)tk;
-    const int k = ki < kErfcxUK - 1 ? ki : kErfcxUK - 1;
-    const double s = ::fma(2.0, tk - (double)k, -1.0);
-    double acc = hw::erfcx_ucoef(kErfcxUD, k);
+// erfcx by the Taylor recurrence about the nearest grid point, for x KNOWN to lie in [kErfcxTLo, kErfcxTHi) (the caller's
+// wave vote): t_0 = f_k, t_1 = d (a f_k - 2/sqrt(pi)), t_{n+1} = (u t_n + w t_{n-1}) / (n + 1) with a = 2 x_k, u = a d,
+// w = 2 d^2 (tools/gen_erfcx_ttable.py: 2e-15 on [-3, 8), 4e-14 down to -5)
+TM_HD double erfcx_tay(double x) {
+    const double s = x - kErfcxTLo;
+    const double kf = __builtin_rint(s * kErfcxTPer);
+    const double d = ::fma(kf, -1.0 / kErfcxTPer, s);
+    const double a = ::fma(kf, 2.0 / kErfcxTPer, 2.0 * kErfcxTLo);
+    const double f = hw::erfcx_tval((int)kf);
+    const double u = a * d, w = (d + d) * d;
+    double tm = f, t = d * ::fma(a, f, -1.12837916709551257390);
+    double acc = f + t;
 #pragma unroll
-    for (int j = kErfcxUD - 1; j >= 0; --j) acc = ::fma(acc, s, hw::erfcx_ucoef(j, k));
+    for (int n = 1; n < kErfcxTD; ++n) {
+        const double tn = ::fma(u, t, w * tm) * (1.0 / (n + 1));
+        tm = t;
+        t = tn;
+        acc += t;
+    }
+    return acc;
+}
+TM_HD float erfcx_tay(float x) {
+    const float s = x - (float)kErfcxTLo;
+    const float kf = __builtin_rintf(s * (float)kErfcxTPerF);
+    const float d = ::fmaf(kf, (float)(-1.0 / kErfcxTPerF), s);
+    const float a = ::fmaf(kf, (float)(2.0 / kErfcxTPerF), (float)(2.0 * kErfcxTLo));
+    const float f = hw::erfcx_tval_f((int)kf);
+    const float u = a * d, w = (d + d) * d;
+    float tm = f, t = d * ::fmaf(a, f, -1.12837916709551257390f);
+    float acc = f + t;
+#pragma unroll
+    for (int n = 1; n < kErfcxTDF; ++n) {
+        const float tn = ::fmaf(u, t, w * tm) * (1.0f / (float)(n + 1));
+        tm = t;
+        t = tn;
+        acc += t;
+    }
     return acc;
 }
 #endif
 template <bool UNI = false> TM_HD double erfcx_hot(double x) {
 #if TRAMP_ERFCX_UNIFORM
-    if (UNI && TM_WAVE_ALL(x >= kErfcxULo && x < kErfcxUHi))        // a NaN fails the test: the wave takes the general path
-        return erfcx_ugrid(x);
+    if (UNI && TM_WAVE_ALL(x >= kErfcxTLo && x < kErfcxTHi))        // a NaN fails the test: the wave takes the general path
+        return erfcx_tay(x);
 #endif
     const double w = ::fmin(::fabs(x), 1e300);                // erfcx(1e300) = 5.6e-301; a NaN x reaches the caller through x itself
     const double t = 4.0 * rcp_pos(4.0 + w);
@@ -254,6 +288,9 @@ template <bool UNI = false> TM_HD double erfcx_hot(double x) {
 // f32: the same construction on the float table (4e-7 relative for x >= 0, a few ulp of float; the library's
 // erfcxf is ~45 instructions)
 template <bool UNI = false> TM_HD float erfcx_hot(float x) {
+#if TRAMP_ERFCX_UNIFORM
+    if (UNI && TM_WAVE_ALL(x >= (float)kErfcxTLo && x < (float)kErfcxTHi)) return erfcx_tay(x);
+#endif
     const float w = ::fminf(::fabsf(x), 1e37f);
     const float t = 4.0f * hw::rcp_est(4.0f + w);
     const float tk = t * (float)kErfcxKF;
@@ -272,7 +309,7 @@ template <bool UNI = false> TM_HD float erfcx_hot(float x) {
 template <typename T, bool UNI = false> TM_HD void erfcx_setup() {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (sizeof(T) == 8) erfcx_lds_init<UNI>();
-    else erfcx_lds_init_f();
+    else erfcx_lds_init_f<UNI>();
 #endif
 }
 
@@ -759,6 +796,12 @@ TM_HD PwlOut<T> pwl_posterior_regions(T bz, T bx, const PwlConst<T>& c) {
     o.r = p0 * rs[0] + p1 * rs[1];
     T d = rs[0] - rs[1];
     o.v = p0 * vs[0] + p1 * vs[1] + p0 * p1 * (d * d);
+    // A NaN or infinite message makes the reference's softmax NaN in every channel and direction (checked on the reference:
+    // inf - inf in the region log-partitions).  Here a region of slope 0 does not look at its mean (Sgn forward: r = p0 -
+    // p1), and erfcx_hot swallows a NaN argument: carry the non-finite input into r and v explicitly.
+    const T poison = (bz - bz) + (bx - bx);             // 0 for finite messages
+    o.r += poison;
+    o.v += poison;
     o.mask = mask;
     return o;
 }
@@ -776,32 +819,40 @@ TM_HD PwlOut<T> pwl_posterior_regions(T bz, T bx, const PwlConst<T>& c) {
 // heavier region, so M2 - M1^2 cancels at most like (distance between the region means)^2 / v - never like r^2 / v.
 // Forward direction (posterior of x = slope z + x0): a region of slope 0 is the point mass x0_k; slope +-1 enters with
 // rho_k = slope_k r0_k and G_k -> slope_k G_k.
-// Taken when EVERY lane of the wave has both arguments on the erfcx grid (UNI; else: far from the reference's log_Phi
-// mask threshold, |x| < 0.98 cut / sqrt2, where e is finite), so mask = 3 by construction; any other wave - a lane near
+// Taken when EVERY lane of the wave has both arguments on the erfcx grid [-5, 8) (UNI; else: far from the reference's
+// log_Phi mask threshold, |x| < 0.98 cut / sqrt2, where e is finite), so mask = 3 by construction; any other wave - a lane near
 // or under the mask, a NaN, an infinity - takes pwl_posterior_regions, the literal region-by-region form.
 template <typename T> struct PwlMomentLim;
 template <> struct PwlMomentLim<double> { static constexpr double value = 0.98 * 30.0 * 0.70710678118654752440; };
 template <> struct PwlMomentLim<float> { static constexpr float value = 0.98f * 8.0f * 0.70710678f; };
 
-template <typename T, int KIND, bool FWD, bool UNI>
+// VOTE = false (the resident pipeline's lean form): no wave vote and no early return - every lane is evaluated with its
+// erfcx arguments clamped into the domain, and the function returns whether THIS lane was inside it; the caller flags
+// the instance and redoes it on the region-by-region form (ew_resident.h).
+template <typename T, int KIND, bool FWD, bool UNI, bool VOTE = true>
 TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o) {
     static_assert(KIND >= 0 && KIND < 3, "Sgn / Abs / Relu only");
     constexpr double sl0 = pwl_slope(KIND, 0), sl1 = pwl_slope(KIND, 1);
     // b_k = bz + slope_k (bx - ax x0_k): x0 = 0 wherever the slope is not (Abs, Relu); slope 0: b_k = bz
     const T b0 = (sl0 == 0.0) ? bz : bz + bx;
     const T b1 = (sl1 == 0.0) ? bz : (sl1 == 1.0 ? bz + bx : bz - bx);
-    const T x0 = b0 * c.kx[0], x1 = b1 * c.kx[1];
+    T x0 = b0 * c.kx[0], x1 = b1 * c.kx[1];
     bool ok;
-    constexpr bool GRID = UNI && sizeof(T) == 8 && TRAMP_ERFCX_UNIFORM;
-    if (GRID) ok = fmin_(x0, x1) >= T(kErfcxULo) && fmax_(x0, x1) < T(kErfcxUHi);
+    constexpr bool GRID = UNI && TRAMP_ERFCX_UNIFORM;
+    if (GRID) ok = fmin_(x0, x1) >= T(kErfcxTLo) && fmax_(x0, x1) < T(kErfcxTHi);
     else ok = fmax_(fabs_(x0), fabs_(x1)) < PwlMomentLim<T>::value;
     if (KIND == 0) ok = ok && fabs_(bx) <= RcpCap<T>::value;             // bx enters through exp only: a NaN must not be clamped away
-    if (!TM_WAVE_ALL(ok)) return false;
+    if (VOTE) {
+        if (!TM_WAVE_ALL(ok)) return false;
+    } else if (GRID) {                     // (a NaN becomes the lower edge: minNum / maxNum)
+        x0 = fmin_(fmax_(x0, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
+        x1 = fmin_(fmax_(x1, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
+    }
     T e0, e1;
 #if TRAMP_ERFCX_UNIFORM
     if constexpr (GRID) {
-        e0 = T(erfcx_ugrid((double)x0));
-        e1 = T(erfcx_ugrid((double)x1));
+        e0 = erfcx_tay(x0);
+        e1 = erfcx_tay(x1);
     } else
 #endif
     {
@@ -830,7 +881,7 @@ TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o) {
         const T p0 = W0 * iS, p1 = W1 * iS;
         o.r = p0 - p1;
         o.v = T(4) * (p0 * p1);
-        return true;
+        return ok;
     }
     const bool heavy0 = W0 >= W1;
     T n1, n2, cc;
@@ -856,7 +907,7 @@ TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o) {
     const T m1 = n1 * iS;
     o.r = cc + m1;
     o.v = fma_(T(0) - m1, m1, n2 * iS);
-    return true;
+    return ok;
 }
 
 template <typename T, int KIND, bool FWD, bool UNI = true>

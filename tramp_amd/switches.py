@@ -11,6 +11,7 @@ SWITCHES = {
     "TRAMP_HIP_LIB": ("tramp_amd/libtramp_hip.so", "select", "path of the C-ABI library to load (an experimental build)"),
     # componentwise updates (csrc/ew_kernels.hip, ew_resident.h)
     "TRAMP_EW_RESIDENT": ("1", "select", "0: never take the resident single-pass pipeline (the tile kernels' two passes instead)"),
+    "TRAMP_EW_RESIDENT_K7": ("1", "select", "0: the Sgn / Abs / Relu channels stay on the tile kernels' two passes"),
     "TRAMP_EW_RESIDENT_MIN_ROUNDS": ("4", "tune", "rounds of 2 x CUs - 8 tiles below which the pipeline is not worth its fill and drain"),
     "TRAMP_PRIOR_FUSE": ("1", "select", "0: producers never leave prior / likelihood moments (csrc/prior_hint.h)"),
     # dense linear channel (csrc/linear.hip, gemm_mfma.hip)
