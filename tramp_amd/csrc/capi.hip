@@ -53,6 +53,13 @@ extern "C" int tramp_ctx_create(int device, tramp_ctx** out) {
         delete ctx;
         return TRAMP_ENOMEM;
     }
+    unsigned* stat = nullptr;
+    if (hipHostMalloc((void**)&stat, 64, hipHostMallocDefault) == hipSuccess) {       // (without it the lean updates keep no statistics)
+        stat[0] = stat[1] = 0;
+        ctx->lean_stat = stat;
+    } else {
+        (void)hipGetLastError();
+    }
     *out = ctx;
     return TRAMP_OK;
 }
@@ -62,6 +69,7 @@ extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->lean_stat) (void)hipHostFree((void*)ctx->lean_stat);
     gemm_sliced_ctx_destroy(ctx);
     flush_deferred_frees(ctx);
     free(ctx->deferred_free);

@@ -363,12 +363,14 @@ __global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_
                                                           const T* __restrict__ in1, T* __restrict__ rbuf,
                                                           double* __restrict__ partials,
                                                           unsigned long long* __restrict__ pcount,
-                                                          uint8_t* __restrict__ mask_out) {
+                                                          uint8_t* __restrict__ mask_out,
+                                                          const unsigned* __restrict__ only = nullptr) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     __shared__ double smem[kBlock / kWave];
     __shared__ unsigned long long smem_u[kBlock / kWave];
     const size_t b = inst0 + blockIdx.y;
+    if (only && !only[b]) return;               // redo of flagged instances only (run_tiles_u: redo_nan)
     op.setup(b);
     const size_t nv = n / VN;
     const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
@@ -424,10 +426,12 @@ __global__ __launch_bounds__(kBlock) void ew_finalize(size_t n, size_t inst0, si
                                                       const double* __restrict__ a_in_d,
                                                       const double* __restrict__ partials,
                                                       const unsigned long long* __restrict__ pcount, int nblk,
-                                                      MsgOut out, double* __restrict__ scal) {
+                                                      MsgOut out, double* __restrict__ scal,
+                                                      const unsigned* __restrict__ only = nullptr) {
     __shared__ double smem[kBlock / kWave];
     __shared__ unsigned long long smem_u[kBlock / kWave];
     const size_t bl = blockIdx.x, b = inst0 + bl;
+    if (only && !only[b]) return;
     const double* pp = partials + (pinst0 + bl) * (size_t)nblk;
     double s = 0.0;
     for (int i = threadIdx.x; i < nblk; i += kBlock) s += pp[i];
@@ -453,10 +457,12 @@ __global__ __launch_bounds__(kBlock) void ew_finalize(size_t n, size_t inst0, si
 template <typename T, typename Op, int U, bool RECOMPUTE, bool NTS>
 __global__ __launch_bounds__(kBlock) void ew_apply_tile(Op op, size_t n, size_t inst0, int tpb, const T* __restrict__ in0,
                                                         const T* __restrict__ in1, const T* __restrict__ rbuf,
-                                                        const double* __restrict__ scal, MsgOut out) {
+                                                        const double* __restrict__ scal, MsgOut out,
+                                                        const unsigned* __restrict__ only = nullptr) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     const size_t bl = blockIdx.y, b = inst0 + bl;
+    if (only && !only[b]) return;
     const size_t nv = n / VN;
     const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
     const V* p1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
@@ -524,17 +530,42 @@ static size_t env_size(const char* name, size_t dflt) {
     return v >= 0 ? (size_t)v : dflt;
 }
 
+// flags[b] = (a_new[b] is NaN), for the redo of a lean resident update (ew_resident.h: a lane outside the lean form's
+// domain poisons its instance's a_new); stat = {flagged instances, batch} in pinned host memory, which the NEXT call's
+// host code reads without synchronising (a heuristic: pwl_dir).  One workgroup.
+__global__ __launch_bounds__(kBlock) void ew_flag_nan(size_t batch, const double* __restrict__ a_new, unsigned* __restrict__ flags,
+                                                      volatile unsigned* stat) {
+    __shared__ unsigned long long smem_u[kBlock / kWave];
+    unsigned long long c = 0;
+    for (size_t i = threadIdx.x; i < batch; i += kBlock) {
+        const double a = a_new[i];
+        const unsigned f = (a == a) ? 0u : 1u;
+        flags[i] = f;
+        c += f;
+    }
+    c = block_sum_u64(c, smem_u);
+    if (threadIdx.x == 0 && stat) {
+        stat[0] = (unsigned)c;
+        stat[1] = (unsigned)batch;
+    }
+}
+
 // Streaming-tile realisation of one update.  `hint` != nullptr: a producer left sum v_i partials for
-// this very message (prior_hint.h): no pass 1, the message is read once.
+// this very message (prior_hint.h): no pass 1, the message is read once.  redo_nan: only the instances whose out.a_new
+// is NaN are updated (the others' workgroups leave at once).
 template <typename T, typename Op, int U>
 static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
-                       const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
+                       const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint,
+                       bool redo_nan = false) {
     constexpr int VN = Vec<T>::N;
     const size_t nv = n / VN;
     const size_t tiles = (nv + (size_t)kBlock * U - 1) / ((size_t)kBlock * U);
     // consecutive tiles per block: enough blocks to fill the chip several times over, setup amortised
     int tpb = 8;
     while (tpb > 1 && (tiles / tpb) * batch < 4096) tpb >>= 1;
+    // redo of a few flagged instances: most workgroups only read their instance's flag and leave - long runs per block keep
+    // the dispatch of those short (a clean 64 x 1e6 update pays ~6 us for the three launches instead of ~20)
+    if (redo_nan) tpb = 64;
     const unsigned ntile = (unsigned)((tiles + tpb - 1) / tpb);          // blocks (= partials) per instance
     if (hint) {
         store_r = false;
@@ -543,9 +574,16 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
     const size_t r_bytes = store_r ? ((batch * n * sizeof(T) + 255) / 256) * 256 : 0;
     const size_t scal_bytes = ((batch * sizeof(double) + 255) / 256) * 256;
     const size_t part_bytes = hint ? 0 : batch * (size_t)ntile * (sizeof(double) + sizeof(unsigned long long));
-    int rc = tramp_ws_reserve(ctx, r_bytes + scal_bytes + part_bytes);
+    const size_t head = redo_nan ? ((batch * sizeof(unsigned) + 255) / 256) * 256 : 0;
+    int rc = tramp_ws_reserve(ctx, head + r_bytes + scal_bytes + part_bytes);
     if (rc) return rc;
-    char* ws = reinterpret_cast<char*>(ctx->ws);
+    char* ws = reinterpret_cast<char*>(ctx->ws) + head;
+    const unsigned* only = nullptr;
+    if (redo_nan) {
+        unsigned* flags = reinterpret_cast<unsigned*>(ctx->ws);
+        hipLaunchKernelGGL(ew_flag_nan, dim3(1), dim3(kBlock), 0, ctx->stream, batch, (const double*)out.a_new, flags, ctx->lean_stat);
+        only = flags;
+    }
     T* rbuf = store_r ? reinterpret_cast<T*>(ws) : nullptr;
     double* scal = reinterpret_cast<double*>(ws + r_bytes);
     double* partials = reinterpret_cast<double*>(ws + r_bytes + scal_bytes);
@@ -560,36 +598,36 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
         dim3 grid(ntile, nb), block(kBlock);
         if (hint) {
             hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, inst0, a_in_d, hint->partials,
-                               (const unsigned long long*)nullptr, hint->nblk, o, scal + inst0);
+                               (const unsigned long long*)nullptr, hint->nblk, o, scal + inst0, only);
         } else {
             hipLaunchKernelGGL((ew_moments_tile<T, Op, U>), grid, block, 0, ctx->stream, op, n, inst0, tpb, p0, p1,
                                rbuf ? rbuf + inst0 * n : nullptr, partials + inst0 * ntile,
-                               pcount ? pcount + inst0 * ntile : nullptr, out.mask);
+                               pcount ? pcount + inst0 * ntile : nullptr, out.mask, only);
             hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, (size_t)0, a_in_d,
                                partials + inst0 * ntile, pcount ? pcount + inst0 * ntile : nullptr, (int)ntile, o,
-                               scal + inst0);
+                               scal + inst0, only);
         }
         // outputs past the Infinity Cache are streamed around the caches (+6 % on the box's copy rate)
         const bool nts = (double)n * (double)batch * sizeof(T) > 192.0 * 1024 * 1024;
         // the apply pass of the light ops has next to no per-block setup to amortise: shorter runs per block
         // stream faster (fused Gauss-Bernoulli / L1 update at 64 x 1e6: 173 / 180 us with 2 tiles per block
         // against 192 / 190 with 8; gpurun_out/r03/fused1.log)
-        const int tpa = Op::HEAVY ? tpb : (tpb > 2 ? 2 : tpb);
+        const int tpa = (Op::HEAVY || redo_nan) ? tpb : (tpb > 2 ? 2 : tpb);
         dim3 grid_a((unsigned)((tiles + tpa - 1) / tpa), nb);
         if (store_r) {
             if (nts)
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, true>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
-                                   p0, p1, rbuf + inst0 * n, scal + inst0, o);
+                                   p0, p1, rbuf + inst0 * n, scal + inst0, o, only);
             else
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, false>), grid_a, block, 0, ctx->stream, op, n, inst0,
-                                   tpa, p0, p1, rbuf + inst0 * n, scal + inst0, o);
+                                   tpa, p0, p1, rbuf + inst0 * n, scal + inst0, o, only);
         } else {
             if (nts)
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, true>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
-                                   p0, p1, (const T*)nullptr, scal + inst0, o);
+                                   p0, p1, (const T*)nullptr, scal + inst0, o, only);
             else
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, false>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
-                                   p0, p1, (const T*)nullptr, scal + inst0, o);
+                                   p0, p1, (const T*)nullptr, scal + inst0, o, only);
         }
     }
     TRAMP_LAUNCH_CHECK(ctx);
@@ -601,27 +639,30 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
 // U = 2 tile): not better in the update
 template <typename T, typename Op>
 static int run_tiles(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0, const void* in1,
-                     const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint) {
+                     const double* a_in_d, const MsgOut& out, bool store_r, const TrampPriorHint* hint, bool redo_nan = false) {
     // two-input heavy factors (K7): one piece per thread and tile - 326 us against 396 (U = 2) and 357 (U = 4) for the
     // moments pass at 64 x 1e6 f64 (tools/probes/probe_k7.hip, round 5: the evaluation's temporaries times U is what the
     // compiler's schedule keeps live)
     if constexpr (Op::HEAVY && Op::NIN > 1 && sizeof(T) == 8)
-        return run_tiles_u<T, Op, 1>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
+        return run_tiles_u<T, Op, 1>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint, redo_nan);
     else
-        return run_tiles_u<T, Op, kTileU>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint);
+        return run_tiles_u<T, Op, kTileU>(ctx, op, n, batch, in0, in1, a_in_d, out, store_r, hint, redo_nan);
 }
 
-bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size) {
+bool resident_covers_shape(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size, size_t tv, int bpc) {
     static const size_t on = env_size("TRAMP_EW_RESIDENT", 1);
     static const size_t min_rounds = env_size("TRAMP_EW_RESIDENT_MIN_ROUNDS", 4);
-    const size_t vn = 16 / elem_size, tv = (size_t)kBlock * kResU;
+    const size_t vn = 16 / elem_size;
     if (!on || !ctx || ctx->num_cu < 16 || batch == 0 || (n % vn) != 0) return false;
     const size_t nv = n / vn;
     // smaller instances: one workgroup each (ew_single); the tile offsets are 32-bit
     if (n <= (size_t)kBlock * kSingleVpt * vn || nv < tv || nv > 0x7fffffffull || batch > 0x3fffffffull) return false;
-    const size_t ps = (size_t)2 * ctx->num_cu - 8, tiles = (nv + tv - 1) / tv;
+    const size_t ps = (size_t)bpc * ctx->num_cu - 8, tiles = (nv + tv - 1) / tv;
     // an instance must fit the window of rounds the pipeline keeps in flight, and there must be rounds to overlap
     return tiles <= ps * (kResDA - 2) + 1 && batch * tiles >= min_rounds * ps;
+}
+bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size) {
+    return resident_covers_shape(ctx, n, batch, elem_size, (size_t)kBlock * kResU, 2);        // kResBlocksPerCU (ew_resident.h; static_assert in ew_resident_impl.h)
 }
 
 template <typename T, typename Op>
@@ -967,10 +1008,28 @@ static int pwl_dir(tramp_ctx* ctx, int dir, size_t n, size_t batch, const double
     if constexpr (KIND < 3) {
         if (res_k7 && n && batch && bz_d && bx_d && az_d && ax_d && out.a_new && out.b_new &&
             (out.damping == 0.0 || (out.a_old && out.b_old))) {
-            int rc;
-            if (dir == TRAMP_FWD) rc = run_resident<T>(ctx, PwlOp<T, KIND, true, true, true>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, ax_d, out);
-            else rc = run_resident<T>(ctx, PwlOp<T, KIND, false, true, true>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, az_d, out);
-            if (rc != kResNotEligible) return rc;
+            // The lean form covers erfcx arguments in [-7.5, 8) (|b| / sqrt(a) up to ~10: moderate signal-to-noise messages); an instance with a
+            // component outside comes back with a_new = NaN and is redone by the tile kernels (run_tiles: redo_nan).  Wide
+            // messages flag most instances and would pay both: the count of the PREVIOUS lean call (pinned host word, read
+            // without synchronising - a heuristic, either path is exact) sends the next 15 calls straight to the tile kernels.
+            static const size_t adapt = env_size("TRAMP_EW_LEAN_ADAPT", 1);
+            if (ctx->lean_stat && ctx->lean_stat[1]) {
+                if (adapt && 4u * ctx->lean_stat[0] > ctx->lean_stat[1]) ctx->lean_skip = 15;
+                ctx->lean_stat[1] = 0;
+            }
+            if (ctx->lean_skip > 0) {
+                ctx->lean_skip -= 1;
+            } else {
+                int rc;
+                if (dir == TRAMP_FWD) rc = run_resident<T>(ctx, PwlOp<T, KIND, true, true, true>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, ax_d, out);
+                else rc = run_resident<T>(ctx, PwlOp<T, KIND, false, true, true>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, az_d, out);
+                if (rc == TRAMP_OK) {
+                    // (resident_covers implies whole 16-byte pieces per instance: the tile kernels apply)
+                    if (dir == TRAMP_FWD) return run_tiles<T>(ctx, PwlOp<T, KIND, true>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, ax_d, out, true, nullptr, true);
+                    return run_tiles<T>(ctx, PwlOp<T, KIND, false>{az_d, ax_d, spec}, n, batch, bz_d, bx_d, az_d, out, true, nullptr, true);
+                }
+                if (rc != kResNotEligible) return rc;
+            }
         }
     }
     if (dir == TRAMP_FWD) {

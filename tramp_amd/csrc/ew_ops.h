@@ -12,7 +12,8 @@ using tmath::RV;
 // ---------------------------------------------------------------- functors
 // Each Op: setup(b) loads the per-instance scalars; eval(in0, in1) -> (r, v, mask);
 // a_msg / TARGET select the message being updated.
-template <typename T> struct EwOut { T r, v; unsigned mask; };
+// dev: lean ops only (OpLean) - 0 where the evaluation was inside its form's domain, positive or NaN where not
+template <typename T> struct EwOut { T r, v; unsigned mask; T dev = T(0); };
 
 template <typename T> struct GbOp {       // K1; in0 = bx
     static constexpr bool HEAVY = false;
@@ -207,9 +208,10 @@ template <typename T, int KIND, bool FWD, bool UNI = true, bool LEAN = false> st
     tmath::PwlSpec spec;          // used by KIND 3 only
     tmath::PwlConst<T> c;
     double a_msg;
-    using Full = PwlOp<T, KIND, FWD, UNI, false>;      // the form with the region-by-region fall-back (redo of a flagged instance)
-    __device__ __host__ Full full() const { return Full{az, ax, spec}; }
-    __device__ static void stage() { tmath::erfcx_setup<T, UNI>(); }
+    __device__ static void stage() {
+        if (LEAN) tmath::erfcx_setup_tay<T>();
+        else tmath::erfcx_setup<T, UNI>();
+    }
     __device__ void prepare(size_t b) {
         const double z = az[b], x = ax[b];
         c = tmath::pwl_const<T, KIND>(z, x, spec);
@@ -219,8 +221,9 @@ template <typename T, int KIND, bool FWD, bool UNI = true, bool LEAN = false> st
     __device__ EwOut<T> eval(T x0, T x1) const {
         if constexpr (LEAN && KIND < 3) {
             tmath::PwlOut<T> o;
-            const bool ok = tmath::pwl_moment_form<T, KIND, FWD, UNI, false>(x0, x1, c, o);
-            return {o.r, o.v, o.mask | (ok ? 0u : 0x80000000u)};
+            T dev;
+            tmath::pwl_moment_form<T, KIND, FWD, UNI, false>(x0, x1, c, o, &dev);
+            return {o.r, o.v, o.mask, dev};
         } else {
             tmath::PwlOut<T> o = tmath::pwl_posterior_fast<T, KIND, FWD, UNI>(x0, x1, c);
             return {o.r, o.v, o.mask};
@@ -233,8 +236,9 @@ template <typename T, int KIND, bool FWD, bool UNI = true, bool LEAN = false> st
 template <typename Op> struct OpBits { static constexpr bool value = false; };
 template <typename T> struct OpBits<SgnLikBitsOp<T>> { static constexpr bool value = true; };
 
-// Lean ops (the resident pipeline's K7): eval() covers the moment form's domain only and reports a lane outside it in bit
-// 31 of EwOut::mask; the pipeline flags the instance and a second kernel redoes it on Op::Full (ew_resident.h).
+// Lean ops (the resident pipeline's K7): eval() covers the moment form's domain only and reports a lane outside it in
+// EwOut::dev (non-zero or NaN); the pipeline poisons the instance's a_new and the caller redoes it on the full form
+// (ew_resident.h, ew_kernels.hip: pwl_dir).
 template <typename Op> struct OpLean { static constexpr bool value = false; };
 template <typename T, int KIND, bool FWD, bool UNI> struct OpLean<PwlOp<T, KIND, FWD, UNI, true>> { static constexpr bool value = true; };
 

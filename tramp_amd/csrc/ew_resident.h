@@ -44,7 +44,6 @@ struct ResArgs {
     unsigned long long* scal;         // [batch] bits of a_in + a_new
     const uint8_t* bits;              // OpBits factors: the second input, one bit per component, rows of bits_stride bytes
     size_t bits_stride;
-    unsigned* redo;                   // [batch] lean ops: instance i had a lane outside the lean form's domain (ew_res_redo)
     void* dummy;                      // 256 U 16-byte pieces: where the overlap of an instance's last tile is "stored"
     MsgOut out;
 };
@@ -89,7 +88,6 @@ __global__ __launch_bounds__(kBlock) void ew_res_prepare(Op op, ResArgs A, Op* _
     }
     if (i < A.batch) {
         A.scal[i] = kResSentinel;
-        if (A.redo) A.redo[i] = 0u;
         Op o = op;
         o.prepare(i);
         ops[i] = o;
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
             const unsigned off = min(first, nv - TV) + tid;
             double acc = 0.0;
             unsigned long long cnt = 0;
-            unsigned bad = 0;                                           // lean ops: a lane outside the form's domain
+            T bad = T(0);                                               // lean ops: sum of EwOut::dev (0 = every lane inside the form's domain)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const unsigned i = off + u * NT;
@@ -307,7 +305,10 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                     T a1 = (Op::NIN > 1) ? vget<T>(x1[sM][u], c) : a0;
                     if (BITS) a1 = ((xb[sM][u] >> (((i * VN) & 7u) + c)) & 1u) ? T(1) : T(-1);
                     EwOut<T> o = op.eval(a0, a1);
-                    if (OpLean<Op>::value) bad |= o.mask;
+                    if (OpLean<Op>::value) {
+                        bad += o.dev;
+                        if (FLAGS & kResSchedBarrier) __builtin_amdgcn_sched_barrier(0);       // one component at a time
+                    }
                     double vi = (double)o.v;
                     if (not_finite(o.r)) vi = __longlong_as_double(0x7ff8000000000000LL);
                     acc += counts ? vi : 0.0;
@@ -331,10 +332,9 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                 // U times the temporaries, and the ring leaves no room for them
                 if (FLAGS & kResSchedBarrier) __builtin_amdgcn_sched_barrier(0);
             }
-            if (OpLean<Op>::value) {
-                // every writer stores the same 1: no atomic; the redo kernel runs after this one (stream order)
-                if (__any((bad >> 31) != 0) && (tid & (kWave - 1)) == 0) A.redo[r_inst[sM]] = 1u;
-            }
+            // a lean op that left its form's domain anywhere in the tile poisons the tile's sum: the instance's a_new comes
+            // out NaN, which is what the caller's redo on the tile kernels looks for (ew_kernels.hip: pwl_dir, ew_flag_nan) (a select, not a branch: no control flow in the pipelined body)
+            if (OpLean<Op>::value) acc += (bad == T(0)) ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
             acc = res_block_sum<NT>(acc, smem);
             if (COUNT) cnt = res_block_sum_u64<NT>(cnt, smem_u);
             if (tid == 0 && DBG != 1) {
@@ -398,45 +398,3 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
         });
 }
 
-
-// ---- redo of the instances a lean op flagged (A.redo): one workgroup per instance, the whole update again on Op::Full
-// (the form with the region-by-region fall-back), two sweeps over the instance.  Launched behind every lean resident
-// update; a workgroup whose instance is not flagged leaves at once.  Flags are raised by components within ~2 % of the
-// reference's log_Phi mask threshold (|y0| >= 29.4: 29 standard deviations), NaN and infinite messages and erfcx
-// arguments outside the table - none of which a converging EP run produces - so the sweep's speed does not matter; its
-// results are those of the tile kernels (same Op::eval, fixed summation order).
-template <typename T, typename FullOp>
-__global__ __launch_bounds__(kBlock) void ew_res_redo(FullOp op, size_t n, const unsigned* __restrict__ redo, const T* __restrict__ in0,
-                                                      const T* __restrict__ in1, const double* __restrict__ a_in_d, MsgOut out) {
-    const size_t b = blockIdx.x;
-    if (!redo[b]) return;
-    __shared__ double smem[kBlock / kWave];
-    op.setup(b);
-    const T* p0 = in0 + b * n;
-    const T* p1 = (FullOp::NIN > 1) ? in1 + b * n : nullptr;
-    double acc = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += kBlock) {
-        const T x0 = p0[i], x1 = (FullOp::NIN > 1) ? p1[i] : x0;
-        const EwOut<T> o = op.eval(x0, x1);
-        acc += not_finite(o.r) ? __longlong_as_double(0x7ff8000000000000LL) : (double)o.v;
-    }
-    acc = block_sum(acc, smem);                     // every thread holds the sum
-    const double v = acc / (double)n;
-    const double a_in = a_in_d[b];
-    const double a_new = tmath::a_new_of(v, a_in);
-    const double d = out.damping;
-    if (threadIdx.x == 0) {
-        out.a_new[b] = (d != 0.0) ? d * out.a_old[b] + (1.0 - d) * a_new : a_new;
-        if (out.v) out.v[b] = v;
-    }
-    const T vinv = T(a_in + a_new), dT = T(d), omd = T(1.0 - d);
-    const T* bold = (d != 0.0) ? reinterpret_cast<const T*>(out.b_old) + b * n : nullptr;
-    T* bo = reinterpret_cast<T*>(out.b_new) + b * n;
-    for (size_t i = threadIdx.x; i < n; i += kBlock) {
-        const T x0 = p0[i], x1 = (FullOp::NIN > 1) ? p1[i] : x0;
-        const T r = op.eval(x0, x1).r;
-        T bn = r * vinv - ((FullOp::TARGET == 0) ? x0 : x1);
-        if (bold) bn = dT * bold[i] + omd * bn;
-        bo[i] = bn;
-    }
-}

@@ -12,13 +12,17 @@ constexpr int kResNotEligible = 1000;      // run_resident: "take the tile kerne
 // 207 us f64 / 94 us f32; deeper rings spill, U = 8 with one workgroup per CU is 5-10 % slower, U = 2 15 % slower).
 constexpr int kResU = 4, kResDL = 1, kResDA = 3;
 
-// Threads per workgroup and 16-byte pieces per thread and tile (NT x U = 1024 pieces per tile for every factor).  The
-// two-region channels K7 run 512 threads x 2 pieces: four waves per SIMD with <= 128 registers each hide the latency of
-// their ~100-instruction evaluation, which two waves per SIMD do not (round 5; tools/probes/probe_k7.hip).
+// Threads per workgroup, 16-byte pieces per thread and tile, workgroups per CU, extra kernel flags.  Measured for the
+// two-region channels K7 in round 5 and dropped: 512 threads x 2 pieces (four waves per SIMD, <= 128 registers: 500-1300
+// spill instructions, 0.8 ms), the same with the target message read a second time instead of held in the ring
+// (kResReloadB: worse), 256 threads x 8 pieces on one workgroup per CU (512 registers: still spills).  Their LEAN form
+// (no control flow in the pipelined body) fits the standard shape.
 // FLAGS: extra kernel flags (ew_resident.h); 64 = kResReloadB, the target message is read a second time instead of being
 // held in registers.
-template <typename Op> struct ResShape { static constexpr int U = kResU, NT = kBlock, FLAGS = 0; };
-template <typename T, int KIND, bool FWD, bool UNI, bool LEAN> struct ResShape<PwlOp<T, KIND, FWD, UNI, LEAN>> { static constexpr int U = 4, NT = 256, FLAGS = 0; };
+template <typename Op> struct ResShape { static constexpr int U = kResU, NT = kBlock, FLAGS = 0, BPC = 2; };
+template <typename T, int KIND, bool FWD, bool UNI, bool LEAN> struct ResShape<PwlOp<T, KIND, FWD, UNI, LEAN>> {
+    static constexpr int U = kResU, NT = kBlock, FLAGS = 0, BPC = 2;
+};
 
 template <typename Op> struct ResidentOp { static constexpr bool value = false; };
 template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value = true; };
@@ -34,6 +38,8 @@ template <typename T> struct ResidentOp<ReluLikOp<T>> { static constexpr bool va
 // rows).  Shared with the producers of prior_hint.h: an FFT epilogue whose consumer takes the resident form leaves no
 // moments (they cost it +45...65 us at 64 x 1e6, more than the resident update costs over the plain apply pass).
 bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size);
+// the same test for a pipeline of `bpc` workgroups per CU and tiles of `tile_pieces` 16-byte pieces
+bool resident_covers_shape(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_size, size_t tile_pieces, int bpc);
 
 // TRAMP_OK: the update ran (launched) in the resident form; kResNotEligible: shape or outputs it does not cover;
 // anything else: an error, ctx->err is set.

@@ -10,13 +10,13 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
                  const double* a_in_d, const MsgOut& out, const void* bits, size_t bits_stride) {
     constexpr int VN = Vec<T>::N;
     constexpr int XF = ResShape<Op>::FLAGS;
-    constexpr int U = ResShape<Op>::U, NT = ResShape<Op>::NT, DL = kResDL, DA = kResDA, BPC = kResBlocksPerCU;
+    constexpr int U = ResShape<Op>::U, NT = ResShape<Op>::NT, DL = kResDL, DA = kResDA, BPC = ResShape<Op>::BPC;
     constexpr size_t TV = (size_t)NT * U;
-    static_assert(TV == (size_t)kBlock * kResU, "resident_covers (ew_kernels.hip) counts tiles of kBlock x kResU pieces");
-    if (out.mask || out.r || !resident_covers(ctx, n, batch, sizeof(T))) return kResNotEligible;
+    if (out.mask || out.r || !resident_covers_shape(ctx, n, batch, sizeof(T), TV, BPC)) return kResNotEligible;
     constexpr bool LEAN = OpLean<Op>::value;
     if (LEAN) {
-        // a flagged instance is redone FROM ITS INPUTS after the pipeline has written its outputs: no in-place updates
+        // a flagged instance is redone FROM ITS INPUTS (by the caller, on the tile kernels) after the pipeline has written its
+        // outputs: no in-place updates
         const char *o0 = reinterpret_cast<const char*>(out.b_new), *o1 = o0 + batch * n * sizeof(T);
         for (const void* in : {in0, in1}) {
             const char* i0 = reinterpret_cast<const char*>(in);
@@ -47,9 +47,8 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
     const size_t slot_bytes = ((A.total * 8 + 255) / 256) * 256;
     const size_t scal_bytes = ((batch * 8 + 255) / 256) * 256;
     const size_t dummy_bytes = TV * 16;
-    const size_t redo_bytes = LEAN ? ((batch * 4 + 255) / 256) * 256 : 0;
     const bool count = OpCounts<Op>::value;
-    int rc = tramp_ws_reserve(ctx, ops_bytes + slot_bytes * (count ? 2 : 1) + scal_bytes + dummy_bytes + redo_bytes);
+    int rc = tramp_ws_reserve(ctx, ops_bytes + slot_bytes * (count ? 2 : 1) + scal_bytes + dummy_bytes);
     if (rc) return rc;
     char* ws = reinterpret_cast<char*>(ctx->ws);
     Op* ops = reinterpret_cast<Op*>(ws);
@@ -64,8 +63,6 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
     A.scal = reinterpret_cast<unsigned long long*>(ws);
     ws += scal_bytes;
     A.dummy = ws;
-    ws += dummy_bytes;
-    A.redo = LEAN ? reinterpret_cast<unsigned*>(ws) : nullptr;
     A.bits = reinterpret_cast<const uint8_t*>(bits);
     A.bits_stride = bits_stride;
     if (OpBits<Op>::value && !bits) return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "packed observation");
@@ -79,13 +76,6 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
         hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, kResDamp | kResSchedBarrier | XF, BPC, 0, NT>), dim3(P), dim3(NT), 0, ctx->stream, (const Op*)ops, A, p0, p1);
     else
         hipLaunchKernelGGL((ew_resident<T, Op, U, DL, DA, kResSchedBarrier | XF, BPC, 0, NT>), dim3(P), dim3(NT), 0, ctx->stream, (const Op*)ops, A, p0, p1);
-    if constexpr (LEAN) {
-        // the flagged instances again, on the form with the fall-back (ew_res_redo); MsgOut as the caller gave it
-        MsgOut o = out;
-        if (!damp) { o.a_old = nullptr; o.b_old = nullptr; o.damping = 0.0; }
-        hipLaunchKernelGGL((ew_res_redo<T, typename Op::Full>), dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, op.full(), n,
-                           (const unsigned*)A.redo, p0, p1, a_in_d, o);
-    }
     TRAMP_LAUNCH_CHECK(ctx);
     ctx->resident_runs += 1;
     return TRAMP_OK;

@@ -102,13 +102,13 @@ namespace tmath {
 // pace: 487 us for the 109-instruction sign likelihood against 280 us for the 163-instruction abs one.)
 // Every kernel that evaluates erfcx_hot calls erfcx_lds_init() first (all threads; it ends in a barrier).
 __shared__ double g_erfcx_lds[(kErfcxD + 1) * kErfcxK];
-// Round 5: the second table holds ONE value per grid point, erfcx(x_k) at x_k = -5 + k / 128 (erfcx_ttable.h, 13 KiB of
-// LDS; f32: k / 64, 3.3 KiB): erfcx' = 2 x erfcx - 2/sqrt(pi) gives every Taylor coefficient about x_k from that value by
+// Round 5: the second table holds ONE value per grid point, erfcx(x_k) at x_k = -7.5 + k / 128 (erfcx_ttable.h, 15.5 KiB
+// of LDS; f32: k / 64, 3.9 KiB): erfcx' = 2 x erfcx - 2/sqrt(pi) gives every Taylor coefficient about x_k from that value by
 // a three-term recurrence, so an evaluation is one 8-byte LDS read and ~30 VALU instructions, no reciprocal, and no
 // exp(x^2) for negative arguments.  (Round 3's table held a degree-7 polynomial per interval of 1/32: eight reads per
 // evaluation, rows colliding in the banks - the LDS, not the VALU, set the pace of the two-region channels K7:
 // tools/probes/probe_k7.hip, 427 us against 358 us for the moments pass at 64 x 1e6.)  Taken when every lane of the wave
-// is inside [-5, 8), else the whole wave evaluates the reciprocal-mapped table below.  Used by K7 (erfcx_hot<true>,
+// is inside [-7.5, 8), else the whole wave evaluates the reciprocal-mapped table below.  Used by K7 (erfcx_hot<true>,
 // pwl_moment_form).  -DTRAMP_ERFCX_UNIFORM=0 removes it.
 #if TRAMP_ERFCX_UNIFORM
 __shared__ double g_erfcx_tlds[kErfcxTK];
@@ -229,7 +229,7 @@ TM_HD float rcp_pos(float x) { return hw::rcp_est(x); }
 #if TRAMP_ERFCX_UNIFORM
 // erfcx by the Taylor recurrence about the nearest grid point, for x KNOWN to lie in [kErfcxTLo, kErfcxTHi) (the caller's
 // wave vote): t_0 = f_k, t_1 = d (a f_k - 2/sqrt(pi)), t_{n+1} = (u t_n + w t_{n-1}) / (n + 1) with a = 2 x_k, u = a d,
-// w = 2 d^2 (tools/gen_erfcx_ttable.py: 2e-15 on [-3, 8), 4e-14 down to -5)
+// w = 2 d^2 (tools/gen_erfcx_ttable.py: 2e-15 on [-3, 8), 4e-14 down to -5, 6e-13 down to -7.5)
 TM_HD double erfcx_tay(double x) {
     const double s = x - kErfcxTLo;
     const double kf = __builtin_rint(s * kErfcxTPer);
@@ -310,6 +310,18 @@ template <typename T, bool UNI = false> TM_HD void erfcx_setup() {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (sizeof(T) == 8) erfcx_lds_init<UNI>();
     else erfcx_lds_init_f<UNI>();
+#endif
+}
+
+// the one-value table alone (the lean K7 form of the resident pipeline never leaves it: 2 KiB of LDS less)
+template <typename T> TM_HD void erfcx_setup_tay() {
+#if defined(__HIP_DEVICE_COMPILE__) && TRAMP_ERFCX_UNIFORM
+    if (sizeof(T) == 8) {
+        for (int i = threadIdx.x; i < kErfcxTK; i += blockDim.x) g_erfcx_tlds[i] = kErfcxTTable[i];
+    } else {
+        for (int i = threadIdx.x; i < kErfcxTKF; i += blockDim.x) g_erfcx_tlds_f[i] = kErfcxTTableF[i];
+    }
+    __syncthreads();
 #endif
 }
 
@@ -819,7 +831,7 @@ TM_HD PwlOut<T> pwl_posterior_regions(T bz, T bx, const PwlConst<T>& c) {
 // heavier region, so M2 - M1^2 cancels at most like (distance between the region means)^2 / v - never like r^2 / v.
 // Forward direction (posterior of x = slope z + x0): a region of slope 0 is the point mass x0_k; slope +-1 enters with
 // rho_k = slope_k r0_k and G_k -> slope_k G_k.
-// Taken when EVERY lane of the wave has both arguments on the erfcx grid [-5, 8) (UNI; else: far from the reference's
+// Taken when EVERY lane of the wave has both arguments on the erfcx grid [-7.5, 8) (UNI; else: far from the reference's
 // log_Phi mask threshold, |x| < 0.98 cut / sqrt2, where e is finite), so mask = 3 by construction; any other wave - a lane near
 // or under the mask, a NaN, an infinity - takes pwl_posterior_regions, the literal region-by-region form.
 template <typename T> struct PwlMomentLim;
@@ -829,8 +841,11 @@ template <> struct PwlMomentLim<float> { static constexpr float value = 0.98f * 
 // VOTE = false (the resident pipeline's lean form): no wave vote and no early return - every lane is evaluated with its
 // erfcx arguments clamped into the domain, and the function returns whether THIS lane was inside it; the caller flags
 // the instance and redoes it on the region-by-region form (ew_resident.h).
+// `dev` (VOTE = false): sum of squares of what the clamps moved - 0 inside the domain, positive outside, NaN for a NaN /
+// infinite message (a float the caller accumulates: lane masks kept alive across the evaluation cost the resident
+// pipeline its registers).
 template <typename T, int KIND, bool FWD, bool UNI, bool VOTE = true>
-TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o) {
+TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o, T* dev = nullptr) {
     static_assert(KIND >= 0 && KIND < 3, "Sgn / Abs / Relu only");
     constexpr double sl0 = pwl_slope(KIND, 0), sl1 = pwl_slope(KIND, 1);
     // b_k = bz + slope_k (bx - ax x0_k): x0 = 0 wherever the slope is not (Abs, Relu); slope 0: b_k = bz
@@ -845,8 +860,14 @@ TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o) {
     if (VOTE) {
         if (!TM_WAVE_ALL(ok)) return false;
     } else if (GRID) {                     // (a NaN becomes the lower edge: minNum / maxNum)
-        x0 = fmin_(fmax_(x0, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
-        x1 = fmin_(fmax_(x1, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
+        const T c0 = fmin_(fmax_(x0, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
+        const T c1 = fmin_(fmax_(x1, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
+        const T d0 = x0 - c0, d1 = x1 - c1;
+        T dv = fma_(d0, d0, d1 * d1);
+        if (KIND == 0) dv += bx - bx;      // bx enters through exp only
+        *dev = dv;
+        x0 = c0;
+        x1 = c1;
     }
     T e0, e1;
 #if TRAMP_ERFCX_UNIFORM

@@ -12,6 +12,7 @@ SWITCHES = {
     # componentwise updates (csrc/ew_kernels.hip, ew_resident.h)
     "TRAMP_EW_RESIDENT": ("1", "select", "0: never take the resident single-pass pipeline (the tile kernels' two passes instead)"),
     "TRAMP_EW_RESIDENT_K7": ("1", "select", "0: the Sgn / Abs / Relu channels stay on the tile kernels' two passes"),
+    "TRAMP_EW_LEAN_ADAPT": ("1", "select", "0: a lean resident K7 update that had to redo more than a quarter of its instances does not send the next 15 calls to the tile kernels"),
     "TRAMP_EW_RESIDENT_MIN_ROUNDS": ("4", "tune", "rounds of 2 x CUs - 8 tiles below which the pipeline is not worth its fill and drain"),
     "TRAMP_PRIOR_FUSE": ("1", "select", "0: producers never leave prior / likelihood moments (csrc/prior_hint.h)"),
     # dense linear channel (csrc/linear.hip, gemm_mfma.hip)
