@@ -302,6 +302,12 @@ int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed, unsigned l
  * tile kernels.  Same entry points, same results to reduction-order rounding, run-to-run reproducible; chosen by shape
  * (TRAMP_EW_RESIDENT=0 turns it off).  How many updates took that form since the context was made: */
 int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs);
+/* The pipeline's workgroups hand tile sums to each other and must all be resident at once (checked by an occupancy query
+ * before every launch).  Should a hand-off still not arrive within the kernel's deadline (2 s; a CU mask or another
+ * process's kernels on the device can do that), the waiting workgroups give up: the update of the affected instances
+ * comes back NaN - never a trap, never a wrong number - and every later call of this context takes the tile kernels.
+ * *gave_up = 1 once that has happened. */
+int tramp_resident_errors(tramp_ctx* ctx, unsigned long long* gave_up);
 /* *yes = 1 when updates of `batch` instances of n components in `dtype` take the resident form (a host-side shape
  * test: the scheduler asks before it arms a producer for a consumer that would not use the moments) */
 int tramp_resident_covers(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int* yes);

@@ -1,0 +1,73 @@
+"""tramp_amd.compat.Backend against the REAL library (the reference itself does not travel to the GPU box): every strict-
+mode call the binding of tests/test_compat_reference.py makes - same argument lists - compared with the oracle, i.e. with
+what the reference's own compute_*_message methods return (tramp/priors/base_prior.py:13-16, likelihoods/
+base_likelihood.py:25-28, channels/base_channel.py:9-17, channels/linear/linear_channel.py:69-117).  f64, 1e-9."""
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from tramp_amd import compat
+    b = compat.Backend()
+    yield b
+    b.close()
+
+
+def close(got, ref, scale=None):
+    a_g, b_g = got
+    a_r, b_r = ref
+    assert a_g == pytest.approx(a_r, rel=1e-9)
+    sc = np.abs(b_r).max() if scale is None else scale
+    np.testing.assert_allclose(b_g, b_r, rtol=1e-9, atol=1e-9 * max(sc, 1e-300))
+
+
+def test_priors_and_likelihoods(be):
+    rs = np.random.RandomState(4)
+    n = 1000
+    b = rs.standard_normal(n) * 2
+    close(be.gb_prior_forward_message(1.3, b, 0.1, 0.2, 1.5), orc.gb_prior_message(1.3, b, rho=0.1, mean=0.2, var=1.5))
+    close(be.l1_prior_forward_message(0.8, b, 1.1), orc.l1_prior_message(0.8, b, gamma=1.1))
+    close(be.gauss_prior_forward_message(b, 0.3, 2.0), orc.gauss_prior_message(1.0, b, mean=0.3, var=2.0))
+    y = rs.standard_normal(n)
+    close(be.gauss_lik_backward_message(b, y, 0.05), orc.gauss_lik_message(1.0, b, y, var=0.05))
+    ys = np.sign(y)
+    close(be.sgn_lik_backward_message(1.7, b, ys), orc.sgn_lik_message(1.7, b, ys))
+    close(be.abs_lik_backward_message(1.7, b, np.abs(y)), orc.abs_lik_message(1.7, b, np.abs(y)))
+    # shapes survive: a message of shape (4, 5) comes back as (4, 5)
+    a_new, b_new = be.gb_prior_forward_message(1.3, b[:20].reshape(4, 5), 0.1, 0.0, 1.0)
+    assert b_new.shape == (4, 5) and isinstance(a_new, float)
+
+
+@pytest.mark.parametrize("kind", ["sgn", "abs", "relu"])
+def test_pwl_channels(be, kind):
+    from tramp_amd import _lib as L
+    rs = np.random.RandomState(6)
+    n = 513
+    bz, bx = rs.standard_normal(n) * 1.5, rs.standard_normal(n)
+    code = dict(sgn=L.SGN, abs=L.ABS, relu=L.RELU)[kind]
+    for d, dc in (("fwd", L.FWD), ("bwd", L.BWD)):
+        ref = orc.pwl_channel_message(kind, d, 1.3, bz, 0.7, bx)
+        close(be.pwl_channel_message(code, dc, 1.3, bz, 0.7, bx), ref, scale=10 * max(np.abs(ref[1]).max(), 1.0))
+
+
+@pytest.mark.parametrize("shape", [(24, 48), (40, 40), (48, 32)])
+def test_linear_channel_from_the_reference_svd(be, shape):
+    "factors exactly as the reference's LinearChannel.__init__ holds them (full U, rectangular S, full V: linear_channel.py:8-15)"
+    from tramp_amd import _lib as L
+    M, N = shape
+    rs = np.random.RandomState(M)
+    W = rs.randn(M, N) / np.sqrt(N)
+    lin = orc.LinearOracle(W)
+    h = be.linear_create(lin.U, lin.S, lin.V, lin.rank)
+    try:
+        bz, bx = rs.standard_normal(N), rs.standard_normal(M)
+        for az, ax in ((1.3, 0.7), (2.0, 0.0), (0.4, 5.0)):
+            close(be.linear_message(h, L.FWD, az, bz, ax, bx), lin.forward_message(az, bz, ax, bx))
+            close(be.linear_message(h, L.BWD, az, bz, ax, bx), lin.backward_message(az, bz, ax, bx))
+    finally:
+        be.linear_destroy(h)

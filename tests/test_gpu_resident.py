@@ -393,3 +393,28 @@ def test_pwl_resident_damping_and_aliased_output(T, ctx, dtype):
     b_new = bio.get()
     for i in range(0, B, 7):
         close(b_new[i], b_ref[i], dtype, scale=10 * max(np.abs(b_ref[i]).max(), 1.0))
+
+
+@pytest.mark.parametrize("which", ["relu", "gb"])
+def test_resident_gives_up_cleanly(which):
+    """A hand-off that never arrives (forced: one tile's sum is withheld, deadline 150 ms) must not trap.  The kernel
+    drains with NaN for the instances it could not finish and raises the host-visible error word; the context takes the
+    tile kernels from then on.  For the lean K7 form the NaN instances are redone by the tile kernels in the same call:
+    no NaN reaches the caller and the redone instances equal a pure tile-kernel run bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRAMP_EW_RESIDENT_TIMEOUT_MS="150", TRAMP_EW_RESIDENT_DBG_SKIP="19")    # tile 4 of instance 2
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_resident_giveup_worker.py"), which], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]                # (a trap would have killed the process)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["resident_ran"] and out["gave_up"] and out["second_call_on_tiles"], out
+    assert out["nan_instances_second"] == 0 and out["oracle_instance0"] and out["finite_agree"], out
+    if which == "relu":
+        assert out["nan_instances_first"] == 0, out                       # redone in the same call
+        assert out["bitwise_equal_instances"] >= 1, out                   # the withheld instance: computed by the tile kernels both times
+    else:
+        assert 1 <= out["nan_instances_first"] < out["B"], out            # loud, and confined to the instances not finished

@@ -55,7 +55,7 @@ extern "C" int tramp_ctx_create(int device, tramp_ctx** out) {
     }
     unsigned* stat = nullptr;
     if (hipHostMalloc((void**)&stat, 64, hipHostMallocDefault) == hipSuccess) {       // (without it the lean updates keep no statistics)
-        stat[0] = stat[1] = 0;
+        stat[0] = stat[1] = stat[2] = 0;
         ctx->lean_stat = stat;
     } else {
         (void)hipGetLastError();
@@ -265,6 +265,12 @@ extern "C" int tramp_resident_covers(tramp_ctx* ctx, int dtype, size_t n, size_t
 extern "C" int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs) {
     if (!ctx || !runs) return TRAMP_EINVAL;
     *runs = ctx->resident_runs;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_resident_errors(tramp_ctx* ctx, unsigned long long* gave_up) {
+    if (!ctx || !gave_up) return TRAMP_EINVAL;
+    *gave_up = (ctx->lean_stat && ctx->lean_stat[2]) ? 1ull : 0ull;
     return TRAMP_OK;
 }
 

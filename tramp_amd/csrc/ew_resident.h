@@ -23,7 +23,8 @@
 // An instance must fit the window: tiles per instance <= P (DA - 2) + 1.  Larger instances and ragged n take the tile
 // kernels.  Deadlock freedom: round k's update waits only for moments of rounds <= k + S (S = rounds an instance can
 // straddle beyond its first), which every workgroup evaluates before it waits for anything of round > k + S - DA; with
-// DA >= S + 2 and all P workgroups resident the dependence is acyclic.  Every spin is bounded (trap after ~2 s).
+// DA >= S + 2 and all P workgroups resident the dependence is acyclic.  Every wait is bounded by the kernel's deadline
+// (res_expired: NaN results and a host-visible error word, never a trap).
 #pragma once
 #include <type_traits>
 
@@ -45,6 +46,9 @@ struct ResArgs {
     const uint8_t* bits;              // OpBits factors: the second input, one bit per component, rows of bits_stride bytes
     size_t bits_stride;
     void* dummy;                      // 256 U 16-byte pieces: where the overlap of an instance's last tile is "stored"
+    volatile unsigned* err_host;      // pinned host word: set to 1 by a workgroup whose wait ran past the deadline
+    long long deadline_ticks;         // 100 MHz ticks from kernel start after which nobody waits any more (0: 2 s)
+    unsigned long long dbg_skip_plus1;  // debug: the tile (instance * tiles + tile, plus 1) whose sum is never published
     MsgOut out;
 };
 
@@ -57,8 +61,21 @@ __device__ __forceinline__ void res_store(unsigned long long* p, unsigned long l
 // s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima).  As a builtin
 // the compiler's own wait-count bookkeeping sees it: registers loaded before it are known to have arrived.
 constexpr int kWaitVm0 = 0x0F70;
+// probes only (tools/probes/probe_*resident.hip): the library's kernels never trap - see res_expired
 __device__ __forceinline__ void res_spin_check(long long t0) {
     if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000LL) __builtin_trap();   // 100 MHz: 2 s
+}
+// A hand-off that has not arrived by the kernel's deadline (2 s from its start unless ResArgs says otherwise) is given
+// up: the waiting workgroup sets the host-visible error word and goes on with NaN - the combiner publishes NaN for the
+// instance (a_new, v and the scalar the streaming workgroups wait for), a streaming workgroup writes a NaN update - so
+// the kernel drains and ENDS, the affected instances are loudly NaN, and the host (run_resident) takes the tile kernels
+// from then on (tramp_resident_errors counts).  What can make a hand-off late: fewer workgroups co-resident than the
+// occupancy query promised (a CU mask, another process's kernels on the device).
+// The combiners stop publishing real scalars AT the deadline (everything later is NaN); the streaming workgroups give up
+// only `grace` ticks after it, so a streaming workgroup never writes a NaN update for an instance whose a_new came out finite.
+__device__ __forceinline__ bool res_expired(long long t_start, const ResArgs& A, long long grace = 0) {
+    const long long lim = (A.deadline_ticks > 0 ? A.deadline_ticks : 200000000LL) + grace;
+    return (long long)__builtin_amdgcn_s_memrealtime() - t_start > lim;
 }
 
 template <typename T, bool NT> __device__ __forceinline__ typename Vec<T>::type res_ld(const typename Vec<T>::type* p) {
@@ -98,14 +115,14 @@ __global__ __launch_bounds__(kBlock) void ew_res_prepare(Op op, ResArgs A, Op* _
 // prior's support counts travel in a second slot array.
 constexpr unsigned kResCombiners = 8;
 
-template <bool COUNT> __device__ __forceinline__ void res_combiner(const ResArgs& A, unsigned c) {
+template <bool COUNT> __device__ __forceinline__ void res_combiner(const ResArgs& A, unsigned c, long long t_start) {
     const unsigned lane = threadIdx.x;
+    bool dead = false;                                     // the deadline has passed: NaN for every instance still to come
     for (unsigned inst = c; inst < A.batch; inst += kResCombiners) {
         const unsigned long long* sl = A.slots + (size_t)inst * A.tiles;
         const unsigned long long* cl = COUNT ? A.cslots + (size_t)inst * A.tiles : nullptr;
         double acc;
         unsigned long long cnt;
-        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
         for (;;) {
             bool ok = true;
             acc = 0.0;
@@ -137,7 +154,12 @@ template <bool COUNT> __device__ __forceinline__ void res_combiner(const ResArgs
             }
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(2);
-            res_spin_check(t0);
+            if (res_expired(t_start, A)) break;
+        }
+        if (dead || res_expired(t_start, A)) {             // (wave-uniform)
+            dead = true;
+            acc = __longlong_as_double(0x7ff8000000000000LL);
+            if (lane == 0 && A.err_host) *A.err_host = 1u;
         }
         acc = wave_sum(acc);
         if (COUNT) cnt = wave_sum_u64(cnt);
@@ -210,8 +232,9 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
     // register ring holds only the messages b.  (With r in registers too every factor but the two priors spilled.)
     __shared__ V r_lds[(FLAGS & kResRegR) ? 1 : DA + 1][U][NT];
     const unsigned tid = threadIdx.x;
+    const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
     if (blockIdx.x < kResCombiners) {
-        if (DBG != 1 && tid < kWave) res_combiner<COUNT>(A, blockIdx.x);
+        if (DBG != 1 && tid < kWave) res_combiner<COUNT>(A, blockIdx.x, t_start);
         return;
     }
     Op::stage();
@@ -341,20 +364,22 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                 unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
                 if (ab == kResSentinel) ab = 0x7ff8000000000000ull;
                 const size_t si = (size_t)r_inst[sM] * A.tiles + r_tile[sM];
-                res_store(A.slots + si, ab);
+                // (debug: one tile's sum goes to the dummy area instead - a select on the address, no branch)
+                unsigned long long* sdst = (si + 1 == A.dbg_skip_plus1) ? reinterpret_cast<unsigned long long*>(A.dummy) : A.slots + si;
+                res_store(sdst, ab);
                 if (COUNT) res_store(A.cslots + si, cnt);
             }
         }
         // ---- update of round j - DL - DA
         if (do_a) {
             if (sbits == kResSentinel) {
-                const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
                 do {
                     __builtin_amdgcn_s_sleep(4);
-                    res_spin_check(t0);
                     sbits = res_load(A.scal + r_inst[sA]);
                     __builtin_amdgcn_s_waitcnt(kWaitVm0);     // on EVERY way out of this loop nothing is pending
-                } while (sbits == kResSentinel);
+                } while (sbits == kResSentinel && !res_expired(t_start, A, 1000000LL));     // 10 ms after the combiners
+                // past the deadline: the sentinel's bits are a NaN - this round's update is written as NaN
+                if (sbits == kResSentinel && tid == 0 && A.err_host) *A.err_host = 1u;
             }
             const T vinv = T(__longlong_as_double((long long)sbits));
             const unsigned la = (lm + 1 > DA) ? 0 : lm + 1;             // (j - DL - DA) mod (DA + 1)

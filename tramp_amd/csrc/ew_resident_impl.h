@@ -1,5 +1,7 @@
 // ew_resident_impl.h - definition of run_resident; included only by the ew_resident_*.hip translation units.
 #pragma once
+#include <stdlib.h>
+
 #include "ew_resident.h"
 #include "ew_resident_host.h"
 
@@ -13,6 +15,14 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
     constexpr int U = ResShape<Op>::U, NT = ResShape<Op>::NT, DL = kResDL, DA = kResDA, BPC = ResShape<Op>::BPC;
     constexpr size_t TV = (size_t)NT * U;
     if (out.mask || out.r || !resident_covers_shape(ctx, n, batch, sizeof(T), TV, BPC)) return kResNotEligible;
+    // A resident update of this context missed a hand-off (ew_resident.h: res_expired) - or the process runs under a CU
+    // mask, which the occupancy query below does not see: the tile kernels from now on.
+    if (ctx->lean_stat && ctx->lean_stat[2]) {
+        if (!ctx->resident_errors_seen) ctx->resident_errors_seen = 1;
+        return kResNotEligible;
+    }
+    static const bool cu_masked = (getenv("HSA_CU_MASK") && *getenv("HSA_CU_MASK")) || (getenv("ROC_GLOBAL_CU_MASK") && *getenv("ROC_GLOBAL_CU_MASK"));
+    if (cu_masked) return kResNotEligible;
     constexpr bool LEAN = OpLean<Op>::value;
     if (LEAN) {
         // a flagged instance is redone FROM ITS INPUTS (by the caller, on the tile kernels) after the pipeline has written its
@@ -68,6 +78,11 @@ int run_resident(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const voi
     if (OpBits<Op>::value && !bits) return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "packed observation");
     A.out = out;
     if (!damp) { A.out.a_old = nullptr; A.out.b_old = nullptr; }
+    static const long long timeout_ms = getenv("TRAMP_EW_RESIDENT_TIMEOUT_MS") ? atoll(getenv("TRAMP_EW_RESIDENT_TIMEOUT_MS")) : 2000;
+    static const long long dbg_skip = getenv("TRAMP_EW_RESIDENT_DBG_SKIP") ? atoll(getenv("TRAMP_EW_RESIDENT_DBG_SKIP")) : 0;
+    A.err_host = ctx->lean_stat ? ctx->lean_stat + 2 : nullptr;
+    A.deadline_ticks = (timeout_ms > 0 ? timeout_ms : 2000) * 100000LL;            // s_memrealtime: 100 MHz
+    A.dbg_skip_plus1 = dbg_skip > 0 ? (unsigned long long)dbg_skip : 0ull;
     ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
     hipLaunchKernelGGL((ew_res_prepare<Op>), dim3((unsigned)((A.total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, op, A, ops);
     const T* p0 = reinterpret_cast<const T*>(in0);

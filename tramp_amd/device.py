@@ -147,6 +147,13 @@ class Context:
         self._call("tramp_resident_stats", C.byref(r))
         return r.value
 
+    def resident_gave_up(self):
+        """True once a resident kernel of this context gave up a hand-off (its deadline passed: the affected instances came
+        back NaN) - every later update takes the tile kernels (include/tramp_hip.h: tramp_resident_errors)"""
+        r = C.c_ulonglong()
+        self._call("tramp_resident_errors", C.byref(r))
+        return bool(r.value)
+
     # -- int8-digit copies of resident matrices (csrc/gemm_sliced.h; opt-in engine of the dense passes)
     def attach_digits(self, mat, digits=0, which=3):
         """Give the resident matrix `mat` [R, C] a copy in signed radix-256 digits: every tramp_matvec_nt / _nn pass over
