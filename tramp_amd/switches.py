@@ -10,13 +10,11 @@ SWITCHES = {
     # name: (default, kind, meaning)
     "TRAMP_HIP_LIB": ("tramp_amd/libtramp_hip.so", "select", "path of the C-ABI library to load (an experimental build)"),
     # componentwise updates (csrc/ew_kernels.hip, ew_resident.h)
-    "TRAMP_EW_RESIDENT": ("1", "select", "0: never take the resident single-pass pipeline (the tile kernels' two passes instead)"),
+    "TRAMP_EW_RESIDENT": ("1", "select", "0: never take the resident single-pass pipeline (the tile kernels' two passes instead); ROCm's HSA_CU_MASK / ROC_GLOBAL_CU_MASK, if set, have the same effect (the co-residency check cannot see a CU mask)"),
     "TRAMP_EW_RESIDENT_K7": ("1", "select", "0: the Sgn / Abs / Relu channels stay on the tile kernels' two passes"),
     "TRAMP_EW_LEAN_ADAPT": ("1", "select", "0: a lean resident K7 update that had to redo more than a quarter of its instances does not send the next 15 calls to the tile kernels"),
     "TRAMP_EW_RESIDENT_TIMEOUT_MS": ("2000", "tune", "deadline of a resident kernel: hand-offs still missing then are given up (NaN update, tile kernels afterwards)"),
     "TRAMP_EW_RESIDENT_DBG_SKIP": (None, "debug", "tile index + 1 whose sum a resident kernel never publishes (forces the give-up path in tests)"),
-    "HSA_CU_MASK": (None, "select", "(ROCm's own variable) set: the resident pipeline is not used - its co-residency check cannot see a CU mask"),
-    "ROC_GLOBAL_CU_MASK": (None, "select", "(ROCm's own variable) as HSA_CU_MASK"),
     "TRAMP_EW_RESIDENT_MIN_ROUNDS": ("4", "tune", "rounds of 2 x CUs - 8 tiles below which the pipeline is not worth its fill and drain"),
     "TRAMP_PRIOR_FUSE": ("1", "select", "0: producers never leave prior / likelihood moments (csrc/prior_hint.h)"),
     # dense linear channel (csrc/linear.hip, gemm_mfma.hip)
