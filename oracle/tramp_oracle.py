@@ -2271,13 +2271,14 @@ def gb_sample(rs, N, rho, mean=0., var=1.):
 # f64 operations that combine them - so that the GPU result can be compared BIT FOR BIT (integer work), and the result
 # itself against the exact product.
 def digit_scale(amax):
-    "per-row power-of-two scale 2^(ilogb(max) + 1): 1 for a zero row, NaN for a non-finite one, 2^-1021 under subnormal maxima"
+    """per-row power-of-two scale 2^(ilogb(max) + 1): 1 for a zero row, never below 2^-960 (the slicing's multiplier
+    2^62 / scale must stay finite), NaN for a non-finite row and for a maximum of 2^1023 or more (scale 2^1024 = inf)"""
     amax = np.asarray(amax, dtype=np.float64)
     sc = np.ones_like(amax)
-    fin = np.isfinite(amax)
+    fin = np.isfinite(amax) & (amax < 2.0 ** 1023)
     pos = fin & (amax > 0)
     m, e = np.frexp(np.where(pos, amax, 1.0))           # amax = m 2^e, m in [0.5, 1): ilogb + 1 = e
-    sc = np.where(pos, np.ldexp(1.0, np.maximum(e, -1021)), sc)
+    sc = np.where(pos, np.ldexp(1.0, np.maximum(e, -960)), sc)
     return np.where(fin, sc, np.nan)
 
 

@@ -59,4 +59,5 @@ def test_special_rows():
     assert np.all(np.isnan(out[1])) and np.all(np.isnan(out[2])) and np.all(out[3] == 0)
     assert np.array_equal(out[0], mat.sum(axis=1))
     assert orc.digit_scale(0.0) == 1.0 and np.isnan(orc.digit_scale(np.inf)) and orc.digit_scale(1.0) == 2.0
-    assert orc.digit_scale(0.75) == 1.0 and orc.digit_scale(1e-320) == 2.0 ** -1021
+    assert orc.digit_scale(0.75) == 1.0 and orc.digit_scale(1e-320) == 2.0 ** -960 and orc.digit_scale(2.0 ** -970) == 2.0 ** -960
+    assert np.isnan(orc.digit_scale(2.0 ** 1023)) and orc.digit_scale(2.0 ** 1022) == 2.0 ** 1023

@@ -158,6 +158,60 @@ def test_special_values(ctx):
     np.testing.assert_allclose(out * 2.0 ** 100, x3 @ mat3.T, rtol=1e-13, atol=1e-14 * np.abs(x3 @ mat3.T).max())
 
 
+def test_rows_at_the_ends_of_the_exponent_range(ctx):
+    """a row whose largest entry is below ~2^-962 made the slicing's multiplier 2^62 / scale overflow (0 * inf =
+    NaN digits, wrong FINITE numbers out); the scale is clamped at 2^-960 now, and a maximum of 2^1023 or more makes the
+    row non-finite.  Against the integer restatement of the oracle, bit for bit."""
+    import tramp_amd as T
+    mat, x = data(32, 128, 4, "nt")
+    mat = mat.copy()
+    mat[3] *= 2.0 ** -1000               # tiny row: scale clamps at 2^-960, digits hold what is left of it
+    mat[4] *= 2.0 ** -1060               # subnormal row
+    mat[5] = 0.0
+    mat[6, 7] = 2.0 ** 1023              # finite, but its scale would be inf
+    for S in (7, 8):
+        out = run(ctx, T, "nt", 0, mat, x, np.float64, S)
+        ref = orc.digit_matvec(mat, x, S)
+        assert np.all(np.isnan(out[:, 6])) and np.all(np.isnan(ref[:, 6]))
+        keep = [r for r in range(32) if r != 6]
+        assert np.all(np.isfinite(out[:, keep]))
+        assert np.array_equal(out[:, keep], ref[:, keep])
+        assert np.all(out[:, 5] == 0.0)
+        exact = x @ mat[keep].T
+        assert np.all(np.abs(out[:, keep] - exact) <= 1e-12 * np.abs(exact).max(axis=0, keepdims=True) + 2.0 ** -1000)
+
+
+def test_digit_copy_does_not_outlive_a_buffer_freed_during_capture(ctx):
+    """tramp_buf_free inside a graph capture defers the hipFree; the digit copy keyed by that pointer must be
+    out of use at once (a later allocation can get the same address, shape and dtype), and freed with the buffer."""
+    import ctypes as C
+    import tramp_amd as T
+    mat, x = data(48, 192, 3, "nt")
+    dt = T.device.dtype_code(np.float64)
+    m_d = ctx.array(mat, np.float64)
+    ctx.attach_digits(m_d, 7, 1)
+    assert ctx.digits_info(m_d)[0] == 7
+    ptr = m_d.ptr
+    ctx._call("tramp_graph_begin")
+    ctx._call("tramp_buf_free", ptr)                 # deferred: the capture is open
+    d, w, nb = C.c_int(), C.c_int(), C.c_size_t()
+    ctx._call("tramp_matrix_digits_info", ptr, C.byref(d), C.byref(w), C.byref(nb))
+    assert d.value == 0, "the digit copy of a buffer released during a capture is still registered"
+    g = C.c_void_p()
+    ctx._call("tramp_graph_end", C.byref(g))
+    if g:
+        ctx._call("tramp_graph_destroy", g)
+    m_d.ptr = None                                    # the wrapper must not free it a second time
+    # a new matrix (quite possibly at the same address): the f64 engine must run, not the old digits
+    m2 = ctx.array(-mat, np.float64)
+    x_d = ctx.array(x, np.float64)
+    out = ctx.empty((x.shape[0], mat.shape[0]), np.float64)
+    n0 = ctx.sliced_runs()
+    ctx._call("tramp_matvec_nt", dt, 0, mat.shape[0], mat.shape[1], x.shape[0], m2.ptr, x_d.ptr, out.ptr)
+    assert ctx.sliced_runs() == n0
+    np.testing.assert_allclose(out.get(), -(x @ mat.T), rtol=1e-12, atol=1e-13)
+
+
 @pytest.mark.parametrize("digits", [7, 8])
 def test_ep_ensemble_on_the_digit_engine(ctx, digits):
     "the sparse-GLM ensemble of tests/test_gpu_ep.py with LinearChannel(digits=...): same fixed point as the oracle's EP"

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 
 static void flush_deferred_frees(tramp_ctx* ctx);
+void gemm_sliced_mark_dead(tramp_ctx* ctx, const void* mat_d);
+void gemm_sliced_reap(tramp_ctx* ctx);
 
 extern "C" const char* tramp_version(void) { return "tramp_hip 0.1 (gfx950)"; }
 
@@ -147,6 +149,7 @@ extern "C" int tramp_graph_destroy(tramp_ctx* ctx, tramp_graph* graph) {
     (void)hipGraphDestroy(graph->graph);
     delete graph;
     if (ctx->graphs_alive > 0) ctx->graphs_alive -= 1;
+    gemm_sliced_reap(ctx);       // digit copies detached while this graph could still replay them (stream synchronised above)
     return TRAMP_OK;
 }
 
@@ -321,8 +324,9 @@ extern "C" int tramp_buf_alloc(tramp_ctx* ctx, size_t bytes, void** dptr) {
 static void flush_deferred_frees(tramp_ctx* ctx) {
     if (!ctx->deferred_n) return;
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < ctx->deferred_n; ++i) (void)hipFree(ctx->deferred_free[i]);
+    for (int i = 0; i < ctx->deferred_n; ++i) (void)hipFree(ctx->deferred_free[i]);      // (their digit copies were marked dead at deferral)
     ctx->deferred_n = 0;
+    gemm_sliced_reap(ctx);
 }
 
 extern "C" int tramp_buf_free(tramp_ctx* ctx, void* dptr) {
@@ -338,6 +342,8 @@ extern "C" int tramp_buf_free(tramp_ctx* ctx, void* dptr) {
             ctx->deferred_cap = cap;
         }
         ctx->deferred_free[ctx->deferred_n++] = dptr;
+        // a digit copy keyed by this pointer is out of use from now on: the address may be handed out again before the flush
+        if (ctx->sliced_reg) gemm_sliced_mark_dead(ctx, dptr);
         return TRAMP_OK;
     }
     TRAMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -41,8 +41,12 @@ __device__ __forceinline__ double sl_scale_of(unsigned long long amax_bits) {
     if (!(m < __builtin_inf())) return __longlong_as_double(0x7ff8000000000000LL);
     if (m == 0.0) return 1.0;
     const int e = (int)((amax_bits >> 52) & 0x7ff);
-    if (e == 0) return 4.450147717014403e-308;                     // subnormal maximum: scale = 2^-1021 covers it
-    return __longlong_as_double((long long)((unsigned long long)(e + 1) << 52));
+    // The slicing multiplies by 2^(6 + 8 (S - 1)) / scale <= 2^62 / scale, which must stay finite: no scale below 2^-960
+    // (a row whose largest entry is under 1e-289 keeps fewer significant digits - it is zero for every purpose).  A
+    // maximum of 2^1023 or more would need the scale 2^1024 = inf: such a row is treated as non-finite (NaN output).
+    if (e >= 2046) return __longlong_as_double(0x7ff8000000000000LL);
+    const int es = e + 1 < 1023 - 960 ? 1023 - 960 : e + 1;
+    return __longlong_as_double((long long)((unsigned long long)es << 52));
 }
 
 // ---------------------------------------------------------------------------------------------- largest magnitudes
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void sl_slice_kernel(size_t R, size_t Rpad,
         for (int i = 0; i < 16; ++i) stage[i][threadIdx.x] = (r0 + i < R && c < C) ? mat[(r0 + i) * ld + c] : T(0);
         __syncthreads();
     }
-    // exact: sc is a power of two >= 2^-1021, the product a power-of-two multiple of a with |.| <= 2^(6 + 8 (S - 1)) <= 2^62
+    // exact: sc is a power of two >= 2^-960 (sl_scale_of: the quotient below stays finite), the product a power-of-two multiple of a with |.| <= 2^(6 + 8 (S - 1)) <= 2^62
     const double inv = (sc == sc) ? __longlong_as_double((long long)(1023 + 6 + 8 * (S - 1)) << 52) / sc : 0.0;
     unsigned dig[S][4];
 #pragma unroll

@@ -18,6 +18,8 @@ struct SlicedMat {
     int8_t* frags;        // [ntile][nkb][S] KiB
     double* scale;        // [ntile 16]
     size_t rows, kdim, ntile, nkb, bytes;
+    bool dead;            // the source matrix was released (or the copy detached) while a capture was open or a captured graph
+                          // alive: never used again, memory reaped by gemm_sliced_reap once neither is the case
 };
 
 struct SlicedReg {
@@ -35,7 +37,7 @@ static const SlicedMat* find(tramp_ctx* ctx, const void* key, int dtype, size_t 
     if (!rg) return nullptr;
     for (int i = 0; i < rg->n; ++i) {
         const SlicedMat& m = rg->v[i];
-        if (m.key == key && m.dtype == dtype && m.R == R && m.C == C && m.nt == nt) return &m;
+        if (!m.dead && m.key == key && m.dtype == dtype && m.R == R && m.C == C && m.nt == nt) return &m;
     }
     return nullptr;
 }
@@ -86,19 +88,38 @@ static void drop(SlicedMat& m) {
     m.scale = nullptr;
 }
 
+// The copies of mat_d (nullptr: all) are taken out of use at once - no synchronisation, no free: callable while a stream
+// capture is open (tramp_buf_free's deferred branch) or a captured graph that recorded a digit pass is alive.  An
+// address re-used by a later allocation therefore never meets the old matrix's digits.
+void gemm_sliced_mark_dead(tramp_ctx* ctx, const void* mat_d) {
+    SlicedReg* rg = reg_of(ctx, false);
+    if (!rg) return;
+    for (int i = 0; i < rg->n; ++i)
+        if (mat_d == nullptr || rg->v[i].key == mat_d) rg->v[i].dead = true;
+}
+
+// Free the dead copies; the caller has synchronised the stream.  Nothing happens while a capture is open or a captured
+// graph is alive (its kernel nodes hold the fragment pointers).
+void gemm_sliced_reap(tramp_ctx* ctx) {
+    SlicedReg* rg = reg_of(ctx, false);
+    if (!rg || ctx->capturing || ctx->graphs_alive > 0) return;
+    int w = 0;
+    for (int i = 0; i < rg->n; ++i) {
+        if (rg->v[i].dead) drop(rg->v[i]);
+        else rg->v[w++] = rg->v[i];
+    }
+    rg->n = w;
+}
+
 extern "C" int tramp_matrix_detach_digits(tramp_ctx* ctx, const void* mat_d) {
     if (!ctx) return TRAMP_EINVAL;
     SlicedReg* rg = reg_of(ctx, false);
     if (!rg) return TRAMP_OK;
-    TRAMP_REQUIRE(ctx, !ctx->capturing);
+    gemm_sliced_mark_dead(ctx, mat_d);
+    if (ctx->capturing || ctx->graphs_alive > 0) return TRAMP_OK;       // reaped later (tramp_graph_destroy, tramp_buf_free, context end)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    int w = 0;
-    for (int i = 0; i < rg->n; ++i) {
-        if (mat_d == nullptr || rg->v[i].key == mat_d) drop(rg->v[i]);
-        else rg->v[w++] = rg->v[i];
-    }
-    rg->n = w;
+    gemm_sliced_reap(ctx);
     return TRAMP_OK;
 }
 
@@ -138,11 +159,13 @@ extern "C" int tramp_matrix_attach_digits(tramp_ctx* ctx, int dtype, size_t R, s
         if (hipMalloc((void**)&m.frags, m.bytes) != hipSuccess || hipMalloc((void**)&m.scale, m.ntile * 16 * sizeof(double)) != hipSuccess) {
             (void)hipGetLastError();
             drop(m);
+            (void)tramp_matrix_detach_digits(ctx, mat_d);
             return tramp_fail(ctx, TRAMP_ENOMEM, "tramp_matrix_attach_digits", "hipMalloc of the digit copy failed");
         }
         rc = dtype == TRAMP_F64 ? slice_matrix_s<double>(ctx, m, (const double*)mat_d) : slice_matrix_s<float>(ctx, m, (const float*)mat_d);
         if (rc) {
             drop(m);
+            (void)tramp_matrix_detach_digits(ctx, mat_d);          // not half a copy: the form already registered goes too
             return rc;
         }
         if (rg->n == rg->cap) {
@@ -168,7 +191,7 @@ extern "C" int tramp_matrix_digits_info(tramp_ctx* ctx, const void* mat_d, int* 
     SlicedReg* rg = reg_of(ctx, false);
     if (rg)
         for (int i = 0; i < rg->n; ++i)
-            if (rg->v[i].key == mat_d) {
+            if (!rg->v[i].dead && rg->v[i].key == mat_d) {
                 d = rg->v[i].S;
                 w |= rg->v[i].nt ? 1 : 2;
                 b += rg->v[i].bytes + rg->v[i].ntile * 16 * sizeof(double);
@@ -183,7 +206,8 @@ template <typename T, int S>
 static int run_sliced(tramp_ctx* ctx, const SlicedMat& m, size_t batch, const T* x, const LinEpi& epi) {
     const size_t len = m.rows;
     const size_t nchunk = (batch + 63) / 64, nbt = nchunk * 4;
-    if (nchunk > 65535) return tramp_fail(ctx, TRAMP_ENOTSUP, "digit pass", "more than 65535 x 64 instances");
+    // (the fold that ends the pass launches dim3(len / 256, batch): batch itself is bounded by the grid's y limit)
+    if (nchunk > 65535 || batch > 65535) return tramp_fail(ctx, TRAMP_ENOTSUP, "digit pass", "more than 65535 instances");
     // splits: a multiple of 8 (= XCDs, as gemm_mfma.hip) that keeps every int32 accumulator exact
     const size_t kmax = max_kb_per_split(S);
     size_t nsplit = 8;
