@@ -895,6 +895,8 @@ def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, wi
         lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device")
         ctx.sync()
         fact_s = time.perf_counter() - tf
+        fz_peak = ctx.factorize_peak_bytes()
+        held = W.nbytes + lin._Uk.nbytes + lin._Vt.nbytes
         del W
         model = (T.GaussBernoulliPrior(size=N, rho=rho, dtype=np_dt, ctx=ctx) @ T.SISOVariable(id="x") @ lin
                  @ T.SISOVariable(id="z") @ T.SgnLikelihood(y=Y.astype(np_dt), dtype=np_dt, ctx=ctx)).to_model()
@@ -917,6 +919,8 @@ def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, wi
         ctx.sync()
         tf = time.perf_counter()
         l1 = T.LinearChannel(W1, dtype=np_dt, ctx=ctx, svd="device")
+        fz_peak = ctx.factorize_peak_bytes()
+        held = W1.nbytes + W2.nbytes + l1._Uk.nbytes + l1._Vt.nbytes
         del W1
         l2 = T.LinearChannel(W2, dtype=np_dt, ctx=ctx, svd="device")
         del W2
@@ -949,7 +953,11 @@ def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, wi
     out = {"workload": workload, "dtype": dname, "instances": B, **shape, "steps": steps, "warmup": warmup,
            "damping": damping, "ms_per_iteration": el / steps * 1e3,
            "msg_components_per_sec": float(N) * B * steps / el,
-           "setup": {"total_s": setup_s, "factorize_s": fact_s},
+           "setup": {"total_s": setup_s, "factorize_s": fact_s,
+                     # device memory at the peak of the (largest) factorisation: its work space + the matrices and factors
+                     # the caller held beside it
+                     "factorize_work_GB": fz_peak / 1e9, "held_beside_GB": held / 1e9,
+                     "peak_device_GB": (fz_peak + held) / 1e9},
            "kernels": kern,
            "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dname],
                         "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dname] if ach else None,

@@ -331,9 +331,13 @@ int tramp_linear_destroy(tramp_ctx* ctx, tramp_linear* lin);
  * 1e-5 sigma_max are re-resolved from the Gram matrix of their own rows, and the rank uses
  * np.linalg.matrix_rank's tolerance sigma_max * max(M,N) * eps.
  * W_d [M,N] row-major of `dtype`; outputs as tramp_linear_create expects
- * (caller-allocated).  Computation is always carried out in f64. */
+ * (caller-allocated).  Computation is always carried out in f64; an f32 W is widened panel by panel, never as a whole. */
 int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_t N, const void* W_d,
                            void* Uk_d, void* Vt_d, double* sing_d, size_t* rank);
+/* Device work space the last tramp_linear_factorize of this context held at most, in bytes (the caller's W, Uk, Vt not
+ * included).  f64 input: ~4 k^2 doubles (the Gram matrix and three k x k work matrices of the spectral split); f32 input:
+ * the same plus a few GiB of widened panels - W, Uk and Vt are never copied to f64 (round 5). */
+int tramp_factorize_peak_bytes(tramp_ctx* ctx, size_t* bytes);
 /* The symmetric eigensolver of tramp_linear_factorize on its own (np.linalg.eigh on the Gram
  * matrix): rocSOLVER syevd up to n = TRAMP_EIG_CAP (default 46336, its 32-bit limit), above that a
  * spectral divide and conquer (matrix sign function by Cholesky-form weighted Halley iterations,

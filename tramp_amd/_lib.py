@@ -81,6 +81,7 @@ _SIGNATURES = {
     "tramp_linear_destroy": [vp, vp],
     "tramp_linear_factorize": [vp, i32, sz, sz, vp, vp, vp, vp, C.POINTER(sz)],
     "tramp_eigh": [vp, sz, vp, vp],
+    "tramp_factorize_peak_bytes": [vp, C.POINTER(sz)],
     "tramp_prior_hint": [vp, i32, dbl, dbl, dbl, sz, sz, vp, vp],
     "tramp_lik_hint": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_prior_hint_stats": [vp, C.POINTER(u64), C.POINTER(u64)],

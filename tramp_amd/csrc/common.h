@@ -61,6 +61,7 @@ struct tramp_ctx {
     unsigned long long resident_runs;           // factor updates that took the resident single-pass pipeline (ew_resident.h)
     volatile unsigned* lean_stat;               // pinned host {flagged instances, batch} of the last lean resident update (ew_flag_nan);
                                                 // [2]: a resident kernel gave up a hand-off (ew_resident.h: res_expired)
+    size_t fz_peak_bytes;                       // work space of the last tramp_linear_factorize (factorize.hip)
     int resident_errors_seen;                   // the host has seen lean_stat[2] and taken the resident pipeline out of service
     int lean_skip;                              // lean updates to skip after one that flagged more than a quarter of its instances
     void* sliced_reg;                           // int8-digit copies of resident matrices (gemm_sliced.hip), by device pointer

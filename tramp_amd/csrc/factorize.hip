@@ -88,6 +88,50 @@ __global__ void scale_cols_inv(double* __restrict__ A, size_t rows, size_t cols,
     }
 }
 
+// ---- f32 inputs without f64 copies of W, U, V (round 5): panels of W are widened to f64 on the fly --------------------
+// A = W^T in column-major [N, M] (lda = N), W row-major f32.  rows [n0, n0 + nc) of A, all M columns -> P [nc, M] (ld nc)
+__global__ void widen_rows_panel(const float* __restrict__ W, size_t M, size_t N, size_t n0, size_t nc, double* __restrict__ P) {
+    GRID_STRIDE(idx, nc * M) {
+        const size_t r = idx % nc, m = idx / nc;
+        P[idx] = (double)W[m * N + n0 + r];
+    }
+}
+// columns [m0, m0 + mc) of A (= rows of W, contiguous) -> P [N, mc] (ld N)
+__global__ void widen_cols_panel(const float* __restrict__ W, size_t N, size_t m0, size_t mc, double* __restrict__ P) {
+    GRID_STRIDE(idx, mc * N) P[idx] = (double)W[m0 * N + idx];
+}
+// Uk32[i, j] = Q[i + (n-1-j) n]  /  Vt32[j, c] = Q[c + (n-1-j) n]: the unit-side factor straight from the eigenvectors
+__global__ void eigvec_to_uk_f32(const double* __restrict__ Q, size_t n, float* __restrict__ Uk) {
+    GRID_STRIDE(idx, n * n) {
+        const size_t i = idx / n, j = idx % n;
+        Uk[idx] = (float)Q[i + (n - 1 - j) * n];
+    }
+}
+__global__ void eigvec_to_vt_f32(const double* __restrict__ Q, size_t n, float* __restrict__ Vt) {
+    GRID_STRIDE(idx, n * n) {
+        const size_t j = idx / n, c = idx % n;
+        Vt[idx] = (float)Q[c + (n - 1 - j) * n];
+    }
+}
+// C [nc, k] (ld nc; column i = A q_i for the ASCENDING eigenvector i, rows n0 ..) -> Vt32[j, n0 + r] = C[r, k-1-j] / sing[j]
+__global__ void store_vt_panel(const double* __restrict__ C, size_t nc, size_t k, size_t N, size_t n0, const double* __restrict__ sing,
+                               double tol, float* __restrict__ Vt) {
+    GRID_STRIDE(idx, nc * k) {
+        const size_t r = idx % nc, j = idx / nc;
+        const double s = sing[j];
+        Vt[j * N + n0 + r] = (float)(C[r + (k - 1 - j) * nc] * ((s > tol) ? 1.0 / s : 0.0));
+    }
+}
+// C [k, mc] (ld k; row i = q_i^T A for the ascending eigenvector i, columns m0 ..) -> Uk32[m0 + r, j] = C[k-1-j, r] / sing[j]
+__global__ void store_uk_panel(const double* __restrict__ C, size_t k, size_t mc, size_t m0, const double* __restrict__ sing,
+                               double tol, float* __restrict__ Uk) {
+    GRID_STRIDE(idx, k * mc) {
+        const size_t j = idx % k, r = idx / k;
+        const double s = sing[j];
+        Uk[(m0 + r) * k + j] = (float)(C[(k - 1 - j) + r * k] * ((s > tol) ? 1.0 / s : 0.0));
+    }
+}
+
 // cross[b + j c] /= sing[b]^2   (j0 x c, column-major)
 __global__ void scale_cross(double* __restrict__ cross, size_t j0, size_t c, const double* __restrict__ sing) {
     GRID_STRIDE(idx, j0 * c) {
@@ -241,15 +285,21 @@ struct Fz {
         rc = tramp_fail(ctx, code, what, detail);
         return rc;
     }
+    std::vector<size_t> owned_bytes;
+    size_t live = 0, peak = 0;           // bytes of work space this factorisation holds / held at most (tramp_factorize_peak_bytes)
     double* alloc(size_t count) {
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(double));
+        const size_t nb = (count ? count : 1) * sizeof(double);
+        hipError_t e = hipMalloc(&p, nb);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             fail(TRAMP_ENOMEM, "factorize: hipMalloc", hipGetErrorString(e));
             return nullptr;
         }
         owned.push_back(p);
+        owned_bytes.push_back(nb);
+        live += nb;
+        if (live > peak) peak = live;
         return (double*)p;
     }
     void release(void* p) {
@@ -257,7 +307,9 @@ struct Fz {
         (void)hipStreamSynchronize(ctx->stream);
         for (size_t i = 0; i < owned.size(); ++i)
             if (owned[i] == p) {
+                live -= owned_bytes[i];
                 owned.erase(owned.begin() + i);
+                owned_bytes.erase(owned_bytes.begin() + i);
                 break;
             }
         (void)hipFree(p);
@@ -266,6 +318,8 @@ struct Fz {
         (void)hipStreamSynchronize(ctx->stream);
         for (void* p : owned) (void)hipFree(p);
         owned.clear();
+        owned_bytes.clear();
+        live = 0;
     }
     // TRAMP_EIG_VERBOSE=1: wall time of each phase of the setup path on stderr (synchronises the stream)
     double t_last = 0.0;
@@ -869,6 +923,89 @@ int factorize_f64(Fz& fz, size_t M, size_t N, const double* W64, double* U64, do
     return TRAMP_OK;
 }
 
+// The f32 entry without f64 copies of W, Uk, Vt (which capped BASELINE configs[2] / configs[4] at N = 49 152 / 65 536: W,
+// U, V in f64 beside the f32 originals and four k x k work matrices is 2.4 x 288 GB at N = 131 072).  The Gram matrix is
+// accumulated in f64 from f64-widened PANELS of W (a few GB at a time), the unit-side factor is written in f32 straight
+// from the eigenvectors, the long-side factor panel by panel (widened W panel x eigenvectors, scaled by 1 / sigma,
+// stored as f32).  Arithmetic identical to the f64 path on the widened matrix up to the order of the panel sums.
+// *done = false (nothing written) when the spectrum has singular values below 1e-5 sigma_max: those need the
+// re-factorisation levels of factorize_f64 on full f64 factors, which the caller then runs.
+int factorize_f32_panels(Fz& fz, size_t M, size_t N, const float* W32, float* Uk32, float* Vt32, double* sing_d, size_t* rank_out,
+                         bool* done) {
+    tramp_ctx* ctx = fz.ctx;
+    hipStream_t st = ctx->stream;
+    *done = false;
+    const size_t k = M < N ? M : N, big = M > N ? M : N;
+    double* G = fz.alloc(k * k);
+    double* D = fz.alloc(k);
+    if (!G || !D) return fz.rc;
+    // panel: pc indices of the LONG side at a time, pc x k doubles <= 2 GiB (and at least 256 indices)
+    size_t pc = ((size_t)2 << 30) / (8 * k);
+    if (pc < 256) pc = 256;
+    if (pc > big) pc = big;
+    double* P = fz.alloc(pc * k);
+    if (!P) return fz.rc;
+    fz.tick("start", k);
+    for (size_t p0 = 0; p0 < big; p0 += pc) {
+        const size_t c = (big - p0 < pc) ? big - p0 : pc;
+        if (M <= N) {
+            hipLaunchKernelGGL(widen_rows_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, W32, M, N, p0, c, P);
+            FZ_OK(bsyrk_upper(fz, rocblas_operation_transpose, M, c, 1.0, P, c, p0 ? 1.0 : 0.0, G, M));      // += P^T P
+        } else {
+            hipLaunchKernelGGL(widen_cols_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, W32, N, p0, c, P);
+            FZ_OK(bsyrk_upper(fz, rocblas_operation_none, N, c, 1.0, P, N, p0 ? 1.0 : 0.0, G, N));            // += P P^T
+        }
+    }
+    fz.release(P);                                   // not held across the eigensolve (its work matrices need the room)
+    fz.tick("gram matrix (f32 panels)", k);
+    FZ_OK(eigh_rec(fz, G, k, D, 0));
+    hipLaunchKernelGGL(eig_to_sing, dim3(kRedBlocks), dim3(kBlock), 0, st, D, k, sing_d, 1.0);
+    std::vector<double> sh(k);
+    FZ_HIP(fz, hipMemcpyAsync(sh.data(), sing_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    const double smax = sh[0];
+    if (!(smax > 0.0) || sh[k - 1] <= 1e-5 * smax) {         // the Gram matrix does not resolve the trailing directions
+        fz.release(G);
+        fz.release(D);
+        return TRAMP_OK;
+    }
+    double tol = smax * (double)big * kEps;
+    const double floor_tol = smax * 64.0 * kEps * sqrt((double)k);
+    if (tol < floor_tol) tol = floor_tol;
+    size_t r = 0;
+    for (size_t j = 0; j < k; ++j) r += sh[j] > tol;
+    *rank_out = r;
+    if (M <= N) hipLaunchKernelGGL(eigvec_to_uk_f32, dim3(kRedBlocks), dim3(kBlock), 0, st, G, k, Uk32);
+    else hipLaunchKernelGGL(eigvec_to_vt_f32, dim3(kRedBlocks), dim3(kBlock), 0, st, G, k, Vt32);
+    // the long side: two panels (widened W, product) of pc2 x k doubles, 1 GiB each
+    size_t pc2 = ((size_t)1 << 30) / (8 * k);
+    if (pc2 < 256) pc2 = 256;
+    if (pc2 > big) pc2 = big;
+    P = fz.alloc(pc2 * k);
+    double* C = fz.alloc(pc2 * k);
+    if (!P || !C) return fz.rc;
+    for (size_t p0 = 0; p0 < big; p0 += pc2) {
+        const size_t c = (big - p0 < pc2) ? big - p0 : pc2;
+        if (M <= N) {
+            hipLaunchKernelGGL(widen_rows_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, W32, M, N, p0, c, P);
+            FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, c, k, M, 1.0, P, c, G, k, 0.0, C, c));     // [c, M] Q
+            hipLaunchKernelGGL(store_vt_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, C, c, k, N, p0, sing_d, tol, Vt32);
+        } else {
+            hipLaunchKernelGGL(widen_cols_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, W32, N, p0, c, P);
+            FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, k, c, N, 1.0, G, k, P, N, 0.0, C, k));  // Q^T [N, c]
+            hipLaunchKernelGGL(store_uk_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, C, k, c, p0, sing_d, tol, Uk32);
+        }
+    }
+    FZ_HIP(fz, hipGetLastError());
+    fz.tick("long-side factor (f32 panels)", k);
+    fz.release(P);
+    fz.release(C);
+    fz.release(G);
+    fz.release(D);
+    *done = true;
+    return TRAMP_OK;
+}
+
 }  // namespace
 
 extern "C" int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_t N, const void* W_d, void* Uk_d,
@@ -895,6 +1032,13 @@ extern "C" int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_
         fz.part_d = fz.alloc(kRedBlocks);
         if (!fz.info_d || !fz.part_d) return fz.rc;
         if (dtype == TRAMP_F32) {
+            bool done = false;
+            FZ_OK(factorize_f32_panels(fz, M, N, (const float*)W_d, (float*)Uk_d, (float*)Vt_d, sing_d, rank_out, &done));
+            if (done) {
+                FZ_HIP(fz, hipStreamSynchronize(ctx->stream));
+                return TRAMP_OK;
+            }
+            // singular values below 1e-5 sigma_max: the re-factorisation levels work on full f64 factors
             W64 = fz.alloc(M * N);
             U64 = fz.alloc(M * k);
             V64 = fz.alloc(k * N);
@@ -914,9 +1058,18 @@ extern "C" int tramp_linear_factorize(tramp_ctx* ctx, int dtype, size_t M, size_
         return TRAMP_OK;
     };
     rc = body();
+    ctx->fz_peak_bytes = fz.peak;
+    if (getenv("TRAMP_EIG_VERBOSE")) fprintf(stderr, "[tramp factorize] peak work space %.2f GB\n", (double)fz.peak / 1e9);
     fz.release_all();
     (void)rocblas_destroy_handle(fz.h);
     return rc;
+}
+
+/* Work space the last tramp_linear_factorize of this context held at most (bytes; the caller's W, Uk, Vt not included). */
+extern "C" int tramp_factorize_peak_bytes(tramp_ctx* ctx, size_t* bytes) {
+    if (!ctx || !bytes) return TRAMP_EINVAL;
+    *bytes = ctx->fz_peak_bytes;
+    return TRAMP_OK;
 }
 
 /* Symmetric eigendecomposition on the device (the eigensolver of tramp_linear_factorize on its own):

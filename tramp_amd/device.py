@@ -147,6 +147,12 @@ class Context:
         self._call("tramp_resident_stats", C.byref(r))
         return r.value
 
+    def factorize_peak_bytes(self):
+        "device work space the last tramp_linear_factorize of this context held at most (bytes)"
+        b = C.c_size_t()
+        self._call("tramp_factorize_peak_bytes", C.byref(b))
+        return b.value
+
     def resident_gave_up(self):
         """True once a resident kernel of this context gave up a hand-off (its deadline passed: the affected instances came
         back NaN) - every later update takes the tile kernels (include/tramp_hip.h: tramp_resident_errors)"""

@@ -187,10 +187,20 @@ class SgnLikelihood(Likelihood):
         self._init_device(dtype, ctx)
         self._set_y(y)
 
+    def repack(self):
+        """Pack the observation again from the device buffer it lives in.  The packed copy is made ONCE, when y is set
+        (the reference's y is static: sgn_likelihood.py:14-19); a caller that passed a DeviceArray and overwrites it in
+        place must call this, or the large-batch updates keep reading the old signs."""
+        self._pack()
+
     def _set_y(self, y):
         """the observation is static and in {-1, +1}: besides y itself keep it packed one bit per component, which is
-        what batches of large instances read (tramp_sgn_lik_bwd_bits: 2T + n/8 bytes moved instead of 3T)"""
+        what batches of large instances read (tramp_sgn_lik_bwd_bits: 2T + n/8 bytes moved instead of 3T).  FROZEN at
+        this point: see repack()."""
         super()._set_y(y)
+        self._pack()
+
+    def _pack(self):
         self._bits = None
         yd = self._y_dev
         if yd is None or not self.isotropic or yd.shape[0] > 65535 or yd.shape[1] == 0:
