@@ -63,10 +63,11 @@ def parse():
     ap.add_argument("--no-tts", action="store_true", help="skip the time-to-solution runs")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[4] EP legs")
     ap.add_argument("--no-digits", action="store_true", help="skip the opt-in int8-digit engine leg (csrc/gemm_sliced.h)")
-    ap.add_argument("--cs1bit-n", type=int, default=int(os.environ.get("TRAMP_BENCH_CS1BIT_N", 49152)),
-                    help="N of the 1-bit CS leg (fp32, alpha = 0.7, 64 instances)")
-    ap.add_argument("--twolayer-n", type=int, default=int(os.environ.get("TRAMP_BENCH_TWOLAYER_N", 65536)),
-                    help="input size of the two-layer leg (fp32, alpha = 0.5 per layer, 64 instances)")
+    ap.add_argument("--cs1bit-n", type=int, default=int(os.environ.get("TRAMP_BENCH_CS1BIT_N", 40960)),
+                    help="N of the 1-bit CS leg (fp32, alpha = 0.7, 64 instances); the default keeps its factorisation (n^3) inside the "
+                         "default run's time budget - the named size 98304 fits one GPU: profiles/r05/bench_configs_full_sizes.json")
+    ap.add_argument("--twolayer-n", type=int, default=int(os.environ.get("TRAMP_BENCH_TWOLAYER_N", 49152)),
+                    help="input size of the two-layer leg (fp32, alpha = 0.5 per layer, 64 instances); named size 131072: same file")
     ap.add_argument("--full", action="store_true",
                     help="every auxiliary leg (f32 duplicates, fused-moment pairs, every elementwise factor, structured "
                          "channels, the 512-instance run, the N=4000 reference-formulation CPU sample, digits8): minutes "
@@ -866,9 +867,11 @@ def _tag_report(ctx):
 
 def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, with_digits=True):
     """BASELINE configs[2] (1-bit compressed sensing, alpha = 0.7, fp32) and configs[4] (two-layer ReLU GLM) as EP
-    ensembles of B instances sharing their Gaussian-ensemble matrices, at the largest N whose factorisation fits the
-    bench's time budget (the named sizes do not fit the f64 factorisation's working set on one GPU: DESIGN 10.4).  Same protocol as the headline: factors from
-    tramp_linear_factorize (timed, reported), `warmup` untimed iterations, `steps` timed ones with PassCallback (no
+    ensembles of B instances sharing their Gaussian-ensemble matrices, at an N whose factorisation (n^3) fits the default
+    run's time budget (the named sizes N = 98 304 / 131 072 fit one GPU since round 5 - f32 inputs are factorised from
+    widened panels - and take 200 s of set-up each: profiles/r05/bench_configs_full_sizes.json).  Same protocol as the
+    headline: factors from tramp_linear_factorize (timed, reported with its peak work space), `warmup` untimed iterations,
+    `steps` timed ones with PassCallback (no
     instance freezes), per-kernel HIP-event times for the roofline of the dominant kernel."""
     import gc
     dt = T.device.dtype_code(np_dt)

@@ -183,9 +183,11 @@ def test_pwl_moment_form_dense(hm, kind, fast):
                     continue
                 e_lit, e_new = abs(v0[i] - vt), abs(v1[i] - vt)
                 # which form this component took (the host harness votes per component): both erfcx arguments on the
-                # grid [-7.5, 8) (fast = 1) / below 0.98 x 30 / sqrt 2 in magnitude (fast = 2)
+                # grid [-7.5, 8) - or, Abs / Relu, one below it with the other >= -4 - (fast = 1) / below 0.98 x 30 / sqrt 2 in magnitude (fast = 2)
                 xs = [-sd * (bz[i] + sl * (bx[i] - ax * x0)) / np.sqrt(2 * (az + sl * sl * ax)) for sd, sl, x0 in orc.PWL_REGIONS[kind]]
-                moment = (min(xs) >= -7.5 and max(xs) < 8) if fast == 1 else max(abs(t) for t in xs) < 0.98 * 30 / np.sqrt(2)
+                lim = 0.98 * 30 / np.sqrt(2)
+                moment = ((max(xs) < 8 and (min(xs) >= -7.5 or (kind != "sgn" and max(xs) >= -4 and min(xs) > -lim)))
+                          if fast == 1 else max(abs(t) for t in xs) < lim)
                 slack = 1e-13 if moment else 5e-11            # (the region-by-region form of rounds 2-4 reaches ~1e-11)
                 # a region deep in its tail has mean = r0 + s0 g / e and second moment v0 + r0^2 - ... cancelling in ANY
                 # f64 form, the reference's included: a few ulp of the largest v0_k + r0_k^2 on top

@@ -887,6 +887,19 @@ extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     const TrampPriorHint* hint = take_hint(ctx, &hc, PRIOR_HINT_SGN_LIK, 0.0, 0.0, 0.0, n, batch, bz_d, az_d, out, y_d);
     SgnLikOp<float> of{az_d};
     SgnLikOp<double> od{az_d};
+    // large batches of large instances with no producer-fused moments: the lean form on the resident pipeline, then the
+    // tile kernels for the instances it could not finish (a_new = NaN: a disagreement beyond the erfcx table, a non-finite
+    // message; ~6 us when there is none)
+    if (!hint && n && batch && bz_d && y_d && a_new_d && b_new_d && !r_d && (damping == 0.0 || (a_old_d && b_old_d))) {
+        int rc = kResNotEligible;
+        if (dtype == TRAMP_F32) rc = run_resident<float>(ctx, SgnLikOp<float, true>{az_d}, n, batch, bz_d, y_d, az_d, out);
+        else if (dtype == TRAMP_F64) rc = run_resident<double>(ctx, SgnLikOp<double, true>{az_d}, n, batch, bz_d, y_d, az_d, out);
+        if (rc == TRAMP_OK) {
+            if (dtype == TRAMP_F32) return run_tiles<float>(ctx, of, n, batch, bz_d, y_d, az_d, out, false, nullptr, true);
+            return run_tiles<double>(ctx, od, n, batch, bz_d, y_d, az_d, out, false, nullptr, true);
+        }
+        if (rc != kResNotEligible) return rc;
+    }
     DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out, hint)),
                    (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out, hint)));
 }
@@ -960,10 +973,16 @@ extern "C" int tramp_sgn_lik_bwd_bits(tramp_ctx* ctx, int dtype, size_t n, size_
         MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, nullptr, v_d, nullptr, nullptr};
         const size_t stride = ((n + 63) / 64) * 8;
         int rc = kResNotEligible;
-        if (dtype == TRAMP_F32) rc = run_resident<float>(ctx, SgnLikBitsOp<float>{az_d}, n, batch, bz_d, nullptr, az_d, out, bits_d, stride);
-        else if (dtype == TRAMP_F64) rc = run_resident<double>(ctx, SgnLikBitsOp<double>{az_d}, n, batch, bz_d, nullptr, az_d, out, bits_d, stride);
+        if (dtype == TRAMP_F32) rc = run_resident<float>(ctx, SgnLikBitsOp<float, true>{az_d}, n, batch, bz_d, nullptr, az_d, out, bits_d, stride);
+        else if (dtype == TRAMP_F64) rc = run_resident<double>(ctx, SgnLikBitsOp<double, true>{az_d}, n, batch, bz_d, nullptr, az_d, out, bits_d, stride);
         if (rc != kResNotEligible) {
-            if (rc == TRAMP_OK) { ctx->hint.kind = PRIOR_HINT_NONE; ctx->hint.ready = false; }     // consumed, as take_hint does
+            if (rc == TRAMP_OK) {
+                ctx->hint.kind = PRIOR_HINT_NONE;       // consumed, as take_hint does
+                ctx->hint.ready = false;
+                // the lean form's unfinished instances (a_new = NaN) again, by the tile kernels on the unpacked observation
+                if (dtype == TRAMP_F32) return run_tiles<float>(ctx, SgnLikOp<float>{az_d}, n, batch, bz_d, y_d, az_d, out, false, nullptr, true);
+                return run_tiles<double>(ctx, SgnLikOp<double>{az_d}, n, batch, bz_d, y_d, az_d, out, false, nullptr, true);
+            }
             return rc;
         }
     }

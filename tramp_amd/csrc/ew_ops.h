@@ -77,43 +77,63 @@ template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1)
     }
 };
 
-template <typename T> struct SgnLikOp {   // K4; in0 = bz, in1 = y
+// LEAN: the resident pipeline's form (tmath::sgn_lik_posterior_lean; a disagreement beyond the erfcx table or a non-finite
+// input comes back in EwOut::dev and the caller redoes the instance on the full form)
+template <typename T, bool LEAN = false> struct SgnLikOp {   // K4; in0 = bz, in1 = y
     static constexpr bool HEAVY = false;     // recomputed in pass 2 (5T moved, not 6T): f32 252 vs 309 us, f64 580 vs 616 us at 64 x 1e6
     static constexpr int NIN = 2;
     static constexpr int TARGET = 0;
     const double* az;
     tmath::RegionConst<T> c;
     double a_msg;
-    __device__ static void stage() {tmath::erfcx_setup<T>(); }
+    __device__ static void stage() {
+        if (LEAN) tmath::erfcx_setup_tay<T>();
+        else tmath::erfcx_setup<T>();
+    }
     __device__ void prepare(size_t b) {
         a_msg = az[b];
         c = tmath::region_const<T>(a_msg);
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T x1) const {
-        RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, x1, c);
-        return {o.r, o.v, 0u};
+        if constexpr (LEAN) {
+            T dev;
+            RV<T> o = tmath::sgn_lik_posterior_lean<T>(x0, x1, c, &dev);
+            return {o.r, o.v, 0u, dev};
+        } else {
+            RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, x1, c);
+            return {o.r, o.v, 0u};
+        }
     }
 };
 
 // K4 with the observation packed one bit per component (y in {-1, +1} is static: 2T + 1/64 T moved instead of 3T);
 // only the resident pipeline reads it (ew_resident.h, ResArgs::bits).  eval's second argument is y rebuilt from its bit.
-template <typename T> struct SgnLikBitsOp {   // in0 = bz
+template <typename T, bool LEAN = false> struct SgnLikBitsOp {   // in0 = bz
     static constexpr bool HEAVY = false;
     static constexpr int NIN = 1;
     static constexpr int TARGET = 0;
     const double* az;
     tmath::RegionConst<T> c;
     double a_msg;
-    __device__ static void stage() { tmath::erfcx_setup<T>(); }
+    __device__ static void stage() {
+        if (LEAN) tmath::erfcx_setup_tay<T>();
+        else tmath::erfcx_setup<T>();
+    }
     __device__ void prepare(size_t b) {
         a_msg = az[b];
         c = tmath::region_const<T>(a_msg);
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T y) const {
-        RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, y, c);
-        return {o.r, o.v, 0u};
+        if constexpr (LEAN) {
+            T dev;
+            RV<T> o = tmath::sgn_lik_posterior_lean<T>(x0, y, c, &dev);
+            return {o.r, o.v, 0u, dev};
+        } else {
+            RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, y, c);
+            return {o.r, o.v, 0u};
+        }
     }
 };
 
@@ -234,13 +254,15 @@ template <typename T, int KIND, bool FWD, bool UNI = true, bool LEAN = false> st
 // Only the L1 prior reports a support count (MAP_L1NormPrior's mask, map_L1_norm_prior.py:16-17): the other
 // ops do not carry the 64-bit counter through their loops.
 template <typename Op> struct OpBits { static constexpr bool value = false; };
-template <typename T> struct OpBits<SgnLikBitsOp<T>> { static constexpr bool value = true; };
+template <typename T, bool LEAN> struct OpBits<SgnLikBitsOp<T, LEAN>> { static constexpr bool value = true; };
 
 // Lean ops (the resident pipeline's K7): eval() covers the moment form's domain only and reports a lane outside it in
 // EwOut::dev (non-zero or NaN); the pipeline poisons the instance's a_new and the caller redoes it on the full form
 // (ew_resident.h, ew_kernels.hip: pwl_dir).
 template <typename Op> struct OpLean { static constexpr bool value = false; };
 template <typename T, int KIND, bool FWD, bool UNI> struct OpLean<PwlOp<T, KIND, FWD, UNI, true>> { static constexpr bool value = true; };
+template <typename T> struct OpLean<SgnLikOp<T, true>> { static constexpr bool value = true; };
+template <typename T> struct OpLean<SgnLikBitsOp<T, true>> { static constexpr bool value = true; };
 
 template <typename Op> struct OpCounts { static constexpr bool value = false; };
 template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };

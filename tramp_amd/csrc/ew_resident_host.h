@@ -27,12 +27,11 @@ template <typename T, int KIND, bool FWD, bool UNI, bool LEAN> struct ResShape<P
 template <typename Op> struct ResidentOp { static constexpr bool value = false; };
 template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value = true; };
-template <typename T> struct ResidentOp<SgnLikOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<AbsLikOp<T>> { static constexpr bool value = true; };
-template <typename T> struct ResidentOp<SgnLikBitsOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<BinaryOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<ReluLikOp<T>> { static constexpr bool value = true; };
-// (the two-region channels K7 enter through pwl_dir in ew_kernels.hip: ew_resident_pwl.hip)
+// (the lean forms - the two-region channels K7, the sign likelihood with its observation unpacked or packed - are
+//  launched by their entry points in ew_kernels.hip, which also run the redo of their unfinished instances)
 
 // The shape test (instances of at least one tile that fit the pipeline's window, enough tiles for four rounds, 16-byte
 // rows).  Shared with the producers of prior_hint.h: an FFT epilogue whose consumer takes the resident form leaves no

@@ -538,6 +538,33 @@ template <typename T> TM_HD RV<T> sgn_lik_posterior_fast(T bz, T y, const Region
     return o;
 }
 
+// Lean form for the resident pipeline (round 5; no control flow, erfcx from the one-value table).  x = -b y / sqrt(2 az):
+// below the table's lower end (-7.5: the observation agrees with the message by more than 10 standard deviations) the
+// truncation no longer acts - erfcx >= 5e24, the corrections s0 g1 and v0 (g2 - g1^2) are below 2e-25 of their terms
+// whether erfcx is exact or the table's edge value - so the argument is simply clamped there.  ABOVE the table (x >= 8: a
+// disagreement of 11 standard deviations) the tail needs erfcx accurately: `dev` > 0 asks the caller for a redo on
+// sgn_lik_posterior_fast; NaN / infinite inputs make it NaN.
+template <typename T> TM_HD RV<T> sgn_lik_posterior_lean(T bz, T y, const RegionConst<T>& c, T* dev) {
+#if TRAMP_ERFCX_UNIFORM
+    const T r0 = (bz * y) * c.v0;
+    const T x = ((T(0) - r0) * c.inv_s0) * T(0.70710678118654752440);
+    const T hi_v = x - fmin_(x, T(kErfcxTHi));
+    *dev = fma_(hi_v, hi_v, x - x);
+    const T xc = fmin_(fmax_(x, T(kErfcxTLo)), T(kErfcxTHi));
+    const T e = erfcx_tay(xc);
+    const T ie = rcp_pos(e);                              // e in [0.07, 5e24]
+    const T g1 = T(kSqrt2OverPi) * ie;
+    const T g2 = T(kTwoOverSqrtPi) * (xc * ie);
+    RV<T> o;
+    o.r = y * (r0 + c.s0 * g1);
+    o.v = c.v0 * (T(1) + g2 - g1 * g1);
+    return o;
+#else
+    *dev = T(0);
+    return sgn_lik_posterior_fast<T>(bz, y, c);
+#endif
+}
+
 // ---- (Leaky)Relu likelihood: y = max(z, 0) + slope_neg * min(z, 0) observed
 // tramp/likelihoods/piecewise_linear_likelihood.py:9-63,201-215,279-291.  Regions pos (slope 1) and
 // neg (slope s): a region with non-zero slope pins z = (y - x0)/slope exactly (v = 0) when that z
@@ -831,7 +858,8 @@ TM_HD PwlOut<T> pwl_posterior_regions(T bz, T bx, const PwlConst<T>& c) {
 // heavier region, so M2 - M1^2 cancels at most like (distance between the region means)^2 / v - never like r^2 / v.
 // Forward direction (posterior of x = slope z + x0): a region of slope 0 is the point mass x0_k; slope +-1 enters with
 // rho_k = slope_k r0_k and G_k -> slope_k G_k.
-// Taken when EVERY lane of the wave has both arguments on the erfcx grid [-7.5, 8) (UNI; else: far from the reference's
+// Taken when EVERY lane of the wave is in the domain spelled out in the function (UNI: both arguments on the erfcx grid
+// [-7.5, 8), or - Abs / Relu - one of them below it while the other is >= -4; else: far from the reference's
 // log_Phi mask threshold, |x| < 0.98 cut / sqrt2, where e is finite), so mask = 3 by construction; any other wave - a lane near
 // or under the mask, a NaN, an infinity - takes pwl_posterior_regions, the literal region-by-region form.
 template <typename T> struct PwlMomentLim;
@@ -854,20 +882,32 @@ TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o, T* de
     T x0 = b0 * c.kx[0], x1 = b1 * c.kx[1];
     bool ok;
     constexpr bool GRID = UNI && TRAMP_ERFCX_UNIFORM;
-    if (GRID) ok = fmin_(x0, x1) >= T(kErfcxTLo) && fmax_(x0, x1) < T(kErfcxTHi);
+    // Domain on the table: both arguments below its upper end (an argument above it is a region deep in its tail whose
+    // weight erfcx ~ 1 / (x sqrt pi) still counts), and not below its lower end - EXCEPT, for Abs / Relu (E_k = 1), when
+    // the other argument is >= -4: erfcx(x < -7.5) >= 5e24 against erfcx(>= -4) <= 1.8e7 makes the other region's share
+    // < 4e-18 whether the large weight is exact or the table's edge value, and the 1 / e terms of its own moments are
+    // below 2e-25 either way.  That is the common high signal-to-noise case (one region holds all the mass).
+    const T xmin = fmin_(x0, x1), xmax = fmax_(x0, x1);
+    constexpr bool SAT = (KIND != 0);
+    // (a saturated argument must still be above the reference's log_Phi mask threshold: mask = 3 is what this form reports)
+    if (GRID) ok = xmax < T(kErfcxTHi) && (xmin >= T(kErfcxTLo) || (SAT && xmax >= T(-4) && xmin > T(0) - PwlMomentLim<T>::value));
     else ok = fmax_(fabs_(x0), fabs_(x1)) < PwlMomentLim<T>::value;
     if (KIND == 0) ok = ok && fabs_(bx) <= RcpCap<T>::value;             // bx enters through exp only: a NaN must not be clamped away
     if (VOTE) {
         if (!TM_WAVE_ALL(ok)) return false;
-    } else if (GRID) {                     // (a NaN becomes the lower edge: minNum / maxNum)
-        const T c0 = fmin_(fmax_(x0, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
-        const T c1 = fmin_(fmax_(x1, T(kErfcxTLo)), T(kErfcxTHi - 0.0078125));
-        const T d0 = x0 - c0, d1 = x1 - c1;
-        T dv = fma_(d0, d0, d1 * d1);
+    } else if (GRID) {
+        // no vote: the deviation from the domain as a float (0 inside; NaN for a NaN / infinite message)
+        const T hi_v = xmax - fmin_(xmax, T(kErfcxTHi));                                   // > 0 above the table (its last point is THi itself)
+        const T lo_v = fmax_(T(kErfcxTLo) - xmin, T(0));                                   // > 0 below it
+        // > 0: the other region is not negligible, or the low argument is at the mask threshold
+        const T other = SAT ? fmax_(T(-4) - xmax, T(0)) + fmax_((T(0) - PwlMomentLim<T>::value) - xmin + T(1e-3), T(0)) : T(1);
+        T dv = fma_(hi_v, hi_v, lo_v * other) + ((x0 - x0) + (x1 - x1));
         if (KIND == 0) dv += bx - bx;      // bx enters through exp only
         *dev = dv;
-        x0 = c0;
-        x1 = c1;
+    }
+    if (GRID) {                            // (a NaN becomes the lower edge: minNum / maxNum; only reachable without the vote)
+        x0 = fmin_(fmax_(x0, T(kErfcxTLo)), T(kErfcxTHi));
+        x1 = fmin_(fmax_(x1, T(kErfcxTLo)), T(kErfcxTHi));
     }
     T e0, e1;
 #if TRAMP_ERFCX_UNIFORM
