@@ -895,7 +895,7 @@ def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, wi
         Y[Y == 0] = 1.0
         ctx.sync()
         tf = time.perf_counter()
-        lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device")
+        lin = T.LinearChannel(W, dtype=np_dt, ctx=ctx, svd="device", digits=0)       # matrix cores first; int8 digits below
         ctx.sync()
         fact_s = time.perf_counter() - tf
         fz_peak = ctx.factorize_peak_bytes()
@@ -921,11 +921,11 @@ def other_config(T, ctx, which, N, B, np_dt, steps=10, warmup=2, damping=0.1, wi
         Y = dev_matvec(W2, M2, M1, A1) + 0.1 * rs.standard_normal((B, M2))
         ctx.sync()
         tf = time.perf_counter()
-        l1 = T.LinearChannel(W1, dtype=np_dt, ctx=ctx, svd="device")
+        l1 = T.LinearChannel(W1, dtype=np_dt, ctx=ctx, svd="device", digits=0)
         fz_peak = ctx.factorize_peak_bytes()
         held = W1.nbytes + W2.nbytes + l1._Uk.nbytes + l1._Vt.nbytes
         del W1
-        l2 = T.LinearChannel(W2, dtype=np_dt, ctx=ctx, svd="device")
+        l2 = T.LinearChannel(W2, dtype=np_dt, ctx=ctx, svd="device", digits=0)
         del W2
         ctx.sync()
         fact_s = time.perf_counter() - tf
@@ -1095,7 +1095,9 @@ def run(args):
         if comm is not None:
             comm.close()
         sys.exit(3)
-    lin = T.LinearChannel(_Shape(M, N), dtype=np_dt, ctx=ctx, factors=(Uk, sing, Vt, lin_rank))
+    # digits=0: the HEADLINE runs on the f64 / f32 matrix cores; the int8-digit engine (the library's default for ensembles
+    # since round 5, TRAMP_MATVEC_DIGITS=auto) is timed beside it under its own key
+    lin = T.LinearChannel(_Shape(M, N), dtype=np_dt, ctx=ctx, factors=(Uk, sing, Vt, lin_rank), digits=0)
     Y = Z + np.sqrt(args.noise_var) * noise
     del Z, noise
     if args.save_factors and rank == 0:
@@ -1290,7 +1292,7 @@ def run(args):
                 ep = model = lin = Uk = Vt = None             # (60 GB of factors and the message buffers go)
                 gc.collect()
                 try:
-                    return other_config(T, ctx, which, n_cfg, 64, np.float32, with_digits=args.full and not args.no_digits)
+                    return other_config(T, ctx, which, n_cfg, 64, np.float32, with_digits=not args.no_digits)
                 finally:
                     gc.collect()
             return go

@@ -342,6 +342,29 @@ class ExpectationPropagation:
                         and np.all(np.asarray(pri.mean) == 0) and lin.rank == min(lin.Nx, lin.Nz):
                     self._rot[i] = dict(side="in", lin=lin, k=min(lin.Nx, lin.Nz))
 
+    def _auto_attach_digits(self):
+        """TRAMP_MATVEC_DIGITS=auto (the default): an ensemble of >= 3 instances runs its dense passes on the int8-digit
+        engine (csrc/gemm_sliced.h: 7 digits for f64 factors, 4 for f32 - at least the accuracy of the matrix-core pass) if
+        the copies fit beside what is already allocated (2 forms x digits bytes per matrix element of Vt, and of Uk unless
+        the output side is carried in Uk's basis) with 8 GiB to spare.  One attach per channel (~1 s at 50 000 x 100 000);
+        LinearChannel(digits=0) or TRAMP_MATVEC_DIGITS=0 opts out, explicit digits are left alone."""
+        if self.batch < 3:
+            return
+        from .channels import LinearChannel
+        masks = self._lin_masks()
+        for f in self.factors:
+            if type(f) is not LinearChannel or f.digits or not getattr(f, "_digits_auto", False):
+                continue
+            uk = not (masks.get(f, 0) & 1)
+            digits = 7 if self.dtype == np.float64 else 4
+            need = 2 * digits * (f._Vt.shape[0] * f._Vt.shape[1] + (f._Uk.shape[0] * f._Uk.shape[1] if uk else 0))
+            free, _ = self.ctx.mem_info()
+            if free < need * 1.1 + (8 << 30):
+                f._digits_auto = False                 # asked once: not on this device
+                continue
+            f.attach_digits(digits, uk=uk)
+            f._digits_auto = False
+
     def _lin_masks(self):
         "LinearChannel -> tramp_linear_set_rotated mask (1 output side, 2 input side)"
         masks = {}
@@ -1112,6 +1135,8 @@ class ExpectationPropagation:
             # a warm start after a NON-adaptive run: the variable -> factor buffers are from before it, rebuild them
             self._adaptive_allocate(fresh=(not warm_start) or not getattr(self, "_prev_adaptive", False))
         self._prev_adaptive = adaptive
+        if not adaptive:
+            self._auto_attach_digits()
         if self._device_monitor and not adaptive:
             self._reset_monitor()            # a warm start begins a new run of the stopping rule (i = 0 again)
             stopper, host_cbs = self._split_callback(callback)

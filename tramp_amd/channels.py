@@ -574,9 +574,18 @@ class LinearChannel(Channel):
         self._handle = h
         self._t_key = self._u_key = None
         # opt-in: the dense passes of ensembles on the int8 matrix cores (csrc/gemm_sliced.h).  digits=None reads the
-        # switch TRAMP_MATVEC_DIGITS (0 = off, the default); 7 is f64-equivalent, 4 is the f32 setting.
+        # switch TRAMP_MATVEC_DIGITS (0 = off; 7 is f64-equivalent, 4 is the f32 setting).
+        # round 5: "auto" (the default of the switch) leaves the decision to the chain scheduler, which attaches them when an
+        # ENSEMBLE of >= 3 instances iterates and device memory allows (algos.py: _auto_attach_digits) - 1.4x on the dense
+        # passes at f64 accuracy, parity-tested against the goldens like the matrix-core engines
+        # (tests/test_gpu_digits_engine_suite.py); digits=0 / TRAMP_MATVEC_DIGITS=0 keeps the f64 / f32 matrix cores.
+        self._digits_auto = False
         if digits is None:
-            digits = int(os.environ.get("TRAMP_MATVEC_DIGITS", "0"))
+            env = os.environ.get("TRAMP_MATVEC_DIGITS", "auto").strip().lower()
+            if env in ("auto", ""):
+                digits, self._digits_auto = 0, True
+            else:
+                digits = int(env)
         self.digits = 0
         if digits:
             self.attach_digits(int(digits))

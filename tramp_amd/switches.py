@@ -19,7 +19,7 @@ SWITCHES = {
     "TRAMP_PRIOR_FUSE": ("1", "select", "0: producers never leave prior / likelihood moments (csrc/prior_hint.h)"),
     # dense linear channel (csrc/linear.hip, gemm_mfma.hip)
     "TRAMP_MATVEC_ALGO": ("0", "debug", "force a matrix-pass engine: 1 GEMV (VALU), 2 f64 / f32 MFMA, 3 the int8-digit copy; 0 = the digit copy if attached, else by batch size"),
-    "TRAMP_MATVEC_DIGITS": ("0", "select", "radix-256 digits of the int8 copies LinearChannel attaches to its factors (csrc/gemm_sliced.h): 0 none, 7 f64-equivalent, 8, 6, 4 (f32)"),
+    "TRAMP_MATVEC_DIGITS": ("auto", "select", "int8 copies of a LinearChannel's factors (csrc/gemm_sliced.h) in radix-256 digits: auto = the chain scheduler attaches 7 (f64) / 4 (f32) for ensembles of >= 3 instances when memory allows; 0 never; 7, 8, 6, 4 at construction"),
     "TRAMP_MFMA_SPLIT": ("0", "tune", "split-K factor of the MFMA passes; 0 = chosen from the grid size"),
     "TRAMP_MFMA_LDS_PAD": ("0", "tune", "extra dynamic LDS per workgroup of the MFMA passes (occupancy experiments)"),
     "TRAMP_MFMA_CHUNK_2D": ("0", "tune", "1: 64-instance chunks on the grid's y axis instead of interleaved in x"),
