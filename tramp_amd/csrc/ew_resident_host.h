@@ -21,7 +21,7 @@ constexpr int kResU = 4, kResDL = 1, kResDA = 3;
 // held in registers.
 template <typename Op> struct ResShape { static constexpr int U = kResU, NT = kBlock, FLAGS = 0, BPC = 2; };
 template <typename T, int KIND, bool FWD, bool UNI, bool LEAN> struct ResShape<PwlOp<T, KIND, FWD, UNI, LEAN>> {
-    static constexpr int U = sizeof(T) == 4 ? 2 : kResU, NT = kBlock, FLAGS = 0, BPC = 2;
+    static constexpr int U = sizeof(T) == 4 ? 2 : kResU, NT = kBlock, FLAGS = 0, BPC = sizeof(T) == 4 ? 3 : 2;
 };
 
 template <typename Op> struct ResidentOp { static constexpr bool value = false; };
