@@ -169,14 +169,14 @@ DFT_SHAPES = [(64,), (1000,), (8192,), (16, 32), (10, 160), (640, 32), (4, 8, 16
 @pytest.mark.parametrize("real", [True, False])
 @pytest.mark.parametrize("engine", ["own", "rocfft"])
 def test_dft_channel_real_and_complex_input(ctx, shape, dtype, real, engine, monkeypatch):
-    """DFTChannel messages (dft_channel.py:47-67) on rocFFT (the default) and on the own engine's natural-order transforms
-    (TRAMP_DFT_FFT=own; shapes it does not take - 15, 6x8, a last axis beyond one block - stay on rocFFT), for real z and
+    """DFTChannel messages (dft_channel.py:47-67) on rocFFT (TRAMP_DFT_FFT=rocfft) and on the own engine's natural-order
+    transforms (the default since round 5; shapes it does not take - 15, 6x8, a last axis beyond one block - stay on rocFFT), for real z and
     for complex z (real=False: planar [2, ...] arrays on both sides)."""
     import tramp_amd as T
     if engine == "own":
         monkeypatch.setenv("TRAMP_DFT_FFT", "own")
     else:
-        monkeypatch.delenv("TRAMP_DFT_FFT", raising=False)
+        monkeypatch.setenv("TRAMP_DFT_FFT", "rocfft")
     rs = np.random.RandomState(len(shape) + int(real))
     B, n = 3, int(np.prod(shape))
     ch = T.DFTChannel(real=real, shape=shape, dtype=dtype, ctx=ctx)
@@ -253,7 +253,7 @@ def test_complex_dft_channel_matches_reference_goldens(ctx, dtype, engine, monke
     if engine == "own":
         monkeypatch.setenv("TRAMP_DFT_FFT", "own")
     else:
-        monkeypatch.delenv("TRAMP_DFT_FFT", raising=False)
+        monkeypatch.setenv("TRAMP_DFT_FFT", "rocfft")
     _, dft = _load_complex_goldens()
     tol = 1e-12 if dtype == np.float64 else 3e-5
     for c in dft:

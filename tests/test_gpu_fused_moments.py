@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _own_fft_engine(monkeypatch):
     """These tests exercise the own FFT engine at sizes below the default switch-over (csrc/conv.hip own_engine_wanted:
-    rocFFT under 32768 points per signal); tests that compare engines set TRAMP_CONV_FFT themselves."""
+    rocFFT under 32768 points per signal until round 5; now the default anyway); tests that compare engines set TRAMP_CONV_FFT themselves."""
     monkeypatch.setenv("TRAMP_CONV_FFT", "own")
 
 

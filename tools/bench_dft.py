@@ -17,7 +17,7 @@ for shape, B in [((1 << 20,), 64), ((1000000,), 64), ((1024, 1024), 64), ((4096,
         if eng == "own":
             os.environ["TRAMP_DFT_FFT"] = "own"
         else:
-            os.environ.pop("TRAMP_DFT_FFT", None)
+            os.environ["TRAMP_DFT_FFT"] = "rocfft"
         ch = T.DFTChannel(shape=shape, dtype=np_dt, ctx=ctx)
         az, ax = ctx.array(np.full(B, 1.3)), ctx.array(np.full(B, 0.7))
         bz, bx = ctx.randn((B, n), np_dt, seed=1), ctx.randn((B, 2 * n), np_dt, seed=2)

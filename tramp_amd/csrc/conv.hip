@@ -472,16 +472,20 @@ void conv_free_fft2(tramp_conv* cv) {
     cv->partner = nullptr;
 }
 
-// Which engine transforms a signal of `points` complex points per instance.  Measured (tools/sweep_engine_defaults.sh,
-// profiles/r03/sweep_engine_defaults.txt): the own engine wins where the transforms are bound by memory - 256 x 256 and up
-// 1.05-1.27x, a 10^6-point gradient channel 2x - and loses 10-30 % on small arrays (128 x 128, 32^3, n <= 8192), which are
-// bound by launches and latency and where rocFFT has fused small-size kernels.  Default: own engine from 32768 points;
-// TRAMP_CONV_FFT=own / =rocfft force one everywhere (the tests run both), TRAMP_CONV_FFT_MIN_POINTS moves the threshold.
+// Which engine transforms a signal of `points` complex points per instance.  Round 5: the OWN engine wherever it has a
+// plan (lengths 2^a 5^b in its range; everything else - odd lengths, primes, signals below its smallest tile - is
+// rocFFT's), so no vendor library sits on the iteration path of the shapes it covers.  Measured
+// (tools/sweep_engine_defaults.sh, profiles/r05/sweep_engine_defaults.txt): ahead where the transforms are bound by
+// memory - 256 x 256 and up 1.05-1.27x, a 10^6-point gradient channel 2x - and 10-30 % behind rocFFT's fused small-size
+// kernels on small arrays (128 x 128, 32^3, n <= 8192), which are bound by launches; what the switch buys there is the
+// absence of rocFFT's run-time kernel compilation (78 s on a fresh box for the first f64 plan) and one code path.
+// TRAMP_CONV_FFT=own / =rocfft force one everywhere (the tests run both); TRAMP_CONV_FFT_MIN_POINTS=32768 restores the
+// round-3 threshold.
 bool own_engine_wanted(size_t points) {
     const char* eng = getenv("TRAMP_CONV_FFT");
     if (eng && strcmp(eng, "rocfft") == 0) return false;
     if (eng && strcmp(eng, "own") == 0) return true;
-    static const size_t min_points = getenv("TRAMP_CONV_FFT_MIN_POINTS") ? (size_t)atol(getenv("TRAMP_CONV_FFT_MIN_POINTS")) : 32768;
+    static const size_t min_points = getenv("TRAMP_CONV_FFT_MIN_POINTS") ? (size_t)atol(getenv("TRAMP_CONV_FFT_MIN_POINTS")) : 0;
     return points >= min_points;
 }
 
@@ -1654,14 +1658,13 @@ extern "C" int tramp_dft_create(tramp_ctx* ctx, int dtype, int ndim, const size_
     h->work_batch = 0;
     h->fftn = nullptr;
     h->complex_in = false;
-    // The spectrum is this channel's MESSAGE, so it has to leave in natural order - a plain library transform.  The own engine
-    // can deliver that at no extra pass (fft_pow2.h natural-order mode: last axis <= 4096 complex) and is then level with
-    // rocFFT at 1024 x 1024 (1.04x f64, 0.96x f32) but behind it at 4096 x 4096 (0.86x: the second pass of a long axis must
-    // go out of place) and on small arrays (0.6-0.8x, launch-bound); a gather through an index table after a permuted-order
-    // transform was slower everywhere (0.5-0.98x).  tools/bench_dft.py, profiles/r03/bench_dft_*.txt.  So: rocFFT by
-    // default, TRAMP_DFT_FFT=own selects the own engine where it applies.
+    // The spectrum is this channel's MESSAGE, so it has to leave in natural order.  The own engine delivers that at no extra
+    // pass (fft_pow2.h natural-order mode: last axis <= 4096 complex): level with rocFFT at 1024 x 1024 (1.04x f64, 0.96x
+    // f32), behind it at 4096 x 4096 (0.86x: the second pass of a long axis must go out of place) and on small arrays
+    // (0.6-0.8x, launch-bound) - tools/bench_dft.py, profiles/r03/bench_dft_*.txt.  Round 5: the own engine is the default
+    // where it applies (no vendor library on the iteration path); TRAMP_DFT_FFT=rocfft selects the library transform.
     const char* eng = getenv("TRAMP_DFT_FFT");
-    if (eng && strcmp(eng, "own") == 0 && fftnd_supported(dtype, ndim, h->dims, false)) {
+    if (!(eng && strcmp(eng, "rocfft") == 0) && fftnd_supported(dtype, ndim, h->dims, false)) {
         int rc = fftnd_plan_create(ctx, dtype, ndim, h->dims, &h->fftn, false);
         if (!rc) {
             if (fftnd_natural_ok(h->fftn)) rc = fftnd_enable_natural(ctx, h->fftn);

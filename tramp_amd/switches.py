@@ -32,9 +32,9 @@ SWITCHES = {
     "TRAMP_EIG_VERBOSE": (None, "debug", "set: phase timings of the factorisation on stderr"),
     # structured channels (csrc/conv.hip, fft_pow2.hip)
     "TRAMP_CONV_FFT": ("auto", "select", "own | rocfft: FFT engine of the convolution / gradient channels"),
-    "TRAMP_CONV_FFT_MIN_POINTS": ("32768", "tune", "signals shorter than this go to rocFFT under TRAMP_CONV_FFT=auto"),
+    "TRAMP_CONV_FFT_MIN_POINTS": ("0", "tune", "signals shorter than this go to rocFFT under TRAMP_CONV_FFT=auto (32768 was the measured break-even of round 3; 0 = the own engine wherever it has a plan)"),
     "TRAMP_CONV_IPB": ("0", "tune", "images per workgroup of the one-launch small-image kernel; 0 = chosen from the shape"),
-    "TRAMP_DFT_FFT": ("auto", "select", "own | rocfft: FFT engine of DFTChannel"),
+    "TRAMP_DFT_FFT": ("own", "select", "own | rocfft: FFT engine of DFTChannel (own: natural-order mode of the own engine where it applies, else rocFFT)"),
     "TRAMP_FFT_BLOCK_THREADS": ("0", "tune", "threads of the own engine's block pass; 0 = by length"),
     "TRAMP_FFT_STRIDED_THREADS": ("0", "tune", "threads of the own engine's strided pass; 0 = by length"),
     "TRAMP_FFT_AXIS_THREADS": ("0", "tune", "threads of the own engine's long-axis pass (N-D transforms)"),
