@@ -302,6 +302,11 @@ int tramp_prior_hint_stats(tramp_ctx* ctx, unsigned long long* armed, unsigned l
  * tile kernels.  Same entry points, same results to reduction-order rounding, run-to-run reproducible; chosen by shape
  * (TRAMP_EW_RESIDENT=0 turns it off).  How many updates took that form since the context was made: */
 int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs);
+/* A FEW instances too large for one workgroup (BASELINE configs[1] read literally: ONE instance of 10^6 components) are
+ * updated in ONE launch: batch x G workgroups, all resident, share the instances, exchange their block sums through
+ * self-validating granules and write the update from their registers (ew_kernels.hip: ew_coop; TRAMP_EW_COOP=0 turns it
+ * off).  How many updates took that form: */
+int tramp_coop_stats(tramp_ctx* ctx, unsigned long long* runs);
 /* The pipeline's workgroups hand tile sums to each other and must all be resident at once (checked by an occupancy query
  * before every launch).  Should a hand-off still not arrive within the kernel's deadline (2 s; a CU mask or another
  * process's kernels on the device can do that), the waiting workgroups give up: the update of the affected instances

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "tramp_region_log_partition": [vp, i32, i32, i32, vp, sz, sz, vp, vp, vp, vp, vp],
     "tramp_resident_stats": [vp, C.POINTER(u64)],
     "tramp_resident_errors": [vp, C.POINTER(u64)],
+    "tramp_coop_stats": [vp, C.POINTER(u64)],
     "tramp_resident_covers": [vp, i32, sz, sz, C.POINTER(i32)],
     "tramp_linear_variance": [vp, vp, i32, sz, vp, vp, vp, vp, vp],
     "tramp_linear_message": [vp, vp, i32, sz, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp, i32],

@@ -55,6 +55,22 @@ extern "C" int tramp_ctx_create(int device, tramp_ctx** out) {
         delete ctx;
         return TRAMP_ENOMEM;
     }
+    // granules and arrival counters of the one-launch elementwise form: sentinel / zero between calls
+    ctx->capacity_coop = (size_t)2 * (size_t)(ctx->num_cu > 0 ? ctx->num_cu : 0);
+    if (ctx->capacity_coop) {
+        if (hipMalloc((void**)&ctx->coop_slots, coop_slot_bytes(ctx->capacity_coop)) == hipSuccess &&
+            hipMalloc((void**)&ctx->coop_epoch, 64) == hipSuccess &&
+            hipMemset(ctx->coop_slots, 0xFF, coop_slot_bytes(ctx->capacity_coop)) == hipSuccess &&
+            hipMemset(ctx->coop_epoch, 0, 64) == hipSuccess) {
+        } else {
+            (void)hipGetLastError();
+            if (ctx->coop_slots) (void)hipFree(ctx->coop_slots);
+            if (ctx->coop_epoch) (void)hipFree(ctx->coop_epoch);
+            ctx->coop_slots = nullptr;
+            ctx->coop_epoch = nullptr;
+            ctx->capacity_coop = 0;
+        }
+    }
     unsigned* stat = nullptr;
     if (hipHostMalloc((void**)&stat, 64, hipHostMallocDefault) == hipSuccess) {       // (without it the lean updates keep no statistics)
         stat[0] = stat[1] = stat[2] = 0;
@@ -72,6 +88,8 @@ extern "C" int tramp_ctx_destroy(tramp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->lean_stat) (void)hipHostFree((void*)ctx->lean_stat);
+    if (ctx->coop_slots) (void)hipFree(ctx->coop_slots);
+    if (ctx->coop_epoch) (void)hipFree(ctx->coop_epoch);
     gemm_sliced_ctx_destroy(ctx);
     flush_deferred_frees(ctx);
     free(ctx->deferred_free);
@@ -268,6 +286,12 @@ extern "C" int tramp_resident_covers(tramp_ctx* ctx, int dtype, size_t n, size_t
 extern "C" int tramp_resident_stats(tramp_ctx* ctx, unsigned long long* runs) {
     if (!ctx || !runs) return TRAMP_EINVAL;
     *runs = ctx->resident_runs;
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_coop_stats(tramp_ctx* ctx, unsigned long long* runs) {
+    if (!ctx || !runs) return TRAMP_EINVAL;
+    *runs = ctx->coop_runs;
     return TRAMP_OK;
 }
 

@@ -39,6 +39,13 @@ struct TrampPriorHint {
     bool ready;               // a producer has left the partials of the CURRENT contents of buf
 };
 
+// Granules of the one-launch form (ew_coop), in two banks of [capacity] block sums followed by the instance totals:
+// R <= 16 copies per instance (one per 32 workgroups, so no line has more than 32 pollers), each copy on a line of its
+// own 4352 bytes from the next.  batch * R <= capacity / 32 + batch lines.
+constexpr size_t kCoopLineStride = 544;            // in 8-byte granules
+__host__ __device__ inline size_t coop_total_lines(size_t capacity) { return capacity / 32 + capacity + 2; }
+inline size_t coop_slot_bytes(size_t capacity) { return 2 * (capacity + coop_total_lines(capacity) * kCoopLineStride) * 8; }
+
 struct tramp_ctx {
     int device;
     hipStream_t stream;
@@ -61,6 +68,10 @@ struct tramp_ctx {
     unsigned long long resident_runs;           // factor updates that took the resident single-pass pipeline (ew_resident.h)
     volatile unsigned* lean_stat;               // pinned host {flagged instances, batch} of the last lean resident update (ew_flag_nan);
                                                 // [2]: a resident kernel gave up a hand-off (ew_resident.h: res_expired)
+    unsigned long long* coop_slots;             // two banks of granules of the one-launch form (ew_kernels.hip: ew_coop); the bank the next launch uses is all sentinel
+    unsigned* coop_epoch;                       // device word: launches of the one-launch form so far (its parity picks the bank)
+    size_t capacity_coop;                       // 2 x CUs: the workgroups one such launch may use
+    unsigned long long coop_runs;               // updates that took the one-launch form
     size_t fz_peak_bytes;                       // work space of the last tramp_linear_factorize (factorize.hip)
     int resident_errors_seen;                   // the host has seen lean_stat[2] and taken the resident pipeline out of service
     int lean_skip;                              // lean updates to skip after one that flagged more than a quarter of its instances

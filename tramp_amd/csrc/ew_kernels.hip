@@ -665,6 +665,223 @@ bool resident_covers(const tramp_ctx* ctx, size_t n, size_t batch, size_t elem_s
     return resident_covers_shape(ctx, n, batch, elem_size, (size_t)kBlock * kResU, 2);        // kResBlocksPerCU (ew_resident.h; static_assert in ew_resident_impl.h)
 }
 
+// ---------------------------------------------------------------- one launch for a FEW large instances (round 5)
+// BASELINE configs[1] read literally is ONE instance of 10^6 components: 16 MB that the tile form handles in three
+// launches (14 us, launch-bound).  Here G workgroups share an instance, all of them resident at once (batch * G <= 2 x
+// CUs, checked by an occupancy query): each loads its slice into registers, evaluates, and publishes its block sum of v
+// in an 8-byte self-validating granule (as ew_resident.h).  Workgroup 0 of the instance polls the G granules, folds them
+// in index order (a run-to-run reproducible mean) and publishes the total in up to 16 copies; the others poll one copy
+// (<= 32 pollers per line) and write the update from their registers: the message is read once and written once in
+// ONE launch.
+//
+// No atomics and no reset launch: the granules live in TWO banks and a device-side epoch word picks the bank.  Every
+// launch reads the epoch first, works in bank (epoch & 1), and puts the whole OTHER bank back to the sentinel (the
+// launch before used it and is complete; the next one will use it).  Workgroup (0, 0) adds one to the epoch as its last
+// act, after it has seen the total of every instance - by then every workgroup of the launch has read the epoch.  The
+// state lives on the device, so the launch replays unchanged inside a hipGraph.  (Measured on the way here: an atomic
+// arrival counter costs 0.2 us per same-address atomic - 7 us at 32 per address; one lane resetting 489 granules in turn
+// 10 us; every workgroup polling all G granules 26 us.)
+//
+// A hand-off that has not arrived by the deadline is given up like the resident pipeline's: NaN result, host-visible
+// error word, tile kernels afterwards.
+constexpr unsigned long long kCoopSentinel = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned long long kCoopNaN = 0x7ff8000000000000ull;
+
+template <typename T, typename Op, int K>
+__global__ __launch_bounds__(kBlock, 2) void ew_coop(Op op, size_t n, unsigned G, size_t chunk, const T* __restrict__ in0,
+                                                     const T* __restrict__ in1, MsgOut out, unsigned long long* __restrict__ slots,
+                                                     size_t capacity, unsigned* __restrict__ epoch, long long deadline_ticks,
+                                                     volatile unsigned* err_host) {
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    __shared__ double smem[kBlock / kWave];
+    __shared__ double s_tot;
+    const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
+    const long long lim = deadline_ticks > 0 ? deadline_ticks : 200000000LL;
+    const size_t b = blockIdx.y;
+    const unsigned g = blockIdx.x, tid = threadIdx.x;
+    const unsigned e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const size_t lines = coop_total_lines(capacity), bank = capacity + lines * kCoopLineStride;
+    unsigned long long* mine_bank = slots + (e & 1u) * bank;
+    {   // the other bank back to the sentinel: [capacity] block sums + one granule per total line
+        unsigned long long* other = slots + ((e + 1u) & 1u) * bank;
+        const size_t npos = capacity + lines, nthr = (size_t)gridDim.x * gridDim.y * kBlock;
+        for (size_t pos = ((size_t)b * gridDim.x + g) * kBlock + tid; pos < npos; pos += nthr) {
+            const size_t at = pos < capacity ? pos : capacity + (pos - capacity) * kCoopLineStride;
+            __hip_atomic_store(other + at, kCoopSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    op.setup(b);
+    const size_t nv = n / VN;
+    const size_t p0 = (size_t)g * chunk, p1 = (p0 + chunk < nv) ? p0 + chunk : nv;
+    const V* q0 = reinterpret_cast<const V*>(in0 + b * n);
+    const V* q1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
+    const double d = out.damping;
+    const V* bold = (d != 0.0) ? reinterpret_cast<const V*>(reinterpret_cast<const T*>(out.b_old) + b * n) : nullptr;
+    V x0[K], x1[K], vold[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const size_t i = p0 + tid + (size_t)k * kBlock;
+        if (i < p1) {
+            x0[k] = q0[i];
+            if (Op::NIN > 1) x1[k] = q1[i];
+            if (bold) vold[k] = bold[i];
+        }
+    }
+    V rr[K];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const size_t i = p0 + tid + (size_t)k * kBlock;
+        if (i < p1) {
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                const T a0 = vget<T>(x0[k], j);
+                const T a1 = (Op::NIN > 1) ? vget<T>(x1[k], j) : a0;
+                EwOut<T> o = op.eval(a0, a1);
+                acc += (double)o.v;
+                if (not_finite(o.r)) acc += __longlong_as_double((long long)kCoopNaN);
+                vset<T>(rr[k], j, o.r);
+            }
+            if (Op::TARGET != 0) x0[k] = x1[k];                     // keep the target message
+        }
+    }
+    acc = block_sum(acc, smem);
+    unsigned long long* sl = mine_bank + b * (size_t)G;                 // this instance's block sums
+    const unsigned R = (G + 31u) / 32u < 16u ? (G + 31u) / 32u : 16u;    // copies of the total, <= 32 pollers each
+    unsigned long long* tot = mine_bank + capacity + (b * R) * kCoopLineStride;
+    if (tid == 0) {
+        unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+        if (ab == kCoopSentinel) ab = kCoopNaN;
+        __hip_atomic_store(sl + g, ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < kWave) {
+        double part = 0.0;
+        bool gave_up = false;
+        if (g == 0) {
+            for (;;) {
+                bool ok = true;
+                part = 0.0;
+                for (unsigned i = tid; i < G; i += kWave) {            // lane-strided, then a fixed-order wave sum
+                    const unsigned long long bits = __hip_atomic_load(sl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && bits != kCoopSentinel;
+                    part += __longlong_as_double((long long)bits);
+                }
+                if (__all(ok)) break;
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t_start > lim) {
+                    gave_up = true;
+                    break;
+                }
+            }
+            part = __shfl(wave_sum(part), 0);                          // lane 0 holds the sum
+            if (gave_up) part = __longlong_as_double((long long)kCoopNaN);
+            unsigned long long tb = (unsigned long long)__double_as_longlong(part);
+            if (tb == kCoopSentinel) tb = kCoopNaN;
+            if (tid < R) __hip_atomic_store(tot + tid * kCoopLineStride, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned long long* mine = tot + (g % R) * kCoopLineStride;
+            for (;;) {
+                const unsigned long long bits = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bits != kCoopSentinel) {
+                    part = __longlong_as_double((long long)bits);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t_start > lim + 1000000LL) {     // + 10 ms: workgroup 0 reports first
+                    gave_up = true;
+                    part = __longlong_as_double((long long)kCoopNaN);
+                    break;
+                }
+            }
+        }
+        if (gave_up && tid == 0 && err_host) *err_host = 1u;
+        if (tid == 0) s_tot = part;
+    }
+    __syncthreads();
+    const double v = s_tot / (double)n;
+    const double a_in = op.a_msg;
+    const double a_new = tmath::a_new_of(v, a_in);
+    if (g == 0 && tid == 0) {
+        out.a_new[b] = (d != 0.0) ? d * out.a_old[b] + (1.0 - d) * a_new : a_new;
+        if (out.v) out.v[b] = v;
+    }
+    const T vinv = T(a_in + a_new), dT = T(d), omd = T(1.0 - d);
+    V* bo = reinterpret_cast<V*>(reinterpret_cast<T*>(out.b_new) + b * n);
+    V* ro = out.r ? reinterpret_cast<V*>(reinterpret_cast<T*>(out.r) + b * n) : nullptr;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const size_t i = p0 + tid + (size_t)k * kBlock;
+        if (i < p1) {
+            V vo;
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                T bn = vget<T>(rr[k], j) * vinv - vget<T>(x0[k], j);
+                if (bold) bn = dT * vget<T>(vold[k], j) + omd * bn;
+                vset<T>(vo, j, bn);
+            }
+            bo[i] = vo;
+            if (ro) ro[i] = rr[k];
+        }
+    }
+    // the epoch moves on once the total of EVERY instance is out: every workgroup of the launch has then read it
+    if (g == 0 && b == 0 && tid < kWave) {
+        const unsigned long long* t0 = mine_bank + capacity;
+        for (;;) {
+            bool ok = true;
+            for (unsigned i = tid; i < gridDim.y; i += kWave)
+                ok = ok && __hip_atomic_load(t0 + ((size_t)i * R) * kCoopLineStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kCoopSentinel;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t_start > lim + 2000000LL) {
+                if (tid == 0 && err_host) *err_host = 1u;
+                break;
+            }
+        }
+        if (tid == 0) __hip_atomic_store(epoch, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T, typename Op, int K>
+static int launch_coop(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, unsigned G, size_t chunk, const void* in0, const void* in1,
+                       const MsgOut& out) {
+    static int occ = -1;
+    if (occ < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ew_coop<T, Op, K>, kBlock, 0) != hipSuccess) occ = 0;
+    if (occ < 2) return kResNotEligible;
+    static const long long timeout_ms = getenv("TRAMP_EW_RESIDENT_TIMEOUT_MS") ? atoll(getenv("TRAMP_EW_RESIDENT_TIMEOUT_MS")) : 2000;
+    MsgOut o = out;
+    if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
+    ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
+    hipLaunchKernelGGL((ew_coop<T, Op, K>), dim3(G, (unsigned)batch), dim3(kBlock), 0, ctx->stream, op, n, G, chunk,
+                       reinterpret_cast<const T*>(in0), reinterpret_cast<const T*>(in1), o, ctx->coop_slots, ctx->capacity_coop, ctx->coop_epoch,
+                       (timeout_ms > 0 ? timeout_ms : 2000) * 100000LL, ctx->lean_stat ? ctx->lean_stat + 2 : nullptr);
+    TRAMP_LAUNCH_CHECK(ctx);
+    ctx->coop_runs += 1;
+    return TRAMP_OK;
+}
+
+// kResNotEligible: the shape (or the context's state) is not for the one-launch form
+template <typename T, typename Op>
+static int run_coop(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, const void* in0, const void* in1, const MsgOut& out) {
+    static const size_t on = env_size("TRAMP_EW_COOP", 1);
+    static const bool cu_masked = (getenv("HSA_CU_MASK") && *getenv("HSA_CU_MASK")) || (getenv("ROC_GLOBAL_CU_MASK") && *getenv("ROC_GLOBAL_CU_MASK"));
+    constexpr int VN = Vec<T>::N;
+    if (!on || cu_masked || !ctx->coop_slots || ctx->capacity_coop == 0 || (ctx->lean_stat && ctx->lean_stat[2])) return kResNotEligible;
+    if (out.mask || out.count || (n % VN) != 0 || batch == 0 || batch > ctx->capacity_coop) return kResNotEligible;
+    const size_t nv = n / VN;
+    size_t G = ctx->capacity_coop / batch;                      // workgroups per instance: all of them resident at once
+    const size_t gmax = (nv + kBlock - 1) / kBlock;              // at least one piece per thread
+    if (G > gmax) G = gmax;
+    if (G < 2) return kResNotEligible;
+    const size_t chunk = (nv + G - 1) / G;
+    G = (nv + chunk - 1) / chunk;
+    const size_t per_thread = (chunk + kBlock - 1) / kBlock;
+    if (per_thread > 8) return kResNotEligible;
+    if (per_thread <= 1) return launch_coop<T, Op, 1>(ctx, op, n, batch, (unsigned)G, chunk, in0, in1, out);
+    if (per_thread <= 2) return launch_coop<T, Op, 2>(ctx, op, n, batch, (unsigned)G, chunk, in0, in1, out);
+    if (per_thread <= 4) return launch_coop<T, Op, 4>(ctx, op, n, batch, (unsigned)G, chunk, in0, in1, out);
+    return launch_coop<T, Op, 8>(ctx, op, n, batch, (unsigned)G, chunk, in0, in1, out);
+}
+
 template <typename T, typename Op>
 static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void* in0,
                         const void* in1, const double* a_in_d, const MsgOut& out,
@@ -683,6 +900,11 @@ static int run_two_pass(tramp_ctx* ctx, Op op, size_t n, size_t batch, const voi
         }
     }
     const bool vec = (n % VN) == 0;
+    // a few instances too large for one workgroup, small enough for one wave of resident workgroups: ONE launch
+    if (vec && !hint && n > (size_t)kBlock * kSingleVpt * VN) {
+        const int rc = run_coop<T, Op>(ctx, op, n, batch, in0, in1, out);
+        if (rc != kResNotEligible) return rc;
+    }
     const int nblk = blocks_for(n, VN);
     // heavy factors (erfcx / log / tanh per component) park r in a scratch; light ones recompute
     const bool store_r = Op::HEAVY;

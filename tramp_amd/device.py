@@ -153,6 +153,12 @@ class Context:
         self._call("tramp_factorize_peak_bytes", C.byref(b))
         return b.value
 
+    def coop_runs(self):
+        "factor updates that took the one-launch form for a few large instances (csrc/ew_kernels.hip: ew_coop)"
+        r = C.c_ulonglong()
+        self._call("tramp_coop_stats", C.byref(r))
+        return r.value
+
     def resident_gave_up(self):
         """True once a resident kernel of this context gave up a hand-off (its deadline passed: the affected instances came
         back NaN) - every later update takes the tile kernels (include/tramp_hip.h: tramp_resident_errors)"""

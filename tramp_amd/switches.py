@@ -12,6 +12,7 @@ SWITCHES = {
     # componentwise updates (csrc/ew_kernels.hip, ew_resident.h)
     "TRAMP_EW_RESIDENT": ("1", "select", "0: never take the resident single-pass pipeline (the tile kernels' two passes instead); ROCm's HSA_CU_MASK / ROC_GLOBAL_CU_MASK, if set, have the same effect (the co-residency check cannot see a CU mask)"),
     "TRAMP_EW_RESIDENT_K7": ("1", "select", "0: the Sgn / Abs / Relu channels stay on the tile kernels' two passes"),
+    "TRAMP_EW_COOP": ("1", "select", "0: a few large instances take the tile kernels' three launches instead of the one-launch cooperative form"),
     "TRAMP_EW_LEAN_ADAPT": ("1", "select", "0: a lean resident K7 update that had to redo more than a quarter of its instances does not send the next 15 calls to the tile kernels"),
     "TRAMP_EW_RESIDENT_TIMEOUT_MS": ("2000", "tune", "deadline of a resident kernel: hand-offs still missing then are given up (NaN update, tile kernels afterwards)"),
     "TRAMP_EW_RESIDENT_DBG_SKIP": (None, "debug", "tile index + 1 whose sum a resident kernel never publishes (forces the give-up path in tests)"),
