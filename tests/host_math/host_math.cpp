@@ -123,7 +123,8 @@ void hm_relu_lik_f64(size_t n, const double* bz, const double* y, double az, dou
     }
 }
 double hm_a_new(double v, double a) { return a_new_of(v, a); }
-// which: 0 erfcx_hot<false>, 1 erfcx_hot<true> (uniform-grid table), 2 exp_fast, 3 exp_clamped, 4 tanh_hot, 5 rcp_pos, 6 expit
+// which: 0 erfcx_hot<false>, 1 erfcx_hot<true> (uniform-grid table), 2 exp_fast, 3 exp_clamped, 4 tanh_hot, 5 rcp_pos, 6 expit,
+// 7 tanh_tab (the table form of the binary prior)
 void hm_special_f64(int which, size_t n, const double* x, double* out) {
     for (size_t i = 0; i < n; ++i) {
         switch (which) {
@@ -133,6 +134,7 @@ void hm_special_f64(int which, size_t n, const double* x, double* out) {
             case 3: out[i] = exp_clamped(x[i]); break;
             case 4: out[i] = tanh_hot(x[i]); break;
             case 5: out[i] = rcp_pos(x[i]); break;
+            case 7: out[i] = tanh_tab(x[i]); break;
             default: out[i] = expit<double>(x[i]); break;
         }
     }
@@ -142,6 +144,7 @@ void hm_special_f32(int which, size_t n, const float* x, float* out) {
         switch (which) {
             case 0: out[i] = erfcx_hot<false>(x[i]); break;
             case 3: out[i] = exp_clamped(x[i]); break;
+            case 7: out[i] = tanh_tab(x[i]); break;
             default: out[i] = expit<float>(x[i]); break;
         }
     }

@@ -258,6 +258,33 @@ def test_binary_prior_and_relu_likelihood_resident(T, ctx, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_relu_likelihood_lean_form_redoes_what_it_cannot_finish(T, ctx, dtype):
+    """ReluLikelihood on the pipeline is the lean form (csrc/ew_ops.h ReluLikOp<T, true>: the flat region's half line from
+    the one-value erfcx table, no control flow).  A flat component whose message sits far inside z > 0 (erfcx argument
+    past the table) sends its instance to the tile kernels - same result as the oracle; an observation no region holds
+    (y < 0: piecewise_linear_likelihood.py:36-63, softmax of (-inf, -inf)) or a NaN message makes its own instance NaN
+    and leaves the others alone."""
+    B, n = shape_for(ctx, dtype)
+    rs = np.random.RandomState(29)
+    y = np.maximum(rs.standard_normal((B, n)), 0.0).astype(dtype)
+    az = rs.uniform(0.4, 2.5, B)
+    bz = (rs.standard_normal((B, n)) * 1.5).astype(dtype)
+    flat = np.flatnonzero(y[3] == 0)[:3]
+    bz[3, flat] = [60.0, 25.0, -80.0]                  # two beyond the table's upper end, one far below its lower end
+    y[5, 7] = -1.0
+    bz[9, np.flatnonzero(y[9] == 0)[0]] = np.nan
+    lk = T.ReluLikelihood(y=y, dtype=dtype, ctx=ctx)
+    runs0 = ctx.resident_runs()
+    a_new, b_new = lk.compute_backward_message(az, bz)
+    assert ctx.resident_runs() == runs0 + 1
+    assert np.isnan(a_new[5]) and np.isnan(a_new[9]) and np.all(np.isfinite(np.delete(a_new, [5, 9])))
+    for i in (0, 3, 4, 6, B - 1):
+        a_ref, b_ref = orc.relu_lik_message(az[i], bz[i].astype(np.float64), y[i].astype(np.float64))
+        close_a(a_new[i], a_ref, az[i], dtype)
+        close(b_new[i], b_ref, dtype, scale=10 * np.abs(b_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_resident_pipeline_on_seeded_random_shapes_around_its_limits(T, ctx, dtype):
     """Shapes drawn around the eligibility limits of the pipeline (tiles per instance from 1 to past the window, batches
     that just fill or just miss the minimum number of rounds, instance lengths that end inside a tile): whatever form

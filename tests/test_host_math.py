@@ -293,6 +293,11 @@ def test_special_functions_of_the_streaming_kernels(hm):
     xt = np.concatenate([rng.uniform(-30, 30, 20000), rng.uniform(-0.3, 0.3, 5000), [0.0, 0.25, -0.25, 1e-300]])
     got, exp = _special(hm, 4, xt), np.tanh(xt)
     assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)) < 2e-13
+    # the table form (tanh_table.h, round 5): the binary prior's
+    xt = np.concatenate([xt, 10.0 ** rng.uniform(-12, 0, 3000), (np.arange(1249) + 0.5) / 64, [19.5, 19.5 + 1e-9, -25.0, 700.0, np.inf, -np.inf]])
+    got, exp = _special(hm, 7, xt), np.tanh(xt)
+    assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)) < 1e-15
+    assert np.isnan(_special(hm, 7, [np.nan])[0]) and _special(hm, 7, [-0.0])[0] == 0.0
     xr = 10.0 ** rng.uniform(-300, 300, 20000)
     assert np.max(np.abs(_special(hm, 5, xr) * xr - 1.0)) < 4e-16
     xs = rng.uniform(-800, 800, 20000)
@@ -301,6 +306,9 @@ def test_special_functions_of_the_streaming_kernels(hm):
     x32 = np.concatenate([rng.uniform(0, 30, 5000), rng.uniform(-3, 0, 2000)]).astype(np.float32)
     got, exp = _special(hm, 0, x32, f32=True), special.erfcx(x32.astype(np.float64))
     assert np.max(np.abs(got - exp) / exp) < 3e-6
+    xt32 = np.concatenate([rng.uniform(-12, 12, 5000), 10.0 ** rng.uniform(-8, 0, 1000), [9.5, 9.6, -40.0, np.inf]]).astype(np.float32)
+    got, exp = _special(hm, 7, xt32, f32=True), np.tanh(xt32.astype(np.float64))
+    assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-30)) < 4e-7 and np.isnan(_special(hm, 7, np.float32([np.nan]), f32=True)[0])
     xe32 = rng.uniform(-85, 88, 5000).astype(np.float32)           # normal f32 results
     got, exp = _special(hm, 3, xe32, f32=True), np.exp(xe32.astype(np.float64))
     assert np.max(np.abs(got - exp) / exp) < 1e-6

@@ -1235,6 +1235,18 @@ extern "C" int tramp_relu_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     ReluLikOp<float> of{az_d, slope_neg};
     ReluLikOp<double> od{az_d, slope_neg};
+    // Relu proper at large shapes: the lean form on the resident pipeline, then the tile kernels for the instances it could
+    // not finish (as tramp_sgn_lik_bwd)
+    if (slope_neg == 0.0 && n && batch && bz_d && y_d && a_new_d && b_new_d && !r_d && (damping == 0.0 || (a_old_d && b_old_d))) {
+        int rc = kResNotEligible;
+        if (dtype == TRAMP_F32) rc = run_resident<float>(ctx, ReluLikOp<float, true>{az_d, 0.0}, n, batch, bz_d, y_d, az_d, out);
+        else if (dtype == TRAMP_F64) rc = run_resident<double>(ctx, ReluLikOp<double, true>{az_d, 0.0}, n, batch, bz_d, y_d, az_d, out);
+        if (rc == TRAMP_OK) {
+            if (dtype == TRAMP_F32) return run_tiles<float>(ctx, of, n, batch, bz_d, y_d, az_d, out, true, nullptr, true);
+            return run_tiles<double>(ctx, od, n, batch, bz_d, y_d, az_d, out, true, nullptr, true);
+        }
+        if (rc != kResNotEligible) return rc;
+    }
     DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bz_d, y_d, az_d, out)),
                    (run_two_pass<double>(ctx, od, n, batch, bz_d, y_d, az_d, out)));
 }

@@ -68,11 +68,11 @@ template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1)
     const double* ax;
     double b0;                              // natural parameter 0.5 log(p+ / p-), binary_prior.py:27
     double a_msg;
-    __device__ static void stage() {}
+    __device__ static void stage() { tmath::tanh_setup<T>(); }
     __device__ void prepare(size_t b) { a_msg = ax[b]; }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T) const {
-        const T t = tmath::tanh_hot(x0 + T(b0));                 // beliefs/binary.py:8-13
+        const T t = tmath::tanh_tab(x0 + T(b0));                 // beliefs/binary.py:8-13
         return {t, T(1) - t * t, 0u};
     }
 };
@@ -152,7 +152,10 @@ template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
     }
 };
 
-template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
+// LEAN (slope_neg == 0 only): the resident pipeline's form - no control flow; the flat region's half-line by
+// tmath::sgn_lik_posterior_lean (z <= 0 is the sign likelihood's y = -1), the pinned region by selects; an observation that
+// no region holds (y < 0, NaN) or a message beyond the erfcx table comes back in EwOut::dev and the caller redoes the instance.
+template <typename T, bool LEAN = false> struct ReluLikOp {  // in0 = bz, in1 = y
     static constexpr bool HEAVY = true;
     static constexpr int NIN = 2;
     static constexpr int TARGET = 0;
@@ -161,7 +164,10 @@ template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
     tmath::RegionConst<T> c;
     T sT;
     double a_msg;
-    __device__ static void stage() {tmath::erfcx_setup<T>(); }
+    __device__ static void stage() {
+        if (LEAN) tmath::erfcx_setup_tay<T>();
+        else tmath::erfcx_setup<T>();
+    }
     __device__ void prepare(size_t b) {
         a_msg = az[b];
         c = tmath::region_const<T>(a_msg);
@@ -169,8 +175,17 @@ template <typename T> struct ReluLikOp {  // in0 = bz, in1 = y
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T x1) const {
-        RV<T> o = tmath::relu_lik_posterior<T>(x0, x1, sT, c);
-        return {o.r, o.v, 0u};
+        if constexpr (LEAN) {
+            T dev;
+            const RV<T> h = tmath::sgn_lik_posterior_lean<T>(x0, T(-1), c, &dev);
+            const bool pos = x1 > T(0), none = !(x1 >= T(0));
+            dev = pos ? T(0) : dev;                                   // a pinned component does not look at the message
+            dev = none ? T(__builtin_nan("")) : dev;
+            return {pos ? x1 : h.r, pos ? T(0) : h.v, 0u, dev};
+        } else {
+            RV<T> o = tmath::relu_lik_posterior<T>(x0, x1, sT, c);
+            return {o.r, o.v, 0u};
+        }
     }
 };
 
@@ -263,6 +278,7 @@ template <typename Op> struct OpLean { static constexpr bool value = false; };
 template <typename T, int KIND, bool FWD, bool UNI> struct OpLean<PwlOp<T, KIND, FWD, UNI, true>> { static constexpr bool value = true; };
 template <typename T> struct OpLean<SgnLikOp<T, true>> { static constexpr bool value = true; };
 template <typename T> struct OpLean<SgnLikBitsOp<T, true>> { static constexpr bool value = true; };
+template <typename T> struct OpLean<ReluLikOp<T, true>> { static constexpr bool value = true; };
 
 template <typename Op> struct OpCounts { static constexpr bool value = false; };
 template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };

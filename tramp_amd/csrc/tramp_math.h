@@ -84,10 +84,12 @@ TM_HD float fma_(float a, float b, float c) { return ::fmaf(a, b, c); }
 #if defined(__HIPCC__)
 #include "erfcx_table.h"
 #include "erfcx_ttable.h"
+#include "tanh_table.h"
 #else
 #define __device__              // the generated tables say `__device__ const`: plain constants for a host compiler
 #include "erfcx_table.h"
 #include "erfcx_ttable.h"
+#include "tanh_table.h"
 #undef __device__
 #endif
 namespace tmath {
@@ -114,6 +116,9 @@ __shared__ double g_erfcx_lds[(kErfcxD + 1) * kErfcxK];
 __shared__ double g_erfcx_tlds[kErfcxTK];
 __shared__ float g_erfcx_tlds_f[kErfcxTKF];
 #endif
+// tanh(k / 64) (tanh_table.h, 9.8 KiB of LDS; f32: k / 32, 1.2 KiB): the binary prior's tanh_tab.  Staged by tanh_setup().
+__shared__ double g_tanh_lds[kTanhK];
+__shared__ float g_tanh_lds_f[kTanhKF];
 template <bool UNI = false> __device__ __forceinline__ void erfcx_lds_init() {
     for (int i = threadIdx.x; i < (kErfcxD + 1) * kErfcxK; i += blockDim.x)
         g_erfcx_lds[i] = kErfcxTable[i % kErfcxK][i / kErfcxK];
@@ -150,6 +155,8 @@ __device__ __forceinline__ float erfcx_coef_f(int j, int k) { return g_erfcx_lds
 __device__ __forceinline__ double erfcx_tval(int k) { return g_erfcx_tlds[k]; }
 __device__ __forceinline__ float erfcx_tval_f(int k) { return g_erfcx_tlds_f[k]; }
 #endif
+__device__ __forceinline__ double tanh_tval(int k) { return g_tanh_lds[k]; }
+__device__ __forceinline__ float tanh_tval_f(int k) { return g_tanh_lds_f[k]; }
 #else
 // host harness: an f32 division stands for the f64 estimate (1e-7 instead of 4.6e-8: the cubic correction of rcp_1to2
 // ends below 1e-20 either way), the correctly rounded f32 operations for the f32 estimates, the tables where they are
@@ -166,6 +173,8 @@ TM_HD float erfcx_coef_f(int j, int k) { return kErfcxTableF[k][j]; }
 TM_HD double erfcx_tval(int k) { return kErfcxTTable[k]; }
 TM_HD float erfcx_tval_f(int k) { return kErfcxTTableF[k]; }
 #endif
+TM_HD double tanh_tval(int k) { return kTanhTable[k]; }
+TM_HD float tanh_tval_f(int k) { return kTanhTableF[k]; }
 #endif
 }  // namespace hw
 
@@ -349,6 +358,50 @@ TM_HD double tanh_hot(double x) {
     return x < 0.0 ? -t : t;
 }
 TM_HD float tanh_hot(float x) { return ::tanhf(x); }
+
+// tanh from the table of tanh(k / 64) (tanh_table.h) by the addition formula about the nearest grid point:
+// tanh|x| = (t_k + th) / (1 + t_k th), th = tanh(|x| - x_k) by its odd series (|h| <= 1/128: the h^9 term is 3e-19).  One LDS
+// read, one reciprocal of a number within 1 % of 1, ~20 VALU instructions (tanh_hot: ~50); 3e-16 against mpmath.  Past the
+// table tanh rounds to 1.  A NaN stays a NaN (its index is the last entry's).  The kernel stages the table: tanh_setup().
+template <typename T> TM_HD void tanh_setup() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (sizeof(T) == 8) {
+        for (int i = threadIdx.x; i < kTanhK; i += blockDim.x) g_tanh_lds[i] = kTanhTable[i];
+    } else {
+        for (int i = threadIdx.x; i < kTanhKF; i += blockDim.x) g_tanh_lds_f[i] = kTanhTableF[i];
+    }
+    __syncthreads();
+#endif
+}
+TM_HD double tanh_tab(double x) {
+    const double ax = ::fabs(x);
+    const double ai = ::fmin(ax, kTanhHi);                    // the index never sees a NaN ...
+    const double axc = ax > kTanhHi ? kTanhHi : ax;           // ... the offset does
+    const double kf = __builtin_rint(ai * kTanhPer);
+    const double h = ::fma(kf, -1.0 / kTanhPer, axc);
+    const double t0 = hw::tanh_tval((int)kf);
+    const double h2 = h * h;
+    double p = ::fma(h2, -17.0 / 315.0, 2.0 / 15.0);
+    p = ::fma(p, h2, -1.0 / 3.0);
+    p = ::fma(p, h2, 1.0);
+    const double th = h * p;
+    const double t = (t0 + th) * rcp_1to2(::fma(t0, th, 1.0));
+    return ::copysign(t, x);
+}
+TM_HD float tanh_tab(float x) {
+    const float ax = ::fabsf(x);
+    const float ai = ::fminf(ax, (float)kTanhHiF);
+    const float axc = ax > (float)kTanhHiF ? (float)kTanhHiF : ax;
+    const float kf = __builtin_rintf(ai * (float)kTanhPerF);
+    const float h = ::fmaf(kf, -1.0f / (float)kTanhPerF, axc);
+    const float t0 = hw::tanh_tval_f((int)kf);
+    const float h2 = h * h;
+    float p = ::fmaf(h2, 2.0f / 15.0f, -1.0f / 3.0f);
+    p = ::fmaf(p, h2, 1.0f);
+    const float th = h * p;
+    const float t = (t0 + th) * hw::rcp_est(::fmaf(t0, th, 1.0f));
+    return ::copysignf(t, x);
+}
 
 // scipy.special.expit, branch-free: one exp of -|x| (never overflows), one reciprocal of 1 + e in [1, 2].
 template <typename T> TM_HD T expit(T x) {
