@@ -138,16 +138,16 @@ template <typename T, bool LEAN = false> struct SgnLikBitsOp {   // in0 = bz
 };
 
 template <typename T> struct AbsLikOp {   // K5; in0 = bz, in1 = y
-    static constexpr bool HEAVY = false;      // 64 instructions per component (tanh_hot): recomputed in pass 2 (5T moved, not 6T)
+    static constexpr bool HEAVY = false;      // ~35 instructions per component (tanh_tab): recomputed in pass 2 (5T moved, not 6T)
     static constexpr int NIN = 2;
     static constexpr int TARGET = 0;
     const double* az;
     double a_msg;
-    __device__ static void stage() {}
+    __device__ static void stage() { tmath::tanh_setup<T>(); }
     __device__ void prepare(size_t b) { a_msg = az[b]; }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T x1) const {
-        RV<T> o = tmath::abs_lik_posterior<T>(x0, x1);
+        RV<T> o = tmath::abs_lik_posterior<T, true>(x0, x1);
         return {o.r, o.v, 0u};
     }
 };

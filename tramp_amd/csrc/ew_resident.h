@@ -317,11 +317,13 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
             double acc = 0.0;
             unsigned long long cnt = 0;
             T bad = T(0);                                               // lean ops: sum of EwOut::dev (0 = every lane inside the form's domain)
+            T poison = T(0);                                            // sum of 0 * r: NaN once any posterior mean is not finite
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const unsigned i = off + u * NT;
                 const bool counts = i >= first;
                 V vr;
+                double pacc = 0.0;                                      // this piece's sum of v: the `counts` select once per piece
 #pragma unroll
                 for (int c = 0; c < VN; ++c) {
                     const T a0 = vget<T>(x0[sM][u], c);
@@ -332,9 +334,8 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                         bad += o.dev;
                         if (FLAGS & kResSchedBarrier) __builtin_amdgcn_sched_barrier(0);       // one component at a time
                     }
-                    double vi = (double)o.v;
-                    if (not_finite(o.r)) vi = __longlong_as_double(0x7ff8000000000000LL);
-                    acc += counts ? vi : 0.0;
+                    pacc += (double)o.v;
+                    poison = tmath::fma_(o.r, T(0), poison);
                     if (OpCounts<Op>::value) cnt += counts ? (o.mask & 1u) : 0u;
                     vset<T>(vr, c, o.r);
                     if (MASK) {
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                         *mo = (uint8_t)o.mask;          // (lean ops have no mask output: run_resident refuses out.mask)
                     }
                 }
+                acc += counts ? pacc : 0.0;
                 if (STORE_R) {
                     V* dst = counts ? &pr[base + i] : reinterpret_cast<V*>(A.dummy) + tid + u * NT;
                     __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&vr), reinterpret_cast<NV*>(dst));
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
             // a lean op that left its form's domain anywhere in the tile poisons the tile's sum: the instance's a_new comes
             // out NaN, which is what the caller's redo on the tile kernels looks for (ew_kernels.hip: pwl_dir, ew_flag_nan) (a select, not a branch: no control flow in the pipelined body)
             if (OpLean<Op>::value) acc += (bad == T(0)) ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+            acc += (double)poison;                                      // (pieces that do not count are repeats of ones that do)
             acc = res_block_sum<NT>(acc, smem);
             if (COUNT) cnt = res_block_sum_u64<NT>(cnt, smem_u);
             if (tid == 0 && DBG != 1) {

@@ -275,6 +275,36 @@ TM_HD float erfcx_tay(float x) {
     }
     return acc;
 }
+// Two f32 evaluations at once on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per
+// issue; plain f32 issues at the f64 rate on gfx950, which is what bounds the f32 two-region channels): the two regions of
+// a K7 component are the pair.  Same operations in the same order as erfcx_tay(float): bit-identical results.
+typedef float tm_v2f __attribute__((ext_vector_type(2)));
+TM_HD void erfcx_tay_pair(float x0, float x1, float* e0, float* e1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const tm_v2f x = {x0, x1};
+    const tm_v2f s = x - (float)kErfcxTLo;
+    const tm_v2f sp = s * (float)kErfcxTPerF;
+    const tm_v2f kf = {__builtin_rintf(sp.x), __builtin_rintf(sp.y)};
+    const tm_v2f d = __builtin_elementwise_fma(kf, (tm_v2f)(float)(-1.0 / kErfcxTPerF), s);
+    const tm_v2f a = __builtin_elementwise_fma(kf, (tm_v2f)(float)(2.0 / kErfcxTPerF), (tm_v2f)(float)(2.0 * kErfcxTLo));
+    const tm_v2f f = {hw::erfcx_tval_f((int)kf.x), hw::erfcx_tval_f((int)kf.y)};
+    const tm_v2f u = a * d, w = (d + d) * d;
+    tm_v2f tm = f, t = d * __builtin_elementwise_fma(a, f, (tm_v2f)(-1.12837916709551257390f));
+    tm_v2f acc = f + t;
+#pragma unroll
+    for (int n = 1; n < kErfcxTDF; ++n) {
+        const tm_v2f tn = __builtin_elementwise_fma(u, t, w * tm) * (1.0f / (float)(n + 1));
+        tm = t;
+        t = tn;
+        acc += t;
+    }
+    *e0 = acc.x;
+    *e1 = acc.y;
+#else
+    *e0 = erfcx_tay(x0);
+    *e1 = erfcx_tay(x1);
+#endif
+}
 #endif
 template <bool UNI = false> TM_HD double erfcx_hot(double x) {
 #if TRAMP_ERFCX_UNIFORM
@@ -647,8 +677,9 @@ template <typename T> TM_HD RV<T> relu_lik_posterior(T bz, T y, T slope_neg, con
 
 // ---- A7: abs likelihood (tramp/likelihoods/abs_likelihood.py:31-36,
 //          tramp/beliefs/binary.py:8-13) ------------------------------------------
-template <typename T> TM_HD RV<T> abs_lik_posterior(T bz, T y) {
-    T t = tanh_hot(bz * y);
+// TAB: tanh from the staged table (tanh_setup; the streaming kernels)
+template <typename T, bool TAB = false> TM_HD RV<T> abs_lik_posterior(T bz, T y) {
+    T t = TAB ? tanh_tab(bz * y) : tanh_hot(bz * y);
     RV<T> o;
     o.r = y * t;
     o.v = (y * y) * (T(1) - t * t);
@@ -965,8 +996,12 @@ TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o, T* de
     T e0, e1;
 #if TRAMP_ERFCX_UNIFORM
     if constexpr (GRID) {
-        e0 = erfcx_tay(x0);
-        e1 = erfcx_tay(x1);
+        if constexpr (sizeof(T) == 4) {
+            erfcx_tay_pair(x0, x1, &e0, &e1);
+        } else {
+            e0 = erfcx_tay(x0);
+            e1 = erfcx_tay(x1);
+        }
     } else
 #endif
     {
