@@ -105,6 +105,13 @@ template <typename T, bool LEAN = false> struct SgnLikOp {   // K4; in0 = bz, in
             return {o.r, o.v, 0u};
         }
     }
+    // two components at once (f32 lean form: packed-f32 arithmetic, OpPair)
+    __device__ void eval2(float a0, float a1, float y0, float y1, EwOut<float>& o0, EwOut<float>& o1) const {
+        tmath::tm_v2f r, v, dev;
+        tmath::sgn_lik_posterior_lean_v2(tmath::tm_v2f{a0, a1}, tmath::tm_v2f{y0, y1}, c, &r, &v, &dev);
+        o0 = {r.x, v.x, 0u, dev.x};
+        o1 = {r.y, v.y, 0u, dev.y};
+    }
 };
 
 // K4 with the observation packed one bit per component (y in {-1, +1} is static: 2T + 1/64 T moved instead of 3T);
@@ -134,6 +141,12 @@ template <typename T, bool LEAN = false> struct SgnLikBitsOp {   // in0 = bz
             RV<T> o = tmath::sgn_lik_posterior_fast<T>(x0, y, c);
             return {o.r, o.v, 0u};
         }
+    }
+    __device__ void eval2(float a0, float a1, float y0, float y1, EwOut<float>& o0, EwOut<float>& o1) const {
+        tmath::tm_v2f r, v, dev;
+        tmath::sgn_lik_posterior_lean_v2(tmath::tm_v2f{a0, a1}, tmath::tm_v2f{y0, y1}, c, &r, &v, &dev);
+        o0 = {r.x, v.x, 0u, dev.x};
+        o1 = {r.y, v.y, 0u, dev.y};
     }
 };
 
@@ -186,6 +199,14 @@ template <typename T, bool LEAN = false> struct ReluLikOp {  // in0 = bz, in1 = 
             RV<T> o = tmath::relu_lik_posterior<T>(x0, x1, sT, c);
             return {o.r, o.v, 0u};
         }
+    }
+    __device__ void eval2(float a0, float a1, float y0, float y1, EwOut<float>& o0, EwOut<float>& o1) const {
+        tmath::tm_v2f r, v, dev;
+        tmath::sgn_lik_posterior_lean_v2(tmath::tm_v2f{a0, a1}, tmath::tm_v2f{-1.0f, -1.0f}, c, &r, &v, &dev);
+        const bool p0 = y0 > 0.0f, p1 = y1 > 0.0f, n0 = !(y0 >= 0.0f), n1 = !(y1 >= 0.0f);
+        const float nan = __builtin_nanf("");
+        o0 = {p0 ? y0 : r.x, p0 ? 0.0f : v.x, 0u, n0 ? nan : (p0 ? 0.0f : dev.x)};
+        o1 = {p1 ? y1 : r.y, p1 ? 0.0f : v.y, 0u, n1 ? nan : (p1 ? 0.0f : dev.y)};
     }
 };
 
@@ -279,6 +300,12 @@ template <typename T, int KIND, bool FWD, bool UNI> struct OpLean<PwlOp<T, KIND,
 template <typename T> struct OpLean<SgnLikOp<T, true>> { static constexpr bool value = true; };
 template <typename T> struct OpLean<SgnLikBitsOp<T, true>> { static constexpr bool value = true; };
 template <typename T> struct OpLean<ReluLikOp<T, true>> { static constexpr bool value = true; };
+
+// OpPair: f32 lean ops with eval2 (two components per call on the packed-f32 pipe)
+template <typename Op> struct OpPair { static constexpr bool value = false; };
+template <> struct OpPair<SgnLikOp<float, true>> { static constexpr bool value = true; };
+template <> struct OpPair<SgnLikBitsOp<float, true>> { static constexpr bool value = true; };
+template <> struct OpPair<ReluLikOp<float, true>> { static constexpr bool value = true; };
 
 template <typename Op> struct OpCounts { static constexpr bool value = false; };
 template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };

@@ -324,6 +324,26 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                 const bool counts = i >= first;
                 V vr;
                 double pacc = 0.0;                                      // this piece's sum of v: the `counts` select once per piece
+                if constexpr (OpPair<Op>::value && (VN % 2) == 0 && !MASK) {
+#pragma unroll
+                    for (int c = 0; c < VN; c += 2) {
+                        const T a0 = vget<T>(x0[sM][u], c), a1 = vget<T>(x0[sM][u], c + 1);
+                        T y0 = (Op::NIN > 1) ? vget<T>(x1[sM][u], c) : a0, y1 = (Op::NIN > 1) ? vget<T>(x1[sM][u], c + 1) : a1;
+                        if (BITS) {
+                            y0 = ((xb[sM][u] >> (((i * VN) & 7u) + c)) & 1u) ? T(1) : T(-1);
+                            y1 = ((xb[sM][u] >> (((i * VN) & 7u) + c + 1)) & 1u) ? T(1) : T(-1);
+                        }
+                        EwOut<T> o0, o1;
+                        op.eval2(a0, a1, y0, y1, o0, o1);
+                        bad += o0.dev + o1.dev;
+                        pacc += (double)o0.v;
+                        pacc += (double)o1.v;
+                        poison = tmath::fma_(o0.r, T(0), poison);
+                        poison = tmath::fma_(o1.r, T(0), poison);
+                        vset<T>(vr, c, o0.r);
+                        vset<T>(vr, c + 1, o1.r);
+                    }
+                } else {
 #pragma unroll
                 for (int c = 0; c < VN; ++c) {
                     const T a0 = vget<T>(x0[sM][u], c);
@@ -343,6 +363,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                                              : reinterpret_cast<uint8_t*>(A.dummy) + tid;
                         *mo = (uint8_t)o.mask;          // (lean ops have no mask output: run_resident refuses out.mask)
                     }
+                }
                 }
                 acc += counts ? pacc : 0.0;
                 if (STORE_R) {

@@ -24,6 +24,8 @@ template <typename T, int KIND, bool FWD, bool UNI, bool LEAN> struct ResShape<P
     static constexpr int U = sizeof(T) == 4 ? 2 : kResU, NT = kBlock, FLAGS = 0, BPC = sizeof(T) == 4 ? 3 : 2;
 };
 
+// (the f32 lean likelihoods on three workgroups per CU of half-size tiles, the f32 K7 shape: 166-168 us against 164-170 us
+// at 64 x 1e6 - no difference, the standard shape stays)
 template <typename Op> struct ResidentOp { static constexpr bool value = false; };
 template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value = true; };

@@ -279,9 +279,8 @@ TM_HD float erfcx_tay(float x) {
 // issue; plain f32 issues at the f64 rate on gfx950, which is what bounds the f32 two-region channels): the two regions of
 // a K7 component are the pair.  Same operations in the same order as erfcx_tay(float): bit-identical results.
 typedef float tm_v2f __attribute__((ext_vector_type(2)));
-TM_HD void erfcx_tay_pair(float x0, float x1, float* e0, float* e1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const tm_v2f x = {x0, x1};
+#if defined(__HIPCC__)
+__device__ __forceinline__ tm_v2f erfcx_tay_v2(tm_v2f x) {
     const tm_v2f s = x - (float)kErfcxTLo;
     const tm_v2f sp = s * (float)kErfcxTPerF;
     const tm_v2f kf = {__builtin_rintf(sp.x), __builtin_rintf(sp.y)};
@@ -298,8 +297,14 @@ TM_HD void erfcx_tay_pair(float x0, float x1, float* e0, float* e1) {
         t = tn;
         acc += t;
     }
-    *e0 = acc.x;
-    *e1 = acc.y;
+    return acc;
+}
+#endif
+TM_HD void erfcx_tay_pair(float x0, float x1, float* e0, float* e1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const tm_v2f e = erfcx_tay_v2(tm_v2f{x0, x1});
+    *e0 = e.x;
+    *e1 = e.y;
 #else
     *e0 = erfcx_tay(x0);
     *e1 = erfcx_tay(x1);
@@ -647,6 +652,24 @@ template <typename T> TM_HD RV<T> sgn_lik_posterior_lean(T bz, T y, const Region
     return sgn_lik_posterior_fast<T>(bz, y, c);
 #endif
 }
+
+#if defined(__HIPCC__) && TRAMP_ERFCX_UNIFORM
+// Two f32 components at once on the packed-f32 pipe (erfcx_tay_v2): the same operations in the same order as the scalar form.
+__device__ __forceinline__ void sgn_lik_posterior_lean_v2(tm_v2f bz, tm_v2f y, const RegionConst<float>& c, tm_v2f* r, tm_v2f* v, tm_v2f* dev) {
+    const tm_v2f r0 = (bz * y) * c.v0;
+    const tm_v2f x = ((0.0f - r0) * c.inv_s0) * 0.70710678118654752440f;
+    const tm_v2f xh = {fmin_(x.x, (float)kErfcxTHi), fmin_(x.y, (float)kErfcxTHi)};
+    const tm_v2f hi_v = x - xh;
+    *dev = __builtin_elementwise_fma(hi_v, hi_v, x - x);
+    const tm_v2f xc = {fmax_(xh.x, (float)kErfcxTLo), fmax_(xh.y, (float)kErfcxTLo)};
+    const tm_v2f e = erfcx_tay_v2(xc);
+    const tm_v2f ie = {rcp_pos(e.x), rcp_pos(e.y)};
+    const tm_v2f g1 = (float)kSqrt2OverPi * ie;
+    const tm_v2f g2 = (float)kTwoOverSqrtPi * (xc * ie);
+    *r = y * (r0 + c.s0 * g1);
+    *v = c.v0 * (1.0f + g2 - g1 * g1);
+}
+#endif
 
 // ---- (Leaky)Relu likelihood: y = max(z, 0) + slope_neg * min(z, 0) observed
 // tramp/likelihoods/piecewise_linear_likelihood.py:9-63,201-215,279-291.  Regions pos (slope 1) and
