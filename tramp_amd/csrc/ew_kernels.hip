@@ -703,14 +703,6 @@ __global__ __launch_bounds__(kBlock, 2) void ew_coop(Op op, size_t n, unsigned G
     const unsigned e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const size_t lines = coop_total_lines(capacity), bank = capacity + lines * kCoopLineStride;
     unsigned long long* mine_bank = slots + (e & 1u) * bank;
-    {   // the other bank back to the sentinel: [capacity] block sums + one granule per total line
-        unsigned long long* other = slots + ((e + 1u) & 1u) * bank;
-        const size_t npos = capacity + lines, nthr = (size_t)gridDim.x * gridDim.y * kBlock;
-        for (size_t pos = ((size_t)b * gridDim.x + g) * kBlock + tid; pos < npos; pos += nthr) {
-            const size_t at = pos < capacity ? pos : capacity + (pos - capacity) * kCoopLineStride;
-            __hip_atomic_store(other + at, kCoopSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     op.setup(b);
     const size_t nv = n / VN;
     const size_t p0 = (size_t)g * chunk, p1 = (p0 + chunk < nv) ? p0 + chunk : nv;
@@ -726,6 +718,15 @@ __global__ __launch_bounds__(kBlock, 2) void ew_coop(Op op, size_t n, unsigned G
             x0[k] = q0[i];
             if (Op::NIN > 1) x1[k] = q1[i];
             if (bold) vold[k] = bold[i];
+        }
+    }
+    {   // the other bank back to the sentinel: [capacity] block sums + one granule per total line (after the message's
+        // loads are out: the stores wait for the epoch word, the loads need not)
+        unsigned long long* other = slots + ((e + 1u) & 1u) * bank;
+        const size_t npos = capacity + lines, nthr = (size_t)gridDim.x * gridDim.y * kBlock;
+        for (size_t pos = ((size_t)b * gridDim.x + g) * kBlock + tid; pos < npos; pos += nthr) {
+            const size_t at = pos < capacity ? pos : capacity + (pos - capacity) * kCoopLineStride;
+            __hip_atomic_store(other + at, kCoopSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     V rr[K];
