@@ -21,10 +21,15 @@ for np_dt in (np.float64, np.float32):
     sg = T.SgnLikelihood(y=y, dtype=np_dt, ctx=ctx)
     ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
     relu, sgn, abs_ = T.ReluChannel(dtype=np_dt, ctx=ctx), T.SgnChannel(dtype=np_dt, ctx=ctx), T.AbsChannel(dtype=np_dt, ctx=ctx)
+    bp = T.BinaryPrior(size=N, p_pos=0.3, dtype=np_dt, ctx=ctx)
+    yr = ctx.array(np.maximum(np.random.RandomState(1).standard_normal((B, N)), 0.0).astype(np_dt), np_dt)
+    rl = T.ReluLikelihood(y=yr, dtype=np_dt, ctx=ctx)
     for _ in range(2):
         if not ONLY_K7:
             gb.compute_forward_message(ax, bx, **kw)
             l1.compute_forward_message(ax, bx, **kw)
+            bp.compute_forward_message(ax, bx, **kw)
+            rl.compute_backward_message(az, bz, **kw)
             sg.compute_backward_message(az, bz, **kw)
             ab.compute_backward_message(az, bz, **kw)
         relu.compute_backward_message(az, bz, ax, bx, **kw)
@@ -41,6 +46,6 @@ for np_dt in (np.float64, np.float32):
             ch.compute_backward_message(az, bz, ax, bx, out_a=a_msg, out_b=b_msg)
             gb.compute_forward_message(a_msg, b_msg, **kw)
         del ch
-    del bz, bx, y, b_new
+    del bz, bx, y, yr, b_new
 ctx.sync()
 print("done", ctx.prior_hint_stats())
