@@ -282,7 +282,8 @@ def denoiser_roofline(T, ctx, dtype, shapes=((1, 1_000_000), (64, 1_000_000), (4
       B64_standalone the prior called on a message whose producer is unknown: the resident single-pass pipeline
                      (csrc/ew_resident.h; 2T moved) - the tile kernels' moments pass + update pass (3T) where the
                      shape is outside the pipeline's window.
-      B1             one instance (latency regime, data stays in cache); B4096_n4096: an instance fits one
+      B1             one instance (BASELINE configs[1] read literally; latency regime, data stays in cache): the
+                     one-launch form of round 5 (csrc/ew_kernels.hip: ew_coop); B4096_n4096: an instance fits one
                      workgroup's registers, single launch."""
     out = {}
     np_dt = np.float64 if dtype == "f64" else np.float32
@@ -294,11 +295,11 @@ def denoiser_roofline(T, ctx, dtype, shapes=((1, 1_000_000), (64, 1_000_000), (4
         a_new = ctx.empty((B,), np.float64)
         b_new = ctx.empty((B, N), np_dt)
         call = lambda: p.compute_forward_message(ax, bx, out_a=a_new, out_b=b_new)      # noqa: E731
-        runs0 = ctx.resident_runs()
+        runs0, coop0 = ctx.resident_runs(), ctx.coop_runs()
         if B == 64:
             # per-call HIP-event samples, median: the first calls after the dense loop run on a package that is still
             # coming back from its power limit (a mean over 10 calls read 7 % high)
-            ms = float(np.median(_event_samples(ctx, [call], 30)[0]))
+            ms = float(np.median(_event_samples(ctx, [call], 12, inner=5)[0]))
         else:
             ms = _timed(ctx, call, 50 if B == 1 else 10)
         resident = ctx.resident_runs() > runs0
@@ -308,7 +309,9 @@ def denoiser_roofline(T, ctx, dtype, shapes=((1, 1_000_000), (64, 1_000_000), (4
                     "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS, "components_per_sec": N * B / (ms * 1e-3),
                     "form": ("resident single-pass pipeline (csrc/ew_resident.h): every byte crosses HBM once, 2T moved"
                              if resident else "moments pass + update pass (3T moved)") if B == 64 else
-                            ("single launch, instance in registers" if B == 4096 else "two launches, cache resident")}
+                            ("single launch, instance in registers" if B == 4096 else
+                             ("one launch: G workgroups per instance exchange block sums in flight (ew_coop)"
+                              if ctx.coop_runs() > coop0 else "three launches (tile kernels), cache resident"))}
         del bx, b_new
     if fused:
         # the producer-fused form (csrc/prior_hint.h), measured on the pair (producer, prior); since round 4 the
@@ -317,9 +320,11 @@ def denoiser_roofline(T, ctx, dtype, shapes=((1, 1_000_000), (64, 1_000_000), (4
     return out
 
 
-def _event_samples(ctx, fns, reps):
-    """per-call HIP-event timings (ms) of several callables, interleaved (a b a b ...) so that clock / thermal
-    drift hits them alike; returns one list of samples per callable"""
+def _event_samples(ctx, fns, reps, inner=1):
+    """HIP-event timings (ms per call) of several callables, interleaved (a b a b ...) so that clock / thermal
+    drift hits them alike; returns one list of samples per callable.  inner: calls per sample, back to back - a single
+    call between two events also counts the host's latency from the first event to the launch (20-40 us of Python:
+    +15-20 % on a 200 us update, which is what the iteration never pays because it enqueues ahead)."""
     for fn in fns:
         for _ in range(2):
             fn()
@@ -328,11 +333,12 @@ def _event_samples(ctx, fns, reps):
         for k, fn in enumerate(fns):
             e0, e1 = ctx.event(), ctx.event()
             e0.record()
-            fn()
+            for _ in range(inner):
+                fn()
             e1.record()
             samples[k].append((e0, e1))
     ctx.sync()
-    return [[a.elapsed_ms(b) for a, b in ss] for ss in samples]
+    return [[a.elapsed_ms(b) / inner for a, b in ss] for ss in samples]
 
 
 def fused_updates_n1e6(T, ctx, dtype, only=None):
@@ -482,7 +488,7 @@ def factor_updates_n1e6(T, ctx, dtype, only=None):
         if only and name not in only:
             continue
         runs0 = ctx.resident_runs()
-        ms = float(np.median(_event_samples(ctx, [fn], 12)[0]))
+        ms = float(np.median(_event_samples(ctx, [fn], 8, inner=5)[0]))
         resident = ctx.resident_runs() > runs0
         alg = nT * esz * N * B
         rec = {"kernel": kern, "us_per_update": ms * 1e3, "algorithmic_bytes_per_component": nT * esz,
