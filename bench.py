@@ -440,10 +440,11 @@ def fused_updates_n1e6(T, ctx, dtype, only=None):
     return out
 
 
-# VALU instructions per component of the first pass (profiles/r02/elementwise_traffic_and_instructions.txt,
-# rocprofv3 --pmc SQ_INSTS_VALU of these very launches); a wave64 f64 instruction occupies a SIMD for 4 cycles
-VALU_PER_COMPONENT_F64 = {"l1_prior": 33 + 28, "sgn_lik": 81 + 11, "abs_lik": 63 + 60, "relu_bwd": 184 + 11,
-                          "relu_fwd": 167 + 11, "sgn_bwd": 202 + 11, "abs_bwd": 182 + 11}
+# VALU instructions per component of the resident single-pass kernels (profiles/r05/elementwise_traffic_and_instructions.txt,
+# rocprofv3 --pmc SQ_INSTS_VALU of these very launches on the final round-5 library; the count includes the polling of
+# waiting waves); a wave64 f64 instruction occupies a SIMD for 4 cycles
+VALU_PER_COMPONENT_F64 = {"l1_prior": 37, "binary_prior": 37, "relu_lik": 86, "sgn_lik": 82, "abs_lik": 41, "relu_bwd": 142,
+                          "relu_fwd": 139, "sgn_bwd": 166, "abs_bwd": 143}
 
 
 def factor_updates_n1e6(T, ctx, dtype, only=None):
