@@ -66,7 +66,7 @@ struct tramp_ctx {
     size_t hint_ws_bytes;
     unsigned long long hint_armed, hint_used;   // producers that left moments / prior updates that ran single-pass
     unsigned long long resident_runs;           // factor updates that took the resident single-pass pipeline (ew_resident.h)
-    volatile unsigned* lean_stat;               // pinned host {flagged instances, batch} of the last lean resident update (ew_flag_nan);
+    volatile unsigned* lean_stat;               // pinned host {flagged instances, batch} of the last lean resident update (pass 1 of its redo: ew_moments_tile, RedoArgs);
                                                 // [2]: a resident kernel gave up a hand-off (ew_resident.h: res_expired)
     unsigned long long* coop_slots;             // two banks of granules of the one-launch form (ew_kernels.hip: ew_coop); the bank the next launch uses is all sentinel
     unsigned* coop_epoch;                       // device word: launches of the one-launch form so far (its parity picks the bank)

@@ -355,6 +355,20 @@ __device__ __forceinline__ void store_vec(typename Vec<T>::type* dst, const type
     }
 }
 
+// The redo of a lean resident update (run_tiles_u: redo_nan): only the instances whose a_new came back NaN are updated,
+// in TWO launches - pass 1 decides per instance from a_flag (nothing writes a_new before pass 2), leaves flags[] for pass 2
+// and the count of flagged instances for the host's heuristic; pass 2 folds the tile sums itself (the arithmetic of
+// ew_finalize, by every workgroup of the instance; tile 0 writes a_new / v).  All null: a plain run.
+struct RedoArgs {
+    const double* a_flag = nullptr;      // pass 1: instance b is redone iff a_flag[b] is NaN
+    unsigned* flags = nullptr;           // pass 1 (tile 0) writes, pass 2 reads
+    volatile unsigned* stat = nullptr;   // pass 1, workgroup (0, 0) of the first chunk: {flagged instances, batch} (pinned host)
+    size_t batch = 0;
+    const double* partials = nullptr;    // pass 2: this chunk's tile sums of pass 1
+    int nblk = 0;
+    const double* a_in = nullptr;
+};
+
 // A block owns `tpb` CONSECUTIVE tiles (a contiguous chunk of the instance): the per-instance setup of the
 // functor (a log and a division for the Gauss-Bernoulli prior) and the block reduction are paid once per
 // chunk, not once per 1024 components, while neighbouring blocks still stream neighbouring addresses.
@@ -363,14 +377,30 @@ __global__ __launch_bounds__(kBlock) void ew_moments_tile(Op op, size_t n, size_
                                                           const T* __restrict__ in1, T* __restrict__ rbuf,
                                                           double* __restrict__ partials,
                                                           unsigned long long* __restrict__ pcount,
-                                                          uint8_t* __restrict__ mask_out,
-                                                          const unsigned* __restrict__ only = nullptr) {
+                                                          uint8_t* __restrict__ mask_out, RedoArgs rd = RedoArgs{}) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     __shared__ double smem[kBlock / kWave];
     __shared__ unsigned long long smem_u[kBlock / kWave];
     const size_t b = inst0 + blockIdx.y;
-    if (only && !only[b]) return;               // redo of flagged instances only (run_tiles_u: redo_nan)
+    if (rd.a_flag) {                            // redo of the NaN instances only
+        if (rd.stat && inst0 == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+            unsigned long long c = 0;
+            for (size_t i = threadIdx.x; i < rd.batch; i += kBlock) {
+                const double a = rd.a_flag[i];
+                c += (a == a) ? 0u : 1u;
+            }
+            c = block_sum_u64(c, smem_u);
+            if (threadIdx.x == 0) {
+                rd.stat[0] = (unsigned)c;
+                rd.stat[1] = (unsigned)rd.batch;
+            }
+        }
+        const double a = rd.a_flag[b];
+        const bool flagged = !(a == a);
+        if (blockIdx.x == 0 && threadIdx.x == 0) rd.flags[b] = flagged ? 1u : 0u;
+        if (!flagged) return;
+    }
     op.setup(b);
     const size_t nv = n / VN;
     const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
@@ -426,12 +456,10 @@ __global__ __launch_bounds__(kBlock) void ew_finalize(size_t n, size_t inst0, si
                                                       const double* __restrict__ a_in_d,
                                                       const double* __restrict__ partials,
                                                       const unsigned long long* __restrict__ pcount, int nblk,
-                                                      MsgOut out, double* __restrict__ scal,
-                                                      const unsigned* __restrict__ only = nullptr) {
+                                                      MsgOut out, double* __restrict__ scal) {
     __shared__ double smem[kBlock / kWave];
     __shared__ unsigned long long smem_u[kBlock / kWave];
     const size_t bl = blockIdx.x, b = inst0 + bl;
-    if (only && !only[b]) return;
     const double* pp = partials + (pinst0 + bl) * (size_t)nblk;
     double s = 0.0;
     for (int i = threadIdx.x; i < nblk; i += kBlock) s += pp[i];
@@ -458,11 +486,11 @@ template <typename T, typename Op, int U, bool RECOMPUTE, bool NTS>
 __global__ __launch_bounds__(kBlock) void ew_apply_tile(Op op, size_t n, size_t inst0, int tpb, const T* __restrict__ in0,
                                                         const T* __restrict__ in1, const T* __restrict__ rbuf,
                                                         const double* __restrict__ scal, MsgOut out,
-                                                        const unsigned* __restrict__ only = nullptr) {
+                                                        RedoArgs rd = RedoArgs{}) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     const size_t bl = blockIdx.y, b = inst0 + bl;
-    if (only && !only[b]) return;
+    if (rd.flags && !rd.flags[b]) return;
     const size_t nv = n / VN;
     const V* p0 = reinterpret_cast<const V*>(in0 + b * n);
     const V* p1 = (Op::NIN > 1) ? reinterpret_cast<const V*>(in1 + b * n) : nullptr;
@@ -471,7 +499,26 @@ __global__ __launch_bounds__(kBlock) void ew_apply_tile(Op op, size_t n, size_t 
     V* bo = reinterpret_cast<V*>(reinterpret_cast<T*>(out.b_new) + b * n);
     V* ro = out.r ? reinterpret_cast<V*>(reinterpret_cast<T*>(out.r) + b * n) : nullptr;
     if (RECOMPUTE) op.setup(b);
-    const T vinv = T(scal[bl]);
+    T vinv;
+    if (rd.partials) {
+        // ew_finalize's arithmetic, by every workgroup of the instance (same fold, same result); tile 0 writes the scalars
+        __shared__ double smem[kBlock / kWave];
+        const double* pp = rd.partials + bl * (size_t)rd.nblk;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < rd.nblk; i += kBlock) s += pp[i];
+        s = block_sum(s, smem);
+        const double v = s / (double)n;
+        const double a_in = rd.a_in[b];
+        const double a_new = tmath::a_new_of(v, a_in);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const double d = out.damping;
+            out.a_new[b] = (d != 0.0) ? d * out.a_old[b] + (1.0 - d) * a_new : a_new;
+            if (out.v) out.v[b] = v;
+        }
+        vinv = T(a_in + a_new);
+    } else {
+        vinv = T(scal[bl]);
+    }
     const T dT = T(out.damping), omd = T(1.0 - out.damping);
     for (int tile = 0; tile < tpb; ++tile) {
         const size_t base = ((size_t)blockIdx.x * tpb + tile) * kBlock * U + threadIdx.x;
@@ -530,26 +577,6 @@ static size_t env_size(const char* name, size_t dflt) {
     return v >= 0 ? (size_t)v : dflt;
 }
 
-// flags[b] = (a_new[b] is NaN), for the redo of a lean resident update (ew_resident.h: a lane outside the lean form's
-// domain poisons its instance's a_new); stat = {flagged instances, batch} in pinned host memory, which the NEXT call's
-// host code reads without synchronising (a heuristic: pwl_dir).  One workgroup.
-__global__ __launch_bounds__(kBlock) void ew_flag_nan(size_t batch, const double* __restrict__ a_new, unsigned* __restrict__ flags,
-                                                      volatile unsigned* stat) {
-    __shared__ unsigned long long smem_u[kBlock / kWave];
-    unsigned long long c = 0;
-    for (size_t i = threadIdx.x; i < batch; i += kBlock) {
-        const double a = a_new[i];
-        const unsigned f = (a == a) ? 0u : 1u;
-        flags[i] = f;
-        c += f;
-    }
-    c = block_sum_u64(c, smem_u);
-    if (threadIdx.x == 0 && stat) {
-        stat[0] = (unsigned)c;
-        stat[1] = (unsigned)batch;
-    }
-}
-
 // Streaming-tile realisation of one update.  `hint` != nullptr: a producer left sum v_i partials for
 // this very message (prior_hint.h): no pass 1, the message is read once.  redo_nan: only the instances whose out.a_new
 // is NaN are updated (the others' workgroups leave at once).
@@ -564,7 +591,7 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
     int tpb = 8;
     while (tpb > 1 && (tiles / tpb) * batch < 4096) tpb >>= 1;
     // redo of a few flagged instances: most workgroups only read their instance's flag and leave - long runs per block keep
-    // the dispatch of those short (a clean 64 x 1e6 update pays ~6 us for the three launches instead of ~20)
+    // the dispatch of those short; two launches (RedoArgs), ~6 us on a clean 64 x 1e6 update
     if (redo_nan) tpb = 64;
     const unsigned ntile = (unsigned)((tiles + tpb - 1) / tpb);          // blocks (= partials) per instance
     if (hint) {
@@ -578,11 +605,16 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
     int rc = tramp_ws_reserve(ctx, head + r_bytes + scal_bytes + part_bytes);
     if (rc) return rc;
     char* ws = reinterpret_cast<char*>(ctx->ws) + head;
-    const unsigned* only = nullptr;
+    RedoArgs rd1, rd2;                  // pass 1 / pass 2 of a redo (RedoArgs); empty otherwise
     if (redo_nan) {
-        unsigned* flags = reinterpret_cast<unsigned*>(ctx->ws);
-        hipLaunchKernelGGL(ew_flag_nan, dim3(1), dim3(kBlock), 0, ctx->stream, batch, (const double*)out.a_new, flags, ctx->lean_stat);
-        only = flags;
+        TRAMP_REQUIRE(ctx, !hint && !out.count && !out.mask);
+        rd1.a_flag = out.a_new;
+        rd1.flags = reinterpret_cast<unsigned*>(ctx->ws);
+        rd1.stat = ctx->lean_stat;
+        rd1.batch = batch;
+        rd2.flags = rd1.flags;
+        rd2.nblk = (int)ntile;
+        rd2.a_in = a_in_d;
     }
     T* rbuf = store_r ? reinterpret_cast<T*>(ws) : nullptr;
     double* scal = reinterpret_cast<double*>(ws + r_bytes);
@@ -598,14 +630,17 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
         dim3 grid(ntile, nb), block(kBlock);
         if (hint) {
             hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, inst0, a_in_d, hint->partials,
-                               (const unsigned long long*)nullptr, hint->nblk, o, scal + inst0, only);
+                               (const unsigned long long*)nullptr, hint->nblk, o, scal + inst0);
         } else {
             hipLaunchKernelGGL((ew_moments_tile<T, Op, U>), grid, block, 0, ctx->stream, op, n, inst0, tpb, p0, p1,
                                rbuf ? rbuf + inst0 * n : nullptr, partials + inst0 * ntile,
-                               pcount ? pcount + inst0 * ntile : nullptr, out.mask, only);
-            hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, (size_t)0, a_in_d,
-                               partials + inst0 * ntile, pcount ? pcount + inst0 * ntile : nullptr, (int)ntile, o,
-                               scal + inst0, only);
+                               pcount ? pcount + inst0 * ntile : nullptr, out.mask, rd1);
+            if (redo_nan)
+                rd2.partials = partials + inst0 * ntile;        // pass 2 finalises inline
+            else
+                hipLaunchKernelGGL(ew_finalize, dim3(nb), block, 0, ctx->stream, n, inst0, (size_t)0, a_in_d,
+                                   partials + inst0 * ntile, pcount ? pcount + inst0 * ntile : nullptr, (int)ntile, o,
+                                   scal + inst0);
         }
         // outputs past the Infinity Cache are streamed around the caches (+6 % on the box's copy rate)
         const bool nts = (double)n * (double)batch * sizeof(T) > 192.0 * 1024 * 1024;
@@ -617,17 +652,17 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
         if (store_r) {
             if (nts)
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, true>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
-                                   p0, p1, rbuf + inst0 * n, scal + inst0, o, only);
+                                   p0, p1, rbuf + inst0 * n, scal + inst0, o, rd2);
             else
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, false, false>), grid_a, block, 0, ctx->stream, op, n, inst0,
-                                   tpa, p0, p1, rbuf + inst0 * n, scal + inst0, o, only);
+                                   tpa, p0, p1, rbuf + inst0 * n, scal + inst0, o, rd2);
         } else {
             if (nts)
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, true>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
-                                   p0, p1, (const T*)nullptr, scal + inst0, o, only);
+                                   p0, p1, (const T*)nullptr, scal + inst0, o, rd2);
             else
                 hipLaunchKernelGGL((ew_apply_tile<T, Op, U, true, false>), grid_a, block, 0, ctx->stream, op, n, inst0, tpa,
-                                   p0, p1, (const T*)nullptr, scal + inst0, o, only);
+                                   p0, p1, (const T*)nullptr, scal + inst0, o, rd2);
         }
     }
     TRAMP_LAUNCH_CHECK(ctx);

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                 if (FLAGS & kResSchedBarrier) __builtin_amdgcn_sched_barrier(0);
             }
             // a lean op that left its form's domain anywhere in the tile poisons the tile's sum: the instance's a_new comes
-            // out NaN, which is what the caller's redo on the tile kernels looks for (ew_kernels.hip: pwl_dir, ew_flag_nan) (a select, not a branch: no control flow in the pipelined body)
+            // out NaN, which is what the caller's redo on the tile kernels looks for (ew_kernels.hip: pwl_dir, RedoArgs) (a select, not a branch: no control flow in the pipelined body)
             if (OpLean<Op>::value) acc += (bad == T(0)) ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
             acc += (double)poison;                                      // (pieces that do not count are repeats of ones that do)
             acc = res_block_sum<NT>(acc, smem);
