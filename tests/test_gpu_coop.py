@@ -34,7 +34,10 @@ def test_priors_and_likelihoods_one_launch(T, ctx, dtype, B, n):
     y = np.sign(rs.standard_normal((B, n))).astype(dtype)
     cases = [(T.GaussBernoulliPrior(size=n, rho=0.1, dtype=dtype, ctx=ctx), "compute_forward_message",
               lambda i: orc.gb_prior_message(ax[i], b[i].astype(np.float64), rho=0.1)),
-             (T.BinaryPrior(size=n, p_pos=0.3, dtype=dtype, ctx=ctx), "compute_forward_message", None),
+             (T.BinaryPrior(size=n, p_pos=0.3, dtype=dtype, ctx=ctx), "compute_forward_message",
+              lambda i: orc.ab_new(*orc.binary_prior_posterior(ax[i], b[i].astype(np.float64), p_pos=0.3), ax[i], b[i].astype(np.float64))),
+             (T.ReluLikelihood(y=np.maximum(y * np.abs(b), 0), dtype=dtype, ctx=ctx), "compute_backward_message",
+              lambda i: orc.relu_lik_message(ax[i], b[i].astype(np.float64), np.maximum(y[i] * np.abs(b[i]), 0).astype(np.float64))),
              (T.SgnLikelihood(y=y, dtype=dtype, ctx=ctx), "compute_backward_message",
               lambda i: orc.sgn_lik_message(ax[i], b[i].astype(np.float64), y[i].astype(np.float64))),
              (T.AbsLikelihood(y=np.abs(b) + 0.1, dtype=dtype, ctx=ctx), "compute_backward_message",
