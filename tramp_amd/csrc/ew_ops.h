@@ -285,6 +285,15 @@ template <typename T, int KIND, bool FWD, bool UNI = true, bool LEAN = false> st
             return {o.r, o.v, o.mask};
         }
     }
+    // two components at once (f32 lean form on the packed-f32 pipe, OpPair)
+    __device__ void eval2(float z0, float z1, float xa, float xb, EwOut<float>& o0, EwOut<float>& o1) const {
+        if constexpr (KIND < 3 && sizeof(T) == 4) {
+            tmath::tm_v2f r, v, dev;
+            tmath::pwl_moment_form_v2<KIND, FWD>(tmath::tm_v2f{z0, z1}, tmath::tm_v2f{xa, xb}, c, &r, &v, &dev);
+            o0 = {r.x, v.x, 3u, dev.x};
+            o1 = {r.y, v.y, 3u, dev.y};
+        }
+    }
 };
 
 // Only the L1 prior reports a support count (MAP_L1NormPrior's mask, map_L1_norm_prior.py:16-17): the other
@@ -306,6 +315,7 @@ template <typename Op> struct OpPair { static constexpr bool value = false; };
 template <> struct OpPair<SgnLikOp<float, true>> { static constexpr bool value = true; };
 template <> struct OpPair<SgnLikBitsOp<float, true>> { static constexpr bool value = true; };
 template <> struct OpPair<ReluLikOp<float, true>> { static constexpr bool value = true; };
+template <int KIND, bool FWD, bool UNI> struct OpPair<PwlOp<float, KIND, FWD, UNI, true>> { static constexpr bool value = KIND < 3; };
 
 template <typename Op> struct OpCounts { static constexpr bool value = false; };
 template <typename T> struct OpCounts<L1Op<T>> { static constexpr bool value = true; };

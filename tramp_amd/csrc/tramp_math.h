@@ -1085,6 +1085,82 @@ TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o, T* de
     return ok;
 }
 
+#if defined(__HIPCC__) && TRAMP_ERFCX_UNIFORM
+// The lean moment form (VOTE = false, the uniform-grid erfcx table) for TWO f32 components at once on the packed-f32 pipe:
+// the lanes of every two-lane operation are the two components, so there is no horizontal sum and no cross-lane select -
+// the same operations in the same order as pwl_moment_form<float, ..., false> per lane.  (Plain f32 issues at the f64
+// rate on gfx950; the f32 K7 updates are instruction-bound at half f64's bytes.)
+__device__ __forceinline__ tm_v2f v2_min(tm_v2f a, tm_v2f b) { return tm_v2f{fmin_(a.x, b.x), fmin_(a.y, b.y)}; }
+__device__ __forceinline__ tm_v2f v2_max(tm_v2f a, tm_v2f b) { return tm_v2f{fmax_(a.x, b.x), fmax_(a.y, b.y)}; }
+__device__ __forceinline__ tm_v2f v2_sel(bool cx, bool cy, tm_v2f a, tm_v2f b) { return tm_v2f{cx ? a.x : b.x, cy ? a.y : b.y}; }
+template <int KIND, bool FWD>
+__device__ __forceinline__ void pwl_moment_form_v2(tm_v2f bz, tm_v2f bx, const PwlConst<float>& c, tm_v2f* ro, tm_v2f* vo, tm_v2f* dev) {
+    static_assert(KIND >= 0 && KIND < 3, "Sgn / Abs / Relu only");
+    constexpr double sl0 = pwl_slope(KIND, 0), sl1 = pwl_slope(KIND, 1);
+    constexpr float THi = (float)kErfcxTHi, TLo = (float)kErfcxTLo, Lim = PwlMomentLim<float>::value;
+    const tm_v2f b0 = (sl0 == 0.0) ? bz : bz + bx;
+    const tm_v2f b1 = (sl1 == 0.0) ? bz : (sl1 == 1.0 ? bz + bx : bz - bx);
+    tm_v2f x0 = b0 * c.kx[0], x1 = b1 * c.kx[1];
+    const tm_v2f xmin = v2_min(x0, x1), xmax = v2_max(x0, x1);
+    constexpr bool SAT = (KIND != 0);
+    const tm_v2f hi_v = xmax - v2_min(xmax, (tm_v2f)THi);
+    const tm_v2f lo_v = v2_max(TLo - xmin, (tm_v2f)0.0f);
+    const tm_v2f other = SAT ? v2_max(-4.0f - xmax, (tm_v2f)0.0f) + v2_max((0.0f - Lim) - xmin + 1e-3f, (tm_v2f)0.0f) : (tm_v2f)1.0f;
+    tm_v2f dv = __builtin_elementwise_fma(hi_v, hi_v, lo_v * other) + ((x0 - x0) + (x1 - x1));
+    if (KIND == 0) dv += bx - bx;
+    *dev = dv;
+    x0 = v2_min(v2_max(x0, (tm_v2f)TLo), (tm_v2f)THi);
+    x1 = v2_min(v2_max(x1, (tm_v2f)TLo), (tm_v2f)THi);
+    const tm_v2f e0 = erfcx_tay_v2(x0), e1 = erfcx_tay_v2(x1);
+    const tm_v2f r00 = b0 * c.reg[0].v0, r01 = b1 * c.reg[1].v0;
+    tm_v2f W0, W1, G0 = c.gv[0], G1 = c.gv[1];
+    if (KIND == 0) {
+        const tm_v2f ab = tm_v2f{fabs_(bx.x), fabs_(bx.y)} * -2.0f;
+        const tm_v2f en = {exp_clamped_nonpos(ab.x), exp_clamped_nonpos(ab.y)};
+        const bool px = bx.x >= 0.0f, py = bx.y >= 0.0f;
+        const tm_v2f E0 = v2_sel(px, py, (tm_v2f)1.0f, en), E1 = v2_sel(px, py, en, (tm_v2f)1.0f);
+        W0 = e0 * E0;
+        W1 = e1 * E1;
+        G0 = (c.gv[0] * c.reg[0].inv_s0) * E0;
+        G1 = (c.gv[1] * c.reg[0].inv_s0) * E1;
+    } else {
+        W0 = e0 * c.reg[0].s0;
+        W1 = e1 * c.reg[1].s0;
+    }
+    const tm_v2f S = W0 + W1;
+    const tm_v2f iS = {rcp_pos(S.x), rcp_pos(S.y)};
+    if (FWD && KIND == 0) {
+        const tm_v2f p0 = W0 * iS, p1 = W1 * iS;
+        *ro = p0 - p1;
+        *vo = 4.0f * (p0 * p1);
+        return;
+    }
+    const bool hx = W0.x >= W1.x, hy = W0.y >= W1.y;
+    tm_v2f n1, n2, cc;
+    if (!FWD || KIND == 1) {
+        const tm_v2f rho0 = r00, rho1 = (FWD && KIND == 1) ? 0.0f - r01 : r01;
+        const tm_v2f g1 = (FWD && KIND == 1) ? 0.0f - G1 : G1;
+        cc = (KIND == 0) ? rho0 : v2_sel(hx, hy, rho0, rho1);
+        const tm_v2f d0 = rho0 - cc, d1 = rho1 - cc;
+        n1 = __builtin_elementwise_fma(W0, d0, __builtin_elementwise_fma(W1, d1, G0 + g1));
+        const tm_v2f q0 = __builtin_elementwise_fma(d0, d0, (tm_v2f)c.reg[0].v0);
+        const tm_v2f q1 = __builtin_elementwise_fma(d1, d1, (tm_v2f)c.reg[KIND == 0 ? 0 : 1].v0);
+        const tm_v2f t0 = __builtin_elementwise_fma((tm_v2f)-2.0f, cc, rho0), t1 = __builtin_elementwise_fma((tm_v2f)-2.0f, cc, rho1);
+        n2 = __builtin_elementwise_fma(W0, q0, __builtin_elementwise_fma(W1, q1, __builtin_elementwise_fma(G0, t0, g1 * t1)));
+    } else {
+        cc = v2_sel(hx, hy, r00, (tm_v2f)0.0f);
+        const tm_v2f d0 = r00 - cc;
+        n1 = __builtin_elementwise_fma(W0, d0, G0) - W1 * cc;
+        const tm_v2f q0 = __builtin_elementwise_fma(d0, d0, (tm_v2f)c.reg[0].v0);
+        const tm_v2f t0 = __builtin_elementwise_fma((tm_v2f)-2.0f, cc, r00);
+        n2 = __builtin_elementwise_fma(W0, q0, __builtin_elementwise_fma(G0, t0, W1 * (cc * cc)));
+    }
+    const tm_v2f m1 = n1 * iS;
+    *ro = cc + m1;
+    *vo = __builtin_elementwise_fma(0.0f - m1, m1, n2 * iS);
+}
+#endif
+
 template <typename T, int KIND, bool FWD, bool UNI = true>
 TM_HD PwlOut<T> pwl_posterior_fast(T bz, T bx, const PwlConst<T>& c) {
     if constexpr (KIND < 3) {
