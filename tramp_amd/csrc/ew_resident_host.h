@@ -21,11 +21,20 @@ constexpr int kResU = 4, kResDL = 1, kResDA = 3;
 // held in registers.
 template <typename Op> struct ResShape { static constexpr int U = kResU, NT = kBlock, FLAGS = 0, BPC = 2; };
 template <typename T, int KIND, bool FWD, bool UNI, bool LEAN> struct ResShape<PwlOp<T, KIND, FWD, UNI, LEAN>> {
-    static constexpr int U = sizeof(T) == 4 ? 2 : kResU, NT = kBlock, FLAGS = 0, BPC = sizeof(T) == 4 ? 3 : 2;
+    static constexpr int U = sizeof(T) == 4 ? 2 : kResU, NT = kBlock, FLAGS = sizeof(T) == 4 ? 8 : 0, BPC = sizeof(T) == 4 ? 3 : 2;
 };
 
 // (the f32 lean likelihoods on three workgroups per CU of half-size tiles, the f32 K7 shape: 166-168 us against 164-170 us
 // at 64 x 1e6 - no difference, the standard shape stays)
+// FLAGS = 8 (kResNtLoad): non-temporal loads of the messages.  Measured per op at 64 x 1e6 (steady clocks): the updates
+// with TWO input streams gain (abs likelihood 270 -> 256 us f64, 143 -> 138 us f32; Relu likelihood 291 -> 280 / 154 -> 147 us;
+// K7 f32 1-3 %), the one-input priors do not (f64: no change; f32: 85 -> 101 us - their 256 MB input is partly resident
+// in the Infinity Cache from the call before, which a non-temporal load gives up), K7 f64 and the bit-packed sign
+// likelihood do not either.
+template <typename T> struct ResShape<AbsLikOp<T>> { static constexpr int U = kResU, NT = kBlock, FLAGS = 8, BPC = 2; };
+template <typename T, bool L> struct ResShape<ReluLikOp<T, L>> { static constexpr int U = kResU, NT = kBlock, FLAGS = 8, BPC = 2; };
+template <> struct ResShape<SgnLikOp<double, true>> { static constexpr int U = kResU, NT = kBlock, FLAGS = 8, BPC = 2; };
+
 template <typename Op> struct ResidentOp { static constexpr bool value = false; };
 template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value = true; };
