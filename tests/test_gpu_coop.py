@@ -123,3 +123,22 @@ def test_one_launch_form_replays_inside_a_graph(T, ctx):
     for a, b in zip(*out):
         assert np.array_equal(a, b)
     assert np.all(np.isfinite(out[0][0])) and not ctx.resident_gave_up()
+
+
+def test_one_launch_form_gives_up_cleanly():
+    """A block sum that never arrives (forced: workgroup 2 of instance 0 does not publish, deadline 100 ms): the kernel
+    ends, instance 0 is loudly NaN, the others are right, the host-visible error word is up and the context takes the
+    tile kernels from then on (the same contract as the resident pipeline's, csrc/ew_resident.h)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRAMP_EW_RESIDENT_TIMEOUT_MS="100", TRAMP_EW_COOP_DBG_SKIP="3")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_coop_giveup_worker.py")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["coop_ran"] and out["gave_up"] and out["second_call_on_tiles"], out
+    assert out["nan_instances_first"] == [1, 0, 0] and out["nan_instances_second"] == 0, out
+    assert out["finite_agree"] and out["oracle"], out

@@ -726,7 +726,7 @@ template <typename T, typename Op, int K>
 __global__ __launch_bounds__(kBlock, 2) void ew_coop(Op op, size_t n, unsigned G, size_t chunk, const T* __restrict__ in0,
                                                      const T* __restrict__ in1, MsgOut out, unsigned long long* __restrict__ slots,
                                                      size_t capacity, unsigned* __restrict__ epoch, long long deadline_ticks,
-                                                     volatile unsigned* err_host) {
+                                                     volatile unsigned* err_host, unsigned dbg_skip_plus1) {
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     __shared__ double smem[kBlock / kWave];
@@ -789,7 +789,8 @@ __global__ __launch_bounds__(kBlock, 2) void ew_coop(Op op, size_t n, unsigned G
     if (tid == 0) {
         unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
         if (ab == kCoopSentinel) ab = kCoopNaN;
-        __hip_atomic_store(sl + g, ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (debug: workgroup dbg_skip_plus1 - 1 of instance 0 never publishes - the give-up path, tests/test_gpu_coop.py)
+        if (!(b == 0 && g + 1 == dbg_skip_plus1)) __hip_atomic_store(sl + g, ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < kWave) {
         double part = 0.0;
@@ -884,12 +885,13 @@ static int launch_coop(tramp_ctx* ctx, const Op& op, size_t n, size_t batch, uns
     if (occ < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ew_coop<T, Op, K>, kBlock, 0) != hipSuccess) occ = 0;
     if (occ < 2) return kResNotEligible;
     static const long long timeout_ms = getenv("TRAMP_EW_RESIDENT_TIMEOUT_MS") ? atoll(getenv("TRAMP_EW_RESIDENT_TIMEOUT_MS")) : 2000;
+    static const unsigned dbg_skip = getenv("TRAMP_EW_COOP_DBG_SKIP") ? (unsigned)atoi(getenv("TRAMP_EW_COOP_DBG_SKIP")) : 0u;
     MsgOut o = out;
     if (o.damping == 0.0) { o.a_old = nullptr; o.b_old = nullptr; }
     ProfScope prof(ctx, PROF_EW, (double)(Op::NIN + 1) * sizeof(T) * (double)n * (double)batch, 0.0);
     hipLaunchKernelGGL((ew_coop<T, Op, K>), dim3(G, (unsigned)batch), dim3(kBlock), 0, ctx->stream, op, n, G, chunk,
                        reinterpret_cast<const T*>(in0), reinterpret_cast<const T*>(in1), o, ctx->coop_slots, ctx->capacity_coop, ctx->coop_epoch,
-                       (timeout_ms > 0 ? timeout_ms : 2000) * 100000LL, ctx->lean_stat ? ctx->lean_stat + 2 : nullptr);
+                       (timeout_ms > 0 ? timeout_ms : 2000) * 100000LL, ctx->lean_stat ? ctx->lean_stat + 2 : nullptr, dbg_skip);
     TRAMP_LAUNCH_CHECK(ctx);
     ctx->coop_runs += 1;
     return TRAMP_OK;

@@ -15,6 +15,7 @@ SWITCHES = {
     "TRAMP_EW_COOP": ("1", "select", "0: a few large instances take the tile kernels' three launches instead of the one-launch cooperative form"),
     "TRAMP_EW_LEAN_ADAPT": ("1", "select", "0: a lean resident K7 update that had to redo more than a quarter of its instances does not send the next 15 calls to the tile kernels"),
     "TRAMP_EW_RESIDENT_TIMEOUT_MS": ("2000", "tune", "deadline of a resident kernel: hand-offs still missing then are given up (NaN update, tile kernels afterwards)"),
+    "TRAMP_EW_COOP_DBG_SKIP": (None, "debug", "workgroup index + 1 of instance 0 whose block sum a one-launch update never publishes (forces its give-up path in tests)"),
     "TRAMP_EW_RESIDENT_DBG_SKIP": (None, "debug", "tile index + 1 whose sum a resident kernel never publishes (forces the give-up path in tests)"),
     "TRAMP_EW_RESIDENT_MIN_ROUNDS": ("4", "tune", "rounds of 2 x CUs - 8 tiles below which the pipeline is not worth its fill and drain"),
     "TRAMP_PRIOR_FUSE": ("1", "select", "0: producers never leave prior / likelihood moments (csrc/prior_hint.h)"),
