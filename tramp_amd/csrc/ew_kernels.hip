@@ -1651,7 +1651,9 @@ __global__ __launch_bounds__(kBlock) void var_post_kernel(size_t n, const double
 
 // Streaming-tile form of the same pass (n a multiple of the 16-byte vector): a block owns `tpb` consecutive
 // tiles of 256 x U vectors (launch shape of tools/probes/probe_copy.hip), 16-byte loads and stores.
-template <typename T, int U>
+// NTS: arrays past the Infinity Cache - loads and stores that do not allocate in the caches (the three input streams and
+// the output are each read / written once: 385 -> 3xx us at 64 x 1e6 f64 with the stopping rule's r_old)
+template <typename T, int U, bool NTS>
 __global__ __launch_bounds__(kBlock) void var_post_tile(size_t n, int tpb, const double* __restrict__ a1,
                                                         const T* __restrict__ b1, const double* __restrict__ a2,
                                                         const T* __restrict__ b2, const T* __restrict__ r_old,
@@ -1677,9 +1679,16 @@ __global__ __launch_bounds__(kBlock) void var_post_tile(size_t n, int tpb, const
         for (int u = 0; u < U; ++u) {
             const size_t i = base + (size_t)u * kBlock;
             if (i < nv) {
-                x1[u] = p1[i];
-                x2[u] = p2[i];
-                if (po) xo[u] = po[i];
+                if (NTS) {
+                    using NVt = typename NativeVec<T>::type;
+                    *reinterpret_cast<NVt*>(&x1[u]) = __builtin_nontemporal_load(reinterpret_cast<const NVt*>(p1 + i));
+                    *reinterpret_cast<NVt*>(&x2[u]) = __builtin_nontemporal_load(reinterpret_cast<const NVt*>(p2 + i));
+                    if (po) *reinterpret_cast<NVt*>(&xo[u]) = __builtin_nontemporal_load(reinterpret_cast<const NVt*>(po + i));
+                } else {
+                    x1[u] = p1[i];
+                    x2[u] = p2[i];
+                    if (po) xo[u] = po[i];
+                }
             }
         }
 #pragma unroll
@@ -1696,7 +1705,7 @@ __global__ __launch_bounds__(kBlock) void var_post_tile(size_t n, int tpb, const
                     sn += (double)ri * (double)ri;
                     vset<T>(out, j, ri);
                 }
-                pr[i] = out;
+                store_vec<T, NTS>(&pr[i], out);
             }
         }
     }
@@ -1749,12 +1758,21 @@ extern "C" int tramp_variable_posterior(tramp_ctx* ctx, int dtype, size_t n, siz
     if (rc) return rc;
     dim3 grid(nblk, (unsigned)batch);
     ProfScope prof(ctx, PROF_VAR_POST, 3.0 * dtype_size(dtype) * (double)n * (double)batch, 0.0);
-    if (tiled && dtype == TRAMP_F64)
-        hipLaunchKernelGGL((var_post_tile<double, U>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
+    const bool nts = (double)n * (double)batch * (double)dtype_size(dtype) > 192.0 * 1024 * 1024;
+    if (tiled && dtype == TRAMP_F64 && nts)
+        hipLaunchKernelGGL((var_post_tile<double, U, true>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
                            (const double*)b1_d, a2_d, (const double*)b2_d, (const double*)r_old_d, (double*)r_d, v_d,
                            ctx->ws);
+    else if (tiled && dtype == TRAMP_F64)
+        hipLaunchKernelGGL((var_post_tile<double, U, false>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
+                           (const double*)b1_d, a2_d, (const double*)b2_d, (const double*)r_old_d, (double*)r_d, v_d,
+                           ctx->ws);
+    else if (tiled && nts)
+        hipLaunchKernelGGL((var_post_tile<float, U, true>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
+                           (const float*)b1_d, a2_d, (const float*)b2_d, (const float*)r_old_d, (float*)r_d, v_d,
+                           ctx->ws);
     else if (tiled)
-        hipLaunchKernelGGL((var_post_tile<float, U>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
+        hipLaunchKernelGGL((var_post_tile<float, U, false>), grid, dim3(kBlock), 0, ctx->stream, n, tpb, a1_d,
                            (const float*)b1_d, a2_d, (const float*)b2_d, (const float*)r_old_d, (float*)r_d, v_d,
                            ctx->ws);
     else if (dtype == TRAMP_F64)
