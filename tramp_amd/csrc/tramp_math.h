@@ -1019,7 +1019,20 @@ TM_HD bool pwl_moment_form(T bz, T bx, const PwlConst<T>& c, PwlOut<T>& o, T* de
     T e0, e1;
 #if TRAMP_ERFCX_UNIFORM
     if constexpr (GRID) {
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (KIND == 0) {
+            // Sgn: both regions have the SAME natural parameters and opposite sides, x1 = -x0 exactly: ONE table evaluation
+            // at |x0| and the reflection erfcx(-t) = 2 exp(t^2) - erfcx(t) for the other (t^2 with its rounding error:
+            // exp(hi) (1 + lo)) - an exp (~20 instructions) instead of a second Taylor evaluation (~32)
+            const T t = fabs_(x0);
+            const T ep = erfcx_tay(t);
+            const T hi = t * t, lo = fma_(t, t, T(0) - hi);
+            T ex = exp_core(hi);
+            ex = fma_(ex, lo, ex);
+            const T en = fma_(T(2), ex, T(0) - ep);
+            const bool pos0 = x0 >= T(0);
+            e0 = pos0 ? ep : en;
+            e1 = pos0 ? en : ep;
+        } else if constexpr (sizeof(T) == 4) {
             erfcx_tay_pair(x0, x1, &e0, &e1);
         } else {
             e0 = erfcx_tay(x0);
@@ -1111,7 +1124,21 @@ __device__ __forceinline__ void pwl_moment_form_v2(tm_v2f bz, tm_v2f bx, const P
     *dev = dv;
     x0 = v2_min(v2_max(x0, (tm_v2f)TLo), (tm_v2f)THi);
     x1 = v2_min(v2_max(x1, (tm_v2f)TLo), (tm_v2f)THi);
-    const tm_v2f e0 = erfcx_tay_v2(x0), e1 = erfcx_tay_v2(x1);
+    tm_v2f e0, e1;
+    if (KIND == 0) {          // x1 = -x0: one table evaluation and the reflection (pwl_moment_form)
+        const tm_v2f t = {fabs_(x0.x), fabs_(x0.y)};
+        const tm_v2f ep = erfcx_tay_v2(t);
+        const tm_v2f hi = t * t, lo = __builtin_elementwise_fma(t, t, 0.0f - hi);
+        tm_v2f ex = {exp_core(hi.x), exp_core(hi.y)};
+        ex = __builtin_elementwise_fma(ex, lo, ex);
+        const tm_v2f en = __builtin_elementwise_fma((tm_v2f)2.0f, ex, 0.0f - ep);
+        const bool qx = x0.x >= 0.0f, qy = x0.y >= 0.0f;
+        e0 = v2_sel(qx, qy, ep, en);
+        e1 = v2_sel(qx, qy, en, ep);
+    } else {
+        e0 = erfcx_tay_v2(x0);
+        e1 = erfcx_tay_v2(x1);
+    }
     const tm_v2f r00 = b0 * c.reg[0].v0, r01 = b1 * c.reg[1].v0;
     tm_v2f W0, W1, G0 = c.gv[0], G1 = c.gv[1];
     if (KIND == 0) {
