@@ -267,10 +267,13 @@ int tramp_diag_factor(tramp_ctx* ctx, int dtype, int which, size_t count,
  *   TRAMP_DIAG_BINARY {b0 = 0.5 log(p+/p-)}  binary_prior.py:27,52-58
  *   TRAMP_DIAG_RELU_LIK {slope of the negative side; 0 = Relu}  piecewise_linear_likelihood.py:9-63,279-291
  *   TRAMP_DIAG_PWL3_LIK {z_lo, z_hi, slope pos/mid/neg, x0 pos/mid/neg}  piecewise_linear_likelihood.py:156-218,293-320
+ *   TRAMP_DIAG_HALFLINE {a0, b0}  exponential_prior.py:54-60 (a0 = 0, b0 = -1/mean), positive_prior.py:56-63 (a0 = 1, b0 = 0)
+ *   TRAMP_DIAG_GM {K, probs[K], means[K], vars[K]} (up to 32 parameters)  gaussian_mixture_prior.py:88-97
  * (the Gaussian factors' MESSAGES are constants in the reference, gaussian_prior.py:86-89: the host mirror
  * returns those; a_new / b_new here are the generic compute_ab_new of the posterior) */
 enum { TRAMP_DIAG_GB = 0, TRAMP_DIAG_L1 = 1, TRAMP_DIAG_SGN_LIK = 2, TRAMP_DIAG_ABS_LIK = 3, TRAMP_DIAG_GAUSS_PRIOR = 4,
-       TRAMP_DIAG_GAUSS_LIK = 5, TRAMP_DIAG_BINARY = 6, TRAMP_DIAG_RELU_LIK = 7, TRAMP_DIAG_PWL3_LIK = 8 };
+       TRAMP_DIAG_GAUSS_LIK = 5, TRAMP_DIAG_BINARY = 6, TRAMP_DIAG_RELU_LIK = 7, TRAMP_DIAG_PWL3_LIK = 8,
+       TRAMP_DIAG_HALFLINE = 9, TRAMP_DIAG_GM = 10 };
 int tramp_diag_factor_p(tramp_ctx* ctx, int dtype, int which, size_t count,
                         const void* a_d, const void* b_d, const void* in2_d,
                         const double* params, int nparams,
@@ -644,6 +647,29 @@ int tramp_binary_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
                            const double* ax_d, const void* bx_d, double b0,
                            double damping, const double* a_old_d, const void* b_old_d,
                            double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+/* ExponentialPrior p(x) = 1[x >= 0] exp(-x / mean) / mean (tramp/priors/exponential_prior.py:8-80: a0 = 0, b0 = -1/mean)
+ * and PositivePrior p(x) = 2 1[x >= 0] N(x | 0, 1) (tramp/priors/positive_prior.py:8-82: a0 = 1, b0 = 0), one kernel:
+ * the posterior is the half-line truncated normal positive.r / positive.v (tramp/beliefs/positive.py:12-17) at
+ * (ax + a0, bx + b0), then compute_ab_new; outputs optional as in tramp_gb_prior_fwd. */
+int tramp_halfline_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                             const double* ax_d, const void* bx_d, double a0, double b0,
+                             double damping, const double* a_old_d, const void* b_old_d,
+                             double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+/* GaussianMixturePrior p(x) = sum_k p_k N(x | m_k, s_k), K <= 8 components given as HOST arrays
+ * (tramp/priors/gaussian_mixture_prior.py:8-139, tramp/beliefs/mixture.py:18-47): softmax over the components'
+ * log-partitions, r = sum s_k r_k, v = mean_i [sum s_k / a_k + sum_{k<l} s_k s_l (r_k - r_l)^2]. */
+int tramp_gm_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                       const double* ax_d, const void* bx_d, int K, const double* probs_h, const double* means_h,
+                       const double* vars_h, double damping, const double* a_old_d, const void* b_old_d,
+                       double* a_new_d, void* b_new_d, void* r_d, double* v_d);
+/* ModulusLikelihood y = |z|, z complex (tramp/likelihoods/modulus_likelihood.py:36-131): the output factor of phase
+ * retrieval.  Complex vectors are PLANAR real arrays (tramp/utils/misc.py:13-27): bz_d, b_old_d, b_new_d, r_d are
+ * [batch, 2, n] (plane 0 = Re, plane 1 = Im), y_d is [batch, n].  rz = (bz / |bz|) y I1(|bz| y) / I0(|bz| y),
+ * v = mean_i y_i^2 (1 - I^2) / 2 (:82-93), then compute_ab_new on the planar array.  Outputs optional as above. */
+int tramp_modulus_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
+                          const double* az_d, const void* bz_d, const void* y_d,
+                          double damping, const double* a_old_d, const void* b_old_d,
+                          double* a_new_d, void* b_new_d, void* r_d, double* v_d);
 /* MAP_L21NormPrior.compute_forward_posterior + compute_ab_new (tramp/priors/map_L21_norm_prior.py:7-20,69-74),
  * axis = 0: bx is [batch, d, n], groups are the d components of a site (the total-variation prior on a
  * gradient field).  count_d[batch]: sites with ||b[:, j]|| > gamma; mask_d[batch, n]: that support, bit-exact
@@ -704,6 +730,10 @@ int tramp_se_mp_channel(tramp_ctx* ctx, int dir, size_t count, const double* alp
 /* BinaryPrior.compute_forward_error (tramp/priors/binary_prior.py:82-86, base_prior.py:66-69):
  * v(ax) = p+ E_{N(ax, ax)}[1 - tanh^2(b + b0)] + p- E_{N(-ax, ax)}[.], host arrays of `count` points. */
 int tramp_se_binary_prior(tramp_ctx* ctx, size_t count, const double* ax, const double* p_pos, double* v);
+/* GaussianMixturePrior.compute_forward_error (tramp/priors/gaussian_mixture_prior.py:132-137, base_prior.py:66-69):
+ * v(ax) = sum_k p_k E_{N(ax m_k, ax + ax^2 s_k)}[v(ax, b)], host arrays (`count` points ax; K <= 8 components). */
+int tramp_se_gm_prior(tramp_ctx* ctx, size_t count, const double* ax, int K, const double* probs,
+                      const double* means, const double* vars, double* v);
 /* K13. Likelihood.compute_backward_error for SgnLikelihood (1-D) and AbsLikelihood (2-D)
  *      tramp/likelihoods/base_likelihood.py:78-81, sgn_likelihood.py:79-92,
  *      abs_likelihood.py:60-69.  Requires az > 1/tau_z (TRAMP_EINVAL otherwise,
@@ -732,6 +762,17 @@ int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, double z_hi,
                       const double* az, const double* tau_z, double* v);
 
 /* ---- log-partitions -------------------------------- */
+/* compute_log_partition of the round-6 priors, out[b] = SUM over the n components (the host takes the mean):
+ *   which 0, params_h = {a0, b0, A0}: positive.A(ax + a0, bx + b0) - A0 - ExponentialPrior (exponential_prior.py:62-65,
+ *     A0 = exponential.A(b0) = -log(-b0)) and PositivePrior (positive_prior.py:65-69, A0 = positive.A(1, 0));
+ *   which 1, params_h = {K, probs[K], means[K], vars[K]}: GaussianMixturePrior (gaussian_mixture_prior.py:99-104). */
+int tramp_prior2_log_partition(tramp_ctx* ctx, int dtype, int which, size_t n, size_t batch, const double* params_h,
+                               int nparams, const double* ax_d, const void* bx_d, double* out_d);
+/* ModulusLikelihood.compute_log_partition AS FOUND (modulus_likelihood.py:125-129: np.absolute acts on each real
+ * coordinate of the planar array): out[b] = sum over both planes of -az y^2 / 2 + log(2 pi y) + log I0(|b| y);
+ * the host divides by 4 n (A.mean() / 2). */
+int tramp_modulus_log_partition(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const double* az_d,
+                                const void* bz_d, const void* y_d, double* out_d);
 /* Log-partition of a factor given as a TABLE OF LINEAR REGIONS - the rest of the piecewise-linear family (LeakyRelu,
  * AsymmetricAbs, HardTanh, HardSigmoid, SymmetricDoor and their observed twins), restated as the reference loops:
  * regions_h = nreg (2 or 3) host rows (zmin, zmax, slope, x0) in the reference's order, +-INFINITY for open ends.

@@ -1774,7 +1774,7 @@ def _rms(x):
 
 
 def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
-             wait_increase=5, max_increase=0.2, record=None):
+             wait_increase=5, max_increase=0.2, record=None, init=None):
     """Expectation propagation on the chain  f0 - x0 - f1 - x1 - ... - fL.
 
     factors[0] is a prior, factors[-1] a likelihood, the others channels;
@@ -1789,12 +1789,16 @@ def ep_chain(factors, shapes, max_iter=200, damping=None, tol=1e-6,
 
     ``record(it, fwd, bwd, rs, vs)`` is called after every iteration with the
     factor->variable messages and posteriors.  Returns dict with the final
-    state and n_iter.
+    state and n_iter.  ``init(i, direction)`` -> (a, b) replaces the zero initial message of variable i's
+    "fwd" / "bwd" edge (CustomInit, initial_conditions.py:45-85; message_passing.py:211-232).
     """
     L = len(factors) - 1            # number of variables
     # fwd[i] = message factor i -> variable i ; bwd[i] = factor i+1 -> variable i
     fwd = [(0, np.zeros(shapes[i])) for i in range(L)]
     bwd = [(0, np.zeros(shapes[i])) for i in range(L)]
+    if init is not None:
+        fwd = [(init(i, "fwd")[0], np.zeros(shapes[i]) + init(i, "fwd")[1]) for i in range(L)]
+        bwd = [(init(i, "bwd")[0], np.zeros(shapes[i]) + init(i, "bwd")[1]) for i in range(L)]
     d = damping if damping else 0.
     old_rs = None
     old_state = None
@@ -2330,3 +2334,282 @@ def digit_matvec(mat, x, S=7):
         with np.errstate(invalid="ignore"):
             out = out + (s * rs[None, :]) * xs[:, None]
     return out
+
+
+# --------------------------------------------------------------------------
+# Round 6: the rest of the reference's separable priors (Exponential, Positive, GaussianMixture) and the
+# complex-valued factors of phase retrieval (ModulusLikelihood, ComplexLinearChannel).
+# Pinned by tests/golden/priors2.npz and tests/golden/complex.npz (tools/make_golden_r6.py).
+# --------------------------------------------------------------------------
+def positive_rv(a, b):
+    "beliefs/positive.py:12-17: mean and variance of N(b/a, 1/a) restricted to [0, inf)"
+    m, v, _ = halfline_moments(b / a, 1 / a, +1)
+    return m, v
+
+
+def positive_A(a, b):
+    "beliefs/positive.py:8-9 (truncated_normal_logZ on [0, inf))"
+    return halfline_logZ(b / a, 1 / a, +1)
+
+
+def exp_prior_posterior(ax, bx, mean=1, isotropic=True):
+    "exponential_prior.py:25-26 (natural parameter b0 = -1/mean), :54-60"
+    r, v = positive_rv(ax, np.asarray(bx, float) - 1. / mean)
+    return r, (v.mean() if isotropic else v)
+
+
+def exp_prior_message(ax, bx, mean=1):
+    r, v = exp_prior_posterior(ax, bx, mean)
+    return ab_new(r, v, ax, bx)
+
+
+def exp_prior_log_partition(ax, bx, mean=1):
+    "exponential_prior.py:62-65 with exponential.A(b) = -log(-b) (beliefs/exponential.py:4-5)"
+    b0 = -1. / mean
+    return (positive_A(ax, np.asarray(bx, float) + b0) + np.log(-b0)).mean()
+
+
+def positive_prior_posterior(ax, bx, isotropic=True):
+    "positive_prior.py:23-25 (a0 = 1, b0 = 0), :56-63"
+    r, v = positive_rv(ax + 1., np.asarray(bx, float) + 0.)
+    return r, (v.mean() if isotropic else v)
+
+
+def positive_prior_message(ax, bx):
+    r, v = positive_prior_posterior(ax, bx)
+    return ab_new(r, v, ax, bx)
+
+
+def positive_prior_log_partition(ax, bx):
+    "positive_prior.py:65-69"
+    return (positive_A(ax + 1., np.asarray(bx, float)) - positive_A(1., 0.)).mean()
+
+
+def gm_params(probs, means, vars_):
+    "gaussian_mixture_prior.py:36-39: a_k = 1/var_k, b_k = mean_k/var_k, eta_k = log p_k - normal.A(a_k, b_k)"
+    probs, means, vars_ = (np.asarray(t, float) for t in (probs, means, vars_))
+    a0, b0 = 1 / vars_, means / vars_
+    return a0, b0, np.log(probs) - normal_A(a0, b0)
+
+
+def _gm_terms(ax, bx, probs, means, vars_):
+    a0, b0, eta = gm_params(probs, means, vars_)
+    bx = np.asarray(bx, float)
+    a = ax + a0.reshape((-1,) + (1,) * bx.ndim)                 # (K, ...) as :89-91
+    b = bx + b0.reshape((-1,) + (1,) * bx.ndim)
+    xi = eta.reshape((-1,) + (1,) * bx.ndim) + normal_A(a, b)
+    return a, b, xi
+
+
+def gm_prior_posterior(ax, bx, probs=(0.5, 0.5), means=(-1, 1), vars_=(1, 1), isotropic=True):
+    "gaussian_mixture_prior.py:88-97 with beliefs/mixture.py:23-41"
+    from scipy.special import softmax
+    a, b, xi = _gm_terms(ax, bx, probs, means, vars_)
+    s = softmax(xi, axis=0)
+    rk = b / a
+    r = (s * rk).sum(axis=0)
+    Dr = 0.5 * sum(sk * sl * (r_k - r_l)**2 for sk, r_k in zip(s, rk) for sl, r_l in zip(s, rk))
+    v = Dr + (s / a).sum(axis=0)
+    return r, (v.mean() if isotropic else v)
+
+
+def gm_prior_message(ax, bx, probs=(0.5, 0.5), means=(-1, 1), vars_=(1, 1)):
+    r, v = gm_prior_posterior(ax, bx, probs, means, vars_)
+    return ab_new(r, v, ax, bx)
+
+
+def gm_prior_log_partition(ax, bx, probs=(0.5, 0.5), means=(-1, 1), vars_=(1, 1)):
+    "gaussian_mixture_prior.py:99-104 with mixture.A (beliefs/mixture.py:18-20)"
+    from scipy.special import logsumexp
+    a0, b0, eta = gm_params(probs, means, vars_)
+    _, _, xi = _gm_terms(ax, bx, probs, means, vars_)
+    return (logsumexp(xi, axis=0) - logsumexp(eta + normal_A(a0, b0))).mean()
+
+
+def se_gm_prior_error(ax, probs=(0.5, 0.5), means=(-1, 1), vars_=(1, 1), method="quadpack"):
+    "gaussian_mixture_prior.py:132-137 (beliefs_measure) through base_prior.py:66-69"
+    def v_func(bx):
+        return gm_prior_posterior(ax, np.asarray(bx, float), probs, means, vars_, isotropic=False)[1]
+    return sum(p * gaussian_measure(ax * m, np.sqrt(ax + ax**2 * v), v_func, method)
+               for p, m, v in zip(probs, means, vars_))
+
+
+def gm_second_moment(probs, means, vars_):
+    "gaussian_mixture_prior.py:53-58"
+    return sum(p * (m**2 + v) for p, m, v in zip(probs, means, vars_))
+
+
+class _SeparablePriorFactor(OracleFactor):
+    kind = "prior"
+
+    def forward(self, az, bz, ax, bx):
+        r, v = self.posterior(ax, bx)
+        return ab_new(r, v, ax, bx)
+
+
+class ExpPriorFactor(_SeparablePriorFactor):
+    def __init__(self, size, mean=1):
+        self.size, self.mean = size, mean
+
+    def posterior(self, ax, bx):
+        return exp_prior_posterior(ax, bx, self.mean)
+
+    def log_partition(self, az, bz, ax, bx):
+        return exp_prior_log_partition(ax, bx, self.mean)
+
+    def second_moment(self):
+        return 2 * self.mean**2
+
+
+class PositivePriorFactor(_SeparablePriorFactor):
+    def __init__(self, size):
+        self.size = size
+
+    def posterior(self, ax, bx):
+        return positive_prior_posterior(ax, bx)
+
+    def log_partition(self, az, bz, ax, bx):
+        return positive_prior_log_partition(ax, bx)
+
+    def second_moment(self):
+        return 1.
+
+
+class GMPriorFactor(_SeparablePriorFactor):
+    def __init__(self, size, probs=(0.5, 0.5), means=(-1, 1), vars_=(1, 1)):
+        self.size, self.probs, self.means, self.vars = size, probs, means, vars_
+
+    def posterior(self, ax, bx):
+        return gm_prior_posterior(ax, bx, self.probs, self.means, self.vars)
+
+    def log_partition(self, az, bz, ax, bx):
+        return gm_prior_log_partition(ax, bx, self.probs, self.means, self.vars)
+
+    def forward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(se_gm_prior_error(ax, self.probs, self.means, self.vars, method), ax)
+
+    def second_moment(self):
+        return gm_second_moment(self.probs, self.means, self.vars)
+
+
+# ---- complex variables as planar real arrays Z[0] = Re z, Z[1] = Im z (tramp/utils/misc.py:13-27) ----
+def ive_ratio(r):
+    "modulus_likelihood.py:9-20: I1(r)/I0(r) from the exponentially scaled Bessel functions, 1 beyond 1e9"
+    from scipy.special import ive
+    r = np.asarray(r, float)
+    out = np.ones_like(r)
+    ind = r < 1e9
+    out[ind] = ive(1, r[ind]) / ive(0, r[ind])
+    return out
+
+
+def modulus_lik_posterior(az, bz, y, isotropic=True):
+    """modulus_likelihood.py:82-93: bz planar (2, ...), y = |z| observed;
+    rz = (bz/|bz|) y I(|bz| y), vz = mean of y^2 (1 - I^2) / 2 (the 1/2 averages the two real coordinates)."""
+    bz = np.asarray(bz, float)
+    c = bz[0] + 1j * bz[1]
+    b = np.abs(c)
+    Ir = ive_ratio(b * y)
+    nz = b != 0
+    unit = np.zeros_like(c)
+    unit[nz] = c[nz] / b[nz]
+    rz = unit * y * Ir
+    vz = 0.5 * y**2 * (1 - Ir**2)
+    return np.stack([rz.real, rz.imag]), (vz.mean() if isotropic else vz)
+
+
+def modulus_lik_message(az, bz, y):
+    r, v = modulus_lik_posterior(az, bz, y)
+    return ab_new(r, v, az, np.asarray(bz, float))
+
+
+def modulus_lik_log_partition(az, bz, y):
+    "modulus_likelihood.py:125-129 (np.absolute of the PLANAR array, elementwise, as found; mean / 2)"
+    from scipy.special import ive
+    b = np.abs(np.asarray(bz, float))
+    A = -0.5 * az * y**2 + np.log(2 * np.pi * y * ive(0, b * y)) + b * y
+    return A.mean() / 2
+
+
+class ModulusLikFactor(OracleFactor):
+    kind = "likelihood"
+
+    def __init__(self, y):
+        self.y = np.asarray(y, float)
+
+    def backward(self, az, bz, ax, bx):
+        return modulus_lik_message(az, bz, self.y)
+
+
+class ComplexLinearOracle:
+    """ComplexLinearChannel (tramp/channels/linear/complex_linear_channel.py:17-162): x = W z for complex W, messages
+    planar (2, N).  Restated on the complex SVD as the reference."""
+
+    def __init__(self, W):
+        W = np.asarray(W)
+        self.W = W
+        self.Nx, self.Nz = W.shape
+        self.rank = np.linalg.matrix_rank(W)
+        self.alpha = self.Nx / self.Nz
+        U, s, VH = np.linalg.svd(W, full_matrices=True)
+        self.U, self.V = U, VH.conj().T
+        self.S = np.zeros((self.Nx, self.Nz))
+        self.S[:len(s), :len(s)] = np.diag(s)
+        self.spectrum = np.diag(self.S.conj().T @ self.S)
+        self.singular = self.spectrum[:self.rank]
+
+    @staticmethod
+    def _c(Z):
+        Z = np.asarray(Z, float)
+        return Z[0] + 1j * Z[1]
+
+    @staticmethod
+    def _p(z):
+        return np.stack([z.real, z.imag])
+
+    def n_eff(self, az, ax):
+        if ax == 0:
+            return 0.
+        if az / ax == 0:
+            return self.rank / self.Nz
+        return np.sum(self.singular / (az / ax + self.singular)) / self.Nz
+
+    def backward_mean(self, az, bz, ax, bx):
+        bz, bx = self._c(bz), self._c(bx)
+        resolvent = 1 / (az + ax * self.spectrum)
+        rz = self.V @ (resolvent * (self.V.conj().T @ bz + self.S.conj().T @ (self.U.conj().T @ bx)))
+        return self._p(rz)
+
+    def forward_mean(self, az, bz, ax, bx):
+        return self._p(self.W @ self._c(self.backward_mean(az, bz, ax, bx)))
+
+    def backward_variance(self, az, ax):
+        return (1 - self.n_eff(az, ax)) / az
+
+    def forward_variance(self, az, ax):
+        if ax == 0:
+            return np.mean(self.singular) * self.rank / (self.Nx * az)
+        return self.n_eff(az, ax) / (self.alpha * ax)
+
+    def backward_message(self, az, bz, ax, bx):
+        return ab_new(self.backward_mean(az, bz, ax, bx), self.backward_variance(az, ax), az, np.asarray(bz, float))
+
+    def forward_message(self, az, bz, ax, bx):
+        return ab_new(self.forward_mean(az, bz, ax, bx), self.forward_variance(az, ax), ax, np.asarray(bx, float))
+
+    def log_partition(self, az, bz, ax, bx):
+        "complex_linear_channel.py:143-150"
+        rz = self.backward_mean(az, bz, ax, bx)
+        b = self._p(self._c(bz) + self.W.conj().T @ self._c(bx))
+        return 0.5 * np.sum(b * rz) + np.sum(np.log(2 * np.pi / (az + ax * self.spectrum)))
+
+
+class ComplexLinearFactor(OracleFactor):
+    def __init__(self, W):
+        self.lin = ComplexLinearOracle(W)
+
+    def forward(self, az, bz, ax, bx):
+        return self.lin.forward_message(az, bz, ax, bx)
+
+    def backward(self, az, bz, ax, bx):
+        return self.lin.backward_message(az, bz, ax, bx)

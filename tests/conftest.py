@@ -120,6 +120,51 @@ def golden_se():
     return load_golden("se")
 
 
+@pytest.fixture(scope="session")
+def golden_priors2():
+    "Exponential / Positive / GaussianMixture priors from the reference (tools/make_golden_r6.py)"
+    with np.load(os.path.join(GOLDEN, "priors2.npz"), allow_pickle=True) as f:
+        return dict(cases=list(f["cases"]), se=list(f["se"]), ep=list(f["ep"]))
+
+
+@pytest.fixture(scope="session")
+def golden_complex():
+    "ModulusLikelihood, ComplexLinearChannel and phase-retrieval EP from the reference (tools/make_golden_r6.py)"
+    with np.load(os.path.join(GOLDEN, "complex.npz"), allow_pickle=True) as f:
+        return dict(modulus=list(f["modulus"]), linear=list(f["linear"]), ep=list(f["ep"]))
+
+
+def prior2_oracle(orc, name, kw):
+    "(posterior(ax, bx, isotropic=True), factor(size), log_partition(ax, bx)) of one round-6 prior from the oracle"
+    if name == "exponential":
+        m = kw.get("mean", 1)
+        return (lambda ax, bx, isotropic=True: orc.exp_prior_posterior(ax, bx, m, isotropic),
+                lambda size: orc.ExpPriorFactor(size, m), lambda ax, bx: orc.exp_prior_log_partition(ax, bx, m))
+    if name == "positive":
+        return (lambda ax, bx, isotropic=True: orc.positive_prior_posterior(ax, bx, isotropic),
+                lambda size: orc.PositivePriorFactor(size), orc.positive_prior_log_partition)
+    p, m, v = kw["probs"], kw["means"], kw["vars"]
+    return (lambda ax, bx, isotropic=True: orc.gm_prior_posterior(ax, bx, p, m, v, isotropic),
+            lambda size: orc.GMPriorFactor(size, p, m, v), lambda ax, bx: orc.gm_prior_log_partition(ax, bx, p, m, v))
+
+
+def redraw_prior2_W(c):
+    "the sensing matrix of a priors2.npz EP case, re-drawn as tools/make_golden_r6.py drew it"
+    rs = np.random.RandomState(1000 * c["seed"] + c["N"])
+    W = rs.randn(c["M"], c["N"]) / np.sqrt(c["N"])
+    assert float(W.sum()) == c["W_sum"]
+    return W
+
+
+def redraw_complex_W(c):
+    "the complex sensing matrix of a complex.npz EP case"
+    rs = np.random.RandomState(77 * c["seed"] + c["N"])
+    M, N = c["M"], c["N"]
+    W = (rs.standard_normal((M, N)) + 1j * rs.standard_normal((M, N))) / np.sqrt(2 * N)
+    assert complex(W.sum()) == c["W_sum"]
+    return W
+
+
 def _gpu_available():
     try:
         from tramp_amd import _lib

@@ -49,6 +49,21 @@ static void pwl_any(size_t n, const T* bz, const T* bx, double az, double ax, T*
         r[i] = o.r; v[i] = o.v; mask[i] = (uint8_t)o.mask;
     }
 }
+template <typename T>
+static void gm(size_t n, const T* bx, double ax, int K, const double* probs, const double* means, const double* vars, T* r, T* v) {
+    GmConst<T> g;
+    g.K = K;
+    for (int k = 0; k < K; ++k) {
+        const double a0 = 1.0 / vars[k], b0 = means[k] / vars[k];
+        const double eta = log(probs[k]) - 0.5 * (b0 * b0 / a0 + log(2 * kPi / a0));
+        const double ad = ax + a0;
+        g.inv_a[k] = T(1.0 / ad); g.c1[k] = T(0.5 / ad); g.c0[k] = T(eta + 0.5 * log(2 * kPi / ad)); g.b0[k] = T(b0);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        RV<T> o = gm_posterior<T>(bx[i], g);
+        r[i] = o.r; v[i] = o.v;
+    }
+}
 extern "C" {
 void hm_gb_f64(size_t n, const double* bx, double ax, double rho, double mean, double var, double* r, double* v, int fast) { gb<double>(n, bx, ax, rho, mean, var, r, v, fast); }
 void hm_gb_f32(size_t n, const float* bx, double ax, double rho, double mean, double var, float* r, float* v, int fast) { gb<float>(n, bx, ax, rho, mean, var, r, v, fast); }
@@ -147,6 +162,27 @@ void hm_special_f32(int which, size_t n, const float* x, float* out) {
             case 7: out[i] = tanh_tab(x[i]); break;
             default: out[i] = expit<float>(x[i]); break;
         }
+    }
+}
+
+// round 6: the rest of the separable priors and the modulus likelihood
+// half-line prior p(x) ~ 1[x >= 0] exp(-a0 x^2 / 2 + b0 x): Exponential (a0 = 0, b0 = -1/mean), Positive (a0 = 1, b0 = 0)
+void hm_halfline_prior_f64(size_t n, const double* bx, double ax, double a0, double b0, double* r, double* v) {
+    RegionConst<double> c = region_const<double>(ax + a0);
+    for (size_t i = 0; i < n; ++i) {
+        RV<double> o = sgn_lik_posterior_fast<double>(bx[i] + b0, 1.0, c);
+        r[i] = o.r; v[i] = o.v;
+    }
+}
+void hm_gm_f64(size_t n, const double* bx, double ax, int K, const double* probs, const double* means, const double* vars, double* r, double* v) { gm<double>(n, bx, ax, K, probs, means, vars, r, v); }
+void hm_gm_f32(size_t n, const float* bx, double ax, int K, const double* probs, const double* means, const double* vars, float* r, float* v) { gm<float>(n, bx, ax, K, probs, means, vars, r, v); }
+void hm_bessel_ratio(size_t n, const double* x, double* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = bessel_i1_over_i0(x[i]);
+}
+void hm_modulus(size_t n, const double* re, const double* im, const double* y, double* rre, double* rim, double* v) {
+    for (size_t i = 0; i < n; ++i) {
+        ModOut o = modulus_posterior(re[i], im[i], y[i]);
+        rre[i] = o.re; rim[i] = o.im; v[i] = o.v;
     }
 }
 }

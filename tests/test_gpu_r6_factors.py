@@ -1,0 +1,294 @@
+"""GPU parity of the factors added in round 6, through the C ABI, against the reference's goldens
+(tests/golden/priors2.npz, complex.npz: tools/make_golden_r6.py) and the oracle:
+ExponentialPrior / PositivePrior / GaussianMixturePrior (tramp/priors/{exponential,positive,gaussian_mixture}_prior.py),
+ModulusLikelihood (tramp/likelihoods/modulus_likelihood.py), ComplexLinearChannel
+(tramp/channels/linear/complex_linear_channel.py) and the phase-retrieval EP they make."""
+import numpy as np
+import pytest
+
+from oracle import tramp_oracle as orc
+from tests.conftest import prior2_oracle, redraw_prior2_W, redraw_complex_W
+from tests.test_gpu_ep import Recorder
+
+pytestmark = pytest.mark.gpu
+
+RT = {np.float64: 1e-9, np.float32: 2e-4}       # north_star: 1e-6 relative f64 / 1e-3 f32 on posterior means
+
+
+def close(a, b, rtol, scale=None):
+    b = np.asarray(b, dtype=float)
+    sc = np.nanmax(np.abs(b)) if scale is None else scale
+    np.testing.assert_allclose(np.asarray(a, dtype=float), b, rtol=rtol, atol=rtol * max(sc, 1e-300), equal_nan=True)
+
+
+def make_prior(T, ctx, name, kw, size, dtype=np.float64, isotropic=True):
+    cls = dict(exponential=T.ExponentialPrior, positive=T.PositivePrior, mixture=T.GaussianMixturePrior)[name]
+    return cls(size=size, isotropic=isotropic, dtype=dtype, ctx=ctx, **kw)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_prior2_against_reference_goldens(ctx, golden_priors2, dtype):
+    import tramp_amd as T
+    rt, n_run = RT[dtype], 0
+    for c in golden_priors2["cases"]:
+        if c.get("diag"):
+            continue
+        bx, ref = c["bx"], c
+        if dtype == np.float32:
+            # f32: without the eight edge inputs (|b| up to 300: x = |b| / sqrt(2 a) in the hundreds, where the reference's
+            # v0 (1 + g2 - g1^2) needs eps x^2 << 1) and inside f32's range; the expected values from the oracle, which the
+            # CPU suite pins on these same goldens
+            if np.abs(bx[8:]).max() / min(1.0, c["ax"]) > 1e4 or c["ax"] > 1e3:
+                continue
+            bx = bx[8:].astype(np.float32)
+            post, _, _ = prior2_oracle(orc, c["name"], c["kwargs"])
+            r_o, v_o = post(c["ax"], bx.astype(np.float64))
+            a_o, b_o = orc.ab_new(r_o, v_o, c["ax"], bx.astype(np.float64))
+            ref = dict(r=r_o, v=v_o, a_new=a_o, b_new=b_o)
+        pr = make_prior(T, ctx, c["name"], c["kwargs"], bx.size, dtype)
+        tag = (c["name"], c["kwargs"], c["ax"])
+        r, v = pr.compute_forward_posterior(c["ax"], bx)
+        close(r, ref["r"], rt)
+        # far tail (b = -300 at a = 1e-3): the reference's own variance formula cancels to eps x^2 - 3e-9 of the mean there
+        close(v, ref["v"], max(rt, 1e-8))
+        a_new, b_new = pr.compute_forward_message(c["ax"], bx)
+        close(a_new, ref["a_new"], max(rt, 1e-7), scale=ref["a_new"] + c["ax"])
+        # (f32: r (a + a_new) - b cancels, compared on the scale of its terms)
+        close(b_new, ref["b_new"], max(rt, 1e-7), scale=None if dtype == np.float64 else max(np.abs(ref["b_new"]).max(), np.abs(bx).max()))
+        if dtype == np.float64:
+            assert abs(pr.compute_log_partition(c["ax"], bx) - c["A"]) <= 1e-10 * max(1.0, abs(c["A"])), tag
+            assert pr.second_moment() == pytest.approx(c["second_moment"], rel=1e-14)
+        n_run += 1
+    assert n_run == (35 if dtype == np.float64 else 28), n_run
+
+
+def test_prior2_diagonal_beliefs(ctx, golden_priors2):
+    "isotropic=False (the mode of the reference's own prior tests, tests/test_priors.py:17-51)"
+    import tramp_amd as T
+    n_run = 0
+    for c in golden_priors2["cases"]:
+        if not c.get("diag"):
+            continue
+        pr = make_prior(T, ctx, c["name"], c["kwargs"], c["bx"].size, isotropic=False)
+        r, v = pr.compute_forward_posterior(c["ax"], c["bx"])
+        close(r, c["r"], 1e-11)
+        close(v, c["v"], 1e-9)
+        a_new, b_new = pr.compute_forward_message(c["ax"], c["bx"])
+        close(a_new, c["a_new"], 1e-8)
+        close(b_new, c["b_new"], 1e-8)
+        post, _, logz = prior2_oracle(orc, c["name"], c["kwargs"])
+        # the reference's diagonal log-partition is the mean of per-component terms: the oracle's isotropic form per component
+        A = np.mean([logz(a, np.array([b])) for a, b in zip(c["ax"][:40], c["bx"][:40])])
+        assert abs(pr.compute_log_partition(c["ax"][:40], c["bx"][:40]) - A) <= 1e-10 * max(1.0, abs(A))
+        n_run += 1
+    assert n_run == 7
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name,kw", [("exponential", dict(mean=0.7)), ("positive", {}),
+                                     ("mixture", dict(probs=[0.2, 0.5, 0.3], means=[-2.0, 0.0, 1.5], vars=[0.3, 0.01, 2.0])),
+                                     ("mixture", dict(probs=[0.125] * 8, means=list(np.linspace(-3, 3, 8)), vars=[0.2] * 8))])
+@pytest.mark.parametrize("n,batch", [(1000, 1), (4096, 3), (100003, 2), (1 << 20, 2), (300000, 5)])
+def test_prior2_every_kernel_form_against_oracle(ctx, name, kw, n, batch, dtype):
+    """ragged and vector lengths, one and several instances with their own precisions: the single-workgroup, tile, one-launch
+    and grid-stride forms of the template all see the new ops; damping fused"""
+    import tramp_amd as T
+    rs = np.random.RandomState(n % 977 + batch)
+    ax = np.exp(rs.uniform(np.log(0.3), np.log(8.0), batch))
+    bx = (ax[:, None] * rs.standard_normal((batch, n)) * 1.2 + 0.3).astype(dtype)
+    pr = make_prior(T, ctx, name, kw, n, dtype)
+    post, _, _ = prior2_oracle(orc, name, kw)
+    rt = RT[dtype]
+    a_new, b_new = pr.compute_forward_message(ax, bx)
+    r, v = pr.compute_forward_posterior(ax, bx)
+    a_old, b_old = np.full(batch, 0.4), 0.1 * rs.standard_normal((batch, n)).astype(dtype)
+    a_d, b_d = pr.compute_forward_message(ctx.array(ax), ctx.array(bx, dtype), damping=0.3, old_a=ctx.array(a_old),
+                                          old_b=ctx.array(b_old, dtype))
+    for b in range(batch):
+        ro, vo = post(ax[b], bx[b].astype(np.float64))
+        close(r[b], ro, rt)
+        close(v[b], vo, max(rt, 1e-9))
+        an, bn = orc.ab_new(ro, vo, ax[b], bx[b].astype(np.float64))
+        close(a_new[b], an, max(rt, 1e-7), scale=an + ax[b])
+        close(b_new[b], bn, max(rt, 1e-7))
+        close(a_d.get()[b], 0.3 * a_old[b] + 0.7 * an, max(rt, 1e-7), scale=an + ax[b])
+        close(b_d.get()[b], 0.3 * b_old[b].astype(np.float64) + 0.7 * bn, max(rt, 1e-7))
+
+
+def test_mixture_se_error(ctx, golden_priors2):
+    import tramp_amd as T
+    for c in golden_priors2["se"]:
+        pr = T.GaussianMixturePrior(size=None, ctx=ctx, **c["kwargs"])
+        assert pr.compute_forward_error(c["ax"]) == pytest.approx(c["v"], rel=1e-7)
+        assert pr.compute_forward_state_evolution(c["ax"]) == pytest.approx(c["a_new"], rel=1e-6)
+    pr = T.GaussianMixturePrior(size=None, ctx=ctx, **golden_priors2["se"][0]["kwargs"])
+    axs = np.array([c["ax"] for c in golden_priors2["se"][:5]])
+    close(pr.compute_forward_error(axs), [c["v"] for c in golden_priors2["se"][:5]], 1e-7)
+
+
+def test_error_conventions_of_the_new_priors(ctx):
+    import tramp_amd as T
+    with pytest.raises(AssertionError):
+        T.ExponentialPrior(size=4, mean=-1.0, ctx=ctx)                   # exponential_prior.py:21
+    with pytest.raises(NotImplementedError):
+        T.ExponentialPrior(size=4, ctx=ctx).compute_forward_error(1.0)    # :73-74
+    with pytest.raises(NotImplementedError):
+        T.PositivePrior(size=4, ctx=ctx).compute_forward_error(1.0)
+    with pytest.raises(NotImplementedError):
+        T.GaussianMixturePrior(size=4, probs=[0.1] * 10, means=[0] * 10, vars=[1] * 10, ctx=ctx)
+    with pytest.raises(T._lib.TrampHipError):
+        T.GaussianMixturePrior(size=4, probs=[0.5, 0.5], means=[0, 1], vars=[1, -1.0], ctx=ctx).compute_forward_message(
+            1.0, np.zeros(4))
+    assert isinstance(T.get_prior(5, "positive", ctx=ctx), T.ExponentialPrior)      # the reference's registry, as found
+    assert isinstance(T.get_prior(5, "mixture", ctx=ctx), T.GaussianMixturePrior)
+    # NaN in, NaN out (and a_new NaN, which the EP monitor turns into the reference's ValueError)
+    a, b = T.PositivePrior(size=8, ctx=ctx).compute_forward_message(1.0, np.array([0, 1, np.nan, 2, 3, 4, 5, 6.0]))
+    assert np.isnan(a) and np.isnan(b[2])
+
+
+def run_traj(T, ctx, model, c, ids, init, max_iter):
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    rec = Recorder(T.EarlyStoppingEP())
+    ep.iterate(max_iter=max_iter, callback=rec, damping=c["damping"], initializer=init)
+    assert ep.n_iter == c["n_iter"], (c.get("name"), c["N"], c["damping"])
+    t = c["traj"]
+    n = min(t[f"v:{ids[0]}"].shape[0], len(rec.iters))
+    for it in range(n):
+        rt = 1e-7 if it < 6 else 1e-5
+        for vid in ids:
+            e = rec.iters[it]["edges"]
+            a_tot = t[f"fwd:{vid}:a"][it] + t[f"bwd:{vid}:a"][it]
+            close(e[(vid, "fwd")][0], t[f"fwd:{vid}:a"][it], rt, scale=a_tot)
+            close(e[(vid, "bwd")][0], t[f"bwd:{vid}:a"][it], rt, scale=a_tot)
+            for d in ("fwd", "bwd"):
+                ref = t[f"{d}:{vid}:b"][it]
+                # (a message whose precision is the floor 1e-11 is round-off of O(1) terms: an absolute floor on the scale)
+                close(np.asarray(rec.iters[it]["b"][(vid, d)]).reshape(ref.shape), ref, rt, scale=max(np.abs(ref).max(), 1e-7))
+            ref = t[f"r:{vid}"][it]
+            close(np.asarray(rec.iters[it]["vars"][vid]["r"]).reshape(ref.shape), ref, rt, scale=max(np.abs(ref).max(), 1e-7))
+            close(rec.iters[it]["vars"][vid]["v"], t[f"v:{vid}"][it], rt)
+    return ep
+
+
+def test_prior2_ep_trajectories(ctx, golden_priors2):
+    "every message of the reference's iterate() behind a dense LinearChannel, with and without damping"
+    import tramp_amd as T
+    assert len(golden_priors2["ep"]) == 14
+    for c in golden_priors2["ep"]:
+        W = redraw_prior2_W(c)
+        model = (make_prior(T, ctx, c["name"], c["kwargs"], c["N"]) @ T.SISOVariable(id="x")
+                 @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+                 @ T.GaussianLikelihood(y=c["y"], var=c["noise_var"], ctx=ctx)).to_model()
+        run_traj(T, ctx, model, c, ["x", "z"], T.CustomInit(a=c["a_init"], b=0), 30)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_modulus_likelihood_against_reference_goldens(ctx, golden_complex, dtype):
+    import tramp_amd as T
+    rt = RT[dtype]
+    for c in golden_complex["modulus"]:
+        if dtype == np.float32 and np.abs(c["bz"]).max() > 1e4:
+            continue
+        lk = T.ModulusLikelihood(y=c["y"], dtype=dtype, ctx=ctx)
+        r, v = lk.compute_backward_posterior(c["az"], c["bz"], c["y"])
+        assert r.shape == (2, c["y"].size)
+        close(r, c["r"], rt)
+        close(v, c["v"], rt)
+        a_new, b_new = lk.compute_backward_message(c["az"], c["bz"])
+        close(a_new, c["a_new"], max(rt, 1e-8), scale=c["a_new"] + c["az"])
+        close(b_new, c["b_new"], max(rt, 1e-8))
+        if dtype == np.float64:
+            # the reference's own value is NaN on these inputs: scipy's ive(0, x) gives up beyond x ~ 1e9 (component 2:
+            # |b| y = 1.5e9) and y = 0 (component 1) is log(0); without the two the oracle (pinned on the goldens, NaN
+            # and all) is the check - and the device value WITH them is the finite / -inf one
+            keep = np.r_[0, 3:c["y"].size]
+            A = T.ModulusLikelihood(y=c["y"][keep], ctx=ctx).compute_log_partition(c["az"], c["bz"][:, keep])
+            assert A == pytest.approx(orc.modulus_lik_log_partition(c["az"], c["bz"][:, keep], c["y"][keep]), rel=1e-11)
+            assert np.isneginf(lk.compute_log_partition(c["az"], c["bz"])) and np.isnan(c["A"])
+    # an ensemble: instance b == the single call on (az_b, bz_b, y_b); damping fused
+    rs = np.random.RandomState(5)
+    B, n = 3, 5000
+    y = np.abs(rs.standard_normal((B, n)) + 1j * rs.standard_normal((B, n)))
+    bz = 2.0 * rs.standard_normal((B, 2, n))
+    az = np.array([0.7, 1.9, 6.0])
+    lk = T.ModulusLikelihood(y=y, dtype=dtype, ctx=ctx)
+    a_new, b_new = lk.compute_backward_message(az, bz)
+    assert b_new.shape == (B, 2, n)
+    for b in range(B):
+        an, bn = orc.modulus_lik_message(az[b], bz[b].astype(dtype).astype(np.float64), y[b].astype(dtype).astype(np.float64))
+        close(a_new[b], an, max(rt, 1e-8), scale=an + az[b])
+        close(b_new[b], bn, max(rt, 1e-8))
+    with pytest.raises(NotImplementedError):
+        lk.compute_backward_error(1.3, 1.0)
+
+
+def test_complex_linear_channel_against_reference_goldens(ctx, golden_complex):
+    import tramp_amd as T
+    for c in golden_complex["linear"]:
+        ch = T.ComplexLinearChannel(c["W"], ctx=ctx, svd="host")
+        assert (ch.Nx, ch.Nz, ch.rank) == (c["M"], c["N"], c["rank"])
+        assert ch.compute_n_eff(c["az"], c["ax"]) == pytest.approx(c["n_eff"], rel=1e-10)
+        rz, vz = ch.compute_backward_posterior(c["az"], c["bz"], c["ax"], c["bx"])
+        rx, vx = ch.compute_forward_posterior(c["az"], c["bz"], c["ax"], c["bx"])
+        assert rz.shape == (2, c["N"]) and rx.shape == (2, c["M"])
+        close(rz, c["rz"], 1e-9)
+        close(rx, c["rx"], 1e-9)
+        assert vz == pytest.approx(c["vz"], rel=1e-10) and vx == pytest.approx(c["vx"], rel=1e-10)
+        # b_new = r (a + a_new) - b cancels down to a_new / a of its terms (ax = 0: a_new is the floor 1e-11 and the
+        # reference's own b_new is round-off of bz): compared on the scale of the terms
+        a, b = ch.compute_backward_message(c["az"], c["bz"], c["ax"], c["bx"])
+        close(a, c["a_bwd"], 1e-8, scale=c["a_bwd"] + c["az"])
+        close(b, c["b_bwd"], 1e-8, scale=max(np.abs(c["b_bwd"]).max(), np.abs(c["bz"]).max() * 1e-4))
+        a, b = ch.compute_forward_message(c["az"], c["bz"], c["ax"], c["bx"])
+        close(a, c["a_fwd"], 1e-8, scale=c["a_fwd"] + c["ax"])
+        close(b, c["b_fwd"], 1e-8, scale=max(np.abs(c["b_fwd"]).max(), np.abs(c["bx"]).max() * 1e-4))
+        assert ch.compute_log_partition(c["az"], c["bz"], c["ax"], c["bx"]) == pytest.approx(c["A"], rel=1e-9)
+        sp = np.sort(np.linalg.svd(c["W"], compute_uv=False)**2)[::-1]
+        close(ch.spectrum[:sp.size], sp, 1e-10)
+
+
+def test_phase_retrieval_ep_trajectories(ctx, golden_complex):
+    """GaussBernoulliPrior(size=(2, N)) -> ComplexLinearChannel -> ModulusLikelihood: every message of the reference's
+    iterate() from a symmetry-breaking initial message (CustomInit), with and without damping"""
+    import tramp_amd as T
+    for c in golden_complex["ep"]:
+        W = redraw_complex_W(c)
+        N = c["N"]
+        model = (T.GaussBernoulliPrior(size=(2, N), rho=c["rho"], ctx=ctx) @ T.SISOVariable(id="x")
+                 @ T.ComplexLinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+                 @ T.ModulusLikelihood(y=c["y"], ctx=ctx)).to_model()
+        init = T.CustomInit(a_init=[("x", "bwd", c["a0"])], b_init=[("x", "bwd", c["b0"])], a=0, b=0)
+        ep = run_traj(T, ctx, model, c, ["x", "z"], init, 25)
+        assert ep.shapes == {"x": (2, N), "z": (2, c["M"])}
+
+
+def test_phase_retrieval_model_api(ctx):
+    """glm_generative(output_type='modulus') -> sample -> to_observed -> EP, as the reference's phase-retrieval examples
+    (examples/glm/plot_complex_pr.py): the signal is recovered up to its global phase, in as many iterations as the oracle
+    takes from the same symmetry-breaking initial message"""
+    import tramp_amd as T
+    np.random.seed(1)
+    N = 64
+    model = T.glm_generative(N=N, alpha=3.0, ensemble_type="complex_gaussian", prior_type="gauss_bernoulli",
+                             output_type="modulus", prior_rho=0.5, ctx=ctx)
+    sample = model.sample(seed=4)
+    assert sample["x"].shape == (2, N) and sample["z"].shape == (2, 192) and sample["y"].shape == (192,)
+    student = model.to_observed({"y": sample["y"]})
+    assert [type(f).__name__ for f in student.factors] == ["GaussBernoulliPrior", "ComplexLinearChannel", "ModulusLikelihood"]
+    b0 = np.random.RandomState(2).standard_normal((2, N))
+    ep = T.ExpectationPropagation(student, ctx=ctx)
+    # EarlyStoppingEP's give-up rule (an increase after iteration 5) fires on the non-monotone start of phase retrieval
+    ep.iterate(max_iter=300, damping=0.3, callback=T.EarlyStoppingEP(max_increase=np.inf),
+               initializer=T.CustomInit(a_init=[("x", "bwd", 0.1)], b_init=[("x", "bwd", b0)]))
+    W = student.factors[1].W
+    fs = [orc.GBPriorFactor((2, N), rho=0.5), orc.ComplexLinearFactor(W), orc.ModulusLikFactor(sample["y"])]
+    with np.errstate(all="ignore"):
+        res = orc.ep_chain(fs, [(2, N), (2, 192)], max_iter=300, damping=0.3, max_increase=np.inf,
+                           init=lambda i, d: (0.1, b0) if (i, d) == (0, "bwd") else (0, 0.0))
+    assert res["status"] == "converged" and abs(ep.n_iter - res["n_iter"]) <= 1
+    r = ep.get_variables_data()["x"]["r"].reshape(2, N)
+    close(r, res["r"][0], 1e-5)
+    xh, x0 = r[0] + 1j * r[1], sample["x"][0] + 1j * sample["x"][1]
+    ph = np.vdot(xh, x0)
+    ph /= abs(ph)
+    assert np.mean(np.abs(xh * ph - x0)**2) < 1e-6 * np.mean(np.abs(x0)**2)

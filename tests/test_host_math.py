@@ -312,3 +312,53 @@ def test_special_functions_of_the_streaming_kernels(hm):
     xe32 = rng.uniform(-85, 88, 5000).astype(np.float32)           # normal f32 results
     got, exp = _special(hm, 3, xe32, f32=True), np.exp(xe32.astype(np.float64))
     assert np.max(np.abs(got - exp) / exp) < 1e-6
+
+
+# ---------------------------------------------------------------- round 6: remaining priors, modulus likelihood
+def test_halfline_and_mixture_priors(hm, golden_priors2):
+    n_run = 0
+    for c in golden_priors2["cases"]:
+        if c.get("diag"):
+            continue
+        bx, ax, kw = np.ascontiguousarray(c["bx"]), float(c["ax"]), c["kwargs"]
+        r, v = np.empty_like(bx), np.empty_like(bx)
+        if c["name"] in ("exponential", "positive"):
+            a0, b0 = (0.0, -1.0 / kw.get("mean", 1)) if c["name"] == "exponential" else (1.0, 0.0)
+            hm.hm_halfline_prior_f64(C.c_size_t(bx.size), ptr(bx), C.c_double(ax), C.c_double(a0), C.c_double(b0), ptr(r), ptr(v))
+        else:
+            K = len(kw["probs"])
+            pr, me, va = (np.asarray(kw[k], dtype=np.float64) for k in ("probs", "means", "vars"))
+            hm.hm_gm_f64(C.c_size_t(bx.size), ptr(bx), C.c_double(ax), C.c_int(K), ptr(pr), ptr(me), ptr(va), ptr(r), ptr(v))
+            b32 = bx.astype(np.float32)
+            if np.abs(bx).max() * max(1.0, 1 / ax) < 1e3:          # f32 form inside its range
+                r32, v32 = np.empty_like(b32), np.empty_like(b32)
+                hm.hm_gm_f32(C.c_size_t(bx.size), ptr(b32), C.c_double(ax), C.c_int(K), ptr(pr), ptr(me), ptr(va), ptr(r32), ptr(v32))
+                close(r32, c["r"], 3e-4)
+                close(v32.mean(dtype=np.float64), c["v"], 1e-3)
+        close(r, c["r"], 1e-11)
+        # the reference's v0 (1 + g2 - g1^2) cancels to eps x^2 in the far tail (b = -300 at a = 1e-3: x = 6.7e3, where it
+        # returns 0.0 for a variance of 1e-5): its own round-off is 3e-9 of the mean there
+        close(v.mean(), c["v"], 1e-8)
+        n_run += 1
+    assert n_run == 35
+
+
+def test_bessel_ratio_and_modulus_posterior(hm, golden_complex):
+    import mpmath as mp
+    mp.mp.dps = 40
+    x = np.concatenate([[0.0, 1e-300, 1e-8, 1e-3], np.linspace(0.01, 60.0, 400), [24.999, 25.0, 25.001, 1e3, 1e6, 9.9e8]])
+    out = np.empty_like(x)
+    hm.hm_bessel_ratio(C.c_size_t(x.size), ptr(x), ptr(out))
+    ref = np.array([float(mp.besseli(1, mp.mpf(t)) / mp.besseli(0, mp.mpf(t))) for t in x])
+    np.testing.assert_allclose(out, ref, rtol=4e-15, atol=1e-305)
+    np.testing.assert_allclose(out, orc.ive_ratio(x), rtol=2e-14, atol=1e-305)
+    edge = np.array([1e9, 2e9, np.inf, np.nan, -3.0])
+    got = np.empty_like(edge)
+    hm.hm_bessel_ratio(C.c_size_t(edge.size), ptr(edge), ptr(got))
+    assert list(got[:4]) == [1.0, 1.0, 1.0, 1.0] and abs(got[4] + float(mp.besseli(1, 3) / mp.besseli(0, 3))) < 1e-15
+    for c in golden_complex["modulus"]:
+        re, im, y = (np.ascontiguousarray(a) for a in (c["bz"][0], c["bz"][1], c["y"]))
+        rre, rim, v = np.empty_like(re), np.empty_like(re), np.empty_like(re)
+        hm.hm_modulus(C.c_size_t(re.size), ptr(re), ptr(im), ptr(y), ptr(rre), ptr(rim), ptr(v))
+        close(np.stack([rre, rim]), c["r"], 1e-13)
+        close(v.mean(), c["v"], 1e-12)

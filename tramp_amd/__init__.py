@@ -10,12 +10,13 @@ There is no CPU fallback: without the built HIP library the compute methods rais
 """
 from . import _lib
 from .device import Context, DeviceArray, default_context
-from .priors import GaussBernoulliPrior, MAP_L1NormPrior, MAP_L21NormPrior, BinaryPrior, GaussianPrior, get_prior
+from .priors import (GaussBernoulliPrior, MAP_L1NormPrior, MAP_L21NormPrior, BinaryPrior, GaussianPrior, ExponentialPrior,
+                     PositivePrior, GaussianMixturePrior, get_prior)
 from . import switches
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, AsymmetricAbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
-                          SymmetricDoorLikelihood, get_likelihood)
-from .channels import (LinearChannel, SolveLinearChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
+                          SymmetricDoorLikelihood, ModulusLikelihood, get_likelihood)
+from .channels import (LinearChannel, SolveLinearChannel, ComplexLinearChannel, ModulusChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
                        SymmetricDoorChannel, ConvChannel, Blur1DChannel, Blur2DChannel,
                        DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel, ReshapeChannel, BiasChannel, SumChannel,

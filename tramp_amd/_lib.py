@@ -16,7 +16,7 @@ FWD, BWD = 0, 1
 GEMV_MAX_BATCH = 8
 REUSE_T, REUSE_U = 1, 2
 (DIAG_GB, DIAG_L1, DIAG_SGN_LIK, DIAG_ABS_LIK, DIAG_GAUSS_PRIOR, DIAG_GAUSS_LIK, DIAG_BINARY, DIAG_RELU_LIK,
- DIAG_PWL3_LIK) = range(9)
+ DIAG_PWL3_LIK, DIAG_HALFLINE, DIAG_GM) = range(11)
 (LOGZ_GB_PRIOR, LOGZ_GAUSS_PRIOR, LOGZ_L1_PRIOR, LOGZ_GAUSS_LIK, LOGZ_SGN_LIK, LOGZ_ABS_LIK, LOGZ_PWL_SGN,
  LOGZ_PWL_ABS, LOGZ_PWL_RELU, LOGZ_VARIABLE) = range(10)
 
@@ -138,6 +138,12 @@ _SIGNATURES = {
     "tramp_damp": [vp, i32, sz, sz, dbl, vp, vp, vp, vp],
     "tramp_damp_to": [vp, i32, sz, sz, dbl, vp, vp, vp, vp, vp, vp],
     "tramp_binary_prior_fwd": [vp, i32, sz, sz, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_halfline_prior_fwd": [vp, i32, sz, sz, vp, vp, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_gm_prior_fwd": [vp, i32, sz, sz, vp, vp, i32, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_modulus_lik_bwd": [vp, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp],
+    "tramp_se_gm_prior": [vp, sz, vp, i32, vp, vp, vp, vp],
+    "tramp_prior2_log_partition": [vp, i32, i32, sz, sz, vp, i32, vp, vp, vp],
+    "tramp_modulus_log_partition": [vp, i32, sz, sz, vp, vp, vp, vp],
     "tramp_l21_prior_fwd": [vp, i32, i32, sz, sz, dbl, vp, vp, dbl, vp, vp, vp, vp, vp, vp, vp, vp],
     "tramp_gauss_channel": [vp, i32, sz, sz, dbl, vp, vp, dbl, vp, vp, vp, vp],
     "tramp_bias_channel": [vp, i32, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp],

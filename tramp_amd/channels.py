@@ -760,6 +760,117 @@ class LinearChannel(Channel):
         return ret_scal(a_new, a, t), ret_vec(b_new, t)
 
 
+class ComplexLinearChannel(Channel):
+    """Complex linear channel x = W z, W complex [Nx, Nz]; messages are planar real arrays (2, N).
+
+    tramp/channels/linear/complex_linear_channel.py:17-162.  On the device the channel IS the dense LinearChannel of the
+    real embedding [[Re W, -Im W], [Im W, Re W]] acting on [Re z; Im z] (the planar layout flattened): every singular
+    value of W appears twice, so n_eff, both variances, alpha and the log-partition are those of the complex channel
+    (pinned on the reference's outputs in tests/golden/complex.npz) - the same MFMA / GEMV kernels, the same
+    factorisation.  Host messages (2, n) or (batch, 2, n); device messages [batch, 2 n].
+    """
+
+    def __init__(self, W, precompute_svd=True, name="W", dtype=np.float64, ctx=None, svd="auto", keep_W=False):
+        if not precompute_svd:
+            raise NotImplementedError("ComplexLinearChannel(precompute_svd=False) is outside the HIP path")
+        W = np.asarray(W)
+        self.name = name
+        self.Nx, self.Nz = (int(s) for s in W.shape)
+        self.precompute_svd = precompute_svd
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.alpha = self.Nx / self.Nz
+        Wr = np.block([[W.real, -W.imag], [W.imag, W.real]])
+        self._real = LinearChannel(Wr, name=name, dtype=dtype, ctx=self.ctx, svd=svd, digits=0)
+        self.rank = self._real.rank // 2
+        sv = np.sqrt(self._real.spectrum)                     # every singular value of W twice, descending
+        self.spectrum = (sv[0::2] ** 2)[:self.Nz]              # complex_linear_channel.py:50-56
+        self.singular = self.spectrum[:self.rank]
+        self.W = W if keep_W else None
+
+    # the scheduler talks to the embedded channel's device state
+    @property
+    def _ctx(self):
+        return self.__dict__.get("_ctx_")
+
+    @_ctx.setter
+    def _ctx(self, c):
+        self.__dict__["_ctx_"] = c
+        if "_real" in self.__dict__ and c is not None:
+            self._real._ctx = c
+
+    def affine_update(self, *a, **k):
+        return self._real.affine_update(*a, **k)
+
+    def sample(self, Z):
+        if self.W is None:
+            raise RuntimeError("ComplexLinearChannel was built with keep_W=False")
+        Z = np.asarray(Z)
+        X = self.W.dot(Z[0] + 1j * Z[1])
+        return np.stack([X.real, X.imag])
+
+    def second_moment(self, tau_z):
+        return tau_z * self.spectrum.sum() / self.Nx            # :72-73
+
+    def compute_n_eff(self, az, ax):
+        return self._real.compute_n_eff(az, ax)
+
+    def compute_backward_variance(self, az, ax):
+        assert az > 0                                            # :109
+        return self._real.compute_backward_variance(az, ax)
+
+    def compute_forward_variance(self, az, ax):
+        return self._real.compute_forward_variance(az, ax)
+
+    def compute_backward_error(self, az, ax, tau_z):
+        return self.compute_backward_variance(az, ax)
+
+    def compute_forward_error(self, az, ax, tau_z):
+        return self.compute_forward_variance(az, ax)
+
+    @staticmethod
+    def _flat(b):
+        "planar host array (2, n) / (batch, 2, n) -> (2 n,) / (batch, 2 n); device arrays pass through"
+        if isinstance(b, DeviceArray):
+            return b, None
+        h = np.asarray(b)
+        if h.ndim not in (2, 3) or h.shape[-2] != 2:
+            raise ValueError(f"expected a planar complex message (2, n) or (batch, 2, n), got {h.shape}")
+        return h.reshape(h.shape[:-2] + (2 * h.shape[-1],)), h.shape[:-2]
+
+    def _call(self, method, az, bz, ax, bx, **kw):
+        fz, lead = self._flat(bz)
+        fx, _ = self._flat(bx)
+        s, vec = getattr(self._real, method)(az, fz, ax, fx, **kw)
+        if method.endswith("posterior"):
+            vec, s = s, vec
+        if lead is not None and not isinstance(vec, DeviceArray):
+            vec = vec.reshape(lead + (2, vec.shape[-1] // 2))
+        return (vec, s) if method.endswith("posterior") else (s, vec)
+
+    def compute_backward_posterior(self, az, bz, ax, bx):
+        return self._call("compute_backward_posterior", az, bz, ax, bx)
+
+    def compute_forward_posterior(self, az, bz, ax, bx):
+        return self._call("compute_forward_posterior", az, bz, ax, bx)
+
+    def compute_backward_mean(self, az, bz, ax, bx):
+        return self.compute_backward_posterior(az, bz, ax, bx)[0]
+
+    def compute_forward_mean(self, az, bz, ax, bx):
+        return self.compute_forward_posterior(az, bz, ax, bx)[0]
+
+    def compute_backward_message(self, az, bz, ax, bx, **kw):
+        return self._call("compute_backward_message", az, bz, ax, bx, **kw)
+
+    def compute_forward_message(self, az, bz, ax, bx, **kw):
+        return self._call("compute_forward_message", az, bz, ax, bx, **kw)
+
+    def compute_log_partition(self, az, bz, ax, bx):
+        "complex_linear_channel.py:143-150 = the real embedding's 0.5 sum(b rz) + 0.5 sum log(2 pi / a) over 2 Nz entries"
+        return self._real.compute_log_partition(az, self._flat(bz)[0], ax, self._flat(bx)[0])
+
+
 class SolveLinearChannel(LinearChannel):
     """LinearChannel(W, precompute_svd=False): the reference's branch that keeps C = W^T W and solves
     (az I + ax C) rz = bz + W^T bx on every call (tramp/channels/linear/linear_channel.py:43-46, 79-82) - on the
@@ -1608,9 +1719,35 @@ class MarchenkoPasturChannel(AnalyticalLinearChannel):
         super().__init__(ensemble=MarchenkoPasturEnsemble(alpha=alpha), name=name)
 
 
+class ModulusChannel(Channel):
+    """Modulus channel x = |z| (tramp/channels/activation/modulus_channel.py:9-43): a GENERATIVE factor only, as in the
+    reference (its posteriors raise NotImplementedError there too); ``Model.to_observed`` turns it into ModulusLikelihood
+    (models/dag_algebra.py:38-39)."""
+
+    def __init__(self, dtype=np.float64, ctx=None):
+        self.repr_init()
+        self._init_device(dtype, ctx)
+
+    def sample(self, Z):
+        "We assume Z[0] = Z.real and Z[1] = Z.imag"
+        Z = np.asarray(Z)
+        return np.absolute(Z[0] + 1j * Z[1])
+
+    def second_moment(self, tau_z):
+        return 2 * tau_z
+
+    def compute_forward_posterior(self, az, bz, ax, bx):
+        raise NotImplementedError
+
+    def compute_backward_posterior(self, az, bz, ax, bx):
+        raise NotImplementedError
+
+
 CHANNEL_CLASSES = {
     "gaussian": GaussianChannel,
     "linear": LinearChannel,
+    "complex_linear": ComplexLinearChannel,
+    "modulus": ModulusChannel,
     "analytical": AnalyticalLinearChannel,
     "marchenko": MarchenkoPasturChannel,
     "sgn": SgnChannel,

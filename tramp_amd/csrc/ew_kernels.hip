@@ -1145,6 +1145,54 @@ extern "C" int tramp_binary_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_
                    (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
 }
 
+// natural parameters of a Gaussian mixture (gaussian_mixture_prior.py:36-39)
+template <typename Op> static bool gm_fill(Op& op, int K, const double* probs, const double* means, const double* vars) {
+    op.K = K;
+    double ps = 0.0;
+    for (int k = 0; k < K; ++k) {
+        if (!(probs[k] > 0.0) || !(vars[k] > 0.0)) return false;
+        op.a0[k] = 1.0 / vars[k];
+        op.b0[k] = means[k] / vars[k];
+        op.eta[k] = log(probs[k]) - 0.5 * (op.b0[k] * op.b0[k] / op.a0[k] + log(2 * tmath::kPi / op.a0[k]));
+        ps += probs[k];
+    }
+    return ps > 0.0;
+}
+
+extern "C" int tramp_halfline_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const double* ax_d,
+                                        const void* bx_d, double a0, double b0, double damping, const double* a_old_d,
+                                        const void* b_old_d, double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax_d && a0 >= 0.0);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    HalfLinePriorOp<float> of{ax_d, a0, b0};
+    HalfLinePriorOp<double> od{ax_d, a0, b0};
+    DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
+                   (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
+}
+
+extern "C" int tramp_gm_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const double* ax_d,
+                                  const void* bx_d, int K, const double* probs_h, const double* means_h,
+                                  const double* vars_h, double damping, const double* a_old_d, const void* b_old_d,
+                                  double* a_new_d, void* b_new_d, void* r_d, double* v_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax_d && probs_h && means_h && vars_h && K >= 1 && K <= tmath::kGmMax);
+    MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
+    if (dtype == TRAMP_F32) {
+        GmOp<float> op{};
+        op.ax = ax_d;
+        TRAMP_REQUIRE(ctx, gm_fill(op, K, probs_h, means_h, vars_h));
+        return run_two_pass<float>(ctx, op, n, batch, bx_d, nullptr, ax_d, out);
+    }
+    if (dtype == TRAMP_F64) {
+        GmOp<double> op{};
+        op.ax = ax_d;
+        TRAMP_REQUIRE(ctx, gm_fill(op, K, probs_h, means_h, vars_h));
+        return run_two_pass<double>(ctx, op, n, batch, bx_d, nullptr, ax_d, out);
+    }
+    return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+}
+
 extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,
                                  const double* az_d, const void* bz_d, const void* y_d,
                                  double damping, const double* a_old_d, const void* b_old_d,
@@ -1500,7 +1548,7 @@ extern "C" int tramp_gauss_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t b
 // isotropic=False: the precision a is an array like b, the posterior variance stays per component and
 // compute_ab_new clips element-wise (tramp/base.py:250-255) - one independent component per thread, no reduction.
 // The mode every factor-level test of the reference runs in (tests/test_priors.py:17-51, test_likelihoods.py:22-83).
-struct DiagParams { double p[8]; };
+struct DiagParams { double p[32]; };
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, const T* __restrict__ a,
@@ -1521,6 +1569,18 @@ __global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, c
         a0 = 1.0 / p0;
     }
     tmath::Pwl3Spec spec{p0, p1, {P.p[2], P.p[3], P.p[4]}, {P.p[5], P.p[6], P.p[7]}};
+    // TRAMP_DIAG_GM: p = {K, probs[K], means[K], vars[K]} (gaussian_mixture_prior.py:36-39)
+    const int gK = which == TRAMP_DIAG_GM ? (int)p0 : 0;
+    double ga0[tmath::kGmMax], gb0[tmath::kGmMax], geta[tmath::kGmMax];
+#pragma unroll
+    for (int k = 0; k < tmath::kGmMax; ++k) {
+        ga0[k] = gb0[k] = geta[k] = 0.0;
+        if (k < gK) {
+            ga0[k] = 1.0 / P.p[1 + 2 * gK + k];
+            gb0[k] = P.p[1 + gK + k] / P.p[1 + 2 * gK + k];
+            geta[k] = log(P.p[1 + k]) - 0.5 * (gb0[k] * gb0[k] / ga0[k] + log(2 * tmath::kPi / ga0[k]));
+        }
+    }
     tmath::erfcx_setup<T>();                               // the half-line moments read erfcx from the LDS table
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) {
         T ai = a[i], bi = b[i];
@@ -1561,6 +1621,27 @@ __global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, c
             case TRAMP_DIAG_RELU_LIK:                      // p0 = slope of the negative side (0: Relu)
                 o = tmath::relu_lik_posterior<T>(bi, in2[i], T(p0), tmath::region_const<T>((double)ai));
                 break;
+            case TRAMP_DIAG_HALFLINE: {                    // p0 = a0, p1 = b0 (exponential_prior.py:54-60, positive_prior.py:56-63)
+                const T at = ai + T(p0);
+                o = tmath::sgn_lik_posterior<T>(bi + T(p1), T(1), at, T(1) / at);
+                break;
+            }
+            case TRAMP_DIAG_GM: {                          // gaussian_mixture_prior.py:88-97 with a per-component precision
+                tmath::GmConst<T> g;
+                g.K = gK;
+#pragma unroll
+                for (int k = 0; k < tmath::kGmMax; ++k) {
+                    if (k < gK) {
+                        const double ad = (double)ai + ga0[k], inv = 1.0 / ad;
+                        g.inv_a[k] = T(inv);
+                        g.c1[k] = T(0.5 * inv);
+                        g.c0[k] = T(geta[k] + 0.5 * log(2 * tmath::kPi / ad));
+                        g.b0[k] = T(gb0[k]);
+                    }
+                }
+                o = tmath::gm_posterior<T>(bi, g);
+                break;
+            }
             default: {                                     // TRAMP_DIAG_PWL3_LIK
                 tmath::PwlOut<T> w = tmath::pwl3_lik_posterior<T>(bi, in2[i], ai, spec);
                 o.r = w.r;
@@ -1581,15 +1662,21 @@ extern "C" int tramp_diag_factor_p(tramp_ctx* ctx, int dtype, int which, size_t 
                                    const void* b_d, const void* in2_d, const double* params, int nparams,
                                    void* a_new_d, void* b_new_d, void* r_d, void* v_d) {
     if (!ctx) return TRAMP_EINVAL;
-    TRAMP_REQUIRE(ctx, which >= 0 && which <= TRAMP_DIAG_PWL3_LIK && a_d && b_d && nparams >= 0 && nparams <= 8);
+    TRAMP_REQUIRE(ctx, which >= 0 && which <= TRAMP_DIAG_GM && a_d && b_d && nparams >= 0 && nparams <= 32);
     TRAMP_REQUIRE(ctx, nparams == 0 || params);
     const bool needs_y = which == TRAMP_DIAG_SGN_LIK || which == TRAMP_DIAG_ABS_LIK || which == TRAMP_DIAG_GAUSS_LIK ||
                          which == TRAMP_DIAG_RELU_LIK || which == TRAMP_DIAG_PWL3_LIK;
     TRAMP_REQUIRE(ctx, !needs_y || in2_d);
-    static const int need[] = {3, 1, 0, 0, 2, 1, 1, 1, 8};
+    static const int need[] = {3, 1, 0, 0, 2, 1, 1, 1, 8, 2, 4};
     TRAMP_REQUIRE(ctx, nparams >= need[which]);
     DiagParams P{};
     for (int i = 0; i < nparams; ++i) P.p[i] = params[i];
+    if (which == TRAMP_DIAG_HALFLINE) TRAMP_REQUIRE(ctx, P.p[0] >= 0.0);
+    if (which == TRAMP_DIAG_GM) {
+        const int K = (int)P.p[0];
+        TRAMP_REQUIRE(ctx, K >= 1 && K <= tmath::kGmMax && nparams >= 1 + 3 * K);
+        for (int k = 0; k < K; ++k) TRAMP_REQUIRE(ctx, P.p[1 + k] > 0.0 && P.p[1 + 2 * K + k] > 0.0);
+    }
     if (which == TRAMP_DIAG_GB) TRAMP_REQUIRE(ctx, P.p[0] > 0.0 && P.p[0] < 1.0 && P.p[2] > 0.0);
     if (which == TRAMP_DIAG_GAUSS_PRIOR) TRAMP_REQUIRE(ctx, P.p[1] > 0.0);
     if (which == TRAMP_DIAG_GAUSS_LIK) TRAMP_REQUIRE(ctx, P.p[0] > 0.0);

@@ -77,6 +77,67 @@ template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1)
     }
 };
 
+// Half-line prior p(x) ~ 1[x >= 0] exp(-a0 x^2 / 2 + b0 x): ExponentialPrior (a0 = 0, b0 = -1/mean;
+// tramp/priors/exponential_prior.py:25-26, 54-60) and PositivePrior (a0 = 1, b0 = 0; positive_prior.py:23-25, 56-63).
+// The posterior is positive.r / positive.v (beliefs/positive.py:12-17) at (ax + a0, bx + b0): the half-line truncated
+// normal of the sign likelihood with y = +1.  in0 = bx
+template <typename T> struct HalfLinePriorOp {
+    static constexpr bool HEAVY = false;     // as the sign likelihood: recomputed in pass 2
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    double a0, b0;
+    // The arithmetic is double whatever the element type: the variance v0 (1 + g2 - g1^2) cancels to eps x^2 at
+    // x = -(b/a) sqrt(a/2), and an exponential prior sits at x = 1 / (mean sqrt(2 ax)) - 22 at ax = 1e-3, where f32
+    // would leave 3 % (tests/test_gpu_r6_factors.py); f32 messages are widened on load and rounded on store.
+    tmath::RegionConst<double> c;
+    double a_msg;
+    __device__ static void stage() { tmath::erfcx_setup<double>(); }
+    __device__ void prepare(size_t b) {
+        a_msg = ax[b];
+        c = tmath::region_const<double>(a_msg + a0);
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T) const {
+        RV<double> o = tmath::sgn_lik_posterior_fast<double>((double)x0 + b0, 1.0, c);
+        return {T(o.r), T(o.v), 0u};
+    }
+};
+
+// GaussianMixturePrior (tramp/priors/gaussian_mixture_prior.py:36-39, 88-97; beliefs/mixture.py:23-41), at most
+// tmath::kGmMax components; a0 = 1/var_k, b0 = mean_k/var_k, eta = log p_k - normal.A(a0, b0).  in0 = bx
+template <typename T> struct GmOp {
+    static constexpr bool HEAVY = false;
+    static constexpr int NIN = 1;
+    static constexpr int TARGET = 0;
+    const double* ax;
+    int K;
+    double a0[tmath::kGmMax], b0[tmath::kGmMax], eta[tmath::kGmMax];
+    tmath::GmConst<T> g;
+    double a_msg;
+    __device__ static void stage() {}
+    __device__ void prepare(size_t b) {
+        a_msg = ax[b];
+        g.K = K;
+#pragma unroll
+        for (int k = 0; k < tmath::kGmMax; ++k) {
+            if (k < K) {
+                const double ad = a_msg + a0[k];
+                const double inv = 1.0 / ad;
+                g.inv_a[k] = T(inv);
+                g.c1[k] = T(0.5 * inv);
+                g.c0[k] = T(eta[k] + 0.5 * log(2 * tmath::kPi / ad));
+                g.b0[k] = T(b0[k]);
+            }
+        }
+    }
+    __device__ void setup(size_t b) { stage(); prepare(b); }
+    __device__ EwOut<T> eval(T x0, T) const {
+        RV<T> o = tmath::gm_posterior<T>(x0, g);
+        return {o.r, o.v, 0u};
+    }
+};
+
 // LEAN: the resident pipeline's form (tmath::sgn_lik_posterior_lean; a disagreement beyond the erfcx table or a non-finite
 // input comes back in EwOut::dev and the caller redoes the instance on the full form)
 template <typename T, bool LEAN = false> struct SgnLikOp {   // K4; in0 = bz, in1 = y

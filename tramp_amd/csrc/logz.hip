@@ -230,6 +230,43 @@ __global__ __launch_bounds__(kBlock) void lin_logz_kernel(int k, size_t N, const
     if (threadIdx.x == 0) out[b] = acc + ((size_t)k < N ? 0.5 * (double)(N - k) * log(k2Pi / az) : 0.0);
 }
 
+
+// ---- round 6: ExponentialPrior / PositivePrior (which = 0: params {a0, b0, A0}) and GaussianMixturePrior (which = 1:
+// params {K, probs[K], means[K], vars[K]}); the host takes the mean as the reference does.
+//   exponential_prior.py:62-65: positive.A(ax, bx + b0) - exponential.A(b0);  positive_prior.py:65-69: positive.A(ax + 1, bx)
+//   - positive.A(1, 0)  (A0 = the subtracted constant);  gaussian_mixture_prior.py:99-104 with beliefs/mixture.py:18-20
+struct Prior2Params { int which, K; double a0, b0, A0; double ga0[tmath::kGmMax], gb0[tmath::kGmMax], geta[tmath::kGmMax]; };
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void prior2_logz_kernel(Prior2Params P, size_t n, const double* __restrict__ ax_d,
+                                                             const T* __restrict__ bx, double* __restrict__ partials) {
+    __shared__ double smem[kBlock / kWave];
+    const size_t b = blockIdx.y;
+    const double ax = ax_d[b];
+    const T* p0 = bx + b * n;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const double x = (double)p0[i];
+        double A;
+        if (P.which == 0) {
+            const double a = ax + P.a0;
+            A = halfline_logZ((x + P.b0) / a, 1.0 / a, +1) - P.A0;
+        } else {
+            double xi[tmath::kGmMax];
+            for (int k = 0; k < P.K; ++k) xi[k] = P.geta[k] + normal_A(ax + P.ga0[k], x + P.gb0[k]);
+            double m = xi[0];
+            for (int k = 1; k < P.K; ++k) m = (xi[k] > m || m != m) ? xi[k] : m;
+            const double mm = (m - m == 0.0) ? m : 0.0;                      // scipy.special.logsumexp
+            double s = 0.0;
+            for (int k = 0; k < P.K; ++k) s += exp(xi[k] - mm);
+            A = log(s) + mm - P.A0;
+        }
+        acc += A;
+    }
+    acc = block_sum(acc, smem);
+    if (threadIdx.x == 0) partials[b * gridDim.x + blockIdx.x] = acc;
+}
+
 }  // namespace
 
 extern "C" int tramp_log_partition(tramp_ctx* ctx, int dtype, int kind, size_t n, size_t batch, double p0, double p1,
@@ -257,6 +294,54 @@ extern "C" int tramp_log_partition(tramp_ctx* ctx, int dtype, int kind, size_t n
     else
         hipLaunchKernelGGL((logz_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, P, n, (const float*)v0_d,
                            needs_v1 ? (const float*)v1_d : nullptr, ctx->ws);
+    hipLaunchKernelGGL(logz_fold_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, ctx->ws, nblk, out_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
+extern "C" int tramp_prior2_log_partition(tramp_ctx* ctx, int dtype, int which, size_t n, size_t batch,
+                                          const double* params_h, int nparams, const double* ax_d, const void* bx_d,
+                                          double* out_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, params_h && ax_d && bx_d && out_d && (which == 0 || which == 1));
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    Prior2Params P{};
+    P.which = which;
+    if (which == 0) {
+        TRAMP_REQUIRE(ctx, nparams >= 3 && params_h[0] >= 0.0);
+        P.a0 = params_h[0];
+        P.b0 = params_h[1];
+        P.A0 = params_h[2];
+    } else {
+        const int K = (int)params_h[0];
+        TRAMP_REQUIRE(ctx, K >= 1 && K <= tmath::kGmMax && nparams >= 1 + 3 * K);
+        P.K = K;
+        double xi0[tmath::kGmMax], m = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const double pk = params_h[1 + k], mk = params_h[1 + K + k], vk = params_h[1 + 2 * K + k];
+            TRAMP_REQUIRE(ctx, pk > 0.0 && vk > 0.0);
+            P.ga0[k] = 1.0 / vk;
+            P.gb0[k] = mk / vk;
+            const double A = 0.5 * (P.gb0[k] * P.gb0[k] / P.ga0[k] + log(k2Pi / P.ga0[k]));
+            P.geta[k] = log(pk) - A;
+            xi0[k] = P.geta[k] + A;                    // = log p_k: mixture.A(a0, b0, eta) = log sum p_k
+            m = xi0[k] > m ? xi0[k] : m;
+        }
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += exp(xi0[k] - m);
+        P.A0 = log(s) + m;
+    }
+    if (!batch) return TRAMP_OK;
+    if (!n) return tramp_fill_f64(ctx, out_d, batch, 0.0);
+    TRAMP_REQUIRE(ctx, batch <= 65535);
+    const int nblk = blocks_for(n, 1);
+    int rc = tramp_ws_reserve(ctx, batch * (size_t)nblk * sizeof(double));
+    if (rc) return rc;
+    dim3 grid(nblk, (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((prior2_logz_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, P, n, ax_d, (const double*)bx_d, ctx->ws);
+    else
+        hipLaunchKernelGGL((prior2_logz_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, P, n, ax_d, (const float*)bx_d, ctx->ws);
     hipLaunchKernelGGL(logz_fold_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, ctx->ws, nblk, out_d);
     TRAMP_LAUNCH_CHECK(ctx);
     return TRAMP_OK;

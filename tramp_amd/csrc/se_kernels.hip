@@ -58,6 +58,7 @@ struct Se1dParams {
     const double* p2;   // mean
     const double* p3;   // var
     tmath::Pwl3Spec spec3;   // mode 3 (three-region likelihood) only
+    struct { int K; double probs[tmath::kGmMax], means[tmath::kGmMax], vars[tmath::kGmMax]; } gm;   // mode 5 only
 };
 
 __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, double* __restrict__ out) {
@@ -128,6 +129,43 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
                 acc += w * norm_pdf(x) * (1.0 - t * t);
             }
             total += wt * acc;
+        }
+    }
+    if (mode == 5) {
+        // Gaussian mixture prior (gaussian_mixture_prior.py:132-137 through base_prior.py:66-69):
+        //   v = sum_k p_k E_{N(ax m_k, ax + ax^2 s_k)}[f],  f(b) = v(ax, b) of the mixture posterior (beliefs/mixture.py:34-41)
+        const double ax = P.p0[pt];
+        const int K = P.gm.K;
+        tmath::GmConst<double> g;
+        g.K = K;
+#pragma unroll
+        for (int k = 0; k < tmath::kGmMax; ++k) {
+            if (k < K) {
+                const double a0 = 1.0 / P.gm.vars[k], b0 = P.gm.means[k] / P.gm.vars[k];
+                const double eta = log(P.gm.probs[k]) - 0.5 * (b0 * b0 / a0 + log(2 * tmath::kPi / a0));
+                const double ad = ax + a0;
+                g.inv_a[k] = 1.0 / ad;
+                g.c1[k] = 0.5 / ad;
+                g.c0[k] = eta + 0.5 * log(2 * tmath::kPi / ad);
+                g.b0[k] = b0;
+            }
+        }
+        for (int br = 0; br < K; ++br) {
+            const double m = ax * P.gm.means[br];
+            const double s = sqrt(ax + ax * ax * P.gm.vars[br]);
+            // the mesh is graded towards the centre of the mixture in b (the posterior changes component around it)
+            double bc = 0.0;
+            for (int k = 0; k < K; ++k) bc += P.gm.probs[k] * P.gm.means[k];
+            double xc = (s > 0) ? (ax * bc - m) / s : 0.0;
+            xc = fmin(fmax(xc, -10.0), 10.0);
+            double acc = 0.0;
+            for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
+                double x, w;
+                graded_node(i, kPanels1D, xc, x, w);
+                tmath::RV<double> o = tmath::gm_posterior<double>(m + s * x, g);
+                acc += w * norm_pdf(x) * o.v;
+            }
+            total += P.gm.probs[br] * acc;
         }
     }
     if (mode == 2) {
@@ -423,6 +461,29 @@ extern "C" int tramp_se_binary_prior(tramp_ctx* ctx, size_t count, const double*
     Se1dParams P{din[0], din[1], nullptr, nullptr, tmath::Pwl3Spec{}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 4, P, dout);
     g_se_evals = (unsigned long long)count * 2 * 8 * kPanels1D;
+    return se_finish(ctx, count, dout, v);
+}
+
+extern "C" int tramp_se_gm_prior(tramp_ctx* ctx, size_t count, const double* ax, int K, const double* probs,
+                                 const double* means, const double* vars, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, ax && probs && means && vars && v && K >= 1 && K <= tmath::kGmMax);
+    if (!count) return TRAMP_OK;
+    for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, ax[i] >= 0.0);
+    const double* hin[1] = {ax};
+    double *din[1], *dout;
+    int rc = se_stage(ctx, count, hin, 1, din, &dout, 0, nullptr);
+    if (rc) return rc;
+    Se1dParams P{din[0], nullptr, nullptr, nullptr, tmath::Pwl3Spec{}};
+    P.gm.K = K;
+    for (int k = 0; k < K; ++k) {
+        TRAMP_REQUIRE(ctx, probs[k] > 0.0 && vars[k] > 0.0);
+        P.gm.probs[k] = probs[k];
+        P.gm.means[k] = means[k];
+        P.gm.vars[k] = vars[k];
+    }
+    hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 5, P, dout);
+    g_se_evals = (unsigned long long)count * K * 8 * kPanels1D;
     return se_finish(ctx, count, dout, v);
 }
 

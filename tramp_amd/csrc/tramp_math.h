@@ -1346,6 +1346,104 @@ TM_HD PwlOut<T> pwl3_lik_posterior(T bz, T y, T az, const Pwl3Spec& sp) {
     return o;
 }
 
+// ---- Gaussian mixture prior (tramp/priors/gaussian_mixture_prior.py:88-97, tramp/beliefs/mixture.py:23-41) ----
+// p(x) = sum_k p_k N(x | m_k, s_k): with a_k = ax + 1/s_k, b_k = bx + m_k/s_k the posterior is a mixture of N(b_k/a_k, 1/a_k)
+// with weights softmax_k(eta_k + normal.A(a_k, b_k)).  Per-instance scalars hoisted: inv_a = 1/a_k, c1 = 0.5/a_k,
+// c0 = eta_k + 0.5 log(2 pi / a_k).  v = sum s_k / a_k + sum_{k<l} s_k s_l (r_k - r_l)^2 (the reference's double sum over
+// ordered pairs, halved).  At most kGmMax components; the loops are unrolled with static indices (registers, no scratch).
+constexpr int kGmMax = 8;
+template <typename T> struct GmConst { int K; T inv_a[kGmMax], c0[kGmMax], c1[kGmMax], b0[kGmMax]; };
+
+template <typename T> TM_HD RV<T> gm_posterior(T bx, const GmConst<T>& g) {
+    T xi[kGmMax], rk[kGmMax];
+    T m = T(-INFINITY);
+#pragma unroll
+    for (int k = 0; k < kGmMax; ++k) {
+        if (k < g.K) {
+            const T bk = bx + g.b0[k];
+            xi[k] = fma_(bk * bk, g.c1[k], g.c0[k]);
+            rk[k] = bk * g.inv_a[k];
+            m = (xi[k] > m || xi[k] != xi[k]) ? xi[k] : m;       // np.max: NaN wins
+        }
+    }
+    T se = T(0), sr = T(0), sv = T(0);
+#pragma unroll
+    for (int k = 0; k < kGmMax; ++k) {
+        if (k < g.K) {
+            xi[k] = exp_(xi[k] - m);                                // +inf - +inf = NaN as scipy's softmax
+            se += xi[k];
+            sr += xi[k] * rk[k];
+            sv += xi[k] * g.inv_a[k];
+        }
+    }
+    const T is = T(1) / se;
+    T dr = T(0);
+#pragma unroll
+    for (int k = 0; k < kGmMax; ++k) {
+#pragma unroll
+        for (int l = k + 1; l < kGmMax; ++l) {
+            if (l < g.K) {
+                const T d = rk[k] - rk[l];
+                dr += (xi[k] * is) * (xi[l] * is) * (d * d);
+            }
+        }
+    }
+    RV<T> o;
+    o.r = sr * is;
+    o.v = dr + sv * is;
+    return o;
+}
+
+// ---- modulus likelihood y = |z|, z complex (tramp/likelihoods/modulus_likelihood.py:9-20, 82-93) ----
+// I(x) = I1(x) / I0(x) (the reference: scipy's ive(1, x) / ive(0, x), 1 from x = 1e9 on and for NaN).  Always in double:
+// x <= 25: the two power series in t = x^2 / 4 (positive terms, no cancellation; 48 terms reach 1e-17 of the sum at 25);
+// x > 25: the large-argument expansions I_nu ~ e^x / sqrt(2 pi x) sum_k e_k(nu) / x^k, e_k = e_{k-1} ((2k-1)^2 - 4 nu^2) / (8k),
+// 19 terms (3e-17 at 25); the common prefactor cancels in the ratio.  Odd in x.
+TM_HD double bessel_i1_over_i0(double x) {
+    if (!(x < 1e9)) return 1.0;
+    const double ax = ::fabs(x);
+    double ratio;
+    if (ax <= 25.0) {
+        const double t = 0.25 * ax * ax;
+        double t0 = 1.0, t1 = 1.0, s0 = 1.0, s1 = 1.0;
+#pragma unroll
+        for (int k = 1; k <= 48; ++k) {
+            t0 *= t * (1.0 / ((double)k * (double)k));
+            t1 *= t * (1.0 / ((double)k * (double)(k + 1)));
+            s0 += t0;
+            s1 += t1;
+        }
+        ratio = (0.5 * ax) * s1 / s0;
+    } else {
+        const double z = 1.0 / ax;
+        double t0 = 1.0, t1 = 1.0, s0 = 1.0, s1 = 1.0;
+#pragma unroll
+        for (int k = 1; k <= 18; ++k) {
+            const double q = (double)(2 * k - 1) * (double)(2 * k - 1);
+            t0 *= z * (q * (1.0 / (8.0 * (double)k)));
+            t1 *= z * ((q - 4.0) * (1.0 / (8.0 * (double)k)));
+            s0 += t0;
+            s1 += t1;
+        }
+        ratio = s1 / s0;
+    }
+    return x < 0.0 ? -ratio : ratio;
+}
+
+// posterior of one complex component: bz = (re, im), y = |z| observed.  rz = (bz / |bz|) y I(|bz| y) (0 where bz = 0),
+// v = y^2 (1 - I^2) / 2 (the 1/2 averages the two real coordinates).  |bz| is np.absolute of the complex number (hypot).
+struct ModOut { double re, im, v; };
+TM_HD ModOut modulus_posterior(double re, double im, double y) {
+    const double b = ::hypot(re, im);
+    const double I = bessel_i1_over_i0(b * y);
+    const double sc = y * I;
+    ModOut o;
+    o.re = (b != 0.0) ? (re / b) * sc : 0.0;
+    o.im = (b != 0.0) ? (im / b) * sc : 0.0;
+    o.v = 0.5 * (y * y) * (1.0 - I * I);
+    return o;
+}
+
 // Gaussian CDF / PDF (tramp/utils/misc.py:50-57) for the SE quadratures.
 TM_HD double norm_cdf(double x) { return 0.5 * (1.0 + ::erf(x / kSqrt2)); }
 TM_HD double norm_pdf(double x) { return ::exp(-0.5 * x * x) / 2.5066282746310002; }

@@ -16,6 +16,18 @@ class GaussianEnsemble:
         return np.random.randn(self.M, self.N) / np.sqrt(self.N)
 
 
+class ComplexGaussianEnsemble:
+    "X.real and X.imag ~ iid N(0, 1/N) (tramp/ensembles/complex_gaussian_ensemble.py:6-24)"
+
+    def __init__(self, M, N):
+        self.M = M
+        self.N = N
+        self.GE = GaussianEnsemble(M, N)
+
+    def generate(self):
+        return self.GE.generate() + 1j * self.GE.generate()
+
+
 class MarchenkoPasturEnsemble:
     def __init__(self, alpha):
         self.alpha = alpha
@@ -44,7 +56,8 @@ class MarchenkoPasturEnsemble:
         return 1 - self.compute_F(gamma) / (4 * gamma)
 
 
-ENSEMBLE_CLASSES = {"gaussian": GaussianEnsemble, "marchenko_pastur": MarchenkoPasturEnsemble}
+ENSEMBLE_CLASSES = {"gaussian": GaussianEnsemble, "complex_gaussian": ComplexGaussianEnsemble,
+                    "marchenko_pastur": MarchenkoPasturEnsemble}
 
 
 def get_ensemble(ensemble_type, **kwargs):

@@ -278,6 +278,100 @@ class AbsLikelihood(Likelihood):
         return float(v[0]) if np.ndim(az) == 0 else v
 
 
+class ModulusLikelihood(Likelihood):
+    """Modulus likelihood y = |z| for complex z: the output factor of phase retrieval.
+
+    tramp/likelihoods/modulus_likelihood.py:36-131.  A complex array is its planar real form Z[0] = Re z, Z[1] = Im z
+    (tramp/utils/misc.py:13-27): host messages are (2, n) or (batch, 2, n), device messages [batch, 2 n]; y is (n,) or
+    (batch, n).  Kernel: csrc/modulus.hip (Bessel ratio I1 / I0 in double).
+    """
+
+    def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
+        if not isotropic:
+            raise NotImplementedError("diagonal beliefs for ModulusLikelihood are outside the HIP path")
+        self.y_name = y_name
+        self.size = self.get_size(y)
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self._set_y(y)
+
+    def sample(self, Z):
+        "We assume Z[0] = Z.real and Z[1] = Z.imag (modulus_likelihood.py:58-61)"
+        Z = np.asarray(Z)
+        return np.absolute(Z[0] + 1j * Z[1])
+
+    def _planar(self, bz):
+        "(device [batch, 2 n], the host shape to give results back in or None)"
+        if isinstance(bz, DeviceArray):
+            return (bz if bz.ndim == 2 else bz.reshape(1, bz.shape[0])), None
+        h = np.asarray(bz, dtype=self.dtype)
+        if h.ndim not in (2, 3) or h.shape[-2] != 2:
+            raise ValueError(f"expected a planar complex message (2, n) or (batch, 2, n), got {h.shape}")
+        return self.ctx.array(np.ascontiguousarray(h.reshape(-1, 2 * h.shape[-1])), self.dtype), h.shape
+
+    def _run(self, az, bz, y=None, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None, want_posterior=False):
+        ctx = self.ctx
+        bd, hshape = self._planar(bz)
+        batch, n2 = bd.shape
+        n = n2 // 2
+        a = ScalArg(ctx, az, batch)
+        yd = self._y_dev
+        if y is not None and y is not self.y:
+            yd = y if isinstance(y, DeviceArray) else ctx.array(np.atleast_2d(np.asarray(y, dtype=self.dtype)), self.dtype)
+        if yd is None:
+            raise ValueError("likelihood has no observation y")
+        if tuple(yd.shape) != (batch, n):
+            raise ValueError(f"y has shape {tuple(yd.shape)}, message has {(batch, 2, n)}")
+        a_new = out_a if out_a is not None else ctx.empty((batch,), np.float64)
+        b_new = out_b if out_b is not None else ctx.empty((batch, n2), self.dtype)
+        r = ctx.empty((batch, n2), self.dtype) if want_posterior else None
+        v = ctx.empty((batch,), np.float64) if want_posterior else None
+        ctx._call("tramp_modulus_lik_bwd", self._dt, n, batch, a.dev.ptr, bd.ptr, yd.ptr, float(damping or 0.0),
+                  old_a.ptr if old_a is not None else None, old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr,
+                  r.ptr if r is not None else None, v.ptr if v is not None else None)
+        return a, hshape, a_new, b_new, r, v
+
+    @staticmethod
+    def _ret_vec(dev, hshape):
+        return dev if hshape is None else dev.get().reshape(hshape)
+
+    @staticmethod
+    def _ret_scal(dev, a, hshape):
+        if hshape is None or not a.was_host:
+            return dev
+        h = dev.get()
+        return float(h[0]) if (a.scalar_like and len(hshape) == 2) else h
+
+    def compute_backward_posterior(self, az, bz, y):
+        "modulus_likelihood.py:82-93"
+        a, hs, _, _, r, v = self._run(az, bz, y=y, want_posterior=True)
+        return self._ret_vec(r, hs), self._ret_scal(v, a, hs)
+
+    def compute_backward_message(self, az, bz, **kw):
+        "Likelihood.compute_backward_message (base_likelihood.py:25-28)"
+        a, hs, a_new, b_new, _, _ = self._run(az, bz, **kw)
+        return self._ret_scal(a_new, a, hs), self._ret_vec(b_new, hs)
+
+    def compute_log_partition(self, az, bz, y=None):
+        "modulus_likelihood.py:125-129, as found: |.| of each real coordinate, A.mean() / 2"
+        ctx = self.ctx
+        bd, hs = self._planar(bz)
+        batch, n2 = bd.shape
+        a = ScalArg(ctx, az, batch)
+        yd = self._y_dev
+        if y is not None and y is not self.y:
+            yd = y if isinstance(y, DeviceArray) else ctx.array(np.atleast_2d(np.asarray(y, dtype=self.dtype)), self.dtype)
+        out = ctx.empty((batch,), np.float64)
+        ctx._call("tramp_modulus_log_partition", self._dt, n2 // 2, batch, a.dev.ptr, bd.ptr, yd.ptr, out.ptr)
+        res = out.get() / (2.0 * n2)
+        return float(res[0]) if (hs is not None and a.was_host and a.scalar_like and len(hs) == 2) else res
+
+    def compute_backward_error(self, az, tau_z):
+        raise NotImplementedError("ModulusLikelihood.compute_backward_error (the 2-D Bessel-weighted average of "
+                                  "modulus_likelihood.py:101-120) is not on the HIP path")
+
+
 class ReluLikelihood(Likelihood):
     """y = relu(z) observed (tramp/likelihoods/piecewise_linear_likelihood.py:279-284): y > 0 pins
     z = y, y == 0 leaves a truncated normal on (-inf, 0]."""
@@ -483,6 +577,7 @@ LIKELIHOOD_CLASSES = {
     "h-tanh": HardTanhLikelihood,
     "h-sigm": HardSigmoidLikelihood,
     "door": SymmetricDoorLikelihood,
+    "modulus": ModulusLikelihood,
 }
 
 

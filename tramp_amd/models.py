@@ -12,11 +12,11 @@ import numpy as np
 
 from .base import Factor, Variable
 from .channels import (AsymmetricAbsChannel, ConvChannel, DFTChannel, GradientChannel, ReshapeChannel, GaussianChannel, HardTanhChannel, HardSigmoidChannel, SymmetricDoorChannel, SgnChannel, AbsChannel, ReluChannel, LeakyReluChannel, LinearChannel,
-                       PiecewiseLinearChannel, get_channel)
+                       ComplexLinearChannel, ModulusChannel, PiecewiseLinearChannel, get_channel)
 from .ensembles import get_ensemble
 from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, AsymmetricAbsLikelihood, ReluLikelihood,
                           LeakyReluLikelihood, HardTanhLikelihood, HardSigmoidLikelihood,
-                          SymmetricDoorLikelihood, Likelihood)
+                          SymmetricDoorLikelihood, ModulusLikelihood, Likelihood)
 from .priors import Prior, get_prior
 from .variables import SISOVariable, SILeafVariable
 
@@ -42,6 +42,8 @@ def channel2likelihood(channel, y, y_name):
         return HardSigmoidLikelihood(y=y, y_name=y_name, **kw)
     if isinstance(channel, SymmetricDoorChannel):
         return SymmetricDoorLikelihood(width=channel.width, y=y, y_name=y_name, **kw)
+    if isinstance(channel, ModulusChannel):
+        return ModulusLikelihood(y=y, y_name=y_name, **kw)                # dag_algebra.py:38-39
     raise NotImplementedError(f"cannot convert {channel} to likelihood")
 
 
@@ -196,6 +198,10 @@ class Model:
     def _out_shape(self, factor, in_shape):
         if isinstance(factor, Prior):
             return (factor.size,) if np.isscalar(factor.size) else tuple(factor.size)
+        if isinstance(factor, ComplexLinearChannel):
+            return (2, factor.Nx)                   # planar complex vectors
+        if isinstance(factor, ModulusChannel):
+            return tuple(in_shape[1:])
         if isinstance(factor, LinearChannel):
             return (factor.Nx,)
         if isinstance(factor, ConvChannel):
@@ -247,8 +253,11 @@ def glm_generative(N, alpha, ensemble_type, prior_type, output_type, dtype=np.fl
     "tramp/models/generalized_linear_model.py:17-36"
     M = int(alpha * N)
     F = get_ensemble(ensemble_type, M=M, N=N, **_get_kwargs("ensemble", kwargs)).generate()
-    prior = get_prior(size=N, prior_type=prior_type, dtype=dtype, ctx=ctx, **_get_kwargs("prior", kwargs))
-    linear = get_channel("linear", W=F, name="F", dtype=dtype, ctx=ctx, keep_W=True)
+    # phase retrieval: complex signal as a planar (2, N) array behind a complex matrix (generalized_linear_model.py:26-28)
+    size = (2, N) if output_type == "modulus" else N
+    prior = get_prior(size=size, prior_type=prior_type, dtype=dtype, ctx=ctx, **_get_kwargs("prior", kwargs))
+    linear = get_channel("complex_linear" if output_type == "modulus" else "linear", W=F, name="F", dtype=dtype, ctx=ctx,
+                         keep_W=True)
     okw = _get_kwargs("output", kwargs)
     okw.update(dtype=dtype, ctx=ctx)
     output = get_channel(output_type, **okw)

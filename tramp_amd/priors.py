@@ -55,6 +55,32 @@ class Prior(Factor):
     def compute_forward_overlap(self, ax):
         return self.second_moment() - self.compute_forward_error(ax)
 
+    def _logz2(self, which, params, ax, bx):
+        "mean over the components of the prior's log-partition (tramp_prior2_log_partition returns the sums)"
+        import ctypes as C
+        ctx = self.ctx
+        if not self.isotropic and np.ndim(ax) > 0 and not isinstance(bx, DeviceArray):
+            # diagonal beliefs: n instances of one component each, then the reference's A.mean()
+            vh = np.asarray(bx, dtype=self.dtype).reshape(-1, 1)
+            ah = np.broadcast_to(np.asarray(ax, dtype=np.float64).ravel(), (vh.shape[0],)).copy()
+            iso, self.isotropic = self.isotropic, True
+            try:
+                per = np.atleast_1d(self._logz2(which, params, ah, vh))
+            finally:
+                self.isotropic = iso
+            return float(per.mean())
+        v = VecArg(ctx, bx, self.dtype)
+        a = ScalArg(ctx, ax, v.batch)
+        par = [float(x) for x in params]
+        arr = (C.c_double * len(par))(*par)
+        out = ctx.empty((v.batch,), np.float64)
+        ctx._call("tramp_prior2_log_partition", self._dt, int(which), v.n, v.batch, arr, len(par), a.dev.ptr, v.dev.ptr,
+                  out.ptr)
+        res = out.get() / v.n
+        if a.was_host and a.scalar_like and v.was_host and len(v.host_shape) == 1:
+            return float(res[0])
+        return res
+
 
 class GaussBernoulliPrior(Prior):
     r"""Gauss-Bernoulli prior p(x) = (1-rho) delta(x) + rho N(x | mean, var).
@@ -205,6 +231,138 @@ class BinaryPrior(Prior):
         n = ax_h.shape[0]
         pp, v = np.full(n, float(self.p_pos)), np.empty(n)
         self.ctx._call("tramp_se_binary_prior", n, ax_h.ctypes.data, pp.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(ax) == 0 else v
+
+
+class _HalfLinePrior(Prior):
+    """Priors supported on x >= 0 whose tilted posterior is a half-line truncated normal (tramp/beliefs/positive.py):
+    p(x) ~ 1[x >= 0] exp(-a0 x^2 / 2 + b0 x).  One kernel (tramp_halfline_prior_fwd) for both subclasses."""
+    _a0 = 0.0
+    _b0 = 0.0
+    _diag_which = _lib.DIAG_HALFLINE
+
+    def _diag_params(self):
+        return (self._a0, self._b0)
+
+    def _kernel(self, b, a, damping, old_a, old_b, a_new, b_new, r, v):
+        self.ctx._call("tramp_halfline_prior_fwd", self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr, float(self._a0),
+                       float(self._b0), damping, old_a, old_b, a_new.ptr, b_new.ptr,
+                       r.ptr if r is not None else None, v.ptr if v is not None else None)
+
+    def compute_forward_error(self, ax):
+        raise NotImplementedError      # as the reference: beliefs_measure is not implemented (exponential_prior.py:73-74)
+
+
+class ExponentialPrior(_HalfLinePrior):
+    r"""Exponential prior p(x) = 1[x >= 0] exp(-x / mean) / mean.
+
+    tramp/priors/exponential_prior.py:8-80: natural parameter b = -1/mean, posterior positive.r / positive.v at
+    (ax, bx + b).  (The reference's ``sample`` draws with scale 1/mean, :28-30; restated as found.)
+    """
+
+    def __init__(self, size, mean=1, isotropic=True, dtype=np.float64, ctx=None):
+        assert mean > 0
+        self.size = size
+        self.mean = mean
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.b = -1 / mean                                       # :26
+        self._a0, self._b0 = 0.0, self.b
+
+    def sample(self):
+        return np.random.exponential(scale=1 / self.mean, size=self.size)
+
+    def second_moment(self):
+        return 2 * self.mean**2
+
+    def compute_log_partition(self, ax, bx):
+        "exponential_prior.py:62-65: positive.A(ax, bx + b) - exponential.A(b), exponential.A(b) = -log(-b)"
+        return self._logz2(0, (0.0, self.b, -np.log(-self.b)), ax, bx)
+
+
+class PositivePrior(_HalfLinePrior):
+    r"""Positive (half-normal) prior p(x) = 2 1[x >= 0] N(x | 0, 1).
+
+    tramp/priors/positive_prior.py:8-82: natural parameters a = 1, b = 0.
+    """
+
+    def __init__(self, size, isotropic=True, dtype=np.float64, ctx=None):
+        self.size = size
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.a = 1.
+        self.b = 0.
+        self._a0, self._b0 = 1.0, 0.0
+
+    def sample(self):
+        return np.abs(np.random.standard_normal(self.size))     # scipy.stats.halfnorm.rvs (:27-29)
+
+    def second_moment(self):
+        return 1.
+
+    def compute_log_partition(self, ax, bx):
+        "positive_prior.py:65-69: positive.A(ax + 1, bx) - positive.A(1, 0);  positive.A(1, 0) = log(sqrt(2 pi) / 2)"
+        return self._logz2(0, (1.0, 0.0, 0.5 * np.log(2 * np.pi) + np.log(0.5)), ax, bx)
+
+
+class GaussianMixturePrior(Prior):
+    r"""Gaussian mixture prior p(x) = sum_k p_k N(x | r_k, v_k), at most 8 components on the HIP path.
+
+    tramp/priors/gaussian_mixture_prior.py:8-139 with tramp/beliefs/mixture.py.
+    """
+    _diag_which = _lib.DIAG_GM
+
+    def __init__(self, size, probs=[0.5, 0.5], means=[-1, 1], vars=[1, 1], isotropic=True, dtype=np.float64, ctx=None):
+        self.size = size
+        assert len(probs) == len(means) == len(vars)
+        self.K = len(probs)
+        if self.K > 8:
+            raise NotImplementedError("GaussianMixturePrior on the HIP path holds at most 8 components")
+        self.probs = np.array(probs)
+        self.means = np.array(means)
+        self.vars = np.array(vars)
+        self.isotropic = isotropic
+        self.repr_init()
+        self._init_device(dtype, ctx)
+        self.sigmas = np.sqrt(vars)
+        self.a = 1 / self.vars                                   # :36-39
+        self.b = self.means / self.vars
+        self.eta = np.log(self.probs) - 0.5 * (self.b**2 / self.a + np.log(2 * np.pi / self.a))
+
+    def _tables(self):
+        import ctypes as C
+        return [(C.c_double * self.K)(*[float(x) for x in t]) for t in (self.probs, self.means, self.vars)]
+
+    def _diag_params(self):
+        return (self.K,) + tuple(self.probs) + tuple(self.means) + tuple(self.vars)
+
+    def sample(self):
+        shape = (self.size, self.K)
+        X_gauss = self.means + self.sigmas * np.random.standard_normal(shape)
+        X_cluster = np.random.multinomial(n=1, pvals=self.probs, size=self.size)
+        return (X_gauss * X_cluster).sum(axis=1)
+
+    def second_moment(self):
+        return sum(p * (m**2 + v) for p, m, v in zip(self.probs, self.means, self.vars))
+
+    def _kernel(self, b, a, damping, old_a, old_b, a_new, b_new, r, v):
+        pr, me, va = self._tables()
+        self.ctx._call("tramp_gm_prior_fwd", self._dt, b.n, b.batch, a.dev.ptr, b.dev.ptr, self.K, pr, me, va,
+                       damping, old_a, old_b, a_new.ptr, b_new.ptr,
+                       r.ptr if r is not None else None, v.ptr if v is not None else None)
+
+    def compute_log_partition(self, ax, bx):
+        "gaussian_mixture_prior.py:99-104"
+        return self._logz2(1, self._diag_params(), ax, bx)
+
+    def compute_forward_error(self, ax):
+        "gaussian_mixture_prior.py:132-137 through base_prior.py:66-69, device quadrature (tramp_se_gm_prior)"
+        ax_h = np.atleast_1d(np.asarray(ax, dtype=np.float64))
+        pr, me, va = self._tables()
+        v = np.empty(ax_h.shape[0])
+        self.ctx._call("tramp_se_gm_prior", ax_h.shape[0], ax_h.ctypes.data, self.K, pr, me, va, v.ctypes.data)
         return float(v[0]) if np.ndim(ax) == 0 else v
 
 
@@ -377,6 +535,9 @@ PRIOR_CLASSES = {
     "L1_norm": MAP_L1NormPrior,
     "L21_norm": MAP_L21NormPrior,
     "binary": BinaryPrior,
+    "exponential": ExponentialPrior,
+    "positive": ExponentialPrior,          # as found in the reference's registry (tramp/priors/__init__.py:19)
+    "mixture": GaussianMixturePrior,
 }
 
 
