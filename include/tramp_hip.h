@@ -740,6 +740,10 @@ int tramp_se_gm_prior(tramp_ctx* ctx, size_t count, const double* ax, int K, con
  *      mirroring the reference's AssertionError). */
 int tramp_se_sgn_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
 int tramp_se_abs_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
+/* ModulusLikelihood.compute_backward_error (tramp/likelihoods/modulus_likelihood.py:101-120, base_likelihood.py:78-81):
+ * the 2-D average of (2 pi / sqrt(u)) relu(b) relu(y) ive(0, b y) y^2 (1 - (I1/I0)(b y)^2) / 2, u = az tau_z - 1 > 0,
+ * by the adaptive panel refinement of K14; u <= 0 is the closed form 1 / az of the reference's 1-D branch. */
+int tramp_se_modulus_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
 /* ReluLikelihood SE error (only the flat region has a variance; 1-D quadrature). */
 int tramp_se_relu_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v);
 /* K14. Channel.compute_forward_error / compute_backward_error for Sgn/Abs/Relu channels

@@ -2531,14 +2531,42 @@ def modulus_lik_log_partition(az, bz, y):
     return A.mean() / 2
 
 
+def se_modulus_lik_error(az, tau_z, method="quadpack"):
+    """ModulusLikelihood.beliefs_measure (modulus_likelihood.py:101-120) through base_likelihood.py:78-81:
+    u_eff = max(0, az tau_z - 1); u_eff = 0: a 1-D average of sqrt(2 pi az) relu(y) v(0, y), y = xi / sqrt(az);
+    otherwise the 2-D average of (2 pi / sqrt(u_eff)) relu(b) relu(y) ive(0, b y) v(b, y) with b = sqrt(az u_eff) xi_b,
+    y = b / az + xi_y / sqrt(az), v(b, y) = y^2 (1 - I(b y)^2) / 2."""
+    from scipy.special import ive
+
+    def v_func(b, y):
+        Ir = ive_ratio(np.atleast_1d(np.abs(b) * y))[0]
+        return 0.5 * y**2 * (1 - Ir**2)
+    u_eff = np.maximum(0, az * tau_z - 1)
+    if u_eff == 0:
+        def f_y(xi_y):
+            y = xi_y / np.sqrt(az)
+            return np.sqrt(2 * np.pi * az) * np.maximum(0, y) * v_func(0., y)
+        return gaussian_measure(0, 1, f_y, method)
+    sz_eff = np.sqrt(az * u_eff)
+
+    def f_scaled(xi_b, xi_y):
+        b = sz_eff * xi_b
+        y = b / az + xi_y / np.sqrt(az)
+        return (2 * np.pi / np.sqrt(u_eff)) * np.maximum(0, b) * np.maximum(0, y) * ive(0, b * y) * v_func(b, y)
+    return gaussian_measure_2d(0, 1, 0, 1, f_scaled, method)
+
+
 class ModulusLikFactor(OracleFactor):
     kind = "likelihood"
 
     def __init__(self, y):
-        self.y = np.asarray(y, float)
+        self.y = None if y is None else np.asarray(y, float)
 
     def backward(self, az, bz, ax, bx):
         return modulus_lik_message(az, bz, self.y)
+
+    def backward_se(self, az, ax, tau_z, method="quadpack"):
+        return a_new(se_modulus_lik_error(az, tau_z, method), az)
 
 
 class ComplexLinearOracle:

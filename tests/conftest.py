@@ -131,7 +131,8 @@ def golden_priors2():
 def golden_complex():
     "ModulusLikelihood, ComplexLinearChannel and phase-retrieval EP from the reference (tools/make_golden_r6.py)"
     with np.load(os.path.join(GOLDEN, "complex.npz"), allow_pickle=True) as f:
-        return dict(modulus=list(f["modulus"]), linear=list(f["linear"]), ep=list(f["ep"]))
+        return dict(modulus=list(f["modulus"]), linear=list(f["linear"]), ep=list(f["ep"]), se=list(f["se"]),
+                    se_traj=list(f["se_traj"]))
 
 
 def prior2_oracle(orc, name, kw):

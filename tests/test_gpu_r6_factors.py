@@ -218,8 +218,6 @@ def test_modulus_likelihood_against_reference_goldens(ctx, golden_complex, dtype
         an, bn = orc.modulus_lik_message(az[b], bz[b].astype(dtype).astype(np.float64), y[b].astype(dtype).astype(np.float64))
         close(a_new[b], an, max(rt, 1e-8), scale=an + az[b])
         close(b_new[b], bn, max(rt, 1e-8))
-    with pytest.raises(NotImplementedError):
-        lk.compute_backward_error(1.3, 1.0)
 
 
 def test_complex_linear_channel_against_reference_goldens(ctx, golden_complex):
@@ -292,3 +290,37 @@ def test_phase_retrieval_model_api(ctx):
     ph = np.vdot(xh, x0)
     ph /= abs(ph)
     assert np.mean(np.abs(xh * ph - x0)**2) < 1e-6 * np.mean(np.abs(x0)**2)
+
+
+def test_modulus_se_error_and_phase_retrieval_state_evolution(ctx, golden_complex):
+    """ModulusLikelihood.compute_backward_error (2-D Bessel-weighted average) against the reference's dblquad values, and
+    the StateEvolution recursion of phase retrieval (glm_state_evolution with a Marchenko-Pastur channel) against the
+    reference's trajectory - every scalar message of every iteration"""
+    import tramp_amd as T
+    lk = T.ModulusLikelihood(y=None, ctx=ctx)
+    for c in golden_complex["se"]:
+        assert lk.compute_backward_error(c["az"], c["tau_z"]) == pytest.approx(c["v"], rel=1e-7), (c["az"], c["tau_z"])
+        assert lk.compute_backward_state_evolution(c["az"], c["tau_z"]) == pytest.approx(c["a_new"], rel=1e-6)
+    az = np.array([c["az"] for c in golden_complex["se"]])
+    tz = np.array([c["tau_z"] for c in golden_complex["se"]])
+    close(lk.compute_backward_error(az, tz), [c["v"] for c in golden_complex["se"]], 1e-7)
+    for c in golden_complex["se_traj"]:
+        model = T.glm_state_evolution(alpha=c["alpha"], prior_type="gauss_bernoulli", output_type="modulus",
+                                      prior_rho=c["rho"])
+        se = T.StateEvolution(model)
+        rec = []
+        stop = T.EarlyStopping()
+
+        def cb(algo, i, max_iter):
+            rec.append((algo.get_edges_data(), algo.get_variables_data()))
+            return stop(algo, i, max_iter)
+        se.iterate(max_iter=60, callback=cb, initializer=T.ConstantInit(a=c["a0"]))
+        assert abs(se.n_iter - c["n_iter"]) <= 1
+        t = c["traj"]
+        for it in range(min(len(rec), t["v:x"].shape[0])):
+            rt = 1e-5 if it < 8 else 1e-3           # quadrature differences compound over the recursion
+            for vid in ("x", "z"):
+                a_tot = t[f"fwd:{vid}:a"][it] + t[f"bwd:{vid}:a"][it]
+                close(rec[it][0][(vid, "fwd")], t[f"fwd:{vid}:a"][it], rt, scale=a_tot)
+                close(rec[it][0][(vid, "bwd")], t[f"bwd:{vid}:a"][it], rt, scale=a_tot)
+                close(rec[it][1][vid]["v"], t[f"v:{vid}"][it], rt)

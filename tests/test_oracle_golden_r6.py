@@ -140,3 +140,22 @@ def test_phase_retrieval_ep_trajectories(golden_complex):
             res = orc.ep_chain(fs, [(2, N), (2, M)], max_iter=25, damping=c["damping"], record=record, init=init)
         assert res["n_iter"] == c["n_iter"]
         _check_traj(recs, c["traj"], ["x", "z"])
+
+
+def test_modulus_se_error_and_phase_retrieval_se(golden_complex):
+    assert len(golden_complex["se"]) == 10
+    for c in golden_complex["se"]:
+        v = orc.se_modulus_lik_error(c["az"], c["tau_z"])
+        close(v, c["v"], 1e-9)
+        close(orc.a_new(v, c["az"]), c["a_new"], 1e-7)
+    for c in golden_complex["se_traj"][:1]:
+        fs = [orc.GBPriorFactor(None, rho=c["rho"]), orc.MPFactor(c["alpha"]), orc.ModulusLikFactor(None)]
+        recs = []
+        res = orc.se_chain(fs, max_iter=60, a0=c["a0"], record=lambda it, f, b, v: recs.append((f, b, v)))
+        assert res["n_iter"] == c["n_iter"]
+        t = c["traj"]
+        for it in range(len(recs)):
+            for i, vid in enumerate(["x", "z"]):
+                close(recs[it][0][i], t[f"fwd:{vid}:a"][it], 1e-5)
+                close(recs[it][1][i], t[f"bwd:{vid}:a"][it], 1e-5)
+                close(recs[it][2][i], t[f"v:{vid}"][it], 1e-5)

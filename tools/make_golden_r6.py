@@ -188,12 +188,40 @@ def complex_cases():
     return mod, lin, ep
 
 
+def modulus_se_cases():
+    "ModulusLikelihood.compute_backward_error on a grid, and the SE trajectory of phase retrieval (alpha = 2.5, rho = 0.5)"
+    from tramp.models import glm_state_evolution
+    from tramp.algos import StateEvolution, EarlyStopping, ConstantInit
+    lk = ModulusLikelihood(y=None)
+    grid = []
+    for az, tau in [(1.3, 1.0), (2.0, 1.0), (0.5, 2.0), (1.0, 1.0), (5.0, 1.0), (1.05, 1.0), (40.0, 1.0), (0.9, 3.0),
+                    (300.0, 0.5), (1.0 + 1e-6, 1.0)]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            grid.append(dict(az=az, tau_z=tau, v=float(lk.compute_backward_error(az, tau)),
+                             a_new=float(lk.compute_backward_state_evolution(az, tau))))
+        print("se modulus", az, tau, grid[-1]["v"])
+    trajs = []
+    for alpha, rho, a0 in [(2.5, 0.5, 0.1), (1.6, 0.3, 1.0)]:
+        model = glm_state_evolution(alpha=alpha, prior_type="gauss_bernoulli", output_type="modulus", prior_rho=rho)
+        se = StateEvolution(model)
+        rec = mg.Recorder(EarlyStopping())
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            se.iterate(max_iter=60, callback=rec, initializer=ConstantInit(a=a0))
+        trajs.append(dict(alpha=alpha, rho=rho, a0=a0, n_iter=se.n_iter, tau=model.get_second_moments(),
+                          traj=mg.pack_traj(rec.iters)))
+        print("se phase retrieval", alpha, rho, "n_iter", se.n_iter, rec.iters[-1])
+    return grid, trajs
+
+
 def main():
     mg.save("priors2", cases=np.array(prior_cases(), dtype=object), se=np.array(se_cases(), dtype=object),
             ep=np.array(ep_cases(), dtype=object))
     mod, lin, ep = complex_cases()
+    grid, trajs = modulus_se_cases()
     mg.save("complex", modulus=np.array(mod, dtype=object), linear=np.array(lin, dtype=object),
-            ep=np.array(ep, dtype=object))
+            ep=np.array(ep, dtype=object), se=np.array(grid, dtype=object), se_traj=np.array(trajs, dtype=object))
 
 
 if __name__ == "__main__":

@@ -156,6 +156,7 @@ _SIGNATURES = {
     "tramp_se_mp_channel": [vp, i32, sz, vp, vp, vp, vp, vp, vp],
     "tramp_se_sgn_lik": [vp, sz, vp, vp, vp],
     "tramp_se_abs_lik": [vp, sz, vp, vp, vp],
+    "tramp_se_modulus_lik": [vp, sz, vp, vp, vp],
     "tramp_se_pwl_channel": [vp, i32, i32, sz, vp, vp, vp, vp],
     "tramp_randn": [vp, i32, vp, sz, u64, dbl],
     "tramp_ep_monitor": [vp, i32, i32, sz, vp, vp, dbl, dbl, i32, vp, vp, vp, vp, vp],

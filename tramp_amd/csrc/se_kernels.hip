@@ -306,6 +306,18 @@ __device__ __forceinline__ double abs_lik_integrand(double x1, double x2, double
     return (y * y) * (1.0 - t * t);
 }
 
+// KIND 6: ModulusLikelihood.beliefs_measure for u_eff = az tau - 1 > 0 (modulus_likelihood.py:111-120):
+//   b = sqrt(az u_eff) x1, y = b / az + x2 / sqrt(az),
+//   f = (2 pi / sqrt(u_eff)) relu(b) relu(y) ive(0, b y) v(b, y),  v = y^2 (1 - I(b y)^2) / 2   (:64-70)
+__device__ __forceinline__ double modulus_lik_integrand(double x1, double x2, double az, double tau) {
+    const double u_eff = az * tau - 1.0;
+    const double b = sqrt(az * u_eff) * x1;
+    const double y = b / az + x2 / sqrt(az);
+    if (!(b > 0.0) || !(y > 0.0)) return 0.0;
+    const double I = tmath::bessel_i1_over_i0(b * y);
+    return (2 * tmath::kPi / sqrt(u_eff)) * b * y * tmath::bessel_i0e(b * y) * (0.5 * (y * y) * (1.0 - I * I));
+}
+
 // grid: (strips, count); each block integrates a strip of x1 nodes against ALL x2 nodes.
 // nodes: [2][n] = x, w*pdf(x) for the uniform mesh (precomputed by se_nodes_kernel).
 template <int KIND, bool FWD>
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void se_2d_kernel(Se2dParams P, const doubl
                                                        int strip, double* __restrict__ partials) {
     __shared__ double smem[kBlock / kWave];
     const int pt = blockIdx.y;
-    const double az = P.az[pt], ax = (KIND == 3) ? 0.0 : P.ax[pt], tau = P.tau[pt];
+    const double az = P.az[pt], ax = (KIND == 3 || KIND == 6) ? 0.0 : P.ax[pt], tau = P.tau[pt];
     const double* xs = nodes;
     const double* ws = nodes + n;
     const int i0 = blockIdx.x * strip;
@@ -326,8 +338,9 @@ __global__ __launch_bounds__(kBlock) void se_2d_kernel(Se2dParams P, const doubl
             const double x2 = xs[j];
             double f;
             if (KIND == 3) f = abs_lik_integrand(x1, x2, az, tau);
+            else if (KIND == 6) f = modulus_lik_integrand(x1, x2, az, tau);
             else if (KIND == 5) f = pwl3_integrand<FWD>(x1, x2, az, ax, tau, P.spec3);
-            else f = pwl_integrand<(KIND == 3 || KIND == 5 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
+            else f = pwl_integrand<(KIND == 3 || KIND == 5 || KIND == 6 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
             row += ws[j] * f;
         }
         acc += w1 * row;
@@ -572,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void se_2d_refine_kernel(Se2dParams P, int 
     const int e = blockIdx.x;
     if (e >= n_in) return;
     const SePanel p = in[e];
-    const double az = P.az[pt], ax = (KIND == 3) ? 0.0 : P.ax[pt], tau = P.tau[pt];
+    const double az = P.az[pt], ax = (KIND == 3 || KIND == 6) ? 0.0 : P.ax[pt], tau = P.tau[pt];
     const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double hc = 0.5 * p.h;                                  // child edge
     const double cx0 = p.x0 + (c & 1) * hc, cy0 = p.y0 + (c >> 1) * hc;
@@ -582,8 +595,9 @@ __global__ __launch_bounds__(kBlock) void se_2d_refine_kernel(Se2dParams P, int 
     const double w = 0.25 * hc * hc * kGLw[gi] * kGLw[gj] * norm_pdf(x1) * norm_pdf(x2);
     double f;
     if (KIND == 3) f = abs_lik_integrand(x1, x2, az, tau);
+    else if (KIND == 6) f = modulus_lik_integrand(x1, x2, az, tau);
     else if (KIND == 5) f = pwl3_integrand<FWD>(x1, x2, az, ax, tau, P.spec3);
-    else f = pwl_integrand<(KIND == 3 || KIND == 5 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
+    else f = pwl_integrand<(KIND == 3 || KIND == 5 || KIND == 6 ? 0 : KIND), FWD>(x1, x2, az, ax, tau, P.spec);
     double v = w * f;
     v = wave_sum(v);
     if (lane == 0) child_int[c] = v;
@@ -765,6 +779,32 @@ extern "C" int tramp_se_abs_lik(tramp_ctx* ctx, size_t count, const double* az, 
     if (!count) return TRAMP_OK;
     for (size_t i = 0; i < count; ++i) TRAMP_REQUIRE(ctx, az[i] - 1.0 / tau_z[i] > 0.0);   // abs_likelihood.py:61-62
     return se_2d_run<3, false>(ctx, count, az, nullptr, tau_z, v);
+}
+
+extern "C" int tramp_se_modulus_lik(tramp_ctx* ctx, size_t count, const double* az, const double* tau_z, double* v) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az && tau_z && v);
+    if (!count) return TRAMP_OK;
+    // u_eff = max(0, az tau - 1) = 0 (modulus_likelihood.py:103-110): the 1-D average of sqrt(2 pi az) relu(y) y^2 / 2 over
+    // y = xi / sqrt(az) is 1 / az in closed form (int_0^inf xi^3 N(xi) = 2 / sqrt(2 pi)); those points never reach the device
+    std::vector<double> a2, t2;
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < count; ++i) {
+        TRAMP_REQUIRE(ctx, az[i] > 0.0 && tau_z[i] > 0.0);
+        if (az[i] * tau_z[i] - 1.0 > 0.0) {
+            a2.push_back(az[i]);
+            t2.push_back(tau_z[i]);
+            idx.push_back(i);
+        } else {
+            v[i] = 1.0 / az[i];
+        }
+    }
+    if (idx.empty()) return TRAMP_OK;
+    std::vector<double> out(idx.size());
+    int rc = se_2d_run<6, false>(ctx, idx.size(), a2.data(), nullptr, t2.data(), out.data());
+    if (rc) return rc;
+    for (size_t j = 0; j < idx.size(); ++j) v[idx[j]] = out[j];
+    return TRAMP_OK;
 }
 
 extern "C" int tramp_se_pwl_channel(tramp_ctx* ctx, int kind, int dir, size_t count, const double* az,

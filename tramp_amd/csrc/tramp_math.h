@@ -1430,6 +1430,30 @@ TM_HD double bessel_i1_over_i0(double x) {
     return x < 0.0 ? -ratio : ratio;
 }
 
+// scipy's ive(0, x) = exp(-|x|) I0(x), the same two expansions as bessel_i1_over_i0
+TM_HD double bessel_i0e(double x) {
+    const double ax = ::fabs(x);
+    if (ax <= 25.0) {
+        const double t = 0.25 * ax * ax;
+        double t0 = 1.0, s0 = 1.0;
+#pragma unroll
+        for (int k = 1; k <= 48; ++k) {
+            t0 *= t * (1.0 / ((double)k * (double)k));
+            s0 += t0;
+        }
+        return s0 * ::exp(-ax);
+    }
+    const double z = 1.0 / ax;
+    double t0 = 1.0, s0 = 1.0;
+#pragma unroll
+    for (int k = 1; k <= 18; ++k) {
+        const double q = (double)(2 * k - 1) * (double)(2 * k - 1);
+        t0 *= z * (q * (1.0 / (8.0 * (double)k)));
+        s0 += t0;
+    }
+    return s0 / ::sqrt(2 * kPi * ax);
+}
+
 // posterior of one complex component: bz = (re, im), y = |z| observed.  rz = (bz / |bz|) y I(|bz| y) (0 where bz = 0),
 // v = y^2 (1 - I^2) / 2 (the 1/2 averages the two real coordinates).  |bz| is np.absolute of the complex number (hypot).
 struct ModOut { double re, im, v; };

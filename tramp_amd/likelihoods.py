@@ -368,8 +368,12 @@ class ModulusLikelihood(Likelihood):
         return float(res[0]) if (hs is not None and a.was_host and a.scalar_like and len(hs) == 2) else res
 
     def compute_backward_error(self, az, tau_z):
-        raise NotImplementedError("ModulusLikelihood.compute_backward_error (the 2-D Bessel-weighted average of "
-                                  "modulus_likelihood.py:101-120) is not on the HIP path")
+        "beliefs_measure modulus_likelihood.py:101-120 (2-D Bessel-weighted average, K14 family: tramp_se_modulus_lik)"
+        az_h = np.atleast_1d(np.asarray(az, dtype=np.float64))
+        tz = np.broadcast_to(np.asarray(tau_z, dtype=np.float64), az_h.shape).copy()
+        v = np.empty_like(az_h)
+        self.ctx._call("tramp_se_modulus_lik", az_h.shape[0], az_h.ctypes.data, tz.ctypes.data, v.ctypes.data)
+        return float(v[0]) if np.ndim(az) == 0 else v
 
 
 class ReluLikelihood(Likelihood):
