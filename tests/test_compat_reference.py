@@ -199,6 +199,32 @@ class FakeLib:
     def _tramp_abs_lik_bwd(self, ctx, dtype, n, batch, az_d, bz_d, y_d, damping, a_old, b_old, a_new_d, b_new_d, r_d, v_d):
         self._lik(orc.abs_lik_message, n, az_d, bz_d, y_d, a_new_d, b_new_d)
 
+    # round 6
+    def _tramp_binary_prior_fwd(self, ctx, dtype, n, batch, ax_d, bx_d, b0, damping, a_old, b_old, a_new_d, b_new_d, r_d, v_d):
+        n = self._n(n)
+        ax, bx = self.view(ax_d, 1, "ax")[0], self.view(bx_d, n, "bx")
+        r = np.tanh(bx + b0)                                   # binary_prior.py:52-58 with the natural parameter itself
+        self._out(a_new_d, b_new_d, n, *orc.ab_new(r, (1 - r**2).mean(), ax, bx.copy()))
+
+    def _tramp_halfline_prior_fwd(self, ctx, dtype, n, batch, ax_d, bx_d, a0, b0, damping, a_old, b_old, a_new_d, b_new_d, r_d, v_d):
+        n = self._n(n)
+        ax, bx = self.view(ax_d, 1, "ax")[0], self.view(bx_d, n, "bx").copy()
+        r, v = orc.positive_rv(ax + a0, bx + b0)
+        self._out(a_new_d, b_new_d, n, *orc.ab_new(r, v.mean(), ax, bx))
+
+    def _tramp_gm_prior_fwd(self, ctx, dtype, n, batch, ax_d, bx_d, K, probs, means, vars_, damping, a_old, b_old, a_new_d, b_new_d,
+                            r_d, v_d):
+        n = self._n(n)
+        ax, bx = self.view(ax_d, 1, "ax")[0], self.view(bx_d, n, "bx").copy()
+        assert len(probs) == len(means) == len(vars_) == K, "the mixture tables are HOST arrays of K doubles"
+        self._out(a_new_d, b_new_d, n, *orc.gm_prior_message(ax, bx, list(probs), list(means), list(vars_)))
+
+    def _tramp_modulus_lik_bwd(self, ctx, dtype, n, batch, az_d, bz_d, y_d, damping, a_old, b_old, a_new_d, b_new_d, r_d, v_d):
+        n = self._n(n)
+        az, bz, y = self.view(az_d, 1, "az")[0], self.view(bz_d, 2 * n, "bz").copy().reshape(2, n), self.view(y_d, n, "y").copy()
+        a_new, b_new = orc.modulus_lik_message(az, bz, y)
+        self._out(a_new_d, b_new_d, 2 * n, a_new, b_new.reshape(-1))
+
     def _tramp_pwl_channel(self, ctx, dtype, kind, direction, n, batch, az_d, bz_d, ax_d, bx_d, damping, a_old, b_old, a_new_d,
                            b_new_d, r_d, v_d, mask_d):
         n = self._n(n)
@@ -266,6 +292,31 @@ def build(ref, which):
     if which == "cs1bit":
         W, x, y = teacher(2, 64, 0.7, 0.25, "sgn", None)
         return (GaussBernoulliPrior(size=64, rho=0.25) @ V(id="x") @ LinearChannel(W) @ V(id="z") @ SgnLikelihood(y=y)).to_model(), 4
+    if which == "phase_retrieval":
+        from tramp.channels import ComplexLinearChannel
+        from tramp.likelihoods import ModulusLikelihood
+        rs = np.random.RandomState(3)
+        N, M = 32, 80
+        W = (rs.standard_normal((M, N)) + 1j * rs.standard_normal((M, N))) / np.sqrt(2 * N)
+        x = rs.standard_normal((2, N)) * rs.binomial(1, 0.6, (2, N))
+        y = np.abs(W @ (x[0] + 1j * x[1]))
+        return (GaussBernoulliPrior(size=(2, N), rho=0.6) @ V(id="x") @ ComplexLinearChannel(W) @ V(id="z")
+                @ ModulusLikelihood(y=y)).to_model(), 4
+    if which in ("exp_glm", "positive_glm", "mixture_glm", "binary_glm"):
+        from tramp.priors import ExponentialPrior, PositivePrior, GaussianMixturePrior, BinaryPrior
+        rs = np.random.RandomState(5)
+        N, M = 48, 32
+        W = rs.randn(M, N) / np.sqrt(N)
+        prior = dict(exp_glm=lambda: ExponentialPrior(size=N, mean=0.7), positive_glm=lambda: PositivePrior(size=N),
+                     mixture_glm=lambda: GaussianMixturePrior(size=N, probs=[0.2, 0.5, 0.3], means=[-2.0, 0.0, 1.5],
+                                                              vars=[0.3, 0.01, 2.0]),
+                     binary_glm=lambda: BinaryPrior(size=N, p_pos=0.3))[which]()
+        x = np.abs(rs.standard_normal(N)) if which != "binary_glm" else np.sign(rs.standard_normal(N))
+        # (binary: a noisy problem - once tanh saturates, v = 1 - r^2 is round-off and a_new = 1 / v amplifies an ulp of the
+        #  incoming message to 1e-5 of the outgoing one, in the reference's own run as in any other)
+        nv = 2.0 if which == "binary_glm" else 1e-2
+        y = W @ x + np.sqrt(nv) * rs.standard_normal(M)
+        return (prior @ V(id="x") @ LinearChannel(W) @ V(id="z") @ GaussianLikelihood(y=y, var=nv)).to_model(), 4
     rs = np.random.RandomState(1)
     N, M1, M2 = 64, 128, 32
     W1, W2 = rs.randn(M1, N) / np.sqrt(N), rs.randn(M2, M1) / np.sqrt(M1)
@@ -275,10 +326,10 @@ def build(ref, which):
             @ LinearChannel(W2) @ V(id="z2") @ GaussianLikelihood(y=y, var=1e-2)).to_model(), 7
 
 
-def run(ref, model, n_iter, damping):
+def run(ref, model, n_iter, damping, init=None):
     from tramp.algos import ExpectationPropagation
     ep = ExpectationPropagation(model)
-    ep.iterate(max_iter=n_iter, damping=damping)
+    ep.iterate(max_iter=n_iter, damping=damping, initializer=init)
     data = ep.get_variables_data()
     msgs = {(str(s), str(t)): (d["a"], np.array(d["b"], copy=True)) for s, t, d in ep.message_dag.edges(data=True)
             if "a" in d}
@@ -325,6 +376,50 @@ def test_reference_iterate_runs_through_the_c_abi(ref, which, damping):
            "two_layer": ["tramp_gauss_lik_bwd", "tramp_linear_message", "tramp_pwl_channel", "tramp_linear_message"]}[which]
     assert compute == (fwd + bwd) * it1, compute[:12]
     # every buffer was released, every call converted to the header's argument types (checked in FakeLib._convert)
+    live = sum(nb for _, nb in lib.buffers.values())
+    factors = sum(8 * (h["M"] * h["k"] + h["k"] * h["N"] + h["k"]) for h in lib.handles.values())
+    assert live == factors, "message buffers leaked"
+
+
+@pytest.mark.parametrize("which", ["phase_retrieval", "exp_glm", "positive_glm", "mixture_glm", "binary_glm"])
+def test_reference_iterate_runs_the_round6_factors_through_the_c_abi(ref, which):
+    """the factors added in round 6 under the reference's own scheduler: phase retrieval (GaussBernoulliPrior on a planar
+    (2, N) variable -> ComplexLinearChannel -> ModulusLikelihood) and sparse regression behind the Exponential / Positive /
+    GaussianMixture / Binary priors"""
+    from tramp.algos import ConstantInit, CustomInit
+    from tramp_amd import compat
+    np.random.seed(0)
+    n_iter, damping = 6, 0.3
+    if which == "phase_retrieval":
+        b0 = np.random.RandomState(9).standard_normal((2, 32))
+        init = CustomInit(a_init=[("x", "bwd", 0.1)], b_init=[("x", "bwd", b0)], a=0, b=0)
+    else:
+        init = ConstantInit(a=1e-3 if which == "exp_glm" else 0, b=0)
+    model, _ = build(ref, which)
+    with np.errstate(all="ignore"):
+        data0, msgs0, it0 = run(ref, model, n_iter, damping, init)
+    lib = FakeLib()
+    binding = compat.bind_reference(compat.Backend(lib=lib))
+    try:
+        model_b, _ = build(ref, which)
+        assert lib.calls.count("tramp_linear_create") == 1
+        start = len(lib.calls)
+        with np.errstate(all="ignore"):
+            data1, msgs1, it1 = run(ref, model_b, n_iter, damping, init)
+        compute = [c for c in lib.calls[start:] if c not in ("tramp_buf_alloc", "tramp_buf_free", "tramp_h2d", "tramp_d2h")]
+    finally:
+        binding.unbind()
+    assert it1 == it0
+    for vid in data0:
+        np.testing.assert_allclose(data1[vid]["r"], data0[vid]["r"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(data1[vid]["v"], data0[vid]["v"], rtol=1e-8)
+    for key in msgs0:
+        np.testing.assert_allclose(msgs1[key][0], msgs0[key][0], rtol=1e-8)
+        np.testing.assert_allclose(msgs1[key][1], msgs0[key][1], rtol=1e-8, atol=1e-8 * max(np.abs(msgs0[key][1]).max(), 1e-6))
+    prior = dict(phase_retrieval="tramp_gb_prior_fwd", exp_glm="tramp_halfline_prior_fwd", positive_glm="tramp_halfline_prior_fwd",
+                 mixture_glm="tramp_gm_prior_fwd", binary_glm="tramp_binary_prior_fwd")[which]
+    lik = "tramp_modulus_lik_bwd" if which == "phase_retrieval" else "tramp_gauss_lik_bwd"
+    assert compute == ([prior, "tramp_linear_message"] + [lik, "tramp_linear_message"]) * it1, compute[:8]
     live = sum(nb for _, nb in lib.buffers.values())
     factors = sum(8 * (h["M"] * h["k"] + h["k"] * h["N"] + h["k"]) for h in lib.handles.values())
     assert live == factors, "message buffers leaked"

@@ -71,3 +71,37 @@ def test_linear_channel_from_the_reference_svd(be, shape):
             close(be.linear_message(h, L.BWD, az, bz, ax, bx), lin.backward_message(az, bz, ax, bx))
     finally:
         be.linear_destroy(h)
+
+
+def test_round6_priors_modulus_and_complex_channel(be):
+    """the strict-mode calls the round-6 bindings make (tests/test_compat_reference.py runs the same ones under the
+    reference's own iterate()): Binary / Exponential / Positive / GaussianMixture priors, ModulusLikelihood and the
+    ComplexLinearChannel built from the reference's complex SVD in its real embedding"""
+    from tramp_amd import _lib as L
+    rs = np.random.RandomState(8)
+    n = 777
+    b = rs.standard_normal(n) * 2
+    r = np.tanh(b + 0.5 * np.log(0.3 / 0.7))
+    close(be.binary_prior_forward_message(1.3, b, 0.3), orc.ab_new(r, (1 - r**2).mean(), 1.3, b))
+    close(be.halfline_prior_forward_message(1.3, b, 0.0, -1 / 0.7), orc.exp_prior_message(1.3, b, mean=0.7))
+    close(be.halfline_prior_forward_message(0.6, b, 1.0, 0.0), orc.positive_prior_message(0.6, b))
+    mix = ([0.2, 0.5, 0.3], [-2.0, 0.0, 1.5], [0.3, 0.01, 2.0])
+    close(be.gm_prior_forward_message(1.3, b, *mix), orc.gm_prior_message(1.3, b, *mix))
+    bz = rs.standard_normal((2, n)) * 1.5
+    y = np.abs(rs.standard_normal(n) + 1j * rs.standard_normal(n))
+    got = be.modulus_lik_backward_message(1.7, bz, y)
+    assert got[1].shape == (2, n)
+    close(got, orc.modulus_lik_message(1.7, bz, y))
+    for M, N in ((24, 16), (16, 24)):
+        W = (rs.standard_normal((M, N)) + 1j * rs.standard_normal((M, N))) / np.sqrt(2 * N)
+        lin = orc.ComplexLinearOracle(W)
+        h = be.complex_linear_create(lin.U, lin.S, lin.V, lin.rank)
+        try:
+            cz, cx = rs.standard_normal((2, N)), rs.standard_normal((2, M))
+            for az, ax in ((1.3, 0.7), (0.4, 5.0)):
+                a, bb = be.linear_message(h, L.FWD, az, cz.reshape(-1), ax, cx.reshape(-1))
+                close((a, bb.reshape(2, M)), lin.forward_message(az, cz, ax, cx))
+                a, bb = be.linear_message(h, L.BWD, az, cz.reshape(-1), ax, cx.reshape(-1))
+                close((a, bb.reshape(2, N)), lin.backward_message(az, cz, ax, cx))
+        finally:
+            be.linear_destroy(h)

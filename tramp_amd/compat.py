@@ -24,6 +24,14 @@ What is bound (reference method -> entry point):
                                                   (channels/base_channel.py:9-17, piecewise_linear_channel.py:27-53) -> tramp_pwl_channel
     LinearChannel.__init__ (keeps the reference's own SVD, uploads its thin factors once)                     -> tramp_linear_create
     LinearChannel.compute_forward_message, compute_backward_message (linear_channel.py:69-117)                -> tramp_linear_message
+  round 6:
+    BinaryPrior.compute_forward_message           (priors/binary_prior.py:52-58)                              -> tramp_binary_prior_fwd
+    ExponentialPrior / PositivePrior.compute_forward_message (priors/exponential_prior.py:54-60, positive_prior.py:56-63)
+                                                                                                               -> tramp_halfline_prior_fwd
+    GaussianMixturePrior.compute_forward_message  (priors/gaussian_mixture_prior.py:88-97)                    -> tramp_gm_prior_fwd
+    ModulusLikelihood.compute_backward_message    (likelihoods/modulus_likelihood.py:82-93)                   -> tramp_modulus_lik_bwd
+    ComplexLinearChannel.__init__ / compute_*_message (channels/linear/complex_linear_channel.py:36-141): the thin factors of
+        the reference's complex SVD in their real embedding [[Re, -Im], [Im, Re]]              -> tramp_linear_create / _message
 
 `Backend(lib=...)` takes any object with the library's entry points as attributes: the real `ctypes.CDLL` (default) or
 the recording stand-in of tests/test_compat_reference.py, which checks every call against `tramp_amd._lib._SIGNATURES`
@@ -136,7 +144,47 @@ class Backend:
                         "tramp_gauss_prior_fwd")
             return self._finish(s, d_a, d_b, n, bx.shape)
 
+    def binary_prior_forward_message(self, ax, bx, p_pos):
+        bx = np.asarray(bx, dtype=np.float64)
+        n = bx.size
+        with self._Scope(self) as s:
+            d_ax, d_bx, d_a, d_b = s.up([ax]), s.up(bx.ravel()), s.out(1), s.out(n)
+            self._check(self.lib.tramp_binary_prior_fwd(self.ctx, L.F64, sz(n), sz(1), d_ax, d_bx, float(0.5 * np.log(p_pos / (1 - p_pos))),
+                                                        0.0, None, None, d_a, d_b, None, None), "tramp_binary_prior_fwd")
+            return self._finish(s, d_a, d_b, n, bx.shape)
+
+    def halfline_prior_forward_message(self, ax, bx, a0, b0):
+        "ExponentialPrior (a0 = 0, b0 = -1/mean) and PositivePrior (a0 = 1, b0 = 0)"
+        bx = np.asarray(bx, dtype=np.float64)
+        n = bx.size
+        with self._Scope(self) as s:
+            d_ax, d_bx, d_a, d_b = s.up([ax]), s.up(bx.ravel()), s.out(1), s.out(n)
+            self._check(self.lib.tramp_halfline_prior_fwd(self.ctx, L.F64, sz(n), sz(1), d_ax, d_bx, float(a0), float(b0), 0.0, None,
+                                                          None, d_a, d_b, None, None), "tramp_halfline_prior_fwd")
+            return self._finish(s, d_a, d_b, n, bx.shape)
+
+    def gm_prior_forward_message(self, ax, bx, probs, means, vars_):
+        bx = np.asarray(bx, dtype=np.float64)
+        n, K = bx.size, len(probs)
+        tabs = [(C.c_double * K)(*[float(x) for x in t]) for t in (probs, means, vars_)]
+        with self._Scope(self) as s:
+            d_ax, d_bx, d_a, d_b = s.up([ax]), s.up(bx.ravel()), s.out(1), s.out(n)
+            self._check(self.lib.tramp_gm_prior_fwd(self.ctx, L.F64, sz(n), sz(1), d_ax, d_bx, int(K), tabs[0], tabs[1], tabs[2], 0.0,
+                                                    None, None, d_a, d_b, None, None), "tramp_gm_prior_fwd")
+            return self._finish(s, d_a, d_b, n, bx.shape)
+
     # ---- likelihoods: (az, bz; y) -> (az_new, bz_new)
+    def modulus_lik_backward_message(self, az, bz, y):
+        "bz planar (2, n) (tramp/utils/misc.py:13-27), y = |z| of n components"
+        bz, y = np.asarray(bz, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        n = y.size
+        assert bz.shape == (2,) + y.shape, "the message of a ModulusLikelihood is the planar array (2,) + y.shape"
+        with self._Scope(self) as s:
+            d_az, d_bz, d_y, d_a, d_b = s.up([az]), s.up(bz.ravel()), s.up(y.ravel()), s.out(1), s.out(2 * n)
+            self._check(self.lib.tramp_modulus_lik_bwd(self.ctx, L.F64, sz(n), sz(1), d_az, d_bz, d_y, 0.0, None, None, d_a, d_b,
+                                                       None, None), "tramp_modulus_lik_bwd")
+            return self._finish(s, d_a, d_b, 2 * n, bz.shape)
+
     def gauss_lik_backward_message(self, bz, y, var):
         y = np.asarray(y, dtype=np.float64)
         n = y.size
@@ -185,6 +233,25 @@ class Backend:
         self._check(self.lib.tramp_linear_create(self.ctx, L.F64, sz(M), sz(N), sz(int(rank)), bufs[0], bufs[1], bufs[2], C.byref(h)),
                     "tramp_linear_create")
         return h, bufs, (M, N)
+
+    def complex_linear_create(self, U, S, V, rank):
+        """ComplexLinearChannel: the reference's complex SVD W = U S V^H (complex_linear_channel.py:8-15) in the real
+        embedding E(A) = [[Re A, -Im A], [Im A, Re A]] (E is multiplicative and E(A^H) = E(A)^T): W_r = E(U_k) diag(s, s)
+        E(V_k)^T acts on planar vectors [Re; Im] - the same thin-factor handle as a real channel of shape [2M, 2N]"""
+        M, N = U.shape[0], V.shape[0]
+        k = min(M, N)
+        sing = np.zeros(k)
+        d = np.real(np.diag(S))
+        sing[:d.size] = d[:k]
+
+        def emb(A):
+            return np.block([[A.real, -A.imag], [A.imag, A.real]])
+        Uk, Vk = emb(U[:, :k]), emb(V[:, :k])
+        bufs = [self.upload(np.ascontiguousarray(Uk)), self.upload(np.ascontiguousarray(Vk.T)), self.upload(np.concatenate([sing, sing]))]
+        h = vp()
+        self._check(self.lib.tramp_linear_create(self.ctx, L.F64, sz(2 * M), sz(2 * N), sz(2 * int(rank)), bufs[0], bufs[1], bufs[2],
+                                                 C.byref(h)), "tramp_linear_create")
+        return h, bufs, (2 * M, 2 * N)
 
     def linear_destroy(self, handle):
         h, bufs, _ = handle
@@ -300,4 +367,56 @@ def bind_reference(backend=None):
     b._patch(tc.LinearChannel, "__init__", linear_init)
     b._patch(tc.LinearChannel, "compute_forward_message", linear_fwd)
     b._patch(tc.LinearChannel, "compute_backward_message", linear_bwd)
+
+    # ---- round 6: the rest of the separable priors and the complex factors of phase retrieval
+    def binary_fwd(self, ax, bx):
+        return be.binary_prior_forward_message(ax, bx, self.p_pos)
+
+    def exp_fwd(self, ax, bx):
+        return be.halfline_prior_forward_message(ax, bx, 0.0, self.b)           # exponential_prior.py:26, 54-60
+
+    def positive_fwd(self, ax, bx):
+        return be.halfline_prior_forward_message(ax, bx, self.a, self.b)         # positive_prior.py:23-25, 56-63
+
+    def gm_fwd(self, ax, bx):
+        return be.gm_prior_forward_message(ax, bx, self.probs, self.means, self.vars)
+
+    def modulus_bwd(self, az, bz):
+        return be.modulus_lik_backward_message(az, bz, self.y)
+
+    b._patch(tp.BinaryPrior, "compute_forward_message", binary_fwd)
+    b._patch(tp.ExponentialPrior, "compute_forward_message", exp_fwd)
+    b._patch(tp.PositivePrior, "compute_forward_message", positive_fwd)
+    b._patch(tp.GaussianMixturePrior, "compute_forward_message", gm_fwd)
+    b._patch(tl.ModulusLikelihood, "compute_backward_message", modulus_bwd)
+
+    clin_init = tc.ComplexLinearChannel.__init__
+    clin_fwd, clin_bwd = tc.ComplexLinearChannel.compute_forward_message, tc.ComplexLinearChannel.compute_backward_message
+
+    def complex_init(self, W, precompute_svd=True, name="W"):
+        clin_init(self, W, precompute_svd=precompute_svd, name=name)
+        self._hip = be.complex_linear_create(self.U, self.S, self.V, self.rank) if precompute_svd else None
+
+    def _chandle(self):
+        h = getattr(self, "_hip", None)
+        if h is None and getattr(self, "precompute_svd", False):
+            h = self._hip = be.complex_linear_create(self.U, self.S, self.V, self.rank)
+        return h
+
+    def _planar_message(h, direction, az, bz, ax, bx):
+        bz, bx = np.asarray(bz, dtype=np.float64), np.asarray(bx, dtype=np.float64)
+        a_new, b_new = be.linear_message(h, direction, az, bz.reshape(-1), ax, bx.reshape(-1))
+        return a_new, b_new.reshape((bx if direction == L.FWD else bz).shape)
+
+    def complex_fwd(self, az, bz, ax, bx):
+        h = _chandle(self)
+        return clin_fwd(self, az, bz, ax, bx) if h is None else _planar_message(h, L.FWD, az, bz, ax, bx)
+
+    def complex_bwd(self, az, bz, ax, bx):
+        h = _chandle(self)
+        return clin_bwd(self, az, bz, ax, bx) if h is None else _planar_message(h, L.BWD, az, bz, ax, bx)
+
+    b._patch(tc.ComplexLinearChannel, "__init__", complex_init)
+    b._patch(tc.ComplexLinearChannel, "compute_forward_message", complex_fwd)
+    b._patch(tc.ComplexLinearChannel, "compute_backward_message", complex_bwd)
     return b
