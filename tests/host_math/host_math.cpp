@@ -50,7 +50,7 @@ static void pwl_any(size_t n, const T* bz, const T* bx, double az, double ax, T*
     }
 }
 template <typename T>
-static void gm(size_t n, const T* bx, double ax, int K, const double* probs, const double* means, const double* vars, T* r, T* v) {
+static void gm(size_t n, const T* bx, double ax, int K, const double* probs, const double* means, const double* vars, T* r, T* v, int fast) {
     GmConst<T> g;
     g.K = K;
     for (int k = 0; k < K; ++k) {
@@ -60,7 +60,9 @@ static void gm(size_t n, const T* bx, double ax, int K, const double* probs, con
         g.inv_a[k] = T(1.0 / ad); g.c1[k] = T(0.5 / ad); g.c0[k] = T(eta + 0.5 * log(2 * kPi / ad)); g.b0[k] = T(b0);
     }
     for (size_t i = 0; i < n; ++i) {
-        RV<T> o = gm_posterior<T>(bx[i], g);
+        RV<T> o = (fast && K == 2) ? gm_posterior_k<T, 2>(bx[i], g)
+                : (fast && K == 3) ? gm_posterior_k<T, 3>(bx[i], g)
+                : (fast && K == 4) ? gm_posterior_k<T, 4>(bx[i], g) : gm_posterior<T>(bx[i], g);
         r[i] = o.r; v[i] = o.v;
     }
 }
@@ -174,8 +176,8 @@ void hm_halfline_prior_f64(size_t n, const double* bx, double ax, double a0, dou
         r[i] = o.r; v[i] = o.v;
     }
 }
-void hm_gm_f64(size_t n, const double* bx, double ax, int K, const double* probs, const double* means, const double* vars, double* r, double* v) { gm<double>(n, bx, ax, K, probs, means, vars, r, v); }
-void hm_gm_f32(size_t n, const float* bx, double ax, int K, const double* probs, const double* means, const double* vars, float* r, float* v) { gm<float>(n, bx, ax, K, probs, means, vars, r, v); }
+void hm_gm_f64(size_t n, const double* bx, double ax, int K, const double* probs, const double* means, const double* vars, double* r, double* v, int fast) { gm<double>(n, bx, ax, K, probs, means, vars, r, v, fast); }
+void hm_gm_f32(size_t n, const float* bx, double ax, int K, const double* probs, const double* means, const double* vars, float* r, float* v, int fast) { gm<float>(n, bx, ax, K, probs, means, vars, r, v, fast); }
 void hm_bessel_ratio(size_t n, const double* x, double* out) {
     for (size_t i = 0; i < n; ++i) out[i] = bessel_i1_over_i0(x[i]);
 }

@@ -328,11 +328,15 @@ def test_halfline_and_mixture_priors(hm, golden_priors2):
         else:
             K = len(kw["probs"])
             pr, me, va = (np.asarray(kw[k], dtype=np.float64) for k in ("probs", "means", "vars"))
-            hm.hm_gm_f64(C.c_size_t(bx.size), ptr(bx), C.c_double(ax), C.c_int(K), ptr(pr), ptr(me), ptr(va), ptr(r), ptr(v))
+            # the run-time form (K <= 8) and the straight-line form of the streaming kernels (K = 2..4, polynomial exp)
+            hm.hm_gm_f64(C.c_size_t(bx.size), ptr(bx), C.c_double(ax), C.c_int(K), ptr(pr), ptr(me), ptr(va), ptr(r), ptr(v), 0)
+            close(r, c["r"], 1e-11)
+            close(v.mean(), c["v"], 1e-10)
+            hm.hm_gm_f64(C.c_size_t(bx.size), ptr(bx), C.c_double(ax), C.c_int(K), ptr(pr), ptr(me), ptr(va), ptr(r), ptr(v), 1)
             b32 = bx.astype(np.float32)
             if np.abs(bx).max() * max(1.0, 1 / ax) < 1e3:          # f32 form inside its range
                 r32, v32 = np.empty_like(b32), np.empty_like(b32)
-                hm.hm_gm_f32(C.c_size_t(bx.size), ptr(b32), C.c_double(ax), C.c_int(K), ptr(pr), ptr(me), ptr(va), ptr(r32), ptr(v32))
+                hm.hm_gm_f32(C.c_size_t(bx.size), ptr(b32), C.c_double(ax), C.c_int(K), ptr(pr), ptr(me), ptr(va), ptr(r32), ptr(v32), 1)
                 close(r32, c["r"], 3e-4)
                 close(v32.mean(dtype=np.float64), c["v"], 1e-3)
         close(r, c["r"], 1e-11)

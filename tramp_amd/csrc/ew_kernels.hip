@@ -591,8 +591,11 @@ static int run_tiles_u(tramp_ctx* ctx, Op op, size_t n, size_t batch, const void
     int tpb = 8;
     while (tpb > 1 && (tiles / tpb) * batch < 4096) tpb >>= 1;
     // redo of a few flagged instances: most workgroups only read their instance's flag and leave - long runs per block keep
-    // the dispatch of those short; two launches (RedoArgs), ~6 us on a clean 64 x 1e6 update
-    if (redo_nan) tpb = 64;
+    // the dispatch of those short; two launches (RedoArgs), ~6 us on a clean 64 x 1e6 update.  16 tiles per block (round 6;
+    // 64 before): a flagged instance of 1e6 components is then 31 workgroups, not 8 - with 2-3 of 64 instances flagged the
+    // redo costs 0.07 ms instead of 0.19 ms, and nothing when none is (tools/probes/probe_exp_prior.py)
+    static const size_t redo_tpb = env_size("TRAMP_EW_REDO_TPB", 16);
+    if (redo_nan) tpb = (int)redo_tpb;
     const unsigned ntile = (unsigned)((tiles + tpb - 1) / tpb);          // blocks (= partials) per instance
     if (hint) {
         store_r = false;
@@ -1167,8 +1170,52 @@ extern "C" int tramp_halfline_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, siz
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     HalfLinePriorOp<float> of{ax_d, a0, b0};
     HalfLinePriorOp<double> od{ax_d, a0, b0};
+    // f64, large batches of large instances: the lean form on the resident pipeline, then the tile kernels for the instances
+    // it could not finish (an erfcx argument beyond the table - an exponential prior at ax << 1 / mean^2 sits there - or a
+    // non-finite message); the count of the previous lean call sends wide messages straight to the tile kernels, as for
+    // the two-region channels (pwl_dir)
+    if (dtype == TRAMP_F64 && n && batch && bx_d && a_new_d && b_new_d && !r_d && (damping == 0.0 || (a_old_d && b_old_d))) {
+        static const size_t adapt = env_size("TRAMP_EW_LEAN_ADAPT", 1);
+        if (ctx->lean_stat && ctx->lean_stat[1]) {
+            if (adapt && 4u * ctx->lean_stat[0] > ctx->lean_stat[1]) ctx->lean_skip = 15;
+            ctx->lean_stat[1] = 0;
+        }
+        if (ctx->lean_skip > 0) {
+            ctx->lean_skip -= 1;
+        } else {
+            const int rc = run_resident<double>(ctx, HalfLinePriorOp<double, true>{ax_d, a0, b0}, n, batch, bx_d, nullptr, ax_d, out);
+            if (rc == TRAMP_OK) return run_tiles<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out, false, nullptr, true);
+            if (rc != kResNotEligible) return rc;
+        }
+    }
     DISPATCH_DTYPE(ctx, dtype, (run_two_pass<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out)),
                    (run_two_pass<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out)));
+}
+
+template <typename T, int KC>
+static int gm_run(tramp_ctx* ctx, int K, const double* probs, const double* means, const double* vars, size_t n, size_t batch,
+                  const double* ax_d, const void* bx_d, const MsgOut& out) {
+    GmOp<T, KC> op{};
+    op.ax = ax_d;
+    TRAMP_REQUIRE(ctx, gm_fill(op, K, probs, means, vars));
+    return run_two_pass<T>(ctx, op, n, batch, bx_d, nullptr, ax_d, out);
+}
+
+template <typename T>
+static int gm_by_k(tramp_ctx* ctx, int K, const double* probs, const double* means, const double* vars, size_t n, size_t batch,
+                   const double* ax_d, const void* bx_d, const MsgOut& out) {
+    switch (K) {
+        case 2: return gm_run<T, 2>(ctx, K, probs, means, vars, n, batch, ax_d, bx_d, out);
+        case 3: return gm_run<T, 3>(ctx, K, probs, means, vars, n, batch, ax_d, bx_d, out);
+        case 4: return gm_run<T, 4>(ctx, K, probs, means, vars, n, batch, ax_d, bx_d, out);
+        default: return gm_run<T, 0>(ctx, K, probs, means, vars, n, batch, ax_d, bx_d, out);
+    }
+}
+
+static int gm_dispatch(tramp_ctx* ctx, int dtype, int K, const double* probs, const double* means, const double* vars, size_t n,
+                       size_t batch, const double* ax_d, const void* bx_d, const MsgOut& out) {
+    DISPATCH_DTYPE(ctx, dtype, (gm_by_k<float>(ctx, K, probs, means, vars, n, batch, ax_d, bx_d, out)),
+                   (gm_by_k<double>(ctx, K, probs, means, vars, n, batch, ax_d, bx_d, out)));
 }
 
 extern "C" int tramp_gm_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch, const double* ax_d,
@@ -1178,19 +1225,7 @@ extern "C" int tramp_gm_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, size_t ba
     if (!ctx) return TRAMP_EINVAL;
     TRAMP_REQUIRE(ctx, ax_d && probs_h && means_h && vars_h && K >= 1 && K <= tmath::kGmMax);
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
-    if (dtype == TRAMP_F32) {
-        GmOp<float> op{};
-        op.ax = ax_d;
-        TRAMP_REQUIRE(ctx, gm_fill(op, K, probs_h, means_h, vars_h));
-        return run_two_pass<float>(ctx, op, n, batch, bx_d, nullptr, ax_d, out);
-    }
-    if (dtype == TRAMP_F64) {
-        GmOp<double> op{};
-        op.ax = ax_d;
-        TRAMP_REQUIRE(ctx, gm_fill(op, K, probs_h, means_h, vars_h));
-        return run_two_pass<double>(ctx, op, n, batch, bx_d, nullptr, ax_d, out);
-    }
-    return tramp_fail(ctx, TRAMP_EINVAL, "invalid argument", "dtype");
+    return gm_dispatch(ctx, dtype, K, probs_h, means_h, vars_h, n, batch, ax_d, bx_d, out);
 }
 
 extern "C" int tramp_sgn_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t batch,

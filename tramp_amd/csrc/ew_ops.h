@@ -81,7 +81,9 @@ template <typename T> struct BinaryOp {   // binary prior p(x) = p+ delta(x - 1)
 // tramp/priors/exponential_prior.py:25-26, 54-60) and PositivePrior (a0 = 1, b0 = 0; positive_prior.py:23-25, 56-63).
 // The posterior is positive.r / positive.v (beliefs/positive.py:12-17) at (ax + a0, bx + b0): the half-line truncated
 // normal of the sign likelihood with y = +1.  in0 = bx
-template <typename T> struct HalfLinePriorOp {
+// LEAN (f64): the resident pipeline's form as for the sign likelihood (tmath::sgn_lik_posterior_lean: no control flow,
+// one-value erfcx table; an argument beyond the table comes back in EwOut::dev and the caller redoes the instance)
+template <typename T, bool LEAN = false> struct HalfLinePriorOp {
     static constexpr bool HEAVY = false;     // as the sign likelihood: recomputed in pass 2
     static constexpr int NIN = 1;
     static constexpr int TARGET = 0;
@@ -92,21 +94,31 @@ template <typename T> struct HalfLinePriorOp {
     // would leave 3 % (tests/test_gpu_r6_factors.py); f32 messages are widened on load and rounded on store.
     tmath::RegionConst<double> c;
     double a_msg;
-    __device__ static void stage() { tmath::erfcx_setup<double>(); }
+    __device__ static void stage() {
+        if (LEAN) tmath::erfcx_setup_tay<double>();
+        else tmath::erfcx_setup<double>();
+    }
     __device__ void prepare(size_t b) {
         a_msg = ax[b];
         c = tmath::region_const<double>(a_msg + a0);
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T) const {
-        RV<double> o = tmath::sgn_lik_posterior_fast<double>((double)x0 + b0, 1.0, c);
-        return {T(o.r), T(o.v), 0u};
+        if constexpr (LEAN) {
+            double dev;
+            RV<double> o = tmath::sgn_lik_posterior_lean<double>((double)x0 + b0, 1.0, c, &dev);
+            return {T(o.r), T(o.v), 0u, T(dev)};
+        } else {
+            RV<double> o = tmath::sgn_lik_posterior_fast<double>((double)x0 + b0, 1.0, c);
+            return {T(o.r), T(o.v), 0u};
+        }
     }
 };
 
 // GaussianMixturePrior (tramp/priors/gaussian_mixture_prior.py:36-39, 88-97; beliefs/mixture.py:23-41), at most
 // tmath::kGmMax components; a0 = 1/var_k, b0 = mean_k/var_k, eta = log p_k - normal.A(a0, b0).  in0 = bx
-template <typename T> struct GmOp {
+// KC: the number of components at compile time (2..4: straight-line code, resident pipeline), 0 = run time (up to kGmMax)
+template <typename T, int KC = 0> struct GmOp {
     static constexpr bool HEAVY = false;
     static constexpr int NIN = 1;
     static constexpr int TARGET = 0;
@@ -120,8 +132,8 @@ template <typename T> struct GmOp {
         a_msg = ax[b];
         g.K = K;
 #pragma unroll
-        for (int k = 0; k < tmath::kGmMax; ++k) {
-            if (k < K) {
+        for (int k = 0; k < (KC ? KC : tmath::kGmMax); ++k) {
+            if (KC || k < K) {
                 const double ad = a_msg + a0[k];
                 const double inv = 1.0 / ad;
                 g.inv_a[k] = T(inv);
@@ -133,7 +145,9 @@ template <typename T> struct GmOp {
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }
     __device__ EwOut<T> eval(T x0, T) const {
-        RV<T> o = tmath::gm_posterior<T>(x0, g);
+        RV<T> o;
+        if constexpr (KC != 0) o = tmath::gm_posterior_k<T, KC>(x0, g);
+        else o = tmath::gm_posterior<T>(x0, g);
         return {o.r, o.v, 0u};
     }
 };
@@ -370,6 +384,7 @@ template <typename T, int KIND, bool FWD, bool UNI> struct OpLean<PwlOp<T, KIND,
 template <typename T> struct OpLean<SgnLikOp<T, true>> { static constexpr bool value = true; };
 template <typename T> struct OpLean<SgnLikBitsOp<T, true>> { static constexpr bool value = true; };
 template <typename T> struct OpLean<ReluLikOp<T, true>> { static constexpr bool value = true; };
+template <typename T> struct OpLean<HalfLinePriorOp<T, true>> { static constexpr bool value = true; };
 
 // OpPair: f32 lean ops with eval2 (two components per call on the packed-f32 pipe)
 template <typename Op> struct OpPair { static constexpr bool value = false; };

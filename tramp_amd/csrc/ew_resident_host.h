@@ -40,6 +40,8 @@ template <typename T> struct ResidentOp<GbOp<T>> { static constexpr bool value =
 template <typename T> struct ResidentOp<L1Op<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<AbsLikOp<T>> { static constexpr bool value = true; };
 template <typename T> struct ResidentOp<BinaryOp<T>> { static constexpr bool value = true; };
+template <typename T> struct ResidentOp<GmOp<T, 2>> { static constexpr bool value = true; };     // straight-line forms only
+template <typename T> struct ResidentOp<GmOp<T, 3>> { static constexpr bool value = true; };
 template <typename T, bool L> struct ResidentOp<ReluLikOp<T, L>> { static constexpr bool value = true; };
 // (the lean forms - the two-region channels K7, the sign likelihood with its observation unpacked or packed - are
 //  launched by their entry points in ew_kernels.hip, which also run the redo of their unfinished instances)

@@ -6,3 +6,8 @@ RES_INSTANTIATE(double, L1Op<double>)
 RES_INSTANTIATE(float, L1Op<float>)
 RES_INSTANTIATE(double, BinaryOp<double>)
 RES_INSTANTIATE(float, BinaryOp<float>)
+RES_INSTANTIATE(double, GmOp<double, 2>)
+RES_INSTANTIATE(float, GmOp<float, 2>)
+RES_INSTANTIATE(double, GmOp<double, 3>)
+RES_INSTANTIATE(float, GmOp<float, 3>)
+RES_INSTANTIATE(double, HalfLinePriorOp<double, true>)

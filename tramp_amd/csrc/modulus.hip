@@ -6,8 +6,9 @@
 //     b = |bz|,  I = I1(b y) / I0(b y),  rz = (bz / b) y I,  v_i = y^2 (1 - I^2) / 2,   v = mean_i v_i   (:82-93)
 // then compute_ab_new on the planar array (tramp/base.py:250-255).  The Bessel ratio is evaluated in double whatever the
 // element type (tramp_math.h: bessel_i1_over_i0).  Three launches like the other separable factors whose update needs
-// the instance mean first: moments -> scalar -> apply (the posterior is recomputed in the apply pass: 3 reads + 2 writes
-// per component instead of parking two planes of r).
+// the instance mean first: moments -> scalar -> apply.  The update is bound by the Bessel ratio (two power series of
+// 10 + 1.6 |bz| y terms per component), so pass 1 parks the ratio I (one double per complex component, workspace) and
+// pass 2 only rebuilds the phase bz / |bz|.
 #include "common.h"
 #include "tramp_math.h"
 
@@ -15,15 +16,19 @@ namespace {
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void modulus_pass1_kernel(size_t n, const T* __restrict__ bz, const T* __restrict__ y,
-                                                               double* __restrict__ partials) {
+                                                               double* __restrict__ partials, double* __restrict__ ratio) {
     __shared__ double smem[kBlock / kWave];
     const size_t b = blockIdx.y;
     const T* re = bz + b * 2 * n;
     const T* im = re + n;
     const T* yy = y + b * n;
     double sv = 0.0;
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (size_t)gridDim.x * kBlock)
-        sv += tmath::modulus_posterior((double)re[j], (double)im[j], (double)yy[j]).v;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (size_t)gridDim.x * kBlock) {
+        const double yv = (double)yy[j];
+        const double I = tmath::bessel_i1_over_i0(::hypot((double)re[j], (double)im[j]) * yv);
+        ratio[b * n + j] = I;
+        sv += 0.5 * (yv * yv) * (1.0 - I * I);
+    }
     sv = block_sum(sv, smem);
     if (threadIdx.x == 0) partials[b * gridDim.x + blockIdx.x] = sv;
 }
@@ -49,15 +54,18 @@ __global__ __launch_bounds__(kBlock) void modulus_finish_kernel(const double* __
 template <typename T>
 __global__ __launch_bounds__(kBlock) void modulus_pass2_kernel(size_t n, const double* __restrict__ az,
                                                                const double* __restrict__ a_raw, const T* bz,
-                                                               const T* __restrict__ y, double damping, const T* b_old,
-                                                               T* b_new, T* r_out) {
+                                                               const T* __restrict__ y, const double* __restrict__ ratio,
+                                                               double damping, const T* b_old, T* b_new, T* r_out) {
     const size_t b = blockIdx.y;
     const double asum = az[b] + a_raw[b];
     const size_t off = b * 2 * n;
     const T* yy = y + b * n;
     for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (size_t)gridDim.x * kBlock) {
         const double re = (double)bz[off + j], im = (double)bz[off + n + j];
-        const tmath::ModOut o = tmath::modulus_posterior(re, im, (double)yy[j]);
+        const double bm = ::hypot(re, im), sc = (double)yy[j] * ratio[b * n + j];
+        tmath::ModOut o;
+        o.re = (bm != 0.0) ? (re / bm) * sc : 0.0;                       // tmath::modulus_posterior with I from pass 1
+        o.im = (bm != 0.0) ? (im / bm) * sc : 0.0;
         double b0 = o.re * asum - re, b1 = o.im * asum - im;
         if (damping != 0.0) {
             b0 = damping * (double)b_old[off + j] + (1.0 - damping) * b0;
@@ -138,29 +146,30 @@ extern "C" int tramp_modulus_lik_bwd(tramp_ctx* ctx, int dtype, size_t n, size_t
     if (!n || !batch) return TRAMP_OK;
     TRAMP_REQUIRE(ctx, batch <= 65535);
     const int nblk = blocks_for(n, 1);
-    int rc = tramp_ws_reserve(ctx, batch * ((size_t)nblk + 1) * sizeof(double));
+    int rc = tramp_ws_reserve(ctx, batch * ((size_t)nblk + 1 + n) * sizeof(double));
     if (rc) return rc;
     double* partials = ctx->ws;
     double* a_raw = ctx->ws + batch * (size_t)nblk;
+    double* ratio = a_raw + batch;
     dim3 grid(nblk, (unsigned)batch);
     // algorithmic traffic: both planes of the message and the observation in, both planes of the update out
     ProfScope prof(ctx, PROF_EW, 5.0 * dtype_size(dtype) * (double)n * (double)batch, 0.0);
     if (dtype == TRAMP_F64)
         hipLaunchKernelGGL((modulus_pass1_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, (const double*)bz_d,
-                           (const double*)y_d, partials);
+                           (const double*)y_d, partials, ratio);
     else
         hipLaunchKernelGGL((modulus_pass1_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, (const float*)bz_d,
-                           (const float*)y_d, partials);
+                           (const float*)y_d, partials, ratio);
     hipLaunchKernelGGL(modulus_finish_kernel, dim3((unsigned)batch), dim3(kBlock), 0, ctx->stream, partials, nblk,
                        (double)n, az_d, damping, a_old_d, a_new_d, a_raw, v_d);
     if (b_new_d || r_d) {
         if (dtype == TRAMP_F64)
             hipLaunchKernelGGL((modulus_pass2_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, az_d, a_raw,
-                               (const double*)bz_d, (const double*)y_d, damping, (const double*)b_old_d,
+                               (const double*)bz_d, (const double*)y_d, ratio, damping, (const double*)b_old_d,
                                (double*)b_new_d, (double*)r_d);
         else
             hipLaunchKernelGGL((modulus_pass2_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, az_d, a_raw,
-                               (const float*)bz_d, (const float*)y_d, damping, (const float*)b_old_d, (float*)b_new_d,
+                               (const float*)bz_d, (const float*)y_d, ratio, damping, (const float*)b_old_d, (float*)b_new_d,
                                (float*)r_d);
     }
     TRAMP_LAUNCH_CHECK(ctx);

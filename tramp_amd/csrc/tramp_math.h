@@ -1394,11 +1394,55 @@ template <typename T> TM_HD RV<T> gm_posterior(T bx, const GmConst<T>& g) {
     return o;
 }
 
+// The same with the number of components a compile-time constant (2..4: what mixture priors use in practice): straight-line
+// code for the streaming kernels and the resident pipeline - polynomial exp of a non-positive argument, one reciprocal of
+// the normaliser in [1, K], and the variance in its centred form sum_k s_k (1/a_k + (r_k - r)^2), which is the reference's
+// half double sum over pairs term for term rearranged (all terms non-negative: nothing cancels).
+template <typename T, int K> TM_HD RV<T> gm_posterior_k(T bx, const GmConst<T>& g) {
+    T e[K], rk[K];
+    T m = T(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T bk = bx + g.b0[k];
+        e[k] = fma_(bk * bk, g.c1[k], g.c0[k]);
+        rk[k] = bk * g.inv_a[k];
+        m = k == 0 ? e[0] : fmax_(m, e[k]);
+    }
+    T se = T(0), sr = T(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        e[k] = exp_clamped_nonpos(e[k] - m);                       // a NaN message travels through rk
+        se += e[k];
+        sr = fma_(e[k], rk[k], sr);
+    }
+    const T is = rcp_pos(se);
+    RV<T> o;
+    o.r = sr * is;
+    T sv = T(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T d = rk[k] - o.r;
+        sv = fma_(e[k], fma_(d, d, g.inv_a[k]), sv);
+    }
+    o.v = sv * is;
+    return o;
+}
+
 // ---- modulus likelihood y = |z|, z complex (tramp/likelihoods/modulus_likelihood.py:9-20, 82-93) ----
 // I(x) = I1(x) / I0(x) (the reference: scipy's ive(1, x) / ive(0, x), 1 from x = 1e9 on and for NaN).  Always in double:
 // x <= 25: the two power series in t = x^2 / 4 (positive terms, no cancellation; 48 terms reach 1e-17 of the sum at 25);
 // x > 25: the large-argument expansions I_nu ~ e^x / sqrt(2 pi x) sum_k e_k(nu) / x^k, e_k = e_{k-1} ((2k-1)^2 - 4 nu^2) / (8k),
 // 19 terms (3e-17 at 25); the common prefactor cancels in the ratio.  Odd in x.
+// reciprocals 1 / k^2 and 1 / (k (k + 1)), k = 1..48, of the two power series (read through the scalar cache: the loop
+// index is wave-uniform, only the trip count depends on the lane)
+TM_SCALAR_TABLE double kBesselInvKK[48] = {1.0, 0.25, 0.1111111111111111, 0.0625, 0.04, 0.027777777777777776, 0.02040816326530612, 0.015625, 0.012345679012345678, 0.01, 0.008264462809917356, 0.006944444444444444, 0.005917159763313609, 0.00510204081632653, 0.0044444444444444444, 0.00390625, 0.0034602076124567475, 0.0030864197530864196, 0.002770083102493075, 0.0025, 0.0022675736961451248, 0.002066115702479339, 0.001890359168241966, 0.001736111111111111, 0.0016, 0.0014792899408284023, 0.0013717421124828531, 0.0012755102040816326, 0.0011890606420927466, 0.0011111111111111111, 0.001040582726326743, 0.0009765625, 0.0009182736455463728, 0.0008650519031141869, 0.0008163265306122449, 0.0007716049382716049, 0.0007304601899196494, 0.0006925207756232687, 0.0006574621959237344, 0.000625, 0.000594883997620464, 0.0005668934240362812, 0.0005408328826392645, 0.0005165289256198347, 0.0004938271604938272, 0.0004725897920604915, 0.0004526935264825713, 0.00043402777777777775};
+TM_SCALAR_TABLE double kBesselInvKK1[48] = {0.5, 0.16666666666666666, 0.08333333333333333, 0.05, 0.03333333333333333, 0.023809523809523808, 0.017857142857142856, 0.013888888888888888, 0.011111111111111112, 0.00909090909090909, 0.007575757575757576, 0.00641025641025641, 0.005494505494505495, 0.004761904761904762, 0.004166666666666667, 0.003676470588235294, 0.0032679738562091504, 0.0029239766081871343, 0.002631578947368421, 0.002380952380952381, 0.0021645021645021645, 0.001976284584980237, 0.0018115942028985507, 0.0016666666666666668, 0.0015384615384615385, 0.0014245014245014246, 0.0013227513227513227, 0.0012315270935960591, 0.0011494252873563218, 0.001075268817204301, 0.0010080645161290322, 0.000946969696969697, 0.00089126559714795, 0.0008403361344537816, 0.0007936507936507937, 0.0007507507507507507, 0.0007112375533428165, 0.0006747638326585695, 0.000641025641025641, 0.0006097560975609756, 0.0005807200929152149, 0.0005537098560354374, 0.0005285412262156448, 0.000505050505050505, 0.0004830917874396135, 0.00046253469010175765, 0.0004432624113475177, 0.00042517006802721087};
+// terms of the power series at |x|: t^k / (k!)^2 is below 1e-17 of the sum from k = 10 + 1.6 |x| on (checked against a
+// 40-digit evaluation on [0, 25], tests/test_host_math.py)
+TM_HD int bessel_series_terms(double ax) {
+    const int k = 10 + (int)(1.6 * ax) + 1;
+    return k < 48 ? k : 48;
+}
 TM_HD double bessel_i1_over_i0(double x) {
     if (!(x < 1e9)) return 1.0;
     const double ax = ::fabs(x);
@@ -1406,10 +1450,10 @@ TM_HD double bessel_i1_over_i0(double x) {
     if (ax <= 25.0) {
         const double t = 0.25 * ax * ax;
         double t0 = 1.0, t1 = 1.0, s0 = 1.0, s1 = 1.0;
-#pragma unroll
-        for (int k = 1; k <= 48; ++k) {
-            t0 *= t * (1.0 / ((double)k * (double)k));
-            t1 *= t * (1.0 / ((double)k * (double)(k + 1)));
+        const int kmax = bessel_series_terms(ax);
+        for (int k = 0; k < kmax; ++k) {
+            t0 *= t * kBesselInvKK[k];
+            t1 *= t * kBesselInvKK1[k];
             s0 += t0;
             s1 += t1;
         }
@@ -1436,9 +1480,9 @@ TM_HD double bessel_i0e(double x) {
     if (ax <= 25.0) {
         const double t = 0.25 * ax * ax;
         double t0 = 1.0, s0 = 1.0;
-#pragma unroll
-        for (int k = 1; k <= 48; ++k) {
-            t0 *= t * (1.0 / ((double)k * (double)k));
+        const int kmax = bessel_series_terms(ax);
+        for (int k = 0; k < kmax; ++k) {
+            t0 *= t * kBesselInvKK[k];
             s0 += t0;
         }
         return s0 * ::exp(-ax);
