@@ -14,6 +14,7 @@ SWITCHES = {
     "TRAMP_EW_RESIDENT_K7": ("1", "select", "0: the Sgn / Abs / Relu channels stay on the tile kernels' two passes"),
     "TRAMP_EW_COOP": ("1", "select", "0: a few large instances take the tile kernels' three launches instead of the one-launch cooperative form"),
     "TRAMP_EW_LEAN_ADAPT": ("1", "select", "0: a lean resident K7 update that had to redo more than a quarter of its instances does not send the next 15 calls to the tile kernels"),
+    "TRAMP_EW_REDO_TPB": ("16", "tune", "tiles per workgroup in the redo of a lean resident update's flagged instances (64 before round 6: 0.19 ms with 2-3 of 64 instances flagged, 0.07 ms at 16)"),
     "TRAMP_EW_RESIDENT_TIMEOUT_MS": ("2000", "tune", "deadline of a resident kernel: hand-offs still missing then are given up (NaN update, tile kernels afterwards)"),
     "TRAMP_EW_COOP_DBG_SKIP": (None, "debug", "workgroup index + 1 of instance 0 whose block sum a one-launch update never publishes (forces its give-up path in tests)"),
     "TRAMP_EW_RESIDENT_DBG_SKIP": (None, "debug", "tile index + 1 whose sum a resident kernel never publishes (forces the give-up path in tests)"),
