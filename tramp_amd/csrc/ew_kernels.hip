@@ -1170,11 +1170,12 @@ extern "C" int tramp_halfline_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, siz
     MsgOut out{damping, a_old_d, b_old_d, a_new_d, b_new_d, r_d, v_d, nullptr, nullptr};
     HalfLinePriorOp<float> of{ax_d, a0, b0};
     HalfLinePriorOp<double> od{ax_d, a0, b0};
-    // f64, large batches of large instances: the lean form on the resident pipeline, then the tile kernels for the instances
-    // it could not finish (an erfcx argument beyond the table - an exponential prior at ax << 1 / mean^2 sits there - or a
-    // non-finite message); the count of the previous lean call sends wide messages straight to the tile kernels, as for
-    // the two-region channels (pwl_dir)
-    if (dtype == TRAMP_F64 && n && batch && bx_d && a_new_d && b_new_d && !r_d && (damping == 0.0 || (a_old_d && b_old_d))) {
+    // large batches of large instances: the lean form on the resident pipeline (double arithmetic for f32 messages too),
+    // then the tile kernels for the instances it could not finish (an erfcx argument beyond the table - an exponential
+    // prior at ax << 1 / mean^2 sits there - or a non-finite message); the count of the previous lean call sends wide
+    // messages straight to the tile kernels, as for the two-region channels (pwl_dir)
+    if ((dtype == TRAMP_F64 || dtype == TRAMP_F32) && n && batch && bx_d && a_new_d && b_new_d && !r_d &&
+        (damping == 0.0 || (a_old_d && b_old_d))) {
         static const size_t adapt = env_size("TRAMP_EW_LEAN_ADAPT", 1);
         if (ctx->lean_stat && ctx->lean_stat[1]) {
             if (adapt && 4u * ctx->lean_stat[0] > ctx->lean_stat[1]) ctx->lean_skip = 15;
@@ -1182,9 +1183,13 @@ extern "C" int tramp_halfline_prior_fwd(tramp_ctx* ctx, int dtype, size_t n, siz
         }
         if (ctx->lean_skip > 0) {
             ctx->lean_skip -= 1;
-        } else {
+        } else if (dtype == TRAMP_F64) {
             const int rc = run_resident<double>(ctx, HalfLinePriorOp<double, true>{ax_d, a0, b0}, n, batch, bx_d, nullptr, ax_d, out);
             if (rc == TRAMP_OK) return run_tiles<double>(ctx, od, n, batch, bx_d, nullptr, ax_d, out, false, nullptr, true);
+            if (rc != kResNotEligible) return rc;
+        } else {
+            const int rc = run_resident<float>(ctx, HalfLinePriorOp<float, true>{ax_d, a0, b0}, n, batch, bx_d, nullptr, ax_d, out);
+            if (rc == TRAMP_OK) return run_tiles<float>(ctx, of, n, batch, bx_d, nullptr, ax_d, out, false, nullptr, true);
             if (rc != kResNotEligible) return rc;
         }
     }

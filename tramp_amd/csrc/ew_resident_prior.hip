@@ -11,3 +11,4 @@ RES_INSTANTIATE(float, GmOp<float, 2>)
 RES_INSTANTIATE(double, GmOp<double, 3>)
 RES_INSTANTIATE(float, GmOp<float, 3>)
 RES_INSTANTIATE(double, HalfLinePriorOp<double, true>)
+RES_INSTANTIATE(float, HalfLinePriorOp<float, true>)
