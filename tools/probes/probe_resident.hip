@@ -149,40 +149,34 @@ template <typename T> __global__ void sign_kernel(T* p, size_t count) {
 }
 
 template <typename T> static void sweep(Buffers& B) {
-    const double alg2 = 2.0 * sizeof(T) * B.n * B.batch, alg3 = 1.5 * alg2;
+    const double alg2 = 2.0 * sizeof(T) * B.n * B.batch;
     hipLaunchKernelGGL((fill_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in0, B.n * B.batch, 1.3);
     hipLaunchKernelGGL((fill_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in1_buf, B.n * B.batch, 0.7);
     hipLaunchKernelGGL((sign_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in1_buf, B.n * B.batch);
     const size_t stride = ((B.n + 63) / 64) * 8;
     hipLaunchKernelGGL((pack_kernel<T>), dim3((unsigned)((stride + 255) / 256), (unsigned)B.batch), dim3(256), 0, 0, B.n, stride, (const T*)B.in1_buf, (uint8_t*)B.bits);
     CK(hipDeviceSynchronize());
-    B.in1 = B.in1_buf;
+    B.in1 = nullptr;
     {
-        SgnLikOp<T> op{};
-        op.az = B.a_in;
-        reference<T, SgnLikOp<T>>(B, op);
-        using Op = SgnLikOp<T>;
+        // round 6: the Gauss-Bernoulli prior with r parked in LDS (the library's shape), in registers, and recomputed at
+        // the update (kResRecompute: no LDS, b ring only) on two, three and four workgroups per CU
+        double a0 = 1.0, b0 = 0.0, eta = 0.5 * log(2 * 3.141592653589793) - log(0.05 / 0.95);
+        GbOp<T> op{B.a_in, a0, b0, eta};
+        reference<T, GbOp<T>>(B, op);
+        using Op = GbOp<T>;
         //                 U DL DA wg/CU nosync flags NT
-        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 0, 256, alg3)
-        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16, 256, alg3)
-    }
-    {
-        SgnLikBitsOp<T> op{};
-        op.az = B.a_in;
-        using Op = SgnLikBitsOp<T>;
-        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 0, 256, alg3)
-        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16, 256, alg3)
-        VARIANTN(T, Op, op, 4, 2, 3, 2, 0, 0, 256, alg3)
-        VARIANTN(T, Op, op, 4, 1, 3, 1, 0, 0, 512, alg3)
-    }
-    {
-        AbsLikOp<T> op{};
-        op.az = B.a_in;
-        hipLaunchKernelGGL((fill_kernel<T>), dim3(4096), dim3(256), 0, 0, (T*)B.in1_buf, B.n * B.batch, 0.7);
-        reference<T, AbsLikOp<T>>(B, op);
-        using Op = AbsLikOp<T>;
-        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 0, 256, alg3)
-        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16, 256, alg3)
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16, 256, alg2)
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16 | 32, 256, alg2)
+        VARIANTN(T, Op, op, 4, 1, 3, 2, 0, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 4, 1, 3, 3, 0, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 4, 2, 3, 2, 0, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 4, 2, 3, 3, 0, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 2, 1, 3, 4, 0, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 2, 2, 3, 4, 0, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 2, 3, 3, 4, 0, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 4, 1, 3, 3, 0, 128, 256, alg2)
+        VARIANTN(T, Op, op, 4, 1, 3, 3, 1, 16 | 128, 256, alg2)
+        VARIANTN(T, Op, op, 2, 2, 3, 4, 1, 16 | 128, 256, alg2)
     }
 }
 

@@ -209,6 +209,14 @@ constexpr int kResDamp = 1, kResStoreR = 2, kResMask = 4, kResNtLoad = 8, kResSc
 // 256 MB Infinity Cache, so HBM still sees it once).  The ring then holds two rounds of inputs instead of five of b: the
 // heavy two-input factors (K7) evaluate without spilling.
 constexpr int kResReloadB = 64;
+// kResRecompute (one-input factors; probes only - no library instantiation uses it): the posterior mean r is NOT parked
+// while its round waits for the mean - the update stage evaluates the factor a second time from b, which the ring holds
+// anyway.  No LDS, half the registers of the register-parked form, so three or four workgroups per CU fit.  Measured in
+// round 6 for the Gauss-Bernoulli prior at 64 x 1e6 (tools/probes/probe_resident.hip, profiles/r06/probe_resident_recompute.txt):
+// 223 us parked (LDS or registers alike) against 276 / 238 / 269 us recomputed on 2 / 3 / 4 workgroups per CU, and deeper
+// load prefetch (DL = 2, 3) is slower still - the pipeline is not short of loads in flight, the second evaluation costs
+// what it costs.  Kept as a flag so the measurement can be repeated.
+constexpr int kResRecompute = 128;
 
 // DBG (probes only): 1 = no slots, no combiner, no polling (the pipeline as a plain stream with a constant scalar).
 // Every tile is FULL: the last tile of an instance starts at nv - 256 U, overlapping its predecessor; the overlap is
@@ -230,7 +238,9 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
     __shared__ unsigned long long smem_u[NT / kWave];
     // r of the rounds that wait for their mean: in LDS (each thread parks and fetches its own pieces: no barrier), so the
     // register ring holds only the messages b.  (With r in registers too every factor but the two priors spilled.)
-    __shared__ V r_lds[(FLAGS & kResRegR) ? 1 : DA + 1][U][NT];
+    constexpr bool RECOMP = (FLAGS & kResRecompute) != 0;
+    static_assert(!RECOMP || (Op::NIN == 1 && !BITS && !OpLean<Op>::value), "kResRecompute: one-input factors with a full form");
+    __shared__ V r_lds[(FLAGS & (kResRegR | kResRecompute)) ? 1 : DA + 1][U][NT];
     const unsigned tid = threadIdx.x;
     const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
     if (blockIdx.x < kResCombiners) {
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
                 // keep (b, r): b in the ring, r in LDS
                 if (Op::TARGET != 0 && !RELOAD) x0[sM][u] = x1[sM][u];
                 if (FLAGS & kResRegR) x1[sM][u] = vr;
-                else r_lds[lm][u][tid] = vr;
+                else if (!RECOMP) r_lds[lm][u][tid] = vr;
                 // one 16-byte piece at a time: interleaving all U evaluations (the scheduler's choice when left alone) needs
                 // U times the temporaries, and the ring leaves no room for them
                 if (FLAGS & kResSchedBarrier) __builtin_amdgcn_sched_barrier(0);
@@ -413,7 +423,14 @@ __global__ __launch_bounds__(NT, BPC * NT / 256) void ew_resident(const Op* __re
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 V vo;
-                const V vr = (FLAGS & kResRegR) ? x1[sA][u] : r_lds[la][u][tid];
+                V vr;
+                if constexpr (RECOMP) {
+                    const Op opA = ops[r_inst[sA]];
+#pragma unroll
+                    for (int c = 0; c < VN; ++c) vset<T>(vr, c, opA.eval(vget<T>(x0[sA][u], c), T(0)).r);
+                } else {
+                    vr = (FLAGS & kResRegR) ? x1[sA][u] : r_lds[la][u][tid];
+                }
 #pragma unroll
                 for (int c = 0; c < VN; ++c) {
                     T bn = vget<T>(vr, c) * vinv - vget<T>(RELOAD ? xt[sA][u] : x0[sA][u], c);
