@@ -324,3 +324,69 @@ def test_modulus_se_error_and_phase_retrieval_state_evolution(ctx, golden_comple
                 close(rec[it][0][(vid, "fwd")], t[f"fwd:{vid}:a"][it], rt, scale=a_tot)
                 close(rec[it][0][(vid, "bwd")], t[f"bwd:{vid}:a"][it], rt, scale=a_tot)
                 close(rec[it][1][vid]["v"], t[f"v:{vid}"][it], rt)
+
+
+@pytest.mark.parametrize("which", ["phase_retrieval", "mixture", "exponential"])
+def test_ensembles_and_graph_replay_of_the_round6_factors(ctx, which):
+    """several instances at once (each must equal the oracle's single run on its own data), the device-side stopping rule,
+    and the iteration captured as a hipGraph: the same bits as the eager loop"""
+    import tramp_amd as T
+    rs = np.random.RandomState(11)
+    B = 3
+    if which == "phase_retrieval":
+        N, M = 40, 120
+        W = (rs.standard_normal((M, N)) + 1j * rs.standard_normal((M, N))) / np.sqrt(N)
+        X = rs.standard_normal((B, 2, N)) * rs.binomial(1, 0.5, (B, 2, N))
+        Y = np.abs(np.einsum("mn,bn->bm", W, X[:, 0] + 1j * X[:, 1]))
+        b0 = rs.standard_normal((2, N))
+        model = (T.GaussBernoulliPrior(size=(2, N), rho=0.5, ctx=ctx) @ T.SISOVariable(id="x")
+                 @ T.ComplexLinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z") @ T.ModulusLikelihood(y=Y, ctx=ctx)).to_model()
+        init = T.CustomInit(a_init=[("x", "bwd", 0.1)], b_init=[("x", "bwd", b0)])
+        kw = dict(max_iter=300, damping=0.3, callback=T.EarlyStoppingEP(max_increase=np.inf), initializer=init)
+
+        def oracle(b):
+            fs = [orc.GBPriorFactor((2, N), rho=0.5), orc.ComplexLinearFactor(W), orc.ModulusLikFactor(Y[b])]
+            return orc.ep_chain(fs, [(2, N), (2, M)], max_iter=300, damping=0.3, max_increase=np.inf,
+                                init=lambda i, d: (0.1, b0) if (i, d) == (0, "bwd") else (0, 0.0))
+        shape = (2, N)
+    else:
+        N, M, nv = 96, 64, 1e-2
+        W = rs.randn(M, N) / np.sqrt(N)
+        if which == "mixture":
+            kwp = dict(probs=[0.2, 0.5, 0.3], means=[-2.0, 0.0, 1.5], vars=[0.3, 0.01, 2.0])
+            prior, pf = T.GaussianMixturePrior(size=N, ctx=ctx, **kwp), orc.GMPriorFactor(N, kwp["probs"], kwp["means"], kwp["vars"])
+            k = rs.choice(3, size=(B, N), p=kwp["probs"])
+            X = np.asarray(kwp["means"])[k] + np.sqrt(np.asarray(kwp["vars"]))[k] * rs.standard_normal((B, N))
+        else:
+            prior, pf = T.ExponentialPrior(size=N, mean=0.7, ctx=ctx), orc.ExpPriorFactor(N, 0.7)
+            X = rs.exponential(0.7, (B, N))
+        Y = X @ W.T + np.sqrt(nv) * rs.standard_normal((B, M))
+        model = (prior @ T.SISOVariable(id="x") @ T.LinearChannel(W, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+                 @ T.GaussianLikelihood(y=Y, var=nv, ctx=ctx)).to_model()
+        a0 = 1e-3 if which == "exponential" else 0
+        kw = dict(max_iter=100, damping=0.2, initializer=T.CustomInit(a=a0, b=0))
+
+        def oracle(b):
+            fs = [pf, orc.LinearFactor(W), orc.GaussLikFactor(Y[b], nv)]
+            return orc.ep_chain(fs, [N, M], max_iter=100, damping=0.2, init=lambda i, d: (a0, 0.0))
+        shape = (N,)
+    runs = []
+    for graph in (False, True):
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        assert ep.batch == B
+        ep.iterate(graph=graph, **kw)
+        d = ep.get_variables_data()
+        runs.append((ep.n_iter_instance.copy(), ep.status.copy(), np.asarray(d["x"]["r"]).copy(), np.asarray(d["x"]["v"]).copy()))
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b), "the captured iteration differs from the eager loop"
+    n_it, status, r, v = runs[0]
+    code = dict(max_iter=0, converged=1, diverged=2)
+    for b in range(B):
+        with np.errstate(all="ignore"):
+            res = oracle(b)
+        # per instance: the oracle's own stopping decision (converged / gave up / cut short) and iteration count
+        assert status[b] == code[res["status"]] and abs(int(n_it[b]) - res["n_iter"]) <= 1, (b, status[b], n_it[b], res["status"], res["n_iter"])
+        close(r.reshape((B,) + shape)[b], res["r"][0], 2e-5)
+        close(np.atleast_1d(v)[b], res["v"][0], 1e-4)
+    if which == "phase_retrieval":
+        assert np.all(status == 1)

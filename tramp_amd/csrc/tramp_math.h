@@ -1349,48 +1349,46 @@ TM_HD PwlOut<T> pwl3_lik_posterior(T bz, T y, T az, const Pwl3Spec& sp) {
 // ---- Gaussian mixture prior (tramp/priors/gaussian_mixture_prior.py:88-97, tramp/beliefs/mixture.py:23-41) ----
 // p(x) = sum_k p_k N(x | m_k, s_k): with a_k = ax + 1/s_k, b_k = bx + m_k/s_k the posterior is a mixture of N(b_k/a_k, 1/a_k)
 // with weights softmax_k(eta_k + normal.A(a_k, b_k)).  Per-instance scalars hoisted: inv_a = 1/a_k, c1 = 0.5/a_k,
-// c0 = eta_k + 0.5 log(2 pi / a_k).  v = sum s_k / a_k + sum_{k<l} s_k s_l (r_k - r_l)^2 (the reference's double sum over
-// ordered pairs, halved).  At most kGmMax components; the loops are unrolled with static indices (registers, no scratch).
+// c0 = eta_k + 0.5 log(2 pi / a_k).  Softmax with the polynomial exp of a non-positive argument and one reciprocal of the
+// normaliser; v in the centred form sum_k s_k (1/a_k + (r_k - r)^2) - the reference's half double sum over ordered pairs,
+// rearranged, all terms non-negative.  At most kGmMax components, the number known at run time: the loops are unrolled
+// with static indices and predicated (registers, no scratch).
 constexpr int kGmMax = 8;
 template <typename T> struct GmConst { int K; T inv_a[kGmMax], c0[kGmMax], c1[kGmMax], b0[kGmMax]; };
 
 template <typename T> TM_HD RV<T> gm_posterior(T bx, const GmConst<T>& g) {
-    T xi[kGmMax], rk[kGmMax];
+    T e[kGmMax], rk[kGmMax];
     T m = T(-INFINITY);
 #pragma unroll
     for (int k = 0; k < kGmMax; ++k) {
         if (k < g.K) {
             const T bk = bx + g.b0[k];
-            xi[k] = fma_(bk * bk, g.c1[k], g.c0[k]);
+            e[k] = fma_(bk * bk, g.c1[k], g.c0[k]);
             rk[k] = bk * g.inv_a[k];
-            m = (xi[k] > m || xi[k] != xi[k]) ? xi[k] : m;       // np.max: NaN wins
+            m = fmax_(m, e[k]);
         }
     }
-    T se = T(0), sr = T(0), sv = T(0);
+    T se = T(0), sr = T(0);
 #pragma unroll
     for (int k = 0; k < kGmMax; ++k) {
         if (k < g.K) {
-            xi[k] = exp_(xi[k] - m);                                // +inf - +inf = NaN as scipy's softmax
-            se += xi[k];
-            sr += xi[k] * rk[k];
-            sv += xi[k] * g.inv_a[k];
+            e[k] = exp_clamped_nonpos(e[k] - m);                   // a NaN message travels through rk
+            se += e[k];
+            sr = fma_(e[k], rk[k], sr);
         }
     }
-    const T is = T(1) / se;
-    T dr = T(0);
-#pragma unroll
-    for (int k = 0; k < kGmMax; ++k) {
-#pragma unroll
-        for (int l = k + 1; l < kGmMax; ++l) {
-            if (l < g.K) {
-                const T d = rk[k] - rk[l];
-                dr += (xi[k] * is) * (xi[l] * is) * (d * d);
-            }
-        }
-    }
+    const T is = rcp_pos(se);                                      // se in [1, K]
     RV<T> o;
     o.r = sr * is;
-    o.v = dr + sv * is;
+    T sv = T(0);
+#pragma unroll
+    for (int k = 0; k < kGmMax; ++k) {
+        if (k < g.K) {
+            const T d = rk[k] - o.r;
+            sv = fma_(e[k], fma_(d, d, g.inv_a[k]), sv);
+        }
+    }
+    o.v = sv * is;
     return o;
 }
 
