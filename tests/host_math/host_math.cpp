@@ -54,10 +54,7 @@ static void gm(size_t n, const T* bx, double ax, int K, const double* probs, con
     GmConst<T> g;
     g.K = K;
     for (int k = 0; k < K; ++k) {
-        const double a0 = 1.0 / vars[k], b0 = means[k] / vars[k];
-        const double eta = log(probs[k]) - 0.5 * (b0 * b0 / a0 + log(2 * kPi / a0));
-        const double ad = ax + a0;
-        g.inv_a[k] = T(1.0 / ad); g.c1[k] = T(0.5 / ad); g.c0[k] = T(eta + 0.5 * log(2 * kPi / ad)); g.b0[k] = T(b0);
+        gm_const_k<T>(g, k, ax, log(probs[k]), 1.0 / vars[k], means[k] / vars[k]);
     }
     for (size_t i = 0; i < n; ++i) {
         RV<T> o = (fast && K == 2) ? gm_posterior_k<T, 2>(bx[i], g)

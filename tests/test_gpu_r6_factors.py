@@ -390,3 +390,19 @@ def test_ensembles_and_graph_replay_of_the_round6_factors(ctx, which):
         close(np.atleast_1d(v)[b], res["v"][0], 1e-4)
     if which == "phase_retrieval":
         assert np.all(status == 1)
+
+
+@pytest.mark.parametrize("n", [3000, 1 << 18])
+def test_mixture_narrow_component_far_from_zero_f32(ctx, n):
+    "mean^2 / var = 4e4: the constants are formed without the cancellation between eta_k and normal.A (tramp_math.h: gm_const_k)"
+    import tramp_amd as T
+    rs = np.random.RandomState(n % 101)
+    kw = dict(probs=[0.3, 0.7], means=[2.0, -0.5], vars=[1e-4, 0.5])
+    B = 3
+    ax = np.array([0.05, 1.3, 40.0])
+    bx = (ax[:, None] * np.where(rs.rand(B, n) < 0.3, 2.0, -0.5) + np.sqrt(ax)[:, None] * rs.standard_normal((B, n))).astype(np.float32)
+    r, v = T.GaussianMixturePrior(size=n, dtype=np.float32, ctx=ctx, **kw).compute_forward_posterior(ax, bx)
+    for b in range(B):
+        r_o, v_o = orc.gm_prior_posterior(ax[b], bx[b].astype(np.float64), kw["probs"], kw["means"], kw["vars"])
+        close(r[b], r_o, 2e-5)
+        close(v[b], v_o, 2e-4)

@@ -366,3 +366,18 @@ def test_bessel_ratio_and_modulus_posterior(hm, golden_complex):
         hm.hm_modulus(C.c_size_t(re.size), ptr(re), ptr(im), ptr(y), ptr(rre), ptr(rim), ptr(v))
         close(np.stack([rre, rim]), c["r"], 1e-13)
         close(v.mean(), c["v"], 1e-12)
+
+
+def test_mixture_narrow_component_far_from_zero_keeps_its_digits_in_f32(hm):
+    """a component with mean^2 / var = 4e4 (mean 2, var 1e-4): eta_k and normal.A(a_k, b_k) are each ~2e4 and cancel - the
+    kernels' constants take them against each other analytically (tramp_math.h: gm_const_k), so f32 messages stay at 1e-5"""
+    rs = np.random.RandomState(3)
+    pr, me, va = (np.array(t, dtype=np.float64) for t in ([0.3, 0.7], [2.0, -0.5], [1e-4, 0.5]))
+    for ax in (0.05, 1.3, 40.0):
+        bx = (ax * np.where(rs.rand(400) < 0.3, 2.0, -0.5) + np.sqrt(ax) * rs.standard_normal(400)).astype(np.float32)
+        r_o, v_o = orc.gm_prior_posterior(ax, bx.astype(np.float64), pr, me, va, isotropic=False)
+        for fast in (0, 1):
+            r32, v32 = np.empty_like(bx), np.empty_like(bx)
+            hm.hm_gm_f32(C.c_size_t(bx.size), ptr(bx), C.c_double(ax), C.c_int(2), ptr(pr), ptr(me), ptr(va), ptr(r32), ptr(v32), fast)
+            close(r32, r_o, 2e-5)
+            close(v32, v_o, 2e-4)

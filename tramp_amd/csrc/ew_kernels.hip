@@ -1156,7 +1156,7 @@ template <typename Op> static bool gm_fill(Op& op, int K, const double* probs, c
         if (!(probs[k] > 0.0) || !(vars[k] > 0.0)) return false;
         op.a0[k] = 1.0 / vars[k];
         op.b0[k] = means[k] / vars[k];
-        op.eta[k] = log(probs[k]) - 0.5 * (op.b0[k] * op.b0[k] / op.a0[k] + log(2 * tmath::kPi / op.a0[k]));
+        op.logp[k] = log(probs[k]);
         ps += probs[k];
     }
     return ps > 0.0;
@@ -1611,14 +1611,14 @@ __global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, c
     tmath::Pwl3Spec spec{p0, p1, {P.p[2], P.p[3], P.p[4]}, {P.p[5], P.p[6], P.p[7]}};
     // TRAMP_DIAG_GM: p = {K, probs[K], means[K], vars[K]} (gaussian_mixture_prior.py:36-39)
     const int gK = which == TRAMP_DIAG_GM ? (int)p0 : 0;
-    double ga0[tmath::kGmMax], gb0[tmath::kGmMax], geta[tmath::kGmMax];
+    double ga0[tmath::kGmMax], gb0[tmath::kGmMax], glogp[tmath::kGmMax];
 #pragma unroll
     for (int k = 0; k < tmath::kGmMax; ++k) {
-        ga0[k] = gb0[k] = geta[k] = 0.0;
+        ga0[k] = gb0[k] = glogp[k] = 0.0;
         if (k < gK) {
             ga0[k] = 1.0 / P.p[1 + 2 * gK + k];
             gb0[k] = P.p[1 + gK + k] / P.p[1 + 2 * gK + k];
-            geta[k] = log(P.p[1 + k]) - 0.5 * (gb0[k] * gb0[k] / ga0[k] + log(2 * tmath::kPi / ga0[k]));
+            glogp[k] = log(P.p[1 + k]);
         }
     }
     tmath::erfcx_setup<T>();                               // the half-line moments read erfcx from the LDS table
@@ -1671,13 +1671,7 @@ __global__ __launch_bounds__(kBlock) void diag_kernel(int which, size_t count, c
                 g.K = gK;
 #pragma unroll
                 for (int k = 0; k < tmath::kGmMax; ++k) {
-                    if (k < gK) {
-                        const double ad = (double)ai + ga0[k], inv = 1.0 / ad;
-                        g.inv_a[k] = T(inv);
-                        g.c1[k] = T(0.5 * inv);
-                        g.c0[k] = T(geta[k] + 0.5 * log(2 * tmath::kPi / ad));
-                        g.b0[k] = T(gb0[k]);
-                    }
+                    if (k < gK) tmath::gm_const_k<T>(g, k, (double)ai, glogp[k], ga0[k], gb0[k]);
                 }
                 o = tmath::gm_posterior<T>(bi, g);
                 break;

@@ -116,7 +116,7 @@ template <typename T, bool LEAN = false> struct HalfLinePriorOp {
 };
 
 // GaussianMixturePrior (tramp/priors/gaussian_mixture_prior.py:36-39, 88-97; beliefs/mixture.py:23-41), at most
-// tmath::kGmMax components; a0 = 1/var_k, b0 = mean_k/var_k, eta = log p_k - normal.A(a0, b0).  in0 = bx
+// tmath::kGmMax components; a0 = 1/var_k, b0 = mean_k/var_k, logp = log p_k.  in0 = bx
 // KC: the number of components at compile time (2..4: straight-line code, resident pipeline), 0 = run time (up to kGmMax)
 template <typename T, int KC = 0> struct GmOp {
     static constexpr bool HEAVY = false;
@@ -124,7 +124,7 @@ template <typename T, int KC = 0> struct GmOp {
     static constexpr int TARGET = 0;
     const double* ax;
     int K;
-    double a0[tmath::kGmMax], b0[tmath::kGmMax], eta[tmath::kGmMax];
+    double a0[tmath::kGmMax], b0[tmath::kGmMax], logp[tmath::kGmMax];
     tmath::GmConst<T> g;
     double a_msg;
     __device__ static void stage() {}
@@ -133,14 +133,7 @@ template <typename T, int KC = 0> struct GmOp {
         g.K = K;
 #pragma unroll
         for (int k = 0; k < (KC ? KC : tmath::kGmMax); ++k) {
-            if (KC || k < K) {
-                const double ad = a_msg + a0[k];
-                const double inv = 1.0 / ad;
-                g.inv_a[k] = T(inv);
-                g.c1[k] = T(0.5 * inv);
-                g.c0[k] = T(eta[k] + 0.5 * log(2 * tmath::kPi / ad));
-                g.b0[k] = T(b0[k]);
-            }
+            if (KC || k < K) tmath::gm_const_k<T>(g, k, a_msg, logp[k], a0[k], b0[k]);
         }
     }
     __device__ void setup(size_t b) { stage(); prepare(b); }

@@ -141,13 +141,7 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
 #pragma unroll
         for (int k = 0; k < tmath::kGmMax; ++k) {
             if (k < K) {
-                const double a0 = 1.0 / P.gm.vars[k], b0 = P.gm.means[k] / P.gm.vars[k];
-                const double eta = log(P.gm.probs[k]) - 0.5 * (b0 * b0 / a0 + log(2 * tmath::kPi / a0));
-                const double ad = ax + a0;
-                g.inv_a[k] = 1.0 / ad;
-                g.c1[k] = 0.5 / ad;
-                g.c0[k] = eta + 0.5 * log(2 * tmath::kPi / ad);
-                g.b0[k] = b0;
+                tmath::gm_const_k<double>(g, k, ax, log(P.gm.probs[k]), 1.0 / P.gm.vars[k], P.gm.means[k] / P.gm.vars[k]);
             }
         }
         for (int br = 0; br < K; ++br) {

@@ -1354,7 +1354,20 @@ TM_HD PwlOut<T> pwl3_lik_posterior(T bz, T y, T az, const Pwl3Spec& sp) {
 // rearranged, all terms non-negative.  At most kGmMax components, the number known at run time: the loops are unrolled
 // with static indices and predicated (registers, no scratch).
 constexpr int kGmMax = 8;
-template <typename T> struct GmConst { int K; T inv_a[kGmMax], c0[kGmMax], c1[kGmMax], b0[kGmMax]; };
+template <typename T> struct GmConst { int K; T inv_a[kGmMax], c0[kGmMax], c1[kGmMax], b0[kGmMax], tb0[kGmMax]; };
+
+// The constants of component k for a message of precision ax: xi_k = eta_k + normal.A(a_k, b_k) with eta_k = log p_k -
+// normal.A(a0_k, b0_k) (gaussian_mixture_prior.py:36-39) is written as c0 + c1 bx (bx + 2 b0): the b0^2 / a0 of eta and the
+// b0^2 / a_k of normal.A are taken against each other analytically (b0^2 (1/a_k - 1/a0) = -ax mean b0 / a_k), so a narrow
+// component far from zero (mean^2 / var = 4e4 at mean 2, var 1e-4) does not cost f32 messages their digits.
+template <typename T> TM_HD void gm_const_k(GmConst<T>& g, int k, double ax, double logp, double a0, double b0) {
+    const double ad = ax + a0, inv = 1.0 / ad;
+    g.inv_a[k] = T(inv);
+    g.c1[k] = T(0.5 * inv);
+    g.c0[k] = T(logp + 0.5 * ::log(a0 * inv) - 0.5 * ax * (b0 / a0) * b0 * inv);
+    g.b0[k] = T(b0);
+    g.tb0[k] = T(2.0 * b0);
+}
 
 template <typename T> TM_HD RV<T> gm_posterior(T bx, const GmConst<T>& g) {
     T e[kGmMax], rk[kGmMax];
@@ -1362,9 +1375,8 @@ template <typename T> TM_HD RV<T> gm_posterior(T bx, const GmConst<T>& g) {
 #pragma unroll
     for (int k = 0; k < kGmMax; ++k) {
         if (k < g.K) {
-            const T bk = bx + g.b0[k];
-            e[k] = fma_(bk * bk, g.c1[k], g.c0[k]);
-            rk[k] = bk * g.inv_a[k];
+            e[k] = fma_(bx * (bx + g.tb0[k]), g.c1[k], g.c0[k]);
+            rk[k] = (bx + g.b0[k]) * g.inv_a[k];
             m = fmax_(m, e[k]);
         }
     }
@@ -1401,9 +1413,8 @@ template <typename T, int K> TM_HD RV<T> gm_posterior_k(T bx, const GmConst<T>& 
     T m = T(0);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const T bk = bx + g.b0[k];
-        e[k] = fma_(bk * bk, g.c1[k], g.c0[k]);
-        rk[k] = bk * g.inv_a[k];
+        e[k] = fma_(bx * (bx + g.tb0[k]), g.c1[k], g.c0[k]);
+        rk[k] = (bx + g.b0[k]) * g.inv_a[k];
         m = k == 0 ? e[0] : fmax_(m, e[k]);
     }
     T se = T(0), sr = T(0);
