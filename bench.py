@@ -454,7 +454,9 @@ def fused_updates_n1e6(T, ctx, dtype, only=None):
 # rocprofv3 --pmc SQ_INSTS_VALU of these very launches on the final round-5 library; the count includes the polling of
 # waiting waves); a wave64 f64 instruction occupies a SIMD for 4 cycles
 VALU_PER_COMPONENT_F64 = {"l1_prior": 37, "binary_prior": 37, "relu_lik": 86, "sgn_lik": 82, "abs_lik": 41, "relu_bwd": 142,
-                          "relu_fwd": 139, "sgn_bwd": 166, "abs_bwd": 143}
+                          "relu_fwd": 139, "sgn_bwd": 166, "abs_bwd": 143,
+                          # round 6 (profiles/r06/elementwise_traffic_and_instructions_round6_factors.txt)
+                          "positive_prior": 75, "exp_prior": 75, "mixture_k2": 83, "mixture_k3": 114}
 
 
 def factor_updates_n1e6(T, ctx, dtype, only=None):
@@ -488,6 +490,16 @@ def factor_updates_n1e6(T, ctx, dtype, only=None):
         ab = T.AbsLikelihood(y=y, dtype=np_dt, ctx=ctx)
         cases.append(("sgn_lik", "K4", 3, lambda: sg.compute_backward_message(az, bz, **kw)))
         cases.append(("abs_lik", "K5", 3, lambda: ab.compute_backward_message(az, bz, **kw)))
+    # round 6: the rest of the separable priors (--full only)
+    if want("positive_prior", "exp_prior"):
+        pp, ex = T.PositivePrior(size=N, dtype=np_dt, ctx=ctx), T.ExponentialPrior(size=N, mean=0.7, dtype=np_dt, ctx=ctx)
+        cases.append(("positive_prior", "half-line prior", 2, lambda: pp.compute_forward_message(ax, bx, **kw)))
+        cases.append(("exp_prior", "half-line prior", 2, lambda: ex.compute_forward_message(ax, bx, **kw)))
+    if want("mixture_k2", "mixture_k3"):
+        g2 = T.GaussianMixturePrior(size=N, dtype=np_dt, ctx=ctx)
+        g3 = T.GaussianMixturePrior(size=N, probs=[0.2, 0.5, 0.3], means=[-2.0, 0.0, 1.5], vars=[0.3, 0.01, 2.0], dtype=np_dt, ctx=ctx)
+        cases.append(("mixture_k2", "Gaussian mixture K = 2", 2, lambda: g2.compute_forward_message(ax, bx, **kw)))
+        cases.append(("mixture_k3", "Gaussian mixture K = 3", 2, lambda: g3.compute_forward_message(ax, bx, **kw)))
     relu, sgn, abs_ = (T.ReluChannel(dtype=np_dt, ctx=ctx), T.SgnChannel(dtype=np_dt, ctx=ctx),
                        T.AbsChannel(dtype=np_dt, ctx=ctx))
     cases += [("relu_bwd", "K7", 3, lambda: relu.compute_backward_message(az, bz, ax, bx, **kw)),

@@ -406,3 +406,41 @@ def test_mixture_narrow_component_far_from_zero_f32(ctx, n):
         r_o, v_o = orc.gm_prior_posterior(ax[b], bx[b].astype(np.float64), kw["probs"], kw["means"], kw["vars"])
         close(r[b], r_o, 2e-5)
         close(v[b], v_o, 2e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name,kw", [("exponential", dict(mean=0.7)), ("positive", {}),
+                                     ("mixture", dict(probs=[0.5, 0.5], means=[-1, 1], vars=[1, 1])),
+                                     ("mixture", dict(probs=[0.2, 0.5, 0.3], means=[-2.0, 0.0, 1.5], vars=[0.3, 0.01, 2.0]))])
+@pytest.mark.parametrize("damping", [0.0, 0.3])
+def test_round6_priors_on_the_resident_pipeline(ctx, name, kw, dtype, damping):
+    """many instances of several tiles each: the update takes the resident single-pass pipeline (the half-line priors its
+    lean form, with the tile kernels' redo of the instances whose messages leave the erfcx table) - asserted - and equals
+    the oracle instance by instance, with the damping fused; a non-finite message poisons only its own instance"""
+    import tramp_amd as T
+    B, n = 300, 7 * (2048 if dtype == np.float64 else 4096)
+    if not ctx.resident_covers(dtype, n, B):
+        pytest.skip("the pipeline does not cover this shape on this device")
+    rs = np.random.RandomState(B + len(kw))
+    ax = np.exp(rs.uniform(np.log(0.3), np.log(8.0), B))
+    bx = (ax[:, None] * rs.standard_normal((B, n)) * 1.2 + 0.3).astype(dtype)
+    bx[5, 100] = -60.0                 # far beyond the erfcx table for the half-line priors: this instance is redone
+    bx[7, 9] = np.nan
+    a_old, b_old = np.full(B, 0.4), (0.1 * rs.standard_normal((B, n))).astype(dtype)
+    pr = make_prior(T, ctx, name, kw, n, dtype)
+    post, _, _ = prior2_oracle(orc, name, kw)
+    a_d, b_d = ctx.empty((B,), np.float64), ctx.empty((B, n), dtype)
+    runs0 = ctx.resident_runs()
+    extra = dict(damping=damping, old_a=ctx.array(a_old), old_b=ctx.array(b_old, dtype)) if damping else {}
+    pr.compute_forward_message(ctx.array(ax), ctx.array(bx, dtype), out_a=a_d, out_b=b_d, **extra)
+    assert ctx.resident_runs() == runs0 + 1, "the update did not take the resident pipeline"
+    a_h, b_h = a_d.get(), b_d.get()
+    rt = RT[dtype]
+    assert np.isnan(a_h[7]) and np.isnan(b_h[7]).any() and np.isfinite(np.delete(a_h, 7)).all()
+    for b in (0, 5, 6, 8, 150, 299):
+        ro, vo = post(ax[b], bx[b].astype(np.float64))
+        an, bn = orc.ab_new(ro, vo, ax[b], bx[b].astype(np.float64))
+        if damping:
+            an, bn = damping * a_old[b] + (1 - damping) * an, damping * b_old[b].astype(np.float64) + (1 - damping) * bn
+        close(a_h[b], an, max(rt, 1e-7), scale=an + ax[b])
+        close(b_h[b], bn, max(rt, 1e-7), scale=max(np.abs(bn).max(), np.abs(bx[b]).max()))
