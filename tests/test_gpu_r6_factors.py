@@ -444,3 +444,25 @@ def test_round6_priors_on_the_resident_pipeline(ctx, name, kw, dtype, damping):
             an, bn = damping * a_old[b] + (1 - damping) * an, damping * b_old[b].astype(np.float64) + (1 - damping) * bn
         close(a_h[b], an, max(rt, 1e-7), scale=an + ax[b])
         close(b_h[b], bn, max(rt, 1e-7), scale=max(np.abs(bn).max(), np.abs(bx[b]).max()))
+
+
+def test_phase_retrieval_ep_fp32(ctx, golden_complex):
+    "fp32 vectors (scalars stay f64): 1e-3 on the posterior means of the reference's first iterations"
+    import tramp_amd as T
+    c = golden_complex["ep"][0]
+    W = redraw_complex_W(c)
+    N = c["N"]
+    dt = np.float32
+    model = (T.GaussBernoulliPrior(size=(2, N), rho=c["rho"], dtype=dt, ctx=ctx) @ T.SISOVariable(id="x")
+             @ T.ComplexLinearChannel(W, dtype=dt, ctx=ctx, svd="host") @ T.SISOVariable(id="z")
+             @ T.ModulusLikelihood(y=c["y"], dtype=dt, ctx=ctx)).to_model()
+    ep = T.ExpectationPropagation(model, ctx=ctx)
+    rec = Recorder(T.PassCallback())
+    ep.iterate(max_iter=5, callback=rec, damping=c["damping"],
+               initializer=T.CustomInit(a_init=[("x", "bwd", c["a0"])], b_init=[("x", "bwd", c["b0"])], a=0, b=0))
+    t = c["traj"]
+    for it in range(5):
+        for vid in ("x", "z"):
+            ref = t[f"r:{vid}"][it]
+            close(np.asarray(rec.iters[it]["vars"][vid]["r"]).reshape(ref.shape), ref, 2e-3, scale=max(np.abs(ref).max(), 1e-3))
+            close(rec.iters[it]["vars"][vid]["v"], t[f"v:{vid}"][it], 2e-3)
