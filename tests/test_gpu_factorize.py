@@ -170,3 +170,87 @@ def test_factorization_f32_inputs(T, ctx):
     assert ch.rank == 64
     Vt = ch._Vt.get().astype(np.float64)
     np.testing.assert_allclose(Vt @ Vt.T, np.eye(64), atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 6: the tridiagonal path (csrc/tridiag_eig.h) - own blocked Householder tridiagonalisation, rocSOLVER stedc on the
+# tridiagonal matrix, one Cuppen merge of two halves where stedc's 32-bit indexing ends (forced at small orders with
+# TRAMP_TD_MERGE_ABOVE), blocked back-transformation.  Same bar as the other two eigensolver configurations.
+class env_set:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _tridiag_matrix(kind, n):
+    rs = np.random.RandomState(n + len(kind))
+    if kind == "gram":
+        Wm = rs.randn(n, 2 * n) / np.sqrt(2 * n)
+        return Wm @ Wm.T
+    if kind == "deficient":                      # half the spectrum is an n/2-fold zero eigenvalue: deflation
+        Wm = rs.randn(n, n // 2) / np.sqrt(n)
+        return Wm @ Wm.T
+    if kind == "indefinite":
+        B = rs.randn(n, n)
+        return 0.5 * (B + B.T)
+    if kind == "identity":
+        return np.eye(n)
+    if kind == "tridiagonal":                    # already tridiagonal: every reflector is the identity (tau = 0)
+        e = rs.randn(n - 1)
+        return np.diag(rs.rand(n) + 2.0) + np.diag(e, 1) + np.diag(e, -1)
+    Q, _ = np.linalg.qr(rs.randn(n, n))
+    if kind == "clustered":                      # pairs of eigenvalues 1e-13 apart: Givens deflation in the merge
+        lam = np.repeat([1.0, 2.0, 2.0 + 1e-13, 5.0], n // 4 + 1)[:n]
+    else:                                        # "graded": twelve decades
+        lam = np.logspace(-12, 0, n)
+    G = (Q * lam) @ Q.T
+    return 0.5 * (G + G.T)
+
+
+@pytest.mark.parametrize("merge_above", [None, 64])
+@pytest.mark.parametrize("kind,n", [("gram", 64), ("gram", 257), ("gram", 1031), ("deficient", 700), ("indefinite", 513),
+                                    ("identity", 300), ("tridiagonal", 400), ("clustered", 512), ("graded", 600)])
+def test_eigh_tridiagonal_path(T, ctx, kind, n, merge_above):
+    G = _tridiag_matrix(kind, n)
+    with env_set(TRAMP_EIG_METHOD="tridiag", TRAMP_TD_MERGE_ABOVE=merge_above):
+        w, V = _eigh(T, ctx, G)
+    wr = np.linalg.eigvalsh(G)
+    nG = np.abs(wr).max()
+    assert np.all(np.diff(w) >= 0.0)
+    np.testing.assert_allclose(w, wr, rtol=0, atol=1e-13 * nG)
+    assert np.abs(G @ V - V * w).max() < 2e-13 * nG
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+
+
+@pytest.mark.parametrize("merge_above", [None, 64])
+def test_device_factorization_golden_tridiagonal_path(T, ctx, golden_linear, merge_above):
+    "the golden factorisations of the reference's LinearChannel.__init__ through the tridiagonal path"
+    with env_set(TRAMP_EIG_METHOD="tridiag", TRAMP_TD_MERGE_ABOVE=merge_above):
+        test_device_factorization_golden(T, ctx, golden_linear, None)
+
+
+def test_eigh_tridiagonal_path_large(T, ctx):
+    "n = 3000 (a dozen panels, ragged last tile) with and without the merge: residual and orthogonality on the device result"
+    n = 3000
+    G = _tridiag_matrix("gram", n)
+    wr = np.linalg.eigvalsh(G)
+    for merge_above in (None, 1024):
+        with env_set(TRAMP_EIG_METHOD="tridiag", TRAMP_TD_MERGE_ABOVE=merge_above):
+            w, V = _eigh(T, ctx, G)
+        np.testing.assert_allclose(w, wr, rtol=0, atol=1e-13 * wr.max())
+        assert np.abs(G @ V - V * w).max() < 2e-13 * wr.max()
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12

@@ -35,8 +35,10 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -590,6 +592,17 @@ int cholqr2(Fz& fz, double* Y, size_t m, size_t r, size_t ld, double* gram /* r 
 
 int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth);
 
+#include "tridiag_eig.h"
+
+// TRAMP_EIG_METHOD: "split" = rocSOLVER syevd / the spectral divide and conquer above its cap (rounds 2-5),
+// "tridiag" = the own tridiagonalisation + stedc + back-transformation of tridiag_eig.h (round 6)
+int eig_method_from_env() {
+    const char* s = getenv("TRAMP_EIG_METHOD");
+    if (s && !strcmp(s, "tridiag")) return 1;
+    if (s && !strcmp(s, "split")) return 0;
+    return 0;
+}
+
 // one spectral split of the symmetric A (n x n, full storage, ld = n); eigenvectors overwrite A,
 // ascending eigenvalues go to w_d[n]
 int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
@@ -743,6 +756,12 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
 // symmetric eigendecomposition: A (n x n column-major, upper triangle valid) -> eigenvectors in A,
 // ascending eigenvalues in w_d
 int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth) {
+    const int method = eig_method_from_env();             // read per call, as TRAMP_EIG_CAP is
+    if (method == 1 && n >= 64 && n <= 2 * kStedcCap) {
+        const unsigned nts = (unsigned)((n + 31) / 32);
+        hipLaunchKernelGGL(symmetrize_tiles, dim3(nts, nts), dim3(kBlock), 0, fz.ctx->stream, A, n, 0);
+        return eigh_tridiag(fz, A, n, w_d);
+    }
     const size_t cap = (depth == 0 || fz.sub_cap > fz.eig_cap) ? fz.eig_cap : fz.sub_cap;
     if (n <= cap) {
         double* E = fz.alloc(n);

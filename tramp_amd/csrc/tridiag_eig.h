@@ -1,0 +1,745 @@
+// tridiag_eig.h - symmetric eigensolver of the set-up path by Householder tridiagonalisation (round 6).  Included by
+// factorize.hip inside its anonymous namespace (uses Fz, bgemm, FZ_* and the small kernels defined there).
+//
+// rocSOLVER's syevd is bound by its tridiagonalisation (n = 24 576: sytrd 9.3 s of 12.6 s, one read of the FULL trailing matrix
+// per column at 4.2 TB/s; stedc 1.2 s; ormtr 2.1 s at 14 TFLOP/s - tools/probes/probe_syevd_parts.cpp), and the spectral
+// divide and conquer that replaced it above 16 384 spends 20 + n^3 products per level.  Here:
+//   * dsytrd / dlatrd (LAPACK, lower triangle) with an own symv that reads only the LOWER triangle of the trailing matrix
+//     (half the bytes): 256 x 256 tiles, a lane owns a row, a wave a 64-column strip; row sums through LDS, column sums by a
+//     transposing butterfly over the wave; per-tile partial vectors folded in fixed order (run-to-run reproducible);
+//   * the panel's level-2 pieces as six fused launches per column (no host round trip: beta, tau, alpha stay on the device);
+//   * the trailing rank-2nb update by rocBLAS (syr2k on diagonal tiles, gemm below), every call inside 2^31 elements;
+//   * the tridiagonal problem by rocSOLVER's stedc (n <= 46 340: its 32-bit indexing), above that ONE Cuppen merge of two
+//     stedc halves written here (deflation on the host, secular equation by bisection about the nearer pole, Loewner
+//     vector, eigenvectors, one gemm);
+//   * the back-transformation in panels of 256 reflectors (compact WY, three gemms per panel).
+// Prototype with the same operations in the same order: tools/proto_tridiag_eig.py.
+#pragma once
+
+constexpr int kTdTile = 256;          // symv tile edge
+constexpr int kTdNb = 64;             // reflectors per reduction panel
+constexpr int kTdBt = 256;            // reflectors per back-transformation panel
+
+// ---- y = (L + strict(L)^T) v on the lower triangle of the m x m block At (column-major, lda): tile (I, Js), Js <= I --------
+// row_part[Js m + r]: sum over the tile's columns of L[r, c] v[c] (r >= c);  col_part[I m + c]: sum over its rows of L[r, c] v[r] (r > c)
+// one 16-column group of the wave's strip: FULL = the tile lies strictly below the diagonal and inside the matrix
+template <bool FULL>
+__device__ __forceinline__ void td_symv_group(const double* __restrict__ At, size_t lda, size_t m, size_t r0, size_t cg, bool diag,
+                                              int lane, const double* __restrict__ vcol16, const double (&vr)[4],
+                                              double (&racc)[4], double (&cacc)[16]) {
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const size_t c = cg + cc;
+        const double vc = vcol16[cc];
+        const double* col = At + c * lda + r0 + lane;
+        double a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (FULL) {
+                a[s] = col[s * 64];
+            } else {
+                const size_t r = r0 + (size_t)s * 64 + lane;
+                a[s] = ((c < m) && (r < m) && (!diag || r >= c)) ? col[s * 64] : 0.0;
+            }
+        }
+        double cs = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            racc[s] = fma(a[s], vc, racc[s]);
+            // the diagonal entry belongs to the row sum only
+            const bool strict = FULL || !diag || (r0 + (size_t)s * 64 + lane > c);
+            cs = fma(strict ? a[s] : 0.0, vr[s], cs);
+        }
+        cacc[cc] = cs;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void td_symv_lower(const double* __restrict__ At, size_t lda, size_t m,
+                                                     const double* __restrict__ v, double* __restrict__ row_part,
+                                                     double* __restrict__ col_part) {
+    const unsigned Js = blockIdx.x, I = blockIdx.y;
+    if (Js > I) return;
+    __shared__ double vrow[kTdTile], vcol[kTdTile], rsum[4][kTdTile];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t r0 = (size_t)I * kTdTile, c0 = (size_t)Js * kTdTile;
+    vrow[tid] = (r0 + tid < m) ? v[r0 + tid] : 0.0;
+    vcol[tid] = (c0 + tid < m) ? v[c0 + tid] : 0.0;
+    __syncthreads();
+    double racc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool diag = (I == Js);
+    const bool full = !diag && r0 + kTdTile <= m;                      // (c0 + 256 <= r0 then)
+    const double vr[4] = {vrow[lane], vrow[64 + lane], vrow[128 + lane], vrow[192 + lane]};
+    // the wave's 64-column strip in four groups of 16: the column sums of a group leave through a transposing butterfly
+    // (four steps inside 16-lane groups, then two plain steps across them), 16 accumulators live at a time
+    for (int g = 0; g < 4; ++g) {
+        const size_t cg = c0 + (size_t)w * 64 + (size_t)g * 16;
+        double cacc[16];
+        if (full) td_symv_group<true>(At, lda, m, r0, cg, diag, lane, vcol + w * 64 + g * 16, vr, racc, cacc);
+        else td_symv_group<false>(At, lda, m, r0, cg, diag, lane, vcol + w * 64 + g * 16, vr, racc, cacc);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const bool up = (lane & off) != 0;
+#pragma unroll
+            for (int i = 0; i < off; ++i) {
+                const double keep = up ? cacc[i + off] : cacc[i];
+                const double send = up ? cacc[i] : cacc[i + off];
+                cacc[i] = keep + __shfl_xor(send, off);
+            }
+        }
+        double t = cacc[0];                                              // column (lane & 15) of the group, summed over 16 lanes
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        const size_t c = cg + (lane & 15);
+        if (lane < 16 && c < m) col_part[(size_t)I * m + c] = t;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rsum[w][s * 64 + lane] = racc[s];
+    __syncthreads();
+    if (r0 + tid < m) row_part[(size_t)Js * m + r0 + tid] = (rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]);
+}
+
+// ---- column j of the trailing block, updated by the panel's earlier reflectors (dlatrd):
+//      At[r, j] -= sum_{c < jj} V[r, c] W[j, c] + W[r, c] V[j, c],  r = j .. m - 1;  V = At[:, :jj] (lda), W (ldw)
+__global__ __launch_bounds__(256) void td_col_update(double* __restrict__ At, size_t lda, size_t m, int j,
+                                                     const double* __restrict__ W, size_t ldw) {
+    __shared__ double wrow[kTdNb], vrow[kTdNb];
+    if (threadIdx.x < j) {
+        wrow[threadIdx.x] = W[j + (size_t)threadIdx.x * ldw];
+        vrow[threadIdx.x] = At[j + (size_t)threadIdx.x * lda];
+    }
+    __syncthreads();
+    const size_t r = (size_t)j + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    double acc = 0.0;
+    for (int c = 0; c < j; ++c) acc += At[r + (size_t)c * lda] * wrow[c] + W[r + (size_t)c * ldw] * vrow[c];
+    At[r + (size_t)j * lda] -= acc;
+}
+
+// ---- dlarfg on x = At[j+1:, j] (one workgroup of 1024): beta -> e, tau, d = At[j, j]; v = x / (alpha - beta) with v[0] = 1
+__global__ __launch_bounds__(1024) void td_larfg(double* __restrict__ At, size_t lda, size_t m, int j, double* __restrict__ d,
+                                                 double* __restrict__ e, double* __restrict__ tau) {
+    __shared__ double sm[1024 / kWave];
+    __shared__ double s_scale;
+    double* col = At + (size_t)j * lda;
+    const size_t len = m - (size_t)j - 1;                  // alpha and x
+    double ss = 0.0;
+    for (size_t i = 1 + threadIdx.x; i < len; i += 1024) {
+        const double x = col[j + 1 + i];
+        ss = fma(x, x, ss);
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 1024 / kWave; ++i) t += sm[i];
+        const double alpha = col[j + 1];
+        double beta = alpha, tv = 0.0, sc = 0.0;
+        if (t > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + t), alpha);
+            tv = (beta - alpha) / beta;
+            sc = 1.0 / (alpha - beta);
+        }
+        d[0] = col[j];
+        e[0] = beta;
+        tau[0] = tv;
+        col[j + 1] = 1.0;
+        s_scale = sc;
+    }
+    __syncthreads();
+    const double sc = s_scale;
+    for (size_t i = 1 + threadIdx.x; i < len; i += 1024) col[j + 1 + i] *= sc;
+}
+
+// ---- tmp[c] = sum_r W[r, c] v[r], tmp[kTdNb + c] = sum_r V[r, c] v[r],  r = j+1 .. m-1, c < jj;  one workgroup per dot
+__global__ __launch_bounds__(256) void td_panel_dots(const double* __restrict__ At, size_t lda, size_t m, int j,
+                                                     const double* __restrict__ W, size_t ldw, double* __restrict__ tmp) {
+    __shared__ double sm[256 / kWave];
+    const int c = blockIdx.x % j;
+    const bool useW = blockIdx.x < (unsigned)j;
+    const double* M = useW ? W + (size_t)c * ldw : At + (size_t)c * lda;
+    const double* v = At + (size_t)j * lda;
+    double acc = 0.0;
+    for (size_t r = (size_t)j + 1 + threadIdx.x; r < m; r += 256) acc = fma(M[r], v[r], acc);
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) tmp[(useW ? 0 : kTdNb) + c] = acc;
+}
+
+// ---- w = tau (fold(symv partials) - V tmpW - W tmpV) for rows j+1 .. m-1 -> W[:, j]; per-block partial of w . v
+__global__ __launch_bounds__(256) void td_w_form(const double* __restrict__ At, size_t lda, size_t m, int j,
+                                                 double* __restrict__ W, size_t ldw, const double* __restrict__ tmp,
+                                                 const double* __restrict__ tau, const double* __restrict__ row_part,
+                                                 const double* __restrict__ col_part, size_t ms, unsigned nbt,
+                                                 double* __restrict__ dots) {
+    __shared__ double tW[kTdNb], tV[kTdNb], sm[256 / kWave];
+    if (threadIdx.x < j) {
+        tW[threadIdx.x] = tmp[threadIdx.x];
+        tV[threadIdx.x] = tmp[kTdNb + threadIdx.x];
+    }
+    __syncthreads();
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;          // index within the symv's sub-block (rows j+1 ..)
+    double prod = 0.0;
+    if (q < ms) {
+        const size_t r = (size_t)j + 1 + q;
+        const unsigned I = (unsigned)(q / kTdTile);
+        double y = 0.0;
+        for (unsigned Js = 0; Js <= I; ++Js) y += row_part[(size_t)Js * ms + q];
+        for (unsigned Ii = I; Ii < nbt; ++Ii) y += col_part[(size_t)Ii * ms + q];
+        double corr = 0.0;
+        for (int c = 0; c < j; ++c) corr += At[r + (size_t)c * lda] * tW[c] + W[r + (size_t)c * ldw] * tV[c];
+        const double w = tau[0] * (y - corr);
+        W[r + (size_t)j * ldw] = w;
+        prod = w * At[r + (size_t)j * lda];
+    }
+    prod = block_sum(prod, sm);
+    if (threadIdx.x == 0) dots[blockIdx.x] = prod;
+}
+
+// ---- w += -(tau / 2)(w . v) v
+__global__ __launch_bounds__(256) void td_w_finish(const double* __restrict__ At, size_t lda, size_t m, int j,
+                                                   double* __restrict__ W, size_t ldw, const double* __restrict__ tau,
+                                                   const double* __restrict__ dots, unsigned ndots) {
+    __shared__ double s_alpha;
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned i = 0; i < ndots; ++i) t += dots[i];
+        s_alpha = -0.5 * tau[0] * t;
+    }
+    __syncthreads();
+    const size_t r = (size_t)j + 1 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < m) W[r + (size_t)j * ldw] += s_alpha * At[r + (size_t)j * lda];
+}
+
+// the panel is done: the sub-diagonal entries (held at 1 while the panel's reflectors were in use) get their e back;
+// the last diagonal entry of the whole matrix goes to d
+__global__ void td_restore_subdiag(double* __restrict__ At, size_t lda, int pb, const double* __restrict__ e) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < pb) At[(size_t)j + 1 + (size_t)j * lda] = e[j];
+}
+__global__ void get_diag_last(const double* __restrict__ A, size_t n, double* __restrict__ d) { d[n - 1] = A[(n - 1) + (n - 1) * n]; }
+
+// rank-2pb update of the lower triangle of C (mt x mt, ldc): C -= V W^T + W V^T;  V (ldv), W (ldw) are mt x pb
+int td_syr2k_lower(Fz& fz, size_t mt, int pb, const double* V, size_t ldv, const double* W, size_t ldw, double* C, size_t ldc) {
+    if (!mt) return TRAMP_OK;
+    const size_t T = min3(tile_for(ldv), tile_for(ldw), tile_for(ldc));
+    const double m1 = -1.0, one = 1.0;
+    for (size_t j0 = 0; j0 < mt; j0 += T) {
+        const size_t nj = mt - j0 < T ? mt - j0 : T;
+        FZ_RB(fz, rocblas_dsyr2k(fz.h, rocblas_fill_lower, rocblas_operation_none, (rocblas_int)nj, pb, &m1, V + j0,
+                                 (rocblas_int)ldv, W + j0, (rocblas_int)ldw, &one, C + j0 + j0 * ldc, (rocblas_int)ldc));
+        for (size_t i0 = j0 + T; i0 < mt; i0 += T) {
+            const size_t mi = mt - i0 < T ? mt - i0 : T;
+            FZ_RB(fz, rocblas_dgemm(fz.h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)mi, (rocblas_int)nj,
+                                    pb, &m1, V + i0, (rocblas_int)ldv, W + j0, (rocblas_int)ldw, &one, C + i0 + j0 * ldc,
+                                    (rocblas_int)ldc));
+            FZ_RB(fz, rocblas_dgemm(fz.h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)mi, (rocblas_int)nj,
+                                    pb, &m1, W + i0, (rocblas_int)ldw, V + j0, (rocblas_int)ldv, &one, C + i0 + j0 * ldc,
+                                    (rocblas_int)ldc));
+        }
+    }
+    return TRAMP_OK;
+}
+
+// A (n x n, column-major, LOWER triangle valid) -> d[n], e[n-1], tau[n-1] on the device, reflectors below the sub-diagonal
+int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* tau) {
+    hipStream_t st = fz.ctx->stream;
+    const unsigned nbt_max = (unsigned)((n + kTdTile - 1) / kTdTile);
+    double* W = fz.alloc(n * kTdNb);
+    double* row_part = fz.alloc((size_t)nbt_max * n);
+    double* col_part = fz.alloc((size_t)nbt_max * n);
+    double* tmp = fz.alloc(2 * kTdNb);
+    double* dots = fz.alloc(nbt_max + 1);
+    if (!W || !row_part || !col_part || !tmp || !dots) return fz.rc;
+    // TRAMP_TD_PROFILE=1 (diagnosis): synchronise after every launch and report the time per kernel family
+    static const bool prof = getenv("TRAMP_TD_PROFILE") != nullptr;
+    double tacc[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int k, double& t0) {
+        if (!prof) return;
+        (void)hipStreamSynchronize(st);
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double now = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+        tacc[k] += now - t0;
+        t0 = now;
+    };
+    for (size_t i = 0; i + 1 < n; i += kTdNb) {
+        const int pb = (int)((n - 1 - i) < (size_t)kTdNb ? (n - 1 - i) : (size_t)kTdNb);
+        const size_t m = n - i;
+        double* At = A + i + i * n;
+        const size_t ldw = m;
+        double t0 = 0.0;
+        if (prof) {
+            (void)hipStreamSynchronize(st);
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            t0 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+        }
+        for (int j = 0; j < pb; ++j) {
+            if (j) hipLaunchKernelGGL(td_col_update, dim3((unsigned)((m - j + 255) / 256)), dim3(256), 0, st, At, n, m, j, W, ldw);
+            stamp(0, t0);
+            hipLaunchKernelGGL(td_larfg, dim3(1), dim3(1024), 0, st, At, n, m, j, d + i + j, e + i + j, tau + i + j);
+            stamp(1, t0);
+            const size_t ms = m - (size_t)j - 1;                     // the symv's block: rows / columns j+1 ..
+            const unsigned nbt = (unsigned)((ms + kTdTile - 1) / kTdTile);
+            hipLaunchKernelGGL(td_symv_lower, dim3(nbt, nbt), dim3(256), 0, st, At + (j + 1) + (size_t)(j + 1) * n, n, ms,
+                               At + (j + 1) + (size_t)j * n, row_part, col_part);
+            stamp(2, t0);
+            if (j) hipLaunchKernelGGL(td_panel_dots, dim3(2 * j), dim3(256), 0, st, At, n, m, j, W, ldw, tmp);
+            stamp(3, t0);
+            const unsigned nblk_r = (unsigned)((ms + 255) / 256);
+            hipLaunchKernelGGL(td_w_form, dim3(nblk_r), dim3(256), 0, st, At, n, m, j, W, ldw, tmp, tau + i + j, row_part,
+                               col_part, ms, nbt, dots);
+            stamp(4, t0);
+            hipLaunchKernelGGL(td_w_finish, dim3(nblk_r), dim3(256), 0, st, At, n, m, j, W, ldw, tau + i + j, dots, nblk_r);
+            stamp(5, t0);
+        }
+        // trailing update with V = At[pb:, :pb] (its unit entry in place), W[pb:, :]
+        const size_t mt = m - (size_t)pb;
+        FZ_OK(td_syr2k_lower(fz, mt, pb, At + pb, n, W + pb, ldw, At + pb + (size_t)pb * n, n));
+        hipLaunchKernelGGL(td_restore_subdiag, dim3((pb + 63) / 64), dim3(64), 0, st, At, n, pb, e + i);
+        stamp(6, t0);
+    }
+    if (prof)
+        fprintf(stderr, "[tramp tridiag] n=%zu (synchronised launches): col_update %.3f s, larfg %.3f, symv %.3f, panel_dots %.3f, "
+                        "w_form %.3f, w_finish %.3f, syr2k %.3f\n", n, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6]);
+    hipLaunchKernelGGL(get_diag_last, dim3(1), dim3(1), 0, st, A, n, d);
+    fz.release(W);
+    fz.release(row_part);
+    fz.release(col_part);
+    fz.release(tmp);
+    fz.release(dots);
+    fz.tick("tridiag: sytrd", n);
+    return TRAMP_OK;
+}
+
+// ---- back-transformation: C <- H(0) H(1) ... H(n-2) C, the reflectors below the sub-diagonal of A (as td_sytrd_lower left
+// them, the sub-diagonal itself holding e), panels of kTdBt reflectors, last panel first.
+// Vp (mp x pb, ld mp) = unit lower trapezoidal copy of the panel
+__global__ void td_copy_panel(const double* __restrict__ A, size_t n, size_t i, int pb, size_t mp, double* __restrict__ Vp) {
+    const size_t total = mp * (size_t)pb;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t r = idx % mp, c = idx / mp;                    // row r of the panel = row i + 1 + r of A
+        Vp[idx] = (r < c) ? 0.0 : (r == c ? 1.0 : A[(i + 1 + r) + (i + c) * n]);
+    }
+}
+
+int td_backtransform(Fz& fz, const double* A, size_t n, const double* tau_d, double* C, size_t ncols) {
+    hipStream_t st = fz.ctx->stream;
+    if (n < 2) return TRAMP_OK;
+    double* Vp = fz.alloc(n * kTdBt);
+    double* S = fz.alloc((size_t)kTdBt * kTdBt);
+    double* Td = fz.alloc((size_t)kTdBt * kTdBt);
+    double* W1 = fz.alloc((size_t)kTdBt * ncols);
+    double* W2 = fz.alloc((size_t)kTdBt * ncols);
+    if (!Vp || !S || !Td || !W1 || !W2) return fz.rc;
+    std::vector<double> hS((size_t)kTdBt * kTdBt), hT((size_t)kTdBt * kTdBt), htau(n);
+    FZ_HIP(fz, hipMemcpyAsync(htau.data(), tau_d, (n - 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    const size_t npan = (n - 1 + kTdBt - 1) / kTdBt;
+    for (size_t p = npan; p-- > 0;) {
+        const size_t i = p * kTdBt;
+        const int pb = (int)((n - 1 - i) < (size_t)kTdBt ? (n - 1 - i) : (size_t)kTdBt);
+        const size_t mp = n - i - 1;
+        hipLaunchKernelGGL(td_copy_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, A, n, i, pb, mp, Vp);
+        // T of the compact WY form (dlarft, forward columnwise) from S = Vp^T Vp, on the host (pb <= 256)
+        FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, pb, pb, mp, 1.0, Vp, mp, Vp, mp, 0.0, S, pb));
+        FZ_HIP(fz, hipMemcpyAsync(hS.data(), S, (size_t)pb * pb * sizeof(double), hipMemcpyDeviceToHost, st));
+        FZ_HIP(fz, hipStreamSynchronize(st));
+        for (int j = 0; j < pb; ++j) {
+            const double tj = htau[i + j];
+            for (int r = 0; r < pb; ++r) hT[r + (size_t)j * pb] = 0.0;
+            hT[j + (size_t)j * pb] = tj;
+            for (int r = 0; r < j; ++r) {
+                double acc = 0.0;
+                for (int c = r; c < j; ++c) acc += hT[r + (size_t)c * pb] * hS[c + (size_t)j * pb];
+                hT[r + (size_t)j * pb] = -tj * acc;
+            }
+        }
+        FZ_HIP(fz, hipMemcpyAsync(Td, hT.data(), (size_t)pb * pb * sizeof(double), hipMemcpyHostToDevice, st));
+        // C[i+1:, :] -= Vp (T (Vp^T C[i+1:, :]))
+        FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, pb, ncols, mp, 1.0, Vp, mp, C + i + 1, n, 0.0, W1, pb));
+        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, pb, ncols, pb, 1.0, Td, pb, W1, pb, 0.0, W2, pb));
+        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, mp, ncols, pb, -1.0, Vp, mp, W2, pb, 1.0, C + i + 1, n));
+        FZ_HIP(fz, hipStreamSynchronize(st));                          // hT / hS are reused by the next panel
+    }
+    fz.release(Vp);
+    fz.release(S);
+    fz.release(Td);
+    fz.release(W1);
+    fz.release(W2);
+    fz.tick("tridiag: back-transformation", n);
+    return TRAMP_OK;
+}
+
+constexpr size_t kStedcCap = 46336;      // rocSOLVER's 32-bit indexing of the n x n eigenvector matrix
+
+// ====================================================================================================================
+// One Cuppen merge (LAPACK dlaed1-4 restated for the device): T = diag(T1', T2') + rho u u^T with
+// T1' = T1 - |beta| e_last e_last^T, T2' = T2 - |beta| e_first e_first^T, beta = the coupling off-diagonal entry.
+// The halves go to rocSOLVER's stedc (each below its 32-bit limit); the merge is written here:
+//   z = [Q1^T e_last ; sign(beta) Q2^T e_first] / sqrt 2, rho = 2 |beta|;  D + rho z z^T with D = diag(D1, D2) sorted;
+//   deflation on the host (dlaed2: negligible z_j; pairs of close d by a Givens rotation) - mandatory: the eigenvectors of
+//   these tridiagonal matrices are localised, |z_j| falls to 1e-200;
+//   secular equation 1 + rho sum z_j^2 / (d_j - lam) = 0 by bisection in mu = lam - d_o about the nearer pole d_o (one wave
+//   per root; geometric steps while the bracket spans decades): lam_i = d_o(i) + mu_i, differences d_j - lam_i formed as
+//   (d_j - d_o(i)) - mu_i, never through lam itself;
+//   Loewner's vector zhat (Gu & Eisenstat) so that the computed eigenvectors zhat_j / (d_j - lam_i) are orthogonal to working
+//   precision whatever the last bits of the roots;  Q = [columns that take part] V, one gemm.
+// Prototype: tools/proto_tridiag_eig.py (same operations, same order).
+
+__global__ void td_gather_z(const double* __restrict__ C1, size_t n1, const double* __restrict__ C2, size_t n2, double sgn,
+                            double* __restrict__ z) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < n1) z[j] = C1[(n1 - 1) + j * n1] * 0.70710678118654752440;
+    else if (j < n1 + n2) z[j] = sgn * C2[(j - n1) * n2] * 0.70710678118654752440;
+}
+
+// Q0[:, t] = column src[t] of blockdiag(C1, C2)   (src < n1: a column of C1 over zeros, else one of C2 under zeros)
+__global__ void td_build_q0(const double* __restrict__ C1, size_t n1, const double* __restrict__ C2, size_t n2,
+                            const unsigned* __restrict__ src, double* __restrict__ Q0) {
+    const size_t n = n1 + n2;
+    const size_t t = blockIdx.y;
+    const unsigned s = src[t];
+    double* out = Q0 + t * n;
+    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) {
+        double v = 0.0;
+        if (s < n1) v = (r < n1) ? C1[r + (size_t)s * n1] : 0.0;
+        else v = (r >= n1) ? C2[(r - n1) + (size_t)(s - n1) * n2] : 0.0;
+        out[r] = v;
+    }
+}
+
+// columns p and j of Q <- (c qp + s qj, c qj - s qp)
+__global__ void td_rotate_cols(double* __restrict__ Q, size_t n, size_t p, size_t j, double c, double s) {
+    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) {
+        const double qp = Q[r + p * n], qj = Q[r + j * n];
+        Q[r + p * n] = c * qp + s * qj;
+        Q[r + j * n] = c * qj - s * qp;
+    }
+}
+
+// dst[:, t] = src[:, idx[t]]  for t < count
+__global__ void td_gather_cols(const double* __restrict__ src, size_t n, const unsigned* __restrict__ idx, double* __restrict__ dst) {
+    const size_t t = blockIdx.y;
+    const double* in = src + (size_t)idx[t] * n;
+    double* out = dst + t * n;
+    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) out[r] = in[r];
+}
+
+// one wave per root: (org, mu) of root i of 1 + rho sum_j z2_j / (d_j - lam), d ascending, k poles
+__global__ __launch_bounds__(256) void td_secular(const double* __restrict__ d, const double* __restrict__ z2, unsigned k, double rho,
+                                                  double z2sum, unsigned* __restrict__ org, double* __restrict__ mu) {
+    const unsigned i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= k) return;
+    const int lane = threadIdx.x & 63;
+    const bool last = (i + 1 == k);
+    const double di = d[i];
+    const double hi_pole = last ? d[k - 1] + rho * z2sum : d[i + 1];
+    const double gap = hi_pole - di;
+    const double mid = 0.5 * gap;
+    auto feval = [&](unsigned o, double m_) {
+        const double dorg = d[o];
+        double acc = 0.0;
+        for (unsigned j = lane; j < k; j += 64) acc += z2[j] / ((d[j] - dorg) - m_);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);      // every lane holds the sum: uniform branches
+        return 1.0 + rho * acc;
+    };
+    const double fm = feval(i, mid);
+    unsigned o;
+    double lo, hi;
+    if (fm > 0.0 || last) {
+        o = i;
+        lo = 0.0;
+        hi = last ? gap : mid;
+        if (last && !(fm > 0.0)) lo = mid;
+    } else {
+        o = i + 1;
+        lo = -mid;
+        hi = 0.0;
+    }
+    for (int it = 0; it < 220; ++it) {
+        double m_;
+        if (lo != 0.0 && hi != 0.0 && (hi / lo > 4.0 || lo / hi > 4.0)) m_ = copysign(sqrt(lo * hi), lo);
+        else if (lo == 0.0 && hi != 0.0 && it < 80) m_ = it ? hi * 0.00390625 : hi * 0.5;
+        else if (hi == 0.0 && lo != 0.0 && it < 80) m_ = it ? lo * 0.00390625 : lo * 0.5;
+        else m_ = 0.5 * (lo + hi);
+        if (m_ == lo || m_ == hi) break;
+        const double f = feval(o, m_);
+        if (f > 0.0) hi = m_;
+        else lo = m_;
+    }
+    if (lane == 0) {
+        org[i] = o;
+        mu[i] = (lo != 0.0 && hi != 0.0) ? 0.5 * (lo + hi) : (lo == 0.0 ? hi : lo);
+    }
+}
+
+// one wave per j: zhat_j = sign(z_j) sqrt(| prod_i (lam_i - d_j) / (rho prod_{i != j} (d_i - d_j)) |)
+__global__ __launch_bounds__(256) void td_loewner(const double* __restrict__ d, const double* __restrict__ z, unsigned k, double rho,
+                                                  const unsigned* __restrict__ org, const double* __restrict__ mu,
+                                                  double* __restrict__ zhat) {
+    const unsigned j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= k) return;
+    const int lane = threadIdx.x & 63;
+    const double dj = d[j];
+    double prod = 1.0;
+    for (unsigned i = lane; i < k; i += 64) {
+        const double num = (d[org[i]] - dj) + mu[i];                  // lam_i - d_j
+        const double den = (i == j) ? rho : d[i] - dj;
+        prod *= num / den;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) prod *= __shfl_xor(prod, off);
+    if (lane == 0) zhat[j] = copysign(sqrt(fabs(prod)), z[j]);
+}
+
+// one workgroup per root i: V[:, i] = normalised zhat_j / ((d_j - d_org(i)) - mu_i)
+__global__ __launch_bounds__(256) void td_secular_vectors(const double* __restrict__ d, const double* __restrict__ zhat, unsigned k,
+                                                          const unsigned* __restrict__ org, const double* __restrict__ mu,
+                                                          double* __restrict__ V) {
+    __shared__ double sm[256 / kWave];
+    const unsigned i = blockIdx.x;
+    const double dorg = d[org[i]], m_ = mu[i];
+    double* col = V + (size_t)i * k;
+    double ss = 0.0;
+    for (unsigned j = threadIdx.x; j < k; j += 256) {
+        const double x = zhat[j] / ((d[j] - dorg) - m_);
+        col[j] = x;
+        ss = fma(x, x, ss);
+    }
+    ss = block_sum(ss, sm);
+    const double inv = 1.0 / sqrt(ss);
+    for (unsigned j = threadIdx.x; j < k; j += 256) col[j] *= inv;
+}
+
+// dst[:, pos[t]] = src[:, idx[t]]
+__global__ void td_scatter_cols(const double* __restrict__ src, size_t n, const unsigned* __restrict__ idx,
+                                const unsigned* __restrict__ pos, double* __restrict__ dst) {
+    const size_t t = blockIdx.y;
+    const double* in = src + (size_t)idx[t] * n;
+    double* out = dst + (size_t)pos[t] * n;
+    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) out[r] = in[r];
+}
+
+__global__ void td_roots_to_lambda(const double* __restrict__ d, const unsigned* __restrict__ org, const double* __restrict__ mu,
+                                   unsigned k, double* __restrict__ lam) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < k) lam[i] = d[org[i]] + mu[i];
+}
+
+// eigen-decomposition of the symmetric tridiagonal (d, e) of order n > kStedcCap (host copies hd, he): eigenvectors -> QT (n x n,
+// allocated here, handed to the caller), ascending eigenvalues -> w_d
+int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double>& he, double* w_d, double** QT_out) {
+    hipStream_t st = fz.ctx->stream;
+    const size_t n1 = n / 2, n2 = n - n1;
+    if (n1 > kStedcCap || n2 > kStedcCap) return fz.fail(TRAMP_ENOTSUP, "factorize", "tridiagonal merge: halves beyond rocSOLVER's range");
+    const double beta = he[n1 - 1];
+    const double ab = fabs(beta), sgn = beta >= 0.0 ? 1.0 : -1.0;
+    hd[n1 - 1] -= ab;
+    hd[n1] -= ab;
+    double* D = fz.alloc(n);
+    double* E = fz.alloc(n);
+    double* C1 = fz.alloc(n1 * n1);
+    double* C2 = fz.alloc(n2 * n2);
+    if (!D || !E || !C1 || !C2) return fz.rc;
+    FZ_HIP(fz, hipMemcpyAsync(D, hd.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    FZ_HIP(fz, hipMemcpyAsync(E, he.data(), (n - 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    FZ_RB(fz, rocsolver_dstedc(fz.h, rocblas_evect_tridiagonal, (rocblas_int)n1, D, E, C1, (rocblas_int)n1, fz.info_d));
+    FZ_OK(check_info(fz, "rocsolver_dstedc"));
+    FZ_RB(fz, rocsolver_dstedc(fz.h, rocblas_evect_tridiagonal, (rocblas_int)n2, D + n1, E + n1, C2, (rocblas_int)n2, fz.info_d));
+    FZ_OK(check_info(fz, "rocsolver_dstedc"));
+    fz.tick("tridiag: stedc of the halves", n);
+    // ---- z and the poles on the host
+    double* zd = fz.alloc(n);
+    if (!zd) return fz.rc;
+    hipLaunchKernelGGL(td_gather_z, dim3(nblk(n)), dim3(kBlock), 0, st, C1, n1, C2, n2, sgn, zd);
+    std::vector<double> d0(n), z0(n);
+    FZ_HIP(fz, hipMemcpyAsync(d0.data(), D, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    FZ_HIP(fz, hipMemcpyAsync(z0.data(), zd, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    const double rho = 2.0 * ab;
+    std::vector<unsigned> order(n);
+    for (size_t t = 0; t < n; ++t) order[t] = (unsigned)t;
+    std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return d0[a] < d0[b]; });
+    std::vector<double> d(n), z(n);
+    double dmax = 0.0, zmax = 0.0;
+    for (size_t t = 0; t < n; ++t) {
+        d[t] = d0[order[t]];
+        z[t] = z0[order[t]];
+        dmax = fmax(dmax, fabs(d[t]));
+        zmax = fmax(zmax, fabs(z[t]));
+    }
+    // Q0 = blockdiag(C1, C2) with its columns in the sorted order
+    double* Q0 = fz.alloc(n * n);
+    unsigned* idx_d = (unsigned*)fz.alloc(n);                 // (n doubles hold 2n unsigned)
+    if (!Q0 || !idx_d) return fz.rc;
+    FZ_HIP(fz, hipMemcpyAsync(idx_d, order.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(td_build_q0, dim3(64, (unsigned)n), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d, Q0);
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    fz.release(C1);
+    fz.release(C2);
+    // ---- deflation (dlaed2)
+    const double tol = 8.0 * kEps * fmax(dmax, zmax);
+    std::vector<unsigned> live;
+    live.reserve(n);
+    size_t n_rot = 0;
+    for (size_t j = 0; j < n; ++j) {
+        if (!(rho * fabs(z[j]) > tol)) continue;               // type 1: (d_j, q_j) is an eigenpair as it stands
+        if (!live.empty()) {
+            const size_t p = live.back();
+            const double c0 = z[j], s0 = z[p];
+            const double t0 = hypot(c0, s0);
+            if (fabs((d[j] - d[p]) * (c0 / t0) * (s0 / t0)) <= tol) {
+                // type 2: rotate (p, j) so that z_p = 0; p leaves with its rotated eigenvalue
+                const double c = c0 / t0, s = -s0 / t0;
+                hipLaunchKernelGGL(td_rotate_cols, dim3(64), dim3(kBlock), 0, st, Q0, n, p, j, c, s);
+                const double dp = d[p], dj = d[j];
+                d[p] = dp * c * c + dj * s * s;
+                d[j] = dp * s * s + dj * c * c;
+                z[j] = t0;
+                z[p] = 0.0;
+                live.back() = (unsigned)j;
+                ++n_rot;
+                continue;
+            }
+        }
+        live.push_back((unsigned)j);
+    }
+    const size_t k = live.size();
+    // the rotated d's need not be ascending any more within a run of rotations: sort the poles that take part
+    std::stable_sort(live.begin(), live.end(), [&](unsigned a, unsigned b) { return d[a] < d[b]; });
+    std::vector<char> is_live(n, 0);
+    for (unsigned t : live) is_live[t] = 1;
+    std::vector<double> lam(n);
+    std::vector<double> dk(k), zk(k), z2k(k);
+    double z2sum = 0.0;
+    for (size_t i = 0; i < k; ++i) {
+        dk[i] = d[live[i]];
+        zk[i] = z[live[i]];
+        z2k[i] = zk[i] * zk[i];
+        z2sum += z2k[i];
+    }
+    static const bool verbose = getenv("TRAMP_EIG_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[tramp tridiag] merge n=%zu: %zu of the poles take part (%zu rotations), rho = %.3e\n", n, k, n_rot, rho);
+    double* OUT = nullptr;
+    std::vector<double> lam_live(k);
+    double* R = nullptr;
+    if (k) {
+        double* dk_d = fz.alloc(k);
+        double* zk_d = fz.alloc(k);
+        double* z2_d = fz.alloc(k);
+        double* mu_d = fz.alloc(k);
+        double* zh_d = fz.alloc(k);
+        double* lam_d = fz.alloc(k);
+        unsigned* org_d = (unsigned*)fz.alloc(k);
+        double* QL = fz.alloc(n * k);
+        double* V = fz.alloc(k * k);
+        if (!dk_d || !zk_d || !z2_d || !mu_d || !zh_d || !lam_d || !org_d || !QL || !V) return fz.rc;
+        FZ_HIP(fz, hipMemcpyAsync(dk_d, dk.data(), k * sizeof(double), hipMemcpyHostToDevice, st));
+        FZ_HIP(fz, hipMemcpyAsync(zk_d, zk.data(), k * sizeof(double), hipMemcpyHostToDevice, st));
+        FZ_HIP(fz, hipMemcpyAsync(z2_d, z2k.data(), k * sizeof(double), hipMemcpyHostToDevice, st));
+        FZ_HIP(fz, hipMemcpyAsync(idx_d, live.data(), k * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(td_gather_cols, dim3(64, (unsigned)k), dim3(kBlock), 0, st, Q0, n, idx_d, QL);
+        hipLaunchKernelGGL(td_secular, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, st, dk_d, z2_d, (unsigned)k, rho, z2sum, org_d, mu_d);
+        hipLaunchKernelGGL(td_loewner, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, st, dk_d, zk_d, (unsigned)k, rho, org_d, mu_d, zh_d);
+        hipLaunchKernelGGL(td_secular_vectors, dim3((unsigned)k), dim3(256), 0, st, dk_d, zh_d, (unsigned)k, org_d, mu_d, V);
+        hipLaunchKernelGGL(td_roots_to_lambda, dim3(nblk(k)), dim3(kBlock), 0, st, dk_d, org_d, mu_d, (unsigned)k, lam_d);
+        FZ_HIP(fz, hipMemcpyAsync(lam_live.data(), lam_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
+        FZ_HIP(fz, hipStreamSynchronize(st));
+        fz.tick("tridiag: secular equation + vectors", k);
+        R = fz.alloc(n * k);
+        if (!R) return fz.rc;
+        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, k, k, 1.0, QL, n, V, k, 0.0, R, n));
+        FZ_HIP(fz, hipStreamSynchronize(st));
+        fz.tick("tridiag: merge gemm", k);
+        fz.release(QL);
+        fz.release(V);
+        fz.release(dk_d);
+        fz.release(zk_d);
+        fz.release(z2_d);
+        fz.release(mu_d);
+        fz.release(zh_d);
+        fz.release(lam_d);
+        fz.release(org_d);
+    }
+    // ---- final order: eigenvalue t comes from R column (live) or Q0 column (deflated)
+    struct Ev { double lam; unsigned col; char from_r; };
+    std::vector<Ev> ev;
+    ev.reserve(n);
+    for (size_t i = 0; i < k; ++i) ev.push_back({lam_live[i], (unsigned)i, 1});
+    for (size_t t = 0; t < n; ++t)
+        if (!is_live[t]) ev.push_back({d[t], (unsigned)t, 0});
+    std::stable_sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.lam < b.lam; });
+    OUT = fz.alloc(n * n);
+    if (!OUT) return fz.rc;
+    std::vector<unsigned> from_r_idx, from_r_pos, from_q_idx, from_q_pos;
+    std::vector<double> w(n);
+    for (size_t t = 0; t < n; ++t) {
+        w[t] = ev[t].lam;
+        if (ev[t].from_r) { from_r_idx.push_back(ev[t].col); from_r_pos.push_back((unsigned)t); }
+        else { from_q_idx.push_back(ev[t].col); from_q_pos.push_back((unsigned)t); }
+    }
+    // scatter: OUT[:, pos] = src[:, idx]  - as a gather with an index table over the destination columns
+    unsigned* pos_d = (unsigned*)fz.alloc(n);
+    if (!pos_d) return fz.rc;
+    auto scatter = [&](const double* src, std::vector<unsigned>& idx, std::vector<unsigned>& pos) -> int {
+        const size_t cnt = idx.size();
+        if (!cnt) return TRAMP_OK;
+        FZ_HIP(fz, hipMemcpyAsync(idx_d, idx.data(), cnt * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        FZ_HIP(fz, hipMemcpyAsync(pos_d, pos.data(), cnt * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(td_scatter_cols, dim3(64, (unsigned)cnt), dim3(kBlock), 0, st, src, n, idx_d, pos_d, OUT);
+        FZ_HIP(fz, hipStreamSynchronize(st));
+        return TRAMP_OK;
+    };
+    if (R) FZ_OK(scatter(R, from_r_idx, from_r_pos));
+    FZ_OK(scatter(Q0, from_q_idx, from_q_pos));
+    FZ_HIP(fz, hipMemcpyAsync(w_d, w.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    if (R) fz.release(R);
+    fz.release(Q0);
+    fz.release(idx_d);
+    fz.release(pos_d);
+    fz.release(D);
+    fz.release(E);
+    fz.release(zd);
+    *QT_out = OUT;
+    return TRAMP_OK;
+}
+
+// A (n x n column-major, both triangles valid) -> eigenvectors in A, ascending eigenvalues in w_d
+int eigh_tridiag(Fz& fz, double* A, size_t n, double* w_d) {
+    hipStream_t st = fz.ctx->stream;
+    if (n > 2 * kStedcCap) return fz.fail(TRAMP_ENOTSUP, "factorize", "tridiagonal eigensolver: n beyond one merge of two stedc halves");
+    double* e = fz.alloc(n);
+    double* tau = fz.alloc(n);
+    if (!e || !tau) return fz.rc;
+    FZ_OK(td_sytrd_lower(fz, A, n, w_d, e, tau));
+    double* C = nullptr;
+    // TRAMP_TD_MERGE_ABOVE (test hook): orders above it take the merge of two stedc halves although one stedc call would do
+    const size_t merge_above = [] {
+        const char* s = getenv("TRAMP_TD_MERGE_ABOVE");
+        const long v = s ? atol(s) : 0;
+        return (v >= 64 && (size_t)v < kStedcCap) ? (size_t)v : kStedcCap;
+    }();
+    if (n <= merge_above) {
+        C = fz.alloc(n * n);
+        if (!C) return fz.rc;
+        FZ_RB(fz, rocsolver_dstedc(fz.h, rocblas_evect_tridiagonal, (rocblas_int)n, w_d, e, C, (rocblas_int)n, fz.info_d));
+        FZ_OK(check_info(fz, "rocsolver_dstedc"));
+        fz.tick("tridiag: rocsolver stedc", n);
+    } else {
+        std::vector<double> hd(n), he(n);
+        FZ_HIP(fz, hipMemcpyAsync(hd.data(), w_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        FZ_HIP(fz, hipMemcpyAsync(he.data(), e, (n - 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+        FZ_HIP(fz, hipStreamSynchronize(st));
+        FZ_OK(td_stedc_merge(fz, n, hd, he, w_d, &C));
+    }
+    FZ_OK(td_backtransform(fz, A, n, tau, C, n));
+    FZ_HIP(fz, hipMemcpyAsync(A, C, n * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    FZ_HIP(fz, hipStreamSynchronize(st));
+    fz.release(e);
+    fz.release(tau);
+    fz.release(C);
+    return TRAMP_OK;
+}
