@@ -2,9 +2,10 @@
 captured from the reference's LinearChannel.__init__ (tramp/channels/linear/linear_channel.py:8-15,
 30-46: np.linalg.matrix_rank + full SVD) and against NumPy.
 
-Three eigensolver configurations are exercised on the same cases: rocSOLVER alone, one spectral
-divide-and-conquer split (TRAMP_EIG_CAP below the matrix size - the path BASELINE configs[3] takes at
-k = 50000), and a cap small enough to force recursion.
+Three configurations of the rounds 2-5 eigensolver (TRAMP_EIG_METHOD=split) are exercised on the same cases: rocSOLVER
+alone, one spectral divide-and-conquer split (TRAMP_EIG_CAP below the matrix size), and a cap small enough to force
+recursion; then the round-6 default, the tridiagonal path (one stedc call, and the Cuppen merge BASELINE configs[3]
+takes at k = 50000, forced at small orders) - see the end of the file.
 """
 import ctypes as C
 import os
@@ -24,12 +25,14 @@ def T():
 
 
 class eig_cap:
-    "TRAMP_EIG_CAP is read (getenv) by every tramp_linear_factorize / tramp_eigh call."
+    "TRAMP_EIG_CAP / TRAMP_EIG_METHOD are read (getenv) by every tramp_linear_factorize / tramp_eigh call."
 
     def __init__(self, cap):
         self.cap = cap
 
     def __enter__(self):
+        self.old_method = os.environ.get("TRAMP_EIG_METHOD")
+        os.environ["TRAMP_EIG_METHOD"] = "split"
         self.old = os.environ.get("TRAMP_EIG_CAP")
         if self.cap is None:
             os.environ.pop("TRAMP_EIG_CAP", None)
@@ -41,6 +44,10 @@ class eig_cap:
             os.environ.pop("TRAMP_EIG_CAP", None)
         else:
             os.environ["TRAMP_EIG_CAP"] = self.old
+        if self.old_method is None:
+            os.environ.pop("TRAMP_EIG_METHOD", None)
+        else:
+            os.environ["TRAMP_EIG_METHOD"] = self.old_method
 
 
 def _W(case):
@@ -221,12 +228,17 @@ def _tridiag_matrix(kind, n):
     return 0.5 * (G + G.T)
 
 
-@pytest.mark.parametrize("merge_above", [None, 64])
+MERGES = {"stedc": dict(TRAMP_TD_MERGE_ABOVE=None, TRAMP_TD_MERGE_DENSE=None),            # one stedc call
+          "merge": dict(TRAMP_TD_MERGE_ABOVE=64, TRAMP_TD_MERGE_DENSE=None),              # two halves + the merge (per-half basis
+          "merge-dense": dict(TRAMP_TD_MERGE_ABOVE=64, TRAMP_TD_MERGE_DENSE=1)}           # unless a rotation crosses them) / dense
+
+
+@pytest.mark.parametrize("merge", list(MERGES))
 @pytest.mark.parametrize("kind,n", [("gram", 64), ("gram", 257), ("gram", 1031), ("deficient", 700), ("indefinite", 513),
                                     ("identity", 300), ("tridiagonal", 400), ("clustered", 512), ("graded", 600)])
-def test_eigh_tridiagonal_path(T, ctx, kind, n, merge_above):
+def test_eigh_tridiagonal_path(T, ctx, kind, n, merge):
     G = _tridiag_matrix(kind, n)
-    with env_set(TRAMP_EIG_METHOD="tridiag", TRAMP_TD_MERGE_ABOVE=merge_above):
+    with env_set(TRAMP_EIG_METHOD="tridiag", **MERGES[merge]):
         w, V = _eigh(T, ctx, G)
     wr = np.linalg.eigvalsh(G)
     nG = np.abs(wr).max()
@@ -236,10 +248,10 @@ def test_eigh_tridiagonal_path(T, ctx, kind, n, merge_above):
     assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
 
 
-@pytest.mark.parametrize("merge_above", [None, 64])
-def test_device_factorization_golden_tridiagonal_path(T, ctx, golden_linear, merge_above):
+@pytest.mark.parametrize("merge", list(MERGES))
+def test_device_factorization_golden_tridiagonal_path(T, ctx, golden_linear, merge):
     "the golden factorisations of the reference's LinearChannel.__init__ through the tridiagonal path"
-    with env_set(TRAMP_EIG_METHOD="tridiag", TRAMP_TD_MERGE_ABOVE=merge_above):
+    with env_set(TRAMP_EIG_METHOD="tridiag", **MERGES[merge]):
         test_device_factorization_golden(T, ctx, golden_linear, None)
 
 
@@ -248,8 +260,8 @@ def test_eigh_tridiagonal_path_large(T, ctx):
     n = 3000
     G = _tridiag_matrix("gram", n)
     wr = np.linalg.eigvalsh(G)
-    for merge_above in (None, 1024):
-        with env_set(TRAMP_EIG_METHOD="tridiag", TRAMP_TD_MERGE_ABOVE=merge_above):
+    for merge_above, dense, panel in ((None, None, None), (1024, None, 256), (1024, 1, 1000)):
+        with env_set(TRAMP_EIG_METHOD="tridiag", TRAMP_TD_MERGE_ABOVE=merge_above, TRAMP_TD_MERGE_DENSE=dense, TRAMP_TD_BT_PANEL=panel):
             w, V = _eigh(T, ctx, G)
         np.testing.assert_allclose(w, wr, rtol=0, atol=1e-13 * wr.max())
         assert np.abs(G @ V - V * w).max() < 2e-13 * wr.max()

@@ -594,13 +594,25 @@ int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth);
 
 #include "tridiag_eig.h"
 
-// TRAMP_EIG_METHOD: "split" = rocSOLVER syevd / the spectral divide and conquer above its cap (rounds 2-5),
-// "tridiag" = the own tridiagonalisation + stedc + back-transformation of tridiag_eig.h (round 6)
+// TRAMP_EIG_METHOD: "tridiag" (default from round 6) = the own tridiagonalisation + stedc + back-transformation of
+// tridiag_eig.h; "split" = rocSOLVER syevd / the spectral divide and conquer above its cap (rounds 2-5)
 int eig_method_from_env() {
     const char* s = getenv("TRAMP_EIG_METHOD");
-    if (s && !strcmp(s, "tridiag")) return 1;
     if (s && !strcmp(s, "split")) return 0;
-    return 0;
+    return 1;
+}
+
+// work space of the tridiagonal path beyond A itself: the eigenvector matrix of T, and for the merge the two halves, V,
+// the product and the ordered result (dense basis: one more n x n)
+bool tridiag_fits(size_t n) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    const double nn = 8.0 * (double)n * (double)n;
+    const double need = (n <= kStedcCap ? 1.3 : 3.6) * nn + (double)(64u << 20);
+    return (double)free_b > need;
 }
 
 // one spectral split of the symmetric A (n x n, full storage, ld = n); eigenvectors overwrite A,
@@ -757,7 +769,7 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
 // ascending eigenvalues in w_d
 int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth) {
     const int method = eig_method_from_env();             // read per call, as TRAMP_EIG_CAP is
-    if (method == 1 && n >= 64 && n <= 2 * kStedcCap) {
+    if (method == 1 && n >= 64 && n <= 2 * kStedcCap && tridiag_fits(n)) {
         const unsigned nts = (unsigned)((n + 31) / 32);
         hipLaunchKernelGGL(symmetrize_tiles, dim3(nts, nts), dim3(kBlock), 0, fz.ctx->stream, A, n, 0);
         return eigh_tridiag(fz, A, n, w_d);

@@ -18,7 +18,7 @@
 
 constexpr int kTdTile = 256;          // symv tile edge
 constexpr int kTdNb = 64;             // reflectors per reduction panel
-constexpr int kTdBt = 256;            // reflectors per back-transformation panel
+constexpr size_t kTdBtDefault = 2048;  // reflectors per back-transformation panel (TRAMP_TD_BT_PANEL)
 
 // ---- y = (L + strict(L)^T) v on the lower triangle of the m x m block At (column-major, lda): tile (I, Js), Js <= I --------
 // row_part[Js m + r]: sum over the tile's columns of L[r, c] v[c] (r >= c);  col_part[I m + c]: sum over its rows of L[r, c] v[r] (r > c)
@@ -313,7 +313,7 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
 }
 
 // ---- back-transformation: C <- H(0) H(1) ... H(n-2) C, the reflectors below the sub-diagonal of A (as td_sytrd_lower left
-// them, the sub-diagonal itself holding e), panels of kTdBt reflectors, last panel first.
+// them, the sub-diagonal itself holding e), panels of kTdBtDefault reflectors, last panel first.
 // Vp (mp x pb, ld mp) = unit lower trapezoidal copy of the panel
 __global__ void td_copy_panel(const double* __restrict__ A, size_t n, size_t i, int pb, size_t mp, double* __restrict__ Vp) {
     const size_t total = mp * (size_t)pb;
@@ -323,50 +323,52 @@ __global__ void td_copy_panel(const double* __restrict__ A, size_t n, size_t i, 
     }
 }
 
+// Tinv = strict upper triangle of S + diag(1 / tau) (zero below): the inverse of the compact-WY factor T of the panel, since
+// T^-1 + T^-T = V^T V for Q = I - V T V^T orthogonal (Puglisi; Joffrain et al., "Accumulating Householder transformations,
+// revisited").  tau_j = 0 (H_j = I) takes 1e300 on the diagonal: T_jj = 1e-300 and that reflector's row and column of T vanish.
+__global__ void td_tinv_from_gram(double* __restrict__ S, int pb, const double* __restrict__ tau) {
+    const int total = pb * pb;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+        const int r = idx % pb, c = idx / pb;
+        if (r > c) S[idx] = 0.0;
+        else if (r == c) {
+            const double t = tau[r];
+            S[idx] = (t != 0.0) ? 1.0 / t : 1e300;
+        }
+    }
+}
+
+// C (n x ncols, ld n) <- Q C, panels of kTdBt reflectors, last panel first:  C[i+1:, :] -= Vp T (Vp^T C[i+1:, :]) with the
+// product by T as one triangular solve with T^-1 - no host work, no synchronisation between the panels
 int td_backtransform(Fz& fz, const double* A, size_t n, const double* tau_d, double* C, size_t ncols) {
     hipStream_t st = fz.ctx->stream;
     if (n < 2) return TRAMP_OK;
-    double* Vp = fz.alloc(n * kTdBt);
-    double* S = fz.alloc((size_t)kTdBt * kTdBt);
-    double* Td = fz.alloc((size_t)kTdBt * kTdBt);
-    double* W1 = fz.alloc((size_t)kTdBt * ncols);
-    double* W2 = fz.alloc((size_t)kTdBt * ncols);
-    if (!Vp || !S || !Td || !W1 || !W2) return fz.rc;
-    std::vector<double> hS((size_t)kTdBt * kTdBt), hT((size_t)kTdBt * kTdBt), htau(n);
-    FZ_HIP(fz, hipMemcpyAsync(htau.data(), tau_d, (n - 1) * sizeof(double), hipMemcpyDeviceToHost, st));
-    FZ_HIP(fz, hipStreamSynchronize(st));
+    const char* env = getenv("TRAMP_TD_BT_PANEL");
+    const long ev = env ? atol(env) : 0;
+    const size_t kTdBt = (ev >= 32 && ev <= 8192) ? (size_t)ev : kTdBtDefault;
+    const size_t bt = n - 1 < kTdBt ? n - 1 : kTdBt;
+    double* Vp = fz.alloc(n * bt);
+    double* S = fz.alloc(bt * bt);
+    double* W1 = fz.alloc(bt * ncols);
+    if (!Vp || !S || !W1) return fz.rc;
+    const double one = 1.0;
     const size_t npan = (n - 1 + kTdBt - 1) / kTdBt;
     for (size_t p = npan; p-- > 0;) {
         const size_t i = p * kTdBt;
-        const int pb = (int)((n - 1 - i) < (size_t)kTdBt ? (n - 1 - i) : (size_t)kTdBt);
+        const int pb = (int)((n - 1 - i) < kTdBt ? (n - 1 - i) : kTdBt);
         const size_t mp = n - i - 1;
         hipLaunchKernelGGL(td_copy_panel, dim3(kRedBlocks), dim3(kBlock), 0, st, A, n, i, pb, mp, Vp);
-        // T of the compact WY form (dlarft, forward columnwise) from S = Vp^T Vp, on the host (pb <= 256)
         FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, pb, pb, mp, 1.0, Vp, mp, Vp, mp, 0.0, S, pb));
-        FZ_HIP(fz, hipMemcpyAsync(hS.data(), S, (size_t)pb * pb * sizeof(double), hipMemcpyDeviceToHost, st));
-        FZ_HIP(fz, hipStreamSynchronize(st));
-        for (int j = 0; j < pb; ++j) {
-            const double tj = htau[i + j];
-            for (int r = 0; r < pb; ++r) hT[r + (size_t)j * pb] = 0.0;
-            hT[j + (size_t)j * pb] = tj;
-            for (int r = 0; r < j; ++r) {
-                double acc = 0.0;
-                for (int c = r; c < j; ++c) acc += hT[r + (size_t)c * pb] * hS[c + (size_t)j * pb];
-                hT[r + (size_t)j * pb] = -tj * acc;
-            }
-        }
-        FZ_HIP(fz, hipMemcpyAsync(Td, hT.data(), (size_t)pb * pb * sizeof(double), hipMemcpyHostToDevice, st));
-        // C[i+1:, :] -= Vp (T (Vp^T C[i+1:, :]))
+        hipLaunchKernelGGL(td_tinv_from_gram, dim3(64), dim3(kBlock), 0, st, S, pb, tau_d + i);
         FZ_OK(bgemm(fz, rocblas_operation_transpose, rocblas_operation_none, pb, ncols, mp, 1.0, Vp, mp, C + i + 1, n, 0.0, W1, pb));
-        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, pb, ncols, pb, 1.0, Td, pb, W1, pb, 0.0, W2, pb));
-        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, mp, ncols, pb, -1.0, Vp, mp, W2, pb, 1.0, C + i + 1, n));
-        FZ_HIP(fz, hipStreamSynchronize(st));                          // hT / hS are reused by the next panel
+        FZ_RB(fz, rocblas_dtrsm(fz.h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                (rocblas_int)pb, (rocblas_int)ncols, &one, S, (rocblas_int)pb, W1, (rocblas_int)pb));
+        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, mp, ncols, pb, -1.0, Vp, mp, W1, pb, 1.0, C + i + 1, n));
     }
+    FZ_HIP(fz, hipStreamSynchronize(st));
     fz.release(Vp);
     fz.release(S);
-    fz.release(Td);
     fz.release(W1);
-    fz.release(W2);
     fz.tick("tridiag: back-transformation", n);
     return TRAMP_OK;
 }
@@ -494,10 +496,10 @@ __global__ __launch_bounds__(256) void td_loewner(const double* __restrict__ d, 
     if (lane == 0) zhat[j] = copysign(sqrt(fabs(prod)), z[j]);
 }
 
-// one workgroup per root i: V[:, i] = normalised zhat_j / ((d_j - d_org(i)) - mu_i)
+// one workgroup per root i: V[row[j], i] = normalised zhat_j / ((d_j - d_org(i)) - mu_i); row = where pole j's basis column sits
 __global__ __launch_bounds__(256) void td_secular_vectors(const double* __restrict__ d, const double* __restrict__ zhat, unsigned k,
                                                           const unsigned* __restrict__ org, const double* __restrict__ mu,
-                                                          double* __restrict__ V) {
+                                                          const unsigned* __restrict__ row, double* __restrict__ V) {
     __shared__ double sm[256 / kWave];
     const unsigned i = blockIdx.x;
     const double dorg = d[org[i]], m_ = mu[i];
@@ -505,12 +507,27 @@ __global__ __launch_bounds__(256) void td_secular_vectors(const double* __restri
     double ss = 0.0;
     for (unsigned j = threadIdx.x; j < k; j += 256) {
         const double x = zhat[j] / ((d[j] - dorg) - m_);
-        col[j] = x;
+        col[row[j]] = x;
         ss = fma(x, x, ss);
     }
     ss = block_sum(ss, sm);
     const double inv = 1.0 / sqrt(ss);
     for (unsigned j = threadIdx.x; j < k; j += 256) col[j] *= inv;
+}
+
+// OUT[:, pos[t]] = column src[t] of blockdiag(C1, C2)
+__global__ void td_scatter_half_cols(const double* __restrict__ C1, size_t n1, const double* __restrict__ C2, size_t n2,
+                                     const unsigned* __restrict__ src, const unsigned* __restrict__ pos, double* __restrict__ OUT) {
+    const size_t n = n1 + n2;
+    const size_t t = blockIdx.y;
+    const unsigned s = src[t];
+    double* out = OUT + (size_t)pos[t] * n;
+    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) {
+        double v = 0.0;
+        if (s < n1) v = (r < n1) ? C1[r + (size_t)s * n1] : 0.0;
+        else v = (r >= n1) ? C2[(r - n1) + (size_t)(s - n1) * n2] : 0.0;
+        out[r] = v;
+    }
 }
 
 // dst[:, pos[t]] = src[:, idx[t]]
@@ -528,8 +545,12 @@ __global__ void td_roots_to_lambda(const double* __restrict__ d, const unsigned*
     if (i < k) lam[i] = d[org[i]] + mu[i];
 }
 
-// eigen-decomposition of the symmetric tridiagonal (d, e) of order n > kStedcCap (host copies hd, he): eigenvectors -> QT (n x n,
-// allocated here, handed to the caller), ascending eigenvalues -> w_d
+// eigen-decomposition of the symmetric tridiagonal (d, e) of order n (host copies hd, he) from two stedc halves: eigenvectors
+// -> QT (n x n, allocated here, handed to the caller), ascending eigenvalues -> w_d.
+// The basis blockdiag(Q1, Q2) is never formed while no Givens rotation of the deflation pairs a column of Q1 with one of Q2
+// (the usual case): the columns that take part are gathered per half, V's rows are laid out [poles of half 1 | poles of half 2]
+// and the product is two gemms of half the height - half the flops of the dense one (dlaed3 does the same with its column
+// types).  A rotation across the halves falls back to the dense basis.
 int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double>& he, double* w_d, double** QT_out) {
     hipStream_t st = fz.ctx->stream;
     const size_t n1 = n / 2, n2 = n - n1;
@@ -570,20 +591,13 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
         dmax = fmax(dmax, fabs(d[t]));
         zmax = fmax(zmax, fabs(z[t]));
     }
-    // Q0 = blockdiag(C1, C2) with its columns in the sorted order
-    double* Q0 = fz.alloc(n * n);
-    unsigned* idx_d = (unsigned*)fz.alloc(n);                 // (n doubles hold 2n unsigned)
-    if (!Q0 || !idx_d) return fz.rc;
-    FZ_HIP(fz, hipMemcpyAsync(idx_d, order.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(td_build_q0, dim3(64, (unsigned)n), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d, Q0);
-    FZ_HIP(fz, hipStreamSynchronize(st));
-    fz.release(C1);
-    fz.release(C2);
-    // ---- deflation (dlaed2)
+    // ---- deflation (dlaed2) on the sorted poles; the rotations are recorded and applied to the basis afterwards
+    struct Rot { unsigned p, j; double c, s; };
+    std::vector<Rot> rots;
     const double tol = 8.0 * kEps * fmax(dmax, zmax);
     std::vector<unsigned> live;
     live.reserve(n);
-    size_t n_rot = 0;
+    size_t n_cross = 0;
     for (size_t j = 0; j < n; ++j) {
         if (!(rho * fabs(z[j]) > tol)) continue;               // type 1: (d_j, q_j) is an eigenpair as it stands
         if (!live.empty()) {
@@ -593,14 +607,14 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
             if (fabs((d[j] - d[p]) * (c0 / t0) * (s0 / t0)) <= tol) {
                 // type 2: rotate (p, j) so that z_p = 0; p leaves with its rotated eigenvalue
                 const double c = c0 / t0, s = -s0 / t0;
-                hipLaunchKernelGGL(td_rotate_cols, dim3(64), dim3(kBlock), 0, st, Q0, n, p, j, c, s);
+                rots.push_back({(unsigned)p, (unsigned)j, c, s});
+                if ((order[p] < n1) != (order[j] < n1)) ++n_cross;
                 const double dp = d[p], dj = d[j];
                 d[p] = dp * c * c + dj * s * s;
                 d[j] = dp * s * s + dj * c * c;
                 z[j] = t0;
                 z[p] = 0.0;
                 live.back() = (unsigned)j;
-                ++n_rot;
                 continue;
             }
         }
@@ -611,7 +625,6 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
     std::stable_sort(live.begin(), live.end(), [&](unsigned a, unsigned b) { return d[a] < d[b]; });
     std::vector<char> is_live(n, 0);
     for (unsigned t : live) is_live[t] = 1;
-    std::vector<double> lam(n);
     std::vector<double> dk(k), zk(k), z2k(k);
     double z2sum = 0.0;
     for (size_t i = 0; i < k; ++i) {
@@ -620,9 +633,43 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
         z2k[i] = zk[i] * zk[i];
         z2sum += z2k[i];
     }
+    const bool dense = n_cross != 0 || getenv("TRAMP_TD_MERGE_DENSE") != nullptr;
     static const bool verbose = getenv("TRAMP_EIG_VERBOSE") != nullptr;
-    if (verbose) fprintf(stderr, "[tramp tridiag] merge n=%zu: %zu of the poles take part (%zu rotations), rho = %.3e\n", n, k, n_rot, rho);
-    double* OUT = nullptr;
+    if (verbose)
+        fprintf(stderr, "[tramp tridiag] merge n=%zu: %zu of the poles take part (%zu rotations, %zu across the halves: %s basis), rho = %.3e\n",
+                n, k, rots.size(), n_cross, dense ? "dense" : "per-half", rho);
+    unsigned* idx_d = (unsigned*)fz.alloc(n);                 // (n doubles hold 2n unsigned)
+    unsigned* pos_d = (unsigned*)fz.alloc(n);
+    if (!idx_d || !pos_d) return fz.rc;
+    // ---- the basis: Q0 (dense) or the halves in place
+    double* Q0 = nullptr;
+    if (dense) {
+        Q0 = fz.alloc(n * n);                                 // blockdiag(C1, C2) with its columns in the sorted order
+        if (!Q0) return fz.rc;
+        FZ_HIP(fz, hipMemcpyAsync(idx_d, order.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(td_build_q0, dim3(64, (unsigned)n), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d, Q0);
+        FZ_HIP(fz, hipStreamSynchronize(st));
+        fz.release(C1);
+        fz.release(C2);
+        C1 = C2 = nullptr;
+        for (const Rot& r : rots) hipLaunchKernelGGL(td_rotate_cols, dim3(64), dim3(kBlock), 0, st, Q0, n, (size_t)r.p, (size_t)r.j, r.c, r.s);
+    } else {
+        for (const Rot& r : rots) {
+            const unsigned sp = order[r.p], sj = order[r.j];
+            if (sp < n1) hipLaunchKernelGGL(td_rotate_cols, dim3(64), dim3(kBlock), 0, st, C1, n1, (size_t)sp, (size_t)sj, r.c, r.s);
+            else hipLaunchKernelGGL(td_rotate_cols, dim3(64), dim3(kBlock), 0, st, C2, n2, (size_t)(sp - n1), (size_t)(sj - n1), r.c, r.s);
+        }
+    }
+    // rows of V: dense - pole i at row i; per-half - the poles of half 1 first
+    std::vector<unsigned> vrow(k), g1, g2;
+    if (dense) {
+        for (size_t i = 0; i < k; ++i) vrow[i] = (unsigned)i;
+    } else {
+        for (size_t i = 0; i < k; ++i) (order[live[i]] < n1 ? g1 : g2).push_back((unsigned)i);
+        for (size_t r = 0; r < g1.size(); ++r) vrow[g1[r]] = (unsigned)r;
+        for (size_t r = 0; r < g2.size(); ++r) vrow[g2[r]] = (unsigned)(g1.size() + r);
+    }
+    const size_t k1 = g1.size(), k2 = g2.size();
     std::vector<double> lam_live(k);
     double* R = nullptr;
     if (k) {
@@ -633,27 +680,52 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
         double* zh_d = fz.alloc(k);
         double* lam_d = fz.alloc(k);
         unsigned* org_d = (unsigned*)fz.alloc(k);
-        double* QL = fz.alloc(n * k);
+        unsigned* row_d = (unsigned*)fz.alloc(k);
         double* V = fz.alloc(k * k);
-        if (!dk_d || !zk_d || !z2_d || !mu_d || !zh_d || !lam_d || !org_d || !QL || !V) return fz.rc;
+        if (!dk_d || !zk_d || !z2_d || !mu_d || !zh_d || !lam_d || !org_d || !row_d || !V) return fz.rc;
         FZ_HIP(fz, hipMemcpyAsync(dk_d, dk.data(), k * sizeof(double), hipMemcpyHostToDevice, st));
         FZ_HIP(fz, hipMemcpyAsync(zk_d, zk.data(), k * sizeof(double), hipMemcpyHostToDevice, st));
         FZ_HIP(fz, hipMemcpyAsync(z2_d, z2k.data(), k * sizeof(double), hipMemcpyHostToDevice, st));
-        FZ_HIP(fz, hipMemcpyAsync(idx_d, live.data(), k * sizeof(unsigned), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(td_gather_cols, dim3(64, (unsigned)k), dim3(kBlock), 0, st, Q0, n, idx_d, QL);
+        FZ_HIP(fz, hipMemcpyAsync(row_d, vrow.data(), k * sizeof(unsigned), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(td_secular, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, st, dk_d, z2_d, (unsigned)k, rho, z2sum, org_d, mu_d);
         hipLaunchKernelGGL(td_loewner, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, st, dk_d, zk_d, (unsigned)k, rho, org_d, mu_d, zh_d);
-        hipLaunchKernelGGL(td_secular_vectors, dim3((unsigned)k), dim3(256), 0, st, dk_d, zh_d, (unsigned)k, org_d, mu_d, V);
+        hipLaunchKernelGGL(td_secular_vectors, dim3((unsigned)k), dim3(256), 0, st, dk_d, zh_d, (unsigned)k, org_d, mu_d, row_d, V);
         hipLaunchKernelGGL(td_roots_to_lambda, dim3(nblk(k)), dim3(kBlock), 0, st, dk_d, org_d, mu_d, (unsigned)k, lam_d);
         FZ_HIP(fz, hipMemcpyAsync(lam_live.data(), lam_d, k * sizeof(double), hipMemcpyDeviceToHost, st));
         FZ_HIP(fz, hipStreamSynchronize(st));
         fz.tick("tridiag: secular equation + vectors", k);
         R = fz.alloc(n * k);
         if (!R) return fz.rc;
-        FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, k, k, 1.0, QL, n, V, k, 0.0, R, n));
-        FZ_HIP(fz, hipStreamSynchronize(st));
+        std::vector<unsigned> cols(k);
+        if (dense) {
+            double* QL = fz.alloc(n * k);
+            if (!QL) return fz.rc;
+            FZ_HIP(fz, hipMemcpyAsync(idx_d, live.data(), k * sizeof(unsigned), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(td_gather_cols, dim3(64, (unsigned)k), dim3(kBlock), 0, st, Q0, n, idx_d, QL);
+            FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, k, k, 1.0, QL, n, V, k, 0.0, R, n));
+            FZ_HIP(fz, hipStreamSynchronize(st));
+            fz.release(QL);
+        } else {
+            // R[0:n1, :] = C1[:, poles of half 1] V[0:k1, :],  R[n1:, :] = C2[:, poles of half 2] V[k1:, :]
+            double* CL = fz.alloc((k1 * n1 > k2 * n2 ? k1 * n1 : k2 * n2) + 1);
+            if (!CL) return fz.rc;
+            for (int half = 0; half < 2; ++half) {
+                const std::vector<unsigned>& g = half ? g2 : g1;
+                const size_t kh = g.size(), nh = half ? n2 : n1;
+                double* Rh = R + (half ? n1 : 0);
+                if (!kh) {
+                    FZ_HIP(fz, hipMemset2DAsync(Rh, n * sizeof(double), 0, nh * sizeof(double), k, st));
+                    continue;
+                }
+                for (size_t r = 0; r < kh; ++r) cols[r] = order[live[g[r]]] - (half ? (unsigned)n1 : 0u);
+                FZ_HIP(fz, hipMemcpyAsync(idx_d, cols.data(), kh * sizeof(unsigned), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(td_gather_cols, dim3(64, (unsigned)kh), dim3(kBlock), 0, st, half ? C2 : C1, nh, idx_d, CL);
+                FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, nh, k, kh, 1.0, CL, nh, V + (half ? k1 : 0), k, 0.0, Rh, n));
+                FZ_HIP(fz, hipStreamSynchronize(st));          // idx_d and CL are reused by the other half
+            }
+            fz.release(CL);
+        }
         fz.tick("tridiag: merge gemm", k);
-        fz.release(QL);
         fz.release(V);
         fz.release(dk_d);
         fz.release(zk_d);
@@ -662,16 +734,17 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
         fz.release(zh_d);
         fz.release(lam_d);
         fz.release(org_d);
+        fz.release(row_d);
     }
-    // ---- final order: eigenvalue t comes from R column (live) or Q0 column (deflated)
+    // ---- final order: eigenvalue t comes from R column (took part) or a basis column (deflated)
     struct Ev { double lam; unsigned col; char from_r; };
     std::vector<Ev> ev;
     ev.reserve(n);
     for (size_t i = 0; i < k; ++i) ev.push_back({lam_live[i], (unsigned)i, 1});
     for (size_t t = 0; t < n; ++t)
-        if (!is_live[t]) ev.push_back({d[t], (unsigned)t, 0});
+        if (!is_live[t]) ev.push_back({d[t], dense ? (unsigned)t : order[t], 0});
     std::stable_sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.lam < b.lam; });
-    OUT = fz.alloc(n * n);
+    double* OUT = fz.alloc(n * n);
     if (!OUT) return fz.rc;
     std::vector<unsigned> from_r_idx, from_r_pos, from_q_idx, from_q_pos;
     std::vector<double> w(n);
@@ -680,29 +753,37 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
         if (ev[t].from_r) { from_r_idx.push_back(ev[t].col); from_r_pos.push_back((unsigned)t); }
         else { from_q_idx.push_back(ev[t].col); from_q_pos.push_back((unsigned)t); }
     }
-    // scatter: OUT[:, pos] = src[:, idx]  - as a gather with an index table over the destination columns
-    unsigned* pos_d = (unsigned*)fz.alloc(n);
-    if (!pos_d) return fz.rc;
-    auto scatter = [&](const double* src, std::vector<unsigned>& idx, std::vector<unsigned>& pos) -> int {
-        const size_t cnt = idx.size();
-        if (!cnt) return TRAMP_OK;
-        FZ_HIP(fz, hipMemcpyAsync(idx_d, idx.data(), cnt * sizeof(unsigned), hipMemcpyHostToDevice, st));
-        FZ_HIP(fz, hipMemcpyAsync(pos_d, pos.data(), cnt * sizeof(unsigned), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(td_scatter_cols, dim3(64, (unsigned)cnt), dim3(kBlock), 0, st, src, n, idx_d, pos_d, OUT);
-        FZ_HIP(fz, hipStreamSynchronize(st));
+    auto upload = [&](std::vector<unsigned>& idx, std::vector<unsigned>& pos) -> int {
+        FZ_HIP(fz, hipMemcpyAsync(idx_d, idx.data(), idx.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        FZ_HIP(fz, hipMemcpyAsync(pos_d, pos.data(), pos.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
         return TRAMP_OK;
     };
-    if (R) FZ_OK(scatter(R, from_r_idx, from_r_pos));
-    FZ_OK(scatter(Q0, from_q_idx, from_q_pos));
+    if (!from_r_idx.empty()) {
+        FZ_OK(upload(from_r_idx, from_r_pos));
+        hipLaunchKernelGGL(td_scatter_cols, dim3(64, (unsigned)from_r_idx.size()), dim3(kBlock), 0, st, R, n, idx_d, pos_d, OUT);
+        FZ_HIP(fz, hipStreamSynchronize(st));
+    }
+    if (!from_q_idx.empty()) {
+        FZ_OK(upload(from_q_idx, from_q_pos));
+        if (dense)
+            hipLaunchKernelGGL(td_scatter_cols, dim3(64, (unsigned)from_q_idx.size()), dim3(kBlock), 0, st, Q0, n, idx_d, pos_d, OUT);
+        else
+            hipLaunchKernelGGL(td_scatter_half_cols, dim3(64, (unsigned)from_q_idx.size()), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d,
+                               pos_d, OUT);
+        FZ_HIP(fz, hipStreamSynchronize(st));
+    }
     FZ_HIP(fz, hipMemcpyAsync(w_d, w.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     FZ_HIP(fz, hipStreamSynchronize(st));
     if (R) fz.release(R);
-    fz.release(Q0);
+    if (Q0) fz.release(Q0);
+    if (C1) fz.release(C1);
+    if (C2) fz.release(C2);
     fz.release(idx_d);
     fz.release(pos_d);
     fz.release(D);
     fz.release(E);
     fz.release(zd);
+    fz.tick("tridiag: merge ordering", n);
     *QT_out = OUT;
     return TRAMP_OK;
 }
