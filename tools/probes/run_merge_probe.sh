@@ -1,8 +1,8 @@
-export TRAMP_EIG_METHOD=tridiag TRAMP_EIG_VERBOSE=1
-for kind in gram deficient identity; do
-  TRAMP_TD_MERGE_ABOVE=64 timeout 300 python tools/probes/probe_eigh.py --kind $kind 100 777 4097 2>&1 | grep -v "^\[tramp" 
+timeout 600 python -m pytest tests/test_gpu_factorize.py -x -q -m gpu 2>&1 | tail -n 2
+TRAMP_TD_PROFILE=1 TRAMP_EIG_VERBOSE=1 timeout 300 python tools/probes/probe_eigh.py 32768 2>&1 | grep "synchronised"
+for rep in 1 2; do
+for lib in build_ab/libtramp_prev.so tramp_amd/libtramp_hip.so; do
+echo "== $lib"
+TRAMP_HIP_LIB=$PWD/$lib timeout 300 python tools/probes/probe_eigh.py 24576 32768 2>&1 | grep "gram n"
 done
-for pb in 256 512 1024 2048; do
-echo "== back-transformation panel $pb"
-TRAMP_TD_BT_PANEL=$pb timeout 300 python tools/probes/probe_eigh.py 8192 24576 2>&1 | grep "back-tr\|gram n"
 done

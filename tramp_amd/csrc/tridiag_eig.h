@@ -7,12 +7,14 @@
 //   * dsytrd / dlatrd (LAPACK, lower triangle) with an own symv that reads only the LOWER triangle of the trailing matrix
 //     (half the bytes): 256 x 256 tiles, a lane owns a row, a wave a 64-column strip; row sums through LDS, column sums by a
 //     transposing butterfly over the wave; per-tile partial vectors folded in fixed order (run-to-run reproducible);
-//   * the panel's level-2 pieces as six fused launches per column (no host round trip: beta, tau, alpha stay on the device);
+//   * the panel's level-2 pieces in four launches per column - column step (previous w's last term + column update + dlarfg
+//     through a last-workgroup ticket), the panel's dots, symv, w - with no host round trip: beta, tau, alpha stay on the device;
 //   * the trailing rank-2nb update by rocBLAS (syr2k on diagonal tiles, gemm below), every call inside 2^31 elements;
 //   * the tridiagonal problem by rocSOLVER's stedc (n <= 46 340: its 32-bit indexing), above that ONE Cuppen merge of two
 //     stedc halves written here (deflation on the host, secular equation by bisection about the nearer pole, Loewner
 //     vector, eigenvectors, one gemm);
-//   * the back-transformation in panels of 256 reflectors (compact WY, three gemms per panel).
+//   * the back-transformation in panels of 2048 reflectors (compact WY with T^-1 = striu(V^T V) + diag(1 / tau) applied by a
+//     triangular solve: three gemms and one trsm per panel, no host work).
 // Prototype with the same operations in the same order: tools/proto_tridiag_eig.py.
 #pragma once
 
@@ -98,60 +100,96 @@ __global__ __launch_bounds__(256, 2) void td_symv_lower(const double* __restrict
     if (r0 + tid < m) row_part[(size_t)Js * m + r0 + tid] = (rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]);
 }
 
-// ---- column j of the trailing block, updated by the panel's earlier reflectors (dlatrd):
-//      At[r, j] -= sum_{c < jj} V[r, c] W[j, c] + W[r, c] V[j, c],  r = j .. m - 1;  V = At[:, :jj] (lda), W (ldw)
-__global__ __launch_bounds__(256) void td_col_update(double* __restrict__ At, size_t lda, size_t m, int j,
-                                                     const double* __restrict__ W, size_t ldw) {
-    __shared__ double wrow[kTdNb], vrow[kTdNb];
-    if (threadIdx.x < j) {
-        wrow[threadIdx.x] = W[j + (size_t)threadIdx.x * ldw];
-        vrow[threadIdx.x] = At[j + (size_t)threadIdx.x * lda];
-    }
-    __syncthreads();
-    const size_t r = (size_t)j + (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= m) return;
-    double acc = 0.0;
-    for (int c = 0; c < j; ++c) acc += At[r + (size_t)c * lda] * wrow[c] + W[r + (size_t)c * ldw] * vrow[c];
-    At[r + (size_t)j * lda] -= acc;
-}
-
-// ---- dlarfg on x = At[j+1:, j] (one workgroup of 1024): beta -> e, tau, d = At[j, j]; v = x / (alpha - beta) with v[0] = 1
-__global__ __launch_bounds__(1024) void td_larfg(double* __restrict__ At, size_t lda, size_t m, int j, double* __restrict__ d,
-                                                 double* __restrict__ e, double* __restrict__ tau) {
-    __shared__ double sm[1024 / kWave];
-    __shared__ double s_scale;
-    double* col = At + (size_t)j * lda;
-    const size_t len = m - (size_t)j - 1;                  // alpha and x
-    double ss = 0.0;
-    for (size_t i = 1 + threadIdx.x; i < len; i += 1024) {
-        const double x = col[j + 1 + i];
-        ss = fma(x, x, ss);
-    }
-    ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+// ---- one launch per column j of the panel (dlatrd's level-2 pieces around the symv), rows r = j .. m-1 of the trailing block:
+//   1. the previous column's w gets its last term: W[r, j-1] = wpre[r - j] + alpha v_{j-1}[r], alpha = -(tau_{j-1} / 2)(w . v)
+//      from the per-block dots td_w_form left (every workgroup folds them itself);
+//   2. column j is updated by the panel's reflectors so far: At[r, j] -= sum_{c < j} V[r, c] W[j, c] + W[r, c] V[j, c]
+//      (V = At[:, :j]; W[j, j-1] is formed locally from wpre, so no workgroup waits for another);
+//   3. dlarfg on x = At[j+1:, j]: every workgroup leaves its part of |x[1:]|^2, the LAST one to arrive (ticket counter, device-
+//      scope fences) folds them in fixed order, writes d, e = beta, tau, sets the unit entry and scales x[1:] by 1 / (alpha - beta).
+__global__ __launch_bounds__(256) void td_col_step(double* __restrict__ At, size_t lda, size_t m, int j, double* __restrict__ W,
+                                                   size_t ldw, const double* __restrict__ wpre, const double* __restrict__ dots,
+                                                   unsigned ndots, double* __restrict__ d, double* __restrict__ e,
+                                                   double* __restrict__ tau, double* __restrict__ nrm_part,
+                                                   unsigned* __restrict__ counter) {
+    __shared__ double wrow[kTdNb], vrow[kTdNb], sm[256 / kWave];
+    __shared__ double s_alpha;
+    __shared__ bool s_last;
+    const int tid = threadIdx.x;
+    if (j) {
         double t = 0.0;
-        for (int i = 0; i < 1024 / kWave; ++i) t += sm[i];
-        const double alpha = col[j + 1];
-        double beta = alpha, tv = 0.0, sc = 0.0;
-        if (t > 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + t), alpha);
-            tv = (beta - alpha) / beta;
-            sc = 1.0 / (alpha - beta);
+        for (unsigned i = tid; i < ndots; i += 256) t += dots[i];
+        t = block_sum(t, sm);
+        if (tid == 0) s_alpha = -0.5 * tau[-1] * t;
+        __syncthreads();
+        if (tid < j) {
+            vrow[tid] = At[j + (size_t)tid * lda];
+            wrow[tid] = (tid == j - 1) ? wpre[0] + s_alpha * vrow[tid] : W[j + (size_t)tid * ldw];
         }
-        d[0] = col[j];
+        __syncthreads();
+    }
+    const size_t r = (size_t)j + (size_t)blockIdx.x * 256 + tid;
+    double ss = 0.0;
+    if (r < m) {
+        double acc = 0.0;
+        if (j) {
+            const double vprev = At[r + (size_t)(j - 1) * lda];
+            const double wfin = wpre[r - (size_t)j] + s_alpha * vprev;
+            W[r + (size_t)(j - 1) * ldw] = wfin;
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};
+            int c = 0;
+            for (; c + 4 <= j - 1; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] += At[r + (size_t)(c + u) * lda] * wrow[c + u] + W[r + (size_t)(c + u) * ldw] * vrow[c + u];
+            }
+            for (; c < j - 1; ++c) a4[0] += At[r + (size_t)c * lda] * wrow[c] + W[r + (size_t)c * ldw] * vrow[c];
+            acc = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + (vprev * wrow[j - 1] + wfin * vrow[j - 1]);
+        }
+        const double x = At[r + (size_t)j * lda] - acc;
+        At[r + (size_t)j * lda] = x;
+        if (r == (size_t)j) d[0] = x;
+        if (r >= (size_t)j + 2) ss = x * x;
+    }
+    ss = block_sum(ss, sm);
+    if (tid == 0) {
+        nrm_part[blockIdx.x] = ss;
+        __threadfence();
+        s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double t = 0.0;
+    for (unsigned i = tid; i < gridDim.x; i += 256) t += nrm_part[i];
+    t = block_sum(t, sm);
+    double* col = At + (size_t)j * lda;
+    const double alpha = col[j + 1];
+    double beta = alpha, tv = 0.0, sc = 0.0;
+    if (t > 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + t), alpha);
+        tv = (beta - alpha) / beta;
+        sc = 1.0 / (alpha - beta);
+    }
+    __syncthreads();                                       // everyone has read alpha
+    if (tid == 0) {
         e[0] = beta;
         tau[0] = tv;
         col[j + 1] = 1.0;
-        s_scale = sc;
+        *counter = 0u;
     }
-    __syncthreads();
-    const double sc = s_scale;
-    for (size_t i = 1 + threadIdx.x; i < len; i += 1024) col[j + 1 + i] *= sc;
+    size_t i = (size_t)j + 2 + tid;
+    for (; i + 768 < m; i += 1024) {                          // four rows in flight per thread
+        const double x0 = col[i], x1 = col[i + 256], x2 = col[i + 512], x3 = col[i + 768];
+        col[i] = x0 * sc;
+        col[i + 256] = x1 * sc;
+        col[i + 512] = x2 * sc;
+        col[i + 768] = x3 * sc;
+    }
+    for (; i < m; i += 256) col[i] *= sc;
 }
 
-// ---- tmp[c] = sum_r W[r, c] v[r], tmp[kTdNb + c] = sum_r V[r, c] v[r],  r = j+1 .. m-1, c < jj;  one workgroup per dot
+// ---- tmp[c] = sum_r W[r, c] v[r], tmp[kTdNb + c] = sum_r V[r, c] v[r],  r = j+1 .. m-1, c < j;  one workgroup per dot.
+//      (A launch of its own: as extra grid rows of the symv launch the symv's registers overflowed - 20 spills, 7-10 % slower.)
 __global__ __launch_bounds__(256) void td_panel_dots(const double* __restrict__ At, size_t lda, size_t m, int j,
                                                      const double* __restrict__ W, size_t ldw, double* __restrict__ tmp) {
     __shared__ double sm[256 / kWave];
@@ -165,9 +203,11 @@ __global__ __launch_bounds__(256) void td_panel_dots(const double* __restrict__ 
     if (threadIdx.x == 0) tmp[(useW ? 0 : kTdNb) + c] = acc;
 }
 
-// ---- w = tau (fold(symv partials) - V tmpW - W tmpV) for rows j+1 .. m-1 -> W[:, j]; per-block partial of w . v
+// ---- w = tau (fold(symv partials) - V tmpW - W tmpV) for rows j+1 .. m-1 -> wpre (its last term waits for w . v: the next
+//      column's td_col_step, or td_w_finish after the panel's last column); per-block partial of w . v
 __global__ __launch_bounds__(256) void td_w_form(const double* __restrict__ At, size_t lda, size_t m, int j,
-                                                 double* __restrict__ W, size_t ldw, const double* __restrict__ tmp,
+                                                 const double* __restrict__ W, size_t ldw, double* __restrict__ wpre,
+                                                 const double* __restrict__ tmp,
                                                  const double* __restrict__ tau, const double* __restrict__ row_part,
                                                  const double* __restrict__ col_part, size_t ms, unsigned nbt,
                                                  double* __restrict__ dots) {
@@ -182,32 +222,49 @@ __global__ __launch_bounds__(256) void td_w_form(const double* __restrict__ At, 
     if (q < ms) {
         const size_t r = (size_t)j + 1 + q;
         const unsigned I = (unsigned)(q / kTdTile);
-        double y = 0.0;
-        for (unsigned Js = 0; Js <= I; ++Js) y += row_part[(size_t)Js * ms + q];
-        for (unsigned Ii = I; Ii < nbt; ++Ii) y += col_part[(size_t)Ii * ms + q];
-        double corr = 0.0;
-        for (int c = 0; c < j; ++c) corr += At[r + (size_t)c * lda] * tW[c] + W[r + (size_t)c * ldw] * tV[c];
+        // nbt + 1 partial vectors and 2 j panel columns per row: four independent chains each, so the loads overlap (fixed order)
+        double y4[4] = {0.0, 0.0, 0.0, 0.0};
+        unsigned Js = 0;
+        for (; Js + 4 <= I + 1; Js += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y4[u] += row_part[(size_t)(Js + u) * ms + q];
+        }
+        for (; Js <= I; ++Js) y4[0] += row_part[(size_t)Js * ms + q];
+        unsigned Ii = I;
+        for (; Ii + 4 <= nbt; Ii += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y4[u] += col_part[(size_t)(Ii + u) * ms + q];
+        }
+        for (; Ii < nbt; ++Ii) y4[0] += col_part[(size_t)Ii * ms + q];
+        const double y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
+        double c4[4] = {0.0, 0.0, 0.0, 0.0};
+        int c = 0;
+        for (; c + 4 <= j; c += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c4[u] += At[r + (size_t)(c + u) * lda] * tW[c + u] + W[r + (size_t)(c + u) * ldw] * tV[c + u];
+        }
+        for (; c < j; ++c) c4[0] += At[r + (size_t)c * lda] * tW[c] + W[r + (size_t)c * ldw] * tV[c];
+        const double corr = (c4[0] + c4[1]) + (c4[2] + c4[3]);
         const double w = tau[0] * (y - corr);
-        W[r + (size_t)j * ldw] = w;
+        wpre[q] = w;
         prod = w * At[r + (size_t)j * lda];
     }
     prod = block_sum(prod, sm);
     if (threadIdx.x == 0) dots[blockIdx.x] = prod;
 }
 
-// ---- w += -(tau / 2)(w . v) v
+// ---- W[:, j] = wpre - (tau / 2)(w . v) v   (the panel's last column; the others get this inside the next td_col_step)
 __global__ __launch_bounds__(256) void td_w_finish(const double* __restrict__ At, size_t lda, size_t m, int j,
-                                                   double* __restrict__ W, size_t ldw, const double* __restrict__ tau,
-                                                   const double* __restrict__ dots, unsigned ndots) {
-    __shared__ double s_alpha;
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (unsigned i = 0; i < ndots; ++i) t += dots[i];
-        s_alpha = -0.5 * tau[0] * t;
-    }
-    __syncthreads();
-    const size_t r = (size_t)j + 1 + (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r < m) W[r + (size_t)j * ldw] += s_alpha * At[r + (size_t)j * lda];
+                                                   double* __restrict__ W, size_t ldw, const double* __restrict__ wpre,
+                                                   const double* __restrict__ tau, const double* __restrict__ dots, unsigned ndots) {
+    __shared__ double sm[256 / kWave];
+    double t = 0.0;
+    for (unsigned i = threadIdx.x; i < ndots; i += 256) t += dots[i];
+    t = block_sum(t, sm);
+    const double alpha = -0.5 * tau[0] * t;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t r = (size_t)j + 1 + q;
+    if (r < m) W[r + (size_t)j * ldw] = wpre[q] + alpha * At[r + (size_t)j * lda];
 }
 
 // the panel is done: the sub-diagonal entries (held at 1 while the panel's reflectors were in use) get their e back;
@@ -249,10 +306,14 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
     double* col_part = fz.alloc((size_t)nbt_max * n);
     double* tmp = fz.alloc(2 * kTdNb);
     double* dots = fz.alloc(nbt_max + 1);
-    if (!W || !row_part || !col_part || !tmp || !dots) return fz.rc;
+    double* wpre = fz.alloc(n);
+    double* nrm_part = fz.alloc(nbt_max + 2);
+    unsigned* counter = (unsigned*)fz.alloc(1);
+    if (!W || !row_part || !col_part || !tmp || !dots || !wpre || !nrm_part || !counter) return fz.rc;
+    FZ_HIP(fz, hipMemsetAsync(counter, 0, sizeof(double), st));
     // TRAMP_TD_PROFILE=1 (diagnosis): synchronise after every launch and report the time per kernel family
     static const bool prof = getenv("TRAMP_TD_PROFILE") != nullptr;
-    double tacc[7] = {0, 0, 0, 0, 0, 0, 0};
+    double tacc[4] = {0, 0, 0, 0};
     auto stamp = [&](int k, double& t0) {
         if (!prof) return;
         (void)hipStreamSynchronize(st);
@@ -274,40 +335,43 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
             clock_gettime(CLOCK_MONOTONIC, &ts);
             t0 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
         }
+        unsigned ndots_prev = 0;
         for (int j = 0; j < pb; ++j) {
-            if (j) hipLaunchKernelGGL(td_col_update, dim3((unsigned)((m - j + 255) / 256)), dim3(256), 0, st, At, n, m, j, W, ldw);
+            hipLaunchKernelGGL(td_col_step, dim3((unsigned)((m - j + 255) / 256)), dim3(256), 0, st, At, n, m, j, W, ldw, wpre, dots,
+                               ndots_prev, d + i + j, e + i + j, tau + i + j, nrm_part, counter);
             stamp(0, t0);
-            hipLaunchKernelGGL(td_larfg, dim3(1), dim3(1024), 0, st, At, n, m, j, d + i + j, e + i + j, tau + i + j);
-            stamp(1, t0);
             const size_t ms = m - (size_t)j - 1;                     // the symv's block: rows / columns j+1 ..
             const unsigned nbt = (unsigned)((ms + kTdTile - 1) / kTdTile);
+            if (j) hipLaunchKernelGGL(td_panel_dots, dim3(2 * j), dim3(256), 0, st, At, n, m, j, W, ldw, tmp);
             hipLaunchKernelGGL(td_symv_lower, dim3(nbt, nbt), dim3(256), 0, st, At + (j + 1) + (size_t)(j + 1) * n, n, ms,
                                At + (j + 1) + (size_t)j * n, row_part, col_part);
-            stamp(2, t0);
-            if (j) hipLaunchKernelGGL(td_panel_dots, dim3(2 * j), dim3(256), 0, st, At, n, m, j, W, ldw, tmp);
-            stamp(3, t0);
+            stamp(1, t0);
             const unsigned nblk_r = (unsigned)((ms + 255) / 256);
-            hipLaunchKernelGGL(td_w_form, dim3(nblk_r), dim3(256), 0, st, At, n, m, j, W, ldw, tmp, tau + i + j, row_part,
+            hipLaunchKernelGGL(td_w_form, dim3(nblk_r), dim3(256), 0, st, At, n, m, j, W, ldw, wpre, tmp, tau + i + j, row_part,
                                col_part, ms, nbt, dots);
-            stamp(4, t0);
-            hipLaunchKernelGGL(td_w_finish, dim3(nblk_r), dim3(256), 0, st, At, n, m, j, W, ldw, tau + i + j, dots, nblk_r);
-            stamp(5, t0);
+            stamp(2, t0);
+            ndots_prev = nblk_r;
         }
+        hipLaunchKernelGGL(td_w_finish, dim3(ndots_prev), dim3(256), 0, st, At, n, m, pb - 1, W, ldw, wpre, tau + i + pb - 1, dots,
+                           ndots_prev);
         // trailing update with V = At[pb:, :pb] (its unit entry in place), W[pb:, :]
         const size_t mt = m - (size_t)pb;
         FZ_OK(td_syr2k_lower(fz, mt, pb, At + pb, n, W + pb, ldw, At + pb + (size_t)pb * n, n));
         hipLaunchKernelGGL(td_restore_subdiag, dim3((pb + 63) / 64), dim3(64), 0, st, At, n, pb, e + i);
-        stamp(6, t0);
+        stamp(3, t0);
     }
     if (prof)
-        fprintf(stderr, "[tramp tridiag] n=%zu (synchronised launches): col_update %.3f s, larfg %.3f, symv %.3f, panel_dots %.3f, "
-                        "w_form %.3f, w_finish %.3f, syr2k %.3f\n", n, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6]);
+        fprintf(stderr, "[tramp tridiag] n=%zu (synchronised launches): column step %.3f s, symv + panel dots %.3f, w_form %.3f, "
+                        "w_finish + syr2k %.3f\n", n, tacc[0], tacc[1], tacc[2], tacc[3]);
     hipLaunchKernelGGL(get_diag_last, dim3(1), dim3(1), 0, st, A, n, d);
     fz.release(W);
     fz.release(row_part);
     fz.release(col_part);
     fz.release(tmp);
     fz.release(dots);
+    fz.release(wpre);
+    fz.release(nrm_part);
+    fz.release(counter);
     fz.tick("tridiag: sytrd", n);
     return TRAMP_OK;
 }
