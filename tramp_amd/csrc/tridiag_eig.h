@@ -9,7 +9,8 @@
 //     transposing butterfly over the wave; per-tile partial vectors folded in fixed order (run-to-run reproducible);
 //   * the panel's level-2 pieces in four launches per column - column step (previous w's last term + column update + dlarfg
 //     through a last-workgroup ticket), the panel's dots, symv, w - with no host round trip: beta, tau, alpha stay on the device;
-//   * the trailing rank-2nb update by rocBLAS (syr2k on diagonal tiles, gemm below), every call inside 2^31 elements;
+//   * the trailing rank-2nb update as one rocBLAS gemm of depth 2 nb per block column of 2048 ([V | W][W | V]^T: the
+//     trailing matrix is read and written once per panel), every call inside 2^31 elements;
 //   * the tridiagonal problem by rocSOLVER's stedc (n <= 46 340: its 32-bit indexing), above that ONE Cuppen merge of two
 //     stedc halves written here (deflation on the host, secular equation by bisection about the nearer pole, Loewner
 //     vector, eigenvectors, one gemm);
@@ -59,8 +60,13 @@ __device__ __forceinline__ void td_symv_group(const double* __restrict__ At, siz
 __global__ __launch_bounds__(256, 2) void td_symv_lower(const double* __restrict__ At, size_t lda, size_t m,
                                                      const double* __restrict__ v, double* __restrict__ row_part,
                                                      double* __restrict__ col_part) {
-    const unsigned Js = blockIdx.x, I = blockIdx.y;
-    if (Js > I) return;
+    // one workgroup per tile of the lower triangle, enumerated row by row: t = I (I + 1) / 2 + Js  (a square grid whose upper
+    // half exits at once cost 6-9 % of the kernel: tools/probes/probe_symv.hip)
+    const unsigned t = blockIdx.x;
+    unsigned I = (unsigned)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((size_t)(I + 1) * (I + 2) / 2 <= t) ++I;
+    while ((size_t)I * (I + 1) / 2 > t) --I;
+    const unsigned Js = t - (unsigned)((size_t)I * (I + 1) / 2);
     __shared__ double vrow[kTdTile], vcol[kTdTile], rsum[4][kTdTile];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t r0 = (size_t)I * kTdTile, c0 = (size_t)Js * kTdTile;
@@ -275,24 +281,35 @@ __global__ void td_restore_subdiag(double* __restrict__ At, size_t lda, int pb, 
 }
 __global__ void get_diag_last(const double* __restrict__ A, size_t n, double* __restrict__ d) { d[n - 1] = A[(n - 1) + (n - 1) * n]; }
 
-// rank-2pb update of the lower triangle of C (mt x mt, ldc): C -= V W^T + W V^T;  V (ldv), W (ldw) are mt x pb
-int td_syr2k_lower(Fz& fz, size_t mt, int pb, const double* V, size_t ldv, const double* W, size_t ldw, double* C, size_t ldc) {
+// rank-2pb update of the lower triangle of C (mt x mt, ldc): C -= V W^T + W V^T;  V (ldv), W (ldw) are mt x pb.
+// As ONE product of depth 2 pb per block column: C[j0:, j0:j0+B] -= [V | W][j0:, :] ([W | V][j0:j0+B, :])^T - the two gemms of
+// depth pb it replaces read and wrote C twice (and rocBLAS's syr2k on the diagonal tiles ran at a fraction of its gemm).  The
+// diagonal blocks are updated as full squares: their upper triangles are never read by this reduction (2 % more flops at B = 2048).
+__global__ void td_concat_panels(const double* __restrict__ V, size_t ldv, const double* __restrict__ W, size_t ldw, size_t mt, int pb,
+                                 double* __restrict__ VW, double* __restrict__ WV) {
+    const size_t total = mt * (size_t)pb;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t r = idx % mt, c = idx / mt;
+        const double v = V[r + c * ldv], w = W[r + c * ldw];
+        VW[idx] = v;
+        VW[idx + total] = w;
+        WV[idx] = w;
+        WV[idx + total] = v;
+    }
+}
+
+constexpr size_t kTdUpd = 2048;          // block-column width of the trailing update
+
+int td_syr2k_lower(Fz& fz, size_t mt, int pb, const double* V, size_t ldv, const double* W, size_t ldw, double* C, size_t ldc,
+                   double* VW, double* WV) {
     if (!mt) return TRAMP_OK;
-    const size_t T = min3(tile_for(ldv), tile_for(ldw), tile_for(ldc));
+    hipLaunchKernelGGL(td_concat_panels, dim3(kRedBlocks), dim3(kBlock), 0, fz.ctx->stream, V, ldv, W, ldw, mt, pb, VW, WV);
     const double m1 = -1.0, one = 1.0;
-    for (size_t j0 = 0; j0 < mt; j0 += T) {
-        const size_t nj = mt - j0 < T ? mt - j0 : T;
-        FZ_RB(fz, rocblas_dsyr2k(fz.h, rocblas_fill_lower, rocblas_operation_none, (rocblas_int)nj, pb, &m1, V + j0,
-                                 (rocblas_int)ldv, W + j0, (rocblas_int)ldw, &one, C + j0 + j0 * ldc, (rocblas_int)ldc));
-        for (size_t i0 = j0 + T; i0 < mt; i0 += T) {
-            const size_t mi = mt - i0 < T ? mt - i0 : T;
-            FZ_RB(fz, rocblas_dgemm(fz.h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)mi, (rocblas_int)nj,
-                                    pb, &m1, V + i0, (rocblas_int)ldv, W + j0, (rocblas_int)ldw, &one, C + i0 + j0 * ldc,
-                                    (rocblas_int)ldc));
-            FZ_RB(fz, rocblas_dgemm(fz.h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)mi, (rocblas_int)nj,
-                                    pb, &m1, W + i0, (rocblas_int)ldw, V + j0, (rocblas_int)ldv, &one, C + i0 + j0 * ldc,
-                                    (rocblas_int)ldc));
-        }
+    for (size_t j0 = 0; j0 < mt; j0 += kTdUpd) {
+        const size_t nj = mt - j0 < kTdUpd ? mt - j0 : kTdUpd;
+        FZ_RB(fz, rocblas_dgemm(fz.h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)(mt - j0), (rocblas_int)nj,
+                                2 * pb, &m1, VW + j0, (rocblas_int)mt, WV + j0, (rocblas_int)mt, &one, C + j0 + j0 * ldc,
+                                (rocblas_int)ldc));
     }
     return TRAMP_OK;
 }
@@ -307,9 +324,11 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
     double* tmp = fz.alloc(2 * kTdNb);
     double* dots = fz.alloc(nbt_max + 1);
     double* wpre = fz.alloc(n);
+    double* VW = fz.alloc(2 * n * kTdNb);
+    double* WV = fz.alloc(2 * n * kTdNb);
     double* nrm_part = fz.alloc(nbt_max + 2);
     unsigned* counter = (unsigned*)fz.alloc(1);
-    if (!W || !row_part || !col_part || !tmp || !dots || !wpre || !nrm_part || !counter) return fz.rc;
+    if (!W || !row_part || !col_part || !tmp || !dots || !wpre || !nrm_part || !counter || !VW || !WV) return fz.rc;
     FZ_HIP(fz, hipMemsetAsync(counter, 0, sizeof(double), st));
     // TRAMP_TD_PROFILE=1 (diagnosis): synchronise after every launch and report the time per kernel family
     static const bool prof = getenv("TRAMP_TD_PROFILE") != nullptr;
@@ -343,7 +362,7 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
             const size_t ms = m - (size_t)j - 1;                     // the symv's block: rows / columns j+1 ..
             const unsigned nbt = (unsigned)((ms + kTdTile - 1) / kTdTile);
             if (j) hipLaunchKernelGGL(td_panel_dots, dim3(2 * j), dim3(256), 0, st, At, n, m, j, W, ldw, tmp);
-            hipLaunchKernelGGL(td_symv_lower, dim3(nbt, nbt), dim3(256), 0, st, At + (j + 1) + (size_t)(j + 1) * n, n, ms,
+            hipLaunchKernelGGL(td_symv_lower, dim3(nbt * (nbt + 1) / 2), dim3(256), 0, st, At + (j + 1) + (size_t)(j + 1) * n, n, ms,
                                At + (j + 1) + (size_t)j * n, row_part, col_part);
             stamp(1, t0);
             const unsigned nblk_r = (unsigned)((ms + 255) / 256);
@@ -356,7 +375,7 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
                            ndots_prev);
         // trailing update with V = At[pb:, :pb] (its unit entry in place), W[pb:, :]
         const size_t mt = m - (size_t)pb;
-        FZ_OK(td_syr2k_lower(fz, mt, pb, At + pb, n, W + pb, ldw, At + pb + (size_t)pb * n, n));
+        FZ_OK(td_syr2k_lower(fz, mt, pb, At + pb, n, W + pb, ldw, At + pb + (size_t)pb * n, n, VW, WV));
         hipLaunchKernelGGL(td_restore_subdiag, dim3((pb + 63) / 64), dim3(64), 0, st, At, n, pb, e + i);
         stamp(3, t0);
     }
@@ -370,6 +389,8 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
     fz.release(tmp);
     fz.release(dots);
     fz.release(wpre);
+    fz.release(VW);
+    fz.release(WV);
     fz.release(nrm_part);
     fz.release(counter);
     fz.tick("tridiag: sytrd", n);
