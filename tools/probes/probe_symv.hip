@@ -172,6 +172,92 @@ __global__ __launch_bounds__(256, 2) void symvB(const double* __restrict__ At, s
     if (r0 + tid < m) row_part[(size_t)Js * m + r0 + tid] = (rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]);
 }
 
+
+// ---------------------------------------------------------------- variant C: tiles of 64 S rows x 256 columns (S slabs per lane, groups of G columns)
+template <bool FULL, int S, int G>
+__device__ __forceinline__ void groupC(const double* __restrict__ At, size_t lda, size_t m, size_t r0, size_t cg, int lane,
+                                       const double* __restrict__ vcolg, const double (&vr)[S], double (&racc)[S], double (&cacc)[G]) {
+#pragma unroll
+    for (int cc = 0; cc < G; ++cc) {
+        const size_t c = cg + cc;
+        const double vc = vcolg[cc];
+        const double* col = At + c * lda + r0 + lane;
+        double a[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (FULL) a[s] = col[s * 64];
+            else {
+                const size_t r = r0 + (size_t)s * 64 + lane;
+                a[s] = ((c < m) && (r < m) && (r >= c)) ? col[s * 64] : 0.0;
+            }
+        }
+        double cs = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            racc[s] = fma(a[s], vc, racc[s]);
+            const bool strict = FULL || (r0 + (size_t)s * 64 + lane > c);
+            cs = fma(strict ? a[s] : 0.0, vr[s], cs);
+        }
+        cacc[cc] = cs;
+    }
+}
+
+template <int S, int G, int OCC>
+__global__ __launch_bounds__(256, OCC) void symvC(const double* __restrict__ At, size_t lda, size_t m, const double* __restrict__ v,
+                                                double* __restrict__ row_part, double* __restrict__ col_part) {
+    // tile (I, Js): rows [R I, +R), R = 64 S, columns [256 Js, +256), Js <= Q I + Q - 1, Q = R / 256;  t = Q I (I + 1) / 2 + Js
+    constexpr int R = 64 * S, Q = R / 256;
+    const unsigned t = blockIdx.x;
+    unsigned I = (unsigned)((sqrt(8.0 * (double)t / Q + 1.0) - 1.0) * 0.5);
+    while ((size_t)Q * (I + 1) * (I + 2) / 2 <= t) ++I;
+    while ((size_t)Q * I * (I + 1) / 2 > t) --I;
+    const unsigned Js = t - (unsigned)((size_t)Q * I * (I + 1) / 2);
+    const size_t r0 = (size_t)I * R, c0 = (size_t)Js * 256;
+    if (c0 >= m) return;
+    __shared__ double vrow[R], vcol[256], rsum[4][R];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int h = 0; h < Q; ++h) vrow[h * 256 + tid] = (r0 + h * 256 + tid < m) ? v[r0 + h * 256 + tid] : 0.0;
+    vcol[tid] = (c0 + tid < m) ? v[c0 + tid] : 0.0;
+    __syncthreads();
+    double racc[S], vr[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        racc[s] = 0.0;
+        vr[s] = vrow[s * 64 + lane];
+    }
+    const bool full = (c0 + 256 <= r0) && (r0 + R <= m);
+    for (int g = 0; g < 64 / G; ++g) {
+        const size_t cg = c0 + (size_t)w * 64 + (size_t)g * G;
+        double cacc[G];
+        if (full) groupC<true, S, G>(At, lda, m, r0, cg, lane, vcol + w * 64 + g * G, vr, racc, cacc);
+        else groupC<false, S, G>(At, lda, m, r0, cg, lane, vcol + w * 64 + g * G, vr, racc, cacc);
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            const bool up = (lane & off) != 0;
+#pragma unroll
+            for (int i = 0; i < off; ++i) {
+                const double keep = up ? cacc[i + off] : cacc[i];
+                const double send = up ? cacc[i] : cacc[i + off];
+                cacc[i] = keep + __shfl_xor(send, off);
+            }
+        }
+        double tt = cacc[0];                                             // column (lane & (G - 1)) of the group, summed over G lanes
+#pragma unroll
+        for (int off = G; off < 64; off <<= 1) tt += __shfl_xor(tt, off);
+        const size_t c = cg + (lane & (G - 1));
+        if (lane < G && c < m) col_part[(size_t)I * m + c] = tt;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) rsum[w][s * 64 + lane] = racc[s];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < Q; ++h) {
+        const int rr = h * 256 + tid;
+        if (r0 + rr < m) row_part[(size_t)Js * m + r0 + rr] = (rsum[0][rr] + rsum[1][rr]) + (rsum[2][rr] + rsum[3][rr]);
+    }
+}
+
 // ---------------------------------------------------------------- plain read of the lower-triangle tiles (ceiling)
 __global__ __launch_bounds__(256) void read_tiles(const double* __restrict__ At, size_t lda, size_t m, double* __restrict__ out) {
     const unsigned Js = blockIdx.x, I = blockIdx.y;
@@ -224,6 +310,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const double bytes = 8.0 * (double)m * (double)m / 2.0;
+    int mode = 0;
     auto check = [&](const char* name) {
         if (n > 8192) return;
         std::vector<double> hr((size_t)nbt * m), hc((size_t)nbt * m);
@@ -234,7 +321,8 @@ int main(int argc, char** argv) {
             const unsigned I = (unsigned)(q / kTile);
             double y = 0.0;
             for (unsigned Js = 0; Js <= I; ++Js) y += hr[(size_t)Js * m + q];
-            for (unsigned Ii = I; Ii < nbt; ++Ii) y += hc[(size_t)Ii * m + q];
+            if (mode == 0) for (unsigned Ii = I; Ii < nbt; ++Ii) y += hc[(size_t)Ii * m + q];
+            else for (unsigned Ii = (unsigned)(q / (256 * mode)); Ii < (nbt + mode - 1) / mode; ++Ii) y += hc[(size_t)Ii * m + q];
             double ref = 0.0;
             for (size_t c = 0; c < m; ++c) ref += h[(off + q) + (off + c) * n] * hv[off + c];
             err = fmax(err, fabs(y - ref));
@@ -264,5 +352,17 @@ int main(int argc, char** argv) {
     time("symv A (shipped)", [&] { hipLaunchKernelGGL((symvA<0>), dim3(nbt, nbt), dim3(256), 0, 0, At, n, m, vv, rp, cp, nbt); }, true);
     time("symv A, triangular grid", [&] { hipLaunchKernelGGL((symvA<1>), dim3(nbt * (nbt + 1) / 2), dim3(256), 0, 0, At, n, m, vv, rp, cp, nbt); }, true);
     time("symv B (16-byte loads)", [&] { hipLaunchKernelGGL(symvB, dim3(nbt, nbt), dim3(256), 0, 0, At, n, m, vv, rp, cp, nbt); }, true);
+    mode = 2;
+    { const unsigned nbr = (unsigned)((m + 511) / 512);
+      const dim3 g(nbr * (nbr + 1));
+      time("C 512x256 G=8 occ2", [&] { hipLaunchKernelGGL((symvC<8, 8, 2>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true);
+      time("C 512x256 G=4 occ2", [&] { hipLaunchKernelGGL((symvC<8, 4, 2>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true);
+      time("C 512x256 G=4 occ3", [&] { hipLaunchKernelGGL((symvC<8, 4, 3>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true);
+      time("C 512x256 G=2 occ4", [&] { hipLaunchKernelGGL((symvC<8, 2, 4>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true); }
+    mode = 1;
+    { const unsigned nbr = (unsigned)((m + 255) / 256);
+      const dim3 g(nbr * (nbr + 1) / 2);
+      time("C 256x256 G=8 occ3", [&] { hipLaunchKernelGGL((symvC<4, 8, 3>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true);
+      time("C 256x256 G=4 occ4", [&] { hipLaunchKernelGGL((symvC<4, 4, 4>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true); }
     return 0;
 }

@@ -5,8 +5,8 @@
 // per column at 4.2 TB/s; stedc 1.2 s; ormtr 2.1 s at 14 TFLOP/s - tools/probes/probe_syevd_parts.cpp), and the spectral
 // divide and conquer that replaced it above 16 384 spends 20 + n^3 products per level.  Here:
 //   * dsytrd / dlatrd (LAPACK, lower triangle) with an own symv that reads only the LOWER triangle of the trailing matrix
-//     (half the bytes): 256 x 256 tiles, a lane owns a row, a wave a 64-column strip; row sums through LDS, column sums by a
-//     transposing butterfly over the wave; per-tile partial vectors folded in fixed order (run-to-run reproducible);
+//     (half the bytes): 512 x 256 tiles, a lane owns eight rows, a wave a 64-column strip; row sums through LDS, column sums by
+//     a transposing butterfly over the wave; per-tile partial vectors folded in fixed order (run-to-run reproducible);
 //   * the panel's level-2 pieces in four launches per column - column step (previous w's last term + column update + dlarfg
 //     through a last-workgroup ticket), the panel's dots, symv, w - with no host round trip: beta, tau, alpha stay on the device;
 //   * the trailing rank-2nb update as one rocBLAS gemm of depth 2 nb per block column of 2048 ([V | W][W | V]^T: the
@@ -23,34 +23,41 @@ constexpr int kTdTile = 256;          // symv tile edge
 constexpr int kTdNb = 64;             // reflectors per reduction panel
 constexpr size_t kTdBtDefault = 2048;  // reflectors per back-transformation panel (TRAMP_TD_BT_PANEL)
 
-// ---- y = (L + strict(L)^T) v on the lower triangle of the m x m block At (column-major, lda): tile (I, Js), Js <= I --------
+// ---- y = (L + strict(L)^T) v on the lower triangle of the m x m block At (column-major, lda) ------------------------------------
+// tile (I, Js): rows [512 I, +512), columns [256 Js, +256), Js <= 2 I + 1 (the tiles that touch the lower triangle);
 // row_part[Js m + r]: sum over the tile's columns of L[r, c] v[c] (r >= c);  col_part[I m + c]: sum over its rows of L[r, c] v[r] (r > c)
-// one 16-column group of the wave's strip: FULL = the tile lies strictly below the diagonal and inside the matrix
+// A lane owns eight rows (64 apart), a wave a 64-column strip in groups of four columns: the row sums stay in registers and
+// leave through LDS at the end, the column sums of a group leave through a transposing butterfly over the wave.
+// Shape chosen with tools/probes/probe_symv.hip (512 x 256 tiles, groups of 4: 171 VGPRs, no spills; 5.3 TB/s at m = 45 000
+// against 4.9 for 256 x 256 tiles in groups of 16, a plain read of the same bytes runs at 6.4).
+constexpr int kTdRows = 512;          // symv tile height
+constexpr int kTdSlabs = kTdRows / 64, kTdGrp = 4;
+
 template <bool FULL>
-__device__ __forceinline__ void td_symv_group(const double* __restrict__ At, size_t lda, size_t m, size_t r0, size_t cg, bool diag,
-                                              int lane, const double* __restrict__ vcol16, const double (&vr)[4],
-                                              double (&racc)[4], double (&cacc)[16]) {
+__device__ __forceinline__ void td_symv_group(const double* __restrict__ At, size_t lda, size_t m, size_t r0, size_t cg, int lane,
+                                              const double* __restrict__ vcolg, const double (&vr)[kTdSlabs],
+                                              double (&racc)[kTdSlabs], double (&cacc)[kTdGrp]) {
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
+    for (int cc = 0; cc < kTdGrp; ++cc) {
         const size_t c = cg + cc;
-        const double vc = vcol16[cc];
+        const double vc = vcolg[cc];
         const double* col = At + c * lda + r0 + lane;
-        double a[4];
+        double a[kTdSlabs];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < kTdSlabs; ++s) {
             if (FULL) {
                 a[s] = col[s * 64];
             } else {
                 const size_t r = r0 + (size_t)s * 64 + lane;
-                a[s] = ((c < m) && (r < m) && (!diag || r >= c)) ? col[s * 64] : 0.0;
+                a[s] = ((c < m) && (r < m) && (r >= c)) ? col[s * 64] : 0.0;
             }
         }
         double cs = 0.0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < kTdSlabs; ++s) {
             racc[s] = fma(a[s], vc, racc[s]);
             // the diagonal entry belongs to the row sum only
-            const bool strict = FULL || !diag || (r0 + (size_t)s * 64 + lane > c);
+            const bool strict = FULL || (r0 + (size_t)s * 64 + lane > c);
             cs = fma(strict ? a[s] : 0.0, vr[s], cs);
         }
         cacc[cc] = cs;
@@ -60,32 +67,35 @@ __device__ __forceinline__ void td_symv_group(const double* __restrict__ At, siz
 __global__ __launch_bounds__(256, 2) void td_symv_lower(const double* __restrict__ At, size_t lda, size_t m,
                                                      const double* __restrict__ v, double* __restrict__ row_part,
                                                      double* __restrict__ col_part) {
-    // one workgroup per tile of the lower triangle, enumerated row by row: t = I (I + 1) / 2 + Js  (a square grid whose upper
-    // half exits at once cost 6-9 % of the kernel: tools/probes/probe_symv.hip)
+    // one workgroup per tile, enumerated row by row: t = I (I + 1) + Js  (a square grid whose upper half exits at once cost
+    // 6-9 % of the kernel)
     const unsigned t = blockIdx.x;
-    unsigned I = (unsigned)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((size_t)(I + 1) * (I + 2) / 2 <= t) ++I;
-    while ((size_t)I * (I + 1) / 2 > t) --I;
-    const unsigned Js = t - (unsigned)((size_t)I * (I + 1) / 2);
-    __shared__ double vrow[kTdTile], vcol[kTdTile], rsum[4][kTdTile];
+    unsigned I = (unsigned)((sqrt(4.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((size_t)(I + 1) * (I + 2) <= t) ++I;
+    while ((size_t)I * (I + 1) > t) --I;
+    const unsigned Js = t - (unsigned)((size_t)I * (I + 1));
+    const size_t r0 = (size_t)I * kTdRows, c0 = (size_t)Js * kTdTile;
+    if (c0 >= m) return;
+    __shared__ double vrow[kTdRows], vcol[kTdTile], rsum[4][kTdRows];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t r0 = (size_t)I * kTdTile, c0 = (size_t)Js * kTdTile;
-    vrow[tid] = (r0 + tid < m) ? v[r0 + tid] : 0.0;
+#pragma unroll
+    for (int h = 0; h < kTdRows / 256; ++h) vrow[h * 256 + tid] = (r0 + h * 256 + tid < m) ? v[r0 + h * 256 + tid] : 0.0;
     vcol[tid] = (c0 + tid < m) ? v[c0 + tid] : 0.0;
     __syncthreads();
-    double racc[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool diag = (I == Js);
-    const bool full = !diag && r0 + kTdTile <= m;                      // (c0 + 256 <= r0 then)
-    const double vr[4] = {vrow[lane], vrow[64 + lane], vrow[128 + lane], vrow[192 + lane]};
-    // the wave's 64-column strip in four groups of 16: the column sums of a group leave through a transposing butterfly
-    // (four steps inside 16-lane groups, then two plain steps across them), 16 accumulators live at a time
-    for (int g = 0; g < 4; ++g) {
-        const size_t cg = c0 + (size_t)w * 64 + (size_t)g * 16;
-        double cacc[16];
-        if (full) td_symv_group<true>(At, lda, m, r0, cg, diag, lane, vcol + w * 64 + g * 16, vr, racc, cacc);
-        else td_symv_group<false>(At, lda, m, r0, cg, diag, lane, vcol + w * 64 + g * 16, vr, racc, cacc);
+    double racc[kTdSlabs], vr[kTdSlabs];
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
+    for (int s = 0; s < kTdSlabs; ++s) {
+        racc[s] = 0.0;
+        vr[s] = vrow[s * 64 + lane];
+    }
+    const bool full = (c0 + kTdTile <= r0) && (r0 + kTdRows <= m);      // strictly below the diagonal and inside the matrix
+    for (int g = 0; g < 64 / kTdGrp; ++g) {
+        const size_t cg = c0 + (size_t)w * 64 + (size_t)g * kTdGrp;
+        double cacc[kTdGrp];
+        if (full) td_symv_group<true>(At, lda, m, r0, cg, lane, vcol + w * 64 + g * kTdGrp, vr, racc, cacc);
+        else td_symv_group<false>(At, lda, m, r0, cg, lane, vcol + w * 64 + g * kTdGrp, vr, racc, cacc);
+#pragma unroll
+        for (int off = kTdGrp / 2; off >= 1; off >>= 1) {
             const bool up = (lane & off) != 0;
 #pragma unroll
             for (int i = 0; i < off; ++i) {
@@ -94,16 +104,20 @@ __global__ __launch_bounds__(256, 2) void td_symv_lower(const double* __restrict
                 cacc[i] = keep + __shfl_xor(send, off);
             }
         }
-        double t = cacc[0];                                              // column (lane & 15) of the group, summed over 16 lanes
-        t += __shfl_xor(t, 16);
-        t += __shfl_xor(t, 32);
-        const size_t c = cg + (lane & 15);
-        if (lane < 16 && c < m) col_part[(size_t)I * m + c] = t;
+        double tt = cacc[0];                                             // column (lane & 3) of the group, summed over 4 lanes
+#pragma unroll
+        for (int off = kTdGrp; off < 64; off <<= 1) tt += __shfl_xor(tt, off);
+        const size_t c = cg + (lane & (kTdGrp - 1));
+        if (lane < kTdGrp && c < m) col_part[(size_t)I * m + c] = tt;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) rsum[w][s * 64 + lane] = racc[s];
+    for (int s = 0; s < kTdSlabs; ++s) rsum[w][s * 64 + lane] = racc[s];
     __syncthreads();
-    if (r0 + tid < m) row_part[(size_t)Js * m + r0 + tid] = (rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]);
+#pragma unroll
+    for (int h = 0; h < kTdRows / 256; ++h) {
+        const int rr = h * 256 + tid;
+        if (r0 + rr < m) row_part[(size_t)Js * m + r0 + rr] = (rsum[0][rr] + rsum[1][rr]) + (rsum[2][rr] + rsum[3][rr]);
+    }
 }
 
 // ---- one launch per column j of the panel (dlatrd's level-2 pieces around the symv), rows r = j .. m-1 of the trailing block:
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(256) void td_w_form(const double* __restrict__ At, 
                                                  const double* __restrict__ W, size_t ldw, double* __restrict__ wpre,
                                                  const double* __restrict__ tmp,
                                                  const double* __restrict__ tau, const double* __restrict__ row_part,
-                                                 const double* __restrict__ col_part, size_t ms, unsigned nbt,
+                                                 const double* __restrict__ col_part, size_t ms, unsigned nbr,
                                                  double* __restrict__ dots) {
     __shared__ double tW[kTdNb], tV[kTdNb], sm[256 / kWave];
     if (threadIdx.x < j) {
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256) void td_w_form(const double* __restrict__ At, 
     double prod = 0.0;
     if (q < ms) {
         const size_t r = (size_t)j + 1 + q;
-        const unsigned I = (unsigned)(q / kTdTile);
+        const unsigned I = (unsigned)(q / kTdTile);                   // last 256-column block with a row sum for q
         // nbt + 1 partial vectors and 2 j panel columns per row: four independent chains each, so the loads overlap (fixed order)
         double y4[4] = {0.0, 0.0, 0.0, 0.0};
         unsigned Js = 0;
@@ -236,12 +250,12 @@ __global__ __launch_bounds__(256) void td_w_form(const double* __restrict__ At, 
             for (int u = 0; u < 4; ++u) y4[u] += row_part[(size_t)(Js + u) * ms + q];
         }
         for (; Js <= I; ++Js) y4[0] += row_part[(size_t)Js * ms + q];
-        unsigned Ii = I;
-        for (; Ii + 4 <= nbt; Ii += 4) {
+        unsigned Ii = (unsigned)(q / kTdRows);                        // first 512-row block with a column sum for q
+        for (; Ii + 4 <= nbr; Ii += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) y4[u] += col_part[(size_t)(Ii + u) * ms + q];
         }
-        for (; Ii < nbt; ++Ii) y4[0] += col_part[(size_t)Ii * ms + q];
+        for (; Ii < nbr; ++Ii) y4[0] += col_part[(size_t)Ii * ms + q];
         const double y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
         double c4[4] = {0.0, 0.0, 0.0, 0.0};
         int c = 0;
@@ -360,14 +374,14 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
                                ndots_prev, d + i + j, e + i + j, tau + i + j, nrm_part, counter);
             stamp(0, t0);
             const size_t ms = m - (size_t)j - 1;                     // the symv's block: rows / columns j+1 ..
-            const unsigned nbt = (unsigned)((ms + kTdTile - 1) / kTdTile);
+            const unsigned nbr = (unsigned)((ms + kTdRows - 1) / kTdRows);
             if (j) hipLaunchKernelGGL(td_panel_dots, dim3(2 * j), dim3(256), 0, st, At, n, m, j, W, ldw, tmp);
-            hipLaunchKernelGGL(td_symv_lower, dim3(nbt * (nbt + 1) / 2), dim3(256), 0, st, At + (j + 1) + (size_t)(j + 1) * n, n, ms,
+            hipLaunchKernelGGL(td_symv_lower, dim3(nbr * (nbr + 1)), dim3(256), 0, st, At + (j + 1) + (size_t)(j + 1) * n, n, ms,
                                At + (j + 1) + (size_t)j * n, row_part, col_part);
             stamp(1, t0);
             const unsigned nblk_r = (unsigned)((ms + 255) / 256);
             hipLaunchKernelGGL(td_w_form, dim3(nblk_r), dim3(256), 0, st, At, n, m, j, W, ldw, wpre, tmp, tau + i + j, row_part,
-                               col_part, ms, nbt, dots);
+                               col_part, ms, nbr, dots);
             stamp(2, t0);
             ndots_prev = nblk_r;
         }
