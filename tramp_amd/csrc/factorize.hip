@@ -594,12 +594,16 @@ int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth);
 
 #include "tridiag_eig.h"
 
-// TRAMP_EIG_METHOD: "tridiag" (default from round 6) = the own tridiagonalisation + stedc + back-transformation of
-// tridiag_eig.h; "split" = rocSOLVER syevd / the spectral divide and conquer above its cap (rounds 2-5)
+// TRAMP_EIG_METHOD: unset = "auto" (round 6): orders from 6144 on take the own tridiagonalisation + stedc + back-transformation
+// of tridiag_eig.h, smaller ones rocSOLVER's syevd (0.15 s against 0.24 s at n = 4096; 0.67 against 0.61 s at 8192);
+// "tridiag" = the tridiagonal path from order 64 on; "split" = rocSOLVER syevd / the spectral divide and conquer above its cap
+// (rounds 2-5)
+constexpr size_t kTridiagAutoMin = 6144;
 int eig_method_from_env() {
     const char* s = getenv("TRAMP_EIG_METHOD");
     if (s && !strcmp(s, "split")) return 0;
-    return 1;
+    if (s && !strcmp(s, "tridiag")) return 1;
+    return 2;
 }
 
 // work space of the tridiagonal path beyond A itself: the eigenvector matrix of T, and for the merge the two halves, V,
@@ -769,7 +773,7 @@ int eigh_split(Fz& fz, double* A, size_t n, double* w_d, int depth) {
 // ascending eigenvalues in w_d
 int eigh_rec(Fz& fz, double* A, size_t n, double* w_d, int depth) {
     const int method = eig_method_from_env();             // read per call, as TRAMP_EIG_CAP is
-    if (method == 1 && n >= 64 && n <= 2 * kStedcCap && tridiag_fits(n)) {
+    if (method != 0 && n >= (method == 1 ? 64 : kTridiagAutoMin) && n <= 2 * kStedcCap && tridiag_fits(n)) {
         const unsigned nts = (unsigned)((n + 31) / 32);
         hipLaunchKernelGGL(symmetrize_tiles, dim3(nts, nts), dim3(kBlock), 0, fz.ctx->stream, A, n, 0);
         return eigh_tridiag(fz, A, n, w_d);

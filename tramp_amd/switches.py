@@ -32,7 +32,7 @@ SWITCHES = {
     # factorisation (csrc/factorize.hip)
     "TRAMP_EIG_CAP": ("46336", "tune", "largest symmetric eigenproblem handed to rocSOLVER syevd whole; above it the spectral split"),
     "TRAMP_EIG_SUBCAP": ("16384", "tune", "halves of a forced split are split again down to this size"),
-    "TRAMP_EIG_METHOD": ("tridiag", "select", "tridiag: symmetric eigenproblems of order 64 .. 92672 go through the own tridiagonalisation (csrc/tridiag_eig.h), rocSOLVER stedc on the tridiagonal matrix (one Cuppen merge of two halves above 46336) and the blocked back-transformation, memory permitting; split: rocSOLVER syevd below TRAMP_EIG_CAP, spectral divide and conquer above (rounds 2-5, and the fallback)"),
+    "TRAMP_EIG_METHOD": ("auto", "select", "auto: symmetric eigenproblems of order 6144 .. 92672 go through the own tridiagonalisation (csrc/tridiag_eig.h), rocSOLVER stedc on the tridiagonal matrix (one Cuppen merge of two halves above 46336) and the blocked back-transformation, memory permitting, the others through `split`; tridiag: the same from order 64 on; split: rocSOLVER syevd below TRAMP_EIG_CAP, spectral divide and conquer above (rounds 2-5)"),
     "TRAMP_TD_BT_PANEL": ("2048", "tune", "reflectors per panel of the tridiagonal path's back-transformation (32 .. 8192)"),
     "TRAMP_TD_MERGE_DENSE": (None, "debug", "set: the merge of the tridiagonal path forms the dense basis blockdiag(Q1, Q2) even when no deflation rotation pairs columns of the two halves (the fallback, reachable in tests)"),
     "TRAMP_TD_MERGE_ABOVE": (None, "debug", "order above which the tridiagonal path merges two stedc halves although one stedc call would do (tests reach the merge at small orders)"),
