@@ -359,6 +359,10 @@ int main(int argc, char** argv) {
       time("C 512x256 G=4 occ2", [&] { hipLaunchKernelGGL((symvC<8, 4, 2>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true);
       time("C 512x256 G=4 occ3", [&] { hipLaunchKernelGGL((symvC<8, 4, 3>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true);
       time("C 512x256 G=2 occ4", [&] { hipLaunchKernelGGL((symvC<8, 2, 4>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true); }
+    mode = 4;
+    { const unsigned nbr = (unsigned)((m + 1023) / 1024);
+      const dim3 g(2 * nbr * (nbr + 1));
+      time("C 1024x256 G=2 occ2", [&] { hipLaunchKernelGGL((symvC<16, 2, 2>), g, dim3(256), 0, 0, At, n, m, vv, rp, cp); }, true); }
     mode = 1;
     { const unsigned nbr = (unsigned)((m + 255) / 256);
       const dim3 g(nbr * (nbr + 1) / 2);
