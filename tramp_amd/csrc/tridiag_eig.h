@@ -499,10 +499,10 @@ __global__ void td_gather_z(const double* __restrict__ C1, size_t n1, const doub
 __global__ void td_build_q0(const double* __restrict__ C1, size_t n1, const double* __restrict__ C2, size_t n2,
                             const unsigned* __restrict__ src, double* __restrict__ Q0) {
     const size_t n = n1 + n2;
-    const size_t t = blockIdx.y;
+    const size_t t = blockIdx.x;                              // grid: x = column (beyond 65 535), y = row chunk
     const unsigned s = src[t];
     double* out = Q0 + t * n;
-    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) {
+    for (size_t r = (size_t)blockIdx.y * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.y * kBlock) {
         double v = 0.0;
         if (s < n1) v = (r < n1) ? C1[r + (size_t)s * n1] : 0.0;
         else v = (r >= n1) ? C2[(r - n1) + (size_t)(s - n1) * n2] : 0.0;
@@ -521,10 +521,10 @@ __global__ void td_rotate_cols(double* __restrict__ Q, size_t n, size_t p, size_
 
 // dst[:, t] = src[:, idx[t]]  for t < count
 __global__ void td_gather_cols(const double* __restrict__ src, size_t n, const unsigned* __restrict__ idx, double* __restrict__ dst) {
-    const size_t t = blockIdx.y;
+    const size_t t = blockIdx.x;                              // grid: x = column (beyond 65 535), y = row chunk
     const double* in = src + (size_t)idx[t] * n;
     double* out = dst + t * n;
-    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) out[r] = in[r];
+    for (size_t r = (size_t)blockIdx.y * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.y * kBlock) out[r] = in[r];
 }
 
 // one wave per root: (org, mu) of root i of 1 + rho sum_j z2_j / (d_j - lam), d ascending, k poles
@@ -618,10 +618,10 @@ __global__ __launch_bounds__(256) void td_secular_vectors(const double* __restri
 __global__ void td_scatter_half_cols(const double* __restrict__ C1, size_t n1, const double* __restrict__ C2, size_t n2,
                                      const unsigned* __restrict__ src, const unsigned* __restrict__ pos, double* __restrict__ OUT) {
     const size_t n = n1 + n2;
-    const size_t t = blockIdx.y;
+    const size_t t = blockIdx.x;                              // grid: x = column (beyond 65 535), y = row chunk
     const unsigned s = src[t];
     double* out = OUT + (size_t)pos[t] * n;
-    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) {
+    for (size_t r = (size_t)blockIdx.y * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.y * kBlock) {
         double v = 0.0;
         if (s < n1) v = (r < n1) ? C1[r + (size_t)s * n1] : 0.0;
         else v = (r >= n1) ? C2[(r - n1) + (size_t)(s - n1) * n2] : 0.0;
@@ -632,10 +632,10 @@ __global__ void td_scatter_half_cols(const double* __restrict__ C1, size_t n1, c
 // dst[:, pos[t]] = src[:, idx[t]]
 __global__ void td_scatter_cols(const double* __restrict__ src, size_t n, const unsigned* __restrict__ idx,
                                 const unsigned* __restrict__ pos, double* __restrict__ dst) {
-    const size_t t = blockIdx.y;
+    const size_t t = blockIdx.x;                              // grid: x = column (beyond 65 535), y = row chunk
     const double* in = src + (size_t)idx[t] * n;
     double* out = dst + (size_t)pos[t] * n;
-    for (size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.x * kBlock) out[r] = in[r];
+    for (size_t r = (size_t)blockIdx.y * kBlock + threadIdx.x; r < n; r += (size_t)gridDim.y * kBlock) out[r] = in[r];
 }
 
 __global__ void td_roots_to_lambda(const double* __restrict__ d, const unsigned* __restrict__ org, const double* __restrict__ mu,
@@ -746,7 +746,7 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
         Q0 = fz.alloc(n * n);                                 // blockdiag(C1, C2) with its columns in the sorted order
         if (!Q0) return fz.rc;
         FZ_HIP(fz, hipMemcpyAsync(idx_d, order.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(td_build_q0, dim3(64, (unsigned)n), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d, Q0);
+        hipLaunchKernelGGL(td_build_q0, dim3((unsigned)n, 64), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d, Q0);
         FZ_HIP(fz, hipStreamSynchronize(st));
         fz.release(C1);
         fz.release(C2);
@@ -800,7 +800,7 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
             double* QL = fz.alloc(n * k);
             if (!QL) return fz.rc;
             FZ_HIP(fz, hipMemcpyAsync(idx_d, live.data(), k * sizeof(unsigned), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(td_gather_cols, dim3(64, (unsigned)k), dim3(kBlock), 0, st, Q0, n, idx_d, QL);
+            hipLaunchKernelGGL(td_gather_cols, dim3((unsigned)k, 64), dim3(kBlock), 0, st, Q0, n, idx_d, QL);
             FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, n, k, k, 1.0, QL, n, V, k, 0.0, R, n));
             FZ_HIP(fz, hipStreamSynchronize(st));
             fz.release(QL);
@@ -818,7 +818,7 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
                 }
                 for (size_t r = 0; r < kh; ++r) cols[r] = order[live[g[r]]] - (half ? (unsigned)n1 : 0u);
                 FZ_HIP(fz, hipMemcpyAsync(idx_d, cols.data(), kh * sizeof(unsigned), hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(td_gather_cols, dim3(64, (unsigned)kh), dim3(kBlock), 0, st, half ? C2 : C1, nh, idx_d, CL);
+                hipLaunchKernelGGL(td_gather_cols, dim3((unsigned)kh, 64), dim3(kBlock), 0, st, half ? C2 : C1, nh, idx_d, CL);
                 FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, nh, k, kh, 1.0, CL, nh, V + (half ? k1 : 0), k, 0.0, Rh, n));
                 FZ_HIP(fz, hipStreamSynchronize(st));          // idx_d and CL are reused by the other half
             }
@@ -859,15 +859,15 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
     };
     if (!from_r_idx.empty()) {
         FZ_OK(upload(from_r_idx, from_r_pos));
-        hipLaunchKernelGGL(td_scatter_cols, dim3(64, (unsigned)from_r_idx.size()), dim3(kBlock), 0, st, R, n, idx_d, pos_d, OUT);
+        hipLaunchKernelGGL(td_scatter_cols, dim3((unsigned)from_r_idx.size(), 64), dim3(kBlock), 0, st, R, n, idx_d, pos_d, OUT);
         FZ_HIP(fz, hipStreamSynchronize(st));
     }
     if (!from_q_idx.empty()) {
         FZ_OK(upload(from_q_idx, from_q_pos));
         if (dense)
-            hipLaunchKernelGGL(td_scatter_cols, dim3(64, (unsigned)from_q_idx.size()), dim3(kBlock), 0, st, Q0, n, idx_d, pos_d, OUT);
+            hipLaunchKernelGGL(td_scatter_cols, dim3((unsigned)from_q_idx.size(), 64), dim3(kBlock), 0, st, Q0, n, idx_d, pos_d, OUT);
         else
-            hipLaunchKernelGGL(td_scatter_half_cols, dim3(64, (unsigned)from_q_idx.size()), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d,
+            hipLaunchKernelGGL(td_scatter_half_cols, dim3((unsigned)from_q_idx.size(), 64), dim3(kBlock), 0, st, C1, n1, C2, n2, idx_d,
                                pos_d, OUT);
         FZ_HIP(fz, hipStreamSynchronize(st));
     }
