@@ -88,6 +88,14 @@ def golden_tree():
 
 
 @pytest.fixture(scope="session")
+def golden_models2():
+    "tools/make_golden_models2.py: the remaining total-variation / classification model builders, Marchenko-Pastur transforms"
+    path = os.path.join(GOLDEN, "models2.npz")
+    with np.load(path, allow_pickle=True) as f:
+        return dict(models=list(f["models"]), mp=list(f["mp"]))
+
+
+@pytest.fixture(scope="session")
 def golden_diag():
     return load_golden("diag")
 

@@ -1,0 +1,68 @@
+"""Host-side pieces completed in round 6 (no GPU): every ensemble of the reference's registry (tramp/ensembles/__init__.py:11-21),
+the Marchenko-Pastur transforms against values computed by the reference (tests/golden/models2.npz), and the structure of the
+remaining total-variation model builders (tramp/models/total_variation_model.py:59-92) - the graphs only, nothing is computed."""
+import numpy as np
+import pytest
+
+
+def test_ensemble_registry_matches_the_reference():
+    from tramp_amd import ensembles as E
+    assert set(E.ENSEMBLE_CLASSES) >= {"gaussian", "complex_gaussian", "rotation", "unitary", "binary", "ternary", "marchenko",
+                                       "random_feature", "complex_unitary"}
+    np.random.seed(3)
+    M, N = 300, 400
+    X = E.get_ensemble("binary", M=M, N=N, p_pos=0.3).generate()
+    assert X.shape == (M, N) and set(np.unique(X * np.sqrt(N)).round(12)) == {-1.0, 1.0}
+    assert abs((X > 0).mean() - 0.3) < 0.01
+    X = E.get_ensemble("ternary", M=M, N=N, p_pos=0.2, p_neg=0.5).generate()
+    assert set(np.unique(X * np.sqrt(N)).round(12)) == {-1.0, 0.0, 1.0}
+    assert abs((X > 0).mean() - 0.2) < 0.01 and abs((X < 0).mean() - 0.5) < 0.01
+    R = E.get_ensemble("rotation", N=17).generate()
+    np.testing.assert_allclose(R @ R.T, np.eye(17), atol=1e-12)
+    assert np.linalg.det(R) == pytest.approx(1.0, abs=1e-10)
+    U = E.get_ensemble("unitary", N=9).generate()
+    np.testing.assert_allclose(U @ U.conj().T, np.eye(9), atol=1e-12)
+    X = E.get_ensemble("complex_unitary", M=7, N=11).generate()
+    np.testing.assert_allclose(np.abs(X), 1.0, atol=1e-14)
+    X = E.get_ensemble("random_feature", M=200, N=300, f="relu_zero_mean").generate()
+    assert X.shape == (200, 300) and abs(X.mean() * np.sqrt(300)) < 0.02          # the activation is centred under N(0, 1)
+    with pytest.raises(KeyError):
+        E.get_ensemble("random_feature", M=2, N=3, f="nope")
+    X = E.get_ensemble("complex_gaussian", M=200, N=300).generate()
+    assert np.iscomplexobj(X) and abs(X.real.var() * 300 - 1) < 0.05 and abs(X.imag.var() * 300 - 1) < 0.05
+
+
+def test_marchenko_pastur_transforms_match_the_reference(golden_models2):
+    from tramp_amd.ensembles import MarchenkoPasturEnsemble
+    for c in golden_models2["mp"]:
+        ens = MarchenkoPasturEnsemble(alpha=c["alpha"])
+        assert ens.z_min == pytest.approx(c["z_min"], rel=1e-14) and ens.z_max == pytest.approx(c["z_max"], rel=1e-14)
+        assert ens.mean_spectrum == pytest.approx(c["mean_spectrum"], rel=1e-12)
+        assert ens.eta_transform(c["gamma"]) == pytest.approx(c["eta"], rel=1e-13)
+        assert ens.shannon_transform(c["gamma"]) == pytest.approx(c["shannon"], rel=1e-13, abs=1e-15)
+        assert ens.measure(lambda z: z * z) == pytest.approx(c["measure_sq"], rel=1e-10)
+        # the Shannon transform is the measure of log(1 + gamma z) (Tulino & Verdu), up to the alpha normalisation the class uses
+        if c["alpha"] <= 1:
+            direct = ens.measure(lambda z: np.log1p(c["gamma"] * z))
+            assert ens.shannon_transform(c["gamma"]) == pytest.approx(direct, rel=1e-6, abs=1e-9)
+
+
+class _NoDevice:
+    "a context stand-in: the model builders only construct factor objects here, nothing is launched"
+
+
+@pytest.mark.parametrize("builder,kw", [("sparse_gradient_regression", dict(grad_rho=0.1)),
+                                        ("sparse_gradient_classification", dict(grad_rho=0.1)),
+                                        ("tv_regression", dict(grad_scale=0.5)), ("tv_classification", dict(grad_scale=0.5))])
+def test_total_variation_builders_exist_with_the_reference_signatures(builder, kw):
+    import inspect
+    import tramp_amd as T
+    sig = inspect.signature(getattr(T, builder))
+    names = list(sig.parameters)
+    assert names[:3] == ["A", "y", "x_shape"] and names[3] == list(kw)[0] and names[4:6] == ["noise_var", "prior_var"]
+
+
+def test_factor_model_rejects_what_the_reference_rejects():
+    import tramp_amd as T
+    with pytest.raises(TypeError):
+        T.FactorModel("not a dag")

@@ -23,7 +23,10 @@ from .channels import (LinearChannel, SolveLinearChannel, ComplexLinearChannel, 
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
 from .variables import SISOVariable, SILeafVariable, SIMOVariable, MISOVariable, MILeafVariable
 from .models import (Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution,
-                     sparse_gradient_regression, committee, soft_committee, sgn_committee)
+                     sparse_gradient_regression, sparse_gradient_classification, tv_regression, tv_classification,
+                     FactorModel, committee, soft_committee, sgn_committee)
+from .ensembles import (GaussianEnsemble, ComplexGaussianEnsemble, MarchenkoPasturEnsemble, BinaryEnsemble, TernaryEnsemble,
+                        RotationEnsemble, UnitaryEnsemble, ComplexUnitaryEnsemble, RandomFeatureEnsemble, get_ensemble)
 from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, EarlyStopping,
                     ConstantInit, CustomInit, NoisyInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
                     TrackEstimate, TrackMessages, TrackObjective, TrackOverlaps, LogProgress)

@@ -334,7 +334,7 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
     const unsigned nbt_max = (unsigned)((n + kTdTile - 1) / kTdTile);
     double* W = fz.alloc(n * kTdNb);
     double* row_part = fz.alloc((size_t)nbt_max * n);
-    double* col_part = fz.alloc((size_t)nbt_max * n);
+    double* col_part = fz.alloc((size_t)((n + kTdRows - 1) / kTdRows) * n);
     double* tmp = fz.alloc(2 * kTdNb);
     double* dots = fz.alloc(nbt_max + 1);
     double* wpre = fz.alloc(n);
@@ -397,6 +397,7 @@ int td_sytrd_lower(Fz& fz, double* A, size_t n, double* d, double* e, double* ta
         fprintf(stderr, "[tramp tridiag] n=%zu (synchronised launches): column step %.3f s, symv + panel dots %.3f, w_form %.3f, "
                         "w_finish + syr2k %.3f\n", n, tacc[0], tacc[1], tacc[2], tacc[3]);
     hipLaunchKernelGGL(get_diag_last, dim3(1), dim3(1), 0, st, A, n, d);
+    FZ_HIP(fz, hipGetLastError());                            // a launch that failed anywhere in the reduction
     fz.release(W);
     fz.release(row_part);
     fz.release(col_part);
@@ -464,6 +465,7 @@ int td_backtransform(Fz& fz, const double* A, size_t n, const double* tau_d, dou
                                 (rocblas_int)pb, (rocblas_int)ncols, &one, S, (rocblas_int)pb, W1, (rocblas_int)pb));
         FZ_OK(bgemm(fz, rocblas_operation_none, rocblas_operation_none, mp, ncols, pb, -1.0, Vp, mp, W1, pb, 1.0, C + i + 1, n));
     }
+    FZ_HIP(fz, hipGetLastError());
     FZ_HIP(fz, hipStreamSynchronize(st));
     fz.release(Vp);
     fz.release(S);
@@ -872,6 +874,7 @@ int td_stedc_merge(Fz& fz, size_t n, std::vector<double>& hd, std::vector<double
         FZ_HIP(fz, hipStreamSynchronize(st));
     }
     FZ_HIP(fz, hipMemcpyAsync(w_d, w.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    FZ_HIP(fz, hipGetLastError());
     FZ_HIP(fz, hipStreamSynchronize(st));
     if (R) fz.release(R);
     if (Q0) fz.release(Q0);

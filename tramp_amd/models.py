@@ -274,22 +274,85 @@ def glm_state_evolution(alpha, prior_type, output_type, **kwargs):
     return (prior @ SISOVariable(id="x") @ linear @ SISOVariable(id="z") @ output).to_model()
 
 
-def sparse_gradient_regression(A, y, x_shape, grad_rho, noise_var, prior_var=1.0, dtype=np.float64, ctx=None):
-    """tramp/models/total_variation_model.py:12-25,43-48,67-71: a signal with a Gauss-Bernoulli prior on its
-    gradient (variable "x'" with two parents: the gradient channel and that prior), observed through the
-    dense matrix A with Gaussian noise.  y: [M] or [instances, M]."""
+def _gradient_block(x_shape, prior_var, grad_prior, kw):
+    """tramp/models/total_variation_model.py:12-40: a signal x with a Gaussian prior whose gradient field x' has a second
+    parent, the prior ``grad_prior`` (variable "x'" with two parents), flattened for the dense channel that follows."""
     from .channels import GradientChannel, ReshapeChannel
-    from .priors import GaussianPrior, GaussBernoulliPrior
+    from .priors import GaussianPrior
     from .variables import SIMOVariable, MILeafVariable
-    x_shape = tuple(x_shape)
-    d, N = len(x_shape), int(np.prod(x_shape))
-    kw = dict(dtype=dtype, ctx=ctx)
-    block = (GaussianPrior(size=x_shape, var=prior_var, **kw) @ SIMOVariable(id="x", n_next=2) @ (
-        (GradientChannel(shape=x_shape, **kw) + GaussBernoulliPrior(size=(d,) + x_shape, rho=grad_rho, **kw))
-        @ MILeafVariable(id="x'", n_prev=2))) @ ReshapeChannel(prev_shape=x_shape, next_shape=N, **kw)
+    N = int(np.prod(x_shape))
+    return (GaussianPrior(size=x_shape, var=prior_var, **kw) @ SIMOVariable(id="x", n_next=2) @ (
+        (GradientChannel(shape=x_shape, **kw) + grad_prior) @ MILeafVariable(id="x'", n_prev=2))
+    ) @ ReshapeChannel(prev_shape=x_shape, next_shape=N, **kw)
+
+
+def _sparse_gradient_block(x_shape, prior_var, grad_rho, kw):
+    "total_variation_model.py:12-25: Gauss-Bernoulli prior on the gradient"
+    from .priors import GaussBernoulliPrior
+    return _gradient_block(x_shape, prior_var, GaussBernoulliPrior(size=(len(x_shape),) + x_shape, rho=grad_rho, **kw), kw)
+
+
+def _tv_block(x_shape, prior_var, grad_scale, kw):
+    """total_variation_model.py:28-40: the group penalty MAP_L21NormPrior(axis=0) on the gradient.  (The reference passes
+    ``scale=grad_scale`` to a constructor whose argument is ``gamma`` - map_L21_norm_prior.py:41 - and raises; this is the
+    model its docstrings describe.)"""
+    from .priors import MAP_L21NormPrior
+    return _gradient_block(x_shape, prior_var, MAP_L21NormPrior(size=(len(x_shape),) + x_shape, gamma=grad_scale, axis=0, **kw), kw)
+
+
+def _regression_block(A, y, noise_var, kw):
+    "total_variation_model.py:43-48"
     lin = A if isinstance(A, LinearChannel) else LinearChannel(A, name="A", **kw)
-    return (block @ SISOVariable(id="r") @ lin @ SISOVariable(id="z")
-            @ GaussianLikelihood(y=y, var=noise_var, **kw)).to_model()
+    return DAG([lin, SISOVariable(id="z"), GaussianLikelihood(y=y, var=noise_var, **kw)])
+
+
+def _classification_block(A, y, noise_var, kw):
+    "total_variation_model.py:51-56: noisy sign observations, the noise as a hidden GaussianChannel"
+    from .channels import GaussianChannel
+    from .likelihoods import SgnLikelihood
+    lin = A if isinstance(A, LinearChannel) else LinearChannel(A, name="A", **kw)
+    return DAG([lin, SISOVariable(id="z"), GaussianChannel(var=noise_var, **kw), SISOVariable(id="a"), SgnLikelihood(y=y, **kw)])
+
+
+def sparse_gradient_regression(A, y, x_shape, grad_rho, noise_var, prior_var=1.0, dtype=np.float64, ctx=None):
+    """tramp/models/total_variation_model.py:59-63: a signal with a Gauss-Bernoulli prior on its gradient, observed
+    through the dense matrix A with Gaussian noise.  y: [M] or [instances, M]."""
+    kw = dict(dtype=dtype, ctx=ctx)
+    return (_sparse_gradient_block(tuple(x_shape), prior_var, grad_rho, kw) @ SISOVariable(id="r")
+            @ _regression_block(A, y, noise_var, kw)).to_model()
+
+
+def sparse_gradient_classification(A, y, x_shape, grad_rho, noise_var, prior_var=1.0, dtype=np.float64, ctx=None):
+    "total_variation_model.py:66-70: the same signal model under noisy sign observations y = sgn(A x + noise)"
+    kw = dict(dtype=dtype, ctx=ctx)
+    return (_sparse_gradient_block(tuple(x_shape), prior_var, grad_rho, kw) @ SISOVariable(id="r")
+            @ _classification_block(A, y, noise_var, kw)).to_model()
+
+
+def tv_regression(A, y, x_shape, grad_scale, noise_var, prior_var=1.0, dtype=np.float64, ctx=None):
+    "total_variation_model.py:73-77: total-variation (group-L21) penalty on the gradient, Gaussian observations"
+    kw = dict(dtype=dtype, ctx=ctx)
+    return (_tv_block(tuple(x_shape), prior_var, grad_scale, kw) @ SISOVariable(id="r")
+            @ _regression_block(A, y, noise_var, kw)).to_model()
+
+
+def tv_classification(A, y, x_shape, grad_scale, noise_var, prior_var=1.0, dtype=np.float64, ctx=None):
+    "total_variation_model.py:80-84: total-variation penalty, noisy sign observations"
+    kw = dict(dtype=dtype, ctx=ctx)
+    return (_tv_block(tuple(x_shape), prior_var, grad_scale, kw) @ SISOVariable(id="r")
+            @ _classification_block(A, y, noise_var, kw)).to_model()
+
+
+class FactorModel(Model):
+    """tramp/models/factor_model.py:5-13: a model from a factor DAG whose roots are all priors."""
+
+    def __init__(self, factor_dag):
+        if not isinstance(factor_dag, DAG):
+            raise TypeError(f"factor_dag {factor_dag} is not a FactorDAG")
+        if factor_dag.ins:
+            raise ValueError(f"{len(factor_dag.ins)} root node(s) not a prior")
+        self.factor_dag = factor_dag
+        Model.__init__(self, factor_dag)
 
 
 def committee(K, N, alpha, ensemble_type, priors, activation1, activation2, noise_var, dtype=np.float64, ctx=None):
