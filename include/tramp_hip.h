@@ -699,6 +699,12 @@ int tramp_sum_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k,
                       const double* const* az_d, const void* const* bz_d,
                       const double* ax_d, const void* bx_d, int target, double damping,
                       const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d);
+/* DuplicateChannel x_1 = ... = x_K = z (tramp/channels/shape/duplicate_channel.py:24-31), K <= 8: ax_d / bx_d are host
+ * arrays of K device pointers (the messages x_k -> factor), (az, bz) the message z -> factor.  target = -1: backward
+ * message to z; target = k: forward message to x_k.  Constant damping fused (old may alias new). */
+int tramp_duplicate_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k, const double* az_d,
+                            const void* bz_d, const double* const* ax_d, const void* const* bx_d, int target,
+                            double damping, const double* a_old_d, const void* b_old_d, double* a_new_d, void* b_new_d);
 /* Variable.forward_message / backward_message on a tree (tramp/base.py:186-211): out = sum of the k
  * incoming messages (host arrays of k device pointers, k <= 8) minus message `exclude` (the target's own;
  * -1: plain sum = Variable.posterior_ab, base.py:152-155). */

@@ -2641,3 +2641,24 @@ class ComplexLinearFactor(OracleFactor):
 
     def backward(self, az, bz, ax, bx):
         return self.lin.backward_message(az, bz, ax, bx)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DuplicateChannel x_1 = ... = x_K = z (tramp/channels/shape/duplicate_channel.py:24-31; the messages through
+# base_channel.py:102-105 and base.py:250-255, 329-365).  Test infrastructure like the rest of this file.
+def duplicate_posterior(az, bz, ax, bx):
+    a = az + sum(ax)
+    b = bz + sum(bx)
+    return b / a, 1.0 / a
+
+
+def duplicate_backward_message(az, bz, ax, bx):
+    r, v = duplicate_posterior(az, bz, ax, bx)
+    return ab_new(r, v, az, bz)
+
+
+def duplicate_forward_message(az, bz, ax, bx):
+    "one message per output: compute_ab_new(rz, vz, ax_k, bx_k)"
+    r, v = duplicate_posterior(az, bz, ax, bx)
+    outs = [ab_new(r, v, a, b) for a, b in zip(ax, bx)]
+    return [o[0] for o in outs], [o[1] for o in outs]

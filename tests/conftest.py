@@ -92,7 +92,7 @@ def golden_models2():
     "tools/make_golden_models2.py: the remaining total-variation / classification model builders, Marchenko-Pastur transforms"
     path = os.path.join(GOLDEN, "models2.npz")
     with np.load(path, allow_pickle=True) as f:
-        return dict(models=list(f["models"]), mp=list(f["mp"]))
+        return dict(models=list(f["models"]), mp=list(f["mp"]), dup_fn=list(f["dup_fn"]), dup_ep=list(f["dup_ep"]))
 
 
 @pytest.fixture(scope="session")

@@ -66,3 +66,19 @@ def test_factor_model_rejects_what_the_reference_rejects():
     import tramp_amd as T
     with pytest.raises(TypeError):
         T.FactorModel("not a dag")
+
+
+def test_duplicate_channel_oracle_matches_the_reference(golden_models2):
+    "oracle/tramp_oracle.py's restatement of DuplicateChannel against the vectors computed by the reference"
+    from oracle import tramp_oracle as orc
+    for c in golden_models2["dup_fn"]:
+        r, v = orc.duplicate_posterior(c["az"], c["bz"], c["ax"], c["bx"])
+        np.testing.assert_allclose(r, c["rz"], rtol=1e-14)
+        assert v == pytest.approx(c["vz"], rel=1e-14) and v == pytest.approx(c["v_bwd_err"], rel=1e-14)
+        a, b = orc.duplicate_backward_message(c["az"], c["bz"], c["ax"], c["bx"])
+        assert a == pytest.approx(c["a_bwd"], rel=1e-13)
+        np.testing.assert_allclose(b, c["b_bwd"], rtol=1e-12, atol=1e-13)
+        fa, fb = orc.duplicate_forward_message(c["az"], c["bz"], c["ax"], c["bx"])
+        for k in range(c["K"]):
+            assert fa[k] == pytest.approx(c["a_fwd"][k], rel=1e-13)
+            np.testing.assert_allclose(fb[k], c["b_fwd"][k], rtol=1e-12, atol=1e-13)

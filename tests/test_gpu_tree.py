@@ -743,3 +743,123 @@ def test_remaining_total_variation_models_match_reference(ctx, golden_models2, w
                 else:
                     close(np.ravel(val), np.ravel(ref), 1e-5, 1e-6 * max(1.0, float(np.abs(ref).max())))
         close(iters[-1]["r:x"], np.ravel(e["final_r"]), 1e-4, 1e-5 * max(1.0, float(np.abs(e["final_r"]).max())))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_duplicate_channel_matches_reference(ctx, golden_models2, dtype):
+    "DuplicateChannel (channels/shape/duplicate_channel.py): posterior, the backward message, the K forward messages; damping; ensembles"
+    import tramp_amd as T
+    rt = 1e-12 if dtype == np.float64 else 3e-6
+    for c in golden_models2["dup_fn"]:
+        K = c["K"]
+        ch = T.DuplicateChannel(n_next=K, dtype=dtype, ctx=ctx)
+        sc = max(1.0, float(np.abs(c["bz"]).max()))
+        a, b = ch.compute_backward_message(c["az"], c["bz"], c["ax"], c["bx"])
+        close(a, c["a_bwd"], max(rt, 1e-12))
+        close(b, c["b_bwd"], rt * 10, rt * 10 * sc)
+        fa, fb = ch.compute_forward_message(c["az"], c["bz"], c["ax"], c["bx"])
+        for k in range(K):
+            close(fa[k], c["a_fwd"][k], max(rt, 1e-12))
+            close(fb[k], c["b_fwd"][k], rt * 10, rt * 10 * sc)
+            a1, b1 = ch.compute_forward_message(c["az"], c["bz"], c["ax"], c["bx"], target=k)
+            assert np.array_equal(b1, fb[k]) and a1 == fa[k]
+        r, v = ch.compute_backward_posterior(c["az"], c["bz"], c["ax"], c["bx"])
+        close(r, c["rz"], rt * 10, rt * 10)
+        close(v, c["vz"], max(rt, 1e-12))
+        assert ch.compute_backward_error(c["az"], c["ax"], 1.0) == pytest.approx(c["v_bwd_err"], rel=1e-14)
+        assert ch.second_moment(0.7) == (0.7,) * K and len(ch.sample(c["bz"])) == K
+    # an ensemble of instances with per-instance precisions, and fused damping, against the oracle
+    rs = np.random.RandomState(5)
+    B, n, K = 3, 257, 3
+    ch = T.DuplicateChannel(n_next=K, dtype=dtype, ctx=ctx)
+    az, bz = rs.uniform(0.5, 2, B), rs.standard_normal((B, n))
+    ax, bx = [rs.uniform(0.2, 3, B) for _ in range(K)], [rs.standard_normal((B, n)) for _ in range(K)]
+    a, b = ch.compute_backward_message(az, bz, ax, bx)
+    for i in range(B):
+        wa, wb = orc.duplicate_backward_message(az[i], bz[i], [q[i] for q in ax], [q[i] for q in bx])
+        close(a[i], wa, max(rt, 1e-12))
+        close(b[i], wb, rt * 10, rt * 40)
+    if dtype == np.float64:
+        old_a, old_b = ctx.array(rs.uniform(0.5, 1, B), np.float64), ctx.array(rs.standard_normal((B, n)), np.float64)
+        oa, ob = old_a.get(), old_b.get()
+        out_a, out_b = ctx.empty((B,), np.float64), ctx.empty((B, n), np.float64)
+        ch.compute_forward_message(ctx.array(az, np.float64), ctx.array(bz, np.float64), [ctx.array(q, np.float64) for q in ax],
+                                   [ctx.array(q, np.float64) for q in bx], target=1, damping=0.3, old_a=old_a, old_b=old_b,
+                                   out_a=out_a, out_b=out_b)
+        for i in range(B):
+            fa, fb = orc.duplicate_forward_message(az[i], bz[i], [q[i] for q in ax], [q[i] for q in bx])
+            close(out_a.get()[i], 0.3 * oa[i] + 0.7 * fa[1], 1e-12)
+            close(out_b.get()[i], 0.3 * ob[i] + 0.7 * fb[1], 1e-11, 1e-12)
+    with pytest.raises(ValueError):
+        ch.compute_backward_message(1.0, bz[0], ax[:2], bx[:2])
+
+
+def test_duplicate_channel_ep_matches_reference(ctx, golden_models2):
+    """A signal observed twice - through Gaussian noise and through a dense matrix - behind a DuplicateChannel (the one factor with
+    several outputs): every message and posterior of every iteration of the reference's EP, the stopping iteration, and the
+    same model with the SIMO variable that does the same job."""
+    import tramp_amd as T
+    from tramp_amd.base import Variable
+    from tramp_amd.variables import SIMOVariable
+    for e in golden_models2["dup_ep"]:
+        N = e["N"]
+        model = (T.GaussBernoulliPrior(size=N, rho=e["rho"], ctx=ctx) @ T.SISOVariable(id="z") @ T.DuplicateChannel(n_next=2, ctx=ctx) @ (
+            T.SISOVariable(id="x1") @ T.GaussianLikelihood(y=e["y1"], var=e["nv1"], ctx=ctx)
+            + T.SISOVariable(id="x2") @ T.LinearChannel(e["A"], name="A", ctx=ctx) @ T.SISOVariable(id="w")
+            @ T.GaussianLikelihood(y=e["y2"], var=e["nv2"], ctx=ctx))).to_model()
+        assert not model.is_chain
+        ep = T.ExpectationPropagation(model, ctx=ctx)
+        iters = []
+
+        class Rec(T.EarlyStoppingEP):
+            def __call__(self, algo, i, max_iter):
+                rec = {}
+                for (src, dst) in algo.msg:
+                    key = f"{src.id if isinstance(src, Variable) else type(src).__name__}->" \
+                          f"{dst.id if isinstance(dst, Variable) else type(dst).__name__}"
+                    rec[key + ":a"], rec[key + ":b"] = algo.get_message(src, dst)
+                for vid, d in algo.get_variables_data().items():
+                    rec["r:" + vid], rec["v:" + vid] = np.array(d["r"]), np.array(d["v"])
+                iters.append(rec)
+                return super().__call__(algo, i, max_iter)
+        ep.iterate(max_iter=30, callback=Rec(), damping=e["damping"])
+        assert ep.n_iter == e["n_iter"]
+        tr = e["traj"]
+        # two GaussianLikelihood factors share a class name in the recorder's keys: compare the keys that are unambiguous
+        amb = [k for k in tr if "GaussianLikelihood" in k]
+        for it, got in enumerate(iters[:len(tr["v:z"])]):
+            for key, val in got.items():
+                if key in amb:
+                    continue
+                ref = np.asarray(tr[key][it], dtype=float)
+                if ("->" in key and key.endswith(":a")) or key.startswith("v:"):
+                    close(np.ravel(val)[0], ref, 1e-7)
+                else:
+                    close(np.ravel(val), np.ravel(ref), 1e-6, 1e-7 * max(1.0, float(np.abs(ref).max())))
+        close(iters[-1]["r:z"], e["final_r"], 1e-5, 1e-6)
+        assert np.mean((iters[-1]["r:z"] - e["x"]) ** 2) < np.mean((e["y1"] - e["x"]) ** 2)
+        # the same posterior from a variable with two children (what the reference's docs recommend instead)
+        m2 = (T.GaussBernoulliPrior(size=N, rho=e["rho"], ctx=ctx) @ SIMOVariable(id="z", n_next=2) @ (
+            T.GaussianLikelihood(y=e["y1"], var=e["nv1"], ctx=ctx)
+            + T.LinearChannel(e["A"], name="A", ctx=ctx) @ T.SISOVariable(id="w")
+            @ T.GaussianLikelihood(y=e["y2"], var=e["nv2"], ctx=ctx))).to_model()
+        ep2 = T.ExpectationPropagation(m2, ctx=ctx).iterate(max_iter=200, damping=e["damping"], callback=T.EarlyStoppingEP(tol=1e-10))
+        ep1 = T.ExpectationPropagation(model, ctx=ctx).iterate(max_iter=200, damping=e["damping"], callback=T.EarlyStoppingEP(tol=1e-10))
+        close(ep1.get_variable_data("z")["r"], ep2.get_variable_data("z")["r"], 1e-5, 1e-6)
+
+
+def test_duplicate_channel_state_evolution(ctx):
+    "SE through the K-output factor: at the fixed point the precision into z is the sum of the outputs' (duplicate_channel.py:39-42)"
+    import tramp_amd as T
+    model = (T.GaussBernoulliPrior(size=100, rho=0.2, ctx=ctx) @ T.SISOVariable(id="z") @ T.DuplicateChannel(n_next=2, ctx=ctx) @ (
+        T.SISOVariable(id="x1") @ T.GaussianLikelihood(y=None, var=0.5, ctx=ctx)
+        + T.SISOVariable(id="x2") @ T.GaussianLikelihood(y=None, var=0.25, ctx=ctx))).to_model()
+    se = T.StateEvolution(model)
+    se.iterate(max_iter=50)
+    data = se.get_variables_data()
+    # two Gaussian observations of precisions 2 and 4 are one of precision 6
+    ref = (T.GaussBernoulliPrior(size=100, rho=0.2, ctx=ctx) @ T.SISOVariable(id="z") @ T.GaussianLikelihood(y=None, var=1 / 6.0, ctx=ctx)).to_model()
+    se2 = T.StateEvolution(ref)
+    se2.iterate(max_iter=50)
+    close(data["z"]["v"], se2.get_variables_data()["z"]["v"], 1e-9)
+    close(data["x1"]["v"], data["z"]["v"], 1e-9)

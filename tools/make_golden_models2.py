@@ -5,6 +5,7 @@
   tv_regression (:81-85), tv_classification (:88-92) - built here BY HAND from the reference's factor classes, because
   the module itself cannot run (np.product is gone from NumPy 2, and tv_block passes scale= to MAP_L21NormPrior, whose
   argument is gamma): every message and posterior of every EP iteration;
+* DuplicateChannel (tramp/channels/shape/duplicate_channel.py): posterior and messages, and EP on a signal observed twice;
 * MarchenkoPasturEnsemble.eta_transform / shannon_transform / measure (tramp/ensembles/marchenko_pastur_ensemble.py:31-53).
 
 Runs ONLY in the build container (needs /root/reference); the output is data.   -> tests/golden/models2.npz
@@ -80,6 +81,45 @@ def model_cases():
     return out
 
 
+def duplicate_cases():
+    """DuplicateChannel (tramp/channels/shape/duplicate_channel.py): function level, and EP on a signal seen twice -
+    directly through Gaussian noise and through a dense matrix (every message of every iteration)."""
+    from tramp.channels import DuplicateChannel
+    rs = np.random.RandomState(23)
+    fn = []
+    for K, n in [(2, 33), (3, 17)]:
+        ch = DuplicateChannel(n_next=K)
+        az, bz = 1.3, rs.standard_normal(n) * 2
+        ax = [float(a) for a in rs.uniform(0.2, 3.0, K)]
+        bx = [rs.standard_normal(n) for _ in range(K)]
+        rz, vz = ch.compute_backward_posterior(az, bz, ax, bx)
+        ab, bb = ch.compute_backward_message(az, bz, ax, bx)
+        # the forward messages as Factor.forward_message forms them (base.py:329-346): compute_ab_new per output
+        fwd = [ch.compute_ab_new(rz, vz, a, b) for a, b in zip(ax, bx)]
+        fn.append(dict(K=K, az=az, bz=bz, ax=ax, bx=bx, rz=rz, vz=float(vz), a_bwd=float(ab), b_bwd=bb,
+                       a_fwd=[float(f[0]) for f in fwd], b_fwd=[f[1] for f in fwd],
+                       v_bwd_err=float(ch.compute_backward_error(az, ax, 1.0))))
+    eps = []
+    for N, M, rho, nv1, nv2, damping in [(40, 25, 0.2, 0.5, 0.05, None), (64, 30, 0.1, 1.0, 0.02, 0.3)]:
+        r = np.random.RandomState(41 + N)
+        x = r.standard_normal(N) * r.binomial(1, rho, N)
+        A = r.standard_normal((M, N)) / np.sqrt(N)
+        y1 = x + np.sqrt(nv1) * r.standard_normal(N)
+        y2 = A @ x + np.sqrt(nv2) * r.standard_normal(M)
+        model = (GaussBernoulliPrior(size=N, rho=rho) @ V(id="z") @ DuplicateChannel(n_next=2) @ (
+            V(id="x1") @ GaussianLikelihood(y1, var=nv1)
+            + V(id="x2") @ LinearChannel(A, name="A") @ V(id="w") @ GaussianLikelihood(y2, var=nv2))).to_model()
+        ep = ExpectationPropagation(model)
+        rec = mg.TreeRecorder(EarlyStoppingEP())
+        with np.errstate(all="ignore"):
+            ep.iterate(max_iter=30, callback=rec, damping=damping)
+        eps.append(dict(N=N, M=M, rho=rho, nv1=nv1, nv2=nv2, damping=damping, x=x, A=A, y1=y1, y2=y2, n_iter=ep.n_iter,
+                        traj=mg.pack_traj(rec.iters[:10]), final_r=rec.iters[-1]["r:z"],
+                        mse=float(np.mean((rec.iters[-1]["r:z"] - x)**2))))
+        print("duplicate ep", N, damping, "n_iter", ep.n_iter, "mse", eps[-1]["mse"], "vs y1", float(np.mean((y1 - x)**2)))
+    return fn, eps
+
+
 def mp_cases():
     out = []
     for alpha in (0.3, 0.5, 1.0, 2.5):
@@ -94,6 +134,8 @@ def mp_cases():
 if __name__ == "__main__":
     models = model_cases()
     mps = mp_cases()
+    dup_fn, dup_ep = duplicate_cases()
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "models2.npz")
-    np.savez_compressed(path, models=np.array(models, dtype=object), mp=np.array(mps, dtype=object))
+    np.savez_compressed(path, models=np.array(models, dtype=object), mp=np.array(mps, dtype=object),
+                        dup_fn=np.array(dup_fn, dtype=object), dup_ep=np.array(dup_ep, dtype=object))
     print("wrote", path, os.path.getsize(path), "bytes")

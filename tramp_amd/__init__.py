@@ -19,7 +19,7 @@ from .likelihoods import (GaussianLikelihood, SgnLikelihood, AbsLikelihood, Asym
 from .channels import (LinearChannel, SolveLinearChannel, ComplexLinearChannel, ModulusChannel, SgnChannel, AbsChannel, ReluChannel, GaussianChannel,
                        LeakyReluChannel, AsymmetricAbsChannel, HardTanhChannel, HardSigmoidChannel,
                        SymmetricDoorChannel, ConvChannel, Blur1DChannel, Blur2DChannel,
-                       DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel, ReshapeChannel, BiasChannel, SumChannel,
+                       DifferentialChannel, LaplacianChannel, DFTChannel, RotationChannel, GradientChannel, UnitaryChannel, ReshapeChannel, BiasChannel, SumChannel, DuplicateChannel,
                        MarchenkoPasturChannel, AnalyticalLinearChannel, get_channel)
 from .variables import SISOVariable, SILeafVariable, SIMOVariable, MISOVariable, MILeafVariable
 from .models import (Model, DAG, MultiLayerModel, glm_generative, glm_state_evolution,

@@ -148,6 +148,7 @@ _SIGNATURES = {
     "tramp_gauss_channel": [vp, i32, sz, sz, dbl, vp, vp, dbl, vp, vp, vp, vp],
     "tramp_bias_channel": [vp, i32, i32, sz, sz, vp, vp, vp, dbl, vp, vp, vp, vp],
     "tramp_sum_channel": [vp, i32, sz, sz, i32, C.POINTER(vp), C.POINTER(vp), vp, vp, i32, dbl, vp, vp, vp, vp],
+    "tramp_duplicate_channel": [vp, i32, sz, sz, i32, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, dbl, vp, vp, vp, vp],
     "tramp_message_sum": [vp, i32, sz, sz, i32, C.POINTER(vp), C.POINTER(vp), i32, vp, vp],
     "tramp_sq_dist": [vp, i32, sz, sz, vp, vp, vp],
     "tramp_se_gb_prior": [vp, sz, vp, vp, vp, vp, vp],

@@ -183,6 +183,79 @@ class SumChannel(Channel):
         return [o[0] for o in outs], [o[1] for o in outs]
 
 
+class DuplicateChannel(Channel):
+    """x_1 = ... = x_K = z (tramp/channels/shape/duplicate_channel.py:4-51): one input, K outputs.  ``ax``, ``bx`` are lists
+    of K messages; the forward message is the list of K messages, or the one to ``x_target``."""
+
+    n_prev = 1
+
+    def __init__(self, n_next, dtype=np.float64, ctx=None):
+        self.n_next = n_next
+        self.repr_init()
+        self._init_device(dtype, ctx)
+
+    def sample(self, Z):
+        return (Z,) * self.n_next
+
+    def second_moment(self, tau_z):
+        return (tau_z,) * self.n_next
+
+    def compute_backward_error(self, az, ax, tau_z):
+        return 1.0 / (az + sum(ax))                                           # :39-42
+
+    def compute_forward_error(self, az, ax, tau_z):
+        return [self.compute_backward_error(az, ax, tau_z)] * self.n_next     # :34-37
+
+    def compute_backward_state_evolution(self, az, ax, tau_z):
+        v = self.compute_backward_error(az, ax, tau_z)                        # base_channel.py:107-110
+        return np.clip(1.0 / v - az, 1e-11, 1e11)
+
+    def compute_forward_state_evolution(self, az, ax, tau_z):
+        v = self.compute_backward_error(az, ax, tau_z)
+        return [np.clip(1.0 / v - a, 1e-11, 1e11) for a in ax]
+
+    def _message(self, target, az, bz, ax, bx, out_a=None, out_b=None, damping=0.0, old_a=None, old_b=None):
+        ctx = self.ctx
+        if len(ax) != self.n_next or len(bx) != self.n_next:
+            raise ValueError(f"expect {self.n_next} messages")
+        z = VecArg(ctx, bz, self.dtype)
+        xs = [VecArg(ctx, b, self.dtype) for b in bx]
+        B, n = z.batch, z.n
+        if any((x.batch, x.n) != (B, n) for x in xs):
+            raise ValueError("the duplicated messages must have the shape of the input")
+        a_z = ScalArg(ctx, az, B)
+        axs = [ScalArg(ctx, a, B) for a in ax]
+        ap = (C.c_void_p * self.n_next)(*[a.dev.ptr for a in axs])
+        bp = (C.c_void_p * self.n_next)(*[x.dev.ptr for x in xs])
+        a_new = out_a if out_a is not None else ctx.empty((B,), np.float64)
+        b_new = out_b if out_b is not None else out_vec(ctx, z, self.dtype)
+        ctx._call("tramp_duplicate_channel", self._dt, n, B, self.n_next, a_z.dev.ptr, z.dev.ptr, ap, bp, target,
+                  float(damping or 0.0), old_a.ptr if old_a is not None else None,
+                  old_b.ptr if old_b is not None else None, a_new.ptr, b_new.ptr)
+        return ret_scal(a_new, a_z, z), ret_vec(b_new, z)
+
+    def compute_backward_message(self, az, bz, ax, bx, **kw):
+        return self._message(-1, az, bz, ax, bx, **kw)                        # base_channel.py:102-105
+
+    def compute_forward_message(self, az, bz, ax, bx, target=None, **kw):
+        "message to x_target; without ``target`` the list of all K messages as the reference returns (base.py:329-346)"
+        if target is not None:
+            return self._message(target, az, bz, ax, bx, **kw)
+        outs = [self._message(k, az, bz, ax, bx) for k in range(self.n_next)]
+        return [o[0] for o in outs], [o[1] for o in outs]
+
+    def compute_backward_posterior(self, az, bz, ax, bx):
+        "r = b / a, v = 1 / a with a = az + sum ax, b = bz + sum bx (:24-31) - through the message: r = (b_new + bz) / (az + a_new)"
+        a_new, b_new = self.compute_backward_message(az, bz, ax, bx)
+        a = np.asarray(az, dtype=float) + np.asarray(a_new, dtype=float)
+        r = (np.asarray(b_new, dtype=float) + np.asarray(bz, dtype=float)) / (a[..., None] if np.ndim(a) else a)
+        return r, 1.0 / a
+
+    def compute_forward_posterior(self, az, bz, ax, bx):
+        rz, vz = self.compute_backward_posterior(az, bz, ax, bx)              # :18-22
+        return [rz] * self.n_next, [vz] * self.n_next
+
+
 # ------------------------------------------------------------------ componentwise
 class PiecewiseLinearChannel(Channel):
     """x = f(z), f piecewise linear with two half-line regions (kernel K7).
@@ -1745,6 +1818,7 @@ class ModulusChannel(Channel):
 
 CHANNEL_CLASSES = {
     "gaussian": GaussianChannel,
+    "duplicate": DuplicateChannel,
     "linear": LinearChannel,
     "complex_linear": ComplexLinearChannel,
     "modulus": ModulusChannel,

@@ -2329,6 +2329,63 @@ extern "C" int tramp_sum_channel(tramp_ctx* ctx, int dtype, size_t n, size_t bat
     return TRAMP_OK;
 }
 
+// ---------------------------------------------------------------- duplicate channel x_1 = ... = x_K = z
+// DuplicateChannel (tramp/channels/shape/duplicate_channel.py:24-31 with base_channel.py:102-105 and base.py:250-255):
+//     a = az + sum_k ax_k,  b = bz + sum_k bx_k  (in that order),  r = b / a,  v = 1 / a;
+//     the message to the neighbour whose own message is (a_t, b_t):  a_new = clip(1 / v - a_t),  b_new = r (a_t + a_new) - b_t.
+// target = -1: the backward message to z; target = k: the forward message to x_k.  Constant damping fused.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void duplicate_channel_kernel(size_t n, int k, int target, const double* __restrict__ az,
+                                                                   const T* __restrict__ bz, MsgPtrs xs, double damping,
+                                                                   const double* a_old, const T* b_old, double* a_new, T* b_new) {
+    const size_t b = blockIdx.y;
+    double s = 0.0;
+    for (int j = 0; j < k; ++j) s += xs.a[j][b];
+    const double a = az[b] + s;
+    const double v = 1.0 / a;
+    const double a_t = target < 0 ? az[b] : xs.a[target][b];
+    const double an = tmath::a_new_of(v, a_t);
+    const double asum = a_t + an;
+    const T* b_t = target < 0 ? bz : static_cast<const T*>(xs.b[target]);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        double sb = 0.0;
+        for (int j = 0; j < k; ++j) sb += (double)static_cast<const T*>(xs.b[j])[b * n + i];
+        const double r = ((double)bz[b * n + i] + sb) / a;
+        double out = r * asum - (double)b_t[b * n + i];
+        if (damping != 0.0) out = damping * (double)b_old[b * n + i] + (1.0 - damping) * out;
+        b_new[b * n + i] = (T)out;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a_new[b] = (damping != 0.0) ? damping * a_old[b] + (1.0 - damping) * an : an;
+}
+
+extern "C" int tramp_duplicate_channel(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k, const double* az_d,
+                                       const void* bz_d, const double* const* ax_d, const void* const* bx_d, int target,
+                                       double damping, const double* a_old_d, const void* b_old_d, double* a_new_d,
+                                       void* b_new_d) {
+    if (!ctx) return TRAMP_EINVAL;
+    TRAMP_REQUIRE(ctx, az_d && bz_d && ax_d && bx_d && a_new_d && b_new_d);
+    TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
+    TRAMP_REQUIRE(ctx, k >= 1 && k <= kMaxMsgs && target >= -1 && target < k);
+    TRAMP_REQUIRE(ctx, damping == 0.0 || (a_old_d && b_old_d));
+    if (!n || !batch) return TRAMP_OK;
+    TRAMP_REQUIRE(ctx, batch <= 65535);
+    MsgPtrs xs{};
+    for (int j = 0; j < k; ++j) {
+        TRAMP_REQUIRE(ctx, ax_d[j] && bx_d[j]);
+        xs.a[j] = ax_d[j];
+        xs.b[j] = bx_d[j];
+    }
+    dim3 grid(blocks_for(n, 1), (unsigned)batch);
+    if (dtype == TRAMP_F64)
+        hipLaunchKernelGGL((duplicate_channel_kernel<double>), grid, dim3(kBlock), 0, ctx->stream, n, k, target, az_d,
+                           (const double*)bz_d, xs, damping, a_old_d, (const double*)b_old_d, a_new_d, (double*)b_new_d);
+    else
+        hipLaunchKernelGGL((duplicate_channel_kernel<float>), grid, dim3(kBlock), 0, ctx->stream, n, k, target, az_d,
+                           (const float*)bz_d, xs, damping, a_old_d, (const float*)b_old_d, a_new_d, (float*)b_new_d);
+    TRAMP_LAUNCH_CHECK(ctx);
+    return TRAMP_OK;
+}
+
 extern "C" int tramp_message_sum(tramp_ctx* ctx, int dtype, size_t n, size_t batch, int k,
                                  const double* const* a_in_d, const void* const* b_in_d, int exclude,
                                  double* a_out_d, void* b_out_d) {

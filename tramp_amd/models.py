@@ -237,8 +237,9 @@ class Model:
             if isinstance(node, Factor) and node.n_next:
                 taus = [self.dag.nodes[p]["tau"] for p in self.dag.predecessors(node)]
                 tau = node.second_moment(*taus)
-                for succ in self.dag.successors(node):
-                    self.dag.nodes[succ]["tau"] = tau
+                succs = list(self.dag.successors(node))
+                for k, succ in enumerate(succs):              # a K-output factor returns one value per output (base_model.py:120-123)
+                    self.dag.nodes[succ]["tau"] = tau[k] if node.n_next > 1 else tau
 
     def get_second_moments(self):
         return {v.id: self.dag.nodes[v].get("tau") for v in self.variables}

@@ -51,8 +51,8 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.variables = model.variables
         self.factors = model.factors
         for f in self.factors:
-            if f.n_next > 1:
-                raise ValueError(f"{f}: factors with several outputs are outside the HIP path")
+            if f.n_next > 1 and not (f.n_prev == 1 and hasattr(f, "_message")):
+                raise ValueError(f"{f}: factors with several outputs are outside the HIP path (DuplicateChannel is the one there is)")
         for v in self.variables:
             if v.n_prev == 0:
                 raise ValueError(f"variable {v.id} has no incoming factor")
@@ -220,6 +220,8 @@ class TreeExpectationPropagation(ExpectationPropagation):
         g = self.model.dag
         if f.n_prev > 1:
             return self._multi_input_send(f, direction)
+        if f.n_next > 1:
+            return self._multi_output_send(f, direction)
         prev = next(iter(g.predecessors(f)), None)
         nxt = next(iter(g.successors(f)), None)
         target = nxt if direction == "fwd" else prev
@@ -289,6 +291,27 @@ class TreeExpectationPropagation(ExpectationPropagation):
                 f.compute_forward_message(az, bz, x.a, x.b, **kw)
             else:
                 f.compute_backward_message(az, bz, x.a, x.b, target=k, **kw)
+            self._mark(out)
+
+    def _multi_output_send(self, f, direction):
+        "one-input, K-output factor (DuplicateChannel): forward one message per output, backward to its input"
+        g = self.model.dag
+        prev = next(iter(g.predecessors(f)))
+        nxts = list(g.successors(f))
+        z = self._latest((prev, f))
+        xs = [self._latest((x, f)) for x in nxts]
+        ax, bx = [m.a for m in xs], [m.b for m in xs]
+        d = self.damping
+        targets = [(prev, None)] if direction == "bwd" else [(x, k) for k, x in enumerate(nxts)]
+        for tgt, k in targets:
+            out, old = self.msg[(f, tgt)], self._old((f, tgt))
+            kw = dict(out_a=out.a, out_b=out.b)
+            if d:
+                kw.update(damping=d, old_a=old.a, old_b=old.b)
+            if k is None:
+                f.compute_backward_message(z.a, z.b, ax, bx, **kw)
+            else:
+                f.compute_forward_message(z.a, z.b, ax, bx, target=k, **kw)
             self._mark(out)
 
     def _variable_send(self, v, targets):
@@ -421,6 +444,19 @@ class TreeStateEvolution:
                 news, tgts = [f.compute_forward_state_evolution(az, self.msg[(nxt, f)], taus)], [nxt]
             else:
                 news, tgts = f.compute_backward_state_evolution(az, self.msg[(nxt, f)], taus), prevs
+            for new, t in zip(news, tgts):
+                if np.any(np.isnan(new)):
+                    raise ValueError(f"{f.id}->{t.id} a is nan")
+                self.msg[(f, t)] = d * self.msg[(f, t)] + (1 - d) * new if d else new
+            return
+        if f.n_next > 1:                                    # K-output factor (DuplicateChannel)
+            prev = next(iter(g.predecessors(f)))
+            nxts = list(g.successors(f))
+            ax = [self.msg[(x, f)] for x in nxts]
+            if direction == "fwd":
+                news, tgts = f.compute_forward_state_evolution(self.msg[(prev, f)], ax, self.taus[prev.id]), nxts
+            else:
+                news, tgts = [f.compute_backward_state_evolution(self.msg[(prev, f)], ax, self.taus[prev.id])], [prev]
             for new, t in zip(news, tgts):
                 if np.any(np.isnan(new)):
                     raise ValueError(f"{f.id}->{t.id} a is nan")
