@@ -1228,8 +1228,7 @@ def run(args):
                            "decision": "RCCL refused the communicator (e.g. two ranks on one device): every rank computed "
                                        "the factors itself, results travel over host sockets"}),
                       "factors_loaded_from": args.load_factors,
-                      "eigensolver": "spectral divide and conquer + rocSOLVER syevd halves" if k > 46336
-                                     else "rocSOLVER syevd"},
+                      "eigensolver": _eigensolver_label(k)},
             "env_overrides": T.switches.overrides(),       # {} = every library switch at its default (tramp_amd/switches.py)
             "mse_after_run": float(np.mean(mse_inst)),
             "v_after_run": float(np.mean(v_inst)),
@@ -1367,6 +1366,15 @@ def claim_stdout():
         sys.stdout.flush()
         _RESULT_FD = os.dup(1)
         os.dup2(2, 1)
+
+
+def _eigensolver_label(k):
+    "which eigensolver tramp_linear_factorize takes for a Gram matrix of order k under the current switches (csrc/factorize.hip: eigh_rec)"
+    method = os.environ.get("TRAMP_EIG_METHOD", "auto")
+    if method != "split" and (k >= 6144 or method == "tridiag") and 64 <= k <= 92672:
+        return ("own Householder tridiagonalisation + rocSOLVER stedc" + (" halves + one Cuppen merge" if k > 46336 else "")
+                + " + blocked back-transformation (csrc/tridiag_eig.h)")
+    return "spectral divide and conquer + rocSOLVER syevd halves" if k > 46336 else "rocSOLVER syevd"
 
 
 def _sig(x, digits=6):
