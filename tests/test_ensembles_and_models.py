@@ -82,3 +82,29 @@ def test_duplicate_channel_oracle_matches_the_reference(golden_models2):
         for k in range(c["K"]):
             assert fa[k] == pytest.approx(c["a_fwd"][k], rel=1e-13)
             np.testing.assert_allclose(fb[k], c["b_fwd"][k], rtol=1e-12, atol=1e-13)
+
+
+def test_metrics_match_the_reference_formulas():
+    """tramp/algos/metrics.py:5-41 restated here (mean over all components; sign / phase symmetric minima; overlap) against
+    tramp_amd.metrics, one signal and an ensemble of instances"""
+    import tramp_amd as T
+    rs = np.random.RandomState(0)
+    x = rs.randn(2, 50)                                          # a planar complex signal
+    p = -x + 0.1 * rs.randn(2, 50)
+    assert T.METRICS["mse"](x, p) == pytest.approx(np.mean((x - p) ** 2), rel=1e-15)
+    assert T.METRICS["overlap"](x, p) == pytest.approx(np.mean(x * p), rel=1e-15)
+    assert T.METRICS["sign_mse"](x, p) == pytest.approx(min(np.mean((x - p) ** 2), np.mean((x + p) ** 2)), rel=1e-15)
+    z, zp = x[0] + 1j * x[1], p[0] + 1j * p[1]
+    want = min(np.mean(np.abs(z - np.exp(1j * phi) * zp) ** 2) / 2 for phi in np.linspace(0, 2 * np.pi, 100))
+    assert T.METRICS["phase_mse"](x, p) == pytest.approx(want, rel=1e-13)
+    assert T.METRICS["phase_mse"](x, p) < 0.02 < T.METRICS["mse"](x, p)
+    # an ensemble: per-instance scores, the true signal shared or per instance
+    P = np.stack([p, x + 0.2 * rs.randn(2, 50), x[::-1].copy()])
+    got = T.phase_symmetric_mse(x, P.reshape(3, -1), batch=3)
+    assert got.shape == (3,) and got[0] == pytest.approx(want, rel=1e-13)
+    np.testing.assert_allclose(T.mean_squared_error(np.stack([x, x, x]), P, batch=3), [np.mean((x - q) ** 2) for q in P], rtol=1e-14)
+    np.testing.assert_allclose(T.sign_symmetric_mse(x.ravel(), np.stack([p.ravel(), -p.ravel()])), [T.sign_symmetric_mse(x, p)] * 2, rtol=1e-14)
+    with pytest.raises(ValueError):
+        T.mean_squared_error(np.zeros(7), np.zeros(10))
+    with pytest.raises(KeyError):
+        T.TrackErrors({"x": x}, metrics=["nope"])

@@ -290,6 +290,18 @@ def test_phase_retrieval_model_api(ctx):
     ph = np.vdot(xh, x0)
     ph /= abs(ph)
     assert np.mean(np.abs(xh * ph - x0)**2) < 1e-6 * np.mean(np.abs(x0)**2)
+    # the reference's way of scoring it (examples/glm/plot_complex_pr.py: TrackErrors with the phase-symmetric mse, algos/metrics.py:18-26):
+    # a grid of 100 phases, so the score is bounded by the grid's resolution; the plain mse sees the arbitrary global phase
+    track = T.TrackErrors({"x": sample["x"]}, metrics=["mse", "phase_mse", "sign_mse", "overlap"], every=10)
+    ep2 = T.ExpectationPropagation(student, ctx=ctx)
+    ep2.iterate(max_iter=300, damping=0.3, callback=T.JoinCallback([track, T.EarlyStoppingEP(max_increase=np.inf)]),
+                initializer=T.CustomInit(a_init=[("x", "bwd", 0.1)], b_init=[("x", "bwd", b0)]))
+    last = track.records[-1]
+    assert set(last) == {"id", "iter", "mse", "phase_mse", "sign_mse", "overlap"} and last["id"] == "x"
+    # (the last record is the last multiple of ten iterations, r the final iterate: both sit on the phase grid's floor)
+    assert last["phase_mse"] == pytest.approx(T.phase_symmetric_mse(sample["x"], r), rel=1e-2)
+    assert last["phase_mse"] < 2e-3 * np.mean(sample["x"]**2) and last["phase_mse"] < 0.05 * last["mse"]
+    assert track.records[0]["phase_mse"] > 10 * last["phase_mse"]
 
 
 def test_modulus_se_error_and_phase_retrieval_state_evolution(ctx, golden_complex):

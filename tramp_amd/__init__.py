@@ -31,4 +31,6 @@ from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, Ear
                     ConstantInit, CustomInit, NoisyInit, JoinCallback, PassCallback, TrackEvolution, TrackErrors,
                     TrackEstimate, TrackMessages, TrackObjective, TrackOverlaps, LogProgress)
 
+from .metrics import METRICS, mean_squared_error, sign_symmetric_mse, phase_symmetric_mse, overlap
+
 __version__ = "0.1.0"

@@ -172,17 +172,30 @@ class TrackEvolution:
 
 
 class TrackErrors:
-    "tramp/algos/callbacks.py:131-162 (mse against the true signal, computed on the device)"
+    """tramp/algos/callbacks.py:131-162: the metrics of tramp/algos/metrics.py against the true signal, per instance.  The default
+    ["mse"] is reduced on the device; "sign_mse", "phase_mse", "overlap" are scored on the host from the posterior means."""
 
-    def __init__(self, true_values, every=1):
-        self.true_values, self.every, self.records = true_values, every, []
+    def __init__(self, true_values, metrics=("mse",), every=1):
+        from .metrics import METRICS
+        self.true_values, self.metrics, self.every, self.records = true_values, list(metrics), every, []
+        for m in self.metrics:
+            if m not in METRICS:
+                raise KeyError(m)
 
     def __call__(self, algo, i, max_iter):
+        from .metrics import METRICS
         if i == 0:
             self.records = []
         if i % self.every == 0:
+            host = [m for m in self.metrics if m != "mse"]
+            data = algo.get_variables_data(list(self.true_values)) if host else {}
             for vid, x in self.true_values.items():
-                self.records.append(dict(id=vid, mse=algo.mse(vid, x), iter=i))
+                rec = dict(id=vid, iter=i)
+                if "mse" in self.metrics:
+                    rec["mse"] = algo.mse(vid, x)
+                for m in host:
+                    rec[m] = METRICS[m](x, data[vid]["r"], batch=getattr(algo, "batch", None))
+                self.records.append(rec)
         return False
 
 
