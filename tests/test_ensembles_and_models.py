@@ -108,3 +108,29 @@ def test_metrics_match_the_reference_formulas():
         T.mean_squared_error(np.zeros(7), np.zeros(10))
     with pytest.raises(KeyError):
         T.TrackErrors({"x": x}, metrics=["nope"])
+
+
+def test_experiment_grid_and_binary_search():
+    "tramp/experiments/multiple_experiments.py and critical_alpha.py:7-29 restated: grids, failures logged and skipped, bisection"
+    from tramp_amd import experiments as X
+    grid = X.get_experiments_from_kwargs(alpha=[0.5, 1.0], rho=np.array([0.1, 0.2, 0.3]), name="cs")
+    assert len(grid) == 6 and grid[0] == dict(alpha=0.5, rho=0.1, name="cs") and grid[-1] == dict(alpha=1.0, rho=0.3, name="cs")
+    calls = []
+
+    def run(alpha, rho):
+        calls.append((alpha, rho))
+        if alpha == 1.0 and rho == 0.2:
+            raise RuntimeError("diverged")
+        return [dict(source="EP", v=alpha * rho), dict(source="SE", v=alpha + rho)] if rho > 0.1 else dict(source="EP", v=0.0)
+    seen = []
+    df = X.run_experiments(run, on_progress=lambda i, n: seen.append((i, n)), alpha=[0.5, 1.0], rho=[0.1, 0.2])
+    assert len(calls) == 4 and seen[-1] == (4, 4)
+    assert len(df) == 1 + 2 + 1 and set(df.columns) == {"source", "v", "alpha", "rho"}          # the failing experiment is skipped
+    with pytest.raises(RuntimeError):
+        X.simple_run_experiments(run, alpha=[1.0], rho=[0.2])
+    res = X.binary_search(lambda x: x > 0.3217, 0.0, 1.0, 1e-6)
+    assert res["xmin"] <= 0.3217 <= res["xmax"] and res["xerr"] < 1e-6 and abs(res["xmid"] - 0.3217) < 1e-6
+    with pytest.raises(ValueError):
+        X.binary_search(lambda x: True, 0.0, 1.0, 1e-3)
+    with pytest.raises(ValueError):
+        X.TeacherStudentScenario(object(), "not a model")

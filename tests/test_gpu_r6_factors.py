@@ -478,3 +478,43 @@ def test_phase_retrieval_ep_fp32(ctx, golden_complex):
             ref = t[f"r:{vid}"][it]
             close(np.asarray(rec.iters[it]["vars"][vid]["r"]).reshape(ref.shape), ref, 2e-3, scale=max(np.abs(ref).max(), 1e-3))
             close(rec.iters[it]["vars"][vid]["v"], t[f"v:{vid}"][it], 2e-3)
+
+
+def test_teacher_student_scenarios_and_critical_alpha(ctx):
+    """tramp/experiments: BayesOptimalScenario.run_all on the sparse GLM (EP's variance and mse agree with state evolution), the same
+    with an ensemble of teacher samples as ONE run, the convergence data frames, and find_critical_alpha on noiseless compressed
+    sensing (perfect recovery above the Gauss-Bernoulli threshold, alpha_c between rho and 1)"""
+    import tramp_amd as T
+    np.random.seed(7)
+    N, alpha, rho = 2000, 0.8, 0.2
+    model = T.glm_generative(N=N, alpha=alpha, ensemble_type="gaussian", prior_type="gauss_bernoulli", output_type="gaussian",
+                             prior_rho=rho, output_var=1e-3, ctx=ctx)
+    sc = T.BayesOptimalScenario(model, x_ids=["x"])
+    recs = sc.run_all(metrics=["mse", "overlap"], max_iter=100, damping=0.1)
+    by = {r["source"]: r for r in recs}
+    assert set(by) == {"SE", "EP", "mse", "overlap"} and by["EP"]["n_iter"] < 100
+    assert by["EP"]["v"] == pytest.approx(by["mse"]["v"], rel=0.3) and by["EP"]["v"] == pytest.approx(by["SE"]["v"], rel=0.3)
+    assert by["mse"]["v"] < 0.05 * rho
+    # four teacher samples on the ensemble axis: one EP run, per-instance scores
+    recs4 = sc.run_all(source="EP", metrics=["mse"], instances=4, max_iter=100, damping=0.1)
+    by4 = {r["source"]: r for r in recs4}
+    assert sc.ep.batch == 4 and np.shape(by4["mse"]["v"]) == (4,) and np.shape(by4["EP"]["v"]) == (4,)
+    assert np.all(np.asarray(by4["mse"]["v"]) < 0.05 * rho) and np.ptp(by4["mse"]["v"]) > 0
+    np.testing.assert_allclose(by4["mse"]["v"], by4["EP"]["v"], rtol=0.3)
+    # convergence data frames
+    sc.setup(seed=3)
+    df = sc.ep_convergence(metrics=["mse"], max_iter=30, damping=0.1)
+    assert list(df.columns) == ["id", "iter", "mse", "v"] and len(df) >= 5 and float(df["mse"].iloc[-1]) < float(df["mse"].iloc[0])
+    dfs = sc.se_convergence(max_iter=30)
+    # (the damped run of run_all stops on its tolerance a little short of the fixed point)
+    assert float(dfs["v"].iloc[-1]) == pytest.approx(by["SE"]["v"], rel=1e-2)
+    assert T.run_state_evolution(["x"], sc.student, max_iter=30)[0]["v"] == pytest.approx(float(dfs["v"].iloc[-1]), rel=1e-2)
+    # critical alpha of noiseless sparse recovery from an informed start: between rho (counting bound) and 1
+    ac = T.find_critical_alpha("x", 1e3, "perfect", 0.05, 0.95, T.glm_state_evolution, alpha_tol=1e-2, vtol=1e-6,
+                               prior_type="gauss_bernoulli", output_type="gaussian", prior_rho=0.3, output_var=1e-11)
+    assert 0.3 <= ac < 0.6
+    v_above = T.find_state_evolution_mse("x", 1e3, ac + 0.05, T.glm_state_evolution, prior_type="gauss_bernoulli",
+                                         output_type="gaussian", prior_rho=0.3, output_var=1e-11)
+    v_below = T.find_state_evolution_mse("x", 1e3, max(ac - 0.05, 0.05), T.glm_state_evolution, prior_type="gauss_bernoulli",
+                                         output_type="gaussian", prior_rho=0.3, output_var=1e-11)
+    assert v_above < 1e-6 < v_below

@@ -33,4 +33,8 @@ from .algos import (ExpectationPropagation, StateEvolution, EarlyStoppingEP, Ear
 
 from .metrics import METRICS, mean_squared_error, sign_symmetric_mse, phase_symmetric_mse, overlap
 
+from . import experiments
+from .experiments import (TeacherStudentScenario, BayesOptimalScenario, run_state_evolution, run_experiments,
+                          simple_run_experiments, save_experiments, binary_search, find_state_evolution_mse, find_critical_alpha)
+
 __version__ = "0.1.0"

@@ -170,6 +170,11 @@ class TrackEvolution:
                 self.records.append(dict(id=vid, v=d["v"], iter=i))
         return False
 
+    def get_dataframe(self):
+        "the records as a pandas DataFrame (tramp/algos/callbacks.py: get_dataframe of every tracking callback)"
+        import pandas as pd
+        return pd.DataFrame(self.records)
+
 
 class TrackErrors:
     """tramp/algos/callbacks.py:131-162: the metrics of tramp/algos/metrics.py against the true signal, per instance.  The default
@@ -198,6 +203,11 @@ class TrackErrors:
                 self.records.append(rec)
         return False
 
+    def get_dataframe(self):
+        "the records as a pandas DataFrame (tramp/algos/callbacks.py: get_dataframe of every tracking callback)"
+        import pandas as pd
+        return pd.DataFrame(self.records)
+
 
 class TrackEstimate:
     "tramp/algos/callbacks.py:111-128: the posterior means, every `every` iterations"
@@ -213,6 +223,11 @@ class TrackEstimate:
                 self.records.append(dict(id=vid, r=d["r"], iter=i))
         return False
 
+    def get_dataframe(self):
+        "the records as a pandas DataFrame (tramp/algos/callbacks.py: get_dataframe of every tracking callback)"
+        import pandas as pd
+        return pd.DataFrame(self.records)
+
 
 class TrackMessages:
     "tramp/algos/callbacks.py:49-62: the scalar part a of every factor->variable message"
@@ -227,6 +242,11 @@ class TrackMessages:
             rec = dict(a=float(a[0]) if a.size == 1 else a, n_iter=algo.n_iter, direction=direction, id=vid)
             self.records.append({k: rec[k] for k in (*self.keys, "id") if k in rec})
         return False
+
+    def get_dataframe(self):
+        "the records as a pandas DataFrame (tramp/algos/callbacks.py: get_dataframe of every tracking callback)"
+        import pandas as pd
+        return pd.DataFrame(self.records)
 
 
 class TrackObjective:
@@ -261,6 +281,11 @@ class TrackOverlaps:
                 self.records.append(dict(id=vid, m=np.sum(r * x, axis=-1) / n, q=np.sum(r * r, axis=-1) / n,
                                          Q=np.sum(x * x, axis=-1) / n, iter=i))
         return False
+
+    def get_dataframe(self):
+        "the records as a pandas DataFrame (tramp/algos/callbacks.py: get_dataframe of every tracking callback)"
+        import pandas as pd
+        return pd.DataFrame(self.records)
 
 
 class LogProgress:
@@ -1287,6 +1312,9 @@ class StateEvolution:
     def get_variables_data(self, ids="all", want_r=False):
         return {v.id: dict(v=self.v[i]) for i, v in enumerate(self.variables)
                 if ids == "all" or v.id in ids}
+
+    def get_variable_data(self, id):
+        return self.get_variables_data([id])[id]
 
     def get_edges_data(self):
         out = {}

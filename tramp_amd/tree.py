@@ -519,5 +519,8 @@ class TreeStateEvolution:
     def get_variables_data(self, ids="all", want_r=False):
         return {v.id: dict(v=self.v[i]) for i, v in enumerate(self.variables) if ids == "all" or v.id in ids}
 
+    def get_variable_data(self, id):
+        return self.get_variables_data([id])[id]
+
     def get_edges_data(self):
         return {(getattr(s, "id", s), getattr(t, "id", t)): a for (s, t), a in self.msg.items()}
