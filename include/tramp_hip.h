@@ -775,7 +775,8 @@ int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, double z_hi,
 /* compute_log_partition of the round-6 priors, out[b] = SUM over the n components (the host takes the mean):
  *   which 0, params_h = {a0, b0, A0}: positive.A(ax + a0, bx + b0) - A0 - ExponentialPrior (exponential_prior.py:62-65,
  *     A0 = exponential.A(b0) = -log(-b0)) and PositivePrior (positive_prior.py:65-69, A0 = positive.A(1, 0));
- *   which 1, params_h = {K, probs[K], means[K], vars[K]}: GaussianMixturePrior (gaussian_mixture_prior.py:99-104). */
+ *   which 1, params_h = {K, probs[K], means[K], vars[K]}: GaussianMixturePrior (gaussian_mixture_prior.py:99-104);
+ *   which 2, params_h = {b0}: BinaryPrior (binary_prior.py:64-67): binary.A(bx + b0) - binary.A(b0) - ax / 2. */
 int tramp_prior2_log_partition(tramp_ctx* ctx, int dtype, int which, size_t n, size_t batch, const double* params_h,
                                int nparams, const double* ax_d, const void* bx_d, double* out_d);
 /* ModulusLikelihood.compute_log_partition AS FOUND (modulus_likelihood.py:125-129: np.absolute acts on each real

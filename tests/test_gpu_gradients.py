@@ -37,7 +37,12 @@ def prior_cases(T, ctx):
     kw = dict(size=1, ctx=ctx)
     return [("gb", T.GaussBernoulliPrior(rho=0.3, mean=0.4, var=1.3, **kw), False),
             ("gauss", T.GaussianPrior(mean=-0.2, var=0.7, **kw), False),
-            ("l1", T.MAP_L1NormPrior(gamma=0.8, **kw), True)]
+            ("l1", T.MAP_L1NormPrior(gamma=0.8, **kw), True),
+            # round 6 (and the binary prior of round 4): the same identities for the rest of the separable priors
+            ("binary", T.BinaryPrior(p_pos=0.3, **kw), False),
+            ("exponential", T.ExponentialPrior(mean=0.7, **kw), False),
+            ("positive", T.PositivePrior(**kw), False),
+            ("mixture", T.GaussianMixturePrior(probs=[0.2, 0.5, 0.3], means=[-2.0, 0.0, 1.5], vars=[0.3, 0.05, 2.0], **kw), False)]
 
 
 def test_prior_posterior_is_gradient_of_log_partition(ctx):
@@ -55,6 +60,18 @@ def test_prior_posterior_is_gradient_of_log_partition(ctx):
         np.testing.assert_allclose(-2 * d1(A_a, a, H), second, rtol=2e-6, atol=TOL, err_msg=name + ": -2 dA/da")
 
 
+def test_binary_prior_log_partition_value(ctx):
+    "binary_prior.py:64-67 literally: mean(logaddexp(b, -b)) - logaddexp(b0, -b0) - ax / 2 with b = bx + b0, also where exp(b) overflows"
+    import tramp_amd as T
+    rs = np.random.RandomState(5)
+    bx = np.concatenate([rs.standard_normal(500) * 3, [0.0, 800.0, -800.0, 1e-300]])
+    for p_pos, ax in ((0.3, 1.7), (0.5, 0.2), (0.999, 40.0)):
+        pr = T.BinaryPrior(size=bx.size, p_pos=p_pos, ctx=ctx)
+        b0 = 0.5 * np.log(p_pos / (1 - p_pos))
+        want = np.mean(np.logaddexp(bx + b0, -(bx + b0)) - np.logaddexp(b0, -b0) - 0.5 * ax)
+        assert pr.compute_log_partition(ax, bx) == pytest.approx(want, rel=1e-13)
+
+
 def test_likelihood_posterior_is_gradient_of_log_partition(ctx):
     import tramp_amd as T
     a, b = grid(2, 193)
@@ -62,9 +79,22 @@ def test_likelihood_posterior_is_gradient_of_log_partition(ctx):
     y_g = rs.randn(a.size, 1)
     y_s = np.sign(rs.randn(a.size, 1))
     y_a = np.abs(rs.randn(a.size, 1)) + 0.1
+    z = rs.randn(a.size, 1) * 1.5
+    y_relu = np.maximum(z, 0.0)                                   # half of the observations sit on the atom y = 0
+    y_leaky = np.where(z > 0, z, 0.1 * z)
+    y_tanh = np.clip(z, -1.0, 1.0)                                # atoms at +-1
+    y_sigm = np.clip(z / 5.0 + 0.5, 0.0, 1.0)                     # atoms at 0 and 1 (rare at this scale)
+    y_door = np.where(np.abs(z) < 0.8, -1.0, 1.0)
     for name, lik, y in (("gaussian", T.GaussianLikelihood(y=y_g, var=0.4, ctx=ctx), y_g),
                          ("sgn", T.SgnLikelihood(y=y_s, ctx=ctx), y_s),
-                         ("abs", T.AbsLikelihood(y=y_a, ctx=ctx), y_a)):
+                         ("abs", T.AbsLikelihood(y=y_a, ctx=ctx), y_a),
+                         # the rest of the piecewise-linear family (round 4 / 5 kernels): the identities per observation,
+                         # on the point-mass branches (r = the pre-image, v = 0) and on the truncated-normal ones
+                         ("relu", T.ReluLikelihood(y=y_relu, ctx=ctx), y_relu),
+                         ("l-relu", T.LeakyReluLikelihood(slope=0.1, y=y_leaky, ctx=ctx), y_leaky),
+                         ("h-tanh", T.HardTanhLikelihood(y=y_tanh, ctx=ctx), y_tanh),
+                         ("h-sigm", T.HardSigmoidLikelihood(y=y_sigm, ctx=ctx), y_sigm),
+                         ("door", T.SymmetricDoorLikelihood(width=0.8, y=y_door, ctx=ctx), y_door)):
         r, v = lik.compute_backward_posterior(a, b, y)
         A_b = lambda bb: np.asarray(lik.compute_log_partition(a, bb, y))            # noqa: E731
         A_a = lambda aa: np.asarray(lik.compute_log_partition(aa, b, y))            # noqa: E731

@@ -251,6 +251,10 @@ __global__ __launch_bounds__(kBlock) void prior2_logz_kernel(Prior2Params P, siz
         if (P.which == 0) {
             const double a = ax + P.a0;
             A = halfline_logZ((x + P.b0) / a, 1.0 / a, +1) - P.A0;
+        } else if (P.which == 2) {
+            // BinaryPrior (binary_prior.py:48-51, 64-67; beliefs/binary.py:4-5): logaddexp(b, -b) = |b| + log1p(exp(-2 |b|))
+            const double bb = fabs(x + P.b0);
+            A = bb + log1p(exp(-2.0 * bb)) - P.A0 - 0.5 * ax;
         } else {
             double xi[tmath::kGmMax];
             for (int k = 0; k < P.K; ++k) xi[k] = P.geta[k] + normal_A(ax + P.ga0[k], x + P.gb0[k]);
@@ -303,7 +307,7 @@ extern "C" int tramp_prior2_log_partition(tramp_ctx* ctx, int dtype, int which, 
                                           const double* params_h, int nparams, const double* ax_d, const void* bx_d,
                                           double* out_d) {
     if (!ctx) return TRAMP_EINVAL;
-    TRAMP_REQUIRE(ctx, params_h && ax_d && bx_d && out_d && (which == 0 || which == 1));
+    TRAMP_REQUIRE(ctx, params_h && ax_d && bx_d && out_d && which >= 0 && which <= 2);
     TRAMP_REQUIRE(ctx, dtype == TRAMP_F32 || dtype == TRAMP_F64);
     Prior2Params P{};
     P.which = which;
@@ -312,6 +316,10 @@ extern "C" int tramp_prior2_log_partition(tramp_ctx* ctx, int dtype, int which, 
         P.a0 = params_h[0];
         P.b0 = params_h[1];
         P.A0 = params_h[2];
+    } else if (which == 2) {
+        TRAMP_REQUIRE(ctx, nparams >= 1);
+        P.b0 = params_h[0];                              // the prior's natural parameter, A0 = binary.A(b0)
+        P.A0 = fabs(P.b0) + log1p(exp(-2.0 * fabs(P.b0)));
     } else {
         const int K = (int)params_h[0];
         TRAMP_REQUIRE(ctx, K >= 1 && K <= tmath::kGmMax && nparams >= 1 + 3 * K);

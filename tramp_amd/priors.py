@@ -225,6 +225,10 @@ class BinaryPrior(Prior):
                        damping, old_a, old_b, a_new.ptr, b_new.ptr,
                        r.ptr if r is not None else None, v.ptr if v is not None else None)
 
+    def compute_log_partition(self, ax, bx):
+        "binary_prior.py:64-67: mean of binary.A(bx + b) - binary.A(b) - ax / 2, binary.A(b) = logaddexp(b, -b)"
+        return self._logz2(2, (self.b,), ax, bx)
+
     def compute_forward_error(self, ax):
         "binary_prior.py:82-86 through base_prior.py:66-69, device quadrature (tramp_se_binary_prior)"
         ax_h = np.atleast_1d(np.asarray(ax, dtype=np.float64))
