@@ -134,3 +134,45 @@ def test_experiment_grid_and_binary_search():
         X.binary_search(lambda x: True, 0.0, 1.0, 1e-3)
     with pytest.raises(ValueError):
         X.TeacherStudentScenario(object(), "not a model")
+
+
+EXAMPLE_IMPORTS = """
+import sys
+assert "tramp" not in sys.modules
+from tramp_amd.compat import install_as_tramp
+install_as_tramp()
+# every import line of the reference's examples/ (except the matplotlib helpers qplot / plot_compare of experiments/plots.py)
+from tramp.models import glm_generative, glm_state_evolution, MultiLayerModel
+from tramp.experiments import save_experiments, run_state_evolution, BayesOptimalScenario, TeacherStudentScenario
+from tramp.experiments import run_experiments, find_critical_alpha
+from tramp.algos.metrics import mean_squared_error, sign_symmetric_mse
+from tramp.algos import EarlyStopping, EarlyStoppingEP, CustomInit, ConstantInit, NoisyInit, StateEvolution
+from tramp.algos import ExpectationPropagation, TrackEstimate
+from tramp.variables import SISOVariable as V, SILeafVariable as O, MILeafVariable, SIMOVariable
+from tramp.priors.base_prior import Prior
+from tramp.priors import BinaryPrior, GaussianPrior, GaussBernoulliPrior, MAP_L21NormPrior
+from tramp.ensembles import GaussianEnsemble
+from tramp.channels import (GaussianChannel, LinearChannel, Blur2DChannel, GradientChannel, DFTChannel, ReshapeChannel,
+                            LeakyReluChannel, HardTanhChannel, BiasChannel)
+from tramp.likelihoods import GaussianLikelihood
+import tramp, tramp_amd
+assert tramp is tramp_amd and Prior is tramp_amd.priors.Prior
+print("ok")
+"""
+
+
+def test_reference_import_paths_resolve_to_this_package():
+    "compat.install_as_tramp(): a script written against the reference's package layout imports this package (own process)"
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", EXAMPLE_IMPORTS], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+    # a different tramp already imported: refused
+    code = ("import sys, types; sys.modules['tramp'] = types.ModuleType('tramp')\n"
+            "from tramp_amd.compat import install_as_tramp\n"
+            "try:\n    install_as_tramp()\nexcept ImportError as e:\n    print('refused')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert out.stdout.strip() == "refused", out.stderr[-2000:]

@@ -105,3 +105,41 @@ def test_round6_priors_modulus_and_complex_channel(be):
                 close((a, bb.reshape(2, N)), lin.backward_message(az, cz, ax, cx))
         finally:
             be.linear_destroy(h)
+
+
+REFERENCE_STYLE_SCRIPT = """
+import numpy as np
+from tramp_amd.compat import install_as_tramp
+install_as_tramp()
+# --- from here on the script is written against the reference's API (cf. examples/glm: a sparse-CS sweep over alpha) ---
+from tramp.models import glm_generative
+from tramp.experiments import BayesOptimalScenario, run_experiments
+from tramp.algos import EarlyStopping, EarlyStoppingEP
+
+
+def run_cs(N, alpha, rho):
+    model = glm_generative(N=N, alpha=alpha, ensemble_type="gaussian", prior_type="gauss_bernoulli",
+                           output_type="gaussian", prior_rho=rho, output_var=1e-4)
+    scenario = BayesOptimalScenario(model, x_ids=["x"])
+    return scenario.run_all(metrics=["mse"], max_iter=100, damping=0.1)
+
+
+np.random.seed(0)
+df = run_experiments(run_cs, N=1000, alpha=[0.3, 0.9], rho=0.2)
+piv = {(r.alpha, r.source): float(r.v) for r in df.itertuples()}
+assert set(df.columns) >= {"source", "x_id", "v", "alpha", "rho", "N"} and len(df) == 6
+assert piv[(0.9, "mse")] < 1e-3 < piv[(0.3, "mse")]                      # recovery above the transition, failure below
+assert abs(piv[(0.9, "EP")] - piv[(0.9, "SE")]) < 0.5 * piv[(0.9, "SE")] + 1e-5
+print("ok")
+"""
+
+
+def test_a_script_written_for_the_reference_runs_on_this_package():
+    "compat.install_as_tramp(): an examples/glm-style sweep (BayesOptimalScenario + run_experiments) under the reference's import paths"
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", REFERENCE_STYLE_SCRIPT], capture_output=True, text=True,
+                         env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1000:], out.stderr[-3000:])

@@ -37,4 +37,13 @@ from . import experiments
 from .experiments import (TeacherStudentScenario, BayesOptimalScenario, run_state_evolution, run_experiments,
                           simple_run_experiments, save_experiments, binary_search, find_state_evolution_mse, find_critical_alpha)
 
+# the reference's nested module paths (tramp.algos.metrics, tramp.priors.base_prior, ...) under this package's name
+import sys as _sys
+from . import metrics as _metrics, priors as _priors, likelihoods as _likelihoods, channels as _channels, algos as _algos, models as _models
+for _path, _mod in (("algos.metrics", _metrics), ("algos.callbacks", _algos), ("algos.initial_conditions", _algos),
+                    ("priors.base_prior", _priors), ("likelihoods.base_likelihood", _likelihoods),
+                    ("channels.base_channel", _channels), ("models.base_model", _models)):
+    _sys.modules[f"{__name__}.{_path}"] = _mod
+    setattr(_sys.modules[f"{__name__}.{_path.rsplit('.', 1)[0]}"], _path.rsplit(".", 1)[1], _mod)
+
 __version__ = "0.1.0"

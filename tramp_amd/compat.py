@@ -420,3 +420,35 @@ def bind_reference(backend=None):
     b._patch(tc.ComplexLinearChannel, "compute_forward_message", complex_fwd)
     b._patch(tc.ComplexLinearChannel, "compute_backward_message", complex_bwd)
     return b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The other direction: a script written against the reference's package layout runs on this package.
+_ALIASES = ("algos", "base", "channels", "ensembles", "experiments", "likelihoods", "models", "priors", "variables")
+_SUBMODULE_ALIASES = {"algos.metrics": "metrics", "algos.callbacks": "algos", "algos.initial_conditions": "algos",
+                      "priors.base_prior": "priors", "likelihoods.base_likelihood": "likelihoods",
+                      "channels.base_channel": "channels", "models.base_model": "models"}
+
+
+def install_as_tramp(name="tramp"):
+    """Register this package under the reference's import paths: after ``tramp_amd.compat.install_as_tramp()`` the lines
+    ``from tramp.models import glm_generative``, ``from tramp.experiments import BayesOptimalScenario``,
+    ``from tramp.algos.metrics import mean_squared_error`` ... of a script written for the reference import THIS package
+    (every name examples/ of the reference imports, except the matplotlib helpers of tramp/experiments/plots.py).  Refuses when a
+    different ``tramp`` is already imported - use bind_reference() to keep the reference's scheduler on the HIP kernels instead."""
+    import importlib
+    import sys
+    pkg = importlib.import_module(__package__)
+    have = sys.modules.get(name)
+    if have is not None and have is not pkg:
+        raise ImportError(f"a different {name!r} package is already imported from {getattr(have, '__file__', '?')}")
+    sys.modules[name] = pkg
+    for sub in _ALIASES:
+        sys.modules[f"{name}.{sub}"] = importlib.import_module(f"{__package__}.{sub}")
+    for path, target in _SUBMODULE_ALIASES.items():
+        mod = importlib.import_module(f"{__package__}.{target}")
+        sys.modules[f"{name}.{path}"] = mod
+        sys.modules[f"{__package__}.{path}"] = mod           # tramp_amd.algos.metrics ... resolve as well
+        parent, leaf = path.rsplit(".", 1)
+        setattr(importlib.import_module(f"{__package__}.{parent}"), leaf, mod)
+    return pkg
