@@ -336,6 +336,10 @@ class ExpectationPropagation:
         self.ctx = ctx or next((f._ctx for f in dev_factors if f._ctx is not None), None) or default_context()
         for f in dev_factors:
             f._ctx = self.ctx
+        for f in self.factors:                                  # observations seen as [instances, components] of their variable
+            if hasattr(f, "bind_shape") and f.n_prev == 1:
+                (var,) = self.model.dag.predecessors(f)
+                f.bind_shape(self.shapes.get(var.id))
         if batch is None:
             batch = 1
             for f in self.factors:
@@ -1137,6 +1141,8 @@ class ExpectationPropagation:
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
         adaptive = isinstance(damping, str) and damping == "adaptive"
+        if isinstance(damping, (int, np.integer, np.floating)) and not isinstance(damping, bool):
+            damping = float(damping)                           # the reference's examples pass damping=0
         if damping is not None and damping is not False and not isinstance(damping, float) and not adaptive:
             raise ValueError("damping must be None, a float (constant damping) or 'adaptive'")
         self.damping = 0.0 if adaptive else (float(damping) if damping else 0.0)

@@ -61,6 +61,12 @@ class TeacherStudentScenario:
         ep.iterate(**algo_kwargs)
         self.ep = ep
         x_data = ep.get_variables_data(self.x_ids)
+        for vid in self.x_ids:
+            # the estimates in the variable's own shape, as the reference hands them out (an image stays an image, a planar
+            # complex vector (2, n)); an ensemble of instances keeps its leading axis
+            shape = tuple(ep.shapes[vid])
+            r = np.asarray(x_data[vid]["r"])
+            x_data[vid]["r"] = r.reshape(shape) if r.size == int(np.prod(shape)) else r.reshape((-1,) + shape)
         x_data["n_iter"] = ep.n_iter
         self.x_pred = {vid: x_data[vid]["r"] for vid in self.x_ids}
         return x_data

@@ -31,6 +31,23 @@ class Likelihood(Factor):
         else:
             self._y_dev = self.ctx.array(np.atleast_2d(np.asarray(y, dtype=self.dtype)), self.dtype)
 
+    def bind_shape(self, shape):
+        """The scheduler knows the shape of the observed variable: an observation of exactly that shape is ONE instance (an
+        image y of shape (h, w) is not h instances of w components), (B,) + shape is an ensemble of B.  Re-views the device
+        copy as [instances, components]."""
+        yd = self._y_dev
+        if yd is None or shape is None:
+            return
+        n = int(np.prod(shape))
+        if n == 0 or yd.size % n:
+            raise ValueError(f"observation of shape {tuple(np.shape(self.y))} does not match the variable's shape {tuple(shape)}")
+        if yd.shape != (yd.size // n, n):
+            self._y_dev = yd.reshape(yd.size // n, n)
+            self._rebind()
+
+    def _rebind(self):
+        "hook: state derived from the [instances, components] view of y"
+
     def _y_for(self, b: VecArg, y=None):
         yd = self._y_dev
         if y is not None and y is not self.y:
@@ -200,6 +217,9 @@ class SgnLikelihood(Likelihood):
         super()._set_y(y)
         self._pack()
 
+    def _rebind(self):
+        self._pack()
+
     def _pack(self):
         self._bits = None
         yd = self._y_dev
@@ -285,6 +305,10 @@ class ModulusLikelihood(Likelihood):
     (tramp/utils/misc.py:13-27): host messages are (2, n) or (batch, 2, n), device messages [batch, 2 n]; y is (n,) or
     (batch, n).  Kernel: csrc/modulus.hip (Bessel ratio I1 / I0 in double).
     """
+
+    def bind_shape(self, shape):
+        "the observed variable is planar complex (2, n): y = |z| has the shape of ONE plane"
+        super().bind_shape(None if shape is None else tuple(shape[1:]))
 
     def __init__(self, y, y_name="y", isotropic=True, dtype=np.float64, ctx=None):
         if not isotropic:

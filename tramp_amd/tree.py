@@ -67,6 +67,10 @@ class TreeExpectationPropagation(ExpectationPropagation):
         self.ctx = ctx or next((f._ctx for f in dev_factors if f._ctx is not None), None) or default_context()
         for f in dev_factors:
             f._ctx = self.ctx
+        for f in self.factors:                                  # observations seen as [instances, components] of their variable
+            if hasattr(f, "bind_shape") and f.n_prev == 1:
+                (var,) = self.model.dag.predecessors(f)
+                f.bind_shape(self.shapes.get(var.id))
         if batch is None:
             batch = 1
             for f in self.factors:
