@@ -428,3 +428,81 @@ def test_the_sparse_fft_example_runs_on_this_package():
     out = subprocess.run([sys.executable, "-c", SPARSE_FFT_SCRIPT], capture_output=True, text=True,
                          env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1000:], out.stderr[-3000:])
+
+
+VAE_STYLE_SCRIPT = """
+import numpy as np
+from tramp_amd.compat import install_as_tramp
+install_as_tramp()
+# --- the model building and the EP run of examples/vae_prior/plot_vae.py (lines as written there; random decoder weights
+#     instead of the trained ones, a prior sample instead of an MNIST digit) ---
+from tramp.algos import ExpectationPropagation, TrackEstimate, NoisyInit
+from tramp.algos.metrics import mean_squared_error
+from tramp.variables import SISOVariable as V, SILeafVariable as O
+from tramp.likelihoods import GaussianLikelihood
+from tramp.priors import GaussianPrior
+from tramp.channels import LinearChannel, ReshapeChannel, LeakyReluChannel, HardTanhChannel, BiasChannel
+
+rs = np.random.RandomState(0)
+D, N1, N = 20, 60, 144
+W1, W2 = rs.standard_normal((N1, D)) / np.sqrt(D), rs.standard_normal((N, N1)) / np.sqrt(N1)
+b1, b2 = 0.1 * rs.standard_normal(N1), 0.1 * rs.standard_normal(N)
+shape = (N)
+
+
+def build_prior():
+    prior_x = (GaussianPrior(size=D) @ V(id="z_0") @
+               LinearChannel(W1, name="W_1") @ V(id="Wz_1") @ BiasChannel(b1) @ V(id="b_1") @ LeakyReluChannel(0) @ V(id="z_1") @
+               LinearChannel(W2, name="W_2") @ V(id="Wz_2") @ BiasChannel(b2) @ V(id="b_2") @ HardTanhChannel() @ V(id="z_2") @
+               ReshapeChannel(prev_shape=N, next_shape=shape))
+    return prior_x
+
+
+# sample_from_prior
+model = build_prior() @ O(id="y")
+model = model.to_model()
+x_star = model.sample()["y"]
+assert x_star.shape == (N,) and np.abs(x_star).max() <= 1.0
+
+# inpainting: a band of pixels removed
+F = np.identity(N)
+for rem in range(60, 84):
+    F[rem, rem] = 0
+F_obs = np.delete(F, np.where(~F.any(axis=0))[0], axis=0)
+y = F_obs @ x_star
+model = build_prior() @ V(id="x") @ LinearChannel(F_obs, name="F") @ V(id="z")
+model = model @ GaussianLikelihood(y=y, var=1e-2)
+model = model.to_model_dag()
+model = model.to_model()
+
+initializer = NoisyInit()
+x_tracker = TrackEstimate(ids="x", every=100)
+callback = x_tracker
+ep = ExpectationPropagation(model)
+ep.iterate(
+    max_iter=250,
+    callback=callback,
+    initializer=initializer,
+    damping=0.5
+)
+df_track = x_tracker.get_dataframe()
+ep_x_data = ep.get_variables_data(["x"])
+x_pred = {x_id: data["r"] for x_id, data in ep_x_data.items()}
+mse_ep = {x_id: data["v"] for x_id, data in ep_x_data.items()}
+mse = min(mean_squared_error(x_star, x_pred['x']), mean_squared_error(x_star, -x_pred['x']))
+print(f"mse_ep: {float(np.ravel(mse_ep['x'])[0]):.3f} mse: {mse: .3f}")
+assert len(df_track) >= 2 and set(df_track.columns) >= {"id", "r", "iter"}
+assert mse < 0.5 * np.mean(x_star ** 2)
+print("ok")
+"""
+
+
+def test_the_vae_prior_example_structure_runs_on_this_package():
+    "examples/vae_prior/plot_vae.py: decoder chain as a prior (Linear, Bias, LeakyRelu(0), HardTanh, Reshape with integer shapes), inpainting"
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", VAE_STYLE_SCRIPT], capture_output=True, text=True,
+                         env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1000:], out.stderr[-3000:])

@@ -548,3 +548,19 @@ def test_pwl_channels_non_finite_messages_give_nan(T, ctx, kind):
                 assert np.isnan(r[1]) and np.all(np.isfinite(np.delete(r, 1))) and np.isnan(v), (kind, which, val, r, v)
                 a_new, _ = msg(1.3, bz, 0.7, bx)
                 assert np.isnan(a_new)
+
+
+def test_linear_channel_sample_with_and_without_a_kept_matrix(ctx):
+    "LinearChannel.sample (linear_channel.py:48-50): a host W stays referenced; from a device W the factors reproduce W z"
+    import tramp_amd as T
+    rs = np.random.RandomState(3)
+    W = rs.standard_normal((40, 70)) / np.sqrt(70)
+    z = rs.standard_normal(70)
+    ch = T.LinearChannel(W, ctx=ctx)
+    assert ch.W is W
+    np.testing.assert_allclose(ch.sample(z), W @ z, rtol=1e-14)
+    chd = T.LinearChannel(ctx.array(W, np.float64), ctx=ctx, svd="device")
+    assert chd.W is None
+    np.testing.assert_allclose(chd.sample(z), W @ z, rtol=1e-11, atol=1e-12)
+    Z = rs.standard_normal((3, 70))
+    np.testing.assert_allclose(chd.sample(Z), Z @ W.T, rtol=1e-11, atol=1e-12)

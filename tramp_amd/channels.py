@@ -640,7 +640,9 @@ class LinearChannel(Channel):
         self.spectrum = np.zeros(self.Nz)                       # diag(S^T S), linear_channel.py:41
         self.spectrum[:k] = sing_h**2
         self.singular = self.spectrum[:self.rank]
-        self.W = W if keep_W else None
+        # a host matrix stays referenced (it costs no device memory); a device matrix only on request - the 40 GB W of the
+        # headline run is freed by its caller once the factors exist.  sample() works either way.
+        self.W = W if (keep_W or not isinstance(W, DeviceArray)) else None
         h = C.c_void_p()
         ctx._call("tramp_linear_create", self._dt, self.Nx, self.Nz, self.rank, self._Uk.ptr,
                   self._Vt.ptr, self._sing.ptr, C.byref(h))
@@ -690,10 +692,21 @@ class LinearChannel(Channel):
         self._handle = None
 
     def sample(self, Z):
-        if self.W is None:
-            raise RuntimeError("LinearChannel was built with keep_W=False")
-        W = self.W.get() if isinstance(self.W, DeviceArray) else self.W
-        return W @ Z
+        "x = W z (linear_channel.py:48-50); without a kept W through the factors, W z = Uk (s * (Vt z)), two dense passes on the device"
+        if self.W is not None:
+            W = self.W.get() if isinstance(self.W, DeviceArray) else self.W
+            return W @ Z
+        ctx = self.ctx
+        Zh = np.asarray(Z, dtype=self.dtype)
+        z2 = Zh.reshape(1, -1) if Zh.ndim == 1 else Zh.reshape(Zh.shape[0], -1)
+        k = self._Vt.shape[0]
+        zd, t = ctx.array(np.ascontiguousarray(z2), self.dtype), ctx.empty((z2.shape[0], k), self.dtype)
+        ctx._call("tramp_matvec_nt", self._dt, 0, k, self.Nz, z2.shape[0], self._Vt.ptr, zd.ptr, t.ptr)
+        th = t.get() * self._sing.get()[None, :].astype(self.dtype)
+        x = ctx.empty((z2.shape[0], self.Nx), self.dtype)
+        ctx._call("tramp_matvec_nt", self._dt, 0, self.Nx, k, z2.shape[0], self._Uk.ptr, ctx.array(th, self.dtype).ptr, x.ptr)
+        xh = x.get().astype(np.float64)
+        return xh[0] if Zh.ndim == 1 else xh
 
     def second_moment(self, tau_z):
         return tau_z * self.spectrum.sum() / self.Nx            # linear_channel.py:55-56

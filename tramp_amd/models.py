@@ -115,6 +115,12 @@ class DAG:
     def to_model(self):
         return Model(self)
 
+    def to_model_dag(self):
+        "tramp/models/dag_algebra.py:215-219: the closed graph as a model DAG (here the same object; .to_model() follows)"
+        if self.ins or self.outs:
+            raise ValueError(f"model graph has {len(self.ins)} unconnected inputs and {len(self.outs)} unconnected outputs")
+        return self
+
 
 class Model:
     """tramp/models/base_model.py:28-148 for tree-structured (bipartite, acyclic) models."""
