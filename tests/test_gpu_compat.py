@@ -506,3 +506,73 @@ def test_the_vae_prior_example_structure_runs_on_this_package():
     out = subprocess.run([sys.executable, "-c", VAE_STYLE_SCRIPT], capture_output=True, text=True,
                          env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1000:], out.stderr[-3000:])
+
+
+BENCHMARK_SCRIPT = """
+import numpy as np
+from time import time
+from tramp_amd.compat import install_as_tramp
+install_as_tramp()
+# --- run_benchmark of examples/figures/compute_benchmark.py:17-70 (the script BASELINE.json's metric comes from), its EP and SE
+#     branches as written there; the Lasso / pymc3 competitors are not this package's business ---
+from tramp.ensembles import GaussianEnsemble
+from tramp.priors import GaussBernoulliPrior
+from tramp.channels import GaussianChannel, LinearChannel
+from tramp.variables import SISOVariable as V, SILeafVariable as O
+from tramp.algos.metrics import mean_squared_error
+from tramp.experiments import BayesOptimalScenario, run_experiments
+
+
+def run_benchmark(alpha, algo, seed):
+    # create scenario
+    N, rho, noise_var = 1000, 0.05, 1e-2
+    M = int(alpha*N)
+    A = GaussianEnsemble(M=M, N=N).generate()
+    t0 = time()
+    model = (
+        GaussBernoulliPrior(size=N, rho=rho) @ V("x") @
+        LinearChannel(A) @ V("z") @ GaussianChannel(var=noise_var) @ O("y")
+    ).to_model()
+    t1 = time()
+    record = {"svd_time": t1 - t0}  # svd precomputation time
+    scenario = BayesOptimalScenario(model, x_ids=["x"])
+    scenario.setup(seed)
+    y = scenario.observations["y"]
+    # run algo
+    t0 = time()
+    if algo == "SE":
+        x_data = scenario.run_se(max_iter=1000, damping=0.1)
+        record["mse"] = x_data["x"]["v"]
+        record["n_iter"] = x_data["n_iter"]
+    if algo == "EP":
+        x_data = scenario.run_ep(max_iter=1000, damping=0.1)
+        x_pred = x_data["x"]["r"]
+        record["n_iter"] = x_data["n_iter"]
+    t1 = time()
+    record["time"] = t1-t0
+    if algo != "SE":
+        record["mse"] = mean_squared_error(x_pred, scenario.x_true["x"])
+    return record
+
+
+df = run_experiments(run_benchmark, algo=["EP", "SE"], alpha=[0.3, 0.6], seed=[1, 2])
+assert len(df) == 8 and set(df.columns) == {"svd_time", "mse", "n_iter", "time", "alpha", "algo", "seed"}, df
+g = df.assign(mse=df.mse.map(lambda v: float(np.ravel(v)[0]))).groupby(["algo", "alpha"]).mse.mean()
+print(g)
+assert g["EP", 0.6] < 5e-3 and g["SE", 0.6] < 5e-3 and g["EP", 0.3] > g["EP", 0.6]
+for a in (0.3, 0.6):                                                     # EP at N = 1000 follows state evolution
+    assert abs(np.log(g["EP", a] / g["SE", a])) < 0.15, (a, g)
+assert df[df.algo == "EP"].time.max() < 5.0
+print("ok")
+"""
+
+
+def test_the_reference_benchmark_function_runs_as_written():
+    "examples/figures/compute_benchmark.py:17-70, EP and SE branches: the function BASELINE.json's metric is defined by"
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", BENCHMARK_SCRIPT], capture_output=True, text=True,
+                         env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1500:], out.stderr[-3000:])
