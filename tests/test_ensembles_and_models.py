@@ -176,3 +176,31 @@ def test_reference_import_paths_resolve_to_this_package():
             "try:\n    install_as_tramp()\nexcept ImportError as e:\n    print('refused')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert out.stdout.strip() == "refused", out.stderr[-2000:]
+
+
+def test_qplot_and_compare_plots():
+    "tramp/experiments/plots.py counterparts: facets, styles, multiple y columns, renaming; Agg backend, nothing shown"
+    import matplotlib
+    matplotlib.use("Agg")
+    import pandas as pd
+    from tramp_amd import experiments as X
+    rows = [dict(alpha=a, rho=r, source=s, v=a * r + (0.1 if s == "EP" else 0.0), mse=a * r)
+            for a in np.linspace(0.1, 1, 5) for r in (0.2, 0.5) for s in ("EP", "SE")]
+    df = pd.DataFrame(rows)
+    fig = X.qplot(df, x="alpha", y="v", marker="source", column="rho", rename={"alpha": "a", "rho": "r"})
+    axs = fig.get_axes()
+    assert len(axs) == 2 and [len(ax.get_lines()) for ax in axs] == [2, 2] and axs[0].get_title() == "r=0.2" and axs[0].get_xlabel() == "a"
+    assert axs[0].get_lines()[0].get_linestyle() == "None" and axs[0].get_lines()[0].get_marker() == "."
+    fig = X.qplot(df[df.source == "SE"], x="alpha", y=["v", "mse"], y_markers=["-", "x"], color="rho", y_legend=True)
+    (ax,) = fig.get_axes()
+    assert len(ax.get_lines()) == 4 and {l.get_label() for l in ax.get_lines()} == {"rho=0.2 v", "rho=0.2 mse", "rho=0.5 v", "rho=0.5 mse"}
+    with pytest.raises(ValueError):
+        X.qplot(df, x="alpha", y=["v", "mse"], y_markers=["-"])
+    with pytest.raises(ValueError):
+        X.qplot(df, x="alpha", y=["v", "mse"], y_markers=["-", "?"])
+    rs = np.random.RandomState(0)
+    assert len(X.plot_compare(rs.randn(300), rs.randn(300)).get_axes()[0].get_lines()) == 2
+    fig = X.plot_compare_complex(rs.randn(2, 50), rs.randn(50) + 1j * rs.randn(50))
+    assert [ax.get_xlabel() for ax in fig.get_axes()] == ["phase x true", "modulus x true"]
+    X.plot_function(np.tanh)
+    matplotlib.pyplot.close("all")

@@ -555,6 +555,7 @@ def run_benchmark(alpha, algo, seed):
     return record
 
 
+np.random.seed(11)                                  # (the sensing matrices are drawn before setup(seed) reseeds)
 df = run_experiments(run_benchmark, algo=["EP", "SE"], alpha=[0.3, 0.6], seed=[1, 2])
 assert len(df) == 8 and set(df.columns) == {"svd_time", "mse", "n_iter", "time", "alpha", "algo", "seed"}, df
 g = df.assign(mse=df.mse.map(lambda v: float(np.ravel(v)[0]))).groupby(["algo", "alpha"]).mse.mean()
@@ -574,5 +575,171 @@ def test_the_reference_benchmark_function_runs_as_written():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", BENCHMARK_SCRIPT], capture_output=True, text=True,
+                         env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1500:], out.stderr[-3000:])
+
+
+SPARSE_EXAMPLES_SCRIPT = """
+import numpy as np
+from tramp_amd.compat import install_as_tramp
+install_as_tramp()
+# --- examples/sparse/plot_sparse_gradient.py: teacher class and student builder as written there ---
+from tramp.algos import EarlyStoppingEP
+from tramp.experiments import TeacherStudentScenario
+from tramp.variables import SISOVariable as V, SILeafVariable as O, MILeafVariable, SIMOVariable
+from tramp.channels import GaussianChannel, GradientChannel, Blur2DChannel
+from tramp.priors import GaussBernoulliPrior, GaussianPrior
+from tramp.priors.base_prior import Prior
+from tramp.models import MultiLayerModel
+
+
+class SparseGradTeacher():
+    def __init__(self, N, rho, noise_var):
+        self.prior_grad = GaussBernoulliPrior(size=(1, N), rho=rho)
+        self.channel = GaussianChannel(var=noise_var)
+
+    def sample(self, seed=None):
+        if seed:
+            np.random.seed(seed)
+        x_prime = self.prior_grad.sample()
+        x = x_prime.ravel().cumsum()
+        x = x - x.mean()
+        y = self.channel.sample(x)
+        return {"x": x, "z": x_prime, "y": y}
+
+
+def build_sparse_grad_student(N, rho, noise_var):
+    x_shape = (N,)
+    z_shape = (1, N)
+    student = (
+        GaussianPrior(size=x_shape) @
+        SIMOVariable(id="x", n_next=2) @ (
+            GaussianChannel(var=noise_var) @ O("y") + (
+                GradientChannel(shape=x_shape) +
+                GaussBernoulliPrior(size=z_shape, rho=rho)
+            ) @ MILeafVariable(id="z", n_prev=2)
+        )
+    ).to_model()
+    return student
+
+
+size, rho, noise_var, seed = 400, 0.04, 1e-2, 1
+teacher = SparseGradTeacher(size, rho, noise_var)
+student = build_sparse_grad_student(size, rho, noise_var)
+scenario = TeacherStudentScenario(teacher, student, x_ids=["x", "z"])
+scenario.setup(seed=seed)
+_ = scenario.run_ep(
+    max_iter=1000, damping=0.1, callback=EarlyStoppingEP(tol=1e-2)
+)
+x, y = scenario.x_true["x"], scenario.observations["y"]
+assert scenario.x_pred["z"].shape == (1, size) and scenario.x_true["z"].shape == (1, size)
+assert np.mean((scenario.x_pred["x"] - x) ** 2) < 0.5 * np.mean((y - x) ** 2)
+
+# --- examples/sparse/plot_raccoon_deconv.py:60-73 on a small image: MultiLayerModel with a sample-only prior, Blur2DChannel ---
+class BlocksPrior(Prior):
+    def __init__(self):
+        rs = np.random.RandomState(0)
+        x = np.kron(rs.standard_normal((6, 4)), np.ones((8, 12)))
+        self.x = (x - x.mean()) / x.std()
+        self.size = self.x.shape
+
+    def sample(self):
+        return self.x
+
+
+prior = BlocksPrior()
+x_shape = prior.size
+blur = Blur2DChannel(shape=x_shape, sigma=[2, 2])
+noise = GaussianChannel(var=0.1)
+teacher = MultiLayerModel([prior, blur, noise], ids=["x", "z", "y"])
+prior = GaussianPrior(size=x_shape)
+basic_deconv = MultiLayerModel(
+    [prior, blur, noise], ids=["x", "z", "y"]
+)
+scenario = TeacherStudentScenario(teacher, basic_deconv, x_ids=["x", "z"])
+scenario.setup(seed=1)
+_ = scenario.run_ep(max_iter=100, damping=0)
+assert scenario.x_pred["x"].shape == x_shape and scenario.x_pred["z"].shape == x_shape
+mse_z = np.mean((scenario.x_pred["z"] - scenario.x_true["z"]) ** 2)
+mse_y = np.mean((scenario.observations["y"] - scenario.x_true["z"]) ** 2)
+print("deconvolution: mse of the blurred image", mse_z, "against the observation's", mse_y)
+assert mse_z < 0.5 * mse_y
+print("ok")
+"""
+
+
+def test_the_sparse_gradient_and_deconvolution_examples_run_on_this_package():
+    "examples/sparse/plot_sparse_gradient.py and plot_raccoon_deconv.py (small image): teacher classes, MultiLayerModel, Blur2DChannel"
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", SPARSE_EXAMPLES_SCRIPT], capture_output=True, text=True,
+                         env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1500:], out.stderr[-3000:])
+
+
+PLOT_EXAMPLES_SCRIPT = """
+import matplotlib
+matplotlib.use("Agg")
+import numpy as np
+from tramp_amd.compat import install_as_tramp
+install_as_tramp()
+# --- examples/glm/plot_cs.py:19-39 and plot_complex_pr.py:19-45 as written (N smaller) ---
+from tramp.models import glm_generative
+from tramp.experiments import BayesOptimalScenario, qplot, plot_compare, plot_compare_complex
+
+np.random.seed(3)                                   # (the examples draw their sensing matrices unseeded)
+teacher = glm_generative(
+    N=500, alpha=0.8, ensemble_type="gaussian", prior_type="gauss_bernoulli",
+    output_type="gaussian", output_var=1e-11, prior_rho=0.5
+)
+scenario = BayesOptimalScenario(teacher, x_ids=["x"])
+scenario.setup(seed=42)
+scenario.student.plot()
+ep_evo = scenario.ep_convergence(metrics=["mse"], max_iter=10)
+fig = qplot(
+    ep_evo, x="iter", y=["v", "mse"], y_markers=["-", "."],
+    y_legend=True
+)
+assert 5 <= len(ep_evo) <= 10 and len(fig.get_axes()[0].get_lines()) == 2, (len(ep_evo), len(fig.get_axes()[0].get_lines()), ep_evo)
+plot_compare(scenario.x_true["x"], scenario.x_pred["x"])
+assert float(ep_evo.mse.iloc[-1]) < 1e-3 * float(ep_evo.mse.iloc[0])
+
+model = glm_generative(
+    N=300, alpha=2, ensemble_type="complex_gaussian",
+    prior_type="gauss_bernoulli", output_type="modulus",
+    prior_mean=0.01, prior_rho=0.5
+)
+scenario = BayesOptimalScenario(model, x_ids=["x"])
+scenario.setup(seed=42)
+scenario.student.plot()
+ep_evo = scenario.ep_convergence(
+    metrics=["mse", "phase_mse"], max_iter=20  # no damping
+)
+qplot(
+    ep_evo, x="iter", y=["phase_mse", "v"],
+    y_markers=["x", "-"], y_legend=True
+)
+ep_evo = scenario.ep_convergence(
+    metrics=["mse", "phase_mse"], max_iter=70, damping=0.3
+)
+qplot(
+    ep_evo, x="iter", y=["mse", "phase_mse", "v"],
+    y_markers=[".", "x", "-"], y_legend=True
+)
+plot_compare_complex(scenario.x_true["x"], scenario.x_pred["x"])
+assert set(ep_evo.columns) == {"id", "iter", "mse", "phase_mse", "v"} and len(ep_evo) >= 20
+print("ok")
+"""
+
+
+def test_the_plot_examples_run_on_this_package():
+    "examples/glm/plot_cs.py and plot_complex_pr.py: setup / student.plot() / ep_convergence / qplot / plot_compare as written"
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", PLOT_EXAMPLES_SCRIPT], capture_output=True, text=True,
                          env=dict(os.environ, PYTHONPATH=root), cwd=root, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-1500:], out.stderr[-3000:])

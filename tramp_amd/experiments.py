@@ -12,6 +12,8 @@ from .algos import (ExpectationPropagation, StateEvolution, TrackErrors, TrackEv
 from .metrics import METRICS
 from .models import Model
 
+from .plots import qplot, plot_compare, plot_compare_complex, plot_function  # noqa: F401  (tramp.experiments exports them)
+
 logger = logging.getLogger(__name__)
 
 

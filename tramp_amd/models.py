@@ -170,6 +170,22 @@ class Model:
         succ = list(self.dag.successors(variable))
         return succ[0] if succ else None
 
+    def plot(self, layout=None):
+        """the factor graph drawn with networkx / matplotlib (tramp/models/base_model.py:57-58): variables as circles with their ids,
+        factors as squares with their class names"""
+        import matplotlib.pyplot as plt
+        g = self.dag
+        pos = layout or nx.spring_layout(g, seed=0)
+        fig, ax = plt.subplots(1, 1, figsize=(6, 4))
+        nx.draw_networkx_edges(g, pos, ax=ax)
+        nx.draw_networkx_nodes(g, pos, nodelist=self.variables, node_shape="o", node_color="w", edgecolors="k", ax=ax)
+        nx.draw_networkx_nodes(g, pos, nodelist=self.factors, node_shape="s", node_color="lightgray", edgecolors="k", ax=ax)
+        labels = {n: (n.id if isinstance(n, Variable) else type(n).__name__.replace("Channel", "").replace("Prior", "")
+                      .replace("Likelihood", "")) for n in g.nodes}
+        nx.draw_networkx_labels(g, pos, labels=labels, font_size=8, ax=ax)
+        ax.set_axis_off()
+        return fig
+
     def to_observed(self, observations):
         "tramp/models/dag_algebra.py:243-291: observed leaf + its channel -> likelihood"
         g = self.dag.copy()
