@@ -340,6 +340,56 @@ df = run_experiments(run_se_pr, a0=[0.1, 1000], prior_rho=[0.6], prior_mean=0, a
 assert len(df) == 2 and float(df[df.a0 == 1000].v.iloc[0]) < 0.1, df
 df = run_experiments(run_se_abs, a0=[1000], prior_rho=[0.4], prior_mean=0, alpha=[1.0])
 assert len(df) == 2 and set(df.x_id) == {"x", "z"}, df
+
+
+def run_critical_door(a0, output_width, prior_p_pos, criterion):  # door_critical_lines.py:7-15 (alpha_tol 0.05 here)
+    alpha = find_critical_alpha(
+        id="x", a0=a0, mse_criterion=criterion,
+        alpha_min=0.1, alpha_max=3., alpha_tol=0.05,
+        model_builder=glm_state_evolution,
+        prior_type="binary", output_type="door",
+        output_width=output_width, prior_p_pos=prior_p_pos
+    )
+    return dict(alpha=alpha)
+
+
+df = run_experiments(run_critical_door, a0=[0.1, 1000], output_width=[1.0], prior_p_pos=0.51, criterion=["random", "perfect"])
+# from the uninformed start a0 = 0.1: "random" = where the estimate leaves the prior's variance, "perfect" = where it reaches v = 0.
+# From a0 = 1000 the binary prior saturates the message at the 1e11 clip, where v = 0 is a stable fixed point at EVERY alpha (the
+# information of the door observation grows like sqrt(az) - csrc/se_kernels.hip GainAcc), so neither criterion has a bracket in
+# [0.1, 3]: binary_search raises "Bad bounds" and run_experiments skips those, as the reference does whenever its bracket fails
+# (its informed runs are decided by the round-off of 1 / v - az at the clip)
+assert len(df) == 2 and set(df.a0) == {0.1} and set(df.criterion) == {"random", "perfect"}, df
+crit = df.set_index("criterion").alpha
+assert 0.1 < crit["random"] < crit["perfect"] < 3.0, df
+for a0, alpha, want_perfect in ((0.1, 1.0, False), (0.1, 3.0, True), (1000, 1.0, True), (1000, 3.0, True)):
+    v = run_se_door(a0, alpha, 1.0, 0.51)[0]["v"]
+    assert (v < 1e-6) == want_perfect, (a0, alpha, v)
+
+# tmp/plot_symmetric_door.py:20-41: the door teacher, its factors printed, EP dynamics on both variables
+import matplotlib
+matplotlib.use("Agg")
+from tramp.experiments import qplot, plot_compare
+teacher = glm_generative(
+    N=500, alpha=1.6, ensemble_type="gaussian", prior_type="binary",
+    output_type="door", output_width=1., prior_p_pos=0.51
+)
+for factor in teacher.factors:
+    print(factor)
+scenario = BayesOptimalScenario(teacher, x_ids=["x", "z"])
+scenario.setup(seed=42)
+scenario.student.plot()
+ep_evo = scenario.ep_convergence(
+    metrics=["mse", "sign_mse"], damping=0.1, max_iter=40
+)
+fig = qplot(
+    ep_evo, x="iter",
+    y=["mse", "sign_mse", "v"],  y_markers=["x", ".", "-"],
+    column="id", y_legend=True
+)
+plot_compare(scenario.x_true["x"], scenario.x_pred["x"])
+assert len(fig.get_axes()) == 2 and set(ep_evo.id) == {"x", "z"} and len(ep_evo) == 80
+assert np.all(ep_evo.sign_mse <= ep_evo.mse + 1e-12)
 print("ok")
 """
 

@@ -180,3 +180,27 @@ def test_adaptive_2d_quadrature_matches_the_dense_grid(ctx):
         assert ev.value <= 1_000_000, (k, a, x, ev.value)
         np.testing.assert_allclose([f, b], [vf, vb], rtol=1e-7, atol=1e-12)
         assert ch.compute_forward_error(a, x, t) == f                # run-to-run bit-identical
+
+
+def test_likelihood_errors_keep_their_information_at_saturated_messages(ctx):
+    """State evolution from an informed start runs at az = 1e11 (the clip of base.py:245-248).  An observation that leaves z
+    continuous (sign, ReLU's flat branch, the door) then carries delta = 1 - az v ~ c / sqrt(az tau) << 1, and a_new = 1 / v - az
+    is that small quantity times az: the kernels sum delta itself (csrc/se_kernels.hip GainAcc), so a_new stays positive, grows
+    like sqrt(az) and varies smoothly - with v summed directly it was round-off of either sign at az >= 1e8."""
+    import tramp_amd as T
+    tau = 1.0
+    az = np.logspace(2, 11, 19)
+    for name, lik in (("sgn", T.SgnLikelihood(y=None, ctx=ctx)), ("relu", T.ReluLikelihood(y=None, ctx=ctx)),
+                      ("door", T.SymmetricDoorLikelihood(width=1.0, y=None, ctx=ctx)),
+                      ("h-tanh", T.HardTanhLikelihood(y=None, ctx=ctx))):
+        v = np.array([lik.compute_backward_error(a, tau) for a in az])
+        delta = 1.0 - az * v
+        assert np.all(delta > 0) and np.all(delta < 1), (name, delta)
+        a_new = az * delta / (1 - delta)
+        if name in ("sgn", "door"):                              # every observation is a set: a_new / sqrt(az) tends to a constant
+            c = a_new / np.sqrt(az)
+            assert np.all(np.abs(c[-6:] / c[-1] - 1) < 0.02), (name, c)
+            assert np.all(np.diff(a_new) > 0), name
+        # the message the scheduler forms from v: positive and equal to the gain form to 1e-6 even at the clip
+        got = np.array([lik.compute_backward_state_evolution(a, tau) for a in az])
+        np.testing.assert_allclose(got, np.clip(a_new, 1e-11, 1e11), rtol=1e-5, err_msg=name)

@@ -47,6 +47,38 @@ __device__ __forceinline__ void graded_node(int idx, int P, double xc, double& x
     w = L * 3.0 * t2 * h * kGLw[g];
 }
 
+// The same grading on a segment [lo, hi] around xc in it: P/2 panels on each side.
+__device__ __forceinline__ void graded_node_seg(int idx, int P, double lo, double hi, double xc, double& x, double& w) {
+    const int half = P / 2;
+    const int panel = idx >> 3, g = idx & 7;
+    const bool right = panel >= half;
+    const int pi = right ? panel - half : panel;
+    const double L = right ? (hi - xc) : (xc - lo);
+    const double h = 0.5 / half;
+    const double t = (pi + 0.5) * (1.0 / half) + h * kGLx[g];
+    const double t2 = t * t;
+    x = right ? xc + L * t2 * t : xc - L * t2 * t;
+    w = L * 3.0 * t2 * h * kGLw[g];
+}
+
+// Observations that leave z continuous (a half line, an interval, their unions) - the information they carry about a z that the
+// incoming message already pins to 1 / az is the small quantity  delta = 1 - az v;  v itself then only says 1 / az and
+// a_new = 1 / v - az cancels (state evolution from an informed start runs at az = 1e11, delta ~ 1e-6).  For a truncated normal on
+// pieces [alpha_i, beta_i] (standardised about the message's mean):  p (1 - az var) = A + B^2 / Z  with
+//     A = sum_i beta_i phi(beta_i) - alpha_i phi(alpha_i),  B = sum_i phi(alpha_i) - phi(beta_i),  Z = sum_i Phi(beta_i) - Phi(alpha_i)
+// - every term is non-zero only within a few 1 / sqrt(az) of a boundary, so delta is summed without cancellation and
+// v = (1 - delta) / az.  One piece of one observation:
+struct GainAcc {
+    double A = 0.0, B = 0.0, Z = 0.0;
+    __device__ __forceinline__ void piece(double alpha, double beta) {      // +-INFINITY allowed
+        const double pa = isinf(alpha) ? 0.0 : norm_pdf(alpha), pb = isinf(beta) ? 0.0 : norm_pdf(beta);
+        A += (isinf(beta) ? 0.0 : beta * pb) - (isinf(alpha) ? 0.0 : alpha * pa);
+        B += pa - pb;
+        Z += (isinf(beta) ? 1.0 : norm_cdf(beta)) - (isinf(alpha) ? 0.0 : norm_cdf(alpha));
+    }
+    __device__ __forceinline__ double gain() const { return Z > 0.0 ? A + B * B / Z : 0.0; }
+};
+
 // ---------------------------------------------------------------- K13: GB prior, sgn likelihood
 // mode 0: Gauss-Bernoulli prior  (gauss_bernoulli_prior.py:59-62,116-122; base_prior.py:66-69)
 //         v = (1-rho) E_{N(0, ax)}[f] + rho E_{N(ax mean, ax + ax^2 var)}[f],  f(b) = v(ax, b)
@@ -65,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
     __shared__ double smem[kBlock / kWave];
     const int pt = blockIdx.x;
     double total = 0.0;
+    bool gain_mode = false;
     if (mode == 0) {
         const double ax = P.p0[pt], rho = P.p1[pt], mean = P.p2[pt], var = P.p3[pt];
         const double a0 = 1.0 / var, b0 = mean / var;
@@ -101,13 +134,13 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
             for (int yy = 0; yy < 2; ++yy) {
                 const double y = yy ? -1.0 : 1.0;
                 const double r0 = (y * bz) / az;
-                tmath::HalfLine<double> h = tmath::halfline<double>(r0, v0, +1);
-                // positive.p: P[N(r0, v0) > 0] = norm_cdf(inf) - norm_cdf(-r0/s0)
-                const double p = 1.0 - norm_cdf((0 - r0) / sqrt(v0));
-                f += p * h.var;
+                GainAcc g;                                       // y z > 0: the half line (0, inf) about y r0
+                g.piece((0 - r0) / sqrt(v0), INFINITY);
+                f += g.gain();
             }
             acc += w * norm_pdf(x) * f;
         }
+        gain_mode = true;
         total = acc;
     }
     if (mode == 4) {
@@ -174,10 +207,11 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
             double x, w;
             graded_node(i, kPanels1D, 0.0, x, w);
             const double r0 = (s * x) / az;
-            tmath::HalfLine<double> h = tmath::halfline<double>(r0, v0, -1);
-            const double p = norm_cdf((0 - r0) / sqrt(v0));
-            acc += w * norm_pdf(x) * p * h.var;
+            GainAcc g;                                           // y = 0: z <= 0; y > 0 pins z (its whole mass is gain)
+            g.piece(-INFINITY, (0 - r0) / sqrt(v0));
+            acc += w * norm_pdf(x) * (g.gain() + (1.0 - g.Z));
         }
+        gain_mode = true;
         total = acc;
     }
     if (mode == 3) {
@@ -189,27 +223,46 @@ __global__ __launch_bounds__(kBlock) void se_1d_kernel(int mode, Se1dParams P, d
         const double s = sqrt(mz + mz * mz * tau);
         const double v0 = 1.0 / az, s0 = sqrt(v0);
         const tmath::Pwl3Spec sp = P.spec3;
+        // the integrand lives at the two region boundaries (r0 = zlo, zhi): one mesh segment per boundary, graded at it
+        const double xlo = fmin(fmax(sp.zlo * az / s, -9.999), 9.999), xhi = fmin(fmax(sp.zhi * az / s, -9.999), 9.999);
+        const double xmid = 0.5 * (xlo + xhi);
         double acc = 0.0;
-        for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
-            double x, w;
-            graded_node(i, kPanels1D, 0.0, x, w);
-            const double bz = s * x, r0 = bz / az;
-            double f = 0.0;
+        for (int seg = 0; seg < 2; ++seg) {
+            for (int i = threadIdx.x; i < 8 * kPanels1D; i += kBlock) {
+                double x, w;
+                if (seg == 0) graded_node_seg(i, kPanels1D, -10.0, xmid, xlo, x, w);
+                else graded_node_seg(i, kPanels1D, xmid, 10.0, xhi, x, w);
+                const double r0 = (s * x) / az;
+                const double a1 = (sp.zlo - r0) / s0, a2 = (sp.zhi - r0) / s0;       // boundaries, standardised
+                // regions [pos, mid, neg] = (zhi, inf), (zlo, zhi), (-inf, zlo); flat ones with the same x0 are ONE observation
+                double f = 0.0;
+                bool done[3] = {false, false, false};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (sp.slope[k] != 0.0) continue;
-                const double lo = (k == 0) ? sp.zhi : (k == 1 ? sp.zlo : -INFINITY);
-                const double hi = (k == 0) ? INFINITY : (k == 1 ? sp.zhi : sp.zlo);
-                const double p = (k == 0 ? 1.0 : norm_cdf((hi - r0) / s0)) - (k == 2 ? 0.0 : norm_cdf((lo - r0) / s0));
-                tmath::PwlOut<double> o = tmath::pwl3_lik_posterior<double>(bz, sp.x0[k], az, sp);
-                f += p * o.v;
+                for (int k = 0; k < 3; ++k) {
+                    const double lo_k = (k == 0) ? a2 : (k == 1 ? a1 : -INFINITY), hi_k = (k == 0) ? INFINITY : (k == 1 ? a2 : a1);
+                    if (sp.slope[k] != 0.0) {                    // a sloped region pins z: its mass is gain
+                        f += (isinf(hi_k) ? 1.0 : norm_cdf(hi_k)) - (isinf(lo_k) ? 0.0 : norm_cdf(lo_k));
+                        continue;
+                    }
+                    if (done[k]) continue;
+                    GainAcc g;
+#pragma unroll
+                    for (int j = k; j < 3; ++j) {
+                        if (sp.slope[j] != 0.0 || sp.x0[j] != sp.x0[k] || done[j]) continue;
+                        g.piece((j == 0) ? a2 : (j == 1 ? a1 : -INFINITY), (j == 0) ? INFINITY : (j == 1 ? a2 : a1));
+                        done[j] = true;
+                    }
+                    f += g.gain();
+                }
+                acc += w * norm_pdf(x) * f;
             }
-            acc += w * norm_pdf(x) * f;
         }
+        gain_mode = true;
         total = acc;
     }
     total = block_sum(total, smem);
-    if (threadIdx.x == 0) out[pt] = total;
+    // the modes that summed delta = 1 - az v (sign, ReLU, three-region likelihoods) hand out v = (1 - delta) / az
+    if (threadIdx.x == 0) out[pt] = gain_mode ? (1.0 - total) / P.p0[pt] : total;
 }
 
 // ---------------------------------------------------------------- K14: 2-D averages
@@ -537,7 +590,7 @@ extern "C" int tramp_se_pwl3_lik(tramp_ctx* ctx, size_t count, double z_lo, doub
     Se1dParams P{din[0], din[1], nullptr, nullptr,
                  tmath::Pwl3Spec{z_lo, z_hi, {slopes3[0], slopes3[1], slopes3[2]}, {x03[0], x03[1], x03[2]}}};
     hipLaunchKernelGGL(se_1d_kernel, dim3((unsigned)count), dim3(kBlock), 0, ctx->stream, 3, P, dout);
-    g_se_evals = (unsigned long long)count * 1 * 8 * kPanels1D;
+    g_se_evals = (unsigned long long)count * 2 * 8 * kPanels1D;
     return se_finish(ctx, count, dout, v);
 }
 
