@@ -982,7 +982,10 @@ class ExpectationPropagation:
                         r = unrot(self.r[i]).get()
                         if use_frozen:
                             r[done] = unrot(self._frozen_r[i]).get()[done]
-                    d["r"] = r[0] if self.batch == 1 else r
+                    # in the variable's own shape, as the reference hands estimates out ((2, n) planar complex, images, (d,) + shape
+                    # gradient fields); an ensemble keeps its leading instance axis
+                    shape = tuple(self.shapes[v.id])
+                    d["r"] = r[0].reshape(shape) if self.batch == 1 else r.reshape((self.batch,) + shape)
                 out[v.id] = d
         return out
 
