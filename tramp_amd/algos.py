@@ -1125,7 +1125,7 @@ class ExpectationPropagation:
         return stop[0], [cb for cb in members if cb is not stop[0] and type(cb) is not PassCallback]
 
     def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False,
-                check_every=1, graph=False, restore_messages=None):
+                check_every=1, graph=False, restore_messages=None, update_dA=False):
         """message_passing.py:330-357.  The NaN guard and the per-instance stopping rule run on the device
         after every iteration (csrc/monitor.hip); ``check_every`` = k makes the host look at their state
         words - and run the remaining host callbacks - only every k-th iteration, the sweeps themselves
@@ -1141,6 +1141,8 @@ class ExpectationPropagation:
         keeps those of its stopping iteration, and a NaN puts every instance back one iteration before ValueError
         is raised (message_passing.py:187-209, callbacks.py:233-240,277-283); a warm start then continues each
         instance from where its own run would have stopped."""
+        if update_dA:
+            raise NotImplementedError("update_dA (the per-message free-energy increments of message_passing.py:245-246) is not tracked")
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
         adaptive = isinstance(damping, str) and damping == "adaptive"
@@ -1275,7 +1277,9 @@ class StateEvolution:
         self.n_iter = 0
         self.default_stopping = EarlyStopping()
 
-    def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False):
+    def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False, update_dA=False):
+        if update_dA:
+            raise NotImplementedError("update_dA is not tracked")
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
         d = float(damping) if damping else 0.0

@@ -488,8 +488,10 @@ class TreeStateEvolution:
         for f in targets:
             self.msg[(v, f)] = a_hat - self.msg[(f, v)]
 
-    def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False):
+    def iterate(self, max_iter=200, callback=None, initializer=None, damping=None, warm_start=False, update_dA=False):
         from .algos import ConstantInit
+        if update_dA:
+            raise NotImplementedError("update_dA is not tracked")
         initializer = initializer or ConstantInit(a=0, b=0)
         callback = callback or self.default_stopping
         d = float(damping) if damping else 0.0
